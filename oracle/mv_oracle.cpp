@@ -1,0 +1,1360 @@
+/*
+ * oracle/mv_oracle.cpp -- CPU restatement ("oracle") of the reference hot path.
+ *
+ * TEST INFRASTRUCTURE.  See mv_oracle.h for who may use it and for the parity
+ * status (RNG helpers pinned; physics + pixels "parity unpinned").
+ *
+ * Plain scalar C++17, libstdc++ only.  Build: oracle/Makefile (g++ -O2
+ * -ffp-contract=off, no -ffast-math) so that every fp32 operation is a single
+ * IEEE-754 rounding in source order -- the HIP kernels are built the same way and
+ * tests compare the two bit for bit.
+ *
+ * Each block cites the reference file:line it follows (paths relative to
+ * /root/reference/src/libs).  Where the reference hands the arithmetic to Bullet
+ * 2.89 / Magnum (not vendored) the published algorithm is restated and marked [3P].
+ */
+#include "mv_oracle.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cfloat>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <random>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace mvo {
+
+// ------------------------------------------------------------------------------------------------
+// RNG helpers -- util/include/util/util.hpp:25-56.  Same libstdc++ templates as the reference.
+// ------------------------------------------------------------------------------------------------
+using Rng = std::mt19937;
+
+static inline int randRange(int low, int high, Rng &rng) { return std::uniform_int_distribution<>{low, high - 1}(rng); }
+static inline bool randomBool(Rng &rng) { return bool(randRange(0, 2, rng)); }
+static inline float frand(Rng &rng) { return std::uniform_real_distribution<float>{0, 1}(rng); }
+
+// ------------------------------------------------------------------------------------------------
+// Constants (every number read from the cited reference line)
+// ------------------------------------------------------------------------------------------------
+static const float DT = 1.0f / 15.0f;                 // env/include/env/env.hpp:160-161
+static const float CAP_R = 0.33f;                     // env/src/agent.cpp:53
+static const float CAP_HH = 1.05f * 0.5f;             // env/src/agent.cpp:52 (btCapsuleShape height/2)
+static const float AGENT_HEIGHT = 1.75f;              // env/include/env/agent.hpp:110
+static const float STEP_HEIGHT = 0.2f;                // env/src/agent.cpp:59
+static const float GRAVITY = 1.4f * 9.8f;             // kinematic_character_controller.hpp:169
+static const float FALL_SPEED = 55.0f;                // kinematic_character_controller.cpp:135
+static const float MAX_H_SPEED = 4.5f;                // .hpp:173
+static const float MAX_AIR_SPEED = 1.0f;              // .hpp:174
+static const float NORMAL_DECEL = 15.0f;              // .hpp:175
+static const float MAX_ACCEL = 35.0f + 15.0f;         // .hpp:176
+static const float MAX_AIR_ACCEL = 3.0f;              // .hpp:176
+static const float EXCEED_DECEL = (35.0f + 15.0f) * 2;// .hpp:177
+static const float MAX_PEN_DEPTH = 0.041f;            // .hpp:155
+static const float MAX_SLOPE_COS = 0.70710678f;       // .cpp:146 cos(45 deg)
+static const float ALLOWED_CCD_PEN = 0.04f;           // [3P] btDispatcherInfo::m_allowedCcdPenetration default
+static const float CAST_RADIUS = 0.001f;              // [3P] btContinuousConvexCollision "radius"
+static const int CAST_MAX_ITER = 64;                  // [3P] MAX_ITERATIONS
+static const float SIMD_EPS = FLT_EPSILON;            // [3P] SIMD_EPSILON
+static const float ROTATE_RAD = 3.5f, ROTATE_X_RAD = 1.5f; // env/include/env/agent.hpp:109
+static const float PI_F = 3.14159274f;                // Magnum::Constants::pi() as float
+static const float OBJ_HALF = 0.39f;                  // component_object_stacking.hpp:172
+static const float OBJ_COLL_HALF = 0.39f * 1.15f;     // :181 collision scale
+static const float OBJ_COLL_YOFF = -0.05f;            // :182 collision offset
+static const float CARRY_SCALE = 0.78f;               // :63
+
+enum { CX = 32, CY = 16, CZ = 32, CHUNK = CX * CY * CZ };
+enum { MAX_BOXES = 16, MAX_OBJECTS = 80, MAX_AGENTS = 8 };
+
+// voxel byte: voxel_state.hpp:10-37 + platforms.hpp:28-34 folded into one byte per cell
+enum { VX_SOLID = 1, VX_OPAQUE = 2, VX_OBJECT = 4, VX_TERRAIN_SHIFT = 3, VX_COLOR_SHIFT = 6 };
+
+static const unsigned LAYOUT_COLORS[14] = {  // env/include/env/const.hpp:121-136
+    0xffffff, 0xffffe6, 0xccffcc, 0xe6ecff, 0xd9d9d9, 0xffebcc, 0xb3b3b3, 0xb3b3b3, 0xb3b3b3, 0xb3b3b3,
+    0x555555, 0x555555, 0x555555, 0x555555};
+static const unsigned COLOR_BUILDING_ZONE = 0x555555, COLOR_MOVABLE_BOX = 0xadd8e6, COLOR_AGENT_EYES = 0x2c3e50,
+                      COLOR_UI_BAR = 0x2eb5d0;  // const.hpp:25-56
+static const unsigned AGENT_COLORS[7] = {0xffdd3c, 0x3bb372, 0x2eb5d0, 0xffb400, 0xd468ee, 0x222222, 0xff0000};  // const.hpp:85
+
+struct V3 {
+    float x, y, z;
+};
+static inline V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+static inline V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+static inline float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static inline float len2(V3 a) { return dot(a, a); }
+
+// ------------------------------------------------------------------------------------------------
+// fp32 sin/cos used wherever a result feeds state or pixels (cephes-style minimax polynomials,
+// one rounding per op, identical sequence in the HIP kernels).  |x| <= ~8.
+// ------------------------------------------------------------------------------------------------
+static void mv_sincos(float x, float *s_out, float *c_out)
+{
+    const float TWO_OVER_PI = 0.636619772f;
+    const float PIO2_HI = 1.57079625f;        // 0x3FC90FDA
+    const float PIO2_LO = 7.54978942e-08f;    // pi/2 - PIO2_HI
+    float kf = floorf(x * TWO_OVER_PI + 0.5f);
+    int k = (int)kf;
+    float r = x - kf * PIO2_HI;
+    r = r - kf * PIO2_LO;
+    float r2 = r * r;
+    float sp = ((-1.9515295891e-4f * r2 + 8.3321608736e-3f) * r2 - 1.6666654611e-1f) * r2 * r + r;
+    float cp = ((2.443315711809948e-5f * r2 - 1.388731625493765e-3f) * r2 + 4.166664568298827e-2f) * r2 * r2 -
+               0.5f * r2 + 1.0f;
+    float s, c;
+    switch (k & 3) {
+        case 0: s = sp; c = cp; break;
+        case 1: s = cp; c = -sp; break;
+        case 2: s = -sp; c = -cp; break;
+        default: s = -cp; c = sp; break;
+    }
+    *s_out = s;
+    *c_out = c;
+}
+
+// y-axis rotation matrix entries (c, s) the way Bullet builds them from an axis-angle quaternion:
+// [3P] btQuaternion::setRotation + btMatrix3x3::setRotation, restated for axis (0,1,0).
+static void yaw_matrix(float angle, float *c_out, float *s_out)
+{
+    float sh, ch;
+    mv_sincos(angle * 0.5f, &sh, &ch);
+    float qy = sh, w = ch;
+    float d = qy * qy + w * w;
+    float s = 2.0f / d;
+    float ys = qy * s;
+    float wy = w * ys;
+    float yy = qy * ys;
+    *c_out = 1.0f - yy;
+    *s_out = wy;
+}
+
+// ------------------------------------------------------------------------------------------------
+// State
+// ------------------------------------------------------------------------------------------------
+struct Box {  // merged layout parallelepiped, voxel units, max exclusive
+    int min[3], max[3];
+    int type, slot;
+};
+
+struct Object {  // movable box: component_object_stacking.hpp:170-198
+    int x, y, z;
+    int state;  // 0 = placed at voxel, 1+k = carried by agent k
+};
+
+struct Agent {
+    V3 pos;                      // ghost origin == capsule centre (agent.cpp:45)
+    float m00, m02, m20, m22;    // yaw basis (agent.cpp:128-133 accumulates matrix products)
+    float pitch;                 // currXRotation (agent.cpp:110-126)
+    float hvx, hvz;              // horizontalVelocity (y is always 0)
+    float vvel, voffset;         // m_verticalVelocity, m_verticalOffset
+    float step_offset;           // m_currentStepOffset (persists across steps)
+    float jump_speed;            // m_jumpSpeed (10 until first jump)
+    int was_jumping;
+    int carrying;                // object index or -1
+    int picked_up, visited_zone; // scenario_tower_building.hpp:24-28
+    int spawn[3];                // fallDetection.agentInitialPositions
+    float last_reward, total_reward;
+    float shaping[4];            // teamSpirit, towerPickedUpObject, towerVisitedBuildingZoneWithObject, towerBuildingReward
+    int action;                  // bitmask env.hpp:22-42
+};
+
+static const char *SHAPING_KEYS[4] = {"teamSpirit", "towerPickedUpObject", "towerVisitedBuildingZoneWithObject",
+                                     "towerBuildingReward"};
+static const float SHAPING_DEFAULT[4] = {0.1f, 0.1f, 0.1f, 1.0f};  // scenario_tower_building.hpp:44-52
+
+struct Env {
+    int numAgents = 1;
+    Rng rng{std::random_device{}()};  // env.hpp:169
+    // float params (scenario.hpp:225-232)
+    float p_episodeLengthSec = 60.0f, p_verticalLookLimitRad = 0.2f;
+
+    int L = 0, H = 0, W = 0;
+    int bz[4] = {0, 0, 0, 0};  // minx, maxx, minz, maxz  (min.y == max.y == 1)
+    unsigned layoutColor = 0, wallColor = 0;
+    int drawWalls = 1;
+    int numObjects = 0, numBoxes = 0;
+    Box boxes[MAX_BOXES];
+    Object objects[MAX_OBJECTS];
+    Agent agents[MAX_AGENTS];
+    std::vector<uint8_t> chunk = std::vector<uint8_t>(CHUNK, 0);
+
+    int done = 0, numFrames = 0, highestTower = 0;
+    float episodeSec = 0, episodeLen = 0, bzReward = 0;
+    float barHalfWidth = 0.24f;  // scenario_default.hpp:69,164-169
+
+    static int cell(int x, int y, int z) { return (y * CZ + z) * CX + x; }
+    static bool inChunk(int x, int y, int z) { return x >= 0 && x < CX && y >= 0 && y < CY && z >= 0 && z < CZ; }
+    uint8_t vox(int x, int y, int z) const { return inChunk(x, y, z) ? chunk[cell(x, y, z)] : 0; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Procedural generation
+// ------------------------------------------------------------------------------------------------
+static unsigned randomLayoutColor(Rng &rng) { return LAYOUT_COLORS[randRange(0, 14, rng)]; }  // const.hpp:139-143
+
+static void fill_box(Env &e, int x0, int y0, int z0, int x1, int y1, int z1, uint8_t v)
+{   // component_voxel_grid.hpp:83-90 addBoundingBox
+    for (int x = x0; x < x1; ++x)
+        for (int y = y0; y < y1; ++y)
+            for (int z = z0; z < z1; ++z)
+                if (Env::inChunk(x, y, z)) e.chunk[Env::cell(x, y, z)] = v;
+}
+
+// Canonical greedy merge of layout voxels into parallelepipeds.  The reference
+// (component_voxel_grid.hpp:108-187) visits an unordered_map in hash order, which makes its
+// decomposition implementation-defined; the union is the same.  Ours:
+// keys sorted by (type, colour slot); per key scan y, then z, then lowest x; grow the x-run, then
+// +z, then +y.
+static void merge_boxes(Env &e)
+{
+    std::vector<uint8_t> visited(CHUNK, 0);
+    e.numBoxes = 0;
+    for (int key = 0; key < 16; ++key) {
+        const int type = key >> 2, slot = key & 3;
+        if (type == 0) continue;
+        for (int y = 0; y < CY; ++y)
+            for (int z = 0; z < CZ; ++z)
+                for (int x = 0; x < CX; ++x) {
+                    auto match = [&](int xx, int yy, int zz) {
+                        if (!Env::inChunk(xx, yy, zz)) return false;
+                        const int c = Env::cell(xx, yy, zz);
+                        const uint8_t v = e.chunk[c];
+                        return !visited[c] && (v & 3) == type && (v >> VX_COLOR_SHIFT) == slot;
+                    };
+                    if (!match(x, y, z)) continue;
+                    int x1 = x;
+                    while (match(x1 + 1, y, z)) ++x1;
+                    int z1 = z;
+                    for (;;) {
+                        bool ok = true;
+                        for (int xx = x; xx <= x1 && ok; ++xx) ok = match(xx, y, z1 + 1);
+                        if (!ok) break;
+                        ++z1;
+                    }
+                    int y1 = y;
+                    for (;;) {
+                        bool ok = true;
+                        for (int zz = z; zz <= z1 && ok; ++zz)
+                            for (int xx = x; xx <= x1 && ok; ++xx) ok = match(xx, y1 + 1, zz);
+                        if (!ok) break;
+                        ++y1;
+                    }
+                    for (int yy = y; yy <= y1; ++yy)
+                        for (int zz = z; zz <= z1; ++zz)
+                            for (int xx = x; xx <= x1; ++xx) visited[Env::cell(xx, yy, zz)] = 1;
+                    if (e.numBoxes < MAX_BOXES) {
+                        Box &b = e.boxes[e.numBoxes++];
+                        b.min[0] = x; b.min[1] = y; b.min[2] = z;
+                        b.max[0] = x1 + 1; b.max[1] = y1 + 1; b.max[2] = z1 + 1;
+                        b.type = type; b.slot = slot;
+                    }
+                }
+    }
+}
+
+static bool in_building_zone(const Env &e, int x, int z)
+{   // scenario_tower_building.cpp:227-230 (x/z interval only, any height)
+    return x >= e.bz[0] && x < e.bz[1] && z >= e.bz[2] && z < e.bz[3];
+}
+
+static float building_reward_coeff(float height)
+{   // scenario_tower_building.cpp:246-251 ; powf(2,h) is exact for integral h
+    float res = height * 0.05f;
+    res += std::min(0.05f * ldexpf(1.0f, (int)height), 20.0f);
+    return res;
+}
+
+static float tower_reward(const Env &e)
+{   // scenario_tower_building.cpp:232-241.  The reference sums over an unordered_set; we fix the
+    // order to object index.
+    float r = 0.0f;
+    for (int i = 0; i < e.numObjects; ++i) {
+        const Object &o = e.objects[i];
+        if (o.state == 0 && in_building_zone(e, o.x, o.z)) r += building_reward_coeff(float(o.y));
+    }
+    return r;
+}
+
+static void env_reset(Env &e)
+{
+    // ---- Env::reset, env/src/env.cpp:57-76 ; EnvState::reset env.hpp:135-151
+    e.done = 0; e.episodeSec = 0; e.numFrames = 0;
+    const int seed = randRange(0, 1 << 30, e.rng);
+    e.rng.seed((unsigned long)seed);
+
+    // ---- TowerBuildingScenario::reset, scenario_tower_building.cpp:129-154
+    std::fill(e.chunk.begin(), e.chunk.end(), 0);
+    unsigned layoutColor = randomLayoutColor(e.rng);
+    while (layoutColor == COLOR_BUILDING_ZONE) layoutColor = randomLayoutColor(e.rng);
+
+    // ---- TowerBuildingPlatform::init, :19-76
+    Rng &rng = e.rng;
+    const int A = e.numAgents;
+    int height = randRange(5, 7, rng);
+    int length = randRange(12, 30, rng);
+    int width = randRange(12, 25, rng);
+    const int bzL = randRange(3, 9, rng), bzW = randRange(3, 9, rng);
+    const int matL = randRange(2, 8, rng), matW = randRange(2, 8, rng);
+    length = std::max(bzL + matL + 3, length);
+    width = std::max(bzW + matW + 3, width);
+    const int bzX = randRange(1, length - bzL - 1, rng), bzZ = randRange(1, width - bzW - 1, rng);
+    const int matX = randRange(1, length - matL - 1, rng), matZ = randRange(1, width - matW - 1, rng);
+
+    struct C3 { int x, y, z; };
+    std::vector<C3> cand;
+    for (int x = 1; x < length - 1; ++x)
+        for (int z = 1; z < width - 1; ++z) cand.push_back(C3{x, 2, z});
+    std::shuffle(cand.begin(), cand.end(), rng);
+
+    const int nAgentSpawns = std::min(A, int(cand.size()));
+    const int maxRandomObjects = std::min(int(cand.size()) - A, 25);
+    const int spawnObjects = randRange(0, std::max(1, maxRandomObjects), rng);
+    std::vector<C3> objs(cand.begin() + nAgentSpawns, cand.begin() + nAgentSpawns + spawnObjects);
+    for (auto &c : objs) {
+        if (c.x >= matX && c.x < matX + matL && c.z >= matZ && c.z < matZ + matW) continue;
+        c.y -= 1;
+    }
+    for (int x = matX; x < matX + matL; ++x)
+        for (int z = matZ; z < matZ + matW; ++z) objs.push_back(C3{x, 1, z});
+
+    e.L = length; e.H = height; e.W = width;
+    e.bz[0] = bzX; e.bz[1] = bzX + bzL; e.bz[2] = bzZ; e.bz[3] = bzZ + bzW;
+
+    // ---- vg.addPlatform(platform, layoutColor, randomLayoutColor(rng), randomBool(rng)), :145.
+    // GCC evaluates the arguments right to left: randomBool first.
+    const bool drawWalls = randomBool(rng);
+    const unsigned wallColor = randomLayoutColor(rng);
+    e.layoutColor = layoutColor; e.wallColor = wallColor; e.drawWalls = drawWalls;
+
+    // floor (platforms.hpp:167-176) then walls S,N,E,W (:178-190); later fills override earlier
+    // ones exactly like grid.set() does (component_voxel_grid.hpp:73-90).
+    const uint8_t vFloor = VX_SOLID | VX_OPAQUE | (0 << VX_COLOR_SHIFT);
+    const uint8_t vWall = VX_SOLID | (drawWalls ? VX_OPAQUE : 0) | (1 << VX_COLOR_SHIFT);
+    fill_box(e, 0, 0, 0, length, 1, width, vFloor);
+    fill_box(e, 0, 0, 0, 1, height, width, vWall);
+    fill_box(e, length - 1, 0, 0, length, height, width, vWall);
+    fill_box(e, 0, 0, 0, length, height, 1, vWall);
+    fill_box(e, 0, 0, width - 1, length, height, width, vWall);
+    // building zone terrain box has min.y == max.y == 1 -> writes no voxels (:83-88 + SURVEY A.4)
+
+    merge_boxes(e);
+
+    // ---- addEpisodeDrawables :161-177 + ObjectStackingComponent::addDrawablesAndCollisions
+    e.numObjects = std::min(int(objs.size()), int(MAX_OBJECTS));
+    for (int i = 0; i < e.numObjects; ++i) {
+        e.objects[i] = Object{objs[i].x, objs[i].y, objs[i].z, 0};
+        if (Env::inChunk(objs[i].x, objs[i].y, objs[i].z)) e.chunk[Env::cell(objs[i].x, objs[i].y, objs[i].z)] |= VX_OBJECT;
+    }
+    e.highestTower = 0;
+    e.bzReward = tower_reward(e);
+    // episodeLengthSec :263-266
+    e.episodeLen = e.p_episodeLengthSec + 4.0f * float(e.numObjects);
+    e.barHalfWidth = 0.24f;
+
+    // ---- DefaultScenario::spawnAgents, scenario_default.hpp:80-97 ; agent ctor agent.cpp:24-65
+    for (int i = 0; i < A; ++i) {
+        const C3 sp = cand[i < nAgentSpawns ? i : 0];
+        Agent &a = e.agents[i];
+        float keepShaping[4];
+        std::memcpy(keepShaping, a.shaping, sizeof keepShaping);
+        const float randomRotation = frand(rng) * PI_F * 2;
+        float c, s;
+        yaw_matrix(randomRotation, &c, &s);
+        a.pos = v3(float(sp.x) + 0.5f, float(sp.y) + 0.0f + AGENT_HEIGHT, float(sp.z) + 0.5f);
+        a.m00 = c; a.m02 = s; a.m20 = -s; a.m22 = c;
+        a.pitch = 0;
+        a.hvx = a.hvz = 0; a.vvel = 0; a.voffset = 0; a.step_offset = 0; a.jump_speed = 10.0f; a.was_jumping = 0;
+        a.carrying = -1; a.picked_up = 0; a.visited_zone = 0;
+        a.spawn[0] = sp.x; a.spawn[1] = sp.y; a.spawn[2] = sp.z;
+        a.last_reward = 0; a.total_reward = 0; a.action = 0;
+        std::memcpy(a.shaping, keepShaping, sizeof keepShaping);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Collision geometry.  A vertical capsule (segment half-length CAP_HH, radius r) against an
+// axis-aligned box == the capsule CENTRE against the box grown by CAP_HH in +-y, rounded by r.
+// ------------------------------------------------------------------------------------------------
+struct Collider {
+    int kind;    // 0 none, 1 box (lo/hi already grown in y by CAP_HH), 2 vertical capsule (other agent)
+    V3 lo, hi;   // box bounds; capsule: lo = centre, hi.x = segment half-length
+};
+
+struct Closest {
+    float dist;  // signed distance of the capsule surface to the collider (negative = penetrating)
+    V3 n;        // unit normal from the collider towards the capsule
+};
+
+static Closest closest_box(V3 p, V3 lo, V3 hi, float r)
+{
+    const float qx = std::min(std::max(p.x, lo.x), hi.x);
+    const float qy = std::min(std::max(p.y, lo.y), hi.y);
+    const float qz = std::min(std::max(p.z, lo.z), hi.z);
+    const V3 v = v3(p.x - qx, p.y - qy, p.z - qz);
+    const float d2 = len2(v);
+    Closest c;
+    if (d2 > 0.0f) {
+        const float d = sqrtf(d2);
+        const float inv = 1.0f / d;
+        c.dist = d - r;
+        c.n = v * inv;
+    } else {  // centre inside the grown box: exit through the nearest face
+        float m = p.x - lo.x; V3 n = v3(-1, 0, 0);
+        float t = hi.x - p.x; if (t < m) { m = t; n = v3(1, 0, 0); }
+        t = p.y - lo.y; if (t < m) { m = t; n = v3(0, -1, 0); }
+        t = hi.y - p.y; if (t < m) { m = t; n = v3(0, 1, 0); }
+        t = p.z - lo.z; if (t < m) { m = t; n = v3(0, 0, -1); }
+        t = hi.z - p.z; if (t < m) { m = t; n = v3(0, 0, 1); }
+        c.dist = -m - r;
+        c.n = n;
+    }
+    return c;
+}
+
+static Closest closest_capsule(V3 p, V3 centre, float halfLen, float r)
+{
+    const float qy = std::min(std::max(p.y, centre.y - halfLen), centre.y + halfLen);
+    const V3 v = v3(p.x - centre.x, p.y - qy, p.z - centre.z);
+    const float d2 = len2(v);
+    Closest c;
+    if (d2 > 1e-12f) {
+        const float d = sqrtf(d2);
+        const float inv = 1.0f / d;
+        c.dist = d - r;
+        c.n = v * inv;
+    } else {
+        c.dist = -r;
+        c.n = v3(1, 0, 0);
+    }
+    return c;
+}
+
+// rBox: capsule radius against boxes; rCap: summed radii against another capsule
+static Closest closest(const Collider &col, V3 p, float rBox, float rCap)
+{
+    if (col.kind == 1) return closest_box(p, col.lo, col.hi, rBox);
+    return closest_capsule(p, col.lo, col.hi.x, rCap);
+}
+
+// [3P] Bullet 2.89 btContinuousConvexCollision::calcTimeOfImpact restated for a translating
+// convex shape with exact closest points (conservative advancement).  Call sites in the
+// reference: kinematic_character_controller.cpp:252,363,425 (ghost convexSweepTest).
+static bool convex_cast(const Collider &col, V3 p, V3 d, float *fraction, V3 *normal)
+{
+    float lambda = 0.0f, lastLambda = 0.0f;
+    int numIter = 0;
+    Closest c = closest(col, p, CAP_R, 2 * CAP_R);
+    float dist = c.dist + ALLOWED_CCD_PEN;
+    V3 n = c.n;
+    float proj = -dot(d, n);
+    if (proj <= SIMD_EPS) return false;
+    while (dist > CAST_RADIUS) {
+        proj = -dot(d, n);
+        if (proj <= SIMD_EPS) return false;
+        lambda = lambda + dist / proj;
+        if (lambda > 1.0f) return false;
+        if (lambda < 0.0f) return false;
+        if (lambda <= lastLambda) return false;
+        lastLambda = lambda;
+        const V3 x = v3(p.x + lambda * d.x, p.y + lambda * d.y, p.z + lambda * d.z);
+        c = closest(col, x, CAP_R, 2 * CAP_R);
+        dist = c.dist + ALLOWED_CCD_PEN;
+        n = c.n;
+        if (++numIter > CAST_MAX_ITER) return false;
+    }
+    *fraction = lambda;
+    *normal = n;
+    return true;
+}
+
+struct Colliders {
+    int n = 0;
+    Collider c[MAX_BOXES + MAX_OBJECTS + MAX_AGENTS];
+};
+
+// Collider order == index order used for tie-breaks: layout boxes, movable boxes, agents.
+static void build_colliders(const Env &e, int self, Colliders &out)
+{
+    out.n = 0;
+    for (int i = 0; i < MAX_BOXES; ++i) {
+        Collider &c = out.c[out.n++];
+        if (i < e.numBoxes && (e.boxes[i].type & VX_SOLID)) {  // layout_utils.cpp:42-49
+            const Box &b = e.boxes[i];
+            c.kind = 1;
+            c.lo = v3(float(b.min[0]), float(b.min[1]) - CAP_HH, float(b.min[2]));
+            c.hi = v3(float(b.max[0]), float(b.max[1]) + CAP_HH, float(b.max[2]));
+        } else c.kind = 0;
+    }
+    for (int i = 0; i < MAX_OBJECTS; ++i) {
+        Collider &c = out.c[out.n++];
+        if (i < e.numObjects && e.objects[i].state == 0) {  // carried boxes: CF_NO_CONTACT_RESPONSE physics.hpp:76-85
+            const Object &o = e.objects[i];
+            const float cx = float(o.x) + 0.5f, cy = float(o.y) + 0.5f + OBJ_COLL_YOFF, cz = float(o.z) + 0.5f;
+            c.kind = 1;
+            c.lo = v3(cx - OBJ_COLL_HALF, (cy - OBJ_COLL_HALF) - CAP_HH, cz - OBJ_COLL_HALF);
+            c.hi = v3(cx + OBJ_COLL_HALF, (cy + OBJ_COLL_HALF) + CAP_HH, cz + OBJ_COLL_HALF);
+        } else c.kind = 0;
+    }
+    for (int i = 0; i < MAX_AGENTS; ++i) {
+        Collider &c = out.c[out.n++];
+        if (i < e.numAgents && i != self) {  // collision filter agent.cpp:63
+            c.kind = 2;
+            c.lo = e.agents[i].pos;
+            c.hi = v3(2 * CAP_HH, 0, 0);
+        } else c.kind = 0;
+    }
+}
+
+// [3P] btCollisionWorld::objectQuerySingle + ClosestConvexResultCallback, with the controller's
+// KinematicClosestNotMeConvexResultCallback filter (kinematic_character_controller.cpp:53-93).
+static bool sweep(const Colliders &cs, V3 from, V3 to, V3 up, float minSlopeDot, float *fraction, V3 *normal)
+{
+    const V3 d = to - from;
+    float best = 1.0f;
+    bool hit = false;
+    for (int i = 0; i < cs.n; ++i) {
+        if (cs.c[i].kind == 0) continue;
+        float f; V3 n;
+        if (!convex_cast(cs.c[i], from, d, &f, &n)) continue;
+        if (!(len2(n) > 0.0001f)) continue;
+        if (!(f < best)) continue;
+        if (dot(up, n) < minSlopeDot) continue;
+        best = f; *normal = n; hit = true;
+    }
+    *fraction = best;
+    return hit;
+}
+
+// kinematic_character_controller.cpp:156-221.  [3P] the manifold is restated as one exact
+// closest-point pair per overlapping object.
+static bool recover_from_penetration(const Colliders &cs, V3 &pos)
+{
+    for (int i = 0; i < cs.n; ++i) {
+        if (cs.c[i].kind == 0) continue;
+        const Closest c = closest(cs.c[i], pos, CAP_R, 2 * CAP_R);
+        if (c.dist < -MAX_PEN_DEPTH) {
+            const float push = -c.dist;
+            pos = v3(pos.x + c.n.x * push, pos.y + c.n.y * push, pos.z + c.n.z * push);
+            return true;
+        }
+    }
+    return false;
+}
+
+static bool on_ground(const Agent &a)
+{   // kinematic_character_controller.cpp:679-682
+    return (fabsf(a.vvel) < SIMD_EPS) && (fabsf(a.voffset) < SIMD_EPS);
+}
+
+// kinematic_character_controller.cpp:753-792
+static void set_acceleration(Agent &a, V3 acc, float dt)
+{
+    const bool isOnGround = on_ground(a);
+    const float accMag = sqrtf(len2(acc));
+    const float currMax = isOnGround ? MAX_ACCEL : MAX_AIR_ACCEL;
+    if (!(len2(acc) < SIMD_EPS * SIMD_EPS)) {  // !fuzzyZero
+        const float k = currMax / accMag;
+        acc = acc * k;
+    }
+    if (isOnGround) {
+        a.hvx += acc.x * dt;
+        a.hvz += acc.z * dt;
+        const float speed = sqrtf(a.hvx * a.hvx + a.hvz * a.hvz);
+        if (speed > MAX_H_SPEED) {
+            const float dv = EXCEED_DECEL * dt;
+            const float k = (speed - dv > MAX_H_SPEED) ? (speed - dv) / speed : MAX_H_SPEED / speed;
+            a.hvx *= k; a.hvz *= k;
+        }
+    } else {
+        const float speed = sqrtf(a.hvx * a.hvx + a.hvz * a.hvz);
+        const float nx = a.hvx + acc.x * dt, nz = a.hvz + acc.z * dt;
+        const float newSpeed = sqrtf(nx * nx + nz * nz);
+        if (newSpeed <= MAX_AIR_SPEED || newSpeed < speed) { a.hvx = nx; a.hvz = nz; }
+    }
+}
+
+static V3 lerp3(V3 a, V3 b, float rt)
+{   // [3P] btVector3::setInterpolate3
+    const float s = 1.0f - rt;
+    return v3(s * a.x + rt * b.x, s * a.y + rt * b.y, s * a.z + rt * b.z);
+}
+
+// kinematic_character_controller.cpp:519-602 (preStep + playerStep) with stepUp :223-304,
+// stepForwardAndStrafe :337-393, stepDown :400-442, updateTargetPositionBasedOnCollision :313-329
+static void player_step(Env &e, int idx, float dt)
+{
+    Agent &a = e.agents[idx];
+    Colliders cs;
+    build_colliders(e, idx, cs);
+
+    V3 cur = a.pos, target = a.pos;
+    const V3 original = cur;
+    const V3 UP = v3(0, 1, 0);
+
+    const bool wasOnGround = on_ground(a);
+    a.vvel -= GRAVITY * dt;
+    if (a.vvel > 0.0f && a.vvel > a.jump_speed) a.vvel = a.jump_speed;
+    if (a.vvel < 0.0f && fabsf(a.vvel) > fabsf(FALL_SPEED)) a.vvel = -fabsf(FALL_SPEED);
+    a.voffset = a.vvel * dt;
+
+    // ---- stepUp
+    {
+        const float stepHeight = (a.vvel < 0.0f) ? STEP_HEIGHT : 0.0f;
+        const V3 start = cur;
+        target = v3(cur.x, cur.y + stepHeight + (a.voffset > 0.0f ? a.voffset : 0.0f), cur.z);
+        cur = target;
+        float f; V3 n;
+        if (sweep(cs, start, target, v3(0, -1, 0), MAX_SLOPE_COS, &f, &n)) {
+            if (dot(n, UP) > 0.0f) {
+                a.step_offset = stepHeight * f;
+                cur = lerp3(cur, target, f);
+            }
+            int loops = 0;
+            while (recover_from_penetration(cs, cur)) {
+                if (++loops > 4) break;
+            }
+            target = cur;
+            if (a.voffset > 0) { a.voffset = 0.0f; a.vvel = 0.0f; a.step_offset = STEP_HEIGHT; }
+        } else {
+            a.step_offset = stepHeight;
+            cur = target;
+        }
+    }
+
+    // ---- stepForwardAndStrafe
+    {
+        const V3 hv = v3(a.hvx, 0, a.hvz);
+        target = v3(cur.x + hv.x * dt, cur.y + hv.y * dt, cur.z + hv.z * dt);
+        int maxIter = 10;
+        while (maxIter-- > 0) {
+            const V3 negDir = cur - target;
+            float f = 1.0f; V3 n = v3(0, 0, 0);
+            bool hit = false;
+            if (!(cur.x == target.x && cur.y == target.y && cur.z == target.z)) hit = sweep(cs, cur, target, negDir, 0.0f, &f, &n);
+            if (!hit) break;
+            // updateTargetPositionBasedOnCollision
+            V3 dir = target - cur;
+            const float movLen = sqrtf(len2(dir));
+            if (movLen > SIMD_EPS) {
+                dir = dir * (1.0f / movLen);
+                const float mag = dot(dir, n);
+                const V3 par = n * mag;
+                const V3 perp = dir - par;
+                target = cur;
+                target = target + perp * movLen;
+                target = target + par * (movLen * f);
+            }
+            V3 cd = target - cur;
+            const float dist2 = len2(cd);
+            if (dist2 > 0.0001f) {
+                cd = cd * (1.0f / sqrtf(dist2));
+                if (dot(cd, hv) <= 0.0f) { target = cur; break; }
+            } else { target = cur; break; }
+        }
+        cur = target;
+    }
+
+    // ---- stepDown
+    {
+        float downVel = (a.vvel < 0.0f) ? -a.vvel : 0.0f;
+        if (downVel > 0.0f && downVel > FALL_SPEED && (wasOnGround || !a.was_jumping)) downVel = FALL_SPEED;
+        target = v3(target.x, target.y - (a.step_offset + downVel * dt), target.z);
+        float f; V3 n;
+        if (sweep(cs, cur, target, UP, MAX_SLOPE_COS, &f, &n)) {
+            cur = lerp3(cur, target, f);
+            a.vvel = 0.0f; a.voffset = 0.0f; a.was_jumping = 0;
+        } else cur = target;
+    }
+
+    a.hvx = (cur.x - original.x) / dt;
+    a.hvz = (cur.z - original.z) / dt;
+
+    int loops = 0;
+    while (recover_from_penetration(cs, cur)) {
+        if (++loops > 4) break;
+    }
+    a.pos = cur;
+
+    const float speed = sqrtf(a.hvx * a.hvx + a.hvz * a.hvz);
+    if (on_ground(a)) {
+        if (speed - NORMAL_DECEL * dt < 0) { a.hvx = 0; a.hvz = 0; }
+        else { const float k = (speed - NORMAL_DECEL * dt) / speed; a.hvx *= k; a.hvz *= k; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Agent frames
+// ------------------------------------------------------------------------------------------------
+struct Cam {
+    V3 eye;
+    float c[3][3];  // columns = camera right / up / back in world space
+};
+
+static Cam camera_of(const Agent &a)
+{   // agent.cpp:33 (+0.41), :95 (+0.05), :110-126 (pitch about local X)
+    Cam cam;
+    cam.eye = v3(a.pos.x, (a.pos.y + 0.05f) + 0.41f, a.pos.z);
+    float sp, cp;
+    mv_sincos(a.pitch, &sp, &cp);
+    cam.c[0][0] = a.m00; cam.c[0][1] = a.m02 * sp; cam.c[0][2] = a.m02 * cp;
+    cam.c[1][0] = 0.0f;  cam.c[1][1] = cp;         cam.c[1][2] = -sp;
+    cam.c[2][0] = a.m20; cam.c[2][1] = a.m22 * sp; cam.c[2][2] = a.m22 * cp;
+    return cam;
+}
+
+static V3 cam_to_world(const Cam &cam, V3 v)
+{
+    return v3((cam.c[0][0] * v.x + cam.c[0][1] * v.y) + cam.c[0][2] * v.z + cam.eye.x,
+              (cam.c[1][0] * v.x + cam.c[1][1] * v.y) + cam.c[1][2] * v.z + cam.eye.y,
+              (cam.c[2][0] * v.x + cam.c[2][1] * v.y) + cam.c[2][2] * v.z + cam.eye.z);
+}
+
+static void voxel_of(V3 p, int out[3])
+{   // voxel_grid.hpp:18-21,144-149 (origin 0, voxelSize 1)
+    out[0] = (int)lroundf(floorf(p.x)); out[1] = (int)lroundf(floorf(p.y)); out[2] = (int)lroundf(floorf(p.z));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Rewards -- scenario.hpp:259-298
+// ------------------------------------------------------------------------------------------------
+static void reward_agent(Env &e, int key, int idx, float mult) { e.agents[idx].last_reward += e.agents[idx].shaping[key] * mult; }
+static void reward_team(Env &e, int key, int idx, float mult)
+{
+    reward_agent(e, key, idx, mult * (1 - e.agents[idx].shaping[0]));
+    for (int i = 0; i < e.numAgents; ++i)
+        e.agents[i].last_reward += e.agents[i].shaping[key] * e.agents[i].shaping[0] * mult / float(e.numAgents);
+}
+
+static int object_at(const Env &e, int x, int y, int z)
+{
+    for (int i = 0; i < e.numObjects; ++i)
+        if (e.objects[i].state == 0 && e.objects[i].x == x && e.objects[i].y == y && e.objects[i].z == z) return i;
+    return -1;
+}
+
+// component_object_stacking.hpp:58-168 + TowerBuilding callbacks scenario_tower_building.cpp:201-225
+static void on_interact(Env &e, int idx)
+{
+    Agent &a = e.agents[idx];
+    const Cam cam = camera_of(a);
+    if (a.carrying >= 0) {
+        const V3 t = cam_to_world(cam, v3(0.0f, -0.44f + -0.3f, -1.0f));
+        int vox[3];
+        voxel_of(t, vox);
+        bool collidesWithAgent = false;
+        for (int j = 0; j < e.numAgents; ++j) {
+            if (j == idx) continue;
+            int c[3];
+            voxel_of(v3(e.agents[j].pos.x, e.agents[j].pos.y + 0.05f, e.agents[j].pos.z), c);
+            if (c[0] == vox[0] && c[1] == vox[1] && c[2] == vox[2]) { collidesWithAgent = true; break; }
+        }
+        // Dense chunk instead of the reference's unbounded hash map: cells outside the chunk in
+        // x/z/+y are refused (deviation); below the chunk everything is empty.
+        const bool placeable = vox[0] >= 0 && vox[0] < CX && vox[2] >= 0 && vox[2] < CZ && vox[1] < CY;
+        const uint8_t v = e.vox(vox[0], vox[1], vox[2]);
+        const bool empty = !(v & VX_SOLID) && !(v & VX_OBJECT);
+        if (placeable && empty && !collidesWithAgent && in_building_zone(e, vox[0], vox[2])) {
+            for (;;) {
+                const int by = vox[1] - 1;
+                if (by < -30) break;
+                const uint8_t vb = e.vox(vox[0], by, vox[2]);
+                if ((vb & VX_SOLID) || (vb & VX_OBJECT)) break;
+                vox[1] = by;
+            }
+            Object &o = e.objects[a.carrying];
+            o.x = vox[0]; o.y = vox[1]; o.z = vox[2]; o.state = 0;
+            if (Env::inChunk(vox[0], vox[1], vox[2])) e.chunk[Env::cell(vox[0], vox[1], vox[2])] |= VX_OBJECT;
+            a.carrying = -1;
+            // placedObject :206-214
+            const float newReward = tower_reward(e);
+            const float delta = newReward - e.bzReward;
+            e.bzReward = newReward;
+            reward_team(e, 3, idx, delta);
+            e.highestTower = std::max(e.highestTower, vox[1] - 1 + 1);
+        }
+    } else {
+        const V3 pickup = cam_to_world(cam, v3(0.0f, -0.44f, -1.0f));
+        int vox[3];
+        voxel_of(pickup, vox);
+        for (int h = 0; h <= 1; ++h) {
+            const int oi = object_at(e, vox[0], vox[1], vox[2]);
+            const bool above = object_at(e, vox[0], vox[1] + 1, vox[2]) >= 0;
+            if (oi >= 0 && !above) {
+                e.objects[oi].state = 1 + idx;
+                if (Env::inChunk(vox[0], vox[1], vox[2])) e.chunk[Env::cell(vox[0], vox[1], vox[2])] &= ~VX_OBJECT;
+                a.carrying = oi;
+                // pickedObject :216-225
+                if (!a.picked_up) { reward_agent(e, 1, idx, 1); a.picked_up = 1; }
+                break;
+            }
+            vox[1] += 1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Env::step -- env/src/env.cpp:83-152
+// ------------------------------------------------------------------------------------------------
+static void env_step(Env &e)
+{
+    const float dt = DT;
+    for (int i = 0; i < e.numAgents; ++i) e.agents[i].last_reward = 0.0f;
+
+    for (int i = 0; i < e.numAgents; ++i) {
+        Agent &a = e.agents[i];
+        const int act = a.action;
+        // forwardDirection/strafeLeftDirection agent.cpp:135-150
+        V3 fwd = v3(a.m20, 0.0f, -a.m22);
+        fwd = fwd * (1.0f / sqrtf(len2(fwd)));
+        V3 left = v3(-a.m00, 0.0f, a.m02);
+        left = left * (1.0f / sqrtf(len2(left)));
+        V3 acc = v3(0, 0, 0);
+        if (act & (1 << 3)) acc = acc + fwd;
+        else if (act & (1 << 4)) acc = acc - fwd;
+        if (act & (1 << 1)) acc = acc + left;
+        else if (act & (1 << 2)) acc = acc - left;
+
+        if (act & ((1 << 5) | (1 << 6))) {  // rotateYAxis agent.cpp:128-133
+            float c, s;
+            yaw_matrix(ROTATE_RAD * dt, &c, &s);
+            if (act & (1 << 5)) { /* look left: +angle */ }
+            else s = -s;
+            const float n00 = a.m00 * c + a.m02 * (-s), n02 = a.m00 * s + a.m02 * c;
+            const float n20 = a.m20 * c + a.m22 * (-s), n22 = a.m20 * s + a.m22 * c;
+            a.m00 = n00; a.m02 = n02; a.m20 = n20; a.m22 = n22;
+        }
+        if (act & (1 << 10)) {  // lookUp agent.cpp:110-116
+            a.pitch += ROTATE_X_RAD * dt;
+            a.pitch = std::min(e.p_verticalLookLimitRad, a.pitch);
+        } else if (act & (1 << 9)) {  // lookDown :118-126
+            a.pitch -= ROTATE_X_RAD * dt * 1.1f;
+            a.pitch = std::max(-e.p_verticalLookLimitRad, a.pitch);
+        }
+
+        set_acceleration(a, acc, dt);
+
+        if ((act & (1 << 7)) && on_ground(a)) {  // agent.cpp:157-161, controller jump() :625-634
+            a.jump_speed = sqrtf(6.2f * 6.2f);
+            a.vvel = a.jump_speed;
+            a.was_jumping = 1;
+        }
+    }
+
+    // bWorld.stepSimulation(dt, 1, dt): controllers run in agent order (env.cpp:126)
+    for (int i = 0; i < e.numAgents; ++i) player_step(e, i, dt);
+
+    // scenario->step(): objectStacking, fallDetection, zone reward (scenario_tower_building.cpp:179-199)
+    for (int i = 0; i < e.numAgents; ++i)
+        if (e.agents[i].action & (1 << 8)) on_interact(e, i);
+
+    for (int i = 0; i < e.numAgents; ++i) {  // component_fall_detection.hpp:33-55
+        Agent &a = e.agents[i];
+        if (a.pos.y + 0.05f < -20.0f) {
+            int p[3] = {a.spawn[0], a.spawn[1], a.spawn[2]};
+            while ((e.vox(p[0], p[1], p[2]) & VX_SOLID) && p[1] < 1000) ++p[1];
+            a.pos = v3(float(p[0]) + 0.5f, float(p[1]) + 0.5f, float(p[2]) + 0.5f);
+            a.m00 = 1; a.m02 = 0; a.m20 = 0; a.m22 = 1;  // warp(): xform.setIdentity()
+            a.hvx = a.hvz = 0; a.vvel = 0;
+        }
+    }
+
+    for (int i = 0; i < e.numAgents; ++i) {
+        Agent &a = e.agents[i];
+        if (a.carrying >= 0) {
+            int vox[3];
+            voxel_of(v3(a.pos.x, a.pos.y + 0.05f, a.pos.z), vox);
+            if (in_building_zone(e, vox[0], vox[2]) && !a.visited_zone) {
+                reward_team(e, 2, i, 1);
+                a.visited_zone = 1;
+            }
+        }
+    }
+
+    e.episodeSec += dt;
+    // updateUI scenario_default.hpp:164-169 ; remainingTimeFraction env.hpp:224-228
+    e.barHalfWidth = std::max(0.0f, (e.episodeLen - e.episodeSec) / e.episodeLen) * 0.24f;
+    if (e.episodeSec >= e.episodeLen) e.done = 1;
+
+    for (int i = 0; i < e.numAgents; ++i) {
+        e.agents[i].action = 0;
+        e.agents[i].total_reward += e.agents[i].last_reward;
+    }
+    ++e.numFrames;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Software first-person renderer.  One primary ray per pixel centre; for opaque convex solids
+// with depth test + back-face culling this selects the same surface as the GL rasteriser
+// (magnum_env_renderer.cpp:288-340).  Shading = Magnum Shaders::Phong [3P] with the uniforms
+// set at :200-203; projection = env_renderer.hpp:34-38 (hfov 100, aspect 128/72 regardless of
+// the framebuffer size).
+// ------------------------------------------------------------------------------------------------
+static const float TAN_HALF_FOV = 1.19175359f;                      // tan(50 deg)
+static const float TAN_HALF_FOV_Y = 1.19175359f / (128.0f / 72.0f);
+static const float NEAR_Z = 0.01f, FAR_Z = 120.0f;
+
+struct Prim {
+    int kind;   // 1 = box in frame `frame`, 2 = vertical capsule in world
+    int frame;  // -1 world axes, k>=0: camera frame of agent k
+    V3 lo, hi;  // box bounds in its frame; capsule: lo = centre, hi = (radius, halfLen, 0)
+    unsigned color;
+};
+
+static void build_prims(const Env &e, int viewer, std::vector<Prim> &out)
+{
+    out.clear();
+    for (int i = 0; i < e.numBoxes; ++i) {  // layout_utils.cpp:17-50
+        const Box &b = e.boxes[i];
+        if (!(b.type & VX_OPAQUE)) continue;
+        Prim p; p.kind = 1; p.frame = -1;
+        p.lo = v3(float(b.min[0]), float(b.min[1]), float(b.min[2]));
+        p.hi = v3(float(b.max[0]), float(b.max[1]), float(b.max[2]));
+        p.color = b.slot == 0 ? e.layoutColor : e.wallColor;
+        out.push_back(p);
+    }
+    {   // building zone slab, layout_utils.cpp:53-68
+        Prim p; p.kind = 1; p.frame = -1;
+        p.lo = v3(float(e.bz[0]), 1.0f, float(e.bz[2]));
+        p.hi = v3(float(e.bz[1]), 1.0f + 0.05f, float(e.bz[3]));
+        p.color = COLOR_BUILDING_ZONE;
+        out.push_back(p);
+    }
+    for (int i = 0; i < e.numObjects; ++i) {  // component_object_stacking.hpp:170-198, :146-152
+        const Object &o = e.objects[i];
+        Prim p; p.kind = 1; p.color = COLOR_MOVABLE_BOX;
+        if (o.state == 0) {
+            p.frame = -1;
+            const V3 c = v3(float(o.x) + 0.5f, float(o.y) + 0.5f, float(o.z) + 0.5f);
+            p.lo = v3(c.x - OBJ_HALF, c.y - OBJ_HALF, c.z - OBJ_HALF);
+            p.hi = v3(c.x + OBJ_HALF, c.y + OBJ_HALF, c.z + OBJ_HALF);
+        } else {
+            p.frame = o.state - 1;
+            const float hh = OBJ_HALF * CARRY_SCALE;
+            const V3 c = v3(0.0f, -0.44f + -0.3f, -1.0f);
+            p.lo = v3(c.x - hh, c.y - hh, c.z - hh);
+            p.hi = v3(c.x + hh, c.y + hh, c.z + hh);
+        }
+        out.push_back(p);
+    }
+    for (int k = 0; k < e.numAgents; ++k) {  // scenario_default.hpp:99-170
+        if (k != viewer) {
+            Prim body; body.kind = 2; body.frame = -1;
+            const Agent &a = e.agents[k];
+            body.lo = v3(a.pos.x, (a.pos.y + 0.05f) + 0.09f, a.pos.z);
+            body.hi = v3(0.35f, 0.36f, 0.0f);
+            body.color = AGENT_COLORS[k % 7];
+            out.push_back(body);
+            Prim eyes; eyes.kind = 1; eyes.frame = k;
+            eyes.lo = v3(-0.25f, -0.12f, -0.19f - 0.2f);
+            eyes.hi = v3(0.25f, 0.12f, -0.19f + 0.2f);
+            eyes.color = COLOR_AGENT_EYES;
+            out.push_back(eyes);
+        }
+        Prim bar; bar.kind = 1; bar.frame = k;
+        bar.lo = v3(-e.barHalfWidth, -0.131f - 0.0015f, -0.2f - 0.001f);
+        bar.hi = v3(e.barHalfWidth, -0.131f + 0.0015f, -0.2f + 0.001f);
+        bar.color = COLOR_UI_BAR;
+        out.push_back(bar);
+    }
+}
+
+// slab test; returns entry t and entry-face normal (back faces culled: the camera inside a
+// box sees nothing of it)
+static bool ray_box(V3 o, V3 d, V3 lo, V3 hi, float *t_out, V3 *n_out)
+{
+    float tEnter = -INFINITY, tExit = INFINITY;
+    int axis = -1;
+    const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}, l[3] = {lo.x, lo.y, lo.z}, h[3] = {hi.x, hi.y, hi.z};
+    for (int k = 0; k < 3; ++k) {
+        if (dd[k] == 0.0f) {
+            if (oo[k] < l[k] || oo[k] > h[k]) return false;
+        } else {
+            const float inv = 1.0f / dd[k];
+            const float t1 = (l[k] - oo[k]) * inv, t2 = (h[k] - oo[k]) * inv;
+            const float tn = std::min(t1, t2), tf = std::max(t1, t2);
+            if (tn > tEnter) { tEnter = tn; axis = k; }
+            tExit = std::min(tExit, tf);
+        }
+    }
+    if (axis < 0 || tEnter > tExit || tEnter < NEAR_Z || tEnter > FAR_Z) return false;
+    V3 n = v3(0, 0, 0);
+    const float sgn = dd[axis] > 0 ? -1.0f : 1.0f;
+    if (axis == 0) n.x = sgn; else if (axis == 1) n.y = sgn; else n.z = sgn;
+    *t_out = tEnter; *n_out = n;
+    return true;
+}
+
+// vertical capsule (radius r, segment half-length hl): cylinder side + two spheres
+static bool ray_capsule(V3 o, V3 d, V3 c, float r, float hl, float *t_out, V3 *n_out)
+{
+    bool hit = false;
+    float best = INFINITY; V3 bn = v3(0, 0, 0);
+    const float ox = o.x - c.x, oz = o.z - c.z;
+    const float A = d.x * d.x + d.z * d.z;
+    if (A > 0.0f) {
+        const float B = ox * d.x + oz * d.z;
+        const float C = (ox * ox + oz * oz) - r * r;
+        const float disc = B * B - A * C;
+        if (disc >= 0.0f) {
+            const float t = (-B - sqrtf(disc)) / A;
+            const float y = o.y + t * d.y;
+            if (t >= NEAR_Z && t <= FAR_Z && y >= c.y - hl && y <= c.y + hl) {
+                hit = true; best = t;
+                const float inv = 1.0f / r;
+                bn = v3((ox + t * d.x) * inv, 0.0f, (oz + t * d.z) * inv);
+            }
+        }
+    }
+    for (int s = 0; s < 2; ++s) {
+        const float cy = s == 0 ? c.y - hl : c.y + hl;
+        const float oy = o.y - cy;
+        const float A3 = (d.x * d.x + d.y * d.y) + d.z * d.z;
+        const float B3 = (ox * d.x + oy * d.y) + oz * d.z;
+        const float C3 = ((ox * ox + oy * oy) + oz * oz) - r * r;
+        const float disc = B3 * B3 - A3 * C3;
+        if (disc >= 0.0f) {
+            const float t = (-B3 - sqrtf(disc)) / A3;
+            const float y = o.y + t * d.y;
+            const bool capSide = s == 0 ? (y <= cy) : (y >= cy);
+            if (t >= NEAR_Z && t <= FAR_Z && capSide && t < best) {
+                hit = true; best = t;
+                const float inv = 1.0f / r;
+                bn = v3((ox + t * d.x) * inv, (oy + t * d.y) * inv, (oz + t * d.z) * inv);
+            }
+        }
+    }
+    if (hit) { *t_out = best; *n_out = bn; }
+    return hit;
+}
+
+static inline V3 mat_mul(const float m[3][3], V3 v)
+{
+    return v3((m[0][0] * v.x + m[0][1] * v.y) + m[0][2] * v.z, (m[1][0] * v.x + m[1][1] * v.y) + m[1][2] * v.z,
+              (m[2][0] * v.x + m[2][1] * v.y) + m[2][2] * v.z);
+}
+static inline V3 mat_tmul(const float m[3][3], V3 v)
+{
+    return v3((m[0][0] * v.x + m[1][0] * v.y) + m[2][0] * v.z, (m[0][1] * v.x + m[1][1] * v.y) + m[2][1] * v.z,
+              (m[0][2] * v.x + m[1][2] * v.y) + m[2][2] * v.z);
+}
+
+static inline float pow300(float x)
+{
+    const float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8, x32 = x16 * x16, x64 = x32 * x32,
+                x128 = x64 * x64, x256 = x128 * x128;
+    return ((x256 * x32) * x8) * x4;
+}
+
+static inline uint8_t to_u8(float v)
+{
+    v = std::min(std::max(v, 0.0f), 1.0f);
+    return (uint8_t)(int)floorf(v * 255.0f + 0.5f);
+}
+
+static void render_agent(const Env &e, int viewer, int W, int H, uint8_t *out)
+{
+    std::vector<Prim> prims;
+    build_prims(e, viewer, prims);
+    Cam cams[MAX_AGENTS];
+    for (int k = 0; k < e.numAgents; ++k) cams[k] = camera_of(e.agents[k]);
+    const Cam &cam = cams[viewer];
+
+    // ray origins/rotations into every agent frame are per-frame constants
+    V3 originIn[MAX_AGENTS];
+    for (int k = 0; k < e.numAgents; ++k) originIn[k] = mat_tmul(cams[k].c, cam.eye - cams[k].eye);
+
+    const V3 LIGHT = v3(0.0f, 4.0f, 2.0f);
+    const float AMB = float(0x55) / 255.0f, DIF = float(0xbb) / 255.0f, LCOL = float(0xaa) / 255.0f;
+
+    for (int j = 0; j < H; ++j)
+        for (int i = 0; i < W; ++i) {
+            const float xn = ((float(i) + 0.5f) / float(W)) * 2.0f - 1.0f;
+            const float yn = ((float(j) + 0.5f) / float(H)) * 2.0f - 1.0f;
+            const V3 dc = v3(xn * TAN_HALF_FOV, yn * TAN_HALF_FOV_Y, -1.0f);
+            const V3 dw = mat_mul(cam.c, dc);
+
+            float best = INFINITY; V3 bestN = v3(0, 0, 0); unsigned bestColor = 0; bool any = false;
+            for (size_t pi = 0; pi < prims.size(); ++pi) {
+                const Prim &p = prims[pi];
+                float t; V3 n;  // n ends up in the viewer's camera space
+                bool hit;
+                if (p.kind == 2) {
+                    hit = ray_capsule(cam.eye, dw, p.lo, p.hi.x, p.hi.y, &t, &n);
+                    if (hit) n = mat_tmul(cam.c, n);
+                } else if (p.frame < 0) {
+                    hit = ray_box(cam.eye, dw, p.lo, p.hi, &t, &n);
+                    if (hit) n = mat_tmul(cam.c, n);
+                } else if (p.frame == viewer) {
+                    hit = ray_box(v3(0, 0, 0), dc, p.lo, p.hi, &t, &n);
+                } else {
+                    const V3 dk = mat_tmul(cams[p.frame].c, dw);
+                    hit = ray_box(originIn[p.frame], dk, p.lo, p.hi, &t, &n);
+                    if (hit) n = mat_tmul(cam.c, mat_mul(cams[p.frame].c, n));
+                }
+                if (hit && t < best) { best = t; bestN = n; bestColor = p.color; any = true; }
+            }
+
+            uint8_t *px = out + (size_t(j) * W + i) * 4;
+            if (!any) { px[0] = px[1] = px[2] = 0; px[3] = 255; continue; }
+            const V3 P = dc * best;  // camera-space position
+            V3 Ld = LIGHT - P;
+            Ld = Ld * (1.0f / sqrtf(len2(Ld)));
+            const float intensity = std::max(0.0f, dot(bestN, Ld));
+            float spec = 0.0f;
+            if (intensity > 0.001f) {
+                // reflect(-L, N) = -L + 2 (N.L) N
+                const float k2 = 2.0f * dot(bestN, Ld);
+                const V3 R = v3(k2 * bestN.x - Ld.x, k2 * bestN.y - Ld.y, k2 * bestN.z - Ld.z);
+                V3 Vd = v3(-P.x, -P.y, -P.z);
+                Vd = Vd * (1.0f / sqrtf(len2(Vd)));
+                spec = pow300(std::max(0.0f, dot(Vd, R)));
+                spec = std::min(std::max(spec, 0.0f), 1.0f);
+            }
+            const float col[3] = {float((bestColor >> 16) & 255) / 255.0f, float((bestColor >> 8) & 255) / 255.0f,
+                                  float(bestColor & 255) / 255.0f};
+            for (int ch = 0; ch < 3; ++ch) {
+                const float v = (AMB * col[ch] + (DIF * col[ch]) * LCOL * intensity) + spec;
+                px[ch] = to_u8(v);
+            }
+            px[3] = 255;
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// VectorEnv + MegaverseGym -- env/src/vector_env.cpp, bindings/megaverse.cpp
+// ------------------------------------------------------------------------------------------------
+struct Gym {
+    int w, h, numEnvs, numAgents, numThreads;
+    std::vector<std::unique_ptr<Env>> envs;
+    std::vector<uint8_t> done;
+    std::vector<float> trueObjective;
+    std::vector<uint8_t> obs;
+    Rng rng{std::random_device{}()};  // megaverse.cpp:253
+
+    template <typename F> void parallel_envs(F f)
+    {   // vector_env.cpp:12,65-68 static block partition, caller participates
+        const int T = std::max(1, std::min(numThreads, numEnvs));
+        const int per = numEnvs / T + (numEnvs % T != 0);
+        std::vector<std::thread> th;
+        auto work = [&](int t) {
+            const int s = t * per, en = std::min(s + per, numEnvs);
+            for (int i = s; i < en; ++i) f(i);
+        };
+        for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+    }
+
+    void render()
+    {
+        parallel_envs([&](int i) {
+            for (int a = 0; a < numAgents; ++a)
+                render_agent(*envs[i], a, w, h, obs.data() + (size_t(i) * numAgents + a) * size_t(w) * h * 4);
+        });
+    }
+
+    void step(bool doRender)
+    {
+        parallel_envs([&](int i) { env_step(*envs[i]); });
+        for (int i = 0; i < numEnvs; ++i) {  // vector_env.cpp:93-105, serial
+            if (envs[i]->done) {
+                done[i] = 1;
+                for (int a = 0; a < numAgents; ++a) trueObjective[size_t(i) * numAgents + a] = float(envs[i]->highestTower);
+                env_reset(*envs[i]);
+            } else done[i] = 0;
+        }
+        if (doRender) render();
+    }
+};
+
+}  // namespace mvo
+
+// ------------------------------------------------------------------------------------------------
+// C API
+// ------------------------------------------------------------------------------------------------
+using namespace mvo;
+struct mvo_gym : Gym {};
+
+extern "C" {
+
+mvo_gym *mvo_create(const char *scenario, int w, int h, int num_envs, int num_agents_per_env, int num_threads,
+                    const char *const *keys, const float *vals, int n_params)
+{
+    std::string s(scenario ? scenario : "");
+    for (auto &ch : s) ch = (char)tolower(ch);
+    if (s != "towerbuilding") { fprintf(stderr, "mv_oracle: unknown scenario %s\n", s.c_str()); return nullptr; }
+    if (num_agents_per_env < 1 || num_agents_per_env > MAX_AGENTS || num_envs < 1) return nullptr;
+    auto *g = new mvo_gym();
+    g->w = w; g->h = h; g->numEnvs = num_envs; g->numAgents = num_agents_per_env; g->numThreads = std::max(1, num_threads);
+    for (int i = 0; i < num_envs; ++i) {
+        auto e = std::make_unique<Env>();
+        e->numAgents = num_agents_per_env;
+        for (int k = 0; k < n_params; ++k) {
+            if (!strcmp(keys[k], "episodeLengthSec")) e->p_episodeLengthSec = vals[k];
+            if (!strcmp(keys[k], "verticalLookLimitRad")) e->p_verticalLookLimitRad = vals[k];
+        }
+        for (int a = 0; a < MAX_AGENTS; ++a) std::memcpy(e->agents[a].shaping, SHAPING_DEFAULT, sizeof SHAPING_DEFAULT);
+        g->envs.push_back(std::move(e));
+    }
+    g->done.assign(num_envs, 0);
+    g->trueObjective.assign(size_t(num_envs) * num_agents_per_env, 0.0f);
+    g->obs.assign(size_t(num_envs) * num_agents_per_env * w * h * 4, 0);
+    return g;
+}
+
+void mvo_close(mvo_gym *g) { delete g; }
+
+void mvo_seed(mvo_gym *g, int seed)
+{   // megaverse.cpp:60-69
+    g->rng.seed((unsigned long)seed);
+    for (auto &e : g->envs) {
+        const int noise = randRange(0, 1 << 30, g->rng);
+        e->rng.seed((unsigned long)noise);
+    }
+}
+
+void mvo_reset(mvo_gym *g)
+{   // vector_env.cpp:110-120
+    for (auto &e : g->envs) env_reset(*e);
+    g->render();
+}
+
+int mvo_action_mask(const int *actions, int n)
+{   // megaverse.cpp:100-116
+    static const int spaces[6] = {3, 3, 3, 2, 2, 3};
+    int actionIdx = 0, mask = 0;
+    for (int i = 0; i < n && i < 6; ++i) {
+        if (actions[i] > 0) mask |= 1 << (actionIdx + actions[i]);
+        actionIdx += spaces[i] - 1;
+    }
+    return mask;
+}
+
+void mvo_set_actions(mvo_gym *g, int env, int agent, const int *actions, int n) { g->envs[env]->agents[agent].action = mvo_action_mask(actions, n); }
+void mvo_set_action_mask(mvo_gym *g, int env, int agent, int mask) { g->envs[env]->agents[agent].action = mask; }
+void mvo_step(mvo_gym *g) { g->step(true); }
+void mvo_step_norender(mvo_gym *g) { g->step(false); }
+void mvo_render(mvo_gym *g) { g->render(); }
+int mvo_is_done(mvo_gym *g, int env) { return g->done[env]; }
+
+void mvo_get_last_rewards(mvo_gym *g, float *out)
+{   // megaverse.cpp:128-137 (read after the auto-reset zero-filled them)
+    int k = 0;
+    for (int i = 0; i < g->numEnvs; ++i)
+        for (int a = 0; a < g->numAgents; ++a) out[k++] = g->envs[i]->agents[a].last_reward;
+}
+
+float mvo_true_objective(mvo_gym *g, int env, int agent) { return g->trueObjective[size_t(env) * g->numAgents + agent]; }
+const uint8_t *mvo_get_observation(mvo_gym *g, int env, int agent) { return g->obs.data() + (size_t(env) * g->numAgents + agent) * size_t(g->w) * g->h * 4; }
+
+float mvo_get_reward_shaping(mvo_gym *g, int env, int agent, const char *key, int *found)
+{
+    for (int k = 0; k < 4; ++k)
+        if (!strcmp(key, SHAPING_KEYS[k])) { if (found) *found = 1; return g->envs[env]->agents[agent].shaping[k]; }
+    if (found) *found = 0;
+    return 0.0f;
+}
+void mvo_set_reward_shaping(mvo_gym *g, int env, int agent, const char *key, float v)
+{
+    for (int k = 0; k < 4; ++k)
+        if (!strcmp(key, SHAPING_KEYS[k])) g->envs[env]->agents[agent].shaping[k] = v;
+}
+
+// ---- snapshot (layout: DESIGN.md "snapshot format") ----
+#pragma pack(push, 4)
+struct SnapAgent {
+    float pos[3], basis[4], pitch, hv[2], vvel, voffset, step_offset, jump_speed;
+    int32_t was_jumping, carrying, picked_up, visited_zone, spawn[3];
+    float last_reward, total_reward, shaping[4];
+};
+struct SnapHeader {
+    int32_t L, H, W, bz[4], layout_color, wall_color, draw_walls, num_objects, num_boxes, num_frames, done, highest_tower,
+        num_agents;
+    float episode_sec, episode_len, bz_reward, bar_half_width;
+    int32_t boxes[MAX_BOXES][8];
+    int8_t objects[MAX_OBJECTS][4];
+    SnapAgent agents[MAX_AGENTS];
+    uint8_t chunk[CHUNK];
+};
+#pragma pack(pop)
+
+int mvo_snapshot_size(mvo_gym *) { return (int)sizeof(SnapHeader); }
+
+void mvo_snapshot(mvo_gym *g, int env, void *out)
+{
+    const Env &e = *g->envs[env];
+    auto *s = new SnapHeader();
+    std::memset(s, 0, sizeof *s);
+    s->L = e.L; s->H = e.H; s->W = e.W;
+    for (int i = 0; i < 4; ++i) s->bz[i] = e.bz[i];
+    s->layout_color = (int)e.layoutColor; s->wall_color = (int)e.wallColor; s->draw_walls = e.drawWalls;
+    s->num_objects = e.numObjects; s->num_boxes = e.numBoxes; s->num_frames = e.numFrames; s->done = e.done;
+    s->highest_tower = e.highestTower; s->num_agents = e.numAgents;
+    s->episode_sec = e.episodeSec; s->episode_len = e.episodeLen; s->bz_reward = e.bzReward; s->bar_half_width = e.barHalfWidth;
+    for (int i = 0; i < e.numBoxes; ++i) {
+        const Box &b = e.boxes[i];
+        int32_t *o = s->boxes[i];
+        o[0] = b.min[0]; o[1] = b.min[1]; o[2] = b.min[2]; o[3] = b.max[0]; o[4] = b.max[1]; o[5] = b.max[2]; o[6] = b.type; o[7] = b.slot;
+    }
+    for (int i = 0; i < e.numObjects; ++i) {
+        s->objects[i][0] = (int8_t)e.objects[i].x; s->objects[i][1] = (int8_t)e.objects[i].y;
+        s->objects[i][2] = (int8_t)e.objects[i].z; s->objects[i][3] = (int8_t)e.objects[i].state;
+    }
+    for (int i = 0; i < e.numAgents; ++i) {
+        const Agent &a = e.agents[i];
+        SnapAgent &o = s->agents[i];
+        o.pos[0] = a.pos.x; o.pos[1] = a.pos.y; o.pos[2] = a.pos.z;
+        o.basis[0] = a.m00; o.basis[1] = a.m02; o.basis[2] = a.m20; o.basis[3] = a.m22;
+        o.pitch = a.pitch; o.hv[0] = a.hvx; o.hv[1] = a.hvz; o.vvel = a.vvel; o.voffset = a.voffset;
+        o.step_offset = a.step_offset; o.jump_speed = a.jump_speed; o.was_jumping = a.was_jumping; o.carrying = a.carrying;
+        o.picked_up = a.picked_up; o.visited_zone = a.visited_zone;
+        for (int k = 0; k < 3; ++k) o.spawn[k] = a.spawn[k];
+        o.last_reward = a.last_reward; o.total_reward = a.total_reward;
+        for (int k = 0; k < 4; ++k) o.shaping[k] = a.shaping[k];
+    }
+    std::memcpy(s->chunk, e.chunk.data(), CHUNK);
+    std::memcpy(out, s, sizeof *s);
+    delete s;
+}
+
+// ---- spec helpers ----
+uint32_t mvo_mt19937_nth(uint32_t seed, int n)
+{
+    Rng r(seed);
+    uint32_t v = 0;
+    for (int i = 0; i < n; ++i) v = (uint32_t)r();
+    return v;
+}
+int mvo_rand_range_seq(uint32_t seed, const int *lo, const int *hi, int n, int *out)
+{
+    Rng r(seed);
+    for (int i = 0; i < n; ++i) out[i] = randRange(lo[i], hi[i], r);
+    return 0;
+}
+void mvo_frand_seq(uint32_t seed, int n, float *out)
+{
+    Rng r(seed);
+    for (int i = 0; i < n; ++i) out[i] = frand(r);
+}
+void mvo_shuffle_iota(uint32_t seed, int n, int *out)
+{
+    Rng r(seed);
+    std::vector<int> v(n);
+    for (int i = 0; i < n; ++i) v[i] = i;
+    std::shuffle(v.begin(), v.end(), r);
+    for (int i = 0; i < n; ++i) out[i] = v[i];
+}
+void mvo_get_coords(const float *v, int *out) { voxel_of(v3(v[0], v[1], v[2]), out); }
+float mvo_building_reward_coeff(float h) { return building_reward_coeff(h); }
+void mvo_sincos(float x, float *s, float *c) { mv_sincos(x, s, c); }
+
+}  // extern "C"

@@ -1,0 +1,45 @@
+/*
+ * oracle/ref_util_shim.cpp -- C wrappers around the REFERENCE's own RNG helpers.
+ *
+ * TEST INFRASTRUCTURE.  This file contains no reference code: it #includes
+ * <util/util.hpp> from where it lies under /root/reference/src/libs/util/include
+ * (-I given by oracle/Makefile) and exports randRange / randomBool / frand
+ * (util.hpp:25-56) through a C ABI so tests can pin oracle/ and the HIP RNG
+ * restatement against the real reference functions.  Output goes to oracle/_ref/
+ * (git-ignored, travels to the GPU box with the snapshot).
+ *
+ * Only util.hpp (+ macro.hpp) is buildable this way: every other header on the
+ * hot path pulls in Magnum/Corrade/Bullet, which are not vendored.
+ */
+#include <util/util.hpp>
+
+extern "C" {
+
+void mvref_rand_range_seq(unsigned seed, const int *lo, const int *hi, int n, int *out)
+{
+    Megaverse::Rng rng(seed);
+    for (int i = 0; i < n; ++i) out[i] = Megaverse::randRange(lo[i], hi[i], rng);
+}
+
+void mvref_frand_seq(unsigned seed, int n, float *out)
+{
+    Megaverse::Rng rng(seed);
+    for (int i = 0; i < n; ++i) out[i] = Megaverse::frand(rng);
+}
+
+void mvref_random_bool_seq(unsigned seed, int n, int *out)
+{
+    Megaverse::Rng rng(seed);
+    for (int i = 0; i < n; ++i) out[i] = Megaverse::randomBool(rng) ? 1 : 0;
+}
+
+/* MegaverseGym::seed's per-env seed rule restated with the reference helper:
+ * bindings/megaverse.cpp:64-68 */
+void mvref_env_seeds(int seed, int n, int *out)
+{
+    Megaverse::Rng rng;
+    rng.seed((unsigned long)seed);
+    for (int i = 0; i < n; ++i) out[i] = Megaverse::randRange(0, 1 << 30, rng);
+}
+
+}
