@@ -1,0 +1,113 @@
+/*
+ * include/megaverse_hip.h -- C ABI of libmegaverse_hip.so, the MI355X-native drop-in for the
+ * reference's MegaverseGym hot path.
+ *
+ * Every entry point replaces one method of class MegaverseGym in the reference's pybind11 module
+ * (reference: src/libs/bindings/megaverse.cpp; the Python-visible table is at :267-292).  A
+ * maintainer binds these from the existing pybind shim or via ctypes
+ * (megaverse_amd/extension.py does exactly that).  Plain pointers and sizes only; no torch, no
+ * STL, no exceptions.  Return value: 0 = ok, negative = error (mv_last_error() has the text);
+ * the reference instead logs and calls exit(-1) (src/libs/util/src/tiny_logger.cpp:109-113).
+ *
+ * Threading: like the reference every call is made from one host thread per gym.
+ * All device work is enqueued on one HIP stream (mv_set_stream; default: the null stream);
+ * mv_step() returns without synchronising, host getters synchronise that stream.
+ */
+#ifndef MEGAVERSE_HIP_H
+#define MEGAVERSE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mv_gym mv_gym;
+
+typedef struct mv_config {
+    const char *scenario;          /* case-insensitive registered name (scenarios/init.hpp:26-57); "TowerBuilding" */
+    int32_t obs_width, obs_height; /* megaverse.cpp:38 w, h */
+    int32_t num_envs;              /* envs simulated by THIS process (one process per GPU) */
+    int32_t num_agents_per_env;
+    int32_t num_simulation_threads;/* accepted for signature parity; the GPU path has no thread pool */
+    int32_t use_vulkan;            /* accepted for signature parity; ignored */
+    int32_t device;                /* HIP device ordinal */
+    const char *const *param_keys; /* FloatParams (megaverse.cpp:45, scenario.hpp:225-242) */
+    const float *param_vals;
+    int32_t num_params;
+    /* env sharding across GPUs: this process owns global envs [env_offset, env_offset+num_envs)
+     * of total_envs; mv_seed() draws the per-env seeds for the whole job so that a sharded run is
+     * bit-identical to the single-process run.  0 / 0 = not sharded. */
+    int32_t env_offset, total_envs;
+} mv_config;
+
+const char *mv_last_error(void);
+
+/* MegaverseGym::MegaverseGym (megaverse.cpp:38-58) / close (:227-243).  mv_close is idempotent
+ * and valid before the first reset (megaverse/tests/test_env.py:28-30). */
+int mv_create(const mv_config *cfg, mv_gym **out);
+int mv_close(mv_gym *g);
+int mv_destroy(mv_gym *g); /* mv_close + free the handle */
+
+int mv_num_agents(const mv_gym *g);                 /* numAgents(), megaverse.cpp:71-74 */
+int mv_action_space_sizes(int32_t *out6);           /* actionSpaceSizes(), :95-98 -> {3,3,3,2,2,3} */
+int mv_seed(mv_gym *g, int32_t seed);               /* seed(), :60-69 */
+int mv_reset(mv_gym *g);                            /* reset(), :76-93 (+ first render) */
+
+/* setActions(), :100-116: multi-discrete -> Action bitmask for one agent (host staging) */
+int mv_set_actions(mv_gym *g, int32_t env_idx, int32_t agent_idx, const int32_t *actions, int32_t n);
+/* batched forms the reference lacks (SURVEY.md 3.2 hot loop iii): [N*A][6] multi-discrete */
+int mv_set_actions_batched(mv_gym *g, const int32_t *host_actions);
+int mv_set_actions_device(mv_gym *g, const int32_t *device_actions);
+/* benchmark policy: i.i.d. uniform per head, counter-based (seed, step, agent, head) -> action;
+ * same stream as megaverse_amd.rollout.sample_actions() on the host */
+int mv_sample_random_actions(mv_gym *g, uint32_t seed, uint32_t step_index);
+
+int mv_step(mv_gym *g);                             /* step(), :118-121: VectorEnv::step incl. auto-reset + render */
+int mv_step_no_render(mv_gym *g);                   /* physics/logic/auto-reset only */
+int mv_render(mv_gym *g);                           /* observation pass only */
+
+int mv_is_done(mv_gym *g, int32_t env_idx);         /* isDone(), :123-126 -> 0/1, <0 on error */
+int mv_get_dones(mv_gym *g, uint8_t *out);          /* [N] */
+int mv_get_last_rewards(mv_gym *g, float *out);     /* getLastRewards(), :128-137 -> [N*A] env-major */
+int mv_true_objective(mv_gym *g, int32_t env_idx, int32_t agent_idx, float *out); /* :203-206 */
+int mv_get_true_objectives(mv_gym *g, float *out);  /* [N*A] */
+
+/* getObservation(), :139-143: (h, w, 4) uint8, rows bottom-up like glReadPixels.  The reference
+ * returns a view of host memory; here the frame lives in HBM: copy one frame out ... */
+int mv_get_observation(mv_gym *g, int32_t env_idx, int32_t agent_idx, uint8_t *out_host);
+/* ... or take the device slab [N*A][h][w][4] (valid until mv_close; rewritten by every step) */
+void *mv_obs_device_ptr(mv_gym *g);
+void *mv_rewards_device_ptr(mv_gym *g);             /* float [N*A] */
+void *mv_dones_device_ptr(mv_gym *g);               /* uint8 [N] */
+void *mv_true_objectives_device_ptr(mv_gym *g);     /* float [N*A] */
+/* let the caller own the observation slab (e.g. a torch tensor / an RCCL gather buffer) */
+int mv_set_obs_buffer(mv_gym *g, void *device_ptr);
+int mv_set_stream(mv_gym *g, void *hip_stream);
+
+/* setRenderResolution/drawHires/getHiresObservation (:145-178,203-207); drawOverview is a no-op
+ * exactly like a reference build without WITH_GUI (:180-201) */
+int mv_set_render_resolution(mv_gym *g, int32_t w, int32_t h);
+int mv_draw_hires(mv_gym *g);
+int mv_get_hires_observation(mv_gym *g, int32_t env_idx, int32_t agent_idx, uint8_t *out_host);
+int mv_draw_overview(mv_gym *g);
+
+/* getRewardShaping/setRewardShaping (:208-217); one key at a time across the C boundary */
+int mv_num_reward_shaping_keys(const mv_gym *g);
+const char *mv_reward_shaping_key(const mv_gym *g, int32_t i);
+int mv_get_reward_shaping(mv_gym *g, int32_t env_idx, int32_t agent_idx, const char *key, float *out);
+int mv_set_reward_shaping(mv_gym *g, int32_t env_idx, int32_t agent_idx, const char *key, float value);
+
+int mv_synchronize(mv_gym *g);
+
+/* test hooks: packed state snapshot of one env (layout in DESIGN.md, same bytes as the oracle's
+ * mvo_snapshot) and the raw device RNG streams */
+int mv_debug_snapshot_size(const mv_gym *g);
+int mv_debug_snapshot(mv_gym *g, int32_t env_idx, void *out_host);
+int mv_debug_rng(int32_t device, uint32_t seed, int32_t what, const int32_t *lo, const int32_t *hi, int32_t n, void *out_host);
+int mv_debug_math(int32_t device, int32_t what, const float *a, const float *b, int32_t n, float *out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

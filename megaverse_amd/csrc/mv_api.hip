@@ -1,0 +1,662 @@
+// megaverse_amd/csrc/mv_api.hip -- host side of libmegaverse_hip.so: the C ABI declared in
+// include/megaverse_hip.h, HBM allocation, kernel sequencing on one HIP stream.
+//
+// Mirrors class MegaverseGym of the reference (src/libs/bindings/megaverse.cpp:34-262) method by
+// method; the per-step control flow mirrors VectorEnv::step (src/libs/env/src/vector_env.cpp:89-108):
+//   step all envs  ->  for done envs: record trueObjective, reset  ->  draw.
+// There is NO CPU fallback: if no HIP device can be opened mv_create fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cctype>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../include/megaverse_hip.h"
+#include "mv_math.h"
+#include "mv_rng.h"
+#include "mv_types.h"
+
+namespace mv {
+void launch_reset(const GymView &gv, int force_all, hipStream_t stream);
+void launch_step(const GymView &gv, hipStream_t stream);
+void launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream);
+}  // namespace mv
+
+using namespace mv;
+
+static thread_local std::string g_err;
+static int fail(const std::string &msg)
+{
+    g_err = msg;
+    return -1;
+}
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+static const char *SHAPING_KEYS[NUM_SHAPING] = {"teamSpirit", "towerPickedUpObject", "towerVisitedBuildingZoneWithObject",
+                                                "towerBuildingReward"};
+static const float SHAPING_DEFAULT[NUM_SHAPING] = {0.1f, 0.1f, 0.1f, 1.0f};   // scenario_tower_building.hpp:44-52
+static const int ACTION_SPACE[6] = {3, 3, 3, 2, 2, 3};                          // env.cpp:33
+
+struct mv_gym {
+    int device = 0;
+    int w = 0, h = 0, renderW = 768, renderH = 432;   // megaverse.cpp:261
+    int N = 0, A = 0, envOffset = 0, totalEnvs = 0;
+    bool closed = false, wasReset = false;
+    hipStream_t stream = nullptr;
+    GymView gv{};
+    uint32_t *obs = nullptr, *ownedObs = nullptr, *hiresObs = nullptr;
+    int hiresW = 0, hiresH = 0;
+    // host mirrors
+    int32_t *hActions[2] = {nullptr, nullptr};   // pinned staging, double buffered
+    hipEvent_t actionsCopied[2] = {nullptr, nullptr};
+    int stage = 0;
+    bool actionsDirty = false;
+    int32_t *dMultiDiscrete = nullptr;           // [N*A*6] scratch for batched host actions
+    std::vector<float> hRewards, hTrueObj;
+    std::vector<uint8_t> hDone;
+    bool mirrorsFresh = false;
+    std::mt19937 rng{std::random_device{}()};    // megaverse.cpp:253
+};
+
+// ------------------------------------------------------------------------------------------------
+// small utility kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void set_seeds_kernel(EnvHeader *hdr, const uint32_t *seeds, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { hdr[i].next_seed = seeds[i]; hdr[i].seed_is_env_seed = 1; }
+}
+
+__device__ __forceinline__ int action_mask_of(const int32_t *a)
+{   // MegaverseGym::setActions, megaverse.cpp:100-116
+    int idx = 0, mask = 0;
+    const int sizes[6] = {3, 3, 3, 2, 2, 3};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        if (a[i] > 0) mask |= 1 << (idx + a[i]);
+        idx += sizes[i] - 1;
+    }
+    return mask;
+}
+
+__global__ void masks_from_multidiscrete_kernel(const int32_t *md, int32_t *masks, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) masks[i] = action_mask_of(md + (size_t)i * 6);
+}
+
+__device__ __forceinline__ uint32_t fmix32(uint32_t h)
+{
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+
+__global__ void sample_actions_kernel(int32_t *masks, int n, uint32_t seed, uint32_t step, uint32_t agentOffset)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t base = fmix32(fmix32(seed ^ fmix32(step + 0x9E3779B9u)) ^ ((agentOffset + (uint32_t)i) * 0x85EBCA6Bu + 1u));
+    const int sizes[6] = {3, 3, 3, 2, 2, 3};
+    int32_t a[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const uint32_t hsh = fmix32(base + (uint32_t)k * 0xC2B2AE35u);
+        a[k] = (int32_t)(((uint64_t)hsh * (uint64_t)sizes[k]) >> 32);
+    }
+    masks[i] = action_mask_of(a);
+}
+
+__global__ void set_shaping_kernel(AgentState *agents, int idx, int key, float v) { agents[idx].shaping[key] = v; }
+
+__global__ void debug_rng_kernel(uint32_t seed, int what, const int32_t *lo, const int32_t *hi, int n, void *out)
+{
+    __shared__ uint32_t s_mt[624];
+    __shared__ uint16_t s_items[4096];
+    Mt19937 g{s_mt, 624};
+    mt_seed(g, seed);
+    const int lane = threadIdx.x & 63;
+    if (what == 0) {
+        for (int i = 0; i < n; ++i) { const uint32_t v = mt_next(g); if (lane == 0) ((uint32_t *)out)[i] = v; }
+    } else if (what == 1) {
+        for (int i = 0; i < n; ++i) { const int v = rand_range(g, lo[i], hi[i]); if (lane == 0) ((int32_t *)out)[i] = v; }
+    } else if (what == 2) {
+        for (int i = 0; i < n; ++i) { const float v = frand(g); if (lane == 0) ((float *)out)[i] = v; }
+    } else if (what == 3) {
+        for (int i = lane; i < n; i += 64) s_items[i] = (uint16_t)i;
+        __syncthreads();
+        shuffle_u16(g, s_items, n);
+        for (int i = lane; i < n; i += 64) ((int32_t *)out)[i] = s_items[i];
+    }
+}
+
+__global__ void debug_math_kernel(int what, const float *a, const float *b, int n, float *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (what == 0) out[i] = a[i] / b[i];
+    else if (what == 1) out[i] = sqrtf(a[i]);
+    else if (what == 2) { float s, c; sincos_poly(a[i], s, c); out[2 * i] = s; out[2 * i + 1] = c; }
+    else if (what == 3) out[i] = a[i] * b[i] + a[i];   // must NOT be contracted into an fma
+    else if (what == 4) out[i] = floorf(a[i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+static std::string lower(const char *s)
+{
+    std::string r(s ? s : "");
+    for (auto &c : r) c = (char)std::tolower((unsigned char)c);
+    return r;
+}
+
+static int check(mv_gym *g)
+{
+    if (!g) return fail("null gym handle");
+    if (g->closed) return fail("gym is closed");
+    return 0;
+}
+
+static int refresh_mirrors(mv_gym *g)
+{
+    if (g->mirrorsFresh) return 0;
+    const size_t NA = (size_t)g->N * g->A;
+    HIP_TRY(hipMemcpyAsync(g->hRewards.data(), g->gv.rewards, NA * sizeof(float), hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipMemcpyAsync(g->hTrueObj.data(), g->gv.true_objective, NA * sizeof(float), hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipMemcpyAsync(g->hDone.data(), g->gv.done, (size_t)g->N, hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    g->mirrorsFresh = true;
+    return 0;
+}
+
+extern "C" {
+
+const char *mv_last_error(void) { return g_err.c_str(); }
+
+int mv_action_space_sizes(int32_t *out6)
+{
+    for (int i = 0; i < 6; ++i) out6[i] = ACTION_SPACE[i];
+    return 0;
+}
+
+int mv_create(const mv_config *cfg, mv_gym **out)
+{
+    if (!cfg || !out) return fail("mv_create: null argument");
+    *out = nullptr;
+    // Scenario::create (scenario.hpp:61-77) is fatal on unknown names; we return an error instead
+    if (lower(cfg->scenario) != "towerbuilding")
+        return fail("Unknown scenario " + lower(cfg->scenario) + " (this build accelerates: towerbuilding)");
+    if (cfg->num_envs < 1 || cfg->num_agents_per_env < 1 || cfg->num_agents_per_env > MAX_AGENTS)
+        return fail("mv_create: num_envs >= 1 and 1 <= num_agents_per_env <= 8 required");
+    if (cfg->obs_width < 1 || cfg->obs_height < 1) return fail("mv_create: bad observation size");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail("mv_create: no HIP device available (this library has no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail("mv_create: bad device ordinal");
+    HIP_TRY(hipSetDevice(cfg->device));
+
+    mv_gym *g = new mv_gym();
+    g->device = cfg->device;
+    g->w = cfg->obs_width; g->h = cfg->obs_height;
+    g->N = cfg->num_envs; g->A = cfg->num_agents_per_env;
+    g->envOffset = cfg->total_envs > 0 ? cfg->env_offset : 0;
+    g->totalEnvs = cfg->total_envs > 0 ? cfg->total_envs : cfg->num_envs;
+    const size_t N = g->N, NA = (size_t)g->N * g->A;
+
+    GymView &gv = g->gv;
+    gv.num_envs = g->N; gv.num_agents = g->A;
+#define ALLOC(ptr, bytes)                                                          \
+    do {                                                                           \
+        hipError_t e_ = hipMalloc((void **)&(ptr), (bytes));                       \
+        if (e_ != hipSuccess) { mv_destroy(g); return fail(std::string("hipMalloc ") + #ptr + ": " + hipGetErrorString(e_)); } \
+        (void)hipMemset((ptr), 0, (bytes));                                        \
+    } while (0)
+    ALLOC(gv.hdr, N * sizeof(EnvHeader));
+    ALLOC(gv.boxes, N * MAX_BOXES * sizeof(LayoutBox));
+    ALLOC(gv.objects, N * MAX_OBJECTS * sizeof(MovableObject));
+    ALLOC(gv.agents, NA * sizeof(AgentState));
+    ALLOC(gv.chunk, N * (size_t)CHUNK_BYTES);
+    ALLOC(gv.actions, NA * sizeof(int32_t));
+    ALLOC(gv.rewards, NA * sizeof(float));
+    ALLOC(gv.done, N);
+    ALLOC(gv.true_objective, NA * sizeof(float));
+    ALLOC(g->ownedObs, NA * (size_t)g->w * g->h * 4);
+    ALLOC(g->dMultiDiscrete, NA * 6 * sizeof(int32_t));
+#undef ALLOC
+    g->obs = g->ownedObs;
+    for (int b = 0; b < 2; ++b) {
+        if (hipHostMalloc((void **)&g->hActions[b], NA * sizeof(int32_t), hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&g->actionsCopied[b], hipEventDisableTiming) != hipSuccess) {
+            mv_destroy(g);
+            return fail("mv_create: pinned staging allocation failed");
+        }
+        std::memset(g->hActions[b], 0, NA * sizeof(int32_t));
+    }
+    g->hRewards.assign(NA, 0.0f); g->hTrueObj.assign(NA, 0.0f); g->hDone.assign(N, 0);
+
+    // headers: float params + unseeded envs take their seed from random_device (env.hpp:169)
+    float episodeLen = 60.0f, lookLimit = 0.2f;   // scenario.hpp:225-232
+    for (int k = 0; k < cfg->num_params; ++k) {
+        if (!std::strcmp(cfg->param_keys[k], "episodeLengthSec")) episodeLen = cfg->param_vals[k];
+        if (!std::strcmp(cfg->param_keys[k], "verticalLookLimitRad")) lookLimit = cfg->param_vals[k];
+    }
+    std::vector<EnvHeader> hh(N);
+    std::random_device rd;
+    for (size_t i = 0; i < N; ++i) {
+        std::memset(&hh[i], 0, sizeof(EnvHeader));
+        hh[i].p_episode_len_sec = episodeLen; hh[i].p_vertical_look_limit = lookLimit;
+        hh[i].next_seed = (uint32_t)rd(); hh[i].seed_is_env_seed = 1;
+        hh[i].bar_half_width = 0.24f;
+    }
+    std::vector<AgentState> ha(NA);
+    for (size_t i = 0; i < NA; ++i) {
+        std::memset(&ha[i], 0, sizeof(AgentState));
+        for (int k = 0; k < NUM_SHAPING; ++k) ha[i].shaping[k] = SHAPING_DEFAULT[k];
+        ha[i].carrying = -1; ha[i].jump_speed = 10.0f; ha[i].m00 = 1.0f; ha[i].m22 = 1.0f;
+    }
+    if (hipMemcpy(gv.hdr, hh.data(), N * sizeof(EnvHeader), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(gv.agents, ha.data(), NA * sizeof(AgentState), hipMemcpyHostToDevice) != hipSuccess) {
+        mv_destroy(g);
+        return fail("mv_create: initial upload failed");
+    }
+    *out = g;
+    return 0;
+}
+
+int mv_close(mv_gym *g)
+{
+    if (!g || g->closed) return 0;
+    (void)hipSetDevice(g->device);
+    (void)hipStreamSynchronize(g->stream);
+    GymView &gv = g->gv;
+    void *ptrs[] = {gv.hdr, gv.boxes, gv.objects, gv.agents, gv.chunk, gv.actions, gv.rewards, gv.done, gv.true_objective,
+                    g->ownedObs, g->hiresObs, g->dMultiDiscrete};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    for (int b = 0; b < 2; ++b) {
+        if (g->hActions[b]) (void)hipHostFree(g->hActions[b]);
+        if (g->actionsCopied[b]) (void)hipEventDestroy(g->actionsCopied[b]);
+        g->hActions[b] = nullptr; g->actionsCopied[b] = nullptr;
+    }
+    gv = GymView{};
+    g->ownedObs = g->hiresObs = g->obs = nullptr; g->dMultiDiscrete = nullptr;
+    g->closed = true;
+    return 0;
+}
+
+int mv_destroy(mv_gym *g)
+{
+    if (!g) return 0;
+    mv_close(g);
+    delete g;
+    return 0;
+}
+
+int mv_num_agents(const mv_gym *g) { return g ? g->A : -1; }
+
+int mv_set_stream(mv_gym *g, void *s)
+{
+    if (check(g)) return -1;
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    g->stream = (hipStream_t)s;
+    return 0;
+}
+
+int mv_set_obs_buffer(mv_gym *g, void *p)
+{
+    if (check(g)) return -1;
+    g->obs = p ? (uint32_t *)p : g->ownedObs;
+    return 0;
+}
+
+int mv_seed(mv_gym *g, int32_t seed)
+{   // MegaverseGym::seed, megaverse.cpp:60-69: master rng -> one randRange(0, 1<<30) per env
+    if (check(g)) return -1;
+    HIP_TRY(hipSetDevice(g->device));
+    g->rng.seed((unsigned long)seed);
+    std::vector<uint32_t> seeds(g->N);
+    for (int i = 0; i < g->totalEnvs; ++i) {
+        const int noise = std::uniform_int_distribution<>{0, (1 << 30) - 1}(g->rng);
+        if (i >= g->envOffset && i < g->envOffset + g->N) seeds[i - g->envOffset] = (uint32_t)noise;
+    }
+    uint32_t *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, g->N * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpyAsync(d, seeds.data(), g->N * sizeof(uint32_t), hipMemcpyHostToDevice, g->stream));
+    hipLaunchKernelGGL(set_seeds_kernel, dim3((g->N + 255) / 256), dim3(256), 0, g->stream, g->gv.hdr, d, g->N);
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    HIP_TRY(hipFree(d));
+    return 0;
+}
+
+int mv_render(mv_gym *g)
+{
+    if (check(g)) return -1;
+    HIP_TRY(hipSetDevice(g->device));
+    launch_raster(g->gv, g->obs, g->w, g->h, g->stream);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int mv_reset(mv_gym *g)
+{   // MegaverseGym::reset (megaverse.cpp:76-93) -> VectorEnv::reset (vector_env.cpp:110-120)
+    if (check(g)) return -1;
+    HIP_TRY(hipSetDevice(g->device));
+    launch_reset(g->gv, 1, g->stream);
+    HIP_TRY(hipGetLastError());
+    g->wasReset = true;
+    g->mirrorsFresh = false;
+    return mv_render(g);
+}
+
+int mv_set_actions(mv_gym *g, int32_t env, int32_t agent, const int32_t *actions, int32_t n)
+{
+    if (check(g)) return -1;
+    if (env < 0 || env >= g->N || agent < 0 || agent >= g->A) return fail("mv_set_actions: index out of range");
+    int idx = 0, mask = 0;
+    for (int i = 0; i < n && i < 6; ++i) {
+        if (actions[i] > 0) mask |= 1 << (idx + actions[i]);
+        idx += ACTION_SPACE[i] - 1;
+    }
+    g->hActions[g->stage][(size_t)env * g->A + agent] = mask;
+    g->actionsDirty = true;
+    return 0;
+}
+
+int mv_set_actions_batched(mv_gym *g, const int32_t *host_actions)
+{
+    if (check(g)) return -1;
+    HIP_TRY(hipSetDevice(g->device));
+    const int n = g->N * g->A;
+    HIP_TRY(hipMemcpyAsync(g->dMultiDiscrete, host_actions, (size_t)n * 6 * sizeof(int32_t), hipMemcpyHostToDevice, g->stream));
+    hipLaunchKernelGGL(masks_from_multidiscrete_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, g->dMultiDiscrete, g->gv.actions, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(g->stream));   // host_actions may be pageable and reused by the caller
+    return 0;
+}
+
+int mv_set_actions_device(mv_gym *g, const int32_t *device_actions)
+{
+    if (check(g)) return -1;
+    HIP_TRY(hipSetDevice(g->device));
+    const int n = g->N * g->A;
+    hipLaunchKernelGGL(masks_from_multidiscrete_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, device_actions, g->gv.actions, n);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int mv_sample_random_actions(mv_gym *g, uint32_t seed, uint32_t step)
+{
+    if (check(g)) return -1;
+    HIP_TRY(hipSetDevice(g->device));
+    const int n = g->N * g->A;
+    hipLaunchKernelGGL(sample_actions_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, g->gv.actions, n, seed, step,
+                       (uint32_t)(g->envOffset * g->A));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int step_impl(mv_gym *g, bool render)
+{
+    if (check(g)) return -1;
+    if (!g->wasReset) return fail("mv_step: call mv_reset first");
+    HIP_TRY(hipSetDevice(g->device));
+    if (g->actionsDirty) {
+        const int s = g->stage;
+        HIP_TRY(hipMemcpyAsync(g->gv.actions, g->hActions[s], (size_t)g->N * g->A * sizeof(int32_t), hipMemcpyHostToDevice, g->stream));
+        HIP_TRY(hipEventRecord(g->actionsCopied[s], g->stream));
+        g->stage = 1 - s;
+        HIP_TRY(hipEventSynchronize(g->actionsCopied[g->stage]));   // long done: recorded one step ago
+        std::memset(g->hActions[g->stage], 0, (size_t)g->N * g->A * sizeof(int32_t));   // actions are cleared every tick (env.cpp:141-142)
+        g->actionsDirty = false;
+    }
+    launch_step(g->gv, g->stream);
+    launch_reset(g->gv, 0, g->stream);
+    if (render) launch_raster(g->gv, g->obs, g->w, g->h, g->stream);
+    HIP_TRY(hipGetLastError());
+    g->mirrorsFresh = false;
+    return 0;
+}
+
+int mv_step(mv_gym *g) { return step_impl(g, true); }
+int mv_step_no_render(mv_gym *g) { return step_impl(g, false); }
+
+int mv_synchronize(mv_gym *g)
+{
+    if (check(g)) return -1;
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    return 0;
+}
+
+int mv_is_done(mv_gym *g, int32_t env)
+{
+    if (check(g)) return -1;
+    if (env < 0 || env >= g->N) return fail("mv_is_done: index out of range");
+    if (refresh_mirrors(g)) return -1;
+    return g->hDone[env] ? 1 : 0;
+}
+
+int mv_get_dones(mv_gym *g, uint8_t *out)
+{
+    if (check(g) || refresh_mirrors(g)) return -1;
+    std::memcpy(out, g->hDone.data(), g->N);
+    return 0;
+}
+
+int mv_get_last_rewards(mv_gym *g, float *out)
+{
+    if (check(g) || refresh_mirrors(g)) return -1;
+    std::memcpy(out, g->hRewards.data(), (size_t)g->N * g->A * sizeof(float));
+    return 0;
+}
+
+int mv_true_objective(mv_gym *g, int32_t env, int32_t agent, float *out)
+{
+    if (check(g)) return -1;
+    if (env < 0 || env >= g->N || agent < 0 || agent >= g->A) return fail("mv_true_objective: index out of range");
+    if (refresh_mirrors(g)) return -1;
+    *out = g->hTrueObj[(size_t)env * g->A + agent];
+    return 0;
+}
+
+int mv_get_true_objectives(mv_gym *g, float *out)
+{
+    if (check(g) || refresh_mirrors(g)) return -1;
+    std::memcpy(out, g->hTrueObj.data(), (size_t)g->N * g->A * sizeof(float));
+    return 0;
+}
+
+int mv_get_observation(mv_gym *g, int32_t env, int32_t agent, uint8_t *out)
+{
+    if (check(g)) return -1;
+    if (env < 0 || env >= g->N || agent < 0 || agent >= g->A) return fail("mv_get_observation: index out of range");
+    const size_t frameBytes = (size_t)g->w * g->h * 4;
+    HIP_TRY(hipMemcpyAsync(out, (const uint8_t *)g->obs + ((size_t)env * g->A + agent) * frameBytes, frameBytes, hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    return 0;
+}
+
+void *mv_obs_device_ptr(mv_gym *g) { return (g && !g->closed) ? g->obs : nullptr; }
+void *mv_rewards_device_ptr(mv_gym *g) { return (g && !g->closed) ? g->gv.rewards : nullptr; }
+void *mv_dones_device_ptr(mv_gym *g) { return (g && !g->closed) ? g->gv.done : nullptr; }
+void *mv_true_objectives_device_ptr(mv_gym *g) { return (g && !g->closed) ? g->gv.true_objective : nullptr; }
+
+int mv_set_render_resolution(mv_gym *g, int32_t w, int32_t h)
+{
+    if (check(g)) return -1;
+    if (w < 1 || h < 1) return fail("mv_set_render_resolution: bad size");
+    g->renderW = w; g->renderH = h;
+    return 0;
+}
+
+int mv_draw_hires(mv_gym *g)
+{   // MegaverseGym::drawHires, megaverse.cpp:154-178: a second renderer at renderW x renderH
+    if (check(g)) return -1;
+    HIP_TRY(hipSetDevice(g->device));
+    if (!g->hiresObs || g->hiresW != g->renderW || g->hiresH != g->renderH) {
+        if (g->hiresObs) { HIP_TRY(hipStreamSynchronize(g->stream)); HIP_TRY(hipFree(g->hiresObs)); g->hiresObs = nullptr; }
+        HIP_TRY(hipMalloc((void **)&g->hiresObs, (size_t)g->N * g->A * g->renderW * g->renderH * 4));
+        g->hiresW = g->renderW; g->hiresH = g->renderH;
+    }
+    launch_raster(g->gv, g->hiresObs, g->hiresW, g->hiresH, g->stream);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int mv_get_hires_observation(mv_gym *g, int32_t env, int32_t agent, uint8_t *out)
+{
+    if (check(g)) return -1;
+    if (!g->hiresObs) return fail("mv_get_hires_observation: call mv_draw_hires first");
+    if (env < 0 || env >= g->N || agent < 0 || agent >= g->A) return fail("mv_get_hires_observation: index out of range");
+    const size_t frameBytes = (size_t)g->hiresW * g->hiresH * 4;
+    HIP_TRY(hipMemcpyAsync(out, (const uint8_t *)g->hiresObs + ((size_t)env * g->A + agent) * frameBytes, frameBytes, hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    return 0;
+}
+
+int mv_draw_overview(mv_gym *g) { return check(g) ? -1 : 0; }
+
+int mv_num_reward_shaping_keys(const mv_gym *) { return NUM_SHAPING; }
+const char *mv_reward_shaping_key(const mv_gym *, int32_t i) { return (i >= 0 && i < NUM_SHAPING) ? SHAPING_KEYS[i] : nullptr; }
+
+static int shaping_index(const char *key)
+{
+    for (int k = 0; k < NUM_SHAPING; ++k)
+        if (!std::strcmp(key, SHAPING_KEYS[k])) return k;
+    return -1;
+}
+
+int mv_get_reward_shaping(mv_gym *g, int32_t env, int32_t agent, const char *key, float *out)
+{
+    if (check(g)) return -1;
+    const int k = shaping_index(key);
+    if (k < 0) return fail(std::string("unknown reward shaping key ") + key);
+    if (env < 0 || env >= g->N || agent < 0 || agent >= g->A) return fail("mv_get_reward_shaping: index out of range");
+    HIP_TRY(hipMemcpyAsync(out, &g->gv.agents[(size_t)env * g->A + agent].shaping[k], sizeof(float), hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    return 0;
+}
+
+int mv_set_reward_shaping(mv_gym *g, int32_t env, int32_t agent, const char *key, float v)
+{
+    if (check(g)) return -1;
+    const int k = shaping_index(key);
+    if (k < 0) return fail(std::string("unknown reward shaping key ") + key);
+    if (env < 0 || env >= g->N || agent < 0 || agent >= g->A) return fail("mv_set_reward_shaping: index out of range");
+    hipLaunchKernelGGL(set_shaping_kernel, dim3(1), dim3(1), 0, g->stream, g->gv.agents, env * g->A + agent, k, v);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- test hooks ---------------------------------------------------------------------------------
+#pragma pack(push, 4)
+struct SnapAgent {
+    float pos[3], basis[4], pitch, hv[2], vvel, voffset, step_offset, jump_speed;
+    int32_t was_jumping, carrying, picked_up, visited_zone, spawn[3];
+    float last_reward, total_reward, shaping[4];
+};
+struct Snap {
+    int32_t L, H, W, bz[4], layout_color, wall_color, draw_walls, num_objects, num_boxes, num_frames, done, highest_tower,
+        num_agents;
+    float episode_sec, episode_len, bz_reward, bar_half_width;
+    int32_t boxes[MAX_BOXES][8];
+    int8_t objects[MAX_OBJECTS][4];
+    SnapAgent agents[MAX_AGENTS];
+    uint8_t chunk[CHUNK_BYTES];
+};
+#pragma pack(pop)
+
+int mv_debug_snapshot_size(const mv_gym *) { return (int)sizeof(Snap); }
+
+int mv_debug_snapshot(mv_gym *g, int32_t env, void *out)
+{
+    if (check(g)) return -1;
+    if (env < 0 || env >= g->N) return fail("mv_debug_snapshot: index out of range");
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    EnvHeader h;
+    std::vector<LayoutBox> boxes(MAX_BOXES);
+    std::vector<MovableObject> objs(MAX_OBJECTS);
+    std::vector<AgentState> ag(g->A);
+    Snap *s = new Snap();
+    std::memset(s, 0, sizeof *s);
+    hipError_t e = hipMemcpy(&h, g->gv.hdr + env, sizeof h, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(boxes.data(), g->gv.boxes + (size_t)env * MAX_BOXES, MAX_BOXES * sizeof(LayoutBox), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(objs.data(), g->gv.objects + (size_t)env * MAX_OBJECTS, MAX_OBJECTS * sizeof(MovableObject), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(ag.data(), g->gv.agents + (size_t)env * g->A, g->A * sizeof(AgentState), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(s->chunk, g->gv.chunk + (size_t)env * CHUNK_BYTES, CHUNK_BYTES, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { delete s; return fail(std::string("mv_debug_snapshot: ") + hipGetErrorString(e)); }
+    s->L = h.L; s->H = h.H; s->W = h.W;
+    for (int i = 0; i < 4; ++i) s->bz[i] = h.bz[i];
+    s->layout_color = h.layout_color; s->wall_color = h.wall_color; s->draw_walls = h.draw_walls;
+    s->num_objects = h.num_objects; s->num_boxes = h.num_boxes; s->num_frames = h.num_frames; s->done = h.done;
+    s->highest_tower = h.highest_tower; s->num_agents = g->A;
+    s->episode_sec = h.episode_sec; s->episode_len = h.episode_len; s->bz_reward = h.bz_reward; s->bar_half_width = h.bar_half_width;
+    for (int i = 0; i < h.num_boxes && i < MAX_BOXES; ++i) {
+        const LayoutBox &b = boxes[i];
+        int32_t *o = s->boxes[i];
+        o[0] = b.min[0]; o[1] = b.min[1]; o[2] = b.min[2]; o[3] = b.max[0]; o[4] = b.max[1]; o[5] = b.max[2]; o[6] = b.type; o[7] = b.slot;
+    }
+    for (int i = 0; i < h.num_objects && i < MAX_OBJECTS; ++i) {
+        s->objects[i][0] = objs[i].x; s->objects[i][1] = objs[i].y; s->objects[i][2] = objs[i].z; s->objects[i][3] = objs[i].state;
+    }
+    for (int i = 0; i < g->A; ++i) {
+        const AgentState &a = ag[i];
+        SnapAgent &o = s->agents[i];
+        o.pos[0] = a.pos[0]; o.pos[1] = a.pos[1]; o.pos[2] = a.pos[2];
+        o.basis[0] = a.m00; o.basis[1] = a.m02; o.basis[2] = a.m20; o.basis[3] = a.m22;
+        o.pitch = a.pitch; o.hv[0] = a.hvx; o.hv[1] = a.hvz; o.vvel = a.vvel; o.voffset = a.voffset;
+        o.step_offset = a.step_offset; o.jump_speed = a.jump_speed; o.was_jumping = a.was_jumping; o.carrying = a.carrying;
+        o.picked_up = a.picked_up; o.visited_zone = a.visited_zone;
+        for (int k = 0; k < 3; ++k) o.spawn[k] = a.spawn[k];
+        o.last_reward = a.last_reward; o.total_reward = a.total_reward;
+        for (int k = 0; k < 4; ++k) o.shaping[k] = a.shaping[k];
+    }
+    std::memcpy(out, s, sizeof *s);
+    delete s;
+    return 0;
+}
+
+int mv_debug_rng(int32_t device, uint32_t seed, int32_t what, const int32_t *lo, const int32_t *hi, int32_t n, void *out)
+{
+    HIP_TRY(hipSetDevice(device));
+    if (what == 3 && n > 4096) return fail("mv_debug_rng: shuffle n <= 4096");
+    int32_t *dlo = nullptr, *dhi = nullptr;
+    void *dout = nullptr;
+    HIP_TRY(hipMalloc(&dout, (size_t)n * 4));
+    if (what == 1) {
+        HIP_TRY(hipMalloc((void **)&dlo, (size_t)n * 4));
+        HIP_TRY(hipMalloc((void **)&dhi, (size_t)n * 4));
+        HIP_TRY(hipMemcpy(dlo, lo, (size_t)n * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dhi, hi, (size_t)n * 4, hipMemcpyHostToDevice));
+    }
+    hipLaunchKernelGGL(debug_rng_kernel, dim3(1), dim3(64), 0, nullptr, seed, what, dlo, dhi, n, dout);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(dout); (void)hipFree(dlo); (void)hipFree(dhi);
+    return 0;
+}
+
+int mv_debug_math(int32_t device, int32_t what, const float *a, const float *b, int32_t n, float *out)
+{
+    HIP_TRY(hipSetDevice(device));
+    float *da = nullptr, *db = nullptr, *dout = nullptr;
+    const size_t outN = (what == 2) ? 2 * (size_t)n : (size_t)n;
+    HIP_TRY(hipMalloc((void **)&da, (size_t)n * 4));
+    HIP_TRY(hipMalloc((void **)&db, (size_t)n * 4));
+    HIP_TRY(hipMalloc((void **)&dout, outN * 4));
+    HIP_TRY(hipMemcpy(da, a, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(db, b ? b : a, (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(debug_math_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, what, da, db, n, dout);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dout, outN * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,79 @@
+// megaverse_amd/csrc/mv_math.h -- fp32 device math for the simulator kernels.
+//
+// Numerics contract (DESIGN.md "numerics"): the library is built with -ffp-contract=off and no
+// fast-math, so every fp32 +,-,*,/ and sqrt below is one IEEE-754 round-to-nearest operation in
+// source order (hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt keeps / and sqrtf exact).
+// That is what lets the parity tests demand bit-equal state and pixels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mv {
+
+struct V3 {
+    float x, y, z;
+};
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ float len2(V3 a) { return dot(a, a); }
+
+// select-based min/max with std::min/std::max operand semantics (no fminf NaN/-0 rules)
+__device__ __forceinline__ float fmin_sel(float a, float b) { return (b < a) ? b : a; }
+__device__ __forceinline__ float fmax_sel(float a, float b) { return (a < b) ? b : a; }
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fmin_sel(fmax_sel(v, lo), hi); }
+
+// sin/cos on |x| <~ 8: two-step pi/2 reduction + cephes-style minimax polynomials
+__device__ __forceinline__ void sincos_poly(float x, float &s, float &c)
+{
+    const float TWO_OVER_PI = 0.636619772f;
+    const float PIO2_HI = 1.57079625f;
+    const float PIO2_LO = 7.54978942e-08f;
+    const float kf = floorf(x * TWO_OVER_PI + 0.5f);
+    const int k = (int)kf;
+    float r = x - kf * PIO2_HI;
+    r = r - kf * PIO2_LO;
+    const float r2 = r * r;
+    const float sp = ((-1.9515295891e-4f * r2 + 8.3321608736e-3f) * r2 - 1.6666654611e-1f) * r2 * r + r;
+    const float cp = ((2.443315711809948e-5f * r2 - 1.388731625493765e-3f) * r2 + 4.166664568298827e-2f) * r2 * r2 -
+                     0.5f * r2 + 1.0f;
+    const int q = k & 3;
+    s = (q == 0) ? sp : (q == 1) ? cp : (q == 2) ? -sp : -cp;
+    c = (q == 0) ? cp : (q == 1) ? -sp : (q == 2) ? -cp : sp;
+}
+
+// (cos, sin) entries of the y-rotation matrix built from an axis-angle quaternion
+__device__ __forceinline__ void yaw_matrix(float angle, float &c_out, float &s_out)
+{
+    float sh, ch;
+    sincos_poly(angle * 0.5f, sh, ch);
+    const float d = sh * sh + ch * ch;
+    const float s = 2.0f / d;
+    const float ys = sh * s;
+    const float wy = ch * ys;
+    const float yy = sh * ys;
+    c_out = 1.0f - yy;
+    s_out = wy;
+}
+
+// ---- wave64 helpers ------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+__device__ __forceinline__ float bcast_f(float v, int src_lane) { return __shfl(v, src_lane, 64); }
+__device__ __forceinline__ int bcast_i(int v, int src_lane) { return __shfl(v, src_lane, 64); }
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, off, 64);
+        const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), off, 64);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        v = (o < v) ? o : v;
+    }
+    return v;
+}
+
+}  // namespace mv

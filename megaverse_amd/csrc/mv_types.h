@@ -1,0 +1,78 @@
+// megaverse_amd/csrc/mv_types.h -- HBM-resident state of the batched voxel-world simulator.
+//
+// Layout rule: one wavefront owns one env in the step/reset kernels, so everything a wave needs
+// for an env is contiguous per env (array-of-structs per kind); the raster kernel reads the same
+// arrays.  All sizes are multiples of 16 B so a wave's loads are aligned dwordx4.
+#pragma once
+#include <stdint.h>
+
+namespace mv {
+
+enum : int {
+    CX = 32, CY = 16, CZ = 32, CHUNK_BYTES = CX * CY * CZ,   // dense voxel chunk, 1 B per cell
+    MAX_BOXES = 16, MAX_OBJECTS = 80, MAX_AGENTS = 8,
+    NUM_SHAPING = 4,
+};
+
+// voxel cell byte (reference: env/include/env/voxel_state.hpp:10-37, scenarios/platforms.hpp:28-34)
+enum : int { VX_SOLID = 1, VX_OPAQUE = 2, VX_OBJECT = 4, VX_TERRAIN_SHIFT = 3, VX_COLOR_SHIFT = 6 };
+
+// action bits (reference: env/include/env/env.hpp:22-42)
+enum : int {
+    ACT_LEFT = 1 << 1, ACT_RIGHT = 1 << 2, ACT_FORWARD = 1 << 3, ACT_BACKWARD = 1 << 4, ACT_LOOK_LEFT = 1 << 5,
+    ACT_LOOK_RIGHT = 1 << 6, ACT_JUMP = 1 << 7, ACT_INTERACT = 1 << 8, ACT_LOOK_DOWN = 1 << 9, ACT_LOOK_UP = 1 << 10,
+};
+
+struct alignas(16) EnvHeader {   // 128 B
+    int32_t L, H, W;                    // room extents in voxels (x, y, z)
+    int32_t bz[4];                      // building zone min x, max x, min z, max z (y == 1)
+    int32_t layout_color, wall_color;   // 0xRRGGBB
+    int32_t draw_walls;
+    int32_t num_objects, num_boxes;
+    int32_t num_frames, done, highest_tower;
+    float episode_sec, episode_len, bz_reward, bar_half_width;
+    uint32_t next_seed;                 // value the next Env::reset() re-seeds with (env.cpp:61-62)
+    int32_t seed_is_env_seed;           // 1: next_seed is the Env::seed() value, reset must draw first
+    float p_episode_len_sec, p_vertical_look_limit;   // float params (scenario.hpp:225-232)
+    int32_t pad[9];
+};
+static_assert(sizeof(EnvHeader) == 128, "EnvHeader must be 128 B");
+
+struct alignas(16) LayoutBox {   // 32 B, merged layout parallelepiped (voxel units, max exclusive)
+    int32_t min[3]; int32_t type;
+    int32_t max[3]; int32_t slot;
+};
+
+struct alignas(4) MovableObject {   // 4 B
+    int8_t x, y, z;
+    int8_t state;   // 0 placed at (x,y,z); 1+k carried by agent k
+};
+
+struct alignas(16) AgentState {   // 128 B
+    float pos[3];                 // capsule centre == Bullet ghost origin
+    float m00, m02, m20, m22;     // yaw basis
+    float pitch;
+    float hvx, hvz, vvel, voffset, step_offset, jump_speed;
+    int32_t was_jumping, carrying, picked_up, visited_zone;
+    int32_t spawn[3];
+    float last_reward, total_reward;
+    float shaping[NUM_SHAPING];
+    int32_t pad[5];
+};
+static_assert(sizeof(AgentState) == 128, "AgentState must be 128 B");
+
+// Everything a kernel needs, passed by value.
+struct GymView {
+    int32_t num_envs, num_agents;
+    EnvHeader *hdr;            // [N]
+    LayoutBox *boxes;          // [N][MAX_BOXES]
+    MovableObject *objects;    // [N][MAX_OBJECTS]
+    AgentState *agents;        // [N][A]
+    uint8_t *chunk;            // [N][CHUNK_BYTES]
+    int32_t *actions;          // [N][A] bitmasks
+    float *rewards;            // [N*A] as reported by get_last_rewards (0 on done steps)
+    uint8_t *done;             // [N]
+    float *true_objective;     // [N*A]
+};
+
+}  // namespace mv

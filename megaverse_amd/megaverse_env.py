@@ -1,0 +1,174 @@
+"""MegaverseEnv: the reference's Python surface on top of the HIP simulator.
+
+Reference: megaverse/megaverse_env.py:42-201 (class MegaverseEnv(gym.Env)).  Same constructor
+arguments, attributes (num_envs, num_agents_per_env, num_agents, action_space, observation_space,
+is_multiagent) and methods (seed/reset/step/render/close + reward-shaping accessors), same return
+conventions: ``reset() -> [obs]*num_agents`` with obs uint8 (3, H, W) *un-flipped* (rows bottom-up),
+``step(actions) -> (obs, rewards, dones, infos)`` with ``infos[i] = {'true_reward': ...}`` on done.
+
+Differences, all additive:
+  * img_w/img_h are constructor keywords (reference hard-codes 128x72, megaverse_env.py:51-52);
+  * ``step_batched`` / ``observations_tensor`` return one device tensor instead of O(num_agents)
+    numpy views (the Python loops at megaverse_env.py:121-130,138-141 cap the reference well below
+    the GPU's rate);
+  * gym and cv2 are optional.
+"""
+import numpy as np
+
+from . import spaces
+from .extension import MegaverseGym, set_megaverse_log_level
+
+MEGAVERSE8 = ['TowerBuilding', 'ObstaclesEasy', 'ObstaclesHard', 'Collect', 'Sokoban', 'HexMemory', 'HexExplore', 'Rearrange']
+OBSTACLES_MULTITASK = ['ObstaclesWalls', 'ObstaclesSteps', 'ObstaclesLava', 'ObstaclesEasy', 'ObstaclesHard']
+
+
+def make_env_multitask(multitask_name, task_idx, num_envs, num_agents_per_env, num_simulation_threads, use_vulkan=False, params=None):
+    """reference: megaverse_env.py:27-39"""
+    assert 'multitask' in multitask_name
+    if multitask_name.endswith('megaverse8'):
+        tasks = MEGAVERSE8
+    elif multitask_name.endswith('obstacles'):
+        tasks = OBSTACLES_MULTITASK
+    else:
+        raise NotImplementedError()
+    scenario = tasks[task_idx % len(tasks)]
+    return MegaverseEnv(scenario, num_envs, num_agents_per_env, num_simulation_threads, use_vulkan, params)
+
+
+class MegaverseEnv:
+    def __init__(self, scenario_name, num_envs, num_agents_per_env, num_simulation_threads=1, use_vulkan=False, params=None,
+                 img_w=128, img_h=72, device=0, env_offset=0, total_envs=0):
+        scenario_name = scenario_name.casefold()
+        self.scenario_name = scenario_name
+        self.is_multiagent = True
+        set_megaverse_log_level(2)
+
+        self.img_w, self.img_h, self.channels = int(img_w), int(img_h), 3
+        self.use_vulkan = use_vulkan
+        self.num_agents = num_envs * num_agents_per_env
+        self.num_envs = num_envs
+        self.num_agents_per_env = num_agents_per_env
+        self.device = device
+
+        float_params = {}
+        if params is not None:
+            for k, v in params.items():
+                if isinstance(v, float):
+                    float_params[k] = v
+                else:
+                    raise Exception('Params of type %r not supported', type(v))
+
+        self.env = MegaverseGym(self.scenario_name, self.img_w, self.img_h, num_envs, num_agents_per_env, num_simulation_threads,
+                                use_vulkan, float_params, device=device, env_offset=env_offset, total_envs=total_envs)
+        self.default_shaping_scheme = self.env.get_reward_shaping(0, 0)
+        self.action_space = self.generate_action_space(self.env.action_space_sizes())
+        self.observation_space = spaces.Box(0, 255, (self.channels, self.img_h, self.img_w), dtype=np.uint8)
+        self._obs_tensor = None
+
+    @staticmethod
+    def generate_action_space(action_space_sizes):
+        return spaces.Tuple([spaces.Discrete(sz) for sz in action_space_sizes])
+
+    def seed(self, seed=None):
+        if seed is None:
+            return
+        assert isinstance(seed, int), 'Expect seed to be an integer'
+        self.env.seed(seed)
+
+    # ---- reference-shaped (list of per-agent numpy arrays) ----
+    def observations(self):
+        """list of (3, H, W) uint8, one per agent (megaverse_env.py:121-130)"""
+        frames = self.observations_numpy()
+        return [frames[i] for i in range(self.num_agents)]
+
+    def observations_numpy(self):
+        """(num_agents, 3, H, W) uint8 on the host: one D2H copy for the whole batch"""
+        t = self.observations_tensor()
+        return t.cpu().numpy()
+
+    def reset(self):
+        self.env.reset()
+        return self.observations()
+
+    def step(self, actions):
+        self.env.set_actions_batched(np.asarray(actions, dtype=np.int32).reshape(self.num_agents, -1))
+        self.env.step()
+        dones_env = self.env.get_dones()
+        dones, infos = [], []
+        true_obj = self.env.get_true_objectives() if dones_env.any() else None
+        for env_i in range(self.num_envs):
+            done = bool(dones_env[env_i])
+            dones.extend([done] * self.num_agents_per_env)
+            if done:
+                infos.extend([dict(true_reward=float(true_obj[env_i * self.num_agents_per_env + j])) for j in range(self.num_agents_per_env)])
+            else:
+                infos.extend([{} for _ in range(self.num_agents_per_env)])
+        rewards = self.env.get_last_rewards()
+        return self.observations(), rewards, dones, infos
+
+    # ---- batched device path ----
+    def _torch(self):
+        import torch
+        return torch
+
+    def observations_tensor(self, rgba=False):
+        """uint8 CUDA tensor viewing the HBM observation slab written by the raster kernel:
+        (num_agents, 3, H, W) (a permuted view, no copy) or (num_agents, H, W, 4) if rgba."""
+        torch = self._torch()
+        if self._obs_tensor is None:
+            self._obs_tensor = torch.empty((self.num_agents, self.img_h, self.img_w, 4), dtype=torch.uint8, device=f'cuda:{self.device}')
+            self.env.set_obs_buffer(self._obs_tensor.data_ptr())
+            self.env.render()
+        self.env.synchronize()
+        if rgba:
+            return self._obs_tensor
+        return self._obs_tensor[..., :3].permute(0, 3, 1, 2)
+
+    def step_batched(self, actions=None):
+        """actions: int32 [num_agents, 6] (numpy, or a CUDA torch tensor) or None (keep what was set).
+        Returns (obs uint8 CUDA view (num_agents,3,H,W), rewards float32 np [num_agents], dones bool np [num_envs])."""
+        if actions is not None:
+            if hasattr(actions, 'data_ptr'):
+                self.env.set_actions_device(actions.contiguous().data_ptr())
+            else:
+                self.env.set_actions_batched(actions)
+        if self._obs_tensor is None:
+            self.observations_tensor()
+        self.env.step()
+        return self.observations_tensor(), self.env.get_rewards_array(), self.env.get_dones().astype(bool)
+
+    # ---- rendering (megaverse_env.py:164-184): returns the tiled BGR image, shows it if cv2 exists ----
+    def convert_obs(self, obs):
+        if not self.use_vulkan:
+            obs = obs[::-1]
+        return np.ascontiguousarray(obs[:, :, [2, 1, 0]])
+
+    def render(self, mode='human'):
+        self.env.draw_overview()
+        self.env.draw_hires()
+        rows = []
+        for env_i in range(self.num_envs):
+            obs = [self.convert_obs(self.env.get_hires_observation(env_i, i)) for i in range(self.num_agents_per_env)]
+            rows.append(np.concatenate(obs, axis=1))
+        obs_final = np.concatenate(rows, axis=0)
+        if mode == 'human':
+            try:
+                import cv2  # type: ignore
+                cv2.imshow(f'agent_{id(self)}', obs_final)
+                cv2.waitKey(1)
+            except Exception:  # noqa: BLE001 - headless image
+                pass
+        return obs_final
+
+    def get_default_reward_shaping(self):
+        return self.default_shaping_scheme
+
+    def get_current_reward_shaping(self, actor_idx: int):
+        return self.env.get_reward_shaping(actor_idx // self.num_agents_per_env, actor_idx % self.num_agents_per_env)
+
+    def set_reward_shaping(self, reward_shaping: dict, actor_idx: int):
+        return self.env.set_reward_shaping(actor_idx // self.num_agents_per_env, actor_idx % self.num_agents_per_env, reward_shaping)
+
+    def close(self):
+        if self.env:
+            self.env.close()
