@@ -193,6 +193,16 @@ __device__ __forceinline__ bool recover_from_penetration(const Col (&col)[2], V3
     return true;
 }
 
+// "while (recover()) { if (++n > 4) break; }" == at most five calls.  Written as straight-line
+// predicated code: no wave-level op (ballot/shuffle) sits inside a loop with a data-dependent exit.
+__device__ __forceinline__ void recover_up_to_5(const Col (&col)[2], V3 &pos)
+{
+    bool more = true;
+#pragma unroll
+    for (int it = 0; it < 5; ++it)
+        if (more) more = recover_from_penetration(col, pos);
+}
+
 __device__ __forceinline__ bool on_ground(const AgentState &a) { return (fabsf(a.vvel) < SIMD_EPS) && (fabsf(a.voffset) < SIMD_EPS); }
 
 __device__ __forceinline__ void set_acceleration(AgentState &a, V3 acc, float dt)
@@ -252,10 +262,7 @@ __device__ __forceinline__ void player_step(AgentState &a, const Col (&col)[2], 
                 a.step_offset = stepHeight * f;
                 cur = lerp3(cur, target, f);
             }
-            int loops = 0;
-            while (recover_from_penetration(col, cur)) {
-                if (++loops > 4) break;
-            }
+            recover_up_to_5(col, cur);
             target = cur;
             if (a.voffset > 0) { a.voffset = 0.0f; a.vvel = 0.0f; a.step_offset = STEP_HEIGHT; }
         } else {
@@ -267,30 +274,35 @@ __device__ __forceinline__ void player_step(AgentState &a, const Col (&col)[2], 
     {   // stepForwardAndStrafe
         const V3 hv = v3(a.hvx, 0.0f, a.hvz);
         target = v3(cur.x + hv.x * dt, cur.y + hv.y * dt, cur.z + hv.z * dt);
-        int maxIter = 10;
-        while (maxIter-- > 0) {
-            const V3 negDir = cur - target;
-            float f = 1.0f; V3 n = v3(0, 0, 0);
-            bool hit = false;
-            if (!(cur.x == target.x && cur.y == target.y && cur.z == target.z)) hit = sweep(col, cur, target, negDir, 0.0f, f, n);
-            if (!hit) break;
-            V3 dir = target - cur;
-            const float movLen = sqrtf(len2(dir));
-            if (movLen > SIMD_EPS) {
-                dir = dir * (1.0f / movLen);
-                const float mag = dot(dir, n);
-                const V3 par = n * mag;
-                const V3 perp = dir - par;
-                target = cur;
-                target = target + perp * movLen;
-                target = target + par * (movLen * f);
+        bool active = true;
+#pragma unroll 1
+        for (int it = 0; it < 10; ++it) {   // "int maxIter = 10; while (maxIter-- > 0)" with breaks -> flag
+            if (active) {
+                const V3 negDir = cur - target;
+                float f = 1.0f; V3 n = v3(0, 0, 0);
+                bool hit = false;
+                if (!(cur.x == target.x && cur.y == target.y && cur.z == target.z)) hit = sweep(col, cur, target, negDir, 0.0f, f, n);
+                if (!hit) active = false;
+                else {
+                    V3 dir = target - cur;
+                    const float movLen = sqrtf(len2(dir));
+                    if (movLen > SIMD_EPS) {
+                        dir = dir * (1.0f / movLen);
+                        const float mag = dot(dir, n);
+                        const V3 par = n * mag;
+                        const V3 perp = dir - par;
+                        target = cur;
+                        target = target + perp * movLen;
+                        target = target + par * (movLen * f);
+                    }
+                    V3 cd = target - cur;
+                    const float dist2 = len2(cd);
+                    if (dist2 > 0.0001f) {
+                        cd = cd * (1.0f / sqrtf(dist2));
+                        if (dot(cd, hv) <= 0.0f) { target = cur; active = false; }
+                    } else { target = cur; active = false; }
+                }
             }
-            V3 cd = target - cur;
-            const float dist2 = len2(cd);
-            if (dist2 > 0.0001f) {
-                cd = cd * (1.0f / sqrtf(dist2));
-                if (dot(cd, hv) <= 0.0f) { target = cur; break; }
-            } else { target = cur; break; }
         }
         cur = target;
     }
@@ -309,10 +321,7 @@ __device__ __forceinline__ void player_step(AgentState &a, const Col (&col)[2], 
     a.hvx = (cur.x - original.x) / dt;
     a.hvz = (cur.z - original.z) / dt;
 
-    int loops = 0;
-    while (recover_from_penetration(col, cur)) {
-        if (++loops > 4) break;
-    }
+    recover_up_to_5(col, cur);
     a.pos[0] = cur.x; a.pos[1] = cur.y; a.pos[2] = cur.z;
 
     const float speed = sqrtf(a.hvx * a.hvx + a.hvz * a.hvz);
@@ -370,6 +379,22 @@ __device__ __forceinline__ int object_at(const ObjRegs &o, int x, int y, int z)
     if (m0) return (__ffsll((long long)m0) - 1) - 16;
     if (m1) return 48 + (__ffsll((long long)m1) - 1);
     return -1;
+}
+
+// placed objects of column (x,z) as a bit set over y: bit (y+32), y in [-32,31]
+__device__ __forceinline__ unsigned long long column_objects(const ObjRegs &o, int x, int z)
+{
+    unsigned long long m = 0ull;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        if (o.valid[k] && o.state[k] == 0 && o.x[k] == x && o.z[k] == z && o.y[k] >= -32 && o.y[k] < 32) m |= 1ull << (o.y[k] + 32);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)m, off, 64);
+        const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(m >> 32), off, 64);
+        m |= ((unsigned long long)hi << 32) | lo;
+    }
+    return m;
 }
 
 __device__ __forceinline__ bool in_zone(const EnvHeader &h, int x, int z) { return x >= h.bz[0] && x < h.bz[1] && z >= h.bz[2] && z < h.bz[3]; }
@@ -557,12 +582,14 @@ __global__ __launch_bounds__(64) void step_kernel(GymView gv)
                         if (c[0] == vx[0] && c[1] == vx[1] && c[2] == vx[2]) collidesWithAgent = true;
                     }
                 const bool placeable = vx[0] >= 0 && vx[0] < CX && vx[2] >= 0 && vx[2] < CZ && vx[1] < CY;
-                const bool empty = !(vox(vx[0], vx[1], vx[2]) & VX_SOLID) && !(in_chunk(vx[0], vx[1], vx[2]) && object_at(ob, vx[0], vx[1], vx[2]) >= 0);
+                const unsigned long long colObj = column_objects(ob, vx[0], vx[2]);   // wave op, outside the loop
+                auto has_obj = [&](int y) { return in_chunk(vx[0], y, vx[2]) && ((colObj >> (y + 32)) & 1ull); };
+                const bool empty = !(vox(vx[0], vx[1], vx[2]) & VX_SOLID) && !has_obj(vx[1]);
                 if (placeable && empty && !collidesWithAgent && in_zone(h, vx[0], vx[2])) {
                     for (;;) {
                         const int by = vx[1] - 1;
                         if (by < -30) break;
-                        if ((vox(vx[0], by, vx[2]) & VX_SOLID) || (in_chunk(vx[0], by, vx[2]) && object_at(ob, vx[0], by, vx[2]) >= 0)) break;
+                        if ((vox(vx[0], by, vx[2]) & VX_SOLID) || has_obj(by)) break;
                         vx[1] = by;
                     }
                     const int oidx = a.carrying;
@@ -581,19 +608,21 @@ __global__ __launch_bounds__(64) void step_kernel(GymView gv)
                 const V3 pickup = cam_to_world(cam, v3(0.0f, -0.44f, -1.0f));
                 int vx[3];
                 voxel_of(pickup, vx);
-                for (int hh = 0; hh <= 1; ++hh) {
-                    const int oidx = object_at(ob, vx[0], vx[1], vx[2]);
-                    const bool above = object_at(ob, vx[0], vx[1] + 1, vx[2]) >= 0;
-                    if (oidx >= 0 && !above) {
+                // maxPickupHeight == 1: try the voxel, then the one above; an object with another one
+                // on top of it cannot be taken (component_object_stacking.hpp:131-167)
+                const int o0 = object_at(ob, vx[0], vx[1], vx[2]);
+                const int o1 = object_at(ob, vx[0], vx[1] + 1, vx[2]);
+                const int o2 = object_at(ob, vx[0], vx[1] + 2, vx[2]);
+                int oidx = -1, py = vx[1];
+                if (o0 >= 0 && o1 < 0) { oidx = o0; py = vx[1]; }
+                else if (o1 >= 0 && o2 < 0) { oidx = o1; py = vx[1] + 1; }
+                if (oidx >= 0) {
 #pragma unroll
-                        for (int k = 0; k < 2; ++k)
-                            if (oi[k] == oidx) ob.state[k] = 1 + i;
-                        if (lane == 0 && in_chunk(vx[0], vx[1], vx[2])) chunk[(vx[1] * CZ + vx[2]) * CX + vx[0]] &= (uint8_t)~VX_OBJECT;
-                        a.carrying = oidx;
-                        if (!a.picked_up) { reward_agent(ag, 1, i, 1); a.picked_up = 1; }
-                        break;
-                    }
-                    vx[1] += 1;
+                    for (int k = 0; k < 2; ++k)
+                        if (oi[k] == oidx) ob.state[k] = 1 + i;
+                    if (lane == 0 && in_chunk(vx[0], py, vx[2])) chunk[(py * CZ + vx[2]) * CX + vx[0]] &= (uint8_t)~VX_OBJECT;
+                    a.carrying = oidx;
+                    if (!a.picked_up) { reward_agent(ag, 1, i, 1); a.picked_up = 1; }
                 }
             }
         }
