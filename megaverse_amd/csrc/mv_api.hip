@@ -64,6 +64,9 @@ struct mv_gym {
     std::vector<uint8_t> hDone;
     bool mirrorsFresh = false;
     std::mt19937 rng{std::random_device{}()};    // megaverse.cpp:253
+    // in-stream profiling
+    std::vector<hipEvent_t> profEvents;          // 4 per profiled step
+    int profMax = 0, profCount = 0;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -285,6 +288,8 @@ int mv_close(mv_gym *g)
         if (g->actionsCopied[b]) (void)hipEventDestroy(g->actionsCopied[b]);
         g->hActions[b] = nullptr; g->actionsCopied[b] = nullptr;
     }
+    for (hipEvent_t e : g->profEvents) (void)hipEventDestroy(e);
+    g->profEvents.clear();
     gv = GymView{};
     g->ownedObs = g->hiresObs = g->obs = nullptr; g->dMultiDiscrete = nullptr;
     g->closed = true;
@@ -416,9 +421,15 @@ static int step_impl(mv_gym *g, bool render)
         std::memset(g->hActions[g->stage], 0, (size_t)g->N * g->A * sizeof(int32_t));   // actions are cleared every tick (env.cpp:141-142)
         g->actionsDirty = false;
     }
+    const bool prof = render && g->profCount < g->profMax;
+    hipEvent_t *ev = prof ? &g->profEvents[(size_t)g->profCount * 4] : nullptr;
+    if (prof) HIP_TRY(hipEventRecord(ev[0], g->stream));
     launch_step(g->gv, g->stream);
+    if (prof) HIP_TRY(hipEventRecord(ev[1], g->stream));
     launch_reset(g->gv, 0, g->stream);
+    if (prof) HIP_TRY(hipEventRecord(ev[2], g->stream));
     if (render) launch_raster(g->gv, g->obs, g->w, g->h, g->stream);
+    if (prof) { HIP_TRY(hipEventRecord(ev[3], g->stream)); ++g->profCount; }
     HIP_TRY(hipGetLastError());
     g->mirrorsFresh = false;
     return 0;
@@ -431,6 +442,41 @@ int mv_synchronize(mv_gym *g)
 {
     if (check(g)) return -1;
     HIP_TRY(hipStreamSynchronize(g->stream));
+    return 0;
+}
+
+int mv_profile_begin(mv_gym *g, int32_t max_steps)
+{
+    if (check(g)) return -1;
+    if (max_steps < 0) return fail("mv_profile_begin: max_steps < 0");
+    HIP_TRY(hipSetDevice(g->device));
+    while ((int)g->profEvents.size() < max_steps * 4) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        g->profEvents.push_back(e);
+    }
+    g->profMax = max_steps;
+    g->profCount = 0;
+    return 0;
+}
+
+int mv_profile_end(mv_gym *g, float *avg_ms3, int32_t *counts3)
+{
+    if (check(g)) return -1;
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    double sum[3] = {0, 0, 0};
+    for (int i = 0; i < g->profCount; ++i)
+        for (int k = 0; k < 3; ++k) {
+            float ms = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms, g->profEvents[(size_t)i * 4 + k], g->profEvents[(size_t)i * 4 + k + 1]));
+            sum[k] += ms;
+        }
+    for (int k = 0; k < 3; ++k) {
+        avg_ms3[k] = g->profCount ? (float)(sum[k] / g->profCount) : 0.0f;
+        counts3[k] = g->profCount;
+    }
+    g->profMax = 0;
+    g->profCount = 0;
     return 0;
 }
 

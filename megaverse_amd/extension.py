@@ -49,6 +49,7 @@ SYMBOLS = [
     ("mv_get_reward_shaping", C.c_int, [_P, _I, _I, C.c_char_p, C.POINTER(_F)]),
     ("mv_set_reward_shaping", C.c_int, [_P, _I, _I, C.c_char_p, _F]),
     ("mv_synchronize", C.c_int, [_P]),
+    ("mv_profile_begin", C.c_int, [_P, _I]), ("mv_profile_end", C.c_int, [_P, _P, _P]),
     ("mv_debug_snapshot_size", C.c_int, [_P]), ("mv_debug_snapshot", C.c_int, [_P, _I, _P]),
     ("mv_debug_rng", C.c_int, [_I, _U, _I, _P, _P, _I, _P]),
     ("mv_debug_math", C.c_int, [_I, _I, _P, _P, _I, _P]),
@@ -244,6 +245,16 @@ class MegaverseGym:
 
     def set_stream(self, hip_stream):
         self._ck(self._lib.mv_set_stream(self._g, _P(int(hip_stream))))
+
+    def profile_begin(self, max_steps):
+        self._ck(self._lib.mv_profile_begin(self._g, int(max_steps)))
+
+    def profile_end(self):
+        """-> {'step': (avg_ms, n), 'reset': (...), 'raster': (...)} measured with HIP events on the gym's stream"""
+        ms = (C.c_float * 3)()
+        cnt = (C.c_int32 * 3)()
+        self._ck(self._lib.mv_profile_end(self._g, ms, cnt))
+        return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(("step", "reset", "raster"))}
 
     def debug_snapshot_bytes(self, env_idx):
         n = self._lib.mv_debug_snapshot_size(self._g)
