@@ -12,7 +12,7 @@
 //   * generate_canonical<float,24>: one draw / 2^32, clamped below 1 (bits/random.tcc);
 //   * std::shuffle: two swap positions per draw while range^2 fits in 32 bits (bits/stl_algo.h).
 // tests/test_rng_parity.py checks every one of them against the reference's util.hpp compiled in
-// place (oracle/_ref) and against the standard's mt19937 known answer.
+// place (the _ref build of the test tree) and against the standard's mt19937 known answer.
 //
 // Execution model: every lane of the wave runs the same scalar code on the same values ("uniform
 // execution"); LDS reads are broadcasts, LDS writes are done by lane 0 only.  The block is exactly

@@ -1,0 +1,115 @@
+"""GPU: the MegaverseEnv / MegaverseGym surface, mirroring the reference's own Python tests
+(megaverse/tests/test_env.py) test for test, on TowerBuilding."""
+import copy
+
+import numpy as np
+import pytest
+
+from megaverse_amd import MegaverseEnv
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(300)]
+
+
+def sample_actions(e):
+    return [e.action_space.sample() for _ in range(e.num_agents)]
+
+
+def make_test_env(num_envs, num_agents_per_env, num_simulation_threads, use_vulkan=False, params=None):
+    return MegaverseEnv('TowerBuilding', num_envs, num_agents_per_env, num_simulation_threads, use_vulkan, params)
+
+
+def test_env(hip):                      # test_env.py:22-26
+    e = make_test_env(1, 1, 1)
+    o = e.reset()
+    assert len(o) == 1 and o[0].shape == (3, 72, 128) and o[0].dtype == np.uint8
+    obs, rew, dones, infos = e.step(sample_actions(e))
+    assert len(obs) == len(rew) == len(dones) == len(infos) == 1
+    e.close()
+
+
+def test_env_close_immediately(hip):    # test_env.py:28-30
+    e = make_test_env(1, 1, 1)
+    e.close()
+    e.close()                           # idempotent
+
+
+def test_two_envs_same_process(hip):    # test_env.py:32-40
+    e1, e2 = make_test_env(1, 1, 1), make_test_env(1, 1, 1)
+    e1.reset(); e2.reset()
+    e1.close(); e2.close()
+
+
+def test_seeds(hip):                    # test_env.py:42-55
+    e1 = make_test_env(1, 1, 1); e1.seed(42)
+    e2 = make_test_env(1, 1, 1); e2.seed(42)
+    obs1, obs2 = e1.reset(), e2.reset()
+    assert np.array_equal(obs1, obs2)
+    # unlike the reference ("after this we have randomness due to physics?") the whole rollout is deterministic
+    for st in range(50):
+        a = [tuple(int(v) for v in row) for row in np.random.default_rng(st).integers(0, 2, (1, 6))]
+        o1, r1, d1, _ = e1.step(a)
+        o2, r2, d2, _ = e2.step(a)
+        assert np.array_equal(o1, o2) and r1 == r2 and d1 == d2
+    e2.close(); e1.close()
+
+
+@pytest.mark.parametrize("episode_length_sec", [60.0, -300.0])
+def test_render_and_auto_reset(hip, episode_length_sec):    # test_env.py:57-88 (rendering, 1-second episodes)
+    params = {'episodeLengthSec': episode_length_sec}
+    e1 = make_test_env(2, 2, 2, params=params)
+    e2 = make_test_env(1, 1, 1, params=params)
+    e1.reset(); e2.reset()
+    img = e1.render(mode='rgb_array')
+    assert img.shape == (2 * 432, 2 * 768, 3) and img.dtype == np.uint8      # hires 768x432 tiles (megaverse.cpp:261)
+    seen_done = False
+    for i in range(30):
+        obs, rew, dones, infos = e1.step(sample_actions(e1))
+        assert len(obs) == 4 and len(dones) == 4 and dones[0] == dones[1] and dones[2] == dones[3]
+        for d, info in zip(dones, infos):
+            assert ('true_reward' in info) == bool(d)
+        seen_done |= any(dones)
+        e2.step(sample_actions(e2))
+        if i % 10 == 0:
+            e1.render(mode='rgb_array'); e2.render(mode='rgb_array')
+    assert seen_done == (episode_length_sec < 0)
+    e2.close(); e1.close()
+
+
+def test_reward_shaping(hip):           # test_env.py:123-140
+    e = MegaverseEnv('TowerBuilding', num_envs=3, num_agents_per_env=2, num_simulation_threads=2, use_vulkan=True)
+    default_reward_shaping = e.get_default_reward_shaping()
+    assert default_reward_shaping == pytest.approx({'teamSpirit': 0.1, 'towerPickedUpObject': 0.1,
+                                                    'towerVisitedBuildingZoneWithObject': 0.1, 'towerBuildingReward': 1.0})
+    for idx in (0, 1, 2, 5):
+        assert default_reward_shaping == e.get_current_reward_shaping(idx)
+    new_reward_shaping = copy.deepcopy(default_reward_shaping)
+    for k, v in new_reward_shaping.items():
+        new_reward_shaping[k] = v * 3
+    e.set_reward_shaping(new_reward_shaping, 3)
+    assert default_reward_shaping == e.get_current_reward_shaping(0)
+    assert default_reward_shaping == e.get_current_reward_shaping(1)
+    assert default_reward_shaping != e.get_current_reward_shaping(3)
+    e.reset()
+    assert e.get_current_reward_shaping(3) == pytest.approx(new_reward_shaping)   # survives episode boundaries
+    e.close()
+
+
+def test_params_must_be_float(hip):     # megaverse_env.py:62-68
+    with pytest.raises(Exception):
+        MegaverseEnv('TowerBuilding', 1, 1, 1, params={'episodeLengthSec': 1})
+
+
+def test_batched_device_observations(hip):
+    import torch
+    e = MegaverseEnv('TowerBuilding', 8, 2, 1, img_w=128, img_h=128)
+    e.seed(1)
+    ref_list = e.reset()
+    t = e.observations_tensor()
+    assert t.is_cuda and tuple(t.shape) == (16, 3, 128, 128) and t.dtype == torch.uint8
+    assert np.array_equal(t.cpu().numpy(), np.stack(ref_list))
+    acts = torch.randint(0, 2, (16, 6), dtype=torch.int32, device='cuda')
+    obs, rew, dones = e.step_batched(acts)
+    assert obs.data_ptr() == t.data_ptr() and rew.shape == (16,) and dones.shape == (8,)
+    one = e.env.get_observation(3, 1)                       # per-frame copy == slice of the slab
+    assert np.array_equal(one[:, :, :3].transpose(2, 0, 1), obs[7].cpu().numpy())
+    e.close()

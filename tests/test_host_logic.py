@@ -1,0 +1,54 @@
+"""CPU: host-side logic of the package (random-policy stream, spaces, sharding, seeds)."""
+import numpy as np
+import pytest
+
+from megaverse_amd import distributed, spaces
+from megaverse_amd.rollout import ACTION_SPACE_SIZES, action_masks, sample_actions
+
+
+def test_sample_actions_is_a_pure_function_in_range():
+    a = sample_actions(1234, 17, 4096)
+    b = sample_actions(1234, 17, 4096)
+    assert np.array_equal(a, b) and a.dtype == np.int32 and a.shape == (4096, 6)
+    for k, size in enumerate(ACTION_SPACE_SIZES):
+        assert a[:, k].min() == 0 and a[:, k].max() == size - 1
+        freq = np.bincount(a[:, k], minlength=size) / len(a)
+        assert np.all(np.abs(freq - 1.0 / size) < 0.05)
+    assert not np.array_equal(a, sample_actions(1234, 18, 4096))
+    assert not np.array_equal(a, sample_actions(1235, 17, 4096))
+
+
+def test_sample_actions_shards_compose():
+    full = sample_actions(7, 3, 64)
+    assert np.array_equal(full[16:48], sample_actions(7, 3, 32, agent_offset=16))
+
+
+def test_action_space_and_observation_space():
+    sp = spaces.Tuple([spaces.Discrete(n) for n in ACTION_SPACE_SIZES])
+    s = sp.sample()
+    assert len(s) == 6 and all(0 <= v < n for v, n in zip(s, ACTION_SPACE_SIZES))
+    box = spaces.Box(0, 255, (3, 72, 128), dtype=np.uint8)
+    assert tuple(box.shape) == (3, 72, 128)
+
+
+def test_shard_range_partitions():
+    for total, world in [(1024, 8), (1000, 8), (7, 3), (5, 8)]:
+        seen = []
+        for r in range(world):
+            off, cnt = distributed.shard_range(r, world, total)
+            seen.extend(range(off, off + cnt))
+        assert seen == list(range(total))
+
+
+def test_env_seeds_host_restatement_matches_oracle_and_reference():
+    import oracle_lib
+    n = 700     # > 624: crosses a twist
+    lo, hi = np.zeros(n, np.int32), np.full(n, 1 << 30, np.int32)
+    want = np.empty(n, np.int32)
+    oracle_lib.lib().mvo_rand_range_seq(42, lo.ctypes.data, hi.ctypes.data, n, want.ctypes.data)
+    assert np.array_equal(distributed.env_seeds(42, n), want)
+    ref = oracle_lib.ref_lib()
+    if ref is not None:
+        r = np.empty(n, np.int32)
+        ref.mvref_env_seeds(42, n, r.ctypes.data)
+        assert np.array_equal(r, want)
