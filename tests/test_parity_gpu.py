@@ -27,8 +27,9 @@ def test_fp32_ops_are_ieee_exact_on_device(hip):
     out = np.empty(n, np.float32)
     assert lib.mv_debug_math(0, 0, a.ctypes.data, b.ctypes.data, n, out.ctypes.data) == 0
     assert np.array_equal(out.view(np.uint32), (a / b).view(np.uint32)), "fp32 divide is not correctly rounded"
-    lib.mv_debug_math(0, 1, np.abs(a).ctypes.data, None, n, out.ctypes.data)
-    assert np.array_equal(out.view(np.uint32), np.sqrt(np.abs(a)).view(np.uint32)), "sqrtf is not correctly rounded"
+    aa = np.abs(a)
+    lib.mv_debug_math(0, 1, aa.ctypes.data, None, n, out.ctypes.data)
+    assert np.array_equal(out.view(np.uint32), np.sqrt(aa).view(np.uint32)), "sqrtf is not correctly rounded"
     lib.mv_debug_math(0, 3, a.ctypes.data, b.ctypes.data, n, out.ctypes.data)
     assert np.array_equal(out.view(np.uint32), ((a * b).astype(np.float32) + a).view(np.uint32)), "a*b+a was contracted to fma"
     x = rng.uniform(-7, 7, 4096).astype(np.float32)
