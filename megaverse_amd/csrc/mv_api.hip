@@ -23,7 +23,7 @@
 namespace mv {
 void launch_reset(const GymView &gv, int force_all, hipStream_t stream);
 void launch_step(const GymView &gv, hipStream_t stream);
-void launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream);
+int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream);
 }  // namespace mv
 
 using namespace mv;
@@ -197,7 +197,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
         return fail("Unknown scenario " + lower(cfg->scenario) + " (this build accelerates: towerbuilding)");
     if (cfg->num_envs < 1 || cfg->num_agents_per_env < 1 || cfg->num_agents_per_env > MAX_AGENTS)
         return fail("mv_create: num_envs >= 1 and 1 <= num_agents_per_env <= 8 required");
-    if (cfg->obs_width < 1 || cfg->obs_height < 1) return fail("mv_create: bad observation size");
+    if (cfg->obs_width < 1 || cfg->obs_height < 1 || cfg->obs_width > 1024 || cfg->obs_height > 1024) return fail("mv_create: observation size must be within 1..1024");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -344,7 +344,7 @@ int mv_render(mv_gym *g)
 {
     if (check(g)) return -1;
     HIP_TRY(hipSetDevice(g->device));
-    launch_raster(g->gv, g->obs, g->w, g->h, g->stream);
+    if (launch_raster(g->gv, g->obs, g->w, g->h, g->stream)) return fail("mv_render: observation size above 1024x1024");
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -428,7 +428,7 @@ static int step_impl(mv_gym *g, bool render)
     if (prof) HIP_TRY(hipEventRecord(ev[1], g->stream));
     launch_reset(g->gv, 0, g->stream);
     if (prof) HIP_TRY(hipEventRecord(ev[2], g->stream));
-    if (render) launch_raster(g->gv, g->obs, g->w, g->h, g->stream);
+    if (render && launch_raster(g->gv, g->obs, g->w, g->h, g->stream)) return fail("mv_step: observation size above 1024x1024");
     if (prof) { HIP_TRY(hipEventRecord(ev[3], g->stream)); ++g->profCount; }
     HIP_TRY(hipGetLastError());
     g->mirrorsFresh = false;
@@ -550,7 +550,7 @@ int mv_draw_hires(mv_gym *g)
         HIP_TRY(hipMalloc((void **)&g->hiresObs, (size_t)g->N * g->A * g->renderW * g->renderH * 4));
         g->hiresW = g->renderW; g->hiresH = g->renderH;
     }
-    launch_raster(g->gv, g->hiresObs, g->hiresW, g->hiresH, g->stream);
+    if (launch_raster(g->gv, g->hiresObs, g->hiresW, g->hiresH, g->stream)) return fail("mv_draw_hires: render size above 1024x1024");
     HIP_TRY(hipGetLastError());
     return 0;
 }

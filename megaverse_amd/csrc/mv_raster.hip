@@ -10,13 +10,23 @@
 //   is one primary ray against the env's convex primitives, which picks the same front surface a
 //   depth-tested rasteriser does.
 //
-// Mapping: one 256-thread workgroup per agent frame.  The frame's primitive list (<=128 x 32 B)
-// and all agent cameras are staged once in LDS.  Each wavefront walks 16x4-pixel tiles; per tile
-// the 64 lanes first cull the primitive list against the tile's frustum (one or two primitives per
-// lane, __ballot -> 2 x 64-bit survivor masks), then every lane intersects its pixel's ray with
-// just the survivors, iterating the mask bits so the loop is wave-uniform and the primitive comes
-// from an LDS broadcast read.  Culling is conservative (tile bounds at pixel edges, rays at pixel
-// centres), so the image is identical to brute force over all primitives.
+// Mapping: one 256-thread workgroup per agent frame.
+//   prologue (once per frame, all in LDS):
+//     * agent cameras; per-column / per-row ray terms (the pixel -> ray arithmetic is separable);
+//     * the frame's primitive list (<=128), each with its bounds relative to the ray origin of
+//       its frame and its two Phong colour terms;
+//     * frame-level visibility: every primitive's conservative screen rectangle from its 8 projected
+//       corners; invisible ones are dropped, the few that cross the camera plane ("straddlers": the
+//       floor and walls of the room the camera stands in) are kept apart; order-free compaction.
+//   per 16x4-pixel tile (one wavefront):
+//     * culling: rectangle-bounded primitives = 4 integer compares, one or two per lane; straddlers =
+//       one (primitive, frustum plane) pair per lane; __ballot -> survivor masks;
+//     * every lane intersects its pixel-centre ray with the survivors only (mask-bit iteration is
+//       wave-uniform, the primitive is an LDS broadcast read), keeps (depth, slot) minimum;
+//     * entry face of the winner -> normal, Phong, one RGBA8 dword store per lane.
+// Culling is conservative (tile bounds at pixel edges + 1 px slack, rays at pixel centres), and
+// equal-depth hits resolve to the lowest slot, so the image equals brute force over all primitives
+// in slot order - which is what the CPU oracle does and the parity tests compare bit for bit.
 #include <hip/hip_runtime.h>
 #include <math.h>
 
@@ -33,15 +43,20 @@ constexpr float NEAR_Z = 0.01f, FAR_Z = 120.0f;
 constexpr float OBJ_HALF = 0.39f, CARRY_SCALE = 0.78f;
 constexpr int TILE_W = 16, TILE_H = 4;
 constexpr int MAX_PRIMS = 128;
+constexpr int MAX_STRADDLERS = 12;    // x 5 frustum planes = 60 lanes of one wave
+constexpr float STRADDLE_W = 0.05f;   // closer than this to the camera plane: projection unusable
+constexpr int MAX_W = 1024, MAX_H = 1024;
 
 __constant__ unsigned AGENT_COLORS[7] = {0xffdd3c, 0x3bb372, 0x2eb5d0, 0xffb400, 0xd468ee, 0x222222, 0xff0000};
 
 enum : int { PRIM_NONE = 0, PRIM_BOX = 1, PRIM_CAPSULE = 2 };
 
-struct alignas(16) Prim {   // 32 B
-    float lo[3]; uint32_t color;
-    float hi[3]; int32_t meta;   // kind | frame << 8 ; frame 0 = world axes, 1+k = camera frame of agent k
-};
+struct alignas(16) Prim {   // 64 B
+    float lo[3]; int32_t meta;    // box: bounds minus the ray origin of its frame; capsule: centre (world)
+    float hi[3]; int32_t slot;    //                                                 capsule: (radius, halfLen, 0)
+    float k1[3]; float pad0;      // AMB * colour
+    float k2[3]; float pad1;      // (DIF * colour) * LCOL
+};                                // meta = kind | frame << 8 ; frame 0 = world axes, 1+k = camera frame of agent k
 
 struct CamL {
     float eye[3];
@@ -58,28 +73,43 @@ __device__ __forceinline__ V3 mat_tmul(const float *m, V3 v)
     return v3((m[0] * v.x + m[3] * v.y) + m[6] * v.z, (m[1] * v.x + m[4] * v.y) + m[7] * v.z, (m[2] * v.x + m[5] * v.y) + m[8] * v.z);
 }
 
-// entry point of the ray o + t*d into [lo,hi]; inv = 1/d per axis.  Back faces are culled, the
-// hit must lie in [NEAR_Z, FAR_Z] (t is view depth because d.z == -1 in camera space).
-__device__ __forceinline__ bool ray_box(V3 o, V3 d, V3 inv, const float *lo, const float *hi, float &t_out, int &axis_out)
+// Slab test against bounds given RELATIVE to the ray origin.  tn/tf per axis are returned through
+// tEnter/tExit only; the entry axis is recovered for the winning primitive alone (entry_axis()).
+// ANYZERO selects the exact handling of direction components that are exactly 0 (the oracle skips
+// such an axis after an inside test); the common case has none and needs no selects.
+template <bool ANYZERO>
+__device__ __forceinline__ bool ray_box(V3 d, V3 inv, const float *lo, const float *hi, float &t_out)
 {
-    float tEnter = -INFINITY, tExit = INFINITY;
-    int axis = -1;
-    const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}, ii[3] = {inv.x, inv.y, inv.z};
+    float tn[3], tf[3];
+    const float dd[3] = {d.x, d.y, d.z}, ii[3] = {inv.x, inv.y, inv.z};
+    bool outside = false;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        if (dd[k] == 0.0f) {
-            if (oo[k] < lo[k] || oo[k] > hi[k]) return false;
-        } else {
-            const float t1 = (lo[k] - oo[k]) * ii[k], t2 = (hi[k] - oo[k]) * ii[k];
-            const float tn = fmin_sel(t1, t2), tf = fmax_sel(t1, t2);
-            if (tn > tEnter) { tEnter = tn; axis = k; }
-            tExit = fmin_sel(tExit, tf);
+        const float t1 = lo[k] * ii[k], t2 = hi[k] * ii[k];
+        tn[k] = __builtin_fminf(t1, t2);
+        tf[k] = __builtin_fmaxf(t1, t2);
+        if (ANYZERO && dd[k] == 0.0f) {
+            outside |= (lo[k] > 0.0f) || (hi[k] < 0.0f);   // origin outside the slab and never entering it
+            tn[k] = -INFINITY; tf[k] = INFINITY;
         }
     }
-    if (axis < 0 || tEnter > tExit || tEnter < NEAR_Z || tEnter > FAR_Z) return false;
+    const float tEnter = __builtin_fmaxf(__builtin_fmaxf(tn[0], tn[1]), tn[2]);
+    const float tExit = __builtin_fminf(__builtin_fminf(tf[0], tf[1]), tf[2]);
     t_out = tEnter;
-    axis_out = axis;
-    return true;
+    return !outside && tEnter <= tExit && tEnter >= NEAR_Z && tEnter <= FAR_Z;
+}
+
+// first axis (x, y, z order) whose near-plane crossing equals the entry depth
+__device__ __forceinline__ int entry_axis(V3 d, V3 inv, const float *lo, const float *hi, float tEnter)
+{
+    const float dd[3] = {d.x, d.y, d.z}, ii[3] = {inv.x, inv.y, inv.z};
+    int axis = 2;
+#pragma unroll
+    for (int k = 2; k >= 0; --k) {
+        const float tn = __builtin_fminf(lo[k] * ii[k], hi[k] * ii[k]);
+        if (dd[k] != 0.0f && tn == tEnter) axis = k;
+    }
+    return axis;
 }
 
 __device__ __forceinline__ bool ray_capsule(V3 o, V3 d, V3 c, float r, float hl, float &t_out, V3 &n_out)
@@ -143,21 +173,61 @@ __device__ __forceinline__ V3 safe_inv(V3 d)
     return v3(d.x == 0.0f ? 0.0f : 1.0f / d.x, d.y == 0.0f ? 0.0f : 1.0f / d.y, d.z == 0.0f ? 0.0f : 1.0f / d.z);
 }
 
-// max over the box corners of n . (corner - e)
-__device__ __forceinline__ float support(V3 n, V3 e, const float *lo, const float *hi)
+// max over the box corners of n . corner   (bounds relative to the plane's anchor point)
+__device__ __forceinline__ float support(V3 n, const float *lo, const float *hi)
 {
-    const float ax = fmaxf(n.x * (lo[0] - e.x), n.x * (hi[0] - e.x));
-    const float ay = fmaxf(n.y * (lo[1] - e.y), n.y * (hi[1] - e.y));
-    const float az = fmaxf(n.z * (lo[2] - e.z), n.z * (hi[2] - e.z));
+    const float ax = fmaxf(n.x * lo[0], n.x * hi[0]);
+    const float ay = fmaxf(n.y * lo[1], n.y * hi[1]);
+    const float az = fmaxf(n.z * lo[2], n.z * hi[2]);
     return ax + ay + az;
+}
+
+// Conservative screen rectangle from the 8 projected corners of the primitive's bounding box.
+//   0: behind the camera,  1: rectangle valid,  2: straddler (a corner is closer than STRADDLE_W to
+//   the camera plane, so the projection is unbounded -> per-tile plane tests instead).
+__device__ __forceinline__ int screen_rect(const float *blo, const float *bhi, int fr, const CamL *cams, int viewer, int W, int H,
+                                           int rect[4])
+{
+    const CamL &cv = cams[viewer];
+    float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY, wmin = INFINITY, wmax = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        V3 v = v3((c & 1) ? bhi[0] : blo[0], (c & 2) ? bhi[1] : blo[1], (c & 4) ? bhi[2] : blo[2]);
+        if (fr == 0) v = mat_tmul(cv.c, v - v3(cv.eye[0], cv.eye[1], cv.eye[2]));
+        else if (fr != 1 + viewer) {
+            const CamL &ck = cams[fr - 1];
+            const V3 wpos = mat_mul(ck.c, v) + v3(ck.eye[0], ck.eye[1], ck.eye[2]);
+            v = mat_tmul(cv.c, wpos - v3(cv.eye[0], cv.eye[1], cv.eye[2]));
+        }
+        const float w = -v.z;
+        wmin = fminf(wmin, w); wmax = fmaxf(wmax, w);
+        const float iw = 1.0f / fmaxf(w, STRADDLE_W);
+        const float xn = v.x * iw * (1.0f / TAN_HALF_FOV), yn = v.y * iw * (1.0f / TAN_HALF_FOV_Y);
+        xmin = fminf(xmin, xn); xmax = fmaxf(xmax, xn); ymin = fminf(ymin, yn); ymax = fmaxf(ymax, yn);
+    }
+    if (wmax < NEAR_Z * 0.5f) return 0;
+    if (wmin < STRADDLE_W) return 2;
+    // pixel i is covered when its centre (i + 0.5) lies inside; one pixel of slack on every side
+    const float fx0 = (xmin * 0.5f + 0.5f) * float(W) - 1.5f, fx1 = (xmax * 0.5f + 0.5f) * float(W) + 0.5f;
+    const float fy0 = (ymin * 0.5f + 0.5f) * float(H) - 1.5f, fy1 = (ymax * 0.5f + 0.5f) * float(H) + 0.5f;
+    if (fx1 < 0.0f || fy1 < 0.0f || fx0 > float(W) || fy0 > float(H)) return 0;
+    rect[0] = (int)floorf(fmaxf(fx0, 0.0f)); rect[1] = (int)ceilf(fminf(fx1, float(W - 1)));
+    rect[2] = (int)floorf(fmaxf(fy0, 0.0f)); rect[3] = (int)ceilf(fminf(fy1, float(H - 1)));
+    return 1;
 }
 
 }  // namespace
 
-__global__ __launch_bounds__(256) void raster_kernel(GymView gv, uint32_t *obs, int W, int H)
+__global__ __launch_bounds__(256, 4) void raster_kernel(GymView gv, uint32_t *obs, int W, int H)
 {
-    __shared__ Prim s_prim[MAX_PRIMS];
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // column/row ray tables
+    __shared__ Prim s_vis[MAX_PRIMS];     // compacted visible list: straddlers first, then rectangle-bounded primitives
+    __shared__ short4 s_rect[MAX_PRIMS];  // x0,x1,y0,y1 (pixels)
     __shared__ CamL s_cam[MAX_AGENTS];
+    __shared__ int s_cnt[4];              // straddlers in wave 0 / 1, rectangle primitives in wave 0 / 1
+
+    float4 *s_col = reinterpret_cast<float4 *>(s_dyn);   // per column i: (dc.x, c00*dc.x, c10*dc.x, c20*dc.x)
+    float4 *s_row = s_col + W;                            // per row j:    (dc.y, c01*dc.y, c11*dc.y, c21*dc.y)
 
     const int A = gv.num_agents;
     const int frame = blockIdx.x;
@@ -167,7 +237,7 @@ __global__ __launch_bounds__(256) void raster_kernel(GymView gv, uint32_t *obs, 
     const EnvHeader *hdr = gv.hdr + env;
     const AgentState *agents = gv.agents + (size_t)env * A;
 
-    // ---- stage cameras
+    // ---- cameras
     if (tid < A) {
         const AgentState a = agents[tid];
         CamL cam;
@@ -187,42 +257,55 @@ __global__ __launch_bounds__(256) void raster_kernel(GymView gv, uint32_t *obs, 
         const V3 o = mat_tmul(s_cam[tid].c, ev - ek);
         s_cam[tid].origin[0] = o.x; s_cam[tid].origin[1] = o.y; s_cam[tid].origin[2] = o.z;
     }
+    {   // separable ray terms: world dir = (c_k0*dc.x + c_k1*dc.y) + c_k2*(-1), dc = (xn*TAN, yn*TAN_Y, -1)
+        const float *c = s_cam[viewer].c;
+        for (int i = tid; i < W; i += 256) {
+            const float dcx = (((float(i) + 0.5f) / float(W)) * 2.0f - 1.0f) * TAN_HALF_FOV;
+            s_col[i] = make_float4(dcx, c[0] * dcx, c[3] * dcx, c[6] * dcx);
+        }
+        for (int j = tid; j < H; j += 256) {
+            const float dcy = (((float(j) + 0.5f) / float(H)) * 2.0f - 1.0f) * TAN_HALF_FOV_Y;
+            s_row[j] = make_float4(dcy, c[1] * dcy, c[4] * dcy, c[7] * dcy);
+        }
+    }
+    __syncthreads();   // cameras (incl. origin) complete
 
-    // ---- stage the primitive list (slot order == draw order used for depth ties)
+    // ---- this thread's primitive (slot order == draw order used for depth ties); bounds in its own frame
+    int kind = PRIM_NONE, fr = 0;
+    unsigned color = 0;
+    float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
     if (tid < MAX_PRIMS) {
-        Prim p;
-        p.lo[0] = p.lo[1] = p.lo[2] = p.hi[0] = p.hi[1] = p.hi[2] = 0.0f; p.color = 0; p.meta = PRIM_NONE;
         if (tid < MAX_BOXES) {
             if (tid < hdr->num_boxes) {
                 const LayoutBox b = gv.boxes[(size_t)env * MAX_BOXES + tid];
                 if (b.type & VX_OPAQUE) {
-                    p.meta = PRIM_BOX;
-                    p.lo[0] = float(b.min[0]); p.lo[1] = float(b.min[1]); p.lo[2] = float(b.min[2]);
-                    p.hi[0] = float(b.max[0]); p.hi[1] = float(b.max[1]); p.hi[2] = float(b.max[2]);
-                    p.color = (unsigned)(b.slot == 0 ? hdr->layout_color : hdr->wall_color);
+                    kind = PRIM_BOX;
+                    lo[0] = float(b.min[0]); lo[1] = float(b.min[1]); lo[2] = float(b.min[2]);
+                    hi[0] = float(b.max[0]); hi[1] = float(b.max[1]); hi[2] = float(b.max[2]);
+                    color = (unsigned)(b.slot == 0 ? hdr->layout_color : hdr->wall_color);
                 }
             }
         } else if (tid == MAX_BOXES) {   // building-zone slab
-            p.meta = PRIM_BOX;
-            p.lo[0] = float(hdr->bz[0]); p.lo[1] = 1.0f; p.lo[2] = float(hdr->bz[2]);
-            p.hi[0] = float(hdr->bz[1]); p.hi[1] = 1.0f + 0.05f; p.hi[2] = float(hdr->bz[3]);
-            p.color = 0x555555u;
+            kind = PRIM_BOX;
+            lo[0] = float(hdr->bz[0]); lo[1] = 1.0f; lo[2] = float(hdr->bz[2]);
+            hi[0] = float(hdr->bz[1]); hi[1] = 1.0f + 0.05f; hi[2] = float(hdr->bz[3]);
+            color = 0x555555u;
         } else if (tid < MAX_BOXES + 1 + MAX_OBJECTS) {
             const int j = tid - (MAX_BOXES + 1);
             if (j < hdr->num_objects) {
                 const MovableObject o = gv.objects[(size_t)env * MAX_OBJECTS + j];
-                p.color = 0xadd8e6u;
+                color = 0xadd8e6u;
+                kind = PRIM_BOX;
                 if (o.state == 0) {
-                    p.meta = PRIM_BOX;
                     const float cx = float(o.x) + 0.5f, cy = float(o.y) + 0.5f, cz = float(o.z) + 0.5f;
-                    p.lo[0] = cx - OBJ_HALF; p.lo[1] = cy - OBJ_HALF; p.lo[2] = cz - OBJ_HALF;
-                    p.hi[0] = cx + OBJ_HALF; p.hi[1] = cy + OBJ_HALF; p.hi[2] = cz + OBJ_HALF;
+                    lo[0] = cx - OBJ_HALF; lo[1] = cy - OBJ_HALF; lo[2] = cz - OBJ_HALF;
+                    hi[0] = cx + OBJ_HALF; hi[1] = cy + OBJ_HALF; hi[2] = cz + OBJ_HALF;
                 } else {
-                    p.meta = PRIM_BOX | ((int)o.state << 8);
+                    fr = (int)o.state;
                     const float hh = OBJ_HALF * CARRY_SCALE;
                     const float cx = 0.0f, cy = -0.44f + -0.3f, cz = -1.0f;
-                    p.lo[0] = cx - hh; p.lo[1] = cy - hh; p.lo[2] = cz - hh;
-                    p.hi[0] = cx + hh; p.hi[1] = cy + hh; p.hi[2] = cz + hh;
+                    lo[0] = cx - hh; lo[1] = cy - hh; lo[2] = cz - hh;
+                    hi[0] = cx + hh; hi[1] = cy + hh; hi[2] = cz + hh;
                 }
             }
         } else {
@@ -231,25 +314,76 @@ __global__ __launch_bounds__(256) void raster_kernel(GymView gv, uint32_t *obs, 
             if (k < A) {
                 if (part == 0 && k != viewer) {
                     const AgentState a = agents[k];
-                    p.meta = PRIM_CAPSULE;
-                    p.lo[0] = a.pos[0]; p.lo[1] = (a.pos[1] + 0.05f) + 0.09f; p.lo[2] = a.pos[2];
-                    p.hi[0] = 0.35f; p.hi[1] = 0.36f; p.hi[2] = 0.0f;
-                    p.color = AGENT_COLORS[k % 7];
+                    kind = PRIM_CAPSULE;
+                    lo[0] = a.pos[0]; lo[1] = (a.pos[1] + 0.05f) + 0.09f; lo[2] = a.pos[2];
+                    hi[0] = 0.35f; hi[1] = 0.36f; hi[2] = 0.0f;
+                    color = AGENT_COLORS[k % 7];
                 } else if (part == 1 && k != viewer) {
-                    p.meta = PRIM_BOX | ((1 + k) << 8);
-                    p.lo[0] = -0.25f; p.lo[1] = -0.12f; p.lo[2] = -0.19f - 0.2f;
-                    p.hi[0] = 0.25f; p.hi[1] = 0.12f; p.hi[2] = -0.19f + 0.2f;
-                    p.color = 0x2c3e50u;
+                    kind = PRIM_BOX; fr = 1 + k;
+                    lo[0] = -0.25f; lo[1] = -0.12f; lo[2] = -0.19f - 0.2f;
+                    hi[0] = 0.25f; hi[1] = 0.12f; hi[2] = -0.19f + 0.2f;
+                    color = 0x2c3e50u;
                 } else if (part == 2) {
                     const float bw = hdr->bar_half_width;
-                    p.meta = PRIM_BOX | ((1 + k) << 8);
-                    p.lo[0] = -bw; p.lo[1] = -0.131f - 0.0015f; p.lo[2] = -0.2f - 0.001f;
-                    p.hi[0] = bw; p.hi[1] = -0.131f + 0.0015f; p.hi[2] = -0.2f + 0.001f;
-                    p.color = 0x2eb5d0u;
+                    kind = PRIM_BOX; fr = 1 + k;
+                    lo[0] = -bw; lo[1] = -0.131f - 0.0015f; lo[2] = -0.2f - 0.001f;
+                    hi[0] = bw; hi[1] = -0.131f + 0.0015f; hi[2] = -0.2f + 0.001f;
+                    color = 0x2eb5d0u;
                 }
             }
         }
-        s_prim[tid] = p;
+    }
+
+    // ---- frame-level visibility + order-free compaction (ties are resolved on the slot id)
+    int cls = 0;
+    int rect[4] = {0, 0, 0, 0};
+    if (kind != PRIM_NONE) {
+        float blo[3] = {lo[0], lo[1], lo[2]}, bhi[3] = {hi[0], hi[1], hi[2]};
+        if (kind == PRIM_CAPSULE) {
+            const float r = hi[0], hl = hi[1];
+            blo[0] = lo[0] - r; blo[1] = lo[1] - (hl + r); blo[2] = lo[2] - r;
+            bhi[0] = lo[0] + r; bhi[1] = lo[1] + (hl + r); bhi[2] = lo[2] + r;
+        }
+        cls = screen_rect(blo, bhi, fr, s_cam, viewer, W, H, rect);
+        // straddlers that are not world boxes (something glued to a camera touching the viewer's eye, or a
+        // capsule at the lens) are rare: give them the whole screen instead of plane tests
+        if (cls == 2 && (fr != 0 || kind != PRIM_BOX)) { cls = 1; rect[0] = 0; rect[1] = W - 1; rect[2] = 0; rect[3] = H - 1; }
+    }
+    const unsigned long long mS = __ballot(cls == 2), mR = __ballot(cls == 1);
+    if (wave < 2 && lane == 0) { s_cnt[wave] = __popcll(mS); s_cnt[2 + wave] = __popcll(mR); }
+    __syncthreads();
+    int nStrad = s_cnt[0] + s_cnt[1];
+    const int nRect = s_cnt[2] + s_cnt[3];
+    const int extraStrad = nStrad > MAX_STRADDLERS ? nStrad - MAX_STRADDLERS : 0;   // overflow: whole-screen rectangles
+    nStrad -= extraStrad;
+    const int nVis = nStrad + nRect + extraStrad;
+    if (cls != 0) {
+        const unsigned long long below = (1ull << lane) - 1ull;
+        int pos;
+        if (cls == 2) {
+            pos = __popcll(mS & below) + (wave ? s_cnt[0] : 0);
+            if (pos >= MAX_STRADDLERS) { pos = nStrad + nRect + (pos - MAX_STRADDLERS); rect[0] = 0; rect[1] = W - 1; rect[2] = 0; rect[3] = H - 1; }
+        } else pos = nStrad + __popcll(mR & below) + (wave ? s_cnt[2] : 0);
+        Prim p;
+        p.meta = kind | (fr << 8);
+        p.slot = tid;
+        if (kind == PRIM_BOX) {   // bounds relative to the ray origin of the primitive's frame
+            V3 o = v3(0.0f, 0.0f, 0.0f);
+            if (fr == 0) o = v3(s_cam[viewer].eye[0], s_cam[viewer].eye[1], s_cam[viewer].eye[2]);
+            else if (fr != 1 + viewer) o = v3(s_cam[fr - 1].origin[0], s_cam[fr - 1].origin[1], s_cam[fr - 1].origin[2]);
+            p.lo[0] = lo[0] - o.x; p.lo[1] = lo[1] - o.y; p.lo[2] = lo[2] - o.z;
+            p.hi[0] = hi[0] - o.x; p.hi[1] = hi[1] - o.y; p.hi[2] = hi[2] - o.z;
+        } else {
+            p.lo[0] = lo[0]; p.lo[1] = lo[1]; p.lo[2] = lo[2];
+            p.hi[0] = hi[0]; p.hi[1] = hi[1]; p.hi[2] = hi[2];
+        }
+        const float AMB = float(0x55) / 255.0f, DIF = float(0xbb) / 255.0f, LCOL = float(0xaa) / 255.0f;
+        const float col[3] = {float((color >> 16) & 255) / 255.0f, float((color >> 8) & 255) / 255.0f, float(color & 255) / 255.0f};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { p.k1[c] = AMB * col[c]; p.k2[c] = (DIF * col[c]) * LCOL; }
+        p.pad0 = p.pad1 = 0.0f;
+        s_vis[pos] = p;
+        s_rect[pos] = make_short4((short)rect[0], (short)rect[1], (short)rect[2], (short)rect[3]);
     }
     __syncthreads();
 
@@ -258,64 +392,62 @@ __global__ __launch_bounds__(256) void raster_kernel(GymView gv, uint32_t *obs, 
     const int tilesX = (W + TILE_W - 1) / TILE_W, tilesY = (H + TILE_H - 1) / TILE_H;
     const int numTiles = tilesX * tilesY;
     const float LIGHT[3] = {0.0f, 4.0f, 2.0f};
-    const float AMB = float(0x55) / 255.0f, DIF = float(0xbb) / 255.0f, LCOL = float(0xaa) / 255.0f;
     uint32_t *out = obs + (size_t)frame * W * H;
+
+    // this lane's (frustum plane, straddler) pair: plane-major so that one AND of five 12-bit groups
+    // of the ballot gives the straddlers that survive all five planes
+    const int sPlane = lane / MAX_STRADDLERS, sIdx = lane - MAX_STRADDLERS * sPlane;
+    const bool sActive = sPlane < 5 && sIdx < nStrad;
+    const float nzm[3] = {-cam.c[2], -cam.c[5], -cam.c[8]};   // c_k2 * (-1)
 
     for (int tile = wave; tile < numTiles; tile += 4) {
         const int ty = tile / tilesX, tx = tile - ty * tilesX;
+        const int tx0 = tx * TILE_W, ty0 = ty * TILE_H;
+        const int tx1 = min(tx0 + TILE_W, W) - 1, ty1 = min(ty0 + TILE_H, H) - 1;
 
-        // ---- conservative tile-vs-primitive culling, 2 primitives per lane
-        // tile frustum in camera space: x in [x0,x1]*w, y in [y0,y1]*w for depth w = -z >= NEAR
-        const float x0 = ((float(tx * TILE_W) / float(W)) * 2.0f - 1.0f) * TAN_HALF_FOV;
-        const float x1 = ((float(min(tx * TILE_W + TILE_W, W)) / float(W)) * 2.0f - 1.0f) * TAN_HALF_FOV;
-        const float y0 = ((float(ty * TILE_H) / float(H)) * 2.0f - 1.0f) * TAN_HALF_FOV_Y;
-        const float y1 = ((float(min(ty * TILE_H + TILE_H, H)) / float(H)) * 2.0f - 1.0f) * TAN_HALF_FOV_Y;
-        const V3 planeC[5] = {v3(1.0f, 0.0f, x0), v3(-1.0f, 0.0f, -x1), v3(0.0f, 1.0f, y0), v3(0.0f, -1.0f, -y1), v3(0.0f, 0.0f, -1.0f)};
-        V3 planeW[5];
-#pragma unroll
-        for (int q = 0; q < 5; ++q) planeW[q] = mat_mul(cam.c, planeC[q]);
-
-        bool keep[2];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const Prim &p = s_prim[lane + 64 * k];
-            const int kind = p.meta & 255, fr = p.meta >> 8;
-            bool vis = kind != PRIM_NONE;
-            if (vis) {
-                float lo[3] = {p.lo[0], p.lo[1], p.lo[2]}, hi[3] = {p.hi[0], p.hi[1], p.hi[2]};
-                if (kind == PRIM_CAPSULE) {
-                    const float r = p.hi[0], hl = p.hi[1];
-                    lo[0] = p.lo[0] - r; lo[1] = p.lo[1] - (hl + r); lo[2] = p.lo[2] - r;
-                    hi[0] = p.lo[0] + r; hi[1] = p.lo[1] + (hl + r); hi[2] = p.lo[2] + r;
-                }
-#pragma unroll
-                for (int q = 0; q < 5; ++q) {
-                    V3 n, e;
-                    if (fr == 0) { n = planeW[q]; e = eye; }
-                    else if (fr == 1 + viewer) { n = planeC[q]; e = v3(0.0f, 0.0f, 0.0f); }
-                    else { n = mat_tmul(s_cam[fr - 1].c, planeW[q]); e = v3(s_cam[fr - 1].origin[0], s_cam[fr - 1].origin[1], s_cam[fr - 1].origin[2]); }
-                    const float s = support(n, e, lo, hi);
-                    const float bound = (q == 4) ? NEAR_Z * 0.5f : -1e-4f;
-                    if (s < bound) vis = false;
-                }
+        // ---- tile culling.  (a) rectangle-bounded primitives: one or two per lane, 4 integer compares
+        bool keep0 = false, keep1 = false;
+        {
+            if (lane >= nStrad && lane < nVis) {
+                const short4 r = s_rect[lane];
+                keep0 = r.x <= tx1 && r.y >= tx0 && r.z <= ty1 && r.w >= ty0;
             }
-            keep[k] = vis;
+            if (lane + 64 < nVis) {
+                const short4 r = s_rect[lane + 64];
+                keep1 = r.x <= tx1 && r.y >= tx0 && r.z <= ty1 && r.w >= ty0;
+            }
         }
-        unsigned long long m0 = __ballot(keep[0]), m1 = __ballot(keep[1]);
+        // (b) straddlers: survives when no frustum plane has the whole box on its outside.
+        // tile frustum in camera space: x in [x0,x1]*w, y in [y0,y1]*w (w = depth), bounds at pixel EDGES
+        bool planeOk = false;
+        if (sActive) {
+            float a;
+            if (sPlane == 0) a = ((float(tx0) / float(W)) * 2.0f - 1.0f) * TAN_HALF_FOV;
+            else if (sPlane == 1) a = -(((float(tx1 + 1) / float(W)) * 2.0f - 1.0f) * TAN_HALF_FOV);
+            else if (sPlane == 2) a = ((float(ty0) / float(H)) * 2.0f - 1.0f) * TAN_HALF_FOV_Y;
+            else a = -(((float(ty1 + 1) / float(H)) * 2.0f - 1.0f) * TAN_HALF_FOV_Y);
+            const V3 nc = sPlane == 0 ? v3(1.0f, 0.0f, a) : sPlane == 1 ? v3(-1.0f, 0.0f, a) : sPlane == 2 ? v3(0.0f, 1.0f, a)
+                        : sPlane == 3 ? v3(0.0f, -1.0f, a) : v3(0.0f, 0.0f, -1.0f);
+            const V3 nw = mat_mul(cam.c, nc);
+            const Prim &sp = s_vis[sIdx];
+            planeOk = !(support(nw, sp.lo, sp.hi) < (sPlane == 4 ? NEAR_Z * 0.5f : -1e-4f));
+        }
+        const unsigned long long mPlane = __ballot(planeOk);
+        const unsigned long long g = mPlane & (mPlane >> MAX_STRADDLERS) & (mPlane >> (2 * MAX_STRADDLERS)) &
+                                     (mPlane >> (3 * MAX_STRADDLERS)) & (mPlane >> (4 * MAX_STRADDLERS)) & ((1ull << MAX_STRADDLERS) - 1ull);
+        const unsigned long long m0 = __ballot(keep0) | g, m1 = __ballot(keep1);
 
-        // ---- per-pixel rays
-        const int px = tx * TILE_W + (lane & (TILE_W - 1)), py = ty * TILE_H + (lane / TILE_W);
-        const float xn = ((float(px) + 0.5f) / float(W)) * 2.0f - 1.0f;
-        const float yn = ((float(py) + 0.5f) / float(H)) * 2.0f - 1.0f;
-        const V3 dc = v3(xn * TAN_HALF_FOV, yn * TAN_HALF_FOV_Y, -1.0f);
-        const V3 dw = mat_mul(cam.c, dc);
-        const V3 invW = safe_inv(dw), invC = safe_inv(dc);
+        // ---- this lane's pixel and ray
+        const int px = tx0 + (lane & (TILE_W - 1)), py = ty0 + (lane / TILE_W);
+        const float4 cx = s_col[min(px, W - 1)], ry = s_row[min(py, H - 1)];
+        const V3 dc = v3(cx.x, ry.x, -1.0f);
+        const V3 dw = v3((cx.y + ry.y) + nzm[0], (cx.z + ry.z) + nzm[1], (cx.w + ry.w) + nzm[2]);
+        const V3 invW = safe_inv(dw);
+        const bool anyZero = __any(dw.x == 0.0f || dw.y == 0.0f || dw.z == 0.0f);
 
         float best = INFINITY;
-        V3 bestN = v3(0, 0, 0);     // in the winning primitive's own frame
-        int bestFrame = 0;
-        unsigned bestColor = 0;
-        bool any = false;
+        int bestPos = -1, bestSlot = 1 << 30;
+        V3 capN = v3(0, 0, 0);   // normal of the best capsule hit (boxes recompute theirs from the entry axis)
 
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
@@ -323,41 +455,46 @@ __global__ __launch_bounds__(256) void raster_kernel(GymView gv, uint32_t *obs, 
             while (m) {
                 const int bit = __ffsll((long long)m) - 1;
                 m &= m - 1;
-                const Prim &p = s_prim[bit + 64 * half];
-                const int kind = p.meta & 255, fr = p.meta >> 8;
+                const int pos = bit + 64 * half;
+                const Prim &q = s_vis[pos];
+                const int qkind = q.meta & 255, qfr = q.meta >> 8;
                 float t; V3 n = v3(0, 0, 0);
                 bool hit;
-                if (kind == PRIM_CAPSULE) {
-                    hit = ray_capsule(eye, dw, v3(p.lo[0], p.lo[1], p.lo[2]), p.hi[0], p.hi[1], t, n);
+                if (qkind == PRIM_CAPSULE) {
+                    hit = ray_capsule(eye, dw, v3(q.lo[0], q.lo[1], q.lo[2]), q.hi[0], q.hi[1], t, n);
+                } else if (qfr == 0) {
+                    hit = anyZero ? ray_box<true>(dw, invW, q.lo, q.hi, t) : ray_box<false>(dw, invW, q.lo, q.hi, t);
+                } else if (qfr == 1 + viewer) {
+                    hit = ray_box<true>(dc, safe_inv(dc), q.lo, q.hi, t);
                 } else {
-                    int axis = 0;
-                    float dax;
-                    if (fr == 0) {
-                        hit = ray_box(eye, dw, invW, p.lo, p.hi, t, axis);
-                        dax = axis == 0 ? dw.x : axis == 1 ? dw.y : dw.z;
-                    } else if (fr == 1 + viewer) {
-                        hit = ray_box(v3(0.0f, 0.0f, 0.0f), dc, invC, p.lo, p.hi, t, axis);
-                        dax = axis == 0 ? dc.x : axis == 1 ? dc.y : dc.z;
-                    } else {
-                        const CamL &ck = s_cam[fr - 1];
-                        const V3 dk = mat_tmul(ck.c, dw);
-                        hit = ray_box(v3(ck.origin[0], ck.origin[1], ck.origin[2]), dk, safe_inv(dk), p.lo, p.hi, t, axis);
-                        dax = axis == 0 ? dk.x : axis == 1 ? dk.y : dk.z;
-                    }
-                    const float sgn = dax > 0 ? -1.0f : 1.0f;
-                    n = v3(axis == 0 ? sgn : 0.0f, axis == 1 ? sgn : 0.0f, axis == 2 ? sgn : 0.0f);
+                    const V3 dk = mat_tmul(s_cam[qfr - 1].c, dw);
+                    hit = ray_box<true>(dk, safe_inv(dk), q.lo, q.hi, t);
                 }
-                if (hit && t < best) { best = t; bestN = n; bestFrame = fr; bestColor = p.color; any = true; }
+                // nearest hit; equal depth -> the primitive drawn first (lowest slot), as a strict "<" scan in slot order would
+                if (hit && (t < best || (t == best && q.slot < bestSlot))) { best = t; bestPos = pos; bestSlot = q.slot; capN = n; }
             }
         }
 
         // ---- Phong (Magnum Shaders::Phong, uniforms of magnum_env_renderer.cpp:200-203)
         unsigned rgba = 0xff000000u;
-        if (any) {
+        if (bestPos >= 0) {
+            const Prim &q = s_vis[bestPos];
+            const int qkind = q.meta & 255, qfr = q.meta >> 8;
             V3 N;
-            if (bestFrame == 0) N = mat_tmul(cam.c, bestN);
-            else if (bestFrame == 1 + viewer) N = bestN;
-            else N = mat_tmul(cam.c, mat_mul(s_cam[bestFrame - 1].c, bestN));
+            if (qkind == PRIM_CAPSULE) N = mat_tmul(cam.c, capN);
+            else {
+                V3 d, inv;
+                if (qfr == 0) { d = dw; inv = invW; }
+                else if (qfr == 1 + viewer) { d = dc; inv = safe_inv(dc); }
+                else { d = mat_tmul(s_cam[qfr - 1].c, dw); inv = safe_inv(d); }
+                const int axis = entry_axis(d, inv, q.lo, q.hi, best);
+                const float dax = axis == 0 ? d.x : axis == 1 ? d.y : d.z;
+                const float sgn = dax > 0 ? -1.0f : 1.0f;
+                const V3 n = v3(axis == 0 ? sgn : 0.0f, axis == 1 ? sgn : 0.0f, axis == 2 ? sgn : 0.0f);
+                if (qfr == 0) N = mat_tmul(cam.c, n);
+                else if (qfr == 1 + viewer) N = n;
+                else N = mat_tmul(cam.c, mat_mul(s_cam[qfr - 1].c, n));
+            }
             const V3 P = dc * best;
             V3 Ld = v3(LIGHT[0] - P.x, LIGHT[1] - P.y, LIGHT[2] - P.z);
             Ld = Ld * (1.0f / sqrtf(len2(Ld)));
@@ -371,20 +508,21 @@ __global__ __launch_bounds__(256) void raster_kernel(GymView gv, uint32_t *obs, 
                 spec = pow300(fmax_sel(0.0f, dot(Vd, R)));
                 spec = fmin_sel(fmax_sel(spec, 0.0f), 1.0f);
             }
-            const float col[3] = {float((bestColor >> 16) & 255) / 255.0f, float((bestColor >> 8) & 255) / 255.0f,
-                                  float(bestColor & 255) / 255.0f};
             unsigned ch[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) ch[c] = to_u8((AMB * col[c] + (DIF * col[c]) * LCOL * intensity) + spec);
+            for (int c = 0; c < 3; ++c) ch[c] = to_u8((q.k1[c] + q.k2[c] * intensity) + spec);
             rgba = ch[0] | (ch[1] << 8) | (ch[2] << 16) | 0xff000000u;
         }
         if (px < W && py < H) out[(size_t)py * W + px] = rgba;
     }
 }
 
-void launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream)
+int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream)
 {
-    hipLaunchKernelGGL(raster_kernel, dim3(gv.num_envs * gv.num_agents), dim3(256), 0, stream, gv, obs, W, H);
+    if (W > MAX_W || H > MAX_H) return -1;
+    const size_t dyn = (size_t)(W + H) * sizeof(float4);
+    hipLaunchKernelGGL(raster_kernel, dim3(gv.num_envs * gv.num_agents), dim3(256), dyn, stream, gv, obs, W, H);
+    return 0;
 }
 
 }  // namespace mv
