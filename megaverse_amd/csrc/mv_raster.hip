@@ -29,6 +29,7 @@
 // in slot order - which is what the CPU oracle does and the parity tests compare bit for bit.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "mv_math.h"
 #include "mv_types.h"
@@ -165,7 +166,7 @@ __device__ __forceinline__ float pow300(float x)
 __device__ __forceinline__ unsigned to_u8(float v)
 {
     v = fmin_sel(fmax_sel(v, 0.0f), 1.0f);
-    return (unsigned)(int)floorf(v * 255.0f + 0.5f);
+    return (unsigned)(int)(v * 255.0f + 0.5f);   // v >= 0: truncation == floor
 }
 
 __device__ __forceinline__ V3 safe_inv(V3 d)
@@ -218,7 +219,12 @@ __device__ __forceinline__ int screen_rect(const float *blo, const float *bhi, i
 
 }  // namespace
 
-__global__ __launch_bounds__(256, 4) void raster_kernel(GymView gv, uint32_t *obs, int W, int H)
+#ifdef MV_RASTER_STATS
+__device__ unsigned long long g_raster_stats[8];   // tiles, survivors, straddler survivors, nVis sum, frames
+__device__ unsigned long long g_frame_t0[4096], g_frame_t1[4096], g_frame_tp[4096];
+#endif
+
+__global__ __launch_bounds__(256, 4) void raster_kernel(GymView gv, uint32_t *obs, int W, int H, int split)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // column/row ray tables
     __shared__ Prim s_vis[MAX_PRIMS];     // compacted visible list: straddlers first, then rectangle-bounded primitives
@@ -228,9 +234,18 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(GymView gv, uint32_t *ob
 
     float4 *s_col = reinterpret_cast<float4 *>(s_dyn);   // per column i: (dc.x, c00*dc.x, c10*dc.x, c20*dc.x)
     float4 *s_row = s_col + W;                            // per row j:    (dc.y, c01*dc.y, c11*dc.y, c21*dc.y)
+    float *s_colinv = reinterpret_cast<float *>(s_row + H);   // 1/dc.x per column (0 where dc.x == 0)
+    float *s_rowinv = s_colinv + W;                            // 1/dc.y per row
+    float *s_edgex = s_rowinv + H;                             // frustum slope at pixel edge i, i in [0, W]
+    float *s_edgey = s_edgex + (W + 1);                        // frustum slope at pixel edge j, j in [0, H]
 
+#ifdef MV_RASTER_STATS
+    const unsigned long long t_start = wall_clock64();
+#endif
     const int A = gv.num_agents;
-    const int frame = blockIdx.x;
+    // `split` workgroups share one frame (interleaved tiles): frames differ up to 10x in cost, smaller work
+    // units let the dispatcher level the load across CUs
+    const int frame = blockIdx.x / split, part = blockIdx.x - frame * split;
     const int env = frame / A, viewer = frame - env * A;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -262,11 +277,15 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(GymView gv, uint32_t *ob
         for (int i = tid; i < W; i += 256) {
             const float dcx = (((float(i) + 0.5f) / float(W)) * 2.0f - 1.0f) * TAN_HALF_FOV;
             s_col[i] = make_float4(dcx, c[0] * dcx, c[3] * dcx, c[6] * dcx);
+            s_colinv[i] = dcx == 0.0f ? 0.0f : 1.0f / dcx;
         }
         for (int j = tid; j < H; j += 256) {
             const float dcy = (((float(j) + 0.5f) / float(H)) * 2.0f - 1.0f) * TAN_HALF_FOV_Y;
             s_row[j] = make_float4(dcy, c[1] * dcy, c[4] * dcy, c[7] * dcy);
+            s_rowinv[j] = dcy == 0.0f ? 0.0f : 1.0f / dcy;
         }
+        for (int i = tid; i <= W; i += 256) s_edgex[i] = ((float(i) / float(W)) * 2.0f - 1.0f) * TAN_HALF_FOV;
+        for (int j = tid; j <= H; j += 256) s_edgey[j] = ((float(j) / float(H)) * 2.0f - 1.0f) * TAN_HALF_FOV_Y;
     }
     __syncthreads();   // cameras (incl. origin) complete
 
@@ -394,13 +413,16 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(GymView gv, uint32_t *ob
     const float LIGHT[3] = {0.0f, 4.0f, 2.0f};
     uint32_t *out = obs + (size_t)frame * W * H;
 
+#ifdef MV_RASTER_STATS
+    if (tid == 0 && frame < 4096) { g_frame_t0[frame] = t_start; g_frame_tp[frame] = wall_clock64(); }
+#endif
     // this lane's (frustum plane, straddler) pair: plane-major so that one AND of five 12-bit groups
     // of the ballot gives the straddlers that survive all five planes
     const int sPlane = lane / MAX_STRADDLERS, sIdx = lane - MAX_STRADDLERS * sPlane;
     const bool sActive = sPlane < 5 && sIdx < nStrad;
     const float nzm[3] = {-cam.c[2], -cam.c[5], -cam.c[8]};   // c_k2 * (-1)
 
-    for (int tile = wave; tile < numTiles; tile += 4) {
+    for (int tile = part * 4 + wave; tile < numTiles; tile += 4 * split) {
         const int ty = tile / tilesX, tx = tile - ty * tilesX;
         const int tx0 = tx * TILE_W, ty0 = ty * TILE_H;
         const int tx1 = min(tx0 + TILE_W, W) - 1, ty1 = min(ty0 + TILE_H, H) - 1;
@@ -422,10 +444,10 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(GymView gv, uint32_t *ob
         bool planeOk = false;
         if (sActive) {
             float a;
-            if (sPlane == 0) a = ((float(tx0) / float(W)) * 2.0f - 1.0f) * TAN_HALF_FOV;
-            else if (sPlane == 1) a = -(((float(tx1 + 1) / float(W)) * 2.0f - 1.0f) * TAN_HALF_FOV);
-            else if (sPlane == 2) a = ((float(ty0) / float(H)) * 2.0f - 1.0f) * TAN_HALF_FOV_Y;
-            else a = -(((float(ty1 + 1) / float(H)) * 2.0f - 1.0f) * TAN_HALF_FOV_Y);
+            if (sPlane == 0) a = s_edgex[tx0];
+            else if (sPlane == 1) a = -s_edgex[tx1 + 1];
+            else if (sPlane == 2) a = s_edgey[ty0];
+            else a = -s_edgey[ty1 + 1];
             const V3 nc = sPlane == 0 ? v3(1.0f, 0.0f, a) : sPlane == 1 ? v3(-1.0f, 0.0f, a) : sPlane == 2 ? v3(0.0f, 1.0f, a)
                         : sPlane == 3 ? v3(0.0f, -1.0f, a) : v3(0.0f, 0.0f, -1.0f);
             const V3 nw = mat_mul(cam.c, nc);
@@ -437,10 +459,23 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(GymView gv, uint32_t *ob
                                      (mPlane >> (3 * MAX_STRADDLERS)) & (mPlane >> (4 * MAX_STRADDLERS)) & ((1ull << MAX_STRADDLERS) - 1ull);
         const unsigned long long m0 = __ballot(keep0) | g, m1 = __ballot(keep1);
 
+#ifdef MV_RASTER_STATS
+        if (lane == 0) {
+            atomicAdd(&g_raster_stats[0], 1ull);
+            atomicAdd(&g_raster_stats[1], (unsigned long long)(__popcll(m0) + __popcll(m1)));
+            atomicAdd(&g_raster_stats[2], (unsigned long long)__popcll(g));
+            if (tile == 0) { atomicAdd(&g_raster_stats[3], (unsigned long long)nVis); atomicAdd(&g_raster_stats[4], 1ull); atomicAdd(&g_raster_stats[5], (unsigned long long)nStrad); }
+        }
+#endif
         // ---- this lane's pixel and ray
         const int px = tx0 + (lane & (TILE_W - 1)), py = ty0 + (lane / TILE_W);
+        if ((m0 | m1) == 0ull) {   // nothing can be seen through this tile: clear colour (0,0,0), alpha 255
+            if (px < W && py < H) out[(size_t)py * W + px] = 0xff000000u;
+            continue;
+        }
         const float4 cx = s_col[min(px, W - 1)], ry = s_row[min(py, H - 1)];
         const V3 dc = v3(cx.x, ry.x, -1.0f);
+        const int pxc = min(px, W - 1), pyc = min(py, H - 1);
         const V3 dw = v3((cx.y + ry.y) + nzm[0], (cx.z + ry.z) + nzm[1], (cx.w + ry.w) + nzm[2]);
         const V3 invW = safe_inv(dw);
         const bool anyZero = __any(dw.x == 0.0f || dw.y == 0.0f || dw.z == 0.0f);
@@ -465,7 +500,7 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(GymView gv, uint32_t *ob
                 } else if (qfr == 0) {
                     hit = anyZero ? ray_box<true>(dw, invW, q.lo, q.hi, t) : ray_box<false>(dw, invW, q.lo, q.hi, t);
                 } else if (qfr == 1 + viewer) {
-                    hit = ray_box<true>(dc, safe_inv(dc), q.lo, q.hi, t);
+                    hit = ray_box<true>(dc, v3(s_colinv[pxc], s_rowinv[pyc], -1.0f), q.lo, q.hi, t);
                 } else {
                     const V3 dk = mat_tmul(s_cam[qfr - 1].c, dw);
                     hit = ray_box<true>(dk, safe_inv(dk), q.lo, q.hi, t);
@@ -485,13 +520,16 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(GymView gv, uint32_t *ob
             else {
                 V3 d, inv;
                 if (qfr == 0) { d = dw; inv = invW; }
-                else if (qfr == 1 + viewer) { d = dc; inv = safe_inv(dc); }
+                else if (qfr == 1 + viewer) { d = dc; inv = v3(s_colinv[pxc], s_rowinv[pyc], -1.0f); }
                 else { d = mat_tmul(s_cam[qfr - 1].c, dw); inv = safe_inv(d); }
                 const int axis = entry_axis(d, inv, q.lo, q.hi, best);
                 const float dax = axis == 0 ? d.x : axis == 1 ? d.y : d.z;
                 const float sgn = dax > 0 ? -1.0f : 1.0f;
                 const V3 n = v3(axis == 0 ? sgn : 0.0f, axis == 1 ? sgn : 0.0f, axis == 2 ? sgn : 0.0f);
-                if (qfr == 0) N = mat_tmul(cam.c, n);
+                // C^T (sgn e_axis) == sgn * row `axis` of C (adding exact zeros changes nothing but the sign of a zero)
+                if (qfr == 0) N = v3(sgn * (axis == 0 ? cam.c[0] : axis == 1 ? cam.c[3] : cam.c[6]),
+                                     sgn * (axis == 0 ? cam.c[1] : axis == 1 ? cam.c[4] : cam.c[7]),
+                                     sgn * (axis == 0 ? cam.c[2] : axis == 1 ? cam.c[5] : cam.c[8]));
                 else if (qfr == 1 + viewer) N = n;
                 else N = mat_tmul(cam.c, mat_mul(s_cam[qfr - 1].c, n));
             }
@@ -504,9 +542,15 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(GymView gv, uint32_t *ob
                 const float k2 = 2.0f * dot(N, Ld);
                 const V3 R = v3(k2 * N.x - Ld.x, k2 * N.y - Ld.y, k2 * N.z - Ld.z);
                 V3 Vd = v3(-P.x, -P.y, -P.z);
-                Vd = Vd * (1.0f / sqrtf(len2(Vd)));
-                spec = pow300(fmax_sel(0.0f, dot(Vd, R)));
-                spec = fmin_sel(fmax_sel(spec, 0.0f), 1.0f);
+                // shininess 300: cos^300 is below 1e-20 once cos < 0.86, i.e. far under half an ulp of the
+                // diffuse term it is added to (>= 0.04), so the addition is an exact no-op there.  Only
+                // pixels inside the highlight cone pay for the normalisation and the power.
+                const float vr = dot(Vd, R);
+                if (vr > 0.0f && vr * vr > 0.7225f * len2(Vd)) {   // cos > 0.85 (|R| == 1 up to rounding)
+                    Vd = Vd * (1.0f / sqrtf(len2(Vd)));
+                    spec = pow300(fmax_sel(0.0f, dot(Vd, R)));
+                    spec = fmin_sel(fmax_sel(spec, 0.0f), 1.0f);
+                }
             }
             unsigned ch[3];
 #pragma unroll
@@ -515,13 +559,37 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(GymView gv, uint32_t *ob
         }
         if (px < W && py < H) out[(size_t)py * W + px] = rgba;
     }
+#ifdef MV_RASTER_STATS
+    if (lane == 0 && frame < 4096) atomicMax(&g_frame_t1[frame], wall_clock64());
+#endif
 }
+
+#ifdef MV_RASTER_STATS
+extern "C" void mv_debug_raster_stats(unsigned long long *out8)
+{
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_raster_stats), sizeof(unsigned long long) * 8);
+}
+extern "C" void mv_debug_raster_times(unsigned long long *t0, unsigned long long *tp, unsigned long long *t1, int n)
+{
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(t0, HIP_SYMBOL(g_frame_t0), sizeof(unsigned long long) * n);
+    hipMemcpyFromSymbol(tp, HIP_SYMBOL(g_frame_tp), sizeof(unsigned long long) * n);
+    hipMemcpyFromSymbol(t1, HIP_SYMBOL(g_frame_t1), sizeof(unsigned long long) * n);
+    unsigned long long z[4096] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_frame_t1), z, sizeof(z));
+}
+#endif
 
 int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream)
 {
     if (W > MAX_W || H > MAX_H) return -1;
-    const size_t dyn = (size_t)(W + H) * sizeof(float4);
-    hipLaunchKernelGGL(raster_kernel, dim3(gv.num_envs * gv.num_agents), dim3(256), dyn, stream, gv, obs, W, H);
+    const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)(2 * W + 2 * H + 2) * sizeof(float);
+    static const int envSplit = getenv("MV_RASTER_SPLIT") ? atoi(getenv("MV_RASTER_SPLIT")) : 0;
+    const int tiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H);
+    int split = envSplit > 0 ? envSplit : 4;
+    while (split > 1 && tiles < 4 * split * 2) split >>= 1;   // keep at least two tiles per wave
+    hipLaunchKernelGGL(raster_kernel, dim3(gv.num_envs * gv.num_agents * split), dim3(256), dyn, stream, gv, obs, W, H, split);
     return 0;
 }
 
