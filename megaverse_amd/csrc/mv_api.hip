@@ -52,6 +52,7 @@ struct mv_gym {
     bool closed = false, wasReset = false;
     hipStream_t stream = nullptr;
     GymView gv{};
+    uint8_t *arena = nullptr;
     uint32_t *obs = nullptr, *ownedObs = nullptr, *hiresObs = nullptr;
     int hiresW = 0, hiresH = 0;
     // host mirrors
@@ -215,24 +216,35 @@ int mv_create(const mv_config *cfg, mv_gym **out)
 
     GymView &gv = g->gv;
     gv.num_envs = g->N; gv.num_agents = g->A;
-#define ALLOC(ptr, bytes)                                                          \
-    do {                                                                           \
-        hipError_t e_ = hipMalloc((void **)&(ptr), (bytes));                       \
-        if (e_ != hipSuccess) { mv_destroy(g); return fail(std::string("hipMalloc ") + #ptr + ": " + hipGetErrorString(e_)); } \
-        (void)hipMemset((ptr), 0, (bytes));                                        \
-    } while (0)
-    ALLOC(gv.hdr, N * sizeof(EnvHeader));
-    ALLOC(gv.boxes, N * MAX_BOXES * sizeof(LayoutBox));
-    ALLOC(gv.objects, N * MAX_OBJECTS * sizeof(MovableObject));
-    ALLOC(gv.agents, NA * sizeof(AgentState));
-    ALLOC(gv.chunk, N * (size_t)CHUNK_BYTES);
-    ALLOC(gv.actions, NA * sizeof(int32_t));
-    ALLOC(gv.rewards, NA * sizeof(float));
-    ALLOC(gv.done, N);
-    ALLOC(gv.true_objective, NA * sizeof(float));
-    ALLOC(g->ownedObs, NA * (size_t)g->w * g->h * 4);
-    ALLOC(g->dMultiDiscrete, NA * 6 * sizeof(int32_t));
-#undef ALLOC
+    // ONE arena for all simulator state: a step touches ~8 arrays per env, separate small allocations
+    // cost a TLB miss each per wave (measured: 83 % of the physics kernel's time was spent waiting on
+    // ~30 memory operations); one large allocation is backed by large pages.
+    auto up = [](size_t v) { return (v + 4095) & ~size_t(4095); };
+    const size_t szHdr = up(N * sizeof(EnvHeader)), szBoxes = up(N * MAX_BOXES * sizeof(LayoutBox)),
+                 szObj = up(N * MAX_OBJECTS * sizeof(MovableObject)), szAg = up(NA * sizeof(AgentState)),
+                 szChunk = up(N * (size_t)CHUNK_BYTES), szAct = up(NA * sizeof(int32_t)), szRew = up(NA * sizeof(float)),
+                 szDone = up(N), szObjv = up(NA * sizeof(float)), szMd = up(NA * 6 * sizeof(int32_t)),
+                 szObs = up(NA * (size_t)g->w * g->h * 4);
+    const size_t total = szHdr + szBoxes + szObj + szAg + szAct + szRew + szDone + szObjv + szMd + szChunk + szObs;
+    {
+        hipError_t e_ = hipMalloc((void **)&g->arena, total);
+        if (e_ != hipSuccess) { mv_destroy(g); return fail(std::string("hipMalloc arena: ") + hipGetErrorString(e_)); }
+        (void)hipMemset(g->arena, 0, total);
+    }
+    {
+        uint8_t *p = g->arena;
+        gv.hdr = (EnvHeader *)p; p += szHdr;
+        gv.boxes = (LayoutBox *)p; p += szBoxes;
+        gv.objects = (MovableObject *)p; p += szObj;
+        gv.agents = (AgentState *)p; p += szAg;
+        gv.actions = (int32_t *)p; p += szAct;
+        gv.rewards = (float *)p; p += szRew;
+        gv.done = p; p += szDone;
+        gv.true_objective = (float *)p; p += szObjv;
+        g->dMultiDiscrete = (int32_t *)p; p += szMd;
+        gv.chunk = p; p += szChunk;
+        g->ownedObs = (uint32_t *)p; p += szObs;
+    }
     g->obs = g->ownedObs;
     for (int b = 0; b < 2; ++b) {
         if (hipHostMalloc((void **)&g->hActions[b], NA * sizeof(int32_t), hipHostMallocDefault) != hipSuccess ||
@@ -279,10 +291,9 @@ int mv_close(mv_gym *g)
     (void)hipSetDevice(g->device);
     (void)hipStreamSynchronize(g->stream);
     GymView &gv = g->gv;
-    void *ptrs[] = {gv.hdr, gv.boxes, gv.objects, gv.agents, gv.chunk, gv.actions, gv.rewards, gv.done, gv.true_objective,
-                    g->ownedObs, g->hiresObs, g->dMultiDiscrete};
-    for (void *p : ptrs)
-        if (p) (void)hipFree(p);
+    if (g->arena) (void)hipFree(g->arena);
+    if (g->hiresObs) (void)hipFree(g->hiresObs);
+    g->arena = nullptr;
     for (int b = 0; b < 2; ++b) {
         if (g->hActions[b]) (void)hipHostFree(g->hActions[b]);
         if (g->actionsCopied[b]) (void)hipEventDestroy(g->actionsCopied[b]);

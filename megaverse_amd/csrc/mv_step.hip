@@ -397,10 +397,19 @@ __device__ __forceinline__ unsigned long long column_objects(const ObjRegs &o, i
     return m;
 }
 
-__device__ __forceinline__ bool in_zone(const EnvHeader &h, int x, int z) { return x >= h.bz[0] && x < h.bz[1] && z >= h.bz[2] && z < h.bz[3]; }
+// The fields of EnvHeader a tick reads or writes, as scalars.  Copying the whole 128-byte record made
+// hipcc keep its array members in an LDS "promoted alloca", which in turn made every wave read the
+// workgroup size from the AQL dispatch packet in host memory: 16-20 us of a 35 us kernel.
+struct Hdr {
+    int num_objects, num_boxes, num_frames, done, highest_tower;
+    int bz0, bz1, bz2, bz3;
+    float episode_sec, episode_len, bz_reward, bar_half_width, p_vertical_look_limit;
+};
+
+__device__ __forceinline__ bool in_zone(const Hdr &h, int x, int z) { return x >= h.bz0 && x < h.bz1 && z >= h.bz2 && z < h.bz3; }
 
 // sum over objects in index order (float addition order is part of the contract)
-__device__ __forceinline__ float tower_reward(const EnvHeader &h, const ObjRegs &o)
+__device__ __forceinline__ float tower_reward(const Hdr &h, const ObjRegs &o)
 {
     float term[2];
 #pragma unroll
@@ -451,7 +460,13 @@ __global__ __launch_bounds__(64) void step_kernel(GymView gv)
     if (env >= gv.num_envs) return;
     const int A = gv.num_agents;
 
-    EnvHeader h = gv.hdr[env];
+    const EnvHeader *gh = gv.hdr + env;
+    Hdr h;
+    h.num_objects = gh->num_objects; h.num_boxes = gh->num_boxes; h.num_frames = gh->num_frames; h.done = gh->done;
+    h.highest_tower = gh->highest_tower;
+    h.bz0 = gh->bz[0]; h.bz1 = gh->bz[1]; h.bz2 = gh->bz[2]; h.bz3 = gh->bz[3];
+    h.episode_sec = gh->episode_sec; h.episode_len = gh->episode_len; h.bz_reward = gh->bz_reward;
+    h.bar_half_width = gh->bar_half_width; h.p_vertical_look_limit = gh->p_vertical_look_limit;
     uint8_t *chunk = gv.chunk + (size_t)env * CHUNK_BYTES;
     auto vox = [&](int x, int y, int z) -> unsigned { return in_chunk(x, y, z) ? (unsigned)chunk[(y * CZ + z) * CX + x] : 0u; };
 
@@ -672,14 +687,25 @@ __global__ __launch_bounds__(64) void step_kernel(GymView gv)
             gobjw[oi[k]] = o;
         }
     if (lane == 0) {
-        gv.hdr[env] = h;
+        EnvHeader *wh = gv.hdr + env;
+        wh->num_frames = h.num_frames; wh->done = h.done; wh->highest_tower = h.highest_tower;
+        wh->episode_sec = h.episode_sec; wh->bz_reward = h.bz_reward; wh->bar_half_width = h.bar_half_width;
         gv.done[env] = (uint8_t)h.done;
     }
 #pragma unroll
     for (int i = 0; i < A_MAX; ++i)
         if (i < A && lane == i) {
             ag[i].total_reward += ag[i].last_reward;
-            gv.agents[(size_t)env * A + i] = ag[i];
+            // store the fields a tick can change (everything before `shaping`); writing the whole 128 B record
+            // would force the unchanged tail to be carried in scratch memory for the whole kernel
+            AgentState *dst = gv.agents + (size_t)env * A + i;
+            const AgentState &a = ag[i];
+            dst->pos[0] = a.pos[0]; dst->pos[1] = a.pos[1]; dst->pos[2] = a.pos[2];
+            dst->m00 = a.m00; dst->m02 = a.m02; dst->m20 = a.m20; dst->m22 = a.m22; dst->pitch = a.pitch;
+            dst->hvx = a.hvx; dst->hvz = a.hvz; dst->vvel = a.vvel; dst->voffset = a.voffset;
+            dst->step_offset = a.step_offset; dst->jump_speed = a.jump_speed;
+            dst->was_jumping = a.was_jumping; dst->carrying = a.carrying; dst->picked_up = a.picked_up; dst->visited_zone = a.visited_zone;
+            dst->last_reward = a.last_reward; dst->total_reward = a.total_reward;
             gv.actions[(size_t)env * A + i] = 0;
             gv.rewards[(size_t)env * A + i] = ag[i].last_reward;   // zeroed by the reset kernel if done
             if (h.done) gv.true_objective[(size_t)env * A + i] = float(h.highest_tower);   // vector_env.cpp:97-98
