@@ -143,6 +143,13 @@ def main():
         # physics kernel: header + boxes + objects + agent state read+write + action/reward/done
         step_bytes_per_env = 2 * 128 + 512 + 2 * 320 + A * (2 * 128 + 4 + 4 + 4) + 1
         step_ms = prof["step"][0]
+        traffic = None
+        try:   # HBM bytes per raster launch from the committed PMC passes (profiles/), only for the profiled config
+            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if pt["config"] == {"envs_per_gpu": n_env, "agents_per_env": A, "obs": [W, H]}:
+                traffic = pt["kernels"]["mv::raster_kernel"]["traffic_bytes_per_launch"]
+        except Exception:  # noqa: BLE001
+            pass
         line = {
             "metric": METRIC, "value": total_obs / elapsed, "unit": "agent observations/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
@@ -152,9 +159,10 @@ def main():
                        "envs_per_gpu": n_env, "agents_per_env": A, "obs": [W, H], "gather_obs": bool(gathered is not None),
                        "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "kernel": "mv::raster_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": raster_ms, "launches_timed": prof["raster"][1],
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": raster_ms, "launches_timed": prof["raster"][1],
                          "algorithmic_bytes_per_launch": bytes_per_frame * frames,
-                         "note": "VALU-bound ray casting: HBM fraction is low by construction, see DESIGN.md"},
+                         "note": "traffic = HBM bytes/launch from rocprofv3 PMC (profiles/pmc_traffic.json); the kernel is VALU/issue-bound ray casting, "
+                                 "so the HBM fraction is low by construction (DESIGN.md 3.3)"},
             "kernels": {"step": {"avg_launch_ms": step_ms, "algorithmic_GBps": step_bytes_per_env * n_env / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0,
                                  "algorithmic_bytes_per_launch": step_bytes_per_env * n_env},
                         "reset": {"avg_launch_ms": prof["reset"][0]}},

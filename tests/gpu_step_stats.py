@@ -11,9 +11,12 @@ g.seed(42); g.reset()
 for st in range(300):
     g.sample_random_actions(1234, st); g.step_no_render()
 out = (C.c_ulonglong * 16)()
+t0 = np.zeros(1024, np.uint64); t1 = np.zeros(1024, np.uint64)
 lib.mv_debug_step_stats.argtypes = [C.c_void_p] * 3
-lib.mv_debug_step_stats(C.addressof(out), None, None)
+lib.mv_debug_step_stats(C.addressof(out), t0.ctypes.data, t1.ctypes.data)
 n = out[15]
-names = ["kernarg", "actions[env] dword", "hdr.L dword", "hdr.pad[8] dword (same line)", "agents.pad dword", "objects (64 lanes)", "hdr struct 128B"]
-for i, nm in enumerate(names): print(f"  {nm:32s} {out[i]/n*10:.0f} ns")
-print("  rest", (out[10])/n*10, "ns")
+names = ["loads+colliders", "intents", "physics", "scenario", "timers+stores"]
+for i, nm in enumerate(names): print(f"  {nm:28s} {out[i]/n*10:.0f} ns")
+b = t0.min(); st = (t0 - b).astype(float) * 10; en = (t1 - b).astype(float) * 10
+print("last-step wave starts ns: min/med/p90/max", st.min(), np.median(st), np.percentile(st, 90), st.max())
+print("ends ns: min/med/p90/max", en.min(), np.median(en), np.percentile(en, 90), en.max(), " durations med/p90/max", np.median(en - st), np.percentile(en-st, 90), (en - st).max())
