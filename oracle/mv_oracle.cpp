@@ -26,6 +26,7 @@
 #include <memory>
 #include <mutex>
 #include <random>
+#include <set>
 #include <string>
 #include <thread>
 #include <vector>
@@ -71,7 +72,10 @@ static const float OBJ_COLL_YOFF = -0.05f;            // :182 collision offset
 static const float CARRY_SCALE = 0.78f;               // :63
 
 enum { CX = 32, CY = 16, CZ = 32, CHUNK = CX * CY * CZ };
-enum { MAX_BOXES = 16, MAX_OBJECTS = 80, MAX_AGENTS = 8 };
+enum { MAX_BOXES = 128, MAX_OBJECTS = 80, MAX_AGENTS = 8, MAX_TERRAIN = 16, MAX_REWARDS = 16, MAX_SHAPING = 8 };
+enum { SCN_TOWER = 0, SCN_OBSTACLES = 1 };
+enum { TERRAIN_EXIT = 1, TERRAIN_LAVA = 2, TERRAIN_BUILDING_ZONE = 4 };   // scenarios/platforms.hpp:28-34
+static const unsigned COLOR_EXIT_PAD = 0x50c878, COLOR_RED = 0xff0000, COLOR_GREEN = 0x3bb372;   // const.hpp:25-56
 
 // voxel byte: voxel_state.hpp:10-37 + platforms.hpp:28-34 folded into one byte per cell
 enum { VX_SOLID = 1, VX_OPAQUE = 2, VX_OBJECT = 4, VX_TERRAIN_SHIFT = 3, VX_COLOR_SHIFT = 6 };
@@ -145,6 +149,16 @@ struct Box {  // merged layout parallelepiped, voxel units, max exclusive
     int type, slot;
 };
 
+struct TerrainBox {  // platforms.hpp terrainBoxes, voxel units, max exclusive
+    int min[3], max[3];
+    int type;
+};
+
+struct RewardObj {  // green diamond, scenario_obstacles.cpp:251-258
+    int x, y, z;
+    int active;
+};
+
 struct Object {  // movable box: component_object_stacking.hpp:170-198
     int x, y, z;
     int state;  // 0 = placed at voxel, 1+k = carried by agent k
@@ -160,18 +174,36 @@ struct Agent {
     float jump_speed;            // m_jumpSpeed (10 until first jump)
     int was_jumping;
     int carrying;                // object index or -1
-    int picked_up, visited_zone; // scenario_tower_building.hpp:24-28
+    int picked_up, visited_zone; // scenario_tower_building.hpp:24-28 ; Obstacles: visited_zone == agentReachedExit
     int spawn[3];                // fallDetection.agentInitialPositions
     float last_reward, total_reward;
-    float shaping[4];            // teamSpirit, towerPickedUpObject, towerVisitedBuildingZoneWithObject, towerBuildingReward
+    float shaping[MAX_SHAPING];  // per scenario, see SHAPING_KEYS_*
     int action;                  // bitmask env.hpp:22-42
 };
 
-static const char *SHAPING_KEYS[4] = {"teamSpirit", "towerPickedUpObject", "towerVisitedBuildingZoneWithObject",
-                                     "towerBuildingReward"};
-static const float SHAPING_DEFAULT[4] = {0.1f, 0.1f, 0.1f, 1.0f};  // scenario_tower_building.hpp:44-52
+static const char *SHAPING_KEYS_TOWER[4] = {"teamSpirit", "towerPickedUpObject", "towerVisitedBuildingZoneWithObject",
+                                           "towerBuildingReward"};
+static const float SHAPING_DEFAULT_TOWER[4] = {0.1f, 0.1f, 0.1f, 1.0f};  // scenario_tower_building.hpp:44-52
+// scenario_obstacles.hpp:36-44 (+ Scenario::init teamSpirit 0, scenario.hpp:94-103)
+static const char *SHAPING_KEYS_OBST[5] = {"teamSpirit", "obstaclesAgentAtExit", "obstaclesAllAgentsAtExit", "obstaclesExtraReward",
+                                          "obstaclesAgentCarriedObjectToExit"};
+static const float SHAPING_DEFAULT_OBST[5] = {0.0f, 1.0f, 5.0f, 0.5f, 0.0f};
+
+enum { PT_EMPTY = 0, PT_WALL, PT_LAVA, PT_STEP, PT_GAP, PT_START, PT_EXIT, PT_TRANSITION };
+struct ObstacleParams {  // scenario_obstacles.hpp:46-68 defaults, overridden per registered name :94-268
+    int minPlatforms = 1, maxPlatforms = 2, minGap = 1, maxGap = 2, minLava = 1, maxLava = 4, minHeight = 1, maxHeight = 3;
+    int numAllowedMaxDifficulty = 1;
+    std::vector<int> platformTypes = {PT_WALL, PT_LAVA, PT_STEP, PT_GAP};
+};
 
 struct Env {
+    int scenario = SCN_TOWER;
+    ObstacleParams op;
+    int numShaping = 4;
+    const char *const *shapingKeys = SHAPING_KEYS_TOWER;
+    int numTerrain = 0, numRewards = 0, numPlatforms = 0, solved = 0;
+    TerrainBox terrain[MAX_TERRAIN];
+    RewardObj rewards[MAX_REWARDS];
     int numAgents = 1;
     Rng rng{std::random_device{}()};  // env.hpp:169
     // float params (scenario.hpp:225-232)
@@ -284,13 +316,34 @@ static float tower_reward(const Env &e)
     return r;
 }
 
-static void env_reset(Env &e)
-{
-    // ---- Env::reset, env/src/env.cpp:57-76 ; EnvState::reset env.hpp:135-151
-    e.done = 0; e.episodeSec = 0; e.numFrames = 0;
-    const int seed = randRange(0, 1 << 30, e.rng);
-    e.rng.seed((unsigned long)seed);
+struct C3 { int x, y, z; };
 
+// DefaultScenario::spawnAgents, scenario_default.hpp:80-97 ; agent ctor agent.cpp:24-65
+static void spawn_agents(Env &e, const std::vector<C3> &spawns)
+{
+    for (int i = 0; i < e.numAgents; ++i) {
+        const C3 sp = spawns[i < int(spawns.size()) ? i : 0];
+        Agent &a = e.agents[i];
+        float keepShaping[MAX_SHAPING];
+        std::memcpy(keepShaping, a.shaping, sizeof keepShaping);
+        const float randomRotation = frand(e.rng) * PI_F * 2;
+        float c, s;
+        yaw_matrix(randomRotation, &c, &s);
+        a.pos = v3(float(sp.x) + 0.5f, float(sp.y) + 0.0f + AGENT_HEIGHT, float(sp.z) + 0.5f);
+        a.m00 = c; a.m02 = s; a.m20 = -s; a.m22 = c;
+        a.pitch = 0;
+        a.hvx = a.hvz = 0; a.vvel = 0; a.voffset = 0; a.step_offset = 0; a.jump_speed = 10.0f; a.was_jumping = 0;
+        a.carrying = -1; a.picked_up = 0; a.visited_zone = 0;
+        a.spawn[0] = sp.x; a.spawn[1] = sp.y; a.spawn[2] = sp.z;
+        a.last_reward = 0; a.total_reward = 0; a.action = 0;
+        std::memcpy(a.shaping, keepShaping, sizeof keepShaping);
+    }
+}
+
+static void obstacles_generate(Env &e);
+
+static void tower_generate(Env &e)
+{
     // ---- TowerBuildingScenario::reset, scenario_tower_building.cpp:129-154
     std::fill(e.chunk.begin(), e.chunk.end(), 0);
     unsigned layoutColor = randomLayoutColor(e.rng);
@@ -309,7 +362,6 @@ static void env_reset(Env &e)
     const int bzX = randRange(1, length - bzL - 1, rng), bzZ = randRange(1, width - bzW - 1, rng);
     const int matX = randRange(1, length - matL - 1, rng), matZ = randRange(1, width - matW - 1, rng);
 
-    struct C3 { int x, y, z; };
     std::vector<C3> cand;
     for (int x = 1; x < length - 1; ++x)
         for (int z = 1; z < width - 1; ++z) cand.push_back(C3{x, 2, z});
@@ -360,24 +412,397 @@ static void env_reset(Env &e)
     e.episodeLen = e.p_episodeLengthSec + 4.0f * float(e.numObjects);
     e.barHalfWidth = 0.24f;
 
-    // ---- DefaultScenario::spawnAgents, scenario_default.hpp:80-97 ; agent ctor agent.cpp:24-65
-    for (int i = 0; i < A; ++i) {
-        const C3 sp = cand[i < nAgentSpawns ? i : 0];
-        Agent &a = e.agents[i];
-        float keepShaping[4];
-        std::memcpy(keepShaping, a.shaping, sizeof keepShaping);
-        const float randomRotation = frand(rng) * PI_F * 2;
-        float c, s;
-        yaw_matrix(randomRotation, &c, &s);
-        a.pos = v3(float(sp.x) + 0.5f, float(sp.y) + 0.0f + AGENT_HEIGHT, float(sp.z) + 0.5f);
-        a.m00 = c; a.m02 = s; a.m20 = -s; a.m22 = c;
-        a.pitch = 0;
-        a.hvx = a.hvz = 0; a.vvel = 0; a.voffset = 0; a.step_offset = 0; a.jump_speed = 10.0f; a.was_jumping = 0;
-        a.carrying = -1; a.picked_up = 0; a.visited_zone = 0;
-        a.spawn[0] = sp.x; a.spawn[1] = sp.y; a.spawn[2] = sp.z;
-        a.last_reward = 0; a.total_reward = 0; a.action = 0;
-        std::memcpy(a.shaping, keepShaping, sizeof keepShaping);
+    e.numTerrain = 0; e.numRewards = 0; e.numPlatforms = 0; e.solved = 0;
+    spawn_agents(e, std::vector<C3>(cand.begin(), cand.begin() + nAgentSpawns));
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Obstacles family -- scenario_obstacles.cpp:51-195 + platforms.hpp:137-557.
+// The reference places platforms with a Magnum scene graph (90-degree rotations about Y and integer
+// translations) and reads boxes back with lround(); restated with exact integer rigid transforms.
+// ------------------------------------------------------------------------------------------------
+struct Xf {   // p -> R^rot(p) + t,  R = +90 deg about Y: (x, y, z) -> (z, y, -x)
+    int rot = 0;
+    int t[3] = {0, 0, 0};
+};
+static void xf_rot(int rot, const int p[3], int out[3])
+{
+    int x = p[0], y = p[1], z = p[2];
+    for (int i = 0; i < (rot & 3); ++i) { const int nx = z, nz = -x; x = nx; z = nz; }
+    out[0] = x; out[1] = y; out[2] = z;
+}
+static void xf_apply(const Xf &a, const int p[3], int out[3])
+{
+    int r[3];
+    xf_rot(a.rot, p, r);
+    for (int k = 0; k < 3; ++k) out[k] = r[k] + a.t[k];
+}
+static Xf xf_compose(const Xf &a, const Xf &b)   // p -> a(b(p))
+{
+    Xf c;
+    c.rot = (a.rot + b.rot) & 3;
+    xf_apply(a, b.t, c.t);
+    return c;
+}
+// Object3D::rotateYLocal(deg) followed by translateLocal(v): p -> R(p + v)
+static Xf xf_local(int rot, int vx, int vy, int vz)
+{
+    Xf c;
+    c.rot = rot & 3;
+    const int v[3] = {vx, vy, vz};
+    xf_rot(c.rot, v, c.t);
+    return c;
+}
+
+struct BoxI { int min[3], max[3]; };
+static BoxI box_abs(const Xf &root, const BoxI &local)
+{   // MagnumAABB::boundingBox, platforms.hpp:126-133: transform min/max, then sort
+    BoxI b;
+    xf_apply(root, local.min, b.min);
+    xf_apply(root, local.max, b.max);
+    for (int k = 0; k < 3; ++k) if (b.min[k] > b.max[k]) std::swap(b.min[k], b.max[k]);
+    return b;
+}
+enum { WALLS_SOUTH = 1, WALLS_NORTH = 2, WALLS_WEST = 4, WALLS_EAST = 8 };
+
+struct Plat {
+    int kind = PT_EMPTY, walls = 0, length = 0, height = 0, width = -1;
+    Xf parent, local, root;          // root = parent o local
+    int anchorY = 0;                 // nextPlatformAnchor = root o translate(length, anchorY, 0)
+    std::vector<BoxI> layout, wallsB;            // root-local boxes
+    std::vector<std::pair<int, BoxI>> terrain;   // (type, root-local box)
+    std::map<std::pair<int, int>, int> occupancy;
+    int wallHeight = 0, lavaLength = 0, stepHeight = 0, gap = 0, gapX = 0;
+
+    Xf anchor() const { return xf_compose(root, xf_local(0, length, anchorY, 0)); }
+    void updateRoot() { root = xf_compose(parent, local); }
+    void addFloor() { layout.push_back(BoxI{{0, 0, 0}, {length, 1, width}}); }   // platforms.hpp:167-176
+    void addWalls()
+    {   // :178-190
+        if (walls & WALLS_SOUTH) wallsB.push_back(BoxI{{0, 0, 0}, {1, height, width}});
+        if (walls & WALLS_NORTH) wallsB.push_back(BoxI{{length - 1, 0, 0}, {length, height, width}});
+        if (walls & WALLS_EAST) wallsB.push_back(BoxI{{0, 0, 0}, {length, height, 1}});
+        if (walls & WALLS_WEST) wallsB.push_back(BoxI{{0, 0, width - 1}, {length, height, width}});
     }
+    BoxI outerBox() const
+    {   // platformBoundingBox :192-214
+        BoxI o{{0, 0, 0}, {0, 0, 0}};
+        if (!layout.empty()) o = box_abs(root, layout.front());
+        else if (!wallsB.empty()) o = box_abs(root, wallsB.front());
+        auto add = [&](const BoxI &b) {
+            for (int k = 0; k < 3; ++k) { o.min[k] = std::min(o.min[k], std::min(b.min[k], b.max[k])); o.max[k] = std::max(o.max[k], std::max(b.min[k], b.max[k])); }
+        };
+        for (auto &b : layout) add(box_abs(root, b));
+        for (auto &b : wallsB) add(box_abs(root, b));
+        return o;
+    }
+    bool isMaxDifficulty(const ObstacleParams &op) const
+    {
+        if (kind == PT_WALL) return wallHeight >= op.maxHeight;
+        if (kind == PT_LAVA) return lavaLength >= op.maxLava;
+        if (kind == PT_STEP) return stepHeight >= op.maxHeight;
+        return false;
+    }
+    int requiresBoxes() const
+    {
+        auto tri = [](int n) { return n * (n + 1) / 2; };   // util/math_utils.hpp:7-10
+        if (kind == PT_WALL) return tri(wallHeight - 1);
+        if (kind == PT_LAVA) return std::max(1, lavaLength - 1);
+        if (kind == PT_STEP) return tri(stepHeight - 1);
+        if (kind == PT_GAP) return tri(std::max(0, gap - 2));
+        return 0;
+    }
+    void init(Rng &rng, const ObstacleParams &op)
+    {
+        if (kind == PT_TRANSITION) { height = 5; return; }   // :556
+        length = randRange(4, 10, rng);                       // EmptyPlatform::init :314-321
+        if (width == -1) width = randRange(5, 9, rng);
+        height = 5;
+        if (kind == PT_WALL) {
+            wallHeight = randRange(op.minHeight, op.maxHeight + 1, rng);
+            height = randRange(wallHeight + 4, wallHeight + 6, rng);
+        } else if (kind == PT_LAVA) {
+            length = randRange(6, 12, rng);
+            const int minLava = std::min(op.minLava, length - 2), maxLava = std::min(op.maxLava + 1, length - 1);
+            lavaLength = randRange(minLava, maxLava, rng);
+        } else if (kind == PT_STEP) {
+            stepHeight = randRange(op.minHeight, op.maxHeight + 1, rng);
+            height = randRange(stepHeight + 2, stepHeight + 5, rng);
+        } else if (kind == PT_GAP) {
+            gap = randRange(op.minGap, std::min(op.maxGap + 1, length - 1), rng);
+            gapX = randRange(1, length - gap, rng);
+        }
+    }
+    void generate(Rng &rng)
+    {
+        if (kind == PT_STEP) {   // :440-461
+            const int stepX = randRange(1, length, rng);
+            layout.push_back(BoxI{{0, 0, 0}, {stepX + 1, 1, width}});
+            layout.push_back(BoxI{{stepX, stepHeight, 0}, {length, stepHeight + 1, width}});
+            layout.push_back(BoxI{{stepX, 0, 0}, {stepX + 1, stepHeight + 1, width}});
+            anchorY = stepHeight;
+            addWalls();
+            for (int x = stepX + 1; x < length; ++x)
+                for (int z = 1; z < width; ++z) occupancy[{x, z}] = stepHeight;
+            return;
+        }
+        if (kind == PT_GAP) {   // :490-501
+            layout.push_back(BoxI{{0, 0, 0}, {gapX, 1, width}});
+            layout.push_back(BoxI{{gapX + gap, 0, 0}, {length, 1, width}});
+            addWalls();
+            return;
+        }
+        addFloor();
+        addWalls();
+        if (kind == PT_WALL) {   // :352-366
+            const int wallX = randRange(1, length, rng);
+            const int wallThickness = randRange(1, length - wallX + 1, rng);
+            layout.push_back(BoxI{{wallX, 1, 1}, {wallX + wallThickness, 1 + wallHeight, width - 1}});
+            for (int x = wallX; x < wallX + wallThickness; ++x)
+                for (int z = 1; z < width; ++z) occupancy[{x, z}] = wallHeight;
+        } else if (kind == PT_LAVA) {   // :401-409
+            const int lavaX = randRange(1, length - lavaLength, rng);
+            terrain.push_back({TERRAIN_LAVA, BoxI{{lavaX, 1, 1}, {lavaX + lavaLength, 2, width - 1}}});
+        } else if (kind == PT_EXIT) {   // :535-541
+            terrain.push_back({TERRAIN_EXIT, BoxI{{length - 3, 1, 1}, {length - 1, 3, width - 1}}});
+        }
+    }
+    C3 adjust(int x, int y, int z) const
+    {   // adjustTransformation :280-288: voxel centre through the root transform, then floor
+        const int rx = (root.rot & 3);
+        // centre (x+.5, y+.5, z+.5) -> R^rot -> + t -> floor, done in doubled integer coordinates
+        int p2[3] = {2 * x + 1, 2 * y + 1, 2 * z + 1}, r2[3];
+        xf_rot(rx, p2, r2);
+        auto fl = [](int twice) { return (twice >= 0) ? twice / 2 : -((-twice + 1) / 2); };
+        return C3{fl(r2[0] + 2 * root.t[0]), fl(r2[1] + 2 * root.t[1]), fl(r2[2] + 2 * root.t[2])};
+    }
+    std::vector<C3> objectPositions(int n, Rng &rng)
+    {
+        std::vector<C3> out;
+        if (kind == PT_GAP) {   // :505-523
+            std::vector<C3> cand;
+            for (int x = 0; x < length; ++x)
+                for (int z = 1; z < width - 1; ++z) {
+                    if (x >= gapX && x < gapX + gap) continue;
+                    cand.push_back(C3{x, 1, z});
+                }
+            for (int i = 0; i < n; ++i) {
+                const C3 v = cand[randRange(0, int(cand.size()), rng)];
+                const int y = ++occupancy[{v.x, v.z}];
+                out.push_back(adjust(v.x, y, v.z));
+            }
+            return out;
+        }
+        for (int i = 0; i < n; ++i)   // Platform::generateObjectPositions :261-278
+            for (int attempt = 0; attempt < 10; ++attempt) {
+                const int x = randRange(1, length - 1, rng);
+                const int z = randRange(1, width - 1, rng);
+                if (occupancy[{x, z}] < 2 || attempt >= 9) {
+                    const int y = ++occupancy[{x, z}];
+                    out.push_back(adjust(x, y, z));
+                    break;
+                }
+            }
+        return out;
+    }
+};
+
+static bool boxes_collide(const BoxI &a, const BoxI &b)
+{   // BoundingBox::collidesWith :93-104
+    for (int k = 0; k < 3; ++k) if (a.max[k] <= b.min[k] || a.min[k] >= b.max[k]) return false;
+    return true;
+}
+
+// Canonical greedy merge on a dense grid spanning the level's bounding box (same rule as merge_boxes).
+static void merge_dense(const std::vector<uint8_t> &g, const int org[3], const int dim[3], Env &e)
+{
+    auto cell = [&](int x, int y, int z) { return (size_t(y) * dim[2] + z) * dim[0] + x; };
+    std::vector<uint8_t> visited(g.size(), 0);
+    e.numBoxes = 0;
+    for (int key = 0; key < 16; ++key) {
+        const int type = key >> 2, slot = key & 3;
+        if (type == 0) continue;
+        auto match = [&](int x, int y, int z) {
+            if (x < 0 || y < 0 || z < 0 || x >= dim[0] || y >= dim[1] || z >= dim[2]) return false;
+            const size_t c = cell(x, y, z);
+            return !visited[c] && (g[c] & 3) == type && (g[c] >> VX_COLOR_SHIFT) == slot;
+        };
+        for (int y = 0; y < dim[1]; ++y)
+            for (int z = 0; z < dim[2]; ++z)
+                for (int x = 0; x < dim[0]; ++x) {
+                    if (!match(x, y, z)) continue;
+                    int x1 = x;
+                    while (match(x1 + 1, y, z)) ++x1;
+                    int z1 = z;
+                    for (;;) { bool ok = true; for (int xx = x; xx <= x1 && ok; ++xx) ok = match(xx, y, z1 + 1); if (!ok) break; ++z1; }
+                    int y1 = y;
+                    for (;;) {
+                        bool ok = true;
+                        for (int zz = z; zz <= z1 && ok; ++zz) for (int xx = x; xx <= x1 && ok; ++xx) ok = match(xx, y1 + 1, zz);
+                        if (!ok) break;
+                        ++y1;
+                    }
+                    for (int yy = y; yy <= y1; ++yy) for (int zz = z; zz <= z1; ++zz) for (int xx = x; xx <= x1; ++xx) visited[cell(xx, yy, zz)] = 1;
+                    if (e.numBoxes < MAX_BOXES) {
+                        Box &b = e.boxes[e.numBoxes++];
+                        b.min[0] = x + org[0]; b.min[1] = y + org[1]; b.min[2] = z + org[2];
+                        b.max[0] = x1 + 1 + org[0]; b.max[1] = y1 + 1 + org[1]; b.max[2] = z1 + 1 + org[2];
+                        b.type = type; b.slot = slot;
+                    }
+                }
+    }
+}
+
+static void obstacles_generate(Env &e)
+{
+    Rng &rng = e.rng;
+    const ObstacleParams &op = e.op;
+    const bool drawWalls = randRange(0, 2, rng);   // scenario_obstacles.cpp:63
+    std::vector<Plat> platforms;
+    int numPlatforms = 0;
+    for (int attempt = 0; attempt < 20; ++attempt) {   // :68-156
+        platforms.clear();
+        numPlatforms = randRange(op.minPlatforms, op.maxPlatforms + 1, rng);
+        Plat start; start.kind = PT_START; start.walls = WALLS_SOUTH | WALLS_EAST | WALLS_WEST;
+        start.init(rng, op); start.updateRoot(); start.generate(rng);
+        int requiredWidth = start.width;
+        platforms.push_back(start);
+        size_t prev = 0;
+        int numMax = 0;
+        for (int i = 0; i < numPlatforms; ++i) {
+            const int orientation = randRange(0, 3, rng);   // randomSample({STRAIGHT, LEFT, RIGHT})
+            requiredWidth = orientation == 0 ? requiredWidth : -1;
+            Plat np;
+            bool have = false;
+            while (!have || (np.isMaxDifficulty(op) && numMax >= op.numAllowedMaxDifficulty)) {
+                np = Plat();
+                np.kind = op.platformTypes[randRange(0, int(op.platformTypes.size()), rng)];
+                np.walls = WALLS_WEST | WALLS_EAST; np.width = requiredWidth;
+                np.init(rng, op);
+                have = true;
+            }
+            if (np.isMaxDifficulty(op)) ++numMax;
+            np.parent = platforms[prev].anchor();
+            np.updateRoot();
+            np.generate(rng);
+            if (orientation == 1) np.local = xf_local(1, -1, 0, -1);                                   // rotateCCW :149-153
+            else if (orientation == 2) np.local = xf_local(3, platforms[prev].width - 1, 0, -np.width + 1);   // rotateCW :155-159
+            np.updateRoot();
+            platforms.push_back(np);
+            const size_t cur = platforms.size() - 1;
+            if (orientation != 0) {   // :128-138
+                Plat tr; tr.kind = PT_TRANSITION;
+                tr.walls = WALLS_NORTH | (orientation == 1 ? WALLS_WEST : WALLS_EAST);
+                tr.length = platforms[cur].width - 1; tr.width = platforms[prev].width;
+                tr.parent = platforms[prev].anchor(); tr.updateRoot();
+                tr.init(rng, op); tr.generate(rng);
+                platforms.push_back(tr);
+            }
+            prev = cur;
+            requiredWidth = platforms[cur].width;
+        }
+        Plat ex; ex.kind = PT_EXIT; ex.walls = WALLS_NORTH | WALLS_EAST | WALLS_WEST; ex.width = requiredWidth;
+        ex.parent = platforms[prev].anchor();
+        ex.init(rng, op); ex.updateRoot(); ex.generate(rng);
+        platforms.push_back(ex);
+
+        bool selfCollision = false;   // :145-153
+        for (int j = 0; j < int(platforms.size()) && !selfCollision; ++j)
+            for (int k = 0; k < j - 2; ++k)
+                if (boxes_collide(platforms[j].outerBox(), platforms[k].outerBox())) { selfCollision = true; break; }
+        if (!selfCollision) break;
+    }
+    const unsigned layoutColor = randomLayoutColor(rng), wallColor = randomLayoutColor(rng);   // :158-159
+    e.layoutColor = layoutColor; e.wallColor = wallColor; e.drawWalls = drawWalls; e.numPlatforms = numPlatforms;
+
+    // ---- voxelise (vg.addPlatform per platform, component_voxel_grid.hpp:73-84) over the level's bounding box
+    int lo[3] = {1 << 20, 1 << 20, 1 << 20}, hi[3] = {-(1 << 20), -(1 << 20), -(1 << 20)};
+    for (auto &p : platforms) {
+        auto grow = [&](const BoxI &b) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], b.min[k]); hi[k] = std::max(hi[k], b.max[k]); } };
+        for (auto &b : p.layout) grow(box_abs(p.root, b));
+        for (auto &b : p.wallsB) grow(box_abs(p.root, b));
+    }
+    const int dim[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+    std::vector<uint8_t> grid(size_t(dim[0]) * dim[1] * dim[2], 0);
+    auto fill = [&](const BoxI &b, uint8_t v) {
+        for (int x = b.min[0]; x < b.max[0]; ++x) for (int y = b.min[1]; y < b.max[1]; ++y) for (int z = b.min[2]; z < b.max[2]; ++z)
+            grid[(size_t(y - lo[1]) * dim[2] + (z - lo[2])) * dim[0] + (x - lo[0])] = v;
+    };
+    e.numTerrain = 0;
+    for (auto &p : platforms) {
+        for (auto &b : p.layout) fill(box_abs(p.root, b), VX_SOLID | VX_OPAQUE);
+        for (auto &b : p.wallsB) fill(box_abs(p.root, b), VX_SOLID | (drawWalls ? VX_OPAQUE : 0) | (1 << VX_COLOR_SHIFT));
+    }
+    for (auto &p : platforms)   // addEpisodeDrawables :244-248 order: platforms, then map<TerrainType> order (EXIT < LAVA)
+        for (int type : {TERRAIN_EXIT, TERRAIN_LAVA})
+            for (auto &tb : p.terrain)
+                if (tb.first == type && e.numTerrain < MAX_TERRAIN) {
+                    const BoxI b = box_abs(p.root, tb.second);
+                    TerrainBox &t = e.terrain[e.numTerrain++];
+                    for (int k = 0; k < 3; ++k) { t.min[k] = b.min[k]; t.max[k] = b.max[k]; }
+                    t.type = type;
+                }
+    merge_dense(grid, lo, dim, e);
+    std::fill(e.chunk.begin(), e.chunk.end(), 0);   // the 32x16x32 chunk is a TowerBuilding structure; unused here
+    e.L = dim[0]; e.H = dim[1]; e.W = dim[2];
+    e.bz[0] = lo[0]; e.bz[1] = lo[1]; e.bz[2] = lo[2]; e.bz[3] = 0;   // level origin (informational)
+
+    // ---- agent spawn points on the start platform (Platform::agentSpawnPoints :221-243)
+    std::vector<C3> spawns;
+    {
+        Plat &sp = platforms[0];
+        std::set<std::pair<int, int>> used;
+        for (int i = 0; i < e.numAgents; ++i)
+            for (int attempt = 0; attempt < 10; ++attempt) {
+                const int x = randRange(1, sp.length - 1, rng), z = randRange(1, sp.width - 1, rng);
+                if (used.count({x, z})) continue;
+                const int y = sp.occupancy[{x, z}] + 1;
+                sp.occupancy[{x, z}] += 2;
+                spawns.push_back(C3{x, y, z});
+                used.insert({x, z});
+                break;
+            }
+        if (spawns.empty()) spawns.push_back(C3{1, 1, 1});
+    }
+
+    // ---- movable boxes (:166-188) and reward objects (:190-194)
+    std::vector<int> numBoxes(platforms.size(), 0);
+    for (int i = 1; i < int(platforms.size()); ++i) {
+        const int n = platforms[i].requiresBoxes();
+        for (int b = 0; b < n; ++b) ++numBoxes[randRange(std::max(0, i - 2), i, rng)];
+    }
+    std::vector<C3> objs, rews;
+    for (int i = 0; i < int(platforms.size()); ++i) {
+        const float randomBoxesFraction = frand(rng) * 0.5f;
+        const int randomBoxes = int(lroundf(randomBoxesFraction * float(numBoxes[i]))) + randRange(0, 2, rng);
+        const auto c = platforms[i].objectPositions(numBoxes[i] + randomBoxes, rng);
+        objs.insert(objs.end(), c.begin(), c.end());
+    }
+    for (int i = 1; i < int(platforms.size()) - 1; ++i) {
+        const int n = randRange(0, 2, rng);
+        const auto c = platforms[i].objectPositions(n, rng);
+        rews.insert(rews.end(), c.begin(), c.end());
+    }
+    e.numObjects = std::min(int(objs.size()), int(MAX_OBJECTS));
+    for (int i = 0; i < e.numObjects; ++i) e.objects[i] = Object{objs[i].x, objs[i].y, objs[i].z, 0};
+    e.numRewards = std::min(int(rews.size()), int(MAX_REWARDS));
+    for (int i = 0; i < e.numRewards; ++i) e.rewards[i] = RewardObj{rews[i].x, rews[i].y, rews[i].z, 1};
+    e.solved = 0; e.highestTower = 0; e.bzReward = 0;
+    // episodeLengthSec :262-266 counts every generated position, clipped or not
+    e.episodeLen = std::max(e.p_episodeLengthSec, float(numPlatforms) * 35 + float(objs.size()) * 1);
+    e.barHalfWidth = 0.24f;
+    spawn_agents(e, spawns);
+}
+
+static void env_reset(Env &e)
+{
+    // ---- Env::reset, env/src/env.cpp:57-76 ; EnvState::reset env.hpp:135-151
+    e.done = 0; e.episodeSec = 0; e.numFrames = 0;
+    const int seed = randRange(0, 1 << 30, e.rng);
+    e.rng.seed((unsigned long)seed);
+    if (e.scenario == SCN_TOWER) tower_generate(e);
+    else obstacles_generate(e);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -734,6 +1159,27 @@ static void reward_team(Env &e, int key, int idx, float mult)
         e.agents[i].last_reward += e.agents[i].shaping[key] * e.agents[i].shaping[0] * mult / float(e.numAgents);
 }
 
+// VoxelGrid lookups.  TowerBuilding: dense chunk.  Obstacles: the level is a long chain, its voxels are
+// answered from the merged layout boxes / terrain boxes (same set of voxels the reference's hash map holds).
+static bool solid_at(const Env &e, int x, int y, int z)
+{
+    if (e.scenario == SCN_TOWER) return (e.vox(x, y, z) & VX_SOLID) != 0;
+    for (int i = 0; i < e.numBoxes; ++i) {
+        const Box &b = e.boxes[i];
+        if ((b.type & VX_SOLID) && x >= b.min[0] && x < b.max[0] && y >= b.min[1] && y < b.max[1] && z >= b.min[2] && z < b.max[2]) return true;
+    }
+    return false;
+}
+static int terrain_at(const Env &e, int x, int y, int z)
+{
+    int t = 0;
+    for (int i = 0; i < e.numTerrain; ++i) {
+        const TerrainBox &b = e.terrain[i];
+        if (x >= b.min[0] && x < b.max[0] && y >= b.min[1] && y < b.max[1] && z >= b.min[2] && z < b.max[2]) t |= b.type;
+    }
+    return t;
+}
+
 static int object_at(const Env &e, int x, int y, int z)
 {
     for (int i = 0; i < e.numObjects; ++i)
@@ -757,29 +1203,40 @@ static void on_interact(Env &e, int idx)
             voxel_of(v3(e.agents[j].pos.x, e.agents[j].pos.y + 0.05f, e.agents[j].pos.z), c);
             if (c[0] == vox[0] && c[1] == vox[1] && c[2] == vox[2]) { collidesWithAgent = true; break; }
         }
-        // Dense chunk instead of the reference's unbounded hash map: cells outside the chunk in
-        // x/z/+y are refused (deviation); below the chunk everything is empty.
-        const bool placeable = vox[0] >= 0 && vox[0] < CX && vox[2] >= 0 && vox[2] < CZ && vox[1] < CY;
-        const uint8_t v = e.vox(vox[0], vox[1], vox[2]);
-        const bool empty = !(v & VX_SOLID) && !(v & VX_OBJECT);
-        if (placeable && empty && !collidesWithAgent && in_building_zone(e, vox[0], vox[2])) {
+        bool placeable, empty, canPlace;
+        if (e.scenario == SCN_TOWER) {
+            // Dense chunk instead of the reference's unbounded hash map: cells outside the chunk in
+            // x/z/+y are refused (deviation); below the chunk everything is empty.
+            placeable = vox[0] >= 0 && vox[0] < CX && vox[2] >= 0 && vox[2] < CZ && vox[1] < CY;
+            const uint8_t v = e.vox(vox[0], vox[1], vox[2]);
+            empty = !(v & VX_SOLID) && !(v & VX_OBJECT);
+            canPlace = in_building_zone(e, vox[0], vox[2]);   // scenario_tower_building.cpp:201-204
+        } else {
+            placeable = vox[1] > -120 && vox[1] < 120;         // int8 object coordinates
+            empty = !solid_at(e, vox[0], vox[1], vox[2]) && object_at(e, vox[0], vox[1], vox[2]) < 0;
+            canPlace = true;                                   // ObjectStackingCallbacks default
+        }
+        if (placeable && empty && !collidesWithAgent && canPlace) {
             for (;;) {
                 const int by = vox[1] - 1;
                 if (by < -30) break;
-                const uint8_t vb = e.vox(vox[0], by, vox[2]);
-                if ((vb & VX_SOLID) || (vb & VX_OBJECT)) break;
+                if (e.scenario == SCN_TOWER) {
+                    const uint8_t vb = e.vox(vox[0], by, vox[2]);
+                    if ((vb & VX_SOLID) || (vb & VX_OBJECT)) break;
+                } else if (solid_at(e, vox[0], by, vox[2]) || object_at(e, vox[0], by, vox[2]) >= 0) break;
                 vox[1] = by;
             }
             Object &o = e.objects[a.carrying];
             o.x = vox[0]; o.y = vox[1]; o.z = vox[2]; o.state = 0;
             if (Env::inChunk(vox[0], vox[1], vox[2])) e.chunk[Env::cell(vox[0], vox[1], vox[2])] |= VX_OBJECT;
             a.carrying = -1;
-            // placedObject :206-214
-            const float newReward = tower_reward(e);
-            const float delta = newReward - e.bzReward;
-            e.bzReward = newReward;
-            reward_team(e, 3, idx, delta);
-            e.highestTower = std::max(e.highestTower, vox[1] - 1 + 1);
+            if (e.scenario == SCN_TOWER) {   // placedObject :206-214
+                const float newReward = tower_reward(e);
+                const float delta = newReward - e.bzReward;
+                e.bzReward = newReward;
+                reward_team(e, 3, idx, delta);
+                e.highestTower = std::max(e.highestTower, vox[1] - 1 + 1);
+            }
         }
     } else {
         const V3 pickup = cam_to_world(cam, v3(0.0f, -0.44f, -1.0f));
@@ -792,8 +1249,8 @@ static void on_interact(Env &e, int idx)
                 e.objects[oi].state = 1 + idx;
                 if (Env::inChunk(vox[0], vox[1], vox[2])) e.chunk[Env::cell(vox[0], vox[1], vox[2])] &= ~VX_OBJECT;
                 a.carrying = oi;
-                // pickedObject :216-225
-                if (!a.picked_up) { reward_agent(e, 1, idx, 1); a.picked_up = 1; }
+                // pickedObject :216-225 (TowerBuilding only; the Obstacles callbacks are no-ops)
+                if (e.scenario == SCN_TOWER && !a.picked_up) { reward_agent(e, 1, idx, 1); a.picked_up = 1; }
                 break;
             }
             vox[1] += 1;
@@ -856,26 +1313,55 @@ static void env_step(Env &e)
     for (int i = 0; i < e.numAgents; ++i)
         if (e.agents[i].action & (1 << 8)) on_interact(e, i);
 
-    for (int i = 0; i < e.numAgents; ++i) {  // component_fall_detection.hpp:33-55
-        Agent &a = e.agents[i];
-        if (a.pos.y + 0.05f < -20.0f) {
-            int p[3] = {a.spawn[0], a.spawn[1], a.spawn[2]};
-            while ((e.vox(p[0], p[1], p[2]) & VX_SOLID) && p[1] < 1000) ++p[1];
-            a.pos = v3(float(p[0]) + 0.5f, float(p[1]) + 0.5f, float(p[2]) + 0.5f);
-            a.m00 = 1; a.m02 = 0; a.m20 = 0; a.m22 = 1;  // warp(): xform.setIdentity()
-            a.hvx = a.hvz = 0; a.vvel = 0;
-        }
-    }
+    auto reset_agent = [&](Agent &a) {   // FallDetectionComponent::resetAgent :45-55 + controller warp() :509-517
+        int p[3] = {a.spawn[0], a.spawn[1], a.spawn[2]};
+        while (solid_at(e, p[0], p[1], p[2]) && p[1] < 1000) ++p[1];
+        a.pos = v3(float(p[0]) + 0.5f, float(p[1]) + 0.5f, float(p[2]) + 0.5f);
+        a.m00 = 1; a.m02 = 0; a.m20 = 0; a.m22 = 1;  // warp(): xform.setIdentity()
+        a.hvx = a.hvz = 0; a.vvel = 0;
+    };
+    for (int i = 0; i < e.numAgents; ++i)  // component_fall_detection.hpp:33-43
+        if (e.agents[i].pos.y + 0.05f < -20.0f) reset_agent(e.agents[i]);
 
-    for (int i = 0; i < e.numAgents; ++i) {
-        Agent &a = e.agents[i];
-        if (a.carrying >= 0) {
+    if (e.scenario == SCN_TOWER) {
+        for (int i = 0; i < e.numAgents; ++i) {
+            Agent &a = e.agents[i];
+            if (a.carrying >= 0) {
+                int vox[3];
+                voxel_of(v3(a.pos.x, a.pos.y + 0.05f, a.pos.z), vox);
+                if (in_building_zone(e, vox[0], vox[2]) && !a.visited_zone) {
+                    reward_team(e, 2, i, 1);
+                    a.visited_zone = 1;
+                }
+            }
+        }
+    } else {   // ObstaclesScenario::step, scenario_obstacles.cpp:197-239
+        int numAgentsAtExit = 0;
+        for (int i = 0; i < e.numAgents; ++i) {
+            Agent &a = e.agents[i];
             int vox[3];
             voxel_of(v3(a.pos.x, a.pos.y + 0.05f, a.pos.z), vox);
-            if (in_building_zone(e, vox[0], vox[2]) && !a.visited_zone) {
-                reward_team(e, 2, i, 1);
-                a.visited_zone = 1;
+            const int terrain = terrain_at(e, vox[0], vox[1], vox[2]);
+            if (terrain & TERRAIN_EXIT) {
+                ++numAgentsAtExit;
+                if (!a.visited_zone) {
+                    a.visited_zone = 1;   // agentReachedExit[i]
+                    reward_team(e, 1, i, 1);
+                    if (a.carrying >= 0) reward_team(e, 4, i, 1);
+                }
+            } else if (terrain & TERRAIN_LAVA) reset_agent(a);   // agentTouchedLava :274-278
+            for (int r = 0; r < e.numRewards; ++r) {             // green diamonds :224-229
+                RewardObj &ro = e.rewards[r];
+                if (ro.active && ro.x == vox[0] && ro.y == vox[1] && ro.z == vox[2]) {
+                    ro.active = 0;
+                    reward_team(e, 3, i, 1);
+                }
             }
+        }
+        if (numAgentsAtExit == e.numAgents && !e.solved) {
+            e.solved = 1;
+            e.episodeSec = std::max(e.episodeSec, e.episodeLen - 0.3f);   // doneWithTimer(), scenario.hpp:114-117
+            for (int i = 0; i < e.numAgents; ++i) reward_agent(e, 2, i, 1);   // rewardAll
         }
     }
 
@@ -903,7 +1389,7 @@ static const float TAN_HALF_FOV_Y = 1.19175359f / (128.0f / 72.0f);
 static const float NEAR_Z = 0.01f, FAR_Z = 120.0f;
 
 struct Prim {
-    int kind;   // 1 = box in frame `frame`, 2 = vertical capsule in world
+    int kind;   // 1 = box in frame `frame`, 2 = vertical capsule in world, 3 = cone in world (lo = apex, hi = (radius, height, +1 apex up / -1 apex down))
     int frame;  // -1 world axes, k>=0: camera frame of agent k
     V3 lo, hi;  // box bounds in its frame; capsule: lo = centre, hi = (radius, halfLen, 0)
     unsigned color;
@@ -921,11 +1407,19 @@ static void build_prims(const Env &e, int viewer, std::vector<Prim> &out)
         p.color = b.slot == 0 ? e.layoutColor : e.wallColor;
         out.push_back(p);
     }
-    {   // building zone slab, layout_utils.cpp:53-68
+    if (e.scenario == SCN_TOWER) {   // building zone slab, layout_utils.cpp:53-68
         Prim p; p.kind = 1; p.frame = -1;
         p.lo = v3(float(e.bz[0]), 1.0f, float(e.bz[2]));
         p.hi = v3(float(e.bz[1]), 1.0f + 0.05f, float(e.bz[3]));
         p.color = COLOR_BUILDING_ZONE;
+        out.push_back(p);
+    }
+    for (int i = 0; i < e.numTerrain; ++i) {   // addTerrain, layout_utils.cpp:53-68: 0.05 thick slab on the box's floor
+        const TerrainBox &t = e.terrain[i];
+        Prim p; p.kind = 1; p.frame = -1;
+        p.lo = v3(float(t.min[0]), float(t.min[1]), float(t.min[2]));
+        p.hi = v3(float(t.max[0]), float(t.min[1]) + 0.05f, float(t.max[2]));
+        p.color = t.type == TERRAIN_EXIT ? COLOR_EXIT_PAD : COLOR_RED;   // platforms.hpp:47-56
         out.push_back(p);
     }
     for (int i = 0; i < e.numObjects; ++i) {  // component_object_stacking.hpp:170-198, :146-152
@@ -944,6 +1438,18 @@ static void build_prims(const Env &e, int viewer, std::vector<Prim> &out)
             p.hi = v3(c.x + hh, c.y + hh, c.z + hh);
         }
         out.push_back(p);
+    }
+    for (int i = 0; i < e.numRewards; ++i) {   // addDiamond, layout_utils.cpp:114-126 + scenario_obstacles.cpp:254
+        const RewardObj &r = e.rewards[i];
+        if (!r.active) continue;               // collected diamonds are translated far away (:227)
+        const float sx = 0.17f * 0.8f, sy = 0.45f * 0.8f;
+        const V3 c = v3(float(r.x) + 0.5f, float(r.y) + 0.7f, float(r.z) + 0.5f);
+        Prim up; up.kind = 3; up.frame = -1; up.color = COLOR_GREEN;
+        up.lo = v3(c.x, c.y + 0.5f * sy, c.z); up.hi = v3(sx, sy, 1.0f);
+        out.push_back(up);
+        Prim dn = up;
+        dn.lo = v3(c.x, c.y - 1.5f * sy, c.z); dn.hi = v3(sx, sy, -1.0f);
+        out.push_back(dn);
     }
     for (int k = 0; k < e.numAgents; ++k) {  // scenario_default.hpp:99-170
         if (k != viewer) {
@@ -1036,6 +1542,39 @@ static bool ray_capsule(V3 o, V3 d, V3 c, float r, float hl, float *t_out, V3 *n
     return hit;
 }
 
+// Open cone (no base cap, Primitives::coneSolid without CapEnd): apex a, axis +-y (dirSign +1: apex up),
+// height h, base radius r.  Only the outside is visible (back-face culling).
+static bool ray_cone(V3 o, V3 d, V3 a, float r, float h, float dirSign, float *t_out, V3 *n_out)
+{
+    const float k = (r / h) * (r / h);
+    const float ox = o.x - a.x, oz = o.z - a.z;
+    const float s0 = dirSign * (a.y - o.y);      // distance from the apex along the axis at t = 0
+    const float ds = -dirSign * d.y;             // its derivative
+    const float A = (d.x * d.x + d.z * d.z) - k * (ds * ds);
+    const float B = (ox * d.x + oz * d.z) - k * (s0 * ds);
+    const float C = (ox * ox + oz * oz) - k * (s0 * s0);
+    if (A == 0.0f) return false;
+    const float disc = B * B - A * C;
+    if (!(disc >= 0.0f)) return false;
+    const float sq = sqrtf(disc);
+    bool hit = false;
+    float best = INFINITY; V3 bn = v3(0, 0, 0);
+    for (int i = 0; i < 2; ++i) {
+        const float t = (i == 0 ? (-B - sq) : (-B + sq)) / A;
+        const float s = s0 + t * ds;
+        if (!(t >= NEAR_Z && t <= FAR_Z && s >= 0.0f && s <= h && t < best)) continue;
+        const float px = ox + t * d.x, pz = oz + t * d.z;
+        V3 n = v3(px, dirSign * (k * s), pz);
+        if (!(dot(n, d) < 0.0f)) continue;       // back face
+        const float l2 = len2(n);
+        if (!(l2 > 0.0f)) continue;
+        n = n * (1.0f / sqrtf(l2));
+        hit = true; best = t; bn = n;
+    }
+    if (hit) { *t_out = best; *n_out = bn; }
+    return hit;
+}
+
 static inline V3 mat_mul(const float m[3][3], V3 v)
 {
     return v3((m[0][0] * v.x + m[0][1] * v.y) + m[0][2] * v.z, (m[1][0] * v.x + m[1][1] * v.y) + m[1][2] * v.z,
@@ -1089,6 +1628,9 @@ static void render_agent(const Env &e, int viewer, int W, int H, uint8_t *out)
                 bool hit;
                 if (p.kind == 2) {
                     hit = ray_capsule(cam.eye, dw, p.lo, p.hi.x, p.hi.y, &t, &n);
+                    if (hit) n = mat_tmul(cam.c, n);
+                } else if (p.kind == 3) {
+                    hit = ray_cone(cam.eye, dw, p.lo, p.hi.x, p.hi.y, p.hi.z, &t, &n);
                     if (hit) n = mat_tmul(cam.c, n);
                 } else if (p.frame < 0) {
                     hit = ray_box(cam.eye, dw, p.lo, p.hi, &t, &n);
@@ -1168,7 +1710,8 @@ struct Gym {
         for (int i = 0; i < numEnvs; ++i) {  // vector_env.cpp:93-105, serial
             if (envs[i]->done) {
                 done[i] = 1;
-                for (int a = 0; a < numAgents; ++a) trueObjective[size_t(i) * numAgents + a] = float(envs[i]->highestTower);
+                for (int a = 0; a < numAgents; ++a)
+                    trueObjective[size_t(i) * numAgents + a] = envs[i]->scenario == SCN_TOWER ? float(envs[i]->highestTower) : float(envs[i]->solved);
                 env_reset(*envs[i]);
             } else done[i] = 0;
         }
@@ -1191,7 +1734,20 @@ mvo_gym *mvo_create(const char *scenario, int w, int h, int num_envs, int num_ag
 {
     std::string s(scenario ? scenario : "");
     for (auto &ch : s) ch = (char)tolower(ch);
-    if (s != "towerbuilding") { fprintf(stderr, "mv_oracle: unknown scenario %s\n", s.c_str()); return nullptr; }
+    int scen = SCN_TOWER;
+    ObstacleParams op;
+    float carriedDefault = 0.0f;
+    if (s == "towerbuilding") scen = SCN_TOWER;
+    else if (s == "obstacleseasy") { scen = SCN_OBSTACLES; }   // scenario_obstacles.hpp:112-138 (== base defaults)
+    else if (s == "obstaclesmedium") { scen = SCN_OBSTACLES; op.minPlatforms = 2; op.maxPlatforms = 4; op.minLava = 2; op.maxLava = 5; }
+    else if (s == "obstacleshard") {
+        scen = SCN_OBSTACLES; op.minPlatforms = 2; op.maxPlatforms = 7; op.minGap = 2; op.maxGap = 3; op.minLava = 3; op.maxLava = 10;
+        op.minHeight = 2; op.maxHeight = 4;
+    } else if (s == "obstacleswalls" || s == "obstaclessteps" || s == "obstacleslava") {   // :190-268
+        scen = SCN_OBSTACLES; op.minPlatforms = 1; op.maxPlatforms = 4; op.minGap = 1; op.maxGap = 3; op.minLava = 2; op.maxLava = 10;
+        op.minHeight = 1; op.maxHeight = 3; carriedDefault = 1.0f;
+        op.platformTypes = {s == "obstacleswalls" ? PT_WALL : s == "obstaclessteps" ? PT_STEP : PT_LAVA};
+    } else { fprintf(stderr, "mv_oracle: unknown scenario %s\n", s.c_str()); return nullptr; }
     if (num_agents_per_env < 1 || num_agents_per_env > MAX_AGENTS || num_envs < 1) return nullptr;
     auto *g = new mvo_gym();
     g->w = w; g->h = h; g->numEnvs = num_envs; g->numAgents = num_agents_per_env; g->numThreads = std::max(1, num_threads);
@@ -1201,8 +1757,21 @@ mvo_gym *mvo_create(const char *scenario, int w, int h, int num_envs, int num_ag
         for (int k = 0; k < n_params; ++k) {
             if (!strcmp(keys[k], "episodeLengthSec")) e->p_episodeLengthSec = vals[k];
             if (!strcmp(keys[k], "verticalLookLimitRad")) e->p_verticalLookLimitRad = vals[k];
+            auto ip = [&](const char *name, int &dst) { if (!strcmp(keys[k], name)) dst = int(lroundf(vals[k])); };
+            ip("obstaclesMinNumPlatforms", op.minPlatforms); ip("obstaclesMaxNumPlatforms", op.maxPlatforms);
+            ip("obstaclesMinGap", op.minGap); ip("obstaclesMaxGap", op.maxGap); ip("obstaclesMinLava", op.minLava);
+            ip("obstaclesMaxLava", op.maxLava); ip("obstaclesMinHeight", op.minHeight); ip("obstaclesMaxHeight", op.maxHeight);
+            if (!strcmp(keys[k], "obstaclesNumAllowedMaxDifficulty")) op.numAllowedMaxDifficulty = int(vals[k]);
         }
-        for (int a = 0; a < MAX_AGENTS; ++a) std::memcpy(e->agents[a].shaping, SHAPING_DEFAULT, sizeof SHAPING_DEFAULT);
+        e->scenario = scen;
+        e->op = op;
+        e->numShaping = scen == SCN_TOWER ? 4 : 5;
+        e->shapingKeys = scen == SCN_TOWER ? SHAPING_KEYS_TOWER : SHAPING_KEYS_OBST;
+        for (int a = 0; a < MAX_AGENTS; ++a) {
+            std::memset(e->agents[a].shaping, 0, sizeof e->agents[a].shaping);
+            for (int k = 0; k < e->numShaping; ++k)
+                e->agents[a].shaping[k] = scen == SCN_TOWER ? SHAPING_DEFAULT_TOWER[k] : (k == 4 ? carriedDefault : SHAPING_DEFAULT_OBST[k]);
+        }
         g->envs.push_back(std::move(e));
     }
     g->done.assign(num_envs, 0);
@@ -1258,15 +1827,17 @@ const uint8_t *mvo_get_observation(mvo_gym *g, int env, int agent) { return g->o
 
 float mvo_get_reward_shaping(mvo_gym *g, int env, int agent, const char *key, int *found)
 {
-    for (int k = 0; k < 4; ++k)
-        if (!strcmp(key, SHAPING_KEYS[k])) { if (found) *found = 1; return g->envs[env]->agents[agent].shaping[k]; }
+    const Env &e = *g->envs[env];
+    for (int k = 0; k < e.numShaping; ++k)
+        if (!strcmp(key, e.shapingKeys[k])) { if (found) *found = 1; return e.agents[agent].shaping[k]; }
     if (found) *found = 0;
     return 0.0f;
 }
 void mvo_set_reward_shaping(mvo_gym *g, int env, int agent, const char *key, float v)
 {
-    for (int k = 0; k < 4; ++k)
-        if (!strcmp(key, SHAPING_KEYS[k])) g->envs[env]->agents[agent].shaping[k] = v;
+    Env &e = *g->envs[env];
+    for (int k = 0; k < e.numShaping; ++k)
+        if (!strcmp(key, e.shapingKeys[k])) e.agents[agent].shaping[k] = v;
 }
 
 // ---- snapshot (layout: DESIGN.md "snapshot format") ----
@@ -1274,14 +1845,16 @@ void mvo_set_reward_shaping(mvo_gym *g, int env, int agent, const char *key, flo
 struct SnapAgent {
     float pos[3], basis[4], pitch, hv[2], vvel, voffset, step_offset, jump_speed;
     int32_t was_jumping, carrying, picked_up, visited_zone, spawn[3];
-    float last_reward, total_reward, shaping[4];
+    float last_reward, total_reward, shaping[MAX_SHAPING];
 };
 struct SnapHeader {
-    int32_t L, H, W, bz[4], layout_color, wall_color, draw_walls, num_objects, num_boxes, num_frames, done, highest_tower,
-        num_agents;
+    int32_t scenario, L, H, W, bz[4], layout_color, wall_color, draw_walls, num_objects, num_boxes, num_frames, done, highest_tower,
+        num_agents, num_terrain, num_rewards, num_platforms, solved;
     float episode_sec, episode_len, bz_reward, bar_half_width;
     int32_t boxes[MAX_BOXES][8];
+    int32_t terrain[MAX_TERRAIN][8];
     int8_t objects[MAX_OBJECTS][4];
+    int8_t rewards[MAX_REWARDS][4];
     SnapAgent agents[MAX_AGENTS];
     uint8_t chunk[CHUNK];
 };
@@ -1294,7 +1867,17 @@ void mvo_snapshot(mvo_gym *g, int env, void *out)
     const Env &e = *g->envs[env];
     auto *s = new SnapHeader();
     std::memset(s, 0, sizeof *s);
-    s->L = e.L; s->H = e.H; s->W = e.W;
+    s->scenario = e.scenario; s->L = e.L; s->H = e.H; s->W = e.W;
+    s->num_terrain = e.numTerrain; s->num_rewards = e.numRewards; s->num_platforms = e.numPlatforms; s->solved = e.solved;
+    for (int i = 0; i < e.numTerrain; ++i) {
+        const TerrainBox &t = e.terrain[i];
+        int32_t *o = s->terrain[i];
+        o[0] = t.min[0]; o[1] = t.min[1]; o[2] = t.min[2]; o[3] = t.max[0]; o[4] = t.max[1]; o[5] = t.max[2]; o[6] = t.type; o[7] = 0;
+    }
+    for (int i = 0; i < e.numRewards; ++i) {
+        s->rewards[i][0] = (int8_t)e.rewards[i].x; s->rewards[i][1] = (int8_t)e.rewards[i].y; s->rewards[i][2] = (int8_t)e.rewards[i].z;
+        s->rewards[i][3] = (int8_t)e.rewards[i].active;
+    }
     for (int i = 0; i < 4; ++i) s->bz[i] = e.bz[i];
     s->layout_color = (int)e.layoutColor; s->wall_color = (int)e.wallColor; s->draw_walls = e.drawWalls;
     s->num_objects = e.numObjects; s->num_boxes = e.numBoxes; s->num_frames = e.numFrames; s->done = e.done;
@@ -1319,7 +1902,7 @@ void mvo_snapshot(mvo_gym *g, int env, void *out)
         o.picked_up = a.picked_up; o.visited_zone = a.visited_zone;
         for (int k = 0; k < 3; ++k) o.spawn[k] = a.spawn[k];
         o.last_reward = a.last_reward; o.total_reward = a.total_reward;
-        for (int k = 0; k < 4; ++k) o.shaping[k] = a.shaping[k];
+        for (int k = 0; k < MAX_SHAPING; ++k) o.shaping[k] = a.shaping[k];
     }
     std::memcpy(s->chunk, e.chunk.data(), CHUNK);
     std::memcpy(out, s, sizeof *s);

@@ -8,18 +8,21 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 
-MAX_BOXES, MAX_OBJECTS, MAX_AGENTS, CHUNK = 16, 80, 8, 32 * 16 * 32
+MAX_BOXES, MAX_OBJECTS, MAX_AGENTS, CHUNK = 128, 80, 8, 32 * 16 * 32
+MAX_TERRAIN, MAX_REWARDS, MAX_SHAPING = 16, 16, 8
 
 SNAP_AGENT = np.dtype([
     ("pos", "<f4", 3), ("basis", "<f4", 4), ("pitch", "<f4"), ("hv", "<f4", 2), ("vvel", "<f4"), ("voffset", "<f4"),
     ("step_offset", "<f4"), ("jump_speed", "<f4"), ("was_jumping", "<i4"), ("carrying", "<i4"), ("picked_up", "<i4"),
-    ("visited_zone", "<i4"), ("spawn", "<i4", 3), ("last_reward", "<f4"), ("total_reward", "<f4"), ("shaping", "<f4", 4),
+    ("visited_zone", "<i4"), ("spawn", "<i4", 3), ("last_reward", "<f4"), ("total_reward", "<f4"), ("shaping", "<f4", MAX_SHAPING),
 ])
 SNAP = np.dtype([
-    ("L", "<i4"), ("H", "<i4"), ("W", "<i4"), ("bz", "<i4", 4), ("layout_color", "<i4"), ("wall_color", "<i4"),
+    ("scenario", "<i4"), ("L", "<i4"), ("H", "<i4"), ("W", "<i4"), ("bz", "<i4", 4), ("layout_color", "<i4"), ("wall_color", "<i4"),
     ("draw_walls", "<i4"), ("num_objects", "<i4"), ("num_boxes", "<i4"), ("num_frames", "<i4"), ("done", "<i4"),
-    ("highest_tower", "<i4"), ("num_agents", "<i4"), ("episode_sec", "<f4"), ("episode_len", "<f4"), ("bz_reward", "<f4"),
-    ("bar_half_width", "<f4"), ("boxes", "<i4", (MAX_BOXES, 8)), ("objects", "i1", (MAX_OBJECTS, 4)),
+    ("highest_tower", "<i4"), ("num_agents", "<i4"), ("num_terrain", "<i4"), ("num_rewards", "<i4"), ("num_platforms", "<i4"),
+    ("solved", "<i4"), ("episode_sec", "<f4"), ("episode_len", "<f4"), ("bz_reward", "<f4"),
+    ("bar_half_width", "<f4"), ("boxes", "<i4", (MAX_BOXES, 8)), ("terrain", "<i4", (MAX_TERRAIN, 8)),
+    ("objects", "i1", (MAX_OBJECTS, 4)), ("rewards", "i1", (MAX_REWARDS, 4)),
     ("agents", SNAP_AGENT, MAX_AGENTS), ("chunk", "u1", CHUNK),
 ])
 
@@ -130,7 +133,8 @@ class OracleGym:
 
     def get_reward_shaping(self, env_idx, agent_idx):
         out = {}
-        for k in ("teamSpirit", "towerPickedUpObject", "towerVisitedBuildingZoneWithObject", "towerBuildingReward"):
+        for k in ("teamSpirit", "towerPickedUpObject", "towerVisitedBuildingZoneWithObject", "towerBuildingReward",
+                  "obstaclesAgentAtExit", "obstaclesAllAgentsAtExit", "obstaclesExtraReward", "obstaclesAgentCarriedObjectToExit"):
             f = C.c_int(0)
             v = self.L.mvo_get_reward_shaping(self.g, env_idx, agent_idx, k.encode(), C.byref(f))
             if f.value:
