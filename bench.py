@@ -27,7 +27,7 @@ METRIC = "agent observations/sec (whole node), TowerBuilding 128x128 obs, random
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(obs_w, obs_h, agents, budget_s=12.0):
+def cpu_baseline(scenario, obs_w, obs_h, agents, budget_s=12.0):
     """Oracle (CPU restatement, kind 'port') timed on this box's host cores on a bounded sample of
     the same workload: same scenario/obs size/seed/action stream, fewer envs and steps."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -36,7 +36,7 @@ def cpu_baseline(obs_w, obs_h, agents, budget_s=12.0):
     cores = os.cpu_count() or 1
     threads = max(1, cores)
     n_env = max(8, 2 * threads)
-    g = oracle_lib.OracleGym("TowerBuilding", obs_w, obs_h, n_env, agents, threads)
+    g = oracle_lib.OracleGym(scenario, obs_w, obs_h, n_env, agents, threads)
     g.seed(42)
     g.reset()
     steps, t0 = 0, time.perf_counter()
@@ -52,7 +52,7 @@ def cpu_baseline(obs_w, obs_h, agents, budget_s=12.0):
             break
     g.close()
     return {"value": n_env * agents * steps / el, "unit": "agent observations/sec", "cores": threads, "kind": "port",
-            "sample": f"oracle (CPU restatement, software raster) TowerBuilding num_envs={n_env} agents={agents} obs {obs_w}x{obs_h}, "
+            "sample": f"oracle (CPU restatement, software raster) {scenario} num_envs={n_env} agents={agents} obs {obs_w}x{obs_h}, "
                       f"{steps} steps in {el:.1f}s on {threads} threads (static block partition like vector_env.cpp:65-68)"}
 
 
@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs-per-gpu", type=int, default=1024)
     ap.add_argument("--agents", type=int, default=1)
+    ap.add_argument("--scenario", default="TowerBuilding", help="TowerBuilding (headline) or Obstacles{Easy,Medium,Hard,Walls,Steps,Lava}")
     ap.add_argument("--obs", type=int, nargs=2, default=[128, 128], metavar=("W", "H"))
     ap.add_argument("--gather-obs", action="store_true", help="RCCL all-gather of the observation slab every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -89,7 +90,7 @@ def main():
 
     W, H = args.obs
     n_env, A = args.envs_per_gpu, args.agents
-    gym = MegaverseGym("TowerBuilding", W, H, n_env, A, 1, False, {}, device=local_rank, env_offset=rank * n_env,
+    gym = MegaverseGym(args.scenario, W, H, n_env, A, 1, False, {}, device=local_rank, env_offset=rank * n_env,
                        total_envs=world * n_env)
     stream = torch.cuda.current_stream()
     gym.set_stream(stream.cuda_stream)
@@ -137,24 +138,27 @@ def main():
         frames = n_env * A
         # algorithmic bytes of one raster launch (DESIGN.md "kernels"): RGBA8 frame written once +
         # the frame's scene (header 128 B, 16 layout boxes 512 B, 80 movable boxes 320 B, agents 128 B each)
-        bytes_per_frame = W * H * 4 + 128 + 512 + 320 + 128 * A
+        obst = args.scenario.lower().startswith("obstacles")
+        # Obstacles: 128 layout boxes 4096 B + 16 terrain boxes 512 B + 16 reward objects 64 B
+        scene_bytes = (4096 + 512 + 64) if obst else 512
+        bytes_per_frame = W * H * 4 + 128 + scene_bytes + 320 + 128 * A
         raster_ms = prof["raster"][0]
         achieved = bytes_per_frame * frames / (raster_ms * 1e-3) / 1e9 if raster_ms > 0 else 0.0
         # physics kernel: header + boxes + objects + agent state read+write + action/reward/done
-        step_bytes_per_env = 2 * 128 + 512 + 2 * 320 + A * (2 * 128 + 4 + 4 + 4) + 1
+        step_bytes_per_env = 2 * 128 + scene_bytes + 2 * 320 + A * (2 * 128 + 4 + 4 + 4) + 1
         step_ms = prof["step"][0]
         traffic = None
         try:   # HBM bytes per raster launch from the committed PMC passes (profiles/), only for the profiled config
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pt["config"] == {"envs_per_gpu": n_env, "agents_per_env": A, "obs": [W, H]}:
+            if pt["config"] == {"envs_per_gpu": n_env, "agents_per_env": A, "obs": [W, H]} and not obst:
                 traffic = pt["kernels"]["mv::raster_kernel"]["traffic_bytes_per_launch"]
         except Exception:  # noqa: BLE001
             pass
         line = {
-            "metric": METRIC, "value": total_obs / elapsed, "unit": "agent observations/sec", "n_gpus": world,
+            "metric": METRIC if args.scenario == "TowerBuilding" and (W, H) == (128, 128) else METRIC.replace("TowerBuilding 128x128", f"{args.scenario} {W}x{H}"), "value": total_obs / elapsed, "unit": "agent observations/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"TowerBuilding num_envs={n_env} per GPU x {world} GPU(s), num_agents_per_env={A}, obs {W}x{H} RGBA8, "
+            "config": {"workload": f"{args.scenario} num_envs={n_env} per GPU x {world} GPU(s), num_agents_per_env={A}, obs {W}x{H} RGBA8, "
                                    "uniform random multi-discrete actions (device, counter-based), natural auto-resets, master seed 42",
                        "envs_per_gpu": n_env, "agents_per_env": A, "obs": [W, H], "gather_obs": bool(gathered is not None),
                        "parallelism": f"env-shard x{world}"},
@@ -169,7 +173,7 @@ def main():
             "checksum": checksum,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(W, H, A)
+            line["cpu_baseline"] = cpu_baseline(args.scenario, W, H, A)
         print(json.dumps(line), flush=True)
 
     gym.close()

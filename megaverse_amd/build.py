@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 
 
 def sources():
-    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))]
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h", ".cpp"))]
     srcs.append(os.path.join(os.path.dirname(HERE), "include", "megaverse_hip.h"))
     return srcs
 

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/megaverse_hip.h"
+#include "mv_gen.h"
 #include "mv_math.h"
 #include "mv_rng.h"
 #include "mv_types.h"
@@ -24,6 +25,8 @@ namespace mv {
 void launch_reset(const GymView &gv, int force_all, hipStream_t stream);
 void launch_step(const GymView &gv, hipStream_t stream);
 int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream);
+void launch_step_obstacles(const GymView &gv, hipStream_t stream);
+void launch_reset_obstacles(const GymView &gv, const EpisodeBlob *blobs, int *total_consumed, int force_all, hipStream_t stream);
 }  // namespace mv
 
 using namespace mv;
@@ -40,9 +43,13 @@ static int fail(const std::string &msg)
         if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_));          \
     } while (0)
 
-static const char *SHAPING_KEYS[NUM_SHAPING] = {"teamSpirit", "towerPickedUpObject", "towerVisitedBuildingZoneWithObject",
-                                                "towerBuildingReward"};
-static const float SHAPING_DEFAULT[NUM_SHAPING] = {0.1f, 0.1f, 0.1f, 1.0f};   // scenario_tower_building.hpp:44-52
+static const char *SHAPING_KEYS_TOWER[4] = {"teamSpirit", "towerPickedUpObject", "towerVisitedBuildingZoneWithObject",
+                                           "towerBuildingReward"};
+static const float SHAPING_DEFAULT_TOWER[4] = {0.1f, 0.1f, 0.1f, 1.0f};   // scenario_tower_building.hpp:44-52
+// scenario_obstacles.hpp:36-44, teamSpirit 0 from Scenario::init (scenario.hpp:94-103)
+static const char *SHAPING_KEYS_OBST[5] = {"teamSpirit", "obstaclesAgentAtExit", "obstaclesAllAgentsAtExit", "obstaclesExtraReward",
+                                          "obstaclesAgentCarriedObjectToExit"};
+static const float SHAPING_DEFAULT_OBST[5] = {0.0f, 1.0f, 5.0f, 0.5f, 0.0f};
 static const int ACTION_SPACE[6] = {3, 3, 3, 2, 2, 3};                          // env.cpp:33
 
 struct mv_gym {
@@ -65,6 +72,20 @@ struct mv_gym {
     std::vector<uint8_t> hDone;
     bool mirrorsFresh = false;
     std::mt19937 rng{std::random_device{}()};    // megaverse.cpp:253
+    // scenario
+    int scenario = SCN_TOWER;
+    int numShaping = 4;
+    const char *const *shapingKeys = SHAPING_KEYS_TOWER;
+    ObstacleConfig obst;
+    float baseEpisodeLen = 60.0f;
+    // Obstacles: host episode generator + one resident episode per env (refill protocol)
+    std::vector<std::mt19937> envRng;
+    std::vector<int> uploaded;                   // episodes uploaded per env
+    EpisodeBlob *dBlobs = nullptr, *hBlobs = nullptr;   // device [N], pinned staging [N]
+    int *dTotalConsumed = nullptr, *hTotalConsumed = nullptr;   // device counter, pinned mirror
+    int lastTotalSeen = 0;
+    hipEvent_t consumedCopied = nullptr;
+    bool consumedPending = false;
     // in-stream profiling
     std::vector<hipEvent_t> profEvents;          // 4 per profiled step
     int profMax = 0, profCount = 0;
@@ -194,15 +215,31 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     if (!cfg || !out) return fail("mv_create: null argument");
     *out = nullptr;
     // Scenario::create (scenario.hpp:61-77) is fatal on unknown names; we return an error instead
-    if (lower(cfg->scenario) != "towerbuilding")
-        return fail("Unknown scenario " + lower(cfg->scenario) + " (this build accelerates: towerbuilding)");
+    const std::string scen = lower(cfg->scenario);
+    int scenario = SCN_TOWER;
+    ObstacleConfig oc;
+    if (scen == "towerbuilding") scenario = SCN_TOWER;
+    else if (scen == "obstacleseasy") scenario = SCN_OBSTACLES;                       // scenario_obstacles.hpp:112-138
+    else if (scen == "obstaclesmedium") { scenario = SCN_OBSTACLES; oc.min_platforms = 2; oc.max_platforms = 4; oc.min_lava = 2; oc.max_lava = 5; }
+    else if (scen == "obstacleshard") {                                               // :164-189
+        scenario = SCN_OBSTACLES; oc.min_platforms = 2; oc.max_platforms = 7; oc.min_gap = 2; oc.max_gap = 3; oc.min_lava = 3; oc.max_lava = 10;
+        oc.min_height = 2; oc.max_height = 4;
+    } else if (scen == "obstacleswalls" || scen == "obstaclessteps" || scen == "obstacleslava") {   // :190-268
+        scenario = SCN_OBSTACLES; oc.min_platforms = 1; oc.max_platforms = 4; oc.min_gap = 1; oc.max_gap = 3; oc.min_lava = 2; oc.max_lava = 10;
+        oc.min_height = 1; oc.max_height = 3; oc.carried_object_to_exit = 1.0f;
+        oc.platform_types[0] = scen == "obstacleswalls" ? 1 : scen == "obstaclessteps" ? 3 : 2;
+        oc.num_platform_types = 1;
+    } else
+        return fail("Unknown scenario " + scen + " (this build accelerates: TowerBuilding, ObstaclesEasy/Medium/Hard/Walls/Steps/Lava)");
     if (cfg->num_envs < 1 || cfg->num_agents_per_env < 1 || cfg->num_agents_per_env > MAX_AGENTS)
         return fail("mv_create: num_envs >= 1 and 1 <= num_agents_per_env <= 8 required");
     if (cfg->obs_width < 1 || cfg->obs_height < 1 || cfg->obs_width > 1024 || cfg->obs_height > 1024) return fail("mv_create: observation size must be within 1..1024");
 
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        return fail("mv_create: no HIP device available (this library has no CPU fallback)");
+    hipError_t derr = hipInit(0);
+    if (derr == hipSuccess) derr = hipGetDeviceCount(&ndev);
+    if (derr != hipSuccess || ndev <= 0)
+        return fail(std::string("mv_create: no HIP device available (this library has no CPU fallback): ") + hipGetErrorString(derr));
     if (cfg->device < 0 || cfg->device >= ndev) return fail("mv_create: bad device ordinal");
     HIP_TRY(hipSetDevice(cfg->device));
 
@@ -210,6 +247,9 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     g->device = cfg->device;
     g->w = cfg->obs_width; g->h = cfg->obs_height;
     g->N = cfg->num_envs; g->A = cfg->num_agents_per_env;
+    g->scenario = scenario;
+    g->numShaping = scenario == SCN_TOWER ? 4 : 5;
+    g->shapingKeys = scenario == SCN_TOWER ? SHAPING_KEYS_TOWER : SHAPING_KEYS_OBST;
     g->envOffset = cfg->total_envs > 0 ? cfg->env_offset : 0;
     g->totalEnvs = cfg->total_envs > 0 ? cfg->total_envs : cfg->num_envs;
     const size_t N = g->N, NA = (size_t)g->N * g->A;
@@ -225,7 +265,10 @@ int mv_create(const mv_config *cfg, mv_gym **out)
                  szChunk = up(N * (size_t)CHUNK_BYTES), szAct = up(NA * sizeof(int32_t)), szRew = up(NA * sizeof(float)),
                  szDone = up(N), szObjv = up(NA * sizeof(float)), szMd = up(NA * 6 * sizeof(int32_t)),
                  szObs = up(NA * (size_t)g->w * g->h * 4);
-    const size_t total = szHdr + szBoxes + szObj + szAg + szAct + szRew + szDone + szObjv + szMd + szChunk + szObs;
+    const bool obstacles = scenario == SCN_OBSTACLES;
+    const size_t szTerrain = obstacles ? up(N * MAX_TERRAIN * sizeof(TerrainBox)) : 0, szRewObj = obstacles ? up(N * MAX_REWARDS * sizeof(MovableObject)) : 0,
+                 szBlobs = obstacles ? up(N * sizeof(EpisodeBlob)) : 0, szCnt = 4096;
+    const size_t total = szHdr + szBoxes + szObj + szAg + szAct + szRew + szDone + szObjv + szMd + (obstacles ? 0 : szChunk) + szObs + szTerrain + szRewObj + szBlobs + szCnt;
     {
         hipError_t e_ = hipMalloc((void **)&g->arena, total);
         if (e_ != hipSuccess) { mv_destroy(g); return fail(std::string("hipMalloc arena: ") + hipGetErrorString(e_)); }
@@ -242,8 +285,14 @@ int mv_create(const mv_config *cfg, mv_gym **out)
         gv.done = p; p += szDone;
         gv.true_objective = (float *)p; p += szObjv;
         g->dMultiDiscrete = (int32_t *)p; p += szMd;
-        gv.chunk = p; p += szChunk;
+        if (!obstacles) { gv.chunk = p; p += szChunk; }
         g->ownedObs = (uint32_t *)p; p += szObs;
+        g->dTotalConsumed = (int *)p; p += szCnt;
+        if (obstacles) {
+            gv.terrain = (TerrainBox *)p; p += szTerrain;
+            gv.rewards_obj = (MovableObject *)p; p += szRewObj;
+            g->dBlobs = (EpisodeBlob *)p; p += szBlobs;
+        }
     }
     g->obs = g->ownedObs;
     for (int b = 0; b < 2; ++b) {
@@ -259,8 +308,29 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     // headers: float params + unseeded envs take their seed from random_device (env.hpp:169)
     float episodeLen = 60.0f, lookLimit = 0.2f;   // scenario.hpp:225-232
     for (int k = 0; k < cfg->num_params; ++k) {
-        if (!std::strcmp(cfg->param_keys[k], "episodeLengthSec")) episodeLen = cfg->param_vals[k];
-        if (!std::strcmp(cfg->param_keys[k], "verticalLookLimitRad")) lookLimit = cfg->param_vals[k];
+        const char *key = cfg->param_keys[k];
+        const float v = cfg->param_vals[k];
+        if (!std::strcmp(key, "episodeLengthSec")) episodeLen = v;
+        if (!std::strcmp(key, "verticalLookLimitRad")) lookLimit = v;
+        auto ip = [&](const char *name, int &dst) { if (!std::strcmp(key, name)) dst = int(std::lround(v)); };   // Platform::param()
+        ip("obstaclesMinNumPlatforms", oc.min_platforms); ip("obstaclesMaxNumPlatforms", oc.max_platforms);
+        ip("obstaclesMinGap", oc.min_gap); ip("obstaclesMaxGap", oc.max_gap); ip("obstaclesMinLava", oc.min_lava);
+        ip("obstaclesMaxLava", oc.max_lava); ip("obstaclesMinHeight", oc.min_height); ip("obstaclesMaxHeight", oc.max_height);
+        if (!std::strcmp(key, "obstaclesNumAllowedMaxDifficulty")) oc.num_allowed_max_difficulty = int(v);
+    }
+    g->obst = oc;
+    g->baseEpisodeLen = episodeLen;
+    if (obstacles) {
+        std::random_device rdev;
+        for (size_t i = 0; i < N; ++i) g->envRng.emplace_back(rdev());
+        g->uploaded.assign(N, 0);
+        if (hipHostMalloc((void **)&g->hBlobs, N * sizeof(EpisodeBlob), hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void **)&g->hTotalConsumed, sizeof(int), hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&g->consumedCopied, hipEventDisableTiming) != hipSuccess) {
+            mv_destroy(g);
+            return fail("mv_create: pinned episode staging allocation failed");
+        }
+        *g->hTotalConsumed = 0;
     }
     std::vector<EnvHeader> hh(N);
     std::random_device rd;
@@ -269,11 +339,13 @@ int mv_create(const mv_config *cfg, mv_gym **out)
         hh[i].p_episode_len_sec = episodeLen; hh[i].p_vertical_look_limit = lookLimit;
         hh[i].next_seed = (uint32_t)rd(); hh[i].seed_is_env_seed = 1;
         hh[i].bar_half_width = 0.24f;
+        hh[i].scenario = scenario;
     }
     std::vector<AgentState> ha(NA);
     for (size_t i = 0; i < NA; ++i) {
         std::memset(&ha[i], 0, sizeof(AgentState));
-        for (int k = 0; k < NUM_SHAPING; ++k) ha[i].shaping[k] = SHAPING_DEFAULT[k];
+        for (int k = 0; k < g->numShaping; ++k)
+            ha[i].shaping[k] = scenario == SCN_TOWER ? SHAPING_DEFAULT_TOWER[k] : (k == 4 ? oc.carried_object_to_exit : SHAPING_DEFAULT_OBST[k]);
         ha[i].carrying = -1; ha[i].jump_speed = 10.0f; ha[i].m00 = 1.0f; ha[i].m22 = 1.0f;
     }
     if (hipMemcpy(gv.hdr, hh.data(), N * sizeof(EnvHeader), hipMemcpyHostToDevice) != hipSuccess ||
@@ -293,6 +365,10 @@ int mv_close(mv_gym *g)
     GymView &gv = g->gv;
     if (g->arena) (void)hipFree(g->arena);
     if (g->hiresObs) (void)hipFree(g->hiresObs);
+    if (g->hBlobs) (void)hipHostFree(g->hBlobs);
+    if (g->hTotalConsumed) (void)hipHostFree(g->hTotalConsumed);
+    if (g->consumedCopied) (void)hipEventDestroy(g->consumedCopied);
+    g->hBlobs = nullptr; g->hTotalConsumed = nullptr; g->consumedCopied = nullptr; g->dBlobs = nullptr; g->dTotalConsumed = nullptr;
     g->arena = nullptr;
     for (int b = 0; b < 2; ++b) {
         if (g->hActions[b]) (void)hipHostFree(g->hActions[b]);
@@ -342,6 +418,10 @@ int mv_seed(mv_gym *g, int32_t seed)
         const int noise = std::uniform_int_distribution<>{0, (1 << 30) - 1}(g->rng);
         if (i >= g->envOffset && i < g->envOffset + g->N) seeds[i - g->envOffset] = (uint32_t)noise;
     }
+    if (g->scenario == SCN_OBSTACLES) {   // Env::seed (env.cpp:52-55) on the host-side episode generators
+        for (int i = 0; i < g->N; ++i) g->envRng[i].seed((unsigned long)seeds[i]);
+        return 0;
+    }
     uint32_t *d = nullptr;
     HIP_TRY(hipMalloc((void **)&d, g->N * sizeof(uint32_t)));
     HIP_TRY(hipMemcpyAsync(d, seeds.data(), g->N * sizeof(uint32_t), hipMemcpyHostToDevice, g->stream));
@@ -360,11 +440,52 @@ int mv_render(mv_gym *g)
     return 0;
 }
 
+// ---- Obstacles refill protocol --------------------------------------------------------------------
+// Each env keeps ONE host-generated episode resident (dBlobs[env]); the reset kernel swaps it in and
+// bumps hdr.episodes_consumed + *dTotalConsumed.  After every step the counter is copied to pinned
+// memory; the next host call looks at it (the copy finished a whole step ago) and, when it moved,
+// generates + uploads the following episode for exactly the envs that consumed theirs.  Episodes last
+// >= 35 s = 525 steps, so the spare is always in place long before it is needed.
+static int upload_next_episode(mv_gym *g, int env)
+{
+    EpisodeBlob &b = g->hBlobs[env];
+    generate_obstacles_episode(g->envRng[env], g->obst, g->A, g->baseEpisodeLen, b);
+    b.seq = ++g->uploaded[env];
+    HIP_TRY(hipMemcpyAsync(g->dBlobs + env, &b, sizeof b, hipMemcpyHostToDevice, g->stream));
+    return 0;
+}
+
+static int refill_episodes(mv_gym *g, bool force)
+{
+    if (g->scenario != SCN_OBSTACLES) return 0;
+    if (g->consumedPending) {
+        HIP_TRY(hipEventSynchronize(g->consumedCopied));
+        g->consumedPending = false;
+    }
+    if (!force && *g->hTotalConsumed == g->lastTotalSeen) return 0;
+    std::vector<EnvHeader> hh(g->N);
+    HIP_TRY(hipMemcpyAsync(hh.data(), g->gv.hdr, g->N * sizeof(EnvHeader), hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    int total = 0;
+    for (int i = 0; i < g->N; ++i) {
+        if (hh[i].starved) return fail("Obstacles env " + std::to_string(i) + " reset without a fresh episode");
+        total += hh[i].episodes_consumed;
+        if (hh[i].episodes_consumed == g->uploaded[i] && upload_next_episode(g, i)) return -1;
+    }
+    g->lastTotalSeen = total;
+    return 0;
+}
+
 int mv_reset(mv_gym *g)
 {   // MegaverseGym::reset (megaverse.cpp:76-93) -> VectorEnv::reset (vector_env.cpp:110-120)
     if (check(g)) return -1;
     HIP_TRY(hipSetDevice(g->device));
-    launch_reset(g->gv, 1, g->stream);
+    if (g->scenario == SCN_OBSTACLES) {
+        if (refill_episodes(g, true)) return -1;        // every env has an unconsumed episode resident
+        launch_reset_obstacles(g->gv, g->dBlobs, g->dTotalConsumed, 1, g->stream);
+        if (refill_episodes(g, true)) return -1;        // and a spare for the first auto-reset
+    } else
+        launch_reset(g->gv, 1, g->stream);
     HIP_TRY(hipGetLastError());
     g->wasReset = true;
     g->mirrorsFresh = false;
@@ -423,6 +544,7 @@ static int step_impl(mv_gym *g, bool render)
     if (check(g)) return -1;
     if (!g->wasReset) return fail("mv_step: call mv_reset first");
     HIP_TRY(hipSetDevice(g->device));
+    if (refill_episodes(g, false)) return -1;
     if (g->actionsDirty) {
         const int s = g->stage;
         HIP_TRY(hipMemcpyAsync(g->gv.actions, g->hActions[s], (size_t)g->N * g->A * sizeof(int32_t), hipMemcpyHostToDevice, g->stream));
@@ -435,9 +557,16 @@ static int step_impl(mv_gym *g, bool render)
     const bool prof = render && g->profCount < g->profMax;
     hipEvent_t *ev = prof ? &g->profEvents[(size_t)g->profCount * 4] : nullptr;
     if (prof) HIP_TRY(hipEventRecord(ev[0], g->stream));
-    launch_step(g->gv, g->stream);
+    if (g->scenario == SCN_OBSTACLES) launch_step_obstacles(g->gv, g->stream);
+    else launch_step(g->gv, g->stream);
     if (prof) HIP_TRY(hipEventRecord(ev[1], g->stream));
-    launch_reset(g->gv, 0, g->stream);
+    if (g->scenario == SCN_OBSTACLES) {
+        launch_reset_obstacles(g->gv, g->dBlobs, g->dTotalConsumed, 0, g->stream);
+        HIP_TRY(hipMemcpyAsync(g->hTotalConsumed, g->dTotalConsumed, sizeof(int), hipMemcpyDeviceToHost, g->stream));
+        HIP_TRY(hipEventRecord(g->consumedCopied, g->stream));
+        g->consumedPending = true;
+    } else
+        launch_reset(g->gv, 0, g->stream);
     if (prof) HIP_TRY(hipEventRecord(ev[2], g->stream));
     if (render && launch_raster(g->gv, g->obs, g->w, g->h, g->stream)) return fail("mv_step: observation size above 1024x1024");
     if (prof) { HIP_TRY(hipEventRecord(ev[3], g->stream)); ++g->profCount; }
@@ -579,20 +708,20 @@ int mv_get_hires_observation(mv_gym *g, int32_t env, int32_t agent, uint8_t *out
 
 int mv_draw_overview(mv_gym *g) { return check(g) ? -1 : 0; }
 
-int mv_num_reward_shaping_keys(const mv_gym *) { return NUM_SHAPING; }
-const char *mv_reward_shaping_key(const mv_gym *, int32_t i) { return (i >= 0 && i < NUM_SHAPING) ? SHAPING_KEYS[i] : nullptr; }
+int mv_num_reward_shaping_keys(const mv_gym *g) { return g ? g->numShaping : 0; }
+const char *mv_reward_shaping_key(const mv_gym *g, int32_t i) { return (g && i >= 0 && i < g->numShaping) ? g->shapingKeys[i] : nullptr; }
 
-static int shaping_index(const char *key)
+static int shaping_index(const mv_gym *g, const char *key)
 {
-    for (int k = 0; k < NUM_SHAPING; ++k)
-        if (!std::strcmp(key, SHAPING_KEYS[k])) return k;
+    for (int k = 0; k < g->numShaping; ++k)
+        if (!std::strcmp(key, g->shapingKeys[k])) return k;
     return -1;
 }
 
 int mv_get_reward_shaping(mv_gym *g, int32_t env, int32_t agent, const char *key, float *out)
 {
     if (check(g)) return -1;
-    const int k = shaping_index(key);
+    const int k = shaping_index(g, key);
     if (k < 0) return fail(std::string("unknown reward shaping key ") + key);
     if (env < 0 || env >= g->N || agent < 0 || agent >= g->A) return fail("mv_get_reward_shaping: index out of range");
     HIP_TRY(hipMemcpyAsync(out, &g->gv.agents[(size_t)env * g->A + agent].shaping[k], sizeof(float), hipMemcpyDeviceToHost, g->stream));
@@ -603,7 +732,7 @@ int mv_get_reward_shaping(mv_gym *g, int32_t env, int32_t agent, const char *key
 int mv_set_reward_shaping(mv_gym *g, int32_t env, int32_t agent, const char *key, float v)
 {
     if (check(g)) return -1;
-    const int k = shaping_index(key);
+    const int k = shaping_index(g, key);
     if (k < 0) return fail(std::string("unknown reward shaping key ") + key);
     if (env < 0 || env >= g->N || agent < 0 || agent >= g->A) return fail("mv_set_reward_shaping: index out of range");
     hipLaunchKernelGGL(set_shaping_kernel, dim3(1), dim3(1), 0, g->stream, g->gv.agents, env * g->A + agent, k, v);
@@ -616,14 +745,16 @@ int mv_set_reward_shaping(mv_gym *g, int32_t env, int32_t agent, const char *key
 struct SnapAgent {
     float pos[3], basis[4], pitch, hv[2], vvel, voffset, step_offset, jump_speed;
     int32_t was_jumping, carrying, picked_up, visited_zone, spawn[3];
-    float last_reward, total_reward, shaping[4];
+    float last_reward, total_reward, shaping[NUM_SHAPING];
 };
 struct Snap {
-    int32_t L, H, W, bz[4], layout_color, wall_color, draw_walls, num_objects, num_boxes, num_frames, done, highest_tower,
-        num_agents;
+    int32_t scenario, L, H, W, bz[4], layout_color, wall_color, draw_walls, num_objects, num_boxes, num_frames, done, highest_tower,
+        num_agents, num_terrain, num_rewards, num_platforms, solved;
     float episode_sec, episode_len, bz_reward, bar_half_width;
     int32_t boxes[MAX_BOXES][8];
+    int32_t terrain[MAX_TERRAIN][8];
     int8_t objects[MAX_OBJECTS][4];
+    int8_t rewards[MAX_REWARDS][4];
     SnapAgent agents[MAX_AGENTS];
     uint8_t chunk[CHUNK_BYTES];
 };
@@ -646,8 +777,21 @@ int mv_debug_snapshot(mv_gym *g, int32_t env, void *out)
     if (e == hipSuccess) e = hipMemcpy(boxes.data(), g->gv.boxes + (size_t)env * MAX_BOXES, MAX_BOXES * sizeof(LayoutBox), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(objs.data(), g->gv.objects + (size_t)env * MAX_OBJECTS, MAX_OBJECTS * sizeof(MovableObject), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(ag.data(), g->gv.agents + (size_t)env * g->A, g->A * sizeof(AgentState), hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(s->chunk, g->gv.chunk + (size_t)env * CHUNK_BYTES, CHUNK_BYTES, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && g->gv.chunk) e = hipMemcpy(s->chunk, g->gv.chunk + (size_t)env * CHUNK_BYTES, CHUNK_BYTES, hipMemcpyDeviceToHost);
+    std::vector<TerrainBox> terr(MAX_TERRAIN);
+    std::vector<MovableObject> rew(MAX_REWARDS);
+    if (e == hipSuccess && g->gv.terrain) e = hipMemcpy(terr.data(), g->gv.terrain + (size_t)env * MAX_TERRAIN, MAX_TERRAIN * sizeof(TerrainBox), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && g->gv.rewards_obj) e = hipMemcpy(rew.data(), g->gv.rewards_obj + (size_t)env * MAX_REWARDS, MAX_REWARDS * sizeof(MovableObject), hipMemcpyDeviceToHost);
     if (e != hipSuccess) { delete s; return fail(std::string("mv_debug_snapshot: ") + hipGetErrorString(e)); }
+    s->scenario = h.scenario; s->num_terrain = h.num_terrain; s->num_rewards = h.num_rewards; s->num_platforms = h.num_platforms; s->solved = h.solved;
+    for (int i = 0; i < h.num_terrain && i < MAX_TERRAIN; ++i) {
+        const TerrainBox &t = terr[i];
+        int32_t *o = s->terrain[i];
+        o[0] = t.min[0]; o[1] = t.min[1]; o[2] = t.min[2]; o[3] = t.max[0]; o[4] = t.max[1]; o[5] = t.max[2]; o[6] = t.type; o[7] = 0;
+    }
+    for (int i = 0; i < h.num_rewards && i < MAX_REWARDS; ++i) {
+        s->rewards[i][0] = rew[i].x; s->rewards[i][1] = rew[i].y; s->rewards[i][2] = rew[i].z; s->rewards[i][3] = rew[i].state;
+    }
     s->L = h.L; s->H = h.H; s->W = h.W;
     for (int i = 0; i < 4; ++i) s->bz[i] = h.bz[i];
     s->layout_color = h.layout_color; s->wall_color = h.wall_color; s->draw_walls = h.draw_walls;
@@ -672,7 +816,7 @@ int mv_debug_snapshot(mv_gym *g, int32_t env, void *out)
         o.picked_up = a.picked_up; o.visited_zone = a.visited_zone;
         for (int k = 0; k < 3; ++k) o.spawn[k] = a.spawn[k];
         o.last_reward = a.last_reward; o.total_reward = a.total_reward;
-        for (int k = 0; k < 4; ++k) o.shaping[k] = a.shaping[k];
+        for (int k = 0; k < NUM_SHAPING; ++k) o.shaping[k] = a.shaping[k];
     }
     std::memcpy(out, s, sizeof *s);
     delete s;

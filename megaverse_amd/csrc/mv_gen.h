@@ -1,0 +1,21 @@
+// megaverse_amd/csrc/mv_gen.h -- host-side episode generators (see mv_gen_obstacles.cpp)
+#pragma once
+#include <random>
+
+#include "mv_types.h"
+
+namespace mv {
+
+// ObstaclesScenario float params as integers (scenario_obstacles.hpp:46-68; per registered name :94-268)
+struct ObstacleConfig {
+    int min_platforms = 1, max_platforms = 2, min_gap = 1, max_gap = 2, min_lava = 1, max_lava = 4, min_height = 1, max_height = 3;
+    int num_allowed_max_difficulty = 1;
+    int platform_types[4] = {1, 2, 3, 4};   // WALL, LAVA, STEP, GAP
+    int num_platform_types = 4;
+    float carried_object_to_exit = 0.0f;    // default of the obstaclesAgentCarriedObjectToExit shaping key
+};
+
+// Advances `rng` exactly like Env::reset + ObstaclesScenario::reset + spawnAgents and fills `out`.
+void generate_obstacles_episode(std::mt19937 &rng, const ObstacleConfig &cfg, int num_agents, float base_episode_len, EpisodeBlob &out);
+
+}  // namespace mv

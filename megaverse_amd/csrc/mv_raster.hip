@@ -43,18 +43,18 @@ constexpr float TAN_HALF_FOV_Y = 1.19175359f / (128.0f / 72.0f);  // aspect 128/
 constexpr float NEAR_Z = 0.01f, FAR_Z = 120.0f;
 constexpr float OBJ_HALF = 0.39f, CARRY_SCALE = 0.78f;
 constexpr int TILE_W = 16, TILE_H = 4;
-constexpr int MAX_PRIMS = 128;
+constexpr int MAX_VIS = 256;          // visible primitives kept per frame (slots: <=121 TowerBuilding, <=280 Obstacles)
 constexpr int MAX_STRADDLERS = 12;    // x 5 frustum planes = 60 lanes of one wave
 constexpr float STRADDLE_W = 0.05f;   // closer than this to the camera plane: projection unusable
 constexpr int MAX_W = 1024, MAX_H = 1024;
 
 __constant__ unsigned AGENT_COLORS[7] = {0xffdd3c, 0x3bb372, 0x2eb5d0, 0xffb400, 0xd468ee, 0x222222, 0xff0000};
 
-enum : int { PRIM_NONE = 0, PRIM_BOX = 1, PRIM_CAPSULE = 2 };
+enum : int { PRIM_NONE = 0, PRIM_BOX = 1, PRIM_CAPSULE = 2, PRIM_CONE = 3 };
 
 struct alignas(16) Prim {   // 64 B
-    float lo[3]; int32_t meta;    // box: bounds minus the ray origin of its frame; capsule: centre (world)
-    float hi[3]; int32_t slot;    //                                                 capsule: (radius, halfLen, 0)
+    float lo[3]; int32_t meta;    // box: bounds minus the ray origin of its frame; capsule: centre (world); cone: apex (world)
+    float hi[3]; int32_t slot;    //        capsule: (radius, halfLen, 0); cone: (base radius, height, +1 apex up / -1 apex down)
     float k1[3]; float pad0;      // AMB * colour
     float k2[3]; float pad1;      // (DIF * colour) * LCOL
 };                                // meta = kind | frame << 8 ; frame 0 = world axes, 1+k = camera frame of agent k
@@ -156,6 +156,40 @@ __device__ __forceinline__ bool ray_capsule(V3 o, V3 d, V3 c, float r, float hl,
     return hit;
 }
 
+// open cone (no base cap), apex a, axis +-y; only its outside is visible (back-face culling).  Diamonds of the
+// Obstacles scenarios: two of these base to base (layout_utils.cpp:114-126)
+__device__ __forceinline__ bool ray_cone(V3 o, V3 d, V3 a, float r, float h, float dirSign, float &t_out, V3 &n_out)
+{
+    const float k = (r / h) * (r / h);
+    const float ox = o.x - a.x, oz = o.z - a.z;
+    const float s0 = dirSign * (a.y - o.y);
+    const float ds = -dirSign * d.y;
+    const float A = (d.x * d.x + d.z * d.z) - k * (ds * ds);
+    const float B = (ox * d.x + oz * d.z) - k * (s0 * ds);
+    const float C = (ox * ox + oz * oz) - k * (s0 * s0);
+    if (A == 0.0f) return false;
+    const float disc = B * B - A * C;
+    if (!(disc >= 0.0f)) return false;
+    const float sq = sqrtf(disc);
+    bool hit = false;
+    float best = INFINITY; V3 bn = v3(0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float t = (i == 0 ? (-B - sq) : (-B + sq)) / A;
+        const float s = s0 + t * ds;
+        if (!(t >= NEAR_Z && t <= FAR_Z && s >= 0.0f && s <= h && t < best)) continue;
+        const float px = ox + t * d.x, pz = oz + t * d.z;
+        V3 n = v3(px, dirSign * (k * s), pz);
+        if (!(dot(n, d) < 0.0f)) continue;
+        const float l2 = len2(n);
+        if (!(l2 > 0.0f)) continue;
+        n = n * (1.0f / sqrtf(l2));
+        hit = true; best = t; bn = n;
+    }
+    if (hit) { t_out = best; n_out = bn; }
+    return hit;
+}
+
 __device__ __forceinline__ float pow300(float x)
 {
     const float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8, x32 = x16 * x16, x64 = x32 * x32, x128 = x64 * x64,
@@ -227,10 +261,10 @@ __device__ unsigned long long g_frame_t0[4096], g_frame_t1[4096], g_frame_tp[409
 __global__ __launch_bounds__(256, 4) void raster_kernel(GymView gv, uint32_t *obs, int W, int H, int split)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // column/row ray tables
-    __shared__ Prim s_vis[MAX_PRIMS];     // compacted visible list: straddlers first, then rectangle-bounded primitives
-    __shared__ short4 s_rect[MAX_PRIMS];  // x0,x1,y0,y1 (pixels)
+    __shared__ Prim s_vis[MAX_VIS];       // compacted visible list: straddlers first, then rectangle-bounded primitives
+    __shared__ short4 s_rect[MAX_VIS];    // x0,x1,y0,y1 (pixels)
     __shared__ CamL s_cam[MAX_AGENTS];
-    __shared__ int s_cnt[4];              // straddlers in wave 0 / 1, rectangle primitives in wave 0 / 1
+    __shared__ int s_cnt[16];             // [round*4 + wave]: straddlers, [8 + round*4 + wave]: rectangle-bounded primitives
 
     float4 *s_col = reinterpret_cast<float4 *>(s_dyn);   // per column i: (dc.x, c00*dc.x, c10*dc.x, c20*dc.x)
     float4 *s_row = s_col + W;                            // per row j:    (dc.y, c01*dc.y, c11*dc.y, c21*dc.y)
@@ -289,112 +323,176 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(GymView gv, uint32_t *ob
     }
     __syncthreads();   // cameras (incl. origin) complete
 
-    // ---- this thread's primitive (slot order == draw order used for depth ties); bounds in its own frame
-    int kind = PRIM_NONE, fr = 0;
-    unsigned color = 0;
-    float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-    if (tid < MAX_PRIMS) {
-        if (tid < MAX_BOXES) {
-            if (tid < hdr->num_boxes) {
-                const LayoutBox b = gv.boxes[(size_t)env * MAX_BOXES + tid];
-                if (b.type & VX_OPAQUE) {
+    // ---- primitive slots (slot order == the order the reference emits drawables == depth-tie order):
+    //   TowerBuilding: 16 layout slabs | building-zone slab | 80 movable boxes | 3 per agent (body, eyes, time bar)
+    //   Obstacles:     128 layout slabs | 16 terrain slabs | 80 movable boxes | 2 cones per diamond x 16 | 3 per agent
+    const int scen = hdr->scenario;
+    const int nLayout = scen == SCN_TOWER ? TOWER_BOXES : MAX_BOXES;
+    const int slotTerrain = nLayout, nTerrainSlots = scen == SCN_TOWER ? 1 : MAX_TERRAIN;
+    const int slotObjects = slotTerrain + nTerrainSlots;
+    const int slotRewards = slotObjects + MAX_OBJECTS, nRewardSlots = scen == SCN_TOWER ? 0 : 2 * MAX_REWARDS;
+    const int slotAgents = slotRewards + nRewardSlots;
+    const int numSlots = slotAgents + 3 * A;
+
+    int kindR[2], frR[2], clsR[2], rectR[2][4];
+    unsigned colorR[2];
+    float loR[2][3], hiR[2][3];
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+        const int slot = tid + 256 * rd;
+        int kind = PRIM_NONE, fr = 0;
+        unsigned color = 0;
+        float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+        if (slot < numSlots) {
+            if (slot < nLayout) {
+                if (slot < hdr->num_boxes) {
+                    const LayoutBox b = gv.boxes[(size_t)env * MAX_BOXES + slot];
+                    if (b.type & VX_OPAQUE) {
+                        kind = PRIM_BOX;
+                        lo[0] = float(b.min[0]); lo[1] = float(b.min[1]); lo[2] = float(b.min[2]);
+                        hi[0] = float(b.max[0]); hi[1] = float(b.max[1]); hi[2] = float(b.max[2]);
+                        color = (unsigned)(b.slot == 0 ? hdr->layout_color : hdr->wall_color);
+                    }
+                }
+            } else if (slot < slotObjects) {
+                if (scen == SCN_TOWER) {   // building-zone slab (layout_utils.cpp:53-68)
                     kind = PRIM_BOX;
-                    lo[0] = float(b.min[0]); lo[1] = float(b.min[1]); lo[2] = float(b.min[2]);
-                    hi[0] = float(b.max[0]); hi[1] = float(b.max[1]); hi[2] = float(b.max[2]);
-                    color = (unsigned)(b.slot == 0 ? hdr->layout_color : hdr->wall_color);
+                    lo[0] = float(hdr->bz[0]); lo[1] = 1.0f; lo[2] = float(hdr->bz[2]);
+                    hi[0] = float(hdr->bz[1]); hi[1] = 1.0f + 0.05f; hi[2] = float(hdr->bz[3]);
+                    color = 0x555555u;
+                } else if (slot - slotTerrain < hdr->num_terrain) {   // exit pad / lava: 0.05-thick slab on the box's floor
+                    const TerrainBox t = gv.terrain[(size_t)env * MAX_TERRAIN + (slot - slotTerrain)];
+                    kind = PRIM_BOX;
+                    lo[0] = float(t.min[0]); lo[1] = float(t.min[1]); lo[2] = float(t.min[2]);
+                    hi[0] = float(t.max[0]); hi[1] = float(t.min[1]) + 0.05f; hi[2] = float(t.max[2]);
+                    color = t.type == TERRAIN_EXIT ? 0x50c878u : 0xff0000u;   // platforms.hpp:47-56
                 }
-            }
-        } else if (tid == MAX_BOXES) {   // building-zone slab
-            kind = PRIM_BOX;
-            lo[0] = float(hdr->bz[0]); lo[1] = 1.0f; lo[2] = float(hdr->bz[2]);
-            hi[0] = float(hdr->bz[1]); hi[1] = 1.0f + 0.05f; hi[2] = float(hdr->bz[3]);
-            color = 0x555555u;
-        } else if (tid < MAX_BOXES + 1 + MAX_OBJECTS) {
-            const int j = tid - (MAX_BOXES + 1);
-            if (j < hdr->num_objects) {
-                const MovableObject o = gv.objects[(size_t)env * MAX_OBJECTS + j];
-                color = 0xadd8e6u;
-                kind = PRIM_BOX;
-                if (o.state == 0) {
-                    const float cx = float(o.x) + 0.5f, cy = float(o.y) + 0.5f, cz = float(o.z) + 0.5f;
-                    lo[0] = cx - OBJ_HALF; lo[1] = cy - OBJ_HALF; lo[2] = cz - OBJ_HALF;
-                    hi[0] = cx + OBJ_HALF; hi[1] = cy + OBJ_HALF; hi[2] = cz + OBJ_HALF;
-                } else {
-                    fr = (int)o.state;
-                    const float hh = OBJ_HALF * CARRY_SCALE;
-                    const float cx = 0.0f, cy = -0.44f + -0.3f, cz = -1.0f;
-                    lo[0] = cx - hh; lo[1] = cy - hh; lo[2] = cz - hh;
-                    hi[0] = cx + hh; hi[1] = cy + hh; hi[2] = cz + hh;
+            } else if (slot < slotRewards) {
+                const int j = slot - slotObjects;
+                if (j < hdr->num_objects) {
+                    const MovableObject o = gv.objects[(size_t)env * MAX_OBJECTS + j];
+                    color = 0xadd8e6u;
+                    kind = PRIM_BOX;
+                    if (o.state == 0) {
+                        const float cx = float(o.x) + 0.5f, cy = float(o.y) + 0.5f, cz = float(o.z) + 0.5f;
+                        lo[0] = cx - OBJ_HALF; lo[1] = cy - OBJ_HALF; lo[2] = cz - OBJ_HALF;
+                        hi[0] = cx + OBJ_HALF; hi[1] = cy + OBJ_HALF; hi[2] = cz + OBJ_HALF;
+                    } else {
+                        fr = (int)o.state;
+                        const float hh = OBJ_HALF * CARRY_SCALE;
+                        const float cx = 0.0f, cy = -0.44f + -0.3f, cz = -1.0f;
+                        lo[0] = cx - hh; lo[1] = cy - hh; lo[2] = cz - hh;
+                        hi[0] = cx + hh; hi[1] = cy + hh; hi[2] = cz + hh;
+                    }
                 }
-            }
-        } else {
-            const int q = tid - (MAX_BOXES + 1 + MAX_OBJECTS);
-            const int k = q / 3, part = q - 3 * k;
-            if (k < A) {
-                if (part == 0 && k != viewer) {
-                    const AgentState a = agents[k];
-                    kind = PRIM_CAPSULE;
-                    lo[0] = a.pos[0]; lo[1] = (a.pos[1] + 0.05f) + 0.09f; lo[2] = a.pos[2];
-                    hi[0] = 0.35f; hi[1] = 0.36f; hi[2] = 0.0f;
-                    color = AGENT_COLORS[k % 7];
-                } else if (part == 1 && k != viewer) {
-                    kind = PRIM_BOX; fr = 1 + k;
-                    lo[0] = -0.25f; lo[1] = -0.12f; lo[2] = -0.19f - 0.2f;
-                    hi[0] = 0.25f; hi[1] = 0.12f; hi[2] = -0.19f + 0.2f;
-                    color = 0x2c3e50u;
-                } else if (part == 2) {
-                    const float bw = hdr->bar_half_width;
-                    kind = PRIM_BOX; fr = 1 + k;
-                    lo[0] = -bw; lo[1] = -0.131f - 0.0015f; lo[2] = -0.2f - 0.001f;
-                    hi[0] = bw; hi[1] = -0.131f + 0.0015f; hi[2] = -0.2f + 0.001f;
-                    color = 0x2eb5d0u;
+            } else if (slot < slotAgents) {   // diamonds (addDiamond, layout_utils.cpp:114-126; scenario_obstacles.cpp:254)
+                const int j = (slot - slotRewards) >> 1, part = (slot - slotRewards) & 1;
+                if (j < hdr->num_rewards) {
+                    const MovableObject r = gv.rewards_obj[(size_t)env * MAX_REWARDS + j];
+                    if (r.state != 0) {
+                        const float sx = 0.17f * 0.8f, sy = 0.45f * 0.8f;
+                        const float cx = float(r.x) + 0.5f, cy = float(r.y) + 0.7f, cz = float(r.z) + 0.5f;
+                        kind = PRIM_CONE;
+                        color = 0x3bb372u;
+                        lo[0] = cx; lo[2] = cz;
+                        lo[1] = part == 0 ? cy + 0.5f * sy : cy - 1.5f * sy;
+                        hi[0] = sx; hi[1] = sy; hi[2] = part == 0 ? 1.0f : -1.0f;
+                    }
+                }
+            } else {
+                const int q = slot - slotAgents;
+                const int k = q / 3, part = q - 3 * k;
+                if (k < A) {
+                    if (part == 0 && k != viewer) {
+                        const AgentState a = agents[k];
+                        kind = PRIM_CAPSULE;
+                        lo[0] = a.pos[0]; lo[1] = (a.pos[1] + 0.05f) + 0.09f; lo[2] = a.pos[2];
+                        hi[0] = 0.35f; hi[1] = 0.36f; hi[2] = 0.0f;
+                        color = AGENT_COLORS[k % 7];
+                    } else if (part == 1 && k != viewer) {
+                        kind = PRIM_BOX; fr = 1 + k;
+                        lo[0] = -0.25f; lo[1] = -0.12f; lo[2] = -0.19f - 0.2f;
+                        hi[0] = 0.25f; hi[1] = 0.12f; hi[2] = -0.19f + 0.2f;
+                        color = 0x2c3e50u;
+                    } else if (part == 2) {
+                        const float bw = hdr->bar_half_width;
+                        kind = PRIM_BOX; fr = 1 + k;
+                        lo[0] = -bw; lo[1] = -0.131f - 0.0015f; lo[2] = -0.2f - 0.001f;
+                        hi[0] = bw; hi[1] = -0.131f + 0.0015f; hi[2] = -0.2f + 0.001f;
+                        color = 0x2eb5d0u;
+                    }
                 }
             }
         }
+        // frame-level visibility
+        int cls = 0;
+        int rect[4] = {0, 0, 0, 0};
+        if (kind != PRIM_NONE) {
+            float blo[3] = {lo[0], lo[1], lo[2]}, bhi[3] = {hi[0], hi[1], hi[2]};
+            if (kind == PRIM_CAPSULE) {
+                const float r = hi[0], hl = hi[1];
+                blo[0] = lo[0] - r; blo[1] = lo[1] - (hl + r); blo[2] = lo[2] - r;
+                bhi[0] = lo[0] + r; bhi[1] = lo[1] + (hl + r); bhi[2] = lo[2] + r;
+            } else if (kind == PRIM_CONE) {
+                const float r = hi[0], h = hi[1];
+                blo[0] = lo[0] - r; blo[2] = lo[2] - r; bhi[0] = lo[0] + r; bhi[2] = lo[2] + r;
+                blo[1] = hi[2] > 0.0f ? lo[1] - h : lo[1];
+                bhi[1] = hi[2] > 0.0f ? lo[1] : lo[1] + h;
+            }
+            cls = screen_rect(blo, bhi, fr, s_cam, viewer, W, H, rect);
+            // straddlers that are not world boxes (something glued to a camera touching the viewer's eye, a
+            // capsule or a diamond at the lens) are rare: give them the whole screen instead of plane tests
+            if (cls == 2 && (fr != 0 || kind != PRIM_BOX)) { cls = 1; rect[0] = 0; rect[1] = W - 1; rect[2] = 0; rect[3] = H - 1; }
+        }
+        kindR[rd] = kind; frR[rd] = fr; clsR[rd] = cls; colorR[rd] = color;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { loR[rd][c] = lo[c]; hiR[rd][c] = hi[c]; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) rectR[rd][c] = rect[c];
     }
 
-    // ---- frame-level visibility + order-free compaction (ties are resolved on the slot id)
-    int cls = 0;
-    int rect[4] = {0, 0, 0, 0};
-    if (kind != PRIM_NONE) {
-        float blo[3] = {lo[0], lo[1], lo[2]}, bhi[3] = {hi[0], hi[1], hi[2]};
-        if (kind == PRIM_CAPSULE) {
-            const float r = hi[0], hl = hi[1];
-            blo[0] = lo[0] - r; blo[1] = lo[1] - (hl + r); blo[2] = lo[2] - r;
-            bhi[0] = lo[0] + r; bhi[1] = lo[1] + (hl + r); bhi[2] = lo[2] + r;
-        }
-        cls = screen_rect(blo, bhi, fr, s_cam, viewer, W, H, rect);
-        // straddlers that are not world boxes (something glued to a camera touching the viewer's eye, or a
-        // capsule at the lens) are rare: give them the whole screen instead of plane tests
-        if (cls == 2 && (fr != 0 || kind != PRIM_BOX)) { cls = 1; rect[0] = 0; rect[1] = W - 1; rect[2] = 0; rect[3] = H - 1; }
+    // ---- order-free compaction (depth ties are resolved on the slot id): straddlers first, then the rest
+    unsigned long long mSR[2], mRR[2];
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+        mSR[rd] = __ballot(clsR[rd] == 2);
+        mRR[rd] = __ballot(clsR[rd] == 1);
+        if (lane == 0) { s_cnt[rd * 4 + wave] = __popcll(mSR[rd]); s_cnt[8 + rd * 4 + wave] = __popcll(mRR[rd]); }
     }
-    const unsigned long long mS = __ballot(cls == 2), mR = __ballot(cls == 1);
-    if (wave < 2 && lane == 0) { s_cnt[wave] = __popcll(mS); s_cnt[2 + wave] = __popcll(mR); }
     __syncthreads();
-    int nStrad = s_cnt[0] + s_cnt[1];
-    const int nRect = s_cnt[2] + s_cnt[3];
+    int nStrad = 0, nRect = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { nStrad += s_cnt[q]; nRect += s_cnt[8 + q]; }
     const int extraStrad = nStrad > MAX_STRADDLERS ? nStrad - MAX_STRADDLERS : 0;   // overflow: whole-screen rectangles
     nStrad -= extraStrad;
-    const int nVis = nStrad + nRect + extraStrad;
-    if (cls != 0) {
+    const int nVis = min(nStrad + nRect + extraStrad, (int)MAX_VIS);
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+        if (clsR[rd] == 0) continue;
         const unsigned long long below = (1ull << lane) - 1ull;
+        int baseS = 0, baseR = 0;
+        for (int q = 0; q < rd * 4 + wave; ++q) { baseS += s_cnt[q]; baseR += s_cnt[8 + q]; }
         int pos;
-        if (cls == 2) {
-            pos = __popcll(mS & below) + (wave ? s_cnt[0] : 0);
+        int rect[4] = {rectR[rd][0], rectR[rd][1], rectR[rd][2], rectR[rd][3]};
+        if (clsR[rd] == 2) {
+            pos = baseS + __popcll(mSR[rd] & below);
             if (pos >= MAX_STRADDLERS) { pos = nStrad + nRect + (pos - MAX_STRADDLERS); rect[0] = 0; rect[1] = W - 1; rect[2] = 0; rect[3] = H - 1; }
-        } else pos = nStrad + __popcll(mR & below) + (wave ? s_cnt[2] : 0);
+        } else pos = nStrad + baseR + __popcll(mRR[rd] & below);
+        if (pos >= MAX_VIS) continue;   // cannot happen with <= 280 slots unless nearly everything is in view at once
+        const int kind = kindR[rd], fr = frR[rd];
+        const unsigned color = colorR[rd];
         Prim p;
         p.meta = kind | (fr << 8);
-        p.slot = tid;
+        p.slot = tid + 256 * rd;
         if (kind == PRIM_BOX) {   // bounds relative to the ray origin of the primitive's frame
             V3 o = v3(0.0f, 0.0f, 0.0f);
             if (fr == 0) o = v3(s_cam[viewer].eye[0], s_cam[viewer].eye[1], s_cam[viewer].eye[2]);
             else if (fr != 1 + viewer) o = v3(s_cam[fr - 1].origin[0], s_cam[fr - 1].origin[1], s_cam[fr - 1].origin[2]);
-            p.lo[0] = lo[0] - o.x; p.lo[1] = lo[1] - o.y; p.lo[2] = lo[2] - o.z;
-            p.hi[0] = hi[0] - o.x; p.hi[1] = hi[1] - o.y; p.hi[2] = hi[2] - o.z;
+            p.lo[0] = loR[rd][0] - o.x; p.lo[1] = loR[rd][1] - o.y; p.lo[2] = loR[rd][2] - o.z;
+            p.hi[0] = hiR[rd][0] - o.x; p.hi[1] = hiR[rd][1] - o.y; p.hi[2] = hiR[rd][2] - o.z;
         } else {
-            p.lo[0] = lo[0]; p.lo[1] = lo[1]; p.lo[2] = lo[2];
-            p.hi[0] = hi[0]; p.hi[1] = hi[1]; p.hi[2] = hi[2];
+            p.lo[0] = loR[rd][0]; p.lo[1] = loR[rd][1]; p.lo[2] = loR[rd][2];
+            p.hi[0] = hiR[rd][0]; p.hi[1] = hiR[rd][1]; p.hi[2] = hiR[rd][2];
         }
         const float AMB = float(0x55) / 255.0f, DIF = float(0xbb) / 255.0f, LCOL = float(0xaa) / 255.0f;
         const float col[3] = {float((color >> 16) & 255) / 255.0f, float((color >> 8) & 255) / 255.0f, float(color & 255) / 255.0f};
@@ -427,16 +525,18 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(GymView gv, uint32_t *ob
         const int tx0 = tx * TILE_W, ty0 = ty * TILE_H;
         const int tx1 = min(tx0 + TILE_W, W) - 1, ty1 = min(ty0 + TILE_H, H) - 1;
 
-        // ---- tile culling.  (a) rectangle-bounded primitives: one or two per lane, 4 integer compares
-        bool keep0 = false, keep1 = false;
-        {
-            if (lane >= nStrad && lane < nVis) {
-                const short4 r = s_rect[lane];
-                keep0 = r.x <= tx1 && r.y >= tx0 && r.z <= ty1 && r.w >= ty0;
-            }
-            if (lane + 64 < nVis) {
-                const short4 r = s_rect[lane + 64];
-                keep1 = r.x <= tx1 && r.y >= tx0 && r.z <= ty1 && r.w >= ty0;
+        // ---- tile culling.  (a) rectangle-bounded primitives: one per lane per round of 64, 4 integer compares
+        unsigned long long mk[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k * 64 < nVis) {   // wave-uniform
+                const int pos = lane + 64 * k;
+                bool v = false;
+                if (pos >= nStrad && pos < nVis) {
+                    const short4 r = s_rect[pos];
+                    v = r.x <= tx1 && r.y >= tx0 && r.z <= ty1 && r.w >= ty0;
+                }
+                mk[k] = __ballot(v);
             }
         }
         // (b) straddlers: survives when no frustum plane has the whole box on its outside.
@@ -457,19 +557,19 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(GymView gv, uint32_t *ob
         const unsigned long long mPlane = __ballot(planeOk);
         const unsigned long long g = mPlane & (mPlane >> MAX_STRADDLERS) & (mPlane >> (2 * MAX_STRADDLERS)) &
                                      (mPlane >> (3 * MAX_STRADDLERS)) & (mPlane >> (4 * MAX_STRADDLERS)) & ((1ull << MAX_STRADDLERS) - 1ull);
-        const unsigned long long m0 = __ballot(keep0) | g, m1 = __ballot(keep1);
+        mk[0] |= g;
 
 #ifdef MV_RASTER_STATS
         if (lane == 0) {
             atomicAdd(&g_raster_stats[0], 1ull);
-            atomicAdd(&g_raster_stats[1], (unsigned long long)(__popcll(m0) + __popcll(m1)));
+            atomicAdd(&g_raster_stats[1], (unsigned long long)(__popcll(mk[0]) + __popcll(mk[1]) + __popcll(mk[2]) + __popcll(mk[3])));
             atomicAdd(&g_raster_stats[2], (unsigned long long)__popcll(g));
             if (tile == 0) { atomicAdd(&g_raster_stats[3], (unsigned long long)nVis); atomicAdd(&g_raster_stats[4], 1ull); atomicAdd(&g_raster_stats[5], (unsigned long long)nStrad); }
         }
 #endif
         // ---- this lane's pixel and ray
         const int px = tx0 + (lane & (TILE_W - 1)), py = ty0 + (lane / TILE_W);
-        if ((m0 | m1) == 0ull) {   // nothing can be seen through this tile: clear colour (0,0,0), alpha 255
+        if ((mk[0] | mk[1] | mk[2] | mk[3]) == 0ull) {   // nothing can be seen through this tile: clear colour (0,0,0), alpha 255
             if (px < W && py < H) out[(size_t)py * W + px] = 0xff000000u;
             continue;
         }
@@ -484,9 +584,9 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(GymView gv, uint32_t *ob
         int bestPos = -1, bestSlot = 1 << 30;
         V3 capN = v3(0, 0, 0);   // normal of the best capsule hit (boxes recompute theirs from the entry axis)
 
-#pragma unroll 1
-        for (int half = 0; half < 2; ++half) {
-            unsigned long long m = half ? m1 : m0;
+#pragma unroll
+        for (int half = 0; half < 4; ++half) {
+            unsigned long long m = mk[half];
             while (m) {
                 const int bit = __ffsll((long long)m) - 1;
                 m &= m - 1;
@@ -497,6 +597,8 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(GymView gv, uint32_t *ob
                 bool hit;
                 if (qkind == PRIM_CAPSULE) {
                     hit = ray_capsule(eye, dw, v3(q.lo[0], q.lo[1], q.lo[2]), q.hi[0], q.hi[1], t, n);
+                } else if (qkind == PRIM_CONE) {
+                    hit = ray_cone(eye, dw, v3(q.lo[0], q.lo[1], q.lo[2]), q.hi[0], q.hi[1], q.hi[2], t, n);
                 } else if (qfr == 0) {
                     hit = anyZero ? ray_box<true>(dw, invW, q.lo, q.hi, t) : ray_box<false>(dw, invW, q.lo, q.hi, t);
                 } else if (qfr == 1 + viewer) {
@@ -516,7 +618,7 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(GymView gv, uint32_t *ob
             const Prim &q = s_vis[bestPos];
             const int qkind = q.meta & 255, qfr = q.meta >> 8;
             V3 N;
-            if (qkind == PRIM_CAPSULE) N = mat_tmul(cam.c, capN);
+            if (qkind != PRIM_BOX) N = mat_tmul(cam.c, capN);
             else {
                 V3 d, inv;
                 if (qfr == 0) { d = dw; inv = invW; }

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(64) void reset_kernel(GymView gv, int force_all)
     // canonical layout parallelepipeds (== the generic greedy merge the oracle runs on the voxels:
     // keys sorted by (type, slot), scan y,z,x, grow x then z then y).  For this room that is the
     // interior floor slab and four wall slabs.
-    if (lane < MAX_BOXES) {
+    if (lane < TOWER_BOXES) {
         LayoutBox b{{0, 0, 0}, 0, {0, 0, 0}, 0};
         const int wallType = VX_SOLID | (drawWalls ? VX_OPAQUE : 0);
         const int floorIdx = drawWalls ? 0 : 4;       // key 12 vs wall key 13 (drawn) / 5 (invisible)

@@ -1,0 +1,441 @@
+// megaverse_amd/csrc/mv_step_obstacles.hip -- one simulation tick + episode swap-in for the Obstacles family
+// (ObstaclesEasy / Medium / Hard / Walls / Steps / Lava; BASELINE.json configs[2]).
+//
+// Replaces, per env (reference paths relative to src/libs):
+//   Env::step                                   env/src/env.cpp:83-152            (shared pieces: mv_physics.h)
+//   ObstaclesScenario::step / agentTouchedLava  scenarios/src/scenario_obstacles.cpp:197-239,268-278
+//   ObjectStackingComponent (default callbacks) scenarios/include/scenarios/component_object_stacking.hpp:45-168
+//   FallDetectionComponent                      scenarios/include/scenarios/component_fall_detection.hpp:33-55
+//   Scenario::rewardTeam/rewardAll/doneWithTimer env/include/env/scenario.hpp:114-117,259-307
+//   VectorEnv::step done bookkeeping + Env::reset of finished envs (env/src/vector_env.cpp:93-105): the reset
+//   kernel below swaps in the episode the host generator (mv_gen_obstacles.cpp) left resident in HBM.
+//
+// Same mapping as the TowerBuilding kernel (one wavefront per env, colliders in VGPRs) with four colliders per
+// lane: 128 merged layout slabs, 80 movable boxes, 8 agent capsules.  The level is a long chain of platforms,
+// so voxel questions ("is this cell solid / lava / exit / holding a diamond?") are answered from the box
+// lists with ballots instead of a dense chunk; column occupancy for drops and teleports is a 128-bit wave OR.
+#include <hip/hip_runtime.h>
+
+#include "mv_math.h"
+#include "mv_physics.h"
+#include "mv_types.h"
+
+namespace mv {
+
+namespace {
+
+constexpr int NC = 4;
+constexpr int OBJ_BASE = 128, AG_BASE = 208;   // collider slot ranges: [0,128) slabs, [128,208) boxes, [208,216) agents
+
+struct Objs {          // lane l owns movable box l (k = 0) and, for l < 16, box 64 + l (k = 1)
+    int x[2], y[2], z[2], state[2];
+    bool valid[2];
+};
+
+struct Bits128 {       // bit (y + 32) for y in [-32, 95]
+    unsigned long long lo, hi;
+};
+__device__ __forceinline__ void set_range(Bits128 &b, int y0, int y1)   // [y0, y1)
+{
+    for (int y = max(y0, -32); y < min(y1, 96); ++y) {
+        const int i = y + 32;
+        if (i < 64) b.lo |= 1ull << i; else b.hi |= 1ull << (i - 64);
+    }
+}
+__device__ __forceinline__ bool test(const Bits128 &b, int y)
+{
+    const int i = y + 32;
+    if (i < 0 || i >= 128) return false;
+    return i < 64 ? ((b.lo >> i) & 1ull) : ((b.hi >> (i - 64)) & 1ull);
+}
+__device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long m)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)m, off, 64);
+        const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(m >> 32), off, 64);
+        m |= ((unsigned long long)hi << 32) | lo;
+    }
+    return m;
+}
+
+struct BoxI {
+    int min[3], max[3], type;
+    bool valid;
+};
+__device__ __forceinline__ bool contains(const BoxI &b, int x, int y, int z)
+{
+    return b.valid && x >= b.min[0] && x < b.max[0] && y >= b.min[1] && y < b.max[1] && z >= b.min[2] && z < b.max[2];
+}
+
+// solid layout cells of column (x, z)
+__device__ __forceinline__ Bits128 column_solid(const BoxI (&lb)[2], int x, int z)
+{
+    Bits128 m{0ull, 0ull};
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        if (lb[k].valid && (lb[k].type & VX_SOLID) && x >= lb[k].min[0] && x < lb[k].max[0] && z >= lb[k].min[2] && z < lb[k].max[2])
+            set_range(m, lb[k].min[1], lb[k].max[1]);
+    m.lo = wave_or_u64(m.lo); m.hi = wave_or_u64(m.hi);
+    return m;
+}
+// placed movable boxes of column (x, z)
+__device__ __forceinline__ Bits128 column_objects(const Objs &o, int x, int z)
+{
+    Bits128 m{0ull, 0ull};
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        if (o.valid[k] && o.state[k] == 0 && o.x[k] == x && o.z[k] == z) set_range(m, o.y[k], o.y[k] + 1);
+    m.lo = wave_or_u64(m.lo); m.hi = wave_or_u64(m.hi);
+    return m;
+}
+
+__device__ __forceinline__ int object_at(const Objs &o, int x, int y, int z)
+{
+    const bool h0 = o.valid[0] && o.state[0] == 0 && o.x[0] == x && o.y[0] == y && o.z[0] == z;
+    const bool h1 = o.valid[1] && o.state[1] == 0 && o.x[1] == x && o.y[1] == y && o.z[1] == z;
+    const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
+    if (m0) return __ffsll((long long)m0) - 1;
+    if (m1) return 64 + (__ffsll((long long)m1) - 1);
+    return -1;
+}
+
+template <int A_MAX>
+__device__ __forceinline__ void reward_agent(AgentState (&ag)[A_MAX], int key, int idx, float mult)
+{
+#pragma unroll
+    for (int i = 0; i < A_MAX; ++i)
+        if (i == idx) ag[i].last_reward += ag[i].shaping[key] * mult;
+}
+template <int A_MAX>
+__device__ __forceinline__ void reward_team(AgentState (&ag)[A_MAX], int A, int key, int idx, float mult)
+{
+#pragma unroll
+    for (int i = 0; i < A_MAX; ++i)
+        if (i == idx) ag[i].last_reward += ag[i].shaping[key] * (mult * (1 - ag[i].shaping[0]));
+#pragma unroll
+    for (int i = 0; i < A_MAX; ++i)
+        if (i < A) ag[i].last_reward += ag[i].shaping[key] * ag[i].shaping[0] * mult / float(A);
+}
+
+__device__ __forceinline__ void voxel_of(V3 p, int out[3])
+{
+    out[0] = (int)floorf(p.x); out[1] = (int)floorf(p.y); out[2] = (int)floorf(p.z);
+}
+
+}  // namespace
+
+template <int A_MAX>
+__global__ __launch_bounds__(64) void step_obstacles_kernel(GymView gv)
+{
+    const int env = blockIdx.x;
+    const int lane = lane_id();
+    if (env >= gv.num_envs) return;
+    const int A = gv.num_agents;
+
+    // ---- header fields as scalars (never copy the record: see mv_step.hip)
+    EnvHeader *gh = gv.hdr + env;
+    const int numObjects = gh->num_objects, numBoxes = gh->num_boxes, numTerrain = gh->num_terrain, numRewards = gh->num_rewards;
+    int numFrames = gh->num_frames, done = gh->done, solved = gh->solved;
+    float episodeSec = gh->episode_sec;
+    const float episodeLen = gh->episode_len, lookLimit = gh->p_vertical_look_limit;
+
+    // ---- wave-resident scene
+    Col col[NC];
+    BoxI lb[2];
+    Objs ob;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) { col[k].kind = 0; col[k].lo = col[k].hi = v3(0, 0, 0); }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int bi = lane + 64 * k;
+        lb[k].valid = bi < numBoxes;
+        lb[k].type = 0;
+        lb[k].min[0] = lb[k].min[1] = lb[k].min[2] = lb[k].max[0] = lb[k].max[1] = lb[k].max[2] = 0;
+        if (lb[k].valid) {
+            const LayoutBox b = gv.boxes[(size_t)env * MAX_BOXES + bi];
+            lb[k].min[0] = b.min[0]; lb[k].min[1] = b.min[1]; lb[k].min[2] = b.min[2];
+            lb[k].max[0] = b.max[0]; lb[k].max[1] = b.max[1]; lb[k].max[2] = b.max[2];
+            lb[k].type = b.type;
+            if (b.type & VX_SOLID) {
+                col[k].kind = 1;
+                col[k].lo = v3(float(b.min[0]), float(b.min[1]) - CAP_HH, float(b.min[2]));
+                col[k].hi = v3(float(b.max[0]), float(b.max[1]) + CAP_HH, float(b.max[2]));
+            }
+        }
+    }
+    const MovableObject *gobj = gv.objects + (size_t)env * MAX_OBJECTS;
+    const int oi[2] = {lane, lane < 16 ? 64 + lane : -1};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        ob.valid[k] = oi[k] >= 0 && oi[k] < numObjects;
+        ob.x[k] = ob.y[k] = ob.z[k] = 0; ob.state[k] = 0;
+        if (ob.valid[k]) {
+            const MovableObject o = gobj[oi[k]];
+            ob.x[k] = o.x; ob.y[k] = o.y; ob.z[k] = o.z; ob.state[k] = o.state;
+            if (o.state == 0) {
+                const float cx = float(o.x) + 0.5f, cy = float(o.y) + 0.5f + OBJ_COLL_YOFF, cz = float(o.z) + 0.5f;
+                col[2 + k].kind = 1;
+                col[2 + k].lo = v3(cx - OBJ_COLL_HALF, (cy - OBJ_COLL_HALF) - CAP_HH, cz - OBJ_COLL_HALF);
+                col[2 + k].hi = v3(cx + OBJ_COLL_HALF, (cy + OBJ_COLL_HALF) + CAP_HH, cz + OBJ_COLL_HALF);
+            }
+        }
+    }
+    // terrain boxes and diamonds: one per lane (lanes 0..15)
+    BoxI tb;
+    tb.valid = lane < numTerrain; tb.type = 0;
+    tb.min[0] = tb.min[1] = tb.min[2] = tb.max[0] = tb.max[1] = tb.max[2] = 0;
+    if (tb.valid) {
+        const TerrainBox t = gv.terrain[(size_t)env * MAX_TERRAIN + lane];
+        tb.min[0] = t.min[0]; tb.min[1] = t.min[1]; tb.min[2] = t.min[2]; tb.max[0] = t.max[0]; tb.max[1] = t.max[1]; tb.max[2] = t.max[2];
+        tb.type = t.type;
+    }
+    int rwx = 0, rwy = 0, rwz = 0, rwActive = 0;
+    if (lane < numRewards) {
+        const MovableObject r = gv.rewards_obj[(size_t)env * MAX_REWARDS + lane];
+        rwx = r.x; rwy = r.y; rwz = r.z; rwActive = r.state;
+    }
+
+    // ---- agents: wave-uniform copies
+    AgentState ag[A_MAX];
+    int act[A_MAX];
+#pragma unroll
+    for (int i = 0; i < A_MAX; ++i)
+        if (i < A) {
+            ag[i] = gv.agents[(size_t)env * A + i];
+            act[i] = gv.actions[(size_t)env * A + i];
+            ag[i].last_reward = 0.0f;
+        }
+    const float dt = DT;
+
+#pragma unroll
+    for (int i = 0; i < A_MAX; ++i)
+        if (i < A) apply_actions(ag[i], act[i], dt, lookLimit);
+
+    // ---- physics, agent by agent
+#pragma unroll
+    for (int i = 0; i < A_MAX; ++i)
+        if (i < A) {
+            if (A_MAX > 1 && lane >= 32 && lane < 32 + MAX_AGENTS) {   // agent capsules: slot 192 + lane, k = 3
+                const int j = lane - 32;
+                col[3].kind = 0;
+#pragma unroll
+                for (int q = 0; q < A_MAX; ++q)
+                    if (q == j && q < A && q != i) {
+                        col[3].kind = 2;
+                        col[3].lo = v3(ag[q].pos[0], ag[q].pos[1], ag[q].pos[2]);
+                        col[3].hi = v3(2 * CAP_HH, 0.0f, 0.0f);
+                    }
+            }
+            player_step<NC>(ag[i], col, dt);
+        }
+
+    // ---- interact: pick up / put down with the default callbacks (anything may be placed anywhere)
+#pragma unroll
+    for (int i = 0; i < A_MAX; ++i)
+        if (i < A && (act[i] & ACT_INTERACT)) {
+            AgentState &a = ag[i];
+            const Cam cam = camera_of(a);
+            if (a.carrying >= 0) {
+                const V3 t = cam_to_world(cam, v3(0.0f, -0.44f + -0.3f, -1.0f));
+                int vx[3];
+                voxel_of(t, vx);
+                bool collidesWithAgent = false;
+#pragma unroll
+                for (int j = 0; j < A_MAX; ++j)
+                    if (j < A && j != i) {
+                        int c[3];
+                        voxel_of(v3(ag[j].pos[0], ag[j].pos[1] + 0.05f, ag[j].pos[2]), c);
+                        if (c[0] == vx[0] && c[1] == vx[1] && c[2] == vx[2]) collidesWithAgent = true;
+                    }
+                const Bits128 solid = column_solid(lb, vx[0], vx[2]);
+                const Bits128 objs = column_objects(ob, vx[0], vx[2]);
+                const bool placeable = vx[1] > -120 && vx[1] < 120;
+                const bool solidHere = vx[1] >= 96 || vx[1] < -32 ? false : test(solid, vx[1]);
+                const bool empty = !solidHere && !test(objs, vx[1]);
+                if (placeable && empty && !collidesWithAgent) {
+                    for (;;) {
+                        const int by = vx[1] - 1;
+                        if (by < -30) break;
+                        if (test(solid, by) || test(objs, by)) break;
+                        vx[1] = by;
+                    }
+                    const int oidx = a.carrying;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+                        if (oi[k] == oidx) { ob.x[k] = vx[0]; ob.y[k] = vx[1]; ob.z[k] = vx[2]; ob.state[k] = 0; }
+                    a.carrying = -1;
+                }
+            } else {
+                const V3 pickup = cam_to_world(cam, v3(0.0f, -0.44f, -1.0f));
+                int vx[3];
+                voxel_of(pickup, vx);
+                const int o0 = object_at(ob, vx[0], vx[1], vx[2]);
+                const int o1 = object_at(ob, vx[0], vx[1] + 1, vx[2]);
+                const int o2 = object_at(ob, vx[0], vx[1] + 2, vx[2]);
+                int oidx = -1;
+                if (o0 >= 0 && o1 < 0) oidx = o0;
+                else if (o1 >= 0 && o2 < 0) oidx = o1;
+                if (oidx >= 0) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+                        if (oi[k] == oidx) ob.state[k] = 1 + i;
+                    a.carrying = oidx;
+                }
+            }
+        }
+
+    // teleport above the spawn cell (FallDetectionComponent::resetAgent + controller warp)
+    auto reset_agent = [&](AgentState &a) {
+        const Bits128 solid = column_solid(lb, a.spawn[0], a.spawn[2]);
+        int py = a.spawn[1];
+        while (test(solid, py) && py < 1000) ++py;
+        a.pos[0] = float(a.spawn[0]) + 0.5f; a.pos[1] = float(py) + 0.5f; a.pos[2] = float(a.spawn[2]) + 0.5f;
+        a.m00 = 1.0f; a.m02 = 0.0f; a.m20 = 0.0f; a.m22 = 1.0f;
+        a.hvx = 0.0f; a.hvz = 0.0f; a.vvel = 0.0f;
+    };
+
+#pragma unroll
+    for (int i = 0; i < A_MAX; ++i)
+        if (i < A && ag[i].pos[1] + 0.05f < -20.0f) reset_agent(ag[i]);
+
+    // ---- ObstaclesScenario::step: exit pad, lava, diamonds
+    int numAgentsAtExit = 0;
+#pragma unroll
+    for (int i = 0; i < A_MAX; ++i)
+        if (i < A) {
+            AgentState &a = ag[i];
+            int vx[3];
+            voxel_of(v3(a.pos[0], a.pos[1] + 0.05f, a.pos[2]), vx);
+            const bool inside = contains(tb, vx[0], vx[1], vx[2]);
+            const bool onExit = __ballot(inside && (tb.type & TERRAIN_EXIT)) != 0ull;
+            const bool onLava = __ballot(inside && (tb.type & TERRAIN_LAVA)) != 0ull;
+            if (onExit) {
+                ++numAgentsAtExit;
+                if (!a.visited_zone) {
+                    a.visited_zone = 1;
+                    reward_team(ag, A, 1, i, 1);
+                    if (a.carrying >= 0) reward_team(ag, A, 4, i, 1);
+                }
+            } else if (onLava) reset_agent(a);
+            // diamonds: matched against the cell computed before a lava teleport, like the reference
+            const bool got = rwActive && rwx == vx[0] && rwy == vx[1] && rwz == vx[2];
+            const unsigned long long gm = __ballot(got);
+            if (got) rwActive = 0;
+            for (int c = __popcll(gm); c > 0; --c) reward_team(ag, A, 3, i, 1);
+        }
+    if (numAgentsAtExit == A && !solved) {
+        solved = 1;
+        episodeSec = fmax_sel(episodeSec, episodeLen - 0.3f);
+#pragma unroll
+        for (int i = 0; i < A_MAX; ++i)
+            if (i < A) reward_agent(ag, 2, i, 1);
+    }
+
+    // ---- timers / done
+    episodeSec += dt;
+    const float bar = fmax_sel(0.0f, (episodeLen - episodeSec) / episodeLen) * 0.24f;
+    if (episodeSec >= episodeLen) done = 1;
+    ++numFrames;
+
+    // ---- write back
+    MovableObject *gobjw = gv.objects + (size_t)env * MAX_OBJECTS;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        if (ob.valid[k]) {
+            MovableObject o;
+            o.x = (int8_t)ob.x[k]; o.y = (int8_t)ob.y[k]; o.z = (int8_t)ob.z[k]; o.state = (int8_t)ob.state[k];
+            gobjw[oi[k]] = o;
+        }
+    if (lane < numRewards) gv.rewards_obj[(size_t)env * MAX_REWARDS + lane].state = (int8_t)rwActive;
+    if (lane == 0) {
+        gh->num_frames = numFrames; gh->done = done; gh->solved = solved;
+        gh->episode_sec = episodeSec; gh->bar_half_width = bar;
+        gv.done[env] = (uint8_t)done;
+    }
+#pragma unroll
+    for (int i = 0; i < A_MAX; ++i)
+        if (i < A && lane == i) {
+            ag[i].total_reward += ag[i].last_reward;
+            AgentState *dst = gv.agents + (size_t)env * A + i;
+            const AgentState &a = ag[i];
+            dst->pos[0] = a.pos[0]; dst->pos[1] = a.pos[1]; dst->pos[2] = a.pos[2];
+            dst->m00 = a.m00; dst->m02 = a.m02; dst->m20 = a.m20; dst->m22 = a.m22; dst->pitch = a.pitch;
+            dst->hvx = a.hvx; dst->hvz = a.hvz; dst->vvel = a.vvel; dst->voffset = a.voffset;
+            dst->step_offset = a.step_offset; dst->jump_speed = a.jump_speed;
+            dst->was_jumping = a.was_jumping; dst->carrying = a.carrying; dst->picked_up = a.picked_up; dst->visited_zone = a.visited_zone;
+            dst->last_reward = a.last_reward; dst->total_reward = a.total_reward;
+            gv.actions[(size_t)env * A + i] = 0;
+            gv.rewards[(size_t)env * A + i] = a.last_reward;
+            if (done) gv.true_objective[(size_t)env * A + i] = float(solved);   // trueObjective == solved (scenario_obstacles.hpp:34)
+        }
+}
+
+// Episode swap-in: Env::reset for finished envs (or every env when force_all), from the resident EpisodeBlob.
+__global__ __launch_bounds__(64) void reset_obstacles_kernel(GymView gv, const EpisodeBlob *blobs, int *total_consumed, int force_all)
+{
+    const int env = blockIdx.x;
+    const int lane = lane_id();
+    if (env >= gv.num_envs) return;
+    EnvHeader *gh = gv.hdr + env;
+    if (!force_all && !gh->done) return;
+    const EpisodeBlob *b = blobs + env;
+    const int consumed = gh->episodes_consumed;
+    if (b->seq != consumed + 1) {   // the host has not delivered the next episode: must never happen (mv_api.hip keeps one ahead)
+        if (lane == 0) gh->starved = 1;
+        return;
+    }
+    const int A = gv.num_agents;
+    // 128 slabs x 32 B: two 16-byte pieces per slab, 4 per lane
+    const uint4 *src = reinterpret_cast<const uint4 *>(b->boxes);
+    uint4 *dst = reinterpret_cast<uint4 *>(gv.boxes + (size_t)env * MAX_BOXES);
+    for (int i = lane; i < MAX_BOXES * 2; i += 64) dst[i] = src[i];
+    if (lane < MAX_TERRAIN * 2)
+        reinterpret_cast<uint4 *>(gv.terrain + (size_t)env * MAX_TERRAIN)[lane] = reinterpret_cast<const uint4 *>(b->terrain)[lane];
+    for (int i = lane; i < MAX_OBJECTS; i += 64) gv.objects[(size_t)env * MAX_OBJECTS + i] = b->objects[i];
+    if (lane < MAX_REWARDS) gv.rewards_obj[(size_t)env * MAX_REWARDS + lane] = b->rewards[lane];
+
+    for (int k = 0; k < A; ++k) {
+        float cs, sn;
+        yaw_matrix(b->yaw_frand[k] * 3.14159274f * 2, cs, sn);
+        if (lane == 0) {
+            AgentState *a = gv.agents + (size_t)env * A + k;
+            a->pos[0] = float(b->spawn[k][0]) + 0.5f; a->pos[1] = float(b->spawn[k][1]) + 0.0f + 1.75f; a->pos[2] = float(b->spawn[k][2]) + 0.5f;
+            a->m00 = cs; a->m02 = sn; a->m20 = -sn; a->m22 = cs;
+            a->pitch = 0.0f; a->hvx = 0.0f; a->hvz = 0.0f; a->vvel = 0.0f; a->voffset = 0.0f; a->step_offset = 0.0f;
+            a->jump_speed = 10.0f; a->was_jumping = 0; a->carrying = -1; a->picked_up = 0; a->visited_zone = 0;
+            a->spawn[0] = b->spawn[k][0]; a->spawn[1] = b->spawn[k][1]; a->spawn[2] = b->spawn[k][2];
+            a->last_reward = 0.0f; a->total_reward = 0.0f;
+            gv.rewards[(size_t)env * A + k] = 0.0f;
+            gv.actions[(size_t)env * A + k] = 0;
+        }
+    }
+    if (lane == 0) {
+        gh->L = b->dim[0]; gh->H = b->dim[1]; gh->W = b->dim[2];
+        gh->bz[0] = b->org[0]; gh->bz[1] = b->org[1]; gh->bz[2] = b->org[2]; gh->bz[3] = 0;
+        gh->layout_color = b->layout_color; gh->wall_color = b->wall_color; gh->draw_walls = b->draw_walls;
+        gh->num_objects = b->num_objects; gh->num_boxes = b->num_boxes; gh->num_terrain = b->num_terrain;
+        gh->num_rewards = b->num_rewards; gh->num_platforms = b->num_platforms;
+        gh->num_frames = 0; gh->done = 0; gh->highest_tower = 0; gh->solved = 0;
+        gh->episode_sec = 0.0f; gh->episode_len = b->episode_len; gh->bz_reward = 0.0f; gh->bar_half_width = 0.24f;
+        gh->episodes_consumed = consumed + 1;
+        atomicAdd(total_consumed, 1);
+        if (force_all) gv.done[env] = 0;
+    }
+}
+
+void launch_step_obstacles(const GymView &gv, hipStream_t stream)
+{
+    const dim3 grid(gv.num_envs), block(64);
+    if (gv.num_agents == 1) hipLaunchKernelGGL(step_obstacles_kernel<1>, grid, block, 0, stream, gv);
+    else if (gv.num_agents == 2) hipLaunchKernelGGL(step_obstacles_kernel<2>, grid, block, 0, stream, gv);
+    else if (gv.num_agents <= 4) hipLaunchKernelGGL(step_obstacles_kernel<4>, grid, block, 0, stream, gv);
+    else hipLaunchKernelGGL(step_obstacles_kernel<8>, grid, block, 0, stream, gv);
+}
+
+void launch_reset_obstacles(const GymView &gv, const EpisodeBlob *blobs, int *total_consumed, int force_all, hipStream_t stream)
+{
+    hipLaunchKernelGGL(reset_obstacles_kernel, dim3(gv.num_envs), dim3(64), 0, stream, gv, blobs, total_consumed, force_all);
+}
+
+}  // namespace mv

@@ -10,9 +10,14 @@ namespace mv {
 
 enum : int {
     CX = 32, CY = 16, CZ = 32, CHUNK_BYTES = CX * CY * CZ,   // dense voxel chunk, 1 B per cell
-    MAX_BOXES = 16, MAX_OBJECTS = 80, MAX_AGENTS = 8,
-    NUM_SHAPING = 4,
+    MAX_BOXES = 128,          // merged layout parallelepipeds per env (TowerBuilding uses 5, ObstaclesHard up to ~60)
+    TOWER_BOXES = 16,         // collider / primitive slots the TowerBuilding kernels reserve for them
+    MAX_OBJECTS = 80, MAX_AGENTS = 8, MAX_TERRAIN = 16, MAX_REWARDS = 16,
+    NUM_SHAPING = 8,
 };
+
+enum : int { SCN_TOWER = 0, SCN_OBSTACLES = 1 };
+enum : int { TERRAIN_EXIT = 1, TERRAIN_LAVA = 2, TERRAIN_BUILDING_ZONE = 4 };   // scenarios/platforms.hpp:28-34
 
 // voxel cell byte (reference: env/include/env/voxel_state.hpp:10-37, scenarios/platforms.hpp:28-34)
 enum : int { VX_SOLID = 1, VX_OPAQUE = 2, VX_OBJECT = 4, VX_TERRAIN_SHIFT = 3, VX_COLOR_SHIFT = 6 };
@@ -34,7 +39,10 @@ struct alignas(16) EnvHeader {   // 128 B
     uint32_t next_seed;                 // value the next Env::reset() re-seeds with (env.cpp:61-62)
     int32_t seed_is_env_seed;           // 1: next_seed is the Env::seed() value, reset must draw first
     float p_episode_len_sec, p_vertical_look_limit;   // float params (scenario.hpp:225-232)
-    int32_t pad[9];
+    int32_t scenario, num_terrain, num_rewards, num_platforms, solved;   // Obstacles family
+    int32_t episodes_consumed;          // how many host-generated episodes this env has taken (refill protocol)
+    int32_t starved;                    // set if a reset found no fresh episode (must never happen)
+    int32_t pad[2];
 };
 static_assert(sizeof(EnvHeader) == 128, "EnvHeader must be 128 B");
 
@@ -45,7 +53,12 @@ struct alignas(16) LayoutBox {   // 32 B, merged layout parallelepiped (voxel un
 
 struct alignas(4) MovableObject {   // 4 B
     int8_t x, y, z;
-    int8_t state;   // 0 placed at (x,y,z); 1+k carried by agent k
+    int8_t state;   // 0 placed at (x,y,z); 1+k carried by agent k.  Reward objects: 1 = still there
+};
+
+struct alignas(16) TerrainBox {   // 32 B, voxel units, max exclusive (platforms.hpp terrainBoxes)
+    int32_t min[3]; int32_t type;
+    int32_t max[3]; int32_t pad;
 };
 
 struct alignas(16) AgentState {   // 128 B
@@ -56,8 +69,8 @@ struct alignas(16) AgentState {   // 128 B
     int32_t was_jumping, carrying, picked_up, visited_zone;
     int32_t spawn[3];
     float last_reward, total_reward;
-    float shaping[NUM_SHAPING];
-    int32_t pad[5];
+    float shaping[NUM_SHAPING];   // per-scenario reward-shaping coefficients (scenario.hpp:184-215)
+    int32_t pad[1];
 };
 static_assert(sizeof(AgentState) == 128, "AgentState must be 128 B");
 
@@ -68,11 +81,29 @@ struct GymView {
     LayoutBox *boxes;          // [N][MAX_BOXES]
     MovableObject *objects;    // [N][MAX_OBJECTS]
     AgentState *agents;        // [N][A]
-    uint8_t *chunk;            // [N][CHUNK_BYTES]
+    uint8_t *chunk;            // [N][CHUNK_BYTES]   (TowerBuilding)
+    TerrainBox *terrain;       // [N][MAX_TERRAIN]   (Obstacles)
+    MovableObject *rewards_obj;// [N][MAX_REWARDS]   (Obstacles: green diamonds)
     int32_t *actions;          // [N][A] bitmasks
     float *rewards;            // [N*A] as reported by get_last_rewards (0 on done steps)
     uint8_t *done;             // [N]
     float *true_objective;     // [N*A]
+};
+
+// One host-generated episode (Obstacles family): everything Env::reset produces, ready to be swapped in by
+// the reset kernel.  Fixed-size POD so that the host can fill a pinned staging copy and upload it as is.
+struct alignas(16) EpisodeBlob {
+    int32_t seq;                        // 1-based index of this episode for its env; 0 = empty
+    int32_t num_boxes, num_terrain, num_objects, num_rewards, num_platforms;
+    int32_t layout_color, wall_color, draw_walls;
+    int32_t dim[3], org[3];
+    float episode_len;
+    int32_t spawn[MAX_AGENTS][3];
+    float yaw_frand[MAX_AGENTS];        // the frand() drawn for each agent's spawn rotation (scenario_default.hpp:87)
+    LayoutBox boxes[MAX_BOXES];
+    TerrainBox terrain[MAX_TERRAIN];
+    MovableObject objects[MAX_OBJECTS];
+    MovableObject rewards[MAX_REWARDS];
 };
 
 }  // namespace mv

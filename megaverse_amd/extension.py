@@ -70,6 +70,13 @@ def load_library():
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(there is no CPU fallback)")
+        # PyTorch wheels bundle their own HIP/HSA runtime under the system runtime's SONAME.  If torch is
+        # imported AFTER this library, the process ends up with two runtimes and the second one to
+        # initialise reports "no ROCm-capable device".  Importing torch first makes both share one.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(path)
         for name, res, args in SYMBOLS:
             fn = getattr(lib, name)   # AttributeError here == the C ABI lost a symbol
