@@ -72,8 +72,9 @@ static const float OBJ_COLL_YOFF = -0.05f;            // :182 collision offset
 static const float CARRY_SCALE = 0.78f;               // :63
 
 enum { CX = 32, CY = 16, CZ = 32, CHUNK = CX * CY * CZ };
-enum { MAX_BOXES = 128, MAX_OBJECTS = 80, MAX_AGENTS = 8, MAX_TERRAIN = 16, MAX_REWARDS = 16, MAX_SHAPING = 8 };
-enum { SCN_TOWER = 0, SCN_OBSTACLES = 1 };
+enum { MAX_BOXES = 1024, MAX_OBJECTS = 80, MAX_AGENTS = 8, MAX_TERRAIN = 16, MAX_REWARDS = 96, MAX_SHAPING = 8 };
+enum { HM_DIM = 42 };   // Collect heightfield: maxWidth == maxLength == 42 (scenario_collect.cpp:63)
+enum { SCN_TOWER = 0, SCN_OBSTACLES = 1, SCN_COLLECT = 2 };
 enum { TERRAIN_EXIT = 1, TERRAIN_LAVA = 2, TERRAIN_BUILDING_ZONE = 4 };   // scenarios/platforms.hpp:28-34
 static const unsigned COLOR_EXIT_PAD = 0x50c878, COLOR_RED = 0xff0000, COLOR_GREEN = 0x3bb372;   // const.hpp:25-56
 
@@ -154,14 +155,14 @@ struct TerrainBox {  // platforms.hpp terrainBoxes, voxel units, max exclusive
     int type;
 };
 
-struct RewardObj {  // green diamond, scenario_obstacles.cpp:251-258
+struct RewardObj {  // diamond: scenario_obstacles.cpp:251-258 (green), scenario_collect.cpp:190-214 (green +1 / red -1)
     int x, y, z;
-    int active;
+    int active;     // 0 collected, 1 there (Collect: 1 = +1 reward, 2 = -1 reward)
 };
 
 struct Object {  // movable box: component_object_stacking.hpp:170-198
     int x, y, z;
-    int state;  // 0 = placed at voxel, 1+k = carried by agent k
+    int state;  // 0 = placed at voxel, 1+k = carried by agent k, -1 = placed but its grid cell was erased (Collect, see collect_step)
 };
 
 struct Agent {
@@ -188,6 +189,9 @@ static const float SHAPING_DEFAULT_TOWER[4] = {0.1f, 0.1f, 0.1f, 1.0f};  // scen
 static const char *SHAPING_KEYS_OBST[5] = {"teamSpirit", "obstaclesAgentAtExit", "obstaclesAllAgentsAtExit", "obstaclesExtraReward",
                                           "obstaclesAgentCarriedObjectToExit"};
 static const float SHAPING_DEFAULT_OBST[5] = {0.0f, 1.0f, 5.0f, 0.5f, 0.0f};
+// scenario_collect.hpp:44-52 (+ teamSpirit 0)
+static const char *SHAPING_KEYS_COLLECT[5] = {"teamSpirit", "collectSingleGood", "collectSingleBad", "collectAll", "collectAbyss"};
+static const float SHAPING_DEFAULT_COLLECT[5] = {0.0f, 1.0f, -1.0f, 5.0f, -0.5f};
 
 enum { PT_EMPTY = 0, PT_WALL, PT_LAVA, PT_STEP, PT_GAP, PT_START, PT_EXIT, PT_TRANSITION };
 struct ObstacleParams {  // scenario_obstacles.hpp:46-68 defaults, overridden per registered name :94-268
@@ -202,6 +206,8 @@ struct Env {
     int numShaping = 4;
     const char *const *shapingKeys = SHAPING_KEYS_TOWER;
     int numTerrain = 0, numRewards = 0, numPlatforms = 0, solved = 0;
+    // Collect: numPlatforms holds numPositiveRewards, highestTower holds positiveRewardsCollected (scenario_collect.hpp:76)
+    std::vector<int8_t> heightmap = std::vector<int8_t>(HM_DIM * HM_DIM, -1);   // [x * HM_DIM + z]: top solid y of the column, -1 = no voxels
     TerrainBox terrain[MAX_TERRAIN];
     RewardObj rewards[MAX_REWARDS];
     int numAgents = 1;
@@ -795,6 +801,153 @@ static void obstacles_generate(Env &e)
     spawn_agents(e, spawns);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Collect: Perlin heightfield landscape.  siv::PerlinNoise<double> (vendored by the reference as
+// util/include/util/perlin_noise.hpp; restated here, pinned against that header by oracle/_ref):
+// reseed :118-126, noise3D :171-197, Fade/Lerp/Grad :59-79, accumulatedOctaveNoise2D :244-259,
+// accumulatedOctaveNoise2D_0_1 :315-318.
+// ------------------------------------------------------------------------------------------------
+struct Perlin {
+    uint8_t p[512];
+    explicit Perlin(uint32_t seed)
+    {
+        for (int i = 0; i < 256; ++i) p[i] = uint8_t(i);
+        std::shuffle(p, p + 256, std::default_random_engine(seed));
+        for (int i = 0; i < 256; ++i) p[256 + i] = p[i];
+    }
+    static double fade(double t) { return t * t * t * (t * (t * 6 - 15) + 10); }
+    static double mix(double t, double a, double b) { return a + t * (b - a); }
+    static double grad(uint8_t hash, double x, double y, double z)
+    {
+        const int h = hash & 15;
+        const double u = h < 8 ? x : y;
+        const double v = h < 4 ? y : (h == 12 || h == 14 ? x : z);
+        return ((h & 1) == 0 ? u : -u) + ((h & 2) == 0 ? v : -v);
+    }
+    double noise3(double x, double y, double z) const
+    {
+        const int X = int(std::floor(x)) & 255, Y = int(std::floor(y)) & 255, Z = int(std::floor(z)) & 255;
+        x -= std::floor(x); y -= std::floor(y); z -= std::floor(z);
+        const double u = fade(x), v = fade(y), w = fade(z);
+        const int A = p[X] + Y, AA = p[A] + Z, AB = p[A + 1] + Z;
+        const int B = p[X + 1] + Y, BA = p[B] + Z, BB = p[B + 1] + Z;
+        const double x1 = x - 1, y1 = y - 1, z1 = z - 1;
+        const double front = mix(v, mix(u, grad(p[AA], x, y, z), grad(p[BA], x1, y, z)),
+                                    mix(u, grad(p[AB], x, y1, z), grad(p[BB], x1, y1, z)));
+        const double back = mix(v, mix(u, grad(p[AA + 1], x, y, z1), grad(p[BA + 1], x1, y, z1)),
+                                   mix(u, grad(p[AB + 1], x, y1, z1), grad(p[BB + 1], x1, y1, z1)));
+        return mix(w, front, back);
+    }
+    double octaves2_01(double x, double y, int octaves) const
+    {
+        double result = 0, amp = 1;
+        for (int i = 0; i < octaves; ++i) {
+            result += noise3(x, y, 0) * amp;
+            x *= 2; y *= 2; amp /= 2;
+        }
+        return std::clamp<double>(result * 0.5 + 0.5, 0, 1);
+    }
+};
+
+// CollectScenario::reset / createLandscape (scenario_collect.cpp:20-161), spawnAgents, then the reward draws of
+// addEpisodeDrawables (:190-214) -- in the order Env::reset makes them (env.cpp:69-75).
+static void collect_generate(Env &e)
+{
+    Rng &rng = e.rng;
+    static const unsigned landscapeColors[7] = {0xffffff, 0xccffcc, 0xe6ecff, 0xd9d9d9, 0xffebcc, 0xb3b3b3, 0x555555};
+    static const unsigned floorColors[3] = {0xb3b3b3, 0x555555, 0x555555};
+    const unsigned landscapeColor = landscapeColors[randRange(0, 7, rng)];
+    const unsigned floorColor = floorColors[randRange(0, 3, rng)];
+    const int maxWidth = HM_DIM, maxLength = HM_DIM;
+    const int width = randRange(8, maxWidth, rng);     // z extent
+    const int length = randRange(8, maxLength, rng);   // x extent
+    std::vector<int> spawnHeight(size_t(length) * width, 1);
+    const double frequency = double(randRange(1, 100, rng)) / 10.0;
+    const int octaves = randRange(1, 10, rng);
+    const uint32_t seed = uint32_t(randRange(0, 1000000000, rng));
+    const Perlin perlin(seed);
+    const double fx = maxLength / frequency, fz = maxWidth / frequency;
+    const int intensity = randRange(5, 18, rng);
+    const float groundLevel = frand(rng) * 0.5f + 0.2f;
+
+    std::fill(e.heightmap.begin(), e.heightmap.end(), int8_t(-1));
+    for (int x = 0; x < length; ++x)
+        for (int z = 0; z < width; ++z) e.heightmap[x * HM_DIM + z] = 0;   // floor :100-103
+    int top = 0;
+    for (int x = 1; x < length - 1; ++x)
+        for (int z = 1; z < width - 1; ++z) {
+            const double noise = perlin.octaves2_01(x / fx, z / fz, octaves);
+            const double yCoord = intensity * (noise - groundLevel);
+            if (yCoord >= 1) {
+                const int r = int(lround(yCoord));
+                e.heightmap[x * HM_DIM + z] = int8_t(r);
+                spawnHeight[size_t(x) * width + z] = r + 1;
+                top = std::max(top, r);
+            }
+        }
+
+    // canonical merge.  toBoundingBoxes groups by (voxelType, colour) in std::map order (component_voxel_grid.hpp:33-47):
+    // both classes are SOLID|OPAQUE, so the lower colour value comes first; equal colours are ONE class.
+    const unsigned c0 = std::min(landscapeColor, floorColor), c1 = std::max(landscapeColor, floorColor);
+    const int landSlot = landscapeColor == c0 ? 0 : 1, floorSlot = floorColor == c0 ? 0 : 1;
+    {
+        const int org[3] = {0, 0, 0}, dim[3] = {length, top + 1, width};
+        std::vector<uint8_t> g(size_t(dim[0]) * dim[1] * dim[2], 0);
+        for (int x = 0; x < length; ++x)
+            for (int z = 0; z < width; ++z) {
+                g[(size_t(0) * dim[2] + z) * dim[0] + x] = uint8_t(3 | (floorSlot << VX_COLOR_SHIFT));
+                for (int y = 1; y <= e.heightmap[x * HM_DIM + z]; ++y) g[(size_t(y) * dim[2] + z) * dim[0] + x] = uint8_t(3 | (landSlot << VX_COLOR_SHIFT));
+            }
+        merge_dense(g, org, dim, e);
+    }
+    e.layoutColor = c0; e.wallColor = c1; e.drawWalls = 1;
+    e.L = length; e.H = top + 1; e.W = width;
+    e.bz[0] = e.bz[1] = e.bz[2] = e.bz[3] = 0;
+    e.numTerrain = 0;
+    std::fill(e.chunk.begin(), e.chunk.end(), 0);
+
+    std::vector<C3> sp;
+    for (int x = 1; x < length - 1; ++x)
+        for (int z = 1; z < width - 1; ++z) sp.push_back(C3{x, spawnHeight[size_t(x) * width + z], z});
+    std::shuffle(sp.begin(), sp.end(), rng);
+    int offset = 0;
+    const std::vector<C3> agentCells(sp.begin(), sp.begin() + e.numAgents);
+    offset += e.numAgents;
+    int numRewards = randRange(1, int(lround(0.05 * width * length)) + 2, rng);
+    numRewards = std::min(numRewards, int(sp.size()) - offset);
+    const int placedRandomly = std::max(numRewards / 2, 1);
+    std::vector<C3> rews(sp.begin() + offset, sp.begin() + offset + placedRandomly);
+    offset += placedRandomly;
+    std::sort(sp.begin() + offset, sp.end(), [&](const C3 &a, const C3 &b) {   // highest cells first (:135-142)
+        const int ha = spawnHeight[size_t(a.x) * width + a.z], hb = spawnHeight[size_t(b.x) * width + b.z];
+        return ha != hb ? ha > hb : false;
+    });
+    rews.insert(rews.end(), sp.begin() + offset, sp.begin() + offset + (numRewards - placedRandomly));
+    offset += numRewards - placedRandomly;
+    std::shuffle(sp.begin() + offset, sp.end(), rng);
+    const int objectsMin = std::max(3, int(length * width * 0.04));
+    const int objectsMax = std::min(objectsMin + 1, int(lround(0.07 * width * length)) + 2);
+    const int numObjects = std::min(randRange(objectsMin, objectsMax, rng), int(sp.size()) - offset);
+    std::vector<C3> objs;
+    // (:153-156) when the condition fails the reference keeps the PREVIOUS episode's objectPositions; with
+    // (L-2)(W-2) >= 36 cells, <= 8 agents and these count formulas it always holds, so that path is not modelled.
+    if (offset + numObjects < int(sp.size())) objs.assign(sp.begin() + offset, sp.begin() + offset + numObjects);
+
+    e.numObjects = std::min(int(objs.size()), int(MAX_OBJECTS));
+    for (int i = 0; i < e.numObjects; ++i) e.objects[i] = Object{objs[i].x, objs[i].y, objs[i].z, 0};
+    e.solved = 0; e.highestTower = 0; e.bzReward = 0; e.numPlatforms = 0;
+    e.episodeLen = e.p_episodeLengthSec + 2.0f * float(rews.size());   // scenario_collect.hpp:55-59
+    e.barHalfWidth = 0.24f;
+    spawn_agents(e, agentCells);
+    e.numRewards = std::min(int(rews.size()), int(MAX_REWARDS));
+    for (int i = 0; i < int(rews.size()); ++i) {   // one frand per reward, drawn after the agents' rotations
+        const bool good = frand(rng) > 0.3f;
+        if (i < e.numRewards) e.rewards[i] = RewardObj{rews[i].x, rews[i].y, rews[i].z, good ? 1 : 2};
+        if (good) ++e.numPlatforms;   // numPositiveRewards
+    }
+}
+
 static void env_reset(Env &e)
 {
     // ---- Env::reset, env/src/env.cpp:57-76 ; EnvState::reset env.hpp:135-151
@@ -802,7 +955,8 @@ static void env_reset(Env &e)
     const int seed = randRange(0, 1 << 30, e.rng);
     e.rng.seed((unsigned long)seed);
     if (e.scenario == SCN_TOWER) tower_generate(e);
-    else obstacles_generate(e);
+    else if (e.scenario == SCN_OBSTACLES) obstacles_generate(e);
+    else collect_generate(e);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -903,39 +1057,36 @@ static bool convex_cast(const Collider &col, V3 p, V3 d, float *fraction, V3 *no
 
 struct Colliders {
     int n = 0;
-    Collider c[MAX_BOXES + MAX_OBJECTS + MAX_AGENTS];
+    Collider c[MAX_BOXES + MAX_OBJECTS + MAX_AGENTS];   // empty slots are never emitted: only the relative order matters
 };
 
 // Collider order == index order used for tie-breaks: layout boxes, movable boxes, agents.
 static void build_colliders(const Env &e, int self, Colliders &out)
 {
     out.n = 0;
-    for (int i = 0; i < MAX_BOXES; ++i) {
+    for (int i = 0; i < e.numBoxes; ++i) {
+        if (!(e.boxes[i].type & VX_SOLID)) continue;  // layout_utils.cpp:42-49
         Collider &c = out.c[out.n++];
-        if (i < e.numBoxes && (e.boxes[i].type & VX_SOLID)) {  // layout_utils.cpp:42-49
-            const Box &b = e.boxes[i];
-            c.kind = 1;
-            c.lo = v3(float(b.min[0]), float(b.min[1]) - CAP_HH, float(b.min[2]));
-            c.hi = v3(float(b.max[0]), float(b.max[1]) + CAP_HH, float(b.max[2]));
-        } else c.kind = 0;
+        const Box &b = e.boxes[i];
+        c.kind = 1;
+        c.lo = v3(float(b.min[0]), float(b.min[1]) - CAP_HH, float(b.min[2]));
+        c.hi = v3(float(b.max[0]), float(b.max[1]) + CAP_HH, float(b.max[2]));
     }
-    for (int i = 0; i < MAX_OBJECTS; ++i) {
+    for (int i = 0; i < e.numObjects; ++i) {
+        if (e.objects[i].state > 0) continue;  // carried boxes: CF_NO_CONTACT_RESPONSE physics.hpp:76-85
         Collider &c = out.c[out.n++];
-        if (i < e.numObjects && e.objects[i].state == 0) {  // carried boxes: CF_NO_CONTACT_RESPONSE physics.hpp:76-85
-            const Object &o = e.objects[i];
-            const float cx = float(o.x) + 0.5f, cy = float(o.y) + 0.5f + OBJ_COLL_YOFF, cz = float(o.z) + 0.5f;
-            c.kind = 1;
-            c.lo = v3(cx - OBJ_COLL_HALF, (cy - OBJ_COLL_HALF) - CAP_HH, cz - OBJ_COLL_HALF);
-            c.hi = v3(cx + OBJ_COLL_HALF, (cy + OBJ_COLL_HALF) + CAP_HH, cz + OBJ_COLL_HALF);
-        } else c.kind = 0;
+        const Object &o = e.objects[i];
+        const float cx = float(o.x) + 0.5f, cy = float(o.y) + 0.5f + OBJ_COLL_YOFF, cz = float(o.z) + 0.5f;
+        c.kind = 1;
+        c.lo = v3(cx - OBJ_COLL_HALF, (cy - OBJ_COLL_HALF) - CAP_HH, cz - OBJ_COLL_HALF);
+        c.hi = v3(cx + OBJ_COLL_HALF, (cy + OBJ_COLL_HALF) + CAP_HH, cz + OBJ_COLL_HALF);
     }
-    for (int i = 0; i < MAX_AGENTS; ++i) {
+    for (int i = 0; i < e.numAgents; ++i) {
+        if (i == self) continue;  // collision filter agent.cpp:63
         Collider &c = out.c[out.n++];
-        if (i < e.numAgents && i != self) {  // collision filter agent.cpp:63
-            c.kind = 2;
-            c.lo = e.agents[i].pos;
-            c.hi = v3(2 * CAP_HH, 0, 0);
-        } else c.kind = 0;
+        c.kind = 2;
+        c.lo = e.agents[i].pos;
+        c.hi = v3(2 * CAP_HH, 0, 0);
     }
 }
 
@@ -1164,6 +1315,8 @@ static void reward_team(Env &e, int key, int idx, float mult)
 static bool solid_at(const Env &e, int x, int y, int z)
 {
     if (e.scenario == SCN_TOWER) return (e.vox(x, y, z) & VX_SOLID) != 0;
+    if (e.scenario == SCN_COLLECT)   // heightfield: floor at y == 0, landscape columns above it
+        return x >= 0 && x < HM_DIM && z >= 0 && z < HM_DIM && y >= 0 && y <= e.heightmap[x * HM_DIM + z];
     for (int i = 0; i < e.numBoxes; ++i) {
         const Box &b = e.boxes[i];
         if ((b.type & VX_SOLID) && x >= b.min[0] && x < b.max[0] && y >= b.min[1] && y < b.max[1] && z >= b.min[2] && z < b.max[2]) return true;
@@ -1321,9 +1474,36 @@ static void env_step(Env &e)
         a.hvx = a.hvz = 0; a.vvel = 0;
     };
     for (int i = 0; i < e.numAgents; ++i)  // component_fall_detection.hpp:33-43
-        if (e.agents[i].pos.y + 0.05f < -20.0f) reset_agent(e.agents[i]);
+        if (e.agents[i].pos.y + 0.05f < -20.0f) {
+            reset_agent(e.agents[i]);
+            if (e.scenario == SCN_COLLECT) reward_agent(e, 2, i, 1);   // CollectScenario::agentFell, scenario_collect.cpp:214-218
+        }
 
-    if (e.scenario == SCN_TOWER) {
+    if (e.scenario == SCN_COLLECT) {   // CollectScenario::step, scenario_collect.cpp:163-196
+        for (int i = 0; i < e.numAgents; ++i) {
+            Agent &a = e.agents[i];
+            int vox[3];
+            voxel_of(v3(a.pos.x, a.pos.y + 0.05f, a.pos.z), vox);
+            for (int r = 0; r < e.numRewards; ++r) {
+                RewardObj &ro = e.rewards[r];
+                if (!ro.active || ro.x != vox[0] || ro.y != vox[1] || ro.z != vox[2]) continue;
+                const int kind = ro.active;
+                ro.active = 0;
+                if (kind == 1) ++e.highestTower;                 // positiveRewardsCollected
+                reward_team(e, kind == 1 ? 1 : 2, i, 1);
+                if (e.highestTower >= e.numPlatforms && !e.solved) {
+                    e.solved = 1;
+                    e.episodeSec = std::max(e.episodeSec, e.episodeLen - 0.3f);   // doneWithTimer()
+                    reward_team(e, 3, i, 1);
+                }
+                // vg.grid.remove(voxel) erases the whole cell: a movable box that was dropped into the diamond's cell
+                // stays in the world (collision + drawable) but can no longer be found through the grid
+                for (int o = 0; o < e.numObjects; ++o)
+                    if (e.objects[o].state == 0 && e.objects[o].x == vox[0] && e.objects[o].y == vox[1] && e.objects[o].z == vox[2])
+                        e.objects[o].state = -1;
+            }
+        }
+    } else if (e.scenario == SCN_TOWER) {
         for (int i = 0; i < e.numAgents; ++i) {
             Agent &a = e.agents[i];
             if (a.carrying >= 0) {
@@ -1425,7 +1605,7 @@ static void build_prims(const Env &e, int viewer, std::vector<Prim> &out)
     for (int i = 0; i < e.numObjects; ++i) {  // component_object_stacking.hpp:170-198, :146-152
         const Object &o = e.objects[i];
         Prim p; p.kind = 1; p.color = COLOR_MOVABLE_BOX;
-        if (o.state == 0) {
+        if (o.state <= 0) {
             p.frame = -1;
             const V3 c = v3(float(o.x) + 0.5f, float(o.y) + 0.5f, float(o.z) + 0.5f);
             p.lo = v3(c.x - OBJ_HALF, c.y - OBJ_HALF, c.z - OBJ_HALF);
@@ -1442,9 +1622,11 @@ static void build_prims(const Env &e, int viewer, std::vector<Prim> &out)
     for (int i = 0; i < e.numRewards; ++i) {   // addDiamond, layout_utils.cpp:114-126 + scenario_obstacles.cpp:254
         const RewardObj &r = e.rewards[i];
         if (!r.active) continue;               // collected diamonds are translated far away (:227)
-        const float sx = 0.17f * 0.8f, sy = 0.45f * 0.8f;
-        const V3 c = v3(float(r.x) + 0.5f, float(r.y) + 0.7f, float(r.z) + 0.5f);
-        Prim up; up.kind = 3; up.frame = -1; up.color = COLOR_GREEN;
+        // Obstacles: scale (0.17, 0.45, 0.17) * 0.8 at y + 0.7; Collect (scenario_collect.cpp:192,208): unscaled at y + 0.8
+        const bool collect = e.scenario == SCN_COLLECT;
+        const float sx = collect ? 0.17f : 0.17f * 0.8f, sy = collect ? 0.45f : 0.45f * 0.8f;
+        const V3 c = v3(float(r.x) + 0.5f, float(r.y) + (collect ? 0.8f : 0.7f), float(r.z) + 0.5f);
+        Prim up; up.kind = 3; up.frame = -1; up.color = r.active == 2 ? COLOR_RED : COLOR_GREEN;
         up.lo = v3(c.x, c.y + 0.5f * sy, c.z); up.hi = v3(sx, sy, 1.0f);
         out.push_back(up);
         Prim dn = up;
@@ -1711,7 +1893,7 @@ struct Gym {
             if (envs[i]->done) {
                 done[i] = 1;
                 for (int a = 0; a < numAgents; ++a)
-                    trueObjective[size_t(i) * numAgents + a] = envs[i]->scenario == SCN_TOWER ? float(envs[i]->highestTower) : float(envs[i]->solved);
+                    trueObjective[size_t(i) * numAgents + a] = envs[i]->scenario == SCN_TOWER ? float(envs[i]->highestTower) : float(envs[i]->solved);   // scenario_collect.hpp:42
                 env_reset(*envs[i]);
             } else done[i] = 0;
         }
@@ -1747,7 +1929,8 @@ mvo_gym *mvo_create(const char *scenario, int w, int h, int num_envs, int num_ag
         scen = SCN_OBSTACLES; op.minPlatforms = 1; op.maxPlatforms = 4; op.minGap = 1; op.maxGap = 3; op.minLava = 2; op.maxLava = 10;
         op.minHeight = 1; op.maxHeight = 3; carriedDefault = 1.0f;
         op.platformTypes = {s == "obstacleswalls" ? PT_WALL : s == "obstaclessteps" ? PT_STEP : PT_LAVA};
-    } else { fprintf(stderr, "mv_oracle: unknown scenario %s\n", s.c_str()); return nullptr; }
+    } else if (s == "collect") scen = SCN_COLLECT;   // scenarios/init.hpp:45
+    else { fprintf(stderr, "mv_oracle: unknown scenario %s\n", s.c_str()); return nullptr; }
     if (num_agents_per_env < 1 || num_agents_per_env > MAX_AGENTS || num_envs < 1) return nullptr;
     auto *g = new mvo_gym();
     g->w = w; g->h = h; g->numEnvs = num_envs; g->numAgents = num_agents_per_env; g->numThreads = std::max(1, num_threads);
@@ -1766,11 +1949,13 @@ mvo_gym *mvo_create(const char *scenario, int w, int h, int num_envs, int num_ag
         e->scenario = scen;
         e->op = op;
         e->numShaping = scen == SCN_TOWER ? 4 : 5;
-        e->shapingKeys = scen == SCN_TOWER ? SHAPING_KEYS_TOWER : SHAPING_KEYS_OBST;
+        e->shapingKeys = scen == SCN_TOWER ? SHAPING_KEYS_TOWER : scen == SCN_OBSTACLES ? SHAPING_KEYS_OBST : SHAPING_KEYS_COLLECT;
         for (int a = 0; a < MAX_AGENTS; ++a) {
             std::memset(e->agents[a].shaping, 0, sizeof e->agents[a].shaping);
             for (int k = 0; k < e->numShaping; ++k)
-                e->agents[a].shaping[k] = scen == SCN_TOWER ? SHAPING_DEFAULT_TOWER[k] : (k == 4 ? carriedDefault : SHAPING_DEFAULT_OBST[k]);
+                e->agents[a].shaping[k] = scen == SCN_TOWER ? SHAPING_DEFAULT_TOWER[k]
+                                        : scen == SCN_COLLECT ? SHAPING_DEFAULT_COLLECT[k]
+                                        : (k == 4 ? carriedDefault : SHAPING_DEFAULT_OBST[k]);
         }
         g->envs.push_back(std::move(e));
     }
@@ -1857,6 +2042,7 @@ struct SnapHeader {
     int8_t rewards[MAX_REWARDS][4];
     SnapAgent agents[MAX_AGENTS];
     uint8_t chunk[CHUNK];
+    int8_t heightmap[HM_DIM * HM_DIM];
 };
 #pragma pack(pop)
 
@@ -1905,11 +2091,18 @@ void mvo_snapshot(mvo_gym *g, int env, void *out)
         for (int k = 0; k < MAX_SHAPING; ++k) o.shaping[k] = a.shaping[k];
     }
     std::memcpy(s->chunk, e.chunk.data(), CHUNK);
+    std::memcpy(s->heightmap, e.heightmap.data(), HM_DIM * HM_DIM);
     std::memcpy(out, s, sizeof *s);
     delete s;
 }
 
 // ---- spec helpers ----
+void mvo_perlin_octave2_01(uint32_t seed, const double *xs, const double *ys, int n, int octaves, double *out)
+{
+    const Perlin perlin(seed);
+    for (int i = 0; i < n; ++i) out[i] = perlin.octaves2_01(xs[i], ys[i], octaves);
+}
+
 uint32_t mvo_mt19937_nth(uint32_t seed, int n)
 {
     Rng r(seed);

@@ -65,6 +65,8 @@ int mvo_snapshot_size(mvo_gym *g);
 void mvo_snapshot(mvo_gym *g, int env_idx, void *out);
 
 /* ---- spec-level helpers exposed for known-answer tests ---- */
+/* Collect landscape noise: siv::PerlinNoise(seed).accumulatedOctaveNoise2D_0_1 (util/perlin_noise.hpp:315-318) */
+void mvo_perlin_octave2_01(uint32_t seed, const double *xs, const double *ys, int n, int octaves, double *out);
 uint32_t mvo_mt19937_nth(uint32_t seed, int n);            /* n-th output (1-based) */
 int mvo_rand_range_seq(uint32_t seed, const int *lo, const int *hi, int n, int *out);
 void mvo_frand_seq(uint32_t seed, int n, float *out);

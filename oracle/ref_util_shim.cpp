@@ -8,10 +8,12 @@
  * restatement against the real reference functions.  Output goes to oracle/_ref/
  * (git-ignored, travels to the GPU box with the snapshot).
  *
- * Only util.hpp (+ macro.hpp) is buildable this way: every other header on the
- * hot path pulls in Magnum/Corrade/Bullet, which are not vendored.
+ * Only util.hpp (+ macro.hpp) and the self-contained perlin_noise.hpp are buildable this
+ * way: every other header on the hot path pulls in Magnum/Corrade/Bullet, which are not
+ * vendored.
  */
 #include <util/util.hpp>
+#include <util/perlin_noise.hpp>
 
 extern "C" {
 
@@ -40,6 +42,14 @@ void mvref_env_seeds(int seed, int n, int *out)
     Megaverse::Rng rng;
     rng.seed((unsigned long)seed);
     for (int i = 0; i < n; ++i) out[i] = Megaverse::randRange(0, 1 << 30, rng);
+}
+
+/* CollectScenario::createLandscape's noise call (scenario_collect.cpp:80,88) on the reference's vendored
+ * siv::PerlinNoise (util/perlin_noise.hpp:118-126,315-318) */
+void mvref_perlin_octave2_01(unsigned seed, const double *xs, const double *ys, int n, int octaves, double *out)
+{
+    const siv::PerlinNoise perlin(seed);
+    for (int i = 0; i < n; ++i) out[i] = perlin.accumulatedOctaveNoise2D_0_1(xs[i], ys[i], octaves);
 }
 
 }

@@ -8,8 +8,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 
-MAX_BOXES, MAX_OBJECTS, MAX_AGENTS, CHUNK = 128, 80, 8, 32 * 16 * 32
-MAX_TERRAIN, MAX_REWARDS, MAX_SHAPING = 16, 16, 8
+MAX_BOXES, MAX_OBJECTS, MAX_AGENTS, CHUNK = 1024, 80, 8, 32 * 16 * 32
+MAX_TERRAIN, MAX_REWARDS, MAX_SHAPING, HM_DIM = 16, 96, 8, 42
 
 SNAP_AGENT = np.dtype([
     ("pos", "<f4", 3), ("basis", "<f4", 4), ("pitch", "<f4"), ("hv", "<f4", 2), ("vvel", "<f4"), ("voffset", "<f4"),
@@ -23,7 +23,7 @@ SNAP = np.dtype([
     ("solved", "<i4"), ("episode_sec", "<f4"), ("episode_len", "<f4"), ("bz_reward", "<f4"),
     ("bar_half_width", "<f4"), ("boxes", "<i4", (MAX_BOXES, 8)), ("terrain", "<i4", (MAX_TERRAIN, 8)),
     ("objects", "i1", (MAX_OBJECTS, 4)), ("rewards", "i1", (MAX_REWARDS, 4)),
-    ("agents", SNAP_AGENT, MAX_AGENTS), ("chunk", "u1", CHUNK),
+    ("agents", SNAP_AGENT, MAX_AGENTS), ("chunk", "u1", CHUNK), ("heightmap", "i1", HM_DIM * HM_DIM),
 ])
 
 
@@ -72,6 +72,7 @@ def lib():
         L.mvo_building_reward_coeff.argtypes = [C.c_float]
         L.mvo_building_reward_coeff.restype = C.c_float
         L.mvo_sincos.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.mvo_perlin_octave2_01.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -86,6 +87,8 @@ def ref_lib():
     L.mvref_frand_seq.argtypes = [C.c_uint, C.c_int, C.c_void_p]
     L.mvref_random_bool_seq.argtypes = [C.c_uint, C.c_int, C.c_void_p]
     L.mvref_env_seeds.argtypes = [C.c_int, C.c_int, C.c_void_p]
+    if hasattr(L, "mvref_perlin_octave2_01"):
+        L.mvref_perlin_octave2_01.argtypes = [C.c_uint, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     return L
 
 
