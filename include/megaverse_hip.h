@@ -114,6 +114,12 @@ int mv_debug_snapshot_size(const mv_gym *g);
 int mv_debug_snapshot(mv_gym *g, int32_t env_idx, void *out_host);
 int mv_debug_rng(int32_t device, uint32_t seed, int32_t what, const int32_t *lo, const int32_t *hi, int32_t n, void *out_host);
 int mv_debug_math(int32_t device, int32_t what, const float *a, const float *b, int32_t n, float *out_host);
+/* Host-only (no device): the n-th (1-based) episode an env seeded with env_seed generates for a host-generated
+ * scenario (Obstacles family, Collect), as the raw blob the reset kernel swaps in.  Returns the blob size in
+ * bytes (out == NULL: size query only), -1 on error.  Replaces Env::reset's scenario->reset() + spawnAgents
+ * draws (env.cpp:57-76). */
+int mv_debug_generate_episode(const char *scenario, int32_t num_agents, int32_t env_seed, int32_t n, float base_episode_len,
+                              void *out, int32_t out_bytes);
 
 #ifdef __cplusplus
 }

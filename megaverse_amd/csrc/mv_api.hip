@@ -27,6 +27,8 @@ void launch_step(const GymView &gv, hipStream_t stream);
 int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream);
 void launch_step_obstacles(const GymView &gv, hipStream_t stream);
 void launch_reset_obstacles(const GymView &gv, const EpisodeBlob *blobs, int *total_consumed, int force_all, hipStream_t stream);
+void launch_step_collect(const GymView &gv, hipStream_t stream);
+void launch_reset_collect(const GymView &gv, const CollectBlob *blobs, int *total_consumed, int force_all, hipStream_t stream);
 }  // namespace mv
 
 using namespace mv;
@@ -50,6 +52,9 @@ static const float SHAPING_DEFAULT_TOWER[4] = {0.1f, 0.1f, 0.1f, 1.0f};   // sce
 static const char *SHAPING_KEYS_OBST[5] = {"teamSpirit", "obstaclesAgentAtExit", "obstaclesAllAgentsAtExit", "obstaclesExtraReward",
                                           "obstaclesAgentCarriedObjectToExit"};
 static const float SHAPING_DEFAULT_OBST[5] = {0.0f, 1.0f, 5.0f, 0.5f, 0.0f};
+// scenario_collect.hpp:44-52
+static const char *SHAPING_KEYS_COLLECT[5] = {"teamSpirit", "collectSingleGood", "collectSingleBad", "collectAll", "collectAbyss"};
+static const float SHAPING_DEFAULT_COLLECT[5] = {0.0f, 1.0f, -1.0f, 5.0f, -0.5f};
 static const int ACTION_SPACE[6] = {3, 3, 3, 2, 2, 3};                          // env.cpp:33
 
 struct mv_gym {
@@ -81,7 +86,9 @@ struct mv_gym {
     // Obstacles: host episode generator + one resident episode per env (refill protocol)
     std::vector<std::mt19937> envRng;
     std::vector<int> uploaded;                   // episodes uploaded per env
-    EpisodeBlob *dBlobs = nullptr, *hBlobs = nullptr;   // device [N], pinned staging [N]
+    uint8_t *dBlobs = nullptr, *hBlobs = nullptr;   // device [N][blobBytes], pinned staging [N][blobBytes]
+    size_t blobBytes = 0;                           // sizeof(EpisodeBlob) or sizeof(CollectBlob)
+    bool hostEpisodes() const { return scenario != SCN_TOWER; }
     int *dTotalConsumed = nullptr, *hTotalConsumed = nullptr;   // device counter, pinned mirror
     int lastTotalSeen = 0;
     hipEvent_t consumedCopied = nullptr;
@@ -210,14 +217,11 @@ int mv_action_space_sizes(int32_t *out6)
     return 0;
 }
 
-int mv_create(const mv_config *cfg, mv_gym **out)
+}  // extern "C" (helper below has C++ linkage)
+
+// scenario name -> kernel family + generator parameters (scenarios/init.hpp:30-52)
+static bool scenario_from_name(const std::string &scen, int &scenario, ObstacleConfig &oc)
 {
-    if (!cfg || !out) return fail("mv_create: null argument");
-    *out = nullptr;
-    // Scenario::create (scenario.hpp:61-77) is fatal on unknown names; we return an error instead
-    const std::string scen = lower(cfg->scenario);
-    int scenario = SCN_TOWER;
-    ObstacleConfig oc;
     if (scen == "towerbuilding") scenario = SCN_TOWER;
     else if (scen == "obstacleseasy") scenario = SCN_OBSTACLES;                       // scenario_obstacles.hpp:112-138
     else if (scen == "obstaclesmedium") { scenario = SCN_OBSTACLES; oc.min_platforms = 2; oc.max_platforms = 4; oc.min_lava = 2; oc.max_lava = 5; }
@@ -229,8 +233,23 @@ int mv_create(const mv_config *cfg, mv_gym **out)
         oc.min_height = 1; oc.max_height = 3; oc.carried_object_to_exit = 1.0f;
         oc.platform_types[0] = scen == "obstacleswalls" ? 1 : scen == "obstaclessteps" ? 3 : 2;
         oc.num_platform_types = 1;
-    } else
-        return fail("Unknown scenario " + scen + " (this build accelerates: TowerBuilding, ObstaclesEasy/Medium/Hard/Walls/Steps/Lava)");
+    } else if (scen == "collect") scenario = SCN_COLLECT;                              // scenarios/init.hpp:45
+    else return false;
+    return true;
+}
+
+extern "C" {
+
+int mv_create(const mv_config *cfg, mv_gym **out)
+{
+    if (!cfg || !out) return fail("mv_create: null argument");
+    *out = nullptr;
+    // Scenario::create (scenario.hpp:61-77) is fatal on unknown names; we return an error instead
+    const std::string scen = lower(cfg->scenario);
+    int scenario = SCN_TOWER;
+    ObstacleConfig oc;
+    if (!scenario_from_name(scen, scenario, oc))
+        return fail("Unknown scenario " + scen + " (this build accelerates: TowerBuilding, ObstaclesEasy/Medium/Hard/Walls/Steps/Lava, Collect)");
     if (cfg->num_envs < 1 || cfg->num_agents_per_env < 1 || cfg->num_agents_per_env > MAX_AGENTS)
         return fail("mv_create: num_envs >= 1 and 1 <= num_agents_per_env <= 8 required");
     if (cfg->obs_width < 1 || cfg->obs_height < 1 || cfg->obs_width > 1024 || cfg->obs_height > 1024) return fail("mv_create: observation size must be within 1..1024");
@@ -249,26 +268,31 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     g->N = cfg->num_envs; g->A = cfg->num_agents_per_env;
     g->scenario = scenario;
     g->numShaping = scenario == SCN_TOWER ? 4 : 5;
-    g->shapingKeys = scenario == SCN_TOWER ? SHAPING_KEYS_TOWER : SHAPING_KEYS_OBST;
+    g->shapingKeys = scenario == SCN_TOWER ? SHAPING_KEYS_TOWER : scenario == SCN_OBSTACLES ? SHAPING_KEYS_OBST : SHAPING_KEYS_COLLECT;
     g->envOffset = cfg->total_envs > 0 ? cfg->env_offset : 0;
     g->totalEnvs = cfg->total_envs > 0 ? cfg->total_envs : cfg->num_envs;
     const size_t N = g->N, NA = (size_t)g->N * g->A;
 
     GymView &gv = g->gv;
     gv.num_envs = g->N; gv.num_agents = g->A;
+    const bool obstacles = scenario == SCN_OBSTACLES, collect = scenario == SCN_COLLECT, hostEpisodes = obstacles || collect;
+    gv.box_stride = collect ? COLLECT_MAX_BOXES : MAX_BOXES;
+    gv.reward_stride = collect ? COLLECT_MAX_REWARDS : MAX_REWARDS;
+    g->blobBytes = collect ? sizeof(CollectBlob) : obstacles ? sizeof(EpisodeBlob) : 0;
     // ONE arena for all simulator state: a step touches ~8 arrays per env, separate small allocations
     // cost a TLB miss each per wave (measured: 83 % of the physics kernel's time was spent waiting on
     // ~30 memory operations); one large allocation is backed by large pages.
     auto up = [](size_t v) { return (v + 4095) & ~size_t(4095); };
-    const size_t szHdr = up(N * sizeof(EnvHeader)), szBoxes = up(N * MAX_BOXES * sizeof(LayoutBox)),
+    const size_t szHdr = up(N * sizeof(EnvHeader)), szBoxes = up(N * (size_t)gv.box_stride * sizeof(LayoutBox)),
                  szObj = up(N * MAX_OBJECTS * sizeof(MovableObject)), szAg = up(NA * sizeof(AgentState)),
                  szChunk = up(N * (size_t)CHUNK_BYTES), szAct = up(NA * sizeof(int32_t)), szRew = up(NA * sizeof(float)),
                  szDone = up(N), szObjv = up(NA * sizeof(float)), szMd = up(NA * 6 * sizeof(int32_t)),
                  szObs = up(NA * (size_t)g->w * g->h * 4);
-    const bool obstacles = scenario == SCN_OBSTACLES;
-    const size_t szTerrain = obstacles ? up(N * MAX_TERRAIN * sizeof(TerrainBox)) : 0, szRewObj = obstacles ? up(N * MAX_REWARDS * sizeof(MovableObject)) : 0,
-                 szBlobs = obstacles ? up(N * sizeof(EpisodeBlob)) : 0, szCnt = 4096;
-    const size_t total = szHdr + szBoxes + szObj + szAg + szAct + szRew + szDone + szObjv + szMd + (obstacles ? 0 : szChunk) + szObs + szTerrain + szRewObj + szBlobs + szCnt;
+    const size_t szTerrain = obstacles ? up(N * MAX_TERRAIN * sizeof(TerrainBox)) : 0,
+                 szRewObj = hostEpisodes ? up(N * (size_t)gv.reward_stride * sizeof(MovableObject)) : 0,
+                 szHeight = collect ? up(N * (size_t)HM_BYTES) : 0, szBlobs = up(N * g->blobBytes), szCnt = 4096;
+    const size_t total = szHdr + szBoxes + szObj + szAg + szAct + szRew + szDone + szObjv + szMd + (hostEpisodes ? 0 : szChunk) + szObs + szTerrain +
+                         szRewObj + szHeight + szBlobs + szCnt;
     {
         hipError_t e_ = hipMalloc((void **)&g->arena, total);
         if (e_ != hipSuccess) { mv_destroy(g); return fail(std::string("hipMalloc arena: ") + hipGetErrorString(e_)); }
@@ -285,14 +309,15 @@ int mv_create(const mv_config *cfg, mv_gym **out)
         gv.done = p; p += szDone;
         gv.true_objective = (float *)p; p += szObjv;
         g->dMultiDiscrete = (int32_t *)p; p += szMd;
-        if (!obstacles) { gv.chunk = p; p += szChunk; }
+        if (!hostEpisodes) { gv.chunk = p; p += szChunk; }
         g->ownedObs = (uint32_t *)p; p += szObs;
         g->dTotalConsumed = (int *)p; p += szCnt;
-        if (obstacles) {
-            gv.terrain = (TerrainBox *)p; p += szTerrain;
+        if (obstacles) { gv.terrain = (TerrainBox *)p; p += szTerrain; }
+        if (hostEpisodes) {
             gv.rewards_obj = (MovableObject *)p; p += szRewObj;
-            g->dBlobs = (EpisodeBlob *)p; p += szBlobs;
+            g->dBlobs = p; p += szBlobs;
         }
+        if (collect) { gv.heightmap = (int8_t *)p; p += szHeight; }
     }
     g->obs = g->ownedObs;
     for (int b = 0; b < 2; ++b) {
@@ -320,11 +345,11 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     }
     g->obst = oc;
     g->baseEpisodeLen = episodeLen;
-    if (obstacles) {
+    if (hostEpisodes) {
         std::random_device rdev;
         for (size_t i = 0; i < N; ++i) g->envRng.emplace_back(rdev());
         g->uploaded.assign(N, 0);
-        if (hipHostMalloc((void **)&g->hBlobs, N * sizeof(EpisodeBlob), hipHostMallocDefault) != hipSuccess ||
+        if (hipHostMalloc((void **)&g->hBlobs, N * g->blobBytes, hipHostMallocDefault) != hipSuccess ||
             hipHostMalloc((void **)&g->hTotalConsumed, sizeof(int), hipHostMallocDefault) != hipSuccess ||
             hipEventCreateWithFlags(&g->consumedCopied, hipEventDisableTiming) != hipSuccess) {
             mv_destroy(g);
@@ -345,7 +370,8 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     for (size_t i = 0; i < NA; ++i) {
         std::memset(&ha[i], 0, sizeof(AgentState));
         for (int k = 0; k < g->numShaping; ++k)
-            ha[i].shaping[k] = scenario == SCN_TOWER ? SHAPING_DEFAULT_TOWER[k] : (k == 4 ? oc.carried_object_to_exit : SHAPING_DEFAULT_OBST[k]);
+            ha[i].shaping[k] = scenario == SCN_TOWER ? SHAPING_DEFAULT_TOWER[k] : scenario == SCN_COLLECT ? SHAPING_DEFAULT_COLLECT[k]
+                                                     : (k == 4 ? oc.carried_object_to_exit : SHAPING_DEFAULT_OBST[k]);
         ha[i].carrying = -1; ha[i].jump_speed = 10.0f; ha[i].m00 = 1.0f; ha[i].m22 = 1.0f;
     }
     if (hipMemcpy(gv.hdr, hh.data(), N * sizeof(EnvHeader), hipMemcpyHostToDevice) != hipSuccess ||
@@ -418,7 +444,7 @@ int mv_seed(mv_gym *g, int32_t seed)
         const int noise = std::uniform_int_distribution<>{0, (1 << 30) - 1}(g->rng);
         if (i >= g->envOffset && i < g->envOffset + g->N) seeds[i - g->envOffset] = (uint32_t)noise;
     }
-    if (g->scenario == SCN_OBSTACLES) {   // Env::seed (env.cpp:52-55) on the host-side episode generators
+    if (g->hostEpisodes()) {   // Env::seed (env.cpp:52-55) on the host-side episode generators
         for (int i = 0; i < g->N; ++i) g->envRng[i].seed((unsigned long)seeds[i]);
         return 0;
     }
@@ -448,16 +474,25 @@ int mv_render(mv_gym *g)
 // >= 35 s = 525 steps, so the spare is always in place long before it is needed.
 static int upload_next_episode(mv_gym *g, int env)
 {
-    EpisodeBlob &b = g->hBlobs[env];
-    generate_obstacles_episode(g->envRng[env], g->obst, g->A, g->baseEpisodeLen, b);
-    b.seq = ++g->uploaded[env];
-    HIP_TRY(hipMemcpyAsync(g->dBlobs + env, &b, sizeof b, hipMemcpyHostToDevice, g->stream));
+    uint8_t *host = g->hBlobs + (size_t)env * g->blobBytes, *dev = g->dBlobs + (size_t)env * g->blobBytes;
+    size_t bytes = g->blobBytes;
+    if (g->scenario == SCN_OBSTACLES) {
+        EpisodeBlob &b = *reinterpret_cast<EpisodeBlob *>(host);
+        generate_obstacles_episode(g->envRng[env], g->obst, g->A, g->baseEpisodeLen, b);
+        b.seq = ++g->uploaded[env];
+    } else {
+        CollectBlob &b = *reinterpret_cast<CollectBlob *>(host);
+        generate_collect_episode(g->envRng[env], g->A, g->baseEpisodeLen, b);
+        b.seq = ++g->uploaded[env];
+        bytes = offsetof(CollectBlob, boxes) + (size_t)b.num_boxes * sizeof(LayoutBox);   // the slab list is last: used prefix only
+    }
+    HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, g->stream));
     return 0;
 }
 
 static int refill_episodes(mv_gym *g, bool force)
 {
-    if (g->scenario != SCN_OBSTACLES) return 0;
+    if (!g->hostEpisodes()) return 0;
     if (g->consumedPending) {
         HIP_TRY(hipEventSynchronize(g->consumedCopied));
         g->consumedPending = false;
@@ -468,7 +503,8 @@ static int refill_episodes(mv_gym *g, bool force)
     HIP_TRY(hipStreamSynchronize(g->stream));
     int total = 0;
     for (int i = 0; i < g->N; ++i) {
-        if (hh[i].starved) return fail("Obstacles env " + std::to_string(i) + " reset without a fresh episode");
+        if (hh[i].starved & 1) return fail("env " + std::to_string(i) + " reset without a fresh episode");
+        if (hh[i].starved & 2) return fail("env " + std::to_string(i) + ": collision candidate list overflow");
         total += hh[i].episodes_consumed;
         if (hh[i].episodes_consumed == g->uploaded[i] && upload_next_episode(g, i)) return -1;
     }
@@ -480,9 +516,10 @@ int mv_reset(mv_gym *g)
 {   // MegaverseGym::reset (megaverse.cpp:76-93) -> VectorEnv::reset (vector_env.cpp:110-120)
     if (check(g)) return -1;
     HIP_TRY(hipSetDevice(g->device));
-    if (g->scenario == SCN_OBSTACLES) {
+    if (g->hostEpisodes()) {
         if (refill_episodes(g, true)) return -1;        // every env has an unconsumed episode resident
-        launch_reset_obstacles(g->gv, g->dBlobs, g->dTotalConsumed, 1, g->stream);
+        if (g->scenario == SCN_OBSTACLES) launch_reset_obstacles(g->gv, (const EpisodeBlob *)g->dBlobs, g->dTotalConsumed, 1, g->stream);
+        else launch_reset_collect(g->gv, (const CollectBlob *)g->dBlobs, g->dTotalConsumed, 1, g->stream);
         if (refill_episodes(g, true)) return -1;        // and a spare for the first auto-reset
     } else
         launch_reset(g->gv, 1, g->stream);
@@ -558,10 +595,12 @@ static int step_impl(mv_gym *g, bool render)
     hipEvent_t *ev = prof ? &g->profEvents[(size_t)g->profCount * 4] : nullptr;
     if (prof) HIP_TRY(hipEventRecord(ev[0], g->stream));
     if (g->scenario == SCN_OBSTACLES) launch_step_obstacles(g->gv, g->stream);
+    else if (g->scenario == SCN_COLLECT) launch_step_collect(g->gv, g->stream);
     else launch_step(g->gv, g->stream);
     if (prof) HIP_TRY(hipEventRecord(ev[1], g->stream));
-    if (g->scenario == SCN_OBSTACLES) {
-        launch_reset_obstacles(g->gv, g->dBlobs, g->dTotalConsumed, 0, g->stream);
+    if (g->hostEpisodes()) {
+        if (g->scenario == SCN_OBSTACLES) launch_reset_obstacles(g->gv, (const EpisodeBlob *)g->dBlobs, g->dTotalConsumed, 0, g->stream);
+        else launch_reset_collect(g->gv, (const CollectBlob *)g->dBlobs, g->dTotalConsumed, 0, g->stream);
         HIP_TRY(hipMemcpyAsync(g->hTotalConsumed, g->dTotalConsumed, sizeof(int), hipMemcpyDeviceToHost, g->stream));
         HIP_TRY(hipEventRecord(g->consumedCopied, g->stream));
         g->consumedPending = true;
@@ -751,12 +790,13 @@ struct Snap {
     int32_t scenario, L, H, W, bz[4], layout_color, wall_color, draw_walls, num_objects, num_boxes, num_frames, done, highest_tower,
         num_agents, num_terrain, num_rewards, num_platforms, solved;
     float episode_sec, episode_len, bz_reward, bar_half_width;
-    int32_t boxes[MAX_BOXES][8];
+    int32_t boxes[COLLECT_MAX_BOXES][8];
     int32_t terrain[MAX_TERRAIN][8];
     int8_t objects[MAX_OBJECTS][4];
-    int8_t rewards[MAX_REWARDS][4];
+    int8_t rewards[COLLECT_MAX_REWARDS][4];
     SnapAgent agents[MAX_AGENTS];
     uint8_t chunk[CHUNK_BYTES];
+    int8_t heightmap[HM_DIM * HM_DIM];
 };
 #pragma pack(pop)
 
@@ -768,20 +808,22 @@ int mv_debug_snapshot(mv_gym *g, int32_t env, void *out)
     if (env < 0 || env >= g->N) return fail("mv_debug_snapshot: index out of range");
     HIP_TRY(hipStreamSynchronize(g->stream));
     EnvHeader h;
-    std::vector<LayoutBox> boxes(MAX_BOXES);
+    std::vector<LayoutBox> boxes(g->gv.box_stride);
     std::vector<MovableObject> objs(MAX_OBJECTS);
     std::vector<AgentState> ag(g->A);
     Snap *s = new Snap();
     std::memset(s, 0, sizeof *s);
     hipError_t e = hipMemcpy(&h, g->gv.hdr + env, sizeof h, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(boxes.data(), g->gv.boxes + (size_t)env * MAX_BOXES, MAX_BOXES * sizeof(LayoutBox), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(boxes.data(), g->gv.boxes + (size_t)env * g->gv.box_stride, g->gv.box_stride * sizeof(LayoutBox), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(objs.data(), g->gv.objects + (size_t)env * MAX_OBJECTS, MAX_OBJECTS * sizeof(MovableObject), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(ag.data(), g->gv.agents + (size_t)env * g->A, g->A * sizeof(AgentState), hipMemcpyDeviceToHost);
     if (e == hipSuccess && g->gv.chunk) e = hipMemcpy(s->chunk, g->gv.chunk + (size_t)env * CHUNK_BYTES, CHUNK_BYTES, hipMemcpyDeviceToHost);
     std::vector<TerrainBox> terr(MAX_TERRAIN);
-    std::vector<MovableObject> rew(MAX_REWARDS);
+    std::vector<MovableObject> rew(g->gv.reward_stride);
     if (e == hipSuccess && g->gv.terrain) e = hipMemcpy(terr.data(), g->gv.terrain + (size_t)env * MAX_TERRAIN, MAX_TERRAIN * sizeof(TerrainBox), hipMemcpyDeviceToHost);
-    if (e == hipSuccess && g->gv.rewards_obj) e = hipMemcpy(rew.data(), g->gv.rewards_obj + (size_t)env * MAX_REWARDS, MAX_REWARDS * sizeof(MovableObject), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && g->gv.rewards_obj) e = hipMemcpy(rew.data(), g->gv.rewards_obj + (size_t)env * g->gv.reward_stride, g->gv.reward_stride * sizeof(MovableObject), hipMemcpyDeviceToHost);
+    std::memset(s->heightmap, 0xff, sizeof s->heightmap);
+    if (e == hipSuccess && g->gv.heightmap) e = hipMemcpy(s->heightmap, g->gv.heightmap + (size_t)env * HM_BYTES, sizeof s->heightmap, hipMemcpyDeviceToHost);
     if (e != hipSuccess) { delete s; return fail(std::string("mv_debug_snapshot: ") + hipGetErrorString(e)); }
     s->scenario = h.scenario; s->num_terrain = h.num_terrain; s->num_rewards = h.num_rewards; s->num_platforms = h.num_platforms; s->solved = h.solved;
     for (int i = 0; i < h.num_terrain && i < MAX_TERRAIN; ++i) {
@@ -789,7 +831,7 @@ int mv_debug_snapshot(mv_gym *g, int32_t env, void *out)
         int32_t *o = s->terrain[i];
         o[0] = t.min[0]; o[1] = t.min[1]; o[2] = t.min[2]; o[3] = t.max[0]; o[4] = t.max[1]; o[5] = t.max[2]; o[6] = t.type; o[7] = 0;
     }
-    for (int i = 0; i < h.num_rewards && i < MAX_REWARDS; ++i) {
+    for (int i = 0; i < h.num_rewards && i < g->gv.reward_stride; ++i) {
         s->rewards[i][0] = rew[i].x; s->rewards[i][1] = rew[i].y; s->rewards[i][2] = rew[i].z; s->rewards[i][3] = rew[i].state;
     }
     s->L = h.L; s->H = h.H; s->W = h.W;
@@ -798,7 +840,7 @@ int mv_debug_snapshot(mv_gym *g, int32_t env, void *out)
     s->num_objects = h.num_objects; s->num_boxes = h.num_boxes; s->num_frames = h.num_frames; s->done = h.done;
     s->highest_tower = h.highest_tower; s->num_agents = g->A;
     s->episode_sec = h.episode_sec; s->episode_len = h.episode_len; s->bz_reward = h.bz_reward; s->bar_half_width = h.bar_half_width;
-    for (int i = 0; i < h.num_boxes && i < MAX_BOXES; ++i) {
+    for (int i = 0; i < h.num_boxes && i < g->gv.box_stride; ++i) {
         const LayoutBox &b = boxes[i];
         int32_t *o = s->boxes[i];
         o[0] = b.min[0]; o[1] = b.min[1]; o[2] = b.min[2]; o[3] = b.max[0]; o[4] = b.max[1]; o[5] = b.max[2]; o[6] = b.type; o[7] = b.slot;
@@ -821,6 +863,31 @@ int mv_debug_snapshot(mv_gym *g, int32_t env, void *out)
     std::memcpy(out, s, sizeof *s);
     delete s;
     return 0;
+}
+
+// Host-only test hook (no device needed): the n-th episode an env seeded with `env_seed` generates, as the raw
+// blob the reset kernel consumes (EpisodeBlob for the Obstacles family, CollectBlob for Collect).
+int mv_debug_generate_episode(const char *scenario_name, int32_t num_agents, int32_t env_seed, int32_t n, float base_episode_len,
+                              void *out, int32_t out_bytes)
+{
+    int scenario = SCN_TOWER;
+    ObstacleConfig oc;
+    if (!scenario_name || !scenario_from_name(lower(scenario_name), scenario, oc) || scenario == SCN_TOWER)
+        return fail("mv_debug_generate_episode: host-generated scenarios are the Obstacles family and Collect");
+    if (num_agents < 1 || num_agents > MAX_AGENTS || n < 1) return fail("mv_debug_generate_episode: bad arguments");
+    const size_t bytes = scenario == SCN_COLLECT ? sizeof(CollectBlob) : sizeof(EpisodeBlob);
+    if (!out) return (int)bytes;
+    if ((size_t)out_bytes < bytes) return fail("mv_debug_generate_episode: buffer too small");
+    std::mt19937 rng;
+    rng.seed((unsigned long)env_seed);
+    std::vector<uint8_t> buf(bytes, 0);
+    for (int i = 0; i < n; ++i) {
+        std::memset(buf.data(), 0, bytes);
+        if (scenario == SCN_COLLECT) generate_collect_episode(rng, num_agents, base_episode_len, *reinterpret_cast<CollectBlob *>(buf.data()));
+        else generate_obstacles_episode(rng, oc, num_agents, base_episode_len, *reinterpret_cast<EpisodeBlob *>(buf.data()));
+    }
+    std::memcpy(out, buf.data(), bytes);
+    return (int)bytes;
 }
 
 int mv_debug_rng(int32_t device, uint32_t seed, int32_t what, const int32_t *lo, const int32_t *hi, int32_t n, void *out)

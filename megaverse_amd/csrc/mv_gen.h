@@ -18,4 +18,7 @@ struct ObstacleConfig {
 // Advances `rng` exactly like Env::reset + ObstaclesScenario::reset + spawnAgents and fills `out`.
 void generate_obstacles_episode(std::mt19937 &rng, const ObstacleConfig &cfg, int num_agents, float base_episode_len, EpisodeBlob &out);
 
+// Advances `rng` exactly like Env::reset + CollectScenario::reset + spawnAgents + addEpisodeDrawables and fills `out`.
+void generate_collect_episode(std::mt19937 &rng, int num_agents, float base_episode_len, CollectBlob &out);
+
 }  // namespace mv

@@ -43,7 +43,7 @@ constexpr float TAN_HALF_FOV_Y = 1.19175359f / (128.0f / 72.0f);  // aspect 128/
 constexpr float NEAR_Z = 0.01f, FAR_Z = 120.0f;
 constexpr float OBJ_HALF = 0.39f, CARRY_SCALE = 0.78f;
 constexpr int TILE_W = 16, TILE_H = 4;
-constexpr int MAX_VIS = 256;          // visible primitives kept per frame (slots: <=121 TowerBuilding, <=280 Obstacles)
+constexpr int VIS_SMALL = 256, VIS_LARGE = 1024;   // visible primitives kept per frame (TowerBuilding <= 121 slots, Obstacles <= 280; Collect up to ~1300)
 constexpr int MAX_STRADDLERS = 12;    // x 5 frustum planes = 60 lanes of one wave
 constexpr float STRADDLE_W = 0.05f;   // closer than this to the camera plane: projection unusable
 constexpr int MAX_W = 1024, MAX_H = 1024;
@@ -258,13 +258,15 @@ __device__ unsigned long long g_raster_stats[8];   // tiles, survivors, straddle
 __device__ unsigned long long g_frame_t0[4096], g_frame_t1[4096], g_frame_tp[4096];
 #endif
 
-__global__ __launch_bounds__(256, 4) void raster_kernel(GymView gv, uint32_t *obs, int W, int H, int split)
+template <int MAXVIS>
+__global__ __launch_bounds__(256, MAXVIS <= 256 ? 5 : 2) void raster_kernel(GymView gv, uint32_t *obs, int W, int H, int split)
 {
+    constexpr int ROUNDS = MAXVIS / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // column/row ray tables
-    __shared__ Prim s_vis[MAX_VIS];       // compacted visible list: straddlers first, then rectangle-bounded primitives
-    __shared__ short4 s_rect[MAX_VIS];    // x0,x1,y0,y1 (pixels)
+    __shared__ Prim s_vis[MAXVIS];       // compacted visible list: straddlers first, then rectangle-bounded primitives
+    __shared__ short4 s_rect[MAXVIS];    // x0,x1,y0,y1 (pixels)
     __shared__ CamL s_cam[MAX_AGENTS];
-    __shared__ int s_cnt[16];             // [round*4 + wave]: straddlers, [8 + round*4 + wave]: rectangle-bounded primitives
+    __shared__ int s_cnt[16];             // [parity*8 + wave]: straddlers, [parity*8 + 4 + wave]: rectangle-bounded primitives
 
     float4 *s_col = reinterpret_cast<float4 *>(s_dyn);   // per column i: (dc.x, c00*dc.x, c10*dc.x, c20*dc.x)
     float4 *s_row = s_col + W;                            // per row j:    (dc.y, c01*dc.y, c11*dc.y, c21*dc.y)
@@ -323,36 +325,34 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(GymView gv, uint32_t *ob
     }
     __syncthreads();   // cameras (incl. origin) complete
 
-    // ---- primitive slots (slot order == the order the reference emits drawables == depth-tie order):
-    //   TowerBuilding: 16 layout slabs | building-zone slab | 80 movable boxes | 3 per agent (body, eyes, time bar)
-    //   Obstacles:     128 layout slabs | 16 terrain slabs | 80 movable boxes | 2 cones per diamond x 16 | 3 per agent
+    // ---- primitive slots, packed (slot order == the order the reference emits drawables == depth-tie order):
+    //   layout slabs | terrain slabs (TowerBuilding: the building zone) | movable boxes | 2 cones per diamond | 3 per agent
     const int scen = hdr->scenario;
-    const int nLayout = scen == SCN_TOWER ? TOWER_BOXES : MAX_BOXES;
-    const int slotTerrain = nLayout, nTerrainSlots = scen == SCN_TOWER ? 1 : MAX_TERRAIN;
+    const int nLayout = hdr->num_boxes;
+    const int slotTerrain = nLayout, nTerrainSlots = scen == SCN_TOWER ? 1 : hdr->num_terrain;
     const int slotObjects = slotTerrain + nTerrainSlots;
-    const int slotRewards = slotObjects + MAX_OBJECTS, nRewardSlots = scen == SCN_TOWER ? 0 : 2 * MAX_REWARDS;
+    const int slotRewards = slotObjects + hdr->num_objects, nRewardSlots = scen == SCN_TOWER ? 0 : 2 * hdr->num_rewards;
     const int slotAgents = slotRewards + nRewardSlots;
     const int numSlots = slotAgents + 3 * A;
+    const LayoutBox *gboxes = gv.boxes + (size_t)env * gv.box_stride;
 
-    int kindR[2], frR[2], clsR[2], rectR[2][4];
-    unsigned colorR[2];
-    float loR[2][3], hiR[2][3];
-#pragma unroll
-    for (int rd = 0; rd < 2; ++rd) {
+    // Each round classifies 256 slots and appends the visible ones to the LDS list (order-free: depth ties are
+    // resolved on the slot id).  Positions [0, MAX_STRADDLERS) hold the world boxes that cross the eye plane
+    // ("straddlers", culled per tile with frustum planes), rectangle-bounded primitives follow.
+    int nStrad = 0, nRect = 0;   // wave-uniform running totals
+    for (int rd = 0; rd * 256 < numSlots; ++rd) {
         const int slot = tid + 256 * rd;
         int kind = PRIM_NONE, fr = 0;
         unsigned color = 0;
         float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
         if (slot < numSlots) {
             if (slot < nLayout) {
-                if (slot < hdr->num_boxes) {
-                    const LayoutBox b = gv.boxes[(size_t)env * MAX_BOXES + slot];
-                    if (b.type & VX_OPAQUE) {
-                        kind = PRIM_BOX;
-                        lo[0] = float(b.min[0]); lo[1] = float(b.min[1]); lo[2] = float(b.min[2]);
-                        hi[0] = float(b.max[0]); hi[1] = float(b.max[1]); hi[2] = float(b.max[2]);
-                        color = (unsigned)(b.slot == 0 ? hdr->layout_color : hdr->wall_color);
-                    }
+                const LayoutBox b = gboxes[slot];
+                if (b.type & VX_OPAQUE) {
+                    kind = PRIM_BOX;
+                    lo[0] = float(b.min[0]); lo[1] = float(b.min[1]); lo[2] = float(b.min[2]);
+                    hi[0] = float(b.max[0]); hi[1] = float(b.max[1]); hi[2] = float(b.max[2]);
+                    color = (unsigned)(b.slot == 0 ? hdr->layout_color : hdr->wall_color);
                 }
             } else if (slot < slotObjects) {
                 if (scen == SCN_TOWER) {   // building-zone slab (layout_utils.cpp:53-68)
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(GymView gv, uint32_t *ob
                     lo[0] = float(hdr->bz[0]); lo[1] = 1.0f; lo[2] = float(hdr->bz[2]);
                     hi[0] = float(hdr->bz[1]); hi[1] = 1.0f + 0.05f; hi[2] = float(hdr->bz[3]);
                     color = 0x555555u;
-                } else if (slot - slotTerrain < hdr->num_terrain) {   // exit pad / lava: 0.05-thick slab on the box's floor
+                } else {                   // exit pad / lava: 0.05-thick slab on the box's floor
                     const TerrainBox t = gv.terrain[(size_t)env * MAX_TERRAIN + (slot - slotTerrain)];
                     kind = PRIM_BOX;
                     lo[0] = float(t.min[0]); lo[1] = float(t.min[1]); lo[2] = float(t.min[2]);
@@ -368,59 +368,55 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(GymView gv, uint32_t *ob
                     color = t.type == TERRAIN_EXIT ? 0x50c878u : 0xff0000u;   // platforms.hpp:47-56
                 }
             } else if (slot < slotRewards) {
-                const int j = slot - slotObjects;
-                if (j < hdr->num_objects) {
-                    const MovableObject o = gv.objects[(size_t)env * MAX_OBJECTS + j];
-                    color = 0xadd8e6u;
-                    kind = PRIM_BOX;
-                    if (o.state == 0) {
-                        const float cx = float(o.x) + 0.5f, cy = float(o.y) + 0.5f, cz = float(o.z) + 0.5f;
-                        lo[0] = cx - OBJ_HALF; lo[1] = cy - OBJ_HALF; lo[2] = cz - OBJ_HALF;
-                        hi[0] = cx + OBJ_HALF; hi[1] = cy + OBJ_HALF; hi[2] = cz + OBJ_HALF;
-                    } else {
-                        fr = (int)o.state;
-                        const float hh = OBJ_HALF * CARRY_SCALE;
-                        const float cx = 0.0f, cy = -0.44f + -0.3f, cz = -1.0f;
-                        lo[0] = cx - hh; lo[1] = cy - hh; lo[2] = cz - hh;
-                        hi[0] = cx + hh; hi[1] = cy + hh; hi[2] = cz + hh;
-                    }
+                const MovableObject o = gv.objects[(size_t)env * MAX_OBJECTS + (slot - slotObjects)];
+                color = 0xadd8e6u;
+                kind = PRIM_BOX;
+                if (o.state <= 0) {
+                    const float cx = float(o.x) + 0.5f, cy = float(o.y) + 0.5f, cz = float(o.z) + 0.5f;
+                    lo[0] = cx - OBJ_HALF; lo[1] = cy - OBJ_HALF; lo[2] = cz - OBJ_HALF;
+                    hi[0] = cx + OBJ_HALF; hi[1] = cy + OBJ_HALF; hi[2] = cz + OBJ_HALF;
+                } else {
+                    fr = (int)o.state;
+                    const float hh = OBJ_HALF * CARRY_SCALE;
+                    const float cx = 0.0f, cy = -0.44f + -0.3f, cz = -1.0f;
+                    lo[0] = cx - hh; lo[1] = cy - hh; lo[2] = cz - hh;
+                    hi[0] = cx + hh; hi[1] = cy + hh; hi[2] = cz + hh;
                 }
-            } else if (slot < slotAgents) {   // diamonds (addDiamond, layout_utils.cpp:114-126; scenario_obstacles.cpp:254)
+            } else if (slot < slotAgents) {   // diamonds: addDiamond, layout_utils.cpp:114-126
                 const int j = (slot - slotRewards) >> 1, part = (slot - slotRewards) & 1;
-                if (j < hdr->num_rewards) {
-                    const MovableObject r = gv.rewards_obj[(size_t)env * MAX_REWARDS + j];
-                    if (r.state != 0) {
-                        const float sx = 0.17f * 0.8f, sy = 0.45f * 0.8f;
-                        const float cx = float(r.x) + 0.5f, cy = float(r.y) + 0.7f, cz = float(r.z) + 0.5f;
-                        kind = PRIM_CONE;
-                        color = 0x3bb372u;
-                        lo[0] = cx; lo[2] = cz;
-                        lo[1] = part == 0 ? cy + 0.5f * sy : cy - 1.5f * sy;
-                        hi[0] = sx; hi[1] = sy; hi[2] = part == 0 ? 1.0f : -1.0f;
-                    }
+                const MovableObject r = gv.rewards_obj[(size_t)env * gv.reward_stride + j];
+                if (r.state != 0) {
+                    // Obstacles (scenario_obstacles.cpp:254): scale (0.17, 0.45, 0.17) * 0.8 at y + 0.7, green;
+                    // Collect (scenario_collect.cpp:192,208): unscaled at y + 0.8, green (+1) or red (-1)
+                    const bool collect = scen == SCN_COLLECT;
+                    const float sx = collect ? 0.17f : 0.17f * 0.8f, sy = collect ? 0.45f : 0.45f * 0.8f;
+                    const float cx = float(r.x) + 0.5f, cy = float(r.y) + (collect ? 0.8f : 0.7f), cz = float(r.z) + 0.5f;
+                    kind = PRIM_CONE;
+                    color = r.state == 2 ? 0xff0000u : 0x3bb372u;
+                    lo[0] = cx; lo[2] = cz;
+                    lo[1] = part == 0 ? cy + 0.5f * sy : cy - 1.5f * sy;
+                    hi[0] = sx; hi[1] = sy; hi[2] = part == 0 ? 1.0f : -1.0f;
                 }
             } else {
                 const int q = slot - slotAgents;
                 const int k = q / 3, part = q - 3 * k;
-                if (k < A) {
-                    if (part == 0 && k != viewer) {
-                        const AgentState a = agents[k];
-                        kind = PRIM_CAPSULE;
-                        lo[0] = a.pos[0]; lo[1] = (a.pos[1] + 0.05f) + 0.09f; lo[2] = a.pos[2];
-                        hi[0] = 0.35f; hi[1] = 0.36f; hi[2] = 0.0f;
-                        color = AGENT_COLORS[k % 7];
-                    } else if (part == 1 && k != viewer) {
-                        kind = PRIM_BOX; fr = 1 + k;
-                        lo[0] = -0.25f; lo[1] = -0.12f; lo[2] = -0.19f - 0.2f;
-                        hi[0] = 0.25f; hi[1] = 0.12f; hi[2] = -0.19f + 0.2f;
-                        color = 0x2c3e50u;
-                    } else if (part == 2) {
-                        const float bw = hdr->bar_half_width;
-                        kind = PRIM_BOX; fr = 1 + k;
-                        lo[0] = -bw; lo[1] = -0.131f - 0.0015f; lo[2] = -0.2f - 0.001f;
-                        hi[0] = bw; hi[1] = -0.131f + 0.0015f; hi[2] = -0.2f + 0.001f;
-                        color = 0x2eb5d0u;
-                    }
+                if (part == 0 && k != viewer) {
+                    const AgentState a = agents[k];
+                    kind = PRIM_CAPSULE;
+                    lo[0] = a.pos[0]; lo[1] = (a.pos[1] + 0.05f) + 0.09f; lo[2] = a.pos[2];
+                    hi[0] = 0.35f; hi[1] = 0.36f; hi[2] = 0.0f;
+                    color = AGENT_COLORS[k % 7];
+                } else if (part == 1 && k != viewer) {
+                    kind = PRIM_BOX; fr = 1 + k;
+                    lo[0] = -0.25f; lo[1] = -0.12f; lo[2] = -0.19f - 0.2f;
+                    hi[0] = 0.25f; hi[1] = 0.12f; hi[2] = -0.19f + 0.2f;
+                    color = 0x2c3e50u;
+                } else if (part == 2) {
+                    const float bw = hdr->bar_half_width;
+                    kind = PRIM_BOX; fr = 1 + k;
+                    lo[0] = -bw; lo[1] = -0.131f - 0.0015f; lo[2] = -0.2f - 0.001f;
+                    hi[0] = bw; hi[1] = -0.131f + 0.0015f; hi[2] = -0.2f + 0.001f;
+                    color = 0x2eb5d0u;
                 }
             }
         }
@@ -444,65 +440,57 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(GymView gv, uint32_t *ob
             // capsule or a diamond at the lens) are rare: give them the whole screen instead of plane tests
             if (cls == 2 && (fr != 0 || kind != PRIM_BOX)) { cls = 1; rect[0] = 0; rect[1] = W - 1; rect[2] = 0; rect[3] = H - 1; }
         }
-        kindR[rd] = kind; frR[rd] = fr; clsR[rd] = cls; colorR[rd] = color;
+        const unsigned long long mS = __ballot(cls == 2), mR = __ballot(cls == 1);
+        int *cnt = s_cnt + (rd & 1) * 8;   // double-buffered: one barrier per round
+        if (lane == 0) { cnt[wave] = __popcll(mS); cnt[4 + wave] = __popcll(mR); }
+        __syncthreads();
+        int posS = nStrad, posR = nRect, totS = 0, totR = 0;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { loR[rd][c] = lo[c]; hiR[rd][c] = hi[c]; }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) rectR[rd][c] = rect[c];
-    }
-
-    // ---- order-free compaction (depth ties are resolved on the slot id): straddlers first, then the rest
-    unsigned long long mSR[2], mRR[2];
-#pragma unroll
-    for (int rd = 0; rd < 2; ++rd) {
-        mSR[rd] = __ballot(clsR[rd] == 2);
-        mRR[rd] = __ballot(clsR[rd] == 1);
-        if (lane == 0) { s_cnt[rd * 4 + wave] = __popcll(mSR[rd]); s_cnt[8 + rd * 4 + wave] = __popcll(mRR[rd]); }
-    }
-    __syncthreads();
-    int nStrad = 0, nRect = 0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { nStrad += s_cnt[q]; nRect += s_cnt[8 + q]; }
-    const int extraStrad = nStrad > MAX_STRADDLERS ? nStrad - MAX_STRADDLERS : 0;   // overflow: whole-screen rectangles
-    nStrad -= extraStrad;
-    const int nVis = min(nStrad + nRect + extraStrad, (int)MAX_VIS);
-#pragma unroll
-    for (int rd = 0; rd < 2; ++rd) {
-        if (clsR[rd] == 0) continue;
-        const unsigned long long below = (1ull << lane) - 1ull;
-        int baseS = 0, baseR = 0;
-        for (int q = 0; q < rd * 4 + wave; ++q) { baseS += s_cnt[q]; baseR += s_cnt[8 + q]; }
-        int pos;
-        int rect[4] = {rectR[rd][0], rectR[rd][1], rectR[rd][2], rectR[rd][3]};
-        if (clsR[rd] == 2) {
-            pos = baseS + __popcll(mSR[rd] & below);
-            if (pos >= MAX_STRADDLERS) { pos = nStrad + nRect + (pos - MAX_STRADDLERS); rect[0] = 0; rect[1] = W - 1; rect[2] = 0; rect[3] = H - 1; }
-        } else pos = nStrad + baseR + __popcll(mRR[rd] & below);
-        if (pos >= MAX_VIS) continue;   // cannot happen with <= 280 slots unless nearly everything is in view at once
-        const int kind = kindR[rd], fr = frR[rd];
-        const unsigned color = colorR[rd];
-        Prim p;
-        p.meta = kind | (fr << 8);
-        p.slot = tid + 256 * rd;
-        if (kind == PRIM_BOX) {   // bounds relative to the ray origin of the primitive's frame
-            V3 o = v3(0.0f, 0.0f, 0.0f);
-            if (fr == 0) o = v3(s_cam[viewer].eye[0], s_cam[viewer].eye[1], s_cam[viewer].eye[2]);
-            else if (fr != 1 + viewer) o = v3(s_cam[fr - 1].origin[0], s_cam[fr - 1].origin[1], s_cam[fr - 1].origin[2]);
-            p.lo[0] = loR[rd][0] - o.x; p.lo[1] = loR[rd][1] - o.y; p.lo[2] = loR[rd][2] - o.z;
-            p.hi[0] = hiR[rd][0] - o.x; p.hi[1] = hiR[rd][1] - o.y; p.hi[2] = hiR[rd][2] - o.z;
-        } else {
-            p.lo[0] = loR[rd][0]; p.lo[1] = loR[rd][1]; p.lo[2] = loR[rd][2];
-            p.hi[0] = hiR[rd][0]; p.hi[1] = hiR[rd][1]; p.hi[2] = hiR[rd][2];
+        for (int q = 0; q < 4; ++q) {
+            if (q < wave) { posS += cnt[q]; posR += cnt[4 + q]; }
+            totS += cnt[q]; totR += cnt[4 + q];
         }
-        const float AMB = float(0x55) / 255.0f, DIF = float(0xbb) / 255.0f, LCOL = float(0xaa) / 255.0f;
-        const float col[3] = {float((color >> 16) & 255) / 255.0f, float((color >> 8) & 255) / 255.0f, float(color & 255) / 255.0f};
+        nStrad += totS; nRect += totR;
+        if (cls != 0) {
+            const unsigned long long below = (1ull << lane) - 1ull;
+            int pos;
+            if (cls == 2) {
+                pos = posS + __popcll(mS & below);
+                if (pos >= MAX_STRADDLERS) {   // overflow: a whole-screen rectangle, parked behind everything else
+                    pos = MAXVIS - 1 - (pos - MAX_STRADDLERS);
+                    rect[0] = 0; rect[1] = W - 1; rect[2] = 0; rect[3] = H - 1;
+                }
+            } else pos = MAX_STRADDLERS + posR + __popcll(mR & below);
+            if (pos < MAXVIS) {   // more than MAXVIS visible primitives: the excess is dropped (never seen in practice)
+                Prim p;
+                p.meta = kind | (fr << 8);
+                p.slot = slot;
+                if (kind == PRIM_BOX) {   // bounds relative to the ray origin of the primitive's frame
+                    V3 o = v3(0.0f, 0.0f, 0.0f);
+                    if (fr == 0) o = v3(s_cam[viewer].eye[0], s_cam[viewer].eye[1], s_cam[viewer].eye[2]);
+                    else if (fr != 1 + viewer) o = v3(s_cam[fr - 1].origin[0], s_cam[fr - 1].origin[1], s_cam[fr - 1].origin[2]);
+                    p.lo[0] = lo[0] - o.x; p.lo[1] = lo[1] - o.y; p.lo[2] = lo[2] - o.z;
+                    p.hi[0] = hi[0] - o.x; p.hi[1] = hi[1] - o.y; p.hi[2] = hi[2] - o.z;
+                } else {
+                    p.lo[0] = lo[0]; p.lo[1] = lo[1]; p.lo[2] = lo[2];
+                    p.hi[0] = hi[0]; p.hi[1] = hi[1]; p.hi[2] = hi[2];
+                }
+                const float AMB = float(0x55) / 255.0f, DIF = float(0xbb) / 255.0f, LCOL = float(0xaa) / 255.0f;
+                const float col[3] = {float((color >> 16) & 255) / 255.0f, float((color >> 8) & 255) / 255.0f, float(color & 255) / 255.0f};
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { p.k1[c] = AMB * col[c]; p.k2[c] = (DIF * col[c]) * LCOL; }
-        p.pad0 = p.pad1 = 0.0f;
-        s_vis[pos] = p;
-        s_rect[pos] = make_short4((short)rect[0], (short)rect[1], (short)rect[2], (short)rect[3]);
+                for (int c = 0; c < 3; ++c) { p.k1[c] = AMB * col[c]; p.k2[c] = (DIF * col[c]) * LCOL; }
+                p.pad0 = p.pad1 = 0.0f;
+                s_vis[pos] = p;
+                s_rect[pos] = make_short4((short)rect[0], (short)rect[1], (short)rect[2], (short)rect[3]);
+            }
+        }
     }
     __syncthreads();
+    // list layout: [0, nStradKept) straddlers | [MAX_STRADDLERS, rectEnd) rectangles | [xsBegin, MAXVIS) straddler overflow
+    const int nStradKept = min(nStrad, (int)MAX_STRADDLERS);
+    const int xsBegin = MAXVIS - max(nStrad - MAX_STRADDLERS, 0);
+    const int rectEnd = min(MAX_STRADDLERS + nRect, xsBegin);
+    const int scanEnd = xsBegin < MAXVIS ? MAXVIS : rectEnd;   // tile culling scans positions [MAX_STRADDLERS, scanEnd)
 
     const CamL &cam = s_cam[viewer];
     const V3 eye = v3(cam.eye[0], cam.eye[1], cam.eye[2]);
@@ -517,7 +505,7 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(GymView gv, uint32_t *ob
     // this lane's (frustum plane, straddler) pair: plane-major so that one AND of five 12-bit groups
     // of the ballot gives the straddlers that survive all five planes
     const int sPlane = lane / MAX_STRADDLERS, sIdx = lane - MAX_STRADDLERS * sPlane;
-    const bool sActive = sPlane < 5 && sIdx < nStrad;
+    const bool sActive = sPlane < 5 && sIdx < nStradKept;
     const float nzm[3] = {-cam.c[2], -cam.c[5], -cam.c[8]};   // c_k2 * (-1)
 
     for (int tile = part * 4 + wave; tile < numTiles; tile += 4 * split) {
@@ -526,13 +514,14 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(GymView gv, uint32_t *ob
         const int tx1 = min(tx0 + TILE_W, W) - 1, ty1 = min(ty0 + TILE_H, H) - 1;
 
         // ---- tile culling.  (a) rectangle-bounded primitives: one per lane per round of 64, 4 integer compares
-        unsigned long long mk[4] = {0ull, 0ull, 0ull, 0ull};
+        unsigned long long mk[ROUNDS];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (k * 64 < nVis) {   // wave-uniform
+        for (int k = 0; k < ROUNDS; ++k) {
+            mk[k] = 0ull;
+            if (k * 64 < scanEnd) {   // wave-uniform
                 const int pos = lane + 64 * k;
                 bool v = false;
-                if (pos >= nStrad && pos < nVis) {
+                if (pos >= MAX_STRADDLERS && (pos < rectEnd || (pos >= xsBegin && pos < MAXVIS))) {
                     const short4 r = s_rect[pos];
                     v = r.x <= tx1 && r.y >= tx0 && r.z <= ty1 && r.w >= ty0;
                 }
@@ -564,12 +553,15 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(GymView gv, uint32_t *ob
             atomicAdd(&g_raster_stats[0], 1ull);
             atomicAdd(&g_raster_stats[1], (unsigned long long)(__popcll(mk[0]) + __popcll(mk[1]) + __popcll(mk[2]) + __popcll(mk[3])));
             atomicAdd(&g_raster_stats[2], (unsigned long long)__popcll(g));
-            if (tile == 0) { atomicAdd(&g_raster_stats[3], (unsigned long long)nVis); atomicAdd(&g_raster_stats[4], 1ull); atomicAdd(&g_raster_stats[5], (unsigned long long)nStrad); }
+            if (tile == 0) { atomicAdd(&g_raster_stats[3], (unsigned long long)(nStrad + nRect)); atomicAdd(&g_raster_stats[4], 1ull); atomicAdd(&g_raster_stats[5], (unsigned long long)nStrad); }
         }
 #endif
         // ---- this lane's pixel and ray
         const int px = tx0 + (lane & (TILE_W - 1)), py = ty0 + (lane / TILE_W);
-        if ((mk[0] | mk[1] | mk[2] | mk[3]) == 0ull) {   // nothing can be seen through this tile: clear colour (0,0,0), alpha 255
+        unsigned long long anyMask = 0ull;
+#pragma unroll
+        for (int k = 0; k < ROUNDS; ++k) anyMask |= mk[k];
+        if (anyMask == 0ull) {   // nothing can be seen through this tile: clear colour (0,0,0), alpha 255
             if (px < W && py < H) out[(size_t)py * W + px] = 0xff000000u;
             continue;
         }
@@ -585,7 +577,7 @@ __global__ __launch_bounds__(256, 4) void raster_kernel(GymView gv, uint32_t *ob
         V3 capN = v3(0, 0, 0);   // normal of the best capsule hit (boxes recompute theirs from the entry axis)
 
 #pragma unroll
-        for (int half = 0; half < 4; ++half) {
+        for (int half = 0; half < ROUNDS; ++half) {
             unsigned long long m = mk[half];
             while (m) {
                 const int bit = __ffsll((long long)m) - 1;
@@ -691,7 +683,9 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
     const int tiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H);
     int split = envSplit > 0 ? envSplit : 4;
     while (split > 1 && tiles < 4 * split * 2) split >>= 1;   // keep at least two tiles per wave
-    hipLaunchKernelGGL(raster_kernel, dim3(gv.num_envs * gv.num_agents * split), dim3(256), dyn, stream, gv, obs, W, H, split);
+    const dim3 grid(gv.num_envs * gv.num_agents * split), block(256);
+    if (gv.box_stride > VIS_SMALL) hipLaunchKernelGGL(raster_kernel<VIS_LARGE>, grid, block, dyn, stream, gv, obs, W, H, split);
+    else hipLaunchKernelGGL(raster_kernel<VIS_SMALL>, grid, block, dyn, stream, gv, obs, W, H, split);
     return 0;
 }
 

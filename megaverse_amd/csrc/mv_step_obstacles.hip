@@ -16,6 +16,7 @@
 // lists with ballots instead of a dense chunk; column occupancy for drops and teleports is a 128-bit wave OR.
 #include <hip/hip_runtime.h>
 
+#include "mv_boxlist.h"
 #include "mv_math.h"
 #include "mv_physics.h"
 #include "mv_types.h"
@@ -25,39 +26,6 @@ namespace mv {
 namespace {
 
 constexpr int NC = 4;
-constexpr int OBJ_BASE = 128, AG_BASE = 208;   // collider slot ranges: [0,128) slabs, [128,208) boxes, [208,216) agents
-
-struct Objs {          // lane l owns movable box l (k = 0) and, for l < 16, box 64 + l (k = 1)
-    int x[2], y[2], z[2], state[2];
-    bool valid[2];
-};
-
-struct Bits128 {       // bit (y + 32) for y in [-32, 95]
-    unsigned long long lo, hi;
-};
-__device__ __forceinline__ void set_range(Bits128 &b, int y0, int y1)   // [y0, y1)
-{
-    for (int y = max(y0, -32); y < min(y1, 96); ++y) {
-        const int i = y + 32;
-        if (i < 64) b.lo |= 1ull << i; else b.hi |= 1ull << (i - 64);
-    }
-}
-__device__ __forceinline__ bool test(const Bits128 &b, int y)
-{
-    const int i = y + 32;
-    if (i < 0 || i >= 128) return false;
-    return i < 64 ? ((b.lo >> i) & 1ull) : ((b.hi >> (i - 64)) & 1ull);
-}
-__device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long m)
-{
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)m, off, 64);
-        const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(m >> 32), off, 64);
-        m |= ((unsigned long long)hi << 32) | lo;
-    }
-    return m;
-}
 
 struct BoxI {
     int min[3], max[3], type;
@@ -79,50 +47,6 @@ __device__ __forceinline__ Bits128 column_solid(const BoxI (&lb)[2], int x, int 
     m.lo = wave_or_u64(m.lo); m.hi = wave_or_u64(m.hi);
     return m;
 }
-// placed movable boxes of column (x, z)
-__device__ __forceinline__ Bits128 column_objects(const Objs &o, int x, int z)
-{
-    Bits128 m{0ull, 0ull};
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-        if (o.valid[k] && o.state[k] == 0 && o.x[k] == x && o.z[k] == z) set_range(m, o.y[k], o.y[k] + 1);
-    m.lo = wave_or_u64(m.lo); m.hi = wave_or_u64(m.hi);
-    return m;
-}
-
-__device__ __forceinline__ int object_at(const Objs &o, int x, int y, int z)
-{
-    const bool h0 = o.valid[0] && o.state[0] == 0 && o.x[0] == x && o.y[0] == y && o.z[0] == z;
-    const bool h1 = o.valid[1] && o.state[1] == 0 && o.x[1] == x && o.y[1] == y && o.z[1] == z;
-    const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
-    if (m0) return __ffsll((long long)m0) - 1;
-    if (m1) return 64 + (__ffsll((long long)m1) - 1);
-    return -1;
-}
-
-template <int A_MAX>
-__device__ __forceinline__ void reward_agent(AgentState (&ag)[A_MAX], int key, int idx, float mult)
-{
-#pragma unroll
-    for (int i = 0; i < A_MAX; ++i)
-        if (i == idx) ag[i].last_reward += ag[i].shaping[key] * mult;
-}
-template <int A_MAX>
-__device__ __forceinline__ void reward_team(AgentState (&ag)[A_MAX], int A, int key, int idx, float mult)
-{
-#pragma unroll
-    for (int i = 0; i < A_MAX; ++i)
-        if (i == idx) ag[i].last_reward += ag[i].shaping[key] * (mult * (1 - ag[i].shaping[0]));
-#pragma unroll
-    for (int i = 0; i < A_MAX; ++i)
-        if (i < A) ag[i].last_reward += ag[i].shaping[key] * ag[i].shaping[0] * mult / float(A);
-}
-
-__device__ __forceinline__ void voxel_of(V3 p, int out[3])
-{
-    out[0] = (int)floorf(p.x); out[1] = (int)floorf(p.y); out[2] = (int)floorf(p.z);
-}
-
 }  // namespace
 
 template <int A_MAX>

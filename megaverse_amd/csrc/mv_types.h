@@ -14,9 +14,11 @@ enum : int {
     TOWER_BOXES = 16,         // collider / primitive slots the TowerBuilding kernels reserve for them
     MAX_OBJECTS = 80, MAX_AGENTS = 8, MAX_TERRAIN = 16, MAX_REWARDS = 16,
     NUM_SHAPING = 8,
+    // Collect: Perlin heightfield up to 42 x 42 columns (scenario_collect.cpp:63); its merged slabs are many
+    COLLECT_MAX_BOXES = 1024, COLLECT_MAX_REWARDS = 96, HM_DIM = 42, HM_BYTES = 1792,
 };
 
-enum : int { SCN_TOWER = 0, SCN_OBSTACLES = 1 };
+enum : int { SCN_TOWER = 0, SCN_OBSTACLES = 1, SCN_COLLECT = 2 };
 enum : int { TERRAIN_EXIT = 1, TERRAIN_LAVA = 2, TERRAIN_BUILDING_ZONE = 4 };   // scenarios/platforms.hpp:28-34
 
 // voxel cell byte (reference: env/include/env/voxel_state.hpp:10-37, scenarios/platforms.hpp:28-34)
@@ -39,7 +41,8 @@ struct alignas(16) EnvHeader {   // 128 B
     uint32_t next_seed;                 // value the next Env::reset() re-seeds with (env.cpp:61-62)
     int32_t seed_is_env_seed;           // 1: next_seed is the Env::seed() value, reset must draw first
     float p_episode_len_sec, p_vertical_look_limit;   // float params (scenario.hpp:225-232)
-    int32_t scenario, num_terrain, num_rewards, num_platforms, solved;   // Obstacles family
+    int32_t scenario, num_terrain, num_rewards, num_platforms, solved;   // Obstacles family; Collect: num_platforms = number of +1
+                                                                          // diamonds, highest_tower = how many of them were collected
     int32_t episodes_consumed;          // how many host-generated episodes this env has taken (refill protocol)
     int32_t starved;                    // set if a reset found no fresh episode (must never happen)
     int32_t pad[2];
@@ -53,7 +56,8 @@ struct alignas(16) LayoutBox {   // 32 B, merged layout parallelepiped (voxel un
 
 struct alignas(4) MovableObject {   // 4 B
     int8_t x, y, z;
-    int8_t state;   // 0 placed at (x,y,z); 1+k carried by agent k.  Reward objects: 1 = still there
+    int8_t state;   // 0 placed at (x,y,z); 1+k carried by agent k; -1 placed, but its grid cell was erased (Collect).
+                    // Reward objects: 0 collected, 1 still there (Collect: 1 = +1 diamond, 2 = -1 diamond)
 };
 
 struct alignas(16) TerrainBox {   // 32 B, voxel units, max exclusive (platforms.hpp terrainBoxes)
@@ -77,13 +81,15 @@ static_assert(sizeof(AgentState) == 128, "AgentState must be 128 B");
 // Everything a kernel needs, passed by value.
 struct GymView {
     int32_t num_envs, num_agents;
+    int32_t box_stride, reward_stride;   // MAX_BOXES / MAX_REWARDS, or the COLLECT_ sizes
     EnvHeader *hdr;            // [N]
-    LayoutBox *boxes;          // [N][MAX_BOXES]
+    LayoutBox *boxes;          // [N][box_stride]
     MovableObject *objects;    // [N][MAX_OBJECTS]
     AgentState *agents;        // [N][A]
     uint8_t *chunk;            // [N][CHUNK_BYTES]   (TowerBuilding)
     TerrainBox *terrain;       // [N][MAX_TERRAIN]   (Obstacles)
-    MovableObject *rewards_obj;// [N][MAX_REWARDS]   (Obstacles: green diamonds)
+    MovableObject *rewards_obj;// [N][reward_stride] (Obstacles: green diamonds; Collect: green/red diamonds)
+    int8_t *heightmap;         // [N][HM_BYTES]      (Collect: top solid y of column x * HM_DIM + z, -1 = no voxels)
     int32_t *actions;          // [N][A] bitmasks
     float *rewards;            // [N*A] as reported by get_last_rewards (0 on done steps)
     uint8_t *done;             // [N]
@@ -104,6 +110,22 @@ struct alignas(16) EpisodeBlob {
     TerrainBox terrain[MAX_TERRAIN];
     MovableObject objects[MAX_OBJECTS];
     MovableObject rewards[MAX_REWARDS];
+};
+
+// Collect episode.  `boxes` comes last so that only the used prefix needs to travel.
+struct alignas(16) CollectBlob {
+    int32_t seq;
+    int32_t num_boxes, num_objects, num_rewards, num_positive;
+    int32_t layout_color, wall_color;
+    int32_t dim[3];
+    float episode_len;
+    int32_t pad;
+    int32_t spawn[MAX_AGENTS][3];
+    float yaw_frand[MAX_AGENTS];
+    MovableObject objects[MAX_OBJECTS];
+    MovableObject rewards[COLLECT_MAX_REWARDS];
+    int8_t heightmap[HM_BYTES];
+    LayoutBox boxes[COLLECT_MAX_BOXES];
 };
 
 }  // namespace mv

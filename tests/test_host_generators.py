@@ -1,0 +1,114 @@
+"""CPU parity of the product's HOST-side episode generators (mv_gen_obstacles.cpp, mv_gen_collect.cpp, reached through the
+C ABI test hook mv_debug_generate_episode -- no GPU involved) against the oracle's Env::reset restatement: same
+master seed -> same per-env seeds -> byte-identical layout slabs, terrain, movable boxes, diamonds, spawn cells,
+spawn rotations and episode length, over several consecutive episodes of the same env stream."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from megaverse_amd import extension as ext
+
+MAX_AGENTS, MAX_OBJECTS = 8, 80
+LAYOUT_BOX = np.dtype([("min", "<i4", 3), ("type", "<i4"), ("max", "<i4", 3), ("slot", "<i4")])
+TERRAIN_BOX = np.dtype([("min", "<i4", 3), ("type", "<i4"), ("max", "<i4", 3), ("pad", "<i4")])
+OBJ = np.dtype([("x", "i1"), ("y", "i1"), ("z", "i1"), ("state", "i1")])
+EPISODE_BLOB = np.dtype([
+    ("seq", "<i4"), ("num_boxes", "<i4"), ("num_terrain", "<i4"), ("num_objects", "<i4"), ("num_rewards", "<i4"),
+    ("num_platforms", "<i4"), ("layout_color", "<i4"), ("wall_color", "<i4"), ("draw_walls", "<i4"), ("dim", "<i4", 3),
+    ("org", "<i4", 3), ("episode_len", "<f4"), ("spawn", "<i4", (MAX_AGENTS, 3)), ("yaw_frand", "<f4", MAX_AGENTS),
+    ("boxes", LAYOUT_BOX, 128), ("terrain", TERRAIN_BOX, 16), ("objects", OBJ, MAX_OBJECTS), ("rewards", OBJ, 16),
+], align=False)
+COLLECT_BLOB = np.dtype([
+    ("seq", "<i4"), ("num_boxes", "<i4"), ("num_objects", "<i4"), ("num_rewards", "<i4"), ("num_positive", "<i4"),
+    ("layout_color", "<i4"), ("wall_color", "<i4"), ("dim", "<i4", 3), ("episode_len", "<f4"), ("pad", "<i4"),
+    ("spawn", "<i4", (MAX_AGENTS, 3)), ("yaw_frand", "<f4", MAX_AGENTS), ("objects", OBJ, MAX_OBJECTS),
+    ("rewards", OBJ, 96), ("heightmap", "i1", 1792), ("boxes", LAYOUT_BOX, 1024),
+], align=False)
+
+
+def generate(scenario, agents, env_seed, n, base_len=60.0):
+    lib = ext.load_library()
+    size = lib.mv_debug_generate_episode(scenario.encode(), agents, env_seed, n, base_len, None, 0)
+    dt = COLLECT_BLOB if scenario.lower() == "collect" else EPISODE_BLOB
+    assert size == dt.itemsize, (size, dt.itemsize)
+    buf = np.zeros(1, dt)
+    assert lib.mv_debug_generate_episode(scenario.encode(), agents, env_seed, n, base_len, buf.ctypes.data, size) == size
+    return buf[0]
+
+
+def env_seeds(master, n):
+    lo, hi = np.zeros(n, np.int32), np.full(n, 1 << 30, np.int32)
+    out = np.empty(n, np.int32)
+    oracle_lib.lib().mvo_rand_range_seq(master, lo.ctypes.data, hi.ctypes.data, n, out.ctypes.data)
+    return out
+
+
+def check_common(blob, snap, agents):
+    nb = int(snap["num_boxes"])
+    assert int(blob["num_boxes"]) == nb
+    b = blob["boxes"][:nb]
+    got = np.concatenate([b["min"], b["max"], b["type"][:, None], b["slot"][:, None]], axis=1)
+    assert np.array_equal(got, snap["boxes"][:nb])
+    no = int(snap["num_objects"])
+    assert int(blob["num_objects"]) == no
+    o = blob["objects"][:no]
+    assert np.array_equal(np.stack([o["x"], o["y"], o["z"], o["state"]], 1), snap["objects"][:no])
+    nr = int(snap["num_rewards"])
+    assert int(blob["num_rewards"]) == nr
+    r = blob["rewards"][:nr]
+    assert np.array_equal(np.stack([r["x"], r["y"], r["z"], r["state"]], 1), snap["rewards"][:nr])
+    assert np.float32(blob["episode_len"]).tobytes() == np.float32(snap["episode_len"]).tobytes()
+    assert int(blob["layout_color"]) == int(snap["layout_color"]) and int(blob["wall_color"]) == int(snap["wall_color"])
+    for k in range(agents):
+        a = snap["agents"][k]
+        assert np.array_equal(blob["spawn"][k], a["spawn"])
+        # spawn rotation: yaw = frand * pi * 2 (scenario_default.hpp:87).  The bit-exact basis is checked on the GPU
+        # (test_*_parity_gpu.py); here: the same draw, up to the rounding of the device's rotation-matrix helper
+        ang = float(np.float32(np.float32(blob["yaw_frand"][k]) * np.float32(3.14159274)) * np.float32(2))
+        assert abs(np.cos(ang) - float(a["basis"][0])) < 2e-6 and abs(np.sin(ang) - float(a["basis"][1])) < 2e-6
+
+
+@pytest.mark.parametrize("scenario", ["ObstaclesEasy", "ObstaclesMedium", "ObstaclesHard", "ObstaclesWalls", "ObstaclesSteps", "ObstaclesLava"])
+@pytest.mark.parametrize("agents", [1, 4])
+def test_obstacles_generator_matches_oracle(scenario, agents):
+    n_env, master = 12, 100 + agents
+    og = oracle_lib.OracleGym(scenario, 32, 32, n_env, agents, 2)
+    og.seed(master)
+    seeds = env_seeds(master, n_env)
+    for episode in (1, 2, 3):
+        og.reset()
+        for e in range(n_env):
+            blob, snap = generate(scenario, agents, int(seeds[e]), episode), og.snapshot(e)
+            check_common(blob, snap, agents)
+            nt = int(snap["num_terrain"])
+            assert int(blob["num_terrain"]) == nt and int(blob["num_platforms"]) == int(snap["num_platforms"])
+            t = blob["terrain"][:nt]
+            assert np.array_equal(np.concatenate([t["min"], t["max"], t["type"][:, None]], 1), snap["terrain"][:nt, :7])
+            assert int(blob["draw_walls"]) == int(snap["draw_walls"])
+    og.close()
+
+
+@pytest.mark.parametrize("agents", [1, 3, 8])
+def test_collect_generator_matches_oracle(agents):
+    n_env, master = 40, 7 + agents
+    og = oracle_lib.OracleGym("Collect", 32, 32, n_env, agents, 2)
+    og.seed(master)
+    seeds = env_seeds(master, n_env)
+    for episode in (1, 2):
+        og.reset()
+        for e in range(n_env):
+            blob, snap = generate("Collect", agents, int(seeds[e]), episode), og.snapshot(e)
+            check_common(blob, snap, agents)
+            assert np.array_equal(blob["heightmap"][:42 * 42], snap["heightmap"])
+            assert int(blob["num_positive"]) == int(snap["num_platforms"])
+            assert [int(v) for v in blob["dim"]] == [int(snap["L"]), int(snap["H"]), int(snap["W"])]
+    og.close()
+
+
+def test_episode_length_param_is_honoured():
+    b = generate("Collect", 1, 5, 1, base_len=10.0)
+    assert float(b["episode_len"]) == 10.0 + 2.0 * int(b["num_rewards"])
+    b = generate("ObstaclesEasy", 1, 5, 1, base_len=500.0)
+    assert float(b["episode_len"]) == 500.0
