@@ -43,9 +43,11 @@ constexpr float TAN_HALF_FOV_Y = 1.19175359f / (128.0f / 72.0f);  // aspect 128/
 constexpr float NEAR_Z = 0.01f, FAR_Z = 120.0f;
 constexpr float OBJ_HALF = 0.39f, CARRY_SCALE = 0.78f;
 constexpr int TILE_W = 16, TILE_H = 4;
+#ifndef MV_RASTER_WAVES
+#define MV_RASTER_WAVES 6   // waves per SIMD the small variant is compiled for (register budget 512 / n)
+#endif
 constexpr int VIS_SMALL = 256, VIS_LARGE = 1024;   // visible primitives kept per frame (TowerBuilding <= 121 slots, Obstacles <= 280; Collect up to ~1300)
-constexpr int MAX_STRADDLERS = 12;    // x 5 frustum planes = 60 lanes of one wave
-constexpr float STRADDLE_W = 0.05f;   // closer than this to the camera plane: projection unusable
+constexpr float CLIP_W = 0.005f;       // NEAR_Z / 2: boxes are clipped against this depth before projecting
 constexpr int MAX_W = 1024, MAX_H = 1024;
 
 __constant__ unsigned AGENT_COLORS[7] = {0xffdd3c, 0x3bb372, 0x2eb5d0, 0xffb400, 0xd468ee, 0x222222, 0xff0000};
@@ -208,23 +210,17 @@ __device__ __forceinline__ V3 safe_inv(V3 d)
     return v3(d.x == 0.0f ? 0.0f : 1.0f / d.x, d.y == 0.0f ? 0.0f : 1.0f / d.y, d.z == 0.0f ? 0.0f : 1.0f / d.z);
 }
 
-// max over the box corners of n . corner   (bounds relative to the plane's anchor point)
-__device__ __forceinline__ float support(V3 n, const float *lo, const float *hi)
-{
-    const float ax = fmaxf(n.x * lo[0], n.x * hi[0]);
-    const float ay = fmaxf(n.y * lo[1], n.y * hi[1]);
-    const float az = fmaxf(n.z * lo[2], n.z * hi[2]);
-    return ax + ay + az;
-}
-
-// Conservative screen rectangle from the 8 projected corners of the primitive's bounding box.
-//   0: behind the camera,  1: rectangle valid,  2: straddler (a corner is closer than STRADDLE_W to
-//   the camera plane, so the projection is unbounded -> per-tile plane tests instead).
+// Conservative screen rectangle of a box: the projection of its part in front of the plane w = CLIP_W (camera
+// depth; nothing nearer than NEAR_Z = 2 CLIP_W can be hit).  Fully in front: the 8 projected corners.  Crossing
+// the plane (the floor under the viewer, a wall beside it): the corners in front plus the points where the 12
+// edges pierce the plane -- the convex hull of those is the clipped box, so its projection is bounded by theirs.
+//   returns 0: nothing in front of the plane, 1: rect valid (pixels, one pixel of slack on every side)
 __device__ __forceinline__ int screen_rect(const float *blo, const float *bhi, int fr, const CamL *cams, int viewer, int W, int H,
                                            int rect[4])
 {
     const CamL &cv = cams[viewer];
-    float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY, wmin = INFINITY, wmax = -INFINITY;
+    float cx[8], cy[8], cw[8];
+    float wmin = INFINITY, wmax = -INFINITY;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         V3 v = v3((c & 1) ? bhi[0] : blo[0], (c & 2) ? bhi[1] : blo[1], (c & 4) ? bhi[2] : blo[2]);
@@ -234,15 +230,36 @@ __device__ __forceinline__ int screen_rect(const float *blo, const float *bhi, i
             const V3 wpos = mat_mul(ck.c, v) + v3(ck.eye[0], ck.eye[1], ck.eye[2]);
             v = mat_tmul(cv.c, wpos - v3(cv.eye[0], cv.eye[1], cv.eye[2]));
         }
-        const float w = -v.z;
-        wmin = fminf(wmin, w); wmax = fmaxf(wmax, w);
-        const float iw = 1.0f / fmaxf(w, STRADDLE_W);
-        const float xn = v.x * iw * (1.0f / TAN_HALF_FOV), yn = v.y * iw * (1.0f / TAN_HALF_FOV_Y);
-        xmin = fminf(xmin, xn); xmax = fmaxf(xmax, xn); ymin = fminf(ymin, yn); ymax = fmaxf(ymax, yn);
+        cx[c] = v.x; cy[c] = v.y; cw[c] = -v.z;
+        wmin = fminf(wmin, cw[c]); wmax = fmaxf(wmax, cw[c]);
     }
-    if (wmax < NEAR_Z * 0.5f) return 0;
-    if (wmin < STRADDLE_W) return 2;
-    // pixel i is covered when its centre (i + 0.5) lies inside; one pixel of slack on every side
+    if (wmax < CLIP_W) return 0;
+    float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        if (cw[c] >= CLIP_W) {
+            const float iw = 1.0f / cw[c];
+            const float xn = cx[c] * iw, yn = cy[c] * iw;
+            xmin = fminf(xmin, xn); xmax = fmaxf(xmax, xn); ymin = fminf(ymin, yn); ymax = fmaxf(ymax, yn);
+        }
+    if (wmin < CLIP_W) {
+#pragma unroll
+        for (int axis = 0; axis < 3; ++axis)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int d = c | (1 << axis);
+                if (d == c) continue;
+                if ((cw[c] >= CLIP_W) != (cw[d] >= CLIP_W)) {
+                    const float t = (CLIP_W - cw[c]) / (cw[d] - cw[c]);
+                    const float xn = (cx[c] + t * (cx[d] - cx[c])) * (1.0f / CLIP_W), yn = (cy[c] + t * (cy[d] - cy[c])) * (1.0f / CLIP_W);
+                    xmin = fminf(xmin, xn); xmax = fmaxf(xmax, xn); ymin = fminf(ymin, yn); ymax = fmaxf(ymax, yn);
+                }
+            }
+    }
+    xmin *= 1.0f / TAN_HALF_FOV; xmax *= 1.0f / TAN_HALF_FOV; ymin *= 1.0f / TAN_HALF_FOV_Y; ymax *= 1.0f / TAN_HALF_FOV_Y;
+    // pixel i is covered when its centre (i + 0.5) lies inside; one pixel of slack on every side (clamped first: a
+    // point just in front of the plane projects to 1e3 .. 1e6 screen widths)
+    xmin = fmaxf(xmin, -4.0f); xmax = fminf(xmax, 4.0f); ymin = fmaxf(ymin, -4.0f); ymax = fminf(ymax, 4.0f);
     const float fx0 = (xmin * 0.5f + 0.5f) * float(W) - 1.5f, fx1 = (xmax * 0.5f + 0.5f) * float(W) + 0.5f;
     const float fy0 = (ymin * 0.5f + 0.5f) * float(H) - 1.5f, fy1 = (ymax * 0.5f + 0.5f) * float(H) + 0.5f;
     if (fx1 < 0.0f || fy1 < 0.0f || fx0 > float(W) || fy0 > float(H)) return 0;
@@ -259,21 +276,19 @@ __device__ unsigned long long g_frame_t0[4096], g_frame_t1[4096], g_frame_tp[409
 #endif
 
 template <int MAXVIS>
-__global__ __launch_bounds__(256, MAXVIS <= 256 ? 5 : 2) void raster_kernel(GymView gv, uint32_t *obs, int W, int H, int split)
+__global__ __launch_bounds__(256, MAXVIS <= 256 ? MV_RASTER_WAVES : 2) void raster_kernel(GymView gv, uint32_t *obs, int W, int H, int split)
 {
     constexpr int ROUNDS = MAXVIS / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // column/row ray tables
     __shared__ Prim s_vis[MAXVIS];       // compacted visible list: straddlers first, then rectangle-bounded primitives
     __shared__ short4 s_rect[MAXVIS];    // x0,x1,y0,y1 (pixels)
     __shared__ CamL s_cam[MAX_AGENTS];
-    __shared__ int s_cnt[16];             // [parity*8 + wave]: straddlers, [parity*8 + 4 + wave]: rectangle-bounded primitives
+    __shared__ int s_cnt[8];              // [parity*4 + wave]: visible primitives found by each wave this round
 
     float4 *s_col = reinterpret_cast<float4 *>(s_dyn);   // per column i: (dc.x, c00*dc.x, c10*dc.x, c20*dc.x)
     float4 *s_row = s_col + W;                            // per row j:    (dc.y, c01*dc.y, c11*dc.y, c21*dc.y)
     float *s_colinv = reinterpret_cast<float *>(s_row + H);   // 1/dc.x per column (0 where dc.x == 0)
     float *s_rowinv = s_colinv + W;                            // 1/dc.y per row
-    float *s_edgex = s_rowinv + H;                             // frustum slope at pixel edge i, i in [0, W]
-    float *s_edgey = s_edgex + (W + 1);                        // frustum slope at pixel edge j, j in [0, H]
 
 #ifdef MV_RASTER_STATS
     const unsigned long long t_start = wall_clock64();
@@ -320,8 +335,6 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 ? 5 : 2) void raster_kernel(GymV
             s_row[j] = make_float4(dcy, c[1] * dcy, c[4] * dcy, c[7] * dcy);
             s_rowinv[j] = dcy == 0.0f ? 0.0f : 1.0f / dcy;
         }
-        for (int i = tid; i <= W; i += 256) s_edgex[i] = ((float(i) / float(W)) * 2.0f - 1.0f) * TAN_HALF_FOV;
-        for (int j = tid; j <= H; j += 256) s_edgey[j] = ((float(j) / float(H)) * 2.0f - 1.0f) * TAN_HALF_FOV_Y;
     }
     __syncthreads();   // cameras (incl. origin) complete
 
@@ -337,9 +350,8 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 ? 5 : 2) void raster_kernel(GymV
     const LayoutBox *gboxes = gv.boxes + (size_t)env * gv.box_stride;
 
     // Each round classifies 256 slots and appends the visible ones to the LDS list (order-free: depth ties are
-    // resolved on the slot id).  Positions [0, MAX_STRADDLERS) hold the world boxes that cross the eye plane
-    // ("straddlers", culled per tile with frustum planes), rectangle-bounded primitives follow.
-    int nStrad = 0, nRect = 0;   // wave-uniform running totals
+    // resolved on the slot id).
+    int nVis = 0;   // wave-uniform running total
     for (int rd = 0; rd * 256 < numSlots; ++rd) {
         const int slot = tid + 256 * rd;
         int kind = PRIM_NONE, fr = 0;
@@ -436,61 +448,44 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 ? 5 : 2) void raster_kernel(GymV
                 bhi[1] = hi[2] > 0.0f ? lo[1] : lo[1] + h;
             }
             cls = screen_rect(blo, bhi, fr, s_cam, viewer, W, H, rect);
-            // straddlers that are not world boxes (something glued to a camera touching the viewer's eye, a
-            // capsule or a diamond at the lens) are rare: give them the whole screen instead of plane tests
-            if (cls == 2 && (fr != 0 || kind != PRIM_BOX)) { cls = 1; rect[0] = 0; rect[1] = W - 1; rect[2] = 0; rect[3] = H - 1; }
         }
-        const unsigned long long mS = __ballot(cls == 2), mR = __ballot(cls == 1);
-        int *cnt = s_cnt + (rd & 1) * 8;   // double-buffered: one barrier per round
-        if (lane == 0) { cnt[wave] = __popcll(mS); cnt[4 + wave] = __popcll(mR); }
+        const unsigned long long mV = __ballot(cls != 0);
+        int *cnt = s_cnt + (rd & 1) * 4;   // double-buffered: one barrier per round
+        if (lane == 0) cnt[wave] = __popcll(mV);
         __syncthreads();
-        int posS = nStrad, posR = nRect, totS = 0, totR = 0;
+        int pos = nVis, tot = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            if (q < wave) { posS += cnt[q]; posR += cnt[4 + q]; }
-            totS += cnt[q]; totR += cnt[4 + q];
+            if (q < wave) pos += cnt[q];
+            tot += cnt[q];
         }
-        nStrad += totS; nRect += totR;
-        if (cls != 0) {
-            const unsigned long long below = (1ull << lane) - 1ull;
-            int pos;
-            if (cls == 2) {
-                pos = posS + __popcll(mS & below);
-                if (pos >= MAX_STRADDLERS) {   // overflow: a whole-screen rectangle, parked behind everything else
-                    pos = MAXVIS - 1 - (pos - MAX_STRADDLERS);
-                    rect[0] = 0; rect[1] = W - 1; rect[2] = 0; rect[3] = H - 1;
-                }
-            } else pos = MAX_STRADDLERS + posR + __popcll(mR & below);
-            if (pos < MAXVIS) {   // more than MAXVIS visible primitives: the excess is dropped (never seen in practice)
-                Prim p;
-                p.meta = kind | (fr << 8);
-                p.slot = slot;
-                if (kind == PRIM_BOX) {   // bounds relative to the ray origin of the primitive's frame
-                    V3 o = v3(0.0f, 0.0f, 0.0f);
-                    if (fr == 0) o = v3(s_cam[viewer].eye[0], s_cam[viewer].eye[1], s_cam[viewer].eye[2]);
-                    else if (fr != 1 + viewer) o = v3(s_cam[fr - 1].origin[0], s_cam[fr - 1].origin[1], s_cam[fr - 1].origin[2]);
-                    p.lo[0] = lo[0] - o.x; p.lo[1] = lo[1] - o.y; p.lo[2] = lo[2] - o.z;
-                    p.hi[0] = hi[0] - o.x; p.hi[1] = hi[1] - o.y; p.hi[2] = hi[2] - o.z;
-                } else {
-                    p.lo[0] = lo[0]; p.lo[1] = lo[1]; p.lo[2] = lo[2];
-                    p.hi[0] = hi[0]; p.hi[1] = hi[1]; p.hi[2] = hi[2];
-                }
-                const float AMB = float(0x55) / 255.0f, DIF = float(0xbb) / 255.0f, LCOL = float(0xaa) / 255.0f;
-                const float col[3] = {float((color >> 16) & 255) / 255.0f, float((color >> 8) & 255) / 255.0f, float(color & 255) / 255.0f};
-#pragma unroll
-                for (int c = 0; c < 3; ++c) { p.k1[c] = AMB * col[c]; p.k2[c] = (DIF * col[c]) * LCOL; }
-                p.pad0 = p.pad1 = 0.0f;
-                s_vis[pos] = p;
-                s_rect[pos] = make_short4((short)rect[0], (short)rect[1], (short)rect[2], (short)rect[3]);
+        nVis += tot;
+        pos += __popcll(mV & ((1ull << lane) - 1ull));
+        if (cls != 0 && pos < MAXVIS) {   // more than MAXVIS visible primitives: the excess is dropped (never seen in practice)
+            Prim p;
+            p.meta = kind | (fr << 8);
+            p.slot = slot;
+            if (kind == PRIM_BOX) {   // bounds relative to the ray origin of the primitive's frame
+                V3 o = v3(0.0f, 0.0f, 0.0f);
+                if (fr == 0) o = v3(s_cam[viewer].eye[0], s_cam[viewer].eye[1], s_cam[viewer].eye[2]);
+                else if (fr != 1 + viewer) o = v3(s_cam[fr - 1].origin[0], s_cam[fr - 1].origin[1], s_cam[fr - 1].origin[2]);
+                p.lo[0] = lo[0] - o.x; p.lo[1] = lo[1] - o.y; p.lo[2] = lo[2] - o.z;
+                p.hi[0] = hi[0] - o.x; p.hi[1] = hi[1] - o.y; p.hi[2] = hi[2] - o.z;
+            } else {
+                p.lo[0] = lo[0]; p.lo[1] = lo[1]; p.lo[2] = lo[2];
+                p.hi[0] = hi[0]; p.hi[1] = hi[1]; p.hi[2] = hi[2];
             }
+            const float AMB = float(0x55) / 255.0f, DIF = float(0xbb) / 255.0f, LCOL = float(0xaa) / 255.0f;
+            const float col[3] = {float((color >> 16) & 255) / 255.0f, float((color >> 8) & 255) / 255.0f, float(color & 255) / 255.0f};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { p.k1[c] = AMB * col[c]; p.k2[c] = (DIF * col[c]) * LCOL; }
+            p.pad0 = p.pad1 = 0.0f;
+            s_vis[pos] = p;
+            s_rect[pos] = make_short4((short)rect[0], (short)rect[1], (short)rect[2], (short)rect[3]);
         }
     }
     __syncthreads();
-    // list layout: [0, nStradKept) straddlers | [MAX_STRADDLERS, rectEnd) rectangles | [xsBegin, MAXVIS) straddler overflow
-    const int nStradKept = min(nStrad, (int)MAX_STRADDLERS);
-    const int xsBegin = MAXVIS - max(nStrad - MAX_STRADDLERS, 0);
-    const int rectEnd = min(MAX_STRADDLERS + nRect, xsBegin);
-    const int scanEnd = xsBegin < MAXVIS ? MAXVIS : rectEnd;   // tile culling scans positions [MAX_STRADDLERS, scanEnd)
+    nVis = min(nVis, (int)MAXVIS);
 
     const CamL &cam = s_cam[viewer];
     const V3 eye = v3(cam.eye[0], cam.eye[1], cam.eye[2]);
@@ -502,10 +497,6 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 ? 5 : 2) void raster_kernel(GymV
 #ifdef MV_RASTER_STATS
     if (tid == 0 && frame < 4096) { g_frame_t0[frame] = t_start; g_frame_tp[frame] = wall_clock64(); }
 #endif
-    // this lane's (frustum plane, straddler) pair: plane-major so that one AND of five 12-bit groups
-    // of the ballot gives the straddlers that survive all five planes
-    const int sPlane = lane / MAX_STRADDLERS, sIdx = lane - MAX_STRADDLERS * sPlane;
-    const bool sActive = sPlane < 5 && sIdx < nStradKept;
     const float nzm[3] = {-cam.c[2], -cam.c[5], -cam.c[8]};   // c_k2 * (-1)
 
     for (int tile = part * 4 + wave; tile < numTiles; tile += 4 * split) {
@@ -513,47 +504,28 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 ? 5 : 2) void raster_kernel(GymV
         const int tx0 = tx * TILE_W, ty0 = ty * TILE_H;
         const int tx1 = min(tx0 + TILE_W, W) - 1, ty1 = min(ty0 + TILE_H, H) - 1;
 
-        // ---- tile culling.  (a) rectangle-bounded primitives: one per lane per round of 64, 4 integer compares
+        // ---- tile culling: one primitive per lane per round of 64, four integer compares against its screen rectangle
         unsigned long long mk[ROUNDS];
 #pragma unroll
         for (int k = 0; k < ROUNDS; ++k) {
             mk[k] = 0ull;
-            if (k * 64 < scanEnd) {   // wave-uniform
+            if (k * 64 < nVis) {   // wave-uniform
                 const int pos = lane + 64 * k;
                 bool v = false;
-                if (pos >= MAX_STRADDLERS && (pos < rectEnd || (pos >= xsBegin && pos < MAXVIS))) {
+                if (pos < nVis) {
                     const short4 r = s_rect[pos];
                     v = r.x <= tx1 && r.y >= tx0 && r.z <= ty1 && r.w >= ty0;
                 }
                 mk[k] = __ballot(v);
             }
         }
-        // (b) straddlers: survives when no frustum plane has the whole box on its outside.
-        // tile frustum in camera space: x in [x0,x1]*w, y in [y0,y1]*w (w = depth), bounds at pixel EDGES
-        bool planeOk = false;
-        if (sActive) {
-            float a;
-            if (sPlane == 0) a = s_edgex[tx0];
-            else if (sPlane == 1) a = -s_edgex[tx1 + 1];
-            else if (sPlane == 2) a = s_edgey[ty0];
-            else a = -s_edgey[ty1 + 1];
-            const V3 nc = sPlane == 0 ? v3(1.0f, 0.0f, a) : sPlane == 1 ? v3(-1.0f, 0.0f, a) : sPlane == 2 ? v3(0.0f, 1.0f, a)
-                        : sPlane == 3 ? v3(0.0f, -1.0f, a) : v3(0.0f, 0.0f, -1.0f);
-            const V3 nw = mat_mul(cam.c, nc);
-            const Prim &sp = s_vis[sIdx];
-            planeOk = !(support(nw, sp.lo, sp.hi) < (sPlane == 4 ? NEAR_Z * 0.5f : -1e-4f));
-        }
-        const unsigned long long mPlane = __ballot(planeOk);
-        const unsigned long long g = mPlane & (mPlane >> MAX_STRADDLERS) & (mPlane >> (2 * MAX_STRADDLERS)) &
-                                     (mPlane >> (3 * MAX_STRADDLERS)) & (mPlane >> (4 * MAX_STRADDLERS)) & ((1ull << MAX_STRADDLERS) - 1ull);
-        mk[0] |= g;
-
 #ifdef MV_RASTER_STATS
         if (lane == 0) {
+            unsigned long long surv = 0;
+            for (int k = 0; k < ROUNDS; ++k) surv += __popcll(mk[k]);
             atomicAdd(&g_raster_stats[0], 1ull);
-            atomicAdd(&g_raster_stats[1], (unsigned long long)(__popcll(mk[0]) + __popcll(mk[1]) + __popcll(mk[2]) + __popcll(mk[3])));
-            atomicAdd(&g_raster_stats[2], (unsigned long long)__popcll(g));
-            if (tile == 0) { atomicAdd(&g_raster_stats[3], (unsigned long long)(nStrad + nRect)); atomicAdd(&g_raster_stats[4], 1ull); atomicAdd(&g_raster_stats[5], (unsigned long long)nStrad); }
+            atomicAdd(&g_raster_stats[1], surv);
+            if (tile == 0) { atomicAdd(&g_raster_stats[3], (unsigned long long)nVis); atomicAdd(&g_raster_stats[4], 1ull); }
         }
 #endif
         // ---- this lane's pixel and ray
@@ -678,7 +650,7 @@ extern "C" void mv_debug_raster_times(unsigned long long *t0, unsigned long long
 int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream)
 {
     if (W > MAX_W || H > MAX_H) return -1;
-    const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)(2 * W + 2 * H + 2) * sizeof(float);
+    const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)(W + H) * sizeof(float);
     static const int envSplit = getenv("MV_RASTER_SPLIT") ? atoi(getenv("MV_RASTER_SPLIT")) : 0;
     const int tiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H);
     int split = envSplit > 0 ? envSplit : 4;
