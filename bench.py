@@ -139,8 +139,10 @@ def main():
         # algorithmic bytes of one raster launch (DESIGN.md "kernels"): RGBA8 frame written once +
         # the frame's scene (header 128 B, 16 layout boxes 512 B, 80 movable boxes 320 B, agents 128 B each)
         obst = args.scenario.lower().startswith("obstacles")
-        # Obstacles: 128 layout boxes 4096 B + 16 terrain boxes 512 B + 16 reward objects 64 B
-        scene_bytes = (4096 + 512 + 64) if obst else 512
+        collect = args.scenario.lower() == "collect"
+        # Obstacles: 128 layout boxes 4096 B + 16 terrain boxes 512 B + 16 reward objects 64 B;
+        # Collect: ~75 merged slabs on average (oracle statistics) * 32 B + 96 diamonds * 4 B + nothing else
+        scene_bytes = (4096 + 512 + 64) if obst else (75 * 32 + 96 * 4) if collect else 512
         bytes_per_frame = W * H * 4 + 128 + scene_bytes + 320 + 128 * A
         raster_ms = prof["raster"][0]
         achieved = bytes_per_frame * frames / (raster_ms * 1e-3) / 1e9 if raster_ms > 0 else 0.0
@@ -150,7 +152,7 @@ def main():
         traffic = None
         try:   # HBM bytes per raster launch from the committed PMC passes (profiles/), only for the profiled config
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pt["config"] == {"envs_per_gpu": n_env, "agents_per_env": A, "obs": [W, H]} and not obst:
+            if pt["config"] == {"envs_per_gpu": n_env, "agents_per_env": A, "obs": [W, H]} and not obst and not collect:
                 traffic = pt["kernels"]["mv::raster_kernel"]["traffic_bytes_per_launch"]
         except Exception:  # noqa: BLE001
             pass
@@ -169,7 +171,8 @@ def main():
                                  "so the HBM fraction is low by construction (DESIGN.md 3.3)"},
             "kernels": {"step": {"avg_launch_ms": step_ms, "algorithmic_GBps": step_bytes_per_env * n_env / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0,
                                  "algorithmic_bytes_per_launch": step_bytes_per_env * n_env},
-                        "reset": {"avg_launch_ms": prof["reset"][0]}},
+                        "reset": {"avg_launch_ms": prof["reset"][0]},
+                        "frame_setup": {"avg_launch_ms": prof["setup"][0]}},
             "checksum": checksum,
         }
         if world == 1 and not args.no_cpu_baseline:

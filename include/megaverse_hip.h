@@ -101,12 +101,12 @@ int mv_set_reward_shaping(mv_gym *g, int32_t env_idx, int32_t agent_idx, const c
 int mv_synchronize(mv_gym *g);
 
 /* In-stream kernel timing with HIP events on the gym's own stream (bench.py roofline leg).
- * After mv_profile_begin the next max_steps calls of mv_step record events around the three
+ * After mv_profile_begin the next max_steps calls of mv_step record events around the four
  * kernels; mv_profile_end synchronises and returns the mean milliseconds and sample count per
- * kernel: [0] step (physics+logic), [1] reset, [2] raster.  The counterpart in the reference is
+ * kernel: [0] step (physics+logic), [1] reset, [2] frame setup (visible-primitive lists), [3] raster.  The counterpart in the reference is
  * the TinyProfiler timers around venv.step() (src/apps/megaverse_test_app.cpp:68-74). */
 int mv_profile_begin(mv_gym *g, int32_t max_steps);
-int mv_profile_end(mv_gym *g, float *avg_ms3, int32_t *counts3);
+int mv_profile_end(mv_gym *g, float *avg_ms4, int32_t *counts4);
 
 /* test hooks: packed state snapshot of one env (layout in DESIGN.md, same bytes as the oracle's
  * mvo_snapshot) and the raw device RNG streams */

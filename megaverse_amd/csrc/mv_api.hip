@@ -24,7 +24,7 @@
 namespace mv {
 void launch_reset(const GymView &gv, int force_all, hipStream_t stream);
 void launch_step(const GymView &gv, hipStream_t stream);
-int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream);
+int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream, hipEvent_t between = nullptr);
 void launch_step_obstacles(const GymView &gv, hipStream_t stream);
 void launch_reset_obstacles(const GymView &gv, const EpisodeBlob *blobs, int *total_consumed, int force_all, hipStream_t stream);
 void launch_step_collect(const GymView &gv, hipStream_t stream);
@@ -94,7 +94,7 @@ struct mv_gym {
     hipEvent_t consumedCopied = nullptr;
     bool consumedPending = false;
     // in-stream profiling
-    std::vector<hipEvent_t> profEvents;          // 4 per profiled step
+    std::vector<hipEvent_t> profEvents;          // 5 per profiled step
     int profMax = 0, profCount = 0;
 };
 
@@ -291,8 +291,10 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     const size_t szTerrain = obstacles ? up(N * MAX_TERRAIN * sizeof(TerrainBox)) : 0,
                  szRewObj = hostEpisodes ? up(N * (size_t)gv.reward_stride * sizeof(MovableObject)) : 0,
                  szHeight = collect ? up(N * (size_t)HM_BYTES) : 0, szBlobs = up(N * g->blobBytes), szCnt = 4096;
+    gv.vis_stride = collect ? 1024 : 256;
+    const size_t szVisP = up(NA * (size_t)gv.vis_stride * 32), szVisR = up(NA * (size_t)gv.vis_stride * 8), szVisC = up(NA * sizeof(int32_t));
     const size_t total = szHdr + szBoxes + szObj + szAg + szAct + szRew + szDone + szObjv + szMd + (hostEpisodes ? 0 : szChunk) + szObs + szTerrain +
-                         szRewObj + szHeight + szBlobs + szCnt;
+                         szRewObj + szHeight + szBlobs + szCnt + szVisP + szVisR + szVisC;
     {
         hipError_t e_ = hipMalloc((void **)&g->arena, total);
         if (e_ != hipSuccess) { mv_destroy(g); return fail(std::string("hipMalloc arena: ") + hipGetErrorString(e_)); }
@@ -318,6 +320,9 @@ int mv_create(const mv_config *cfg, mv_gym **out)
             g->dBlobs = p; p += szBlobs;
         }
         if (collect) { gv.heightmap = (int8_t *)p; p += szHeight; }
+        gv.vis_prims = p; p += szVisP;
+        gv.vis_rects = p; p += szVisR;
+        gv.vis_count = (int32_t *)p; p += szVisC;
     }
     g->obs = g->ownedObs;
     for (int b = 0; b < 2; ++b) {
@@ -592,7 +597,7 @@ static int step_impl(mv_gym *g, bool render)
         g->actionsDirty = false;
     }
     const bool prof = render && g->profCount < g->profMax;
-    hipEvent_t *ev = prof ? &g->profEvents[(size_t)g->profCount * 4] : nullptr;
+    hipEvent_t *ev = prof ? &g->profEvents[(size_t)g->profCount * 5] : nullptr;
     if (prof) HIP_TRY(hipEventRecord(ev[0], g->stream));
     if (g->scenario == SCN_OBSTACLES) launch_step_obstacles(g->gv, g->stream);
     else if (g->scenario == SCN_COLLECT) launch_step_collect(g->gv, g->stream);
@@ -607,8 +612,8 @@ static int step_impl(mv_gym *g, bool render)
     } else
         launch_reset(g->gv, 0, g->stream);
     if (prof) HIP_TRY(hipEventRecord(ev[2], g->stream));
-    if (render && launch_raster(g->gv, g->obs, g->w, g->h, g->stream)) return fail("mv_step: observation size above 1024x1024");
-    if (prof) { HIP_TRY(hipEventRecord(ev[3], g->stream)); ++g->profCount; }
+    if (render && launch_raster(g->gv, g->obs, g->w, g->h, g->stream, prof ? ev[3] : nullptr)) return fail("mv_step: observation size above 1024x1024");
+    if (prof) { HIP_TRY(hipEventRecord(ev[4], g->stream)); ++g->profCount; }
     HIP_TRY(hipGetLastError());
     g->mirrorsFresh = false;
     return 0;
@@ -629,7 +634,7 @@ int mv_profile_begin(mv_gym *g, int32_t max_steps)
     if (check(g)) return -1;
     if (max_steps < 0) return fail("mv_profile_begin: max_steps < 0");
     HIP_TRY(hipSetDevice(g->device));
-    while ((int)g->profEvents.size() < max_steps * 4) {
+    while ((int)g->profEvents.size() < max_steps * 5) {
         hipEvent_t e;
         HIP_TRY(hipEventCreate(&e));
         g->profEvents.push_back(e);
@@ -639,20 +644,20 @@ int mv_profile_begin(mv_gym *g, int32_t max_steps)
     return 0;
 }
 
-int mv_profile_end(mv_gym *g, float *avg_ms3, int32_t *counts3)
+int mv_profile_end(mv_gym *g, float *avg_ms4, int32_t *counts4)
 {
     if (check(g)) return -1;
     HIP_TRY(hipStreamSynchronize(g->stream));
-    double sum[3] = {0, 0, 0};
+    double sum[4] = {0, 0, 0, 0};
     for (int i = 0; i < g->profCount; ++i)
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < 4; ++k) {
             float ms = 0.0f;
-            HIP_TRY(hipEventElapsedTime(&ms, g->profEvents[(size_t)i * 4 + k], g->profEvents[(size_t)i * 4 + k + 1]));
+            HIP_TRY(hipEventElapsedTime(&ms, g->profEvents[(size_t)i * 5 + k], g->profEvents[(size_t)i * 5 + k + 1]));
             sum[k] += ms;
         }
-    for (int k = 0; k < 3; ++k) {
-        avg_ms3[k] = g->profCount ? (float)(sum[k] / g->profCount) : 0.0f;
-        counts3[k] = g->profCount;
+    for (int k = 0; k < 4; ++k) {
+        avg_ms4[k] = g->profCount ? (float)(sum[k] / g->profCount) : 0.0f;
+        counts4[k] = g->profCount;
     }
     g->profMax = 0;
     g->profCount = 0;

@@ -44,7 +44,7 @@ constexpr float NEAR_Z = 0.01f, FAR_Z = 120.0f;
 constexpr float OBJ_HALF = 0.39f, CARRY_SCALE = 0.78f;
 constexpr int TILE_W = 16, TILE_H = 4;
 #ifndef MV_RASTER_WAVES
-#define MV_RASTER_WAVES 6   // waves per SIMD the small variant is compiled for (register budget 512 / n)
+#define MV_RASTER_WAVES 7   // waves per SIMD the small variant is compiled for (register budget 512 / n)
 #endif
 constexpr int VIS_SMALL = 256, VIS_LARGE = 1024;   // visible primitives kept per frame (TowerBuilding <= 121 slots, Obstacles <= 280; Collect up to ~1300)
 constexpr float CLIP_W = 0.005f;       // NEAR_Z / 2: boxes are clipped against this depth before projecting
@@ -54,12 +54,10 @@ __constant__ unsigned AGENT_COLORS[7] = {0xffdd3c, 0x3bb372, 0x2eb5d0, 0xffb400,
 
 enum : int { PRIM_NONE = 0, PRIM_BOX = 1, PRIM_CAPSULE = 2, PRIM_CONE = 3 };
 
-struct alignas(16) Prim {   // 64 B
-    float lo[3]; int32_t meta;    // box: bounds minus the ray origin of its frame; capsule: centre (world); cone: apex (world)
-    float hi[3]; int32_t slot;    //        capsule: (radius, halfLen, 0); cone: (base radius, height, +1 apex up / -1 apex down)
-    float k1[3]; float pad0;      // AMB * colour
-    float k2[3]; float pad1;      // (DIF * colour) * LCOL
-};                                // meta = kind | frame << 8 ; frame 0 = world axes, 1+k = camera frame of agent k
+struct alignas(16) Prim {   // 32 B, one visible primitive of a frame (written by frame_setup_kernel, read by raster_kernel)
+    float lo[3]; uint32_t meta;   // box: bounds minus the ray origin of its frame; capsule: centre (world); cone: apex (world)
+    float hi[3]; uint32_t color;  //        capsule: (radius, halfLen, 0); cone: (base radius, height, +1 apex up / -1 apex down)
+};                                // meta = kind | frame << 4 | slot << 8 ; frame 0 = world axes, 1+k = camera frame of agent k
 
 struct CamL {
     float eye[3];
@@ -275,33 +273,21 @@ __device__ unsigned long long g_raster_stats[8];   // tiles, survivors, straddle
 __device__ unsigned long long g_frame_t0[4096], g_frame_t1[4096], g_frame_tp[4096];
 #endif
 
-template <int MAXVIS>
-__global__ __launch_bounds__(256, MAXVIS <= 256 ? MV_RASTER_WAVES : 2) void raster_kernel(GymView gv, uint32_t *obs, int W, int H, int split)
+// ---- pass 1, one workgroup per frame: which primitives can this camera see, and where on the screen?
+__global__ __launch_bounds__(256) void frame_setup_kernel(GymView gv, int W, int H)
 {
-    constexpr int ROUNDS = MAXVIS / 64;
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // column/row ray tables
-    __shared__ Prim s_vis[MAXVIS];       // compacted visible list: straddlers first, then rectangle-bounded primitives
-    __shared__ short4 s_rect[MAXVIS];    // x0,x1,y0,y1 (pixels)
     __shared__ CamL s_cam[MAX_AGENTS];
     __shared__ int s_cnt[8];              // [parity*4 + wave]: visible primitives found by each wave this round
 
-    float4 *s_col = reinterpret_cast<float4 *>(s_dyn);   // per column i: (dc.x, c00*dc.x, c10*dc.x, c20*dc.x)
-    float4 *s_row = s_col + W;                            // per row j:    (dc.y, c01*dc.y, c11*dc.y, c21*dc.y)
-    float *s_colinv = reinterpret_cast<float *>(s_row + H);   // 1/dc.x per column (0 where dc.x == 0)
-    float *s_rowinv = s_colinv + W;                            // 1/dc.y per row
-
-#ifdef MV_RASTER_STATS
-    const unsigned long long t_start = wall_clock64();
-#endif
     const int A = gv.num_agents;
-    // `split` workgroups share one frame (interleaved tiles): frames differ up to 10x in cost, smaller work
-    // units let the dispatcher level the load across CUs
-    const int frame = blockIdx.x / split, part = blockIdx.x - frame * split;
+    const int frame = blockIdx.x;
     const int env = frame / A, viewer = frame - env * A;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
     const EnvHeader *hdr = gv.hdr + env;
     const AgentState *agents = gv.agents + (size_t)env * A;
+    const int maxVis = gv.vis_stride;
+    Prim *vis = reinterpret_cast<Prim *>(gv.vis_prims) + (size_t)frame * maxVis;
+    short4 *rects = reinterpret_cast<short4 *>(gv.vis_rects) + (size_t)frame * maxVis;
 
     // ---- cameras
     if (tid < A) {
@@ -323,21 +309,6 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 ? MV_RASTER_WAVES : 2) void rast
         const V3 o = mat_tmul(s_cam[tid].c, ev - ek);
         s_cam[tid].origin[0] = o.x; s_cam[tid].origin[1] = o.y; s_cam[tid].origin[2] = o.z;
     }
-    {   // separable ray terms: world dir = (c_k0*dc.x + c_k1*dc.y) + c_k2*(-1), dc = (xn*TAN, yn*TAN_Y, -1)
-        const float *c = s_cam[viewer].c;
-        for (int i = tid; i < W; i += 256) {
-            const float dcx = (((float(i) + 0.5f) / float(W)) * 2.0f - 1.0f) * TAN_HALF_FOV;
-            s_col[i] = make_float4(dcx, c[0] * dcx, c[3] * dcx, c[6] * dcx);
-            s_colinv[i] = dcx == 0.0f ? 0.0f : 1.0f / dcx;
-        }
-        for (int j = tid; j < H; j += 256) {
-            const float dcy = (((float(j) + 0.5f) / float(H)) * 2.0f - 1.0f) * TAN_HALF_FOV_Y;
-            s_row[j] = make_float4(dcy, c[1] * dcy, c[4] * dcy, c[7] * dcy);
-            s_rowinv[j] = dcy == 0.0f ? 0.0f : 1.0f / dcy;
-        }
-    }
-    __syncthreads();   // cameras (incl. origin) complete
-
     // ---- primitive slots, packed (slot order == the order the reference emits drawables == depth-tie order):
     //   layout slabs | terrain slabs (TowerBuilding: the building zone) | movable boxes | 2 cones per diamond | 3 per agent
     const int scen = hdr->scenario;
@@ -461,10 +432,10 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 ? MV_RASTER_WAVES : 2) void rast
         }
         nVis += tot;
         pos += __popcll(mV & ((1ull << lane) - 1ull));
-        if (cls != 0 && pos < MAXVIS) {   // more than MAXVIS visible primitives: the excess is dropped (never seen in practice)
+        if (cls != 0 && pos < maxVis) {   // more than vis_stride visible primitives: the excess is dropped (never seen in practice)
             Prim p;
-            p.meta = kind | (fr << 8);
-            p.slot = slot;
+            p.meta = (uint32_t)(kind | (fr << 4) | (slot << 8));
+            p.color = color;
             if (kind == PRIM_BOX) {   // bounds relative to the ray origin of the primitive's frame
                 V3 o = v3(0.0f, 0.0f, 0.0f);
                 if (fr == 0) o = v3(s_cam[viewer].eye[0], s_cam[viewer].eye[1], s_cam[viewer].eye[2]);
@@ -475,17 +446,97 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 ? MV_RASTER_WAVES : 2) void rast
                 p.lo[0] = lo[0]; p.lo[1] = lo[1]; p.lo[2] = lo[2];
                 p.hi[0] = hi[0]; p.hi[1] = hi[1]; p.hi[2] = hi[2];
             }
-            const float AMB = float(0x55) / 255.0f, DIF = float(0xbb) / 255.0f, LCOL = float(0xaa) / 255.0f;
-            const float col[3] = {float((color >> 16) & 255) / 255.0f, float((color >> 8) & 255) / 255.0f, float(color & 255) / 255.0f};
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { p.k1[c] = AMB * col[c]; p.k2[c] = (DIF * col[c]) * LCOL; }
-            p.pad0 = p.pad1 = 0.0f;
-            s_vis[pos] = p;
-            s_rect[pos] = make_short4((short)rect[0], (short)rect[1], (short)rect[2], (short)rect[3]);
+            vis[pos] = p;
+            rects[pos] = make_short4((short)rect[0], (short)rect[1], (short)rect[2], (short)rect[3]);
         }
     }
+    if (tid == 0) gv.vis_count[frame] = min(nVis, maxVis);
+
+}
+
+template <int MAXVIS>
+__global__ __launch_bounds__(256, MAXVIS <= 256 ? MV_RASTER_WAVES : 2) void raster_kernel(GymView gv, uint32_t *obs, int W, int H, int split)
+{
+    constexpr int ROUNDS = MAXVIS / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // column/row ray tables
+    __shared__ Prim s_vis[MAXVIS];       // this frame's visible list
+    __shared__ short4 s_rect[MAXVIS];    // x0,x1,y0,y1 (pixels)
+    __shared__ CamL s_cam[MAX_AGENTS];
+    __shared__ float s_lutA[256], s_lutD[256];   // colour byte -> AMB * c / 255 and (DIF * c / 255) * LCOL
+
+    float4 *s_col = reinterpret_cast<float4 *>(s_dyn);   // per column i: (dc.x, c00*dc.x, c10*dc.x, c20*dc.x)
+    float4 *s_row = s_col + W;                            // per row j:    (dc.y, c01*dc.y, c11*dc.y, c21*dc.y)
+    float *s_colinv = reinterpret_cast<float *>(s_row + H);   // 1/dc.x per column (0 where dc.x == 0)
+    float *s_rowinv = s_colinv + W;                            // 1/dc.y per row
+
+#ifdef MV_RASTER_STATS
+    const unsigned long long t_start = wall_clock64();
+#endif
+    const int A = gv.num_agents;
+    // `split` workgroups share one frame (interleaved tiles): frames differ up to 10x in cost, smaller work
+    // units let the dispatcher level the load across CUs.  Workgroup ids are dealt round-robin over the 8 XCDs;
+    // the parts of one frame are given ids that are congruent mod 8 so that they share one XCD's L2 (the frame's
+    // list is read `split` times, neighbouring tiles write neighbouring lines).
+    int frame, part;
+    {
+        const int per = 8 * split, group = blockIdx.x / per, r = blockIdx.x - group * per;
+        frame = group * 8 + (r & 7); part = r >> 3;
+        const int frames = gridDim.x / split;
+        if (group * 8 + 8 > frames) { const int b = blockIdx.x - group * per; const int nf = frames - group * 8; frame = group * 8 + b % nf; part = b / nf; }
+    }
+    const int env = frame / A, viewer = frame - env * A;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    const AgentState *agents = gv.agents + (size_t)env * A;
+
+    // ---- cameras
+    if (tid < A) {
+        const AgentState a = agents[tid];
+        CamL cam;
+        cam.eye[0] = a.pos[0]; cam.eye[1] = (a.pos[1] + 0.05f) + 0.41f; cam.eye[2] = a.pos[2];
+        float sp, cp;
+        sincos_poly(a.pitch, sp, cp);
+        cam.c[0] = a.m00; cam.c[1] = a.m02 * sp; cam.c[2] = a.m02 * cp;
+        cam.c[3] = 0.0f;  cam.c[4] = cp;         cam.c[5] = -sp;
+        cam.c[6] = a.m20; cam.c[7] = a.m22 * sp; cam.c[8] = a.m22 * cp;
+        cam.origin[0] = cam.origin[1] = cam.origin[2] = 0.0f;
+        s_cam[tid] = cam;
+    }
     __syncthreads();
-    nVis = min(nVis, (int)MAXVIS);
+    if (tid < A) {
+        const V3 ev = v3(s_cam[viewer].eye[0], s_cam[viewer].eye[1], s_cam[viewer].eye[2]);
+        const V3 ek = v3(s_cam[tid].eye[0], s_cam[tid].eye[1], s_cam[tid].eye[2]);
+        const V3 o = mat_tmul(s_cam[tid].c, ev - ek);
+        s_cam[tid].origin[0] = o.x; s_cam[tid].origin[1] = o.y; s_cam[tid].origin[2] = o.z;
+    }
+    {   // separable ray terms: world dir = (c_k0*dc.x + c_k1*dc.y) + c_k2*(-1), dc = (xn*TAN, yn*TAN_Y, -1)
+        const float *c = s_cam[viewer].c;
+        for (int i = tid; i < W; i += 256) {
+            const float dcx = (((float(i) + 0.5f) / float(W)) * 2.0f - 1.0f) * TAN_HALF_FOV;
+            s_col[i] = make_float4(dcx, c[0] * dcx, c[3] * dcx, c[6] * dcx);
+            s_colinv[i] = dcx == 0.0f ? 0.0f : 1.0f / dcx;
+        }
+        for (int j = tid; j < H; j += 256) {
+            const float dcy = (((float(j) + 0.5f) / float(H)) * 2.0f - 1.0f) * TAN_HALF_FOV_Y;
+            s_row[j] = make_float4(dcy, c[1] * dcy, c[4] * dcy, c[7] * dcy);
+            s_rowinv[j] = dcy == 0.0f ? 0.0f : 1.0f / dcy;
+        }
+    }
+
+    // ---- this frame's visible list (frame_setup_kernel) and the colour tables
+    const int nVis = min(gv.vis_count[frame], (int)MAXVIS);
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(reinterpret_cast<const Prim *>(gv.vis_prims) + (size_t)frame * gv.vis_stride);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_vis);
+        for (int i = tid; i < nVis * 2; i += 256) dst[i] = src[i];
+        const short4 *rs = reinterpret_cast<const short4 *>(gv.vis_rects) + (size_t)frame * gv.vis_stride;
+        for (int i = tid; i < nVis; i += 256) s_rect[i] = rs[i];
+        const float AMB = float(0x55) / 255.0f, DIF = float(0xbb) / 255.0f, LCOL = float(0xaa) / 255.0f;
+        const float c = float(tid) / 255.0f;
+        s_lutA[tid] = AMB * c;
+        s_lutD[tid] = (DIF * c) * LCOL;
+    }
+    __syncthreads();   // cameras (incl. origin), ray tables, list, colour tables complete
 
     const CamL &cam = s_cam[viewer];
     const V3 eye = v3(cam.eye[0], cam.eye[1], cam.eye[2]);
@@ -556,7 +607,7 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 ? MV_RASTER_WAVES : 2) void rast
                 m &= m - 1;
                 const int pos = bit + 64 * half;
                 const Prim &q = s_vis[pos];
-                const int qkind = q.meta & 255, qfr = q.meta >> 8;
+                const int qkind = q.meta & 15, qfr = (q.meta >> 4) & 15;
                 float t; V3 n = v3(0, 0, 0);
                 bool hit;
                 if (qkind == PRIM_CAPSULE) {
@@ -572,7 +623,8 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 ? MV_RASTER_WAVES : 2) void rast
                     hit = ray_box<true>(dk, safe_inv(dk), q.lo, q.hi, t);
                 }
                 // nearest hit; equal depth -> the primitive drawn first (lowest slot), as a strict "<" scan in slot order would
-                if (hit && (t < best || (t == best && q.slot < bestSlot))) { best = t; bestPos = pos; bestSlot = q.slot; capN = n; }
+                const int qslot = (int)(q.meta >> 8);
+                if (hit && (t < best || (t == best && qslot < bestSlot))) { best = t; bestPos = pos; bestSlot = qslot; capN = n; }
             }
         }
 
@@ -580,7 +632,7 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 ? MV_RASTER_WAVES : 2) void rast
         unsigned rgba = 0xff000000u;
         if (bestPos >= 0) {
             const Prim &q = s_vis[bestPos];
-            const int qkind = q.meta & 255, qfr = q.meta >> 8;
+            const int qkind = q.meta & 15, qfr = (q.meta >> 4) & 15;
             V3 N;
             if (qkind != PRIM_BOX) N = mat_tmul(cam.c, capN);
             else {
@@ -620,7 +672,10 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 ? MV_RASTER_WAVES : 2) void rast
             }
             unsigned ch[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) ch[c] = to_u8((q.k1[c] + q.k2[c] * intensity) + spec);
+            for (int c = 0; c < 3; ++c) {
+                const unsigned byte = (q.color >> (16 - 8 * c)) & 255u;
+                ch[c] = to_u8((s_lutA[byte] + s_lutD[byte] * intensity) + spec);
+            }
             rgba = ch[0] | (ch[1] << 8) | (ch[2] << 16) | 0xff000000u;
         }
         if (px < W && py < H) out[(size_t)py * W + px] = rgba;
@@ -647,7 +702,7 @@ extern "C" void mv_debug_raster_times(unsigned long long *t0, unsigned long long
 }
 #endif
 
-int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream)
+int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream, hipEvent_t between)
 {
     if (W > MAX_W || H > MAX_H) return -1;
     const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)(W + H) * sizeof(float);
@@ -655,8 +710,10 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
     const int tiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H);
     int split = envSplit > 0 ? envSplit : 4;
     while (split > 1 && tiles < 4 * split * 2) split >>= 1;   // keep at least two tiles per wave
+    hipLaunchKernelGGL(frame_setup_kernel, dim3(gv.num_envs * gv.num_agents), dim3(256), 0, stream, gv, W, H);
+    if (between) (void)hipEventRecord(between, stream);
     const dim3 grid(gv.num_envs * gv.num_agents * split), block(256);
-    if (gv.box_stride > VIS_SMALL) hipLaunchKernelGGL(raster_kernel<VIS_LARGE>, grid, block, dyn, stream, gv, obs, W, H, split);
+    if (gv.vis_stride > VIS_SMALL) hipLaunchKernelGGL(raster_kernel<VIS_LARGE>, grid, block, dyn, stream, gv, obs, W, H, split);
     else hipLaunchKernelGGL(raster_kernel<VIS_SMALL>, grid, block, dyn, stream, gv, obs, W, H, split);
     return 0;
 }

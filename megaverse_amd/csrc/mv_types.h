@@ -94,6 +94,11 @@ struct GymView {
     float *rewards;            // [N*A] as reported by get_last_rewards (0 on done steps)
     uint8_t *done;             // [N]
     float *true_objective;     // [N*A]
+    // per-frame visible-primitive lists (mv_raster.hip: frame_setup_kernel -> raster_kernel)
+    void *vis_prims;           // [N*A][vis_stride] 32-byte records
+    void *vis_rects;           // [N*A][vis_stride] short4 screen rectangles
+    int32_t *vis_count;        // [N*A]
+    int32_t vis_stride;        // 256, or 1024 for Collect
 };
 
 // One host-generated episode (Obstacles family): everything Env::reset produces, ready to be swapped in by

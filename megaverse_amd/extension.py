@@ -258,11 +258,11 @@ class MegaverseGym:
         self._ck(self._lib.mv_profile_begin(self._g, int(max_steps)))
 
     def profile_end(self):
-        """-> {'step': (avg_ms, n), 'reset': (...), 'raster': (...)} measured with HIP events on the gym's stream"""
-        ms = (C.c_float * 3)()
-        cnt = (C.c_int32 * 3)()
+        """-> {'step': (avg_ms, n), 'reset': (...), 'setup': (...), 'raster': (...)} measured with HIP events on the gym's stream"""
+        ms = (C.c_float * 4)()
+        cnt = (C.c_int32 * 4)()
         self._ck(self._lib.mv_profile_end(self._g, ms, cnt))
-        return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(("step", "reset", "raster"))}
+        return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(("step", "reset", "setup", "raster"))}
 
     def debug_snapshot_bytes(self, env_idx):
         n = self._lib.mv_debug_snapshot_size(self._g)
