@@ -18,24 +18,27 @@ import oracle_lib  # noqa: E402
 from megaverse_amd.rollout import action_masks, sample_actions  # noqa: E402
 
 SCALAR_FIELDS = ["L", "H", "W", "bz", "layout_color", "wall_color", "draw_walls", "num_objects", "num_boxes", "episode_len",
-                 "bz_reward", "highest_tower", "num_frames", "episode_sec"]
+                 "bz_reward", "highest_tower", "num_frames", "episode_sec", "num_terrain", "num_rewards", "num_platforms", "solved"]
 
 
 def snap_dict(s, A):
     d = {k: np.asarray(s[k]).copy() for k in SCALAR_FIELDS}
     d["boxes"] = s["boxes"][: int(s["num_boxes"])].copy()
     d["objects"] = s["objects"][: int(s["num_objects"])].copy()
+    d["terrain"] = s["terrain"][: int(s["num_terrain"])].copy()
+    d["rewards"] = s["rewards"][: int(s["num_rewards"])].copy()
     for f in ("pos", "basis", "pitch", "hv", "vvel", "carrying", "spawn", "total_reward"):
         d["agent_" + f] = np.stack([np.asarray(s["agents"][k][f]) for k in range(A)])
     d["chunk_sum"] = np.asarray(s["chunk"]).astype(np.int64).sum()
     return d
 
 
-def make(name, N, A, steps, trace_every, W, H, params=None, seed=42, action_seed=1234):
-    g = oracle_lib.OracleGym("TowerBuilding", W, H, N, A, 1, False, params)
+def make(name, N, A, steps, trace_every, W, H, params=None, seed=42, action_seed=1234, scenario="TowerBuilding"):
+    g = oracle_lib.OracleGym(scenario, W, H, N, A, 1, False, params)
     g.seed(seed)
     g.reset()
-    out = {"N": N, "A": A, "steps": steps, "trace_every": trace_every, "W": W, "H": H, "seed": seed, "action_seed": action_seed}
+    out = {"N": N, "A": A, "steps": steps, "trace_every": trace_every, "W": W, "H": H, "seed": seed, "action_seed": action_seed,
+           "scenario": np.array(scenario)}
     if params:
         out["param_keys"] = np.array(list(params.keys()))
         out["param_vals"] = np.array(list(params.values()), np.float32)
@@ -68,6 +71,15 @@ def make(name, N, A, steps, trace_every, W, H, params=None, seed=42, action_seed
 
 
 if __name__ == "__main__":
+    only = sys.argv[1:]
+    if only:   # python make_golden.py new  -> only the fixtures that do not exist yet
+        _make = make
+        def make(name, **kw):  # noqa: E306
+            if not os.path.exists(os.path.join(HERE, name + ".npz")):
+                _make(name, **kw)
     make("tower_a1", N=6, A=1, steps=1200, trace_every=100, W=64, H=64)
     make("tower_a4", N=3, A=4, steps=600, trace_every=100, W=64, H=64)
     make("tower_short_episodes", N=4, A=2, steps=400, trace_every=50, W=32, H=32, params={"episodeLengthSec": -220.0})
+    make("obstacles_hard_a2", N=4, A=2, steps=500, trace_every=100, W=64, H=64, scenario="ObstaclesHard", seed=7)
+    make("obstacles_easy_a1", N=6, A=1, steps=1200, trace_every=100, W=32, H=32, scenario="ObstaclesEasy", seed=11)
+    make("collect_a2", N=5, A=2, steps=1100, trace_every=100, W=64, H=64, scenario="Collect", seed=3)

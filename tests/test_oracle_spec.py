@@ -283,13 +283,13 @@ def test_done_step_semantics():
     g.close()
 
 
-@pytest.mark.parametrize("name", ["tower_a1", "tower_a4", "tower_short_episodes"])
+@pytest.mark.parametrize("name", ["tower_a1", "tower_a4", "tower_short_episodes", "obstacles_hard_a2", "obstacles_easy_a1", "collect_a2"])
 def test_oracle_reproduces_golden(name):
     """restatement-relative: the committed vectors were generated by this oracle (tests/golden/make_golden.py)"""
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     N, A, steps, every, W, H = (int(z[k]) for k in ("N", "A", "steps", "trace_every", "W", "H"))
     params = dict(zip(z["param_keys"].tolist(), z["param_vals"].tolist())) if "param_keys" in z else None
-    g = oracle_lib.OracleGym("TowerBuilding", W, H, N, A, 1, False, params)
+    g = oracle_lib.OracleGym(str(z["scenario"]) if "scenario" in z else "TowerBuilding", W, H, N, A, 1, False, params)
     g.seed(int(z["seed"]))
     g.reset()
     for e in range(N):
