@@ -90,7 +90,8 @@ def main():
 
     W, H = args.obs
     n_env, A = args.envs_per_gpu, args.agents
-    gym = MegaverseGym(args.scenario, W, H, n_env, A, 1, False, {}, device=local_rank, env_offset=rank * n_env,
+    gym = MegaverseGym(args.scenario, W, H, n_env, A, 8, False, {},   # 8 = episode-feeder threads (host-generated scenarios)
+                       device=local_rank, env_offset=rank * n_env,
                        total_envs=world * n_env)
     stream = torch.cuda.current_stream()
     gym.set_stream(stream.cuda_stream)

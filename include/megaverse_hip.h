@@ -120,6 +120,10 @@ int mv_debug_math(int32_t device, int32_t what, const float *a, const float *b, 
  * draws (env.cpp:57-76). */
 int mv_debug_generate_episode(const char *scenario, int32_t num_agents, int32_t env_seed, int32_t n, float base_episode_len,
                               void *out, int32_t out_bytes);
+/* Host-only: runs the background episode feeder (worker pool that keeps every env's next episode generated ahead of
+ * time; replaces the serial Env::reset inside VectorEnv::step, vector_env.cpp:93-105) for `rounds` episodes per env
+ * and compares each delivered episode with sequential generation.  0 = identical. */
+int mv_debug_feeder_selftest(const char *scenario, int32_t num_envs, int32_t num_agents, int32_t threads, int32_t rounds);
 
 #ifdef __cplusplus
 }

@@ -11,11 +11,13 @@
 #include <cctype>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <random>
 #include <string>
 #include <vector>
 
 #include "../../include/megaverse_hip.h"
+#include "mv_feeder.h"
 #include "mv_gen.h"
 #include "mv_math.h"
 #include "mv_rng.h"
@@ -26,9 +28,9 @@ void launch_reset(const GymView &gv, int force_all, hipStream_t stream);
 void launch_step(const GymView &gv, hipStream_t stream);
 int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream, hipEvent_t between = nullptr);
 void launch_step_obstacles(const GymView &gv, hipStream_t stream);
-void launch_reset_obstacles(const GymView &gv, const EpisodeBlob *blobs, int *total_consumed, int force_all, hipStream_t stream);
+void launch_reset_obstacles(const GymView &gv, const EpisodeBlob *blobs, int *status, int force_all, hipStream_t stream);
 void launch_step_collect(const GymView &gv, hipStream_t stream);
-void launch_reset_collect(const GymView &gv, const CollectBlob *blobs, int *total_consumed, int force_all, hipStream_t stream);
+void launch_reset_collect(const GymView &gv, const CollectBlob *blobs, int *status, int force_all, hipStream_t stream);
 }  // namespace mv
 
 using namespace mv;
@@ -83,16 +85,20 @@ struct mv_gym {
     const char *const *shapingKeys = SHAPING_KEYS_TOWER;
     ObstacleConfig obst;
     float baseEpisodeLen = 60.0f;
-    // Obstacles: host episode generator + one resident episode per env (refill protocol)
-    std::vector<std::mt19937> envRng;
-    std::vector<int> uploaded;                   // episodes uploaded per env
-    uint8_t *dBlobs = nullptr, *hBlobs = nullptr;   // device [N][blobBytes], pinned staging [N][blobBytes]
+    // Obstacles / Collect: background episode feeder + one resident episode per env (refill protocol below)
+    std::unique_ptr<EpisodeFeeder> feeder;
+    int feederThreads = 1;
+    std::vector<int> uploaded, uploadBatch;         // episodes uploaded per env; envs of the current upload batch
+    uint8_t *dBlobs = nullptr, *hBlobs = nullptr;   // device [N][blobBytes], pinned feeder slots [N][blobBytes]
     size_t blobBytes = 0;                           // sizeof(EpisodeBlob) or sizeof(CollectBlob)
     bool hostEpisodes() const { return scenario != SCN_TOWER; }
-    int *dTotalConsumed = nullptr, *hTotalConsumed = nullptr;   // device counter, pinned mirror
+    int *dStatus = nullptr, *hStatus = nullptr;     // [N + 2]: consumed per env, total, error flags (device, pinned mirror)
     int lastTotalSeen = 0;
-    hipEvent_t consumedCopied = nullptr;
-    bool consumedPending = false;
+    bool statusPending = false, refillForce = true;
+    hipStream_t copyStream = nullptr;               // status read-back + episode uploads, off the step path
+    hipEvent_t resetDone = nullptr, statusCopied = nullptr;
+    std::vector<hipEvent_t> uploadEvents;           // ring, one per upload batch
+    size_t uploadRing = 0;
     // in-stream profiling
     std::vector<hipEvent_t> profEvents;          // 5 per profiled step
     int profMax = 0, profCount = 0;
@@ -290,7 +296,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
                  szObs = up(NA * (size_t)g->w * g->h * 4);
     const size_t szTerrain = obstacles ? up(N * MAX_TERRAIN * sizeof(TerrainBox)) : 0,
                  szRewObj = hostEpisodes ? up(N * (size_t)gv.reward_stride * sizeof(MovableObject)) : 0,
-                 szHeight = collect ? up(N * (size_t)HM_BYTES) : 0, szBlobs = up(N * g->blobBytes), szCnt = 4096;
+                 szHeight = collect ? up(N * (size_t)HM_BYTES) : 0, szBlobs = up(N * g->blobBytes), szCnt = up((N + 2) * sizeof(int32_t));
     gv.vis_stride = collect ? 1024 : 256;
     const size_t szVisP = up(NA * (size_t)gv.vis_stride * 32), szVisR = up(NA * (size_t)gv.vis_stride * 8), szVisC = up(NA * sizeof(int32_t));
     const size_t total = szHdr + szBoxes + szObj + szAg + szAct + szRew + szDone + szObjv + szMd + (hostEpisodes ? 0 : szChunk) + szObs + szTerrain +
@@ -313,7 +319,8 @@ int mv_create(const mv_config *cfg, mv_gym **out)
         g->dMultiDiscrete = (int32_t *)p; p += szMd;
         if (!hostEpisodes) { gv.chunk = p; p += szChunk; }
         g->ownedObs = (uint32_t *)p; p += szObs;
-        g->dTotalConsumed = (int *)p; p += szCnt;
+        g->dStatus = (int *)p; p += szCnt;
+        gv.episode_status = g->dStatus;
         if (obstacles) { gv.terrain = (TerrainBox *)p; p += szTerrain; }
         if (hostEpisodes) {
             gv.rewards_obj = (MovableObject *)p; p += szRewObj;
@@ -351,16 +358,26 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     g->obst = oc;
     g->baseEpisodeLen = episodeLen;
     if (hostEpisodes) {
-        std::random_device rdev;
-        for (size_t i = 0; i < N; ++i) g->envRng.emplace_back(rdev());
         g->uploaded.assign(N, 0);
-        if (hipHostMalloc((void **)&g->hBlobs, N * g->blobBytes, hipHostMallocDefault) != hipSuccess ||
-            hipHostMalloc((void **)&g->hTotalConsumed, sizeof(int), hipHostMallocDefault) != hipSuccess ||
-            hipEventCreateWithFlags(&g->consumedCopied, hipEventDisableTiming) != hipSuccess) {
+        g->feederThreads = std::min(32, std::max(1, (int)cfg->num_simulation_threads));
+        if (const char *e = getenv("MV_FEEDER_THREADS")) g->feederThreads = std::min(64, std::max(1, atoi(e)));
+        g->uploadEvents.assign(64, nullptr);
+        bool ok = hipHostMalloc((void **)&g->hBlobs, N * g->blobBytes, hipHostMallocDefault) == hipSuccess &&
+                  hipHostMalloc((void **)&g->hStatus, (N + 2) * sizeof(int), hipHostMallocDefault) == hipSuccess &&
+                  hipStreamCreateWithFlags(&g->copyStream, hipStreamNonBlocking) == hipSuccess &&
+                  hipEventCreateWithFlags(&g->resetDone, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&g->statusCopied, hipEventDisableTiming) == hipSuccess;
+        for (auto &e : g->uploadEvents) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
             mv_destroy(g);
-            return fail("mv_create: pinned episode staging allocation failed");
+            return fail("mv_create: pinned episode staging / copy stream allocation failed");
         }
-        *g->hTotalConsumed = 0;
+        std::memset(g->hStatus, 0, (N + 2) * sizeof(int));
+        g->feeder = std::make_unique<EpisodeFeeder>(scenario, oc, g->N, g->A, episodeLen, g->hBlobs, g->blobBytes, g->device, g->feederThreads);
+        std::vector<uint32_t> seeds(N);
+        std::random_device rdev;   // unseeded envs take their seed from random_device (env.hpp:169)
+        for (auto &v : seeds) v = (uint32_t)rdev();
+        g->feeder->reseed(seeds, std::vector<int>(N, 1));
     }
     std::vector<EnvHeader> hh(N);
     std::random_device rd;
@@ -396,10 +413,16 @@ int mv_close(mv_gym *g)
     GymView &gv = g->gv;
     if (g->arena) (void)hipFree(g->arena);
     if (g->hiresObs) (void)hipFree(g->hiresObs);
+    if (g->copyStream) (void)hipStreamSynchronize(g->copyStream);
+    g->feeder.reset();   // joins the workers before their slots go away
     if (g->hBlobs) (void)hipHostFree(g->hBlobs);
-    if (g->hTotalConsumed) (void)hipHostFree(g->hTotalConsumed);
-    if (g->consumedCopied) (void)hipEventDestroy(g->consumedCopied);
-    g->hBlobs = nullptr; g->hTotalConsumed = nullptr; g->consumedCopied = nullptr; g->dBlobs = nullptr; g->dTotalConsumed = nullptr;
+    if (g->hStatus) (void)hipHostFree(g->hStatus);
+    if (g->resetDone) (void)hipEventDestroy(g->resetDone);
+    if (g->statusCopied) (void)hipEventDestroy(g->statusCopied);
+    for (hipEvent_t e : g->uploadEvents) if (e) (void)hipEventDestroy(e);
+    g->uploadEvents.clear();
+    if (g->copyStream) (void)hipStreamDestroy(g->copyStream);
+    g->hBlobs = nullptr; g->hStatus = nullptr; g->resetDone = g->statusCopied = nullptr; g->copyStream = nullptr; g->dBlobs = nullptr; g->dStatus = nullptr;
     g->arena = nullptr;
     for (int b = 0; b < 2; ++b) {
         if (g->hActions[b]) (void)hipHostFree(g->hActions[b]);
@@ -450,7 +473,18 @@ int mv_seed(mv_gym *g, int32_t seed)
         if (i >= g->envOffset && i < g->envOffset + g->N) seeds[i - g->envOffset] = (uint32_t)noise;
     }
     if (g->hostEpisodes()) {   // Env::seed (env.cpp:52-55) on the host-side episode generators
-        for (int i = 0; i < g->N; ++i) g->envRng[i].seed((unsigned long)seeds[i]);
+        HIP_TRY(hipStreamSynchronize(g->stream));
+        HIP_TRY(hipStreamSynchronize(g->copyStream));
+        g->statusPending = false;
+        std::vector<int> first(g->N);
+        for (int i = 0; i < g->N; ++i) {
+            // the episode resident on the device (if any) was drawn from the old stream: it is replaced before the next
+            // reset can consume it, because the env now counts as "consumed everything uploaded"
+            g->uploaded[i] = g->hStatus[i];
+            first[i] = g->uploaded[i] + 1;
+        }
+        g->refillForce = true;
+        g->feeder->reseed(seeds, first);
         return 0;
     }
     uint32_t *d = nullptr;
@@ -471,49 +505,56 @@ int mv_render(mv_gym *g)
     return 0;
 }
 
-// ---- Obstacles refill protocol --------------------------------------------------------------------
-// Each env keeps ONE host-generated episode resident (dBlobs[env]); the reset kernel swaps it in and
-// bumps hdr.episodes_consumed + *dTotalConsumed.  After every step the counter is copied to pinned
-// memory; the next host call looks at it (the copy finished a whole step ago) and, when it moved,
-// generates + uploads the following episode for exactly the envs that consumed theirs.  Episodes last
-// >= 35 s = 525 steps, so the spare is always in place long before it is needed.
-static int upload_next_episode(mv_gym *g, int env)
+// ---- episode refill protocol (Obstacles family, Collect) ---------------------------------------------
+// Each env keeps ONE generated episode resident in HBM (dBlobs[env]); the reset kernel swaps it in and bumps
+// status[env] / status[N].  After the reset kernel of step t the copy stream reads the status words back to pinned
+// memory.  Step t+1 starts by looking at them (that copy finished long ago: the raster of step t is still
+// running) and uploads -- on the copy stream, from the feeder's pinned slots, where the episodes were generated
+// ahead of time by the worker pool -- the next episode of exactly the envs that consumed theirs.  The step path
+// itself only ever enqueues; it waits for the host only if generation falls behind (wait_ready).
+static int refill_episodes(mv_gym *g)
 {
-    uint8_t *host = g->hBlobs + (size_t)env * g->blobBytes, *dev = g->dBlobs + (size_t)env * g->blobBytes;
-    size_t bytes = g->blobBytes;
-    if (g->scenario == SCN_OBSTACLES) {
-        EpisodeBlob &b = *reinterpret_cast<EpisodeBlob *>(host);
-        generate_obstacles_episode(g->envRng[env], g->obst, g->A, g->baseEpisodeLen, b);
-        b.seq = ++g->uploaded[env];
-    } else {
-        CollectBlob &b = *reinterpret_cast<CollectBlob *>(host);
-        generate_collect_episode(g->envRng[env], g->A, g->baseEpisodeLen, b);
-        b.seq = ++g->uploaded[env];
-        bytes = offsetof(CollectBlob, boxes) + (size_t)b.num_boxes * sizeof(LayoutBox);   // the slab list is last: used prefix only
+    if (!g->hostEpisodes()) return 0;
+    if (g->statusPending) {
+        HIP_TRY(hipEventSynchronize(g->statusCopied));
+        g->statusPending = false;
     }
-    HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, g->stream));
+    const int N = g->N;
+    const int flags = g->hStatus[N + 1];
+    if (flags & 1) return fail("an env reset without a fresh episode resident (refill protocol violated)");
+    if (flags & 2) return fail("collision candidate list overflow (more than 128 bodies around one agent)");
+    if (!g->refillForce && g->hStatus[N] == g->lastTotalSeen) return 0;
+    hipEvent_t ev = g->uploadEvents[g->uploadRing++ % g->uploadEvents.size()];
+    HIP_TRY(hipEventSynchronize(ev));   // 64 batches ago
+    std::vector<int> &batch = g->uploadBatch;
+    batch.clear();
+    for (int i = 0; i < N; ++i) {
+        if (g->hStatus[i] != g->uploaded[i]) continue;   // its resident episode has not been consumed yet
+        size_t bytes = 0;
+        const uint8_t *src = g->feeder->wait_ready(i, g->uploaded[i] + 1, &bytes);
+        if (!src) return fail("episode feeder: episode " + std::to_string(g->uploaded[i] + 1) + " of env " + std::to_string(i) + " was never generated");
+        HIP_TRY(hipMemcpyAsync(g->dBlobs + (size_t)i * g->blobBytes, src, bytes, hipMemcpyHostToDevice, g->copyStream));
+        ++g->uploaded[i];
+        batch.push_back(i);
+    }
+    if (!batch.empty()) {
+        HIP_TRY(hipEventRecord(ev, g->copyStream));
+        for (int i : batch) g->feeder->recycle(i, ev);   // regenerate a slot only once its upload has left it
+        HIP_TRY(hipStreamWaitEvent(g->stream, ev, 0));
+    }
+    g->lastTotalSeen = g->hStatus[N];
+    g->refillForce = false;
     return 0;
 }
 
-static int refill_episodes(mv_gym *g, bool force)
+// after a reset kernel: read the status words back without touching the step path
+static int read_back_status(mv_gym *g)
 {
-    if (!g->hostEpisodes()) return 0;
-    if (g->consumedPending) {
-        HIP_TRY(hipEventSynchronize(g->consumedCopied));
-        g->consumedPending = false;
-    }
-    if (!force && *g->hTotalConsumed == g->lastTotalSeen) return 0;
-    std::vector<EnvHeader> hh(g->N);
-    HIP_TRY(hipMemcpyAsync(hh.data(), g->gv.hdr, g->N * sizeof(EnvHeader), hipMemcpyDeviceToHost, g->stream));
-    HIP_TRY(hipStreamSynchronize(g->stream));
-    int total = 0;
-    for (int i = 0; i < g->N; ++i) {
-        if (hh[i].starved & 1) return fail("env " + std::to_string(i) + " reset without a fresh episode");
-        if (hh[i].starved & 2) return fail("env " + std::to_string(i) + ": collision candidate list overflow");
-        total += hh[i].episodes_consumed;
-        if (hh[i].episodes_consumed == g->uploaded[i] && upload_next_episode(g, i)) return -1;
-    }
-    g->lastTotalSeen = total;
+    HIP_TRY(hipEventRecord(g->resetDone, g->stream));
+    HIP_TRY(hipStreamWaitEvent(g->copyStream, g->resetDone, 0));
+    HIP_TRY(hipMemcpyAsync(g->hStatus, g->dStatus, (size_t)(g->N + 2) * sizeof(int), hipMemcpyDeviceToHost, g->copyStream));
+    HIP_TRY(hipEventRecord(g->statusCopied, g->copyStream));
+    g->statusPending = true;
     return 0;
 }
 
@@ -522,10 +563,11 @@ int mv_reset(mv_gym *g)
     if (check(g)) return -1;
     HIP_TRY(hipSetDevice(g->device));
     if (g->hostEpisodes()) {
-        if (refill_episodes(g, true)) return -1;        // every env has an unconsumed episode resident
-        if (g->scenario == SCN_OBSTACLES) launch_reset_obstacles(g->gv, (const EpisodeBlob *)g->dBlobs, g->dTotalConsumed, 1, g->stream);
-        else launch_reset_collect(g->gv, (const CollectBlob *)g->dBlobs, g->dTotalConsumed, 1, g->stream);
-        if (refill_episodes(g, true)) return -1;        // and a spare for the first auto-reset
+        g->refillForce = true;
+        if (refill_episodes(g)) return -1;              // every env has an unconsumed episode resident
+        if (g->scenario == SCN_OBSTACLES) launch_reset_obstacles(g->gv, (const EpisodeBlob *)g->dBlobs, g->dStatus, 1, g->stream);
+        else launch_reset_collect(g->gv, (const CollectBlob *)g->dBlobs, g->dStatus, 1, g->stream);
+        if (read_back_status(g)) return -1;             // the spares for the first auto-resets go up with the next step
     } else
         launch_reset(g->gv, 1, g->stream);
     HIP_TRY(hipGetLastError());
@@ -586,7 +628,7 @@ static int step_impl(mv_gym *g, bool render)
     if (check(g)) return -1;
     if (!g->wasReset) return fail("mv_step: call mv_reset first");
     HIP_TRY(hipSetDevice(g->device));
-    if (refill_episodes(g, false)) return -1;
+    if (refill_episodes(g)) return -1;
     if (g->actionsDirty) {
         const int s = g->stage;
         HIP_TRY(hipMemcpyAsync(g->gv.actions, g->hActions[s], (size_t)g->N * g->A * sizeof(int32_t), hipMemcpyHostToDevice, g->stream));
@@ -604,11 +646,9 @@ static int step_impl(mv_gym *g, bool render)
     else launch_step(g->gv, g->stream);
     if (prof) HIP_TRY(hipEventRecord(ev[1], g->stream));
     if (g->hostEpisodes()) {
-        if (g->scenario == SCN_OBSTACLES) launch_reset_obstacles(g->gv, (const EpisodeBlob *)g->dBlobs, g->dTotalConsumed, 0, g->stream);
-        else launch_reset_collect(g->gv, (const CollectBlob *)g->dBlobs, g->dTotalConsumed, 0, g->stream);
-        HIP_TRY(hipMemcpyAsync(g->hTotalConsumed, g->dTotalConsumed, sizeof(int), hipMemcpyDeviceToHost, g->stream));
-        HIP_TRY(hipEventRecord(g->consumedCopied, g->stream));
-        g->consumedPending = true;
+        if (g->scenario == SCN_OBSTACLES) launch_reset_obstacles(g->gv, (const EpisodeBlob *)g->dBlobs, g->dStatus, 0, g->stream);
+        else launch_reset_collect(g->gv, (const CollectBlob *)g->dBlobs, g->dStatus, 0, g->stream);
+        if (read_back_status(g)) return -1;
     } else
         launch_reset(g->gv, 0, g->stream);
     if (prof) HIP_TRY(hipEventRecord(ev[2], g->stream));
@@ -893,6 +933,58 @@ int mv_debug_generate_episode(const char *scenario_name, int32_t num_agents, int
     }
     std::memcpy(out, buf.data(), bytes);
     return (int)bytes;
+}
+
+// Host-only test hook: drives an EpisodeFeeder (worker pool, per-env ordering, recycle) without a device and checks
+// every episode it delivers against a straight sequential generation from the same seeds.  Returns 0 when equal.
+int mv_debug_feeder_selftest(const char *scenario_name, int32_t num_envs, int32_t num_agents, int32_t threads, int32_t rounds)
+{
+    int scenario = SCN_TOWER;
+    ObstacleConfig oc;
+    if (!scenario_name || !scenario_from_name(lower(scenario_name), scenario, oc) || scenario == SCN_TOWER)
+        return fail("mv_debug_feeder_selftest: host-generated scenarios only");
+    const size_t bytes = scenario == SCN_COLLECT ? sizeof(CollectBlob) : sizeof(EpisodeBlob);
+    std::vector<uint8_t> slots((size_t)num_envs * bytes, 0), want(bytes);
+    std::vector<uint32_t> seeds(num_envs);
+    for (int i = 0; i < num_envs; ++i) seeds[i] = 1000u + 7u * (uint32_t)i;
+    std::vector<std::mt19937> rng(num_envs);
+    for (int i = 0; i < num_envs; ++i) rng[i].seed((unsigned long)seeds[i]);
+    EpisodeFeeder feeder(scenario, oc, num_envs, num_agents, 60.0f, slots.data(), bytes, 0, threads);
+    feeder.reseed(seeds, std::vector<int>(num_envs, 1));
+    for (int r = 1; r <= rounds; ++r)
+        for (int k = 0; k < num_envs; ++k) {
+            const int i = (r & 1) ? k : num_envs - 1 - k;   // consume in varying order
+            size_t used = 0;
+            const uint8_t *got = feeder.wait_ready(i, r, &used);
+            if (!got) return fail("feeder selftest: episode not delivered");
+            std::memset(want.data(), 0, bytes);
+            if (scenario == SCN_COLLECT) {
+                CollectBlob &b = *reinterpret_cast<CollectBlob *>(want.data());
+                generate_collect_episode(rng[i], num_agents, 60.0f, b);
+                b.seq = r;
+            } else {
+                EpisodeBlob &b = *reinterpret_cast<EpisodeBlob *>(want.data());
+                generate_obstacles_episode(rng[i], oc, num_agents, 60.0f, b);
+                b.seq = r;
+            }
+            if (used > bytes) return fail("feeder selftest: used bytes out of range");
+            // compare the meaningful fields: counts first, then the used prefix of each array via the generators' own layout
+            if (scenario == SCN_COLLECT) {
+                const CollectBlob &a = *reinterpret_cast<const CollectBlob *>(got), &b = *reinterpret_cast<const CollectBlob *>(want.data());
+                if (a.seq != b.seq || a.num_boxes != b.num_boxes || a.num_objects != b.num_objects || a.num_rewards != b.num_rewards ||
+                    std::memcmp(a.boxes, b.boxes, sizeof(LayoutBox) * (size_t)b.num_boxes) || std::memcmp(a.heightmap, b.heightmap, HM_DIM * HM_DIM) ||
+                    std::memcmp(a.spawn, b.spawn, sizeof a.spawn) || std::memcmp(a.yaw_frand, b.yaw_frand, sizeof(float) * (size_t)num_agents))
+                    return fail("feeder selftest: Collect episode differs from sequential generation");
+            } else {
+                const EpisodeBlob &a = *reinterpret_cast<const EpisodeBlob *>(got), &b = *reinterpret_cast<const EpisodeBlob *>(want.data());
+                if (a.seq != b.seq || a.num_boxes != b.num_boxes || a.num_objects != b.num_objects || a.num_rewards != b.num_rewards ||
+                    std::memcmp(a.boxes, b.boxes, sizeof(LayoutBox) * (size_t)b.num_boxes) || std::memcmp(a.spawn, b.spawn, sizeof a.spawn) ||
+                    std::memcmp(a.yaw_frand, b.yaw_frand, sizeof(float) * (size_t)num_agents))
+                    return fail("feeder selftest: Obstacles episode differs from sequential generation");
+            }
+            feeder.recycle(i, nullptr);
+        }
+    return 0;
 }
 
 int mv_debug_rng(int32_t device, uint32_t seed, int32_t what, const int32_t *lo, const int32_t *hi, int32_t n, void *out)

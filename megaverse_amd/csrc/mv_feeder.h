@@ -1,0 +1,68 @@
+// megaverse_amd/csrc/mv_feeder.h -- background episode generation for the host-generated scenarios
+// (Obstacles family, Collect).
+//
+// The reference generates an env's next episode inside VectorEnv::step, serially, on the thread that is
+// stepping (vector_env.cpp:93-105 -> Env::reset): "reset is the serial straggler" (SURVEY.md 8a row E).
+// Here generation is off the step path entirely: every env always has its NEXT episode generated ahead of
+// time in a pinned host slot by a small worker pool, so consuming an episode costs the step path one
+// host-to-device copy enqueue.  An env's episodes form one RNG stream (Env::seed, then one
+// randRange + re-seed per Env::reset), so per-env generation order is all that has to be preserved.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <random>
+#include <thread>
+#include <vector>
+
+#include "mv_gen.h"
+
+namespace mv {
+
+class EpisodeFeeder {
+public:
+    // slots: pinned host memory, num_envs * slot_bytes, owned by the caller
+    EpisodeFeeder(int scenario, const ObstacleConfig &cfg, int num_envs, int num_agents, float base_episode_len, uint8_t *slots,
+                  size_t slot_bytes, int device, int num_threads);
+    ~EpisodeFeeder();
+    EpisodeFeeder(const EpisodeFeeder &) = delete;
+    EpisodeFeeder &operator=(const EpisodeFeeder &) = delete;
+
+    // Env::seed for every env (values.size() == num_envs).  Drops episodes generated from the old streams and starts
+    // generating `first_seq[i]` (the sequence number the device expects next) for every env.
+    void reseed(const std::vector<uint32_t> &values, const std::vector<int> &first_seq);
+
+    // Blocks until episode `seq` of `env` is complete in its slot; returns the slot and how many bytes of it are used.
+    const uint8_t *wait_ready(int env, int seq, size_t *used_bytes);
+
+    // The slot of `env` was handed to an asynchronous copy that `copied` completes: once it has, generate seq + 1 into it.
+    void recycle(int env, hipEvent_t copied);
+
+    int num_threads() const { return int(workers_.size()); }
+
+private:
+    struct Task { int env; hipEvent_t after; };
+    void worker_main();
+    void generate(int env);
+
+    const int scenario_, num_envs_, num_agents_, device_;
+    const ObstacleConfig cfg_;
+    const float base_len_;
+    uint8_t *const slots_;
+    const size_t slot_bytes_;
+    std::vector<std::mt19937> rng_;
+    std::vector<int> next_seq_;                  // sequence number the next generated episode of env i gets (worker-owned once queued)
+    std::vector<std::atomic<int>> ready_seq_;    // sequence number of the complete episode in slot i (0 = none)
+    std::vector<size_t> used_bytes_;
+    std::mutex mu_;
+    std::condition_variable cv_task_, cv_done_;
+    std::deque<Task> tasks_;
+    int in_flight_ = 0;
+    bool stop_ = false;
+    std::vector<std::thread> workers_;
+};
+
+}  // namespace mv

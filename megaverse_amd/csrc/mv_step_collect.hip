@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64) void step_collect_kernel(GymView gv)
                 if (keep && pos < MAX_CAND) { Col c; c.kind = 2; c.lo = centre; c.hi = v3(2 * CAP_HH, 0.0f, 0.0f); s_cand[pos] = c; }
                 count += __popcll(m);
             }
-            if (count > MAX_CAND) starved |= 2;
+            if (count > MAX_CAND) { starved |= 2; if (lane == 0) atomicOr(&gv.episode_status[gv.num_envs + 1], 2); }
             __syncthreads();
             Col col[NC];
 #pragma unroll
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64) void step_collect_kernel(GymView gv)
 }
 
 // Episode swap-in: Env::reset for finished envs (or every env when force_all), from the resident CollectBlob.
-__global__ __launch_bounds__(64) void reset_collect_kernel(GymView gv, const CollectBlob *blobs, int *total_consumed, int force_all)
+__global__ __launch_bounds__(64) void reset_collect_kernel(GymView gv, const CollectBlob *blobs, int *status, int force_all)
 {
     const int env = blockIdx.x;
     const int lane = lane_id();
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(64) void reset_collect_kernel(GymView gv, const Col
     const CollectBlob *b = blobs + env;
     const int consumed = gh->episodes_consumed;
     if (b->seq != consumed + 1) {   // the host has not delivered the next episode: must never happen (mv_api.hip keeps one ahead)
-        if (lane == 0) gh->starved |= 1;
+        if (lane == 0) { gh->starved |= 1; atomicOr(&status[gv.num_envs + 1], 1); }
         return;
     }
     const int A = gv.num_agents;
@@ -374,7 +374,8 @@ __global__ __launch_bounds__(64) void reset_collect_kernel(GymView gv, const Col
         gh->num_frames = 0; gh->done = 0; gh->highest_tower = 0; gh->solved = 0;
         gh->episode_sec = 0.0f; gh->episode_len = b->episode_len; gh->bz_reward = 0.0f; gh->bar_half_width = 0.24f;
         gh->episodes_consumed = consumed + 1;
-        atomicAdd(total_consumed, 1);
+        status[env] = consumed + 1;              // per-env count, total, error flags: copied to the host after every step
+        atomicAdd(&status[gv.num_envs], 1);
         if (force_all) gv.done[env] = 0;
     }
 }
@@ -388,9 +389,9 @@ void launch_step_collect(const GymView &gv, hipStream_t stream)
     else hipLaunchKernelGGL(step_collect_kernel<8>, grid, block, 0, stream, gv);
 }
 
-void launch_reset_collect(const GymView &gv, const CollectBlob *blobs, int *total_consumed, int force_all, hipStream_t stream)
+void launch_reset_collect(const GymView &gv, const CollectBlob *blobs, int *status, int force_all, hipStream_t stream)
 {
-    hipLaunchKernelGGL(reset_collect_kernel, dim3(gv.num_envs), dim3(64), 0, stream, gv, blobs, total_consumed, force_all);
+    hipLaunchKernelGGL(reset_collect_kernel, dim3(gv.num_envs), dim3(64), 0, stream, gv, blobs, status, force_all);
 }
 
 }  // namespace mv

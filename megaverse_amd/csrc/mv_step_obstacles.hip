@@ -296,7 +296,7 @@ __global__ __launch_bounds__(64) void step_obstacles_kernel(GymView gv)
 }
 
 // Episode swap-in: Env::reset for finished envs (or every env when force_all), from the resident EpisodeBlob.
-__global__ __launch_bounds__(64) void reset_obstacles_kernel(GymView gv, const EpisodeBlob *blobs, int *total_consumed, int force_all)
+__global__ __launch_bounds__(64) void reset_obstacles_kernel(GymView gv, const EpisodeBlob *blobs, int *status, int force_all)
 {
     const int env = blockIdx.x;
     const int lane = lane_id();
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(64) void reset_obstacles_kernel(GymView gv, const E
     const EpisodeBlob *b = blobs + env;
     const int consumed = gh->episodes_consumed;
     if (b->seq != consumed + 1) {   // the host has not delivered the next episode: must never happen (mv_api.hip keeps one ahead)
-        if (lane == 0) gh->starved = 1;
+        if (lane == 0) { gh->starved |= 1; atomicOr(&status[gv.num_envs + 1], 1); }
         return;
     }
     const int A = gv.num_agents;
@@ -343,7 +343,8 @@ __global__ __launch_bounds__(64) void reset_obstacles_kernel(GymView gv, const E
         gh->num_frames = 0; gh->done = 0; gh->highest_tower = 0; gh->solved = 0;
         gh->episode_sec = 0.0f; gh->episode_len = b->episode_len; gh->bz_reward = 0.0f; gh->bar_half_width = 0.24f;
         gh->episodes_consumed = consumed + 1;
-        atomicAdd(total_consumed, 1);
+        status[env] = consumed + 1;              // per-env count, total, error flags: copied to the host after every step
+        atomicAdd(&status[gv.num_envs], 1);
         if (force_all) gv.done[env] = 0;
     }
 }
@@ -357,9 +358,9 @@ void launch_step_obstacles(const GymView &gv, hipStream_t stream)
     else hipLaunchKernelGGL(step_obstacles_kernel<8>, grid, block, 0, stream, gv);
 }
 
-void launch_reset_obstacles(const GymView &gv, const EpisodeBlob *blobs, int *total_consumed, int force_all, hipStream_t stream)
+void launch_reset_obstacles(const GymView &gv, const EpisodeBlob *blobs, int *status, int force_all, hipStream_t stream)
 {
-    hipLaunchKernelGGL(reset_obstacles_kernel, dim3(gv.num_envs), dim3(64), 0, stream, gv, blobs, total_consumed, force_all);
+    hipLaunchKernelGGL(reset_obstacles_kernel, dim3(gv.num_envs), dim3(64), 0, stream, gv, blobs, status, force_all);
 }
 
 }  // namespace mv

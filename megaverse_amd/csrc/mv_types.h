@@ -90,6 +90,7 @@ struct GymView {
     TerrainBox *terrain;       // [N][MAX_TERRAIN]   (Obstacles)
     MovableObject *rewards_obj;// [N][reward_stride] (Obstacles: green diamonds; Collect: green/red diamonds)
     int8_t *heightmap;         // [N][HM_BYTES]      (Collect: top solid y of column x * HM_DIM + z, -1 = no voxels)
+    int32_t *episode_status;   // [N + 2] host-generated scenarios: episodes consumed per env, their total, error flags
     int32_t *actions;          // [N][A] bitmasks
     float *rewards;            // [N*A] as reported by get_last_rewards (0 on done steps)
     uint8_t *done;             // [N]

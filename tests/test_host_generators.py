@@ -112,3 +112,11 @@ def test_episode_length_param_is_honoured():
     assert float(b["episode_len"]) == 10.0 + 2.0 * int(b["num_rewards"])
     b = generate("ObstaclesEasy", 1, 5, 1, base_len=500.0)
     assert float(b["episode_len"]) == 500.0
+
+
+@pytest.mark.parametrize("scenario,threads", [("ObstaclesHard", 1), ("ObstaclesHard", 6), ("Collect", 4)])
+def test_background_feeder_delivers_each_envs_stream_in_order(scenario, threads):
+    """the worker pool (mv_feeder.cpp) against straight sequential generation, 5 episodes x 24 envs, no device involved"""
+    lib = ext.load_library()
+    rc = lib.mv_debug_feeder_selftest(scenario.encode(), 24, 2, threads, 5)
+    assert rc == 0, lib.mv_last_error().decode()

@@ -85,3 +85,26 @@ def test_reward_shaping_keys(hip):
     assert hg.get_reward_shaping(0, 1)["obstaclesAgentCarriedObjectToExit"] == 1.0
     assert hg.get_reward_shaping(0, 1)["obstaclesAllAgentsAtExit"] == 5.0
     og.close(); hg.close()
+
+
+def test_reseed_mid_run_takes_effect_at_the_next_reset(hip):
+    """Env::seed re-seeds the env's stream immediately (env.cpp:52-55): the episode that was generated ahead of time
+    from the old stream must not be used"""
+    N, A = 6, 2
+    og, hg = make_pair(N, A, 32, 32, seed=21, scenario="ObstaclesMedium")
+    for st in range(30):
+        set_same_actions(og, hg, N, A, 5, st)
+        og.step_norender(); hg.step_no_render()
+    og.seed(99); hg.seed(99)
+    og.reset(); hg.reset()
+    for e in range(N):
+        d = diff_snapshots(og.snapshot(e), hip_snapshot(hg, e), A)
+        assert not d, (e, d[:5])
+    for st in range(20):
+        set_same_actions(og, hg, N, A, 6, st)
+        og.step_norender(); hg.step_no_render()
+    og.reset(); hg.reset()
+    for e in range(N):
+        d = diff_snapshots(og.snapshot(e), hip_snapshot(hg, e), A)
+        assert not d, (e, d[:5])
+    og.close(); hg.close()
