@@ -63,7 +63,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs-per-gpu", type=int, default=1024)
     ap.add_argument("--agents", type=int, default=1)
-    ap.add_argument("--scenario", default="TowerBuilding", help="TowerBuilding (headline) or Obstacles{Easy,Medium,Hard,Walls,Steps,Lava}")
+    ap.add_argument("--scenario", default="TowerBuilding",
+                    help="TowerBuilding (headline), Obstacles{Easy,Medium,Hard,Walls,Steps,Lava}, Collect, or Mixed (configs[4])")
     ap.add_argument("--obs", type=int, nargs=2, default=[128, 128], metavar=("W", "H"))
     ap.add_argument("--gather-obs", action="store_true", help="RCCL all-gather of the observation slab every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -90,13 +91,18 @@ def main():
 
     W, H = args.obs
     n_env, A = args.envs_per_gpu, args.agents
-    gym = MegaverseGym(args.scenario, W, H, n_env, A, 8, False, {},   # 8 = episode-feeder threads (host-generated scenarios)
-                       device=local_rank, env_offset=rank * n_env,
-                       total_envs=world * n_env)
-    stream = torch.cuda.current_stream()
-    gym.set_stream(stream.cuda_stream)
-    obs = torch.empty((n_env * A, H, W, 4), dtype=torch.uint8, device=f"cuda:{local_rank}")
-    gym.set_obs_buffer(obs.data_ptr())
+    mixed = args.scenario.lower() == "mixed"
+    if mixed:   # BASELINE.json configs[4]: the in-scope MEGAVERSE8 members dealt round-robin by env index
+        from megaverse_amd.multitask import MEGAVERSE_IN_SCOPE, MultiTaskGym
+        gym = MultiTaskGym(MEGAVERSE_IN_SCOPE, W, H, n_env, A, 8, {}, device=local_rank, env_offset=rank * n_env, total_envs=world * n_env)
+        obs = gym.attach(f"cuda:{local_rank}")
+    else:
+        gym = MegaverseGym(args.scenario, W, H, n_env, A, 8, False, {},   # 8 = episode-feeder threads (host-generated scenarios)
+                           device=local_rank, env_offset=rank * n_env, total_envs=world * n_env)
+        stream = torch.cuda.current_stream()
+        gym.set_stream(stream.cuda_stream)
+        obs = torch.empty((n_env * A, H, W, 4), dtype=torch.uint8, device=f"cuda:{local_rank}")
+        gym.set_obs_buffer(obs.data_ptr())
     gathered = None
     if args.gather_obs and world > 1:
         gathered = torch.empty((world * n_env * A, H, W, 4), dtype=torch.uint8, device=f"cuda:{local_rank}")
@@ -107,6 +113,8 @@ def main():
         gym.sample_random_actions(1234, i)
         gym.step()
         if gathered is not None:
+            if mixed:
+                gym.synchronize()
             dist.all_gather_into_tensor(gathered, obs)
 
     for i in range(args.warmup):
@@ -127,6 +135,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     prof = gym.profile_end()
+    if mixed:   # one profile per scenario: report the sums (the launches overlap on the GPU, so these are upper bounds)
+        prof = {k: (sum(p[k][0] for p in prof), prof[0][k][1]) for k in prof[0]}
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
     if world > 1:
@@ -176,7 +186,7 @@ def main():
                         "frame_setup": {"avg_launch_ms": prof["setup"][0]}},
             "checksum": checksum,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not mixed:   # (the oracle runs one scenario per gym)
             line["cpu_baseline"] = cpu_baseline(args.scenario, W, H, A)
         print(json.dumps(line), flush=True)
 

@@ -39,6 +39,10 @@ typedef struct mv_config {
      * of total_envs; mv_seed() draws the per-env seeds for the whole job so that a sharded run is
      * bit-identical to the single-process run.  0 / 0 = not sharded. */
     int32_t env_offset, total_envs;
+    /* 0 or 1: this process owns a contiguous block.  k > 1: it owns every k-th env starting at env_offset
+     * (global index of local env j = env_offset + j * env_stride): the layout of a multi-task job that deals
+     * scenarios round-robin by env index (megaverse_env.py:27-39, one gym per scenario). */
+    int32_t env_stride;
 } mv_config;
 
 const char *mv_last_error(void);

@@ -62,7 +62,7 @@ static const int ACTION_SPACE[6] = {3, 3, 3, 2, 2, 3};                          
 struct mv_gym {
     int device = 0;
     int w = 0, h = 0, renderW = 768, renderH = 432;   // megaverse.cpp:261
-    int N = 0, A = 0, envOffset = 0, totalEnvs = 0;
+    int N = 0, A = 0, envOffset = 0, envStride = 1, totalEnvs = 0;
     bool closed = false, wasReset = false;
     hipStream_t stream = nullptr;
     GymView gv{};
@@ -137,11 +137,14 @@ __device__ __forceinline__ uint32_t fmix32(uint32_t h)
     return h;
 }
 
-__global__ void sample_actions_kernel(int32_t *masks, int n, uint32_t seed, uint32_t step, uint32_t agentOffset)
+__global__ void sample_actions_kernel(int32_t *masks, int n, uint32_t seed, uint32_t step, uint32_t envOffset, uint32_t envStride, uint32_t A)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t base = fmix32(fmix32(seed ^ fmix32(step + 0x9E3779B9u)) ^ ((agentOffset + (uint32_t)i) * 0x85EBCA6Bu + 1u));
+    // job-wide agent id: a sharded or strided gym draws exactly the actions the single big gym would
+    const uint32_t env = (uint32_t)i / A, agent = (uint32_t)i - env * A;
+    const uint32_t gid = (envOffset + env * envStride) * A + agent;
+    const uint32_t base = fmix32(fmix32(seed ^ fmix32(step + 0x9E3779B9u)) ^ (gid * 0x85EBCA6Bu + 1u));
     const int sizes[6] = {3, 3, 3, 2, 2, 3};
     int32_t a[6];
 #pragma unroll
@@ -276,6 +279,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     g->numShaping = scenario == SCN_TOWER ? 4 : 5;
     g->shapingKeys = scenario == SCN_TOWER ? SHAPING_KEYS_TOWER : scenario == SCN_OBSTACLES ? SHAPING_KEYS_OBST : SHAPING_KEYS_COLLECT;
     g->envOffset = cfg->total_envs > 0 ? cfg->env_offset : 0;
+    g->envStride = cfg->total_envs > 0 && cfg->env_stride > 1 ? cfg->env_stride : 1;
     g->totalEnvs = cfg->total_envs > 0 ? cfg->total_envs : cfg->num_envs;
     const size_t N = g->N, NA = (size_t)g->N * g->A;
 
@@ -470,7 +474,8 @@ int mv_seed(mv_gym *g, int32_t seed)
     std::vector<uint32_t> seeds(g->N);
     for (int i = 0; i < g->totalEnvs; ++i) {
         const int noise = std::uniform_int_distribution<>{0, (1 << 30) - 1}(g->rng);
-        if (i >= g->envOffset && i < g->envOffset + g->N) seeds[i - g->envOffset] = (uint32_t)noise;
+        const int rel = i - g->envOffset;
+        if (rel >= 0 && rel % g->envStride == 0 && rel / g->envStride < g->N) seeds[rel / g->envStride] = (uint32_t)noise;
     }
     if (g->hostEpisodes()) {   // Env::seed (env.cpp:52-55) on the host-side episode generators
         HIP_TRY(hipStreamSynchronize(g->stream));
@@ -618,7 +623,7 @@ int mv_sample_random_actions(mv_gym *g, uint32_t seed, uint32_t step)
     HIP_TRY(hipSetDevice(g->device));
     const int n = g->N * g->A;
     hipLaunchKernelGGL(sample_actions_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, g->gv.actions, n, seed, step,
-                       (uint32_t)(g->envOffset * g->A));
+                       (uint32_t)g->envOffset, (uint32_t)g->envStride, (uint32_t)g->A);
     HIP_TRY(hipGetLastError());
     return 0;
 }

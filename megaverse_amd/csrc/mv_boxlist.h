@@ -19,12 +19,16 @@ struct Objs {          // lane l owns movable box l (k = 0) and, for l < 16, box
 struct Bits128 {       // bit (y + 32) for y in [-32, 95]
     unsigned long long lo, hi;
 };
+__device__ __forceinline__ unsigned long long low_bits(int n)   // n in [0, 64]: the n lowest bits
+{
+    return n >= 64 ? ~0ull : (1ull << n) - 1ull;
+}
 __device__ __forceinline__ void set_range(Bits128 &b, int y0, int y1)   // [y0, y1)
 {
-    for (int y = max(y0, -32); y < min(y1, 96); ++y) {
-        const int i = y + 32;
-        if (i < 64) b.lo |= 1ull << i; else b.hi |= 1ull << (i - 64);
-    }
+    const int lo = min(max(y0 + 32, 0), 128), hi = min(max(y1 + 32, 0), 128);
+    if (lo >= hi) return;
+    b.lo |= low_bits(min(hi, 64)) & ~low_bits(min(lo, 64));
+    b.hi |= low_bits(max(hi - 64, 0)) & ~low_bits(max(lo - 64, 0));
 }
 __device__ __forceinline__ bool test(const Bits128 &b, int y)
 {

@@ -268,10 +268,6 @@ __device__ __forceinline__ int screen_rect(const float *blo, const float *bhi, i
 
 }  // namespace
 
-#ifdef MV_RASTER_STATS
-__device__ unsigned long long g_raster_stats[8];   // tiles, survivors, straddler survivors, nVis sum, frames
-__device__ unsigned long long g_frame_t0[4096], g_frame_t1[4096], g_frame_tp[4096];
-#endif
 
 // ---- pass 1, one workgroup per frame: which primitives can this camera see, and where on the screen?
 __global__ __launch_bounds__(256) void frame_setup_kernel(GymView gv, int W, int H)
@@ -469,9 +465,6 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 ? MV_RASTER_WAVES : 2) void rast
     float *s_colinv = reinterpret_cast<float *>(s_row + H);   // 1/dc.x per column (0 where dc.x == 0)
     float *s_rowinv = s_colinv + W;                            // 1/dc.y per row
 
-#ifdef MV_RASTER_STATS
-    const unsigned long long t_start = wall_clock64();
-#endif
     const int A = gv.num_agents;
     // `split` workgroups share one frame (interleaved tiles): frames differ up to 10x in cost, smaller work
     // units let the dispatcher level the load across CUs.  Workgroup ids are dealt round-robin over the 8 XCDs;
@@ -545,9 +538,6 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 ? MV_RASTER_WAVES : 2) void rast
     const float LIGHT[3] = {0.0f, 4.0f, 2.0f};
     uint32_t *out = obs + (size_t)frame * W * H;
 
-#ifdef MV_RASTER_STATS
-    if (tid == 0 && frame < 4096) { g_frame_t0[frame] = t_start; g_frame_tp[frame] = wall_clock64(); }
-#endif
     const float nzm[3] = {-cam.c[2], -cam.c[5], -cam.c[8]};   // c_k2 * (-1)
 
     for (int tile = part * 4 + wave; tile < numTiles; tile += 4 * split) {
@@ -570,15 +560,6 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 ? MV_RASTER_WAVES : 2) void rast
                 mk[k] = __ballot(v);
             }
         }
-#ifdef MV_RASTER_STATS
-        if (lane == 0) {
-            unsigned long long surv = 0;
-            for (int k = 0; k < ROUNDS; ++k) surv += __popcll(mk[k]);
-            atomicAdd(&g_raster_stats[0], 1ull);
-            atomicAdd(&g_raster_stats[1], surv);
-            if (tile == 0) { atomicAdd(&g_raster_stats[3], (unsigned long long)nVis); atomicAdd(&g_raster_stats[4], 1ull); }
-        }
-#endif
         // ---- this lane's pixel and ray
         const int px = tx0 + (lane & (TILE_W - 1)), py = ty0 + (lane / TILE_W);
         unsigned long long anyMask = 0ull;
@@ -680,27 +661,8 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 ? MV_RASTER_WAVES : 2) void rast
         }
         if (px < W && py < H) out[(size_t)py * W + px] = rgba;
     }
-#ifdef MV_RASTER_STATS
-    if (lane == 0 && frame < 4096) atomicMax(&g_frame_t1[frame], wall_clock64());
-#endif
 }
 
-#ifdef MV_RASTER_STATS
-extern "C" void mv_debug_raster_stats(unsigned long long *out8)
-{
-    hipDeviceSynchronize();
-    hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_raster_stats), sizeof(unsigned long long) * 8);
-}
-extern "C" void mv_debug_raster_times(unsigned long long *t0, unsigned long long *tp, unsigned long long *t1, int n)
-{
-    hipDeviceSynchronize();
-    hipMemcpyFromSymbol(t0, HIP_SYMBOL(g_frame_t0), sizeof(unsigned long long) * n);
-    hipMemcpyFromSymbol(tp, HIP_SYMBOL(g_frame_tp), sizeof(unsigned long long) * n);
-    hipMemcpyFromSymbol(t1, HIP_SYMBOL(g_frame_t1), sizeof(unsigned long long) * n);
-    unsigned long long z[4096] = {0};
-    hipMemcpyToSymbol(HIP_SYMBOL(g_frame_t1), z, sizeof(z));
-}
-#endif
 
 int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream, hipEvent_t between)
 {

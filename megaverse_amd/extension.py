@@ -20,7 +20,7 @@ class _Config(C.Structure):
         ("scenario", C.c_char_p), ("obs_width", C.c_int32), ("obs_height", C.c_int32), ("num_envs", C.c_int32),
         ("num_agents_per_env", C.c_int32), ("num_simulation_threads", C.c_int32), ("use_vulkan", C.c_int32),
         ("device", C.c_int32), ("param_keys", C.POINTER(C.c_char_p)), ("param_vals", C.POINTER(C.c_float)),
-        ("num_params", C.c_int32), ("env_offset", C.c_int32), ("total_envs", C.c_int32),
+        ("num_params", C.c_int32), ("env_offset", C.c_int32), ("total_envs", C.c_int32), ("env_stride", C.c_int32),
     ]
 
 
@@ -100,14 +100,14 @@ class MegaverseGym:
     """Same constructor and methods as the reference's pybind class (megaverse.cpp:267-292)."""
 
     def __init__(self, scenario, w, h, num_envs, num_agents_per_env, num_simulation_threads, use_vulkan, float_params,
-                 device=0, env_offset=0, total_envs=0):
+                 device=0, env_offset=0, total_envs=0, env_stride=1):
         self._lib = load_library()
         fp = dict(float_params or {})
         keys = (C.c_char_p * max(1, len(fp)))(*[k.encode() for k in fp])
         vals = (C.c_float * max(1, len(fp)))(*[float(v) for v in fp.values()])
         self._keep = (keys, vals)
         cfg = _Config(scenario.encode(), int(w), int(h), int(num_envs), int(num_agents_per_env), int(num_simulation_threads),
-                      int(bool(use_vulkan)), int(device), keys, vals, len(fp), int(env_offset), int(total_envs))
+                      int(bool(use_vulkan)), int(device), keys, vals, len(fp), int(env_offset), int(total_envs), int(env_stride))
         handle = _P()
         self._g = None
         if self._lib.mv_create(C.byref(cfg), C.byref(handle)) != 0:

@@ -1,0 +1,115 @@
+"""Multi-task batches: several scenarios stepped side by side on one GPU.
+
+Reference: megaverse/megaverse_env.py:11-39.  The reference runs a multi-task job as one MegaverseGym per scenario
+(``make_env_multitask`` picks ``tasks[task_idx % len(tasks)]`` per worker); BASELINE.json configs[4] deals the scenarios
+round-robin by env index.  ``MultiTaskGym`` owns one HIP gym per scenario, each on its own stream so that the GPU
+overlaps their kernels (a latency-bound physics launch of one scenario runs under the raster of another), and all of
+them write into ONE observation slab, scenario-major: frames of scenario k are rows [k * n_k * A, (k + 1) * n_k * A).
+
+Global env index i  <->  (scenario i % S, local env i // S).  Seeds and the benchmark's random actions are drawn per
+GLOBAL env index (mv_config.env_stride), so the job is bit-identical to S separately seeded single-scenario jobs that
+share one master stream -- and every sub-gym is bit-exact against the oracle by the single-scenario parity tests.
+"""
+import numpy as np
+
+from .extension import MegaverseGym
+
+MEGAVERSE_IN_SCOPE = ["TowerBuilding", "ObstaclesEasy", "ObstaclesHard", "Collect"]   # the MEGAVERSE8 members this build covers
+
+
+class MultiTaskGym:
+    def __init__(self, scenarios, w, h, num_envs, num_agents_per_env, num_simulation_threads=4, float_params=None, device=0,
+                 env_offset=0, total_envs=0):
+        S = len(scenarios)
+        if num_envs % S:
+            raise ValueError("num_envs must be a multiple of the number of scenarios")
+        self.scenarios = list(scenarios)
+        self.w, self.h, self.num_envs, self.num_agents_per_env = int(w), int(h), int(num_envs), int(num_agents_per_env)
+        self.per_task = num_envs // S
+        total = total_envs if total_envs > 0 else num_envs
+        self.gyms = [MegaverseGym(name, w, h, self.per_task, num_agents_per_env, num_simulation_threads, False, float_params or {},
+                                  device=device, env_offset=env_offset + k, total_envs=total, env_stride=S)
+                     for k, name in enumerate(self.scenarios)]
+        self._streams = None
+        self._obs = None
+
+    # ---- plumbing: torch owns the slab and the streams
+    def attach(self, torch_device):
+        import torch
+        A, n = self.num_agents_per_env, self.per_task
+        self._obs = torch.empty((self.num_envs * A, self.h, self.w, 4), dtype=torch.uint8, device=torch_device)
+        self._streams = [torch.cuda.Stream(device=torch_device) for _ in self.gyms]
+        frame_bytes = self.h * self.w * 4
+        for k, g in enumerate(self.gyms):
+            g.set_stream(self._streams[k].cuda_stream)
+            g.set_obs_buffer(self._obs.data_ptr() + k * n * A * frame_bytes)
+        return self._obs
+
+    def locate(self, env_idx):
+        """global env index -> (sub-gym, local env index)"""
+        S = len(self.gyms)
+        return self.gyms[env_idx % S], env_idx // S
+
+    def frame_row(self, env_idx, agent_idx=0):
+        """row of the shared observation slab that holds (global env, agent)"""
+        S, A = len(self.gyms), self.num_agents_per_env
+        return ((env_idx % S) * self.per_task + env_idx // S) * A + agent_idx
+
+    # ---- MegaverseGym surface, env indices are global
+    def num_agents(self):
+        return self.num_envs * self.num_agents_per_env
+
+    def seed(self, seed):
+        for g in self.gyms:
+            g.seed(seed)
+
+    def reset(self):
+        for g in self.gyms:
+            g.reset()
+
+    def set_actions(self, env_idx, agent_idx, actions):
+        g, j = self.locate(env_idx)
+        g.set_actions(j, agent_idx, actions)
+
+    def sample_random_actions(self, seed, step_index):
+        for g in self.gyms:
+            g.sample_random_actions(seed, step_index)
+
+    def step(self):
+        for g in self.gyms:
+            g.step()
+
+    def synchronize(self):
+        for g in self.gyms:
+            g.synchronize()
+
+    def is_done(self, env_idx):
+        g, j = self.locate(env_idx)
+        return g.is_done(j)
+
+    def get_observation(self, env_idx, agent_idx):
+        g, j = self.locate(env_idx)
+        return g.get_observation(j, agent_idx)
+
+    def get_last_rewards(self):
+        """env-major over GLOBAL env indices, like MegaverseGym::getLastRewards (megaverse.cpp:128-137)"""
+        S, A = len(self.gyms), self.num_agents_per_env
+        out = np.empty((self.per_task, S, A), np.float32)
+        for k, g in enumerate(self.gyms):
+            out[:, k, :] = g.get_rewards_array().reshape(self.per_task, A)
+        return out.reshape(-1)
+
+    def true_objective(self, env_idx, agent_idx):
+        g, j = self.locate(env_idx)
+        return g.true_objective(j, agent_idx)
+
+    def profile_begin(self, n):
+        for g in self.gyms:
+            g.profile_begin(n)
+
+    def profile_end(self):
+        return [g.profile_end() for g in self.gyms]
+
+    def close(self):
+        for g in self.gyms:
+            g.close()

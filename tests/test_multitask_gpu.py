@@ -1,0 +1,53 @@
+"""MultiTaskGym (BASELINE.json configs[4] layout: scenarios dealt round-robin by env index, one HIP gym and one stream per
+scenario, one shared observation slab): every sub-gym must simulate exactly the envs of the job-wide seed/action streams."""
+import numpy as np
+import pytest
+
+import oracle_lib
+from hip_util import diff_snapshots, hip_snapshot
+from megaverse_amd.multitask import MEGAVERSE_IN_SCOPE, MultiTaskGym
+from megaverse_amd.rollout import action_masks, sample_actions
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
+
+
+def test_multitask_equals_per_scenario_oracles(hip):
+    import torch
+    N, A, W, H, S = 8, 2, 64, 64, len(MEGAVERSE_IN_SCOPE)
+    mt = MultiTaskGym(MEGAVERSE_IN_SCOPE, W, H, N, A, 2)
+    obs = mt.attach("cuda:0")
+    mt.seed(77); mt.reset()
+    ogs = []
+    for name in MEGAVERSE_IN_SCOPE:   # the oracle has no stride: simulate all N global envs as this scenario, compare the owned ones
+        og = oracle_lib.OracleGym(name, W, H, N, A, 2)
+        og.seed(77); og.reset()
+        ogs.append(og)
+
+    def compare(tag):
+        mt.synchronize()
+        torch.cuda.synchronize()
+        slab = obs.cpu().numpy()
+        for i in range(N):
+            k, j = i % S, i // S
+            d = diff_snapshots(ogs[k].snapshot(i), hip_snapshot(mt.gyms[k], j), A)
+            assert not d, (tag, i, MEGAVERSE_IN_SCOPE[k], d[:4])
+            for a in range(A):
+                assert np.array_equal(ogs[k].get_observation(i, a), slab[mt.frame_row(i, a)]), (tag, i, a)
+
+    compare("reset")
+    for st in range(50):
+        masks = action_masks(sample_actions(1234, st, N * A))
+        for og in ogs:
+            for e in range(N):
+                for a in range(A):
+                    og.set_action_mask(e, a, int(masks[e * A + a]))
+            og.step()
+        mt.sample_random_actions(1234, st)
+        mt.step()
+    compare("after 50 steps")
+    r = mt.get_last_rewards().reshape(N, A)
+    for i in range(N):
+        assert np.array_equal(r[i], ogs[i % S].get_last_rewards().reshape(N, A)[i])
+    for og in ogs:
+        og.close()
+    mt.close()
