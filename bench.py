@@ -186,7 +186,7 @@ def main():
                         "frame_setup": {"avg_launch_ms": prof["setup"][0]}},
             "checksum": checksum,
         }
-        if world == 1 and not args.no_cpu_baseline and not mixed:   # (the oracle runs one scenario per gym)
+        if world == 1 and not args.no_cpu_baseline and not mixed:   # (the CPU baseline runs one scenario per gym)
             line["cpu_baseline"] = cpu_baseline(args.scenario, W, H, A)
         print(json.dumps(line), flush=True)
 

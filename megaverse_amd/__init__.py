@@ -6,3 +6,5 @@ Python surface (megaverse/megaverse_env.py) plus batched / multi-GPU helpers.
 """
 from .extension import MegaverseGym, set_megaverse_log_level, load_library  # noqa: F401
 from .megaverse_env import MegaverseEnv, MEGAVERSE8, OBSTACLES_MULTITASK, make_env_multitask  # noqa: F401
+from .multitask import MultiTaskGym, MEGAVERSE_IN_SCOPE  # noqa: F401
+from .rl import make_megaverse, MEGAVERSE_ENVS  # noqa: F401

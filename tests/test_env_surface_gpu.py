@@ -113,3 +113,36 @@ def test_batched_device_observations(hip):
     one = e.env.get_observation(3, 1)                       # per-frame copy == slice of the slab
     assert np.array_equal(one[:, :, :3].transpose(2, 0, 1), obs[7].cpu().numpy())
     e.close()
+
+
+def test_rl_wrapper_bookkeeping(hip):
+    """megaverse_rl/megaverse_utils.py:30-93: 5-tuple step, per-episode extra stats, team-spirit annealing"""
+    from types import SimpleNamespace
+    from megaverse_amd.rl import MEGAVERSE_ENVS, make_megaverse
+    assert [s.name for s in MEGAVERSE_ENVS][:4] == ["TowerBuilding", "ObstaclesEasy", "ObstaclesHard", "Collect"]
+    cfg = SimpleNamespace(megaverse_num_envs_per_instance=3, megaverse_num_agents_per_env=2, megaverse_num_simulation_threads=1,
+                          megaverse_use_vulkan=False, megaverse_increase_team_spirit=True, megaverse_max_team_spirit_steps=1000.0)
+    env = make_megaverse("TowerBuilding", cfg, img_w=32, img_h=32, params={"episodeLengthSec": -220.0})   # episodes of a few seconds
+    assert env.num_agents == 6 and env.is_multiagent
+    env.seed(3)
+    obs, info = env.reset()
+    assert len(obs) == 6 and obs[0].shape == (3, 32, 32) and info == {}
+    env.set_training_info({"approx_total_training_steps": 250})
+    from megaverse_amd.rollout import sample_actions
+    seen_done = 0
+    for st in range(400):
+        obs, rewards, terminated, truncated, infos = env.step(sample_actions(7, st, 6))
+        assert len(rewards) == 6 and len(terminated) == 6 and truncated == [False] * 6
+        for i, inf in enumerate(infos):
+            if terminated[i]:
+                seen_done += 1
+                st_ = inf["episode_extra_stats"]
+                assert inf["true_objective"] == inf["true_reward"] == st_["z_towerbuilding_true_objective"]
+                assert "z_towerbuilding_reward" in st_ and st_["z_approx_total_training_steps"] == 250
+                assert st_["teamSpirit"] == 0.25 and env.get_current_reward_shaping(i)["teamSpirit"] == 0.25
+            else:
+                assert inf == {}
+    assert seen_done >= 6
+    obs_t, rewards, term, trunc, infos = env.step_batched(sample_actions(7, 999, 6))
+    assert tuple(obs_t.shape) == (6, 3, 32, 32) and obs_t.is_cuda and rewards.shape == (6,) and term.shape == (6,)
+    env.close()
