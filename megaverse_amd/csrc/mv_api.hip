@@ -19,6 +19,7 @@
 #include "../../include/megaverse_hip.h"
 #include "mv_feeder.h"
 #include "mv_gen.h"
+#include "mv_raster.h"
 #include "mv_math.h"
 #include "mv_rng.h"
 #include "mv_types.h"
@@ -26,7 +27,6 @@
 namespace mv {
 void launch_reset(const GymView &gv, int force_all, hipStream_t stream);
 void launch_step(const GymView &gv, hipStream_t stream);
-int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream, hipEvent_t between = nullptr);
 void launch_step_obstacles(const GymView &gv, hipStream_t stream);
 void launch_reset_obstacles(const GymView &gv, const EpisodeBlob *blobs, int *status, int force_all, hipStream_t stream);
 void launch_step_collect(const GymView &gv, hipStream_t stream);
@@ -302,9 +302,10 @@ int mv_create(const mv_config *cfg, mv_gym **out)
                  szRewObj = hostEpisodes ? up(N * (size_t)gv.reward_stride * sizeof(MovableObject)) : 0,
                  szHeight = collect ? up(N * (size_t)HM_BYTES) : 0, szBlobs = up(N * g->blobBytes), szCnt = up((N + 2) * sizeof(int32_t));
     gv.vis_stride = collect ? 1024 : 256;
-    const size_t szVisP = up(NA * (size_t)gv.vis_stride * 32), szVisR = up(NA * (size_t)gv.vis_stride * 8), szVisC = up(NA * sizeof(int32_t));
+    const size_t szVisP = up(NA * (size_t)gv.vis_stride * 32), szVisR = up(NA * (size_t)gv.vis_stride * 8), szVisC = up(NA * sizeof(int32_t)),
+                 szLpt = 2 * up(NA * sizeof(int32_t));
     const size_t total = szHdr + szBoxes + szObj + szAg + szAct + szRew + szDone + szObjv + szMd + (hostEpisodes ? 0 : szChunk) + szObs + szTerrain +
-                         szRewObj + szHeight + szBlobs + szCnt + szVisP + szVisR + szVisC;
+                         szRewObj + szHeight + szBlobs + szCnt + szVisP + szVisR + szVisC + szLpt;
     {
         hipError_t e_ = hipMalloc((void **)&g->arena, total);
         if (e_ != hipSuccess) { mv_destroy(g); return fail(std::string("hipMalloc arena: ") + hipGetErrorString(e_)); }
@@ -334,6 +335,8 @@ int mv_create(const mv_config *cfg, mv_gym **out)
         gv.vis_prims = p; p += szVisP;
         gv.vis_rects = p; p += szVisR;
         gv.vis_count = (int32_t *)p; p += szVisC;
+        gv.lpt_bucket = (int32_t *)p; p += up(NA * sizeof(int32_t));
+        gv.lpt_order = (int32_t *)p; p += up(NA * sizeof(int32_t));
     }
     g->obs = g->ownedObs;
     for (int b = 0; b < 2; ++b) {

@@ -1,0 +1,13 @@
+// megaverse_amd/csrc/mv_raster.h -- host interface of the observation pass (mv_raster.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "mv_types.h"
+
+namespace mv {
+
+// frame setup + frame sort + raster of every agent's W x H observation into `obs` on `stream`; `between` (optional) is
+// recorded between the setup/sort kernels and the raster kernel; -1 if W/H are too large
+int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream, hipEvent_t between = nullptr);
+
+}  // namespace mv

@@ -32,6 +32,7 @@
 #include <stdlib.h>
 
 #include "mv_math.h"
+#include "mv_raster.h"
 #include "mv_types.h"
 
 namespace mv {
@@ -47,6 +48,7 @@ constexpr int TILE_W = 16, TILE_H = 4;
 #define MV_RASTER_WAVES 7   // waves per SIMD the small variant is compiled for (register budget 512 / n)
 #endif
 constexpr int VIS_SMALL = 256, VIS_LARGE = 1024;   // visible primitives kept per frame (TowerBuilding <= 121 slots, Obstacles <= 280; Collect up to ~1300)
+constexpr int LPT_BUCKETS = 256;
 constexpr float CLIP_W = 0.005f;       // NEAR_Z / 2: boxes are clipped against this depth before projecting
 constexpr int MAX_W = 1024, MAX_H = 1024;
 
@@ -273,6 +275,7 @@ __device__ __forceinline__ int screen_rect(const float *blo, const float *bhi, i
 __global__ __launch_bounds__(256) void frame_setup_kernel(GymView gv, int W, int H)
 {
     __shared__ CamL s_cam[MAX_AGENTS];
+    __shared__ int s_cost;                // tiles x primitives the raster pass will have to look at (scheduling estimate)
     __shared__ int s_cnt[8];              // [parity*4 + wave]: visible primitives found by each wave this round
 
     const int A = gv.num_agents;
@@ -282,6 +285,8 @@ __global__ __launch_bounds__(256) void frame_setup_kernel(GymView gv, int W, int
     const EnvHeader *hdr = gv.hdr + env;
     const AgentState *agents = gv.agents + (size_t)env * A;
     const int maxVis = gv.vis_stride;
+    if (tid == 0) s_cost = 0;
+    int myCost = 0;
     Prim *vis = reinterpret_cast<Prim *>(gv.vis_prims) + (size_t)frame * maxVis;
     short4 *rects = reinterpret_cast<short4 *>(gv.vis_rects) + (size_t)frame * maxVis;
 
@@ -444,14 +449,41 @@ __global__ __launch_bounds__(256) void frame_setup_kernel(GymView gv, int W, int
             }
             vis[pos] = p;
             rects[pos] = make_short4((short)rect[0], (short)rect[1], (short)rect[2], (short)rect[3]);
+            myCost += ((rect[1] / TILE_W) - (rect[0] / TILE_W) + 1) * ((rect[3] / TILE_H) - (rect[2] / TILE_H) + 1);
         }
     }
-    if (tid == 0) gv.vis_count[frame] = min(nVis, maxVis);
+    if (myCost) atomicAdd(&s_cost, myCost);
+    __syncthreads();
+    if (tid == 0) {
+        gv.vis_count[frame] = min(nVis, maxVis);
+        // longest-processing-time-first scheduling of the raster pass: frames are binned by estimated cost, the raster
+        // kernel takes them from the most expensive bin down (frames differ several-fold in cost; starting the heavy
+        // ones first keeps the tail of the launch short); frame_order_kernel turns the bins into a permutation
+        const int tiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H);
+        gv.lpt_bucket[frame] = min(LPT_BUCKETS - 1, (16 * s_cost) / max(tiles, 1));   // 1/16 of "one primitive on every tile"
+    }
+}
 
+// ---- pass 1b, one workgroup: counting sort of the frames by cost bin, most expensive first.  (A "last workgroup of
+// frame_setup_kernel does it" variant was slower: its device-scope fences write back every XCD's L2, 22 us vs 6 us.)
+__global__ __launch_bounds__(1024) void frame_order_kernel(GymView gv, int frames, int *order)
+{
+    __shared__ int s_hist[LPT_BUCKETS], s_start[LPT_BUCKETS];
+    const int tid = threadIdx.x;
+    if (tid < LPT_BUCKETS) s_hist[tid] = 0;
+    __syncthreads();
+    for (int f = tid; f < frames; f += 1024) atomicAdd(&s_hist[gv.lpt_bucket[f]], 1);
+    __syncthreads();
+    if (tid == 0) {   // 256 bins: a serial scan is a few hundred cycles, once per step
+        int acc = 0;
+        for (int b = LPT_BUCKETS - 1; b >= 0; --b) { s_start[b] = acc; acc += s_hist[b]; }
+    }
+    __syncthreads();
+    for (int f = tid; f < frames; f += 1024) order[atomicAdd(&s_start[gv.lpt_bucket[f]], 1)] = f;
 }
 
 template <int MAXVIS>
-__global__ __launch_bounds__(256, MAXVIS <= 256 ? MV_RASTER_WAVES : 2) void raster_kernel(GymView gv, uint32_t *obs, int W, int H, int split)
+__global__ __launch_bounds__(256, MAXVIS <= 256 ? MV_RASTER_WAVES : 2) void raster_kernel(GymView gv, uint32_t *obs, int W, int H, int split, const int *order)
 {
     constexpr int ROUNDS = MAXVIS / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // column/row ray tables
@@ -477,6 +509,7 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 ? MV_RASTER_WAVES : 2) void rast
         const int frames = gridDim.x / split;
         if (group * 8 + 8 > frames) { const int b = blockIdx.x - group * per; const int nf = frames - group * 8; frame = group * 8 + b % nf; part = b / nf; }
     }
+    frame = order[frame];   // `frame` so far was a position in the cost-sorted order (most expensive first)
     const int env = frame / A, viewer = frame - env * A;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -664,6 +697,8 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 ? MV_RASTER_WAVES : 2) void rast
 }
 
 
+// One observation pass: frame setup -> frame sort -> raster, on `stream`.  (Running the sort on a side stream from the
+// previous pass's bins was tried: the cross-stream event packets cost more than the 6 us single-workgroup bubble.)
 int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream, hipEvent_t between)
 {
     if (W > MAX_W || H > MAX_H) return -1;
@@ -672,11 +707,13 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
     const int tiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H);
     int split = envSplit > 0 ? envSplit : 4;
     while (split > 1 && tiles < 4 * split * 2) split >>= 1;   // keep at least two tiles per wave
-    hipLaunchKernelGGL(frame_setup_kernel, dim3(gv.num_envs * gv.num_agents), dim3(256), 0, stream, gv, W, H);
+    const int frames = gv.num_envs * gv.num_agents;
+    hipLaunchKernelGGL(frame_setup_kernel, dim3(frames), dim3(256), 0, stream, gv, W, H);
+    hipLaunchKernelGGL(frame_order_kernel, dim3(1), dim3(1024), 0, stream, gv, frames, gv.lpt_order);
     if (between) (void)hipEventRecord(between, stream);
-    const dim3 grid(gv.num_envs * gv.num_agents * split), block(256);
-    if (gv.vis_stride > VIS_SMALL) hipLaunchKernelGGL(raster_kernel<VIS_LARGE>, grid, block, dyn, stream, gv, obs, W, H, split);
-    else hipLaunchKernelGGL(raster_kernel<VIS_SMALL>, grid, block, dyn, stream, gv, obs, W, H, split);
+    const dim3 grid(frames * split), block(256);
+    if (gv.vis_stride > VIS_SMALL) hipLaunchKernelGGL(raster_kernel<VIS_LARGE>, grid, block, dyn, stream, gv, obs, W, H, split, gv.lpt_order);
+    else hipLaunchKernelGGL(raster_kernel<VIS_SMALL>, grid, block, dyn, stream, gv, obs, W, H, split, gv.lpt_order);
     return 0;
 }
 

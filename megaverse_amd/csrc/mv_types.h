@@ -100,6 +100,8 @@ struct GymView {
     void *vis_rects;           // [N*A][vis_stride] short4 screen rectangles
     int32_t *vis_count;        // [N*A]
     int32_t vis_stride;        // 256, or 1024 for Collect
+    int32_t *lpt_bucket;       // [N*A] cost bin of every frame (raster scheduling)
+    int32_t *lpt_order;        // [N*A] frames sorted by cost bin, most expensive first
 };
 
 // One host-generated episode (Obstacles family): everything Env::reset produces, ready to be swapped in by
