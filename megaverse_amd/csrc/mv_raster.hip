@@ -44,6 +44,10 @@ constexpr float TAN_HALF_FOV_Y = 1.19175359f / (128.0f / 72.0f);  // aspect 128/
 constexpr float NEAR_Z = 0.01f, FAR_Z = 120.0f;
 constexpr float OBJ_HALF = 0.39f, CARRY_SCALE = 0.78f;
 constexpr int TILE_W = 16, TILE_H = 4;
+#ifndef MV_RASTER_PPL
+#define MV_RASTER_PPL 1   // 2 was measured: 114 us vs 99 us (bigger tiles keep more survivors, registers cost occupancy)
+#endif
+constexpr int PPL = MV_RASTER_PPL;   // pixels per lane in the raster kernel: a wave's tile is 16 x (4 PPL)
 #ifndef MV_RASTER_WAVES
 #define MV_RASTER_WAVES 7   // waves per SIMD the small variant is compiled for (register budget 512 / n)
 #endif
@@ -566,20 +570,23 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 ? MV_RASTER_WAVES : 2) void rast
 
     const CamL &cam = s_cam[viewer];
     const V3 eye = v3(cam.eye[0], cam.eye[1], cam.eye[2]);
-    const int tilesX = (W + TILE_W - 1) / TILE_W, tilesY = (H + TILE_H - 1) / TILE_H;
+    const int tilesX = (W + TILE_W - 1) / TILE_W, tilesY = (H + TILE_H * PPL - 1) / (TILE_H * PPL);
     const int numTiles = tilesX * tilesY;
     const float LIGHT[3] = {0.0f, 4.0f, 2.0f};
     uint32_t *out = obs + (size_t)frame * W * H;
 
     const float nzm[3] = {-cam.c[2], -cam.c[5], -cam.c[8]};   // c_k2 * (-1)
 
+    // Every lane traces PPL pixels of a 16 x (4 PPL) tile: the rows py, py + 4, ...  (PPL > 1 shares the column terms, the
+    // survivor records and the culling between rays and overlaps their dependency chains -- and lost, see MV_RASTER_PPL.)
     for (int tile = part * 4 + wave; tile < numTiles; tile += 4 * split) {
         const int ty = tile / tilesX, tx = tile - ty * tilesX;
-        const int tx0 = tx * TILE_W, ty0 = ty * TILE_H;
-        const int tx1 = min(tx0 + TILE_W, W) - 1, ty1 = min(ty0 + TILE_H, H) - 1;
+        const int tx0 = tx * TILE_W, ty0 = ty * (TILE_H * PPL);
+        const int tx1 = min(tx0 + TILE_W, W) - 1, ty1 = min(ty0 + TILE_H * PPL, H) - 1;
 
         // ---- tile culling: one primitive per lane per round of 64, four integer compares against its screen rectangle
         unsigned long long mk[ROUNDS];
+        unsigned long long anyMask = 0ull;
 #pragma unroll
         for (int k = 0; k < ROUNDS; ++k) {
             mk[k] = 0ull;
@@ -591,27 +598,39 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 ? MV_RASTER_WAVES : 2) void rast
                     v = r.x <= tx1 && r.y >= tx0 && r.z <= ty1 && r.w >= ty0;
                 }
                 mk[k] = __ballot(v);
+                anyMask |= mk[k];
             }
         }
-        // ---- this lane's pixel and ray
-        const int px = tx0 + (lane & (TILE_W - 1)), py = ty0 + (lane / TILE_W);
-        unsigned long long anyMask = 0ull;
-#pragma unroll
-        for (int k = 0; k < ROUNDS; ++k) anyMask |= mk[k];
+        // ---- this lane's pixels and rays
+        const int px = tx0 + (lane & (TILE_W - 1)), pyBase = ty0 + (lane / TILE_W);
         if (anyMask == 0ull) {   // nothing can be seen through this tile: clear colour (0,0,0), alpha 255
-            if (px < W && py < H) out[(size_t)py * W + px] = 0xff000000u;
+#pragma unroll
+            for (int k = 0; k < PPL; ++k)
+                if (px < W && pyBase + TILE_H * k < H) out[(size_t)(pyBase + TILE_H * k) * W + px] = 0xff000000u;
             continue;
         }
-        const float4 cx = s_col[min(px, W - 1)], ry = s_row[min(py, H - 1)];
-        const V3 dc = v3(cx.x, ry.x, -1.0f);
-        const int pxc = min(px, W - 1), pyc = min(py, H - 1);
-        const V3 dw = v3((cx.y + ry.y) + nzm[0], (cx.z + ry.z) + nzm[1], (cx.w + ry.w) + nzm[2]);
-        const V3 invW = safe_inv(dw);
-        const bool anyZero = __any(dw.x == 0.0f || dw.y == 0.0f || dw.z == 0.0f);
+        const int pxc = min(px, W - 1);
+        const float4 cx = s_col[pxc];
+        const float cxinv = s_colinv[pxc];
+        int pyc[PPL];
+        V3 dc[PPL], dw[PPL], invW[PPL];
+        bool zeroLane = false;
+#pragma unroll
+        for (int k = 0; k < PPL; ++k) {
+            pyc[k] = min(pyBase + TILE_H * k, H - 1);
+            const float4 ry = s_row[pyc[k]];
+            dc[k] = v3(cx.x, ry.x, -1.0f);
+            dw[k] = v3((cx.y + ry.y) + nzm[0], (cx.z + ry.z) + nzm[1], (cx.w + ry.w) + nzm[2]);
+            invW[k] = safe_inv(dw[k]);
+            zeroLane = zeroLane || dw[k].x == 0.0f || dw[k].y == 0.0f || dw[k].z == 0.0f;
+        }
+        const bool anyZero = __any(zeroLane);
 
-        float best = INFINITY;
-        int bestPos = -1, bestSlot = 1 << 30;
-        V3 capN = v3(0, 0, 0);   // normal of the best capsule hit (boxes recompute theirs from the entry axis)
+        float best[PPL];
+        int bestPos[PPL], bestSlot[PPL];
+        V3 capN[PPL];   // normal of the best capsule/cone hit (boxes recompute theirs from the entry axis)
+#pragma unroll
+        for (int k = 0; k < PPL; ++k) { best[k] = INFINITY; bestPos[k] = -1; bestSlot[k] = 1 << 30; capN[k] = v3(0, 0, 0); }
 
 #pragma unroll
         for (int half = 0; half < ROUNDS; ++half) {
@@ -622,79 +641,87 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 ? MV_RASTER_WAVES : 2) void rast
                 const int pos = bit + 64 * half;
                 const Prim &q = s_vis[pos];
                 const int qkind = q.meta & 15, qfr = (q.meta >> 4) & 15;
-                float t; V3 n = v3(0, 0, 0);
-                bool hit;
-                if (qkind == PRIM_CAPSULE) {
-                    hit = ray_capsule(eye, dw, v3(q.lo[0], q.lo[1], q.lo[2]), q.hi[0], q.hi[1], t, n);
-                } else if (qkind == PRIM_CONE) {
-                    hit = ray_cone(eye, dw, v3(q.lo[0], q.lo[1], q.lo[2]), q.hi[0], q.hi[1], q.hi[2], t, n);
-                } else if (qfr == 0) {
-                    hit = anyZero ? ray_box<true>(dw, invW, q.lo, q.hi, t) : ray_box<false>(dw, invW, q.lo, q.hi, t);
-                } else if (qfr == 1 + viewer) {
-                    hit = ray_box<true>(dc, v3(s_colinv[pxc], s_rowinv[pyc], -1.0f), q.lo, q.hi, t);
-                } else {
-                    const V3 dk = mat_tmul(s_cam[qfr - 1].c, dw);
-                    hit = ray_box<true>(dk, safe_inv(dk), q.lo, q.hi, t);
-                }
-                // nearest hit; equal depth -> the primitive drawn first (lowest slot), as a strict "<" scan in slot order would
                 const int qslot = (int)(q.meta >> 8);
-                if (hit && (t < best || (t == best && qslot < bestSlot))) { best = t; bestPos = pos; bestSlot = qslot; capN = n; }
+#pragma unroll
+                for (int k = 0; k < PPL; ++k) {
+                    float t; V3 n = v3(0, 0, 0);
+                    bool hit;
+                    if (qkind == PRIM_CAPSULE) {
+                        hit = ray_capsule(eye, dw[k], v3(q.lo[0], q.lo[1], q.lo[2]), q.hi[0], q.hi[1], t, n);
+                    } else if (qkind == PRIM_CONE) {
+                        hit = ray_cone(eye, dw[k], v3(q.lo[0], q.lo[1], q.lo[2]), q.hi[0], q.hi[1], q.hi[2], t, n);
+                    } else if (qfr == 0) {
+                        hit = anyZero ? ray_box<true>(dw[k], invW[k], q.lo, q.hi, t) : ray_box<false>(dw[k], invW[k], q.lo, q.hi, t);
+                    } else if (qfr == 1 + viewer) {
+                        hit = ray_box<true>(dc[k], v3(cxinv, s_rowinv[pyc[k]], -1.0f), q.lo, q.hi, t);
+                    } else {
+                        const V3 dk = mat_tmul(s_cam[qfr - 1].c, dw[k]);
+                        hit = ray_box<true>(dk, safe_inv(dk), q.lo, q.hi, t);
+                    }
+                    // nearest hit; equal depth -> the primitive drawn first (lowest slot), as a strict "<" scan in slot order would
+                    if (hit && (t < best[k] || (t == best[k] && qslot < bestSlot[k]))) { best[k] = t; bestPos[k] = pos; bestSlot[k] = qslot; capN[k] = n; }
+                }
             }
         }
 
         // ---- Phong (Magnum Shaders::Phong, uniforms of magnum_env_renderer.cpp:200-203)
-        unsigned rgba = 0xff000000u;
-        if (bestPos >= 0) {
-            const Prim &q = s_vis[bestPos];
-            const int qkind = q.meta & 15, qfr = (q.meta >> 4) & 15;
-            V3 N;
-            if (qkind != PRIM_BOX) N = mat_tmul(cam.c, capN);
-            else {
-                V3 d, inv;
-                if (qfr == 0) { d = dw; inv = invW; }
-                else if (qfr == 1 + viewer) { d = dc; inv = v3(s_colinv[pxc], s_rowinv[pyc], -1.0f); }
-                else { d = mat_tmul(s_cam[qfr - 1].c, dw); inv = safe_inv(d); }
-                const int axis = entry_axis(d, inv, q.lo, q.hi, best);
-                const float dax = axis == 0 ? d.x : axis == 1 ? d.y : d.z;
-                const float sgn = dax > 0 ? -1.0f : 1.0f;
-                const V3 n = v3(axis == 0 ? sgn : 0.0f, axis == 1 ? sgn : 0.0f, axis == 2 ? sgn : 0.0f);
-                // C^T (sgn e_axis) == sgn * row `axis` of C (adding exact zeros changes nothing but the sign of a zero)
-                if (qfr == 0) N = v3(sgn * (axis == 0 ? cam.c[0] : axis == 1 ? cam.c[3] : cam.c[6]),
-                                     sgn * (axis == 0 ? cam.c[1] : axis == 1 ? cam.c[4] : cam.c[7]),
-                                     sgn * (axis == 0 ? cam.c[2] : axis == 1 ? cam.c[5] : cam.c[8]));
-                else if (qfr == 1 + viewer) N = n;
-                else N = mat_tmul(cam.c, mat_mul(s_cam[qfr - 1].c, n));
-            }
-            const V3 P = dc * best;
-            V3 Ld = v3(LIGHT[0] - P.x, LIGHT[1] - P.y, LIGHT[2] - P.z);
-            Ld = Ld * (1.0f / sqrtf(len2(Ld)));
-            const float intensity = fmax_sel(0.0f, dot(N, Ld));
-            float spec = 0.0f;
-            if (intensity > 0.001f) {
-                const float k2 = 2.0f * dot(N, Ld);
-                const V3 R = v3(k2 * N.x - Ld.x, k2 * N.y - Ld.y, k2 * N.z - Ld.z);
-                V3 Vd = v3(-P.x, -P.y, -P.z);
-                // shininess 300: cos^300 is below 1e-20 once cos < 0.86, i.e. far under half an ulp of the
-                // diffuse term it is added to (>= 0.04), so the addition is an exact no-op there.  Only
-                // pixels inside the highlight cone pay for the normalisation and the power.
-                const float vr = dot(Vd, R);
-                if (vr > 0.0f && vr * vr > 0.7225f * len2(Vd)) {   // cos > 0.85 (|R| == 1 up to rounding)
-                    Vd = Vd * (1.0f / sqrtf(len2(Vd)));
-                    spec = pow300(fmax_sel(0.0f, dot(Vd, R)));
-                    spec = fmin_sel(fmax_sel(spec, 0.0f), 1.0f);
-                }
-            }
-            unsigned ch[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const unsigned byte = (q.color >> (16 - 8 * c)) & 255u;
-                ch[c] = to_u8((s_lutA[byte] + s_lutD[byte] * intensity) + spec);
+        for (int k = 0; k < PPL; ++k) {
+            unsigned rgba = 0xff000000u;
+            if (bestPos[k] >= 0) {
+                const Prim &q = s_vis[bestPos[k]];
+                const int qkind = q.meta & 15, qfr = (q.meta >> 4) & 15;
+                V3 N;
+                if (qkind != PRIM_BOX) N = mat_tmul(cam.c, capN[k]);
+                else {
+                    V3 d, inv;
+                    if (qfr == 0) { d = dw[k]; inv = invW[k]; }
+                    else if (qfr == 1 + viewer) { d = dc[k]; inv = v3(cxinv, s_rowinv[pyc[k]], -1.0f); }
+                    else { d = mat_tmul(s_cam[qfr - 1].c, dw[k]); inv = safe_inv(d); }
+                    const int axis = entry_axis(d, inv, q.lo, q.hi, best[k]);
+                    const float dax = axis == 0 ? d.x : axis == 1 ? d.y : d.z;
+                    const float sgn = dax > 0 ? -1.0f : 1.0f;
+                    const V3 n = v3(axis == 0 ? sgn : 0.0f, axis == 1 ? sgn : 0.0f, axis == 2 ? sgn : 0.0f);
+                    // C^T (sgn e_axis) == sgn * row `axis` of C (adding exact zeros changes nothing but the sign of a zero)
+                    if (qfr == 0) N = v3(sgn * (axis == 0 ? cam.c[0] : axis == 1 ? cam.c[3] : cam.c[6]),
+                                         sgn * (axis == 0 ? cam.c[1] : axis == 1 ? cam.c[4] : cam.c[7]),
+                                         sgn * (axis == 0 ? cam.c[2] : axis == 1 ? cam.c[5] : cam.c[8]));
+                    else if (qfr == 1 + viewer) N = n;
+                    else N = mat_tmul(cam.c, mat_mul(s_cam[qfr - 1].c, n));
+                }
+                const V3 P = dc[k] * best[k];
+                V3 Ld = v3(LIGHT[0] - P.x, LIGHT[1] - P.y, LIGHT[2] - P.z);
+                Ld = Ld * (1.0f / sqrtf(len2(Ld)));
+                const float intensity = fmax_sel(0.0f, dot(N, Ld));
+                float spec = 0.0f;
+                if (intensity > 0.001f) {
+                    const float k2 = 2.0f * dot(N, Ld);
+                    const V3 R = v3(k2 * N.x - Ld.x, k2 * N.y - Ld.y, k2 * N.z - Ld.z);
+                    V3 Vd = v3(-P.x, -P.y, -P.z);
+                    // shininess 300: cos^300 is below 1e-20 once cos < 0.86, i.e. far under half an ulp of the
+                    // diffuse term it is added to (>= 0.04), so the addition is an exact no-op there.  Only
+                    // pixels inside the highlight cone pay for the normalisation and the power.
+                    const float vr = dot(Vd, R);
+                    if (vr > 0.0f && vr * vr > 0.7225f * len2(Vd)) {   // cos > 0.85 (|R| == 1 up to rounding)
+                        Vd = Vd * (1.0f / sqrtf(len2(Vd)));
+                        spec = pow300(fmax_sel(0.0f, dot(Vd, R)));
+                        spec = fmin_sel(fmax_sel(spec, 0.0f), 1.0f);
+                    }
+                }
+                unsigned ch[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const unsigned byte = (q.color >> (16 - 8 * c)) & 255u;
+                    ch[c] = to_u8((s_lutA[byte] + s_lutD[byte] * intensity) + spec);
+                }
+                rgba = ch[0] | (ch[1] << 8) | (ch[2] << 16) | 0xff000000u;
             }
-            rgba = ch[0] | (ch[1] << 8) | (ch[2] << 16) | 0xff000000u;
+            const int py = pyBase + TILE_H * k;
+            if (px < W && py < H) out[(size_t)py * W + px] = rgba;
         }
-        if (px < W && py < H) out[(size_t)py * W + px] = rgba;
     }
 }
+
 
 
 // One observation pass: frame setup -> frame sort -> raster, on `stream`.  (Running the sort on a side stream from the
@@ -704,7 +731,7 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
     if (W > MAX_W || H > MAX_H) return -1;
     const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)(W + H) * sizeof(float);
     static const int envSplit = getenv("MV_RASTER_SPLIT") ? atoi(getenv("MV_RASTER_SPLIT")) : 0;
-    const int tiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H);
+    const int tiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H * PPL - 1) / (TILE_H * PPL));
     int split = envSplit > 0 ? envSplit : 4;
     while (split > 1 && tiles < 4 * split * 2) split >>= 1;   // keep at least two tiles per wave
     const int frames = gv.num_envs * gv.num_agents;
