@@ -29,6 +29,8 @@ void launch_reset(const GymView &gv, int force_all, hipStream_t stream);
 void launch_step(const GymView &gv, hipStream_t stream);
 void launch_step_obstacles(const GymView &gv, hipStream_t stream);
 void launch_reset_obstacles(const GymView &gv, const EpisodeBlob *blobs, int *status, int force_all, hipStream_t stream);
+void launch_step_rearrange(const GymView &gv, hipStream_t stream);
+void launch_reset_rearrange(const GymView &gv, const RearrangeBlob *blobs, int *status, int force_all, hipStream_t stream);
 void launch_step_collect(const GymView &gv, hipStream_t stream);
 void launch_reset_collect(const GymView &gv, const CollectBlob *blobs, int *status, int force_all, hipStream_t stream);
 }  // namespace mv
@@ -55,6 +57,9 @@ static const char *SHAPING_KEYS_OBST[5] = {"teamSpirit", "obstaclesAgentAtExit",
                                           "obstaclesAgentCarriedObjectToExit"};
 static const float SHAPING_DEFAULT_OBST[5] = {0.0f, 1.0f, 5.0f, 0.5f, 0.0f};
 // scenario_collect.hpp:44-52
+// scenario_rearrange.hpp:96-102
+static const char *SHAPING_KEYS_REARRANGE[3] = {"teamSpirit", "rearrangeOneMoreObjectCorrectPosition", "rearrangeAllObjectsCorrectPosition"};
+static const float SHAPING_DEFAULT_REARRANGE[3] = {0.0f, 1.0f, 10.0f};
 static const char *SHAPING_KEYS_COLLECT[5] = {"teamSpirit", "collectSingleGood", "collectSingleBad", "collectAll", "collectAbyss"};
 static const float SHAPING_DEFAULT_COLLECT[5] = {0.0f, 1.0f, -1.0f, 5.0f, -0.5f};
 static const int ACTION_SPACE[6] = {3, 3, 3, 2, 2, 3};                          // env.cpp:33
@@ -243,6 +248,7 @@ static bool scenario_from_name(const std::string &scen, int &scenario, ObstacleC
         oc.platform_types[0] = scen == "obstacleswalls" ? 1 : scen == "obstaclessteps" ? 3 : 2;
         oc.num_platform_types = 1;
     } else if (scen == "collect") scenario = SCN_COLLECT;                              // scenarios/init.hpp:45
+    else if (scen == "rearrange") scenario = SCN_REARRANGE;                            // scenarios/init.hpp:49
     else return false;
     return true;
 }
@@ -276,8 +282,9 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     g->w = cfg->obs_width; g->h = cfg->obs_height;
     g->N = cfg->num_envs; g->A = cfg->num_agents_per_env;
     g->scenario = scenario;
-    g->numShaping = scenario == SCN_TOWER ? 4 : 5;
-    g->shapingKeys = scenario == SCN_TOWER ? SHAPING_KEYS_TOWER : scenario == SCN_OBSTACLES ? SHAPING_KEYS_OBST : SHAPING_KEYS_COLLECT;
+    g->numShaping = scenario == SCN_TOWER ? 4 : scenario == SCN_REARRANGE ? 3 : 5;
+    g->shapingKeys = scenario == SCN_TOWER ? SHAPING_KEYS_TOWER : scenario == SCN_OBSTACLES ? SHAPING_KEYS_OBST
+                   : scenario == SCN_COLLECT ? SHAPING_KEYS_COLLECT : SHAPING_KEYS_REARRANGE;
     g->envOffset = cfg->total_envs > 0 ? cfg->env_offset : 0;
     g->envStride = cfg->total_envs > 0 && cfg->env_stride > 1 ? cfg->env_stride : 1;
     g->totalEnvs = cfg->total_envs > 0 ? cfg->total_envs : cfg->num_envs;
@@ -285,10 +292,12 @@ int mv_create(const mv_config *cfg, mv_gym **out)
 
     GymView &gv = g->gv;
     gv.num_envs = g->N; gv.num_agents = g->A;
-    const bool obstacles = scenario == SCN_OBSTACLES, collect = scenario == SCN_COLLECT, hostEpisodes = obstacles || collect;
+    const bool obstacles = scenario == SCN_OBSTACLES, collect = scenario == SCN_COLLECT, rearrange = scenario == SCN_REARRANGE;
+    const bool hostEpisodes = obstacles || collect || rearrange;
+    gv.scenario = scenario;
     gv.box_stride = collect ? COLLECT_MAX_BOXES : MAX_BOXES;
     gv.reward_stride = collect ? COLLECT_MAX_REWARDS : MAX_REWARDS;
-    g->blobBytes = collect ? sizeof(CollectBlob) : obstacles ? sizeof(EpisodeBlob) : 0;
+    g->blobBytes = collect ? sizeof(CollectBlob) : obstacles ? sizeof(EpisodeBlob) : rearrange ? sizeof(RearrangeBlob) : 0;
     // ONE arena for all simulator state: a step touches ~8 arrays per env, separate small allocations
     // cost a TLB miss each per wave (measured: 83 % of the physics kernel's time was spent waiting on
     // ~30 memory operations); one large allocation is backed by large pages.
@@ -300,12 +309,12 @@ int mv_create(const mv_config *cfg, mv_gym **out)
                  szObs = up(NA * (size_t)g->w * g->h * 4);
     const size_t szTerrain = obstacles ? up(N * MAX_TERRAIN * sizeof(TerrainBox)) : 0,
                  szRewObj = hostEpisodes ? up(N * (size_t)gv.reward_stride * sizeof(MovableObject)) : 0,
-                 szHeight = collect ? up(N * (size_t)HM_BYTES) : 0, szBlobs = up(N * g->blobBytes), szCnt = up((N + 2) * sizeof(int32_t));
+                 szHeight = collect ? up(N * (size_t)HM_BYTES) : 0, szItems = rearrange ? up(N * MAX_ITEMS * sizeof(ArrangementItem)) : 0, szBlobs = up(N * g->blobBytes), szCnt = up((N + 2) * sizeof(int32_t));
     gv.vis_stride = collect ? 1024 : 256;
     const size_t szVisP = up(NA * (size_t)gv.vis_stride * 32), szVisR = up(NA * (size_t)gv.vis_stride * 8), szVisC = up(NA * sizeof(int32_t)),
                  szLpt = 2 * up(NA * sizeof(int32_t));
     const size_t total = szHdr + szBoxes + szObj + szAg + szAct + szRew + szDone + szObjv + szMd + (hostEpisodes ? 0 : szChunk) + szObs + szTerrain +
-                         szRewObj + szHeight + szBlobs + szCnt + szVisP + szVisR + szVisC + szLpt;
+                         szRewObj + szHeight + szItems + szBlobs + szCnt + szVisP + szVisR + szVisC + szLpt;
     {
         hipError_t e_ = hipMalloc((void **)&g->arena, total);
         if (e_ != hipSuccess) { mv_destroy(g); return fail(std::string("hipMalloc arena: ") + hipGetErrorString(e_)); }
@@ -332,6 +341,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
             g->dBlobs = p; p += szBlobs;
         }
         if (collect) { gv.heightmap = (int8_t *)p; p += szHeight; }
+        if (rearrange) { gv.items = (ArrangementItem *)p; p += szItems; }
         gv.vis_prims = p; p += szVisP;
         gv.vis_rects = p; p += szVisR;
         gv.vis_count = (int32_t *)p; p += szVisC;
@@ -400,6 +410,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
         std::memset(&ha[i], 0, sizeof(AgentState));
         for (int k = 0; k < g->numShaping; ++k)
             ha[i].shaping[k] = scenario == SCN_TOWER ? SHAPING_DEFAULT_TOWER[k] : scenario == SCN_COLLECT ? SHAPING_DEFAULT_COLLECT[k]
+                                                     : scenario == SCN_REARRANGE ? SHAPING_DEFAULT_REARRANGE[k]
                                                      : (k == 4 ? oc.carried_object_to_exit : SHAPING_DEFAULT_OBST[k]);
         ha[i].carrying = -1; ha[i].jump_speed = 10.0f; ha[i].m00 = 1.0f; ha[i].m22 = 1.0f;
     }
@@ -574,6 +585,7 @@ int mv_reset(mv_gym *g)
         g->refillForce = true;
         if (refill_episodes(g)) return -1;              // every env has an unconsumed episode resident
         if (g->scenario == SCN_OBSTACLES) launch_reset_obstacles(g->gv, (const EpisodeBlob *)g->dBlobs, g->dStatus, 1, g->stream);
+        else if (g->scenario == SCN_REARRANGE) launch_reset_rearrange(g->gv, (const RearrangeBlob *)g->dBlobs, g->dStatus, 1, g->stream);
         else launch_reset_collect(g->gv, (const CollectBlob *)g->dBlobs, g->dStatus, 1, g->stream);
         if (read_back_status(g)) return -1;             // the spares for the first auto-resets go up with the next step
     } else
@@ -651,10 +663,12 @@ static int step_impl(mv_gym *g, bool render)
     if (prof) HIP_TRY(hipEventRecord(ev[0], g->stream));
     if (g->scenario == SCN_OBSTACLES) launch_step_obstacles(g->gv, g->stream);
     else if (g->scenario == SCN_COLLECT) launch_step_collect(g->gv, g->stream);
+    else if (g->scenario == SCN_REARRANGE) launch_step_rearrange(g->gv, g->stream);
     else launch_step(g->gv, g->stream);
     if (prof) HIP_TRY(hipEventRecord(ev[1], g->stream));
     if (g->hostEpisodes()) {
         if (g->scenario == SCN_OBSTACLES) launch_reset_obstacles(g->gv, (const EpisodeBlob *)g->dBlobs, g->dStatus, 0, g->stream);
+        else if (g->scenario == SCN_REARRANGE) launch_reset_rearrange(g->gv, (const RearrangeBlob *)g->dBlobs, g->dStatus, 0, g->stream);
         else launch_reset_collect(g->gv, (const CollectBlob *)g->dBlobs, g->dStatus, 0, g->stream);
         if (read_back_status(g)) return -1;
     } else
@@ -850,6 +864,7 @@ struct Snap {
     SnapAgent agents[MAX_AGENTS];
     uint8_t chunk[CHUNK_BYTES];
     int8_t heightmap[HM_DIM * HM_DIM];
+    int32_t num_items, items[MAX_ITEMS][5];
 };
 #pragma pack(pop)
 
@@ -875,9 +890,19 @@ int mv_debug_snapshot(mv_gym *g, int32_t env, void *out)
     std::vector<MovableObject> rew(g->gv.reward_stride);
     if (e == hipSuccess && g->gv.terrain) e = hipMemcpy(terr.data(), g->gv.terrain + (size_t)env * MAX_TERRAIN, MAX_TERRAIN * sizeof(TerrainBox), hipMemcpyDeviceToHost);
     if (e == hipSuccess && g->gv.rewards_obj) e = hipMemcpy(rew.data(), g->gv.rewards_obj + (size_t)env * g->gv.reward_stride, g->gv.reward_stride * sizeof(MovableObject), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && g->gv.items) {
+        std::vector<ArrangementItem> its(MAX_ITEMS);
+        e = hipMemcpy(its.data(), g->gv.items + (size_t)env * MAX_ITEMS, MAX_ITEMS * sizeof(ArrangementItem), hipMemcpyDeviceToHost);
+        s->num_items = h.num_terrain;
+        for (int i = 0; i < h.num_terrain && i < MAX_ITEMS; ++i) {
+            s->items[i][0] = its[i].shape; s->items[i][1] = its[i].color;
+            s->items[i][2] = its[i].off[0]; s->items[i][3] = its[i].off[1]; s->items[i][4] = its[i].off[2];
+        }
+    }
     std::memset(s->heightmap, 0xff, sizeof s->heightmap);
     if (e == hipSuccess && g->gv.heightmap) e = hipMemcpy(s->heightmap, g->gv.heightmap + (size_t)env * HM_BYTES, sizeof s->heightmap, hipMemcpyDeviceToHost);
     if (e != hipSuccess) { delete s; return fail(std::string("mv_debug_snapshot: ") + hipGetErrorString(e)); }
+    if (h.scenario == SCN_REARRANGE) h.num_terrain = 0;   // (the header reuses it for the item count, reported as num_items)
     s->scenario = h.scenario; s->num_terrain = h.num_terrain; s->num_rewards = h.num_rewards; s->num_platforms = h.num_platforms; s->solved = h.solved;
     for (int i = 0; i < h.num_terrain && i < MAX_TERRAIN; ++i) {
         const TerrainBox &t = terr[i];
@@ -928,7 +953,7 @@ int mv_debug_generate_episode(const char *scenario_name, int32_t num_agents, int
     if (!scenario_name || !scenario_from_name(lower(scenario_name), scenario, oc) || scenario == SCN_TOWER)
         return fail("mv_debug_generate_episode: host-generated scenarios are the Obstacles family and Collect");
     if (num_agents < 1 || num_agents > MAX_AGENTS || n < 1) return fail("mv_debug_generate_episode: bad arguments");
-    const size_t bytes = scenario == SCN_COLLECT ? sizeof(CollectBlob) : sizeof(EpisodeBlob);
+    const size_t bytes = scenario == SCN_COLLECT ? sizeof(CollectBlob) : scenario == SCN_REARRANGE ? sizeof(RearrangeBlob) : sizeof(EpisodeBlob);
     if (!out) return (int)bytes;
     if ((size_t)out_bytes < bytes) return fail("mv_debug_generate_episode: buffer too small");
     std::mt19937 rng;
@@ -937,6 +962,7 @@ int mv_debug_generate_episode(const char *scenario_name, int32_t num_agents, int
     for (int i = 0; i < n; ++i) {
         std::memset(buf.data(), 0, bytes);
         if (scenario == SCN_COLLECT) generate_collect_episode(rng, num_agents, base_episode_len, *reinterpret_cast<CollectBlob *>(buf.data()));
+        else if (scenario == SCN_REARRANGE) generate_rearrange_episode(rng, num_agents, base_episode_len, *reinterpret_cast<RearrangeBlob *>(buf.data()));
         else generate_obstacles_episode(rng, oc, num_agents, base_episode_len, *reinterpret_cast<EpisodeBlob *>(buf.data()));
     }
     std::memcpy(out, buf.data(), bytes);
@@ -951,7 +977,7 @@ int mv_debug_feeder_selftest(const char *scenario_name, int32_t num_envs, int32_
     ObstacleConfig oc;
     if (!scenario_name || !scenario_from_name(lower(scenario_name), scenario, oc) || scenario == SCN_TOWER)
         return fail("mv_debug_feeder_selftest: host-generated scenarios only");
-    const size_t bytes = scenario == SCN_COLLECT ? sizeof(CollectBlob) : sizeof(EpisodeBlob);
+    const size_t bytes = scenario == SCN_COLLECT ? sizeof(CollectBlob) : scenario == SCN_REARRANGE ? sizeof(RearrangeBlob) : sizeof(EpisodeBlob);
     std::vector<uint8_t> slots((size_t)num_envs * bytes, 0), want(bytes);
     std::vector<uint32_t> seeds(num_envs);
     for (int i = 0; i < num_envs; ++i) seeds[i] = 1000u + 7u * (uint32_t)i;
@@ -966,6 +992,14 @@ int mv_debug_feeder_selftest(const char *scenario_name, int32_t num_envs, int32_
             const uint8_t *got = feeder.wait_ready(i, r, &used);
             if (!got) return fail("feeder selftest: episode not delivered");
             std::memset(want.data(), 0, bytes);
+            if (scenario == SCN_REARRANGE) {
+                RearrangeBlob &b = *reinterpret_cast<RearrangeBlob *>(want.data());
+                generate_rearrange_episode(rng[i], num_agents, 60.0f, b);
+                b.seq = r;
+                if (std::memcmp(got, &b, sizeof b)) return fail("feeder selftest: Rearrange episode differs from sequential generation");
+                feeder.recycle(i, nullptr);
+                continue;
+            }
             if (scenario == SCN_COLLECT) {
                 CollectBlob &b = *reinterpret_cast<CollectBlob *>(want.data());
                 generate_collect_episode(rng[i], num_agents, 60.0f, b);

@@ -30,6 +30,22 @@ __device__ __forceinline__ void set_range(Bits128 &b, int y0, int y1)   // [y0, 
     b.lo |= low_bits(min(hi, 64)) & ~low_bits(min(lo, 64));
     b.hi |= low_bits(max(hi - 64, 0)) & ~low_bits(max(lo - 64, 0));
 }
+// Where does a box dropped into cell y of a column come to rest?  (ObjectStackingComponent's "descend until the cell below is
+// solid or holds an object, not below y = -30", component_object_stacking.hpp:92-105) -- loop-free: the highest occupied
+// cell below y decides.  `occ` = solid | objects of the column.
+__device__ __forceinline__ int drop_height(const Bits128 &occ, int y)
+{
+    const int idx = min(y + 32, 128);   // bit index of the start cell; everything above the window is free
+    if (idx <= 0) return y;
+    unsigned long long m;
+    if (idx > 64) {
+        m = occ.hi & low_bits(idx - 64);
+        if (m) return (64 + (63 - __clzll((long long)m)) + 1) - 32;
+        m = occ.lo;
+    } else m = occ.lo & low_bits(idx);
+    if (m) return ((63 - __clzll((long long)m)) + 1) - 32;
+    return min(y, -30);
+}
 __device__ __forceinline__ bool test(const Bits128 &b, int y)
 {
     const int i = y + 32;

@@ -72,6 +72,10 @@ void EpisodeFeeder::generate(int env)
         EpisodeBlob &b = *reinterpret_cast<EpisodeBlob *>(slot);
         generate_obstacles_episode(rng_[env], cfg_, num_agents_, base_len_, b);
         b.seq = seq;
+    } else if (scenario_ == SCN_REARRANGE) {
+        RearrangeBlob &b = *reinterpret_cast<RearrangeBlob *>(slot);
+        generate_rearrange_episode(rng_[env], num_agents_, base_len_, b);
+        b.seq = seq;
     } else {
         CollectBlob &b = *reinterpret_cast<CollectBlob *>(slot);
         generate_collect_episode(rng_[env], num_agents_, base_len_, b);

@@ -21,4 +21,7 @@ void generate_obstacles_episode(std::mt19937 &rng, const ObstacleConfig &cfg, in
 // Advances `rng` exactly like Env::reset + CollectScenario::reset + spawnAgents + addEpisodeDrawables and fills `out`.
 void generate_collect_episode(std::mt19937 &rng, int num_agents, float base_episode_len, CollectBlob &out);
 
+// Advances `rng` exactly like Env::reset + RearrangeScenario::reset + spawnAgents + addEpisodeDrawables and fills `out`.
+void generate_rearrange_episode(std::mt19937 &rng, int num_agents, float base_episode_len, RearrangeBlob &out);
+
 }  // namespace mv

@@ -33,6 +33,7 @@
 
 #include "mv_math.h"
 #include "mv_raster.h"
+#include "mv_rearrange.h"
 #include "mv_types.h"
 
 namespace mv {
@@ -58,7 +59,9 @@ constexpr int MAX_W = 1024, MAX_H = 1024;
 
 __constant__ unsigned AGENT_COLORS[7] = {0xffdd3c, 0x3bb372, 0x2eb5d0, 0xffb400, 0xd468ee, 0x222222, 0xff0000};
 
-enum : int { PRIM_NONE = 0, PRIM_BOX = 1, PRIM_CAPSULE = 2, PRIM_CONE = 3 };
+enum : int { PRIM_NONE = 0, PRIM_BOX = 1, PRIM_CAPSULE = 2, PRIM_CONE = 3,
+             PRIM_SPHERE_S = 4, PRIM_CAPSULE_S = 5, PRIM_CYLINDER_S = 6 };   // unit sphere / capsule (r 1, hl 1) / capped cylinder (r 1, hl 0.5),
+                                                                              // scaled by hi, centred at lo in the primitive's frame
 
 struct alignas(16) Prim {   // 32 B, one visible primitive of a frame (written by frame_setup_kernel, read by raster_kernel)
     float lo[3]; uint32_t meta;   // box: bounds minus the ray origin of its frame; capsule: centre (world); cone: apex (world)
@@ -160,6 +163,53 @@ __device__ __forceinline__ bool ray_capsule(V3 o, V3 d, V3 c, float r, float hl,
     }
     if (hit) { t_out = best; n_out = bn; }
     return hit;
+}
+
+// Unit capped cylinder (Primitives::cylinderSolid(.., halfLength 0.5, CapEnds), rendering/src/render_utils.cpp:30): radius 1, |y| <= hl
+__device__ __forceinline__ bool ray_cylinder_unit(V3 o, V3 d, float hl, float &t_out, V3 &n_out)
+{
+    bool hit = false;
+    float best = INFINITY; V3 bn = v3(0, 0, 0);
+    const float A = d.x * d.x + d.z * d.z;
+    if (A > 0.0f) {
+        const float B = o.x * d.x + o.z * d.z;
+        const float C = (o.x * o.x + o.z * o.z) - 1.0f;
+        const float disc = B * B - A * C;
+        if (disc >= 0.0f) {
+            const float t = (-B - sqrtf(disc)) / A;
+            const float y = o.y + t * d.y;
+            if (t >= NEAR_Z && t <= FAR_Z && y >= -hl && y <= hl) { hit = true; best = t; bn = v3(o.x + t * d.x, 0.0f, o.z + t * d.z); }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {   // caps: entered from outside only (back faces are culled)
+        const float cy = s == 0 ? -hl : hl;
+        const bool entering = s == 0 ? (d.y > 0.0f && o.y < cy) : (d.y < 0.0f && o.y > cy);
+        if (entering) {
+            const float t = (cy - o.y) / d.y;
+            const float x = o.x + t * d.x, z = o.z + t * d.z;
+            if (t >= NEAR_Z && t <= FAR_Z && x * x + z * z <= 1.0f && t < best) { hit = true; best = t; bn = v3(0.0f, s == 0 ? -1.0f : 1.0f, 0.0f); }
+        }
+    }
+    if (hit) { t_out = best; n_out = bn; }
+    return hit;
+}
+
+// Scaled shapes: the ray goes into the shape's unit space (diagonal scale: t is unchanged), the unit-space normal comes back
+// through the inverse-transpose scale.  `rel` = shape centre minus the ray origin, both in the primitive's frame.
+__device__ __forceinline__ bool ray_scaled_shape(int kind, V3 d, V3 rel, V3 scale, float &t_out, V3 &n_out)
+{
+    const V3 oo = v3((0.0f - rel.x) / scale.x, (0.0f - rel.y) / scale.y, (0.0f - rel.z) / scale.z);
+    const V3 dd = v3(d.x / scale.x, d.y / scale.y, d.z / scale.z);
+    V3 nl = v3(0, 0, 0);
+    bool hit;
+    if (kind == PRIM_CYLINDER_S) hit = ray_cylinder_unit(oo, dd, 0.5f, t_out, nl);
+    else hit = ray_capsule(oo, dd, v3(0, 0, 0), 1.0f, kind == PRIM_CAPSULE_S ? 1.0f : 0.0f, t_out, nl);
+    if (!hit) return false;
+    V3 n = v3(nl.x / scale.x, nl.y / scale.y, nl.z / scale.z);
+    n = n * (1.0f / sqrtf(len2(n)));
+    n_out = n;
+    return true;
 }
 
 // open cone (no base cap), apex a, axis +-y; only its outside is visible (back-face culling).  Diamonds of the
@@ -315,10 +365,12 @@ __global__ __launch_bounds__(256) void frame_setup_kernel(GymView gv, int W, int
         s_cam[tid].origin[0] = o.x; s_cam[tid].origin[1] = o.y; s_cam[tid].origin[2] = o.z;
     }
     // ---- primitive slots, packed (slot order == the order the reference emits drawables == depth-tie order):
-    //   layout slabs | terrain slabs (TowerBuilding: the building zone) | movable boxes | 2 cones per diamond | 3 per agent
+    //   layout slabs | terrain slabs (TowerBuilding: the building zone; Rearrange: static boxes + target items) | movable boxes / items
+    //   | 2 cones per diamond | 3 per agent
     const int scen = hdr->scenario;
     const int nLayout = hdr->num_boxes;
-    const int slotTerrain = nLayout, nTerrainSlots = scen == SCN_TOWER ? 1 : hdr->num_terrain;
+    const bool rearrange = scen == SCN_REARRANGE;   // its "terrain" slots: 9 static boxes, then the target arrangement's items
+    const int slotTerrain = nLayout, nTerrainSlots = scen == SCN_TOWER ? 1 : rearrange ? NUM_STATIC + hdr->num_terrain : hdr->num_terrain;
     const int slotObjects = slotTerrain + nTerrainSlots;
     const int slotRewards = slotObjects + hdr->num_objects, nRewardSlots = scen == SCN_TOWER ? 0 : 2 * hdr->num_rewards;
     const int slotAgents = slotRewards + nRewardSlots;
@@ -329,6 +381,7 @@ __global__ __launch_bounds__(256) void frame_setup_kernel(GymView gv, int W, int
     // resolved on the slot id).
     int nVis = 0;   // wave-uniform running total
     for (int rd = 0; rd * 256 < numSlots; ++rd) {
+        float ext[3] = {0, 0, 0};   // scaled shapes: half extents of the bounding box
         const int slot = tid + 256 * rd;
         int kind = PRIM_NONE, fr = 0;
         unsigned color = 0;
@@ -343,7 +396,27 @@ __global__ __launch_bounds__(256) void frame_setup_kernel(GymView gv, int W, int
                     color = (unsigned)(b.slot == 0 ? hdr->layout_color : hdr->wall_color);
                 }
             } else if (slot < slotObjects) {
-                if (scen == SCN_TOWER) {   // building-zone slab (layout_utils.cpp:53-68)
+                if (rearrange) {
+                    const int j = slot - slotTerrain;
+                    if (j < NUM_STATIC) {   // raised floor + pedestals (addStaticCollidingBox)
+                        V3 blo3, bhi3;
+                        color = static_box(j, blo3, bhi3);
+                        kind = PRIM_BOX;
+                        lo[0] = blo3.x; lo[1] = blo3.y; lo[2] = blo3.z; hi[0] = bhi3.x; hi[1] = bhi3.y; hi[2] = bhi3.z;
+                    } else {                // the target arrangement on the left pedestal
+                        const ArrangementItem it = gv.items[(size_t)env * MAX_ITEMS + (j - NUM_STATIC)];
+                        const V3 sc = item_draw_scale(it.shape);
+                        const float cx = float(it.off[0] + RE_LEFT_X) + 0.5f, cy = float(it.off[1] + RE_LEFT_Y) + 0.5f, cz = float(it.off[2] + RE_LEFT_Z) + 0.5f;
+                        color = (unsigned)it.color;
+                        if (it.shape == SHAPE_BOX) {
+                            kind = PRIM_BOX;
+                            lo[0] = cx - sc.x; lo[1] = cy - sc.y; lo[2] = cz - sc.z; hi[0] = cx + sc.x; hi[1] = cy + sc.y; hi[2] = cz + sc.z;
+                        } else {
+                            kind = it.shape == SHAPE_SPHERE ? PRIM_SPHERE_S : it.shape == SHAPE_CAPSULE ? PRIM_CAPSULE_S : PRIM_CYLINDER_S;
+                            lo[0] = cx; lo[1] = cy; lo[2] = cz; hi[0] = sc.x; hi[1] = sc.y; hi[2] = sc.z;
+                        }
+                    }
+                } else if (scen == SCN_TOWER) {   // building-zone slab (layout_utils.cpp:53-68)
                     kind = PRIM_BOX;
                     lo[0] = float(hdr->bz[0]); lo[1] = 1.0f; lo[2] = float(hdr->bz[2]);
                     hi[0] = float(hdr->bz[1]); hi[1] = 1.0f + 0.05f; hi[2] = float(hdr->bz[3]);
@@ -359,7 +432,23 @@ __global__ __launch_bounds__(256) void frame_setup_kernel(GymView gv, int W, int
                 const MovableObject o = gv.objects[(size_t)env * MAX_OBJECTS + (slot - slotObjects)];
                 color = 0xadd8e6u;
                 kind = PRIM_BOX;
-                if (o.state <= 0) {
+                if (rearrange) {   // the movable copy of item (slot - slotObjects): standing on the right pedestal or carried
+                    const ArrangementItem it = gv.items[(size_t)env * MAX_ITEMS + (slot - slotObjects)];
+                    V3 sc = item_draw_scale(it.shape);
+                    float cx = float(o.x) + 0.5f, cy = float(o.y) + 0.5f, cz = float(o.z) + 0.5f;
+                    if (o.state > 0) {
+                        fr = (int)o.state;
+                        cx = 0.0f; cy = -0.44f + -0.3f; cz = -1.0f;
+                        sc = v3(sc.x * CARRY_SCALE, sc.y * CARRY_SCALE, sc.z * CARRY_SCALE);
+                    }
+                    color = (unsigned)it.color;
+                    if (it.shape == SHAPE_BOX) {
+                        lo[0] = cx - sc.x; lo[1] = cy - sc.y; lo[2] = cz - sc.z; hi[0] = cx + sc.x; hi[1] = cy + sc.y; hi[2] = cz + sc.z;
+                    } else {
+                        kind = it.shape == SHAPE_SPHERE ? PRIM_SPHERE_S : it.shape == SHAPE_CAPSULE ? PRIM_CAPSULE_S : PRIM_CYLINDER_S;
+                        lo[0] = cx; lo[1] = cy; lo[2] = cz; hi[0] = sc.x; hi[1] = sc.y; hi[2] = sc.z;
+                    }
+                } else if (o.state <= 0) {
                     const float cx = float(o.x) + 0.5f, cy = float(o.y) + 0.5f, cz = float(o.z) + 0.5f;
                     lo[0] = cx - OBJ_HALF; lo[1] = cy - OBJ_HALF; lo[2] = cz - OBJ_HALF;
                     hi[0] = cx + OBJ_HALF; hi[1] = cy + OBJ_HALF; hi[2] = cz + OBJ_HALF;
@@ -417,6 +506,10 @@ __global__ __launch_bounds__(256) void frame_setup_kernel(GymView gv, int W, int
                 const float r = hi[0], hl = hi[1];
                 blo[0] = lo[0] - r; blo[1] = lo[1] - (hl + r); blo[2] = lo[2] - r;
                 bhi[0] = lo[0] + r; bhi[1] = lo[1] + (hl + r); bhi[2] = lo[2] + r;
+            } else if (kind >= PRIM_SPHERE_S) {
+                ext[0] = hi[0]; ext[1] = kind == PRIM_CAPSULE_S ? hi[1] * 2.0f : kind == PRIM_CYLINDER_S ? hi[1] * 0.5f : hi[1]; ext[2] = hi[2];
+                blo[0] = lo[0] - ext[0]; blo[1] = lo[1] - ext[1]; blo[2] = lo[2] - ext[2];
+                bhi[0] = lo[0] + ext[0]; bhi[1] = lo[1] + ext[1]; bhi[2] = lo[2] + ext[2];
             } else if (kind == PRIM_CONE) {
                 const float r = hi[0], h = hi[1];
                 blo[0] = lo[0] - r; blo[2] = lo[2] - r; bhi[0] = lo[0] + r; bhi[2] = lo[2] + r;
@@ -441,12 +534,13 @@ __global__ __launch_bounds__(256) void frame_setup_kernel(GymView gv, int W, int
             Prim p;
             p.meta = (uint32_t)(kind | (fr << 4) | (slot << 8));
             p.color = color;
-            if (kind == PRIM_BOX) {   // bounds relative to the ray origin of the primitive's frame
+            if (kind == PRIM_BOX || kind >= PRIM_SPHERE_S) {   // bounds (scaled shapes: centre) relative to the ray origin of the primitive's frame
                 V3 o = v3(0.0f, 0.0f, 0.0f);
                 if (fr == 0) o = v3(s_cam[viewer].eye[0], s_cam[viewer].eye[1], s_cam[viewer].eye[2]);
                 else if (fr != 1 + viewer) o = v3(s_cam[fr - 1].origin[0], s_cam[fr - 1].origin[1], s_cam[fr - 1].origin[2]);
                 p.lo[0] = lo[0] - o.x; p.lo[1] = lo[1] - o.y; p.lo[2] = lo[2] - o.z;
-                p.hi[0] = hi[0] - o.x; p.hi[1] = hi[1] - o.y; p.hi[2] = hi[2] - o.z;
+                if (kind == PRIM_BOX) { p.hi[0] = hi[0] - o.x; p.hi[1] = hi[1] - o.y; p.hi[2] = hi[2] - o.z; }
+                else { p.hi[0] = hi[0]; p.hi[1] = hi[1]; p.hi[2] = hi[2]; }
             } else {
                 p.lo[0] = lo[0]; p.lo[1] = lo[1]; p.lo[2] = lo[2];
                 p.hi[0] = hi[0]; p.hi[1] = hi[1]; p.hi[2] = hi[2];
@@ -486,8 +580,8 @@ __global__ __launch_bounds__(1024) void frame_order_kernel(GymView gv, int frame
     for (int f = tid; f < frames; f += 1024) order[atomicAdd(&s_start[gv.lpt_bucket[f]], 1)] = f;
 }
 
-template <int MAXVIS>
-__global__ __launch_bounds__(256, MAXVIS <= 256 ? MV_RASTER_WAVES : 2) void raster_kernel(GymView gv, uint32_t *obs, int W, int H, int split, const int *order)
+template <int MAXVIS, bool SHAPES>   // SHAPES: the frame may hold scaled spheres / capsules / cylinders (Rearrange)
+__global__ __launch_bounds__(256, MAXVIS <= 256 && !SHAPES ? MV_RASTER_WAVES : MAXVIS <= 256 ? 5 : 2) void raster_kernel(GymView gv, uint32_t *obs, int W, int H, int split, const int *order)
 {
     constexpr int ROUNDS = MAXVIS / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // column/row ray tables
@@ -650,6 +744,9 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 ? MV_RASTER_WAVES : 2) void rast
                         hit = ray_capsule(eye, dw[k], v3(q.lo[0], q.lo[1], q.lo[2]), q.hi[0], q.hi[1], t, n);
                     } else if (qkind == PRIM_CONE) {
                         hit = ray_cone(eye, dw[k], v3(q.lo[0], q.lo[1], q.lo[2]), q.hi[0], q.hi[1], q.hi[2], t, n);
+                    } else if (SHAPES && qkind >= PRIM_SPHERE_S) {   // n comes back in the primitive's frame
+                        const V3 df = qfr == 0 ? dw[k] : qfr == 1 + viewer ? dc[k] : mat_tmul(s_cam[qfr - 1].c, dw[k]);
+                        hit = ray_scaled_shape(qkind, df, v3(q.lo[0], q.lo[1], q.lo[2]), v3(q.hi[0], q.hi[1], q.hi[2]), t, n);
                     } else if (qfr == 0) {
                         hit = anyZero ? ray_box<true>(dw[k], invW[k], q.lo, q.hi, t) : ray_box<false>(dw[k], invW[k], q.lo, q.hi, t);
                     } else if (qfr == 1 + viewer) {
@@ -672,7 +769,11 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 ? MV_RASTER_WAVES : 2) void rast
                 const Prim &q = s_vis[bestPos[k]];
                 const int qkind = q.meta & 15, qfr = (q.meta >> 4) & 15;
                 V3 N;
-                if (qkind != PRIM_BOX) N = mat_tmul(cam.c, capN[k]);
+                if (qkind != PRIM_BOX) {
+                    if (!SHAPES || qfr == 0) N = mat_tmul(cam.c, capN[k]);
+                    else if (qfr == 1 + viewer) N = capN[k];
+                    else N = mat_tmul(cam.c, mat_mul(s_cam[qfr - 1].c, capN[k]));
+                }
                 else {
                     V3 d, inv;
                     if (qfr == 0) { d = dw[k]; inv = invW[k]; }
@@ -739,8 +840,9 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
     hipLaunchKernelGGL(frame_order_kernel, dim3(1), dim3(1024), 0, stream, gv, frames, gv.lpt_order);
     if (between) (void)hipEventRecord(between, stream);
     const dim3 grid(frames * split), block(256);
-    if (gv.vis_stride > VIS_SMALL) hipLaunchKernelGGL(raster_kernel<VIS_LARGE>, grid, block, dyn, stream, gv, obs, W, H, split, gv.lpt_order);
-    else hipLaunchKernelGGL(raster_kernel<VIS_SMALL>, grid, block, dyn, stream, gv, obs, W, H, split, gv.lpt_order);
+    if (gv.vis_stride > VIS_SMALL) hipLaunchKernelGGL((raster_kernel<VIS_LARGE, false>), grid, block, dyn, stream, gv, obs, W, H, split, gv.lpt_order);
+    else if (gv.scenario == SCN_REARRANGE) hipLaunchKernelGGL((raster_kernel<VIS_SMALL, true>), grid, block, dyn, stream, gv, obs, W, H, split, gv.lpt_order);
+    else hipLaunchKernelGGL((raster_kernel<VIS_SMALL, false>), grid, block, dyn, stream, gv, obs, W, H, split, gv.lpt_order);
     return 0;
 }
 

@@ -211,12 +211,9 @@ __global__ __launch_bounds__(64) void step_collect_kernel(GymView gv)
                 // a diamond's cell counts as empty (its voxel is not solid and holds no physics object)
                 const bool empty = !test(solid, vx[1]) && !test(objs, vx[1]);
                 if (placeable && empty && !collidesWithAgent) {
-                    for (;;) {
-                        const int by = vx[1] - 1;
-                        if (by < -30) break;
-                        if (test(solid, by) || test(objs, by)) break;
-                        vx[1] = by;
-                    }
+                    Bits128 occ = solid;
+                    occ.lo |= objs.lo; occ.hi |= objs.hi;
+                    vx[1] = drop_height(occ, vx[1]);
                     const int oidx = a.carrying;
 #pragma unroll
                     for (int k = 0; k < 2; ++k)

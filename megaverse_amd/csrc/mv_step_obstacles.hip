@@ -178,12 +178,9 @@ __global__ __launch_bounds__(64) void step_obstacles_kernel(GymView gv)
                 const bool solidHere = vx[1] >= 96 || vx[1] < -32 ? false : test(solid, vx[1]);
                 const bool empty = !solidHere && !test(objs, vx[1]);
                 if (placeable && empty && !collidesWithAgent) {
-                    for (;;) {
-                        const int by = vx[1] - 1;
-                        if (by < -30) break;
-                        if (test(solid, by) || test(objs, by)) break;
-                        vx[1] = by;
-                    }
+                    Bits128 occ = solid;
+                    occ.lo |= objs.lo; occ.hi |= objs.hi;
+                    vx[1] = drop_height(occ, vx[1]);
                     const int oidx = a.carrying;
 #pragma unroll
                     for (int k = 0; k < 2; ++k)

@@ -18,7 +18,9 @@ enum : int {
     COLLECT_MAX_BOXES = 1024, COLLECT_MAX_REWARDS = 96, HM_DIM = 42, HM_BYTES = 1792,
 };
 
-enum : int { SCN_TOWER = 0, SCN_OBSTACLES = 1, SCN_COLLECT = 2 };
+enum : int { SCN_TOWER = 0, SCN_OBSTACLES = 1, SCN_COLLECT = 2, SCN_REARRANGE = 3 };
+enum : int { MAX_ITEMS = 8, NUM_STATIC = 9 };                                         // Rearrange: arrangement items, static colliding boxes
+enum : int { SHAPE_BOX = 0, SHAPE_CAPSULE = 1, SHAPE_SPHERE = 2, SHAPE_CYLINDER = 4 };   // DrawableType, env/include/env/env.hpp:58-69
 enum : int { TERRAIN_EXIT = 1, TERRAIN_LAVA = 2, TERRAIN_BUILDING_ZONE = 4 };   // scenarios/platforms.hpp:28-34
 
 // voxel cell byte (reference: env/include/env/voxel_state.hpp:10-37, scenarios/platforms.hpp:28-34)
@@ -41,7 +43,8 @@ struct alignas(16) EnvHeader {   // 128 B
     uint32_t next_seed;                 // value the next Env::reset() re-seeds with (env.cpp:61-62)
     int32_t seed_is_env_seed;           // 1: next_seed is the Env::seed() value, reset must draw first
     float p_episode_len_sec, p_vertical_look_limit;   // float params (scenario.hpp:225-232)
-    int32_t scenario, num_terrain, num_rewards, num_platforms, solved;   // Obstacles family; Collect: num_platforms = number of +1
+    int32_t scenario, num_terrain, num_rewards, num_platforms, solved;   // Obstacles family; Rearrange: num_terrain = items,
+                                                                          // num_platforms = maxMatchingObjects; Collect: num_platforms = number of +1
                                                                           // diamonds, highest_tower = how many of them were collected
     int32_t episodes_consumed;          // how many host-generated episodes this env has taken (refill protocol)
     int32_t starved;                    // set if a reset found no fresh episode (must never happen)
@@ -58,6 +61,12 @@ struct alignas(4) MovableObject {   // 4 B
     int8_t x, y, z;
     int8_t state;   // 0 placed at (x,y,z); 1+k carried by agent k; -1 placed, but its grid cell was erased (Collect).
                     // Reward objects: 0 collected, 1 still there (Collect: 1 = +1 diamond, 2 = -1 diamond)
+};
+
+struct alignas(16) ArrangementItem {   // 32 B (scenario_rearrange.hpp:20-48): one item of the target arrangement; item i's movable copy is objects[i]
+    int32_t shape, color;
+    int32_t off[3];
+    int32_t pad[3];
 };
 
 struct alignas(16) TerrainBox {   // 32 B, voxel units, max exclusive (platforms.hpp terrainBoxes)
@@ -82,6 +91,7 @@ static_assert(sizeof(AgentState) == 128, "AgentState must be 128 B");
 struct GymView {
     int32_t num_envs, num_agents;
     int32_t box_stride, reward_stride;   // MAX_BOXES / MAX_REWARDS, or the COLLECT_ sizes
+    int32_t scenario;                    // SCN_*: one scenario per gym
     EnvHeader *hdr;            // [N]
     LayoutBox *boxes;          // [N][box_stride]
     MovableObject *objects;    // [N][MAX_OBJECTS]
@@ -90,6 +100,7 @@ struct GymView {
     TerrainBox *terrain;       // [N][MAX_TERRAIN]   (Obstacles)
     MovableObject *rewards_obj;// [N][reward_stride] (Obstacles: green diamonds; Collect: green/red diamonds)
     int8_t *heightmap;         // [N][HM_BYTES]      (Collect: top solid y of column x * HM_DIM + z, -1 = no voxels)
+    ArrangementItem *items;    // [N][MAX_ITEMS]     (Rearrange: the target arrangement; hdr.num_terrain holds the item count)
     int32_t *episode_status;   // [N + 2] host-generated scenarios: episodes consumed per env, their total, error flags
     int32_t *actions;          // [N][A] bitmasks
     float *rewards;            // [N*A] as reported by get_last_rewards (0 on done steps)
@@ -118,6 +129,20 @@ struct alignas(16) EpisodeBlob {
     TerrainBox terrain[MAX_TERRAIN];
     MovableObject objects[MAX_OBJECTS];
     MovableObject rewards[MAX_REWARDS];
+};
+
+// Rearrange episode (everything RearrangeScenario::reset + spawnAgents + addEpisodeDrawables draw)
+struct alignas(16) RearrangeBlob {
+    int32_t seq;
+    int32_t num_boxes, num_items, max_matching, draw_walls;
+    int32_t dim[3];
+    float episode_len;
+    int32_t pad[3];
+    int32_t spawn[MAX_AGENTS][3];
+    float yaw_frand[MAX_AGENTS];
+    LayoutBox boxes[TOWER_BOXES];
+    ArrangementItem items[MAX_ITEMS];
+    MovableObject objects[MAX_ITEMS];
 };
 
 // Collect episode.  `boxes` comes last so that only the used prefix needs to travel.

@@ -74,7 +74,9 @@ static const float CARRY_SCALE = 0.78f;               // :63
 enum { CX = 32, CY = 16, CZ = 32, CHUNK = CX * CY * CZ };
 enum { MAX_BOXES = 1024, MAX_OBJECTS = 80, MAX_AGENTS = 8, MAX_TERRAIN = 16, MAX_REWARDS = 96, MAX_SHAPING = 8 };
 enum { HM_DIM = 42 };   // Collect heightfield: maxWidth == maxLength == 42 (scenario_collect.cpp:63)
-enum { SCN_TOWER = 0, SCN_OBSTACLES = 1, SCN_COLLECT = 2 };
+enum { SCN_TOWER = 0, SCN_OBSTACLES = 1, SCN_COLLECT = 2, SCN_REARRANGE = 3 };
+enum { MAX_STATIC = 16, MAX_ITEMS = 8 };   // Rearrange: static colliding boxes, arrangement items (arrangementSize < 8)
+enum { SHAPE_BOX = 0, SHAPE_CAPSULE = 1, SHAPE_SPHERE = 2, SHAPE_CYLINDER = 4 };   // DrawableType, env.hpp:58-69
 enum { TERRAIN_EXIT = 1, TERRAIN_LAVA = 2, TERRAIN_BUILDING_ZONE = 4 };   // scenarios/platforms.hpp:28-34
 static const unsigned COLOR_EXIT_PAD = 0x50c878, COLOR_RED = 0xff0000, COLOR_GREEN = 0x3bb372;   // const.hpp:25-56
 
@@ -190,6 +192,9 @@ static const char *SHAPING_KEYS_OBST[5] = {"teamSpirit", "obstaclesAgentAtExit",
                                           "obstaclesAgentCarriedObjectToExit"};
 static const float SHAPING_DEFAULT_OBST[5] = {0.0f, 1.0f, 5.0f, 0.5f, 0.0f};
 // scenario_collect.hpp:44-52 (+ teamSpirit 0)
+// scenario_rearrange.hpp:96-102 (+ teamSpirit 0)
+static const char *SHAPING_KEYS_REARRANGE[3] = {"teamSpirit", "rearrangeOneMoreObjectCorrectPosition", "rearrangeAllObjectsCorrectPosition"};
+static const float SHAPING_DEFAULT_REARRANGE[3] = {0.0f, 1.0f, 10.0f};
 static const char *SHAPING_KEYS_COLLECT[5] = {"teamSpirit", "collectSingleGood", "collectSingleBad", "collectAll", "collectAbyss"};
 static const float SHAPING_DEFAULT_COLLECT[5] = {0.0f, 1.0f, -1.0f, 5.0f, -0.5f};
 
@@ -206,6 +211,14 @@ struct Env {
     int numShaping = 4;
     const char *const *shapingKeys = SHAPING_KEYS_TOWER;
     int numTerrain = 0, numRewards = 0, numPlatforms = 0, solved = 0;
+    // Rearrange (scenario_rearrange.hpp): the target arrangement (drawn, static, on the left pedestal), the movable copy on the
+    // right pedestal == objects[0..numItems) in item order, the pedestals / raised floor as float boxes; numPlatforms holds
+    // maxMatchingObjects
+    struct ArrItem { int shape; unsigned color; int off[3]; };
+    struct StaticBox { V3 lo, hi; unsigned color; };
+    int numItems = 0, numStatic = 0;
+    ArrItem items[MAX_ITEMS];
+    StaticBox statics[MAX_STATIC];
     // Collect: numPlatforms holds numPositiveRewards, highestTower holds positiveRewardsCollected (scenario_collect.hpp:76)
     std::vector<int8_t> heightmap = std::vector<int8_t>(HM_DIM * HM_DIM, -1);   // [x * HM_DIM + z]: top solid y of the column, -1 = no voxels
     TerrainBox terrain[MAX_TERRAIN];
@@ -948,6 +961,150 @@ static void collect_generate(Env &e)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Rearrange -- scenario_rearrange.{hpp,cpp}.  A fixed 19 x 14 room with a raised floor and two pedestals: the target
+// arrangement (2..7 items: cylinder / capsule / box / sphere in random colours, offsets within +-1, stacked up to
+// two high) stands on the left one, the same items -- partly displaced -- on the right one have to be rebuilt.
+// ------------------------------------------------------------------------------------------------
+static const int RE_LEFT[3] = {5, 2, 5}, RE_RIGHT[3] = {13, 2, 5};   // scenario_rearrange.hpp:130-131
+static const unsigned OBJECT_COLORS[14] = {0xffdd3c, 0x3bb372, 0x50c878, 0x2eb5d0, 0xadd8e6, 0x3a7fa6, 0xffb400,
+                                           0xb3b3b3, 0x555555, 0xffffff, 0xff0000, 0xffa770, 0xd468ee, 0xffe6e6};   // const.hpp:96-111
+
+static Env::ArrItem random_item(Rng &rng, int ox, int oy, int oz)
+{   // ArrangementItem::random, scenario_rearrange.hpp:31-44
+    static const int shapes[4] = {SHAPE_CYLINDER, SHAPE_CAPSULE, SHAPE_BOX, SHAPE_SPHERE};
+    Env::ArrItem it;
+    it.shape = shapes[randRange(0, 4, rng)];
+    it.color = OBJECT_COLORS[randRange(0, 14, rng)];
+    it.off[0] = ox; it.off[1] = oy; it.off[2] = oz;
+    return it;
+}
+
+static int rearrange_matching(const Env &e)
+{   // countMatchingObjects :136-151: movable items that stand (not carried) where the target has the same shape + colour
+    int matching = 0;
+    for (int i = 0; i < e.numItems; ++i) {
+        const Object &o = e.objects[i];
+        if (o.state > 0) continue;
+        const int off[3] = {o.x - RE_RIGHT[0], o.y - RE_RIGHT[1], o.z - RE_RIGHT[2]};
+        for (int k = 0; k < e.numItems; ++k) {
+            const Env::ArrItem &t = e.items[k];
+            if (t.shape == e.items[i].shape && t.color == e.items[i].color && t.off[0] == off[0] && t.off[1] == off[1] && t.off[2] == off[2]) { ++matching; break; }
+        }
+    }
+    return matching;
+}
+
+static void rearrange_generate(Env &e)
+{
+    Rng &rng = e.rng;
+    std::fill(e.chunk.begin(), e.chunk.end(), 0);
+    // RearrangePlatform::init :22-27 ; vg.addPlatform(*platform, DARK_GREY, DARK_GREY, randomBool(rng)) :61
+    const int height = randRange(4, 7, rng), length = 19, width = 14;
+    const bool drawWalls = randomBool(rng);
+    e.L = length; e.H = height; e.W = width;
+    e.bz[0] = e.bz[1] = e.bz[2] = e.bz[3] = 0;
+    e.layoutColor = 0x555555; e.wallColor = 0x555555; e.drawWalls = drawWalls;
+    // floor and walls share the colour: when the walls are drawn they are ONE (type, colour) class and merge together
+    const uint8_t vFloor = VX_SOLID | VX_OPAQUE, vWall = uint8_t(VX_SOLID | (drawWalls ? VX_OPAQUE : 0));
+    fill_box(e, 0, 0, 0, length, 1, width, vFloor);
+    fill_box(e, 0, 0, 0, 1, height, width, vWall);
+    fill_box(e, length - 1, 0, 0, length, height, width, vWall);
+    fill_box(e, 0, 0, 0, length, height, 1, vWall);
+    fill_box(e, 0, 0, width - 1, length, height, width, vWall);
+    merge_boxes(e);
+
+    // generateArrangement :68-127 (breadth-first growth; `directions` keeps being re-shuffled in place)
+    const int arrangementSize = randRange(2, 8, rng);
+    e.numItems = 0;
+    std::vector<Env::ArrItem> queue;
+    size_t head = 0;
+    auto used = [&](int x, int y, int z) {
+        for (int i = 0; i < e.numItems; ++i) if (e.items[i].off[0] == x && e.items[i].off[1] == y && e.items[i].off[2] == z) return true;
+        return false;
+    };
+    e.items[e.numItems++] = random_item(rng, 0, 0, 0);
+    queue.push_back(e.items[0]);
+    std::vector<C3> directions{{-1, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
+    while (head < queue.size()) {
+        const Env::ArrItem curr = queue[head++];
+        int maxBranches = randRange(1, int(directions.size()) + 1, rng);
+        maxBranches = randRange(1, maxBranches + 1, rng);
+        int numBranches = 0;
+        std::shuffle(directions.begin(), directions.end(), rng);
+        for (const C3 dir : directions) {
+            const int nx = curr.off[0] + dir.x, ny = curr.off[1] + dir.y, nz = curr.off[2] + dir.z;
+            if (ny >= 2 || std::abs(nx) >= 2 || std::abs(nz) >= 2) continue;
+            if (used(nx, ny, nz)) continue;
+            if (!(ny == 0 || used(nx, ny - 1, nz))) continue;   // on the floor or on top of another item
+            const Env::ArrItem item = random_item(rng, nx, ny, nz);
+            queue.push_back(item);
+            e.items[e.numItems++] = item;
+            ++numBranches;
+            if (numBranches >= maxBranches) break;
+            if (e.numItems >= arrangementSize) break;
+        }
+        if (e.numItems >= arrangementSize) break;
+    }
+
+    // agentStartingPositions :182-201 (drawn by spawnAgents BEFORE the spawn rotations)
+    std::vector<C3> spawns(e.numAgents, C3{0, 0, 0});
+    for (int i = 0; i < e.numAgents; ++i)
+        for (int attempt = 0; attempt < 20; ++attempt) {
+            const int ax = randRange(2, length - 1, rng), az = randRange(2, width - 1, rng);
+            if (std::abs(ax - RE_LEFT[0]) < 2 && std::abs(az - RE_LEFT[2]) < 2) continue;
+            if (std::abs(ax - RE_RIGHT[0]) < 2 && std::abs(az - RE_RIGHT[2]) < 2) continue;
+            spawns[i] = C3{ax, 2, az};
+            break;
+        }
+    spawn_agents(e, spawns);
+
+    // addEpisodeDrawables :265-299: solid (undrawn, uncollided) voxels under both work areas so that drops stop at y == 2
+    for (int dx = -3; dx <= 3; ++dx)
+        for (int dz = -3; dz <= 3; ++dz)
+            for (const int *c : {RE_LEFT, RE_RIGHT})
+                if (Env::inChunk(c[0] + dx, 1, c[2] + dz)) e.chunk[Env::cell(c[0] + dx, 1, c[2] + dz)] |= VX_SOLID;
+    // arrangementDrawables(right, interactive) :203-263: the first numUnmovedItems stay, the others go to random free floor cells
+    const int numUnmoved = randRange(0, e.numItems, rng);
+    std::vector<C3> occupied;
+    for (int i = 0; i < e.numItems; ++i) occupied.push_back(C3{e.items[i].off[0], e.items[i].off[1], e.items[i].off[2]});
+    auto is_occupied = [&](const C3 &c) { for (const C3 &o : occupied) if (o.x == c.x && o.y == c.y && o.z == c.z) return true; return false; };
+    e.numObjects = e.numItems;
+    for (int i = 0; i < e.numItems; ++i) {
+        C3 off{e.items[i].off[0], e.items[i].off[1], e.items[i].off[2]};
+        if (i >= numUnmoved) {
+            while (is_occupied(off)) off = C3{randRange(-2, 3, rng), 0, randRange(-2, 3, rng)};
+            occupied.push_back(off);
+        }
+        e.objects[i] = Object{off.x + RE_RIGHT[0], off.y + RE_RIGHT[1], off.z + RE_RIGHT[2], 0};
+        if (Env::inChunk(e.objects[i].x, e.objects[i].y, e.objects[i].z)) e.chunk[Env::cell(e.objects[i].x, e.objects[i].y, e.objects[i].z)] |= VX_OBJECT;
+    }
+    e.numPlatforms = rearrange_matching(e);   // maxMatchingObjects :272
+
+    // static colliding boxes :276-298: centre +- half extents, raised floor first, then the two pedestals
+    e.numStatic = 0;
+    auto add_static = [&](V3 half, V3 centre, unsigned color) {
+        Env::StaticBox &b = e.statics[e.numStatic++];
+        b.lo = v3(centre.x - half.x, centre.y - half.y, centre.z - half.z);
+        b.hi = v3(centre.x + half.x, centre.y + half.y, centre.z + half.z);
+        b.color = color;
+    };
+    add_static(v3(8.35f, 0.5f, 5.65f), v3(9.5f + 0.0f, 0.0f + 1.0f, 7.0f + 0.0f), 0x555555);
+    const V3 lc = v3(float(RE_LEFT[0]), float(RE_LEFT[1]), float(RE_LEFT[2])), rc = v3(float(RE_RIGHT[0]), float(RE_RIGHT[1]), float(RE_RIGHT[2]));
+    add_static(v3(3.0f, 0.5f, 3.0f), v3(lc.x + 0.5f, lc.y + -0.5f, lc.z + 0.5f), 0xffffff);
+    add_static(v3(1.5f, 0.5f, 1.5f), v3(lc.x + 0.5f, lc.y + -0.45f, lc.z + 0.5f), 0x555555);
+    add_static(v3(3.0f, 0.5f, 3.0f), v3(lc.x + 1.0f, lc.y + -0.66f, lc.z + 1.0f), 0xffffff);
+    add_static(v3(3.0f, 0.5f, 3.0f), v3(lc.x + 1.5f, lc.y + -0.82f, lc.z + 1.5f), 0xffffff);
+    add_static(v3(3.0f, 0.5f, 3.0f), v3(rc.x + 0.5f, rc.y + -0.5f, rc.z + 0.5f), 0x2eb5d0);
+    add_static(v3(1.5f, 0.5f, 1.5f), v3(rc.x + 0.5f, rc.y + -0.45f, rc.z + 0.5f), 0x555555);
+    add_static(v3(3.0f, 0.5f, 3.0f), v3(rc.x + 0.0f, rc.y + -0.66f, rc.z + 1.0f), 0x2eb5d0);
+    add_static(v3(3.0f, 0.5f, 3.0f), v3(rc.x + -0.5f, rc.y + -0.82f, rc.z + 1.5f), 0x2eb5d0);
+
+    e.numTerrain = 0; e.numRewards = 0; e.solved = 0; e.highestTower = 0; e.bzReward = 0;
+    e.episodeLen = e.p_episodeLengthSec;
+    e.barHalfWidth = 0.24f;
+}
+
 static void env_reset(Env &e)
 {
     // ---- Env::reset, env/src/env.cpp:57-76 ; EnvState::reset env.hpp:135-151
@@ -956,7 +1113,8 @@ static void env_reset(Env &e)
     e.rng.seed((unsigned long)seed);
     if (e.scenario == SCN_TOWER) tower_generate(e);
     else if (e.scenario == SCN_OBSTACLES) obstacles_generate(e);
-    else collect_generate(e);
+    else if (e.scenario == SCN_COLLECT) collect_generate(e);
+    else rearrange_generate(e);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1057,10 +1215,27 @@ static bool convex_cast(const Collider &col, V3 p, V3 d, float *fraction, V3 *no
 
 struct Colliders {
     int n = 0;
-    Collider c[MAX_BOXES + MAX_OBJECTS + MAX_AGENTS];   // empty slots are never emitted: only the relative order matters
+    Collider c[MAX_BOXES + MAX_STATIC + MAX_ITEMS + MAX_OBJECTS + MAX_AGENTS];   // empty slots are never emitted: only the relative order matters
 };
 
-// Collider order == index order used for tie-breaks: layout boxes, movable boxes, agents.
+// Rearrange items (arrangementDrawables, scenario_rearrange.cpp:203-263): drawable scale = scales[shape] * 0.45, collision
+// box = that scale times the collision scale (cylinder (1, 0.5, 1), capsule (1, 2, 1)) -- 0.45 high for every shape.
+static V3 item_draw_scale(int shape)
+{
+    const float s = 0.45f;
+    if (shape == SHAPE_CAPSULE) return v3(0.8f * s, 0.5f * s, 0.8f * s);
+    if (shape == SHAPE_CYLINDER) return v3(0.9f * s, 2.0f * s, 0.9f * s);
+    return v3(1.0f * s, 1.0f * s, 1.0f * s);
+}
+static V3 item_collision_half(int shape)
+{
+    const V3 d = item_draw_scale(shape);
+    if (shape == SHAPE_CAPSULE) return v3(d.x * 1.0f, d.y * 2.0f, d.z * 1.0f);
+    if (shape == SHAPE_CYLINDER) return v3(d.x * 1.0f, d.y * 0.5f, d.z * 1.0f);
+    return d;
+}
+
+// Collider order == index order used for tie-breaks: layout boxes, (Rearrange: static boxes, target items), movable boxes, agents.
 static void build_colliders(const Env &e, int self, Colliders &out)
 {
     out.n = 0;
@@ -1072,7 +1247,27 @@ static void build_colliders(const Env &e, int self, Colliders &out)
         c.lo = v3(float(b.min[0]), float(b.min[1]) - CAP_HH, float(b.min[2]));
         c.hi = v3(float(b.max[0]), float(b.max[1]) + CAP_HH, float(b.max[2]));
     }
-    for (int i = 0; i < e.numObjects; ++i) {
+    if (e.scenario == SCN_REARRANGE) {
+        for (int i = 0; i < e.numStatic; ++i) {   // addStaticCollidingBox, layout_utils.cpp:70-83
+            Collider &c = out.c[out.n++];
+            c.kind = 1;
+            c.lo = v3(e.statics[i].lo.x, e.statics[i].lo.y - CAP_HH, e.statics[i].lo.z);
+            c.hi = v3(e.statics[i].hi.x, e.statics[i].hi.y + CAP_HH, e.statics[i].hi.z);
+        }
+        for (int side = 0; side < 2; ++side)      // target items (static), then the movable ones that are not being carried
+            for (int i = 0; i < e.numItems; ++i) {
+                if (side == 1 && e.objects[i].state > 0) continue;
+                const V3 h = item_collision_half(e.items[i].shape);
+                const float cx = float(side == 0 ? e.items[i].off[0] + RE_LEFT[0] : e.objects[i].x) + 0.5f;
+                const float cy = float(side == 0 ? e.items[i].off[1] + RE_LEFT[1] : e.objects[i].y) + 0.5f;
+                const float cz = float(side == 0 ? e.items[i].off[2] + RE_LEFT[2] : e.objects[i].z) + 0.5f;
+                Collider &c = out.c[out.n++];
+                c.kind = 1;
+                c.lo = v3(cx - h.x, (cy - h.y) - CAP_HH, cz - h.z);
+                c.hi = v3(cx + h.x, (cy + h.y) + CAP_HH, cz + h.z);
+            }
+    }
+    for (int i = 0; i < e.numObjects && e.scenario != SCN_REARRANGE; ++i) {
         if (e.objects[i].state > 0) continue;  // carried boxes: CF_NO_CONTACT_RESPONSE physics.hpp:76-85
         Collider &c = out.c[out.n++];
         const Object &o = e.objects[i];
@@ -1314,7 +1509,7 @@ static void reward_team(Env &e, int key, int idx, float mult)
 // answered from the merged layout boxes / terrain boxes (same set of voxels the reference's hash map holds).
 static bool solid_at(const Env &e, int x, int y, int z)
 {
-    if (e.scenario == SCN_TOWER) return (e.vox(x, y, z) & VX_SOLID) != 0;
+    if (e.scenario == SCN_TOWER || e.scenario == SCN_REARRANGE) return (e.vox(x, y, z) & VX_SOLID) != 0;
     if (e.scenario == SCN_COLLECT)   // heightfield: floor at y == 0, landscape columns above it
         return x >= 0 && x < HM_DIM && z >= 0 && z < HM_DIM && y >= 0 && y <= e.heightmap[x * HM_DIM + z];
     for (int i = 0; i < e.numBoxes; ++i) {
@@ -1341,6 +1536,21 @@ static int object_at(const Env &e, int x, int y, int z)
 }
 
 // component_object_stacking.hpp:58-168 + TowerBuilding callbacks scenario_tower_building.cpp:201-225
+// RearrangeScenario::checkDone, scenario_rearrange.cpp:165-180
+static void rearrange_check_done(Env &e, int idx)
+{
+    const int matches = rearrange_matching(e);
+    if (matches > e.numPlatforms) {
+        reward_team(e, 1, idx, 1);
+        e.numPlatforms = matches;   // maxMatchingObjects
+    }
+    if (matches >= e.numItems && !e.solved) {
+        e.solved = 1;
+        reward_team(e, 2, idx, 1);
+        e.episodeSec = std::max(e.episodeSec, e.episodeLen - 0.3f);   // doneWithTimer()
+    }
+}
+
 static void on_interact(Env &e, int idx)
 {
     Agent &a = e.agents[idx];
@@ -1357,13 +1567,15 @@ static void on_interact(Env &e, int idx)
             if (c[0] == vox[0] && c[1] == vox[1] && c[2] == vox[2]) { collidesWithAgent = true; break; }
         }
         bool placeable, empty, canPlace;
-        if (e.scenario == SCN_TOWER) {
+        const bool chunked = e.scenario == SCN_TOWER || e.scenario == SCN_REARRANGE;
+        if (chunked) {
             // Dense chunk instead of the reference's unbounded hash map: cells outside the chunk in
             // x/z/+y are refused (deviation); below the chunk everything is empty.
             placeable = vox[0] >= 0 && vox[0] < CX && vox[2] >= 0 && vox[2] < CZ && vox[1] < CY;
             const uint8_t v = e.vox(vox[0], vox[1], vox[2]);
             empty = !(v & VX_SOLID) && !(v & VX_OBJECT);
-            canPlace = in_building_zone(e, vox[0], vox[2]);   // scenario_tower_building.cpp:201-204
+            if (e.scenario == SCN_TOWER) canPlace = in_building_zone(e, vox[0], vox[2]);   // scenario_tower_building.cpp:201-204
+            else canPlace = std::abs(vox[0] - RE_RIGHT[0]) <= 2 && std::abs(vox[2] - RE_RIGHT[2]) <= 2;   // scenario_rearrange.cpp:130-134
         } else {
             placeable = vox[1] > -120 && vox[1] < 120;         // int8 object coordinates
             empty = !solid_at(e, vox[0], vox[1], vox[2]) && object_at(e, vox[0], vox[1], vox[2]) < 0;
@@ -1373,7 +1585,7 @@ static void on_interact(Env &e, int idx)
             for (;;) {
                 const int by = vox[1] - 1;
                 if (by < -30) break;
-                if (e.scenario == SCN_TOWER) {
+                if (chunked) {
                     const uint8_t vb = e.vox(vox[0], by, vox[2]);
                     if ((vb & VX_SOLID) || (vb & VX_OBJECT)) break;
                 } else if (solid_at(e, vox[0], by, vox[2]) || object_at(e, vox[0], by, vox[2]) >= 0) break;
@@ -1390,6 +1602,7 @@ static void on_interact(Env &e, int idx)
                 reward_team(e, 3, idx, delta);
                 e.highestTower = std::max(e.highestTower, vox[1] - 1 + 1);
             }
+            if (e.scenario == SCN_REARRANGE) rearrange_check_done(e, idx);   // placedObject :153-157
         }
     } else {
         const V3 pickup = cam_to_world(cam, v3(0.0f, -0.44f, -1.0f));
@@ -1404,6 +1617,7 @@ static void on_interact(Env &e, int idx)
                 a.carrying = oi;
                 // pickedObject :216-225 (TowerBuilding only; the Obstacles callbacks are no-ops)
                 if (e.scenario == SCN_TOWER && !a.picked_up) { reward_agent(e, 1, idx, 1); a.picked_up = 1; }
+                if (e.scenario == SCN_REARRANGE) rearrange_check_done(e, idx);   // pickedObject :159-163
                 break;
             }
             vox[1] += 1;
@@ -1474,7 +1688,7 @@ static void env_step(Env &e)
         a.hvx = a.hvz = 0; a.vvel = 0;
     };
     for (int i = 0; i < e.numAgents; ++i)  // component_fall_detection.hpp:33-43
-        if (e.agents[i].pos.y + 0.05f < -20.0f) {
+        if (e.scenario != SCN_REARRANGE && e.agents[i].pos.y + 0.05f < -20.0f) {   // (Rearrange has no FallDetectionComponent)
             reset_agent(e.agents[i]);
             if (e.scenario == SCN_COLLECT) reward_agent(e, 2, i, 1);   // CollectScenario::agentFell, scenario_collect.cpp:214-218
         }
@@ -1503,6 +1717,8 @@ static void env_step(Env &e)
                         e.objects[o].state = -1;
             }
         }
+    } else if (e.scenario == SCN_REARRANGE) {
+        // RearrangeScenario::step is objectStackingComponent.step only (:125-128)
     } else if (e.scenario == SCN_TOWER) {
         for (int i = 0; i < e.numAgents; ++i) {
             Agent &a = e.agents[i];
@@ -1569,7 +1785,9 @@ static const float TAN_HALF_FOV_Y = 1.19175359f / (128.0f / 72.0f);
 static const float NEAR_Z = 0.01f, FAR_Z = 120.0f;
 
 struct Prim {
-    int kind;   // 1 = box in frame `frame`, 2 = vertical capsule in world, 3 = cone in world (lo = apex, hi = (radius, height, +1 apex up / -1 apex down))
+    int kind;   // 1 = box in frame `frame`, 2 = vertical capsule in world, 3 = cone in world (lo = apex, hi = (radius, height, +1 apex up / -1 apex down)),
+                // 4 / 5 / 6 = unit sphere / unit capsule (r 1, half-length 1) / unit capped cylinder (r 1, half-length 0.5), axis y,
+                //             scaled by hi and centred at lo in frame `frame`
     int frame;  // -1 world axes, k>=0: camera frame of agent k
     V3 lo, hi;  // box bounds in its frame; capsule: lo = centre, hi = (radius, halfLen, 0)
     unsigned color;
@@ -1602,7 +1820,30 @@ static void build_prims(const Env &e, int viewer, std::vector<Prim> &out)
         p.color = t.type == TERRAIN_EXIT ? COLOR_EXIT_PAD : COLOR_RED;   // platforms.hpp:47-56
         out.push_back(p);
     }
-    for (int i = 0; i < e.numObjects; ++i) {  // component_object_stacking.hpp:170-198, :146-152
+    if (e.scenario == SCN_REARRANGE) {
+        for (int i = 0; i < e.numStatic; ++i) {   // addStaticCollidingBox, layout_utils.cpp:70-83
+            Prim p; p.kind = 1; p.frame = -1; p.lo = e.statics[i].lo; p.hi = e.statics[i].hi; p.color = e.statics[i].color;
+            out.push_back(p);
+        }
+        for (int side = 0; side < 2; ++side)      // arrangementDrawables :203-263: target (left), then the movable copy (right)
+            for (int i = 0; i < e.numItems; ++i) {
+                const Env::ArrItem &it = e.items[i];
+                V3 sc = item_draw_scale(it.shape);
+                Prim p; p.color = it.color;
+                V3 c;
+                if (side == 0) { p.frame = -1; c = v3(float(it.off[0] + RE_LEFT[0]) + 0.5f, float(it.off[1] + RE_LEFT[1]) + 0.5f, float(it.off[2] + RE_LEFT[2]) + 0.5f); }
+                else if (e.objects[i].state <= 0) { p.frame = -1; c = v3(float(e.objects[i].x) + 0.5f, float(e.objects[i].y) + 0.5f, float(e.objects[i].z) + 0.5f); }
+                else {   // carried: scaled by 0.78 and hung in front of the carrier's camera (component_object_stacking.hpp:146-152)
+                    p.frame = e.objects[i].state - 1;
+                    c = v3(0.0f, -0.44f + -0.3f, -1.0f);
+                    sc = v3(sc.x * CARRY_SCALE, sc.y * CARRY_SCALE, sc.z * CARRY_SCALE);
+                }
+                if (it.shape == SHAPE_BOX) { p.kind = 1; p.lo = v3(c.x - sc.x, c.y - sc.y, c.z - sc.z); p.hi = v3(c.x + sc.x, c.y + sc.y, c.z + sc.z); }
+                else { p.kind = it.shape == SHAPE_SPHERE ? 4 : it.shape == SHAPE_CAPSULE ? 5 : 6; p.lo = c; p.hi = sc; }
+                out.push_back(p);
+            }
+    }
+    for (int i = 0; i < e.numObjects && e.scenario != SCN_REARRANGE; ++i) {  // component_object_stacking.hpp:170-198, :146-152
         const Object &o = e.objects[i];
         Prim p; p.kind = 1; p.color = COLOR_MOVABLE_BOX;
         if (o.state <= 0) {
@@ -1724,6 +1965,51 @@ static bool ray_capsule(V3 o, V3 d, V3 c, float r, float hl, float *t_out, V3 *n
     return hit;
 }
 
+// Unit capped cylinder (Primitives::cylinderSolid(.., halfLength 0.5, CapEnds), render_utils.cpp:30): radius 1, |y| <= hl.
+static bool ray_cylinder_unit(V3 o, V3 d, float hl, float *t_out, V3 *n_out)
+{
+    bool hit = false;
+    float best = INFINITY; V3 bn = v3(0, 0, 0);
+    const float A = d.x * d.x + d.z * d.z;
+    if (A > 0.0f) {
+        const float B = o.x * d.x + o.z * d.z;
+        const float C = (o.x * o.x + o.z * o.z) - 1.0f;
+        const float disc = B * B - A * C;
+        if (disc >= 0.0f) {
+            const float t = (-B - sqrtf(disc)) / A;
+            const float y = o.y + t * d.y;
+            if (t >= NEAR_Z && t <= FAR_Z && y >= -hl && y <= hl) { hit = true; best = t; bn = v3(o.x + t * d.x, 0.0f, o.z + t * d.z); }
+        }
+    }
+    for (int s = 0; s < 2; ++s) {   // caps: entered from outside only (back faces are culled)
+        const float cy = s == 0 ? -hl : hl;
+        const bool entering = s == 0 ? (d.y > 0.0f && o.y < cy) : (d.y < 0.0f && o.y > cy);
+        if (!entering) continue;
+        const float t = (cy - o.y) / d.y;
+        const float x = o.x + t * d.x, z = o.z + t * d.z;
+        if (t >= NEAR_Z && t <= FAR_Z && x * x + z * z <= 1.0f && t < best) { hit = true; best = t; bn = v3(0.0f, s == 0 ? -1.0f : 1.0f, 0.0f); }
+    }
+    if (hit) { *t_out = best; *n_out = bn; }
+    return hit;
+}
+
+// kinds 4 / 5 / 6: the ray is taken into the shape's unit space (the scale is diagonal, so t is unchanged), the unit-space
+// normal comes back through the inverse-transpose scale
+static bool ray_scaled_shape(int kind, V3 o, V3 d, V3 centre, V3 scale, float *t_out, V3 *n_out)
+{
+    const V3 oo = v3((o.x - centre.x) / scale.x, (o.y - centre.y) / scale.y, (o.z - centre.z) / scale.z);
+    const V3 dd = v3(d.x / scale.x, d.y / scale.y, d.z / scale.z);
+    V3 nl;
+    bool hit;
+    if (kind == 6) hit = ray_cylinder_unit(oo, dd, 0.5f, t_out, &nl);
+    else hit = ray_capsule(oo, dd, v3(0, 0, 0), 1.0f, kind == 5 ? 1.0f : 0.0f, t_out, &nl);
+    if (!hit) return false;
+    V3 n = v3(nl.x / scale.x, nl.y / scale.y, nl.z / scale.z);
+    n = n * (1.0f / sqrtf(len2(n)));
+    *n_out = n;
+    return true;
+}
+
 // Open cone (no base cap, Primitives::coneSolid without CapEnd): apex a, axis +-y (dirSign +1: apex up),
 // height h, base radius r.  Only the outside is visible (back-face culling).
 static bool ray_cone(V3 o, V3 d, V3 a, float r, float h, float dirSign, float *t_out, V3 *n_out)
@@ -1814,6 +2100,17 @@ static void render_agent(const Env &e, int viewer, int W, int H, uint8_t *out)
                 } else if (p.kind == 3) {
                     hit = ray_cone(cam.eye, dw, p.lo, p.hi.x, p.hi.y, p.hi.z, &t, &n);
                     if (hit) n = mat_tmul(cam.c, n);
+                } else if (p.kind >= 4) {
+                    if (p.frame < 0) {
+                        hit = ray_scaled_shape(p.kind, cam.eye, dw, p.lo, p.hi, &t, &n);
+                        if (hit) n = mat_tmul(cam.c, n);
+                    } else if (p.frame == viewer) {
+                        hit = ray_scaled_shape(p.kind, v3(0, 0, 0), dc, p.lo, p.hi, &t, &n);
+                    } else {
+                        const V3 dk = mat_tmul(cams[p.frame].c, dw);
+                        hit = ray_scaled_shape(p.kind, originIn[p.frame], dk, p.lo, p.hi, &t, &n);
+                        if (hit) n = mat_tmul(cam.c, mat_mul(cams[p.frame].c, n));
+                    }
                 } else if (p.frame < 0) {
                     hit = ray_box(cam.eye, dw, p.lo, p.hi, &t, &n);
                     if (hit) n = mat_tmul(cam.c, n);
@@ -1930,6 +2227,7 @@ mvo_gym *mvo_create(const char *scenario, int w, int h, int num_envs, int num_ag
         op.minHeight = 1; op.maxHeight = 3; carriedDefault = 1.0f;
         op.platformTypes = {s == "obstacleswalls" ? PT_WALL : s == "obstaclessteps" ? PT_STEP : PT_LAVA};
     } else if (s == "collect") scen = SCN_COLLECT;   // scenarios/init.hpp:45
+    else if (s == "rearrange") scen = SCN_REARRANGE;   // scenarios/init.hpp:49
     else { fprintf(stderr, "mv_oracle: unknown scenario %s\n", s.c_str()); return nullptr; }
     if (num_agents_per_env < 1 || num_agents_per_env > MAX_AGENTS || num_envs < 1) return nullptr;
     auto *g = new mvo_gym();
@@ -1948,13 +2246,15 @@ mvo_gym *mvo_create(const char *scenario, int w, int h, int num_envs, int num_ag
         }
         e->scenario = scen;
         e->op = op;
-        e->numShaping = scen == SCN_TOWER ? 4 : 5;
-        e->shapingKeys = scen == SCN_TOWER ? SHAPING_KEYS_TOWER : scen == SCN_OBSTACLES ? SHAPING_KEYS_OBST : SHAPING_KEYS_COLLECT;
+        e->numShaping = scen == SCN_TOWER ? 4 : scen == SCN_REARRANGE ? 3 : 5;
+        e->shapingKeys = scen == SCN_TOWER ? SHAPING_KEYS_TOWER : scen == SCN_OBSTACLES ? SHAPING_KEYS_OBST
+                       : scen == SCN_COLLECT ? SHAPING_KEYS_COLLECT : SHAPING_KEYS_REARRANGE;
         for (int a = 0; a < MAX_AGENTS; ++a) {
             std::memset(e->agents[a].shaping, 0, sizeof e->agents[a].shaping);
             for (int k = 0; k < e->numShaping; ++k)
                 e->agents[a].shaping[k] = scen == SCN_TOWER ? SHAPING_DEFAULT_TOWER[k]
                                         : scen == SCN_COLLECT ? SHAPING_DEFAULT_COLLECT[k]
+                                        : scen == SCN_REARRANGE ? SHAPING_DEFAULT_REARRANGE[k]
                                         : (k == 4 ? carriedDefault : SHAPING_DEFAULT_OBST[k]);
         }
         g->envs.push_back(std::move(e));
@@ -2043,6 +2343,7 @@ struct SnapHeader {
     SnapAgent agents[MAX_AGENTS];
     uint8_t chunk[CHUNK];
     int8_t heightmap[HM_DIM * HM_DIM];
+    int32_t num_items, items[MAX_ITEMS][5];   // Rearrange: shape, colour, offset x y z
 };
 #pragma pack(pop)
 
@@ -2092,6 +2393,11 @@ void mvo_snapshot(mvo_gym *g, int env, void *out)
     }
     std::memcpy(s->chunk, e.chunk.data(), CHUNK);
     std::memcpy(s->heightmap, e.heightmap.data(), HM_DIM * HM_DIM);
+    s->num_items = e.scenario == SCN_REARRANGE ? e.numItems : 0;
+    for (int i = 0; i < s->num_items; ++i) {
+        s->items[i][0] = e.items[i].shape; s->items[i][1] = (int32_t)e.items[i].color;
+        s->items[i][2] = e.items[i].off[0]; s->items[i][3] = e.items[i].off[1]; s->items[i][4] = e.items[i].off[2];
+    }
     std::memcpy(out, s, sizeof *s);
     delete s;
 }

@@ -28,10 +28,18 @@ COLLECT_BLOB = np.dtype([
 ], align=False)
 
 
+ITEM = np.dtype([("shape", "<i4"), ("color", "<i4"), ("off", "<i4", 3), ("pad", "<i4", 3)])
+REARRANGE_BLOB = np.dtype([
+    ("seq", "<i4"), ("num_boxes", "<i4"), ("num_items", "<i4"), ("max_matching", "<i4"), ("draw_walls", "<i4"), ("dim", "<i4", 3),
+    ("episode_len", "<f4"), ("pad", "<i4", 3), ("spawn", "<i4", (MAX_AGENTS, 3)), ("yaw_frand", "<f4", MAX_AGENTS),
+    ("boxes", LAYOUT_BOX, 16), ("items", ITEM, 8), ("objects", OBJ, 8),
+], align=False)
+
+
 def generate(scenario, agents, env_seed, n, base_len=60.0):
     lib = ext.load_library()
     size = lib.mv_debug_generate_episode(scenario.encode(), agents, env_seed, n, base_len, None, 0)
-    dt = COLLECT_BLOB if scenario.lower() == "collect" else EPISODE_BLOB
+    dt = COLLECT_BLOB if scenario.lower() == "collect" else REARRANGE_BLOB if scenario.lower() == "rearrange" else EPISODE_BLOB
     assert size == dt.itemsize, (size, dt.itemsize)
     buf = np.zeros(1, dt)
     assert lib.mv_debug_generate_episode(scenario.encode(), agents, env_seed, n, base_len, buf.ctypes.data, size) == size
@@ -107,6 +115,40 @@ def test_collect_generator_matches_oracle(agents):
     og.close()
 
 
+@pytest.mark.parametrize("agents", [1, 2, 8])
+def test_rearrange_generator_matches_oracle(agents):
+    n_env, master = 48, 31 + agents
+    og = oracle_lib.OracleGym("Rearrange", 32, 32, n_env, agents, 2)
+    og.seed(master)
+    seeds = env_seeds(master, n_env)
+    walls = set()
+    for episode in (1, 2, 3):
+        og.reset()
+        for e in range(n_env):
+            blob, snap = generate("Rearrange", agents, int(seeds[e]), episode), og.snapshot(e)
+            nb = int(snap["num_boxes"])
+            assert int(blob["num_boxes"]) == nb == 5
+            b = blob["boxes"][:nb]
+            got = np.concatenate([b["min"], b["max"], b["type"][:, None], b["slot"][:, None]], axis=1)
+            assert np.array_equal(got, snap["boxes"][:nb]), (got.tolist(), snap["boxes"][:nb].tolist())
+            ni = int(snap["num_items"])
+            assert int(blob["num_items"]) == ni == int(snap["num_objects"]) and 1 <= ni <= 7
+            it = blob["items"][:ni]
+            assert np.array_equal(np.concatenate([it["shape"][:, None], it["color"][:, None], it["off"]], 1), snap["items"][:ni])
+            o = blob["objects"][:ni]
+            assert np.array_equal(np.stack([o["x"], o["y"], o["z"], o["state"]], 1), snap["objects"][:ni])
+            assert int(blob["max_matching"]) == int(snap["num_platforms"]) and int(blob["draw_walls"]) == int(snap["draw_walls"])
+            assert [int(v) for v in blob["dim"]] == [int(snap["L"]), int(snap["H"]), int(snap["W"])] and float(blob["episode_len"]) == 60.0
+            walls.add(int(blob["draw_walls"]))
+            for k in range(agents):
+                a = snap["agents"][k]
+                assert np.array_equal(blob["spawn"][k], a["spawn"])
+                ang = float(np.float32(np.float32(blob["yaw_frand"][k]) * np.float32(3.14159274)) * np.float32(2))
+                assert abs(np.cos(ang) - float(a["basis"][0])) < 2e-6 and abs(np.sin(ang) - float(a["basis"][1])) < 2e-6
+    assert walls == {0, 1}   # both merge classes (walls drawn / not drawn) were exercised
+    og.close()
+
+
 def test_episode_length_param_is_honoured():
     b = generate("Collect", 1, 5, 1, base_len=10.0)
     assert float(b["episode_len"]) == 10.0 + 2.0 * int(b["num_rewards"])
@@ -114,7 +156,7 @@ def test_episode_length_param_is_honoured():
     assert float(b["episode_len"]) == 500.0
 
 
-@pytest.mark.parametrize("scenario,threads", [("ObstaclesHard", 1), ("ObstaclesHard", 6), ("Collect", 4)])
+@pytest.mark.parametrize("scenario,threads", [("ObstaclesHard", 1), ("ObstaclesHard", 6), ("Collect", 4), ("Rearrange", 3)])
 def test_background_feeder_delivers_each_envs_stream_in_order(scenario, threads):
     """the worker pool (mv_feeder.cpp) against straight sequential generation, 5 episodes x 24 envs, no device involved"""
     lib = ext.load_library()
