@@ -18,6 +18,7 @@
 
 #include "../../include/megaverse_hip.h"
 #include "mv_feeder.h"
+#include "mv_actions.h"
 #include "mv_gen.h"
 #include "mv_raster.h"
 #include "mv_math.h"
@@ -68,6 +69,7 @@ struct mv_gym {
     int device = 0;
     int w = 0, h = 0, renderW = 768, renderH = 432;   // megaverse.cpp:261
     int N = 0, A = 0, envOffset = 0, envStride = 1, totalEnvs = 0;
+    bool samplePending = false;                  // mv_sample_random_actions: the next step draws its own actions
     bool closed = false, wasReset = false;
     hipStream_t stream = nullptr;
     GymView gv{};
@@ -118,46 +120,10 @@ __global__ void set_seeds_kernel(EnvHeader *hdr, const uint32_t *seeds, int n)
     if (i < n) { hdr[i].next_seed = seeds[i]; hdr[i].seed_is_env_seed = 1; }
 }
 
-__device__ __forceinline__ int action_mask_of(const int32_t *a)
-{   // MegaverseGym::setActions, megaverse.cpp:100-116
-    int idx = 0, mask = 0;
-    const int sizes[6] = {3, 3, 3, 2, 2, 3};
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        if (a[i] > 0) mask |= 1 << (idx + a[i]);
-        idx += sizes[i] - 1;
-    }
-    return mask;
-}
-
 __global__ void masks_from_multidiscrete_kernel(const int32_t *md, int32_t *masks, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) masks[i] = action_mask_of(md + (size_t)i * 6);
-}
-
-__device__ __forceinline__ uint32_t fmix32(uint32_t h)
-{
-    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
-    return h;
-}
-
-__global__ void sample_actions_kernel(int32_t *masks, int n, uint32_t seed, uint32_t step, uint32_t envOffset, uint32_t envStride, uint32_t A)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    // job-wide agent id: a sharded or strided gym draws exactly the actions the single big gym would
-    const uint32_t env = (uint32_t)i / A, agent = (uint32_t)i - env * A;
-    const uint32_t gid = (envOffset + env * envStride) * A + agent;
-    const uint32_t base = fmix32(fmix32(seed ^ fmix32(step + 0x9E3779B9u)) ^ (gid * 0x85EBCA6Bu + 1u));
-    const int sizes[6] = {3, 3, 3, 2, 2, 3};
-    int32_t a[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const uint32_t hsh = fmix32(base + (uint32_t)k * 0xC2B2AE35u);
-        a[k] = (int32_t)(((uint64_t)hsh * (uint64_t)sizes[k]) >> 32);
-    }
-    masks[i] = action_mask_of(a);
 }
 
 __global__ void set_shaping_kernel(AgentState *agents, int idx, int key, float v) { agents[idx].shaping[key] = v; }
@@ -287,6 +253,8 @@ int mv_create(const mv_config *cfg, mv_gym **out)
                    : scenario == SCN_COLLECT ? SHAPING_KEYS_COLLECT : SHAPING_KEYS_REARRANGE;
     g->envOffset = cfg->total_envs > 0 ? cfg->env_offset : 0;
     g->envStride = cfg->total_envs > 0 && cfg->env_stride > 1 ? cfg->env_stride : 1;
+    g->gv.sample_on = 0; g->gv.sample_seed = g->gv.sample_step = 0;
+    g->gv.env_offset = g->envOffset; g->gv.env_stride = g->envStride;
     g->totalEnvs = cfg->total_envs > 0 ? cfg->total_envs : cfg->num_envs;
     const size_t N = g->N, NA = (size_t)g->N * g->A;
 
@@ -633,13 +601,11 @@ int mv_set_actions_device(mv_gym *g, const int32_t *device_actions)
 }
 
 int mv_sample_random_actions(mv_gym *g, uint32_t seed, uint32_t step)
-{
+{   // the draw itself happens inside the next step kernel (mv_actions.h): no separate launch, no action buffer traffic
     if (check(g)) return -1;
-    HIP_TRY(hipSetDevice(g->device));
-    const int n = g->N * g->A;
-    hipLaunchKernelGGL(sample_actions_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, g->gv.actions, n, seed, step,
-                       (uint32_t)g->envOffset, (uint32_t)g->envStride, (uint32_t)g->A);
-    HIP_TRY(hipGetLastError());
+    g->samplePending = true;
+    g->gv.sample_seed = seed;
+    g->gv.sample_step = step;
     return 0;
 }
 
@@ -658,6 +624,8 @@ static int step_impl(mv_gym *g, bool render)
         std::memset(g->hActions[g->stage], 0, (size_t)g->N * g->A * sizeof(int32_t));   // actions are cleared every tick (env.cpp:141-142)
         g->actionsDirty = false;
     }
+    g->gv.sample_on = g->samplePending ? 1 : 0;
+    g->samplePending = false;
     const bool prof = render && g->profCount < g->profMax;
     hipEvent_t *ev = prof ? &g->profEvents[(size_t)g->profCount * 5] : nullptr;
     if (prof) HIP_TRY(hipEventRecord(ev[0], g->stream));

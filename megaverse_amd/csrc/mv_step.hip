@@ -22,6 +22,7 @@
 // with each other and share voxels) so they run one after another with wave-uniform state.
 #include <hip/hip_runtime.h>
 
+#include "mv_actions.h"
 #include "mv_math.h"
 #include "mv_physics.h"
 #include "mv_types.h"
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(64) void step_kernel(GymView gv)
     for (int i = 0; i < A_MAX; ++i)
         if (i < A) {
             ag[i] = gv.agents[(size_t)env * A + i];
-            act[i] = gv.actions[(size_t)env * A + i];
+            act[i] = action_of(gv, env, i);
             ag[i].last_reward = 0.0f;   // env.cpp:85
         }
 

@@ -92,6 +92,9 @@ struct GymView {
     int32_t num_envs, num_agents;
     int32_t box_stride, reward_stride;   // MAX_BOXES / MAX_REWARDS, or the COLLECT_ sizes
     int32_t scenario;                    // SCN_*: one scenario per gym
+    int32_t env_offset, env_stride;      // job-wide index of local env j = env_offset + j * env_stride
+    int32_t sample_on;                   // 1: this tick's actions are drawn inside the step kernel (mv_actions.h)
+    uint32_t sample_seed, sample_step;
     EnvHeader *hdr;            // [N]
     LayoutBox *boxes;          // [N][box_stride]
     MovableObject *objects;    // [N][MAX_OBJECTS]
