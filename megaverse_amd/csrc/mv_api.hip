@@ -102,6 +102,7 @@ struct mv_gym {
     int *dStatus = nullptr, *hStatus = nullptr;     // [N + 2]: consumed per env, total, error flags (device, pinned mirror)
     int lastTotalSeen = 0;
     bool statusPending = false, refillForce = true;
+    int stepsSinceStatus = 0;
     hipStream_t copyStream = nullptr;               // status read-back + episode uploads, off the step path
     hipEvent_t resetDone = nullptr, statusCopied = nullptr;
     std::vector<hipEvent_t> uploadEvents;           // ring, one per upload batch
@@ -307,6 +308,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
         if (hostEpisodes) {
             gv.rewards_obj = (MovableObject *)p; p += szRewObj;
             g->dBlobs = p; p += szBlobs;
+            gv.blobs = g->dBlobs;
         }
         if (collect) { gv.heightmap = (int8_t *)p; p += szHeight; }
         if (rearrange) { gv.items = (ArrangementItem *)p; p += szItems; }
@@ -462,7 +464,9 @@ int mv_seed(mv_gym *g, int32_t seed)
     if (g->hostEpisodes()) {   // Env::seed (env.cpp:52-55) on the host-side episode generators
         HIP_TRY(hipStreamSynchronize(g->stream));
         HIP_TRY(hipStreamSynchronize(g->copyStream));
+        HIP_TRY(hipMemcpy(g->hStatus, g->dStatus, (size_t)(g->N + 2) * sizeof(int), hipMemcpyDeviceToHost));   // the current counts, not the last periodic read-back
         g->statusPending = false;
+        g->stepsSinceStatus = 0;
         std::vector<int> first(g->N);
         for (int i = 0; i < g->N; ++i) {
             // the episode resident on the device (if any) was drawn from the old stream: it is replaced before the next
@@ -634,13 +638,13 @@ static int step_impl(mv_gym *g, bool render)
     else if (g->scenario == SCN_REARRANGE) launch_step_rearrange(g->gv, g->stream);
     else launch_step(g->gv, g->stream);
     if (prof) HIP_TRY(hipEventRecord(ev[1], g->stream));
-    if (g->hostEpisodes()) {
-        if (g->scenario == SCN_OBSTACLES) launch_reset_obstacles(g->gv, (const EpisodeBlob *)g->dBlobs, g->dStatus, 0, g->stream);
-        else if (g->scenario == SCN_REARRANGE) launch_reset_rearrange(g->gv, (const RearrangeBlob *)g->dBlobs, g->dStatus, 0, g->stream);
-        else launch_reset_collect(g->gv, (const CollectBlob *)g->dBlobs, g->dStatus, 0, g->stream);
+    // (every step kernel regenerates / swaps the next episode into the envs it finishes)
+    // An env needs its next resident episode only at its NEXT reset, hundreds of steps away (episodes last >= 35 s = 525
+    // ticks), so the status words are read back -- and the refill considered -- every 16th step, not every step.
+    if (g->hostEpisodes() && ++g->stepsSinceStatus >= 16) {
         if (read_back_status(g)) return -1;
-    } else
-        launch_reset(g->gv, 0, g->stream);
+        g->stepsSinceStatus = 0;
+    }   // (TowerBuilding: the step kernel regenerates finished envs itself)
     if (prof) HIP_TRY(hipEventRecord(ev[2], g->stream));
     if (render && launch_raster(g->gv, g->obs, g->w, g->h, g->stream, prof ? ev[3] : nullptr)) return fail("mv_step: observation size above 1024x1024");
     if (prof) { HIP_TRY(hipEventRecord(ev[4], g->stream)); ++g->profCount; }

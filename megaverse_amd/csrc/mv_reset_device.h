@@ -1,0 +1,227 @@
+// megaverse_amd/csrc/mv_reset_device.h -- TowerBuilding episode (re)generation as a device function, so that both the
+// stand-alone reset kernel (mv_reset, force_all) and the tail of the step kernel (auto-reset of a finished env) run it.
+//
+// Replaces, per env:  Env::reset (reference: src/libs/env/src/env.cpp:57-76)
+//   -> TowerBuildingScenario::reset + TowerBuildingPlatform::init/generate
+//      (src/libs/scenarios/src/scenario_tower_building.cpp:19-89,129-154)
+//   -> VoxelGridComponent::addPlatform / toBoundingBoxes (component_voxel_grid.hpp:73-187)
+//   -> ObjectStackingComponent::addDrawablesAndCollisions (component_object_stacking.hpp:170-198)
+//   -> DefaultScenario::spawnAgents (scenario_default.hpp:80-97)
+//
+// One wavefront per env.  The RNG-dependent part is inherently serial and runs as uniform scalar code (mv_rng.h); voxel
+// fill and write-out are lane-parallel through a 16 KiB LDS image of the chunk so HBM only sees full-width coalesced
+// dwordx4 stores.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "mv_math.h"
+#include "mv_rng.h"
+#include "mv_types.h"
+
+namespace mv {
+namespace {
+
+__constant__ unsigned LAYOUT_COLORS[14] = {  // reference: env/include/env/const.hpp:121-136
+    0xffffff, 0xffffe6, 0xccffcc, 0xe6ecff, 0xd9d9d9, 0xffebcc, 0xb3b3b3, 0xb3b3b3, 0xb3b3b3, 0xb3b3b3,
+    0x555555, 0x555555, 0x555555, 0x555555};
+
+__device__ __forceinline__ unsigned random_layout_color(Mt19937 &g) { return LAYOUT_COLORS[rand_range(g, 0, 14)]; }
+
+__device__ __forceinline__ bool in_zone(const int bz[4], int x, int z) { return x >= bz[0] && x < bz[1] && z >= bz[2] && z < bz[3]; }
+
+__device__ __forceinline__ float building_reward_coeff(int h)
+{   // scenario_tower_building.cpp:246-251; 2^h is exact
+    float res = float(h) * 0.05f;
+    const float p = 0.05f * __uint_as_float((unsigned)(127 + h) << 23);
+    res += fmin_sel(p, 20.0f);
+    return res;
+}
+
+// Regenerates env `env` (the caller has decided that it must be: done, or a forced reset).  Called by all 64 lanes of the
+// env's wavefront, which must be the whole workgroup (the function uses __syncthreads()).
+__device__ __forceinline__ void reset_env(const GymView &gv, int env, int force_all)
+{
+    const int lane = lane_id();
+    EnvHeader *hdr = gv.hdr + env;
+    __shared__ __attribute__((aligned(16))) uint32_t s_mt[624];
+    __shared__ __attribute__((aligned(16))) uint16_t s_cand[32 * 32];
+    __shared__ __attribute__((aligned(16))) uint8_t s_chunk[CHUNK_BYTES];
+    __shared__ MovableObject s_obj[MAX_OBJECTS];
+
+    const int A = gv.num_agents;
+    Mt19937 g{s_mt, 624};
+
+    // ---- Env::reset: seed = randRange(0, 1<<30, rng); rng.seed(seed)  (env.cpp:61-62)
+    uint32_t seed = hdr->next_seed;
+    if (hdr->seed_is_env_seed) {
+        mt_seed(g, seed);
+        seed = (uint32_t)rand_range(g, 0, 1 << 30);
+    }
+    mt_seed(g, seed);
+
+    // ---- TowerBuildingScenario::reset (:139-141)
+    unsigned layoutColor = random_layout_color(g);
+    while (layoutColor == 0x555555u) layoutColor = random_layout_color(g);
+
+    // ---- TowerBuildingPlatform::init (:19-39)
+    const int height = rand_range(g, 5, 7);
+    int length = rand_range(g, 12, 30);
+    int width = rand_range(g, 12, 25);
+    const int bzL = rand_range(g, 3, 9), bzW = rand_range(g, 3, 9);
+    const int matL = rand_range(g, 2, 8), matW = rand_range(g, 2, 8);
+    length = max(bzL + matL + 3, length);
+    width = max(bzW + matW + 3, width);
+    const int bzX = rand_range(g, 1, length - bzL - 1), bzZ = rand_range(g, 1, width - bzW - 1);
+    const int matX = rand_range(g, 1, length - matL - 1), matZ = rand_range(g, 1, width - matW - 1);
+
+    // spawn candidates x-major (:41-44), shuffled (:46)
+    const int nz = width - 2, ncand = (length - 2) * nz;
+    for (int i = lane; i < ncand; i += 64) {
+        const int x = 1 + i / nz, z = 1 + i % nz;
+        s_cand[i] = (uint16_t)((x << 8) | z);
+    }
+    __syncthreads();
+    shuffle_u16(g, s_cand, ncand);
+
+    const int nSpawn = min(A, ncand);
+    const int maxRandomObjects = min(ncand - A, 25);
+    const int spawnObjects = rand_range(g, 0, max(1, maxRandomObjects));
+    const int numObjects = min(spawnObjects + matL * matW, (int)MAX_OBJECTS);
+
+    // objects: the random ones (:53-66) then the materials rectangle (:68-72)
+    for (int i = lane; i < numObjects; i += 64) {
+        MovableObject o;
+        if (i < spawnObjects) {
+            const uint16_t c = s_cand[nSpawn + i];
+            const int x = c >> 8, z = c & 255;
+            const bool inMat = x >= matX && x < matX + matL && z >= matZ && z < matZ + matW;
+            o.x = (int8_t)x; o.y = (int8_t)(inMat ? 2 : 1); o.z = (int8_t)z;
+        } else {
+            const int j = i - spawnObjects;
+            o.x = (int8_t)(matX + j / matW); o.y = 1; o.z = (int8_t)(matZ + j % matW);
+        }
+        o.state = 0;
+        s_obj[i] = o;
+    }
+
+    // vg.addPlatform(platform, layoutColor, randomLayoutColor(rng), randomBool(rng)) (:145); the
+    // reference is built with GCC, which evaluates the arguments right to left.
+    const bool drawWalls = random_bool(g);
+    const unsigned wallColor = random_layout_color(g);
+
+    // ---- voxel chunk image in LDS: floor, then the four walls override (platforms.hpp:167-190,
+    // component_voxel_grid.hpp:73-90).  One 16-cell run per lane per round.
+    const uint32_t vFloor = VX_SOLID | VX_OPAQUE;
+    const uint32_t vWall = VX_SOLID | (drawWalls ? VX_OPAQUE : 0) | (1u << VX_COLOR_SHIFT);
+    for (int grp = lane; grp < CHUNK_BYTES / 16; grp += 64) {
+        const int x0 = (grp & 1) * 16, z = (grp >> 1) & (CZ - 1), y = grp >> 6;
+        uint32_t w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t word = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int x = x0 + q * 4 + b;
+                uint32_t v = 0;
+                if (x < length && z < width) {
+                    if (y == 0) v = vFloor;
+                    if (y < height && (x == 0 || x == length - 1 || z == 0 || z == width - 1)) v = vWall;
+                }
+                word |= v << (8 * b);
+            }
+            w[q] = word;
+        }
+        *reinterpret_cast<uint4 *>(s_chunk + grp * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    __syncthreads();
+    for (int i = lane; i < numObjects; i += 64) {
+        const MovableObject o = s_obj[i];
+        s_chunk[(o.y * CZ + o.z) * CX + o.x] |= VX_OBJECT;   // distinct cells, byte-wide LDS RMW
+    }
+    __syncthreads();
+
+    // ---- write-out: chunk (coalesced 16 B / lane), objects, boxes, header, agents
+    uint4 *gchunk = reinterpret_cast<uint4 *>(gv.chunk + (size_t)env * CHUNK_BYTES);
+    for (int grp = lane; grp < CHUNK_BYTES / 16; grp += 64) gchunk[grp] = *reinterpret_cast<const uint4 *>(s_chunk + grp * 16);
+
+    MovableObject *gobj = gv.objects + (size_t)env * MAX_OBJECTS;
+    for (int i = lane; i < MAX_OBJECTS; i += 64) {
+        MovableObject o{0, 0, 0, 0};
+        if (i < numObjects) o = s_obj[i];
+        gobj[i] = o;
+    }
+
+    // canonical layout parallelepipeds (== the generic greedy merge the oracle runs on the voxels:
+    // keys sorted by (type, slot), scan y,z,x, grow x then z then y).  For this room that is the
+    // interior floor slab and four wall slabs.
+    if (lane < TOWER_BOXES) {
+        LayoutBox b{{0, 0, 0}, 0, {0, 0, 0}, 0};
+        const int wallType = VX_SOLID | (drawWalls ? VX_OPAQUE : 0);
+        const int floorIdx = drawWalls ? 0 : 4;       // key 12 vs wall key 13 (drawn) / 5 (invisible)
+        const int wallIdx = drawWalls ? lane - 1 : lane;
+        if (lane == floorIdx) {
+            b.min[0] = 1; b.min[1] = 0; b.min[2] = 1; b.max[0] = length - 1; b.max[1] = 1; b.max[2] = width - 1;
+            b.type = VX_SOLID | VX_OPAQUE; b.slot = 0;
+        } else if (lane < 5) {
+            b.type = wallType; b.slot = 1; b.min[1] = 0; b.max[1] = height;
+            if (wallIdx == 0) { b.min[0] = 0; b.min[2] = 0; b.max[0] = length; b.max[2] = 1; }
+            if (wallIdx == 1) { b.min[0] = 0; b.min[2] = 1; b.max[0] = 1; b.max[2] = width; }
+            if (wallIdx == 2) { b.min[0] = length - 1; b.min[2] = 1; b.max[0] = length; b.max[2] = width; }
+            if (wallIdx == 3) { b.min[0] = 1; b.min[2] = width - 1; b.max[0] = length - 1; b.max[2] = width; }
+        }
+        gv.boxes[(size_t)env * MAX_BOXES + lane] = b;
+    }
+
+    const int bz[4] = {bzX, bzX + bzL, bzZ, bzZ + bzW};
+
+    // initial tower reward, summed in object order (scenario_tower_building.cpp:166-173,232-241)
+    float bzReward = 0.0f;
+    for (int i = 0; i < numObjects; ++i) {
+        const MovableObject o = s_obj[i];
+        if (in_zone(bz, o.x, o.z)) bzReward += building_reward_coeff(o.y);
+    }
+
+    // ---- agents (scenario_default.hpp:80-97, agent.cpp:24-65); one frand per agent, in order
+    for (int k = 0; k < A; ++k) {
+        const uint16_t c = s_cand[k < nSpawn ? k : 0];
+        const int sx = c >> 8, sz = c & 255;
+        const float rot = frand(g) * 3.14159274f * 2;
+        float cs, sn;
+        yaw_matrix(rot, cs, sn);
+        if (lane == 0) {
+            AgentState *ga = gv.agents + (size_t)env * A + k;
+            AgentState a = *ga;   // keeps the per-agent reward shaping
+            a.pos[0] = float(sx) + 0.5f; a.pos[1] = 2.0f + 0.0f + 1.75f; a.pos[2] = float(sz) + 0.5f;
+            a.m00 = cs; a.m02 = sn; a.m20 = -sn; a.m22 = cs;
+            a.pitch = 0.0f; a.hvx = 0.0f; a.hvz = 0.0f; a.vvel = 0.0f; a.voffset = 0.0f; a.step_offset = 0.0f;
+            a.jump_speed = 10.0f; a.was_jumping = 0; a.carrying = -1; a.picked_up = 0; a.visited_zone = 0;
+            a.spawn[0] = sx; a.spawn[1] = 2; a.spawn[2] = sz;
+            a.last_reward = 0.0f; a.total_reward = 0.0f;
+            *ga = a;
+            gv.rewards[(size_t)env * A + k] = 0.0f;   // EnvState::reset zero-fills lastReward (env.hpp:141-143)
+            gv.actions[(size_t)env * A + k] = 0;
+        }
+    }
+
+    // value the next Env::reset() will draw; nothing consumes the env rng during an episode
+    const uint32_t nextSeed = (uint32_t)rand_range(g, 0, 1 << 30);
+
+    if (lane == 0) {
+        EnvHeader h = *hdr;
+        h.L = length; h.H = height; h.W = width;
+        h.bz[0] = bz[0]; h.bz[1] = bz[1]; h.bz[2] = bz[2]; h.bz[3] = bz[3];
+        h.layout_color = (int)layoutColor; h.wall_color = (int)wallColor; h.draw_walls = drawWalls ? 1 : 0;
+        h.num_objects = numObjects; h.num_boxes = 5;
+        h.num_frames = 0; h.done = 0; h.highest_tower = 0;
+        h.episode_sec = 0.0f;
+        h.episode_len = h.p_episode_len_sec + 4.0f * float(numObjects);   // :263-266
+        h.bz_reward = bzReward;
+        h.bar_half_width = 0.24f;
+        h.next_seed = nextSeed; h.seed_is_env_seed = 0;
+        *hdr = h;
+        if (force_all) gv.done[env] = 0;
+    }
+}
+
+}  // namespace
+}  // namespace mv

@@ -25,19 +25,12 @@
 #include "mv_actions.h"
 #include "mv_math.h"
 #include "mv_physics.h"
+#include "mv_reset_device.h"
 #include "mv_types.h"
 
 namespace mv {
 
 namespace {
-
-__device__ __forceinline__ float building_reward_coeff(int h)
-{
-    float res = float(h) * 0.05f;
-    const float p = 0.05f * __uint_as_float((unsigned)(127 + h) << 23);
-    res += fmin_sel(p, 20.0f);
-    return res;
-}
 
 // the wave's view of the movable boxes: lane l owns object l-16 (l>=16) and object 48+l (l<32)
 struct ObjRegs {
@@ -352,6 +345,14 @@ __global__ __launch_bounds__(64) void step_kernel(GymView gv)
             gv.rewards[(size_t)env * A + i] = ag[i].last_reward;   // zeroed by the reset kernel if done
             if (h.done) gv.true_objective[(size_t)env * A + i] = float(h.highest_tower);   // vector_env.cpp:97-98
         }
+
+    // ---- VectorEnv::step's auto-reset (vector_env.cpp:93-105): the wave of a finished env regenerates it right here.  About one
+    // env in two thousand finishes per tick and its wave is not the slowest of the launch even with the generator on top, so
+    // this costs nothing, where a separate "reset whoever is done" launch cost 4-7 us per step.
+    if (h.done) {
+        __syncthreads();   // one wave per workgroup: orders the stores above before the generator's
+        reset_env(gv, env, 0);
+    }
 }
 
 void launch_step(const GymView &gv, hipStream_t stream)

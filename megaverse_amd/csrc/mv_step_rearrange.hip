@@ -42,6 +42,54 @@ __device__ __forceinline__ Bits128 column_solid_room(int x, int z, int H)
 
 }  // namespace
 
+// Episode swap-in: Env::reset of one env from its resident RearrangeBlob (called by the env's whole wavefront: by the stand-alone
+// reset kernel for mv_reset, and by the tail of the step kernel for the auto-reset of VectorEnv::step, vector_env.cpp:93-105)
+__device__ __forceinline__ void swap_in_episode(const GymView &gv, const RearrangeBlob *blobs, int *status, int env, int force_all)
+{
+    const int lane = lane_id();
+    EnvHeader *gh = gv.hdr + env;
+    const RearrangeBlob *b = blobs + env;
+    const int consumed = gh->episodes_consumed;
+    if (b->seq != consumed + 1) {   // the host has not delivered the next episode: must never happen (mv_api.hip keeps one ahead)
+        if (lane == 0) { gh->starved |= 1; atomicOr(&status[gv.num_envs + 1], 1); }
+        return;
+    }
+    const int A = gv.num_agents;
+    if (lane < TOWER_BOXES) gv.boxes[(size_t)env * gv.box_stride + lane] = b->boxes[lane];
+    if (lane < MAX_ITEMS) {
+        gv.items[(size_t)env * MAX_ITEMS + lane] = b->items[lane];
+        gv.objects[(size_t)env * MAX_OBJECTS + lane] = b->objects[lane];
+    }
+    for (int k = 0; k < A; ++k) {
+        float cs, sn;
+        yaw_matrix(b->yaw_frand[k] * 3.14159274f * 2, cs, sn);
+        if (lane == 0) {
+            AgentState *a = gv.agents + (size_t)env * A + k;
+            a->pos[0] = float(b->spawn[k][0]) + 0.5f; a->pos[1] = float(b->spawn[k][1]) + 0.0f + 1.75f; a->pos[2] = float(b->spawn[k][2]) + 0.5f;
+            a->m00 = cs; a->m02 = sn; a->m20 = -sn; a->m22 = cs;
+            a->pitch = 0.0f; a->hvx = 0.0f; a->hvz = 0.0f; a->vvel = 0.0f; a->voffset = 0.0f; a->step_offset = 0.0f;
+            a->jump_speed = 10.0f; a->was_jumping = 0; a->carrying = -1; a->picked_up = 0; a->visited_zone = 0;
+            a->spawn[0] = b->spawn[k][0]; a->spawn[1] = b->spawn[k][1]; a->spawn[2] = b->spawn[k][2];
+            a->last_reward = 0.0f; a->total_reward = 0.0f;
+            gv.rewards[(size_t)env * A + k] = 0.0f;
+            gv.actions[(size_t)env * A + k] = 0;
+        }
+    }
+    if (lane == 0) {
+        gh->L = b->dim[0]; gh->H = b->dim[1]; gh->W = b->dim[2];
+        gh->bz[0] = gh->bz[1] = gh->bz[2] = gh->bz[3] = 0;
+        gh->layout_color = 0x555555; gh->wall_color = 0x555555; gh->draw_walls = b->draw_walls;
+        gh->num_objects = b->num_items; gh->num_boxes = b->num_boxes; gh->num_terrain = b->num_items;
+        gh->num_rewards = 0; gh->num_platforms = b->max_matching;
+        gh->num_frames = 0; gh->done = 0; gh->highest_tower = 0; gh->solved = 0;
+        gh->episode_sec = 0.0f; gh->episode_len = b->episode_len; gh->bz_reward = 0.0f; gh->bar_half_width = 0.24f;
+        gh->episodes_consumed = consumed + 1;
+        status[env] = consumed + 1;
+        atomicAdd(&status[gv.num_envs], 1);
+        if (force_all) gv.done[env] = 0;
+    }
+}
+
 template <int A_MAX>
 __global__ __launch_bounds__(64) void step_rearrange_kernel(GymView gv)
 {
@@ -250,56 +298,20 @@ __global__ __launch_bounds__(64) void step_rearrange_kernel(GymView gv)
             gv.rewards[(size_t)env * A + i] = a.last_reward;
             if (done) gv.true_objective[(size_t)env * A + i] = float(solved);   // scenario_rearrange.hpp:94
         }
+
+    // ---- the auto-reset of VectorEnv::step: the wave of a finished env swaps the next episode in right here
+    if (done) {
+        __syncthreads();   // one wave per workgroup: orders the stores above before the swap-in's
+        swap_in_episode(gv, static_cast<const RearrangeBlob *>(gv.blobs), gv.episode_status, env, 0);
+    }
 }
 
-// Episode swap-in: Env::reset for finished envs (or every env when force_all), from the resident RearrangeBlob.
 __global__ __launch_bounds__(64) void reset_rearrange_kernel(GymView gv, const RearrangeBlob *blobs, int *status, int force_all)
 {
     const int env = blockIdx.x;
-    const int lane = lane_id();
     if (env >= gv.num_envs) return;
-    EnvHeader *gh = gv.hdr + env;
-    if (!force_all && !gh->done) return;
-    const RearrangeBlob *b = blobs + env;
-    const int consumed = gh->episodes_consumed;
-    if (b->seq != consumed + 1) {   // the host has not delivered the next episode: must never happen (mv_api.hip keeps one ahead)
-        if (lane == 0) { gh->starved |= 1; atomicOr(&status[gv.num_envs + 1], 1); }
-        return;
-    }
-    const int A = gv.num_agents;
-    if (lane < TOWER_BOXES) gv.boxes[(size_t)env * gv.box_stride + lane] = b->boxes[lane];
-    if (lane < MAX_ITEMS) {
-        gv.items[(size_t)env * MAX_ITEMS + lane] = b->items[lane];
-        gv.objects[(size_t)env * MAX_OBJECTS + lane] = b->objects[lane];
-    }
-    for (int k = 0; k < A; ++k) {
-        float cs, sn;
-        yaw_matrix(b->yaw_frand[k] * 3.14159274f * 2, cs, sn);
-        if (lane == 0) {
-            AgentState *a = gv.agents + (size_t)env * A + k;
-            a->pos[0] = float(b->spawn[k][0]) + 0.5f; a->pos[1] = float(b->spawn[k][1]) + 0.0f + 1.75f; a->pos[2] = float(b->spawn[k][2]) + 0.5f;
-            a->m00 = cs; a->m02 = sn; a->m20 = -sn; a->m22 = cs;
-            a->pitch = 0.0f; a->hvx = 0.0f; a->hvz = 0.0f; a->vvel = 0.0f; a->voffset = 0.0f; a->step_offset = 0.0f;
-            a->jump_speed = 10.0f; a->was_jumping = 0; a->carrying = -1; a->picked_up = 0; a->visited_zone = 0;
-            a->spawn[0] = b->spawn[k][0]; a->spawn[1] = b->spawn[k][1]; a->spawn[2] = b->spawn[k][2];
-            a->last_reward = 0.0f; a->total_reward = 0.0f;
-            gv.rewards[(size_t)env * A + k] = 0.0f;
-            gv.actions[(size_t)env * A + k] = 0;
-        }
-    }
-    if (lane == 0) {
-        gh->L = b->dim[0]; gh->H = b->dim[1]; gh->W = b->dim[2];
-        gh->bz[0] = gh->bz[1] = gh->bz[2] = gh->bz[3] = 0;
-        gh->layout_color = 0x555555; gh->wall_color = 0x555555; gh->draw_walls = b->draw_walls;
-        gh->num_objects = b->num_items; gh->num_boxes = b->num_boxes; gh->num_terrain = b->num_items;
-        gh->num_rewards = 0; gh->num_platforms = b->max_matching;
-        gh->num_frames = 0; gh->done = 0; gh->highest_tower = 0; gh->solved = 0;
-        gh->episode_sec = 0.0f; gh->episode_len = b->episode_len; gh->bz_reward = 0.0f; gh->bar_half_width = 0.24f;
-        gh->episodes_consumed = consumed + 1;
-        status[env] = consumed + 1;
-        atomicAdd(&status[gv.num_envs], 1);
-        if (force_all) gv.done[env] = 0;
-    }
+    if (!force_all && !gv.hdr[env].done) return;
+    swap_in_episode(gv, blobs, status, env, force_all);
 }
 
 void launch_step_rearrange(const GymView &gv, hipStream_t stream)

@@ -105,6 +105,7 @@ struct GymView {
     int8_t *heightmap;         // [N][HM_BYTES]      (Collect: top solid y of column x * HM_DIM + z, -1 = no voxels)
     ArrangementItem *items;    // [N][MAX_ITEMS]     (Rearrange: the target arrangement; hdr.num_terrain holds the item count)
     int32_t *episode_status;   // [N + 2] host-generated scenarios: episodes consumed per env, their total, error flags
+    const void *blobs;         // [N] resident next episodes (EpisodeBlob / CollectBlob / RearrangeBlob)
     int32_t *actions;          // [N][A] bitmasks
     float *rewards;            // [N*A] as reported by get_last_rewards (0 on done steps)
     uint8_t *done;             // [N]
