@@ -562,6 +562,13 @@ int mv_reset(mv_gym *g)
     if (check(g)) return -1;
     HIP_TRY(hipSetDevice(g->device));
     if (g->hostEpisodes()) {
+        // the periodic status read-back may be up to 15 ticks old: an env that auto-reset since then has consumed its
+        // resident episode without the host knowing -- take the current counts before deciding what to upload
+        HIP_TRY(hipStreamSynchronize(g->stream));
+        HIP_TRY(hipStreamSynchronize(g->copyStream));
+        HIP_TRY(hipMemcpy(g->hStatus, g->dStatus, (size_t)(g->N + 2) * sizeof(int), hipMemcpyDeviceToHost));
+        g->statusPending = false;
+        g->stepsSinceStatus = 0;
         g->refillForce = true;
         if (refill_episodes(g)) return -1;              // every env has an unconsumed episode resident
         if (g->scenario == SCN_OBSTACLES) launch_reset_obstacles(g->gv, (const EpisodeBlob *)g->dBlobs, g->dStatus, 1, g->stream);

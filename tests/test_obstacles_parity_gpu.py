@@ -108,3 +108,29 @@ def test_reseed_mid_run_takes_effect_at_the_next_reset(hip):
         d = diff_snapshots(og.snapshot(e), hip_snapshot(hg, e), A)
         assert not d, (e, d[:5])
     og.close(); hg.close()
+
+
+def test_forced_reset_right_after_auto_resets(hip):
+    """mv_reset a few ticks after some envs auto-reset: the host's periodic status read-back is then out of date and must
+    be refreshed, or the forced reset would find an already consumed episode resident"""
+    N, A = 16, 1
+    og, hg = make_pair(N, A, 32, 32, seed=77, scenario="ObstaclesEasy")
+    st, first_done = 0, None
+    while first_done is None or st < first_done + 3:
+        set_same_actions(og, hg, N, A, 41, st)
+        og.step_norender(); hg.step_no_render()
+        if first_done is None and any(og.is_done(e) for e in range(N)):
+            first_done = st
+        st += 1
+        assert st < 1200
+    og.reset(); hg.reset()
+    for e in range(N):
+        d = diff_snapshots(og.snapshot(e), hip_snapshot(hg, e), A)
+        assert not d, (e, d[:5])
+    for k in range(40):
+        set_same_actions(og, hg, N, A, 42, k)
+        og.step_norender(); hg.step_no_render()
+    for e in range(N):
+        d = diff_snapshots(og.snapshot(e), hip_snapshot(hg, e), A)
+        assert not d, (e, d[:5])
+    og.close(); hg.close()
