@@ -315,7 +315,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
         gv.vis_prims = p; p += szVisP;
         gv.vis_rects = p; p += szVisR;
         gv.vis_count = (int32_t *)p; p += szVisC;
-        gv.lpt_bucket = p; p += up(NA * sizeof(int32_t));
+        gv.lpt_bucket = (int32_t *)p; p += up(NA * sizeof(int32_t));
         gv.lpt_order = (int32_t *)p; p += up(NA * sizeof(int32_t));
     }
     g->obs = g->ownedObs;

@@ -558,7 +558,7 @@ __global__ __launch_bounds__(256) void frame_setup_kernel(GymView gv, int W, int
         // kernel takes them from the most expensive bin down (frames differ several-fold in cost; starting the heavy
         // ones first keeps the tail of the launch short); mv_frame_order.h turns the bins into a permutation
         const int tiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H);
-        gv.lpt_bucket[frame] = (uint8_t)min(LPT_BUCKETS - 1, (16 * s_cost) / max(tiles, 1));   // 1/16 of "one primitive on every tile"
+        gv.lpt_bucket[frame] = min(LPT_BUCKETS - 1, (16 * s_cost) / max(tiles, 1));   // 1/16 of "one primitive on every tile"
     }
 }
 

@@ -115,7 +115,7 @@ struct GymView {
     void *vis_rects;           // [N*A][vis_stride] short4 screen rectangles
     int32_t *vis_count;        // [N*A]
     int32_t vis_stride;        // 256, or 1024 for Collect
-    uint8_t *lpt_bucket;       // [N*A] cost bin of every frame (raster scheduling), padded to 4 KiB
+    int32_t *lpt_bucket;       // [N*A] cost bin of every frame (raster scheduling)
     int32_t *lpt_order;        // [N*A] frames sorted by cost bin, most expensive first
 };
 
