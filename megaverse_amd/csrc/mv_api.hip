@@ -319,14 +319,6 @@ int mv_create(const mv_config *cfg, mv_gym **out)
         gv.lpt_order = (int32_t *)p; p += up(NA * sizeof(int32_t));
     }
     g->obs = g->ownedObs;
-    {   // any permutation is a valid raster order: start with the identity
-        std::vector<int32_t> iota(NA);
-        for (size_t i = 0; i < NA; ++i) iota[i] = (int32_t)i;
-        if (hipMemcpy(gv.lpt_order, iota.data(), NA * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
-            mv_destroy(g);
-            return fail("mv_create: initial upload failed");
-        }
-    }
     for (int b = 0; b < 2; ++b) {
         if (hipHostMalloc((void **)&g->hActions[b], NA * sizeof(int32_t), hipHostMallocDefault) != hipSuccess ||
             hipEventCreateWithFlags(&g->actionsCopied[b], hipEventDisableTiming) != hipSuccess) {

@@ -32,7 +32,6 @@
 #include <stdlib.h>
 
 #include "mv_math.h"
-#include "mv_frame_order.h"
 #include "mv_raster.h"
 #include "mv_rearrange.h"
 #include "mv_types.h"
@@ -54,6 +53,7 @@ constexpr int PPL = MV_RASTER_PPL;   // pixels per lane in the raster kernel: a 
 #define MV_RASTER_WAVES 7   // waves per SIMD the small variant is compiled for (register budget 512 / n)
 #endif
 constexpr int VIS_SMALL = 256, VIS_LARGE = 1024;   // visible primitives kept per frame (TowerBuilding <= 121 slots, Obstacles <= 280; Collect up to ~1300)
+constexpr int LPT_BUCKETS = 256;
 constexpr float CLIP_W = 0.005f;       // NEAR_Z / 2: boxes are clipped against this depth before projecting
 constexpr int MAX_W = 1024, MAX_H = 1024;
 
@@ -556,10 +556,28 @@ __global__ __launch_bounds__(256) void frame_setup_kernel(GymView gv, int W, int
         gv.vis_count[frame] = min(nVis, maxVis);
         // longest-processing-time-first scheduling of the raster pass: frames are binned by estimated cost, the raster
         // kernel takes them from the most expensive bin down (frames differ several-fold in cost; starting the heavy
-        // ones first keeps the tail of the launch short); mv_frame_order.h turns the bins into a permutation
+        // ones first keeps the tail of the launch short); frame_order_kernel turns the bins into a permutation
         const int tiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H);
         gv.lpt_bucket[frame] = min(LPT_BUCKETS - 1, (16 * s_cost) / max(tiles, 1));   // 1/16 of "one primitive on every tile"
     }
+}
+
+// ---- pass 1b, one workgroup: counting sort of the frames by cost bin, most expensive first.  (A "last workgroup of
+// frame_setup_kernel does it" variant was slower: its device-scope fences write back every XCD's L2, 22 us vs 6 us.)
+__global__ __launch_bounds__(1024) void frame_order_kernel(GymView gv, int frames, int *order)
+{
+    __shared__ int s_hist[LPT_BUCKETS], s_start[LPT_BUCKETS];
+    const int tid = threadIdx.x;
+    if (tid < LPT_BUCKETS) s_hist[tid] = 0;
+    __syncthreads();
+    for (int f = tid; f < frames; f += 1024) atomicAdd(&s_hist[gv.lpt_bucket[f]], 1);
+    __syncthreads();
+    if (tid == 0) {   // 256 bins: a serial scan is a few hundred cycles, once per step
+        int acc = 0;
+        for (int b = LPT_BUCKETS - 1; b >= 0; --b) { s_start[b] = acc; acc += s_hist[b]; }
+    }
+    __syncthreads();
+    for (int f = tid; f < frames; f += 1024) order[atomicAdd(&s_start[gv.lpt_bucket[f]], 1)] = f;
 }
 
 template <int MAXVIS, bool SHAPES>   // SHAPES: the frame may hold scaled spheres / capsules / cylinders (Rearrange)
@@ -807,10 +825,8 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 && !SHAPES ? MV_RASTER_WAVES : M
 
 
 
-// One observation pass: frame setup -> raster, on `stream`.  The frame order the raster kernel walks is sorted from the
-// PREVIOUS pass's cost bins by one extra workgroup of the step kernel (mv_frame_order.h) -- consecutive frames of an agent
-// cost about the same, and the sort is off the critical path there.  (As a kernel of its own between setup and raster it
-// was a 6 us single-workgroup bubble; on a side stream the cross-stream event packets cost more than that.)
+// One observation pass: frame setup -> frame sort -> raster, on `stream`.  (Running the sort on a side stream from the
+// previous pass's bins was tried: the cross-stream event packets cost more than the 6 us single-workgroup bubble.)
 int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream, hipEvent_t between)
 {
     if (W > MAX_W || H > MAX_H) return -1;
@@ -821,6 +837,7 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
     while (split > 1 && tiles < 4 * split * 2) split >>= 1;   // keep at least two tiles per wave
     const int frames = gv.num_envs * gv.num_agents;
     hipLaunchKernelGGL(frame_setup_kernel, dim3(frames), dim3(256), 0, stream, gv, W, H);
+    hipLaunchKernelGGL(frame_order_kernel, dim3(1), dim3(1024), 0, stream, gv, frames, gv.lpt_order);
     if (between) (void)hipEventRecord(between, stream);
     const dim3 grid(frames * split), block(256);
     if (gv.vis_stride > VIS_SMALL) hipLaunchKernelGGL((raster_kernel<VIS_LARGE, false>), grid, block, dyn, stream, gv, obs, W, H, split, gv.lpt_order);

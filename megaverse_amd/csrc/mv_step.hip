@@ -23,7 +23,6 @@
 #include <hip/hip_runtime.h>
 
 #include "mv_actions.h"
-#include "mv_frame_order.h"
 #include "mv_math.h"
 #include "mv_physics.h"
 #include "mv_reset_device.h"
@@ -127,10 +126,7 @@ __global__ __launch_bounds__(64) void step_kernel(GymView gv)
 {
     const int env = blockIdx.x;
     const int lane = lane_id();
-    if (env >= gv.num_envs) {   // the one extra workgroup: sorts the frames for the coming raster pass (mv_frame_order.h)
-        if (env == gv.num_envs) sort_frames_by_cost(gv);
-        return;
-    }
+    if (env >= gv.num_envs) return;
     const int A = gv.num_agents;
 
     const EnvHeader *gh = gv.hdr + env;
@@ -361,7 +357,7 @@ __global__ __launch_bounds__(64) void step_kernel(GymView gv)
 
 void launch_step(const GymView &gv, hipStream_t stream)
 {
-    const dim3 grid(gv.num_envs + 1), block(64);   // + 1: the frame-sort workgroup
+    const dim3 grid(gv.num_envs), block(64);
     if (gv.num_agents == 1) hipLaunchKernelGGL(step_kernel<1>, grid, block, 0, stream, gv);
     else if (gv.num_agents == 2) hipLaunchKernelGGL(step_kernel<2>, grid, block, 0, stream, gv);
     else if (gv.num_agents <= 4) hipLaunchKernelGGL(step_kernel<4>, grid, block, 0, stream, gv);

@@ -18,7 +18,6 @@
 
 #include "mv_boxlist.h"
 #include "mv_actions.h"
-#include "mv_frame_order.h"
 #include "mv_math.h"
 #include "mv_physics.h"
 #include "mv_types.h"
@@ -108,10 +107,7 @@ __global__ __launch_bounds__(64) void step_obstacles_kernel(GymView gv)
 {
     const int env = blockIdx.x;
     const int lane = lane_id();
-    if (env >= gv.num_envs) {   // the one extra workgroup: sorts the frames for the coming raster pass (mv_frame_order.h)
-        if (env == gv.num_envs) sort_frames_by_cost(gv);
-        return;
-    }
+    if (env >= gv.num_envs) return;
     const int A = gv.num_agents;
 
     // ---- header fields as scalars (never copy the record: see mv_step.hip)
@@ -365,7 +361,7 @@ __global__ __launch_bounds__(64) void reset_obstacles_kernel(GymView gv, const E
 
 void launch_step_obstacles(const GymView &gv, hipStream_t stream)
 {
-    const dim3 grid(gv.num_envs + 1), block(64);   // + 1: the frame-sort workgroup
+    const dim3 grid(gv.num_envs), block(64);
     if (gv.num_agents == 1) hipLaunchKernelGGL(step_obstacles_kernel<1>, grid, block, 0, stream, gv);
     else if (gv.num_agents == 2) hipLaunchKernelGGL(step_obstacles_kernel<2>, grid, block, 0, stream, gv);
     else if (gv.num_agents <= 4) hipLaunchKernelGGL(step_obstacles_kernel<4>, grid, block, 0, stream, gv);

@@ -15,7 +15,6 @@
 
 #include "mv_boxlist.h"
 #include "mv_actions.h"
-#include "mv_frame_order.h"
 #include "mv_math.h"
 #include "mv_physics.h"
 #include "mv_rearrange.h"
@@ -96,10 +95,7 @@ __global__ __launch_bounds__(64) void step_rearrange_kernel(GymView gv)
 {
     const int env = blockIdx.x;
     const int lane = lane_id();
-    if (env >= gv.num_envs) {   // the one extra workgroup: sorts the frames for the coming raster pass (mv_frame_order.h)
-        if (env == gv.num_envs) sort_frames_by_cost(gv);
-        return;
-    }
+    if (env >= gv.num_envs) return;
     const int A = gv.num_agents;
 
     EnvHeader *gh = gv.hdr + env;
@@ -320,7 +316,7 @@ __global__ __launch_bounds__(64) void reset_rearrange_kernel(GymView gv, const R
 
 void launch_step_rearrange(const GymView &gv, hipStream_t stream)
 {
-    const dim3 grid(gv.num_envs + 1), block(64);   // + 1: the frame-sort workgroup
+    const dim3 grid(gv.num_envs), block(64);
     if (gv.num_agents == 1) hipLaunchKernelGGL(step_rearrange_kernel<1>, grid, block, 0, stream, gv);
     else if (gv.num_agents == 2) hipLaunchKernelGGL(step_rearrange_kernel<2>, grid, block, 0, stream, gv);
     else if (gv.num_agents <= 4) hipLaunchKernelGGL(step_rearrange_kernel<4>, grid, block, 0, stream, gv);
