@@ -182,7 +182,8 @@ def main():
                                  "so the HBM fraction is low by construction (DESIGN.md 3.3)"},
             "kernels": {"step": {"avg_launch_ms": step_ms, "algorithmic_GBps": step_bytes_per_env * n_env / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0,
                                  "algorithmic_bytes_per_launch": step_bytes_per_env * n_env},
-                        "reset": {"avg_launch_ms": prof["reset"][0]},
+                        "reset": {"avg_launch_ms": prof["reset"][0],
+                                  "note": "auto-reset is the tail of the step kernel; this interval only holds event overhead (+ the status read-back every 16th step)"},
                         "frame_setup": {"avg_launch_ms": prof["setup"][0]}},
             "checksum": checksum,
         }

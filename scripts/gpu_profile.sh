@@ -23,7 +23,7 @@ find $OUT -name "*.db" -size +20M -delete
 du -sh $OUT >> $OUT/csv_list.txt
 # other scenario families: kernel stats only
 cd /tmp
-for S in "ObstaclesHard --envs-per-gpu 512" "Collect"; do
+for S in "ObstaclesHard --envs-per-gpu 512" "Collect" "Rearrange"; do
   N=$(echo $S | cut -d' ' -f1)
   timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats_$N -o run -- python $R/bench.py --scenario $S --steps 400 --warmup 50 --no-cpu-baseline > $OUT/prof_stats_$N.log 2>&1
   cd $R; timeout 200 python bench.py --scenario $S > $OUT/bench_$N.json 2> $OUT/bench_$N.err; cd /tmp
