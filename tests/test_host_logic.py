@@ -52,3 +52,50 @@ def test_env_seeds_host_restatement_matches_oracle_and_reference():
         r = np.empty(n, np.int32)
         ref.mvref_env_seeds(42, n, r.ctypes.data)
         assert np.array_equal(r, want)
+
+
+def test_rl_wrapper_bookkeeping_on_a_stub_env():
+    """megaverse_amd/rl.py:Wrapper (reference: megaverse_rl/megaverse_utils.py:30-93) without a device: 5-tuple step, episode
+    statistics on done, team-spirit annealing through the reward-shaping interface"""
+    from megaverse_amd.rl import Wrapper
+
+    class StubEnv:
+        num_agents, num_agents_per_env, is_multiagent, scenario_name = 4, 2, True, "Collect"
+        action_space = observation_space = None
+
+        def __init__(self):
+            self.shaping = [{"teamSpirit": 0.0, "collectAll": 5.0} for _ in range(4)]
+            self.t = 0
+
+        def reset(self):
+            return ["obs"] * 4
+
+        def step(self, actions):
+            self.t += 1
+            done = self.t % 3 == 0
+            infos = [dict(true_reward=1.0) if done else {} for _ in range(4)]
+            return ["obs"] * 4, [0.5, -1.0, 0.0, 2.0], [done] * 4, infos
+
+        def get_default_reward_shaping(self): return dict(self.shaping[0])
+        def get_current_reward_shaping(self, i): return dict(self.shaping[i])
+        def set_reward_shaping(self, rs, i): self.shaping[i] = dict(rs)
+        def close(self): pass
+
+    env = Wrapper(StubEnv(), increase_team_spirit=True, max_team_spirit_steps=200.0)
+    obs, info = env.reset()
+    assert len(obs) == 4 and info == {}
+    env.set_training_info({"approx_total_training_steps": 50})
+    for t in range(1, 7):
+        obs, rew, term, trunc, infos = env.step(None)
+        assert trunc == [False] * 4 and len(rew) == 4
+        if t % 3 == 0:
+            for i, inf in enumerate(infos):
+                st = inf["episode_extra_stats"]
+                assert inf["true_objective"] == 1.0 and st["z_collect_true_objective"] == 1.0
+                assert st["z_collect_reward"] == 3 * [0.5, -1.0, 0.0, 2.0][i]          # the sum over the episode, then reset to 0
+                assert st["z_approx_total_training_steps"] == 50 and st["teamSpirit"] == 0.25
+                assert env.get_current_reward_shaping(i) == {"teamSpirit": 0.25, "collectAll": 5.0}
+        else:
+            assert infos == [{}] * 4
+    assert env.episode_rewards == [0, 0, 0, 0]
+    env.close()
