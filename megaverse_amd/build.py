@@ -26,3 +26,27 @@ def build(force=False, quiet=True):
         cmd = ["make", "-C", CSRC] + (["-B"] if force else [])
         subprocess.check_call(cmd, stdout=subprocess.DEVNULL if quiet else None)
     return LIB
+
+
+PYBIND_DIR = os.path.join(HERE, "pybind")
+
+
+def pybind_module_path():
+    import sysconfig
+    return os.path.join(PYBIND_DIR, "megaverse" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_pybind(force=False, quiet=True):
+    """g++ + pybind11 headers -> megaverse_amd/pybind/megaverse.<abi>.so, the module with the reference's own table
+    (megaverse.extension.megaverse) on top of libmegaverse_hip.so.  Optional: the ctypes binding needs none of it."""
+    import sysconfig
+    import pybind11
+    out, src = pybind_module_path(), os.path.join(PYBIND_DIR, "megaverse_module.cpp")
+    build(force=False, quiet=quiet)
+    fresh = os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(src), os.path.getmtime(LIB))
+    if force or not fresh:
+        cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden", "-I", pybind11.get_include(),
+               "-I", sysconfig.get_paths()["include"], "-I", os.path.join(os.path.dirname(HERE), "include"), src, "-o", out,
+               "-L", HERE, "-lmegaverse_hip", "-Wl,-rpath,$ORIGIN/.."]
+        subprocess.check_call(cmd, stdout=subprocess.DEVNULL if quiet else None)
+    return out

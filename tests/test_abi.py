@@ -71,3 +71,22 @@ def test_product_sources_do_not_use_the_oracle():
         txt = open(os.path.join(ROOT, f)).read()
         body = txt.split("def cpu_baseline", 1)[1].split("\ndef ", 1)[1]
         assert "oracle" not in body
+
+
+REFERENCE_TABLE = ["num_agents", "action_space_sizes", "seed", "reset", "set_actions", "step", "is_done", "get_observation",
+                   "get_last_rewards", "true_objective", "set_render_resolution", "draw_hires", "draw_overview",
+                   "get_hires_observation", "get_reward_shaping", "set_reward_shaping", "close"]   # bindings/megaverse.cpp:274-291
+
+
+def test_pybind_module_has_the_reference_table():
+    """the pybind11 flavour of the binding (megaverse_amd/pybind): same module surface as megaverse.extension.megaverse"""
+    from megaverse_amd import build
+    build.build_pybind()
+    from megaverse_amd.pybind import megaverse as m
+    assert callable(m.set_megaverse_log_level)
+    for name in REFERENCE_TABLE:
+        assert callable(getattr(m.MegaverseGym, name)), name
+    from conftest import _has_gpu
+    if not _has_gpu():   # no device: construction must fail loudly, never fall back to a host implementation
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            m.MegaverseGym("TowerBuilding", 128, 72, 1, 1, 1, False, {})

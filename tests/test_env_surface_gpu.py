@@ -146,3 +146,35 @@ def test_rl_wrapper_bookkeeping(hip):
     obs_t, rewards, term, trunc, infos = env.step_batched(sample_actions(7, 999, 6))
     assert tuple(obs_t.shape) == (6, 3, 32, 32) and obs_t.is_cuda and rewards.shape == (6,) and term.shape == (6,)
     env.close()
+
+
+def test_pybind_flavour_equals_ctypes_flavour(hip):
+    """megaverse_amd/pybind (the reference's pybind table on the C ABI) and the ctypes binding drive the same library"""
+    from megaverse_amd import build
+    build.build_pybind()
+    from megaverse_amd.pybind import megaverse as m
+    from megaverse_amd.extension import MegaverseGym
+    from megaverse_amd.rollout import sample_actions
+    N, A = 3, 2
+    a = m.MegaverseGym("ObstaclesEasy", 48, 32, N, A, 1, False, {"episodeLengthSec": 70.0})
+    b = MegaverseGym("ObstaclesEasy", 48, 32, N, A, 1, False, {"episodeLengthSec": 70.0})
+    assert a.num_agents() == b.num_agents() == A and a.action_space_sizes() == [3, 3, 3, 2, 2, 3]
+    a.seed(5); b.seed(5); a.reset(); b.reset()
+    assert a.get_reward_shaping(0, 1) == b.get_reward_shaping(0, 1)
+    for st in range(25):
+        acts = sample_actions(3, st, N * A)
+        for e in range(N):
+            for k in range(A):
+                a.set_actions(e, k, [int(v) for v in acts[e * A + k]])
+        b.set_actions_batched(acts)
+        a.step(); b.step()
+        assert np.allclose(a.get_last_rewards(), b.get_last_rewards(), rtol=0, atol=0)
+        assert [a.is_done(e) for e in range(N)] == [b.is_done(e) for e in range(N)]
+    for e in range(N):
+        for k in range(A):
+            fa, fb = a.get_observation(e, k), b.get_observation(e, k)
+            assert fa.shape == (32, 48, 4) and np.array_equal(fa, fb)
+            assert a.true_objective(e, k) == b.true_objective(e, k)
+    a.draw_hires()
+    assert a.get_hires_observation(0, 0).shape == (432, 768, 4)
+    a.close(); b.close()
