@@ -844,6 +844,7 @@ struct Snap {
     uint8_t chunk[CHUNK_BYTES];
     int8_t heightmap[HM_DIM * HM_DIM];
     int32_t num_items, items[MAX_ITEMS][5];
+    uint8_t soko[32 * 32];   // Sokoban level cells (oracle only so far): always zero here
 };
 #pragma pack(pop)
 

@@ -74,7 +74,8 @@ static const float CARRY_SCALE = 0.78f;               // :63
 enum { CX = 32, CY = 16, CZ = 32, CHUNK = CX * CY * CZ };
 enum { MAX_BOXES = 1024, MAX_OBJECTS = 80, MAX_AGENTS = 8, MAX_TERRAIN = 16, MAX_REWARDS = 96, MAX_SHAPING = 8 };
 enum { HM_DIM = 42 };   // Collect heightfield: maxWidth == maxLength == 42 (scenario_collect.cpp:63)
-enum { SCN_TOWER = 0, SCN_OBSTACLES = 1, SCN_COLLECT = 2, SCN_REARRANGE = 3 };
+enum { SCN_TOWER = 0, SCN_OBSTACLES = 1, SCN_COLLECT = 2, SCN_REARRANGE = 3, SCN_SOKOBAN = 4 };
+enum { SOKO_DIM = 32, SOKO_WALL = 1, SOKO_GOAL = 2 };   // Sokoban level cells (scenario_sokoban.cpp:28-33), levels up to 32 x 32
 enum { MAX_STATIC = 16, MAX_ITEMS = 8 };   // Rearrange: static colliding boxes, arrangement items (arrangementSize < 8)
 enum { SHAPE_BOX = 0, SHAPE_CAPSULE = 1, SHAPE_SPHERE = 2, SHAPE_CYLINDER = 4 };   // DrawableType, env.hpp:58-69
 enum { TERRAIN_EXIT = 1, TERRAIN_LAVA = 2, TERRAIN_BUILDING_ZONE = 4 };   // scenarios/platforms.hpp:28-34
@@ -195,6 +196,9 @@ static const float SHAPING_DEFAULT_OBST[5] = {0.0f, 1.0f, 5.0f, 0.5f, 0.0f};
 // scenario_rearrange.hpp:96-102 (+ teamSpirit 0)
 static const char *SHAPING_KEYS_REARRANGE[3] = {"teamSpirit", "rearrangeOneMoreObjectCorrectPosition", "rearrangeAllObjectsCorrectPosition"};
 static const float SHAPING_DEFAULT_REARRANGE[3] = {0.0f, 1.0f, 10.0f};
+// scenario_sokoban.hpp:40-47 (+ teamSpirit 0)
+static const char *SHAPING_KEYS_SOKOBAN[4] = {"teamSpirit", "sokobanBoxOnTarget", "sokobanBoxLeavesTarget", "sokobanAllBoxesOnTarget"};
+static const float SHAPING_DEFAULT_SOKOBAN[4] = {0.0f, 1.0f, -1.0f, 10.0f};
 static const char *SHAPING_KEYS_COLLECT[5] = {"teamSpirit", "collectSingleGood", "collectSingleBad", "collectAll", "collectAbyss"};
 static const float SHAPING_DEFAULT_COLLECT[5] = {0.0f, 1.0f, -1.0f, 5.0f, -0.5f};
 
@@ -219,6 +223,13 @@ struct Env {
     int numItems = 0, numStatic = 0;
     ArrItem items[MAX_ITEMS];
     StaticBox statics[MAX_STATIC];
+    // Sokoban (scenario_sokoban.{hpp,cpp}): voxels are 2 units wide; the level's wall / goal cells (drawn as caps and pads, the
+    // walls themselves are solid but invisible); objects[] are the pushable boxes; highestTower holds numBoxesOnGoal.  The
+    // shuffled levels of the file picked last live on across episodes (SokobanScenario::levels).
+    float voxelSize = 1.0f;
+    std::vector<uint8_t> soko = std::vector<uint8_t>(SOKO_DIM * SOKO_DIM, 0);   // [x * SOKO_DIM + z]: SOKO_WALL | SOKO_GOAL
+    std::vector<std::vector<std::string>> sokoLevels;
+    const std::vector<std::string> *sokoFiles = nullptr;                         // shared, owned by the gym
     // Collect: numPlatforms holds numPositiveRewards, highestTower holds positiveRewardsCollected (scenario_collect.hpp:76)
     std::vector<int8_t> heightmap = std::vector<int8_t>(HM_DIM * HM_DIM, -1);   // [x * HM_DIM + z]: top solid y of the column, -1 = no voxels
     TerrainBox terrain[MAX_TERRAIN];
@@ -356,6 +367,19 @@ static void spawn_agents(Env &e, const std::vector<C3> &spawns)
         a.spawn[0] = sp.x; a.spawn[1] = sp.y; a.spawn[2] = sp.z;
         a.last_reward = 0; a.total_reward = 0; a.action = 0;
         std::memcpy(a.shaping, keepShaping, sizeof keepShaping);
+    }
+}
+
+struct F3 { float x, y, z; };
+// same as spawn_agents for starting positions that are not voxel corners (Sokoban)
+static void spawn_agents_at(Env &e, const std::vector<F3> &positions)
+{
+    std::vector<C3> cells;
+    for (const F3 &p : positions) cells.push_back(C3{int(floorf(p.x)), int(floorf(p.y)), int(floorf(p.z))});
+    spawn_agents(e, cells);
+    for (int i = 0; i < e.numAgents; ++i) {
+        const F3 p = positions[i < int(positions.size()) ? i : 0];
+        e.agents[i].pos = v3(p.x + 0.5f, p.y + 0.0f + AGENT_HEIGHT, p.z + 0.5f);
     }
 }
 
@@ -1105,6 +1129,103 @@ static void rearrange_generate(Env &e)
     e.barHalfWidth = 0.24f;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Sokoban -- scenario_sokoban.{hpp,cpp}: Boxoban levels (text files under $BOXOBAN_LEVELS/unfiltered/train), voxel size 2.
+// ------------------------------------------------------------------------------------------------
+static std::vector<std::string> split_tokens(const std::string &text, char delim)
+{   // splitString (util/src/string_utils.cpp:10-25) is strtok_r: empty tokens are skipped
+    std::vector<std::string> out;
+    std::string cur;
+    for (char c : text) {
+        if (c == delim) { if (!cur.empty()) out.push_back(cur); cur.clear(); }
+        else cur.push_back(c);
+    }
+    if (!cur.empty()) out.push_back(cur);
+    return out;
+}
+
+static bool read_file(const std::string &path, std::string &out)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char buf[4096];
+    size_t n;
+    out.clear();
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) out.append(buf, n);
+    fclose(f);
+    return true;
+}
+
+static void sokoban_reload_levels(Env &e)
+{   // reloadLevels :80-102: one random file; a level is stored when the NEXT ';' line is met (the file's last level never is)
+    const std::vector<std::string> &files = *e.sokoFiles;
+    const std::string &path = files[randRange(0, int(files.size()), e.rng)];
+    std::string content;
+    read_file(path, content);
+    const std::vector<std::string> lines = split_tokens(content, '\n');
+    std::vector<std::string> level;
+    for (int i = 0; i < int(lines.size()); ++i) {
+        if (lines[i].find(';') == 0) {
+            if (i > 0) e.sokoLevels.push_back(level);
+            level.clear();
+        } else level.push_back(lines[i]);
+    }
+    std::shuffle(e.sokoLevels.begin(), e.sokoLevels.end(), e.rng);
+}
+
+static void sokoban_generate(Env &e)
+{
+    Rng &rng = e.rng;
+    e.voxelSize = 2.0f;
+    std::fill(e.chunk.begin(), e.chunk.end(), 0);
+    std::fill(e.soko.begin(), e.soko.end(), 0);
+    if (e.sokoLevels.empty()) sokoban_reload_levels(e);
+    const std::vector<std::string> rows = e.sokoLevels.back();   // reset :104-120
+    e.sokoLevels.pop_back();
+
+    // createLayout :122-170
+    static const unsigned floorColors[5] = {0xffffff, 0xffffe6, 0xe6ecff, 0xffebcc, 0x555555};
+    const unsigned floorColor = floorColors[randRange(0, 5, rng)];
+    const int length = std::min(int(rows.size()), int(SOKO_DIM));
+    int width = 0;
+    std::vector<F3> agentPositions;
+    std::vector<C3> boxes;
+    for (int x = 0; x < length; ++x) width = std::max(width, std::min(int(rows[x].size()), int(SOKO_DIM)));
+    const int org[3] = {0, 0, 0}, dim[3] = {length, 3, std::max(width, 1)};
+    std::vector<uint8_t> g(size_t(dim[0]) * dim[1] * dim[2], 0);
+    auto cell = [&](int x, int y, int z) -> uint8_t & { return g[(size_t(y) * dim[2] + z) * dim[0] + x]; };
+    for (int x = 0; x < length; ++x) {
+        const std::string &row = rows[x];
+        for (int z = 0; z < std::min(int(row.size()), int(SOKO_DIM)); ++z) {
+            cell(x, 0, z) = VX_SOLID | VX_OPAQUE;   // floor
+            if (row[z] == '#') {
+                cell(x, 1, z) = VX_SOLID; cell(x, 2, z) = VX_SOLID;   // solid, not drawn
+                e.soko[x * SOKO_DIM + z] |= SOKO_WALL;
+            }
+            if (row[z] == '@' || row[z] == '+')
+                for (int k = 0; k < e.numAgents; ++k) {
+                    const float ax = float(x) + float(k % 2) * 0.5f, az = float(z) + float(k % 4 > 1) * 0.5f;
+                    agentPositions.push_back(F3{ax * e.voxelSize, float(e.voxelSize + 0.3 * float(k) * e.voxelSize), az * e.voxelSize});
+                }
+            if (row[z] == '.' || row[z] == '+') e.soko[x * SOKO_DIM + z] = SOKO_GOAL;   // g.set(...): replaces the cell (a goal is never a wall)
+            if (row[z] == '$' || row[z] == '*') boxes.push_back(C3{x, 1, z});           // ('*' puts a box down but, unlike '.', no goal)
+        }
+    }
+    merge_dense(g, org, dim, e);
+    e.L = length; e.H = 3; e.W = width;
+    e.bz[0] = e.bz[1] = e.bz[2] = e.bz[3] = 0;
+    e.layoutColor = floorColor; e.wallColor = floorColor; e.drawWalls = 0;
+    e.numTerrain = 0; e.numRewards = 0; e.numPlatforms = 0; e.numItems = 0; e.numStatic = 0;
+    e.numObjects = std::min(int(boxes.size()), int(MAX_OBJECTS));
+    for (int i = 0; i < e.numObjects; ++i) e.objects[i] = Object{boxes[i].x, boxes[i].y, boxes[i].z, 0};
+    e.solved = 0; e.highestTower = 0; e.bzReward = 0;
+    e.episodeLen = e.p_episodeLengthSec;
+    e.barHalfWidth = 0.24f;
+    if (agentPositions.empty()) agentPositions.push_back(F3{0, 0, 0});
+    spawn_agents_at(e, agentPositions);
+}
+
+
 static void env_reset(Env &e)
 {
     // ---- Env::reset, env/src/env.cpp:57-76 ; EnvState::reset env.hpp:135-151
@@ -1114,7 +1235,8 @@ static void env_reset(Env &e)
     if (e.scenario == SCN_TOWER) tower_generate(e);
     else if (e.scenario == SCN_OBSTACLES) obstacles_generate(e);
     else if (e.scenario == SCN_COLLECT) collect_generate(e);
-    else rearrange_generate(e);
+    else if (e.scenario == SCN_REARRANGE) rearrange_generate(e);
+    else sokoban_generate(e);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1244,9 +1366,21 @@ static void build_colliders(const Env &e, int self, Colliders &out)
         Collider &c = out.c[out.n++];
         const Box &b = e.boxes[i];
         c.kind = 1;
-        c.lo = v3(float(b.min[0]), float(b.min[1]) - CAP_HH, float(b.min[2]));
-        c.hi = v3(float(b.max[0]), float(b.max[1]) + CAP_HH, float(b.max[2]));
+        const float vs = e.voxelSize;   // addBoundingBoxes scales by the voxel size (layout_utils.cpp:22-34)
+        c.lo = v3(float(b.min[0]) * vs, float(b.min[1]) * vs - CAP_HH, float(b.min[2]) * vs);
+        c.hi = v3(float(b.max[0]) * vs, float(b.max[1]) * vs + CAP_HH, float(b.max[2]) * vs);
     }
+    if (e.scenario == SCN_SOKOBAN)
+        for (int i = 0; i < e.numObjects; ++i) {   // pushable boxes, scenario_sokoban.cpp:275-293: collision scale (1.15, 3, 1.15), offset (0, 0.6, 0)
+            const Object &o = e.objects[i];
+            const float vs = e.voxelSize;
+            const float sx = (vs / 2) * 0.8f, sy = 0.45f * 0.8f;
+            const float cx = (float(o.x) + 0.5f) * vs, cy = (float(o.y) + 0.2f) * vs + 0.6f, cz = (float(o.z) + 0.5f) * vs;
+            Collider &c = out.c[out.n++];
+            c.kind = 1;
+            c.lo = v3(cx - sx * 1.15f, (cy - sy * 3.0f) - CAP_HH, cz - sx * 1.15f);
+            c.hi = v3(cx + sx * 1.15f, (cy + sy * 3.0f) + CAP_HH, cz + sx * 1.15f);
+        }
     if (e.scenario == SCN_REARRANGE) {
         for (int i = 0; i < e.numStatic; ++i) {   // addStaticCollidingBox, layout_utils.cpp:70-83
             Collider &c = out.c[out.n++];
@@ -1267,7 +1401,7 @@ static void build_colliders(const Env &e, int self, Colliders &out)
                 c.hi = v3(cx + h.x, (cy + h.y) + CAP_HH, cz + h.z);
             }
     }
-    for (int i = 0; i < e.numObjects && e.scenario != SCN_REARRANGE; ++i) {
+    for (int i = 0; i < e.numObjects && e.scenario != SCN_REARRANGE && e.scenario != SCN_SOKOBAN; ++i) {
         if (e.objects[i].state > 0) continue;  // carried boxes: CF_NO_CONTACT_RESPONSE physics.hpp:76-85
         Collider &c = out.c[out.n++];
         const Object &o = e.objects[i];
@@ -1625,6 +1759,60 @@ static void on_interact(Env &e, int idx)
     }
 }
 
+static int sokoban_box_at(const Env &e, int x, int y, int z)
+{
+    for (int i = 0; i < e.numObjects; ++i)
+        if (e.objects[i].x == x && e.objects[i].y == y && e.objects[i].z == z) return i;
+    return -1;
+}
+static int sokoban_terrain(const Env &e, int x, int y, int z)
+{
+    if (y != 1 || x < 0 || x >= SOKO_DIM || z < 0 || z >= SOKO_DIM) return 0;
+    return e.soko[x * SOKO_DIM + z];
+}
+
+// SokobanScenario::step :172-236
+static void sokoban_step(Env &e)
+{
+    auto cell_of = [&](V3 p, int out[3]) { out[0] = int(floorf(p.x / e.voxelSize)); out[1] = int(floorf(p.y / e.voxelSize)); out[2] = int(floorf(p.z / e.voxelSize)); };
+    for (int i = 0; i < e.numAgents; ++i) {
+        Agent &a = e.agents[i];
+        if (!(a.action & (1 << 8))) continue;
+        const Cam cam = camera_of(a);
+        const V3 t = cam_to_world(cam, v3(0.0f, -0.44f, -1.0f));   // interactLocation
+        int boxPos[3], agentPos[3];
+        cell_of(t, boxPos);
+        const int bi = sokoban_box_at(e, boxPos[0], boxPos[1], boxPos[2]);
+        if (bi < 0) continue;
+        cell_of(v3(a.pos.x, a.pos.y + 0.05f, a.pos.z), agentPos);
+        const int d[3] = {boxPos[0] - agentPos[0], boxPos[1] - agentPos[1], boxPos[2] - agentPos[2]};
+        if (std::abs(d[0]) + std::abs(d[1]) + std::abs(d[2]) != 1) continue;   // only from the adjacent cell
+        const int want[3] = {boxPos[0] + d[0], boxPos[1] + d[1], boxPos[2] + d[2]};
+        bool occupied = false;
+        for (int j = 0; j < e.numAgents; ++j) {
+            int c[3];
+            cell_of(v3(e.agents[j].pos.x, e.agents[j].pos.y + 0.05f, e.agents[j].pos.z), c);
+            if (c[0] == want[0] && c[1] == want[1] && c[2] == want[2]) { occupied = true; break; }
+        }
+        if (occupied) continue;
+        const int fromTerrain = sokoban_terrain(e, boxPos[0], boxPos[1], boxPos[2]), toTerrain = sokoban_terrain(e, want[0], want[1], want[2]);
+        if (toTerrain == SOKO_WALL || sokoban_box_at(e, want[0], want[1], want[2]) >= 0) continue;
+        e.objects[bi].x = want[0]; e.objects[bi].y = want[1]; e.objects[bi].z = want[2];
+        if (fromTerrain != SOKO_GOAL && toTerrain == SOKO_GOAL) {
+            ++e.highestTower;   // numBoxesOnGoal
+            reward_team(e, 1, i, 1);
+            if (e.highestTower == e.numObjects && !e.solved) {
+                e.solved = 1;
+                reward_team(e, 3, i, 1);
+                e.episodeSec = std::max(e.episodeSec, e.episodeLen - 0.3f);   // doneWithTimer()
+            }
+        } else if (fromTerrain == SOKO_GOAL && toTerrain != SOKO_GOAL) {
+            --e.highestTower;
+            reward_team(e, 2, i, 1);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Env::step -- env/src/env.cpp:83-152
 // ------------------------------------------------------------------------------------------------
@@ -1678,7 +1866,7 @@ static void env_step(Env &e)
 
     // scenario->step(): objectStacking, fallDetection, zone reward (scenario_tower_building.cpp:179-199)
     for (int i = 0; i < e.numAgents; ++i)
-        if (e.agents[i].action & (1 << 8)) on_interact(e, i);
+        if (e.scenario != SCN_SOKOBAN && (e.agents[i].action & (1 << 8))) on_interact(e, i);   // (Sokoban has no ObjectStackingComponent)
 
     auto reset_agent = [&](Agent &a) {   // FallDetectionComponent::resetAgent :45-55 + controller warp() :509-517
         int p[3] = {a.spawn[0], a.spawn[1], a.spawn[2]};
@@ -1688,7 +1876,7 @@ static void env_step(Env &e)
         a.hvx = a.hvz = 0; a.vvel = 0;
     };
     for (int i = 0; i < e.numAgents; ++i)  // component_fall_detection.hpp:33-43
-        if (e.scenario != SCN_REARRANGE && e.agents[i].pos.y + 0.05f < -20.0f) {   // (Rearrange has no FallDetectionComponent)
+        if (e.scenario != SCN_REARRANGE && e.scenario != SCN_SOKOBAN && e.agents[i].pos.y + 0.05f < -20.0f) {   // (Rearrange, Sokoban: no FallDetectionComponent)
             reset_agent(e.agents[i]);
             if (e.scenario == SCN_COLLECT) reward_agent(e, 2, i, 1);   // CollectScenario::agentFell, scenario_collect.cpp:214-218
         }
@@ -1717,6 +1905,8 @@ static void env_step(Env &e)
                         e.objects[o].state = -1;
             }
         }
+    } else if (e.scenario == SCN_SOKOBAN) {
+        sokoban_step(e);
     } else if (e.scenario == SCN_REARRANGE) {
         // RearrangeScenario::step is objectStackingComponent.step only (:125-128)
     } else if (e.scenario == SCN_TOWER) {
@@ -1800,10 +1990,33 @@ static void build_prims(const Env &e, int viewer, std::vector<Prim> &out)
         const Box &b = e.boxes[i];
         if (!(b.type & VX_OPAQUE)) continue;
         Prim p; p.kind = 1; p.frame = -1;
-        p.lo = v3(float(b.min[0]), float(b.min[1]), float(b.min[2]));
-        p.hi = v3(float(b.max[0]), float(b.max[1]), float(b.max[2]));
+        const float vs = e.voxelSize;
+        p.lo = v3(float(b.min[0]) * vs, float(b.min[1]) * vs, float(b.min[2]) * vs);
+        p.hi = v3(float(b.max[0]) * vs, float(b.max[1]) * vs, float(b.max[2]) * vs);
         p.color = b.slot == 0 ? e.layoutColor : e.wallColor;
         out.push_back(p);
+    }
+    if (e.scenario == SCN_SOKOBAN) {   // addEpisodeDrawables :243-294
+        const float vs = e.voxelSize;
+        for (int x = 0; x < e.L; ++x)            // wall caps (0.7 high, the walls themselves are not drawn) and goal pads
+            for (int z = 0; z < e.W; ++z) {
+                const int t = e.soko[x * SOKO_DIM + z];
+                if (!t) continue;
+                const float h = t == SOKO_WALL ? 0.35f : 0.025f;
+                const V3 c = v3(vs * float(x) + vs / 2, vs + h, vs * float(z) + vs / 2);
+                Prim p; p.kind = 1; p.frame = -1;
+                p.lo = v3(c.x - 1.0f, c.y - h, c.z - 1.0f); p.hi = v3(c.x + 1.0f, c.y + h, c.z + 1.0f);
+                p.color = t == SOKO_WALL ? 0xffa770 : 0x50c878;   // LIGHT_ORANGE / LIGHT_GREEN
+                out.push_back(p);
+            }
+        for (int i = 0; i < e.numObjects; ++i) {   // the boxes
+            const Object &o = e.objects[i];
+            const float sx = (vs / 2) * 0.8f, sy = 0.45f * 0.8f;
+            const V3 c = v3((float(o.x) + 0.5f) * vs, (float(o.y) + 0.2f) * vs, (float(o.z) + 0.5f) * vs);
+            Prim p; p.kind = 1; p.frame = -1; p.color = 0x3a7fa6;   // DARK_BLUE
+            p.lo = v3(c.x - sx, c.y - sy, c.z - sx); p.hi = v3(c.x + sx, c.y + sy, c.z + sx);
+            out.push_back(p);
+        }
     }
     if (e.scenario == SCN_TOWER) {   // building zone slab, layout_utils.cpp:53-68
         Prim p; p.kind = 1; p.frame = -1;
@@ -1843,7 +2056,7 @@ static void build_prims(const Env &e, int viewer, std::vector<Prim> &out)
                 out.push_back(p);
             }
     }
-    for (int i = 0; i < e.numObjects && e.scenario != SCN_REARRANGE; ++i) {  // component_object_stacking.hpp:170-198, :146-152
+    for (int i = 0; i < e.numObjects && e.scenario != SCN_REARRANGE && e.scenario != SCN_SOKOBAN; ++i) {  // component_object_stacking.hpp:170-198, :146-152
         const Object &o = e.objects[i];
         Prim p; p.kind = 1; p.color = COLOR_MOVABLE_BOX;
         if (o.state <= 0) {
@@ -2159,6 +2372,7 @@ struct Gym {
     std::vector<uint8_t> done;
     std::vector<float> trueObjective;
     std::vector<uint8_t> obs;
+    std::vector<std::string> sokoFiles;   // Sokoban: the level files found at construction (scenario_sokoban.cpp:40-78)
     Rng rng{std::random_device{}()};  // megaverse.cpp:253
 
     template <typename F> void parallel_envs(F f)
@@ -2228,13 +2442,28 @@ mvo_gym *mvo_create(const char *scenario, int w, int h, int num_envs, int num_ag
         op.platformTypes = {s == "obstacleswalls" ? PT_WALL : s == "obstaclessteps" ? PT_STEP : PT_LAVA};
     } else if (s == "collect") scen = SCN_COLLECT;   // scenarios/init.hpp:45
     else if (s == "rearrange") scen = SCN_REARRANGE;   // scenarios/init.hpp:49
+    else if (s == "sokoban") scen = SCN_SOKOBAN;       // scenarios/init.hpp:46
     else { fprintf(stderr, "mv_oracle: unknown scenario %s\n", s.c_str()); return nullptr; }
     if (num_agents_per_env < 1 || num_agents_per_env > MAX_AGENTS || num_envs < 1) return nullptr;
     auto *g = new mvo_gym();
+    if (scen == SCN_SOKOBAN) {   // $BOXOBAN_LEVELS (or ~/datasets/boxoban) / unfiltered / train / 000.txt .. 999.txt
+        const char *dir = getenv("BOXOBAN_LEVELS");
+        std::string base = dir && *dir ? dir : "~/datasets/boxoban";
+        const size_t tilde = base.find('~');
+        if (tilde != std::string::npos) { const char *home = getenv("HOME"); base.replace(tilde, 1, home ? home : ""); }
+        for (int i = 0; i <= 999; ++i) {
+            char name[16];
+            snprintf(name, sizeof name, "%03d.txt", i);
+            const std::string path = base + "/unfiltered/train/" + name;
+            if (FILE *f = fopen(path.c_str(), "rb")) { fclose(f); g->sokoFiles.push_back(path); }
+        }
+        if (g->sokoFiles.empty()) { fprintf(stderr, "mv_oracle: no Boxoban levels under %s\n", base.c_str()); delete g; return nullptr; }
+    }
     g->w = w; g->h = h; g->numEnvs = num_envs; g->numAgents = num_agents_per_env; g->numThreads = std::max(1, num_threads);
     for (int i = 0; i < num_envs; ++i) {
         auto e = std::make_unique<Env>();
         e->numAgents = num_agents_per_env;
+        if (scen == SCN_SOKOBAN) { e->p_episodeLengthSec = 80.0f; e->sokoFiles = &g->sokoFiles; }   // scenario_sokoban.hpp:49-53
         for (int k = 0; k < n_params; ++k) {
             if (!strcmp(keys[k], "episodeLengthSec")) e->p_episodeLengthSec = vals[k];
             if (!strcmp(keys[k], "verticalLookLimitRad")) e->p_verticalLookLimitRad = vals[k];
@@ -2246,15 +2475,16 @@ mvo_gym *mvo_create(const char *scenario, int w, int h, int num_envs, int num_ag
         }
         e->scenario = scen;
         e->op = op;
-        e->numShaping = scen == SCN_TOWER ? 4 : scen == SCN_REARRANGE ? 3 : 5;
+        e->numShaping = scen == SCN_TOWER || scen == SCN_SOKOBAN ? 4 : scen == SCN_REARRANGE ? 3 : 5;
         e->shapingKeys = scen == SCN_TOWER ? SHAPING_KEYS_TOWER : scen == SCN_OBSTACLES ? SHAPING_KEYS_OBST
-                       : scen == SCN_COLLECT ? SHAPING_KEYS_COLLECT : SHAPING_KEYS_REARRANGE;
+                       : scen == SCN_COLLECT ? SHAPING_KEYS_COLLECT : scen == SCN_SOKOBAN ? SHAPING_KEYS_SOKOBAN : SHAPING_KEYS_REARRANGE;
         for (int a = 0; a < MAX_AGENTS; ++a) {
             std::memset(e->agents[a].shaping, 0, sizeof e->agents[a].shaping);
             for (int k = 0; k < e->numShaping; ++k)
                 e->agents[a].shaping[k] = scen == SCN_TOWER ? SHAPING_DEFAULT_TOWER[k]
                                         : scen == SCN_COLLECT ? SHAPING_DEFAULT_COLLECT[k]
                                         : scen == SCN_REARRANGE ? SHAPING_DEFAULT_REARRANGE[k]
+                                        : scen == SCN_SOKOBAN ? SHAPING_DEFAULT_SOKOBAN[k]
                                         : (k == 4 ? carriedDefault : SHAPING_DEFAULT_OBST[k]);
         }
         g->envs.push_back(std::move(e));
@@ -2344,6 +2574,7 @@ struct SnapHeader {
     uint8_t chunk[CHUNK];
     int8_t heightmap[HM_DIM * HM_DIM];
     int32_t num_items, items[MAX_ITEMS][5];   // Rearrange: shape, colour, offset x y z
+    uint8_t soko[SOKO_DIM * SOKO_DIM];        // Sokoban: wall / goal cells
 };
 #pragma pack(pop)
 
@@ -2393,6 +2624,7 @@ void mvo_snapshot(mvo_gym *g, int env, void *out)
     }
     std::memcpy(s->chunk, e.chunk.data(), CHUNK);
     std::memcpy(s->heightmap, e.heightmap.data(), HM_DIM * HM_DIM);
+    std::memcpy(s->soko, e.soko.data(), SOKO_DIM * SOKO_DIM);
     s->num_items = e.scenario == SCN_REARRANGE ? e.numItems : 0;
     for (int i = 0; i < s->num_items; ++i) {
         s->items[i][0] = e.items[i].shape; s->items[i][1] = (int32_t)e.items[i].color;

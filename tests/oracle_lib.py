@@ -24,7 +24,7 @@ SNAP = np.dtype([
     ("bar_half_width", "<f4"), ("boxes", "<i4", (MAX_BOXES, 8)), ("terrain", "<i4", (MAX_TERRAIN, 8)),
     ("objects", "i1", (MAX_OBJECTS, 4)), ("rewards", "i1", (MAX_REWARDS, 4)),
     ("agents", SNAP_AGENT, MAX_AGENTS), ("chunk", "u1", CHUNK), ("heightmap", "i1", HM_DIM * HM_DIM),
-    ("num_items", "<i4"), ("items", "<i4", (8, 5)),
+    ("num_items", "<i4"), ("items", "<i4", (8, 5)), ("soko", "u1", 32 * 32),
 ])
 
 

@@ -90,3 +90,10 @@ def test_pybind_module_has_the_reference_table():
     if not _has_gpu():   # no device: construction must fail loudly, never fall back to a host implementation
         with pytest.raises(RuntimeError, match="no HIP device"):
             m.MegaverseGym("TowerBuilding", 128, 72, 1, 1, 1, False, {})
+
+
+def test_debug_snapshot_record_has_the_oracles_layout():
+    """tests compare mv_debug_snapshot and mvo_snapshot byte for byte: the two packed records must have one size"""
+    import oracle_lib
+    from megaverse_amd import extension as ext
+    assert ext.load_library().mv_debug_snapshot_size(None) == oracle_lib.SNAP.itemsize
