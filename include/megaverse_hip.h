@@ -129,6 +129,9 @@ int mv_debug_generate_episode(const char *scenario, int32_t num_agents, int32_t 
  * time; replaces the serial Env::reset inside VectorEnv::step, vector_env.cpp:93-105) for `rounds` episodes per env
  * and compares each delivered episode with sequential generation.  0 = identical. */
 int mv_debug_feeder_selftest(const char *scenario, int32_t num_envs, int32_t num_agents, int32_t threads, int32_t rounds);
+/* Host-only: the first n episodes of the Sokoban level generator (scenario_sokoban.cpp:80-170; its kernels come next) as n
+ * packed records; out == NULL: record size.  Returns n, -1 on error. */
+int mv_debug_generate_sokoban(int32_t num_agents, int32_t env_seed, int32_t n, float base_episode_len, void *out, int32_t out_bytes);
 
 #ifdef __cplusplus
 }

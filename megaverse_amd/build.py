@@ -23,7 +23,7 @@ def is_stale():
 def build(force=False, quiet=True):
     """hipcc --offload-arch=gfx950 ... -> libmegaverse_hip.so (cross-compiles without a GPU)."""
     if force or is_stale():
-        cmd = ["make", "-C", CSRC] + (["-B"] if force else [])
+        cmd = ["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 1))] + (["-B"] if force else [])
         subprocess.check_call(cmd, stdout=subprocess.DEVNULL if quiet else None)
     return LIB
 

@@ -1009,6 +1009,24 @@ int mv_debug_feeder_selftest(const char *scenario_name, int32_t num_envs, int32_
     return 0;
 }
 
+// Host-only test hook for the Sokoban generator (the scenario's kernels are not written yet): the first `n` episodes an env
+// seeded with env_seed generates from the level files under $BOXOBAN_LEVELS, as n consecutive SokobanBlob records.
+int mv_debug_generate_sokoban(int32_t num_agents, int32_t env_seed, int32_t n, float base_episode_len, void *out, int32_t out_bytes)
+{
+    if (!out) return (int)sizeof(SokobanBlob);
+    if (num_agents < 1 || num_agents > MAX_AGENTS || n < 1 || (size_t)out_bytes < (size_t)n * sizeof(SokobanBlob))
+        return fail("mv_debug_generate_sokoban: bad arguments");
+    const std::vector<std::string> files = find_boxoban_level_files();
+    if (files.empty()) return fail("mv_debug_generate_sokoban: no Boxoban levels found (BOXOBAN_LEVELS)");
+    std::mt19937 rng;
+    rng.seed((unsigned long)env_seed);
+    SokobanLevels levels;
+    for (int i = 0; i < n; ++i)
+        if (!generate_sokoban_episode(rng, levels, files, num_agents, base_episode_len, reinterpret_cast<SokobanBlob *>(out)[i]))
+            return fail("mv_debug_generate_sokoban: unreadable level file");
+    return n;
+}
+
 int mv_debug_rng(int32_t device, uint32_t seed, int32_t what, const int32_t *lo, const int32_t *hi, int32_t n, void *out)
 {
     HIP_TRY(hipSetDevice(device));

@@ -1,6 +1,8 @@
 // megaverse_amd/csrc/mv_gen.h -- host-side episode generators (see mv_gen_obstacles.cpp)
 #pragma once
 #include <random>
+#include <string>
+#include <vector>
 
 #include "mv_types.h"
 
@@ -23,5 +25,15 @@ void generate_collect_episode(std::mt19937 &rng, int num_agents, float base_epis
 
 // Advances `rng` exactly like Env::reset + RearrangeScenario::reset + spawnAgents + addEpisodeDrawables and fills `out`.
 void generate_rearrange_episode(std::mt19937 &rng, int num_agents, float base_episode_len, RearrangeBlob &out);
+
+// Sokoban keeps state across episodes: the shuffled levels of the file picked last (SokobanScenario::levels)
+struct SokobanLevels {
+    std::vector<std::vector<std::string>> pending;
+};
+// $BOXOBAN_LEVELS (or ~/datasets/boxoban) / unfiltered / train / 000.txt .. 999.txt that exist (scenario_sokoban.cpp:40-78)
+std::vector<std::string> find_boxoban_level_files();
+// Advances `rng` exactly like Env::reset + SokobanScenario::reset + spawnAgents and fills `out`; false if a level file is unreadable.
+bool generate_sokoban_episode(std::mt19937 &rng, SokobanLevels &levels, const std::vector<std::string> &files, int num_agents,
+                              float base_episode_len, SokobanBlob &out);
 
 }  // namespace mv

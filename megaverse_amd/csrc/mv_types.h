@@ -18,7 +18,8 @@ enum : int {
     COLLECT_MAX_BOXES = 1024, COLLECT_MAX_REWARDS = 96, HM_DIM = 42, HM_BYTES = 1792,
 };
 
-enum : int { SCN_TOWER = 0, SCN_OBSTACLES = 1, SCN_COLLECT = 2, SCN_REARRANGE = 3 };
+enum : int { SCN_TOWER = 0, SCN_OBSTACLES = 1, SCN_COLLECT = 2, SCN_REARRANGE = 3, SCN_SOKOBAN = 4 };
+enum : int { SOKO_DIM = 32, SOKO_WALL = 1, SOKO_GOAL = 2 };                            // Sokoban level cells (scenario_sokoban.cpp:28-33)
 enum : int { MAX_ITEMS = 8, NUM_STATIC = 9 };                                         // Rearrange: arrangement items, static colliding boxes
 enum : int { SHAPE_BOX = 0, SHAPE_CAPSULE = 1, SHAPE_SPHERE = 2, SHAPE_CYLINDER = 4 };   // DrawableType, env/include/env/env.hpp:58-69
 enum : int { TERRAIN_EXIT = 1, TERRAIN_LAVA = 2, TERRAIN_BUILDING_ZONE = 4 };   // scenarios/platforms.hpp:28-34
@@ -147,6 +148,20 @@ struct alignas(16) RearrangeBlob {
     LayoutBox boxes[TOWER_BOXES];
     ArrangementItem items[MAX_ITEMS];
     MovableObject objects[MAX_ITEMS];
+};
+
+// Sokoban episode (host generator only so far: the kernels for it are not written yet, mv_create rejects the name)
+struct alignas(16) SokobanBlob {
+    int32_t seq;
+    int32_t num_boxes, num_objects;
+    int32_t dim[3];
+    int32_t floor_color;
+    float episode_len;
+    float spawn[MAX_AGENTS][3];          // agentStartingPositions (not voxel corners: agents share the player's cell)
+    float yaw_frand[MAX_AGENTS];
+    LayoutBox boxes[MAX_BOXES];          // in voxels; one voxel is 2 units wide
+    MovableObject objects[MAX_OBJECTS];  // the pushable boxes
+    uint8_t cells[SOKO_DIM * SOKO_DIM];  // [x * SOKO_DIM + z]: SOKO_WALL / SOKO_GOAL
 };
 
 // Collect episode.  `boxes` comes last so that only the used prefix needs to travel.

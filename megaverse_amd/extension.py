@@ -55,6 +55,7 @@ SYMBOLS = [
     ("mv_debug_math", C.c_int, [_I, _I, _P, _P, _I, _P]),
     ("mv_debug_generate_episode", C.c_int, [C.c_char_p, _I, _I, _I, _F, _P, _I]),
     ("mv_debug_feeder_selftest", C.c_int, [C.c_char_p, _I, _I, _I, _I]),
+    ("mv_debug_generate_sokoban", C.c_int, [_I, _I, _I, _F, _P, _I]),
 ]
 
 

@@ -132,3 +132,44 @@ def test_boxes_move_one_cell_at_a_time_never_into_walls_or_each_other_and_reward
             prev[e] = s
     assert moved > 10
     g.close()
+
+
+def test_product_host_generator_matches_the_oracle():
+    """mv_gen_sokoban.cpp (through the host-only hook mv_debug_generate_sokoban) against the oracle: same master seed -> same
+    level sequence per env (file pick, shuffle, pops), same merged slabs, cells, boxes, spawn positions and rotations"""
+    from megaverse_amd import extension as ext
+    from test_host_generators import LAYOUT_BOX, OBJ, env_seeds
+    blob_t = np.dtype([("seq", "<i4"), ("num_boxes", "<i4"), ("num_objects", "<i4"), ("dim", "<i4", 3), ("floor_color", "<i4"),
+                       ("episode_len", "<f4"), ("spawn", "<f4", (8, 3)), ("yaw_frand", "<f4", 8), ("boxes", LAYOUT_BOX, 128),
+                       ("objects", OBJ, 80), ("cells", "u1", 1024)], align=False)
+    lib = ext.load_library()
+    assert lib.mv_debug_generate_sokoban(1, 0, 1, 80.0, None, 0) == blob_t.itemsize
+    n_env, A, master, episodes = 5, 3, 123, 8      # 8 > 6 usable levels per file: crosses a reload
+    og = oracle_lib.OracleGym("Sokoban", 16, 16, n_env, A, 2)
+    og.seed(master)
+    seeds = env_seeds(master, n_env)
+    blobs = []
+    for e in range(n_env):
+        buf = np.zeros(episodes, blob_t)
+        assert lib.mv_debug_generate_sokoban(A, int(seeds[e]), episodes, 80.0, buf.ctypes.data, buf.nbytes) == episodes, lib.mv_last_error()
+        blobs.append(buf)
+    for ep in range(episodes):
+        og.reset()
+        for e in range(n_env):
+            b, s = blobs[e][ep], og.snapshot(e)
+            nb = int(s["num_boxes"])
+            assert int(b["num_boxes"]) == nb
+            bb = b["boxes"][:nb]
+            assert np.array_equal(np.concatenate([bb["min"], bb["max"], bb["type"][:, None], bb["slot"][:, None]], 1), s["boxes"][:nb])
+            no = int(s["num_objects"])
+            assert int(b["num_objects"]) == no
+            o = b["objects"][:no]
+            assert np.array_equal(np.stack([o["x"], o["y"], o["z"], o["state"]], 1), s["objects"][:no])
+            assert np.array_equal(b["cells"], s["soko"]) and int(b["floor_color"]) == int(s["layout_color"])
+            assert [int(v) for v in b["dim"]] == [int(s["L"]), int(s["H"]), int(s["W"])] and float(b["episode_len"]) == 80.0
+            for k in range(A):
+                want = np.array([b["spawn"][k][0] + np.float32(0.5), b["spawn"][k][1] + np.float32(0.0) + np.float32(1.75), b["spawn"][k][2] + np.float32(0.5)], np.float32)
+                assert np.array_equal(want, s["agents"][k]["pos"]), (ep, e, k)
+                ang = float(np.float32(np.float32(b["yaw_frand"][k]) * np.float32(3.14159274)) * np.float32(2))
+                assert abs(np.cos(ang) - float(s["agents"][k]["basis"][0])) < 2e-6
+    og.close()
