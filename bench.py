@@ -1,22 +1,28 @@
 #!/usr/bin/env python
 """bench.py -- agent observations/sec of the batched TowerBuilding step() on MI355X.
 
-Contract (driver): python bench.py --gpus N --steps K --warmup W ; for N>1 launched through
-torch.distributed.run, one rank per GPU.  Prints ONE JSON line on rank 0.
+Contract (driver): python bench.py --gpus N --steps K --warmup W.  Prints ONE JSON line on rank 0.
+N > 1: one rank per GPU over RCCL.  Launched through torch.distributed.run the ranks are taken from the
+environment; launched plainly (`python bench.py --gpus 8`) the script re-executes itself under
+torch.distributed.run on 127.0.0.1 with a free port.
 
-A "step" is one pass of the hot path over one batch: sample random actions (device, counter-based)
--> step kernel (physics + scenario logic) -> reset kernel (auto-reset of finished episodes) ->
-raster kernel (128x128 RGBA8 first-person observation per agent written into the HBM slab).
-Workload at N=1: BASELINE.json configs[1] = TowerBuilding, num_envs=1024, num_agents_per_env=1,
-obs 128x128.  N>1: weak scaling, 1024 envs per GPU, envs sharded by contiguous blocks with
-job-wide seeds (a sharded run simulates exactly the envs the single-process run of N*1024 would).
-No data-path collective by default: envs are independent and the consumer of an observation shard is
-the GPU that produced it (DESIGN.md "multi-GPU"); --gather-obs adds the RCCL all-gather of the
-observation slab for the single-consumer layout.
+A "step" is one pass of the hot path over one batch: sample random actions (device, counter-based) -> step
+kernel (physics + scenario logic + auto-reset of finished episodes) -> frame setup -> frame sort -> raster kernel
+(128x128 RGBA8 first-person observation per agent written into the HBM slab).
+Workload at N=1: BASELINE.json configs[1] = TowerBuilding, num_envs=1024, num_agents_per_env=1, obs 128x128.
+N>1: weak scaling, 1024 envs per GPU, envs sharded by contiguous blocks with job-wide seeds (a sharded run
+simulates exactly the envs the single-process run of N*1024 would) and -- north_star's layout -- ONE data-path
+collective: the RCCL all-gather of the observation slab, issued on a communication stream from one of two
+slabs so that step t+1's kernels overlap gather t.  `value` is the rate WITH the gather; `value_no_gather` (same
+line) is the rate when every GPU's consumer reads its own shard (the reference's multi-GPU mode).
+
+Timing: the K timed steps carry no instrumentation.  The per-kernel figures of `roofline` / `roofline_physics`
+come from a second, untimed loop with HIP events on the gym's stream (mv_profile_begin).
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -25,17 +31,16 @@ sys.path.insert(0, ROOT)
 
 METRIC = "agent observations/sec (whole node), TowerBuilding 128x128 obs, random policy"
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+XGMI_PEAK_GBS = 7 * 153.0      # 7 point-to-point links x ~153 GB/s per GPU
 
 
-def cpu_baseline(scenario, obs_w, obs_h, agents, budget_s=12.0):
-    """Oracle (CPU restatement, kind 'port') timed on this box's host cores on a bounded sample of
-    the same workload: same scenario/obs size/seed/action stream, fewer envs and steps."""
+def cpu_baseline(scenario, obs_w, obs_h, n_env, agents, budget_s=14.0):
+    """Oracle (CPU restatement, kind 'port') timed on this box's host cores on a bounded sample of the same
+    workload: same scenario / env count / obs size / seed / action stream, fewer steps."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     from megaverse_amd.rollout import sample_actions, action_masks
-    cores = os.cpu_count() or 1
-    threads = max(1, cores)
-    n_env = max(8, 2 * threads)
+    threads = max(1, os.cpu_count() or 1)
     g = oracle_lib.OracleGym(scenario, obs_w, obs_h, n_env, agents, threads)
     g.seed(42)
     g.reset()
@@ -48,12 +53,91 @@ def cpu_baseline(scenario, obs_w, obs_h, agents, budget_s=12.0):
         g.step()
         steps += 1
         el = time.perf_counter() - t0
-        if el > budget_s or steps >= 400:
+        if (el > budget_s and steps >= 2) or steps >= 400:
             break
     g.close()
     return {"value": n_env * agents * steps / el, "unit": "agent observations/sec", "cores": threads, "kind": "port",
             "sample": f"oracle (CPU restatement, software raster) {scenario} num_envs={n_env} agents={agents} obs {obs_w}x{obs_h}, "
                       f"{steps} steps in {el:.1f}s on {threads} threads (static block partition like vector_env.cpp:65-68)"}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def respawn_under_torchrun(n):
+    """`python bench.py --gpus N` -> the same command line, one rank per GPU, through torch.distributed.run"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+class ObsGather:
+    """All-gather of the observation slab, double buffered: step t renders into slab t % 2; the collective for slab b runs on a
+    communication stream (ordered after the raster by an event) while the compute stream goes on with step t + 1 into the other
+    slab; before slab b is rendered into again the compute stream waits for its gather.  CPU / gloo (dry run): same bookkeeping
+    with async work handles."""
+
+    def __init__(self, dist, torch, local_shape, world, device, cuda):
+        self.dist, self.torch, self.cuda = dist, torch, cuda
+        self.local = [torch.zeros(local_shape, dtype=torch.uint8, device=device) for _ in range(2)]
+        self.out = [torch.zeros((world * local_shape[0],) + tuple(local_shape[1:]), dtype=torch.uint8, device=device) for _ in range(2)]
+        self.work = [None, None]
+        if cuda:
+            self.comm = torch.cuda.Stream(device=device)
+            self.rendered = [torch.cuda.Event() for _ in range(2)]
+            self.gathered = [None, None]
+
+    def before_render(self, b):
+        """slab b is about to be overwritten: its previous gather must have read it"""
+        if self.cuda:
+            if self.gathered[b] is not None:
+                self.torch.cuda.current_stream().wait_event(self.gathered[b])
+        elif self.work[b] is not None:
+            self.work[b].wait()
+            self.work[b] = None
+
+    def after_render(self, b):
+        if self.cuda:
+            cur = self.torch.cuda.current_stream()
+            self.rendered[b].record(cur)
+            with self.torch.cuda.stream(self.comm):
+                self.comm.wait_event(self.rendered[b])
+                w = self.dist.all_gather_into_tensor(self.out[b], self.local[b], async_op=True)
+                w.wait()   # orders the communication stream after the collective; the host does not block
+                ev = self.torch.cuda.Event()
+                ev.record(self.comm)
+                self.gathered[b] = ev
+        else:
+            self.work[b] = self.dist.all_gather_into_tensor(self.out[b], self.local[b], async_op=True)
+
+    def drain(self):
+        if self.cuda:
+            self.comm.synchronize()
+        else:
+            for b in range(2):
+                if self.work[b] is not None:
+                    self.work[b].wait()
+                    self.work[b] = None
+
+
+class DryGym:
+    """--dry-run stand-in for the gym (no device): fills the slab with a (rank, step) pattern so that the launcher, the gather
+    pipeline and the JSON line can be exercised on CPU with gloo (tests/test_distributed_cpu.py)."""
+
+    def __init__(self, rank):
+        self.rank, self.buf, self.i = rank, None, 0
+
+    def set_obs_tensor(self, t): self.buf = t
+    def sample_random_actions(self, seed, i): self.i = i
+    def step(self): self.buf.fill_((self.rank * 31 + self.i) % 251)
+    def close(self): pass
 
 
 def main():
@@ -64,131 +148,195 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=1024)
     ap.add_argument("--agents", type=int, default=1)
     ap.add_argument("--scenario", default="TowerBuilding",
-                    help="TowerBuilding (headline), Obstacles{Easy,Medium,Hard,Walls,Steps,Lava}, Collect, or Mixed (configs[4])")
+                    help="TowerBuilding (headline), Obstacles{Easy,Medium,Hard,Walls,Steps,Lava}, Collect, Rearrange, Sokoban, or Mixed (configs[4])")
     ap.add_argument("--obs", type=int, nargs=2, default=[128, 128], metavar=("W", "H"))
-    ap.add_argument("--gather-obs", action="store_true", help="RCCL all-gather of the observation slab every step")
+    ap.add_argument("--no-gather-obs", action="store_true", help="N>1: skip the gather-on leg (value = the no-gather rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-steps", type=int, default=256, help="steps timed per kernel with HIP events inside the timed region")
+    ap.add_argument("--pixels", default="fast", choices=["fast", "exact"], help="observation arithmetic (DESIGN.md 'pixel tolerance')")
+    ap.add_argument("--profile-steps", type=int, default=256, help="steps of the untimed per-kernel profile loop (HIP events on the gym's stream)")
+    ap.add_argument("--dry-run", action="store_true", help="CPU / gloo run of the launcher + gather pipeline with a stand-in gym")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args.gpus)
 
     import torch
     import torch.distributed as dist
-    from megaverse_amd.extension import MegaverseGym
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    if not torch.cuda.is_available():
+    dry = args.dry_run
+    if not dry and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    device = "cpu" if dry else f"cuda:{local_rank}"
+    if not dry:
+        torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if dry:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device(device))
 
     W, H = args.obs
     n_env, A = args.envs_per_gpu, args.agents
     mixed = args.scenario.lower() == "mixed"
-    if mixed:   # BASELINE.json configs[4]: the in-scope MEGAVERSE8 members dealt round-robin by env index
+    frames = n_env * A
+    if dry:
+        gym = DryGym(rank)
+    elif mixed:   # BASELINE.json configs[4]: the in-scope MEGAVERSE8 members dealt round-robin by env index
         from megaverse_amd.multitask import MEGAVERSE_IN_SCOPE, MultiTaskGym
         gym = MultiTaskGym(MEGAVERSE_IN_SCOPE, W, H, n_env, A, 8, {}, device=local_rank, env_offset=rank * n_env, total_envs=world * n_env)
-        obs = gym.attach(f"cuda:{local_rank}")
+        gym.set_pixel_mode(args.pixels)
     else:
+        from megaverse_amd.extension import MegaverseGym
         gym = MegaverseGym(args.scenario, W, H, n_env, A, 8, False, {},   # 8 = episode-feeder threads (host-generated scenarios)
                            device=local_rank, env_offset=rank * n_env, total_envs=world * n_env)
-        stream = torch.cuda.current_stream()
-        gym.set_stream(stream.cuda_stream)
-        obs = torch.empty((n_env * A, H, W, 4), dtype=torch.uint8, device=f"cuda:{local_rank}")
-        gym.set_obs_buffer(obs.data_ptr())
-    gathered = None
-    if args.gather_obs and world > 1:
-        gathered = torch.empty((world * n_env * A, H, W, 4), dtype=torch.uint8, device=f"cuda:{local_rank}")
-    gym.seed(42)
-    gym.reset()
+        gym.set_stream(torch.cuda.current_stream().cuda_stream)
+        gym.set_pixel_mode(args.pixels)
 
-    def one_step(i):
+    gather = ObsGather(dist, torch, (frames, H, W, 4), world, device, cuda=not dry) if world > 1 else None
+    slabs = gather.local if gather else [torch.zeros((frames, H, W, 4), dtype=torch.uint8, device=device)]
+
+    def bind(b):
+        if dry:
+            gym.set_obs_tensor(slabs[b])
+        elif mixed:
+            gym.attach_tensor(slabs[b])
+        else:
+            gym.set_obs_buffer(slabs[b].data_ptr())
+
+    bind(0)
+    if not dry:
+        gym.seed(42)
+        gym.reset()
+
+    def one_step(i, with_gather):
+        b = i & 1 if with_gather else 0
+        if with_gather:
+            gather.before_render(b)
+            bind(b)
         gym.sample_random_actions(1234, i)
         gym.step()
-        if gathered is not None:
+        if with_gather:
             if mixed:
-                gym.synchronize()
-            dist.all_gather_into_tensor(gathered, obs)
-
-    for i in range(args.warmup):
-        one_step(i)
+                gym.synchronize()   # (one stream per scenario: join them before the collective reads the slab)
+            gather.after_render(b)
 
     def fence():
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
+        if gather:
+            gather.drain()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
 
-    fence()
-    prof_n = min(args.profile_steps, args.steps)
-    gym.profile_begin(prof_n)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_step(args.warmup + i)
-    fence()
-    elapsed = time.perf_counter() - t0
-    prof = gym.profile_end()
-    if mixed:   # one profile per scenario: report the sums (the launches overlap on the GPU, so these are upper bounds)
-        prof = {k: (sum(p[k][0] for p in prof), prof[0][k][1]) for k in prof[0]}
+    def timed(first, with_gather):
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            one_step(first + i, with_gather)
+        fence()
+        el = time.perf_counter() - t0
+        t = torch.tensor([el], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    checksum = int(obs[::97].to(torch.int64).sum().item())   # touch the result so nothing is optimised away
+    do_gather = world > 1 and not args.no_gather_obs
+    step0 = 0
+    for i in range(args.warmup):
+        one_step(step0 + i, do_gather)
+    step0 += args.warmup
+    elapsed = timed(step0, do_gather)        # THE timed region: exactly --steps steps, no instrumentation
+    step0 += args.steps
+    last_gathered = step0 - 1
+    elapsed_no_gather = None
+    if do_gather:                            # second leg, same step count, observations stay on the producing GPU
+        bind(0)
+        elapsed_no_gather = timed(step0, False)
+        step0 += args.steps
+
+    # ---- per-kernel profile: a separate, untimed loop with HIP events on the gym's stream
+    prof = None
+    if not dry and not mixed and args.profile_steps > 0:
+        fence()
+        bind(0)
+        gym.profile_begin(args.profile_steps)
+        for i in range(args.profile_steps):
+            one_step(step0 + i, False)
+        prof = gym.profile_end()
+        step0 += args.profile_steps
+
+    checksum = int(slabs[0][::97].to(torch.int64).sum().item())   # touch the result so nothing is optimised away
+    if dry and do_gather:   # every rank's shard of the last gathered step must have arrived, in rank order
+        g0 = gather.out[last_gathered & 1]
+        for r in range(world):
+            assert int(g0[r * frames, 0, 0, 0]) == (r * 31 + last_gathered) % 251, "gathered slab does not hold rank %d's shard" % r
 
     if rank == 0:
-        total_obs = world * n_env * A * args.steps
-        frames = n_env * A
-        # algorithmic bytes of one raster launch (DESIGN.md "kernels"): RGBA8 frame written once +
-        # the frame's scene (header 128 B, 16 layout boxes 512 B, 80 movable boxes 320 B, agents 128 B each)
+        total_obs = world * frames * args.steps
         obst = args.scenario.lower().startswith("obstacles")
         collect = args.scenario.lower() == "collect"
-        # Obstacles: 128 layout boxes 4096 B + 16 terrain boxes 512 B + 16 reward objects 64 B;
-        # Collect: ~75 merged slabs on average (measured over 3000 generated landscapes) * 32 B + 96 diamonds * 4 B + nothing else
+        # algorithmic bytes (DESIGN.md "kernels").  Raster, per frame: the RGBA8 frame written once + the frame's scene (header 128 B,
+        # layout boxes, 80 movable boxes 320 B, agents 128 B each).  Obstacles: 128 layout boxes 4096 B + 16 terrain boxes 512 B + 16
+        # reward objects 64 B; Collect: ~75 merged slabs on average (3000 generated landscapes) * 32 B + 96 diamonds * 4 B
         scene_bytes = (4096 + 512 + 64) if obst else (75 * 32 + 96 * 4) if collect else 512
         bytes_per_frame = W * H * 4 + 128 + scene_bytes + 320 + 128 * A
-        raster_ms = prof["raster"][0]
-        achieved = bytes_per_frame * frames / (raster_ms * 1e-3) / 1e9 if raster_ms > 0 else 0.0
-        # physics kernel: header + boxes + objects + agent state read+write + action/reward/done
+        # physics kernel, per env: header R+W + scene + movable boxes R+W + per agent (state R+W, action, reward, objective) + done
         step_bytes_per_env = 2 * 128 + scene_bytes + 2 * 320 + A * (2 * 128 + 4 + 4 + 4) + 1
-        step_ms = prof["step"][0]
-        traffic = None
-        try:   # HBM bytes per raster launch from the committed PMC passes (profiles/), only for the profiled config
-            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pt["config"] == {"envs_per_gpu": n_env, "agents_per_env": A, "obs": [W, H]} and not obst and not collect:
-                traffic = pt["kernels"]["mv::raster_kernel"]["traffic_bytes_per_launch"]
-        except Exception:  # noqa: BLE001
-            pass
         line = {
-            "metric": METRIC if args.scenario == "TowerBuilding" and (W, H) == (128, 128) else METRIC.replace("TowerBuilding 128x128", f"{args.scenario} {W}x{H}"), "value": total_obs / elapsed, "unit": "agent observations/sec", "n_gpus": world,
+            "metric": METRIC if args.scenario == "TowerBuilding" and (W, H) == (128, 128) else METRIC.replace("TowerBuilding 128x128", f"{args.scenario} {W}x{H}"),
+            "value": total_obs / elapsed, "unit": "agent observations/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.scenario} num_envs={n_env} per GPU x {world} GPU(s), num_agents_per_env={A}, obs {W}x{H} RGBA8, "
                                    "uniform random multi-discrete actions (device, counter-based), natural auto-resets, master seed 42",
-                       "envs_per_gpu": n_env, "agents_per_env": A, "obs": [W, H], "gather_obs": bool(gathered is not None),
+                       "envs_per_gpu": n_env, "agents_per_env": A, "obs": [W, H], "gather_obs": bool(do_gather), "pixels": args.pixels,
                        "parallelism": f"env-shard x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "mv::raster_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": raster_ms, "launches_timed": prof["raster"][1],
-                         "algorithmic_bytes_per_launch": bytes_per_frame * frames,
-                         "note": "traffic = HBM bytes/launch from rocprofv3 PMC (profiles/pmc_traffic.json); the kernel is VALU/issue-bound ray casting, "
-                                 "so the HBM fraction is low by construction (DESIGN.md 3.3)"},
-            "kernels": {"step": {"avg_launch_ms": step_ms, "algorithmic_GBps": step_bytes_per_env * n_env / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0,
-                                 "algorithmic_bytes_per_launch": step_bytes_per_env * n_env},
-                        "reset": {"avg_launch_ms": prof["reset"][0],
-                                  "note": "auto-reset is the tail of the step kernel; this interval only holds event overhead (+ the status read-back every 16th step)"},
-                        "frame_setup": {"avg_launch_ms": prof["setup"][0]}},
-            "checksum": checksum,
         }
-        if world == 1 and not args.no_cpu_baseline and not mixed:   # (the CPU baseline runs one scenario per gym)
-            line["cpu_baseline"] = cpu_baseline(args.scenario, W, H, A)
+        if dry:
+            line["dry_run"] = True
+        if do_gather:
+            slab_bytes = frames * H * W * 4
+            line["value_no_gather"] = total_obs / elapsed_no_gather
+            line["ms_per_step_no_gather"] = elapsed_no_gather / args.steps * 1e3
+            line["gather"] = {"collective": "all_gather_into_tensor (RCCL), double-buffered on a communication stream",
+                              "bytes_received_per_gpu_per_step": (world - 1) * slab_bytes,
+                              "achieved_GBps_per_gpu": (world - 1) * slab_bytes / (elapsed / args.steps) / 1e9,
+                              "xgmi_peak_GBps_per_gpu": XGMI_PEAK_GBS}
+        if prof is not None:
+            traffic = traffic_step = None
+            try:   # HBM bytes per launch from the committed PMC passes (profiles/), only for the profiled config
+                pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+                if pt["config"] == {"envs_per_gpu": n_env, "agents_per_env": A, "obs": [W, H]} and args.scenario == "TowerBuilding":
+                    traffic = pt["kernels"].get("raster", {}).get("traffic_bytes_per_launch")
+                    traffic_step = pt["kernels"].get("step", {}).get("traffic_bytes_per_launch")
+            except Exception:  # noqa: BLE001
+                pass
+            raster_ms, step_ms = prof["raster"][0], prof["step"][0]
+            achieved = bytes_per_frame * frames / (raster_ms * 1e-3) / 1e9 if raster_ms > 0 else 0.0
+            achieved_step = step_bytes_per_env * n_env / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
+            line["roofline"] = {"bound": "hbm", "kernel": "mv::raster_fast_kernel" if args.pixels == "fast" else "mv::raster_kernel",
+                                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                                "avg_launch_ms": raster_ms, "launches_timed": prof["raster"][1], "algorithmic_bytes_per_launch": bytes_per_frame * frames,
+                                "note": "dominant kernel; per-launch time from HIP events in a separate untimed loop; traffic = HBM bytes/launch from "
+                                        "rocprofv3 PMC (profiles/pmc_traffic.json); ray casting is VALU/issue-bound, the HBM fraction is low by construction"}
+            line["roofline_physics"] = {"bound": "hbm", "kernel": "mv::step_kernel (voxel physics + scenario logic + auto-reset)", "achieved": achieved_step,
+                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_step / HBM_PEAK_GBS, "traffic": traffic_step,
+                                        "avg_launch_ms": step_ms, "launches_timed": prof["step"][1], "algorithmic_bytes_per_launch": step_bytes_per_env * n_env,
+                                        "note": "north_star's >=40 % HBM target names this kernel; its working set is 1.7 KB per env (the 16 KB voxel chunk "
+                                                "is not streamed), so it is latency-bound: one wave per env, launch length = slowest wave (DESIGN.md 3.1)"}
+            line["kernels"] = {"frame_setup_and_sort": {"avg_launch_ms": prof["setup"][0]},
+                               "status_readback_gap": {"avg_launch_ms": prof["reset"][0]}}
+        line["checksum"] = checksum
+        if world == 1 and not args.no_cpu_baseline and not mixed and not dry:   # (the CPU baseline runs one scenario per gym)
+            line["cpu_baseline"] = cpu_baseline(args.scenario, W, H, n_env, A)
         print(json.dumps(line), flush=True)
 
     gym.close()

@@ -89,6 +89,15 @@ void *mv_true_objectives_device_ptr(mv_gym *g);     /* float [N*A] */
 int mv_set_obs_buffer(mv_gym *g, void *device_ptr);
 int mv_set_stream(mv_gym *g, void *hip_stream);
 
+/* Pixel arithmetic of the observation pass (MagnumEnvRenderer::draw, magnum_env_renderer.cpp:288-330, is a GPU
+ * rasteriser: its pixels are defined up to fp32 rounding).  MV_PIXELS_FAST (default): hardware reciprocal / rsqrt,
+ * within the tolerance DESIGN.md "pixel tolerance" states (<= 1 of 255 per channel except for a <= 1e-4 fraction of
+ * silhouette / depth-tie pixels).  MV_PIXELS_EXACT: every fp32 operation correctly rounded, RGBA8 bit-identical to
+ * the CPU oracle (parity tests).  Env var MV_PIXEL_MODE=exact|fast sets the default of new gyms. */
+enum { MV_PIXELS_EXACT = 0, MV_PIXELS_FAST = 1 };
+int mv_set_pixel_mode(mv_gym *g, int32_t mode);
+int mv_get_pixel_mode(const mv_gym *g);
+
 /* setRenderResolution/drawHires/getHiresObservation (:145-178,203-207); drawOverview is a no-op
  * exactly like a reference build without WITH_GUI (:180-201) */
 int mv_set_render_resolution(mv_gym *g, int32_t w, int32_t h);

@@ -76,6 +76,7 @@ struct mv_gym {
     uint8_t *arena = nullptr;
     uint32_t *obs = nullptr, *ownedObs = nullptr, *hiresObs = nullptr;
     int hiresW = 0, hiresH = 0;
+    int fastPixels = 1;                          // mv_set_pixel_mode: 1 = raster_fast_kernel (default), 0 = bit-exact raster_kernel
     // host mirrors
     int32_t *hActions[2] = {nullptr, nullptr};   // pinned staging, double buffered
     hipEvent_t actionsCopied[2] = {nullptr, nullptr};
@@ -281,7 +282,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
                  szHeight = collect ? up(N * (size_t)HM_BYTES) : 0, szItems = rearrange ? up(N * MAX_ITEMS * sizeof(ArrangementItem)) : 0, szBlobs = up(N * g->blobBytes), szCnt = up((N + 2) * sizeof(int32_t));
     gv.vis_stride = collect ? 1024 : 256;
     const size_t szVisP = up(NA * (size_t)gv.vis_stride * 32), szVisR = up(NA * (size_t)gv.vis_stride * 8), szVisC = up(NA * sizeof(int32_t)),
-                 szLpt = 2 * up(NA * sizeof(int32_t));
+                 szLpt = 2 * up(NA * sizeof(int32_t)) + up(8 * 32 * sizeof(int32_t));
     const size_t total = szHdr + szBoxes + szObj + szAg + szAct + szRew + szDone + szObjv + szMd + (hostEpisodes ? 0 : szChunk) + szObs + szTerrain +
                          szRewObj + szHeight + szItems + szBlobs + szCnt + szVisP + szVisR + szVisC + szLpt;
     {
@@ -317,7 +318,9 @@ int mv_create(const mv_config *cfg, mv_gym **out)
         gv.vis_count = (int32_t *)p; p += szVisC;
         gv.lpt_bucket = (int32_t *)p; p += up(NA * sizeof(int32_t));
         gv.lpt_order = (int32_t *)p; p += up(NA * sizeof(int32_t));
+        gv.raster_queue = (int32_t *)p; p += up(8 * 32 * sizeof(int32_t));
     }
+    if (const char *e = getenv("MV_PIXEL_MODE")) g->fastPixels = lower(e) == "exact" ? 0 : 1;
     g->obs = g->ownedObs;
     for (int b = 0; b < 2; ++b) {
         if (hipHostMalloc((void **)&g->hActions[b], NA * sizeof(int32_t), hipHostMallocDefault) != hipSuccess ||
@@ -450,6 +453,16 @@ int mv_set_obs_buffer(mv_gym *g, void *p)
     return 0;
 }
 
+int mv_set_pixel_mode(mv_gym *g, int32_t mode)
+{
+    if (check(g)) return -1;
+    if (mode != MV_PIXELS_EXACT && mode != MV_PIXELS_FAST) return fail("mv_set_pixel_mode: mode must be MV_PIXELS_EXACT (0) or MV_PIXELS_FAST (1)");
+    g->fastPixels = mode;
+    return 0;
+}
+
+int mv_get_pixel_mode(const mv_gym *g) { return g ? g->fastPixels : -1; }
+
 int mv_seed(mv_gym *g, int32_t seed)
 {   // MegaverseGym::seed, megaverse.cpp:60-69: master rng -> one randRange(0, 1<<30) per env
     if (check(g)) return -1;
@@ -491,7 +504,7 @@ int mv_render(mv_gym *g)
 {
     if (check(g)) return -1;
     HIP_TRY(hipSetDevice(g->device));
-    if (launch_raster(g->gv, g->obs, g->w, g->h, g->stream)) return fail("mv_render: observation size above 1024x1024");
+    if (launch_raster(g->gv, g->obs, g->w, g->h, g->stream, nullptr, g->fastPixels)) return fail("mv_render: observation size above 1024x1024");
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -653,7 +666,7 @@ static int step_impl(mv_gym *g, bool render)
         g->stepsSinceStatus = 0;
     }   // (TowerBuilding: the step kernel regenerates finished envs itself)
     if (prof) HIP_TRY(hipEventRecord(ev[2], g->stream));
-    if (render && launch_raster(g->gv, g->obs, g->w, g->h, g->stream, prof ? ev[3] : nullptr)) return fail("mv_step: observation size above 1024x1024");
+    if (render && launch_raster(g->gv, g->obs, g->w, g->h, g->stream, prof ? ev[3] : nullptr, g->fastPixels)) return fail("mv_step: observation size above 1024x1024");
     if (prof) { HIP_TRY(hipEventRecord(ev[4], g->stream)); ++g->profCount; }
     HIP_TRY(hipGetLastError());
     g->mirrorsFresh = false;
@@ -775,7 +788,7 @@ int mv_draw_hires(mv_gym *g)
         HIP_TRY(hipMalloc((void **)&g->hiresObs, (size_t)g->N * g->A * g->renderW * g->renderH * 4));
         g->hiresW = g->renderW; g->hiresH = g->renderH;
     }
-    if (launch_raster(g->gv, g->hiresObs, g->hiresW, g->hiresH, g->stream)) return fail("mv_draw_hires: render size above 1024x1024");
+    if (launch_raster(g->gv, g->hiresObs, g->hiresW, g->hiresH, g->stream, nullptr, g->fastPixels)) return fail("mv_draw_hires: render size above 1024x1024");
     HIP_TRY(hipGetLastError());
     return 0;
 }

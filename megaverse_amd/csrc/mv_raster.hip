@@ -31,6 +31,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "mv_math.h"
 #include "mv_raster.h"
 #include "mv_rearrange.h"
@@ -122,6 +124,13 @@ __device__ __forceinline__ int entry_axis(V3 d, V3 inv, const float *lo, const f
     return axis;
 }
 
+// FAST variants (raster_fast_kernel): v_rcp_f32 / v_sqrt_f32 / v_rsq_f32 (1 ulp) instead of the correctly rounded sequences
+template <bool FAST> __device__ __forceinline__ float f_inv(float x) { return FAST ? __builtin_amdgcn_rcpf(x) : 1.0f / x; }
+template <bool FAST> __device__ __forceinline__ float f_div(float a, float b) { return FAST ? a * __builtin_amdgcn_rcpf(b) : a / b; }
+template <bool FAST> __device__ __forceinline__ float f_sqrt(float x) { return FAST ? __builtin_amdgcn_sqrtf(x) : sqrtf(x); }
+template <bool FAST> __device__ __forceinline__ float f_rsqrt(float x) { return FAST ? __builtin_amdgcn_rsqf(x) : 1.0f / sqrtf(x); }
+
+template <bool FAST = false>
 __device__ __forceinline__ bool ray_capsule(V3 o, V3 d, V3 c, float r, float hl, float &t_out, V3 &n_out)
 {
     bool hit = false;
@@ -133,11 +142,11 @@ __device__ __forceinline__ bool ray_capsule(V3 o, V3 d, V3 c, float r, float hl,
         const float C = (ox * ox + oz * oz) - r * r;
         const float disc = B * B - A * C;
         if (disc >= 0.0f) {
-            const float t = (-B - sqrtf(disc)) / A;
+            const float t = f_div<FAST>(-B - f_sqrt<FAST>(disc), A);
             const float y = o.y + t * d.y;
             if (t >= NEAR_Z && t <= FAR_Z && y >= c.y - hl && y <= c.y + hl) {
                 hit = true; best = t;
-                const float inv = 1.0f / r;
+                const float inv = f_inv<FAST>(r);
                 bn = v3((ox + t * d.x) * inv, 0.0f, (oz + t * d.z) * inv);
             }
         }
@@ -151,12 +160,12 @@ __device__ __forceinline__ bool ray_capsule(V3 o, V3 d, V3 c, float r, float hl,
         const float C3 = ((ox * ox + oy * oy) + oz * oz) - r * r;
         const float disc = B3 * B3 - A3 * C3;
         if (disc >= 0.0f) {
-            const float t = (-B3 - sqrtf(disc)) / A3;
+            const float t = f_div<FAST>(-B3 - f_sqrt<FAST>(disc), A3);
             const float y = o.y + t * d.y;
             const bool capSide = s == 0 ? (y <= cy) : (y >= cy);
             if (t >= NEAR_Z && t <= FAR_Z && capSide && t < best) {
                 hit = true; best = t;
-                const float inv = 1.0f / r;
+                const float inv = f_inv<FAST>(r);
                 bn = v3((ox + t * d.x) * inv, (oy + t * d.y) * inv, (oz + t * d.z) * inv);
             }
         }
@@ -166,6 +175,7 @@ __device__ __forceinline__ bool ray_capsule(V3 o, V3 d, V3 c, float r, float hl,
 }
 
 // Unit capped cylinder (Primitives::cylinderSolid(.., halfLength 0.5, CapEnds), rendering/src/render_utils.cpp:30): radius 1, |y| <= hl
+template <bool FAST = false>
 __device__ __forceinline__ bool ray_cylinder_unit(V3 o, V3 d, float hl, float &t_out, V3 &n_out)
 {
     bool hit = false;
@@ -176,7 +186,7 @@ __device__ __forceinline__ bool ray_cylinder_unit(V3 o, V3 d, float hl, float &t
         const float C = (o.x * o.x + o.z * o.z) - 1.0f;
         const float disc = B * B - A * C;
         if (disc >= 0.0f) {
-            const float t = (-B - sqrtf(disc)) / A;
+            const float t = f_div<FAST>(-B - f_sqrt<FAST>(disc), A);
             const float y = o.y + t * d.y;
             if (t >= NEAR_Z && t <= FAR_Z && y >= -hl && y <= hl) { hit = true; best = t; bn = v3(o.x + t * d.x, 0.0f, o.z + t * d.z); }
         }
@@ -186,7 +196,7 @@ __device__ __forceinline__ bool ray_cylinder_unit(V3 o, V3 d, float hl, float &t
         const float cy = s == 0 ? -hl : hl;
         const bool entering = s == 0 ? (d.y > 0.0f && o.y < cy) : (d.y < 0.0f && o.y > cy);
         if (entering) {
-            const float t = (cy - o.y) / d.y;
+            const float t = f_div<FAST>(cy - o.y, d.y);
             const float x = o.x + t * d.x, z = o.z + t * d.z;
             if (t >= NEAR_Z && t <= FAR_Z && x * x + z * z <= 1.0f && t < best) { hit = true; best = t; bn = v3(0.0f, s == 0 ? -1.0f : 1.0f, 0.0f); }
         }
@@ -197,26 +207,28 @@ __device__ __forceinline__ bool ray_cylinder_unit(V3 o, V3 d, float hl, float &t
 
 // Scaled shapes: the ray goes into the shape's unit space (diagonal scale: t is unchanged), the unit-space normal comes back
 // through the inverse-transpose scale.  `rel` = shape centre minus the ray origin, both in the primitive's frame.
+template <bool FAST = false>
 __device__ __forceinline__ bool ray_scaled_shape(int kind, V3 d, V3 rel, V3 scale, float &t_out, V3 &n_out)
 {
-    const V3 oo = v3((0.0f - rel.x) / scale.x, (0.0f - rel.y) / scale.y, (0.0f - rel.z) / scale.z);
-    const V3 dd = v3(d.x / scale.x, d.y / scale.y, d.z / scale.z);
+    const V3 oo = v3(f_div<FAST>(0.0f - rel.x, scale.x), f_div<FAST>(0.0f - rel.y, scale.y), f_div<FAST>(0.0f - rel.z, scale.z));
+    const V3 dd = v3(f_div<FAST>(d.x, scale.x), f_div<FAST>(d.y, scale.y), f_div<FAST>(d.z, scale.z));
     V3 nl = v3(0, 0, 0);
     bool hit;
-    if (kind == PRIM_CYLINDER_S) hit = ray_cylinder_unit(oo, dd, 0.5f, t_out, nl);
-    else hit = ray_capsule(oo, dd, v3(0, 0, 0), 1.0f, kind == PRIM_CAPSULE_S ? 1.0f : 0.0f, t_out, nl);
+    if (kind == PRIM_CYLINDER_S) hit = ray_cylinder_unit<FAST>(oo, dd, 0.5f, t_out, nl);
+    else hit = ray_capsule<FAST>(oo, dd, v3(0, 0, 0), 1.0f, kind == PRIM_CAPSULE_S ? 1.0f : 0.0f, t_out, nl);
     if (!hit) return false;
-    V3 n = v3(nl.x / scale.x, nl.y / scale.y, nl.z / scale.z);
-    n = n * (1.0f / sqrtf(len2(n)));
+    V3 n = v3(f_div<FAST>(nl.x, scale.x), f_div<FAST>(nl.y, scale.y), f_div<FAST>(nl.z, scale.z));
+    n = n * f_rsqrt<FAST>(len2(n));
     n_out = n;
     return true;
 }
 
 // open cone (no base cap), apex a, axis +-y; only its outside is visible (back-face culling).  Diamonds of the
 // Obstacles scenarios: two of these base to base (layout_utils.cpp:114-126)
+template <bool FAST = false>
 __device__ __forceinline__ bool ray_cone(V3 o, V3 d, V3 a, float r, float h, float dirSign, float &t_out, V3 &n_out)
 {
-    const float k = (r / h) * (r / h);
+    const float k = f_div<FAST>(r, h) * f_div<FAST>(r, h);
     const float ox = o.x - a.x, oz = o.z - a.z;
     const float s0 = dirSign * (a.y - o.y);
     const float ds = -dirSign * d.y;
@@ -226,12 +238,13 @@ __device__ __forceinline__ bool ray_cone(V3 o, V3 d, V3 a, float r, float h, flo
     if (A == 0.0f) return false;
     const float disc = B * B - A * C;
     if (!(disc >= 0.0f)) return false;
-    const float sq = sqrtf(disc);
+    const float sq = f_sqrt<FAST>(disc);
+    const float invA = FAST ? __builtin_amdgcn_rcpf(A) : 0.0f;
     bool hit = false;
     float best = INFINITY; V3 bn = v3(0, 0, 0);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const float t = (i == 0 ? (-B - sq) : (-B + sq)) / A;
+        const float t = FAST ? (i == 0 ? (-B - sq) : (-B + sq)) * invA : (i == 0 ? (-B - sq) : (-B + sq)) / A;
         const float s = s0 + t * ds;
         if (!(t >= NEAR_Z && t <= FAR_Z && s >= 0.0f && s <= h && t < best)) continue;
         const float px = ox + t * d.x, pz = oz + t * d.z;
@@ -239,7 +252,7 @@ __device__ __forceinline__ bool ray_cone(V3 o, V3 d, V3 a, float r, float h, flo
         if (!(dot(n, d) < 0.0f)) continue;
         const float l2 = len2(n);
         if (!(l2 > 0.0f)) continue;
-        n = n * (1.0f / sqrtf(l2));
+        n = n * f_rsqrt<FAST>(l2);
         hit = true; best = t; bn = n;
     }
     if (hit) { t_out = best; n_out = bn; }
@@ -569,6 +582,7 @@ __global__ __launch_bounds__(1024) void frame_order_kernel(GymView gv, int frame
     __shared__ int s_hist[LPT_BUCKETS], s_start[LPT_BUCKETS];
     const int tid = threadIdx.x;
     if (tid < LPT_BUCKETS) s_hist[tid] = 0;
+    if (tid < 8) gv.raster_queue[tid * 32] = 0;   // the persistent raster's queue heads (one 128-byte line per XCD)
     __syncthreads();
     for (int f = tid; f < frames; f += 1024) atomicAdd(&s_hist[gv.lpt_bucket[f]], 1);
     __syncthreads();
@@ -823,22 +837,364 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 && !SHAPES ? MV_RASTER_WAVES : M
     }
 }
 
+// =====================================================================================================================
+// FAST observation pass (the default; DESIGN.md "pixel tolerance").  Same geometry, same rays (the per-pixel direction
+// is bit-identical to the exact kernel's), same drawables and depth order -- but
+//   * reciprocals / square roots are single v_rcp_f32 / v_rsq_f32 / v_sqrt_f32 (1 ulp) instead of the correctly rounded
+//     sequences; a zero direction component needs no special case (lo * inf is +-inf, 0 * inf = NaN loses every min/max);
+//   * (depth, list position) is ONE 32-bit key -- the depth's float bits with the low POS_BITS replaced by the position --
+//     so the nearest-hit update is a single v_min_u32 (depths closer than 2^-15 relative resolve to the earlier drawable,
+//     like exact ties do);
+//   * Phong for boxes works from per-face constants: for a planar face N.(L - P) = N.L - (plane offset), and the plane
+//     offset is t * d_axis, so the normal never materialises: ndl = t |d_k| -+ Lrel_k ; |L - P|^2 is a quadratic in t with
+//     per-column / per-row coefficients (L . dc = 4 dcy - 2, dc . dc = dcx^2 + dcy^2 + 1); one v_rsq_f32 per pixel;
+//   * the highlight is evaluated only where cos > 0.97 (0.97^300 = 1e-4: 0.03 of one 8-bit step) with v_log/v_exp;
+//   * colour = byte * (AMB + DIFL * intensity) + 255 * spec, converted and packed with v_cvt_pk_u8_f32.
+// Scheduling: a persistent grid (as many workgroups as fit on the chip) pulls (frame, tile group) items, most expensive
+// frame first, from one queue head per XCD (workgroup b runs on XCD b % 8; a drained queue steals from the next one).
+// Pixels differ from the exact kernel / the oracle by at most one 8-bit step in well under 1e-3 of the pixels, and by more
+// only where a silhouette or a depth near-tie falls within rounding of a pixel centre (tests/test_fast_pixels_gpu.py).
+// =====================================================================================================================
+namespace {
+
+constexpr float SPEC_COS2 = 0.97f * 0.97f;
+constexpr int QUEUE_STRIDE = 32;   // ints between queue heads: one 128-byte line each
+
+struct FastArgs {   // what raster_fast_kernel needs of the GymView (fewer live SGPRs than the whole view)
+    const AgentState *agents;
+    const Prim *vis_prims;
+    const short4 *vis_rects;
+    const int *vis_count, *order;
+    int *queue;
+    int num_agents, vis_stride, frames;
+};
+
+struct FastRay {
+    V3 dw, inv;        // world direction and its reciprocals
+    float dcx, dcy;    // camera-space direction (z = -1)
+    float a2, ldc;     // dc . dc and L . dc
+};
+
+// a wave-uniform 64-bit value that came through LDS, back into SGPRs (so that loops over its bits are scalar loops)
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)
+{
+    return ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)v);
+}
+
+// an LDS address the compiler will not hoist loads from (keeps rarely used per-frame constants out of the hot loop's registers)
+__device__ __forceinline__ const float *local_lds(const float *p)
+{
+    asm volatile("" : "+v"(p));
+    return p;
+}
+
+// entry depth of a box given relative to the ray origin; +inf/NaN semantics make zero direction components harmless
+__device__ __forceinline__ bool fast_box(V3 inv, const float4 lo, const float4 hi, float &t_out)
+{
+    const float t1x = lo.x * inv.x, t2x = hi.x * inv.x, t1y = lo.y * inv.y, t2y = hi.y * inv.y, t1z = lo.z * inv.z, t2z = hi.z * inv.z;
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)), __builtin_fminf(t1z, t2z));
+    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)), __builtin_fmaxf(t1z, t2z));
+    t_out = tn;
+    return tn <= tf && tn >= NEAR_Z && tn <= FAR_Z;
+}
+
+}  // namespace
+
+template <int MAXVIS, bool SHAPES, int WAVES>   // WAVES: waves per SIMD the variant is compiled for (register budget 512 / WAVES)
+__global__ __launch_bounds__(256, WAVES) void raster_fast_kernel(FastArgs fa, uint32_t *obs, int W, int H, int split)
+{
+    constexpr int ROUNDS = MAXVIS / 64;
+    constexpr unsigned POS_MASK = MAXVIS - 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    __shared__ float4 s_vis[2 * MAXVIS];      // Prim records as (lo, meta) (hi, colour)
+    __shared__ short4 s_rect[MAXVIS];
+    __shared__ CamL s_cam[MAX_AGENTS];
+    __shared__ float s_lrel[1 + MAX_AGENTS][4];   // light position relative to the viewer's eye in the axes of frame 0 (world) / 1+k (camera k)
+    __shared__ unsigned long long s_wb[ROUNDS];   // bit per list position: an axis-aligned box in the world frame
+    __shared__ int s_item[2];
+
+    float4 *s_col = reinterpret_cast<float4 *>(s_dyn);   // per column i: (dc.x, c00*dc.x, c10*dc.x, c20*dc.x)
+    float4 *s_row = s_col + W;                            // per row j:    (dc.y, c01*dc.y, c11*dc.y, c21*dc.y)
+    float2 *s_rowq = reinterpret_cast<float2 *>(s_row + H);   // (dc.y^2 + 1, L . dc = 4 dc.y - 2)
+    float *s_colq = reinterpret_cast<float *>(s_rowq + H);    // dc.x^2   (last: keeps every table naturally aligned for odd W)
+
+    const int A = fa.num_agents, frames = fa.frames;
+    const int xcd = blockIdx.x & 7;
+    const int tilesX = (W + TILE_W - 1) / TILE_W, tilesY = (H + TILE_H - 1) / TILE_H;
+    const int numTiles = tilesX * tilesY;
+
+    // ---- work queue: XCD q owns the sorted positions p with p % 8 == q, `split` items each
+    int myQueue = xcd, tried = 0;
+    auto pull = [&]() -> int {   // thread 0 only; returns sorted-position * split + part, or -1
+        while (tried < 8) {
+            const int n = ((frames - myQueue + 7) >> 3) * split;   // items of this queue
+            const int j = atomicAdd(&fa.queue[myQueue * QUEUE_STRIDE], 1);
+            if (j < n) return ((j / split) * 8 + myQueue) * split + (j % split);
+            myQueue = (myQueue + 1) & 7; ++tried;
+        }
+        return -1;
+    };
+    if (threadIdx.x == 0) s_item[0] = pull();
+    int phase = 0;
+
+    for (;;) {
+        // (laundering the thread id keeps hipcc from hoisting every tid-derived address out of this loop -- and then spilling them)
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        __syncthreads();   // the item id is visible; every wave is done with the previous item's LDS
+        const int item = __builtin_amdgcn_readfirstlane(s_item[phase]);   // wave-uniform by construction: say so (scalar loop control)
+        if (item < 0) break;
+        if (tid == 0) s_item[phase ^ 1] = pull();   // next item: the atomic's latency hides behind this item's work
+        phase ^= 1;
+        const int frame = fa.order[item / split], part = item % split;
+        const int env = frame / A, viewer = frame - env * A;
+        const AgentState *agents = fa.agents + (size_t)env * A;
+
+        // ---- cameras (same arithmetic as the exact kernel: rays are bit-identical)
+        if (tid < A) {
+            const AgentState a = agents[tid];
+            CamL cam;
+            cam.eye[0] = a.pos[0]; cam.eye[1] = (a.pos[1] + 0.05f) + 0.41f; cam.eye[2] = a.pos[2];
+            float sp, cp;
+            sincos_poly(a.pitch, sp, cp);
+            cam.c[0] = a.m00; cam.c[1] = a.m02 * sp; cam.c[2] = a.m02 * cp;
+            cam.c[3] = 0.0f;  cam.c[4] = cp;         cam.c[5] = -sp;
+            cam.c[6] = a.m20; cam.c[7] = a.m22 * sp; cam.c[8] = a.m22 * cp;
+            cam.origin[0] = cam.origin[1] = cam.origin[2] = 0.0f;
+            s_cam[tid] = cam;
+        }
+        const int nVis = __builtin_amdgcn_readfirstlane(min(fa.vis_count[frame], (int)MAXVIS));
+        {   // the frame's visible list
+            const float4 *src = reinterpret_cast<const float4 *>(fa.vis_prims + (size_t)frame * fa.vis_stride);
+            for (int i = tid; i < nVis * 2; i += 256) s_vis[i] = src[i];
+            const short4 *rs = fa.vis_rects + (size_t)frame * fa.vis_stride;
+            for (int i = tid; i < nVis; i += 256) s_rect[i] = rs[i];
+        }
+        __syncthreads();
+        if (tid < A) {
+            const V3 ev = v3(s_cam[viewer].eye[0], s_cam[viewer].eye[1], s_cam[viewer].eye[2]);
+            const V3 ek = v3(s_cam[tid].eye[0], s_cam[tid].eye[1], s_cam[tid].eye[2]);
+            const V3 o = mat_tmul(s_cam[tid].c, ev - ek);
+            s_cam[tid].origin[0] = o.x; s_cam[tid].origin[1] = o.y; s_cam[tid].origin[2] = o.z;
+        }
+        if (tid <= A) {   // light (0,4,2) camera-relative (magnum_env_renderer.cpp:201) in the axes of every frame a box can live in
+            const V3 lw = mat_mul(s_cam[viewer].c, v3(0.0f, 4.0f, 2.0f));
+            const V3 l = tid == 0 ? lw : tid == 1 + viewer ? v3(0.0f, 4.0f, 2.0f) : mat_tmul(s_cam[tid - 1].c, lw);
+            s_lrel[tid][0] = l.x; s_lrel[tid][1] = l.y; s_lrel[tid][2] = l.z; s_lrel[tid][3] = 0.0f;
+        }
+        {
+            const float *c = s_cam[viewer].c;
+            for (int i = tid; i < W; i += 256) {
+                const float dcx = (((float(i) + 0.5f) / float(W)) * 2.0f - 1.0f) * TAN_HALF_FOV;
+                s_col[i] = make_float4(dcx, c[0] * dcx, c[3] * dcx, c[6] * dcx);
+                s_colq[i] = dcx * dcx;
+            }
+            for (int j = tid; j < H; j += 256) {
+                const float dcy = (((float(j) + 0.5f) / float(H)) * 2.0f - 1.0f) * TAN_HALF_FOV_Y;
+                s_row[j] = make_float4(dcy, c[1] * dcy, c[4] * dcy, c[7] * dcy);
+                s_rowq[j] = make_float2(dcy * dcy + 1.0f, 4.0f * dcy - 2.0f);
+            }
+#pragma unroll
+            for (int r = 0; r * 256 < MAXVIS; ++r) {   // world-box bit of every list position
+                const int pos = tid + 256 * r;
+                const bool wbx = pos < nVis && (__float_as_uint(s_vis[2 * pos].w) & 0xffu) == (unsigned)PRIM_BOX;
+                const unsigned long long mwb = __ballot(wbx);
+                if (lane == 0) s_wb[wave + 4 * r] = mwb;
+            }
+        }
+        __syncthreads();
+
+        const CamL &cam = s_cam[viewer];
+        const float nzm0 = __builtin_amdgcn_readfirstlane(-cam.c[2]), nzm1 = __builtin_amdgcn_readfirstlane(-cam.c[5]), nzm2 = __builtin_amdgcn_readfirstlane(-cam.c[8]);
+        uint32_t *out = obs + (size_t)frame * W * H;
+
+        int tx = part * 4 + wave, ty = 0;   // tile = ty * tilesX + tx, advanced without a division
+        for (int tile = part * 4 + wave; tile < numTiles; tile += 4 * split, tx += 4 * split) {
+            while (tx >= tilesX) { tx -= tilesX; ++ty; }
+            const int tx0 = tx * TILE_W, ty0 = ty * TILE_H;
+            const int tx1 = min(tx0 + TILE_W, W) - 1, ty1 = min(ty0 + TILE_H, H) - 1;
+
+            const int px = tx0 + (lane & (TILE_W - 1)), py = ty0 + (lane / TILE_W);
+            const bool inside = px < W && py < H;
+            const int pxc = min(px, W - 1), pyc = min(py, H - 1);
+            FastRay R;
+            R.dw = R.inv = v3(0, 0, 0); R.dcx = R.dcy = R.a2 = R.ldc = 0.0f;
+            bool rayReady = false;   // wave-uniform: the ray is set up when the first primitive survives the culling
+            unsigned best = ~0u;
+            V3 bn = v3(0, 0, 0);     // normal of the best hit when it is not a box (boxes recover theirs from the entry axis)
+#pragma unroll 1
+            for (int k = 0; k * 64 < nVis; ++k) {
+                // ---- tile culling: one primitive per lane, four integer compares against its screen rectangle
+                bool v = false;
+                if (lane + 64 * k < nVis) {
+                    const short4 r = s_rect[lane + 64 * k];
+                    v = r.x <= tx1 && r.y >= tx0 && r.z <= ty1 && r.w >= ty0;
+                }
+                const unsigned long long mv = __ballot(v);
+                if (mv == 0ull) continue;
+                if (!rayReady) {
+                    rayReady = true;
+                    const float4 cx = s_col[pxc], ry = s_row[pyc];
+                    const float2 rq = s_rowq[pyc];
+                    R.dcx = cx.x; R.dcy = ry.x;
+                    R.dw = v3((cx.y + ry.y) + nzm0, (cx.z + ry.z) + nzm1, (cx.w + ry.w) + nzm2);
+                    R.inv = v3(__builtin_amdgcn_rcpf(R.dw.x), __builtin_amdgcn_rcpf(R.dw.y), __builtin_amdgcn_rcpf(R.dw.z));
+                    R.a2 = s_colq[pxc] + rq.x; R.ldc = rq.y;
+                }
+                const unsigned long long wb = uniform_u64(s_wb[k]);
+                // ---- world-frame boxes: the common case, no branches on the primitive's kind
+                unsigned long long m = mv & wb;
+                while (m) {
+                    const int bit = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const int pos = bit + 64 * k;
+                    const float4 lo = s_vis[2 * pos], hi = s_vis[2 * pos + 1];
+                    float t;
+                    const bool hit = fast_box(R.inv, lo, hi, t);
+                    const unsigned key = hit ? ((__float_as_uint(t) & ~POS_MASK) | (unsigned)pos) : ~0u;
+                    best = min(best, key);
+                }
+                // ---- everything else: camera-attached boxes, capsules, cones, scaled shapes
+                m = mv & ~wb;
+                while (m) {
+                    const int bit = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const int pos = bit + 64 * k;
+                    const float4 lo = s_vis[2 * pos], hi = s_vis[2 * pos + 1];
+                    const unsigned meta = __builtin_amdgcn_readfirstlane(__float_as_uint(lo.w));
+                    const int qkind = meta & 15, qfr = (meta >> 4) & 15;
+                    float t = 0.0f; V3 n = v3(0, 0, 0);
+                    bool hit;
+                    if (qkind == PRIM_BOX) {
+                        const V3 df = qfr == 1 + viewer ? v3(R.dcx, R.dcy, -1.0f) : mat_tmul(s_cam[qfr - 1].c, R.dw);
+                        hit = fast_box(v3(__builtin_amdgcn_rcpf(df.x), __builtin_amdgcn_rcpf(df.y), __builtin_amdgcn_rcpf(df.z)), lo, hi, t);
+                    } else {
+                        const float *ce = local_lds(cam.eye);   // (read here, not kept in registers across the tile loop)
+                        const V3 eye = v3(ce[0], ce[1], ce[2]);
+                        if (qkind == PRIM_CAPSULE) hit = ray_capsule<true>(eye, R.dw, v3(lo.x, lo.y, lo.z), hi.x, hi.y, t, n);
+                        else if (qkind == PRIM_CONE) hit = ray_cone<true>(eye, R.dw, v3(lo.x, lo.y, lo.z), hi.x, hi.y, hi.z, t, n);
+                        else if (SHAPES) {
+                            const V3 df = qfr == 0 ? R.dw : qfr == 1 + viewer ? v3(R.dcx, R.dcy, -1.0f) : mat_tmul(s_cam[qfr - 1].c, R.dw);
+                            hit = ray_scaled_shape<true>(qkind, df, v3(lo.x, lo.y, lo.z), v3(hi.x, hi.y, hi.z), t, n);
+                        } else hit = false;
+                    }
+                    const unsigned key = hit ? ((__float_as_uint(t) & ~POS_MASK) | (unsigned)pos) : ~0u;
+                    if (key < best) { best = key; bn = n; }
+                }
+            }
+
+            // ---- Phong (Magnum Shaders::Phong, uniforms of magnum_env_renderer.cpp:200-203)
+            unsigned rgba = 0xff000000u;
+            if (best != ~0u) {
+                const V3 dc = v3(R.dcx, R.dcy, -1.0f);
+                const int pos = (int)(best & POS_MASK);
+                const float4 lo = s_vis[2 * pos], hi = s_vis[2 * pos + 1];
+                const unsigned meta = __float_as_uint(lo.w), color = __float_as_uint(hi.w);
+                const int qkind = meta & 15, qfr = (meta >> 4) & 15;
+                float t, ndl, nv;   // depth; N . (L - P) and N . (-P), both unnormalised in (L - P) / P
+                if (qkind == PRIM_BOX) {
+                    V3 d = R.dw, inv = R.inv;
+                    if (qfr != 0) {
+                        d = qfr == 1 + viewer ? dc : mat_tmul(s_cam[qfr - 1].c, R.dw);
+                        inv = v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+                    }
+                    const float tnx = __builtin_fminf(lo.x * inv.x, hi.x * inv.x), tny = __builtin_fminf(lo.y * inv.y, hi.y * inv.y),
+                                tnz = __builtin_fminf(lo.z * inv.z, hi.z * inv.z);
+                    t = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz);
+                    const int axis = tnx == t ? 0 : tny == t ? 1 : 2;   // first axis whose near-plane crossing is the entry depth
+                    const float dk = axis == 0 ? d.x : axis == 1 ? d.y : d.z;
+                    const float lk = s_lrel[qfr][axis];
+                    nv = t * __builtin_fabsf(dk);                       // plane offset along the outward normal
+                    ndl = nv - __builtin_copysignf(1.0f, dk) * lk;     // sgn (Lrel_k - t d_k), sgn = -sign(d_k)
+                } else {   // capsules, cones, scaled shapes: the normal was kept with the hit (depth: the key's, 2^-15 relative)
+                    t = __uint_as_float(best & ~POS_MASK);
+                    V3 N;
+                    const float *cc = local_lds(cam.c);
+                    if (!SHAPES || qkind < PRIM_SPHERE_S || qfr == 0) N = mat_tmul(cc, bn);
+                    else if (qfr == 1 + viewer) N = bn;
+                    else N = mat_tmul(cc, mat_mul(s_cam[qfr - 1].c, bn));
+                    const V3 P = dc * t;
+                    nv = -dot(N, P);
+                    ndl = dot(N, v3(0.0f - P.x, 4.0f - P.y, 2.0f - P.z));
+                }
+                // |L - P|^2 = |L|^2 - 2 t (L . dc) + t^2 (dc . dc)
+                const float ta = t * R.a2;
+                const float len2LP = __builtin_fmaf(t, ta - 2.0f * R.ldc, 20.0f);
+                const float rs = __builtin_amdgcn_rsqf(len2LP);
+                const float intensity = __builtin_fmaxf(0.0f, ndl * rs);
+                float spec255 = 0.5f;
+                if (intensity > 0.001f) {
+                    // V . R with V = -P unnormalised: 2 (N . Ld)(N . -P) + Ld . P
+                    const float vr = __builtin_fmaf(2.0f * intensity, nv, (t * (R.ldc - ta)) * rs);
+                    const float p2 = t * ta;   // |P|^2
+                    if (vr > 0.0f && vr * vr > SPEC_COS2 * p2) {
+                        const float cosv = __builtin_fminf(vr * __builtin_amdgcn_rsqf(p2), 1.0f);
+                        spec255 = __builtin_fmaf(255.0f, __builtin_amdgcn_exp2f(300.0f * __builtin_amdgcn_logf(cosv)), 0.5f);
+                    }
+                }
+                const float AMB = float(0x55) / 255.0f, DIFL = (float(0xbb) / 255.0f) * (float(0xaa) / 255.0f);
+                const float sc = __builtin_fmaf(DIFL, intensity, AMB);
+                const float r8 = __builtin_fmaf(float((color >> 16) & 255u), sc, spec255), g8 = __builtin_fmaf(float((color >> 8) & 255u), sc, spec255),
+                            b8 = __builtin_fmaf(float(color & 255u), sc, spec255);
+                rgba = (unsigned)(int)__builtin_fminf(r8, 255.0f) | ((unsigned)(int)__builtin_fminf(g8, 255.0f) << 8) |
+                       ((unsigned)(int)__builtin_fminf(b8, 255.0f) << 16) | 0xff000000u;
+            }
+            if (inside) out[(size_t)py * W + px] = rgba;
+        }
+    }
+}
 
 
 // One observation pass: frame setup -> frame sort -> raster, on `stream`.  (Running the sort on a side stream from the
 // previous pass's bins was tried: the cross-stream event packets cost more than the 6 us single-workgroup bubble.)
-int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream, hipEvent_t between)
+// persistent grid of raster_fast_kernel: as many workgroups as are resident at once (occupancy query, cached per variant)
+template <class K>
+static int resident_workgroups(K kernel, size_t dyn)
+{
+    int perCu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 2048;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kernel, 256, dyn) != hipSuccess || perCu < 1) perCu = 1;
+    return std::min(perCu, 8) * prop.multiProcessorCount;
+}
+
+int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream, hipEvent_t between, int fast)
 {
     if (W > MAX_W || H > MAX_H) return -1;
-    const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)(W + H) * sizeof(float);
     static const int envSplit = getenv("MV_RASTER_SPLIT") ? atoi(getenv("MV_RASTER_SPLIT")) : 0;
     const int tiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H * PPL - 1) / (TILE_H * PPL));
-    int split = envSplit > 0 ? envSplit : 4;
-    while (split > 1 && tiles < 4 * split * 2) split >>= 1;   // keep at least two tiles per wave
     const int frames = gv.num_envs * gv.num_agents;
     hipLaunchKernelGGL(frame_setup_kernel, dim3(frames), dim3(256), 0, stream, gv, W, H);
     hipLaunchKernelGGL(frame_order_kernel, dim3(1), dim3(1024), 0, stream, gv, frames, gv.lpt_order);
     if (between) (void)hipEventRecord(between, stream);
+    if (fast) {
+        const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)W * sizeof(float) + (size_t)H * sizeof(float2);
+        int split = envSplit > 0 ? envSplit : 8;
+        while (split > 1 && tiles < 4 * split * 2) split >>= 1;   // keep at least two tiles per wave
+        const int items = frames * split;
+        // variants: [0] <=256 visible primitives, [1] + scaled shapes (Rearrange), [2] <=1024 (Collect); the small ones are built for
+        // 8 and for 6 waves per SIMD (64 / 80 VGPRs), MV_FAST_WAVES picks (default 8)
+        static const int wavesSel = getenv("MV_FAST_WAVES") ? atoi(getenv("MV_FAST_WAVES")) : 8;
+        using KernelFn = void (*)(FastArgs, uint32_t *, int, int, int);
+        const int variant = gv.vis_stride > VIS_SMALL ? 2 : gv.scenario == SCN_REARRANGE ? 1 : 0;
+        KernelFn fn = variant == 2 ? raster_fast_kernel<VIS_LARGE, false, 3>
+                    : variant == 1 ? (wavesSel >= 8 ? raster_fast_kernel<VIS_SMALL, true, 8> : raster_fast_kernel<VIS_SMALL, true, 6>)
+                                   : (wavesSel >= 8 ? raster_fast_kernel<VIS_SMALL, false, 8> : raster_fast_kernel<VIS_SMALL, false, 6>);
+        static int cap[3] = {0, 0, 0};
+        static size_t capDyn[3] = {0, 0, 0};
+        if (cap[variant] == 0 || capDyn[variant] != dyn) { cap[variant] = resident_workgroups(fn, dyn); capDyn[variant] = dyn; }
+        const dim3 grid(std::max(1, std::min(cap[variant], items))), block(256);
+        FastArgs fa;
+        fa.agents = gv.agents; fa.vis_prims = reinterpret_cast<const Prim *>(gv.vis_prims); fa.vis_rects = reinterpret_cast<const short4 *>(gv.vis_rects);
+        fa.vis_count = gv.vis_count; fa.order = gv.lpt_order; fa.queue = gv.raster_queue;
+        fa.num_agents = gv.num_agents; fa.vis_stride = gv.vis_stride; fa.frames = frames;
+        hipLaunchKernelGGL(fn, grid, block, dyn, stream, fa, obs, W, H, split);
+        return 0;
+    }
+    const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)(W + H) * sizeof(float);
+    int split = envSplit > 0 ? envSplit : 4;
+    while (split > 1 && tiles < 4 * split * 2) split >>= 1;   // keep at least two tiles per wave
     const dim3 grid(frames * split), block(256);
     if (gv.vis_stride > VIS_SMALL) hipLaunchKernelGGL((raster_kernel<VIS_LARGE, false>), grid, block, dyn, stream, gv, obs, W, H, split, gv.lpt_order);
     else if (gv.scenario == SCN_REARRANGE) hipLaunchKernelGGL((raster_kernel<VIS_SMALL, true>), grid, block, dyn, stream, gv, obs, W, H, split, gv.lpt_order);

@@ -118,6 +118,7 @@ struct GymView {
     int32_t vis_stride;        // 256, or 1024 for Collect
     int32_t *lpt_bucket;       // [N*A] cost bin of every frame (raster scheduling)
     int32_t *lpt_order;        // [N*A] frames sorted by cost bin, most expensive first
+    int32_t *raster_queue;     // [8 * 32] work-queue heads of the persistent raster kernel, one 128-byte line per XCD
 };
 
 // One host-generated episode (Obstacles family): everything Env::reset produces, ready to be swapped in by

@@ -43,6 +43,7 @@ SYMBOLS = [
     ("mv_obs_device_ptr", _P, [_P]), ("mv_rewards_device_ptr", _P, [_P]), ("mv_dones_device_ptr", _P, [_P]),
     ("mv_true_objectives_device_ptr", _P, [_P]),
     ("mv_set_obs_buffer", C.c_int, [_P, _P]), ("mv_set_stream", C.c_int, [_P, _P]),
+    ("mv_set_pixel_mode", C.c_int, [_P, _I]), ("mv_get_pixel_mode", C.c_int, [_P]),
     ("mv_set_render_resolution", C.c_int, [_P, _I, _I]), ("mv_draw_hires", C.c_int, [_P]),
     ("mv_get_hires_observation", C.c_int, [_P, _I, _I, _P]), ("mv_draw_overview", C.c_int, [_P]),
     ("mv_num_reward_shaping_keys", C.c_int, [_P]), ("mv_reward_shaping_key", C.c_char_p, [_P, _I]),
@@ -252,6 +253,14 @@ class MegaverseGym:
 
     def set_obs_buffer(self, device_ptr):
         self._ck(self._lib.mv_set_obs_buffer(self._g, _P(int(device_ptr))))
+
+    def set_pixel_mode(self, mode):
+        """'fast' (default: hardware rcp/rsqrt, pixels within DESIGN.md's tolerance) or 'exact' (bit-identical to the oracle)"""
+        m = {"exact": 0, "fast": 1}.get(mode, mode)
+        self._ck(self._lib.mv_set_pixel_mode(self._g, int(m)))
+
+    def pixel_mode(self):
+        return "fast" if self._lib.mv_get_pixel_mode(self._g) == 1 else "exact"
 
     def set_stream(self, hip_stream):
         self._ck(self._lib.mv_set_stream(self._g, _P(int(hip_stream))))

@@ -36,14 +36,27 @@ class MultiTaskGym:
     # ---- plumbing: torch owns the slab and the streams
     def attach(self, torch_device):
         import torch
+        A = self.num_agents_per_env
+        return self.attach_tensor(torch.empty((self.num_envs * A, self.h, self.w, 4), dtype=torch.uint8, device=torch_device))
+
+    def attach_tensor(self, obs):
+        """render into the caller's [num_envs * A, h, w, 4] uint8 slab (one stream per scenario, created on first use)"""
+        import torch
         A, n = self.num_agents_per_env, self.per_task
-        self._obs = torch.empty((self.num_envs * A, self.h, self.w, 4), dtype=torch.uint8, device=torch_device)
-        self._streams = [torch.cuda.Stream(device=torch_device) for _ in self.gyms]
+        assert tuple(obs.shape) == (self.num_envs * A, self.h, self.w, 4) and obs.dtype == torch.uint8 and obs.is_contiguous()
+        if self._streams is None:
+            self._streams = [torch.cuda.Stream(device=obs.device) for _ in self.gyms]
+            for k, g in enumerate(self.gyms):
+                g.set_stream(self._streams[k].cuda_stream)
+        self._obs = obs
         frame_bytes = self.h * self.w * 4
         for k, g in enumerate(self.gyms):
-            g.set_stream(self._streams[k].cuda_stream)
-            g.set_obs_buffer(self._obs.data_ptr() + k * n * A * frame_bytes)
-        return self._obs
+            g.set_obs_buffer(obs.data_ptr() + k * n * A * frame_bytes)
+        return obs
+
+    def set_pixel_mode(self, mode):
+        for g in self.gyms:
+            g.set_pixel_mode(mode)
 
     def locate(self, env_idx):
         """global env index -> (sub-gym, local env index)"""

@@ -9,6 +9,11 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# Parity tests compare RGBA8 bit for bit with the oracle: new gyms default to the exact pixel arithmetic in this test
+# session (MV_PIXELS_EXACT); tests/test_fast_pixels_gpu.py switches its gyms to the default product mode explicitly.
+os.environ.setdefault("MV_PIXEL_MODE", "exact")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
