@@ -878,7 +878,13 @@ struct FastRay {
 // a wave-uniform 64-bit value that came through LDS, back into SGPRs (so that loops over its bits are scalar loops)
 __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)
 {
-    return ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;   // (the builtin returns int: no sign extension of the low half)
+}
+
+__device__ __forceinline__ float uniform_f32(float v)   // (the builtin takes an int: pass the BITS, not the value)
+{
+    return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v)));
 }
 
 // an LDS address the compiler will not hoist loads from (keeps rarely used per-frame constants out of the hot loop's registers)
@@ -1006,7 +1012,7 @@ __global__ __launch_bounds__(256, WAVES) void raster_fast_kernel(FastArgs fa, ui
         __syncthreads();
 
         const CamL &cam = s_cam[viewer];
-        const float nzm0 = __builtin_amdgcn_readfirstlane(-cam.c[2]), nzm1 = __builtin_amdgcn_readfirstlane(-cam.c[5]), nzm2 = __builtin_amdgcn_readfirstlane(-cam.c[8]);
+        const float nzm0 = uniform_f32(-cam.c[2]), nzm1 = uniform_f32(-cam.c[5]), nzm2 = uniform_f32(-cam.c[8]);
         uint32_t *out = obs + (size_t)frame * W * H;
 
         int tx = part * 4 + wave, ty = 0;   // tile = ty * tilesX + tx, advanced without a division

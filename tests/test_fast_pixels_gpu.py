@@ -16,7 +16,7 @@ from megaverse_amd.extension import MegaverseGym
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
 
 PIX_GT1 = 1e-4    # fraction of pixels allowed to differ by more than one 8-bit step in some channel
-PIX_ANY = 2e-3    # fraction of pixels allowed to differ at all
+PIX_ANY = 5e-4    # fraction of pixels allowed to differ at all (measured: 2e-5 .. 1.3e-4)
 
 
 def compare(ref, got, what):
