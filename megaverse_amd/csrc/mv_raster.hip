@@ -70,6 +70,14 @@ struct alignas(16) Prim {   // 32 B, one visible primitive of a frame (written b
     float hi[3]; uint32_t color;  //        capsule: (radius, halfLen, 0); cone: (base radius, height, +1 apex up / -1 apex down)
 };                                // meta = kind | frame << 4 | slot << 8 ; frame 0 = world axes, 1+k = camera frame of agent k
 
+// Per-frame header written by frame_setup_kernel for raster_fast_kernel (so that its prologue is a plain copy): floats
+//   [0] visible count (int bits)   [4 + 16 k ..] camera of agent k: eye(3) c(9) origin(3)   [FH_LREL + 4 f ..] light position relative
+//   to the viewer's eye in the axes of frame f (0 world, 1 + k camera k)   [FH_WB + 2 r ..] 64-bit mask of list positions 64 r .. 64 r + 63
+//   that hold an axis-aligned box in the world frame
+enum : int { FH_CAM = 4, FH_CAM_STRIDE = 16, FH_LREL = FH_CAM + FH_CAM_STRIDE * MAX_AGENTS, FH_WB = FH_LREL + 4 * (1 + MAX_AGENTS),
+             FH_FLOATS = FH_WB + 2 * 16 };
+static_assert(FH_FLOATS * 4 <= FRAME_HDR_BYTES, "frame header does not fit its slot");
+
 struct CamL {
     float eye[3];
     float c[9];       // row-major 3x3, columns = camera right/up/back in world
@@ -344,6 +352,7 @@ __global__ __launch_bounds__(256) void frame_setup_kernel(GymView gv, int W, int
     __shared__ CamL s_cam[MAX_AGENTS];
     __shared__ int s_cost;                // tiles x primitives the raster pass will have to look at (scheduling estimate)
     __shared__ int s_cnt[8];              // [parity*4 + wave]: visible primitives found by each wave this round
+    __shared__ unsigned s_wbits[32];      // world-frame-box bit of every list position (frame header, raster_fast_kernel)
 
     const int A = gv.num_agents;
     const int frame = blockIdx.x;
@@ -353,6 +362,7 @@ __global__ __launch_bounds__(256) void frame_setup_kernel(GymView gv, int W, int
     const AgentState *agents = gv.agents + (size_t)env * A;
     const int maxVis = gv.vis_stride;
     if (tid == 0) s_cost = 0;
+    if (tid < 32) s_wbits[tid] = 0u;
     int myCost = 0;
     Prim *vis = reinterpret_cast<Prim *>(gv.vis_prims) + (size_t)frame * maxVis;
     short4 *rects = reinterpret_cast<short4 *>(gv.vis_rects) + (size_t)frame * maxVis;
@@ -560,11 +570,32 @@ __global__ __launch_bounds__(256) void frame_setup_kernel(GymView gv, int W, int
             }
             vis[pos] = p;
             rects[pos] = make_short4((short)rect[0], (short)rect[1], (short)rect[2], (short)rect[3]);
+            if (kind == PRIM_BOX && fr == 0) atomicOr(&s_wbits[pos >> 5], 1u << (pos & 31));
             myCost += ((rect[1] / TILE_W) - (rect[0] / TILE_W) + 1) * ((rect[3] / TILE_H) - (rect[2] / TILE_H) + 1);
         }
     }
     if (myCost) atomicAdd(&s_cost, myCost);
     __syncthreads();
+    {   // frame header
+        float *fh = reinterpret_cast<float *>(gv.vis_hdr + (size_t)frame * FRAME_HDR_BYTES);
+        if (tid == 0) fh[0] = __int_as_float(min(nVis, maxVis));
+        if (tid < A) {
+            const CamL &cm = s_cam[tid];
+            float *o = fh + FH_CAM + FH_CAM_STRIDE * tid;
+            o[0] = cm.eye[0]; o[1] = cm.eye[1]; o[2] = cm.eye[2];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) o[3 + q] = cm.c[q];
+            o[12] = cm.origin[0]; o[13] = cm.origin[1]; o[14] = cm.origin[2]; o[15] = 0.0f;
+        }
+        if (tid >= 64 && tid <= 64 + A) {   // light (0,4,2) camera-relative (magnum_env_renderer.cpp:201) in the axes of every frame a box can live in
+            const int f = tid - 64;
+            const V3 lw = mat_mul(s_cam[viewer].c, v3(0.0f, 4.0f, 2.0f));
+            const V3 l = f == 0 ? lw : f == 1 + viewer ? v3(0.0f, 4.0f, 2.0f) : mat_tmul(s_cam[f - 1].c, lw);
+            float *o = fh + FH_LREL + 4 * f;
+            o[0] = l.x; o[1] = l.y; o[2] = l.z; o[3] = 0.0f;
+        }
+        if (tid >= 128 && tid < 160) fh[FH_WB + (tid - 128)] = __uint_as_float(s_wbits[tid - 128]);
+    }
     if (tid == 0) {
         gv.vis_count[frame] = min(nVis, maxVis);
         // longest-processing-time-first scheduling of the raster pass: frames are binned by estimated cost, the raster
@@ -582,7 +613,6 @@ __global__ __launch_bounds__(1024) void frame_order_kernel(GymView gv, int frame
     __shared__ int s_hist[LPT_BUCKETS], s_start[LPT_BUCKETS];
     const int tid = threadIdx.x;
     if (tid < LPT_BUCKETS) s_hist[tid] = 0;
-    if (tid < 8) gv.raster_queue[tid * 32] = 0;   // the persistent raster's queue heads (one 128-byte line per XCD)
     __syncthreads();
     for (int f = tid; f < frames; f += 1024) atomicAdd(&s_hist[gv.lpt_bucket[f]], 1);
     __syncthreads();
@@ -849,30 +879,24 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 && !SHAPES ? MV_RASTER_WAVES : M
 //     offset is t * d_axis, so the normal never materialises: ndl = t |d_k| -+ Lrel_k ; |L - P|^2 is a quadratic in t with
 //     per-column / per-row coefficients (L . dc = 4 dcy - 2, dc . dc = dcx^2 + dcy^2 + 1); one v_rsq_f32 per pixel;
 //   * the highlight is evaluated only where cos > 0.97 (0.97^300 = 1e-4: 0.03 of one 8-bit step) with v_log/v_exp;
-//   * colour = byte * (AMB + DIFL * intensity) + 255 * spec, converted and packed with v_cvt_pk_u8_f32.
-// Scheduling: a persistent grid (as many workgroups as fit on the chip) pulls (frame, tile group) items, most expensive
-// frame first, from one queue head per XCD (workgroup b runs on XCD b % 8; a drained queue steals from the next one).
-// Pixels differ from the exact kernel / the oracle by at most one 8-bit step in well under 1e-3 of the pixels, and by more
-// only where a silhouette or a depth near-tie falls within rounding of a pixel centre (tests/test_fast_pixels_gpu.py).
+//   * colour = byte * (AMB + DIFL * intensity) + 255 * spec, converted by truncation after + 0.5 like the exact kernel.
+// Structure: `split` workgroups per frame (interleaved tile groups), launched most-expensive-frame-first -- the hardware
+// dispatcher is the work queue.  The prologue is a plain copy (frame_setup_kernel leaves cameras, light vectors, world-box
+// masks and the count in a per-frame header) with ONE barrier; world-frame boxes are traced two at a time (one LDS round
+// trip per pair, two independent dependency chains); everything wave-uniform is kept in SGPRs explicitly.
+// Pixels differ from the exact kernel / the oracle by at most one 8-bit step in ~5e-5 of the pixels, and by more only where a
+// silhouette or a depth near-tie falls within rounding of a pixel centre, ~1e-6 (tests/test_fast_pixels_gpu.py).
 // =====================================================================================================================
 namespace {
 
 constexpr float SPEC_COS2 = 0.97f * 0.97f;
-constexpr int QUEUE_STRIDE = 32;   // ints between queue heads: one 128-byte line each
 
 struct FastArgs {   // what raster_fast_kernel needs of the GymView (fewer live SGPRs than the whole view)
-    const AgentState *agents;
+    const unsigned char *vis_hdr;
     const Prim *vis_prims;
     const short4 *vis_rects;
-    const int *vis_count, *order;
-    int *queue;
+    const int *order;
     int num_agents, vis_stride, frames;
-};
-
-struct FastRay {
-    V3 dw, inv;        // world direction and its reciprocals
-    float dcx, dcy;    // camera-space direction (z = -1)
-    float a2, ldc;     // dc . dc and L . dc
 };
 
 // a wave-uniform 64-bit value that came through LDS, back into SGPRs (so that loops over its bits are scalar loops)
@@ -914,255 +938,193 @@ __global__ __launch_bounds__(256, WAVES) void raster_fast_kernel(FastArgs fa, ui
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     __shared__ float4 s_vis[2 * MAXVIS];      // Prim records as (lo, meta) (hi, colour)
     __shared__ short4 s_rect[MAXVIS];
-    __shared__ CamL s_cam[MAX_AGENTS];
-    __shared__ float s_lrel[1 + MAX_AGENTS][4];   // light position relative to the viewer's eye in the axes of frame 0 (world) / 1+k (camera k)
-    __shared__ unsigned long long s_wb[ROUNDS];   // bit per list position: an axis-aligned box in the world frame
-    __shared__ int s_item[2];
+    __shared__ __attribute__((aligned(16))) float s_hdr[FH_FLOATS];
+    static_assert(ROUNDS <= 16, "world-box masks: 16 x 64 positions");
 
     float4 *s_col = reinterpret_cast<float4 *>(s_dyn);   // per column i: (dc.x, c00*dc.x, c10*dc.x, c20*dc.x)
     float4 *s_row = s_col + W;                            // per row j:    (dc.y, c01*dc.y, c11*dc.y, c21*dc.y)
     float2 *s_rowq = reinterpret_cast<float2 *>(s_row + H);   // (dc.y^2 + 1, L . dc = 4 dc.y - 2)
     float *s_colq = reinterpret_cast<float *>(s_rowq + H);    // dc.x^2   (last: keeps every table naturally aligned for odd W)
 
-    const int A = fa.num_agents, frames = fa.frames;
-    const int xcd = blockIdx.x & 7;
-    const int tilesX = (W + TILE_W - 1) / TILE_W, tilesY = (H + TILE_H - 1) / TILE_H;
-    const int numTiles = tilesX * tilesY;
+    const int A = fa.num_agents;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Workgroup ids are dealt round-robin over the 8 XCDs; the `split` parts of one frame get ids that are congruent mod 8 so
+    // that they share one XCD's L2 (the frame's list is read `split` times, neighbouring tiles write neighbouring lines).
+    int position, part;
+    {
+        const int per = 8 * split, group = blockIdx.x / per, r = blockIdx.x - group * per;
+        position = group * 8 + (r & 7); part = r >> 3;
+        const int frames = fa.frames;
+        if (group * 8 + 8 > frames) { const int nf = frames - group * 8; position = group * 8 + r % nf; part = r / nf; }
+    }
+    const int frame = __builtin_amdgcn_readfirstlane(fa.order[position]);   // most expensive frames first
+    const int viewer = frame % A;
+    const float *gh = reinterpret_cast<const float *>(fa.vis_hdr + (size_t)frame * FRAME_HDR_BYTES);
+    const int nVis = __builtin_amdgcn_readfirstlane(min(__float_as_int(gh[0]), (int)MAXVIS));
 
-    // ---- work queue: XCD q owns the sorted positions p with p % 8 == q, `split` items each
-    int myQueue = xcd, tried = 0;
-    auto pull = [&]() -> int {   // thread 0 only; returns sorted-position * split + part, or -1
-        while (tried < 8) {
-            const int n = ((frames - myQueue + 7) >> 3) * split;   // items of this queue
-            const int j = atomicAdd(&fa.queue[myQueue * QUEUE_STRIDE], 1);
-            if (j < n) return ((j / split) * 8 + myQueue) * split + (j % split);
-            myQueue = (myQueue + 1) & 7; ++tried;
+    // ---- prologue: copies + the separable ray tables, one barrier
+    if (tid < FH_FLOATS) s_hdr[tid] = gh[tid];
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(fa.vis_prims + (size_t)frame * fa.vis_stride);
+        for (int i = tid; i < nVis * 2; i += 256) s_vis[i] = src[i];
+        const short4 *rs = fa.vis_rects + (size_t)frame * fa.vis_stride;
+        for (int i = tid; i < nVis; i += 256) s_rect[i] = rs[i];
+        const float *c = gh + FH_CAM + FH_CAM_STRIDE * viewer + 3;   // (same arithmetic as the exact kernel: rays are bit-identical)
+        for (int i = tid; i < W; i += 256) {
+            const float dcx = (((float(i) + 0.5f) / float(W)) * 2.0f - 1.0f) * TAN_HALF_FOV;
+            s_col[i] = make_float4(dcx, c[0] * dcx, c[3] * dcx, c[6] * dcx);
+            s_colq[i] = dcx * dcx;
         }
-        return -1;
-    };
-    if (threadIdx.x == 0) s_item[0] = pull();
-    int phase = 0;
-
-    for (;;) {
-        // (laundering the thread id keeps hipcc from hoisting every tid-derived address out of this loop -- and then spilling them)
-        int tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));
-        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        __syncthreads();   // the item id is visible; every wave is done with the previous item's LDS
-        const int item = __builtin_amdgcn_readfirstlane(s_item[phase]);   // wave-uniform by construction: say so (scalar loop control)
-        if (item < 0) break;
-        if (tid == 0) s_item[phase ^ 1] = pull();   // next item: the atomic's latency hides behind this item's work
-        phase ^= 1;
-        const int frame = fa.order[item / split], part = item % split;
-        const int env = frame / A, viewer = frame - env * A;
-        const AgentState *agents = fa.agents + (size_t)env * A;
-
-        // ---- cameras (same arithmetic as the exact kernel: rays are bit-identical)
-        if (tid < A) {
-            const AgentState a = agents[tid];
-            CamL cam;
-            cam.eye[0] = a.pos[0]; cam.eye[1] = (a.pos[1] + 0.05f) + 0.41f; cam.eye[2] = a.pos[2];
-            float sp, cp;
-            sincos_poly(a.pitch, sp, cp);
-            cam.c[0] = a.m00; cam.c[1] = a.m02 * sp; cam.c[2] = a.m02 * cp;
-            cam.c[3] = 0.0f;  cam.c[4] = cp;         cam.c[5] = -sp;
-            cam.c[6] = a.m20; cam.c[7] = a.m22 * sp; cam.c[8] = a.m22 * cp;
-            cam.origin[0] = cam.origin[1] = cam.origin[2] = 0.0f;
-            s_cam[tid] = cam;
-        }
-        const int nVis = __builtin_amdgcn_readfirstlane(min(fa.vis_count[frame], (int)MAXVIS));
-        {   // the frame's visible list
-            const float4 *src = reinterpret_cast<const float4 *>(fa.vis_prims + (size_t)frame * fa.vis_stride);
-            for (int i = tid; i < nVis * 2; i += 256) s_vis[i] = src[i];
-            const short4 *rs = fa.vis_rects + (size_t)frame * fa.vis_stride;
-            for (int i = tid; i < nVis; i += 256) s_rect[i] = rs[i];
-        }
-        __syncthreads();
-        if (tid < A) {
-            const V3 ev = v3(s_cam[viewer].eye[0], s_cam[viewer].eye[1], s_cam[viewer].eye[2]);
-            const V3 ek = v3(s_cam[tid].eye[0], s_cam[tid].eye[1], s_cam[tid].eye[2]);
-            const V3 o = mat_tmul(s_cam[tid].c, ev - ek);
-            s_cam[tid].origin[0] = o.x; s_cam[tid].origin[1] = o.y; s_cam[tid].origin[2] = o.z;
-        }
-        if (tid <= A) {   // light (0,4,2) camera-relative (magnum_env_renderer.cpp:201) in the axes of every frame a box can live in
-            const V3 lw = mat_mul(s_cam[viewer].c, v3(0.0f, 4.0f, 2.0f));
-            const V3 l = tid == 0 ? lw : tid == 1 + viewer ? v3(0.0f, 4.0f, 2.0f) : mat_tmul(s_cam[tid - 1].c, lw);
-            s_lrel[tid][0] = l.x; s_lrel[tid][1] = l.y; s_lrel[tid][2] = l.z; s_lrel[tid][3] = 0.0f;
-        }
-        {
-            const float *c = s_cam[viewer].c;
-            for (int i = tid; i < W; i += 256) {
-                const float dcx = (((float(i) + 0.5f) / float(W)) * 2.0f - 1.0f) * TAN_HALF_FOV;
-                s_col[i] = make_float4(dcx, c[0] * dcx, c[3] * dcx, c[6] * dcx);
-                s_colq[i] = dcx * dcx;
-            }
-            for (int j = tid; j < H; j += 256) {
-                const float dcy = (((float(j) + 0.5f) / float(H)) * 2.0f - 1.0f) * TAN_HALF_FOV_Y;
-                s_row[j] = make_float4(dcy, c[1] * dcy, c[4] * dcy, c[7] * dcy);
-                s_rowq[j] = make_float2(dcy * dcy + 1.0f, 4.0f * dcy - 2.0f);
-            }
-#pragma unroll
-            for (int r = 0; r * 256 < MAXVIS; ++r) {   // world-box bit of every list position
-                const int pos = tid + 256 * r;
-                const bool wbx = pos < nVis && (__float_as_uint(s_vis[2 * pos].w) & 0xffu) == (unsigned)PRIM_BOX;
-                const unsigned long long mwb = __ballot(wbx);
-                if (lane == 0) s_wb[wave + 4 * r] = mwb;
-            }
-        }
-        __syncthreads();
-
-        const CamL &cam = s_cam[viewer];
-        const float nzm0 = uniform_f32(-cam.c[2]), nzm1 = uniform_f32(-cam.c[5]), nzm2 = uniform_f32(-cam.c[8]);
-        uint32_t *out = obs + (size_t)frame * W * H;
-
-        int tx = part * 4 + wave, ty = 0;   // tile = ty * tilesX + tx, advanced without a division
-        for (int tile = part * 4 + wave; tile < numTiles; tile += 4 * split, tx += 4 * split) {
-            while (tx >= tilesX) { tx -= tilesX; ++ty; }
-            const int tx0 = tx * TILE_W, ty0 = ty * TILE_H;
-            const int tx1 = min(tx0 + TILE_W, W) - 1, ty1 = min(ty0 + TILE_H, H) - 1;
-
-            const int px = tx0 + (lane & (TILE_W - 1)), py = ty0 + (lane / TILE_W);
-            const bool inside = px < W && py < H;
-            const int pxc = min(px, W - 1), pyc = min(py, H - 1);
-            FastRay R;
-            R.dw = R.inv = v3(0, 0, 0); R.dcx = R.dcy = R.a2 = R.ldc = 0.0f;
-            bool rayReady = false;   // wave-uniform: the ray is set up when the first primitive survives the culling
-            unsigned best = ~0u;
-            V3 bn = v3(0, 0, 0);     // normal of the best hit when it is not a box (boxes recover theirs from the entry axis)
-#pragma unroll 1
-            for (int k = 0; k * 64 < nVis; ++k) {
-                // ---- tile culling: one primitive per lane, four integer compares against its screen rectangle
-                bool v = false;
-                if (lane + 64 * k < nVis) {
-                    const short4 r = s_rect[lane + 64 * k];
-                    v = r.x <= tx1 && r.y >= tx0 && r.z <= ty1 && r.w >= ty0;
-                }
-                const unsigned long long mv = __ballot(v);
-                if (mv == 0ull) continue;
-                if (!rayReady) {
-                    rayReady = true;
-                    const float4 cx = s_col[pxc], ry = s_row[pyc];
-                    const float2 rq = s_rowq[pyc];
-                    R.dcx = cx.x; R.dcy = ry.x;
-                    R.dw = v3((cx.y + ry.y) + nzm0, (cx.z + ry.z) + nzm1, (cx.w + ry.w) + nzm2);
-                    R.inv = v3(__builtin_amdgcn_rcpf(R.dw.x), __builtin_amdgcn_rcpf(R.dw.y), __builtin_amdgcn_rcpf(R.dw.z));
-                    R.a2 = s_colq[pxc] + rq.x; R.ldc = rq.y;
-                }
-                const unsigned long long wb = uniform_u64(s_wb[k]);
-                // ---- world-frame boxes: the common case, no branches on the primitive's kind
-                unsigned long long m = mv & wb;
-                while (m) {
-                    const int bit = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    const int pos = bit + 64 * k;
-                    const float4 lo = s_vis[2 * pos], hi = s_vis[2 * pos + 1];
-                    float t;
-                    const bool hit = fast_box(R.inv, lo, hi, t);
-                    const unsigned key = hit ? ((__float_as_uint(t) & ~POS_MASK) | (unsigned)pos) : ~0u;
-                    best = min(best, key);
-                }
-                // ---- everything else: camera-attached boxes, capsules, cones, scaled shapes
-                m = mv & ~wb;
-                while (m) {
-                    const int bit = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    const int pos = bit + 64 * k;
-                    const float4 lo = s_vis[2 * pos], hi = s_vis[2 * pos + 1];
-                    const unsigned meta = __builtin_amdgcn_readfirstlane(__float_as_uint(lo.w));
-                    const int qkind = meta & 15, qfr = (meta >> 4) & 15;
-                    float t = 0.0f; V3 n = v3(0, 0, 0);
-                    bool hit;
-                    if (qkind == PRIM_BOX) {
-                        const V3 df = qfr == 1 + viewer ? v3(R.dcx, R.dcy, -1.0f) : mat_tmul(s_cam[qfr - 1].c, R.dw);
-                        hit = fast_box(v3(__builtin_amdgcn_rcpf(df.x), __builtin_amdgcn_rcpf(df.y), __builtin_amdgcn_rcpf(df.z)), lo, hi, t);
-                    } else {
-                        const float *ce = local_lds(cam.eye);   // (read here, not kept in registers across the tile loop)
-                        const V3 eye = v3(ce[0], ce[1], ce[2]);
-                        if (qkind == PRIM_CAPSULE) hit = ray_capsule<true>(eye, R.dw, v3(lo.x, lo.y, lo.z), hi.x, hi.y, t, n);
-                        else if (qkind == PRIM_CONE) hit = ray_cone<true>(eye, R.dw, v3(lo.x, lo.y, lo.z), hi.x, hi.y, hi.z, t, n);
-                        else if (SHAPES) {
-                            const V3 df = qfr == 0 ? R.dw : qfr == 1 + viewer ? v3(R.dcx, R.dcy, -1.0f) : mat_tmul(s_cam[qfr - 1].c, R.dw);
-                            hit = ray_scaled_shape<true>(qkind, df, v3(lo.x, lo.y, lo.z), v3(hi.x, hi.y, hi.z), t, n);
-                        } else hit = false;
-                    }
-                    const unsigned key = hit ? ((__float_as_uint(t) & ~POS_MASK) | (unsigned)pos) : ~0u;
-                    if (key < best) { best = key; bn = n; }
-                }
-            }
-
-            // ---- Phong (Magnum Shaders::Phong, uniforms of magnum_env_renderer.cpp:200-203)
-            unsigned rgba = 0xff000000u;
-            if (best != ~0u) {
-                const V3 dc = v3(R.dcx, R.dcy, -1.0f);
-                const int pos = (int)(best & POS_MASK);
-                const float4 lo = s_vis[2 * pos], hi = s_vis[2 * pos + 1];
-                const unsigned meta = __float_as_uint(lo.w), color = __float_as_uint(hi.w);
-                const int qkind = meta & 15, qfr = (meta >> 4) & 15;
-                float t, ndl, nv;   // depth; N . (L - P) and N . (-P), both unnormalised in (L - P) / P
-                if (qkind == PRIM_BOX) {
-                    V3 d = R.dw, inv = R.inv;
-                    if (qfr != 0) {
-                        d = qfr == 1 + viewer ? dc : mat_tmul(s_cam[qfr - 1].c, R.dw);
-                        inv = v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-                    }
-                    const float tnx = __builtin_fminf(lo.x * inv.x, hi.x * inv.x), tny = __builtin_fminf(lo.y * inv.y, hi.y * inv.y),
-                                tnz = __builtin_fminf(lo.z * inv.z, hi.z * inv.z);
-                    t = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz);
-                    const int axis = tnx == t ? 0 : tny == t ? 1 : 2;   // first axis whose near-plane crossing is the entry depth
-                    const float dk = axis == 0 ? d.x : axis == 1 ? d.y : d.z;
-                    const float lk = s_lrel[qfr][axis];
-                    nv = t * __builtin_fabsf(dk);                       // plane offset along the outward normal
-                    ndl = nv - __builtin_copysignf(1.0f, dk) * lk;     // sgn (Lrel_k - t d_k), sgn = -sign(d_k)
-                } else {   // capsules, cones, scaled shapes: the normal was kept with the hit (depth: the key's, 2^-15 relative)
-                    t = __uint_as_float(best & ~POS_MASK);
-                    V3 N;
-                    const float *cc = local_lds(cam.c);
-                    if (!SHAPES || qkind < PRIM_SPHERE_S || qfr == 0) N = mat_tmul(cc, bn);
-                    else if (qfr == 1 + viewer) N = bn;
-                    else N = mat_tmul(cc, mat_mul(s_cam[qfr - 1].c, bn));
-                    const V3 P = dc * t;
-                    nv = -dot(N, P);
-                    ndl = dot(N, v3(0.0f - P.x, 4.0f - P.y, 2.0f - P.z));
-                }
-                // |L - P|^2 = |L|^2 - 2 t (L . dc) + t^2 (dc . dc)
-                const float ta = t * R.a2;
-                const float len2LP = __builtin_fmaf(t, ta - 2.0f * R.ldc, 20.0f);
-                const float rs = __builtin_amdgcn_rsqf(len2LP);
-                const float intensity = __builtin_fmaxf(0.0f, ndl * rs);
-                float spec255 = 0.5f;
-                if (intensity > 0.001f) {
-                    // V . R with V = -P unnormalised: 2 (N . Ld)(N . -P) + Ld . P
-                    const float vr = __builtin_fmaf(2.0f * intensity, nv, (t * (R.ldc - ta)) * rs);
-                    const float p2 = t * ta;   // |P|^2
-                    if (vr > 0.0f && vr * vr > SPEC_COS2 * p2) {
-                        const float cosv = __builtin_fminf(vr * __builtin_amdgcn_rsqf(p2), 1.0f);
-                        spec255 = __builtin_fmaf(255.0f, __builtin_amdgcn_exp2f(300.0f * __builtin_amdgcn_logf(cosv)), 0.5f);
-                    }
-                }
-                const float AMB = float(0x55) / 255.0f, DIFL = (float(0xbb) / 255.0f) * (float(0xaa) / 255.0f);
-                const float sc = __builtin_fmaf(DIFL, intensity, AMB);
-                const float r8 = __builtin_fmaf(float((color >> 16) & 255u), sc, spec255), g8 = __builtin_fmaf(float((color >> 8) & 255u), sc, spec255),
-                            b8 = __builtin_fmaf(float(color & 255u), sc, spec255);
-                rgba = (unsigned)(int)__builtin_fminf(r8, 255.0f) | ((unsigned)(int)__builtin_fminf(g8, 255.0f) << 8) |
-                       ((unsigned)(int)__builtin_fminf(b8, 255.0f) << 16) | 0xff000000u;
-            }
-            if (inside) out[(size_t)py * W + px] = rgba;
+        for (int j = tid; j < H; j += 256) {
+            const float dcy = (((float(j) + 0.5f) / float(H)) * 2.0f - 1.0f) * TAN_HALF_FOV_Y;
+            s_row[j] = make_float4(dcy, c[1] * dcy, c[4] * dcy, c[7] * dcy);
+            s_rowq[j] = make_float2(dcy * dcy + 1.0f, 4.0f * dcy - 2.0f);
         }
     }
-}
+    __syncthreads();
 
+    const float *camv = s_hdr + FH_CAM + FH_CAM_STRIDE * viewer;   // eye(3) c(9) origin(3)
+    const float nzm0 = uniform_f32(-camv[3 + 2]), nzm1 = uniform_f32(-camv[3 + 5]), nzm2 = uniform_f32(-camv[3 + 8]);
+    uint32_t *out = obs + (size_t)frame * W * H;
+    const int tilesX = (W + TILE_W - 1) / TILE_W, tilesY = (H + TILE_H - 1) / TILE_H;
+    const int numTiles = tilesX * tilesY;
+    const int lx = lane & (TILE_W - 1), ly = lane / TILE_W;
 
-// One observation pass: frame setup -> frame sort -> raster, on `stream`.  (Running the sort on a side stream from the
-// previous pass's bins was tried: the cross-stream event packets cost more than the 6 us single-workgroup bubble.)
-// persistent grid of raster_fast_kernel: as many workgroups as are resident at once (occupancy query, cached per variant)
-template <class K>
-static int resident_workgroups(K kernel, size_t dyn)
-{
-    int perCu = 0, dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 2048;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kernel, 256, dyn) != hipSuccess || perCu < 1) perCu = 1;
-    return std::min(perCu, 8) * prop.multiProcessorCount;
+    int tx = part * 4 + wave, ty = 0;   // tile = ty * tilesX + tx, advanced without a division
+    for (int tile = part * 4 + wave; tile < numTiles; tile += 4 * split, tx += 4 * split) {
+        while (tx >= tilesX) { tx -= tilesX; ++ty; }
+        const int tx0 = tx * TILE_W, ty0 = ty * TILE_H;
+        const int tx1 = min(tx0 + TILE_W, W) - 1, ty1 = min(ty0 + TILE_H, H) - 1;
+        const int px = tx0 + lx, py = ty0 + ly;
+        const bool inside = px < W && py < H;
+        const int pxc = min(px, W - 1), pyc = min(py, H - 1);
+        V3 dw = v3(0, 0, 0), inv = v3(0, 0, 0);
+        float dcx = 0.0f, dcy = 0.0f, a2 = 0.0f, ldc = 0.0f;
+        bool rayReady = false;   // wave-uniform: the ray is set up when the first primitive survives the culling
+        unsigned best = ~0u;
+        V3 bn = v3(0, 0, 0);     // normal of the best hit when it is not a box (boxes recover theirs from the entry axis)
+#pragma unroll 1
+        for (int k = 0; k * 64 < nVis; ++k) {
+            // ---- tile culling: one primitive per lane, four integer compares against its screen rectangle
+            bool v = false;
+            if (lane + 64 * k < nVis) {
+                const short4 r = s_rect[lane + 64 * k];
+                v = r.x <= tx1 && r.y >= tx0 && r.z <= ty1 && r.w >= ty0;
+            }
+            const unsigned long long mvis = __ballot(v);
+            if (mvis == 0ull) continue;
+            if (!rayReady) {
+                rayReady = true;
+                const float4 cx = s_col[pxc], ry = s_row[pyc];
+                const float2 rq = s_rowq[pyc];
+                dcx = cx.x; dcy = ry.x;
+                dw = v3((cx.y + ry.y) + nzm0, (cx.z + ry.z) + nzm1, (cx.w + ry.w) + nzm2);
+                inv = v3(__builtin_amdgcn_rcpf(dw.x), __builtin_amdgcn_rcpf(dw.y), __builtin_amdgcn_rcpf(dw.z));
+                a2 = s_colq[pxc] + rq.x; ldc = rq.y;
+            }
+            const unsigned long long wb = uniform_u64(*reinterpret_cast<const unsigned long long *>(s_hdr + FH_WB + 2 * k));
+            // ---- world-frame boxes, two per trip: one LDS wait per pair, two independent chains
+            unsigned long long m = mvis & wb;
+            while (m) {
+                const int p0 = __ffsll((long long)m) - 1 + 64 * k;
+                m &= m - 1;
+                const int p1 = m ? __ffsll((long long)m) - 1 + 64 * k : p0;
+                m &= m - 1;   // (stays 0 when there was no second one)
+                const float4 lo0 = s_vis[2 * p0], hi0 = s_vis[2 * p0 + 1], lo1 = s_vis[2 * p1], hi1 = s_vis[2 * p1 + 1];
+                float t0, t1;
+                const bool h0 = fast_box(inv, lo0, hi0, t0);
+                const bool h1 = fast_box(inv, lo1, hi1, t1);
+                const unsigned k0 = h0 ? ((__float_as_uint(t0) & ~POS_MASK) | (unsigned)p0) : ~0u;
+                const unsigned k1 = h1 ? ((__float_as_uint(t1) & ~POS_MASK) | (unsigned)p1) : ~0u;
+                best = min(best, min(k0, k1));
+            }
+            // ---- everything else: camera-attached boxes, capsules, cones, scaled shapes
+            m = mvis & ~wb;
+            while (m) {
+                const int bit = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const int pos = bit + 64 * k;
+                const float4 lo = s_vis[2 * pos], hi = s_vis[2 * pos + 1];
+                const unsigned meta = __builtin_amdgcn_readfirstlane(__float_as_uint(lo.w));
+                const int qkind = meta & 15, qfr = (meta >> 4) & 15;
+                float t = 0.0f; V3 n = v3(0, 0, 0);
+                bool hit;
+                if (qkind == PRIM_BOX) {
+                    const V3 df = qfr == 1 + viewer ? v3(dcx, dcy, -1.0f) : mat_tmul(local_lds(s_hdr + FH_CAM + FH_CAM_STRIDE * (qfr - 1) + 3), dw);
+                    hit = fast_box(v3(__builtin_amdgcn_rcpf(df.x), __builtin_amdgcn_rcpf(df.y), __builtin_amdgcn_rcpf(df.z)), lo, hi, t);
+                } else {
+                    const float *ce = local_lds(camv);   // (read here, not kept in registers across the tile loop)
+                    const V3 eye = v3(ce[0], ce[1], ce[2]);
+                    if (qkind == PRIM_CAPSULE) hit = ray_capsule<true>(eye, dw, v3(lo.x, lo.y, lo.z), hi.x, hi.y, t, n);
+                    else if (qkind == PRIM_CONE) hit = ray_cone<true>(eye, dw, v3(lo.x, lo.y, lo.z), hi.x, hi.y, hi.z, t, n);
+                    else if (SHAPES) {
+                        const V3 df = qfr == 0 ? dw : qfr == 1 + viewer ? v3(dcx, dcy, -1.0f) : mat_tmul(local_lds(s_hdr + FH_CAM + FH_CAM_STRIDE * (qfr - 1) + 3), dw);
+                        hit = ray_scaled_shape<true>(qkind, df, v3(lo.x, lo.y, lo.z), v3(hi.x, hi.y, hi.z), t, n);
+                    } else hit = false;
+                }
+                const unsigned key = hit ? ((__float_as_uint(t) & ~POS_MASK) | (unsigned)pos) : ~0u;
+                if (key < best) { best = key; bn = n; }
+            }
+        }
+
+        // ---- Phong (Magnum Shaders::Phong, uniforms of magnum_env_renderer.cpp:200-203)
+        unsigned rgba = 0xff000000u;
+        if (best != ~0u) {
+            const V3 dc = v3(dcx, dcy, -1.0f);
+            const int pos = (int)(best & POS_MASK);
+            const float4 lo = s_vis[2 * pos], hi = s_vis[2 * pos + 1];
+            const unsigned meta = __float_as_uint(lo.w), color = __float_as_uint(hi.w);
+            const int qkind = meta & 15, qfr = (meta >> 4) & 15;
+            float t, ndl, nv;   // depth; N . (L - P) and N . (-P), both unnormalised in (L - P) / P
+            if (qkind == PRIM_BOX) {
+                V3 d = dw, iv = inv;
+                if (qfr != 0) {
+                    d = qfr == 1 + viewer ? dc : mat_tmul(local_lds(s_hdr + FH_CAM + FH_CAM_STRIDE * (qfr - 1) + 3), dw);
+                    iv = v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+                }
+                const float tnx = __builtin_fminf(lo.x * iv.x, hi.x * iv.x), tny = __builtin_fminf(lo.y * iv.y, hi.y * iv.y),
+                            tnz = __builtin_fminf(lo.z * iv.z, hi.z * iv.z);
+                t = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz);
+                const int axis = tnx == t ? 0 : tny == t ? 1 : 2;   // first axis whose near-plane crossing is the entry depth
+                const float dk = axis == 0 ? d.x : axis == 1 ? d.y : d.z;
+                const float lk = s_hdr[FH_LREL + 4 * qfr + axis];
+                nv = t * __builtin_fabsf(dk);                                                      // plane offset along the outward normal
+                ndl = nv - __uint_as_float(__float_as_uint(lk) ^ (__float_as_uint(dk) & 0x80000000u));   // sgn (Lrel_k - t d_k), sgn = -sign(d_k)
+            } else {   // capsules, cones, scaled shapes: the normal was kept with the hit (depth: the key's, 2^-15 relative)
+                t = __uint_as_float(best & ~POS_MASK);
+                V3 N;
+                const float *cc = local_lds(camv + 3);
+                if (!SHAPES || qkind < PRIM_SPHERE_S || qfr == 0) N = mat_tmul(cc, bn);
+                else if (qfr == 1 + viewer) N = bn;
+                else N = mat_tmul(cc, mat_mul(local_lds(s_hdr + FH_CAM + FH_CAM_STRIDE * (qfr - 1) + 3), bn));
+                const V3 P = dc * t;
+                nv = -dot(N, P);
+                ndl = dot(N, v3(0.0f - P.x, 4.0f - P.y, 2.0f - P.z));
+            }
+            // |L - P|^2 = |L|^2 - 2 t (L . dc) + t^2 (dc . dc)
+            const float ta = t * a2;
+            const float len2LP = __builtin_fmaf(t, ta - 2.0f * ldc, 20.0f);
+            const float rs = __builtin_amdgcn_rsqf(len2LP);
+            const float intensity = __builtin_fmaxf(0.0f, ndl * rs);
+            float spec255 = 0.5f;
+            if (intensity > 0.001f) {
+                // V . R with V = -P unnormalised: 2 (N . Ld)(N . -P) + Ld . P
+                const float vr = __builtin_fmaf(2.0f * intensity, nv, (t * (ldc - ta)) * rs);
+                const float p2 = t * ta;   // |P|^2
+                if (vr > 0.0f && vr * vr > SPEC_COS2 * p2) {
+                    const float cosv = __builtin_fminf(vr * __builtin_amdgcn_rsqf(p2), 1.0f);
+                    spec255 = __builtin_fmaf(255.0f, __builtin_amdgcn_exp2f(300.0f * __builtin_amdgcn_logf(cosv)), 0.5f);
+                }
+            }
+            const float AMB = float(0x55) / 255.0f, DIFL = (float(0xbb) / 255.0f) * (float(0xaa) / 255.0f);
+            const float sc = __builtin_fmaf(DIFL, intensity, AMB);
+            const float r8 = __builtin_fmaf(float((color >> 16) & 255u), sc, spec255), g8 = __builtin_fmaf(float((color >> 8) & 255u), sc, spec255),
+                        b8 = __builtin_fmaf(float(color & 255u), sc, spec255);
+            rgba = (unsigned)(int)__builtin_fminf(r8, 255.0f) | ((unsigned)(int)__builtin_fminf(g8, 255.0f) << 8) |
+                   ((unsigned)(int)__builtin_fminf(b8, 255.0f) << 16) | 0xff000000u;
+        }
+        if (inside) out[(size_t)py * W + px] = rgba;
+    }
 }
 
 int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream, hipEvent_t between, int fast)
@@ -1176,26 +1138,20 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
     if (between) (void)hipEventRecord(between, stream);
     if (fast) {
         const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)W * sizeof(float) + (size_t)H * sizeof(float2);
-        int split = envSplit > 0 ? envSplit : 8;
+        int split = envSplit > 0 ? envSplit : 4;
         while (split > 1 && tiles < 4 * split * 2) split >>= 1;   // keep at least two tiles per wave
-        const int items = frames * split;
         // variants: [0] <=256 visible primitives, [1] + scaled shapes (Rearrange), [2] <=1024 (Collect); the small ones are built for
-        // 8 and for 6 waves per SIMD (64 / 80 VGPRs), MV_FAST_WAVES picks (default 8)
+        // 8 and for 6 waves per SIMD (64 / 80 VGPRs), MV_FAST_WAVES picks
         static const int wavesSel = getenv("MV_FAST_WAVES") ? atoi(getenv("MV_FAST_WAVES")) : 8;
         using KernelFn = void (*)(FastArgs, uint32_t *, int, int, int);
         const int variant = gv.vis_stride > VIS_SMALL ? 2 : gv.scenario == SCN_REARRANGE ? 1 : 0;
         KernelFn fn = variant == 2 ? raster_fast_kernel<VIS_LARGE, false, 3>
                     : variant == 1 ? (wavesSel >= 8 ? raster_fast_kernel<VIS_SMALL, true, 8> : raster_fast_kernel<VIS_SMALL, true, 6>)
                                    : (wavesSel >= 8 ? raster_fast_kernel<VIS_SMALL, false, 8> : raster_fast_kernel<VIS_SMALL, false, 6>);
-        static int cap[3] = {0, 0, 0};
-        static size_t capDyn[3] = {0, 0, 0};
-        if (cap[variant] == 0 || capDyn[variant] != dyn) { cap[variant] = resident_workgroups(fn, dyn); capDyn[variant] = dyn; }
-        const dim3 grid(std::max(1, std::min(cap[variant], items))), block(256);
         FastArgs fa;
-        fa.agents = gv.agents; fa.vis_prims = reinterpret_cast<const Prim *>(gv.vis_prims); fa.vis_rects = reinterpret_cast<const short4 *>(gv.vis_rects);
-        fa.vis_count = gv.vis_count; fa.order = gv.lpt_order; fa.queue = gv.raster_queue;
-        fa.num_agents = gv.num_agents; fa.vis_stride = gv.vis_stride; fa.frames = frames;
-        hipLaunchKernelGGL(fn, grid, block, dyn, stream, fa, obs, W, H, split);
+        fa.vis_hdr = gv.vis_hdr; fa.vis_prims = reinterpret_cast<const Prim *>(gv.vis_prims); fa.vis_rects = reinterpret_cast<const short4 *>(gv.vis_rects);
+        fa.order = gv.lpt_order; fa.num_agents = gv.num_agents; fa.vis_stride = gv.vis_stride; fa.frames = frames;
+        hipLaunchKernelGGL(fn, dim3(frames * split), dim3(256), dyn, stream, fa, obs, W, H, split);
         return 0;
     }
     const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)(W + H) * sizeof(float);

@@ -18,6 +18,8 @@ enum : int {
     COLLECT_MAX_BOXES = 1024, COLLECT_MAX_REWARDS = 96, HM_DIM = 42, HM_BYTES = 1792,
 };
 
+enum : int { FRAME_HDR_BYTES = 1024 };   // per-frame header of the observation pass (mv_raster.hip: FH_*)
+
 enum : int { SCN_TOWER = 0, SCN_OBSTACLES = 1, SCN_COLLECT = 2, SCN_REARRANGE = 3, SCN_SOKOBAN = 4 };
 enum : int { SOKO_DIM = 32, SOKO_WALL = 1, SOKO_GOAL = 2 };                            // Sokoban level cells (scenario_sokoban.cpp:28-33)
 enum : int { MAX_ITEMS = 8, NUM_STATIC = 9 };                                         // Rearrange: arrangement items, static colliding boxes
@@ -118,7 +120,7 @@ struct GymView {
     int32_t vis_stride;        // 256, or 1024 for Collect
     int32_t *lpt_bucket;       // [N*A] cost bin of every frame (raster scheduling)
     int32_t *lpt_order;        // [N*A] frames sorted by cost bin, most expensive first
-    int32_t *raster_queue;     // [8 * 32] work-queue heads of the persistent raster kernel, one 128-byte line per XCD
+    uint8_t *vis_hdr;          // [N*A][FRAME_HDR_BYTES] per-frame header for raster_fast_kernel (cameras, light vectors, masks, count)
 };
 
 // One host-generated episode (Obstacles family): everything Env::reset produces, ready to be swapped in by
