@@ -879,7 +879,7 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 && !SHAPES ? MV_RASTER_WAVES : M
 //     offset is t * d_axis, so the normal never materialises: ndl = t |d_k| -+ Lrel_k ; |L - P|^2 is a quadratic in t with
 //     per-column / per-row coefficients (L . dc = 4 dcy - 2, dc . dc = dcx^2 + dcy^2 + 1); one v_rsq_f32 per pixel;
 //   * the highlight is evaluated only where cos > 0.97 (0.97^300 = 1e-4: 0.03 of one 8-bit step) with v_log/v_exp;
-//   * colour = byte * (AMB + DIFL * intensity) + 255 * spec, converted by truncation after + 0.5 like the exact kernel.
+//   * colour = byte * (AMB + DIFL * intensity) + 255 * spec, rounded, saturated and packed by v_cvt_pk_u8_f32.
 // Structure: `split` workgroups per frame (interleaved tile groups), launched most-expensive-frame-first -- the hardware
 // dispatcher is the work queue.  The prologue is a plain copy (frame_setup_kernel leaves cameras, light vectors, world-box
 // masks and the count in a per-frame header) with ONE barrier; world-frame boxes are traced two at a time (one LDS round
@@ -911,11 +911,23 @@ __device__ __forceinline__ float uniform_f32(float v)   // (the builtin takes an
     return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v)));
 }
 
-// an LDS address the compiler will not hoist loads from (keeps rarely used per-frame constants out of the hot loop's registers)
-__device__ __forceinline__ const float *local_lds(const float *p)
+// Rarely used per-frame constants are read from LDS where they are needed instead of living in registers across the tile loop.
+// The pointer is laundered so that hipcc does not hoist the loads -- as an LDS (address space 3) pointer: laundering a generic
+// pointer turns the loads into flat_load, whose s_waitcnt vmcnt(0) would also wait for the previous tile's pixel store.
+typedef __attribute__((address_space(3))) const float lds_float;
+__device__ __forceinline__ lds_float *local_lds(const float *p)
 {
-    asm volatile("" : "+v"(p));
-    return p;
+    lds_float *q = (lds_float *)p;
+    asm volatile("" : "+v"(q));
+    return q;
+}
+__device__ __forceinline__ V3 lds_tmul(lds_float *m, V3 v)   // mat_tmul with the matrix in LDS
+{
+    return v3((m[0] * v.x + m[3] * v.y) + m[6] * v.z, (m[1] * v.x + m[4] * v.y) + m[7] * v.z, (m[2] * v.x + m[5] * v.y) + m[8] * v.z);
+}
+__device__ __forceinline__ V3 lds_mul(lds_float *m, V3 v)
+{
+    return v3((m[0] * v.x + m[1] * v.y) + m[2] * v.z, (m[3] * v.x + m[4] * v.y) + m[5] * v.z, (m[6] * v.x + m[7] * v.y) + m[8] * v.z);
 }
 
 // entry depth of a box given relative to the ray origin; +inf/NaN semantics make zero direction components harmless
@@ -1006,11 +1018,10 @@ __global__ __launch_bounds__(256, WAVES) void raster_fast_kernel(FastArgs fa, ui
 #pragma unroll 1
         for (int k = 0; k * 64 < nVis; ++k) {
             // ---- tile culling: one primitive per lane, four integer compares against its screen rectangle
-            bool v = false;
-            if (lane + 64 * k < nVis) {
-                const short4 r = s_rect[lane + 64 * k];
-                v = r.x <= tx1 && r.y >= tx0 && r.z <= ty1 && r.w >= ty0;
-            }
+            const int cpos = min(lane + 64 * k, nVis - 1);
+            const uint2 rr = *reinterpret_cast<const uint2 *>(&s_rect[cpos]);   // one 8-byte read; x0 | x1 << 16, y0 | y1 << 16 (all >= 0)
+            const bool v = (lane + 64 * k < nVis) & ((int)(rr.x & 0xffffu) <= tx1) & ((int)(rr.x >> 16) >= tx0) & ((int)(rr.y & 0xffffu) <= ty1) &
+                           ((int)(rr.y >> 16) >= ty0);
             const unsigned long long mvis = __ballot(v);
             if (mvis == 0ull) continue;
             if (!rayReady) {
@@ -1050,15 +1061,15 @@ __global__ __launch_bounds__(256, WAVES) void raster_fast_kernel(FastArgs fa, ui
                 float t = 0.0f; V3 n = v3(0, 0, 0);
                 bool hit;
                 if (qkind == PRIM_BOX) {
-                    const V3 df = qfr == 1 + viewer ? v3(dcx, dcy, -1.0f) : mat_tmul(local_lds(s_hdr + FH_CAM + FH_CAM_STRIDE * (qfr - 1) + 3), dw);
+                    const V3 df = qfr == 1 + viewer ? v3(dcx, dcy, -1.0f) : lds_tmul(local_lds(s_hdr + FH_CAM + FH_CAM_STRIDE * (qfr - 1) + 3), dw);
                     hit = fast_box(v3(__builtin_amdgcn_rcpf(df.x), __builtin_amdgcn_rcpf(df.y), __builtin_amdgcn_rcpf(df.z)), lo, hi, t);
                 } else {
-                    const float *ce = local_lds(camv);   // (read here, not kept in registers across the tile loop)
+                    lds_float *ce = local_lds(camv);   // (read here, not kept in registers across the tile loop)
                     const V3 eye = v3(ce[0], ce[1], ce[2]);
                     if (qkind == PRIM_CAPSULE) hit = ray_capsule<true>(eye, dw, v3(lo.x, lo.y, lo.z), hi.x, hi.y, t, n);
                     else if (qkind == PRIM_CONE) hit = ray_cone<true>(eye, dw, v3(lo.x, lo.y, lo.z), hi.x, hi.y, hi.z, t, n);
                     else if (SHAPES) {
-                        const V3 df = qfr == 0 ? dw : qfr == 1 + viewer ? v3(dcx, dcy, -1.0f) : mat_tmul(local_lds(s_hdr + FH_CAM + FH_CAM_STRIDE * (qfr - 1) + 3), dw);
+                        const V3 df = qfr == 0 ? dw : qfr == 1 + viewer ? v3(dcx, dcy, -1.0f) : lds_tmul(local_lds(s_hdr + FH_CAM + FH_CAM_STRIDE * (qfr - 1) + 3), dw);
                         hit = ray_scaled_shape<true>(qkind, df, v3(lo.x, lo.y, lo.z), v3(hi.x, hi.y, hi.z), t, n);
                     } else hit = false;
                 }
@@ -1079,7 +1090,7 @@ __global__ __launch_bounds__(256, WAVES) void raster_fast_kernel(FastArgs fa, ui
             if (qkind == PRIM_BOX) {
                 V3 d = dw, iv = inv;
                 if (qfr != 0) {
-                    d = qfr == 1 + viewer ? dc : mat_tmul(local_lds(s_hdr + FH_CAM + FH_CAM_STRIDE * (qfr - 1) + 3), dw);
+                    d = qfr == 1 + viewer ? dc : lds_tmul(local_lds(s_hdr + FH_CAM + FH_CAM_STRIDE * (qfr - 1) + 3), dw);
                     iv = v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
                 }
                 const float tnx = __builtin_fminf(lo.x * iv.x, hi.x * iv.x), tny = __builtin_fminf(lo.y * iv.y, hi.y * iv.y),
@@ -1093,10 +1104,10 @@ __global__ __launch_bounds__(256, WAVES) void raster_fast_kernel(FastArgs fa, ui
             } else {   // capsules, cones, scaled shapes: the normal was kept with the hit (depth: the key's, 2^-15 relative)
                 t = __uint_as_float(best & ~POS_MASK);
                 V3 N;
-                const float *cc = local_lds(camv + 3);
-                if (!SHAPES || qkind < PRIM_SPHERE_S || qfr == 0) N = mat_tmul(cc, bn);
+                lds_float *cc = local_lds(camv + 3);
+                if (!SHAPES || qkind < PRIM_SPHERE_S || qfr == 0) N = lds_tmul(cc, bn);
                 else if (qfr == 1 + viewer) N = bn;
-                else N = mat_tmul(cc, mat_mul(local_lds(s_hdr + FH_CAM + FH_CAM_STRIDE * (qfr - 1) + 3), bn));
+                else N = lds_tmul(cc, lds_mul(local_lds(s_hdr + FH_CAM + FH_CAM_STRIDE * (qfr - 1) + 3), bn));
                 const V3 P = dc * t;
                 nv = -dot(N, P);
                 ndl = dot(N, v3(0.0f - P.x, 4.0f - P.y, 2.0f - P.z));
@@ -1106,24 +1117,24 @@ __global__ __launch_bounds__(256, WAVES) void raster_fast_kernel(FastArgs fa, ui
             const float len2LP = __builtin_fmaf(t, ta - 2.0f * ldc, 20.0f);
             const float rs = __builtin_amdgcn_rsqf(len2LP);
             const float intensity = __builtin_fmaxf(0.0f, ndl * rs);
-            float spec255 = 0.5f;
+            float spec255 = 0.0f;
             if (intensity > 0.001f) {
                 // V . R with V = -P unnormalised: 2 (N . Ld)(N . -P) + Ld . P
                 const float vr = __builtin_fmaf(2.0f * intensity, nv, (t * (ldc - ta)) * rs);
                 const float p2 = t * ta;   // |P|^2
                 if (vr > 0.0f && vr * vr > SPEC_COS2 * p2) {
                     const float cosv = __builtin_fminf(vr * __builtin_amdgcn_rsqf(p2), 1.0f);
-                    spec255 = __builtin_fmaf(255.0f, __builtin_amdgcn_exp2f(300.0f * __builtin_amdgcn_logf(cosv)), 0.5f);
+                    spec255 = 255.0f * __builtin_amdgcn_exp2f(300.0f * __builtin_amdgcn_logf(cosv));
                 }
             }
             const float AMB = float(0x55) / 255.0f, DIFL = (float(0xbb) / 255.0f) * (float(0xaa) / 255.0f);
             const float sc = __builtin_fmaf(DIFL, intensity, AMB);
             const float r8 = __builtin_fmaf(float((color >> 16) & 255u), sc, spec255), g8 = __builtin_fmaf(float((color >> 8) & 255u), sc, spec255),
                         b8 = __builtin_fmaf(float(color & 255u), sc, spec255);
-            rgba = (unsigned)(int)__builtin_fminf(r8, 255.0f) | ((unsigned)(int)__builtin_fminf(g8, 255.0f) << 8) |
-                   ((unsigned)(int)__builtin_fminf(b8, 255.0f) << 16) | 0xff000000u;
+            // v_cvt_pk_u8_f32: round to nearest (even on ties; the exact kernel rounds ties up: they do not occur), saturate, insert the byte
+            rgba = __builtin_amdgcn_cvt_pk_u8_f32(b8, 2, __builtin_amdgcn_cvt_pk_u8_f32(g8, 1, __builtin_amdgcn_cvt_pk_u8_f32(r8, 0, 0xff000000u)));
         }
-        if (inside) out[(size_t)py * W + px] = rgba;
+        if (inside) out[(unsigned)(py * W + px)] = rgba;   // (32-bit offset from the frame's base: scalar-base addressing)
     }
 }
 
