@@ -124,6 +124,7 @@ int mv_profile_end(mv_gym *g, float *avg_ms4, int32_t *counts4);
 
 /* test hooks: packed state snapshot of one env (layout in DESIGN.md, same bytes as the oracle's
  * mvo_snapshot) and the raw device RNG streams */
+int mv_debug_set_agent_pos(mv_gym *g, int32_t env_idx, int32_t agent_idx, float x, float y, float z); /* teleport (fall-detection tests) */
 int mv_debug_snapshot_size(const mv_gym *g);
 int mv_debug_snapshot(mv_gym *g, int32_t env_idx, void *out_host);
 int mv_debug_rng(int32_t device, uint32_t seed, int32_t what, const int32_t *lo, const int32_t *hi, int32_t n, void *out_host);

@@ -104,8 +104,13 @@ struct mv_gym {
     int lastTotalSeen = 0;
     bool statusPending = false, refillForce = true;
     int stepsSinceStatus = 0;
+    int spares = 2;                                 // resident episodes per env (ring); the host keeps uploaded <= consumed + spares
+    int statusPeriod = 16;                          // steps between status read-backs (1 when episodes can be only a few ticks long)
+    int deficit = 0;                                // spares still to be uploaded (their episodes were not generated yet at the last look)
+    hipEvent_t stepDone = nullptr;                  // after the last step kernel: uploads never overlap a kernel that may read the ring
     hipStream_t copyStream = nullptr;               // status read-back + episode uploads, off the step path
     hipEvent_t resetDone = nullptr, statusCopied = nullptr;
+    bool stepDoneValid = false;
     std::vector<hipEvent_t> uploadEvents;           // ring, one per upload batch
     size_t uploadRing = 0;
     // in-stream profiling
@@ -129,6 +134,7 @@ __global__ void masks_from_multidiscrete_kernel(const int32_t *md, int32_t *mask
 }
 
 __global__ void set_shaping_kernel(AgentState *agents, int idx, int key, float v) { agents[idx].shaping[key] = v; }
+__global__ void set_agent_pos_kernel(AgentState *agents, int idx, float x, float y, float z) { agents[idx].pos[0] = x; agents[idx].pos[1] = y; agents[idx].pos[2] = z; }
 
 __global__ void debug_rng_kernel(uint32_t seed, int what, const int32_t *lo, const int32_t *hi, int n, void *out)
 {
@@ -279,8 +285,9 @@ int mv_create(const mv_config *cfg, mv_gym **out)
                  szObs = up(NA * (size_t)g->w * g->h * 4);
     const size_t szTerrain = obstacles ? up(N * MAX_TERRAIN * sizeof(TerrainBox)) : 0,
                  szRewObj = hostEpisodes ? up(N * (size_t)gv.reward_stride * sizeof(MovableObject)) : 0,
-                 szHeight = collect ? up(N * (size_t)HM_BYTES) : 0, szItems = rearrange ? up(N * MAX_ITEMS * sizeof(ArrangementItem)) : 0, szBlobs = up(N * g->blobBytes), szCnt = up((N + 2) * sizeof(int32_t));
+                 szHeight = collect ? up(N * (size_t)HM_BYTES) : 0, szItems = rearrange ? up(N * MAX_ITEMS * sizeof(ArrangementItem)) : 0, szBlobs = up(N * g->blobBytes * (size_t)g->spares), szCnt = up((N + 2) * sizeof(int32_t));
     gv.vis_stride = collect ? 1024 : 256;
+    gv.spares = g->spares;
     const size_t szVisP = up(NA * (size_t)gv.vis_stride * 32), szVisR = up(NA * (size_t)gv.vis_stride * 8), szVisC = up(NA * sizeof(int32_t)),
                  szLpt = 2 * up(NA * sizeof(int32_t)) + up(NA * (size_t)FRAME_HDR_BYTES);
     const size_t total = szHdr + szBoxes + szObj + szAg + szAct + szRew + szDone + szObjv + szMd + (hostEpisodes ? 0 : szChunk) + szObs + szTerrain +
@@ -347,22 +354,35 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     }
     g->obst = oc;
     g->baseEpisodeLen = episodeLen;
+    {   // status words (episodes consumed, error flags) travel back on a side stream for every scenario
+        bool ok = hipHostMalloc((void **)&g->hStatus, (N + 2) * sizeof(int), hipHostMallocDefault) == hipSuccess &&
+                  hipStreamCreateWithFlags(&g->copyStream, hipStreamNonBlocking) == hipSuccess &&
+                  hipEventCreateWithFlags(&g->resetDone, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&g->stepDone, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&g->statusCopied, hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            mv_destroy(g);
+            return fail("mv_create: status staging / copy stream allocation failed");
+        }
+        std::memset(g->hStatus, 0, (N + 2) * sizeof(int));
+    }
     if (hostEpisodes) {
         g->uploaded.assign(N, 0);
         g->feederThreads = std::min(32, std::max(1, (int)cfg->num_simulation_threads));
         if (const char *e = getenv("MV_FEEDER_THREADS")) g->feederThreads = std::min(64, std::max(1, atoi(e)));
+        // An env needs a fresh resident episode at every reset.  Two are kept resident, and the consumed counts are read back
+        // every 16th step -- unless episodes can time out within a few ticks (a small or negative episodeLengthSec: the Obstacles
+        // family never goes below 35 s per platform, Collect and Rearrange take the parameter as is), then after every step.
+        const float minLenSec = obstacles ? std::max(episodeLen, 35.0f) : episodeLen;
+        g->statusPeriod = minLenSec * 15.0f >= 64.0f ? 16 : 1;
+        if (const char *e = getenv("MV_STATUS_PERIOD")) g->statusPeriod = std::max(1, atoi(e));   // (tests: provoke starvation)
         g->uploadEvents.assign(64, nullptr);
-        bool ok = hipHostMalloc((void **)&g->hBlobs, N * g->blobBytes, hipHostMallocDefault) == hipSuccess &&
-                  hipHostMalloc((void **)&g->hStatus, (N + 2) * sizeof(int), hipHostMallocDefault) == hipSuccess &&
-                  hipStreamCreateWithFlags(&g->copyStream, hipStreamNonBlocking) == hipSuccess &&
-                  hipEventCreateWithFlags(&g->resetDone, hipEventDisableTiming) == hipSuccess &&
-                  hipEventCreateWithFlags(&g->statusCopied, hipEventDisableTiming) == hipSuccess;
+        bool ok = hipHostMalloc((void **)&g->hBlobs, N * g->blobBytes, hipHostMallocDefault) == hipSuccess;
         for (auto &e : g->uploadEvents) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
         if (!ok) {
             mv_destroy(g);
-            return fail("mv_create: pinned episode staging / copy stream allocation failed");
+            return fail("mv_create: pinned episode staging allocation failed");
         }
-        std::memset(g->hStatus, 0, (N + 2) * sizeof(int));
         g->feeder = std::make_unique<EpisodeFeeder>(scenario, oc, g->N, g->A, episodeLen, g->hBlobs, g->blobBytes, g->device, g->feederThreads);
         std::vector<uint32_t> seeds(N);
         std::random_device rdev;   // unseeded envs take their seed from random_device (env.hpp:169)
@@ -400,20 +420,26 @@ int mv_close(mv_gym *g)
 {
     if (!g || g->closed) return 0;
     (void)hipSetDevice(g->device);
+    // order: nothing may still target the arena (episode uploads / status read-backs on the copy stream, kernels on the step
+    // stream) or the pinned slots (feeder workers) when they are freed.  The step stream may be caller-owned and already gone:
+    // its errors are ignored, the device-wide synchronise below covers whatever was enqueued on it.
     (void)hipStreamSynchronize(g->stream);
+    (void)hipGetLastError();
+    if (g->copyStream) (void)hipStreamSynchronize(g->copyStream);
+    (void)hipDeviceSynchronize();
+    g->feeder.reset();   // joins the workers before their slots go away
     GymView &gv = g->gv;
     if (g->arena) (void)hipFree(g->arena);
     if (g->hiresObs) (void)hipFree(g->hiresObs);
-    if (g->copyStream) (void)hipStreamSynchronize(g->copyStream);
-    g->feeder.reset();   // joins the workers before their slots go away
     if (g->hBlobs) (void)hipHostFree(g->hBlobs);
     if (g->hStatus) (void)hipHostFree(g->hStatus);
     if (g->resetDone) (void)hipEventDestroy(g->resetDone);
+    if (g->stepDone) (void)hipEventDestroy(g->stepDone);
     if (g->statusCopied) (void)hipEventDestroy(g->statusCopied);
     for (hipEvent_t e : g->uploadEvents) if (e) (void)hipEventDestroy(e);
     g->uploadEvents.clear();
     if (g->copyStream) (void)hipStreamDestroy(g->copyStream);
-    g->hBlobs = nullptr; g->hStatus = nullptr; g->resetDone = g->statusCopied = nullptr; g->copyStream = nullptr; g->dBlobs = nullptr; g->dStatus = nullptr;
+    g->hBlobs = nullptr; g->hStatus = nullptr; g->resetDone = g->stepDone = g->statusCopied = nullptr; g->copyStream = nullptr; g->dBlobs = nullptr; g->dStatus = nullptr;
     g->arena = nullptr;
     for (int b = 0; b < 2; ++b) {
         if (g->hActions[b]) (void)hipHostFree(g->hActions[b]);
@@ -482,11 +508,13 @@ int mv_seed(mv_gym *g, int32_t seed)
         g->stepsSinceStatus = 0;
         std::vector<int> first(g->N);
         for (int i = 0; i < g->N; ++i) {
-            // the episode resident on the device (if any) was drawn from the old stream: it is replaced before the next
-            // reset can consume it, because the env now counts as "consumed everything uploaded"
+            // the episodes resident on the device were drawn from the old stream: the ring is wiped (sequence number 0 matches
+            // nothing) and every env counts as "consumed everything uploaded"
             g->uploaded[i] = g->hStatus[i];
             first[i] = g->uploaded[i] + 1;
         }
+        HIP_TRY(hipMemset(g->dBlobs, 0, (size_t)g->N * g->spares * g->blobBytes));
+        g->deficit = 0;
         g->refillForce = true;
         g->feeder->reseed(seeds, first);
         return 0;
@@ -509,49 +537,90 @@ int mv_render(mv_gym *g)
     return 0;
 }
 
-// ---- episode refill protocol (Obstacles family, Collect) ---------------------------------------------
-// Each env keeps ONE generated episode resident in HBM (dBlobs[env]); the reset kernel swaps it in and bumps
-// status[env] / status[N].  After the reset kernel of step t the copy stream reads the status words back to pinned
-// memory.  Step t+1 starts by looking at them (that copy finished long ago: the raster of step t is still
-// running) and uploads -- on the copy stream, from the feeder's pinned slots, where the episodes were generated
-// ahead of time by the worker pool -- the next episode of exactly the envs that consumed theirs.  The step path
-// itself only ever enqueues; it waits for the host only if generation falls behind (wait_ready).
+// ---- status flags ----------------------------------------------------------------------------------------------------
+// Kernels raise ST_* bits in status[N + 1], the host generators GEN_* bits (mv_gen.h); both are limits the reference does not
+// have.  They are reported ONCE, by the mv_step / mv_reset that sees them, and cleared: the gym stays usable.
+static int check_status_flags(mv_gym *g)
+{
+    const int N = g->N;
+    const int flags = g->hStatus[N + 1], gen = g->hostEpisodes() ? generator_overflow_take() : 0;
+    if (!flags && !gen) return 0;
+    std::string msg;
+    if (flags & ST_STARVED) msg += "an env finished again before its next episode was resident (it repeated its done step; the next episodes are being uploaded now); ";
+    if (flags & ST_CANDIDATES) msg += "collision candidate list overflow (more than 128 bodies around one agent); ";
+    if (flags & ST_VISIBLE) msg += "a frame had more visible primitives than the raster keeps (256, Collect 1024): the excess was not drawn; ";
+    if (flags & ST_CHUNK) msg += "an object placement outside the 32 x 16 x 32 voxel chunk was refused (the reference's grid is unbounded); ";
+    if (gen & GEN_SLABS) msg += "a generated layout merged into more slabs than an episode record holds (128, Collect 1024): the excess was dropped; ";
+    if (gen & GEN_TERRAIN) msg += "more than 16 terrain boxes in a generated episode; ";
+    if (gen & GEN_OBJECTS) msg += "more than 80 movable boxes in a generated episode; ";
+    if (gen & GEN_REWARDS) msg += "more reward objects than an episode record holds (16, Collect 96); ";
+    if (gen & GEN_COORDS) msg += "a generated level extends beyond +-127 voxels (int8 object coordinates); ";
+    if (flags) {   // clear the device word (and the mirror) so that the next step runs
+        g->hStatus[N + 1] = 0;
+        HIP_TRY(hipMemsetAsync(g->dStatus + N + 1, 0, sizeof(int), g->stream));
+    }
+    return fail("capacity limit hit: " + msg + "reported once, simulation continues");
+}
+
+// ---- episode refill protocol (host-generated scenarios) --------------------------------------------------------------
+// Each env keeps up to `spares` (2) generated episodes resident in HBM, a ring indexed by the episode's sequence number
+// (dBlobs[env][(seq - 1) % spares]); a finished env swaps the next one in at the tail of the step kernel and bumps status[env] /
+// status[N].  A copy stream reads the status words back after the step kernel every `statusPeriod` steps; a later mv_step looks at
+// them and -- still on the copy stream, ordered against the step stream by events only -- tops the ring up from the feeder's pinned
+// slots, where the episodes were generated ahead of time by the worker pool.  The step path itself only ever enqueues; it waits
+// for the host only if an env has NO resident episode left and its next one is still being generated.  An upload never overlaps a
+// step kernel (stepDone): a finished env must not read a half-written slot.
 static int refill_episodes(mv_gym *g)
 {
-    if (!g->hostEpisodes()) return 0;
     if (g->statusPending) {
         HIP_TRY(hipEventSynchronize(g->statusCopied));
         g->statusPending = false;
     }
-    const int N = g->N;
-    const int flags = g->hStatus[N + 1];
-    if (flags & 1) return fail("an env reset without a fresh episode resident (refill protocol violated)");
-    if (flags & 2) return fail("collision candidate list overflow (more than 128 bodies around one agent)");
-    if (!g->refillForce && g->hStatus[N] == g->lastTotalSeen) return 0;
-    hipEvent_t ev = g->uploadEvents[g->uploadRing++ % g->uploadEvents.size()];
-    HIP_TRY(hipEventSynchronize(ev));   // 64 batches ago
-    std::vector<int> &batch = g->uploadBatch;
-    batch.clear();
-    for (int i = 0; i < N; ++i) {
-        if (g->hStatus[i] != g->uploaded[i]) continue;   // its resident episode has not been consumed yet
-        size_t bytes = 0;
-        const uint8_t *src = g->feeder->wait_ready(i, g->uploaded[i] + 1, &bytes);
-        if (!src) return fail("episode feeder: episode " + std::to_string(g->uploaded[i] + 1) + " of env " + std::to_string(i) + " was never generated");
-        HIP_TRY(hipMemcpyAsync(g->dBlobs + (size_t)i * g->blobBytes, src, bytes, hipMemcpyHostToDevice, g->copyStream));
-        ++g->uploaded[i];
-        batch.push_back(i);
+    const int N = g->N, K = g->spares;
+    const bool starved = (g->hStatus[N + 1] & ST_STARVED) != 0;
+    if (starved && g->hostEpisodes()) {   // recover: take the current counts and upload synchronously below
+        HIP_TRY(hipStreamSynchronize(g->stream));
+        HIP_TRY(hipStreamSynchronize(g->copyStream));
+        const int keep = g->hStatus[N + 1];
+        HIP_TRY(hipMemcpy(g->hStatus, g->dStatus, (size_t)(N + 2) * sizeof(int), hipMemcpyDeviceToHost));
+        g->hStatus[N + 1] |= keep;
+        g->refillForce = true;
     }
-    if (!batch.empty()) {
-        HIP_TRY(hipEventRecord(ev, g->copyStream));
-        for (int i : batch) g->feeder->recycle(i, ev);   // regenerate a slot only once its upload has left it
-        HIP_TRY(hipStreamWaitEvent(g->stream, ev, 0));
+    if (g->hostEpisodes() && (g->refillForce || g->deficit > 0 || g->hStatus[N] != g->lastTotalSeen)) {
+        hipEvent_t ev = g->uploadEvents[g->uploadRing++ % g->uploadEvents.size()];
+        HIP_TRY(hipEventSynchronize(ev));   // 64 batches ago
+        std::vector<int> &batch = g->uploadBatch;
+        batch.clear();
+        int deficit = 0;
+        bool waited = false;
+        for (int i = 0; i < N; ++i) {
+            const int consumed = g->hStatus[i];
+            if (g->uploaded[i] >= consumed + K) continue;            // ring full
+            const int need = g->uploaded[i] + 1;
+            const bool must = g->uploaded[i] == consumed;            // nothing resident: the next reset would starve
+            if (!must && !g->feeder->is_ready(i, need)) { deficit += consumed + K - g->uploaded[i]; continue; }   // later
+            size_t bytes = 0;
+            const uint8_t *src = g->feeder->wait_ready(i, need, &bytes);
+            if (!src) return fail("episode feeder: episode " + std::to_string(need) + " of env " + std::to_string(i) + " was never generated");
+            if (!waited && g->stepDoneValid) { HIP_TRY(hipStreamWaitEvent(g->copyStream, g->stepDone, 0)); waited = true; }
+            HIP_TRY(hipMemcpyAsync(g->dBlobs + ((size_t)i * K + (size_t)((need - 1) % K)) * g->blobBytes, src, bytes, hipMemcpyHostToDevice, g->copyStream));
+            ++g->uploaded[i];
+            deficit += consumed + K - g->uploaded[i];
+            batch.push_back(i);
+        }
+        if (!batch.empty()) {
+            HIP_TRY(hipEventRecord(ev, g->copyStream));
+            for (int i : batch) g->feeder->recycle(i, ev);   // regenerate a slot only once its upload has left it
+            HIP_TRY(hipStreamWaitEvent(g->stream, ev, 0));
+        }
+        g->deficit = deficit;
+        g->lastTotalSeen = g->hStatus[N];
+        g->refillForce = false;
     }
-    g->lastTotalSeen = g->hStatus[N];
-    g->refillForce = false;
-    return 0;
+    return check_status_flags(g);
 }
 
-// after a reset kernel: read the status words back without touching the step path
+// after a step / reset kernel: read the status words back without touching the step path
 static int read_back_status(mv_gym *g)
 {
     HIP_TRY(hipEventRecord(g->resetDone, g->stream));
@@ -579,7 +648,9 @@ int mv_reset(mv_gym *g)
         if (g->scenario == SCN_OBSTACLES) launch_reset_obstacles(g->gv, (const EpisodeBlob *)g->dBlobs, g->dStatus, 1, g->stream);
         else if (g->scenario == SCN_REARRANGE) launch_reset_rearrange(g->gv, (const RearrangeBlob *)g->dBlobs, g->dStatus, 1, g->stream);
         else launch_reset_collect(g->gv, (const CollectBlob *)g->dBlobs, g->dStatus, 1, g->stream);
-        if (read_back_status(g)) return -1;             // the spares for the first auto-resets go up with the next step
+        HIP_TRY(hipEventRecord(g->stepDone, g->stream));   // (the reset kernel reads the ring too)
+        g->stepDoneValid = true;
+        if (read_back_status(g)) return -1;             // the second resident episodes go up with the next steps
     } else
         launch_reset(g->gv, 1, g->stream);
     HIP_TRY(hipGetLastError());
@@ -659,12 +730,13 @@ static int step_impl(mv_gym *g, bool render)
     else launch_step(g->gv, g->stream);
     if (prof) HIP_TRY(hipEventRecord(ev[1], g->stream));
     // (every step kernel regenerates / swaps the next episode into the envs it finishes)
-    // An env needs its next resident episode only at its NEXT reset, hundreds of steps away (episodes last >= 35 s = 525
-    // ticks), so the status words are read back -- and the refill considered -- every 16th step, not every step.
-    if (g->hostEpisodes() && ++g->stepsSinceStatus >= 16) {
+    // An env needs a fresh resident episode only at its NEXT reset, normally hundreds of steps away, and two are resident: the status
+    // words are read back -- and the refill considered -- every statusPeriod-th step (16; 1 when episodes can be a few ticks long).
+    if (g->hostEpisodes()) { HIP_TRY(hipEventRecord(g->stepDone, g->stream)); g->stepDoneValid = true; }
+    if (++g->stepsSinceStatus >= g->statusPeriod) {   // (TowerBuilding regenerates finished envs in the kernel: only the error flags matter)
         if (read_back_status(g)) return -1;
         g->stepsSinceStatus = 0;
-    }   // (TowerBuilding: the step kernel regenerates finished envs itself)
+    }
     if (prof) HIP_TRY(hipEventRecord(ev[2], g->stream));
     if (render && launch_raster(g->gv, g->obs, g->w, g->h, g->stream, prof ? ev[3] : nullptr, g->fastPixels)) return fail("mv_step: observation size above 1024x1024");
     if (prof) { HIP_TRY(hipEventRecord(ev[4], g->stream)); ++g->profCount; }
@@ -860,6 +932,15 @@ struct Snap {
     uint8_t soko[32 * 32];   // Sokoban level cells (oracle only so far): always zero here
 };
 #pragma pack(pop)
+
+int mv_debug_set_agent_pos(mv_gym *g, int32_t env, int32_t agent, float x, float y, float z)
+{
+    if (check(g)) return -1;
+    if (env < 0 || env >= g->N || agent < 0 || agent >= g->A) return fail("mv_debug_set_agent_pos: index out of range");
+    hipLaunchKernelGGL(set_agent_pos_kernel, dim3(1), dim3(1), 0, g->stream, g->gv.agents, env * g->A + agent, x, y, z);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
 
 int mv_debug_snapshot_size(const mv_gym *) { return (int)sizeof(Snap); }
 

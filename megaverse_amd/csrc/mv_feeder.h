@@ -38,6 +38,9 @@ public:
     // Blocks until episode `seq` of `env` is complete in its slot; returns the slot and how many bytes of it are used.
     const uint8_t *wait_ready(int env, int seq, size_t *used_bytes);
 
+    // non-blocking: is episode `seq` of `env` complete in its slot?
+    bool is_ready(int env, int seq) const { return ready_seq_[env].load(std::memory_order_acquire) == seq; }
+
     // The slot of `env` was handed to an asynchronous copy that `copied` completes: once it has, generate seq + 1 into it.
     void recycle(int env, hipEvent_t copied);
 

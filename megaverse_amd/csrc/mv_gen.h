@@ -17,6 +17,12 @@ struct ObstacleConfig {
     float carried_object_to_exit = 0.0f;    // default of the obstaclesAgentCarriedObjectToExit shaping key
 };
 
+// Fixed capacities of the episode records (the reference has none): a generator that would exceed one drops the excess AND raises
+// a flag here; mv_step / mv_reset report it (mv_api.hip: check_status_flags).  Process-wide, cleared when reported.
+enum : int { GEN_SLABS = 1, GEN_TERRAIN = 2, GEN_OBJECTS = 4, GEN_REWARDS = 8, GEN_COORDS = 16 };
+void generator_overflow_raise(int flags);
+int generator_overflow_take();   // returns the flags raised since the last call and clears them
+
 // Advances `rng` exactly like Env::reset + ObstaclesScenario::reset + spawnAgents and fills `out`.
 void generate_obstacles_episode(std::mt19937 &rng, const ObstacleConfig &cfg, int num_agents, float base_episode_len, EpisodeBlob &out);
 

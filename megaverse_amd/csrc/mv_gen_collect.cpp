@@ -144,6 +144,7 @@ void generate_collect_episode(std::mt19937 &rng, int num_agents, float base_epis
                         for (int yy = y; yy < y_end; ++yy)
                             for (int zz = z; zz < z_end; ++zz)
                                 for (int xx = x; xx < x_end; ++xx) taken[id(xx, yy, zz)] = 1;
+                        if (out.num_boxes >= COLLECT_MAX_BOXES) generator_overflow_raise(GEN_SLABS);
                         if (out.num_boxes < COLLECT_MAX_BOXES) {
                             LayoutBox &b = out.boxes[out.num_boxes++];
                             b.min[0] = x; b.min[1] = y; b.min[2] = z; b.max[0] = x_end; b.max[1] = y_end; b.max[2] = z_end;
@@ -180,6 +181,7 @@ void generate_collect_episode(std::mt19937 &rng, int num_agents, float base_epis
     const int objects_min = std::max(3, int(nx * nz * 0.04));
     const int objects_max = std::min(objects_min + 1, int(std::lround(0.07 * nz * nx)) + 2);
     const int num_objects = std::min(rand_range(objects_min, objects_max, rng), int(cells.size() - next));
+    if (num_objects > MAX_OBJECTS) generator_overflow_raise(GEN_OBJECTS);
     if (next + num_objects < cells.size())   // always true for <= 8 agents (see oracle note on :153-156)
         for (int i = 0; i < num_objects && i < MAX_OBJECTS; ++i, ++next)
             out.objects[out.num_objects++] = MovableObject{int8_t(cells[next].x), int8_t(cells[next].y), int8_t(cells[next].z), 0};
@@ -190,6 +192,7 @@ void generate_collect_episode(std::mt19937 &rng, int num_agents, float base_epis
     for (size_t i = 0; i < reward_cells.size(); ++i) {   // 70 % of the diamonds are worth +1 (:198)
         const bool good = frand01(rng) > 0.3f;
         if (good) ++out.num_positive;
+        if (int(i) >= COLLECT_MAX_REWARDS) generator_overflow_raise(GEN_REWARDS);
         if (int(i) < COLLECT_MAX_REWARDS)
             out.rewards[out.num_rewards++] = MovableObject{int8_t(reward_cells[i].x), int8_t(reward_cells[i].y), int8_t(reward_cells[i].z), int8_t(good ? 1 : 2)};
     }

@@ -26,7 +26,15 @@
 
 #include "mv_gen.h"
 
+#include <atomic>
+
 namespace mv {
+
+static std::atomic<int> g_generator_overflow{0};
+void generator_overflow_raise(int flags) { g_generator_overflow.fetch_or(flags, std::memory_order_relaxed); }
+int generator_overflow_take() { return g_generator_overflow.exchange(0, std::memory_order_relaxed); }
+static inline bool fits_i8(int v) { return v >= -128 && v <= 127; }
+
 
 namespace {
 
@@ -359,6 +367,7 @@ void generate_obstacles_episode(std::mt19937 &rng, const ObstacleConfig &cfg, in
                         for (int yy = y; yy <= y1; ++yy)
                             for (int zz = z; zz <= z1; ++zz)
                                 for (int xx = x; xx <= x1; ++xx) used[idx(xx, yy, zz)] = 1;
+                        if (nb >= MAX_BOXES) generator_overflow_raise(GEN_SLABS);
                         if (nb < MAX_BOXES) {
                             LayoutBox &b = out.boxes[nb++];
                             b.min[0] = x + lo.x; b.min[1] = y + lo.y; b.min[2] = z + lo.z;
@@ -374,7 +383,8 @@ void generate_obstacles_episode(std::mt19937 &rng, const ObstacleConfig &cfg, in
     for (const auto &p : chain)
         for (int type : {int(TERRAIN_EXIT), int(TERRAIN_LAVA)})
             for (const auto &t : p.terrain)
-                if (t.first == type && out.num_terrain < MAX_TERRAIN) {
+                if (t.first == type && out.num_terrain >= MAX_TERRAIN) generator_overflow_raise(GEN_TERRAIN);
+                else if (t.first == type) {
                     const Aabb b = placed(p.root, t.second);
                     TerrainBox &o = out.terrain[out.num_terrain++];
                     o.min[0] = b.lo.x; o.min[1] = b.lo.y; o.min[2] = b.lo.z; o.max[0] = b.hi.x; o.max[1] = b.hi.y; o.max[2] = b.hi.z;
@@ -412,14 +422,19 @@ void generate_obstacles_episode(std::mt19937 &rng, const ObstacleConfig &cfg, in
         const float fraction = frand01(rng) * 0.5f;
         const int extra = int(std::lround(fraction * float(share[i]))) + rand_range(0, 2, rng);
         for (const Int3 &c : chain[i].scatter(share[i] + extra, rng)) {
+            if (out.num_objects >= MAX_OBJECTS) generator_overflow_raise(GEN_OBJECTS);
+            if (!fits_i8(c.x) || !fits_i8(c.y) || !fits_i8(c.z)) generator_overflow_raise(GEN_COORDS);
             if (out.num_objects < MAX_OBJECTS) out.objects[out.num_objects++] = MovableObject{(int8_t)c.x, (int8_t)c.y, (int8_t)c.z, 0};
             ++total_objects;
         }
     }
     for (int i = 1; i < int(chain.size()) - 1; ++i) {
         const int n = rand_range(0, 2, rng);
-        for (const Int3 &c : chain[i].scatter(n, rng))
+        for (const Int3 &c : chain[i].scatter(n, rng)) {
+            if (out.num_rewards >= MAX_REWARDS) generator_overflow_raise(GEN_REWARDS);
+            if (!fits_i8(c.x) || !fits_i8(c.y) || !fits_i8(c.z)) generator_overflow_raise(GEN_COORDS);
             if (out.num_rewards < MAX_REWARDS) out.rewards[out.num_rewards++] = MovableObject{(int8_t)c.x, (int8_t)c.y, (int8_t)c.z, 1};
+        }
     }
     out.episode_len = std::max(base_episode_len, float(num_platforms) * 35 + float(total_objects) * 1);
 

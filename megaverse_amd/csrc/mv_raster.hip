@@ -553,7 +553,8 @@ __global__ __launch_bounds__(256) void frame_setup_kernel(GymView gv, int W, int
         }
         nVis += tot;
         pos += __popcll(mV & ((1ull << lane) - 1ull));
-        if (cls != 0 && pos < maxVis) {   // more than vis_stride visible primitives: the excess is dropped (never seen in practice)
+        if (cls != 0 && pos >= maxVis) atomicOr(&gv.episode_status[gv.num_envs + 1], (int)ST_VISIBLE);   // dropped -- and reported by mv_step
+        if (cls != 0 && pos < maxVis) {   // at most vis_stride visible primitives per frame
             Prim p;
             p.meta = (uint32_t)(kind | (fr << 4) | (slot << 8));
             p.color = color;

@@ -235,6 +235,8 @@ __global__ __launch_bounds__(64) void step_kernel(GymView gv)
                 const unsigned long long colObj = column_objects(ob, vx[0], vx[2]);   // wave op, outside the loop
                 auto has_obj = [&](int y) { return in_chunk(vx[0], y, vx[2]) && ((colObj >> (y + 32)) & 1ull); };
                 const bool empty = !(vox(vx[0], vx[1], vx[2]) & VX_SOLID) && !has_obj(vx[1]);
+                // the reference's grid is unbounded; a placement this build's 32 x 16 x 32 chunk cannot hold is refused AND reported
+                if (!placeable && !collidesWithAgent && in_zone(h, vx[0], vx[2]) && lane == 0) atomicOr(&gv.episode_status[gv.num_envs + 1], (int)ST_CHUNK);
                 if (placeable && empty && !collidesWithAgent && in_zone(h, vx[0], vx[2])) {
                     for (;;) {
                         const int by = vx[1] - 1;

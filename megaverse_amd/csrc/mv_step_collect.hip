@@ -73,10 +73,10 @@ __device__ __forceinline__ void swap_in_episode(const GymView &gv, const Collect
 {
     const int lane = lane_id();
     EnvHeader *gh = gv.hdr + env;
-    const CollectBlob *b = blobs + env;
     const int consumed = gh->episodes_consumed;
+    const CollectBlob *b = blobs + (size_t)env * gv.spares + consumed % gv.spares;   // ring slot of episode number consumed + 1
     if (b->seq != consumed + 1) {   // the host has not delivered the next episode: must never happen (mv_api.hip keeps one ahead)
-        if (lane == 0) { gh->starved |= 1; atomicOr(&status[gv.num_envs + 1], 1); }
+        if (lane == 0) { gh->starved |= 1; atomicOr(&status[gv.num_envs + 1], (int)ST_STARVED); }
         return;
     }
     const int A = gv.num_agents;
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(64) void step_collect_kernel(GymView gv)
                 if (keep && pos < MAX_CAND) { Col c; c.kind = 2; c.lo = centre; c.hi = v3(2 * CAP_HH, 0.0f, 0.0f); s_cand[pos] = c; }
                 count += __popcll(m);
             }
-            if (count > MAX_CAND) { starved |= 2; if (lane == 0) atomicOr(&gv.episode_status[gv.num_envs + 1], 2); }
+            if (count > MAX_CAND) { starved |= 2; if (lane == 0) atomicOr(&gv.episode_status[gv.num_envs + 1], (int)ST_CANDIDATES); }
             __syncthreads();
             Col col[NC];
 #pragma unroll

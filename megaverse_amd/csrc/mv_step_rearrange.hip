@@ -48,10 +48,10 @@ __device__ __forceinline__ void swap_in_episode(const GymView &gv, const Rearran
 {
     const int lane = lane_id();
     EnvHeader *gh = gv.hdr + env;
-    const RearrangeBlob *b = blobs + env;
     const int consumed = gh->episodes_consumed;
+    const RearrangeBlob *b = blobs + (size_t)env * gv.spares + consumed % gv.spares;   // ring slot of episode number consumed + 1
     if (b->seq != consumed + 1) {   // the host has not delivered the next episode: must never happen (mv_api.hip keeps one ahead)
-        if (lane == 0) { gh->starved |= 1; atomicOr(&status[gv.num_envs + 1], 1); }
+        if (lane == 0) { gh->starved |= 1; atomicOr(&status[gv.num_envs + 1], (int)ST_STARVED); }
         return;
     }
     const int A = gv.num_agents;

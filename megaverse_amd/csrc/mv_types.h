@@ -20,6 +20,9 @@ enum : int {
 
 enum : int { FRAME_HDR_BYTES = 1024 };   // per-frame header of the observation pass (mv_raster.hip: FH_*)
 
+// error flags a kernel raises in episode_status[N + 1]; mv_step reports them (mv_api.hip: check_status_flags)
+enum : int { ST_STARVED = 1, ST_CANDIDATES = 2, ST_VISIBLE = 4, ST_CHUNK = 8 };
+
 enum : int { SCN_TOWER = 0, SCN_OBSTACLES = 1, SCN_COLLECT = 2, SCN_REARRANGE = 3, SCN_SOKOBAN = 4 };
 enum : int { SOKO_DIM = 32, SOKO_WALL = 1, SOKO_GOAL = 2 };                            // Sokoban level cells (scenario_sokoban.cpp:28-33)
 enum : int { MAX_ITEMS = 8, NUM_STATIC = 9 };                                         // Rearrange: arrangement items, static colliding boxes
@@ -107,8 +110,10 @@ struct GymView {
     MovableObject *rewards_obj;// [N][reward_stride] (Obstacles: green diamonds; Collect: green/red diamonds)
     int8_t *heightmap;         // [N][HM_BYTES]      (Collect: top solid y of column x * HM_DIM + z, -1 = no voxels)
     ArrangementItem *items;    // [N][MAX_ITEMS]     (Rearrange: the target arrangement; hdr.num_terrain holds the item count)
-    int32_t *episode_status;   // [N + 2] host-generated scenarios: episodes consumed per env, their total, error flags
-    const void *blobs;         // [N] resident next episodes (EpisodeBlob / CollectBlob / RearrangeBlob)
+    int32_t *episode_status;   // [N + 2] episodes consumed per env (host-generated scenarios), their total, error flags (ST_*)
+    const void *blobs;         // [N][spares] resident next episodes (EpisodeBlob / CollectBlob / RearrangeBlob / SokobanBlob): episode
+                               // number q (1-based) of an env lives in ring slot (q - 1) % spares
+    int32_t spares;            // resident episodes per env (2: a second reset can follow the first before the host has refilled)
     int32_t *actions;          // [N][A] bitmasks
     float *rewards;            // [N*A] as reported by get_last_rewards (0 on done steps)
     uint8_t *done;             // [N]

@@ -51,6 +51,7 @@ SYMBOLS = [
     ("mv_set_reward_shaping", C.c_int, [_P, _I, _I, C.c_char_p, _F]),
     ("mv_synchronize", C.c_int, [_P]),
     ("mv_profile_begin", C.c_int, [_P, _I]), ("mv_profile_end", C.c_int, [_P, _P, _P]),
+    ("mv_debug_set_agent_pos", C.c_int, [_P, _I, _I, _F, _F, _F]),
     ("mv_debug_snapshot_size", C.c_int, [_P]), ("mv_debug_snapshot", C.c_int, [_P, _I, _P]),
     ("mv_debug_rng", C.c_int, [_I, _U, _I, _P, _P, _I, _P]),
     ("mv_debug_math", C.c_int, [_I, _I, _P, _P, _I, _P]),
@@ -274,6 +275,9 @@ class MegaverseGym:
         cnt = (C.c_int32 * 4)()
         self._ck(self._lib.mv_profile_end(self._g, ms, cnt))
         return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(("step", "reset", "setup", "raster"))}
+
+    def debug_set_agent_pos(self, env_idx, agent_idx, x, y, z):
+        self._ck(self._lib.mv_debug_set_agent_pos(self._g, int(env_idx), int(agent_idx), float(x), float(y), float(z)))
 
     def debug_snapshot_bytes(self, env_idx):
         n = self._lib.mv_debug_snapshot_size(self._g)

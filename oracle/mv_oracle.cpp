@@ -2578,6 +2578,9 @@ struct SnapHeader {
 };
 #pragma pack(pop)
 
+/* test hook: put an agent somewhere (e.g. below the fall-detection threshold, component_fall_detection.hpp:33-55) */
+void mvo_debug_set_agent_pos(mvo_gym *g, int env, int agent, float x, float y, float z) { g->envs[env]->agents[agent].pos = v3(x, y, z); }
+
 int mvo_snapshot_size(mvo_gym *) { return (int)sizeof(SnapHeader); }
 
 void mvo_snapshot(mvo_gym *g, int env, void *out)

@@ -61,6 +61,7 @@ void mvo_set_reward_shaping(mvo_gym *g, int env_idx, int agent_idx, const char *
 
 /* Packed state snapshot, layout documented in DESIGN.md ("snapshot format");
  * identical to what mv_debug_snapshot() of the HIP library writes. */
+void mvo_debug_set_agent_pos(mvo_gym *g, int env_idx, int agent_idx, float x, float y, float z); /* test hook: teleport */
 int mvo_snapshot_size(mvo_gym *g);
 void mvo_snapshot(mvo_gym *g, int env_idx, void *out);
 

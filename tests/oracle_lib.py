@@ -61,6 +61,7 @@ def lib():
         L.mvo_get_reward_shaping.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_int)]
         L.mvo_get_reward_shaping.restype = C.c_float
         L.mvo_set_reward_shaping.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_float]
+        L.mvo_debug_set_agent_pos.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float]
         L.mvo_snapshot_size.argtypes = [C.c_void_p]
         L.mvo_snapshot.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.mvo_mt19937_nth.argtypes = [C.c_uint32, C.c_int]
@@ -148,6 +149,8 @@ class OracleGym:
     def set_reward_shaping(self, env_idx, agent_idx, rs):
         for k, v in rs.items():
             self.L.mvo_set_reward_shaping(self.g, env_idx, agent_idx, k.encode(), float(v))
+
+    def debug_set_agent_pos(self, env_idx, agent_idx, x, y, z): self.L.mvo_debug_set_agent_pos(self.g, env_idx, agent_idx, x, y, z)
 
     def snapshot(self, env_idx):
         assert self.L.mvo_snapshot_size(self.g) == SNAP.itemsize, (self.L.mvo_snapshot_size(self.g), SNAP.itemsize)

@@ -1,0 +1,129 @@
+"""Episode refill protocol and capacity limits under stress (sub-16-tick episodes, recoverable starvation), the
+TowerBuilding fall-detection branch, and mv_close / coexistence.  HIP path vs the oracle, bit for bit (exact pixel mode)."""
+import os
+
+import numpy as np
+import pytest
+
+from hip_util import diff_snapshots, hip_snapshot, make_pair, set_same_actions
+from megaverse_amd.extension import MegaverseGym
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
+
+
+def rollout_with_resets(scenario, N, A, params, steps, seed, min_done):
+    og, hg = make_pair(N, A, 32, 32, seed=seed, params=params, scenario=scenario)
+    ndone = 0
+    for st in range(steps):
+        set_same_actions(og, hg, N, A, 77, st)
+        og.step(); hg.step()
+        do = np.array([og.is_done(e) for e in range(N)])
+        assert np.array_equal(do, hg.get_dones().astype(bool)), st
+        ndone += int(do.sum())
+        assert np.array_equal(og.get_last_rewards().view(np.uint32), hg.get_rewards_array().view(np.uint32)), st
+        for e in np.nonzero(do)[0]:
+            for a in range(A):
+                assert og.true_objective(int(e), a) == hg.true_objective(int(e), a)
+        if st % 20 == 0 or st == steps - 1:
+            for e in range(N):
+                d = diff_snapshots(og.snapshot(e), hip_snapshot(hg, e), A)
+                assert not d, (st, e, d[:5])
+            for e in range(0, N, 3):
+                assert np.array_equal(og.get_observation(e, 0), hg.get_observation(e, 0)), (st, e)
+    assert ndone >= min_done, ndone
+    og.close(); hg.close()
+
+
+def test_short_episodes_rearrange():
+    # episodes of 3 ticks: every env resets every third step, the status words are read back after every step
+    rollout_with_resets("Rearrange", 10, 2, {"episodeLengthSec": 0.19}, 150, seed=5, min_done=400)
+
+
+@pytest.mark.parametrize("base,steps,min_done", [(-24.0, 160, 15), (-500.0, 100, 900)])
+def test_short_episodes_collect(base, steps, min_done):
+    # episode length = base + 2 * diamonds: base -24 mixes episodes of a few ticks with longer ones; base -500 ends every episode on
+    # its first tick (every env consumes a generated landscape per step)
+    rollout_with_resets("Collect", 10, 2, {"episodeLengthSec": base}, steps, seed=6, min_done=min_done)
+
+
+def test_back_to_back_resets_obstacles():
+    # the Obstacles family cannot time out early (35 s per platform); consecutive forced resets + a mid-run re-seed drain the ring instead
+    N, A = 8, 2
+    og, hg = make_pair(N, A, 32, 32, seed=9, scenario="ObstaclesMedium")
+    for rd in range(5):
+        for st in range(3):
+            set_same_actions(og, hg, N, A, 3, 10 * rd + st)
+            og.step(); hg.step()
+        og.reset(); hg.reset()
+        if rd == 2:
+            og.seed(1234); hg.seed(1234)
+            og.reset(); hg.reset()
+        for e in range(N):
+            assert not diff_snapshots(og.snapshot(e), hip_snapshot(hg, e), A), (rd, e)
+    og.close(); hg.close()
+
+
+def test_starvation_is_reported_once_and_recovered(monkeypatch):
+    """Forced: 3-tick episodes with the status read back only every 16th step.  The reference would reset inline; here the first
+    mv_step that sees the flag raises once, uploads synchronously, and the gym keeps working (it used to be dead for good)."""
+    monkeypatch.setenv("MV_STATUS_PERIOD", "16")
+    g = MegaverseGym("Rearrange", 32, 32, 6, 1, 1, False, {"episodeLengthSec": 0.19})
+    g.seed(3); g.reset()
+    errors = 0
+    for st in range(200):
+        g.sample_random_actions(1, st)
+        try:
+            g.step()
+        except RuntimeError as e:
+            assert "capacity limit hit" in str(e) and "repeated its done step" in str(e)
+            errors += 1
+    assert 1 <= errors < 60, errors
+    monkeypatch.delenv("MV_STATUS_PERIOD")
+    g.close()
+    g2 = MegaverseGym("Rearrange", 32, 32, 6, 1, 1, False, {"episodeLengthSec": 0.19})   # default period: no starvation at all
+    g2.seed(3); g2.reset()
+    for st in range(200):
+        g2.sample_random_actions(1, st); g2.step()
+    assert g2.get_dones().shape == (6,)
+    g2.close()
+
+
+@pytest.mark.parametrize("A", [1, 3])
+def test_tower_fall_detection_branch(A):
+    """A walled TowerBuilding room cannot be left, so the FallDetectionComponent branch (component_fall_detection.hpp:33-55) is driven by
+    a teleport below y = -20: the agent must reappear above its spawn cell with zero velocities, on both sides identically."""
+    N = 4
+    og, hg = make_pair(N, A, 32, 32, seed=21)
+    for st in range(10):
+        set_same_actions(og, hg, N, A, 8, st); og.step_norender(); hg.step_no_render()
+    for e in range(N):
+        s = og.snapshot(e)
+        p = s["agents"][A - 1]["pos"]
+        for g in (og, hg):
+            g.debug_set_agent_pos(e, A - 1, float(p[0]), -25.0 - e, float(p[2]))
+    set_same_actions(og, hg, N, A, 8, 10); og.step_norender(); hg.step_no_render()
+    for e in range(N):
+        so, sh = og.snapshot(e), hip_snapshot(hg, e)
+        assert not diff_snapshots(so, sh, A), e
+        a = sh["agents"][A - 1]
+        assert a["pos"][1] > 1.0 and abs(a["pos"][0] - (a["spawn"][0] + 0.5)) < 1.0, a["pos"]   # back above the spawn cell
+    for st in range(11, 60):
+        set_same_actions(og, hg, N, A, 8, st); og.step_norender(); hg.step_no_render()
+    for e in range(N):
+        assert not diff_snapshots(og.snapshot(e), hip_snapshot(hg, e), A)
+    og.close(); hg.close()
+
+
+def test_close_with_work_in_flight_and_two_gyms():
+    # mv_close while uploads / read-backs / kernels are still queued, and two gyms alive at once (megaverse/tests/test_env.py:32-40)
+    a = MegaverseGym("Collect", 64, 64, 32, 1, 4, False, {})
+    b = MegaverseGym("ObstaclesHard", 64, 64, 32, 1, 4, False, {})
+    a.seed(1); b.seed(2); a.reset(); b.reset()
+    for st in range(40):
+        a.sample_random_actions(5, st); b.sample_random_actions(6, st)
+        a.step(); b.step()
+    a.close()
+    for st in range(40, 60):
+        b.sample_random_actions(6, st); b.step()
+    assert b.get_dones().shape == (32,)
+    b.close(); b.close()
