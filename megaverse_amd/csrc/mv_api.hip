@@ -27,12 +27,14 @@
 
 namespace mv {
 void launch_reset(const GymView &gv, int force_all, hipStream_t stream);
-void launch_step(const GymView &gv, hipStream_t stream);
-void launch_step_obstacles(const GymView &gv, hipStream_t stream);
+// step kernels: one 256-thread workgroup per env = the tick (wave 0) + the frame setup of the env's frames for a W x H observation
+// (render = 0: tick only)
+void launch_step(const GymView &gv, hipStream_t stream, int W, int H, int render);
+void launch_step_obstacles(const GymView &gv, hipStream_t stream, int W, int H, int render);
 void launch_reset_obstacles(const GymView &gv, const EpisodeBlob *blobs, int *status, int force_all, hipStream_t stream);
-void launch_step_rearrange(const GymView &gv, hipStream_t stream);
+void launch_step_rearrange(const GymView &gv, hipStream_t stream, int W, int H, int render);
 void launch_reset_rearrange(const GymView &gv, const RearrangeBlob *blobs, int *status, int force_all, hipStream_t stream);
-void launch_step_collect(const GymView &gv, hipStream_t stream);
+void launch_step_collect(const GymView &gv, hipStream_t stream, int W, int H, int render);
 void launch_reset_collect(const GymView &gv, const CollectBlob *blobs, int *status, int force_all, hipStream_t stream);
 }  // namespace mv
 
@@ -407,6 +409,11 @@ int mv_create(const mv_config *cfg, mv_gym **out)
                                                      : (k == 4 ? oc.carried_object_to_exit : SHAPING_DEFAULT_OBST[k]);
         ha[i].carrying = -1; ha[i].jump_speed = 10.0f; ha[i].m00 = 1.0f; ha[i].m22 = 1.0f;
     }
+    {
+        std::vector<int32_t> iota(NA);
+        for (size_t i = 0; i < NA; ++i) iota[i] = (int32_t)i;
+        (void)hipMemcpy(gv.lpt_order, iota.data(), NA * sizeof(int32_t), hipMemcpyHostToDevice);   // identity until the first frame sort
+    }
     if (hipMemcpy(gv.hdr, hh.data(), N * sizeof(EnvHeader), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(gv.agents, ha.data(), NA * sizeof(AgentState), hipMemcpyHostToDevice) != hipSuccess) {
         mv_destroy(g);
@@ -724,10 +731,11 @@ static int step_impl(mv_gym *g, bool render)
     const bool prof = render && g->profCount < g->profMax;
     hipEvent_t *ev = prof ? &g->profEvents[(size_t)g->profCount * 5] : nullptr;
     if (prof) HIP_TRY(hipEventRecord(ev[0], g->stream));
-    if (g->scenario == SCN_OBSTACLES) launch_step_obstacles(g->gv, g->stream);
-    else if (g->scenario == SCN_COLLECT) launch_step_collect(g->gv, g->stream);
-    else if (g->scenario == SCN_REARRANGE) launch_step_rearrange(g->gv, g->stream);
-    else launch_step(g->gv, g->stream);
+    const int fused = render ? 1 : 0;   // the step kernel also builds the frame lists when an observation pass follows
+    if (g->scenario == SCN_OBSTACLES) launch_step_obstacles(g->gv, g->stream, g->w, g->h, fused);
+    else if (g->scenario == SCN_COLLECT) launch_step_collect(g->gv, g->stream, g->w, g->h, fused);
+    else if (g->scenario == SCN_REARRANGE) launch_step_rearrange(g->gv, g->stream, g->w, g->h, fused);
+    else launch_step(g->gv, g->stream, g->w, g->h, fused);
     if (prof) HIP_TRY(hipEventRecord(ev[1], g->stream));
     // (every step kernel regenerates / swaps the next episode into the envs it finishes)
     // An env needs a fresh resident episode only at its NEXT reset, normally hundreds of steps away, and two are resident: the status
@@ -738,7 +746,7 @@ static int step_impl(mv_gym *g, bool render)
         g->stepsSinceStatus = 0;
     }
     if (prof) HIP_TRY(hipEventRecord(ev[2], g->stream));
-    if (render && launch_raster(g->gv, g->obs, g->w, g->h, g->stream, prof ? ev[3] : nullptr, g->fastPixels)) return fail("mv_step: observation size above 1024x1024");
+    if (render && launch_raster(g->gv, g->obs, g->w, g->h, g->stream, prof ? ev[3] : nullptr, g->fastPixels, /*setup_done=*/1)) return fail("mv_step: observation size above 1024x1024");
     if (prof) { HIP_TRY(hipEventRecord(ev[4], g->stream)); ++g->profCount; }
     HIP_TRY(hipGetLastError());
     g->mirrorsFresh = false;

@@ -70,6 +70,16 @@ __device__ __forceinline__ T *vector_path(T *p)
 }
 
 // ---- wave64 helpers ------------------------------------------------------------------------
+// Ordering point for LDS / global traffic ONE wavefront exchanges between its own lanes: what __syncthreads() is to a one-wave
+// workgroup minus the s_barrier, so that the tick code (one wave per env) can run as wave 0 of a larger workgroup whose other waves
+// are parked at a real barrier (fused step + frame setup kernels).  A wave's LDS operations execute in order.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 __device__ __forceinline__ float bcast_f(float v, int src_lane) { return __shfl(v, src_lane, 64); }

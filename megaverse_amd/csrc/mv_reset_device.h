@@ -38,7 +38,7 @@ __device__ __forceinline__ float building_reward_coeff(int h)
 }
 
 // Regenerates env `env` (the caller has decided that it must be: done, or a forced reset).  Called by all 64 lanes of the
-// env's wavefront, which must be the whole workgroup (the function uses __syncthreads()).
+// env's wavefront, which must be the whole workgroup (the function orders its LDS traffic with wave_sync()).
 __device__ __forceinline__ void reset_env(const GymView &gv, int env, int force_all)
 {
     const int lane = lane_id();
@@ -80,7 +80,7 @@ __device__ __forceinline__ void reset_env(const GymView &gv, int env, int force_
         const int x = 1 + i / nz, z = 1 + i % nz;
         s_cand[i] = (uint16_t)((x << 8) | z);
     }
-    __syncthreads();
+    wave_sync();
     shuffle_u16(g, s_cand, ncand);
 
     const int nSpawn = min(A, ncand);
@@ -133,12 +133,12 @@ __device__ __forceinline__ void reset_env(const GymView &gv, int env, int force_
         }
         *reinterpret_cast<uint4 *>(s_chunk + grp * 16) = make_uint4(w[0], w[1], w[2], w[3]);
     }
-    __syncthreads();
+    wave_sync();
     for (int i = lane; i < numObjects; i += 64) {
         const MovableObject o = s_obj[i];
         s_chunk[(o.y * CZ + o.z) * CX + o.x] |= VX_OBJECT;   // distinct cells, byte-wide LDS RMW
     }
-    __syncthreads();
+    wave_sync();
 
     // ---- write-out: chunk (coalesced 16 B / lane), objects, boxes, header, agents
     uint4 *gchunk = reinterpret_cast<uint4 *>(gv.chunk + (size_t)env * CHUNK_BYTES);

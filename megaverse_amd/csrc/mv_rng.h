@@ -16,7 +16,7 @@
 //
 // Execution model: every lane of the wave runs the same scalar code on the same values ("uniform
 // execution"); LDS reads are broadcasts, LDS writes are done by lane 0 only.  The block is exactly
-// one wave, so __syncthreads() is a cheap ordering point.
+// one wave, so wave_sync() (mv_math.h) is the ordering point.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -38,7 +38,7 @@ __device__ __forceinline__ void mt_seed(Mt19937 &g, uint32_t seed)
         if (lane == 0) g.mt[i] = x;
     }
     g.idx = 624;
-    __syncthreads();
+    wave_sync();
 }
 
 __device__ __forceinline__ uint32_t mt_mix(uint32_t a, uint32_t b, uint32_t m)
@@ -53,9 +53,9 @@ __device__ __forceinline__ void mt_twist_range(uint32_t *mt, int k0, int k1, int
         const int k = base + lane;
         uint32_t v = 0;
         if (k < k1) v = mt_mix(mt[k], mt[k + 1], mt[k < 227 ? k + 397 : k - 227]);
-        __syncthreads();
+        wave_sync();
         if (k < k1) mt[k] = v;
-        __syncthreads();
+        wave_sync();
     }
 }
 
@@ -66,9 +66,9 @@ __device__ __forceinline__ void mt_twist(Mt19937 &g)
     mt_twist_range(g.mt, 227, 454, lane);   // needs new [0..226]
     mt_twist_range(g.mt, 454, 623, lane);   // needs new [227..395]
     const uint32_t v = mt_mix(g.mt[623], g.mt[0], g.mt[396]);
-    __syncthreads();
+    wave_sync();
     if (lane == 0) g.mt[623] = v;
-    __syncthreads();
+    wave_sync();
     g.idx = 0;
 }
 
@@ -118,9 +118,9 @@ __device__ __forceinline__ void shuffle_u16(Mt19937 &g, uint16_t *a, int n)
     const int lane = (int)(threadIdx.x & 63);
     auto swap_items = [&](int i, int j) {
         const uint16_t vi = a[i], vj = a[j];
-        __syncthreads();
+        wave_sync();
         if (lane == 0) { a[i] = vj; a[j] = vi; }
-        __syncthreads();
+        wave_sync();
     };
     // n*n <= 2^32-1 for every n this simulator uses (n <= 65535), i.e. the paired path
     int i = 1;

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include "mv_actions.h"
+#include "mv_frame.h"
 #include "mv_math.h"
 #include "mv_physics.h"
 #include "mv_reset_device.h"
@@ -122,9 +123,8 @@ __device__ __forceinline__ bool in_chunk(int x, int y, int z) { return x >= 0 &&
 }  // namespace
 
 template <int A_MAX>
-__global__ __launch_bounds__(64) void step_kernel(GymView gv)
+__device__ __forceinline__ void tower_tick(const GymView &gv, const int env)
 {
-    const int env = blockIdx.x;
     const int lane = lane_id();
     if (env >= gv.num_envs) return;
     const int A = gv.num_agents;
@@ -352,18 +352,33 @@ __global__ __launch_bounds__(64) void step_kernel(GymView gv)
     // env in two thousand finishes per tick and its wave is not the slowest of the launch even with the generator on top, so
     // this costs nothing, where a separate "reset whoever is done" launch cost 4-7 us per step.
     if (h.done) {
-        __syncthreads();   // one wave per workgroup: orders the stores above before the generator's
+        wave_sync();   // one wave per env: orders the stores above before the generator's
         reset_env(gv, env, 0);
     }
 }
 
-void launch_step(const GymView &gv, hipStream_t stream)
+// One workgroup of STEP_THREADS per env: wave 0 runs the tick (one wave per env: physics, scenario logic, auto-reset), the others wait at
+// the barrier; then all of them build the lists of the env's frames (mv_frame.h).  `render` = 0: mv_step_no_render.  The tick needs
+// ~150 VGPRs, i.e. 3 waves per SIMD: with 2 waves per env 1024 envs are resident at once (with 4 they would take two rounds, and a
+// launch lasts as long as its slowest tick PER ROUND: measured 41 us vs 25 us).
+template <int A_MAX>
+__global__ __launch_bounds__(STEP_THREADS) void step_kernel(GymView gv, int W, int H, int render)
 {
-    const dim3 grid(gv.num_envs), block(64);
-    if (gv.num_agents == 1) hipLaunchKernelGGL(step_kernel<1>, grid, block, 0, stream, gv);
-    else if (gv.num_agents == 2) hipLaunchKernelGGL(step_kernel<2>, grid, block, 0, stream, gv);
-    else if (gv.num_agents <= 4) hipLaunchKernelGGL(step_kernel<4>, grid, block, 0, stream, gv);
-    else hipLaunchKernelGGL(step_kernel<8>, grid, block, 0, stream, gv);
+    const int env = blockIdx.x;
+    if (threadIdx.x < 64) tower_tick<A_MAX>(gv, env);
+    if (!render) return;
+    __syncthreads();   // the tick's stores (same CU: same L1) before the frame setup's loads
+    const int A = gv.num_agents;
+    for (int a = 0; a < A; ++a) frame_setup_body<STEP_THREADS>(gv, env * A + a, W, H);
+}
+
+void launch_step(const GymView &gv, hipStream_t stream, int W, int H, int render)
+{
+    const dim3 grid(gv.num_envs), block(STEP_THREADS);
+    if (gv.num_agents == 1) hipLaunchKernelGGL(step_kernel<1>, grid, block, 0, stream, gv, W, H, render);
+    else if (gv.num_agents == 2) hipLaunchKernelGGL(step_kernel<2>, grid, block, 0, stream, gv, W, H, render);
+    else if (gv.num_agents <= 4) hipLaunchKernelGGL(step_kernel<4>, grid, block, 0, stream, gv, W, H, render);
+    else hipLaunchKernelGGL(step_kernel<8>, grid, block, 0, stream, gv, W, H, render);
 }
 
 }  // namespace mv

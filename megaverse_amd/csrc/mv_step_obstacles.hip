@@ -18,6 +18,7 @@
 
 #include "mv_boxlist.h"
 #include "mv_actions.h"
+#include "mv_frame.h"
 #include "mv_math.h"
 #include "mv_physics.h"
 #include "mv_types.h"
@@ -103,9 +104,8 @@ __device__ __forceinline__ void swap_in_episode(const GymView &gv, const Episode
 }
 
 template <int A_MAX>
-__global__ __launch_bounds__(64) void step_obstacles_kernel(GymView gv)
+__device__ __forceinline__ void obstacles_tick(const GymView &gv, const int env)
 {
-    const int env = blockIdx.x;
     const int lane = lane_id();
     if (env >= gv.num_envs) return;
     const int A = gv.num_agents;
@@ -346,9 +346,24 @@ __global__ __launch_bounds__(64) void step_obstacles_kernel(GymView gv)
 
     // ---- the auto-reset of VectorEnv::step: the wave of a finished env swaps the next episode in right here
     if (done) {
-        __syncthreads();   // one wave per workgroup: orders the stores above before the swap-in's
+        wave_sync();   // one wave per env: orders the stores above before the swap-in's
         swap_in_episode(gv, static_cast<const EpisodeBlob *>(gv.blobs), gv.episode_status, env, 0);
     }
+}
+
+// One workgroup of STEP_THREADS per env: wave 0 runs the tick (one wave per env: physics, scenario logic, auto-reset), the others wait at
+// the barrier; then all of them build the lists of the env's frames (mv_frame.h).  `render` = 0: mv_step_no_render.  The tick needs
+// ~150 VGPRs, i.e. 3 waves per SIMD: with 2 waves per env 1024 envs are resident at once (with 4 they would take two rounds, and a
+// launch lasts as long as its slowest tick PER ROUND: measured 41 us vs 25 us).
+template <int A_MAX>
+__global__ __launch_bounds__(STEP_THREADS) void step_obstacles_kernel(GymView gv, int W, int H, int render)
+{
+    const int env = blockIdx.x;
+    if (threadIdx.x < 64) obstacles_tick<A_MAX>(gv, env);
+    if (!render) return;
+    __syncthreads();   // the tick's stores (same CU: same L1) before the frame setup's loads
+    const int A = gv.num_agents;
+    for (int a = 0; a < A; ++a) frame_setup_body<STEP_THREADS>(gv, env * A + a, W, H);
 }
 
 __global__ __launch_bounds__(64) void reset_obstacles_kernel(GymView gv, const EpisodeBlob *blobs, int *status, int force_all)
@@ -359,13 +374,13 @@ __global__ __launch_bounds__(64) void reset_obstacles_kernel(GymView gv, const E
     swap_in_episode(gv, blobs, status, env, force_all);
 }
 
-void launch_step_obstacles(const GymView &gv, hipStream_t stream)
+void launch_step_obstacles(const GymView &gv, hipStream_t stream, int W, int H, int render)
 {
-    const dim3 grid(gv.num_envs), block(64);
-    if (gv.num_agents == 1) hipLaunchKernelGGL(step_obstacles_kernel<1>, grid, block, 0, stream, gv);
-    else if (gv.num_agents == 2) hipLaunchKernelGGL(step_obstacles_kernel<2>, grid, block, 0, stream, gv);
-    else if (gv.num_agents <= 4) hipLaunchKernelGGL(step_obstacles_kernel<4>, grid, block, 0, stream, gv);
-    else hipLaunchKernelGGL(step_obstacles_kernel<8>, grid, block, 0, stream, gv);
+    const dim3 grid(gv.num_envs), block(STEP_THREADS);
+    if (gv.num_agents == 1) hipLaunchKernelGGL(step_obstacles_kernel<1>, grid, block, 0, stream, gv, W, H, render);
+    else if (gv.num_agents == 2) hipLaunchKernelGGL(step_obstacles_kernel<2>, grid, block, 0, stream, gv, W, H, render);
+    else if (gv.num_agents <= 4) hipLaunchKernelGGL(step_obstacles_kernel<4>, grid, block, 0, stream, gv, W, H, render);
+    else hipLaunchKernelGGL(step_obstacles_kernel<8>, grid, block, 0, stream, gv, W, H, render);
 }
 
 void launch_reset_obstacles(const GymView &gv, const EpisodeBlob *blobs, int *status, int force_all, hipStream_t stream)
