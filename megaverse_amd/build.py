@@ -3,7 +3,7 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(HERE, "libmegaverse_hip.so")
+LIB = os.environ.get("MV_LIB_PATH") or os.path.join(HERE, "libmegaverse_hip.so")   # MV_LIB_PATH: an experiment's variant build
 CSRC = os.path.join(HERE, "csrc")
 
 
@@ -14,6 +14,8 @@ def sources():
 
 
 def is_stale():
+    if os.environ.get("MV_LIB_PATH"):
+        return False
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)

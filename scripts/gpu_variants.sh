@@ -1,11 +1,18 @@
 #!/bin/bash
-# usage: scripts/gpu_variants.sh "<EXTRA flags variant 1>" "<variant 2>" ...   (run on the GPU box through gpurun)
-# rebuilds mv_raster.o / mv_step*.o with each EXTRA and prints the bench kernel times
-mkdir -p gpurun_out
-for v in "$@"; do
-  touch megaverse_amd/csrc/mv_raster.hip megaverse_amd/csrc/mv_step.hip
-  make -C megaverse_amd/csrc EXTRA="$v" > gpurun_out/build.log 2>&1 || { echo "build failed for $v"; tail -5 gpurun_out/build.log; continue; }
-  echo "== $v"
-  timeout 120 python -u bench.py --no-cpu-baseline --steps 600 ${BENCH_ARGS} 2>/dev/null | grep -o "\"value\": [0-9.]*\|avg_launch_ms\": [0-9.]*" | tr '\n' ' '
-  echo
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/$1
+mkdir -p $OUT
+cd $R
+B="python bench.py --steps 600 --warmup 50 --no-cpu-baseline"
+$B > $OUT/bench_tower_t128.json 2>&1
+$B --scenario Collect > $OUT/bench_collect_t128.json 2>&1
+$B --agents 4 --envs-per-gpu 512 > $OUT/bench_a4_t128.json 2>&1
+$B --envs-per-gpu 4096 > $OUT/bench_n4096_t128.json 2>&1
+for t in 64 192 256; do
+export MV_LIB_PATH=$R/megaverse_amd/_variants/libmv_t$t.so
+$B > $OUT/bench_tower_t$t.json 2>&1
+$B --scenario Collect > $OUT/bench_collect_t$t.json 2>&1
+$B --agents 4 --envs-per-gpu 512 > $OUT/bench_a4_t$t.json 2>&1
+$B --envs-per-gpu 4096 > $OUT/bench_n4096_t$t.json 2>&1
 done
