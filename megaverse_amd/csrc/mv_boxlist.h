@@ -84,23 +84,7 @@ __device__ __forceinline__ int object_at(const Objs &o, int x, int y, int z)
     return -1;
 }
 
-template <int A_MAX>
-__device__ __forceinline__ void reward_agent(AgentState (&ag)[A_MAX], int key, int idx, float mult)
-{
-#pragma unroll
-    for (int i = 0; i < A_MAX; ++i)
-        if (i == idx) ag[i].last_reward += ag[i].shaping[key] * mult;
-}
-template <int A_MAX>
-__device__ __forceinline__ void reward_team(AgentState (&ag)[A_MAX], int A, int key, int idx, float mult)
-{
-#pragma unroll
-    for (int i = 0; i < A_MAX; ++i)
-        if (i == idx) ag[i].last_reward += ag[i].shaping[key] * (mult * (1 - ag[i].shaping[0]));
-#pragma unroll
-    for (int i = 0; i < A_MAX; ++i)
-        if (i < A) ag[i].last_reward += ag[i].shaping[key] * ag[i].shaping[0] * mult / float(A);
-}
+// (Scenario::rewardAgent / rewardTeam live in mv_agents.h: the agent records of an env are in LDS during a tick)
 
 __device__ __forceinline__ void voxel_of(V3 p, int out[3])
 {

@@ -130,18 +130,30 @@ __device__ __forceinline__ int screen_rect(const float *blo, const float *bhi, i
     return 1;
 }
 
-// ---- pass 1, one workgroup of THREADS (64, 128 or 256) threads per frame: which primitives can this camera see, and where on the screen?
-template <int THREADS>
-__device__ __forceinline__ void frame_setup_body(const GymView &gv, const int frame, const int W, const int H)
+// LDS scratch of one frame setup in flight (one per workgroup, or one per wave when every wave of a workgroup sets up its own frame)
+struct FrameScratch {
+    CamL cam[MAX_AGENTS];
+    int cost;                // tiles x primitives the raster pass will have to look at (scheduling estimate)
+    int cnt[8];              // [parity*4 + wave]: visible primitives found by each wave this round
+    unsigned wbits[32];      // world-frame-box bit of every list position (frame header, raster_fast_kernel)
+};
+
+// ---- pass 1: which primitives can this camera see, and where on the screen?  THREADS (64, 128, 256) threads work on one frame:
+// a whole workgroup (WAVE_LOCAL = false, barriers are __syncthreads()), or -- THREADS = 64, WAVE_LOCAL = true -- one wavefront of a
+// workgroup whose other waves are busy with other frames (ordering points are wave_sync()).
+template <int THREADS, bool WAVE_LOCAL>
+__device__ __forceinline__ void frame_setup_body(const GymView &gv, const int frame, const int W, const int H, FrameScratch &fs)
 {
-    __shared__ CamL s_cam[MAX_AGENTS];
-    __shared__ int s_cost;                // tiles x primitives the raster pass will have to look at (scheduling estimate)
-    __shared__ int s_cnt[8];              // [parity*4 + wave]: visible primitives found by each wave this round
-    __shared__ unsigned s_wbits[32];      // world-frame-box bit of every list position (frame header, raster_fast_kernel)
+    static_assert(!WAVE_LOCAL || THREADS == 64, "a wave-local frame setup is one wavefront");
+    auto sync = [] { if (WAVE_LOCAL) wave_sync(); else __syncthreads(); };
+    CamL *const s_cam = fs.cam;
+    int &s_cost = fs.cost;
+    int *const s_cnt = fs.cnt;
+    unsigned *const s_wbits = fs.wbits;
 
     const int A = gv.num_agents;
     const int env = frame / A, viewer = frame - env * A;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = WAVE_LOCAL ? (int)(threadIdx.x & 63) : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const EnvHeader *hdr = gv.hdr + env;
     const AgentState *agents = gv.agents + (size_t)env * A;
     const int maxVis = gv.vis_stride;
@@ -164,7 +176,7 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
         cam.origin[0] = cam.origin[1] = cam.origin[2] = 0.0f;
         s_cam[tid] = cam;
     }
-    __syncthreads();
+    sync();
     if (tid < A) {
         const V3 ev = v3(s_cam[viewer].eye[0], s_cam[viewer].eye[1], s_cam[viewer].eye[2]);
         const V3 ek = v3(s_cam[tid].eye[0], s_cam[tid].eye[1], s_cam[tid].eye[2]);
@@ -329,7 +341,7 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
         const unsigned long long mV = __ballot(cls != 0);
         int *cnt = s_cnt + (rd & 1) * 4;   // double-buffered: one barrier per round
         if (lane == 0) cnt[wave] = __popcll(mV);
-        __syncthreads();
+        sync();
         int pos = nVis, tot = 0;
 #pragma unroll
         for (int q = 0; q < NW; ++q) {
@@ -361,7 +373,7 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
         }
     }
     if (myCost) atomicAdd(&s_cost, myCost);
-    __syncthreads();
+    sync();
     {   // frame header
         float *fh = reinterpret_cast<float *>(gv.vis_hdr + (size_t)frame * FRAME_HDR_BYTES);
         if (tid == 0) fh[0] = __int_as_float(min(nVis, maxVis));
@@ -390,7 +402,7 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
         const int tiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H);
         gv.lpt_bucket[frame] = min(LPT_BUCKETS - 1, (16 * s_cost) / max(tiles, 1));   // 1/16 of "one primitive on every tile"
     }
-    __syncthreads();   // the LDS scratch above is reused by the next frame of this workgroup (fused step + setup kernels)
+    sync();   // the LDS scratch above is reused by the next frame of this workgroup (fused step + setup kernels)
 }
 
 }  // namespace

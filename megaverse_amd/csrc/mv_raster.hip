@@ -240,7 +240,11 @@ __device__ __forceinline__ V3 safe_inv(V3 d)
 
 
 // ---- pass 1 as a kernel of its own (mv_reset, mv_render, hires): one workgroup per frame (mv_frame.h)
-__global__ __launch_bounds__(256) void frame_setup_kernel(GymView gv, int W, int H) { frame_setup_body<256>(gv, blockIdx.x, W, H); }
+__global__ __launch_bounds__(256) void frame_setup_kernel(GymView gv, int W, int H)
+{
+    __shared__ FrameScratch s_fs;
+    frame_setup_body<256, false>(gv, blockIdx.x, W, H, s_fs);
+}
 
 // ---- pass 1b, one workgroup: counting sort of the frames by cost bin, most expensive first.  (A "last workgroup of
 // frame_setup_kernel does it" variant was slower: its device-scope fences write back every XCD's L2, 22 us vs 6 us.)

@@ -22,7 +22,10 @@
 // with each other and share voxels) so they run one after another with wave-uniform state.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "mv_actions.h"
+#include "mv_agents.h"
 #include "mv_frame.h"
 #include "mv_math.h"
 #include "mv_physics.h"
@@ -93,26 +96,6 @@ __device__ __forceinline__ float tower_reward(const Hdr &h, const ObjRegs &o)
     return r;
 }
 
-// Scenario::rewardAgent / rewardTeam (scenario.hpp:259-298); fully unrolled so ag[] stays in VGPRs
-template <int A_MAX>
-__device__ __forceinline__ void reward_agent(AgentState (&ag)[A_MAX], int key, int idx, float mult)
-{
-#pragma unroll
-    for (int i = 0; i < A_MAX; ++i)
-        if (i == idx) ag[i].last_reward += ag[i].shaping[key] * mult;
-}
-
-template <int A_MAX>
-__device__ __forceinline__ void reward_team(AgentState (&ag)[A_MAX], int A, int key, int idx, float mult)
-{
-#pragma unroll
-    for (int i = 0; i < A_MAX; ++i)
-        if (i == idx) ag[i].last_reward += ag[i].shaping[key] * (mult * (1 - ag[i].shaping[0]));
-#pragma unroll
-    for (int i = 0; i < A_MAX; ++i)
-        if (i < A) ag[i].last_reward += ag[i].shaping[key] * ag[i].shaping[0] * mult / float(A);
-}
-
 __device__ __forceinline__ void voxel_of(V3 p, int out[3])
 {
     out[0] = (int)floorf(p.x); out[1] = (int)floorf(p.y); out[2] = (int)floorf(p.z);
@@ -175,138 +158,137 @@ __device__ __forceinline__ void tower_tick(const GymView &gv, const int env)
     } else object_collider(0);
     if (lane < 32) object_collider(1);
 
-    // ---- agents: wave-uniform copies
-    AgentState ag[A_MAX];
-    int act[A_MAX];
-#pragma unroll
-    for (int i = 0; i < A_MAX; ++i)
-        if (i < A) {
-            ag[i] = gv.agents[(size_t)env * A + i];
-            act[i] = action_of(gv, env, i);
-            ag[i].last_reward = 0.0f;   // env.cpp:85
-        }
-
+    // ---- agents: records in LDS (mv_agents.h), one agent's physics fields in registers at a time
+    __shared__ AgentState s_ag[A_MAX];
+    __shared__ int s_act[A_MAX];
+    agents_load(gv, env, A, s_ag, s_act);
     const float dt = DT;
 
-    // ---- actions -> intents (env.cpp:89-122)
-#pragma unroll
-    for (int i = 0; i < A_MAX; ++i)
-        if (i < A) {
-            apply_actions(ag[i], act[i], dt, h.p_vertical_look_limit);
-        }
+    // ---- actions -> intents (env.cpp:89-122): agents are independent here, one lane each
+    if (lane < A) {
+        AgentState a;
+        phys_load(a, s_ag[lane]);
+        apply_actions(a, s_act[lane], dt, h.p_vertical_look_limit);
+        phys_store(s_ag[lane], a);
+    }
+    wave_sync();
 
     // ---- physics, agent by agent (controllers run in addAction order, env.cpp:126)
-#pragma unroll
-    for (int i = 0; i < A_MAX; ++i)
-        if (i < A) {
-            if (A_MAX > 1 && lane >= 32 && lane < 32 + MAX_AGENTS) {   // capsule colliders of the other agents
-                const int j = lane - 32;
-                col[1].kind = 0;
-#pragma unroll
-                for (int q = 0; q < A_MAX; ++q)
-                    if (q == j && q < A && q != i) {
-                        col[1].kind = 2;
-                        col[1].lo = v3(ag[q].pos[0], ag[q].pos[1], ag[q].pos[2]);
-                        col[1].hi = v3(2 * CAP_HH, 0.0f, 0.0f);
-                    }
+#pragma unroll 1
+    for (int i = 0; i < A; ++i) {
+        if (A_MAX > 1 && lane >= 32 && lane < 32 + MAX_AGENTS) {   // capsule colliders of the other agents
+            const int j = lane - 32;
+            col[1].kind = 0;
+            if (j < A && j != i) {
+                col[1].kind = 2;
+                col[1].lo = v3(s_ag[j].pos[0], s_ag[j].pos[1], s_ag[j].pos[2]);
+                col[1].hi = v3(2 * CAP_HH, 0.0f, 0.0f);
             }
-            player_step(ag[i], col, dt);
         }
+        AgentState a;
+        phys_load(a, s_ag[i]);
+        player_step(a, col, dt);
+        if (lane == 0) phys_store(s_ag[i], a);
+        wave_sync();
+    }
 
     // ---- scenario step: interact (component_object_stacking.hpp:45-168)
-#pragma unroll
-    for (int i = 0; i < A_MAX; ++i)
-        if (i < A && (act[i] & ACT_INTERACT)) {
-            AgentState &a = ag[i];
-            const Cam cam = camera_of(a);
-            if (a.carrying >= 0) {
-                const V3 t = cam_to_world(cam, v3(0.0f, -0.44f + -0.3f, -1.0f));
-                int vx[3];
-                voxel_of(t, vx);
-                bool collidesWithAgent = false;
-#pragma unroll
-                for (int j = 0; j < A_MAX; ++j)
-                    if (j < A && j != i) {
-                        int c[3];
-                        voxel_of(v3(ag[j].pos[0], ag[j].pos[1] + 0.05f, ag[j].pos[2]), c);
-                        if (c[0] == vx[0] && c[1] == vx[1] && c[2] == vx[2]) collidesWithAgent = true;
-                    }
-                const bool placeable = vx[0] >= 0 && vx[0] < CX && vx[2] >= 0 && vx[2] < CZ && vx[1] < CY;
-                const unsigned long long colObj = column_objects(ob, vx[0], vx[2]);   // wave op, outside the loop
-                auto has_obj = [&](int y) { return in_chunk(vx[0], y, vx[2]) && ((colObj >> (y + 32)) & 1ull); };
-                const bool empty = !(vox(vx[0], vx[1], vx[2]) & VX_SOLID) && !has_obj(vx[1]);
-                // the reference's grid is unbounded; a placement this build's 32 x 16 x 32 chunk cannot hold is refused AND reported
-                if (!placeable && !collidesWithAgent && in_zone(h, vx[0], vx[2]) && lane == 0) atomicOr(&gv.episode_status[gv.num_envs + 1], (int)ST_CHUNK);
-                if (placeable && empty && !collidesWithAgent && in_zone(h, vx[0], vx[2])) {
-                    for (;;) {
-                        const int by = vx[1] - 1;
-                        if (by < -30) break;
-                        if ((vox(vx[0], by, vx[2]) & VX_SOLID) || has_obj(by)) break;
-                        vx[1] = by;
-                    }
-                    const int oidx = a.carrying;
-#pragma unroll
-                    for (int k = 0; k < 2; ++k)
-                        if (oi[k] == oidx) { ob.x[k] = vx[0]; ob.y[k] = vx[1]; ob.z[k] = vx[2]; ob.state[k] = 0; }
-                    if (lane == 0 && in_chunk(vx[0], vx[1], vx[2])) chunk[(vx[1] * CZ + vx[2]) * CX + vx[0]] |= VX_OBJECT;
-                    a.carrying = -1;
-                    const float newReward = tower_reward(h, ob);
-                    const float delta = newReward - h.bz_reward;
-                    h.bz_reward = newReward;
-                    reward_team(ag, A, 3, i, delta);
-                    h.highest_tower = max(h.highest_tower, vx[1] - 1 + 1);
+#pragma unroll 1
+    for (int i = 0; i < A; ++i) {
+        if (!(s_act[i] & ACT_INTERACT)) continue;
+        AgentState a;
+        phys_load(a, s_ag[i]);
+        const int carrying = s_ag[i].carrying;
+        const Cam cam = camera_of(a);
+        if (carrying >= 0) {
+            const V3 t = cam_to_world(cam, v3(0.0f, -0.44f + -0.3f, -1.0f));
+            int vx[3];
+            voxel_of(t, vx);
+            bool collidesWithAgent = false;
+            for (int j = 0; j < A; ++j)
+                if (j != i) {
+                    int c[3];
+                    voxel_of(v3(s_ag[j].pos[0], s_ag[j].pos[1] + 0.05f, s_ag[j].pos[2]), c);
+                    if (c[0] == vx[0] && c[1] == vx[1] && c[2] == vx[2]) collidesWithAgent = true;
                 }
-            } else {
-                const V3 pickup = cam_to_world(cam, v3(0.0f, -0.44f, -1.0f));
-                int vx[3];
-                voxel_of(pickup, vx);
-                // maxPickupHeight == 1: try the voxel, then the one above; an object with another one
-                // on top of it cannot be taken (component_object_stacking.hpp:131-167)
-                const int o0 = object_at(ob, vx[0], vx[1], vx[2]);
-                const int o1 = object_at(ob, vx[0], vx[1] + 1, vx[2]);
-                const int o2 = object_at(ob, vx[0], vx[1] + 2, vx[2]);
-                int oidx = -1, py = vx[1];
-                if (o0 >= 0 && o1 < 0) { oidx = o0; py = vx[1]; }
-                else if (o1 >= 0 && o2 < 0) { oidx = o1; py = vx[1] + 1; }
-                if (oidx >= 0) {
-#pragma unroll
-                    for (int k = 0; k < 2; ++k)
-                        if (oi[k] == oidx) ob.state[k] = 1 + i;
-                    if (lane == 0 && in_chunk(vx[0], py, vx[2])) chunk[(py * CZ + vx[2]) * CX + vx[0]] &= (uint8_t)~VX_OBJECT;
-                    a.carrying = oidx;
-                    if (!a.picked_up) { reward_agent(ag, 1, i, 1); a.picked_up = 1; }
+            const bool placeable = vx[0] >= 0 && vx[0] < CX && vx[2] >= 0 && vx[2] < CZ && vx[1] < CY;
+            const unsigned long long colObj = column_objects(ob, vx[0], vx[2]);   // wave op, outside the loop
+            auto has_obj = [&](int y) { return in_chunk(vx[0], y, vx[2]) && ((colObj >> (y + 32)) & 1ull); };
+            const bool empty = !(vox(vx[0], vx[1], vx[2]) & VX_SOLID) && !has_obj(vx[1]);
+            // the reference's grid is unbounded; a placement this build's 32 x 16 x 32 chunk cannot hold is refused AND reported
+            if (!placeable && !collidesWithAgent && in_zone(h, vx[0], vx[2]) && lane == 0) atomicOr(&gv.episode_status[gv.num_envs + 1], (int)ST_CHUNK);
+            if (placeable && empty && !collidesWithAgent && in_zone(h, vx[0], vx[2])) {
+                for (;;) {
+                    const int by = vx[1] - 1;
+                    if (by < -30) break;
+                    if ((vox(vx[0], by, vx[2]) & VX_SOLID) || has_obj(by)) break;
+                    vx[1] = by;
                 }
+                const int oidx = carrying;
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    if (oi[k] == oidx) { ob.x[k] = vx[0]; ob.y[k] = vx[1]; ob.z[k] = vx[2]; ob.state[k] = 0; }
+                if (lane == 0 && in_chunk(vx[0], vx[1], vx[2])) chunk[(vx[1] * CZ + vx[2]) * CX + vx[0]] |= VX_OBJECT;
+                if (lane == 0) s_ag[i].carrying = -1;
+                const float newReward = tower_reward(h, ob);
+                const float delta = newReward - h.bz_reward;
+                h.bz_reward = newReward;
+                wave_sync();
+                reward_team_lds(s_ag, A, 3, i, delta);
+                h.highest_tower = max(h.highest_tower, vx[1] - 1 + 1);
+            }
+        } else {
+            const V3 pickup = cam_to_world(cam, v3(0.0f, -0.44f, -1.0f));
+            int vx[3];
+            voxel_of(pickup, vx);
+            // maxPickupHeight == 1: try the voxel, then the one above; an object with another one
+            // on top of it cannot be taken (component_object_stacking.hpp:131-167)
+            const int o0 = object_at(ob, vx[0], vx[1], vx[2]);
+            const int o1 = object_at(ob, vx[0], vx[1] + 1, vx[2]);
+            const int o2 = object_at(ob, vx[0], vx[1] + 2, vx[2]);
+            int oidx = -1, py = vx[1];
+            if (o0 >= 0 && o1 < 0) { oidx = o0; py = vx[1]; }
+            else if (o1 >= 0 && o2 < 0) { oidx = o1; py = vx[1] + 1; }
+            if (oidx >= 0) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    if (oi[k] == oidx) ob.state[k] = 1 + i;
+                if (lane == 0 && in_chunk(vx[0], py, vx[2])) chunk[(py * CZ + vx[2]) * CX + vx[0]] &= (uint8_t)~VX_OBJECT;
+                const int pickedBefore = s_ag[i].picked_up;
+                wave_sync();
+                if (lane == 0) { s_ag[i].carrying = oidx; s_ag[i].picked_up = 1; }
+                wave_sync();
+                if (!pickedBefore) reward_agent_lds(s_ag, 1, i, 1);
             }
         }
+    }
+    wave_sync();
 
-    // ---- fall detection (component_fall_detection.hpp:33-55)
-#pragma unroll
-    for (int i = 0; i < A_MAX; ++i)
-        if (i < A) {
-            AgentState &a = ag[i];
-            if (a.pos[1] + 0.05f < -20.0f) {
-                int p[3] = {a.spawn[0], a.spawn[1], a.spawn[2]};
-                while ((vox(p[0], p[1], p[2]) & VX_SOLID) && p[1] < 1000) ++p[1];
-                a.pos[0] = float(p[0]) + 0.5f; a.pos[1] = float(p[1]) + 0.5f; a.pos[2] = float(p[2]) + 0.5f;
-                a.m00 = 1.0f; a.m02 = 0.0f; a.m20 = 0.0f; a.m22 = 1.0f;
-                a.hvx = 0.0f; a.hvz = 0.0f; a.vvel = 0.0f;
-            }
+    // ---- fall detection (component_fall_detection.hpp:33-55): one lane per agent
+    if (lane < A) {
+        AgentState &a = s_ag[lane];
+        if (a.pos[1] + 0.05f < -20.0f) {
+            int p[3] = {a.spawn[0], a.spawn[1], a.spawn[2]};
+            while ((vox(p[0], p[1], p[2]) & VX_SOLID) && p[1] < 1000) ++p[1];
+            a.pos[0] = float(p[0]) + 0.5f; a.pos[1] = float(p[1]) + 0.5f; a.pos[2] = float(p[2]) + 0.5f;
+            a.m00 = 1.0f; a.m02 = 0.0f; a.m20 = 0.0f; a.m22 = 1.0f;
+            a.hvx = 0.0f; a.hvz = 0.0f; a.vvel = 0.0f;
         }
+    }
+    wave_sync();
 
-    // ---- building-zone visit shaping (scenario_tower_building.cpp:184-198)
-#pragma unroll
-    for (int i = 0; i < A_MAX; ++i)
-        if (i < A) {
-            AgentState &a = ag[i];
-            if (a.carrying >= 0) {
-                int vx[3];
-                voxel_of(v3(a.pos[0], a.pos[1] + 0.05f, a.pos[2]), vx);
-                if (in_zone(h, vx[0], vx[2]) && !a.visited_zone) {
-                    reward_team(ag, A, 2, i, 1);
-                    a.visited_zone = 1;
-                }
-            }
+    // ---- building-zone visit shaping (scenario_tower_building.cpp:184-198), in agent order
+#pragma unroll 1
+    for (int i = 0; i < A; ++i) {
+        if (s_ag[i].carrying < 0) continue;
+        int vx[3];
+        voxel_of(v3(s_ag[i].pos[0], s_ag[i].pos[1] + 0.05f, s_ag[i].pos[2]), vx);
+        if (in_zone(h, vx[0], vx[2]) && !s_ag[i].visited_zone) {
+            wave_sync();
+            if (lane == 0) s_ag[i].visited_zone = 1;
+            reward_team_lds(s_ag, A, 2, i, 1);
         }
+    }
 
     // ---- timers / done (env.cpp:133-151)
     h.episode_sec += dt;
@@ -329,24 +311,8 @@ __device__ __forceinline__ void tower_tick(const GymView &gv, const int env)
         wh->episode_sec = h.episode_sec; wh->bz_reward = h.bz_reward; wh->bar_half_width = h.bar_half_width;
         gv.done[env] = (uint8_t)h.done;
     }
-#pragma unroll
-    for (int i = 0; i < A_MAX; ++i)
-        if (i < A && lane == i) {
-            ag[i].total_reward += ag[i].last_reward;
-            // store the fields a tick can change (everything before `shaping`); writing the whole 128 B record
-            // would force the unchanged tail to be carried in scratch memory for the whole kernel
-            AgentState *dst = gv.agents + (size_t)env * A + i;
-            const AgentState &a = ag[i];
-            dst->pos[0] = a.pos[0]; dst->pos[1] = a.pos[1]; dst->pos[2] = a.pos[2];
-            dst->m00 = a.m00; dst->m02 = a.m02; dst->m20 = a.m20; dst->m22 = a.m22; dst->pitch = a.pitch;
-            dst->hvx = a.hvx; dst->hvz = a.hvz; dst->vvel = a.vvel; dst->voffset = a.voffset;
-            dst->step_offset = a.step_offset; dst->jump_speed = a.jump_speed;
-            dst->was_jumping = a.was_jumping; dst->carrying = a.carrying; dst->picked_up = a.picked_up; dst->visited_zone = a.visited_zone;
-            dst->last_reward = a.last_reward; dst->total_reward = a.total_reward;
-            gv.actions[(size_t)env * A + i] = 0;
-            gv.rewards[(size_t)env * A + i] = ag[i].last_reward;   // zeroed by the reset kernel if done
-            if (h.done) gv.true_objective[(size_t)env * A + i] = float(h.highest_tower);   // vector_env.cpp:97-98
-        }
+    agents_store(gv, env, A, s_ag);
+    if (h.done && lane < A) gv.true_objective[(size_t)env * A + lane] = float(h.highest_tower);   // vector_env.cpp:97-98
 
     // ---- VectorEnv::step's auto-reset (vector_env.cpp:93-105): the wave of a finished env regenerates it right here.  About one
     // env in two thousand finishes per tick and its wave is not the slowest of the launch even with the generator on top, so
@@ -357,28 +323,33 @@ __device__ __forceinline__ void tower_tick(const GymView &gv, const int env)
     }
 }
 
-// One workgroup of STEP_THREADS per env: wave 0 runs the tick (one wave per env: physics, scenario logic, auto-reset), the others wait at
-// the barrier; then all of them build the lists of the env's frames (mv_frame.h).  `render` = 0: mv_step_no_render.  The tick needs
-// ~150 VGPRs, i.e. 3 waves per SIMD: with 2 waves per env 1024 envs are resident at once (with 4 they would take two rounds, and a
-// launch lasts as long as its slowest tick PER ROUND: measured 41 us vs 25 us).
+// One workgroup per env: wave 0 runs the tick (one wave per env: physics, scenario logic, auto-reset), the others wait at the barrier;
+// then the workgroup builds the lists of the env's frames (mv_frame.h).  `render` = 0: mv_step_no_render.
+//   one agent:  STEP_THREADS (128) threads work on the env's one frame together.  The tick needs ~150 VGPRs, i.e. 3 waves per SIMD: with
+//               2 waves per env 1024 envs are resident at once (with 4 they take two rounds, and a launch lasts as long as its slowest
+//               tick PER ROUND: measured 41 us vs 25 us);
+//   A agents:   64 min(A, 4) threads, every wave sets up its own frame(s): a frame setup is a chain of dependent loads (~6 us), A of them
+//               one after the other would cost more than the launch the fusion saves.
 template <int A_MAX>
-__global__ __launch_bounds__(STEP_THREADS) void step_kernel(GymView gv, int W, int H, int render)
+__global__ __launch_bounds__(256) void step_kernel(GymView gv, int W, int H, int render)
 {
+    __shared__ FrameScratch s_fs[A_MAX == 1 ? 1 : 4];
     const int env = blockIdx.x;
     if (threadIdx.x < 64) tower_tick<A_MAX>(gv, env);
     if (!render) return;
     __syncthreads();   // the tick's stores (same CU: same L1) before the frame setup's loads
-    const int A = gv.num_agents;
-    for (int a = 0; a < A; ++a) frame_setup_body<STEP_THREADS>(gv, env * A + a, W, H);
+    if (A_MAX == 1) frame_setup_body<STEP_THREADS, false>(gv, env, W, H, s_fs[0]);
+    else {
+        const int A = gv.num_agents, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+        for (int a = wave; a < A; a += nw) frame_setup_body<64, true>(gv, env * A + a, W, H, s_fs[wave]);
+    }
 }
 
 void launch_step(const GymView &gv, hipStream_t stream, int W, int H, int render)
 {
-    const dim3 grid(gv.num_envs), block(STEP_THREADS);
+    const dim3 grid(gv.num_envs), block(gv.num_agents == 1 ? STEP_THREADS : 64 * std::min(gv.num_agents, 4));
     if (gv.num_agents == 1) hipLaunchKernelGGL(step_kernel<1>, grid, block, 0, stream, gv, W, H, render);
-    else if (gv.num_agents == 2) hipLaunchKernelGGL(step_kernel<2>, grid, block, 0, stream, gv, W, H, render);
-    else if (gv.num_agents <= 4) hipLaunchKernelGGL(step_kernel<4>, grid, block, 0, stream, gv, W, H, render);
-    else hipLaunchKernelGGL(step_kernel<8>, grid, block, 0, stream, gv, W, H, render);
+    else hipLaunchKernelGGL(step_kernel<MAX_AGENTS>, grid, block, 0, stream, gv, W, H, render);   // (agent loops are real loops: one multi-agent build)
 }
 
 }  // namespace mv

@@ -16,8 +16,11 @@
 // lists with ballots instead of a dense chunk; column occupancy for drops and teleports is a 128-bit wave OR.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "mv_boxlist.h"
 #include "mv_actions.h"
+#include "mv_agents.h"
 #include "mv_frame.h"
 #include "mv_math.h"
 #include "mv_physics.h"
@@ -173,137 +176,143 @@ __device__ __forceinline__ void obstacles_tick(const GymView &gv, const int env)
         rwx = r.x; rwy = r.y; rwz = r.z; rwActive = r.state;
     }
 
-    // ---- agents: wave-uniform copies
-    AgentState ag[A_MAX];
-    int act[A_MAX];
-#pragma unroll
-    for (int i = 0; i < A_MAX; ++i)
-        if (i < A) {
-            ag[i] = gv.agents[(size_t)env * A + i];
-            act[i] = action_of(gv, env, i);
-            ag[i].last_reward = 0.0f;
-        }
+    // ---- agents: records in LDS (mv_agents.h), one agent's physics fields in registers at a time
+    __shared__ AgentState s_ag[A_MAX];
+    __shared__ int s_act[A_MAX];
+    agents_load(gv, env, A, s_ag, s_act);
     const float dt = DT;
 
-#pragma unroll
-    for (int i = 0; i < A_MAX; ++i)
-        if (i < A) apply_actions(ag[i], act[i], dt, lookLimit);
+    if (lane < A) {   // actions -> intents: agents are independent here, one lane each
+        AgentState a;
+        phys_load(a, s_ag[lane]);
+        apply_actions(a, s_act[lane], dt, lookLimit);
+        phys_store(s_ag[lane], a);
+    }
+    wave_sync();
 
     // ---- physics, agent by agent
-#pragma unroll
-    for (int i = 0; i < A_MAX; ++i)
-        if (i < A) {
-            if (A_MAX > 1 && lane >= 32 && lane < 32 + MAX_AGENTS) {   // agent capsules: slot 192 + lane, k = 3
-                const int j = lane - 32;
-                col[3].kind = 0;
-#pragma unroll
-                for (int q = 0; q < A_MAX; ++q)
-                    if (q == j && q < A && q != i) {
-                        col[3].kind = 2;
-                        col[3].lo = v3(ag[q].pos[0], ag[q].pos[1], ag[q].pos[2]);
-                        col[3].hi = v3(2 * CAP_HH, 0.0f, 0.0f);
-                    }
+#pragma unroll 1
+    for (int i = 0; i < A; ++i) {
+        if (A_MAX > 1 && lane >= 32 && lane < 32 + MAX_AGENTS) {   // agent capsules: slot 192 + lane, k = 3
+            const int j = lane - 32;
+            col[3].kind = 0;
+            if (j < A && j != i) {
+                col[3].kind = 2;
+                col[3].lo = v3(s_ag[j].pos[0], s_ag[j].pos[1], s_ag[j].pos[2]);
+                col[3].hi = v3(2 * CAP_HH, 0.0f, 0.0f);
             }
-            player_step<NC>(ag[i], col, dt);
         }
+        AgentState a;
+        phys_load(a, s_ag[i]);
+        player_step<NC>(a, col, dt);
+        if (lane == 0) phys_store(s_ag[i], a);
+        wave_sync();
+    }
 
     // ---- interact: pick up / put down with the default callbacks (anything may be placed anywhere)
-#pragma unroll
-    for (int i = 0; i < A_MAX; ++i)
-        if (i < A && (act[i] & ACT_INTERACT)) {
-            AgentState &a = ag[i];
-            const Cam cam = camera_of(a);
-            if (a.carrying >= 0) {
-                const V3 t = cam_to_world(cam, v3(0.0f, -0.44f + -0.3f, -1.0f));
-                int vx[3];
-                voxel_of(t, vx);
-                bool collidesWithAgent = false;
-#pragma unroll
-                for (int j = 0; j < A_MAX; ++j)
-                    if (j < A && j != i) {
-                        int c[3];
-                        voxel_of(v3(ag[j].pos[0], ag[j].pos[1] + 0.05f, ag[j].pos[2]), c);
-                        if (c[0] == vx[0] && c[1] == vx[1] && c[2] == vx[2]) collidesWithAgent = true;
-                    }
-                const Bits128 solid = column_solid(lb, vx[0], vx[2]);
-                const Bits128 objs = column_objects(ob, vx[0], vx[2]);
-                const bool placeable = vx[1] > -120 && vx[1] < 120;
-                const bool solidHere = vx[1] >= 96 || vx[1] < -32 ? false : test(solid, vx[1]);
-                const bool empty = !solidHere && !test(objs, vx[1]);
-                if (placeable && empty && !collidesWithAgent) {
-                    Bits128 occ = solid;
-                    occ.lo |= objs.lo; occ.hi |= objs.hi;
-                    vx[1] = drop_height(occ, vx[1]);
-                    const int oidx = a.carrying;
-#pragma unroll
-                    for (int k = 0; k < 2; ++k)
-                        if (oi[k] == oidx) { ob.x[k] = vx[0]; ob.y[k] = vx[1]; ob.z[k] = vx[2]; ob.state[k] = 0; }
-                    a.carrying = -1;
+#pragma unroll 1
+    for (int i = 0; i < A; ++i) {
+        if (!(s_act[i] & ACT_INTERACT)) continue;
+        AgentState a;
+        phys_load(a, s_ag[i]);
+        const int carrying = s_ag[i].carrying;
+        const Cam cam = camera_of(a);
+        if (carrying >= 0) {
+            const V3 t = cam_to_world(cam, v3(0.0f, -0.44f + -0.3f, -1.0f));
+            int vx[3];
+            voxel_of(t, vx);
+            bool collidesWithAgent = false;
+            for (int j = 0; j < A; ++j)
+                if (j != i) {
+                    int c[3];
+                    voxel_of(v3(s_ag[j].pos[0], s_ag[j].pos[1] + 0.05f, s_ag[j].pos[2]), c);
+                    if (c[0] == vx[0] && c[1] == vx[1] && c[2] == vx[2]) collidesWithAgent = true;
                 }
-            } else {
-                const V3 pickup = cam_to_world(cam, v3(0.0f, -0.44f, -1.0f));
-                int vx[3];
-                voxel_of(pickup, vx);
-                const int o0 = object_at(ob, vx[0], vx[1], vx[2]);
-                const int o1 = object_at(ob, vx[0], vx[1] + 1, vx[2]);
-                const int o2 = object_at(ob, vx[0], vx[1] + 2, vx[2]);
-                int oidx = -1;
-                if (o0 >= 0 && o1 < 0) oidx = o0;
-                else if (o1 >= 0 && o2 < 0) oidx = o1;
-                if (oidx >= 0) {
+            const Bits128 solid = column_solid(lb, vx[0], vx[2]);
+            const Bits128 objs = column_objects(ob, vx[0], vx[2]);
+            const bool placeable = vx[1] > -120 && vx[1] < 120;
+            const bool solidHere = vx[1] >= 96 || vx[1] < -32 ? false : test(solid, vx[1]);
+            const bool empty = !solidHere && !test(objs, vx[1]);
+            if (placeable && empty && !collidesWithAgent) {
+                Bits128 occ = solid;
+                occ.lo |= objs.lo; occ.hi |= objs.hi;
+                vx[1] = drop_height(occ, vx[1]);
 #pragma unroll
-                    for (int k = 0; k < 2; ++k)
-                        if (oi[k] == oidx) ob.state[k] = 1 + i;
-                    a.carrying = oidx;
-                }
+                for (int k = 0; k < 2; ++k)
+                    if (oi[k] == carrying) { ob.x[k] = vx[0]; ob.y[k] = vx[1]; ob.z[k] = vx[2]; ob.state[k] = 0; }
+                if (lane == 0) s_ag[i].carrying = -1;
+            }
+        } else {
+            const V3 pickup = cam_to_world(cam, v3(0.0f, -0.44f, -1.0f));
+            int vx[3];
+            voxel_of(pickup, vx);
+            const int o0 = object_at(ob, vx[0], vx[1], vx[2]);
+            const int o1 = object_at(ob, vx[0], vx[1] + 1, vx[2]);
+            const int o2 = object_at(ob, vx[0], vx[1] + 2, vx[2]);
+            int oidx = -1;
+            if (o0 >= 0 && o1 < 0) oidx = o0;
+            else if (o1 >= 0 && o2 < 0) oidx = o1;
+            if (oidx >= 0) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    if (oi[k] == oidx) ob.state[k] = 1 + i;
+                if (lane == 0) s_ag[i].carrying = oidx;
             }
         }
+        wave_sync();
+    }
+    wave_sync();
 
-    // teleport above the spawn cell (FallDetectionComponent::resetAgent + controller warp)
-    auto reset_agent = [&](AgentState &a) {
-        const Bits128 solid = column_solid(lb, a.spawn[0], a.spawn[2]);
-        int py = a.spawn[1];
+    // teleport above the spawn cell (FallDetectionComponent::resetAgent + controller warp); wave-uniform agent index
+    auto reset_agent = [&](int i) {
+        const int sx = s_ag[i].spawn[0], sy = s_ag[i].spawn[1], sz = s_ag[i].spawn[2];
+        const Bits128 solid = column_solid(lb, sx, sz);
+        int py = sy;
         while (test(solid, py) && py < 1000) ++py;
-        a.pos[0] = float(a.spawn[0]) + 0.5f; a.pos[1] = float(py) + 0.5f; a.pos[2] = float(a.spawn[2]) + 0.5f;
-        a.m00 = 1.0f; a.m02 = 0.0f; a.m20 = 0.0f; a.m22 = 1.0f;
-        a.hvx = 0.0f; a.hvz = 0.0f; a.vvel = 0.0f;
+        wave_sync();
+        if (lane == 0) {
+            AgentState &a = s_ag[i];
+            a.pos[0] = float(sx) + 0.5f; a.pos[1] = float(py) + 0.5f; a.pos[2] = float(sz) + 0.5f;
+            a.m00 = 1.0f; a.m02 = 0.0f; a.m20 = 0.0f; a.m22 = 1.0f;
+            a.hvx = 0.0f; a.hvz = 0.0f; a.vvel = 0.0f;
+        }
+        wave_sync();
     };
 
-#pragma unroll
-    for (int i = 0; i < A_MAX; ++i)
-        if (i < A && ag[i].pos[1] + 0.05f < -20.0f) reset_agent(ag[i]);
+#pragma unroll 1
+    for (int i = 0; i < A; ++i)
+        if (s_ag[i].pos[1] + 0.05f < -20.0f) reset_agent(i);
 
     // ---- ObstaclesScenario::step: exit pad, lava, diamonds
     int numAgentsAtExit = 0;
-#pragma unroll
-    for (int i = 0; i < A_MAX; ++i)
-        if (i < A) {
-            AgentState &a = ag[i];
-            int vx[3];
-            voxel_of(v3(a.pos[0], a.pos[1] + 0.05f, a.pos[2]), vx);
-            const bool inside = contains(tb, vx[0], vx[1], vx[2]);
-            const bool onExit = __ballot(inside && (tb.type & TERRAIN_EXIT)) != 0ull;
-            const bool onLava = __ballot(inside && (tb.type & TERRAIN_LAVA)) != 0ull;
-            if (onExit) {
-                ++numAgentsAtExit;
-                if (!a.visited_zone) {
-                    a.visited_zone = 1;
-                    reward_team(ag, A, 1, i, 1);
-                    if (a.carrying >= 0) reward_team(ag, A, 4, i, 1);
-                }
-            } else if (onLava) reset_agent(a);
-            // diamonds: matched against the cell computed before a lava teleport, like the reference
-            const bool got = rwActive && rwx == vx[0] && rwy == vx[1] && rwz == vx[2];
-            const unsigned long long gm = __ballot(got);
-            if (got) rwActive = 0;
-            for (int c = __popcll(gm); c > 0; --c) reward_team(ag, A, 3, i, 1);
-        }
+#pragma unroll 1
+    for (int i = 0; i < A; ++i) {
+        int vx[3];
+        voxel_of(v3(s_ag[i].pos[0], s_ag[i].pos[1] + 0.05f, s_ag[i].pos[2]), vx);
+        const bool inside = contains(tb, vx[0], vx[1], vx[2]);
+        const bool onExit = __ballot(inside && (tb.type & TERRAIN_EXIT)) != 0ull;
+        const bool onLava = __ballot(inside && (tb.type & TERRAIN_LAVA)) != 0ull;
+        if (onExit) {
+            ++numAgentsAtExit;
+            if (!s_ag[i].visited_zone) {
+                const bool carries = s_ag[i].carrying >= 0;
+                wave_sync();
+                if (lane == 0) s_ag[i].visited_zone = 1;
+                reward_team_lds(s_ag, A, 1, i, 1);
+                if (carries) reward_team_lds(s_ag, A, 4, i, 1);
+            }
+        } else if (onLava) reset_agent(i);
+        // diamonds: matched against the cell computed before a lava teleport, like the reference
+        const bool got = rwActive && rwx == vx[0] && rwy == vx[1] && rwz == vx[2];
+        const unsigned long long gm = __ballot(got);
+        if (got) rwActive = 0;
+        for (int c = __popcll(gm); c > 0; --c) reward_team_lds(s_ag, A, 3, i, 1);
+    }
     if (numAgentsAtExit == A && !solved) {
         solved = 1;
         episodeSec = fmax_sel(episodeSec, episodeLen - 0.3f);
-#pragma unroll
-        for (int i = 0; i < A_MAX; ++i)
-            if (i < A) reward_agent(ag, 2, i, 1);
+        if (lane < A) s_ag[lane].last_reward += s_ag[lane].shaping[2] * 1;   // rewardAgent(obstaclesAllAgentsAtExit) for every agent
+        wave_sync();
     }
 
     // ---- timers / done
@@ -327,22 +336,8 @@ __device__ __forceinline__ void obstacles_tick(const GymView &gv, const int env)
         gh->episode_sec = episodeSec; gh->bar_half_width = bar;
         gv.done[env] = (uint8_t)done;
     }
-#pragma unroll
-    for (int i = 0; i < A_MAX; ++i)
-        if (i < A && lane == i) {
-            ag[i].total_reward += ag[i].last_reward;
-            AgentState *dst = gv.agents + (size_t)env * A + i;
-            const AgentState &a = ag[i];
-            dst->pos[0] = a.pos[0]; dst->pos[1] = a.pos[1]; dst->pos[2] = a.pos[2];
-            dst->m00 = a.m00; dst->m02 = a.m02; dst->m20 = a.m20; dst->m22 = a.m22; dst->pitch = a.pitch;
-            dst->hvx = a.hvx; dst->hvz = a.hvz; dst->vvel = a.vvel; dst->voffset = a.voffset;
-            dst->step_offset = a.step_offset; dst->jump_speed = a.jump_speed;
-            dst->was_jumping = a.was_jumping; dst->carrying = a.carrying; dst->picked_up = a.picked_up; dst->visited_zone = a.visited_zone;
-            dst->last_reward = a.last_reward; dst->total_reward = a.total_reward;
-            gv.actions[(size_t)env * A + i] = 0;
-            gv.rewards[(size_t)env * A + i] = a.last_reward;
-            if (done) gv.true_objective[(size_t)env * A + i] = float(solved);   // trueObjective == solved (scenario_obstacles.hpp:34)
-        }
+    agents_store(gv, env, A, s_ag);
+    if (done && lane < A) gv.true_objective[(size_t)env * A + lane] = float(solved);   // trueObjective == solved (scenario_obstacles.hpp:34)
 
     // ---- the auto-reset of VectorEnv::step: the wave of a finished env swaps the next episode in right here
     if (done) {
@@ -351,19 +346,26 @@ __device__ __forceinline__ void obstacles_tick(const GymView &gv, const int env)
     }
 }
 
-// One workgroup of STEP_THREADS per env: wave 0 runs the tick (one wave per env: physics, scenario logic, auto-reset), the others wait at
-// the barrier; then all of them build the lists of the env's frames (mv_frame.h).  `render` = 0: mv_step_no_render.  The tick needs
-// ~150 VGPRs, i.e. 3 waves per SIMD: with 2 waves per env 1024 envs are resident at once (with 4 they would take two rounds, and a
-// launch lasts as long as its slowest tick PER ROUND: measured 41 us vs 25 us).
+// One workgroup per env: wave 0 runs the tick (one wave per env: physics, scenario logic, auto-reset), the others wait at the barrier;
+// then the workgroup builds the lists of the env's frames (mv_frame.h).  `render` = 0: mv_step_no_render.
+//   one agent:  STEP_THREADS (128) threads work on the env's one frame together.  The tick needs ~150 VGPRs, i.e. 3 waves per SIMD: with
+//               2 waves per env 1024 envs are resident at once (with 4 they take two rounds, and a launch lasts as long as its slowest
+//               tick PER ROUND: measured 41 us vs 25 us);
+//   A agents:   64 min(A, 4) threads, every wave sets up its own frame(s): a frame setup is a chain of dependent loads (~6 us), A of them
+//               one after the other would cost more than the launch the fusion saves.
 template <int A_MAX>
-__global__ __launch_bounds__(STEP_THREADS) void step_obstacles_kernel(GymView gv, int W, int H, int render)
+__global__ __launch_bounds__(256) void step_obstacles_kernel(GymView gv, int W, int H, int render)
 {
+    __shared__ FrameScratch s_fs[A_MAX == 1 ? 1 : 4];
     const int env = blockIdx.x;
     if (threadIdx.x < 64) obstacles_tick<A_MAX>(gv, env);
     if (!render) return;
     __syncthreads();   // the tick's stores (same CU: same L1) before the frame setup's loads
-    const int A = gv.num_agents;
-    for (int a = 0; a < A; ++a) frame_setup_body<STEP_THREADS>(gv, env * A + a, W, H);
+    if (A_MAX == 1) frame_setup_body<STEP_THREADS, false>(gv, env, W, H, s_fs[0]);
+    else {
+        const int A = gv.num_agents, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+        for (int a = wave; a < A; a += nw) frame_setup_body<64, true>(gv, env * A + a, W, H, s_fs[wave]);
+    }
 }
 
 __global__ __launch_bounds__(64) void reset_obstacles_kernel(GymView gv, const EpisodeBlob *blobs, int *status, int force_all)
@@ -376,11 +378,9 @@ __global__ __launch_bounds__(64) void reset_obstacles_kernel(GymView gv, const E
 
 void launch_step_obstacles(const GymView &gv, hipStream_t stream, int W, int H, int render)
 {
-    const dim3 grid(gv.num_envs), block(STEP_THREADS);
+    const dim3 grid(gv.num_envs), block(gv.num_agents == 1 ? STEP_THREADS : 64 * std::min(gv.num_agents, 4));
     if (gv.num_agents == 1) hipLaunchKernelGGL(step_obstacles_kernel<1>, grid, block, 0, stream, gv, W, H, render);
-    else if (gv.num_agents == 2) hipLaunchKernelGGL(step_obstacles_kernel<2>, grid, block, 0, stream, gv, W, H, render);
-    else if (gv.num_agents <= 4) hipLaunchKernelGGL(step_obstacles_kernel<4>, grid, block, 0, stream, gv, W, H, render);
-    else hipLaunchKernelGGL(step_obstacles_kernel<8>, grid, block, 0, stream, gv, W, H, render);
+    else hipLaunchKernelGGL(step_obstacles_kernel<MAX_AGENTS>, grid, block, 0, stream, gv, W, H, render);   // (agent loops are real loops: one multi-agent build)
 }
 
 void launch_reset_obstacles(const GymView &gv, const EpisodeBlob *blobs, int *status, int force_all, hipStream_t stream)

@@ -13,8 +13,11 @@
 // 22-29 movable items, 30-37 other agents.  The room is fixed (19 x H x 14), so "is this cell solid?" is arithmetic.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "mv_boxlist.h"
 #include "mv_actions.h"
+#include "mv_agents.h"
 #include "mv_frame.h"
 #include "mv_math.h"
 #include "mv_physics.h"
@@ -156,38 +159,37 @@ __device__ __forceinline__ void rearrange_tick(const GymView &gv, const int env)
     };
     refresh_item_collider();
 
-    // ---- agents: wave-uniform copies
-    AgentState ag[A_MAX];
-    int act[A_MAX];
-#pragma unroll
-    for (int i = 0; i < A_MAX; ++i)
-        if (i < A) {
-            ag[i] = gv.agents[(size_t)env * A + i];
-            act[i] = action_of(gv, env, i);
-            ag[i].last_reward = 0.0f;
-        }
+    // ---- agents: records in LDS (mv_agents.h), one agent's physics fields in registers at a time
+    __shared__ AgentState s_ag[A_MAX];
+    __shared__ int s_act[A_MAX];
+    agents_load(gv, env, A, s_ag, s_act);
     const float dt = DT;
-#pragma unroll
-    for (int i = 0; i < A_MAX; ++i)
-        if (i < A) apply_actions(ag[i], act[i], dt, lookLimit);
+    if (lane < A) {   // actions -> intents: agents are independent here, one lane each
+        AgentState a;
+        phys_load(a, s_ag[lane]);
+        apply_actions(a, s_act[lane], dt, lookLimit);
+        phys_store(s_ag[lane], a);
+    }
+    wave_sync();
 
     // ---- physics, agent by agent (items do not move during this phase)
-#pragma unroll
-    for (int i = 0; i < A_MAX; ++i)
-        if (i < A) {
-            if (A_MAX > 1 && lane >= LANE_AGENT && lane < LANE_AGENT + MAX_AGENTS) {
-                const int j = lane - LANE_AGENT;
-                col[0].kind = 0;
-#pragma unroll
-                for (int q = 0; q < A_MAX; ++q)
-                    if (q == j && q < A && q != i) {
-                        col[0].kind = 2;
-                        col[0].lo = v3(ag[q].pos[0], ag[q].pos[1], ag[q].pos[2]);
-                        col[0].hi = v3(2 * CAP_HH, 0.0f, 0.0f);
-                    }
+#pragma unroll 1
+    for (int i = 0; i < A; ++i) {
+        if (A_MAX > 1 && lane >= LANE_AGENT && lane < LANE_AGENT + MAX_AGENTS) {
+            const int j = lane - LANE_AGENT;
+            col[0].kind = 0;
+            if (j < A && j != i) {
+                col[0].kind = 2;
+                col[0].lo = v3(s_ag[j].pos[0], s_ag[j].pos[1], s_ag[j].pos[2]);
+                col[0].hi = v3(2 * CAP_HH, 0.0f, 0.0f);
             }
-            player_step<NC>(ag[i], col, dt);
         }
+        AgentState a;
+        phys_load(a, s_ag[i]);
+        player_step<NC>(a, col, dt);
+        if (lane == 0) phys_store(s_ag[i], a);
+        wave_sync();
+    }
 
     // ---- helpers over the movable items
     auto item_at = [&](int x, int y, int z) -> int {   // index of the standing item in that cell, or -1
@@ -207,30 +209,31 @@ __device__ __forceinline__ void rearrange_tick(const GymView &gv, const int env)
     };
     auto check_done = [&](int i) {   // checkDone :165-180
         const int matches = count_matching();
-        if (matches > maxMatching) { reward_team(ag, A, 1, i, 1); maxMatching = matches; }
+        if (matches > maxMatching) { reward_team_lds(s_ag, A, 1, i, 1); maxMatching = matches; }
         if (matches >= numItems && !solved) {
             solved = 1;
-            reward_team(ag, A, 2, i, 1);
+            reward_team_lds(s_ag, A, 2, i, 1);
             episodeSec = fmax_sel(episodeSec, episodeLen - 0.3f);
         }
     };
 
     // ---- interact: pick up / put down (items may only be put down on the right work area)
-#pragma unroll
-    for (int i = 0; i < A_MAX; ++i)
-        if (i < A && (act[i] & ACT_INTERACT)) {
-            AgentState &a = ag[i];
+#pragma unroll 1
+    for (int i = 0; i < A; ++i) {
+        if (s_act[i] & ACT_INTERACT) {
+            AgentState a;
+            phys_load(a, s_ag[i]);
+            const int carrying = s_ag[i].carrying;
             const Cam cam = camera_of(a);
-            if (a.carrying >= 0) {
+            if (carrying >= 0) {
                 const V3 t = cam_to_world(cam, v3(0.0f, -0.44f + -0.3f, -1.0f));
                 int vx[3];
                 voxel_of(t, vx);
                 bool collidesWithAgent = false;
-#pragma unroll
-                for (int j = 0; j < A_MAX; ++j)
-                    if (j < A && j != i) {
+                for (int j = 0; j < A; ++j)
+                    if (j != i) {
                         int c[3];
-                        voxel_of(v3(ag[j].pos[0], ag[j].pos[1] + 0.05f, ag[j].pos[2]), c);
+                        voxel_of(v3(s_ag[j].pos[0], s_ag[j].pos[1] + 0.05f, s_ag[j].pos[2]), c);
                         if (c[0] == vx[0] && c[1] == vx[1] && c[2] == vx[2]) collidesWithAgent = true;
                     }
                 const bool placeable = vx[0] >= 0 && vx[0] < CX && vx[2] >= 0 && vx[2] < CZ && vx[1] < CY;
@@ -243,8 +246,9 @@ __device__ __forceinline__ void rearrange_tick(const GymView &gv, const int env)
                 const bool canPlace = abs(vx[0] - RE_RIGHT_X) <= 2 && abs(vx[2] - RE_RIGHT_Z) <= 2;
                 if (placeable && empty && !collidesWithAgent && canPlace) {
                     vx[1] = drop_height(occ, vx[1]);
-                    if (isItem && itemIdx == a.carrying) { ox = vx[0]; oy = vx[1]; oz = vx[2]; ostate = 0; }
-                    a.carrying = -1;
+                    if (isItem && itemIdx == carrying) { ox = vx[0]; oy = vx[1]; oz = vx[2]; ostate = 0; }
+                    if (lane == 0) s_ag[i].carrying = -1;
+                    wave_sync();
                     check_done(i);
                 }
             } else {
@@ -259,11 +263,14 @@ __device__ __forceinline__ void rearrange_tick(const GymView &gv, const int env)
                 else if (o1 >= 0 && o2 < 0) oidx = o1;
                 if (oidx >= 0) {
                     if (isItem && itemIdx == oidx) ostate = 1 + i;
-                    a.carrying = oidx;
+                    if (lane == 0) s_ag[i].carrying = oidx;
+                    wave_sync();
                     check_done(i);
                 }
             }
         }
+        wave_sync();
+    }
 
     // ---- timers / done
     episodeSec += dt;
@@ -282,22 +289,8 @@ __device__ __forceinline__ void rearrange_tick(const GymView &gv, const int env)
         gh->episode_sec = episodeSec; gh->bar_half_width = bar;
         gv.done[env] = (uint8_t)done;
     }
-#pragma unroll
-    for (int i = 0; i < A_MAX; ++i)
-        if (i < A && lane == i) {
-            ag[i].total_reward += ag[i].last_reward;
-            AgentState *dst = gv.agents + (size_t)env * A + i;
-            const AgentState &a = ag[i];
-            dst->pos[0] = a.pos[0]; dst->pos[1] = a.pos[1]; dst->pos[2] = a.pos[2];
-            dst->m00 = a.m00; dst->m02 = a.m02; dst->m20 = a.m20; dst->m22 = a.m22; dst->pitch = a.pitch;
-            dst->hvx = a.hvx; dst->hvz = a.hvz; dst->vvel = a.vvel; dst->voffset = a.voffset;
-            dst->step_offset = a.step_offset; dst->jump_speed = a.jump_speed;
-            dst->was_jumping = a.was_jumping; dst->carrying = a.carrying; dst->picked_up = a.picked_up; dst->visited_zone = a.visited_zone;
-            dst->last_reward = a.last_reward; dst->total_reward = a.total_reward;
-            gv.actions[(size_t)env * A + i] = 0;
-            gv.rewards[(size_t)env * A + i] = a.last_reward;
-            if (done) gv.true_objective[(size_t)env * A + i] = float(solved);   // scenario_rearrange.hpp:94
-        }
+    agents_store(gv, env, A, s_ag);
+    if (done && lane < A) gv.true_objective[(size_t)env * A + lane] = float(solved);   // scenario_rearrange.hpp:94
 
     // ---- the auto-reset of VectorEnv::step: the wave of a finished env swaps the next episode in right here
     if (done) {
@@ -306,19 +299,26 @@ __device__ __forceinline__ void rearrange_tick(const GymView &gv, const int env)
     }
 }
 
-// One workgroup of STEP_THREADS per env: wave 0 runs the tick (one wave per env: physics, scenario logic, auto-reset), the others wait at
-// the barrier; then all of them build the lists of the env's frames (mv_frame.h).  `render` = 0: mv_step_no_render.  The tick needs
-// ~150 VGPRs, i.e. 3 waves per SIMD: with 2 waves per env 1024 envs are resident at once (with 4 they would take two rounds, and a
-// launch lasts as long as its slowest tick PER ROUND: measured 41 us vs 25 us).
+// One workgroup per env: wave 0 runs the tick (one wave per env: physics, scenario logic, auto-reset), the others wait at the barrier;
+// then the workgroup builds the lists of the env's frames (mv_frame.h).  `render` = 0: mv_step_no_render.
+//   one agent:  STEP_THREADS (128) threads work on the env's one frame together.  The tick needs ~150 VGPRs, i.e. 3 waves per SIMD: with
+//               2 waves per env 1024 envs are resident at once (with 4 they take two rounds, and a launch lasts as long as its slowest
+//               tick PER ROUND: measured 41 us vs 25 us);
+//   A agents:   64 min(A, 4) threads, every wave sets up its own frame(s): a frame setup is a chain of dependent loads (~6 us), A of them
+//               one after the other would cost more than the launch the fusion saves.
 template <int A_MAX>
-__global__ __launch_bounds__(STEP_THREADS) void step_rearrange_kernel(GymView gv, int W, int H, int render)
+__global__ __launch_bounds__(256) void step_rearrange_kernel(GymView gv, int W, int H, int render)
 {
+    __shared__ FrameScratch s_fs[A_MAX == 1 ? 1 : 4];
     const int env = blockIdx.x;
     if (threadIdx.x < 64) rearrange_tick<A_MAX>(gv, env);
     if (!render) return;
     __syncthreads();   // the tick's stores (same CU: same L1) before the frame setup's loads
-    const int A = gv.num_agents;
-    for (int a = 0; a < A; ++a) frame_setup_body<STEP_THREADS>(gv, env * A + a, W, H);
+    if (A_MAX == 1) frame_setup_body<STEP_THREADS, false>(gv, env, W, H, s_fs[0]);
+    else {
+        const int A = gv.num_agents, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+        for (int a = wave; a < A; a += nw) frame_setup_body<64, true>(gv, env * A + a, W, H, s_fs[wave]);
+    }
 }
 
 __global__ __launch_bounds__(64) void reset_rearrange_kernel(GymView gv, const RearrangeBlob *blobs, int *status, int force_all)
@@ -331,11 +331,9 @@ __global__ __launch_bounds__(64) void reset_rearrange_kernel(GymView gv, const R
 
 void launch_step_rearrange(const GymView &gv, hipStream_t stream, int W, int H, int render)
 {
-    const dim3 grid(gv.num_envs), block(STEP_THREADS);
+    const dim3 grid(gv.num_envs), block(gv.num_agents == 1 ? STEP_THREADS : 64 * std::min(gv.num_agents, 4));
     if (gv.num_agents == 1) hipLaunchKernelGGL(step_rearrange_kernel<1>, grid, block, 0, stream, gv, W, H, render);
-    else if (gv.num_agents == 2) hipLaunchKernelGGL(step_rearrange_kernel<2>, grid, block, 0, stream, gv, W, H, render);
-    else if (gv.num_agents <= 4) hipLaunchKernelGGL(step_rearrange_kernel<4>, grid, block, 0, stream, gv, W, H, render);
-    else hipLaunchKernelGGL(step_rearrange_kernel<8>, grid, block, 0, stream, gv, W, H, render);
+    else hipLaunchKernelGGL(step_rearrange_kernel<MAX_AGENTS>, grid, block, 0, stream, gv, W, H, render);   // (agent loops are real loops: one multi-agent build)
 }
 
 void launch_reset_rearrange(const GymView &gv, const RearrangeBlob *blobs, int *status, int force_all, hipStream_t stream)
