@@ -35,6 +35,8 @@ void launch_reset_obstacles(const GymView &gv, const EpisodeBlob *blobs, int *st
 void launch_step_rearrange(const GymView &gv, hipStream_t stream, int W, int H, int render);
 void launch_reset_rearrange(const GymView &gv, const RearrangeBlob *blobs, int *status, int force_all, hipStream_t stream);
 void launch_step_collect(const GymView &gv, hipStream_t stream, int W, int H, int render);
+void launch_step_sokoban(const GymView &gv, hipStream_t stream, int W, int H, int render);
+void launch_reset_sokoban(const GymView &gv, const SokobanBlob *blobs, int *status, int force_all, hipStream_t stream);
 void launch_reset_collect(const GymView &gv, const CollectBlob *blobs, int *status, int force_all, hipStream_t stream);
 }  // namespace mv
 
@@ -63,6 +65,9 @@ static const float SHAPING_DEFAULT_OBST[5] = {0.0f, 1.0f, 5.0f, 0.5f, 0.0f};
 // scenario_rearrange.hpp:96-102
 static const char *SHAPING_KEYS_REARRANGE[3] = {"teamSpirit", "rearrangeOneMoreObjectCorrectPosition", "rearrangeAllObjectsCorrectPosition"};
 static const float SHAPING_DEFAULT_REARRANGE[3] = {0.0f, 1.0f, 10.0f};
+// scenario_sokoban.hpp:40-47, teamSpirit 0
+static const char *SHAPING_KEYS_SOKOBAN[4] = {"teamSpirit", "sokobanBoxOnTarget", "sokobanBoxLeavesTarget", "sokobanAllBoxesOnTarget"};
+static const float SHAPING_DEFAULT_SOKOBAN[4] = {0.0f, 1.0f, -1.0f, 10.0f};
 static const char *SHAPING_KEYS_COLLECT[5] = {"teamSpirit", "collectSingleGood", "collectSingleBad", "collectAll", "collectAbyss"};
 static const float SHAPING_DEFAULT_COLLECT[5] = {0.0f, 1.0f, -1.0f, 5.0f, -0.5f};
 static const int ACTION_SPACE[6] = {3, 3, 3, 2, 2, 3};                          // env.cpp:33
@@ -225,6 +230,7 @@ static bool scenario_from_name(const std::string &scen, int &scenario, ObstacleC
         oc.num_platform_types = 1;
     } else if (scen == "collect") scenario = SCN_COLLECT;                              // scenarios/init.hpp:45
     else if (scen == "rearrange") scenario = SCN_REARRANGE;                            // scenarios/init.hpp:49
+    else if (scen == "sokoban") scenario = SCN_SOKOBAN;                                // scenarios/init.hpp:46
     else return false;
     return true;
 }
@@ -240,7 +246,12 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     int scenario = SCN_TOWER;
     ObstacleConfig oc;
     if (!scenario_from_name(scen, scenario, oc))
-        return fail("Unknown scenario " + scen + " (this build accelerates: TowerBuilding, ObstaclesEasy/Medium/Hard/Walls/Steps/Lava, Collect)");
+        return fail("Unknown scenario " + scen + " (this build accelerates: TowerBuilding, ObstaclesEasy/Medium/Hard/Walls/Steps/Lava, Collect, Rearrange, Sokoban)");
+    std::vector<std::string> levelFiles;
+    if (scenario == SCN_SOKOBAN) {   // SokobanScenario's constructor looks the level files up (scenario_sokoban.cpp:40-78); none is fatal there too
+        levelFiles = find_boxoban_level_files();
+        if (levelFiles.empty()) return fail("Sokoban: no Boxoban level files (set BOXOBAN_LEVELS to the directory that holds unfiltered/train/000.txt ...)");
+    }
     if (cfg->num_envs < 1 || cfg->num_agents_per_env < 1 || cfg->num_agents_per_env > MAX_AGENTS)
         return fail("mv_create: num_envs >= 1 and 1 <= num_agents_per_env <= 8 required");
     if (cfg->obs_width < 1 || cfg->obs_height < 1 || cfg->obs_width > 1024 || cfg->obs_height > 1024) return fail("mv_create: observation size must be within 1..1024");
@@ -258,9 +269,9 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     g->w = cfg->obs_width; g->h = cfg->obs_height;
     g->N = cfg->num_envs; g->A = cfg->num_agents_per_env;
     g->scenario = scenario;
-    g->numShaping = scenario == SCN_TOWER ? 4 : scenario == SCN_REARRANGE ? 3 : 5;
+    g->numShaping = scenario == SCN_TOWER || scenario == SCN_SOKOBAN ? 4 : scenario == SCN_REARRANGE ? 3 : 5;
     g->shapingKeys = scenario == SCN_TOWER ? SHAPING_KEYS_TOWER : scenario == SCN_OBSTACLES ? SHAPING_KEYS_OBST
-                   : scenario == SCN_COLLECT ? SHAPING_KEYS_COLLECT : SHAPING_KEYS_REARRANGE;
+                   : scenario == SCN_COLLECT ? SHAPING_KEYS_COLLECT : scenario == SCN_SOKOBAN ? SHAPING_KEYS_SOKOBAN : SHAPING_KEYS_REARRANGE;
     g->envOffset = cfg->total_envs > 0 ? cfg->env_offset : 0;
     g->envStride = cfg->total_envs > 0 && cfg->env_stride > 1 ? cfg->env_stride : 1;
     g->gv.sample_on = 0; g->gv.sample_seed = g->gv.sample_step = 0;
@@ -270,12 +281,12 @@ int mv_create(const mv_config *cfg, mv_gym **out)
 
     GymView &gv = g->gv;
     gv.num_envs = g->N; gv.num_agents = g->A;
-    const bool obstacles = scenario == SCN_OBSTACLES, collect = scenario == SCN_COLLECT, rearrange = scenario == SCN_REARRANGE;
-    const bool hostEpisodes = obstacles || collect || rearrange;
+    const bool obstacles = scenario == SCN_OBSTACLES, collect = scenario == SCN_COLLECT, rearrange = scenario == SCN_REARRANGE, sokoban = scenario == SCN_SOKOBAN;
+    const bool hostEpisodes = obstacles || collect || rearrange || sokoban;
     gv.scenario = scenario;
     gv.box_stride = collect ? COLLECT_MAX_BOXES : MAX_BOXES;
     gv.reward_stride = collect ? COLLECT_MAX_REWARDS : MAX_REWARDS;
-    g->blobBytes = collect ? sizeof(CollectBlob) : obstacles ? sizeof(EpisodeBlob) : rearrange ? sizeof(RearrangeBlob) : 0;
+    g->blobBytes = collect ? sizeof(CollectBlob) : obstacles ? sizeof(EpisodeBlob) : rearrange ? sizeof(RearrangeBlob) : sokoban ? sizeof(SokobanBlob) : 0;
     // ONE arena for all simulator state: a step touches ~8 arrays per env, separate small allocations
     // cost a TLB miss each per wave (measured: 83 % of the physics kernel's time was spent waiting on
     // ~30 memory operations); one large allocation is backed by large pages.
@@ -287,13 +298,13 @@ int mv_create(const mv_config *cfg, mv_gym **out)
                  szObs = up(NA * (size_t)g->w * g->h * 4);
     const size_t szTerrain = obstacles ? up(N * MAX_TERRAIN * sizeof(TerrainBox)) : 0,
                  szRewObj = hostEpisodes ? up(N * (size_t)gv.reward_stride * sizeof(MovableObject)) : 0,
-                 szHeight = collect ? up(N * (size_t)HM_BYTES) : 0, szItems = rearrange ? up(N * MAX_ITEMS * sizeof(ArrangementItem)) : 0, szBlobs = up(N * g->blobBytes * (size_t)g->spares), szCnt = up((N + 2) * sizeof(int32_t));
+                 szHeight = collect ? up(N * (size_t)HM_BYTES) : 0, szItems = rearrange ? up(N * MAX_ITEMS * sizeof(ArrangementItem)) : 0, szCells = sokoban ? up(N * (size_t)(SOKO_DIM * SOKO_DIM)) : 0, szBlobs = up(N * g->blobBytes * (size_t)g->spares), szCnt = up((N + 2) * sizeof(int32_t));
     gv.vis_stride = collect ? 1024 : 256;
     gv.spares = g->spares;
     const size_t szVisP = up(NA * (size_t)gv.vis_stride * 32), szVisR = up(NA * (size_t)gv.vis_stride * 8), szVisC = up(NA * sizeof(int32_t)),
                  szLpt = 2 * up(NA * sizeof(int32_t)) + up(NA * (size_t)FRAME_HDR_BYTES);
     const size_t total = szHdr + szBoxes + szObj + szAg + szAct + szRew + szDone + szObjv + szMd + (hostEpisodes ? 0 : szChunk) + szObs + szTerrain +
-                         szRewObj + szHeight + szItems + szBlobs + szCnt + szVisP + szVisR + szVisC + szLpt;
+                         szRewObj + szHeight + szItems + szCells + szBlobs + szCnt + szVisP + szVisR + szVisC + szLpt;
     {
         hipError_t e_ = hipMalloc((void **)&g->arena, total);
         if (e_ != hipSuccess) { mv_destroy(g); return fail(std::string("hipMalloc arena: ") + hipGetErrorString(e_)); }
@@ -322,6 +333,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
         }
         if (collect) { gv.heightmap = (int8_t *)p; p += szHeight; }
         if (rearrange) { gv.items = (ArrangementItem *)p; p += szItems; }
+        if (sokoban) { gv.soko_cells = p; p += szCells; }
         gv.vis_prims = p; p += szVisP;
         gv.vis_rects = p; p += szVisR;
         gv.vis_count = (int32_t *)p; p += szVisC;
@@ -342,7 +354,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     g->hRewards.assign(NA, 0.0f); g->hTrueObj.assign(NA, 0.0f); g->hDone.assign(N, 0);
 
     // headers: float params + unseeded envs take their seed from random_device (env.hpp:169)
-    float episodeLen = 60.0f, lookLimit = 0.2f;   // scenario.hpp:225-232
+    float episodeLen = sokoban ? 80.0f : 60.0f, lookLimit = 0.2f;   // scenario.hpp:225-232; Sokoban: scenario_sokoban.hpp:49-53
     for (int k = 0; k < cfg->num_params; ++k) {
         const char *key = cfg->param_keys[k];
         const float v = cfg->param_vals[k];
@@ -385,7 +397,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
             mv_destroy(g);
             return fail("mv_create: pinned episode staging allocation failed");
         }
-        g->feeder = std::make_unique<EpisodeFeeder>(scenario, oc, g->N, g->A, episodeLen, g->hBlobs, g->blobBytes, g->device, g->feederThreads);
+        g->feeder = std::make_unique<EpisodeFeeder>(scenario, oc, g->N, g->A, episodeLen, g->hBlobs, g->blobBytes, g->device, g->feederThreads, levelFiles);
         std::vector<uint32_t> seeds(N);
         std::random_device rdev;   // unseeded envs take their seed from random_device (env.hpp:169)
         for (auto &v : seeds) v = (uint32_t)rdev();
@@ -406,6 +418,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
         for (int k = 0; k < g->numShaping; ++k)
             ha[i].shaping[k] = scenario == SCN_TOWER ? SHAPING_DEFAULT_TOWER[k] : scenario == SCN_COLLECT ? SHAPING_DEFAULT_COLLECT[k]
                                                      : scenario == SCN_REARRANGE ? SHAPING_DEFAULT_REARRANGE[k]
+                                                     : scenario == SCN_SOKOBAN ? SHAPING_DEFAULT_SOKOBAN[k]
                                                      : (k == 4 ? oc.carried_object_to_exit : SHAPING_DEFAULT_OBST[k]);
         ha[i].carrying = -1; ha[i].jump_speed = 10.0f; ha[i].m00 = 1.0f; ha[i].m22 = 1.0f;
     }
@@ -608,7 +621,8 @@ static int refill_episodes(mv_gym *g)
             if (!must && !g->feeder->is_ready(i, need)) { deficit += consumed + K - g->uploaded[i]; continue; }   // later
             size_t bytes = 0;
             const uint8_t *src = g->feeder->wait_ready(i, need, &bytes);
-            if (!src) return fail("episode feeder: episode " + std::to_string(need) + " of env " + std::to_string(i) + " was never generated");
+            if (!src) return fail(g->feeder->failed() ? std::string("episode feeder: a level file could not be read (Sokoban)")
+                                                      : "episode feeder: episode " + std::to_string(need) + " of env " + std::to_string(i) + " was never generated");
             if (!waited && g->stepDoneValid) { HIP_TRY(hipStreamWaitEvent(g->copyStream, g->stepDone, 0)); waited = true; }
             HIP_TRY(hipMemcpyAsync(g->dBlobs + ((size_t)i * K + (size_t)((need - 1) % K)) * g->blobBytes, src, bytes, hipMemcpyHostToDevice, g->copyStream));
             ++g->uploaded[i];
@@ -654,6 +668,7 @@ int mv_reset(mv_gym *g)
         if (refill_episodes(g)) return -1;              // every env has an unconsumed episode resident
         if (g->scenario == SCN_OBSTACLES) launch_reset_obstacles(g->gv, (const EpisodeBlob *)g->dBlobs, g->dStatus, 1, g->stream);
         else if (g->scenario == SCN_REARRANGE) launch_reset_rearrange(g->gv, (const RearrangeBlob *)g->dBlobs, g->dStatus, 1, g->stream);
+        else if (g->scenario == SCN_SOKOBAN) launch_reset_sokoban(g->gv, (const SokobanBlob *)g->dBlobs, g->dStatus, 1, g->stream);
         else launch_reset_collect(g->gv, (const CollectBlob *)g->dBlobs, g->dStatus, 1, g->stream);
         HIP_TRY(hipEventRecord(g->stepDone, g->stream));   // (the reset kernel reads the ring too)
         g->stepDoneValid = true;
@@ -735,6 +750,7 @@ static int step_impl(mv_gym *g, bool render)
     if (g->scenario == SCN_OBSTACLES) launch_step_obstacles(g->gv, g->stream, g->w, g->h, fused);
     else if (g->scenario == SCN_COLLECT) launch_step_collect(g->gv, g->stream, g->w, g->h, fused);
     else if (g->scenario == SCN_REARRANGE) launch_step_rearrange(g->gv, g->stream, g->w, g->h, fused);
+    else if (g->scenario == SCN_SOKOBAN) launch_step_sokoban(g->gv, g->stream, g->w, g->h, fused);
     else launch_step(g->gv, g->stream, g->w, g->h, fused);
     if (prof) HIP_TRY(hipEventRecord(ev[1], g->stream));
     // (every step kernel regenerates / swaps the next episode into the envs it finishes)
@@ -937,7 +953,7 @@ struct Snap {
     uint8_t chunk[CHUNK_BYTES];
     int8_t heightmap[HM_DIM * HM_DIM];
     int32_t num_items, items[MAX_ITEMS][5];
-    uint8_t soko[32 * 32];   // Sokoban level cells (oracle only so far): always zero here
+    uint8_t soko[32 * 32];   // Sokoban level cells
 };
 #pragma pack(pop)
 
@@ -981,6 +997,7 @@ int mv_debug_snapshot(mv_gym *g, int32_t env, void *out)
             s->items[i][2] = its[i].off[0]; s->items[i][3] = its[i].off[1]; s->items[i][4] = its[i].off[2];
         }
     }
+    if (e == hipSuccess && g->gv.soko_cells) e = hipMemcpy(s->soko, g->gv.soko_cells + (size_t)env * (SOKO_DIM * SOKO_DIM), SOKO_DIM * SOKO_DIM, hipMemcpyDeviceToHost);
     std::memset(s->heightmap, 0xff, sizeof s->heightmap);
     if (e == hipSuccess && g->gv.heightmap) e = hipMemcpy(s->heightmap, g->gv.heightmap + (size_t)env * HM_BYTES, sizeof s->heightmap, hipMemcpyDeviceToHost);
     if (e != hipSuccess) { delete s; return fail(std::string("mv_debug_snapshot: ") + hipGetErrorString(e)); }
@@ -1032,8 +1049,8 @@ int mv_debug_generate_episode(const char *scenario_name, int32_t num_agents, int
 {
     int scenario = SCN_TOWER;
     ObstacleConfig oc;
-    if (!scenario_name || !scenario_from_name(lower(scenario_name), scenario, oc) || scenario == SCN_TOWER)
-        return fail("mv_debug_generate_episode: host-generated scenarios are the Obstacles family and Collect");
+    if (!scenario_name || !scenario_from_name(lower(scenario_name), scenario, oc) || scenario == SCN_TOWER || scenario == SCN_SOKOBAN)
+        return fail("mv_debug_generate_episode: the Obstacles family, Collect and Rearrange (Sokoban: mv_debug_generate_sokoban)");
     if (num_agents < 1 || num_agents > MAX_AGENTS || n < 1) return fail("mv_debug_generate_episode: bad arguments");
     const size_t bytes = scenario == SCN_COLLECT ? sizeof(CollectBlob) : scenario == SCN_REARRANGE ? sizeof(RearrangeBlob) : sizeof(EpisodeBlob);
     if (!out) return (int)bytes;
@@ -1057,8 +1074,8 @@ int mv_debug_feeder_selftest(const char *scenario_name, int32_t num_envs, int32_
 {
     int scenario = SCN_TOWER;
     ObstacleConfig oc;
-    if (!scenario_name || !scenario_from_name(lower(scenario_name), scenario, oc) || scenario == SCN_TOWER)
-        return fail("mv_debug_feeder_selftest: host-generated scenarios only");
+    if (!scenario_name || !scenario_from_name(lower(scenario_name), scenario, oc) || scenario == SCN_TOWER || scenario == SCN_SOKOBAN)
+        return fail("mv_debug_feeder_selftest: the Obstacles family, Collect and Rearrange");
     const size_t bytes = scenario == SCN_COLLECT ? sizeof(CollectBlob) : scenario == SCN_REARRANGE ? sizeof(RearrangeBlob) : sizeof(EpisodeBlob);
     std::vector<uint8_t> slots((size_t)num_envs * bytes, 0), want(bytes);
     std::vector<uint32_t> seeds(num_envs);

@@ -7,9 +7,10 @@
 namespace mv {
 
 EpisodeFeeder::EpisodeFeeder(int scenario, const ObstacleConfig &cfg, int num_envs, int num_agents, float base_episode_len, uint8_t *slots,
-                             size_t slot_bytes, int device, int num_threads)
+                             size_t slot_bytes, int device, int num_threads, std::vector<std::string> level_files)
     : scenario_{scenario}, num_envs_{num_envs}, num_agents_{num_agents}, device_{device}, cfg_{cfg}, base_len_{base_episode_len},
-      slots_{slots}, slot_bytes_{slot_bytes}, rng_(num_envs), next_seq_(num_envs, 1), ready_seq_(num_envs), used_bytes_(num_envs, 0)
+      slots_{slots}, slot_bytes_{slot_bytes}, rng_(num_envs), next_seq_(num_envs, 1), ready_seq_(num_envs), used_bytes_(num_envs, 0),
+      soko_files_{std::move(level_files)}, soko_levels_(scenario == SCN_SOKOBAN ? num_envs : 0), soko_undo_(scenario == SCN_SOKOBAN ? num_envs : 0)
 {
     std::random_device rd;   // unseeded envs: Env::EnvState::rng{std::random_device{}()} (env.hpp:169)
     for (int i = 0; i < num_envs; ++i) { rng_[i].seed(rd()); ready_seq_[i].store(0, std::memory_order_relaxed); }
@@ -32,6 +33,15 @@ void EpisodeFeeder::reseed(const std::vector<uint32_t> &values, const std::vecto
     tasks_.clear();                                           // not started yet: their episodes would come from the old streams
     cv_done_.wait(lk, [this] { return in_flight_ == 0; });    // started ones finish first (they own rng_[env])
     for (int i = 0; i < num_envs_; ++i) {
+        if (scenario_ == SCN_SOKOBAN) {   // episodes first_seq .. next_seq - 1 were generated ahead and are dropped: undo what they took
+            std::deque<SokoUndo> &undo = soko_undo_[i];
+            for (int q = next_seq_[i] - 1; q >= first_seq[i] && !undo.empty(); --q) {
+                if (undo.back().reloaded) soko_levels_[i].pending.clear();
+                else soko_levels_[i].pending.push_back(std::move(undo.back().level));
+                undo.pop_back();
+            }
+            undo.clear();
+        }
         rng_[i].seed((unsigned long)values[i]);               // Env::seed, env.cpp:52-55
         next_seq_[i] = first_seq[i];
         ready_seq_[i].store(0, std::memory_order_release);
@@ -43,11 +53,12 @@ void EpisodeFeeder::reseed(const std::vector<uint32_t> &values, const std::vecto
 
 const uint8_t *EpisodeFeeder::wait_ready(int env, int seq, size_t *used_bytes)
 {
+    if (failed()) return nullptr;
     if (ready_seq_[env].load(std::memory_order_acquire) != seq) {
         std::unique_lock<std::mutex> lk(mu_);
         // a healthy pool needs well under a millisecond per episode; a minute means the protocol was violated
         // (asking for an episode that was never scheduled): fail loudly instead of hanging the caller
-        if (!cv_done_.wait_for(lk, std::chrono::seconds(60), [&] { return ready_seq_[env].load(std::memory_order_acquire) == seq; }))
+        if (!cv_done_.wait_for(lk, std::chrono::seconds(60), [&] { return failed() || ready_seq_[env].load(std::memory_order_acquire) == seq; }) || failed())
             return nullptr;
     }
     if (used_bytes) *used_bytes = used_bytes_[env];
@@ -76,6 +87,19 @@ void EpisodeFeeder::generate(int env)
         RearrangeBlob &b = *reinterpret_cast<RearrangeBlob *>(slot);
         generate_rearrange_episode(rng_[env], num_agents_, base_len_, b);
         b.seq = seq;
+    } else if (scenario_ == SCN_SOKOBAN) {
+        SokobanBlob &b = *reinterpret_cast<SokobanBlob *>(slot);
+        SokobanLevels &levels = soko_levels_[env];
+        SokoUndo undo;
+        undo.reloaded = levels.pending.empty();
+        if (!undo.reloaded) undo.level = levels.pending.back();
+        if (!generate_sokoban_episode(rng_[env], levels, soko_files_, num_agents_, base_len_, b)) {
+            failed_.store(true, std::memory_order_release);
+            return;
+        }
+        b.seq = seq;
+        soko_undo_[env].push_back(std::move(undo));
+        while (soko_undo_[env].size() > 8) soko_undo_[env].pop_front();   // never more than spares + 1 episodes ahead
     } else {
         CollectBlob &b = *reinterpret_cast<CollectBlob *>(slot);
         generate_collect_episode(rng_[env], num_agents_, base_len_, b);

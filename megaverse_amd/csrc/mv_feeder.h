@@ -15,6 +15,7 @@
 #include <deque>
 #include <mutex>
 #include <random>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -25,8 +26,9 @@ namespace mv {
 class EpisodeFeeder {
 public:
     // slots: pinned host memory, num_envs * slot_bytes, owned by the caller
+    // level_files: Sokoban only (the Boxoban level files found at construction, scenario_sokoban.cpp:40-78)
     EpisodeFeeder(int scenario, const ObstacleConfig &cfg, int num_envs, int num_agents, float base_episode_len, uint8_t *slots,
-                  size_t slot_bytes, int device, int num_threads);
+                  size_t slot_bytes, int device, int num_threads, std::vector<std::string> level_files = {});
     ~EpisodeFeeder();
     EpisodeFeeder(const EpisodeFeeder &) = delete;
     EpisodeFeeder &operator=(const EpisodeFeeder &) = delete;
@@ -45,6 +47,7 @@ public:
     void recycle(int env, hipEvent_t copied);
 
     int num_threads() const { return int(workers_.size()); }
+    bool failed() const { return failed_.load(std::memory_order_acquire); }   // a generator gave up (Sokoban: unreadable level file)
 
 private:
     struct Task { int env; hipEvent_t after; };
@@ -66,6 +69,13 @@ private:
     int in_flight_ = 0;
     bool stop_ = false;
     std::vector<std::thread> workers_;
+    std::atomic<bool> failed_{false};
+    // Sokoban keeps state across episodes and across Env::seed: the shuffled rest of the level file picked last
+    // (SokobanScenario::levels).  Episodes generated ahead of a re-seed are dropped, so what they took from that list is put back.
+    struct SokoUndo { bool reloaded; std::vector<std::string> level; };
+    std::vector<std::string> soko_files_;
+    std::vector<SokobanLevels> soko_levels_;
+    std::vector<std::deque<SokoUndo>> soko_undo_;
 };
 
 }  // namespace mv

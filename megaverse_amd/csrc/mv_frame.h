@@ -189,7 +189,10 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
     const int scen = hdr->scenario;
     const int nLayout = hdr->num_boxes;
     const bool rearrange = scen == SCN_REARRANGE;   // its "terrain" slots: 9 static boxes, then the target arrangement's items
-    const int slotTerrain = nLayout, nTerrainSlots = scen == SCN_TOWER ? 1 : rearrange ? NUM_STATIC + hdr->num_terrain : hdr->num_terrain;
+    const bool sokoban = scen == SCN_SOKOBAN;       // its "terrain" slots: one per level cell (wall cap / goal pad / nothing), x-major
+    const int sokoW = sokoban ? max(hdr->W, 1) : 1;
+    const int slotTerrain = nLayout, nTerrainSlots = scen == SCN_TOWER ? 1 : rearrange ? NUM_STATIC + hdr->num_terrain
+                                                   : sokoban ? hdr->L * sokoW : hdr->num_terrain;
     const int slotObjects = slotTerrain + nTerrainSlots;
     const int slotRewards = slotObjects + hdr->num_objects, nRewardSlots = scen == SCN_TOWER ? 0 : 2 * hdr->num_rewards;
     const int slotAgents = slotRewards + nRewardSlots;
@@ -213,6 +216,9 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
                     kind = PRIM_BOX;
                     lo[0] = float(b.min[0]); lo[1] = float(b.min[1]); lo[2] = float(b.min[2]);
                     hi[0] = float(b.max[0]); hi[1] = float(b.max[1]); hi[2] = float(b.max[2]);
+                    if (sokoban) {   // addBoundingBoxes scales by the voxel size, 2 (layout_utils.cpp:22-34, scenario_sokoban.cpp:104-120)
+                        lo[0] *= 2.0f; lo[1] *= 2.0f; lo[2] *= 2.0f; hi[0] *= 2.0f; hi[1] *= 2.0f; hi[2] *= 2.0f;
+                    }
                     color = (unsigned)(b.slot == 0 ? hdr->layout_color : hdr->wall_color);
                 }
             } else if (slot < slotObjects) {
@@ -235,6 +241,16 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
                             kind = it.shape == SHAPE_SPHERE ? PRIM_SPHERE_S : it.shape == SHAPE_CAPSULE ? PRIM_CAPSULE_S : PRIM_CYLINDER_S;
                             lo[0] = cx; lo[1] = cy; lo[2] = cz; hi[0] = sc.x; hi[1] = sc.y; hi[2] = sc.z;
                         }
+                    }
+                } else if (sokoban) {   // wall caps (0.7 high: the walls themselves are not drawn) and goal pads, scenario_sokoban.cpp:243-273
+                    const int j = slot - slotTerrain, cxi = j / sokoW, czi = j - cxi * sokoW;
+                    const int t = cxi < SOKO_DIM && czi < SOKO_DIM ? (int)gv.soko_cells[(size_t)env * (SOKO_DIM * SOKO_DIM) + cxi * SOKO_DIM + czi] : 0;
+                    if (t) {
+                        const float hh = t == SOKO_WALL ? 0.35f : 0.025f;
+                        const float cx = 2.0f * float(cxi) + 2.0f / 2, cy = 2.0f + hh, cz = 2.0f * float(czi) + 2.0f / 2;
+                        kind = PRIM_BOX;
+                        lo[0] = cx - 1.0f; lo[1] = cy - hh; lo[2] = cz - 1.0f; hi[0] = cx + 1.0f; hi[1] = cy + hh; hi[2] = cz + 1.0f;
+                        color = t == SOKO_WALL ? 0xffa770u : 0x50c878u;   // LIGHT_ORANGE / LIGHT_GREEN
                     }
                 } else if (scen == SCN_TOWER) {   // building-zone slab (layout_utils.cpp:53-68)
                     kind = PRIM_BOX;
@@ -268,6 +284,11 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
                         kind = it.shape == SHAPE_SPHERE ? PRIM_SPHERE_S : it.shape == SHAPE_CAPSULE ? PRIM_CAPSULE_S : PRIM_CYLINDER_S;
                         lo[0] = cx; lo[1] = cy; lo[2] = cz; hi[0] = sc.x; hi[1] = sc.y; hi[2] = sc.z;
                     }
+                } else if (sokoban) {   // the pushable boxes, scenario_sokoban.cpp:275-293: half extents (0.8, 0.36, 0.8) at (x + 0.5, y + 0.2, z + 0.5) voxels
+                    const float sx = (2.0f / 2) * 0.8f, sy = 0.45f * 0.8f;
+                    const float cx = (float(o.x) + 0.5f) * 2.0f, cy = (float(o.y) + 0.2f) * 2.0f, cz = (float(o.z) + 0.5f) * 2.0f;
+                    color = 0x3a7fa6u;   // DARK_BLUE
+                    lo[0] = cx - sx; lo[1] = cy - sy; lo[2] = cz - sx; hi[0] = cx + sx; hi[1] = cy + sy; hi[2] = cz + sx;
                 } else if (o.state <= 0) {
                     const float cx = float(o.x) + 0.5f, cy = float(o.y) + 0.5f, cz = float(o.z) + 0.5f;
                     lo[0] = cx - OBJ_HALF; lo[1] = cy - OBJ_HALF; lo[2] = cz - OBJ_HALF;

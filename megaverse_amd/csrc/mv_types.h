@@ -110,6 +110,7 @@ struct GymView {
     MovableObject *rewards_obj;// [N][reward_stride] (Obstacles: green diamonds; Collect: green/red diamonds)
     int8_t *heightmap;         // [N][HM_BYTES]      (Collect: top solid y of column x * HM_DIM + z, -1 = no voxels)
     ArrangementItem *items;    // [N][MAX_ITEMS]     (Rearrange: the target arrangement; hdr.num_terrain holds the item count)
+    uint8_t *soko_cells;       // [N][SOKO_DIM * SOKO_DIM] (Sokoban: SOKO_WALL / SOKO_GOAL per level cell, [x * SOKO_DIM + z])
     int32_t *episode_status;   // [N + 2] episodes consumed per env (host-generated scenarios), their total, error flags (ST_*)
     const void *blobs;         // [N][spares] resident next episodes (EpisodeBlob / CollectBlob / RearrangeBlob / SokobanBlob): episode
                                // number q (1-based) of an env lives in ring slot (q - 1) % spares
@@ -158,7 +159,7 @@ struct alignas(16) RearrangeBlob {
     MovableObject objects[MAX_ITEMS];
 };
 
-// Sokoban episode (host generator only so far: the kernels for it are not written yet, mv_create rejects the name)
+// Sokoban episode (mv_gen_sokoban.cpp -> mv_step_sokoban.hip)
 struct alignas(16) SokobanBlob {
     int32_t seq;
     int32_t num_boxes, num_objects;
