@@ -181,6 +181,8 @@ def main():
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device(device))
 
+    if args.scenario.lower() == "sokoban":   # level files: $BOXOBAN_LEVELS, else the synthetic Boxoban-format set the tests use
+        os.environ.setdefault("BOXOBAN_LEVELS", os.path.join(ROOT, "tests", "golden", "boxoban"))
     W, H = args.obs
     n_env, A = args.envs_per_gpu, args.agents
     mixed = args.scenario.lower() == "mixed"

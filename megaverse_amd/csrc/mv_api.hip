@@ -302,7 +302,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     gv.vis_stride = collect ? 1024 : 256;
     gv.spares = g->spares;
     const size_t szVisP = up(NA * (size_t)gv.vis_stride * 32), szVisR = up(NA * (size_t)gv.vis_stride * 8), szVisC = up(NA * sizeof(int32_t)),
-                 szLpt = 2 * up(NA * sizeof(int32_t)) + up(NA * (size_t)FRAME_HDR_BYTES);
+                 szLpt = up(NA * sizeof(int32_t)) + up((NA + 1) * sizeof(int32_t)) + up(NA * (size_t)FRAME_HDR_BYTES);
     const size_t total = szHdr + szBoxes + szObj + szAg + szAct + szRew + szDone + szObjv + szMd + (hostEpisodes ? 0 : szChunk) + szObs + szTerrain +
                          szRewObj + szHeight + szItems + szCells + szBlobs + szCnt + szVisP + szVisR + szVisC + szLpt;
     {
@@ -338,7 +338,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
         gv.vis_rects = p; p += szVisR;
         gv.vis_count = (int32_t *)p; p += szVisC;
         gv.lpt_bucket = (int32_t *)p; p += up(NA * sizeof(int32_t));
-        gv.lpt_order = (int32_t *)p; p += up(NA * sizeof(int32_t));
+        gv.lpt_order = (int32_t *)p; p += up((NA + 1) * sizeof(int32_t));
         gv.vis_hdr = p; p += up(NA * (size_t)FRAME_HDR_BYTES);
     }
     if (const char *e = getenv("MV_PIXEL_MODE")) g->fastPixels = lower(e) == "exact" ? 0 : 1;

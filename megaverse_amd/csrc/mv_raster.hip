@@ -250,15 +250,30 @@ __global__ __launch_bounds__(256) void frame_setup_kernel(GymView gv, int W, int
 // frame_setup_kernel does it" variant was slower: its device-scope fences write back every XCD's L2, 22 us vs 6 us.)
 __global__ __launch_bounds__(1024) void frame_order_kernel(GymView gv, int frames, int *order)
 {
-    __shared__ int s_hist[LPT_BUCKETS], s_start[LPT_BUCKETS];
+    __shared__ int s_hist[LPT_BUCKETS], s_start[LPT_BUCKETS], s_wsum[LPT_BUCKETS / 64];
     const int tid = threadIdx.x;
     if (tid < LPT_BUCKETS) s_hist[tid] = 0;
     __syncthreads();
     for (int f = tid; f < frames; f += 1024) atomicAdd(&s_hist[gv.lpt_bucket[f]], 1);
     __syncthreads();
-    if (tid == 0) {   // 256 bins: a serial scan is a few hundred cycles, once per step
-        int acc = 0;
-        for (int b = LPT_BUCKETS - 1; b >= 0; --b) { s_start[b] = acc; acc += s_hist[b]; }
+    {   // start of every bin in descending cost order: exclusive prefix sum over r = 255 - bin, one thread per bin (a serial scan by one
+        // thread was most of this kernel's 5 us)
+        const int lane = tid & 63, wave = tid >> 6;
+        const int b = LPT_BUCKETS - 1 - tid;
+        const int h = tid < LPT_BUCKETS ? s_hist[b] : 0;
+        int x = h;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int y = __shfl_up(x, off, 64);
+            if (lane >= off) x += y;
+        }
+        if (lane == 63 && tid < LPT_BUCKETS) s_wsum[wave] = x;
+        __syncthreads();
+        if (tid < LPT_BUCKETS) {
+            int base = 0;
+            for (int w = 0; w < wave; ++w) base += s_wsum[w];
+            s_start[b] = base + x - h;
+        }
     }
     __syncthreads();
     for (int f = tid; f < frames; f += 1024) order[atomicAdd(&s_start[gv.lpt_bucket[f]], 1)] = f;
@@ -785,8 +800,7 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
     const int tiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H * PPL - 1) / (TILE_H * PPL));
     const int frames = gv.num_envs * gv.num_agents;
     if (!setup_done) hipLaunchKernelGGL(frame_setup_kernel, dim3(frames), dim3(256), 0, stream, gv, W, H);
-    static const bool noSort = getenv("MV_RASTER_NOSORT") != nullptr;   // (experiment: identity order, as initialised by mv_create)
-    if (!noSort) hipLaunchKernelGGL(frame_order_kernel, dim3(1), dim3(1024), 0, stream, gv, frames, gv.lpt_order);
+    hipLaunchKernelGGL(frame_order_kernel, dim3(1), dim3(1024), 0, stream, gv, frames, gv.lpt_order);
     if (between) (void)hipEventRecord(between, stream);
     if (fast) {
         const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)W * sizeof(float) + (size_t)H * sizeof(float2);
@@ -796,13 +810,14 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
         // 8 and for 6 waves per SIMD (64 / 80 VGPRs), MV_FAST_WAVES picks
         static const int wavesSel = getenv("MV_FAST_WAVES") ? atoi(getenv("MV_FAST_WAVES")) : 8;
         using KernelFn = void (*)(FastArgs, uint32_t *, int, int, int);
-        const int variant = gv.vis_stride > VIS_SMALL ? 2 : gv.scenario == SCN_REARRANGE ? 1 : 0;
-        KernelFn fn = variant == 2 ? raster_fast_kernel<VIS_LARGE, false, 3>
-                    : variant == 1 ? (wavesSel >= 8 ? raster_fast_kernel<VIS_SMALL, true, 8> : raster_fast_kernel<VIS_SMALL, true, 6>)
-                                   : (wavesSel >= 8 ? raster_fast_kernel<VIS_SMALL, false, 8> : raster_fast_kernel<VIS_SMALL, false, 6>);
         FastArgs fa;
         fa.vis_hdr = gv.vis_hdr; fa.vis_prims = reinterpret_cast<const Prim *>(gv.vis_prims); fa.vis_rects = reinterpret_cast<const short4 *>(gv.vis_rects);
         fa.order = gv.lpt_order; fa.num_agents = gv.num_agents; fa.vis_stride = gv.vis_stride; fa.frames = frames;
+        // (Collect, measured and rejected: a 1024-entry launch for the frames above 256 visible primitives + a 256-entry launch for the rest,
+        // 75 + 69 us against 107 us for the single 1024-entry launch: each launch pays its own tail, and the cones, not occupancy, dominate)
+        KernelFn fn = gv.vis_stride > VIS_SMALL ? raster_fast_kernel<VIS_LARGE, false, 3>
+                    : gv.scenario == SCN_REARRANGE ? (wavesSel >= 8 ? raster_fast_kernel<VIS_SMALL, true, 8> : raster_fast_kernel<VIS_SMALL, true, 6>)
+                                                   : (wavesSel >= 8 ? raster_fast_kernel<VIS_SMALL, false, 8> : raster_fast_kernel<VIS_SMALL, false, 6>);
         hipLaunchKernelGGL(fn, dim3(frames * split), dim3(256), dyn, stream, fa, obs, W, H, split);
         return 0;
     }

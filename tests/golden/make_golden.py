@@ -84,3 +84,5 @@ if __name__ == "__main__":
     make("obstacles_easy_a1", N=6, A=1, steps=1200, trace_every=100, W=32, H=32, scenario="ObstaclesEasy", seed=11)
     make("collect_a2", N=5, A=2, steps=1100, trace_every=100, W=64, H=64, scenario="Collect", seed=3)
     make("rearrange_a4", N=4, A=4, steps=1000, trace_every=100, W=64, H=64, scenario="Rearrange", seed=9)
+    os.environ.setdefault("BOXOBAN_LEVELS", os.path.join(HERE, "boxoban"))   # synthetic levels in the public Boxoban text format
+    make("sokoban_a2", N=6, A=2, steps=1300, trace_every=100, W=64, H=64, scenario="Sokoban", seed=4, action_seed=6)

@@ -124,8 +124,10 @@ def test_auto_reset_parity_with_short_episodes(hip):
     og.close(); hg.close()
 
 
-@pytest.mark.parametrize("name", ["tower_a1", "tower_a4", "tower_short_episodes", "obstacles_hard_a2", "obstacles_easy_a1", "collect_a2", "rearrange_a4"])
-def test_hip_reproduces_committed_golden(hip, name):
+@pytest.mark.parametrize("name", ["tower_a1", "tower_a4", "tower_short_episodes", "obstacles_hard_a2", "obstacles_easy_a1", "collect_a2", "rearrange_a4",
+                                  "sokoban_a2"])
+def test_hip_reproduces_committed_golden(hip, name, monkeypatch):
+    monkeypatch.setenv("BOXOBAN_LEVELS", os.path.join(GOLDEN, "boxoban"))
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     N, A, steps, every, W, H = (int(z[k]) for k in ("N", "A", "steps", "trace_every", "W", "H"))
     params = dict(zip(z["param_keys"].tolist(), [float(v) for v in z["param_vals"]])) if "param_keys" in z else {}
