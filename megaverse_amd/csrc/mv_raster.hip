@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 && !SHAPES ? MV_RASTER_WAVES : M
 // is bit-identical to the exact kernel's), same drawables and depth order -- but
 //   * reciprocals / square roots are single v_rcp_f32 / v_rsq_f32 / v_sqrt_f32 (1 ulp) instead of the correctly rounded
 //     sequences; a zero direction component needs no special case (lo * inf is +-inf, 0 * inf = NaN loses every min/max);
-//   * (depth, list position) is ONE 32-bit key -- the depth's float bits with the low POS_BITS replaced by the position --
+//   * (depth, list position) is ONE 32-bit key -- the depth's float bits (relative to NEAR_Z's) with the low POS_BITS replaced by the position --
 //     so the nearest-hit update is a single v_min_u32 (depths closer than 2^-15 relative resolve to the earlier drawable,
 //     like exact ties do);
 //   * Phong for boxes works from per-face constants: for a planar face N.(L - P) = N.L - (plane offset), and the plane
@@ -537,8 +537,8 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 && !SHAPES ? MV_RASTER_WAVES : M
 //   * colour = byte * (AMB + DIFL * intensity) + 255 * spec, rounded, saturated and packed by v_cvt_pk_u8_f32.
 // Structure: `split` workgroups per frame (interleaved tile groups), launched most-expensive-frame-first -- the hardware
 // dispatcher is the work queue.  The prologue is a plain copy (frame_setup_kernel leaves cameras, light vectors, world-box
-// masks and the count in a per-frame header) with ONE barrier; world-frame boxes are traced two at a time (one LDS round
-// trip per pair, two independent dependency chains); everything wave-uniform is kept in SGPRs explicitly.
+// masks and the count in a per-frame header) with ONE barrier; the world-frame box loop fetches the next record from LDS while it
+// intersects the current one; everything wave-uniform is kept in SGPRs explicitly.
 // Pixels differ from the exact kernel / the oracle by at most one 8-bit step in ~5e-5 of the pixels, and by more only where a
 // silhouette or a depth near-tie falls within rounding of a pixel centre, ~1e-6 (tests/test_fast_pixels_gpu.py).
 // =====================================================================================================================
@@ -583,6 +583,28 @@ __device__ __forceinline__ V3 lds_tmul(lds_float *m, V3 v)   // mat_tmul with th
 __device__ __forceinline__ V3 lds_mul(lds_float *m, V3 v)
 {
     return v3((m[0] * v.x + m[1] * v.y) + m[2] * v.z, (m[3] * v.x + m[4] * v.y) + m[5] * v.z, (m[6] * v.x + m[7] * v.y) + m[8] * v.z);
+}
+
+// Depth keys.  A hit's key is (bits(t) - bits(NEAR_Z)) with the low bits replaced by the list position: for NEAR_Z <= t <= FAR_Z it is
+// at most KEY_FAR, and anything else -- t < NEAR_Z (the subtraction wraps), negative, NaN, beyond FAR_Z -- is larger: the range test of
+// the exact kernel costs nothing per primitive, only one compare per pixel at the end.
+constexpr unsigned KEY_NEAR = 0x3c23d70au;   // bits of NEAR_Z = 0.01f
+constexpr unsigned KEY_FAR = 0x42f00000u - KEY_NEAR;   // bits of FAR_Z = 120.0f, relative
+static_assert(NEAR_Z == 0.01f && FAR_Z == 120.0f, "update KEY_NEAR / KEY_FAR");
+
+template <unsigned POS_MASK>
+__device__ __forceinline__ unsigned box_key(V3 inv, const float4 lo, const float4 hi, int pos)
+{
+    const float t1x = lo.x * inv.x, t2x = hi.x * inv.x, t1y = lo.y * inv.y, t2y = hi.y * inv.y, t1z = lo.z * inv.z, t2z = hi.z * inv.z;
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)), __builtin_fminf(t1z, t2z));
+    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)), __builtin_fmaxf(t1z, t2z));
+    const unsigned key = ((__float_as_uint(tn) - KEY_NEAR) & ~POS_MASK) | (unsigned)pos;
+    return tn <= tf ? key : ~0u;
+}
+template <unsigned POS_MASK>
+__device__ __forceinline__ unsigned hit_key(bool hit, float t, int pos)   // other shapes: their intersectors apply the range test themselves
+{
+    return hit ? (((__float_as_uint(t) - KEY_NEAR) & ~POS_MASK) | (unsigned)pos) : ~0u;
 }
 
 // entry depth of a box given relative to the ray origin; +inf/NaN semantics make zero direction components harmless
@@ -689,20 +711,22 @@ __global__ __launch_bounds__(256, WAVES) void raster_fast_kernel(FastArgs fa, ui
                 a2 = s_colq[pxc] + rq.x; ldc = rq.y;
             }
             const unsigned long long wb = uniform_u64(*reinterpret_cast<const unsigned long long *>(s_hdr + FH_WB + 2 * k));
-            // ---- world-frame boxes, two per trip: one LDS wait per pair, two independent chains
+            // ---- world-frame boxes: the next primitive's record is fetched from LDS while the current one is intersected
             unsigned long long m = mvis & wb;
-            while (m) {
-                const int p0 = __ffsll((long long)m) - 1 + 64 * k;
+            if (m) {
+                int p0 = __ffsll((long long)m) - 1 + 64 * k, p1 = 0;
                 m &= m - 1;
-                const int p1 = m ? __ffsll((long long)m) - 1 + 64 * k : p0;
-                m &= m - 1;   // (stays 0 when there was no second one)
-                const float4 lo0 = s_vis[2 * p0], hi0 = s_vis[2 * p0 + 1], lo1 = s_vis[2 * p1], hi1 = s_vis[2 * p1 + 1];
-                float t0, t1;
-                const bool h0 = fast_box(inv, lo0, hi0, t0);
-                const bool h1 = fast_box(inv, lo1, hi1, t1);
-                const unsigned k0 = h0 ? ((__float_as_uint(t0) & ~POS_MASK) | (unsigned)p0) : ~0u;
-                const unsigned k1 = h1 ? ((__float_as_uint(t1) & ~POS_MASK) | (unsigned)p1) : ~0u;
-                best = min(best, min(k0, k1));
+                float4 lo0 = s_vis[2 * p0], hi0 = s_vis[2 * p0 + 1], lo1 = lo0, hi1 = hi0;
+                for (;;) {
+                    bool more = m != 0ull;
+                    if (more) { p1 = __ffsll((long long)m) - 1 + 64 * k; m &= m - 1; lo1 = s_vis[2 * p1]; hi1 = s_vis[2 * p1 + 1]; }
+                    best = min(best, box_key<POS_MASK>(inv, lo0, hi0, p0));
+                    if (!more) break;
+                    more = m != 0ull;
+                    if (more) { p0 = __ffsll((long long)m) - 1 + 64 * k; m &= m - 1; lo0 = s_vis[2 * p0]; hi0 = s_vis[2 * p0 + 1]; }
+                    best = min(best, box_key<POS_MASK>(inv, lo1, hi1, p1));
+                    if (!more) break;
+                }
             }
             // ---- everything else: camera-attached boxes, capsules, cones, scaled shapes
             m = mvis & ~wb;
@@ -728,14 +752,14 @@ __global__ __launch_bounds__(256, WAVES) void raster_fast_kernel(FastArgs fa, ui
                         hit = ray_scaled_shape<true>(qkind, df, v3(lo.x, lo.y, lo.z), v3(hi.x, hi.y, hi.z), t, n);
                     } else hit = false;
                 }
-                const unsigned key = hit ? ((__float_as_uint(t) & ~POS_MASK) | (unsigned)pos) : ~0u;
+                const unsigned key = hit_key<POS_MASK>(hit && t >= NEAR_Z && t <= FAR_Z, t, pos);
                 if (key < best) { best = key; bn = n; }
             }
         }
 
         // ---- Phong (Magnum Shaders::Phong, uniforms of magnum_env_renderer.cpp:200-203)
         unsigned rgba = 0xff000000u;
-        if (best != ~0u) {
+        if (best <= (KEY_FAR | POS_MASK)) {   // a hit between the near and the far plane
             const V3 dc = v3(dcx, dcy, -1.0f);
             const int pos = (int)(best & POS_MASK);
             const float4 lo = s_vis[2 * pos], hi = s_vis[2 * pos + 1];
@@ -757,7 +781,7 @@ __global__ __launch_bounds__(256, WAVES) void raster_fast_kernel(FastArgs fa, ui
                 nv = t * __builtin_fabsf(dk);                                                      // plane offset along the outward normal
                 ndl = nv - __uint_as_float(__float_as_uint(lk) ^ (__float_as_uint(dk) & 0x80000000u));   // sgn (Lrel_k - t d_k), sgn = -sign(d_k)
             } else {   // capsules, cones, scaled shapes: the normal was kept with the hit (depth: the key's, 2^-15 relative)
-                t = __uint_as_float(best & ~POS_MASK);
+                t = __uint_as_float((best & ~POS_MASK) + KEY_NEAR);
                 V3 N;
                 lds_float *cc = local_lds(camv + 3);
                 if (!SHAPES || qkind < PRIM_SPHERE_S || qfr == 0) N = lds_tmul(cc, bn);
