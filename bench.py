@@ -290,8 +290,9 @@ def main():
         # reward objects 64 B; Collect: ~75 merged slabs on average (3000 generated landscapes) * 32 B + 96 diamonds * 4 B
         scene_bytes = (4096 + 512 + 64) if obst else (75 * 32 + 96 * 4) if collect else 512
         bytes_per_frame = W * H * 4 + 128 + scene_bytes + 320 + 128 * A
-        # physics kernel, per env: header R+W + scene + movable boxes R+W + per agent (state R+W, action, reward, objective) + done
-        step_bytes_per_env = 2 * 128 + scene_bytes + 2 * 320 + A * (2 * 128 + 4 + 4 + 4) + 1
+        # physics kernel (tick + frame setup, one launch), per env: header R+W + scene + movable boxes R+W + per agent (state R+W, action,
+        # reward, objective) + done, + per frame the list the raster reads: 800 B header + ~30 visible primitives x 40 B
+        step_bytes_per_env = 2 * 128 + scene_bytes + 2 * 320 + A * (2 * 128 + 4 + 4 + 4) + 1 + A * (800 + 30 * 40)
         line = {
             "metric": METRIC if args.scenario == "TowerBuilding" and (W, H) == (128, 128) else METRIC.replace("TowerBuilding 128x128", f"{args.scenario} {W}x{H}"),
             "value": total_obs / elapsed, "unit": "agent observations/sec", "n_gpus": world,
@@ -329,12 +330,12 @@ def main():
                                 "avg_launch_ms": raster_ms, "launches_timed": prof["raster"][1], "algorithmic_bytes_per_launch": bytes_per_frame * frames,
                                 "note": "dominant kernel; per-launch time from HIP events in a separate untimed loop; traffic = HBM bytes/launch from "
                                         "rocprofv3 PMC (profiles/pmc_traffic.json); ray casting is VALU/issue-bound, the HBM fraction is low by construction"}
-            line["roofline_physics"] = {"bound": "hbm", "kernel": "mv::step_kernel (voxel physics + scenario logic + auto-reset)", "achieved": achieved_step,
+            line["roofline_physics"] = {"bound": "hbm", "kernel": "mv::step_kernel (voxel physics + scenario logic + auto-reset + frame setup)", "achieved": achieved_step,
                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_step / HBM_PEAK_GBS, "traffic": traffic_step,
                                         "avg_launch_ms": step_ms, "launches_timed": prof["step"][1], "algorithmic_bytes_per_launch": step_bytes_per_env * n_env,
                                         "note": "north_star's >=40 % HBM target names this kernel; its working set is 1.7 KB per env (the 16 KB voxel chunk "
                                                 "is not streamed), so it is latency-bound: one wave per env, launch length = slowest wave (DESIGN.md 3.1)"}
-            line["kernels"] = {"frame_setup_and_sort": {"avg_launch_ms": prof["setup"][0]},
+            line["kernels"] = {"frame_setup_and_sort": {"avg_launch_ms": prof["setup"][0], "note": "frame sort only: the frame setup runs inside the step kernel"},
                                "status_readback_gap": {"avg_launch_ms": prof["reset"][0]}}
         line["checksum"] = checksum
         if world == 1 and not args.no_cpu_baseline and not mixed and not dry:   # (the CPU baseline runs one scenario per gym)

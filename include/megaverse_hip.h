@@ -113,12 +113,12 @@ int mv_set_reward_shaping(mv_gym *g, int32_t env_idx, int32_t agent_idx, const c
 
 int mv_synchronize(mv_gym *g);
 
-/* In-stream kernel timing with HIP events on the gym's own stream (bench.py roofline leg).
- * After mv_profile_begin the next max_steps calls of mv_step record events around the four
- * kernels; mv_profile_end synchronises and returns the mean milliseconds and sample count per
- * kernel: [0] step (physics + logic + auto-reset of finished envs), [1] what is left of the former stand-alone
- * reset launch (event overhead, episode-status read-back), [2] frame setup + frame sort, [3] raster.  The counterpart in the reference is
- * the TinyProfiler timers around venv.step() (src/apps/megaverse_test_app.cpp:68-74). */
+/* In-stream kernel timing with HIP events on the gym's own stream (bench.py roofline leg, in a loop of its own: never inside
+ * the timed region).  After mv_profile_begin the next max_steps calls of mv_step record events around the launches;
+ * mv_profile_end synchronises and returns the mean milliseconds and sample count per interval: [0] step kernel (physics + logic +
+ * auto-reset of finished envs + frame setup of the env's frames), [1] status read-back enqueue (every statusPeriod-th step),
+ * [2] frame sort, [3] raster.  The counterpart in the reference is the TinyProfiler timers around venv.step()
+ * (src/apps/megaverse_test_app.cpp:68-74). */
 int mv_profile_begin(mv_gym *g, int32_t max_steps);
 int mv_profile_end(mv_gym *g, float *avg_ms4, int32_t *counts4);
 

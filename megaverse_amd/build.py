@@ -23,10 +23,18 @@ def is_stale():
 
 
 def build(force=False, quiet=True):
-    """hipcc --offload-arch=gfx950 ... -> libmegaverse_hip.so (cross-compiles without a GPU)."""
+    """hipcc --offload-arch=gfx950 ... -> libmegaverse_hip.so (cross-compiles without a GPU).  Several ranks importing the package at
+    once must not run make concurrently: the build is serialised on a lock file, the ranks that waited find the library fresh."""
     if force or is_stale():
-        cmd = ["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 1))] + (["-B"] if force else [])
-        subprocess.check_call(cmd, stdout=subprocess.DEVNULL if quiet else None)
+        import fcntl
+        with open(os.path.join(HERE, ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                if force or is_stale():
+                    cmd = ["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 1))] + (["-B"] if force else [])
+                    subprocess.check_call(cmd, stdout=subprocess.DEVNULL if quiet else None)
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 

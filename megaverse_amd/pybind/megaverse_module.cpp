@@ -11,6 +11,7 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include <cstdlib>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -43,7 +44,13 @@ public:
         cfg.obs_width = w; cfg.obs_height = h;
         cfg.num_envs = num_envs; cfg.num_agents_per_env = num_agents_per_env;
         cfg.num_simulation_threads = num_simulation_threads; cfg.use_vulkan = use_vulkan ? 1 : 0;
-        cfg.device = 0;
+        // The reference's constructor has no device or shard argument (one process = one GPU's worth of envs there too, chosen by
+        // CUDA_VISIBLE_DEVICES).  Through this module the process environment decides: MV_DEVICE, else LOCAL_RANK (torchrun), else 0;
+        // MV_ENV_OFFSET / MV_TOTAL_ENVS place this process's envs in a job-wide seed stream (include/megaverse_hip.h: mv_config).
+        auto env_int = [](const char *name, int fallback) { const char *v = std::getenv(name); return v && *v ? std::atoi(v) : fallback; };
+        cfg.device = env_int("MV_DEVICE", env_int("LOCAL_RANK", 0));
+        cfg.env_offset = env_int("MV_ENV_OFFSET", 0);
+        cfg.total_envs = env_int("MV_TOTAL_ENVS", 0);
         cfg.param_keys = keys.data(); cfg.param_vals = vals.data(); cfg.num_params = int(keys.size());
         check(mv_create(&cfg, &gym_));
     }

@@ -36,7 +36,8 @@ class Wrapper:
         self.num_agents = env.num_agents
         self.is_multiagent = env.is_multiagent
         self.action_space, self.observation_space = env.action_space, env.observation_space
-        self.episode_rewards = [0] * self.num_agents
+        import numpy as np
+        self._returns = np.zeros(self.num_agents, np.float64)
         self.increase_team_spirit = increase_team_spirit
         self.max_team_spirit_steps = max_team_spirit_steps
         self.training_info = {}          # TrainingInfoInterface: the learner writes approx_total_training_steps here
@@ -57,45 +58,58 @@ class Wrapper:
         return self.env.seed(seed)
 
     def reset(self, **kwargs):
-        self.episode_rewards = [0] * self.num_agents
+        self._returns[:] = 0.0
         return self.env.reset(), {}
 
-    def _episode_bookkeeping(self, rewards, dones, infos):
-        name = self.env.scenario_name.casefold()
-        for i, info in enumerate(infos):
-            self.episode_rewards[i] += rewards[i]
-            if dones[i]:
-                extra_stats = info.setdefault("episode_extra_stats", dict())
-                info["true_objective"] = info["true_reward"]
-                extra_stats[f"z_{name}_true_objective"] = info["true_reward"]
-                extra_stats[f"z_{name}_reward"] = self.episode_rewards[i]
-                approx_total_training_steps = self.training_info.get("approx_total_training_steps", 0)
-                extra_stats["z_approx_total_training_steps"] = approx_total_training_steps
-                self.episode_rewards[i] = 0
-                if self.increase_team_spirit:
-                    rew_shaping = self.get_current_reward_shaping(i)
-                    rew_shaping["teamSpirit"] = min(approx_total_training_steps / self.max_team_spirit_steps, 1.0)
-                    self.set_reward_shaping(rew_shaping, i)
-                    extra_stats["teamSpirit"] = rew_shaping["teamSpirit"]
+    @property
+    def episode_rewards(self):
+        """per-agent return of the running episodes (the reference keeps a Python list; here a float64 vector)"""
+        return self._returns.tolist()
+
+    def _finish_episodes(self, rewards, dones, infos):
+        """Vectorised episode statistics (what megaverse_utils.py:61-86 does agent by agent): add the step's rewards to the running
+        returns, then -- only for the agents whose episode ended -- fill the learner-facing keys, anneal teamSpirit and zero the return.
+        `infos` entries of finished agents must carry `true_reward` (MegaverseEnv.step / step_batched put it there)."""
+        import numpy as np
+        self._returns += np.asarray(rewards, dtype=np.float64)
+        finished = np.flatnonzero(np.asarray(dones, dtype=bool))
+        if finished.size == 0:
+            return
+        scenario = self.env.scenario_name.casefold()
+        steps_so_far = self.training_info.get("approx_total_training_steps", 0)
+        team_spirit = min(steps_so_far / self.max_team_spirit_steps, 1.0) if self.increase_team_spirit else None
+        episode_returns = self._returns[finished].tolist()
+        self._returns[finished] = 0.0
+        for i, ret in zip(finished.tolist(), episode_returns):
+            info = infos[i]
+            info["true_objective"] = info["true_reward"]
+            stats = info.setdefault("episode_extra_stats", {})
+            stats.update({f"z_{scenario}_true_objective": info["true_reward"], f"z_{scenario}_reward": ret,
+                          "z_approx_total_training_steps": steps_so_far})
+            if team_spirit is not None:
+                shaping = self.get_current_reward_shaping(i)
+                shaping["teamSpirit"] = team_spirit
+                self.set_reward_shaping(shaping, i)
+                stats["teamSpirit"] = team_spirit
 
     def step(self, action):
         obs, rewards, dones, infos = self.env.step(action)
-        self._episode_bookkeeping(rewards, dones, infos)
+        self._finish_episodes(rewards, dones, infos)
         return obs, rewards, dones, [False] * len(dones), infos
 
     def step_batched(self, actions=None):
         """-> (obs CUDA uint8 (num_agents, 3, H, W) view of the HBM slab, rewards np.float32 [num_agents],
-        terminated np.bool_ [num_agents], truncated, infos) with the same bookkeeping as step()"""
+        terminated np.bool_ [num_agents], truncated, infos) with the same bookkeeping as step(); no per-agent Python work on
+        steps where no episode ends"""
         import numpy as np
         obs, rewards, dones_env = self.env.step_batched(actions)
-        A = self.env.num_agents_per_env
-        dones = np.repeat(dones_env, A)
+        dones = np.repeat(dones_env, self.env.num_agents_per_env)
         infos = [{} for _ in range(self.num_agents)]
         if dones_env.any():
             true_obj = self.env.env.get_true_objectives()
-            for i in np.nonzero(dones)[0]:
-                infos[i] = dict(true_reward=float(true_obj[i]))
-        self._episode_bookkeeping(rewards, dones, infos)
+            for i in np.flatnonzero(dones).tolist():
+                infos[i] = {"true_reward": float(true_obj[i])}
+        self._finish_episodes(rewards, dones, infos)
         return obs, rewards, dones, np.zeros_like(dones), infos
 
     def render(self, *args, **kwargs):
@@ -106,16 +120,16 @@ class Wrapper:
 
 
 def make_megaverse(env_name, cfg=None, env_config=None, render_mode: Optional[str] = None, **kwargs):
-    """megaverse_utils.py:96-122; extra keyword arguments (img_w, img_h, device, ...) go to MegaverseEnv"""
+    """Sample-Factory env factory with the reference's signature (megaverse_utils.py:96-122): `env_name` is a scenario or a
+    `multitask_*` set (the worker index picks the task), `cfg` carries the megaverse_* options (megaverse_params.py:23-54).  Extra
+    keyword arguments (img_w, img_h, device, params, ...) go to MegaverseEnv."""
     cfg = cfg or DEFAULT_CFG
-    scenario_name = env_name.casefold()
-    if "multitask" in scenario_name:
-        task_idx = env_config["worker_index"] if env_config is not None and "worker_index" in env_config else 0
-        env = make_env_multitask(scenario_name, task_idx, num_envs=cfg.megaverse_num_envs_per_instance,
-                                 num_agents_per_env=cfg.megaverse_num_agents_per_env,
-                                 num_simulation_threads=cfg.megaverse_num_simulation_threads, use_vulkan=cfg.megaverse_use_vulkan)
+    sim = dict(num_envs=cfg.megaverse_num_envs_per_instance, num_agents_per_env=cfg.megaverse_num_agents_per_env,
+               num_simulation_threads=cfg.megaverse_num_simulation_threads, use_vulkan=cfg.megaverse_use_vulkan)
+    name = env_name.casefold()
+    if "multitask" in name:
+        worker = (env_config or {}).get("worker_index", 0)
+        env = make_env_multitask(name, worker, **sim)
     else:
-        env = MegaverseEnv(scenario_name=scenario_name, num_envs=cfg.megaverse_num_envs_per_instance,
-                           num_agents_per_env=cfg.megaverse_num_agents_per_env,
-                           num_simulation_threads=cfg.megaverse_num_simulation_threads, use_vulkan=cfg.megaverse_use_vulkan, **kwargs)
+        env = MegaverseEnv(scenario_name=name, **sim, **kwargs)
     return Wrapper(env, cfg.megaverse_increase_team_spirit, cfg.megaverse_max_team_spirit_steps)

@@ -328,6 +328,8 @@ static bool in_building_zone(const Env &e, int x, int z)
     return x >= e.bz[0] && x < e.bz[1] && z >= e.bz[2] && z < e.bz[3];
 }
 
+static int triangular_number(int n) { return n * (n + 1) / 2; }   // util/math_utils.hpp:7-10 (pinned: tests/test_oracle_spec.py)
+
 static float building_reward_coeff(float height)
 {   // scenario_tower_building.cpp:246-251 ; powf(2,h) is exact for integral h
     float res = height * 0.05f;
@@ -549,7 +551,7 @@ struct Plat {
     }
     int requiresBoxes() const
     {
-        auto tri = [](int n) { return n * (n + 1) / 2; };   // util/math_utils.hpp:7-10
+        auto tri = [](int n) { return triangular_number(n); };
         if (kind == PT_WALL) return tri(wallHeight - 1);
         if (kind == PT_LAVA) return std::max(1, lavaLength - 1);
         if (kind == PT_STEP) return tri(stepHeight - 1);
@@ -2672,6 +2674,7 @@ void mvo_shuffle_iota(uint32_t seed, int n, int *out)
 }
 void mvo_get_coords(const float *v, int *out) { voxel_of(v3(v[0], v[1], v[2]), out); }
 float mvo_building_reward_coeff(float h) { return building_reward_coeff(h); }
+int mvo_triangular_number(int n) { return triangular_number(n); }
 void mvo_sincos(float x, float *s, float *c) { mv_sincos(x, s, c); }
 
 }  // extern "C"

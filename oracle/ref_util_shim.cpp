@@ -8,11 +8,16 @@
  * restatement against the real reference functions.  Output goes to oracle/_ref/
  * (git-ignored, travels to the GPU box with the snapshot).
  *
- * Only util.hpp (+ macro.hpp) and the self-contained perlin_noise.hpp are buildable this
- * way: every other header on the hot path pulls in Magnum/Corrade/Bullet, which are not
- * vendored.
+ * Only util.hpp (+ macro.hpp), math_utils.hpp and the self-contained perlin_noise.hpp are buildable
+ * this way: every other header on the hot path pulls in Magnum/Corrade/Bullet, which are not
+ * vendored -- env/const.hpp (colours, parameter names) through util/magnum.hpp,
+ * env/voxel_state.hpp through env/physics.hpp (btBulletDynamicsCommon.h), scenarios/const.hpp
+ * (reward-shaping key strings) through env/const.hpp.  Writing stand-ins for those would be
+ * faking the reference build; their constants stay restated by hand and are checked against the
+ * cited lines by tests/test_oracle_spec.py.
  */
 #include <util/util.hpp>
+#include <util/math_utils.hpp>
 #include <util/perlin_noise.hpp>
 
 extern "C" {
@@ -43,6 +48,9 @@ void mvref_env_seeds(int seed, int n, int *out)
     rng.seed((unsigned long)seed);
     for (int i = 0; i < n; ++i) out[i] = Megaverse::randRange(0, 1 << 30, rng);
 }
+
+/* triangularNumber (util/math_utils.hpp:7-10): how many boxes an Obstacles wall / gap of a given size needs (platforms.hpp) */
+int mvref_triangular_number(int n) { return Megaverse::triangularNumber(n); }
 
 /* CollectScenario::createLandscape's noise call (scenario_collect.cpp:80,88) on the reference's vendored
  * siv::PerlinNoise (util/perlin_noise.hpp:118-126,315-318) */

@@ -67,6 +67,14 @@ def test_env_seed_rule_matches_reference(ref):
     assert np.array_equal(a, b)
 
 
+def test_triangular_number_matches_reference_math_utils_hpp(ref):
+    """boxes an Obstacles wall / step / gap needs (platforms.hpp requiresMovableBoxesToTraverse): the oracle's helper against the
+    reference's own util/math_utils.hpp:7-10 compiled in place"""
+    L = oracle_lib.lib()
+    for n in range(0, 40):
+        assert L.mvo_triangular_number(n) == ref.mvref_triangular_number(n) == n * (n + 1) // 2
+
+
 def test_action_mask_table():
     # bindings/megaverse.cpp:100-116 + enum Action env.hpp:22-42
     L = oracle_lib.lib()
