@@ -148,7 +148,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=1024)
     ap.add_argument("--agents", type=int, default=1)
     ap.add_argument("--scenario", default="TowerBuilding",
-                    help="TowerBuilding (headline), Obstacles{Easy,Medium,Hard,Walls,Steps,Lava}, Collect, Rearrange, Sokoban, or Mixed (configs[4])")
+                    help="TowerBuilding (headline), Obstacles{Easy,Medium,Hard,Walls,Steps,Lava}, Collect, Rearrange, Sokoban, Empty, or Mixed (configs[4])")
     ap.add_argument("--obs", type=int, nargs=2, default=[128, 128], metavar=("W", "H"))
     ap.add_argument("--no-gather-obs", action="store_true", help="N>1: skip the gather-on leg (value = the no-gather rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -68,6 +68,7 @@ static const float SHAPING_DEFAULT_REARRANGE[3] = {0.0f, 1.0f, 10.0f};
 // scenario_sokoban.hpp:40-47, teamSpirit 0
 static const char *SHAPING_KEYS_SOKOBAN[4] = {"teamSpirit", "sokobanBoxOnTarget", "sokobanBoxLeavesTarget", "sokobanAllBoxesOnTarget"};
 static const float SHAPING_DEFAULT_SOKOBAN[4] = {0.0f, 1.0f, -1.0f, 10.0f};
+static const char *SHAPING_KEYS_EMPTY[1] = {"teamSpirit"};   // EmptyScenario::defaultRewardShaping() is {} (scenario_empty.hpp:28) + Scenario::init's teamSpirit
 static const char *SHAPING_KEYS_COLLECT[5] = {"teamSpirit", "collectSingleGood", "collectSingleBad", "collectAll", "collectAbyss"};
 static const float SHAPING_DEFAULT_COLLECT[5] = {0.0f, 1.0f, -1.0f, 5.0f, -0.5f};
 static const int ACTION_SPACE[6] = {3, 3, 3, 2, 2, 3};                          // env.cpp:33
@@ -231,6 +232,7 @@ static bool scenario_from_name(const std::string &scen, int &scenario, ObstacleC
     } else if (scen == "collect") scenario = SCN_COLLECT;                              // scenarios/init.hpp:45
     else if (scen == "rearrange") scenario = SCN_REARRANGE;                            // scenarios/init.hpp:49
     else if (scen == "sokoban") scenario = SCN_SOKOBAN;                                // scenarios/init.hpp:46
+    else if (scen == "empty") scenario = SCN_EMPTY;                                    // scenarios/init.hpp:34
     else return false;
     return true;
 }
@@ -246,7 +248,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     int scenario = SCN_TOWER;
     ObstacleConfig oc;
     if (!scenario_from_name(scen, scenario, oc))
-        return fail("Unknown scenario " + scen + " (this build accelerates: TowerBuilding, ObstaclesEasy/Medium/Hard/Walls/Steps/Lava, Collect, Rearrange, Sokoban)");
+        return fail("Unknown scenario " + scen + " (this build accelerates: TowerBuilding, ObstaclesEasy/Medium/Hard/Walls/Steps/Lava, Collect, Rearrange, Sokoban, Empty)");
     std::vector<std::string> levelFiles;
     if (scenario == SCN_SOKOBAN) {   // SokobanScenario's constructor looks the level files up (scenario_sokoban.cpp:40-78); none is fatal there too
         levelFiles = find_boxoban_level_files();
@@ -269,9 +271,10 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     g->w = cfg->obs_width; g->h = cfg->obs_height;
     g->N = cfg->num_envs; g->A = cfg->num_agents_per_env;
     g->scenario = scenario;
-    g->numShaping = scenario == SCN_TOWER || scenario == SCN_SOKOBAN ? 4 : scenario == SCN_REARRANGE ? 3 : 5;
+    g->numShaping = scenario == SCN_TOWER || scenario == SCN_SOKOBAN ? 4 : scenario == SCN_REARRANGE ? 3 : scenario == SCN_EMPTY ? 1 : 5;
     g->shapingKeys = scenario == SCN_TOWER ? SHAPING_KEYS_TOWER : scenario == SCN_OBSTACLES ? SHAPING_KEYS_OBST
-                   : scenario == SCN_COLLECT ? SHAPING_KEYS_COLLECT : scenario == SCN_SOKOBAN ? SHAPING_KEYS_SOKOBAN : SHAPING_KEYS_REARRANGE;
+                   : scenario == SCN_COLLECT ? SHAPING_KEYS_COLLECT : scenario == SCN_SOKOBAN ? SHAPING_KEYS_SOKOBAN
+                   : scenario == SCN_EMPTY ? SHAPING_KEYS_EMPTY : SHAPING_KEYS_REARRANGE;
     g->envOffset = cfg->total_envs > 0 ? cfg->env_offset : 0;
     g->envStride = cfg->total_envs > 0 && cfg->env_stride > 1 ? cfg->env_stride : 1;
     g->gv.sample_on = 0; g->gv.sample_seed = g->gv.sample_step = 0;
@@ -281,7 +284,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
 
     GymView &gv = g->gv;
     gv.num_envs = g->N; gv.num_agents = g->A;
-    const bool obstacles = scenario == SCN_OBSTACLES, collect = scenario == SCN_COLLECT, rearrange = scenario == SCN_REARRANGE, sokoban = scenario == SCN_SOKOBAN;
+    const bool obstacles = scenario == SCN_OBSTACLES || scenario == SCN_EMPTY, collect = scenario == SCN_COLLECT, rearrange = scenario == SCN_REARRANGE, sokoban = scenario == SCN_SOKOBAN;
     const bool hostEpisodes = obstacles || collect || rearrange || sokoban;
     gv.scenario = scenario;
     gv.box_stride = collect ? COLLECT_MAX_BOXES : MAX_BOXES;
@@ -387,7 +390,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
         // An env needs a fresh resident episode at every reset.  Two are kept resident, and the consumed counts are read back
         // every 16th step -- unless episodes can time out within a few ticks (a small or negative episodeLengthSec: the Obstacles
         // family never goes below 35 s per platform, Collect and Rearrange take the parameter as is), then after every step.
-        const float minLenSec = obstacles ? std::max(episodeLen, 35.0f) : episodeLen;
+        const float minLenSec = scenario == SCN_OBSTACLES ? std::max(episodeLen, 35.0f) : episodeLen;
         g->statusPeriod = minLenSec * 15.0f >= 64.0f ? 16 : 1;
         if (const char *e = getenv("MV_STATUS_PERIOD")) g->statusPeriod = std::max(1, atoi(e));   // (tests: provoke starvation)
         g->uploadEvents.assign(64, nullptr);
@@ -419,6 +422,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
             ha[i].shaping[k] = scenario == SCN_TOWER ? SHAPING_DEFAULT_TOWER[k] : scenario == SCN_COLLECT ? SHAPING_DEFAULT_COLLECT[k]
                                                      : scenario == SCN_REARRANGE ? SHAPING_DEFAULT_REARRANGE[k]
                                                      : scenario == SCN_SOKOBAN ? SHAPING_DEFAULT_SOKOBAN[k]
+                                                     : scenario == SCN_EMPTY ? 0.0f
                                                      : (k == 4 ? oc.carried_object_to_exit : SHAPING_DEFAULT_OBST[k]);
         ha[i].carrying = -1; ha[i].jump_speed = 10.0f; ha[i].m00 = 1.0f; ha[i].m22 = 1.0f;
     }
@@ -666,7 +670,7 @@ int mv_reset(mv_gym *g)
         g->stepsSinceStatus = 0;
         g->refillForce = true;
         if (refill_episodes(g)) return -1;              // every env has an unconsumed episode resident
-        if (g->scenario == SCN_OBSTACLES) launch_reset_obstacles(g->gv, (const EpisodeBlob *)g->dBlobs, g->dStatus, 1, g->stream);
+        if (g->scenario == SCN_OBSTACLES || g->scenario == SCN_EMPTY) launch_reset_obstacles(g->gv, (const EpisodeBlob *)g->dBlobs, g->dStatus, 1, g->stream);
         else if (g->scenario == SCN_REARRANGE) launch_reset_rearrange(g->gv, (const RearrangeBlob *)g->dBlobs, g->dStatus, 1, g->stream);
         else if (g->scenario == SCN_SOKOBAN) launch_reset_sokoban(g->gv, (const SokobanBlob *)g->dBlobs, g->dStatus, 1, g->stream);
         else launch_reset_collect(g->gv, (const CollectBlob *)g->dBlobs, g->dStatus, 1, g->stream);
@@ -747,7 +751,7 @@ static int step_impl(mv_gym *g, bool render)
     hipEvent_t *ev = prof ? &g->profEvents[(size_t)g->profCount * 5] : nullptr;
     if (prof) HIP_TRY(hipEventRecord(ev[0], g->stream));
     const int fused = render ? 1 : 0;   // the step kernel also builds the frame lists when an observation pass follows
-    if (g->scenario == SCN_OBSTACLES) launch_step_obstacles(g->gv, g->stream, g->w, g->h, fused);
+    if (g->scenario == SCN_OBSTACLES || g->scenario == SCN_EMPTY) launch_step_obstacles(g->gv, g->stream, g->w, g->h, fused);
     else if (g->scenario == SCN_COLLECT) launch_step_collect(g->gv, g->stream, g->w, g->h, fused);
     else if (g->scenario == SCN_REARRANGE) launch_step_rearrange(g->gv, g->stream, g->w, g->h, fused);
     else if (g->scenario == SCN_SOKOBAN) launch_step_sokoban(g->gv, g->stream, g->w, g->h, fused);
@@ -1049,7 +1053,7 @@ int mv_debug_generate_episode(const char *scenario_name, int32_t num_agents, int
 {
     int scenario = SCN_TOWER;
     ObstacleConfig oc;
-    if (!scenario_name || !scenario_from_name(lower(scenario_name), scenario, oc) || scenario == SCN_TOWER || scenario == SCN_SOKOBAN)
+    if (!scenario_name || !scenario_from_name(lower(scenario_name), scenario, oc) || scenario == SCN_TOWER || scenario == SCN_SOKOBAN || scenario == SCN_EMPTY)
         return fail("mv_debug_generate_episode: the Obstacles family, Collect and Rearrange (Sokoban: mv_debug_generate_sokoban)");
     if (num_agents < 1 || num_agents > MAX_AGENTS || n < 1) return fail("mv_debug_generate_episode: bad arguments");
     const size_t bytes = scenario == SCN_COLLECT ? sizeof(CollectBlob) : scenario == SCN_REARRANGE ? sizeof(RearrangeBlob) : sizeof(EpisodeBlob);
@@ -1074,7 +1078,7 @@ int mv_debug_feeder_selftest(const char *scenario_name, int32_t num_envs, int32_
 {
     int scenario = SCN_TOWER;
     ObstacleConfig oc;
-    if (!scenario_name || !scenario_from_name(lower(scenario_name), scenario, oc) || scenario == SCN_TOWER || scenario == SCN_SOKOBAN)
+    if (!scenario_name || !scenario_from_name(lower(scenario_name), scenario, oc) || scenario == SCN_TOWER || scenario == SCN_SOKOBAN || scenario == SCN_EMPTY)
         return fail("mv_debug_feeder_selftest: the Obstacles family, Collect and Rearrange");
     const size_t bytes = scenario == SCN_COLLECT ? sizeof(CollectBlob) : scenario == SCN_REARRANGE ? sizeof(RearrangeBlob) : sizeof(EpisodeBlob);
     std::vector<uint8_t> slots((size_t)num_envs * bytes, 0), want(bytes);

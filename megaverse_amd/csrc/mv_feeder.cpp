@@ -79,9 +79,10 @@ void EpisodeFeeder::generate(int env)
     uint8_t *slot = slots_ + size_t(env) * slot_bytes_;
     const int seq = next_seq_[env]++;
     size_t used = slot_bytes_;
-    if (scenario_ == SCN_OBSTACLES) {
+    if (scenario_ == SCN_OBSTACLES || scenario_ == SCN_EMPTY) {
         EpisodeBlob &b = *reinterpret_cast<EpisodeBlob *>(slot);
-        generate_obstacles_episode(rng_[env], cfg_, num_agents_, base_len_, b);
+        if (scenario_ == SCN_EMPTY) generate_empty_episode(rng_[env], num_agents_, base_len_, b);
+        else generate_obstacles_episode(rng_[env], cfg_, num_agents_, base_len_, b);
         b.seq = seq;
     } else if (scenario_ == SCN_REARRANGE) {
         RearrangeBlob &b = *reinterpret_cast<RearrangeBlob *>(slot);

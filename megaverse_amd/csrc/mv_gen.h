@@ -26,6 +26,10 @@ int generator_overflow_take();   // returns the flags raised since the last call
 // Advances `rng` exactly like Env::reset + ObstaclesScenario::reset + spawnAgents and fills `out`.
 void generate_obstacles_episode(std::mt19937 &rng, const ObstacleConfig &cfg, int num_agents, float base_episode_len, EpisodeBlob &out);
 
+// Empty (scenario_empty.{hpp,cpp}, the reference's performance-test scenario): Env::reset's seed draw + the agents' spawn rotations;
+// one static 20 x 2 x 20 box as the only layout slab, every agent at (1, 1, 1).  Same record as the Obstacles family.
+void generate_empty_episode(std::mt19937 &rng, int num_agents, float base_episode_len, EpisodeBlob &out);
+
 // Advances `rng` exactly like Env::reset + CollectScenario::reset + spawnAgents + addEpisodeDrawables and fills `out`.
 void generate_collect_episode(std::mt19937 &rng, int num_agents, float base_episode_len, CollectBlob &out);
 

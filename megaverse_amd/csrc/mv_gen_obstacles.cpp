@@ -441,4 +441,21 @@ void generate_obstacles_episode(std::mt19937 &rng, const ObstacleConfig &cfg, in
     for (int i = 0; i < num_agents; ++i) out.yaw_frand[i] = frand01(rng);
 }
 
+void generate_empty_episode(std::mt19937 &rng, int num_agents, float base_episode_len, EpisodeBlob &out)
+{
+    std::memset(&out, 0, sizeof out);
+    const int episode_seed = rand_range(0, 1 << 30, rng);   // Env::reset: re-seed from the env's own stream (env.cpp:61-62)
+    rng.seed((unsigned long)episode_seed);
+    // EmptyScenario::reset() {} ; addStaticCollidingBox(scale (10, 1, 10), translation (5, 0, 5), BLUE), scenario_empty.cpp:25-28
+    out.num_boxes = 1;
+    LayoutBox &b = out.boxes[0];
+    b.min[0] = -5; b.min[1] = -1; b.min[2] = -5; b.max[0] = 15; b.max[1] = 1; b.max[2] = 15;
+    b.type = VX_SOLID | VX_OPAQUE; b.slot = 0;
+    out.layout_color = 0x2eb5d0; out.wall_color = 0x2eb5d0; out.draw_walls = 0;   // ColorRgb::BLUE
+    out.dim[0] = 20; out.dim[1] = 2; out.dim[2] = 20;
+    out.episode_len = base_episode_len;
+    for (int k = 0; k < num_agents; ++k) { out.spawn[k][0] = out.spawn[k][1] = out.spawn[k][2] = 1; }   // agentStartingPositions :20-23
+    for (int i = 0; i < num_agents; ++i) out.yaw_frand[i] = frand01(rng);
+}
+
 }  // namespace mv

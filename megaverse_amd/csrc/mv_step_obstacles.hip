@@ -279,9 +279,11 @@ __device__ __forceinline__ void obstacles_tick(const GymView &gv, const int env)
         wave_sync();
     };
 
+    if (gv.scenario != SCN_EMPTY) {   // (Empty has no FallDetectionComponent: an agent that walks off the platform keeps falling)
 #pragma unroll 1
-    for (int i = 0; i < A; ++i)
-        if (s_ag[i].pos[1] + 0.05f < -20.0f) reset_agent(i);
+        for (int i = 0; i < A; ++i)
+            if (s_ag[i].pos[1] + 0.05f < -20.0f) reset_agent(i);
+    }
 
     // ---- ObstaclesScenario::step: exit pad, lava, diamonds
     int numAgentsAtExit = 0;

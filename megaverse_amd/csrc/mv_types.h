@@ -23,7 +23,8 @@ enum : int { FRAME_HDR_BYTES = 1024 };   // per-frame header of the observation 
 // error flags a kernel raises in episode_status[N + 1]; mv_step reports them (mv_api.hip: check_status_flags)
 enum : int { ST_STARVED = 1, ST_CANDIDATES = 2, ST_VISIBLE = 4, ST_CHUNK = 8 };
 
-enum : int { SCN_TOWER = 0, SCN_OBSTACLES = 1, SCN_COLLECT = 2, SCN_REARRANGE = 3, SCN_SOKOBAN = 4 };
+enum : int { SCN_TOWER = 0, SCN_OBSTACLES = 1, SCN_COLLECT = 2, SCN_REARRANGE = 3, SCN_SOKOBAN = 4,
+             SCN_EMPTY = 5 };   // Empty runs on the Obstacles kernels (one slab, no terrain) with fall detection off
 enum : int { SOKO_DIM = 32, SOKO_WALL = 1, SOKO_GOAL = 2 };                            // Sokoban level cells (scenario_sokoban.cpp:28-33)
 enum : int { MAX_ITEMS = 8, NUM_STATIC = 9 };                                         // Rearrange: arrangement items, static colliding boxes
 enum : int { SHAPE_BOX = 0, SHAPE_CAPSULE = 1, SHAPE_SPHERE = 2, SHAPE_CYLINDER = 4 };   // DrawableType, env/include/env/env.hpp:58-69

@@ -22,7 +22,7 @@ MEGAVERSE8 = ['TowerBuilding', 'ObstaclesEasy', 'ObstaclesHard', 'Collect', 'Sok
 OBSTACLES_MULTITASK = ['ObstaclesWalls', 'ObstaclesSteps', 'ObstaclesLava', 'ObstaclesEasy', 'ObstaclesHard']
 # what libmegaverse_hip.so can construct (mv_create); HexMemory / HexExplore (rotated-wall mazes) are not built yet
 SUPPORTED_SCENARIOS = ['TowerBuilding', 'ObstaclesEasy', 'ObstaclesMedium', 'ObstaclesHard', 'ObstaclesWalls', 'ObstaclesSteps', 'ObstaclesLava',
-                       'Collect', 'Sokoban', 'Rearrange']
+                       'Collect', 'Sokoban', 'Rearrange', 'Empty']
 _warned_unsupported = False
 
 

@@ -74,7 +74,7 @@ static const float CARRY_SCALE = 0.78f;               // :63
 enum { CX = 32, CY = 16, CZ = 32, CHUNK = CX * CY * CZ };
 enum { MAX_BOXES = 1024, MAX_OBJECTS = 80, MAX_AGENTS = 8, MAX_TERRAIN = 16, MAX_REWARDS = 96, MAX_SHAPING = 8 };
 enum { HM_DIM = 42 };   // Collect heightfield: maxWidth == maxLength == 42 (scenario_collect.cpp:63)
-enum { SCN_TOWER = 0, SCN_OBSTACLES = 1, SCN_COLLECT = 2, SCN_REARRANGE = 3, SCN_SOKOBAN = 4 };
+enum { SCN_TOWER = 0, SCN_OBSTACLES = 1, SCN_COLLECT = 2, SCN_REARRANGE = 3, SCN_SOKOBAN = 4, SCN_EMPTY = 5 };
 enum { SOKO_DIM = 32, SOKO_WALL = 1, SOKO_GOAL = 2 };   // Sokoban level cells (scenario_sokoban.cpp:28-33), levels up to 32 x 32
 enum { MAX_STATIC = 16, MAX_ITEMS = 8 };   // Rearrange: static colliding boxes, arrangement items (arrangementSize < 8)
 enum { SHAPE_BOX = 0, SHAPE_CAPSULE = 1, SHAPE_SPHERE = 2, SHAPE_CYLINDER = 4 };   // DrawableType, env.hpp:58-69
@@ -1228,6 +1228,24 @@ static void sokoban_generate(Env &e)
 }
 
 
+// Empty -- scenario_empty.{hpp,cpp}: the scenario of the reference's own performance test (README.md:243-247).  reset() draws nothing;
+// one static colliding box, scale (10, 1, 10) at (5, 0, 5) (addStaticCollidingBox, layout_utils.cpp:70-83) = the integer slab
+// [-5, 15) x [-1, 1) x [-5, 15), BLUE; every agent starts at (1, 1, 1); no object stacking, no fall detection, no rewards.
+static void empty_generate(Env &e)
+{
+    std::fill(e.chunk.begin(), e.chunk.end(), 0);
+    e.numBoxes = 1;
+    e.boxes[0] = Box{{-5, -1, -5}, {15, 1, 15}, VX_SOLID | VX_OPAQUE, 0};
+    e.L = 20; e.H = 2; e.W = 20;
+    e.bz[0] = e.bz[1] = e.bz[2] = e.bz[3] = 0;
+    e.layoutColor = 0x2eb5d0; e.wallColor = 0x2eb5d0; e.drawWalls = 0;   // ColorRgb::BLUE
+    e.numTerrain = 0; e.numRewards = 0; e.numPlatforms = 0; e.numItems = 0; e.numStatic = 0; e.numObjects = 0;
+    e.solved = 0; e.highestTower = 0; e.bzReward = 0;
+    e.episodeLen = e.p_episodeLengthSec;
+    e.barHalfWidth = 0.24f;
+    spawn_agents(e, std::vector<C3>(size_t(e.numAgents), C3{1, 1, 1}));   // agentStartingPositions, scenario_empty.cpp:20-23
+}
+
 static void env_reset(Env &e)
 {
     // ---- Env::reset, env/src/env.cpp:57-76 ; EnvState::reset env.hpp:135-151
@@ -1238,6 +1256,7 @@ static void env_reset(Env &e)
     else if (e.scenario == SCN_OBSTACLES) obstacles_generate(e);
     else if (e.scenario == SCN_COLLECT) collect_generate(e);
     else if (e.scenario == SCN_REARRANGE) rearrange_generate(e);
+    else if (e.scenario == SCN_EMPTY) empty_generate(e);
     else sokoban_generate(e);
 }
 
@@ -1868,7 +1887,7 @@ static void env_step(Env &e)
 
     // scenario->step(): objectStacking, fallDetection, zone reward (scenario_tower_building.cpp:179-199)
     for (int i = 0; i < e.numAgents; ++i)
-        if (e.scenario != SCN_SOKOBAN && (e.agents[i].action & (1 << 8))) on_interact(e, i);   // (Sokoban has no ObjectStackingComponent)
+        if (e.scenario != SCN_SOKOBAN && e.scenario != SCN_EMPTY && (e.agents[i].action & (1 << 8))) on_interact(e, i);   // (Sokoban, Empty: no ObjectStackingComponent)
 
     auto reset_agent = [&](Agent &a) {   // FallDetectionComponent::resetAgent :45-55 + controller warp() :509-517
         int p[3] = {a.spawn[0], a.spawn[1], a.spawn[2]};
@@ -1878,7 +1897,7 @@ static void env_step(Env &e)
         a.hvx = a.hvz = 0; a.vvel = 0;
     };
     for (int i = 0; i < e.numAgents; ++i)  // component_fall_detection.hpp:33-43
-        if (e.scenario != SCN_REARRANGE && e.scenario != SCN_SOKOBAN && e.agents[i].pos.y + 0.05f < -20.0f) {   // (Rearrange, Sokoban: no FallDetectionComponent)
+        if (e.scenario != SCN_REARRANGE && e.scenario != SCN_SOKOBAN && e.scenario != SCN_EMPTY && e.agents[i].pos.y + 0.05f < -20.0f) {   // (Rearrange, Sokoban, Empty: no FallDetectionComponent)
             reset_agent(e.agents[i]);
             if (e.scenario == SCN_COLLECT) reward_agent(e, 2, i, 1);   // CollectScenario::agentFell, scenario_collect.cpp:214-218
         }
@@ -1907,6 +1926,8 @@ static void env_step(Env &e)
                         e.objects[o].state = -1;
             }
         }
+    } else if (e.scenario == SCN_EMPTY) {
+        // EmptyScenario::step() {} (scenario_empty.hpp:22)
     } else if (e.scenario == SCN_SOKOBAN) {
         sokoban_step(e);
     } else if (e.scenario == SCN_REARRANGE) {
@@ -2445,6 +2466,7 @@ mvo_gym *mvo_create(const char *scenario, int w, int h, int num_envs, int num_ag
     } else if (s == "collect") scen = SCN_COLLECT;   // scenarios/init.hpp:45
     else if (s == "rearrange") scen = SCN_REARRANGE;   // scenarios/init.hpp:49
     else if (s == "sokoban") scen = SCN_SOKOBAN;       // scenarios/init.hpp:46
+    else if (s == "empty") scen = SCN_EMPTY;           // scenarios/init.hpp:34
     else { fprintf(stderr, "mv_oracle: unknown scenario %s\n", s.c_str()); return nullptr; }
     if (num_agents_per_env < 1 || num_agents_per_env > MAX_AGENTS || num_envs < 1) return nullptr;
     auto *g = new mvo_gym();
@@ -2477,7 +2499,7 @@ mvo_gym *mvo_create(const char *scenario, int w, int h, int num_envs, int num_ag
         }
         e->scenario = scen;
         e->op = op;
-        e->numShaping = scen == SCN_TOWER || scen == SCN_SOKOBAN ? 4 : scen == SCN_REARRANGE ? 3 : 5;
+        e->numShaping = scen == SCN_TOWER || scen == SCN_SOKOBAN ? 4 : scen == SCN_REARRANGE ? 3 : scen == SCN_EMPTY ? 1 : 5;   // Empty: teamSpirit only
         e->shapingKeys = scen == SCN_TOWER ? SHAPING_KEYS_TOWER : scen == SCN_OBSTACLES ? SHAPING_KEYS_OBST
                        : scen == SCN_COLLECT ? SHAPING_KEYS_COLLECT : scen == SCN_SOKOBAN ? SHAPING_KEYS_SOKOBAN : SHAPING_KEYS_REARRANGE;
         for (int a = 0; a < MAX_AGENTS; ++a) {
