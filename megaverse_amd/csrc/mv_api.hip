@@ -305,7 +305,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     gv.vis_stride = collect ? 1024 : 256;
     gv.spares = g->spares;
     const size_t szVisP = up(NA * (size_t)gv.vis_stride * 32), szVisR = up(NA * (size_t)gv.vis_stride * 8), szVisC = up(NA * sizeof(int32_t)),
-                 szLpt = up(NA * sizeof(int32_t)) + up((NA + 1) * sizeof(int32_t)) + up(NA * (size_t)FRAME_HDR_BYTES);
+                 szLpt = up(NA * sizeof(int32_t)) + up((NA + 1) * sizeof(int32_t)) + up(NA * (size_t)FRAME_HDR_BYTES) + up(2 * 256 * sizeof(int32_t)) + up(256 * NA * sizeof(int32_t));
     const size_t total = szHdr + szBoxes + szObj + szAg + szAct + szRew + szDone + szObjv + szMd + (hostEpisodes ? 0 : szChunk) + szObs + szTerrain +
                          szRewObj + szHeight + szItems + szCells + szBlobs + szCnt + szVisP + szVisR + szVisC + szLpt;
     {
@@ -343,6 +343,8 @@ int mv_create(const mv_config *cfg, mv_gym **out)
         gv.lpt_bucket = (int32_t *)p; p += up(NA * sizeof(int32_t));
         gv.lpt_order = (int32_t *)p; p += up((NA + 1) * sizeof(int32_t));
         gv.vis_hdr = p; p += up(NA * (size_t)FRAME_HDR_BYTES);
+        gv.lpt_hist = (int32_t *)p; p += up(2 * 256 * sizeof(int32_t));
+        gv.lpt_list = (int32_t *)p; p += up(256 * NA * sizeof(int32_t));
     }
     if (const char *e = getenv("MV_PIXEL_MODE")) g->fastPixels = lower(e) == "exact" ? 0 : 1;
     g->obs = g->ownedObs;
@@ -556,6 +558,7 @@ int mv_render(mv_gym *g)
 {
     if (check(g)) return -1;
     HIP_TRY(hipSetDevice(g->device));
+    g->gv.lpt_parity ^= 1;
     if (launch_raster(g->gv, g->obs, g->w, g->h, g->stream, nullptr, g->fastPixels)) return fail("mv_render: observation size above 1024x1024");
     HIP_TRY(hipGetLastError());
     return 0;
@@ -751,6 +754,7 @@ static int step_impl(mv_gym *g, bool render)
     hipEvent_t *ev = prof ? &g->profEvents[(size_t)g->profCount * 5] : nullptr;
     if (prof) HIP_TRY(hipEventRecord(ev[0], g->stream));
     const int fused = render ? 1 : 0;   // the step kernel also builds the frame lists when an observation pass follows
+    if (render) g->gv.lpt_parity ^= 1;  // (this pass's frame setup fills the other cost histogram)
     if (g->scenario == SCN_OBSTACLES || g->scenario == SCN_EMPTY) launch_step_obstacles(g->gv, g->stream, g->w, g->h, fused);
     else if (g->scenario == SCN_COLLECT) launch_step_collect(g->gv, g->stream, g->w, g->h, fused);
     else if (g->scenario == SCN_REARRANGE) launch_step_rearrange(g->gv, g->stream, g->w, g->h, fused);
@@ -888,6 +892,7 @@ int mv_draw_hires(mv_gym *g)
         HIP_TRY(hipMalloc((void **)&g->hiresObs, (size_t)g->N * g->A * g->renderW * g->renderH * 4));
         g->hiresW = g->renderW; g->hiresH = g->renderH;
     }
+    g->gv.lpt_parity ^= 1;
     if (launch_raster(g->gv, g->hiresObs, g->hiresW, g->hiresH, g->stream, nullptr, g->fastPixels)) return fail("mv_draw_hires: render size above 1024x1024");
     HIP_TRY(hipGetLastError());
     return 0;

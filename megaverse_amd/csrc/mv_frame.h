@@ -421,8 +421,16 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
         // kernel takes them from the most expensive bin down (frames differ several-fold in cost; starting the heavy
         // ones first keeps the tail of the launch short); frame_order_kernel turns the bins into a permutation
         const int tiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H);
-        gv.lpt_bucket[frame] = min(LPT_BUCKETS - 1, (16 * s_cost) / max(tiles, 1));   // 1/16 of "one primitive on every tile"
+        const int bin = min(LPT_BUCKETS - 1, (16 * s_cost) / max(tiles, 1));   // 1/16 of "one primitive on every tile"
+        gv.lpt_bucket[frame] = bin;   // (exact raster kernel: frame_order_kernel sorts on these)
+        // fast raster kernel: the frame appends itself to its bin; every raster workgroup prefix-sums the 256 bin counts in its prologue
+        // and looks its frame up -- no sort kernel, no launch boundary.  The order inside a bin is whatever the atomics made it: it only
+        // schedules.  Two histograms alternate between passes: this pass's raster reads one while the next pass's setup fills the other.
+        const int r = atomicAdd(&gv.lpt_hist[gv.lpt_parity * LPT_BUCKETS + bin], 1);
+        gv.lpt_list[(size_t)bin * (gv.num_envs * gv.num_agents) + r] = frame;
     }
+    if (frame == 0)   // the other parity's histogram: last read by the previous pass's raster, next filled by the next pass's setup
+        for (int i = tid; i < LPT_BUCKETS; i += THREADS) gv.lpt_hist[(1 - gv.lpt_parity) * LPT_BUCKETS + i] = 0;
     sync();   // the LDS scratch above is reused by the next frame of this workgroup (fused step + setup kernels)
 }
 

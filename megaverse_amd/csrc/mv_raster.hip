@@ -550,7 +550,7 @@ struct FastArgs {   // what raster_fast_kernel needs of the GymView (fewer live 
     const unsigned char *vis_hdr;
     const Prim *vis_prims;
     const short4 *vis_rects;
-    const int *order;
+    const int *hist, *list;   // this pass's cost histogram [256] and the per-bin frame lists [256][frames] (mv_frame.h)
     int num_agents, vis_stride, frames;
 };
 
@@ -646,7 +646,26 @@ __global__ __launch_bounds__(256, WAVES) void raster_fast_kernel(FastArgs fa, ui
         const int frames = fa.frames;
         if (group * 8 + 8 > frames) { const int nf = frames - group * 8; position = group * 8 + r % nf; part = r / nf; }
     }
-    const int frame = __builtin_amdgcn_readfirstlane(fa.order[position]);   // most expensive frames first
+    // position -> frame, most expensive frames first: the frame setup left every frame in the list of its cost bin; prefix-sum the 256 bin
+    // counts (bin 255 first) and take entry (position - start) of the bin whose range holds `position`
+    __shared__ int s_wsum[4], s_frame;
+    {
+        const int h = fa.hist[LPT_BUCKETS - 1 - tid];
+        int x = h;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int y = __shfl_up(x, off, 64);
+            if (lane >= off) x += y;
+        }
+        if (lane == 63) s_wsum[wave] = x;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wave; ++w) base += s_wsum[w];
+        const int end = base + x, start = end - h;
+        if (position >= start && position < end) s_frame = fa.list[(size_t)(LPT_BUCKETS - 1 - tid) * fa.frames + (position - start)];
+        __syncthreads();
+    }
+    const int frame = __builtin_amdgcn_readfirstlane(s_frame);
     const int viewer = frame % A;
     const float *gh = reinterpret_cast<const float *>(fa.vis_hdr + (size_t)frame * FRAME_HDR_BYTES);
     const int nVis = __builtin_amdgcn_readfirstlane(min(__float_as_int(gh[0]), (int)MAXVIS));
@@ -824,7 +843,7 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
     const int tiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H * PPL - 1) / (TILE_H * PPL));
     const int frames = gv.num_envs * gv.num_agents;
     if (!setup_done) hipLaunchKernelGGL(frame_setup_kernel, dim3(frames), dim3(256), 0, stream, gv, W, H);
-    hipLaunchKernelGGL(frame_order_kernel, dim3(1), dim3(1024), 0, stream, gv, frames, gv.lpt_order);
+    if (!fast) hipLaunchKernelGGL(frame_order_kernel, dim3(1), dim3(1024), 0, stream, gv, frames, gv.lpt_order);   // (fast: no sort kernel)
     if (between) (void)hipEventRecord(between, stream);
     if (fast) {
         const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)W * sizeof(float) + (size_t)H * sizeof(float2);
@@ -836,7 +855,7 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
         using KernelFn = void (*)(FastArgs, uint32_t *, int, int, int);
         FastArgs fa;
         fa.vis_hdr = gv.vis_hdr; fa.vis_prims = reinterpret_cast<const Prim *>(gv.vis_prims); fa.vis_rects = reinterpret_cast<const short4 *>(gv.vis_rects);
-        fa.order = gv.lpt_order; fa.num_agents = gv.num_agents; fa.vis_stride = gv.vis_stride; fa.frames = frames;
+        fa.hist = gv.lpt_hist + gv.lpt_parity * LPT_BUCKETS; fa.list = gv.lpt_list; fa.num_agents = gv.num_agents; fa.vis_stride = gv.vis_stride; fa.frames = frames;
         // (Collect, measured and rejected: a 1024-entry launch for the frames above 256 visible primitives + a 256-entry launch for the rest,
         // 75 + 69 us against 107 us for the single 1024-entry launch: each launch pays its own tail, and the cones, not occupancy, dominate)
         KernelFn fn = gv.vis_stride > VIS_SMALL ? raster_fast_kernel<VIS_LARGE, false, 3>

@@ -126,7 +126,10 @@ struct GymView {
     int32_t *vis_count;        // [N*A]
     int32_t vis_stride;        // 256, or 1024 for Collect
     int32_t *lpt_bucket;       // [N*A] cost bin of every frame (raster scheduling)
-    int32_t *lpt_order;        // [N*A] frames sorted by cost bin, most expensive first
+    int32_t *lpt_order;        // [N*A] frames sorted by cost bin, most expensive first (exact raster kernel)
+    int32_t *lpt_hist;         // [2][256] frames per cost bin, one histogram per pass parity (fast raster kernel)
+    int32_t *lpt_list;         // [256][N*A] the frames of every bin in arrival order
+    int32_t lpt_parity;        // which histogram this observation pass uses
     uint8_t *vis_hdr;          // [N*A][FRAME_HDR_BYTES] per-frame header for raster_fast_kernel (cameras, light vectors, masks, count)
 };
 
