@@ -16,6 +16,8 @@
 #include "mv_oracle.h"
 
 #include <algorithm>
+#include <functional>
+#include <numeric>
 #include <atomic>
 #include <cfloat>
 #include <cmath>
@@ -1129,6 +1131,101 @@ static void rearrange_generate(Env &e)
     e.numTerrain = 0; e.numRewards = 0; e.solved = 0; e.highestTower = 0; e.bzReward = 0;
     e.episodeLen = e.p_episodeLengthSec;
     e.barHalfWidth = 0.24f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Honeycomb mazes -- src/libs/mazes (vendored in the reference tree, self-contained): HoneyCombMaze::InitialiseGraph
+// (honeycombmaze.cpp:11-43), Kruskal::SpanningTree (kruskal.cpp:6-27), Maze::RemoveBorders (maze.cpp:20-37).  Restated with the same
+// container orders, because the order of a cell's adjacency list is the order HexagonalMazeComponent walks the walls in
+// (component_hexagonal_maze.cpp:52-58), i.e. the order of its RNG draws.  Pinned against the library itself compiled in place
+// (oracle/_ref, tests/test_oracle_hex.py).  The reference seeds Kruskal's mt19937 from std::random_device
+// (spanningtreealgorithm.cpp:3-5): its mazes are not reproducible from the env seed; here the generator takes a seed.
+// ------------------------------------------------------------------------------------------------
+struct HexBorder { int to; double x1, y1, x2, y2; };   // adjacent cell (-1: outside) and the border segment, maze units
+struct HexMaze {
+    int size = 0, cells = 0;
+    std::vector<std::vector<HexBorder>> adj;
+    std::vector<std::pair<double, double>> centers;
+    double xlim = 0, ylim = 0;   // GetCoordinateBounds: [-xlim, xlim] x [-ylim, ylim]
+};
+
+static std::pair<int, int> hex_vextent(int size, int u) { return u < 0 ? std::make_pair(-size - u + 1, size - 1) : std::make_pair(-size + 1, size - 1 - u); }
+static bool hex_valid(int size, int u, int v)
+{
+    if (u <= -size || u >= size) return false;
+    const auto e = hex_vextent(size, u);
+    return v >= e.first && v <= e.second;
+}
+static int hex_vertex_index(int size, int u, int v)
+{
+    if (u <= 0) return ((3 * size + u) * (size + u - 1)) / 2 + v;
+    return (3 * size * (size - 1) + (4 * size - u - 1) * u) / 2 + v;
+}
+
+static void hex_maze_generate(HexMaze &m, int size, uint32_t kruskal_seed)
+{
+    static const int neigh[6][2] = {{-1, 0}, {-1, 1}, {0, 1}, {1, 0}, {1, -1}, {0, -1}};
+    m.size = size;
+    m.cells = 3 * size * (size - 1) + 1;
+    m.adj.assign(m.cells, {});
+    m.centers.assign(m.cells, {0.0, 0.0});
+    const int startvertex = 0, endvertex = 3 * size * (size - 1);
+    const bool bordersForEntranceAndExit = true;   // honeycombmaze.h:15
+    for (int u = -size + 1; u < size; ++u) {
+        const auto ve = hex_vextent(size, u);
+        for (int v = ve.first; v <= ve.second; ++v) {
+            const int node = hex_vertex_index(size, u, v);
+            // the border end points are cos / sin of (n - 2.5) pi / 3 and of that + pi / 3 (honeycombmaze.cpp:63-68).  They are literal
+            // doubles here -- the same table as in the product's host generator -- because a compiler may call sincos() where another calls
+            // cos(): one ulp of a double in a sum that cancels.  (The reference library agrees to 1e-15: tests/test_oracle_hex.py.)
+            static const double HEX_C1[6] = {-0x1.bb67ae8584cabp-1, 0x1.1a62633145c07p-54, 0x1.bb67ae8584cabp-1, 0x1.bb67ae8584cabp-1, 0x1.1a62633145c07p-54, -0x1.bb67ae8584cabp-1};
+            static const double HEX_S1[6] = {-0x1.fffffffffffffp-2, -0x1.0000000000000p+0, -0x1.fffffffffffffp-2, 0x1.fffffffffffffp-2, 0x1.0000000000000p+0, 0x1.fffffffffffffp-2};
+            static const double HEX_C2[6] = {-0x1.72cece675d1fcp-53, 0x1.bb67ae8584caap-1, 0x1.bb67ae8584cabp-1, 0x1.1a62633145c07p-54, -0x1.bb67ae8584ca9p-1, -0x1.bb67ae8584caap-1};
+            static const double HEX_S2[6] = {-0x1.0000000000000p+0, -0x1.0000000000000p-1, 0x1.fffffffffffffp-2, 0x1.0000000000000p+0, 0x1.0000000000003p-1, -0x1.0000000000001p-1};
+            const double dxu = 0x1.bb67ae8584caap-1 /* sqrt(3) / 2 */, dyu = 1.5, dxv = 0x1.bb67ae8584caap+0 /* sqrt(3) */, dyv = 0;
+            const double cx = dxu * u + dxv * v, cy = dyu * u + dyv * v;
+            m.centers[node] = {cx, cy};
+            for (int n = 0; n < 6; ++n) {
+                const int uu = u + neigh[n][0], vv = v + neigh[n][1];
+                const HexBorder b{-1, cx + HEX_C1[n], cy + HEX_S1[n], cx + HEX_C2[n], cy + HEX_S2[n]};
+                if (hex_valid(size, uu, vv)) {
+                    const int nnode = hex_vertex_index(size, uu, vv);
+                    if (nnode > node) continue;
+                    HexBorder a = b; a.to = nnode;
+                    HexBorder c = b; c.to = node;
+                    m.adj[node].push_back(a);
+                    m.adj[nnode].push_back(c);
+                } else {
+                    if (!bordersForEntranceAndExit && ((node == startvertex && n == 0) || (node == endvertex && n == 3))) continue;
+                    m.adj[node].push_back(b);
+                }
+            }
+        }
+    }
+    // Kruskal: every inner edge once (i < neighbour), std::shuffle with the algorithm's own mt19937, union-find with path compression
+    std::vector<std::pair<int, int>> edges;
+    for (int i = 0; i < m.cells; ++i)
+        for (const HexBorder &e : m.adj[i])
+            if (e.to > i) edges.push_back({i, e.to});
+    std::mt19937 generator(kruskal_seed);
+    std::shuffle(edges.begin(), edges.end(), generator);
+    std::vector<int> parent(m.cells);
+    std::iota(parent.begin(), parent.end(), 0);
+    std::function<int(int)> root = [&](int u) { return parent[u] == u ? u : (parent[u] = root(parent[u])); };
+    for (const auto &e : edges) {
+        const int a = root(e.first), b = root(e.second);
+        if (a == b) continue;
+        parent[a] = b;
+        // RemoveBorders: the first matching entry of either list
+        for (int side = 0; side < 2; ++side) {
+            auto &lst = m.adj[side == 0 ? e.first : e.second];
+            const int other = side == 0 ? e.second : e.first;
+            for (size_t i = 0; i < lst.size(); ++i)
+                if (lst[i].to == other) { lst.erase(lst.begin() + i); break; }
+        }
+    }
+    m.xlim = 0x1.bb67ae8584caap+0 * (size - 0.5);
+    m.ylim = 1.5 * size - 0.5;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2697,6 +2794,27 @@ void mvo_shuffle_iota(uint32_t seed, int n, int *out)
 void mvo_get_coords(const float *v, int *out) { voxel_of(v3(v[0], v[1], v[2]), out); }
 float mvo_building_reward_coeff(float h) { return building_reward_coeff(h); }
 int mvo_triangular_number(int n) { return triangular_number(n); }
+
+/* honeycomb maze of `size` with Kruskal seeded by `seed`: per cell the number of borders left, then for every border (cell order, list
+ * order) the adjacent cell and the four coordinates; returns the number of borders (out == NULL: count only).  centers: [cells][2]. */
+int mvo_hex_maze(int size, uint32_t seed, int *cells_out, int *border_counts, int *border_to, double *border_xy, double *centers, double *bounds)
+{
+    HexMaze m;
+    hex_maze_generate(m, size, seed);
+    if (cells_out) *cells_out = m.cells;
+    int n = 0;
+    for (int i = 0; i < m.cells; ++i) {
+        if (border_counts) border_counts[i] = int(m.adj[i].size());
+        for (const HexBorder &b : m.adj[i]) {
+            if (border_to) border_to[n] = b.to;
+            if (border_xy) { border_xy[4 * n] = b.x1; border_xy[4 * n + 1] = b.y1; border_xy[4 * n + 2] = b.x2; border_xy[4 * n + 3] = b.y2; }
+            ++n;
+        }
+        if (centers) { centers[2 * i] = m.centers[i].first; centers[2 * i + 1] = m.centers[i].second; }
+    }
+    if (bounds) { bounds[0] = -m.xlim; bounds[1] = -m.ylim; bounds[2] = m.xlim; bounds[3] = m.ylim; }
+    return n;
+}
 void mvo_sincos(float x, float *s, float *c) { mv_sincos(x, s, c); }
 
 }  // extern "C"

@@ -74,6 +74,8 @@ void mvo_frand_seq(uint32_t seed, int n, float *out);
 void mvo_shuffle_iota(uint32_t seed, int n, int *out);      /* std::shuffle of 0..n-1 */
 int mvo_action_mask(const int *actions, int n);             /* megaverse.cpp:100-116 */
 void mvo_get_coords(const float *v, int *out);              /* voxel_grid.hpp:144-149 */
+int mvo_hex_maze(int size, uint32_t seed, int *cells_out, int *border_counts, int *border_to, double *border_xy, double *centers,
+                 double *bounds);                          /* src/libs/mazes: HoneyCombMaze + Kruskal + RemoveBorders */
 int mvo_triangular_number(int n);                          /* util/math_utils.hpp:7-10 */
 float mvo_building_reward_coeff(float height);              /* scenario_tower_building.cpp:246-251 */
 void mvo_sincos(float x, float *s, float *c);               /* the fp32 polynomial both sides use */
