@@ -76,7 +76,9 @@ static const float CARRY_SCALE = 0.78f;               // :63
 enum { CX = 32, CY = 16, CZ = 32, CHUNK = CX * CY * CZ };
 enum { MAX_BOXES = 1024, MAX_OBJECTS = 80, MAX_AGENTS = 8, MAX_TERRAIN = 16, MAX_REWARDS = 96, MAX_SHAPING = 8 };
 enum { HM_DIM = 42 };   // Collect heightfield: maxWidth == maxLength == 42 (scenario_collect.cpp:63)
-enum { SCN_TOWER = 0, SCN_OBSTACLES = 1, SCN_COLLECT = 2, SCN_REARRANGE = 3, SCN_SOKOBAN = 4, SCN_EMPTY = 5 };
+enum { SCN_TOWER = 0, SCN_OBSTACLES = 1, SCN_COLLECT = 2, SCN_REARRANGE = 3, SCN_SOKOBAN = 4, SCN_EMPTY = 5, SCN_HEX_MEMORY = 6, SCN_HEX_EXPLORE = 7 };
+enum { HEX_MAX_BOXES = 2048, HEX_MAX_OBJS = 128, HEX_FRAMES = 3 };   // Hex*: float boxes (floor, walls, edgings, landmarks), collectables
+enum { HEX_PILLAR = 0, HEX_DIAMOND = 1, HEX_SPHERE = 2 };            // scenario_hex_memory.cpp:163-168 ShapeType
 enum { SOKO_DIM = 32, SOKO_WALL = 1, SOKO_GOAL = 2 };   // Sokoban level cells (scenario_sokoban.cpp:28-33), levels up to 32 x 32
 enum { MAX_STATIC = 16, MAX_ITEMS = 8 };   // Rearrange: static colliding boxes, arrangement items (arrangementSize < 8)
 enum { SHAPE_BOX = 0, SHAPE_CAPSULE = 1, SHAPE_SPHERE = 2, SHAPE_CYLINDER = 4 };   // DrawableType, env.hpp:58-69
@@ -91,6 +93,9 @@ static const unsigned LAYOUT_COLORS[14] = {  // env/include/env/const.hpp:121-13
     0x555555, 0x555555, 0x555555, 0x555555};
 static const unsigned COLOR_BUILDING_ZONE = 0x555555, COLOR_MOVABLE_BOX = 0xadd8e6, COLOR_AGENT_EYES = 0x2c3e50,
                       COLOR_UI_BAR = 0x2eb5d0;  // const.hpp:25-56
+static const unsigned ALL_COLORS[22] = {  // const.hpp:58-83 allColors
+    0xffdd3c, 0x3bb372, 0x50c878, 0x2eb5d0, 0xadd8e6, 0x3a7fa6, 0x2c3e50, 0xffb400, 0xb3b3b3, 0x555555, 0x222222,
+    0xffffff, 0xff0000, 0xffa770, 0xd468ee, 0xffe6e6, 0xffffe6, 0xccffcc, 0xe6ecff, 0xd9d9d9, 0xf2e6ff, 0xffebcc};
 static const unsigned AGENT_COLORS[7] = {0xffdd3c, 0x3bb372, 0x2eb5d0, 0xffb400, 0xd468ee, 0x222222, 0xff0000};  // const.hpp:85
 
 struct V3 {
@@ -201,6 +206,11 @@ static const float SHAPING_DEFAULT_REARRANGE[3] = {0.0f, 1.0f, 10.0f};
 // scenario_sokoban.hpp:40-47 (+ teamSpirit 0)
 static const char *SHAPING_KEYS_SOKOBAN[4] = {"teamSpirit", "sokobanBoxOnTarget", "sokobanBoxLeavesTarget", "sokobanAllBoxesOnTarget"};
 static const float SHAPING_DEFAULT_SOKOBAN[4] = {0.0f, 1.0f, -1.0f, 10.0f};
+// scenario_hex_memory.hpp:37-43, scenario_hex_explore.hpp:28-31 (+ teamSpirit 0)
+static const char *SHAPING_KEYS_HEX_MEMORY[3] = {"teamSpirit", "memoryCollectGood", "memoryCollectBad"};
+static const float SHAPING_DEFAULT_HEX_MEMORY[3] = {0.0f, 1.0f, -1.0f};
+static const char *SHAPING_KEYS_HEX_EXPLORE[2] = {"teamSpirit", "exploreSolved"};
+static const float SHAPING_DEFAULT_HEX_EXPLORE[2] = {0.0f, 5.0f};
 static const char *SHAPING_KEYS_COLLECT[5] = {"teamSpirit", "collectSingleGood", "collectSingleBad", "collectAll", "collectAbyss"};
 static const float SHAPING_DEFAULT_COLLECT[5] = {0.0f, 1.0f, -1.0f, 5.0f, -0.5f};
 
@@ -232,6 +242,15 @@ struct Env {
     std::vector<uint8_t> soko = std::vector<uint8_t>(SOKO_DIM * SOKO_DIM, 0);   // [x * SOKO_DIM + z]: SOKO_WALL | SOKO_GOAL
     std::vector<std::vector<std::string>> sokoLevels;
     const std::vector<std::string> *sokoFiles = nullptr;                         // shared, owned by the gym
+    // HexMemory / HexExplore (component_hexagonal_maze.cpp, scenario_hex_{memory,explore}.cpp): the floor, walls, edgings and
+    // landmarks as float boxes, each in the world frame or in one of the three wall orientations (a rotation about Y: the
+    // vertical capsule stays vertical, so physics and rays treat such a box as an axis-aligned box in ITS frame); the collectables
+    // (HexExplore: hexObjs[0] is the reward diamond).  numPlatforms holds goodObjects.size(), highestTower goodObjectsCollected.
+    struct HexBox { int frame; V3 lo, hi; unsigned color; int collide; };           // frame: -1 world, 0..2 = HEX_ROT[k]
+    struct HexObj { V3 pos, scale; int shape, good, alive; unsigned color; int vox[3]; };   // pos/scale: what addObject got
+    std::vector<HexBox> hexBoxes;
+    std::vector<HexObj> hexObjs;
+    V3 hexTarget = V3{0, 0, 0};                                                     // HexExplore rewardObjectCoords
     // Collect: numPlatforms holds numPositiveRewards, highestTower holds positiveRewardsCollected (scenario_collect.hpp:76)
     std::vector<int8_t> heightmap = std::vector<int8_t>(HM_DIM * HM_DIM, -1);   // [x * HM_DIM + z]: top solid y of the column, -1 = no voxels
     TerrainBox terrain[MAX_TERRAIN];
@@ -353,14 +372,14 @@ static float tower_reward(const Env &e)
 struct C3 { int x, y, z; };
 
 // DefaultScenario::spawnAgents, scenario_default.hpp:80-97 ; agent ctor agent.cpp:24-65
-static void spawn_agents(Env &e, const std::vector<C3> &spawns)
+static void spawn_agents(Env &e, const std::vector<C3> &spawns, const float *yaw = nullptr)   // yaw: HexMemory passes the angles (no draw)
 {
     for (int i = 0; i < e.numAgents; ++i) {
         const C3 sp = spawns[i < int(spawns.size()) ? i : 0];
         Agent &a = e.agents[i];
         float keepShaping[MAX_SHAPING];
         std::memcpy(keepShaping, a.shaping, sizeof keepShaping);
-        const float randomRotation = frand(e.rng) * PI_F * 2;
+        const float randomRotation = yaw ? yaw[i] : frand(e.rng) * PI_F * 2;
         float c, s;
         yaw_matrix(randomRotation, &c, &s);
         a.pos = v3(float(sp.x) + 0.5f, float(sp.y) + 0.0f + AGENT_HEIGHT, float(sp.z) + 0.5f);
@@ -376,11 +395,11 @@ static void spawn_agents(Env &e, const std::vector<C3> &spawns)
 
 struct F3 { float x, y, z; };
 // same as spawn_agents for starting positions that are not voxel corners (Sokoban)
-static void spawn_agents_at(Env &e, const std::vector<F3> &positions)
+static void spawn_agents_at(Env &e, const std::vector<F3> &positions, const float *yaw = nullptr)
 {
     std::vector<C3> cells;
     for (const F3 &p : positions) cells.push_back(C3{int(floorf(p.x)), int(floorf(p.y)), int(floorf(p.z))});
-    spawn_agents(e, cells);
+    spawn_agents(e, cells, yaw);
     for (int i = 0; i < e.numAgents; ++i) {
         const F3 p = positions[i < int(positions.size()) ? i : 0];
         e.agents[i].pos = v3(p.x + 0.5f, p.y + 0.0f + AGENT_HEIGHT, p.z + 0.5f);
@@ -1231,6 +1250,234 @@ static void hex_maze_generate(HexMaze &m, int size, uint32_t kruskal_seed)
 // ------------------------------------------------------------------------------------------------
 // Sokoban -- scenario_sokoban.{hpp,cpp}: Boxoban levels (text files under $BOXOBAN_LEVELS/unfiltered/train), voxel size 2.
 // ------------------------------------------------------------------------------------------------
+// The three wall orientations.  layoutBox.rotateY(-atanf(dz / dx)) (component_hexagonal_maze.cpp:84-90) of a honeycomb border is +30,
+// -30 or 90 degrees; (cos, sin) are literals so that neither libm nor constant folding is involved (the reference's 90 degrees is
+// float(M_PI_2), cos = -4.4e-8: we use exactly 0).  Frame k: local = Ry(r)^T world, Ry(r) = [[c, 0, s], [0, 1, 0], [-s, 0, c]].
+static const float HEX_ROT[HEX_FRAMES][2] = {{0.8660254f, 0.5f}, {0.8660254f, -0.5f}, {0.0f, 1.0f}};
+static inline V3 hex_to_local(int k, V3 p)
+{
+    const float c = HEX_ROT[k][0], s = HEX_ROT[k][1];
+    return v3(c * p.x - s * p.z, p.y, s * p.x + c * p.z);
+}
+static inline V3 hex_to_world(int k, V3 p)
+{
+    const float c = HEX_ROT[k][0], s = HEX_ROT[k][1];
+    return v3(c * p.x + s * p.z, p.y, c * p.z - s * p.x);
+}
+
+struct HexParams {   // HexagonalMazeComponent members after reset(), component_hexagonal_maze.cpp:20-44
+    int size;
+    float scale, wallHeight, omitWalls, landmarkProb;
+    unsigned bottomEdging, topEdging;
+    double xMin, xMax, yMin, yMax;
+};
+
+static void hex_maze_reset(Env &e, HexMaze &m, HexParams &hp, int minSize, int maxSize, float omitMin, float omitMax, uint32_t kruskalSeed)
+{
+    hp.size = randRange(minSize, maxSize, e.rng);
+    // `Kruskal algorithm;` seeds its own mt19937 from std::random_device (mazes/spanningtreealgorithm.h:19-20): not reproducible
+    // in the reference.  Ours: seeded with the episode seed Env::reset drew, no extra draw from the env's generator.
+    hex_maze_generate(m, hp.size, kruskalSeed);
+    hp.scale = 3.5f;
+    hp.wallHeight = frand(e.rng) * 0.55f + 0.85f;
+    hp.omitWalls = frand(e.rng) * (omitMax - omitMin) + omitMin;
+    hp.landmarkProb = frand(e.rng) * 0.15f + 0.15f;
+    hp.bottomEdging = ALL_COLORS[randRange(0, 22, e.rng)];
+    hp.topEdging = ALL_COLORS[randRange(0, 22, e.rng)];
+    hp.xMin = -m.xlim * hp.scale; hp.xMax = m.xlim * hp.scale; hp.yMin = -m.ylim * hp.scale; hp.yMax = m.ylim * hp.scale;
+}
+
+// HexagonalMazeComponent::addDrawablesAndCollisions, component_hexagonal_maze.cpp:46-133
+static void hex_add_maze(Env &e, const HexMaze &m, const HexParams &hp)
+{
+    {   // floor: addStaticCollidingBox(scale, translation): the unit cube [-1, 1]^3 scaled
+        const V3 sc = v3(float(hp.xMax - hp.xMin), 0.0001f, float(hp.yMax - hp.yMin));
+        const V3 tr = v3(float(hp.xMax + hp.xMin) / 2, 0.0f, float(hp.yMax + hp.yMin) / 2);
+        Env::HexBox b; b.frame = -1; b.collide = 1; b.color = randomLayoutColor(e.rng);
+        b.lo = v3(tr.x - sc.x, tr.y - sc.y, tr.z - sc.z); b.hi = v3(tr.x + sc.x, tr.y + sc.y, tr.z + sc.z);
+        e.hexBoxes.push_back(b);
+    }
+    std::set<std::pair<int, int>> existingWalls;
+    for (int cellIdx = 0; cellIdx < m.cells; ++cellIdx)
+        for (const HexBorder &border : m.adj[cellIdx]) {
+            std::pair<int, int> cellPair(cellIdx, border.to);
+            if (cellPair.first > cellPair.second) std::swap(cellPair.first, cellPair.second);
+            if (border.to != -1) {
+                if (existingWalls.count(cellPair)) continue;
+                if (frand(e.rng) < hp.omitWalls) continue;
+            }
+            existingWalls.insert(cellPair);
+            const double x1 = border.x1 * hp.scale, z1 = border.y1 * hp.scale, x2 = border.x2 * hp.scale, z2 = border.y2 * hp.scale;
+            const float length = 0.5f * sqrtf(float((x1 - x2) * (x1 - x2) + (z1 - z2) * (z1 - z2)));
+            const V3 wallT = v3(float(x1 + x2) / 2, hp.wallHeight, float(z1 + z2) / 2);
+            const double deltaX = x1 - x2, deltaZ = z1 - z2;
+            int k = 2;                                           // rotationY = M_PI_2
+            if (std::fabs(deltaX) > 1e-5) k = (deltaZ / deltaX) < 0 ? 0 : 1;   // -atanf(tanAlpha): +30 / -30 degrees (EPSILON 1e-5f, util/macro.hpp:12)
+            const V3 wc = hex_to_local(k, wallT);
+            if (frand(e.rng) < hp.landmarkProb) {
+                const float landmarkWidth = 0.15f, landmarkHeight = landmarkWidth * length / hp.wallHeight;
+                const int numLandmarks = randRange(2, 5, e.rng);
+                for (int li = 0; li < numLandmarks; ++li) {
+                    const float depth = frand(e.rng) * 1.2f + 1.5f;
+                    const float tx = float(li % 2 == 1) * landmarkWidth * 2, ty = float(li > 1) * landmarkHeight * 2 - 0.2f;
+                    // child of the wall box: wallScale * (landmarkTranslation + landmarkScale * cube)
+                    const V3 c = v3(wc.x + length * tx, wc.y + hp.wallHeight * ty, wc.z);
+                    const V3 h = v3(length * landmarkWidth, hp.wallHeight * landmarkHeight, 0.15f * depth);
+                    Env::HexBox b; b.frame = k; b.collide = 0; b.color = ALL_COLORS[randRange(0, 22, e.rng)];
+                    b.lo = v3(c.x - h.x, c.y - h.y, c.z - h.z); b.hi = v3(c.x + h.x, c.y + h.y, c.z + h.z);
+                    e.hexBoxes.push_back(b);
+                }
+            }
+            {   // the wall: drawn DARK_BLUE, btBoxShape(1, 1, 1) under the same transformation
+                const V3 h = v3(length, hp.wallHeight, 0.15f);
+                Env::HexBox b; b.frame = k; b.collide = 1; b.color = 0x3a7fa6;
+                b.lo = v3(wc.x - h.x, wc.y - h.y, wc.z - h.z); b.hi = v3(wc.x + h.x, wc.y + h.y, wc.z + h.z);
+                e.hexBoxes.push_back(b);
+            }
+            {   // bottom edging (the top one is commented out in the reference)
+                const V3 h = v3(length * 1.02f, hp.wallHeight * 0.12f, 0.2f);
+                const V3 c = hex_to_local(k, v3(wallT.x, h.y, wallT.z));
+                Env::HexBox b; b.frame = k; b.collide = 0; b.color = hp.bottomEdging;
+                b.lo = v3(c.x - h.x, c.y - h.y, c.z - h.z); b.hi = v3(c.x + h.x, c.y + h.y, c.z + h.z);
+                e.hexBoxes.push_back(b);
+            }
+        }
+}
+
+static Env::HexObj hex_object(int shape, unsigned color, V3 loc, V3 scale, int good, V3 gridCoord)
+{
+    Env::HexObj o;
+    o.pos = loc; o.scale = scale; o.shape = shape; o.good = good; o.alive = 1; o.color = color;
+    o.vox[0] = (int)lroundf(floorf(gridCoord.x)); o.vox[1] = (int)lroundf(floorf(gridCoord.y)); o.vox[2] = (int)lroundf(floorf(gridCoord.z));
+    return o;
+}
+
+static void hex_common_reset(Env &e)
+{
+    std::fill(e.chunk.begin(), e.chunk.end(), 0);
+    e.numBoxes = 0; e.numObjects = 0; e.numTerrain = 0; e.numRewards = 0; e.numItems = 0; e.numStatic = 0;
+    e.L = e.H = e.W = 0; e.bz[0] = e.bz[1] = e.bz[2] = e.bz[3] = 0; e.drawWalls = 0;
+    e.solved = 0; e.highestTower = 0; e.numPlatforms = 0; e.bzReward = 0; e.barHalfWidth = 0.24f;
+    e.hexBoxes.clear(); e.hexObjs.clear();
+}
+
+// HexExploreScenario: reset :21-41, agentStartingPositions :60-101, addEpisodeDrawables :103-110
+static void hex_explore_generate(Env &e, uint32_t kruskalSeed)
+{
+    hex_common_reset(e);
+    HexMaze m; HexParams hp;
+    hex_maze_reset(e, m, hp, 2, 8, 0.1f, 0.4f, kruskalSeed);
+    const int randomCellIdx = randRange(0, m.cells, e.rng);
+    e.hexTarget = v3(float(m.centers[randomCellIdx].first) * hp.scale, 0.0f, float(m.centers[randomCellIdx].second) * hp.scale);
+
+    // spawnAgents (scenario_default.hpp:80-97): starting positions, then one frand per agent
+    std::vector<int> cellIndices(m.cells, 0);
+    std::iota(cellIndices.begin(), cellIndices.end(), 0);
+    std::shuffle(cellIndices.begin(), cellIndices.end(), e.rng);
+    std::vector<F3> positions;
+    float furthest = 0;
+    for (int cellIdx : cellIndices) {
+        const V3 spawnPos = v3(float(m.centers[cellIdx].first) * hp.scale, 0.1f, float(m.centers[cellIdx].second) * hp.scale);
+        const float distance = sqrtf(len2(e.hexTarget - spawnPos));
+        const float rotation = float(2 * M_PI / e.numAgents);
+        if (distance > furthest) {
+            positions.clear();
+            for (int i = 0; i < e.numAgents; ++i)
+                positions.push_back(F3{spawnPos.x + sinf(float(i) * rotation), spawnPos.y + 0.0f, spawnPos.z + cosf(float(i) * rotation)});
+            furthest = distance;
+        }
+        if (distance > float(hp.size) * hp.scale) break;
+    }
+    if (positions.empty()) positions.assign(size_t(e.numAgents), F3{0, 1, 0});
+    spawn_agents_at(e, positions);
+
+    hex_add_maze(e, m, hp);
+    const float sc = 1.9f;   // the reward object: VIOLET diamond
+    e.hexObjs.push_back(hex_object(HEX_DIAMOND, 0xd468ee, v3(e.hexTarget.x + 0.0f, e.hexTarget.y + 1.2f, e.hexTarget.z + 0.0f),
+                                   v3(0.17f * sc, 0.35f * sc, 0.17f * sc), 1, e.hexTarget));
+    e.episodeLen = e.p_episodeLengthSec;
+}
+
+// HexMemoryScenario: reset :21-82, spawnAgents :131-160, addEpisodeDrawables :163-216
+static void hex_memory_generate(Env &e, uint32_t kruskalSeed)
+{
+    hex_common_reset(e);
+    HexMaze m; HexParams hp;
+    hex_maze_reset(e, m, hp, 2, 8, 0.1f, 0.95f, kruskalSeed);
+
+    double minDistanceToCenter = 1e9f;
+    int centerCellIdx = 0;
+    for (int cellIdx = 0; cellIdx < m.cells; ++cellIdx) {
+        const double d = sqrt(m.centers[cellIdx].first * m.centers[cellIdx].first + m.centers[cellIdx].second * m.centers[cellIdx].second);
+        if (d < minDistanceToCenter) { centerCellIdx = cellIdx; minDistanceToCenter = float(d); }   // float minDistanceToCenter
+    }
+    const V3 landmarkLocation = v3(float(m.centers[centerCellIdx].first * hp.scale), 1.0f, float(m.centers[centerCellIdx].second * hp.scale));
+
+    std::vector<F3> objectCoordinates;
+    for (int cellIdx = 0; cellIdx < m.cells; ++cellIdx) {
+        if (cellIdx == centerCellIdx) continue;
+        // Vector3(frand - 0.5f, 0, frand - 0.5f): GCC evaluates the arguments right to left, z first
+        const float oz = frand(e.rng) - 0.5f;
+        const float ox = frand(e.rng) - 0.5f;
+        const float cx = float(m.centers[cellIdx].first) + ox, cz = float(m.centers[cellIdx].second) + oz;
+        objectCoordinates.push_back(F3{cx * hp.scale, 0.5f + 0.0f, cz * hp.scale});
+    }
+    std::shuffle(objectCoordinates.begin(), objectCoordinates.end(), e.rng);
+    const float fraction = frand(e.rng) * 0.25f + 0.2f;
+    const long numGood = std::lround(ceilf(fraction * objectCoordinates.size()));
+    const long numBad = numGood;
+    const bool haveBad = long(objectCoordinates.size()) >= numGood + numBad;
+
+    // spawnAgents: no draws; agents in a circle around the origin, each looking along its own direction
+    {
+        const float rotationBetweenAgents = float(2 * M_PI / e.numAgents);
+        std::vector<F3> positions;
+        std::vector<float> yaw;
+        for (int i = 0; i < e.numAgents; ++i) {
+            positions.push_back(F3{1.5f * sinf(rotationBetweenAgents * float(i)), 1.5f * 0.3f, 1.5f * cosf(rotationBetweenAgents * float(i))});
+            yaw.push_back(rotationBetweenAgents * i);
+        }
+        spawn_agents_at(e, positions, yaw.data());
+    }
+
+    // addEpisodeDrawables
+    unsigned goodColor = OBJECT_COLORS[randRange(0, 14, e.rng)], badColor = goodColor;
+    int goodShape = randRange(0, 3, e.rng), badShape = goodShape;
+    while (badColor == goodColor && badShape == goodShape) {
+        badColor = OBJECT_COLORS[randRange(0, 14, e.rng)];
+        badShape = randRange(0, 3, e.rng);
+    }
+    hex_add_maze(e, m, hp);
+
+    auto scaleOf = [](int shape) {
+        if (shape == HEX_SPHERE) return v3(0.75f, 0.75f, 0.75f);
+        if (shape == HEX_PILLAR) return v3(0.5f, 2.0f, 0.5f);
+        return v3(0.17f * 2.2f, 0.45f * 2.2f, 0.17f * 2.2f);
+    };
+    auto shiftOf = [](int shape) {
+        if (shape == HEX_SPHERE) return v3(0.5f, 0.1f, 0.5f);
+        if (shape == HEX_PILLAR) return v3(0.5f, 0.05f, 0.5f);
+        return v3(0.5f, 0.6f, 0.5f);
+    };
+    {   // the landmark object in the centre cell shows what to collect; it is not in the grid
+        Env::HexObj o = hex_object(goodShape, goodColor, landmarkLocation + shiftOf(goodShape), scaleOf(goodShape), 1, landmarkLocation);
+        o.alive = 0;
+        e.hexObjs.push_back(o);
+    }
+    const float objScale = 0.6f;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int shape = pass == 0 ? goodShape : badShape;
+        const unsigned color = pass == 0 ? goodColor : badColor;
+        const long from = pass == 0 ? 0 : numGood, to = pass == 0 ? numGood : (haveBad ? numGood + numBad : numGood);
+        for (long i = from; i < to; ++i) {
+            const V3 coord = v3(objectCoordinates[i].x, objectCoordinates[i].y, objectCoordinates[i].z);
+            e.hexObjs.push_back(hex_object(shape, color, coord + shiftOf(shape) * objScale, scaleOf(shape) * objScale, pass == 0, coord));
+        }
+    }
+    e.numPlatforms = int(numGood);
+    e.episodeLen = e.p_episodeLengthSec + 3.0f * float(numGood);   // scenario_hex_memory.hpp:45-49
+}
+
 static std::vector<std::string> split_tokens(const std::string &text, char delim)
 {   // splitString (util/src/string_utils.cpp:10-25) is strtok_r: empty tokens are skipped
     std::vector<std::string> out;
@@ -1354,6 +1601,8 @@ static void env_reset(Env &e)
     else if (e.scenario == SCN_COLLECT) collect_generate(e);
     else if (e.scenario == SCN_REARRANGE) rearrange_generate(e);
     else if (e.scenario == SCN_EMPTY) empty_generate(e);
+    else if (e.scenario == SCN_HEX_MEMORY) hex_memory_generate(e, uint32_t(seed));
+    else if (e.scenario == SCN_HEX_EXPLORE) hex_explore_generate(e, uint32_t(seed));
     else sokoban_generate(e);
 }
 
@@ -1362,7 +1611,8 @@ static void env_reset(Env &e)
 // axis-aligned box == the capsule CENTRE against the box grown by CAP_HH in +-y, rounded by r.
 // ------------------------------------------------------------------------------------------------
 struct Collider {
-    int kind;    // 0 none, 1 box (lo/hi already grown in y by CAP_HH), 2 vertical capsule (other agent)
+    int kind;    // 0 none, 1 box (lo/hi already grown in y by CAP_HH), 2 vertical capsule (other agent), 3 box in hex wall frame `frame`
+    int frame;
     V3 lo, hi;   // box bounds; capsule: lo = centre, hi.x = segment half-length
 };
 
@@ -1419,6 +1669,11 @@ static Closest closest_capsule(V3 p, V3 centre, float halfLen, float r)
 static Closest closest(const Collider &col, V3 p, float rBox, float rCap)
 {
     if (col.kind == 1) return closest_box(p, col.lo, col.hi, rBox);
+    if (col.kind == 3) {   // rotated about Y only: the capsule is vertical in the wall's frame too
+        Closest c = closest_box(hex_to_local(col.frame, p), col.lo, col.hi, rBox);
+        c.n = hex_to_world(col.frame, c.n);
+        return c;
+    }
     return closest_capsule(p, col.lo, col.hi.x, rCap);
 }
 
@@ -1455,7 +1710,7 @@ static bool convex_cast(const Collider &col, V3 p, V3 d, float *fraction, V3 *no
 
 struct Colliders {
     int n = 0;
-    Collider c[MAX_BOXES + MAX_STATIC + MAX_ITEMS + MAX_OBJECTS + MAX_AGENTS];   // empty slots are never emitted: only the relative order matters
+    Collider c[MAX_BOXES + MAX_STATIC + MAX_ITEMS + MAX_OBJECTS + MAX_AGENTS];   // (Hex*: floor + walls <= 1 + 294)   // empty slots are never emitted: only the relative order matters
 };
 
 // Rearrange items (arrangementDrawables, scenario_rearrange.cpp:203-263): drawable scale = scales[shape] * 0.45, collision
@@ -1488,6 +1743,14 @@ static void build_colliders(const Env &e, int self, Colliders &out)
         c.lo = v3(float(b.min[0]) * vs, float(b.min[1]) * vs - CAP_HH, float(b.min[2]) * vs);
         c.hi = v3(float(b.max[0]) * vs, float(b.max[1]) * vs + CAP_HH, float(b.max[2]) * vs);
     }
+    if (e.scenario == SCN_HEX_MEMORY || e.scenario == SCN_HEX_EXPLORE)
+        for (const Env::HexBox &b : e.hexBoxes) {   // floor (addStaticCollidingBox) and walls (btBoxShape(1,1,1) child of the wall box)
+            if (!b.collide) continue;
+            Collider &c = out.c[out.n++];
+            c.kind = b.frame < 0 ? 1 : 3; c.frame = b.frame;
+            c.lo = v3(b.lo.x, b.lo.y - CAP_HH, b.lo.z);
+            c.hi = v3(b.hi.x, b.hi.y + CAP_HH, b.hi.z);
+        }
     if (e.scenario == SCN_SOKOBAN)
         for (int i = 0; i < e.numObjects; ++i) {   // pushable boxes, scenario_sokoban.cpp:275-293: collision scale (1.15, 3, 1.15), offset (0, 0.6, 0)
             const Object &o = e.objects[i];
@@ -1983,8 +2246,9 @@ static void env_step(Env &e)
     for (int i = 0; i < e.numAgents; ++i) player_step(e, i, dt);
 
     // scenario->step(): objectStacking, fallDetection, zone reward (scenario_tower_building.cpp:179-199)
+    const bool hex = e.scenario == SCN_HEX_MEMORY || e.scenario == SCN_HEX_EXPLORE;
     for (int i = 0; i < e.numAgents; ++i)
-        if (e.scenario != SCN_SOKOBAN && e.scenario != SCN_EMPTY && (e.agents[i].action & (1 << 8))) on_interact(e, i);   // (Sokoban, Empty: no ObjectStackingComponent)
+        if (e.scenario != SCN_SOKOBAN && e.scenario != SCN_EMPTY && !hex && (e.agents[i].action & (1 << 8))) on_interact(e, i);   // (Sokoban, Empty, Hex*: no ObjectStackingComponent)
 
     auto reset_agent = [&](Agent &a) {   // FallDetectionComponent::resetAgent :45-55 + controller warp() :509-517
         int p[3] = {a.spawn[0], a.spawn[1], a.spawn[2]};
@@ -1994,7 +2258,7 @@ static void env_step(Env &e)
         a.hvx = a.hvz = 0; a.vvel = 0;
     };
     for (int i = 0; i < e.numAgents; ++i)  // component_fall_detection.hpp:33-43
-        if (e.scenario != SCN_REARRANGE && e.scenario != SCN_SOKOBAN && e.scenario != SCN_EMPTY && e.agents[i].pos.y + 0.05f < -20.0f) {   // (Rearrange, Sokoban, Empty: no FallDetectionComponent)
+        if (e.scenario != SCN_REARRANGE && e.scenario != SCN_SOKOBAN && e.scenario != SCN_EMPTY && !hex && e.agents[i].pos.y + 0.05f < -20.0f) {   // (Rearrange, Sokoban, Empty, Hex*: no FallDetectionComponent)
             reset_agent(e.agents[i]);
             if (e.scenario == SCN_COLLECT) reward_agent(e, 2, i, 1);   // CollectScenario::agentFell, scenario_collect.cpp:214-218
         }
@@ -2022,6 +2286,43 @@ static void env_step(Env &e)
                     if (e.objects[o].state == 0 && e.objects[o].x == vox[0] && e.objects[o].y == vox[1] && e.objects[o].z == vox[2])
                         e.objects[o].state = -1;
             }
+        }
+    } else if (e.scenario == SCN_HEX_EXPLORE) {   // HexExploreScenario::step, scenario_hex_explore.cpp:43-58
+        for (int i = 0; i < e.numAgents; ++i) {
+            const Agent &a = e.agents[i];
+            const V3 t = v3(a.pos.x, a.pos.y + 0.05f, a.pos.z);
+            const float distance = sqrtf(len2(t - e.hexTarget));
+            if (double(distance) < 1.2 && !e.solved) {
+                e.solved = 1;
+                e.episodeSec = std::max(e.episodeSec, e.episodeLen - 0.3f);   // doneWithTimer()
+                reward_team(e, 1, i, 1);
+                Env::HexObj &o = e.hexObjs[0];   // rewardObject->translate({1e3, 1e3, 1e3})
+                o.pos = v3(o.pos.x + 1e3f, o.pos.y + 1e3f, o.pos.z + 1e3f);
+                o.alive = 0;
+                break;
+            }
+        }
+    } else if (e.scenario == SCN_HEX_MEMORY) {    // HexMemoryScenario::step, scenario_hex_memory.cpp:84-127
+        if (e.highestTower >= e.numPlatforms && !e.solved) {
+            e.solved = 1;
+            e.episodeSec = std::max(e.episodeSec, e.episodeLen - 0.3f);
+        }
+        for (int i = 0; i < e.numAgents; ++i) {
+            const Agent &a = e.agents[i];
+            const V3 t = v3(a.pos.x, a.pos.y + 0.05f, a.pos.z);
+            int vox[3];
+            voxel_of(t, vox);
+            for (int dx = -1; dx <= 1; ++dx)
+                for (int dz = -1; dz <= 1; ++dz)
+                    for (Env::HexObj &o : e.hexObjs) {   // a voxel's list is in insertion (= index) order
+                        if (!o.alive || o.vox[0] != vox[0] + dx || o.vox[1] != vox[1] || o.vox[2] != vox[2] + dz) continue;
+                        const float distance = sqrtf(len2(o.pos - t));
+                        if (!(distance < 1.0f)) continue;
+                        reward_team(e, o.good ? 1 : 2, i, 1);
+                        e.highestTower += o.good;
+                        o.pos = v3(o.pos.x + 100.0f, o.pos.y + 100.0f, o.pos.z + 100.0f);   // still drawn, out of everybody's way
+                        o.alive = 0;
+                    }
         }
     } else if (e.scenario == SCN_EMPTY) {
         // EmptyScenario::step() {} (scenario_empty.hpp:22)
@@ -2098,7 +2399,7 @@ struct Prim {
     int kind;   // 1 = box in frame `frame`, 2 = vertical capsule in world, 3 = cone in world (lo = apex, hi = (radius, height, +1 apex up / -1 apex down)),
                 // 4 / 5 / 6 = unit sphere / unit capsule (r 1, half-length 1) / unit capped cylinder (r 1, half-length 0.5), axis y,
                 //             scaled by hi and centred at lo in frame `frame`
-    int frame;  // -1 world axes, k>=0: camera frame of agent k
+    int frame;  // -1 world axes, k in [0, MAX_AGENTS): camera frame of agent k, MAX_AGENTS + k: hex wall orientation k
     V3 lo, hi;  // box bounds in its frame; capsule: lo = centre, hi = (radius, halfLen, 0)
     unsigned color;
 };
@@ -2136,6 +2437,27 @@ static void build_prims(const Env &e, int viewer, std::vector<Prim> &out)
             Prim p; p.kind = 1; p.frame = -1; p.color = 0x3a7fa6;   // DARK_BLUE
             p.lo = v3(c.x - sx, c.y - sy, c.z - sx); p.hi = v3(c.x + sx, c.y + sy, c.z + sx);
             out.push_back(p);
+        }
+    }
+    if (e.scenario == SCN_HEX_MEMORY || e.scenario == SCN_HEX_EXPLORE) {
+        for (const Env::HexBox &b : e.hexBoxes) {
+            Prim p; p.kind = 1; p.frame = b.frame < 0 ? -1 : MAX_AGENTS + b.frame; p.lo = b.lo; p.hi = b.hi; p.color = b.color;
+            out.push_back(p);
+        }
+        for (const Env::HexObj &o : e.hexObjs) {   // layout_utils.cpp:85-126 addSphere / addPillar / addDiamond
+            Prim p; p.frame = -1; p.color = o.color;
+            if (o.shape == HEX_SPHERE) { p.kind = 4; p.lo = o.pos; p.hi = o.scale; out.push_back(p); }
+            else if (o.shape == HEX_PILLAR) {
+                p.kind = 6; p.lo = o.pos; p.hi = o.scale; out.push_back(p);
+                const float capY = 0.47f * o.scale.y;
+                p.hi = v3(o.scale.x * 1.2f, 0.15f, o.scale.z * 1.2f);
+                p.lo = v3(o.pos.x, o.pos.y + capY, o.pos.z); out.push_back(p);
+                p.lo = v3(o.pos.x, o.pos.y - capY, o.pos.z); out.push_back(p);
+            } else {
+                p.kind = 3;
+                p.lo = v3(o.pos.x, o.pos.y + 0.5f * o.scale.y, o.pos.z); p.hi = v3(o.scale.x, o.scale.y, 1.0f); out.push_back(p);
+                p.lo = v3(o.pos.x, o.pos.y - 1.5f * o.scale.y, o.pos.z); p.hi = v3(o.scale.x, o.scale.y, -1.0f); out.push_back(p);
+            }
         }
     }
     if (e.scenario == SCN_TOWER) {   // building zone slab, layout_utils.cpp:53-68
@@ -2412,6 +2734,9 @@ static void render_agent(const Env &e, int viewer, int W, int H, uint8_t *out)
     V3 originIn[MAX_AGENTS];
     for (int k = 0; k < e.numAgents; ++k) originIn[k] = mat_tmul(cams[k].c, cam.eye - cams[k].eye);
 
+    V3 hexOrigin[HEX_FRAMES];
+    for (int k = 0; k < HEX_FRAMES; ++k) hexOrigin[k] = hex_to_local(k, cam.eye);
+
     const V3 LIGHT = v3(0.0f, 4.0f, 2.0f);
     const float AMB = float(0x55) / 255.0f, DIF = float(0xbb) / 255.0f, LCOL = float(0xaa) / 255.0f;
 
@@ -2444,6 +2769,10 @@ static void render_agent(const Env &e, int viewer, int W, int H, uint8_t *out)
                         hit = ray_scaled_shape(p.kind, originIn[p.frame], dk, p.lo, p.hi, &t, &n);
                         if (hit) n = mat_tmul(cam.c, mat_mul(cams[p.frame].c, n));
                     }
+                } else if (p.frame >= MAX_AGENTS) {   // hex wall frame: a rotation about Y around the world origin
+                    const int k = p.frame - MAX_AGENTS;
+                    hit = ray_box(hexOrigin[k], hex_to_local(k, dw), p.lo, p.hi, &t, &n);
+                    if (hit) n = mat_tmul(cam.c, hex_to_world(k, n));
                 } else if (p.frame < 0) {
                     hit = ray_box(cam.eye, dw, p.lo, p.hi, &t, &n);
                     if (hit) n = mat_tmul(cam.c, n);
@@ -2564,6 +2893,8 @@ mvo_gym *mvo_create(const char *scenario, int w, int h, int num_envs, int num_ag
     else if (s == "rearrange") scen = SCN_REARRANGE;   // scenarios/init.hpp:49
     else if (s == "sokoban") scen = SCN_SOKOBAN;       // scenarios/init.hpp:46
     else if (s == "empty") scen = SCN_EMPTY;           // scenarios/init.hpp:34
+    else if (s == "hexmemory") scen = SCN_HEX_MEMORY;  // scenarios/init.hpp:47-48
+    else if (s == "hexexplore") scen = SCN_HEX_EXPLORE;
     else { fprintf(stderr, "mv_oracle: unknown scenario %s\n", s.c_str()); return nullptr; }
     if (num_agents_per_env < 1 || num_agents_per_env > MAX_AGENTS || num_envs < 1) return nullptr;
     auto *g = new mvo_gym();
@@ -2596,9 +2927,11 @@ mvo_gym *mvo_create(const char *scenario, int w, int h, int num_envs, int num_ag
         }
         e->scenario = scen;
         e->op = op;
-        e->numShaping = scen == SCN_TOWER || scen == SCN_SOKOBAN ? 4 : scen == SCN_REARRANGE ? 3 : scen == SCN_EMPTY ? 1 : 5;   // Empty: teamSpirit only
+        e->numShaping = scen == SCN_TOWER || scen == SCN_SOKOBAN ? 4 : scen == SCN_REARRANGE || scen == SCN_HEX_MEMORY ? 3
+                      : scen == SCN_HEX_EXPLORE ? 2 : scen == SCN_EMPTY ? 1 : 5;   // Empty: teamSpirit only
         e->shapingKeys = scen == SCN_TOWER ? SHAPING_KEYS_TOWER : scen == SCN_OBSTACLES ? SHAPING_KEYS_OBST
-                       : scen == SCN_COLLECT ? SHAPING_KEYS_COLLECT : scen == SCN_SOKOBAN ? SHAPING_KEYS_SOKOBAN : SHAPING_KEYS_REARRANGE;
+                       : scen == SCN_COLLECT ? SHAPING_KEYS_COLLECT : scen == SCN_SOKOBAN ? SHAPING_KEYS_SOKOBAN
+                       : scen == SCN_HEX_MEMORY ? SHAPING_KEYS_HEX_MEMORY : scen == SCN_HEX_EXPLORE ? SHAPING_KEYS_HEX_EXPLORE : SHAPING_KEYS_REARRANGE;
         for (int a = 0; a < MAX_AGENTS; ++a) {
             std::memset(e->agents[a].shaping, 0, sizeof e->agents[a].shaping);
             for (int k = 0; k < e->numShaping; ++k)
@@ -2606,6 +2939,8 @@ mvo_gym *mvo_create(const char *scenario, int w, int h, int num_envs, int num_ag
                                         : scen == SCN_COLLECT ? SHAPING_DEFAULT_COLLECT[k]
                                         : scen == SCN_REARRANGE ? SHAPING_DEFAULT_REARRANGE[k]
                                         : scen == SCN_SOKOBAN ? SHAPING_DEFAULT_SOKOBAN[k]
+                                        : scen == SCN_HEX_MEMORY ? SHAPING_DEFAULT_HEX_MEMORY[k]
+                                        : scen == SCN_HEX_EXPLORE ? SHAPING_DEFAULT_HEX_EXPLORE[k]
                                         : (k == 4 ? carriedDefault : SHAPING_DEFAULT_OBST[k]);
         }
         g->envs.push_back(std::move(e));
@@ -2696,6 +3031,11 @@ struct SnapHeader {
     int8_t heightmap[HM_DIM * HM_DIM];
     int32_t num_items, items[MAX_ITEMS][5];   // Rearrange: shape, colour, offset x y z
     uint8_t soko[SOKO_DIM * SOKO_DIM];        // Sokoban: wall / goal cells
+    // Hex*: boxes {lo[3], meta = (frame + 1) | collide << 4, hi[3], colour}, objects {pos[3], meta = shape | good << 4 | alive << 8 |
+    // (vox.x + 128) << 12 | (vox.z + 128) << 20, scale[3], colour} -- the device's own records
+    int32_t hex_num_boxes, hex_num_objs;
+    float hex_target[3];
+    struct HexRec { float a[3]; int32_t meta; float b[3]; int32_t color; } hex_boxes[HEX_MAX_BOXES], hex_objs[HEX_MAX_OBJS];
 };
 #pragma pack(pop)
 
@@ -2753,6 +3093,19 @@ void mvo_snapshot(mvo_gym *g, int env, void *out)
     for (int i = 0; i < s->num_items; ++i) {
         s->items[i][0] = e.items[i].shape; s->items[i][1] = (int32_t)e.items[i].color;
         s->items[i][2] = e.items[i].off[0]; s->items[i][3] = e.items[i].off[1]; s->items[i][4] = e.items[i].off[2];
+    }
+    if (e.scenario == SCN_HEX_MEMORY || e.scenario == SCN_HEX_EXPLORE) {
+        s->hex_num_boxes = int(e.hexBoxes.size()); s->hex_num_objs = int(e.hexObjs.size());
+        s->hex_target[0] = e.hexTarget.x; s->hex_target[1] = e.hexTarget.y; s->hex_target[2] = e.hexTarget.z;
+        for (size_t i = 0; i < e.hexBoxes.size() && i < HEX_MAX_BOXES; ++i) {
+            const Env::HexBox &b = e.hexBoxes[i];
+            s->hex_boxes[i] = SnapHeader::HexRec{{b.lo.x, b.lo.y, b.lo.z}, (b.frame + 1) | (b.collide << 4), {b.hi.x, b.hi.y, b.hi.z}, int32_t(b.color)};
+        }
+        for (size_t i = 0; i < e.hexObjs.size() && i < HEX_MAX_OBJS; ++i) {
+            const Env::HexObj &o = e.hexObjs[i];
+            const int meta = o.shape | (o.good << 4) | (o.alive << 8) | (((o.vox[0] + 128) & 255) << 12) | (((o.vox[2] + 128) & 255) << 20);
+            s->hex_objs[i] = SnapHeader::HexRec{{o.pos.x, o.pos.y, o.pos.z}, meta, {o.scale.x, o.scale.y, o.scale.z}, int32_t(o.color)};
+        }
     }
     std::memcpy(out, s, sizeof *s);
     delete s;

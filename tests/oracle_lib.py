@@ -16,6 +16,8 @@ SNAP_AGENT = np.dtype([
     ("step_offset", "<f4"), ("jump_speed", "<f4"), ("was_jumping", "<i4"), ("carrying", "<i4"), ("picked_up", "<i4"),
     ("visited_zone", "<i4"), ("spawn", "<i4", 3), ("last_reward", "<f4"), ("total_reward", "<f4"), ("shaping", "<f4", MAX_SHAPING),
 ])
+HEX_MAX_BOXES, HEX_MAX_OBJS = 2048, 128
+HEX_REC = np.dtype([("a", "<f4", 3), ("meta", "<i4"), ("b", "<f4", 3), ("color", "<i4")])
 SNAP = np.dtype([
     ("scenario", "<i4"), ("L", "<i4"), ("H", "<i4"), ("W", "<i4"), ("bz", "<i4", 4), ("layout_color", "<i4"), ("wall_color", "<i4"),
     ("draw_walls", "<i4"), ("num_objects", "<i4"), ("num_boxes", "<i4"), ("num_frames", "<i4"), ("done", "<i4"),
@@ -25,6 +27,8 @@ SNAP = np.dtype([
     ("objects", "i1", (MAX_OBJECTS, 4)), ("rewards", "i1", (MAX_REWARDS, 4)),
     ("agents", SNAP_AGENT, MAX_AGENTS), ("chunk", "u1", CHUNK), ("heightmap", "i1", HM_DIM * HM_DIM),
     ("num_items", "<i4"), ("items", "<i4", (8, 5)), ("soko", "u1", 32 * 32),
+    ("hex_num_boxes", "<i4"), ("hex_num_objs", "<i4"), ("hex_target", "<f4", 3),
+    ("hex_boxes", HEX_REC, HEX_MAX_BOXES), ("hex_objs", HEX_REC, HEX_MAX_OBJS),
 ])
 
 
@@ -139,7 +143,8 @@ class OracleGym:
     def get_reward_shaping(self, env_idx, agent_idx):
         out = {}
         for k in ("teamSpirit", "towerPickedUpObject", "towerVisitedBuildingZoneWithObject", "towerBuildingReward",
-                  "obstaclesAgentAtExit", "obstaclesAllAgentsAtExit", "obstaclesExtraReward", "obstaclesAgentCarriedObjectToExit"):
+                  "obstaclesAgentAtExit", "obstaclesAllAgentsAtExit", "obstaclesExtraReward", "obstaclesAgentCarriedObjectToExit",
+                  "memoryCollectGood", "memoryCollectBad", "exploreSolved"):
             f = C.c_int(0)
             v = self.L.mvo_get_reward_shaping(self.g, env_idx, agent_idx, k.encode(), C.byref(f))
             if f.value:
