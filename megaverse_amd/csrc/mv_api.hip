@@ -38,6 +38,8 @@ void launch_step_collect(const GymView &gv, hipStream_t stream, int W, int H, in
 void launch_step_sokoban(const GymView &gv, hipStream_t stream, int W, int H, int render);
 void launch_reset_sokoban(const GymView &gv, const SokobanBlob *blobs, int *status, int force_all, hipStream_t stream);
 void launch_reset_collect(const GymView &gv, const CollectBlob *blobs, int *status, int force_all, hipStream_t stream);
+void launch_step_hex(const GymView &gv, hipStream_t stream, int W, int H, int render);
+void launch_reset_hex(const GymView &gv, const HexBlob *blobs, int *status, int force_all, hipStream_t stream);
 }  // namespace mv
 
 using namespace mv;
@@ -69,6 +71,11 @@ static const float SHAPING_DEFAULT_REARRANGE[3] = {0.0f, 1.0f, 10.0f};
 static const char *SHAPING_KEYS_SOKOBAN[4] = {"teamSpirit", "sokobanBoxOnTarget", "sokobanBoxLeavesTarget", "sokobanAllBoxesOnTarget"};
 static const float SHAPING_DEFAULT_SOKOBAN[4] = {0.0f, 1.0f, -1.0f, 10.0f};
 static const char *SHAPING_KEYS_EMPTY[1] = {"teamSpirit"};   // EmptyScenario::defaultRewardShaping() is {} (scenario_empty.hpp:28) + Scenario::init's teamSpirit
+// scenario_hex_memory.hpp:37-43, scenario_hex_explore.hpp:28-31 (+ teamSpirit 0)
+static const char *SHAPING_KEYS_HEX_MEMORY[3] = {"teamSpirit", "memoryCollectGood", "memoryCollectBad"};
+static const float SHAPING_DEFAULT_HEX_MEMORY[3] = {0.0f, 1.0f, -1.0f};
+static const char *SHAPING_KEYS_HEX_EXPLORE[2] = {"teamSpirit", "exploreSolved"};
+static const float SHAPING_DEFAULT_HEX_EXPLORE[2] = {0.0f, 5.0f};
 static const char *SHAPING_KEYS_COLLECT[5] = {"teamSpirit", "collectSingleGood", "collectSingleBad", "collectAll", "collectAbyss"};
 static const float SHAPING_DEFAULT_COLLECT[5] = {0.0f, 1.0f, -1.0f, 5.0f, -0.5f};
 static const int ACTION_SPACE[6] = {3, 3, 3, 2, 2, 3};                          // env.cpp:33
@@ -233,6 +240,8 @@ static bool scenario_from_name(const std::string &scen, int &scenario, ObstacleC
     else if (scen == "rearrange") scenario = SCN_REARRANGE;                            // scenarios/init.hpp:49
     else if (scen == "sokoban") scenario = SCN_SOKOBAN;                                // scenarios/init.hpp:46
     else if (scen == "empty") scenario = SCN_EMPTY;                                    // scenarios/init.hpp:34
+    else if (scen == "hexmemory") scenario = SCN_HEX_MEMORY;                           // scenarios/init.hpp:47
+    else if (scen == "hexexplore") scenario = SCN_HEX_EXPLORE;                         // scenarios/init.hpp:48
     else return false;
     return true;
 }
@@ -248,7 +257,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     int scenario = SCN_TOWER;
     ObstacleConfig oc;
     if (!scenario_from_name(scen, scenario, oc))
-        return fail("Unknown scenario " + scen + " (this build accelerates: TowerBuilding, ObstaclesEasy/Medium/Hard/Walls/Steps/Lava, Collect, Rearrange, Sokoban, Empty)");
+        return fail("Unknown scenario " + scen + " (this build accelerates: TowerBuilding, ObstaclesEasy/Medium/Hard/Walls/Steps/Lava, Collect, Rearrange, Sokoban, HexMemory, HexExplore, Empty)");
     std::vector<std::string> levelFiles;
     if (scenario == SCN_SOKOBAN) {   // SokobanScenario's constructor looks the level files up (scenario_sokoban.cpp:40-78); none is fatal there too
         levelFiles = find_boxoban_level_files();
@@ -271,9 +280,11 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     g->w = cfg->obs_width; g->h = cfg->obs_height;
     g->N = cfg->num_envs; g->A = cfg->num_agents_per_env;
     g->scenario = scenario;
-    g->numShaping = scenario == SCN_TOWER || scenario == SCN_SOKOBAN ? 4 : scenario == SCN_REARRANGE ? 3 : scenario == SCN_EMPTY ? 1 : 5;
+    g->numShaping = scenario == SCN_TOWER || scenario == SCN_SOKOBAN ? 4 : scenario == SCN_REARRANGE || scenario == SCN_HEX_MEMORY ? 3
+                  : scenario == SCN_HEX_EXPLORE ? 2 : scenario == SCN_EMPTY ? 1 : 5;
     g->shapingKeys = scenario == SCN_TOWER ? SHAPING_KEYS_TOWER : scenario == SCN_OBSTACLES ? SHAPING_KEYS_OBST
                    : scenario == SCN_COLLECT ? SHAPING_KEYS_COLLECT : scenario == SCN_SOKOBAN ? SHAPING_KEYS_SOKOBAN
+                   : scenario == SCN_HEX_MEMORY ? SHAPING_KEYS_HEX_MEMORY : scenario == SCN_HEX_EXPLORE ? SHAPING_KEYS_HEX_EXPLORE
                    : scenario == SCN_EMPTY ? SHAPING_KEYS_EMPTY : SHAPING_KEYS_REARRANGE;
     g->envOffset = cfg->total_envs > 0 ? cfg->env_offset : 0;
     g->envStride = cfg->total_envs > 0 && cfg->env_stride > 1 ? cfg->env_stride : 1;
@@ -285,11 +296,12 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     GymView &gv = g->gv;
     gv.num_envs = g->N; gv.num_agents = g->A;
     const bool obstacles = scenario == SCN_OBSTACLES || scenario == SCN_EMPTY, collect = scenario == SCN_COLLECT, rearrange = scenario == SCN_REARRANGE, sokoban = scenario == SCN_SOKOBAN;
-    const bool hostEpisodes = obstacles || collect || rearrange || sokoban;
+    const bool hex = scenario == SCN_HEX_MEMORY || scenario == SCN_HEX_EXPLORE;
+    const bool hostEpisodes = obstacles || collect || rearrange || sokoban || hex;
     gv.scenario = scenario;
     gv.box_stride = collect ? COLLECT_MAX_BOXES : MAX_BOXES;
     gv.reward_stride = collect ? COLLECT_MAX_REWARDS : MAX_REWARDS;
-    g->blobBytes = collect ? sizeof(CollectBlob) : obstacles ? sizeof(EpisodeBlob) : rearrange ? sizeof(RearrangeBlob) : sokoban ? sizeof(SokobanBlob) : 0;
+    g->blobBytes = collect ? sizeof(CollectBlob) : obstacles ? sizeof(EpisodeBlob) : rearrange ? sizeof(RearrangeBlob) : sokoban ? sizeof(SokobanBlob) : hex ? sizeof(HexBlob) : 0;
     // ONE arena for all simulator state: a step touches ~8 arrays per env, separate small allocations
     // cost a TLB miss each per wave (measured: 83 % of the physics kernel's time was spent waiting on
     // ~30 memory operations); one large allocation is backed by large pages.
@@ -301,13 +313,14 @@ int mv_create(const mv_config *cfg, mv_gym **out)
                  szObs = up(NA * (size_t)g->w * g->h * 4);
     const size_t szTerrain = obstacles ? up(N * MAX_TERRAIN * sizeof(TerrainBox)) : 0,
                  szRewObj = hostEpisodes ? up(N * (size_t)gv.reward_stride * sizeof(MovableObject)) : 0,
-                 szHeight = collect ? up(N * (size_t)HM_BYTES) : 0, szItems = rearrange ? up(N * MAX_ITEMS * sizeof(ArrangementItem)) : 0, szCells = sokoban ? up(N * (size_t)(SOKO_DIM * SOKO_DIM)) : 0, szBlobs = up(N * g->blobBytes * (size_t)g->spares), szCnt = up((N + 2) * sizeof(int32_t));
-    gv.vis_stride = collect ? 1024 : 256;
+                 szHeight = collect ? up(N * (size_t)HM_BYTES) : 0, szItems = rearrange ? up(N * MAX_ITEMS * sizeof(ArrangementItem)) : 0, szCells = sokoban ? up(N * (size_t)(SOKO_DIM * SOKO_DIM)) : 0,
+                 szHexB = hex ? up(N * (size_t)HEX_MAX_BOXES * sizeof(HexRec)) : 0, szHexO = hex ? up(N * (size_t)HEX_MAX_OBJS * sizeof(HexRec)) : 0, szBlobs = up(N * g->blobBytes * (size_t)g->spares), szCnt = up((N + 2) * sizeof(int32_t));
+    gv.vis_stride = collect || hex ? 1024 : 256;
     gv.spares = g->spares;
     const size_t szVisP = up(NA * (size_t)gv.vis_stride * 32), szVisR = up(NA * (size_t)gv.vis_stride * 8), szVisC = up(NA * sizeof(int32_t)),
                  szLpt = up(NA * sizeof(int32_t)) + up((NA + 1) * sizeof(int32_t)) + up(NA * (size_t)FRAME_HDR_BYTES) + up(2 * 256 * sizeof(int32_t)) + up(256 * NA * sizeof(int32_t));
     const size_t total = szHdr + szBoxes + szObj + szAg + szAct + szRew + szDone + szObjv + szMd + (hostEpisodes ? 0 : szChunk) + szObs + szTerrain +
-                         szRewObj + szHeight + szItems + szCells + szBlobs + szCnt + szVisP + szVisR + szVisC + szLpt;
+                         szRewObj + szHeight + szItems + szCells + szHexB + szHexO + szBlobs + szCnt + szVisP + szVisR + szVisC + szLpt;
     {
         hipError_t e_ = hipMalloc((void **)&g->arena, total);
         if (e_ != hipSuccess) { mv_destroy(g); return fail(std::string("hipMalloc arena: ") + hipGetErrorString(e_)); }
@@ -337,6 +350,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
         if (collect) { gv.heightmap = (int8_t *)p; p += szHeight; }
         if (rearrange) { gv.items = (ArrangementItem *)p; p += szItems; }
         if (sokoban) { gv.soko_cells = p; p += szCells; }
+        if (hex) { gv.hex_boxes = (HexRec *)p; p += szHexB; gv.hex_objs = (HexRec *)p; p += szHexO; }
         gv.vis_prims = p; p += szVisP;
         gv.vis_rects = p; p += szVisR;
         gv.vis_count = (int32_t *)p; p += szVisC;
@@ -424,6 +438,8 @@ int mv_create(const mv_config *cfg, mv_gym **out)
             ha[i].shaping[k] = scenario == SCN_TOWER ? SHAPING_DEFAULT_TOWER[k] : scenario == SCN_COLLECT ? SHAPING_DEFAULT_COLLECT[k]
                                                      : scenario == SCN_REARRANGE ? SHAPING_DEFAULT_REARRANGE[k]
                                                      : scenario == SCN_SOKOBAN ? SHAPING_DEFAULT_SOKOBAN[k]
+                                                     : scenario == SCN_HEX_MEMORY ? SHAPING_DEFAULT_HEX_MEMORY[k]
+                                                     : scenario == SCN_HEX_EXPLORE ? SHAPING_DEFAULT_HEX_EXPLORE[k]
                                                      : scenario == SCN_EMPTY ? 0.0f
                                                      : (k == 4 ? oc.carried_object_to_exit : SHAPING_DEFAULT_OBST[k]);
         ha[i].carrying = -1; ha[i].jump_speed = 10.0f; ha[i].m00 = 1.0f; ha[i].m22 = 1.0f;
@@ -575,7 +591,7 @@ static int check_status_flags(mv_gym *g)
     std::string msg;
     if (flags & ST_STARVED) msg += "an env finished again before its next episode was resident (it repeated its done step; the next episodes are being uploaded now); ";
     if (flags & ST_CANDIDATES) msg += "collision candidate list overflow (more than 128 bodies around one agent); ";
-    if (flags & ST_VISIBLE) msg += "a frame had more visible primitives than the raster keeps (256, Collect 1024): the excess was not drawn; ";
+    if (flags & ST_VISIBLE) msg += "a frame had more visible primitives than the raster keeps (256; Collect, Hex* 1024): the excess was not drawn; ";
     if (flags & ST_CHUNK) msg += "an object placement outside the 32 x 16 x 32 voxel chunk was refused (the reference's grid is unbounded); ";
     if (gen & GEN_SLABS) msg += "a generated layout merged into more slabs than an episode record holds (128, Collect 1024): the excess was dropped; ";
     if (gen & GEN_TERRAIN) msg += "more than 16 terrain boxes in a generated episode; ";
@@ -676,6 +692,7 @@ int mv_reset(mv_gym *g)
         if (g->scenario == SCN_OBSTACLES || g->scenario == SCN_EMPTY) launch_reset_obstacles(g->gv, (const EpisodeBlob *)g->dBlobs, g->dStatus, 1, g->stream);
         else if (g->scenario == SCN_REARRANGE) launch_reset_rearrange(g->gv, (const RearrangeBlob *)g->dBlobs, g->dStatus, 1, g->stream);
         else if (g->scenario == SCN_SOKOBAN) launch_reset_sokoban(g->gv, (const SokobanBlob *)g->dBlobs, g->dStatus, 1, g->stream);
+        else if (g->scenario == SCN_HEX_MEMORY || g->scenario == SCN_HEX_EXPLORE) launch_reset_hex(g->gv, (const HexBlob *)g->dBlobs, g->dStatus, 1, g->stream);
         else launch_reset_collect(g->gv, (const CollectBlob *)g->dBlobs, g->dStatus, 1, g->stream);
         HIP_TRY(hipEventRecord(g->stepDone, g->stream));   // (the reset kernel reads the ring too)
         g->stepDoneValid = true;
@@ -759,6 +776,7 @@ static int step_impl(mv_gym *g, bool render)
     else if (g->scenario == SCN_COLLECT) launch_step_collect(g->gv, g->stream, g->w, g->h, fused);
     else if (g->scenario == SCN_REARRANGE) launch_step_rearrange(g->gv, g->stream, g->w, g->h, fused);
     else if (g->scenario == SCN_SOKOBAN) launch_step_sokoban(g->gv, g->stream, g->w, g->h, fused);
+    else if (g->scenario == SCN_HEX_MEMORY || g->scenario == SCN_HEX_EXPLORE) launch_step_hex(g->gv, g->stream, g->w, g->h, fused);
     else launch_step(g->gv, g->stream, g->w, g->h, fused);
     if (prof) HIP_TRY(hipEventRecord(ev[1], g->stream));
     // (every step kernel regenerates / swaps the next episode into the envs it finishes)
@@ -963,6 +981,9 @@ struct Snap {
     int8_t heightmap[HM_DIM * HM_DIM];
     int32_t num_items, items[MAX_ITEMS][5];
     uint8_t soko[32 * 32];   // Sokoban level cells
+    int32_t hex_num_boxes, hex_num_objs;
+    float hex_target[3];
+    HexRec hex_boxes[HEX_MAX_BOXES], hex_objs[HEX_MAX_OBJS];
 };
 #pragma pack(pop)
 
@@ -1011,6 +1032,14 @@ int mv_debug_snapshot(mv_gym *g, int32_t env, void *out)
     if (e == hipSuccess && g->gv.heightmap) e = hipMemcpy(s->heightmap, g->gv.heightmap + (size_t)env * HM_BYTES, sizeof s->heightmap, hipMemcpyDeviceToHost);
     if (e != hipSuccess) { delete s; return fail(std::string("mv_debug_snapshot: ") + hipGetErrorString(e)); }
     if (h.scenario == SCN_REARRANGE) h.num_terrain = 0;   // (the header reuses it for the item count, reported as num_items)
+    if (e == hipSuccess && g->gv.hex_boxes) {   // Hex*: the header's box / collider / reward counts describe the hex lists
+        s->hex_num_boxes = h.num_boxes; s->hex_num_objs = h.num_rewards;
+        s->hex_target[0] = h.hex_target[0]; s->hex_target[1] = 0.0f; s->hex_target[2] = h.hex_target[1];
+        e = hipMemcpy(s->hex_boxes, g->gv.hex_boxes + (size_t)env * HEX_MAX_BOXES, (size_t)std::min(h.num_boxes, (int)HEX_MAX_BOXES) * sizeof(HexRec), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(s->hex_objs, g->gv.hex_objs + (size_t)env * HEX_MAX_OBJS, (size_t)std::min(h.num_rewards, (int)HEX_MAX_OBJS) * sizeof(HexRec), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { delete s; return fail(std::string("mv_debug_snapshot: ") + hipGetErrorString(e)); }
+        h.num_boxes = 0; h.num_rewards = 0; h.num_terrain = 0;
+    }
     s->scenario = h.scenario; s->num_terrain = h.num_terrain; s->num_rewards = h.num_rewards; s->num_platforms = h.num_platforms; s->solved = h.solved;
     for (int i = 0; i < h.num_terrain && i < MAX_TERRAIN; ++i) {
         const TerrainBox &t = terr[i];
@@ -1059,9 +1088,10 @@ int mv_debug_generate_episode(const char *scenario_name, int32_t num_agents, int
     int scenario = SCN_TOWER;
     ObstacleConfig oc;
     if (!scenario_name || !scenario_from_name(lower(scenario_name), scenario, oc) || scenario == SCN_TOWER || scenario == SCN_SOKOBAN || scenario == SCN_EMPTY)
-        return fail("mv_debug_generate_episode: the Obstacles family, Collect and Rearrange (Sokoban: mv_debug_generate_sokoban)");
+        return fail("mv_debug_generate_episode: the Obstacles family, Collect, Rearrange, HexMemory and HexExplore (Sokoban: mv_debug_generate_sokoban)");
     if (num_agents < 1 || num_agents > MAX_AGENTS || n < 1) return fail("mv_debug_generate_episode: bad arguments");
-    const size_t bytes = scenario == SCN_COLLECT ? sizeof(CollectBlob) : scenario == SCN_REARRANGE ? sizeof(RearrangeBlob) : sizeof(EpisodeBlob);
+    const bool hex = scenario == SCN_HEX_MEMORY || scenario == SCN_HEX_EXPLORE;
+    const size_t bytes = scenario == SCN_COLLECT ? sizeof(CollectBlob) : scenario == SCN_REARRANGE ? sizeof(RearrangeBlob) : hex ? sizeof(HexBlob) : sizeof(EpisodeBlob);
     if (!out) return (int)bytes;
     if ((size_t)out_bytes < bytes) return fail("mv_debug_generate_episode: buffer too small");
     std::mt19937 rng;
@@ -1070,6 +1100,8 @@ int mv_debug_generate_episode(const char *scenario_name, int32_t num_agents, int
     for (int i = 0; i < n; ++i) {
         std::memset(buf.data(), 0, bytes);
         if (scenario == SCN_COLLECT) generate_collect_episode(rng, num_agents, base_episode_len, *reinterpret_cast<CollectBlob *>(buf.data()));
+        else if (scenario == SCN_HEX_MEMORY) generate_hex_memory_episode(rng, num_agents, base_episode_len, *reinterpret_cast<HexBlob *>(buf.data()));
+        else if (scenario == SCN_HEX_EXPLORE) generate_hex_explore_episode(rng, num_agents, base_episode_len, *reinterpret_cast<HexBlob *>(buf.data()));
         else if (scenario == SCN_REARRANGE) generate_rearrange_episode(rng, num_agents, base_episode_len, *reinterpret_cast<RearrangeBlob *>(buf.data()));
         else generate_obstacles_episode(rng, oc, num_agents, base_episode_len, *reinterpret_cast<EpisodeBlob *>(buf.data()));
     }
@@ -1083,7 +1115,8 @@ int mv_debug_feeder_selftest(const char *scenario_name, int32_t num_envs, int32_
 {
     int scenario = SCN_TOWER;
     ObstacleConfig oc;
-    if (!scenario_name || !scenario_from_name(lower(scenario_name), scenario, oc) || scenario == SCN_TOWER || scenario == SCN_SOKOBAN || scenario == SCN_EMPTY)
+    if (!scenario_name || !scenario_from_name(lower(scenario_name), scenario, oc) || scenario == SCN_TOWER || scenario == SCN_SOKOBAN || scenario == SCN_EMPTY ||
+        scenario == SCN_HEX_MEMORY || scenario == SCN_HEX_EXPLORE)
         return fail("mv_debug_feeder_selftest: the Obstacles family, Collect and Rearrange");
     const size_t bytes = scenario == SCN_COLLECT ? sizeof(CollectBlob) : scenario == SCN_REARRANGE ? sizeof(RearrangeBlob) : sizeof(EpisodeBlob);
     std::vector<uint8_t> slots((size_t)num_envs * bytes, 0), want(bytes);

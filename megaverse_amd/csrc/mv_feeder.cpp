@@ -101,6 +101,12 @@ void EpisodeFeeder::generate(int env)
         b.seq = seq;
         soko_undo_[env].push_back(std::move(undo));
         while (soko_undo_[env].size() > 8) soko_undo_[env].pop_front();   // never more than spares + 1 episodes ahead
+    } else if (scenario_ == SCN_HEX_MEMORY || scenario_ == SCN_HEX_EXPLORE) {
+        HexBlob &b = *reinterpret_cast<HexBlob *>(slot);
+        if (scenario_ == SCN_HEX_MEMORY) generate_hex_memory_episode(rng_[env], num_agents_, base_len_, b);
+        else generate_hex_explore_episode(rng_[env], num_agents_, base_len_, b);
+        b.seq = seq;
+        used = offsetof(HexBlob, boxes) + size_t(b.num_boxes) * sizeof(HexRec);   // the box list is last: used prefix only
     } else {
         CollectBlob &b = *reinterpret_cast<CollectBlob *>(slot);
         generate_collect_episode(rng_[env], num_agents_, base_len_, b);

@@ -50,12 +50,13 @@ struct alignas(16) Prim {   // 32 B, one visible primitive of a frame (written b
 };                                // meta = kind | frame << 4 | slot << 8 ; frame 0 = world axes, 1+k = camera frame of agent k
 
 // Per-frame header written by frame_setup_kernel for raster_fast_kernel (so that its prologue is a plain copy): floats
-//   [0] visible count (int bits)   [4 + 16 k ..] camera of agent k: eye(3) c(9) origin(3)   [FH_LREL + 4 f ..] light position relative
-//   to the viewer's eye in the axes of frame f (0 world, 1 + k camera k)   [FH_WB + 2 r ..] 64-bit mask of list positions 64 r .. 64 r + 63
+//   [16 k ..] frame of reference k -- camera of agent k for k < MAX_AGENTS, hex wall orientation k - MAX_AGENTS after that --: eye(3)
+//   c(9) origin(3), and in the spare 16th float of record 0 the visible count (int bits)   [FH_LREL + 4 f ..] light position relative
+//   to the viewer's eye in the axes of frame f (0 world, 1 + k record k)   [FH_WB + 2 r ..] 64-bit mask of list positions 64 r .. 64 r + 63
 //   that hold an axis-aligned box in the world frame
-enum : int { FH_CAM = 4, FH_CAM_STRIDE = 16, FH_LREL = FH_CAM + FH_CAM_STRIDE * MAX_AGENTS, FH_WB = FH_LREL + 4 * (1 + MAX_AGENTS),
+enum : int { FH_CAM = 0, FH_CAM_STRIDE = 16, FH_COUNT = 15, FH_LREL = FH_CAM + FH_CAM_STRIDE * MAX_CAMS, FH_WB = FH_LREL + 4 * (1 + MAX_CAMS),
              FH_FLOATS = FH_WB + 2 * 16 };
-static_assert(FH_FLOATS * 4 <= FRAME_HDR_BYTES, "frame header does not fit its slot");
+static_assert(FH_FLOATS * 4 <= FRAME_HDR_BYTES && FH_FLOATS <= 256, "frame header: one float per thread of the raster prologue, one slot");
 
 struct CamL {
     float eye[3];
@@ -130,9 +131,23 @@ __device__ __forceinline__ int screen_rect(const float *blo, const float *bhi, i
     return 1;
 }
 
+// Hex scenarios: wall orientation k as a frame of reference without an eye: columns of c = its axes in the world, Ry(r) =
+// [[c, 0, s], [0, 1, 0], [-s, 0, c]] with (cos, sin) = (0.8660254, 0.5), (0.8660254, -0.5), (0, 1) (mv_gen_hex.cpp, mv_physics.h)
+__device__ __forceinline__ CamL hex_frame(int k)
+{
+    const float c = k == 2 ? 0.0f : 0.8660254f, s = k == 0 ? 0.5f : k == 1 ? -0.5f : 1.0f;
+    CamL f;
+    f.eye[0] = f.eye[1] = f.eye[2] = 0.0f;
+    f.c[0] = c; f.c[1] = 0.0f; f.c[2] = s;
+    f.c[3] = 0.0f; f.c[4] = 1.0f; f.c[5] = 0.0f;
+    f.c[6] = -s; f.c[7] = 0.0f; f.c[8] = c;
+    f.origin[0] = f.origin[1] = f.origin[2] = 0.0f;
+    return f;
+}
+
 // LDS scratch of one frame setup in flight (one per workgroup, or one per wave when every wave of a workgroup sets up its own frame)
 struct FrameScratch {
-    CamL cam[MAX_AGENTS];
+    CamL cam[MAX_CAMS];      // agent cameras, then (Hex scenarios) the three wall orientations as eye-less frames
     int cost;                // tiles x primitives the raster pass will have to look at (scheduling estimate)
     int cnt[8];              // [parity*4 + wave]: visible primitives found by each wave this round
     unsigned wbits[32];      // world-frame-box bit of every list position (frame header, raster_fast_kernel)
@@ -176,8 +191,11 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
         cam.origin[0] = cam.origin[1] = cam.origin[2] = 0.0f;
         s_cam[tid] = cam;
     }
+    const int scen = hdr->scenario;
+    const bool hex = scen == SCN_HEX_MEMORY || scen == SCN_HEX_EXPLORE;
+    if (hex && tid >= MAX_AGENTS && tid < MAX_CAMS) s_cam[tid] = hex_frame(tid - MAX_AGENTS);
     sync();
-    if (tid < A) {
+    if (tid < A || (hex && tid >= MAX_AGENTS && tid < MAX_CAMS)) {
         const V3 ev = v3(s_cam[viewer].eye[0], s_cam[viewer].eye[1], s_cam[viewer].eye[2]);
         const V3 ek = v3(s_cam[tid].eye[0], s_cam[tid].eye[1], s_cam[tid].eye[2]);
         const V3 o = mat_tmul(s_cam[tid].c, ev - ek);
@@ -186,15 +204,15 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
     // ---- primitive slots, packed (slot order == the order the reference emits drawables == depth-tie order):
     //   layout slabs | terrain slabs (TowerBuilding: the building zone; Rearrange: static boxes + target items) | movable boxes / items
     //   | 2 cones per diamond | 3 per agent
-    const int scen = hdr->scenario;
     const int nLayout = hdr->num_boxes;
     const bool rearrange = scen == SCN_REARRANGE;   // its "terrain" slots: 9 static boxes, then the target arrangement's items
     const bool sokoban = scen == SCN_SOKOBAN;       // its "terrain" slots: one per level cell (wall cap / goal pad / nothing), x-major
     const int sokoW = sokoban ? max(hdr->W, 1) : 1;
     const int slotTerrain = nLayout, nTerrainSlots = scen == SCN_TOWER ? 1 : rearrange ? NUM_STATIC + hdr->num_terrain
-                                                   : sokoban ? hdr->L * sokoW : hdr->num_terrain;
+                                                   : sokoban ? hdr->L * sokoW : hex ? 0 : hdr->num_terrain;
     const int slotObjects = slotTerrain + nTerrainSlots;
-    const int slotRewards = slotObjects + hdr->num_objects, nRewardSlots = scen == SCN_TOWER ? 0 : 2 * hdr->num_rewards;
+    // (Hex*: layout slots = the maze's boxes, no terrain / movable boxes, three slots per collectable: a pillar is three cylinders)
+    const int slotRewards = slotObjects + hdr->num_objects, nRewardSlots = scen == SCN_TOWER ? 0 : hex ? 3 * hdr->num_rewards : 2 * hdr->num_rewards;
     const int slotAgents = slotRewards + nRewardSlots;
     const int numSlots = slotAgents + 3 * A;
     const LayoutBox *gboxes = gv.boxes + (size_t)env * gv.box_stride;
@@ -210,7 +228,13 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
         unsigned color = 0;
         float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
         if (slot < numSlots) {
-            if (slot < nLayout) {
+            if (slot < nLayout && hex) {   // floor / wall / edging / landmark: a box in the world or in a wall frame (records 8..10)
+                const HexRec b = gv.hex_boxes[(size_t)env * HEX_MAX_BOXES + slot];
+                kind = PRIM_BOX;
+                fr = (b.meta & 15) == 0 ? 0 : MAX_AGENTS + (b.meta & 15);
+                lo[0] = b.a[0]; lo[1] = b.a[1]; lo[2] = b.a[2]; hi[0] = b.b[0]; hi[1] = b.b[1]; hi[2] = b.b[2];
+                color = (unsigned)b.color;
+            } else if (slot < nLayout) {
                 const LayoutBox b = gboxes[slot];
                 if (b.type & VX_OPAQUE) {
                     kind = PRIM_BOX;
@@ -299,6 +323,25 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
                     const float cx = 0.0f, cy = -0.44f + -0.3f, cz = -1.0f;
                     lo[0] = cx - hh; lo[1] = cy - hh; lo[2] = cz - hh;
                     hi[0] = cx + hh; hi[1] = cy + hh; hi[2] = cz + hh;
+                }
+            } else if (slot < slotAgents && hex) {   // collectables: addSphere / addPillar / addDiamond, layout_utils.cpp:85-126
+                const int q = slot - slotRewards, j = q / 3, part = q - 3 * j;
+                const HexRec o = gv.hex_objs[(size_t)env * HEX_MAX_OBJS + j];
+                const int shape = o.meta & 15;
+                color = (unsigned)o.color;
+                if (shape == HEX_SPHERE) {
+                    if (part == 0) { kind = PRIM_SPHERE_S; lo[0] = o.a[0]; lo[1] = o.a[1]; lo[2] = o.a[2]; hi[0] = o.b[0]; hi[1] = o.b[1]; hi[2] = o.b[2]; }
+                } else if (shape == HEX_PILLAR) {   // a cylinder and two caps (1.2 x as wide, 0.15 high) at +-0.47 of its scale
+                    const float capY = 0.47f * o.b[1];
+                    kind = PRIM_CYLINDER_S;
+                    lo[0] = o.a[0]; lo[2] = o.a[2];
+                    lo[1] = part == 0 ? o.a[1] : part == 1 ? o.a[1] + capY : o.a[1] - capY;
+                    hi[0] = part == 0 ? o.b[0] : o.b[0] * 1.2f; hi[1] = part == 0 ? o.b[1] : 0.15f; hi[2] = part == 0 ? o.b[2] : o.b[2] * 1.2f;
+                } else if (part < 2) {              // two cones base to base
+                    kind = PRIM_CONE;
+                    lo[0] = o.a[0]; lo[2] = o.a[2];
+                    lo[1] = part == 0 ? o.a[1] + 0.5f * o.b[1] : o.a[1] - 1.5f * o.b[1];
+                    hi[0] = o.b[0]; hi[1] = o.b[1]; hi[2] = part == 0 ? 1.0f : -1.0f;
                 }
             } else if (slot < slotAgents) {   // diamonds: addDiamond, layout_utils.cpp:114-126
                 const int j = (slot - slotRewards) >> 1, part = (slot - slotRewards) & 1;
@@ -397,16 +440,16 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
     sync();
     {   // frame header
         float *fh = reinterpret_cast<float *>(gv.vis_hdr + (size_t)frame * FRAME_HDR_BYTES);
-        if (tid == 0) fh[0] = __int_as_float(min(nVis, maxVis));
-        if (tid < A) {
+        if (tid == 0) fh[FH_COUNT] = __int_as_float(min(nVis, maxVis));
+        if (tid < A || (hex && tid >= MAX_AGENTS && tid < MAX_CAMS)) {
             const CamL &cm = s_cam[tid];
             float *o = fh + FH_CAM + FH_CAM_STRIDE * tid;
             o[0] = cm.eye[0]; o[1] = cm.eye[1]; o[2] = cm.eye[2];
 #pragma unroll
             for (int q = 0; q < 9; ++q) o[3 + q] = cm.c[q];
-            o[12] = cm.origin[0]; o[13] = cm.origin[1]; o[14] = cm.origin[2]; o[15] = 0.0f;
+            o[12] = cm.origin[0]; o[13] = cm.origin[1]; o[14] = cm.origin[2];   // (o[15] of record 0 is the count)
         }
-        if (tid >= 32 && tid <= 32 + A) {   // light (0,4,2) camera-relative (magnum_env_renderer.cpp:201) in the axes of every frame a box can live in
+        if (tid >= 32 && (tid <= 32 + A || (hex && tid > 32 + MAX_AGENTS && tid <= 32 + MAX_CAMS))) {   // light (0,4,2) camera-relative (magnum_env_renderer.cpp:201) in the axes of every frame a box can live in
             const int f = tid - 32;
             const V3 lw = mat_mul(s_cam[viewer].c, v3(0.0f, 4.0f, 2.0f));
             const V3 l = f == 0 ? lw : f == 1 + viewer ? v3(0.0f, 4.0f, 2.0f) : mat_tmul(s_cam[f - 1].c, lw);

@@ -36,6 +36,11 @@ void generate_collect_episode(std::mt19937 &rng, int num_agents, float base_epis
 // Advances `rng` exactly like Env::reset + RearrangeScenario::reset + spawnAgents + addEpisodeDrawables and fills `out`.
 void generate_rearrange_episode(std::mt19937 &rng, int num_agents, float base_episode_len, RearrangeBlob &out);
 
+// HexExplore / HexMemory: advance `rng` exactly like Env::reset + the scenario's reset + spawnAgents + addEpisodeDrawables and fill `out`
+// (the maze's Kruskal is seeded with the episode seed: mv_gen_hex.cpp)
+void generate_hex_explore_episode(std::mt19937 &rng, int num_agents, float base_episode_len, HexBlob &out);
+void generate_hex_memory_episode(std::mt19937 &rng, int num_agents, float base_episode_len, HexBlob &out);
+
 // Sokoban keeps state across episodes: the shuffled levels of the file picked last (SokobanScenario::levels)
 struct SokobanLevels {
     std::vector<std::vector<std::string>> pending;

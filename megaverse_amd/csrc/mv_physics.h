@@ -37,9 +37,21 @@ constexpr float OBJ_COLL_HALF = 0.39f * 1.15f;
 constexpr float OBJ_COLL_YOFF = -0.05f;
 
 struct Col {
-    int kind;   // 0 none, 1 box (bounds already grown by CAP_HH in y), 2 vertical capsule
+    int kind;   // 0 none, 1 box (bounds already grown by CAP_HH in y), 2 vertical capsule, 3 + k (OBB builds only): box in hex wall frame k
     V3 lo, hi;
 };
+
+// Hex scenarios: the three directions a honeycomb's walls run in, as rotations about Y (mv_gen_hex.cpp); frame k: local = Ry^T world
+__device__ __forceinline__ V3 hex_to_local(int k, V3 p)
+{
+    const float c = k == 2 ? 0.0f : 0.8660254f, s = k == 0 ? 0.5f : k == 1 ? -0.5f : 1.0f;
+    return v3(c * p.x - s * p.z, p.y, s * p.x + c * p.z);
+}
+__device__ __forceinline__ V3 hex_to_world(int k, V3 p)
+{
+    const float c = k == 2 ? 0.0f : 0.8660254f, s = k == 0 ? 0.5f : k == 1 ? -0.5f : 1.0f;
+    return v3(c * p.x + s * p.z, p.y, c * p.z - s * p.x);
+}
 
 struct Closest {
     float dist;
@@ -90,18 +102,25 @@ __device__ __forceinline__ Closest closest_capsule(V3 p, V3 centre, float halfLe
     return c;
 }
 
+template <bool OBB = false>
 __device__ __forceinline__ Closest closest(const Col &col, V3 p)
 {
     if (col.kind == 1) return closest_box(p, col.lo, col.hi, CAP_R);
+    if (OBB && col.kind >= 3) {   // rotated about Y only: the capsule is vertical in the wall's frame too
+        Closest c = closest_box(hex_to_local(col.kind - 3, p), col.lo, col.hi, CAP_R);
+        c.n = hex_to_world(col.kind - 3, c.n);
+        return c;
+    }
     return closest_capsule(p, col.lo, col.hi.x, 2 * CAP_R);
 }
 
 // conservative advancement of the capsule along d against one collider
+template <bool OBB = false>
 __device__ __forceinline__ bool convex_cast(const Col &col, V3 p, V3 d, float &fraction, V3 &normal)
 {
     float lambda = 0.0f, lastLambda = 0.0f;
     int numIter = 0;
-    Closest c = closest(col, p);
+    Closest c = closest<OBB>(col, p);
     float dist = c.dist + ALLOWED_CCD_PEN;
     V3 n = c.n;
     float proj = -dot(d, n);
@@ -115,7 +134,7 @@ __device__ __forceinline__ bool convex_cast(const Col &col, V3 p, V3 d, float &f
         if (lambda <= lastLambda) return false;
         lastLambda = lambda;
         const V3 x = v3(p.x + lambda * d.x, p.y + lambda * d.y, p.z + lambda * d.z);
-        c = closest(col, x);
+        c = closest<OBB>(col, x);
         dist = c.dist + ALLOWED_CCD_PEN;
         n = c.n;
         if (++numIter > CAST_MAX_ITER) return false;
@@ -126,7 +145,7 @@ __device__ __forceinline__ bool convex_cast(const Col &col, V3 p, V3 d, float &f
 }
 
 // closest accepted hit over all colliders of the wave; ties resolved towards the lowest slot
-template <int NC>
+template <int NC, bool OBB = false>
 __device__ __forceinline__ bool sweep(const Col (&col)[NC], V3 from, V3 to, V3 up, float minSlopeDot, float &fraction,
                                       V3 &normal)
 {
@@ -140,7 +159,7 @@ __device__ __forceinline__ bool sweep(const Col (&col)[NC], V3 from, V3 to, V3 u
     for (int k = 0; k < NC; ++k) {
         if (col[k].kind != 0) {
             float f; V3 n;
-            if (convex_cast(col[k], from, d, f, n) && (len2(n) > 0.0001f) && (f < 1.0f) && !(dot(up, n) < minSlopeDot)) {
+            if (convex_cast<OBB>(col[k], from, d, f, n) && (len2(n) > 0.0001f) && (f < 1.0f) && !(dot(up, n) < minSlopeDot)) {
                 const unsigned long long kk = ((unsigned long long)__float_as_uint(f) << 32) | (unsigned)(lane + 64 * k);
                 key = kk < key ? kk : key;
                 nn[k] = n;
@@ -161,7 +180,7 @@ __device__ __forceinline__ bool sweep(const Col (&col)[NC], V3 from, V3 to, V3 u
 }
 
 // push out of the first (lowest slot) collider that is penetrated deeper than MAX_PEN_DEPTH
-template <int NC>
+template <int NC, bool OBB = false>
 __device__ __forceinline__ bool recover_from_penetration(const Col (&col)[NC], V3 &pos)
 {
     Closest c[NC];
@@ -171,7 +190,7 @@ __device__ __forceinline__ bool recover_from_penetration(const Col (&col)[NC], V
         pen[k] = false;
         c[k].dist = 0.0f; c[k].n = v3(0, 0, 0);
         if (col[k].kind != 0) {
-            c[k] = closest(col[k], pos);
+            c[k] = closest<OBB>(col[k], pos);
             pen[k] = c[k].dist < -MAX_PEN_DEPTH;
         }
     }
@@ -196,13 +215,13 @@ __device__ __forceinline__ bool recover_from_penetration(const Col (&col)[NC], V
 
 // "while (recover()) { if (++n > 4) break; }" == at most five calls.  Written as straight-line
 // predicated code: no wave-level op (ballot/shuffle) sits inside a loop with a data-dependent exit.
-template <int NC>
+template <int NC, bool OBB = false>
 __device__ __forceinline__ void recover_up_to_5(const Col (&col)[NC], V3 &pos)
 {
     bool more = true;
 #pragma unroll
     for (int it = 0; it < 5; ++it)
-        if (more) more = recover_from_penetration(col, pos);
+        if (more) more = recover_from_penetration<NC, OBB>(col, pos);
 }
 
 __device__ __forceinline__ bool on_ground(const AgentState &a) { return (fabsf(a.vvel) < SIMD_EPS) && (fabsf(a.voffset) < SIMD_EPS); }
@@ -240,7 +259,7 @@ __device__ __forceinline__ V3 lerp3(V3 a, V3 b, float rt)
 }
 
 // preStep + playerStep of the controller for one agent
-template <int NC>
+template <int NC, bool OBB = false>
 __device__ __forceinline__ void player_step(AgentState &a, const Col (&col)[NC], float dt)
 {
     V3 cur = v3(a.pos[0], a.pos[1], a.pos[2]);
@@ -260,12 +279,12 @@ __device__ __forceinline__ void player_step(AgentState &a, const Col (&col)[NC],
         target = v3(cur.x, cur.y + stepHeight + (a.voffset > 0.0f ? a.voffset : 0.0f), cur.z);
         cur = target;
         float f; V3 n;
-        if (sweep(col, start, target, v3(0, -1, 0), MAX_SLOPE_COS, f, n)) {
+        if (sweep<NC, OBB>(col, start, target, v3(0, -1, 0), MAX_SLOPE_COS, f, n)) {
             if (dot(n, UP) > 0.0f) {
                 a.step_offset = stepHeight * f;
                 cur = lerp3(cur, target, f);
             }
-            recover_up_to_5(col, cur);
+            recover_up_to_5<NC, OBB>(col, cur);
             target = cur;
             if (a.voffset > 0) { a.voffset = 0.0f; a.vvel = 0.0f; a.step_offset = STEP_HEIGHT; }
         } else {
@@ -284,7 +303,7 @@ __device__ __forceinline__ void player_step(AgentState &a, const Col (&col)[NC],
                 const V3 negDir = cur - target;
                 float f = 1.0f; V3 n = v3(0, 0, 0);
                 bool hit = false;
-                if (!(cur.x == target.x && cur.y == target.y && cur.z == target.z)) hit = sweep(col, cur, target, negDir, 0.0f, f, n);
+                if (!(cur.x == target.x && cur.y == target.y && cur.z == target.z)) hit = sweep<NC, OBB>(col, cur, target, negDir, 0.0f, f, n);
                 if (!hit) active = false;
                 else {
                     V3 dir = target - cur;
@@ -315,7 +334,7 @@ __device__ __forceinline__ void player_step(AgentState &a, const Col (&col)[NC],
         if (downVel > 0.0f && downVel > FALL_SPEED && (wasOnGround || !a.was_jumping)) downVel = FALL_SPEED;
         target = v3(target.x, target.y - (a.step_offset + downVel * dt), target.z);
         float f; V3 n;
-        if (sweep(col, cur, target, UP, MAX_SLOPE_COS, f, n)) {
+        if (sweep<NC, OBB>(col, cur, target, UP, MAX_SLOPE_COS, f, n)) {
             cur = lerp3(cur, target, f);
             a.vvel = 0.0f; a.voffset = 0.0f; a.was_jumping = 0;
         } else cur = target;
@@ -324,7 +343,7 @@ __device__ __forceinline__ void player_step(AgentState &a, const Col (&col)[NC],
     a.hvx = (cur.x - original.x) / dt;
     a.hvz = (cur.z - original.z) / dt;
 
-    recover_up_to_5(col, cur);
+    recover_up_to_5<NC, OBB>(col, cur);
     a.pos[0] = cur.x; a.pos[1] = cur.y; a.pos[2] = cur.z;
 
     const float speed = sqrtf(a.hvx * a.hvx + a.hvz * a.hvz);

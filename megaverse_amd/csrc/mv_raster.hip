@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 && !SHAPES ? MV_RASTER_WAVES : M
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // column/row ray tables
     __shared__ Prim s_vis[MAXVIS];       // this frame's visible list
     __shared__ short4 s_rect[MAXVIS];    // x0,x1,y0,y1 (pixels)
-    __shared__ CamL s_cam[MAX_AGENTS];
+    __shared__ CamL s_cam[MAX_CAMS];
     __shared__ float s_lutA[256], s_lutD[256];   // colour byte -> AMB * c / 255 and (DIF * c / 255) * LCOL
 
     float4 *s_col = reinterpret_cast<float4 *>(s_dyn);   // per column i: (dc.x, c00*dc.x, c10*dc.x, c20*dc.x)
@@ -325,8 +325,10 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 && !SHAPES ? MV_RASTER_WAVES : M
         cam.origin[0] = cam.origin[1] = cam.origin[2] = 0.0f;
         s_cam[tid] = cam;
     }
+    const bool hex = gv.scenario == SCN_HEX_MEMORY || gv.scenario == SCN_HEX_EXPLORE;
+    if (hex && tid >= MAX_AGENTS && tid < MAX_CAMS) s_cam[tid] = hex_frame(tid - MAX_AGENTS);
     __syncthreads();
-    if (tid < A) {
+    if (tid < A || (hex && tid >= MAX_AGENTS && tid < MAX_CAMS)) {
         const V3 ev = v3(s_cam[viewer].eye[0], s_cam[viewer].eye[1], s_cam[viewer].eye[2]);
         const V3 ek = v3(s_cam[tid].eye[0], s_cam[tid].eye[1], s_cam[tid].eye[2]);
         const V3 o = mat_tmul(s_cam[tid].c, ev - ek);
@@ -668,7 +670,7 @@ __global__ __launch_bounds__(256, WAVES) void raster_fast_kernel(FastArgs fa, ui
     const int frame = __builtin_amdgcn_readfirstlane(s_frame);
     const int viewer = frame % A;
     const float *gh = reinterpret_cast<const float *>(fa.vis_hdr + (size_t)frame * FRAME_HDR_BYTES);
-    const int nVis = __builtin_amdgcn_readfirstlane(min(__float_as_int(gh[0]), (int)MAXVIS));
+    const int nVis = __builtin_amdgcn_readfirstlane(min(__float_as_int(gh[FH_COUNT]), (int)MAXVIS));
 
     // ---- prologue: copies + the separable ray tables, one barrier
     if (tid < FH_FLOATS) s_hdr[tid] = gh[tid];
@@ -849,8 +851,8 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
         const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)W * sizeof(float) + (size_t)H * sizeof(float2);
         int split = envSplit > 0 ? envSplit : 4;
         while (split > 1 && tiles < 4 * split * 2) split >>= 1;   // keep at least two tiles per wave
-        // variants: [0] <=256 visible primitives, [1] + scaled shapes (Rearrange), [2] <=1024 (Collect); the small ones are built for
-        // 8 and for 6 waves per SIMD (64 / 80 VGPRs), MV_FAST_WAVES picks
+        // variants: [0] <=256 visible primitives, [1] + scaled shapes (Rearrange), [2] <=1024 (Collect), [3] <=1024 + scaled shapes (Hex*); the
+        // small ones are built for 8 and for 6 waves per SIMD (64 / 80 VGPRs), MV_FAST_WAVES picks
         static const int wavesSel = getenv("MV_FAST_WAVES") ? atoi(getenv("MV_FAST_WAVES")) : 8;
         using KernelFn = void (*)(FastArgs, uint32_t *, int, int, int);
         FastArgs fa;
@@ -858,7 +860,8 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
         fa.hist = gv.lpt_hist + gv.lpt_parity * LPT_BUCKETS; fa.list = gv.lpt_list; fa.num_agents = gv.num_agents; fa.vis_stride = gv.vis_stride; fa.frames = frames;
         // (Collect, measured and rejected: a 1024-entry launch for the frames above 256 visible primitives + a 256-entry launch for the rest,
         // 75 + 69 us against 107 us for the single 1024-entry launch: each launch pays its own tail, and the cones, not occupancy, dominate)
-        KernelFn fn = gv.vis_stride > VIS_SMALL ? raster_fast_kernel<VIS_LARGE, false, 3>
+        const bool hexScen = gv.scenario == SCN_HEX_MEMORY || gv.scenario == SCN_HEX_EXPLORE;
+        KernelFn fn = hexScen ? raster_fast_kernel<VIS_LARGE, true, 3> : gv.vis_stride > VIS_SMALL ? raster_fast_kernel<VIS_LARGE, false, 3>
                     : gv.scenario == SCN_REARRANGE ? (wavesSel >= 8 ? raster_fast_kernel<VIS_SMALL, true, 8> : raster_fast_kernel<VIS_SMALL, true, 6>)
                                                    : (wavesSel >= 8 ? raster_fast_kernel<VIS_SMALL, false, 8> : raster_fast_kernel<VIS_SMALL, false, 6>);
         hipLaunchKernelGGL(fn, dim3(frames * split), dim3(256), dyn, stream, fa, obs, W, H, split);
@@ -868,7 +871,8 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
     int split = envSplit > 0 ? envSplit : 4;
     while (split > 1 && tiles < 4 * split * 2) split >>= 1;   // keep at least two tiles per wave
     const dim3 grid(frames * split), block(256);
-    if (gv.vis_stride > VIS_SMALL) hipLaunchKernelGGL((raster_kernel<VIS_LARGE, false>), grid, block, dyn, stream, gv, obs, W, H, split, gv.lpt_order);
+    if (gv.scenario == SCN_HEX_MEMORY || gv.scenario == SCN_HEX_EXPLORE) hipLaunchKernelGGL((raster_kernel<VIS_LARGE, true>), grid, block, dyn, stream, gv, obs, W, H, split, gv.lpt_order);
+    else if (gv.vis_stride > VIS_SMALL) hipLaunchKernelGGL((raster_kernel<VIS_LARGE, false>), grid, block, dyn, stream, gv, obs, W, H, split, gv.lpt_order);
     else if (gv.scenario == SCN_REARRANGE) hipLaunchKernelGGL((raster_kernel<VIS_SMALL, true>), grid, block, dyn, stream, gv, obs, W, H, split, gv.lpt_order);
     else hipLaunchKernelGGL((raster_kernel<VIS_SMALL, false>), grid, block, dyn, stream, gv, obs, W, H, split, gv.lpt_order);
     return 0;

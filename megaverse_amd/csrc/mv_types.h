@@ -16,6 +16,10 @@ enum : int {
     NUM_SHAPING = 8,
     // Collect: Perlin heightfield up to 42 x 42 columns (scenario_collect.cpp:63); its merged slabs are many
     COLLECT_MAX_BOXES = 1024, COLLECT_MAX_REWARDS = 96, HM_DIM = 42, HM_BYTES = 1792,
+    // HexMemory / HexExplore: floor + walls + edgings + landmarks of a honeycomb maze of up to 127 cells (294 walls, each with an
+    // edging and up to 4 landmarks: 1765 boxes at most), collectables (one per cell but the centre one, + the landmark object)
+    HEX_MAX_BOXES = 2048, HEX_MAX_OBJS = 128, HEX_FRAMES = 3,
+    MAX_CAMS = MAX_AGENTS + HEX_FRAMES,   // frames of reference a box can live in besides the world: agent cameras, hex wall orientations
 };
 
 enum : int { FRAME_HDR_BYTES = 1024 };   // per-frame header of the observation pass (mv_raster.hip: FH_*)
@@ -24,7 +28,9 @@ enum : int { FRAME_HDR_BYTES = 1024 };   // per-frame header of the observation 
 enum : int { ST_STARVED = 1, ST_CANDIDATES = 2, ST_VISIBLE = 4, ST_CHUNK = 8 };
 
 enum : int { SCN_TOWER = 0, SCN_OBSTACLES = 1, SCN_COLLECT = 2, SCN_REARRANGE = 3, SCN_SOKOBAN = 4,
-             SCN_EMPTY = 5 };   // Empty runs on the Obstacles kernels (one slab, no terrain) with fall detection off
+             SCN_EMPTY = 5,     // Empty runs on the Obstacles kernels (one slab, no terrain) with fall detection off
+             SCN_HEX_MEMORY = 6, SCN_HEX_EXPLORE = 7 };
+enum : int { HEX_PILLAR = 0, HEX_DIAMOND = 1, HEX_SPHERE = 2 };                       // scenario_hex_memory.cpp:163-168 ShapeType
 enum : int { SOKO_DIM = 32, SOKO_WALL = 1, SOKO_GOAL = 2 };                            // Sokoban level cells (scenario_sokoban.cpp:28-33)
 enum : int { MAX_ITEMS = 8, NUM_STATIC = 9 };                                         // Rearrange: arrangement items, static colliding boxes
 enum : int { SHAPE_BOX = 0, SHAPE_CAPSULE = 1, SHAPE_SPHERE = 2, SHAPE_CYLINDER = 4 };   // DrawableType, env/include/env/env.hpp:58-69
@@ -55,7 +61,7 @@ struct alignas(16) EnvHeader {   // 128 B
                                                                           // diamonds, highest_tower = how many of them were collected
     int32_t episodes_consumed;          // how many host-generated episodes this env has taken (refill protocol)
     int32_t starved;                    // set if a reset found no fresh episode (must never happen)
-    int32_t pad[2];
+    float hex_target[2];                // HexExplore: x, z of rewardObjectCoords (y = 0)
 };
 static_assert(sizeof(EnvHeader) == 128, "EnvHeader must be 128 B");
 
@@ -74,6 +80,15 @@ struct alignas(16) ArrangementItem {   // 32 B (scenario_rearrange.hpp:20-48): o
     int32_t shape, color;
     int32_t off[3];
     int32_t pad[3];
+};
+
+// Hex scenarios: one record type for boxes and collectables.
+//   box:    a = lo, b = hi in the box's frame; meta = (frame + 1) | collide << 4, frame -1 = world, 0..2 = wall orientation HEX_ROT[k]
+//   object: a = position, b = scale as given to addSphere / addPillar / addDiamond (layout_utils.cpp:85-126);
+//           meta = shape | good << 4 | alive << 8 | (voxel x + 128) << 12 | (voxel z + 128) << 20  (its cell in the collect grid, y = 0)
+struct alignas(16) HexRec {   // 32 B
+    float a[3]; int32_t meta;
+    float b[3]; int32_t color;
 };
 
 struct alignas(16) TerrainBox {   // 32 B, voxel units, max exclusive (platforms.hpp terrainBoxes)
@@ -112,6 +127,8 @@ struct GymView {
     int8_t *heightmap;         // [N][HM_BYTES]      (Collect: top solid y of column x * HM_DIM + z, -1 = no voxels)
     ArrangementItem *items;    // [N][MAX_ITEMS]     (Rearrange: the target arrangement; hdr.num_terrain holds the item count)
     uint8_t *soko_cells;       // [N][SOKO_DIM * SOKO_DIM] (Sokoban: SOKO_WALL / SOKO_GOAL per level cell, [x * SOKO_DIM + z])
+    HexRec *hex_boxes;         // [N][HEX_MAX_BOXES] (Hex*: hdr.num_boxes boxes, the first hdr.num_terrain of them collide)
+    HexRec *hex_objs;          // [N][HEX_MAX_OBJS]  (Hex*: hdr.num_rewards collectables)
     int32_t *episode_status;   // [N + 2] episodes consumed per env (host-generated scenarios), their total, error flags (ST_*)
     const void *blobs;         // [N][spares] resident next episodes (EpisodeBlob / CollectBlob / RearrangeBlob / SokobanBlob): episode
                                // number q (1-based) of an env lives in ring slot (q - 1) % spares
@@ -175,6 +192,18 @@ struct alignas(16) SokobanBlob {
     LayoutBox boxes[MAX_BOXES];          // in voxels; one voxel is 2 units wide
     MovableObject objects[MAX_OBJECTS];  // the pushable boxes
     uint8_t cells[SOKO_DIM * SOKO_DIM];  // [x * SOKO_DIM + z]: SOKO_WALL / SOKO_GOAL
+};
+
+// HexMemory / HexExplore episode (mv_gen_hex.cpp -> mv_step_hex.hip).  `boxes` comes last: only the used prefix travels.
+struct alignas(16) HexBlob {
+    int32_t seq;
+    int32_t num_boxes, num_colliders, num_objs, num_good;
+    float episode_len;
+    float target[2];                     // HexExplore: rewardObjectCoords x, z
+    float spawn[MAX_AGENTS][3];          // agentStartingPositions (+ (0.5, 0, 0.5) and the agent height are added on the device)
+    float yaw[MAX_AGENTS];               // spawn rotation in radians (HexExplore: frand * 2 pi; HexMemory: i * 2 pi / A)
+    HexRec objs[HEX_MAX_OBJS];
+    HexRec boxes[HEX_MAX_BOXES];
 };
 
 // Collect episode.  `boxes` comes last so that only the used prefix needs to travel.

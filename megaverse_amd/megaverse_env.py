@@ -20,9 +20,9 @@ from .extension import MegaverseGym, set_megaverse_log_level
 
 MEGAVERSE8 = ['TowerBuilding', 'ObstaclesEasy', 'ObstaclesHard', 'Collect', 'Sokoban', 'HexMemory', 'HexExplore', 'Rearrange']
 OBSTACLES_MULTITASK = ['ObstaclesWalls', 'ObstaclesSteps', 'ObstaclesLava', 'ObstaclesEasy', 'ObstaclesHard']
-# what libmegaverse_hip.so can construct (mv_create); HexMemory / HexExplore (rotated-wall mazes) are not built yet
+# what libmegaverse_hip.so can construct (mv_create): every scenario of the reference's multi-task sets
 SUPPORTED_SCENARIOS = ['TowerBuilding', 'ObstaclesEasy', 'ObstaclesMedium', 'ObstaclesHard', 'ObstaclesWalls', 'ObstaclesSteps', 'ObstaclesLava',
-                       'Collect', 'Sokoban', 'Rearrange', 'Empty']
+                       'Collect', 'Sokoban', 'HexMemory', 'HexExplore', 'Rearrange', 'Empty']
 _warned_unsupported = False
 
 

@@ -1312,7 +1312,7 @@ static void hex_add_maze(Env &e, const HexMaze &m, const HexParams &hp)
             const V3 wallT = v3(float(x1 + x2) / 2, hp.wallHeight, float(z1 + z2) / 2);
             const double deltaX = x1 - x2, deltaZ = z1 - z2;
             int k = 2;                                           // rotationY = M_PI_2
-            if (std::fabs(deltaX) > 1e-5) k = (deltaZ / deltaX) < 0 ? 0 : 1;   // -atanf(tanAlpha): +30 / -30 degrees (EPSILON 1e-5f, util/macro.hpp:12)
+            if (std::fabs(deltaX) > 1e-5f) k = (deltaZ / deltaX) < 0 ? 0 : 1;   // -atanf(tanAlpha): +30 / -30 degrees (EPSILON 1e-5f, util/macro.hpp:12)
             const V3 wc = hex_to_local(k, wallT);
             if (frand(e.rng) < hp.landmarkProb) {
                 const float landmarkWidth = 0.15f, landmarkHeight = landmarkWidth * length / hp.wallHeight;
@@ -1342,6 +1342,9 @@ static void hex_add_maze(Env &e, const HexMaze &m, const HexParams &hp)
                 e.hexBoxes.push_back(b);
             }
         }
+    // our list order (== depth-tie order; the reference's draw order is creation order, its ties are the GL rasteriser's): the
+    // colliding boxes -- floor, walls -- first, so that the device's broadphase streams a prefix of the list
+    std::stable_partition(e.hexBoxes.begin(), e.hexBoxes.end(), [](const Env::HexBox &b) { return b.collide != 0; });
 }
 
 static Env::HexObj hex_object(int shape, unsigned color, V3 loc, V3 scale, int good, V3 gridCoord)

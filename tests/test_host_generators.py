@@ -36,10 +36,17 @@ REARRANGE_BLOB = np.dtype([
 ], align=False)
 
 
+HEX_BLOB = np.dtype([
+    ("seq", "<i4"), ("num_boxes", "<i4"), ("num_colliders", "<i4"), ("num_objs", "<i4"), ("num_good", "<i4"), ("episode_len", "<f4"),
+    ("target", "<f4", 2), ("spawn", "<f4", (MAX_AGENTS, 3)), ("yaw", "<f4", MAX_AGENTS),
+    ("objs", oracle_lib.HEX_REC, oracle_lib.HEX_MAX_OBJS), ("boxes", oracle_lib.HEX_REC, oracle_lib.HEX_MAX_BOXES),
+], align=False)
+
+
 def generate(scenario, agents, env_seed, n, base_len=60.0):
     lib = ext.load_library()
     size = lib.mv_debug_generate_episode(scenario.encode(), agents, env_seed, n, base_len, None, 0)
-    dt = COLLECT_BLOB if scenario.lower() == "collect" else REARRANGE_BLOB if scenario.lower() == "rearrange" else EPISODE_BLOB
+    dt = COLLECT_BLOB if scenario.lower() == "collect" else REARRANGE_BLOB if scenario.lower() == "rearrange" else HEX_BLOB if scenario.lower().startswith("hex") else EPISODE_BLOB
     assert size == dt.itemsize, (size, dt.itemsize)
     buf = np.zeros(1, dt)
     assert lib.mv_debug_generate_episode(scenario.encode(), agents, env_seed, n, base_len, buf.ctypes.data, size) == size
@@ -162,3 +169,37 @@ def test_background_feeder_delivers_each_envs_stream_in_order(scenario, threads)
     lib = ext.load_library()
     rc = lib.mv_debug_feeder_selftest(scenario.encode(), 24, 2, threads, 5)
     assert rc == 0, lib.mv_last_error().decode()
+
+
+@pytest.mark.parametrize("scenario", ["HexExplore", "HexMemory"])
+@pytest.mark.parametrize("agents", [1, 3, 8])
+def test_hex_generator_matches_oracle(scenario, agents):
+    """mv_gen_hex.cpp against the oracle: the maze's boxes (floor, walls, edgings, landmarks; colliders first), the collectables, the
+    agents' starting positions and rotations, the reward cell, the episode length -- byte for byte over three episodes of 24 env streams"""
+    n_env, master = 24, 55 + agents
+    og = oracle_lib.OracleGym(scenario, 32, 32, n_env, agents, 2)
+    og.seed(master)
+    seeds = env_seeds(master, n_env)
+    sizes = set()
+    for episode in (1, 2, 3):
+        og.reset()
+        for e in range(n_env):
+            blob, snap = generate(scenario, agents, int(seeds[e]), episode), og.snapshot(e)
+            nb, no = int(snap["hex_num_boxes"]), int(snap["hex_num_objs"])
+            assert int(blob["num_boxes"]) == nb and int(blob["num_objs"]) == no
+            assert blob["boxes"][:nb].tobytes() == snap["hex_boxes"][:nb].tobytes()
+            assert blob["objs"][:no].tobytes() == snap["hex_objs"][:no].tobytes()
+            ncol = int(((snap["hex_boxes"]["meta"][:nb] >> 4) & 1).sum())
+            assert int(blob["num_colliders"]) == ncol and np.all((blob["boxes"]["meta"][:ncol] >> 4) & 1)
+            assert int(blob["num_good"]) == int(snap["num_platforms"])
+            assert np.float32(blob["episode_len"]).tobytes() == np.float32(snap["episode_len"]).tobytes()
+            assert np.array_equal(blob["target"], snap["hex_target"][[0, 2]])
+            for k in range(agents):
+                a = snap["agents"][k]
+                want = blob["spawn"][k] + np.array([0.5, np.float32(0.0) + np.float32(1.75), 0.5], np.float32)
+                assert want.astype(np.float32).tobytes() == a["pos"].tobytes(), (k, want, a["pos"])
+                ang = float(blob["yaw"][k])
+                assert abs(np.cos(ang) - float(a["basis"][0])) < 2e-6 and abs(np.sin(ang) - float(a["basis"][1])) < 2e-6
+            sizes.add(nb)
+    assert len(sizes) > 10   # mazes of different sizes were drawn
+    og.close()

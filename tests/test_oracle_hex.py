@@ -111,10 +111,11 @@ def test_hex_layout_is_what_the_maze_component_builds(scenario):
         h = walls["b"][0, 1]
         assert 2 * 0.85 - 1e-5 <= h <= 2 * 1.4 + 1e-5 and np.allclose(walls["b"][:, 1], h)
         assert np.allclose(walls["b"][:, 0] - walls["a"][:, 0], 3.5, atol=1e-3)       # a border of a unit hexagon, times the maze scale
-        # every wall is followed by its edging (same frame, not colliding, 0.24 * wallHeight/2 high), landmarks precede their wall
-        idx = np.nonzero(collide[1:] == 1)[0] + 1
-        assert np.all(collide[idx + 1] == 0) and np.all(frame[idx + 1] == frame[idx])
-        assert np.allclose(b[idx + 1]["b"][:, 1], 0.12 * h, atol=1e-5)
+        # colliding boxes come first; one edging per wall (not colliding, 0.24 * wallHeight / 2 high), landmarks in between
+        ncol = int(collide.sum())
+        assert np.all(collide[:ncol] == 1) and np.all(collide[ncol:] == 0)
+        edg = b[ncol:][np.isclose(b[ncol:]["b"][:, 1], 0.12 * h, atol=1e-5) & np.isclose(b[ncol:]["a"][:, 1], 0.0, atol=1e-6)]
+        assert len(edg) == len(walls) and np.array_equal(np.sort(frame[1:ncol]), np.sort(frame[ncol:][np.isin(np.arange(len(b) - ncol), np.nonzero(np.isclose(b[ncol:]["b"][:, 1], 0.12 * h, atol=1e-5) & np.isclose(b[ncol:]["a"][:, 1], 0.0, atol=1e-6))[0])]))
         # the number of walls: rim borders + inner borders left by the spanning tree, minus the randomly omitted ones
         size = next(n for n in range(2, 9) if (b[0]["b"][0] - b[0]["a"][0]) / 4 < 3.5 * (0.5 * 3 ** 0.5 * (2 * n - 1) + 1e-3))
         cells = 3 * size * (size - 1) + 1
