@@ -148,7 +148,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=1024)
     ap.add_argument("--agents", type=int, default=1)
     ap.add_argument("--scenario", default="TowerBuilding",
-                    help="TowerBuilding (headline), Obstacles{Easy,Medium,Hard,Walls,Steps,Lava}, Collect, Rearrange, Sokoban, Empty, or Mixed (configs[4])")
+                    help="TowerBuilding (headline), Obstacles{Easy,Medium,Hard,Walls,Steps,Lava}, Collect, Rearrange, Sokoban, HexMemory, HexExplore, Empty, or Mixed (configs[4])")
     ap.add_argument("--obs", type=int, nargs=2, default=[128, 128], metavar=("W", "H"))
     ap.add_argument("--no-gather-obs", action="store_true", help="N>1: skip the gather-on leg (value = the no-gather rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -181,7 +181,7 @@ def main():
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device(device))
 
-    if args.scenario.lower() == "sokoban":   # level files: $BOXOBAN_LEVELS, else the synthetic Boxoban-format set the tests use
+    if args.scenario.lower() in ("sokoban", "mixed"):   # level files: $BOXOBAN_LEVELS, else the synthetic Boxoban-format set the tests use
         os.environ.setdefault("BOXOBAN_LEVELS", os.path.join(ROOT, "tests", "golden", "boxoban"))
     W, H = args.obs
     n_env, A = args.envs_per_gpu, args.agents
@@ -189,7 +189,7 @@ def main():
     frames = n_env * A
     if dry:
         gym = DryGym(rank)
-    elif mixed:   # BASELINE.json configs[4]: the in-scope MEGAVERSE8 members dealt round-robin by env index
+    elif mixed:   # BASELINE.json configs[4]: the eight MEGAVERSE8 scenarios dealt round-robin by env index
         from megaverse_amd.multitask import MEGAVERSE_IN_SCOPE, MultiTaskGym
         gym = MultiTaskGym(MEGAVERSE_IN_SCOPE, W, H, n_env, A, 8, {}, device=local_rank, env_offset=rank * n_env, total_envs=world * n_env)
         gym.set_pixel_mode(args.pixels)

@@ -621,26 +621,109 @@ __device__ __forceinline__ bool fast_box(V3 inv, const float4 lo, const float4 h
 
 }  // namespace
 
-template <int MAXVIS, bool SHAPES, int WAVES>   // WAVES: waves per SIMD the variant is compiled for (register budget 512 / WAVES)
-__global__ __launch_bounds__(256, WAVES) void raster_fast_kernel(FastArgs fa, uint32_t *obs, int W, int H, int split)
+namespace {
+
+// one primitive that is not an axis-aligned box of the world frame -- a camera-attached box, a capsule, a cone, a scaled shape -- against this
+// lane's ray: its depth key (or ~0u), and for the curved ones the normal in the primitive's frame
+template <bool SHAPES, unsigned POS_MASK>
+__device__ __forceinline__ unsigned fast_other(int pos, const float4 *s_vis, const float *s_hdr, const float *camv, int viewer, V3 dw, float dcx, float dcy, V3 &n)
 {
-    constexpr int ROUNDS = MAXVIS / 64;
-    constexpr unsigned POS_MASK = MAXVIS - 1;
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
-    __shared__ float4 s_vis[2 * MAXVIS];      // Prim records as (lo, meta) (hi, colour)
-    __shared__ short4 s_rect[MAXVIS];
-    __shared__ __attribute__((aligned(16))) float s_hdr[FH_FLOATS];
-    static_assert(ROUNDS <= 16, "world-box masks: 16 x 64 positions");
+    const float4 lo = s_vis[2 * pos], hi = s_vis[2 * pos + 1];
+    const unsigned meta = __builtin_amdgcn_readfirstlane(__float_as_uint(lo.w));
+    const int qkind = meta & 15, qfr = (meta >> 4) & 15;
+    float t = 0.0f;
+    n = v3(0, 0, 0);
+    bool hit;
+    if (qkind == PRIM_BOX) {
+        const V3 df = qfr == 1 + viewer ? v3(dcx, dcy, -1.0f) : lds_tmul(local_lds(s_hdr + FH_CAM + FH_CAM_STRIDE * (qfr - 1) + 3), dw);
+        hit = fast_box(v3(__builtin_amdgcn_rcpf(df.x), __builtin_amdgcn_rcpf(df.y), __builtin_amdgcn_rcpf(df.z)), lo, hi, t);
+    } else {
+        lds_float *ce = local_lds(camv);   // (read here, not kept in registers across the tile loop)
+        const V3 eye = v3(ce[0], ce[1], ce[2]);
+        if (qkind == PRIM_CAPSULE) hit = ray_capsule<true>(eye, dw, v3(lo.x, lo.y, lo.z), hi.x, hi.y, t, n);
+        else if (qkind == PRIM_CONE) hit = ray_cone<true>(eye, dw, v3(lo.x, lo.y, lo.z), hi.x, hi.y, hi.z, t, n);
+        else if (SHAPES) {
+            const V3 df = qfr == 0 ? dw : qfr == 1 + viewer ? v3(dcx, dcy, -1.0f) : lds_tmul(local_lds(s_hdr + FH_CAM + FH_CAM_STRIDE * (qfr - 1) + 3), dw);
+            hit = ray_scaled_shape<true>(qkind, df, v3(lo.x, lo.y, lo.z), v3(hi.x, hi.y, hi.z), t, n);
+        } else hit = false;
+    }
+    const unsigned key = hit_key<POS_MASK>(hit && t >= NEAR_Z && t <= FAR_Z, t, pos);
+    return key;
+}
 
-    float4 *s_col = reinterpret_cast<float4 *>(s_dyn);   // per column i: (dc.x, c00*dc.x, c10*dc.x, c20*dc.x)
-    float4 *s_row = s_col + W;                            // per row j:    (dc.y, c01*dc.y, c11*dc.y, c21*dc.y)
-    float2 *s_rowq = reinterpret_cast<float2 *>(s_row + H);   // (dc.y^2 + 1, L . dc = 4 dc.y - 2)
-    float *s_colq = reinterpret_cast<float *>(s_rowq + H);    // dc.x^2   (last: keeps every table naturally aligned for odd W)
+// Phong (Magnum Shaders::Phong, uniforms of magnum_env_renderer.cpp:200-203) for the winning hit of a pixel; 0xff000000 when there is none
+template <bool SHAPES, unsigned POS_MASK>
+__device__ __forceinline__ unsigned fast_shade(unsigned best, V3 bn, const float4 *s_vis, const float *s_hdr, const float *camv, int viewer, V3 dw, V3 inv, float dcx, float dcy, float a2, float ldc)
+{
+    unsigned rgba = 0xff000000u;
+    if (best <= (KEY_FAR | POS_MASK)) {   // a hit between the near and the far plane
+        const V3 dc = v3(dcx, dcy, -1.0f);
+        const int pos = (int)(best & POS_MASK);
+        const float4 lo = s_vis[2 * pos], hi = s_vis[2 * pos + 1];
+        const unsigned meta = __float_as_uint(lo.w), color = __float_as_uint(hi.w);
+        const int qkind = meta & 15, qfr = (meta >> 4) & 15;
+        float t, ndl, nv;   // depth; N . (L - P) and N . (-P), both unnormalised in (L - P) / P
+        if (qkind == PRIM_BOX) {
+            V3 d = dw, iv = inv;
+            if (qfr != 0) {
+                d = qfr == 1 + viewer ? dc : lds_tmul(local_lds(s_hdr + FH_CAM + FH_CAM_STRIDE * (qfr - 1) + 3), dw);
+                iv = v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+            }
+            const float tnx = __builtin_fminf(lo.x * iv.x, hi.x * iv.x), tny = __builtin_fminf(lo.y * iv.y, hi.y * iv.y),
+                        tnz = __builtin_fminf(lo.z * iv.z, hi.z * iv.z);
+            t = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz);
+            const int axis = tnx == t ? 0 : tny == t ? 1 : 2;   // first axis whose near-plane crossing is the entry depth
+            const float dk = axis == 0 ? d.x : axis == 1 ? d.y : d.z;
+            const float lk = s_hdr[FH_LREL + 4 * qfr + axis];
+            nv = t * __builtin_fabsf(dk);                                                      // plane offset along the outward normal
+            ndl = nv - __uint_as_float(__float_as_uint(lk) ^ (__float_as_uint(dk) & 0x80000000u));   // sgn (Lrel_k - t d_k), sgn = -sign(d_k)
+        } else {   // capsules, cones, scaled shapes: the normal was kept with the hit (depth: the key's, 2^-15 relative)
+            t = __uint_as_float((best & ~POS_MASK) + KEY_NEAR);
+            V3 N;
+            lds_float *cc = local_lds(camv + 3);
+            if (!SHAPES || qkind < PRIM_SPHERE_S || qfr == 0) N = lds_tmul(cc, bn);
+            else if (qfr == 1 + viewer) N = bn;
+            else N = lds_tmul(cc, lds_mul(local_lds(s_hdr + FH_CAM + FH_CAM_STRIDE * (qfr - 1) + 3), bn));
+            const V3 P = dc * t;
+            nv = -dot(N, P);
+            ndl = dot(N, v3(0.0f - P.x, 4.0f - P.y, 2.0f - P.z));
+        }
+        // |L - P|^2 = |L|^2 - 2 t (L . dc) + t^2 (dc . dc)
+        const float ta = t * a2;
+        const float len2LP = __builtin_fmaf(t, ta - 2.0f * ldc, 20.0f);
+        const float rs = __builtin_amdgcn_rsqf(len2LP);
+        const float intensity = __builtin_fmaxf(0.0f, ndl * rs);
+        float spec255 = 0.0f;
+        if (intensity > 0.001f) {
+            // V . R with V = -P unnormalised: 2 (N . Ld)(N . -P) + Ld . P
+            const float vr = __builtin_fmaf(2.0f * intensity, nv, (t * (ldc - ta)) * rs);
+            const float p2 = t * ta;   // |P|^2
+            if (vr > 0.0f && vr * vr > SPEC_COS2 * p2) {
+                const float cosv = __builtin_fminf(vr * __builtin_amdgcn_rsqf(p2), 1.0f);
+                spec255 = 255.0f * __builtin_amdgcn_exp2f(300.0f * __builtin_amdgcn_logf(cosv));
+            }
+        }
+        const float AMB = float(0x55) / 255.0f, DIFL = (float(0xbb) / 255.0f) * (float(0xaa) / 255.0f);
+        const float sc = __builtin_fmaf(DIFL, intensity, AMB);
+        const float r8 = __builtin_fmaf(float((color >> 16) & 255u), sc, spec255), g8 = __builtin_fmaf(float((color >> 8) & 255u), sc, spec255),
+                    b8 = __builtin_fmaf(float(color & 255u), sc, spec255);
+        // v_cvt_pk_u8_f32: round to nearest (even on ties; the exact kernel rounds ties up: they do not occur), saturate, insert the byte
+        rgba = __builtin_amdgcn_cvt_pk_u8_f32(b8, 2, __builtin_amdgcn_cvt_pk_u8_f32(g8, 1, __builtin_amdgcn_cvt_pk_u8_f32(r8, 0, 0xff000000u)));
+    }
+    return rgba;
+}
 
+struct FastFrame { int frame, part, viewer, nVis; };
+
+// The fast kernels' prologue: which frame is this workgroup's, then copies (header, list, rectangles) + the separable ray tables; ends with the
+// one barrier.  Workgroup ids are dealt round-robin over the 8 XCDs; the `split` parts of one frame get ids that are congruent mod 8 so that they
+// share one XCD's L2 (the frame's list is read `split` times, neighbouring tiles write neighbouring lines).
+template <int MAXVIS>
+__device__ __forceinline__ FastFrame fast_prologue(const FastArgs &fa, int W, int H, int split, float4 *s_vis, short4 *s_rect, float *s_hdr, float4 *s_col,
+                                                   float4 *s_row, float2 *s_rowq, float *s_colq)
+{
     const int A = fa.num_agents;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // Workgroup ids are dealt round-robin over the 8 XCDs; the `split` parts of one frame get ids that are congruent mod 8 so
-    // that they share one XCD's L2 (the frame's list is read `split` times, neighbouring tiles write neighbouring lines).
     int position, part;
     {
         const int per = 8 * split, group = blockIdx.x / per, r = blockIdx.x - group * per;
@@ -693,6 +776,59 @@ __global__ __launch_bounds__(256, WAVES) void raster_fast_kernel(FastArgs fa, ui
     }
     __syncthreads();
 
+    return FastFrame{frame, part, viewer, nVis};
+}
+
+// the boxes of one frame of reference among list positions 64 k .. 64 k + 63 (mask m) against this lane's ray, given the ray's inverse
+// direction in that frame: the next record is fetched from LDS while the current one is intersected
+template <unsigned POS_MASK>
+__device__ __forceinline__ void box_run(unsigned long long m, int k, V3 inv, const float4 *s_vis, unsigned &best)
+{
+    if (!m) return;
+    int p0 = __ffsll((long long)m) - 1 + 64 * k, p1 = 0;
+    m &= m - 1;
+    float4 lo0 = s_vis[2 * p0], hi0 = s_vis[2 * p0 + 1], lo1 = lo0, hi1 = hi0;
+    for (;;) {
+        bool more = m != 0ull;
+        if (more) { p1 = __ffsll((long long)m) - 1 + 64 * k; m &= m - 1; lo1 = s_vis[2 * p1]; hi1 = s_vis[2 * p1 + 1]; }
+        best = min(best, box_key<POS_MASK>(inv, lo0, hi0, p0));
+        if (!more) break;
+        more = m != 0ull;
+        if (more) { p0 = __ffsll((long long)m) - 1 + 64 * k; m &= m - 1; lo0 = s_vis[2 * p0]; hi0 = s_vis[2 * p0 + 1]; }
+        best = min(best, box_key<POS_MASK>(inv, lo1, hi1, p1));
+        if (!more) break;
+    }
+}
+
+}  // namespace
+
+// HEXF (Hex scenarios): most primitives are boxes in one of the three wall frames (header records 8..10: rotations about Y by +30, -30, 90
+// degrees around the world origin).  The ray's inverse direction in each of them is set up once per pixel -- four v_rcp_f32, the 90 degree
+// frame only permutes the world one -- and their boxes run through the same prefetching loop as the world's; which list positions hold a box
+// of which frame is found by the wave itself while culling (one LDS read per lane and round) instead of coming from the header.
+// (Measured and rejected for these long lists, ~700 primitives per frame: a two-level variant -- a wave culls the list against a block of 2 x 2
+// tiles once and its tiles only look at the survivors -- 164 / 187 us against 170 / 189 us at 128 x 128 and slower at 64 x 64: the time
+// goes into intersecting the ~19 boxes that survive per tile, not into the rectangle tests.)
+template <int MAXVIS, bool SHAPES, int WAVES, bool HEXF = false>   // WAVES: waves per SIMD the variant is compiled for (register budget 512 / WAVES)
+__global__ __launch_bounds__(256, WAVES) void raster_fast_kernel(FastArgs fa, uint32_t *obs, int W, int H, int split)
+{
+    constexpr int ROUNDS = MAXVIS / 64;
+    constexpr unsigned POS_MASK = MAXVIS - 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    __shared__ float4 s_vis[2 * MAXVIS];      // Prim records as (lo, meta) (hi, colour)
+    __shared__ short4 s_rect[MAXVIS];
+    __shared__ __attribute__((aligned(16))) float s_hdr[FH_FLOATS];
+    static_assert(ROUNDS <= 16, "world-box masks: 16 x 64 positions");
+
+    float4 *s_col = reinterpret_cast<float4 *>(s_dyn);   // per column i: (dc.x, c00*dc.x, c10*dc.x, c20*dc.x)
+    float4 *s_row = s_col + W;                            // per row j:    (dc.y, c01*dc.y, c11*dc.y, c21*dc.y)
+    float2 *s_rowq = reinterpret_cast<float2 *>(s_row + H);   // (dc.y^2 + 1, L . dc = 4 dc.y - 2)
+    float *s_colq = reinterpret_cast<float *>(s_rowq + H);    // dc.x^2   (last: keeps every table naturally aligned for odd W)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const FastFrame ff = fast_prologue<MAXVIS>(fa, W, H, split, s_vis, s_rect, s_hdr, s_col, s_row, s_rowq, s_colq);
+    const int frame = ff.frame, part = ff.part, viewer = ff.viewer, nVis = ff.nVis;
+
     const float *camv = s_hdr + FH_CAM + FH_CAM_STRIDE * viewer;   // eye(3) c(9) origin(3)
     const float nzm0 = uniform_f32(-camv[3 + 2]), nzm1 = uniform_f32(-camv[3 + 5]), nzm2 = uniform_f32(-camv[3 + 8]);
     uint32_t *out = obs + (size_t)frame * W * H;
@@ -709,6 +845,7 @@ __global__ __launch_bounds__(256, WAVES) void raster_fast_kernel(FastArgs fa, ui
         const bool inside = px < W && py < H;
         const int pxc = min(px, W - 1), pyc = min(py, H - 1);
         V3 dw = v3(0, 0, 0), inv = v3(0, 0, 0);
+        float ihx0 = 0.0f, ihz0 = 0.0f, ihx1 = 0.0f, ihz1 = 0.0f;   // HEXF: 1 / (ray direction x, z) in wall frames 0 and 1
         float dcx = 0.0f, dcy = 0.0f, a2 = 0.0f, ldc = 0.0f;
         bool rayReady = false;   // wave-uniform: the ray is set up when the first primitive survives the culling
         unsigned best = ~0u;
@@ -730,6 +867,31 @@ __global__ __launch_bounds__(256, WAVES) void raster_fast_kernel(FastArgs fa, ui
                 dw = v3((cx.y + ry.y) + nzm0, (cx.z + ry.z) + nzm1, (cx.w + ry.w) + nzm2);
                 inv = v3(__builtin_amdgcn_rcpf(dw.x), __builtin_amdgcn_rcpf(dw.y), __builtin_amdgcn_rcpf(dw.z));
                 a2 = s_colq[pxc] + rq.x; ldc = rq.y;
+                if (HEXF) {   // (same products and sums as mat_tmul with the frame's matrix: c x + (-s) z, s x + c z)
+                    const float cx8 = 0.8660254f * dw.x, cz8 = 0.8660254f * dw.z, hx5 = 0.5f * dw.x, hz5 = 0.5f * dw.z;
+                    ihx0 = __builtin_amdgcn_rcpf(cx8 - hz5); ihz0 = __builtin_amdgcn_rcpf(hx5 + cz8);
+                    ihx1 = __builtin_amdgcn_rcpf(cx8 + hz5); ihz1 = __builtin_amdgcn_rcpf(cz8 - hx5);
+                }
+            }
+            if (HEXF) {
+                const unsigned ml = __float_as_uint(s_vis[2 * cpos].w);   // this lane's primitive: kind | frame << 4 | slot << 8
+                const bool box = v && (ml & 15u) == (unsigned)PRIM_BOX;
+                const unsigned fl = (ml >> 4) & 15u;
+                const unsigned long long m0 = __ballot(box && fl == 0u), m1 = __ballot(box && fl == (unsigned)MAX_AGENTS + 1u),
+                                         m2 = __ballot(box && fl == (unsigned)MAX_AGENTS + 2u), m3 = __ballot(box && fl == (unsigned)MAX_AGENTS + 3u);
+                box_run<POS_MASK>(m0, k, inv, s_vis, best);
+                box_run<POS_MASK>(m1, k, v3(ihx0, inv.y, ihz0), s_vis, best);
+                box_run<POS_MASK>(m2, k, v3(ihx1, inv.y, ihz1), s_vis, best);
+                box_run<POS_MASK>(m3, k, v3(0.0f - inv.z, inv.y, inv.x), s_vis, best);   // 90 degrees: (x, z) -> (-z, x)
+                unsigned long long rest = mvis & ~(m0 | m1 | m2 | m3);
+                while (rest) {   // camera-attached boxes, capsules, cones, scaled shapes
+                    const int pos = __ffsll((long long)rest) - 1 + 64 * k;
+                    rest &= rest - 1;
+                    V3 n = v3(0, 0, 0);
+                    const unsigned key = fast_other<SHAPES, POS_MASK>(pos, s_vis, s_hdr, camv, viewer, dw, dcx, dcy, n);
+                    if (key < best) { best = key; bn = n; }
+                }
+                continue;
             }
             const unsigned long long wb = uniform_u64(*reinterpret_cast<const unsigned long long *>(s_hdr + FH_WB + 2 * k));
             // ---- world-frame boxes: the next primitive's record is fetched from LDS while the current one is intersected
@@ -755,85 +917,13 @@ __global__ __launch_bounds__(256, WAVES) void raster_fast_kernel(FastArgs fa, ui
                 const int bit = __ffsll((long long)m) - 1;
                 m &= m - 1;
                 const int pos = bit + 64 * k;
-                const float4 lo = s_vis[2 * pos], hi = s_vis[2 * pos + 1];
-                const unsigned meta = __builtin_amdgcn_readfirstlane(__float_as_uint(lo.w));
-                const int qkind = meta & 15, qfr = (meta >> 4) & 15;
-                float t = 0.0f; V3 n = v3(0, 0, 0);
-                bool hit;
-                if (qkind == PRIM_BOX) {
-                    const V3 df = qfr == 1 + viewer ? v3(dcx, dcy, -1.0f) : lds_tmul(local_lds(s_hdr + FH_CAM + FH_CAM_STRIDE * (qfr - 1) + 3), dw);
-                    hit = fast_box(v3(__builtin_amdgcn_rcpf(df.x), __builtin_amdgcn_rcpf(df.y), __builtin_amdgcn_rcpf(df.z)), lo, hi, t);
-                } else {
-                    lds_float *ce = local_lds(camv);   // (read here, not kept in registers across the tile loop)
-                    const V3 eye = v3(ce[0], ce[1], ce[2]);
-                    if (qkind == PRIM_CAPSULE) hit = ray_capsule<true>(eye, dw, v3(lo.x, lo.y, lo.z), hi.x, hi.y, t, n);
-                    else if (qkind == PRIM_CONE) hit = ray_cone<true>(eye, dw, v3(lo.x, lo.y, lo.z), hi.x, hi.y, hi.z, t, n);
-                    else if (SHAPES) {
-                        const V3 df = qfr == 0 ? dw : qfr == 1 + viewer ? v3(dcx, dcy, -1.0f) : lds_tmul(local_lds(s_hdr + FH_CAM + FH_CAM_STRIDE * (qfr - 1) + 3), dw);
-                        hit = ray_scaled_shape<true>(qkind, df, v3(lo.x, lo.y, lo.z), v3(hi.x, hi.y, hi.z), t, n);
-                    } else hit = false;
-                }
-                const unsigned key = hit_key<POS_MASK>(hit && t >= NEAR_Z && t <= FAR_Z, t, pos);
+                V3 n = v3(0, 0, 0);
+                const unsigned key = fast_other<SHAPES, POS_MASK>(pos, s_vis, s_hdr, camv, viewer, dw, dcx, dcy, n);
                 if (key < best) { best = key; bn = n; }
             }
         }
 
-        // ---- Phong (Magnum Shaders::Phong, uniforms of magnum_env_renderer.cpp:200-203)
-        unsigned rgba = 0xff000000u;
-        if (best <= (KEY_FAR | POS_MASK)) {   // a hit between the near and the far plane
-            const V3 dc = v3(dcx, dcy, -1.0f);
-            const int pos = (int)(best & POS_MASK);
-            const float4 lo = s_vis[2 * pos], hi = s_vis[2 * pos + 1];
-            const unsigned meta = __float_as_uint(lo.w), color = __float_as_uint(hi.w);
-            const int qkind = meta & 15, qfr = (meta >> 4) & 15;
-            float t, ndl, nv;   // depth; N . (L - P) and N . (-P), both unnormalised in (L - P) / P
-            if (qkind == PRIM_BOX) {
-                V3 d = dw, iv = inv;
-                if (qfr != 0) {
-                    d = qfr == 1 + viewer ? dc : lds_tmul(local_lds(s_hdr + FH_CAM + FH_CAM_STRIDE * (qfr - 1) + 3), dw);
-                    iv = v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-                }
-                const float tnx = __builtin_fminf(lo.x * iv.x, hi.x * iv.x), tny = __builtin_fminf(lo.y * iv.y, hi.y * iv.y),
-                            tnz = __builtin_fminf(lo.z * iv.z, hi.z * iv.z);
-                t = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz);
-                const int axis = tnx == t ? 0 : tny == t ? 1 : 2;   // first axis whose near-plane crossing is the entry depth
-                const float dk = axis == 0 ? d.x : axis == 1 ? d.y : d.z;
-                const float lk = s_hdr[FH_LREL + 4 * qfr + axis];
-                nv = t * __builtin_fabsf(dk);                                                      // plane offset along the outward normal
-                ndl = nv - __uint_as_float(__float_as_uint(lk) ^ (__float_as_uint(dk) & 0x80000000u));   // sgn (Lrel_k - t d_k), sgn = -sign(d_k)
-            } else {   // capsules, cones, scaled shapes: the normal was kept with the hit (depth: the key's, 2^-15 relative)
-                t = __uint_as_float((best & ~POS_MASK) + KEY_NEAR);
-                V3 N;
-                lds_float *cc = local_lds(camv + 3);
-                if (!SHAPES || qkind < PRIM_SPHERE_S || qfr == 0) N = lds_tmul(cc, bn);
-                else if (qfr == 1 + viewer) N = bn;
-                else N = lds_tmul(cc, lds_mul(local_lds(s_hdr + FH_CAM + FH_CAM_STRIDE * (qfr - 1) + 3), bn));
-                const V3 P = dc * t;
-                nv = -dot(N, P);
-                ndl = dot(N, v3(0.0f - P.x, 4.0f - P.y, 2.0f - P.z));
-            }
-            // |L - P|^2 = |L|^2 - 2 t (L . dc) + t^2 (dc . dc)
-            const float ta = t * a2;
-            const float len2LP = __builtin_fmaf(t, ta - 2.0f * ldc, 20.0f);
-            const float rs = __builtin_amdgcn_rsqf(len2LP);
-            const float intensity = __builtin_fmaxf(0.0f, ndl * rs);
-            float spec255 = 0.0f;
-            if (intensity > 0.001f) {
-                // V . R with V = -P unnormalised: 2 (N . Ld)(N . -P) + Ld . P
-                const float vr = __builtin_fmaf(2.0f * intensity, nv, (t * (ldc - ta)) * rs);
-                const float p2 = t * ta;   // |P|^2
-                if (vr > 0.0f && vr * vr > SPEC_COS2 * p2) {
-                    const float cosv = __builtin_fminf(vr * __builtin_amdgcn_rsqf(p2), 1.0f);
-                    spec255 = 255.0f * __builtin_amdgcn_exp2f(300.0f * __builtin_amdgcn_logf(cosv));
-                }
-            }
-            const float AMB = float(0x55) / 255.0f, DIFL = (float(0xbb) / 255.0f) * (float(0xaa) / 255.0f);
-            const float sc = __builtin_fmaf(DIFL, intensity, AMB);
-            const float r8 = __builtin_fmaf(float((color >> 16) & 255u), sc, spec255), g8 = __builtin_fmaf(float((color >> 8) & 255u), sc, spec255),
-                        b8 = __builtin_fmaf(float(color & 255u), sc, spec255);
-            // v_cvt_pk_u8_f32: round to nearest (even on ties; the exact kernel rounds ties up: they do not occur), saturate, insert the byte
-            rgba = __builtin_amdgcn_cvt_pk_u8_f32(b8, 2, __builtin_amdgcn_cvt_pk_u8_f32(g8, 1, __builtin_amdgcn_cvt_pk_u8_f32(r8, 0, 0xff000000u)));
-        }
+        const unsigned rgba = fast_shade<SHAPES, POS_MASK>(best, bn, s_vis, s_hdr, camv, viewer, dw, inv, dcx, dcy, a2, ldc);
         if (inside) out[(unsigned)(py * W + px)] = rgba;   // (32-bit offset from the frame's base: scalar-base addressing)
     }
 }
@@ -861,7 +951,7 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
         // (Collect, measured and rejected: a 1024-entry launch for the frames above 256 visible primitives + a 256-entry launch for the rest,
         // 75 + 69 us against 107 us for the single 1024-entry launch: each launch pays its own tail, and the cones, not occupancy, dominate)
         const bool hexScen = gv.scenario == SCN_HEX_MEMORY || gv.scenario == SCN_HEX_EXPLORE;
-        KernelFn fn = hexScen ? raster_fast_kernel<VIS_LARGE, true, 3> : gv.vis_stride > VIS_SMALL ? raster_fast_kernel<VIS_LARGE, false, 3>
+        KernelFn fn = hexScen ? raster_fast_kernel<VIS_LARGE, true, 3, true> : gv.vis_stride > VIS_SMALL ? raster_fast_kernel<VIS_LARGE, false, 3>
                     : gv.scenario == SCN_REARRANGE ? (wavesSel >= 8 ? raster_fast_kernel<VIS_SMALL, true, 8> : raster_fast_kernel<VIS_SMALL, true, 6>)
                                                    : (wavesSel >= 8 ? raster_fast_kernel<VIS_SMALL, false, 8> : raster_fast_kernel<VIS_SMALL, false, 6>);
         hipLaunchKernelGGL(fn, dim3(frames * split), dim3(256), dyn, stream, fa, obs, W, H, split);

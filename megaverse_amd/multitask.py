@@ -14,7 +14,10 @@ import numpy as np
 
 from .extension import MegaverseGym
 
-MEGAVERSE_IN_SCOPE = ["TowerBuilding", "ObstaclesEasy", "ObstaclesHard", "Collect"]   # the MEGAVERSE8 members this build covers
+# megaverse_env.py:18-21 of the reference: the eight scenarios of its multi-task benchmark, all available on the HIP path
+# (Sokoban reads Boxoban level files: $BOXOBAN_LEVELS, as in the reference)
+MEGAVERSE8 = ["TowerBuilding", "ObstaclesEasy", "ObstaclesHard", "Collect", "Sokoban", "HexMemory", "HexExplore", "Rearrange"]
+MEGAVERSE_IN_SCOPE = MEGAVERSE8   # (older name)
 
 
 class MultiTaskGym:

@@ -45,7 +45,7 @@ def pair(scenario, N, A, W, H, seed, params=None):
 
 
 @pytest.mark.parametrize("scenario,A", [("TowerBuilding", 1), ("TowerBuilding", 4), ("ObstaclesHard", 2), ("ObstaclesEasy", 1),
-                                        ("Collect", 2), ("Rearrange", 3)])
+                                        ("Collect", 2), ("Rearrange", 3), ("HexMemory", 2), ("HexExplore", 1)])
 @pytest.mark.parametrize("W,H", [(128, 128), (128, 72), (64, 64), (48, 20)])
 def test_fast_pixels_within_tolerance(hip, scenario, A, W, H):
     N = 8 if (W, H) == (128, 128) else 4
@@ -74,7 +74,8 @@ def test_fast_hires_within_tolerance(hip):
 
 
 @pytest.mark.parametrize("scenario,N,A,W,H", [("TowerBuilding", 1024, 1, 128, 128), ("TowerBuilding", 512, 4, 128, 128),
-                                              ("ObstaclesHard", 512, 1, 128, 128), ("Collect", 256, 1, 64, 64)])
+                                              ("ObstaclesHard", 512, 1, 128, 128), ("Collect", 256, 1, 64, 64),
+                                              ("HexMemory", 256, 2, 64, 64)])
 def test_fast_equals_exact_within_tolerance_at_full_size(hip, scenario, N, A, W, H):
     """BASELINE.json sizes (the oracle is too slow there): the same gym rendered by both kernels after a rollout with natural
     auto-resets; every frame of the slab compared."""

@@ -11,9 +11,12 @@ from megaverse_amd.rollout import action_masks, sample_actions
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
 
 
-def test_multitask_equals_per_scenario_oracles(hip):
+def test_multitask_equals_per_scenario_oracles(hip, monkeypatch):
+    import os
     import torch
-    N, A, W, H, S = 8, 2, 64, 64, len(MEGAVERSE_IN_SCOPE)
+    monkeypatch.setenv("BOXOBAN_LEVELS", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "boxoban"))   # Sokoban
+    N, A, W, H, S = 16, 2, 64, 36, len(MEGAVERSE_IN_SCOPE)
+    assert S == 8
     mt = MultiTaskGym(MEGAVERSE_IN_SCOPE, W, H, N, A, 2)
     obs = mt.attach("cuda:0")
     mt.seed(77); mt.reset()
