@@ -301,6 +301,9 @@ def main():
             "config": {"workload": f"{args.scenario} num_envs={n_env} per GPU x {world} GPU(s), num_agents_per_env={A}, obs {W}x{H} RGBA8, "
                                    "uniform random multi-discrete actions (device, counter-based), natural auto-resets, master seed 42",
                        "envs_per_gpu": n_env, "agents_per_env": A, "obs": [W, H], "gather_obs": bool(do_gather), "pixels": args.pixels,
+                       # the step kernels of tick t + 1 / t + 2 overlap the observation pass of tick t (every tick is still
+                       # stepped and rendered in full; MV_PIPELINE=0 runs the two kernels back to back on one stream)
+                       "pipelined": bool(not dry and not mixed and gym.pipelining()),
                        "parallelism": f"env-shard x{world}"},
         }
         if dry:
@@ -334,7 +337,8 @@ def main():
                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_step / HBM_PEAK_GBS, "traffic": traffic_step,
                                         "avg_launch_ms": step_ms, "launches_timed": prof["step"][1], "algorithmic_bytes_per_launch": step_bytes_per_env * n_env,
                                         "note": "north_star's >=40 % HBM target names this kernel; its working set is 1.7 KB per env (the 16 KB voxel chunk "
-                                                "is not streamed), so it is latency-bound: one wave per env, launch length = slowest wave (DESIGN.md 3.1)"}
+                                                "is not streamed), so it is latency-bound: one wave per env, launch length = slowest wave (DESIGN.md 3.1); "
+                                                "when pipelined it runs concurrently with the previous tick's raster, which stretches its launches"}
             line["kernels"] = {"frame_setup_and_sort": {"avg_launch_ms": prof["setup"][0], "note": "frame sort only: the frame setup runs inside the step kernel"},
                                "status_readback_gap": {"avg_launch_ms": prof["reset"][0]}}
         line["checksum"] = checksum

@@ -98,6 +98,16 @@ enum { MV_PIXELS_EXACT = 0, MV_PIXELS_FAST = 1 };
 int mv_set_pixel_mode(mv_gym *g, int32_t mode);
 int mv_get_pixel_mode(const mv_gym *g);
 
+/* One-step-ahead pipelining (no reference counterpart).  On (default): the step kernels run on an internal stream,
+ * and the step of tick t + 1 may overlap the observation pass of tick t whenever nothing the caller enqueued on its stream feeds
+ * it (device-sampled or host-provided actions).  Nothing observable changes: rewards / dones / true objectives are published into
+ * the arrays above ON THE CALLER'S STREAM, ordered with the observations, and a step never overwrites what a consumer enqueued
+ * before the previous mv_step may still be reading.  mv_set_actions_device makes the next step wait (a policy in the loop is a true
+ * dependency).  Off: everything runs on the caller's stream in order -- cheaper when several gyms already overlap each other
+ * (MultiTaskGym) -- and the exact pixel mode always does.  Env var MV_PIPELINE=0|1 sets the default of new gyms. */
+int mv_set_pipelining(mv_gym *g, int32_t on);
+int mv_get_pipelining(const mv_gym *g);
+
 /* setRenderResolution/drawHires/getHiresObservation (:145-178,203-207); drawOverview is a no-op
  * exactly like a reference build without WITH_GUI (:180-201) */
 int mv_set_render_resolution(mv_gym *g, int32_t w, int32_t h);

@@ -80,13 +80,29 @@ static const char *SHAPING_KEYS_COLLECT[5] = {"teamSpirit", "collectSingleGood",
 static const float SHAPING_DEFAULT_COLLECT[5] = {0.0f, 1.0f, -1.0f, 5.0f, -0.5f};
 static const int ACTION_SPACE[6] = {3, 3, 3, 2, 2, 3};                          // env.cpp:33
 
+static_assert(PIPE_BUFS == 3, "userMark events are created one by one in mv_create");
 struct mv_gym {
     int device = 0;
     int w = 0, h = 0, renderW = 768, renderH = 432;   // megaverse.cpp:261
     int N = 0, A = 0, envOffset = 0, envStride = 1, totalEnvs = 0;
     bool samplePending = false;                  // mv_sample_random_actions: the next step draws its own actions
     bool closed = false, wasReset = false;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;                // the caller's stream: observation passes, published outputs, everything it may consume
+    // One-step-ahead pipelining: the step kernels run on an internal stream.  A step only waits for what the caller had
+    // enqueued on its stream when the PREVIOUS mv_step began (consumers of outputs two steps old), so step t + 1 overlaps the observation
+    // pass of step t whenever nothing on the caller's stream feeds it (device-sampled or host-provided actions).  Everything a step
+    // hands to the observation pass or to the caller exists PIPE_BUFS times: frame lists / headers / cost lists, and the rewards /
+    // dones / true objectives, which the observation pass (on the caller's stream) publishes into the stable public arrays.
+    hipStream_t simStream = nullptr;
+    int pipelined = 1;                           // mv_set_pipelining / MV_PIPELINE: 0 = everything on the caller's stream, in order
+    bool simOnOwnStream = false;                 // where the last step ran
+    hipEvent_t userMark[PIPE_BUFS] = {};          // recorded on `stream` at the start of every mv_step, round-robin
+    int markCount = 0;
+    bool simMustWaitUser = true;                 // the caller's stream holds work the next step depends on (reset, render, device actions, ...)
+    hipEvent_t simDone = nullptr;                // after the last kernel on simStream
+    bool simDoneValid = false;
+    int parity = 0, hist3 = 0;                   // hand-over buffer of the last step (of PIPE_BUFS); cost histogram (of LPT_HISTS) of the last pass
+    GymView gvp[PIPE_BUFS];                      // gv with the buffers of each slot swapped in
     GymView gv{};
     uint8_t *arena = nullptr;
     uint32_t *obs = nullptr, *ownedObs = nullptr, *hiresObs = nullptr;
@@ -127,6 +143,7 @@ struct mv_gym {
     hipEvent_t resetDone = nullptr, statusCopied = nullptr;
     bool stepDoneValid = false;
     std::vector<hipEvent_t> uploadEvents;           // ring, one per upload batch
+    hipEvent_t lastUpload = nullptr;                // the most recent batch (mv_reset: the caller's stream waits for it too)
     size_t uploadRing = 0;
     // in-stream profiling
     std::vector<hipEvent_t> profEvents;          // 5 per profiled step
@@ -146,6 +163,18 @@ __global__ void masks_from_multidiscrete_kernel(const int32_t *md, int32_t *mask
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) masks[i] = action_mask_of(md + (size_t)i * 6);
+}
+
+// step outputs of this parity -> the public arrays (on the caller's stream: ordered with its consumers).  true_objective is only ever
+// recorded by a finishing env (vector_env.cpp:96-101): the others keep the value of their last episode.
+__global__ void publish_kernel(const float *s_rew, const uint8_t *s_done, const float *s_true, float *rew, uint8_t *done, float *true_obj, int n_envs, int A)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_envs * A) return;
+    rew[i] = s_rew[i];
+    const int e = i / A;
+    if (s_done[e]) true_obj[i] = s_true[i];
+    if (i < n_envs) done[i] = s_done[i];
 }
 
 __global__ void set_shaping_kernel(AgentState *agents, int idx, int key, float v) { agents[idx].shaping[key] = v; }
@@ -207,6 +236,35 @@ static int refresh_mirrors(mv_gym *g)
     HIP_TRY(hipMemcpyAsync(g->hDone.data(), g->gv.done, (size_t)g->N, hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
     g->mirrorsFresh = true;
+    return 0;
+}
+
+// the view a kernel launch gets: the buffers of step parity q, this pass's cost histogram, the action-sampling request
+static GymView view(const mv_gym *g, int q, bool direct = false)   // direct: the step writes the public output arrays itself (not pipelined)
+{
+    GymView v = g->gvp[q];
+    if (direct) { v.rewards = g->gv.rewards; v.done = g->gv.done; v.true_objective = g->gv.true_objective; }
+    v.sample_on = g->gv.sample_on; v.sample_seed = g->gv.sample_seed; v.sample_step = g->gv.sample_step;
+    v.lpt_parity = g->hist3;
+    return v;
+}
+
+// Before anything on the caller's stream reads or writes simulator state (reset, render, hires, seeds, test hooks): it waits for the
+// simulation stream, and the next step will wait for it.
+static int sim_join(mv_gym *g)
+{
+    if (g->simDoneValid && g->simOnOwnStream) HIP_TRY(hipStreamWaitEvent(g->stream, g->simDone, 0));
+    g->simMustWaitUser = true;
+    return 0;
+}
+
+static int publish_outputs(mv_gym *g, int q)   // on the caller's stream
+{
+    const GymView &v = g->gvp[q];
+    const int n = g->N * g->A;
+    hipLaunchKernelGGL(publish_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, v.rewards, v.done, v.true_objective, g->gv.rewards, g->gv.done,
+                       g->gv.true_objective, g->N, g->A);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 
@@ -318,9 +376,11 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     gv.vis_stride = collect || hex ? 1024 : 256;
     gv.spares = g->spares;
     const size_t szVisP = up(NA * (size_t)gv.vis_stride * 32), szVisR = up(NA * (size_t)gv.vis_stride * 8), szVisC = up(NA * sizeof(int32_t)),
-                 szLpt = up(NA * sizeof(int32_t)) + up((NA + 1) * sizeof(int32_t)) + up(NA * (size_t)FRAME_HDR_BYTES) + up(2 * 256 * sizeof(int32_t)) + up(256 * NA * sizeof(int32_t));
+                 szLpt = up(NA * sizeof(int32_t)) + up((NA + 1) * sizeof(int32_t)) + up(NA * (size_t)FRAME_HDR_BYTES) + up(256 * NA * sizeof(int32_t));
+    // per step parity (x 2): frame lists, headers, cost lists, and the staging copies of rewards / dones / true objectives
+    const size_t szParity = szVisP + szVisR + szVisC + szLpt + szRew + szDone + szObjv, szHist = up(LPT_HISTS * 256 * sizeof(int32_t));
     const size_t total = szHdr + szBoxes + szObj + szAg + szAct + szRew + szDone + szObjv + szMd + (hostEpisodes ? 0 : szChunk) + szObs + szTerrain +
-                         szRewObj + szHeight + szItems + szCells + szHexB + szHexO + szBlobs + szCnt + szVisP + szVisR + szVisC + szLpt;
+                         szRewObj + szHeight + szItems + szCells + szHexB + szHexO + szBlobs + szCnt + PIPE_BUFS * szParity + szHist;
     {
         hipError_t e_ = hipMalloc((void **)&g->arena, total);
         if (e_ != hipSuccess) { mv_destroy(g); return fail(std::string("hipMalloc arena: ") + hipGetErrorString(e_)); }
@@ -351,16 +411,24 @@ int mv_create(const mv_config *cfg, mv_gym **out)
         if (rearrange) { gv.items = (ArrangementItem *)p; p += szItems; }
         if (sokoban) { gv.soko_cells = p; p += szCells; }
         if (hex) { gv.hex_boxes = (HexRec *)p; p += szHexB; gv.hex_objs = (HexRec *)p; p += szHexO; }
-        gv.vis_prims = p; p += szVisP;
-        gv.vis_rects = p; p += szVisR;
-        gv.vis_count = (int32_t *)p; p += szVisC;
-        gv.lpt_bucket = (int32_t *)p; p += up(NA * sizeof(int32_t));
-        gv.lpt_order = (int32_t *)p; p += up((NA + 1) * sizeof(int32_t));
-        gv.vis_hdr = p; p += up(NA * (size_t)FRAME_HDR_BYTES);
-        gv.lpt_hist = (int32_t *)p; p += up(2 * 256 * sizeof(int32_t));
-        gv.lpt_list = (int32_t *)p; p += up(256 * NA * sizeof(int32_t));
+        gv.lpt_hist = (int32_t *)p; p += szHist;
+        for (int q = 0; q < PIPE_BUFS; ++q) {   // gv.rewards / done / true_objective stay the public arrays; the slot views write their own
+            GymView &v = g->gvp[q];
+            v = gv;
+            v.vis_prims = p; p += szVisP;
+            v.vis_rects = p; p += szVisR;
+            v.vis_count = (int32_t *)p; p += szVisC;
+            v.lpt_bucket = (int32_t *)p; p += up(NA * sizeof(int32_t));
+            v.lpt_order = (int32_t *)p; p += up((NA + 1) * sizeof(int32_t));
+            v.vis_hdr = p; p += up(NA * (size_t)FRAME_HDR_BYTES);
+            v.lpt_list = (int32_t *)p; p += up(256 * NA * sizeof(int32_t));
+            v.rewards = (float *)p; p += szRew;
+            v.done = p; p += szDone;
+            v.true_objective = (float *)p; p += szObjv;
+        }
     }
     if (const char *e = getenv("MV_PIXEL_MODE")) g->fastPixels = lower(e) == "exact" ? 0 : 1;
+    if (const char *e = getenv("MV_PIPELINE")) g->pipelined = atoi(e) != 0;
     g->obs = g->ownedObs;
     for (int b = 0; b < 2; ++b) {
         if (hipHostMalloc((void **)&g->hActions[b], NA * sizeof(int32_t), hipHostMallocDefault) != hipSuccess ||
@@ -390,6 +458,11 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     {   // status words (episodes consumed, error flags) travel back on a side stream for every scenario
         bool ok = hipHostMalloc((void **)&g->hStatus, (N + 2) * sizeof(int), hipHostMallocDefault) == hipSuccess &&
                   hipStreamCreateWithFlags(&g->copyStream, hipStreamNonBlocking) == hipSuccess &&
+                  hipStreamCreateWithFlags(&g->simStream, hipStreamNonBlocking) == hipSuccess &&
+                  hipEventCreateWithFlags(&g->userMark[0], hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&g->userMark[1], hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&g->userMark[2], hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&g->simDone, hipEventDisableTiming) == hipSuccess &&
                   hipEventCreateWithFlags(&g->resetDone, hipEventDisableTiming) == hipSuccess &&
                   hipEventCreateWithFlags(&g->stepDone, hipEventDisableTiming) == hipSuccess &&
                   hipEventCreateWithFlags(&g->statusCopied, hipEventDisableTiming) == hipSuccess;
@@ -447,7 +520,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     {
         std::vector<int32_t> iota(NA);
         for (size_t i = 0; i < NA; ++i) iota[i] = (int32_t)i;
-        (void)hipMemcpy(gv.lpt_order, iota.data(), NA * sizeof(int32_t), hipMemcpyHostToDevice);   // identity until the first frame sort
+        for (int q = 0; q < PIPE_BUFS; ++q) (void)hipMemcpy(g->gvp[q].lpt_order, iota.data(), NA * sizeof(int32_t), hipMemcpyHostToDevice);   // identity until the first frame sort
     }
     if (hipMemcpy(gv.hdr, hh.data(), N * sizeof(EnvHeader), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(gv.agents, ha.data(), NA * sizeof(AgentState), hipMemcpyHostToDevice) != hipSuccess) {
@@ -465,6 +538,7 @@ int mv_close(mv_gym *g)
     // order: nothing may still target the arena (episode uploads / status read-backs on the copy stream, kernels on the step
     // stream) or the pinned slots (feeder workers) when they are freed.  The step stream may be caller-owned and already gone:
     // its errors are ignored, the device-wide synchronise below covers whatever was enqueued on it.
+    if (g->simStream) (void)hipStreamSynchronize(g->simStream);
     (void)hipStreamSynchronize(g->stream);
     (void)hipGetLastError();
     if (g->copyStream) (void)hipStreamSynchronize(g->copyStream);
@@ -481,6 +555,10 @@ int mv_close(mv_gym *g)
     for (hipEvent_t e : g->uploadEvents) if (e) (void)hipEventDestroy(e);
     g->uploadEvents.clear();
     if (g->copyStream) (void)hipStreamDestroy(g->copyStream);
+    if (g->simStream) (void)hipStreamDestroy(g->simStream);
+    for (hipEvent_t &e : g->userMark) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    if (g->simDone) (void)hipEventDestroy(g->simDone);
+    g->simStream = nullptr; g->simDone = nullptr;
     g->hBlobs = nullptr; g->hStatus = nullptr; g->resetDone = g->stepDone = g->statusCopied = nullptr; g->copyStream = nullptr; g->dBlobs = nullptr; g->dStatus = nullptr;
     g->arena = nullptr;
     for (int b = 0; b < 2; ++b) {
@@ -509,8 +587,11 @@ int mv_num_agents(const mv_gym *g) { return g ? g->A : -1; }
 int mv_set_stream(mv_gym *g, void *s)
 {
     if (check(g)) return -1;
+    HIP_TRY(hipStreamSynchronize(g->simStream));
     HIP_TRY(hipStreamSynchronize(g->stream));
     g->stream = (hipStream_t)s;
+    g->simMustWaitUser = true;
+    g->markCount = 0;   // (the marks were recorded on the old stream)
     return 0;
 }
 
@@ -531,6 +612,16 @@ int mv_set_pixel_mode(mv_gym *g, int32_t mode)
 
 int mv_get_pixel_mode(const mv_gym *g) { return g ? g->fastPixels : -1; }
 
+int mv_set_pipelining(mv_gym *g, int32_t on)
+{
+    if (check(g)) return -1;
+    if (sim_join(g)) return -1;
+    g->pipelined = on != 0;
+    return 0;
+}
+
+int mv_get_pipelining(const mv_gym *g) { return g ? g->pipelined : -1; }
+
 int mv_seed(mv_gym *g, int32_t seed)
 {   // MegaverseGym::seed, megaverse.cpp:60-69: master rng -> one randRange(0, 1<<30) per env
     if (check(g)) return -1;
@@ -543,6 +634,7 @@ int mv_seed(mv_gym *g, int32_t seed)
         if (rel >= 0 && rel % g->envStride == 0 && rel / g->envStride < g->N) seeds[rel / g->envStride] = (uint32_t)noise;
     }
     if (g->hostEpisodes()) {   // Env::seed (env.cpp:52-55) on the host-side episode generators
+        HIP_TRY(hipStreamSynchronize(g->simStream));
         HIP_TRY(hipStreamSynchronize(g->stream));
         HIP_TRY(hipStreamSynchronize(g->copyStream));
         HIP_TRY(hipMemcpy(g->hStatus, g->dStatus, (size_t)(g->N + 2) * sizeof(int), hipMemcpyDeviceToHost));   // the current counts, not the last periodic read-back
@@ -561,6 +653,7 @@ int mv_seed(mv_gym *g, int32_t seed)
         g->feeder->reseed(seeds, first);
         return 0;
     }
+    if (sim_join(g)) return -1;
     uint32_t *d = nullptr;
     HIP_TRY(hipMalloc((void **)&d, g->N * sizeof(uint32_t)));
     HIP_TRY(hipMemcpyAsync(d, seeds.data(), g->N * sizeof(uint32_t), hipMemcpyHostToDevice, g->stream));
@@ -574,8 +667,9 @@ int mv_render(mv_gym *g)
 {
     if (check(g)) return -1;
     HIP_TRY(hipSetDevice(g->device));
-    g->gv.lpt_parity ^= 1;
-    if (launch_raster(g->gv, g->obs, g->w, g->h, g->stream, nullptr, g->fastPixels)) return fail("mv_render: observation size above 1024x1024");
+    if (sim_join(g)) return -1;
+    g->hist3 = (g->hist3 + 1) % LPT_HISTS;
+    if (launch_raster(view(g, g->parity), g->obs, g->w, g->h, g->stream, nullptr, g->fastPixels)) return fail("mv_render: observation size above 1024x1024");
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -600,7 +694,7 @@ static int check_status_flags(mv_gym *g)
     if (gen & GEN_COORDS) msg += "a generated level extends beyond +-127 voxels (int8 object coordinates); ";
     if (flags) {   // clear the device word (and the mirror) so that the next step runs
         g->hStatus[N + 1] = 0;
-        HIP_TRY(hipMemsetAsync(g->dStatus + N + 1, 0, sizeof(int), g->stream));
+        HIP_TRY(hipMemsetAsync(g->dStatus + N + 1, 0, sizeof(int), g->simOnOwnStream ? g->simStream : g->stream));
     }
     return fail("capacity limit hit: " + msg + "reported once, simulation continues");
 }
@@ -622,7 +716,7 @@ static int refill_episodes(mv_gym *g)
     const int N = g->N, K = g->spares;
     const bool starved = (g->hStatus[N + 1] & ST_STARVED) != 0;
     if (starved && g->hostEpisodes()) {   // recover: take the current counts and upload synchronously below
-        HIP_TRY(hipStreamSynchronize(g->stream));
+        HIP_TRY(hipStreamSynchronize(g->simStream));
         HIP_TRY(hipStreamSynchronize(g->copyStream));
         const int keep = g->hStatus[N + 1];
         HIP_TRY(hipMemcpy(g->hStatus, g->dStatus, (size_t)(N + 2) * sizeof(int), hipMemcpyDeviceToHost));
@@ -655,7 +749,8 @@ static int refill_episodes(mv_gym *g)
         if (!batch.empty()) {
             HIP_TRY(hipEventRecord(ev, g->copyStream));
             for (int i : batch) g->feeder->recycle(i, ev);   // regenerate a slot only once its upload has left it
-            HIP_TRY(hipStreamWaitEvent(g->stream, ev, 0));
+            HIP_TRY(hipStreamWaitEvent(g->pipelined ? g->simStream : g->stream, ev, 0));   // (mv_reset, and a step in the exact pixel mode, wait for lastUpload themselves)
+            g->lastUpload = ev;
         }
         g->deficit = deficit;
         g->lastTotalSeen = g->hStatus[N];
@@ -665,9 +760,9 @@ static int refill_episodes(mv_gym *g)
 }
 
 // after a step / reset kernel: read the status words back without touching the step path
-static int read_back_status(mv_gym *g)
+static int read_back_status(mv_gym *g, hipStream_t after)
 {
-    HIP_TRY(hipEventRecord(g->resetDone, g->stream));
+    HIP_TRY(hipEventRecord(g->resetDone, after));
     HIP_TRY(hipStreamWaitEvent(g->copyStream, g->resetDone, 0));
     HIP_TRY(hipMemcpyAsync(g->hStatus, g->dStatus, (size_t)(g->N + 2) * sizeof(int), hipMemcpyDeviceToHost, g->copyStream));
     HIP_TRY(hipEventRecord(g->statusCopied, g->copyStream));
@@ -679,9 +774,11 @@ int mv_reset(mv_gym *g)
 {   // MegaverseGym::reset (megaverse.cpp:76-93) -> VectorEnv::reset (vector_env.cpp:110-120)
     if (check(g)) return -1;
     HIP_TRY(hipSetDevice(g->device));
+    if (sim_join(g)) return -1;
     if (g->hostEpisodes()) {
         // the periodic status read-back may be up to 15 ticks old: an env that auto-reset since then has consumed its
         // resident episode without the host knowing -- take the current counts before deciding what to upload
+        HIP_TRY(hipStreamSynchronize(g->simStream));
         HIP_TRY(hipStreamSynchronize(g->stream));
         HIP_TRY(hipStreamSynchronize(g->copyStream));
         HIP_TRY(hipMemcpy(g->hStatus, g->dStatus, (size_t)(g->N + 2) * sizeof(int), hipMemcpyDeviceToHost));
@@ -689,16 +786,18 @@ int mv_reset(mv_gym *g)
         g->stepsSinceStatus = 0;
         g->refillForce = true;
         if (refill_episodes(g)) return -1;              // every env has an unconsumed episode resident
-        if (g->scenario == SCN_OBSTACLES || g->scenario == SCN_EMPTY) launch_reset_obstacles(g->gv, (const EpisodeBlob *)g->dBlobs, g->dStatus, 1, g->stream);
-        else if (g->scenario == SCN_REARRANGE) launch_reset_rearrange(g->gv, (const RearrangeBlob *)g->dBlobs, g->dStatus, 1, g->stream);
-        else if (g->scenario == SCN_SOKOBAN) launch_reset_sokoban(g->gv, (const SokobanBlob *)g->dBlobs, g->dStatus, 1, g->stream);
-        else if (g->scenario == SCN_HEX_MEMORY || g->scenario == SCN_HEX_EXPLORE) launch_reset_hex(g->gv, (const HexBlob *)g->dBlobs, g->dStatus, 1, g->stream);
-        else launch_reset_collect(g->gv, (const CollectBlob *)g->dBlobs, g->dStatus, 1, g->stream);
+        if (g->lastUpload) HIP_TRY(hipStreamWaitEvent(g->stream, g->lastUpload, 0));
+        const GymView v = view(g, g->parity, true);
+        if (g->scenario == SCN_OBSTACLES || g->scenario == SCN_EMPTY) launch_reset_obstacles(v, (const EpisodeBlob *)g->dBlobs, g->dStatus, 1, g->stream);
+        else if (g->scenario == SCN_REARRANGE) launch_reset_rearrange(v, (const RearrangeBlob *)g->dBlobs, g->dStatus, 1, g->stream);
+        else if (g->scenario == SCN_SOKOBAN) launch_reset_sokoban(v, (const SokobanBlob *)g->dBlobs, g->dStatus, 1, g->stream);
+        else if (g->scenario == SCN_HEX_MEMORY || g->scenario == SCN_HEX_EXPLORE) launch_reset_hex(v, (const HexBlob *)g->dBlobs, g->dStatus, 1, g->stream);
+        else launch_reset_collect(v, (const CollectBlob *)g->dBlobs, g->dStatus, 1, g->stream);
         HIP_TRY(hipEventRecord(g->stepDone, g->stream));   // (the reset kernel reads the ring too)
         g->stepDoneValid = true;
-        if (read_back_status(g)) return -1;             // the second resident episodes go up with the next steps
+        if (read_back_status(g, g->stream)) return -1;  // the second resident episodes go up with the next steps
     } else
-        launch_reset(g->gv, 1, g->stream);
+        launch_reset(view(g, g->parity, true), 1, g->stream);
     HIP_TRY(hipGetLastError());
     g->wasReset = true;
     g->mirrorsFresh = false;
@@ -728,6 +827,7 @@ int mv_set_actions_batched(mv_gym *g, const int32_t *host_actions)
     hipLaunchKernelGGL(masks_from_multidiscrete_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, g->dMultiDiscrete, g->gv.actions, n);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(g->stream));   // host_actions may be pageable and reused by the caller
+    g->simMustWaitUser = true;
     return 0;
 }
 
@@ -738,6 +838,7 @@ int mv_set_actions_device(mv_gym *g, const int32_t *device_actions)
     const int n = g->N * g->A;
     hipLaunchKernelGGL(masks_from_multidiscrete_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, device_actions, g->gv.actions, n);
     HIP_TRY(hipGetLastError());
+    g->simMustWaitUser = true;   // the actions come from the caller's stream (a policy that read the last observations): a true dependency
     return 0;
 }
 
@@ -756,10 +857,31 @@ static int step_impl(mv_gym *g, bool render)
     if (!g->wasReset) return fail("mv_step: call mv_reset first");
     HIP_TRY(hipSetDevice(g->device));
     if (refill_episodes(g)) return -1;
+    // ---- what this step must wait for on the caller's stream.  Always: whatever was there when the step PIPE_BUFS - 1 calls ago began --
+    // the observation pass and the consumers of the step that used this slot's buffers last.  Everything, when the caller's stream
+    // feeds the simulation (reset / render / device actions / test hooks since the last step) or when the observation pass reads
+    // simulator state itself (the exact raster kernel takes the cameras from the agent records).
+    // Not pipelined (mv_set_pipelining(0), or the exact pixel mode): the step runs on the caller's stream like everything else -- a hand-over
+    // between two hardware queues costs ~10 us each way, which only pays when something overlaps.
+    const bool own = g->pipelined && !(render && !g->fastPixels);
+    hipStream_t sim = own ? g->simStream : g->stream;
+    if (own) {
+        hipEvent_t mark = g->userMark[g->markCount % PIPE_BUFS];
+        HIP_TRY(hipEventRecord(mark, g->stream));
+        if (g->simMustWaitUser) HIP_TRY(hipStreamWaitEvent(sim, mark, 0));
+        else if (g->markCount >= PIPE_BUFS - 1) HIP_TRY(hipStreamWaitEvent(sim, g->userMark[(g->markCount - (PIPE_BUFS - 1)) % PIPE_BUFS], 0));
+        ++g->markCount;
+    } else {
+        if (g->simOnOwnStream && g->simDoneValid) HIP_TRY(hipStreamWaitEvent(sim, g->simDone, 0));   // the last step ran on the other stream
+        g->markCount = 0;
+    }
+    g->simMustWaitUser = false;
+    g->simOnOwnStream = own;
+    if (!own && g->pipelined && g->lastUpload) HIP_TRY(hipStreamWaitEvent(sim, g->lastUpload, 0));
     if (g->actionsDirty) {
         const int s = g->stage;
-        HIP_TRY(hipMemcpyAsync(g->gv.actions, g->hActions[s], (size_t)g->N * g->A * sizeof(int32_t), hipMemcpyHostToDevice, g->stream));
-        HIP_TRY(hipEventRecord(g->actionsCopied[s], g->stream));
+        HIP_TRY(hipMemcpyAsync(g->gv.actions, g->hActions[s], (size_t)g->N * g->A * sizeof(int32_t), hipMemcpyHostToDevice, sim));
+        HIP_TRY(hipEventRecord(g->actionsCopied[s], sim));
         g->stage = 1 - s;
         HIP_TRY(hipEventSynchronize(g->actionsCopied[g->stage]));   // long done: recorded one step ago
         std::memset(g->hActions[g->stage], 0, (size_t)g->N * g->A * sizeof(int32_t));   // actions are cleared every tick (env.cpp:141-142)
@@ -769,26 +891,33 @@ static int step_impl(mv_gym *g, bool render)
     g->samplePending = false;
     const bool prof = render && g->profCount < g->profMax;
     hipEvent_t *ev = prof ? &g->profEvents[(size_t)g->profCount * 5] : nullptr;
-    if (prof) HIP_TRY(hipEventRecord(ev[0], g->stream));
+    if (prof) HIP_TRY(hipEventRecord(ev[0], sim));
     const int fused = render ? 1 : 0;   // the step kernel also builds the frame lists when an observation pass follows
-    if (render) g->gv.lpt_parity ^= 1;  // (this pass's frame setup fills the other cost histogram)
-    if (g->scenario == SCN_OBSTACLES || g->scenario == SCN_EMPTY) launch_step_obstacles(g->gv, g->stream, g->w, g->h, fused);
-    else if (g->scenario == SCN_COLLECT) launch_step_collect(g->gv, g->stream, g->w, g->h, fused);
-    else if (g->scenario == SCN_REARRANGE) launch_step_rearrange(g->gv, g->stream, g->w, g->h, fused);
-    else if (g->scenario == SCN_SOKOBAN) launch_step_sokoban(g->gv, g->stream, g->w, g->h, fused);
-    else if (g->scenario == SCN_HEX_MEMORY || g->scenario == SCN_HEX_EXPLORE) launch_step_hex(g->gv, g->stream, g->w, g->h, fused);
-    else launch_step(g->gv, g->stream, g->w, g->h, fused);
-    if (prof) HIP_TRY(hipEventRecord(ev[1], g->stream));
+    g->parity = (g->parity + 1) % PIPE_BUFS;
+    if (render) g->hist3 = (g->hist3 + 1) % LPT_HISTS;   // (this pass's frame setup fills the next cost histogram and clears the one after)
+    const GymView v = view(g, g->parity, !own);
+    if (g->scenario == SCN_OBSTACLES || g->scenario == SCN_EMPTY) launch_step_obstacles(v, sim, g->w, g->h, fused);
+    else if (g->scenario == SCN_COLLECT) launch_step_collect(v, sim, g->w, g->h, fused);
+    else if (g->scenario == SCN_REARRANGE) launch_step_rearrange(v, sim, g->w, g->h, fused);
+    else if (g->scenario == SCN_SOKOBAN) launch_step_sokoban(v, sim, g->w, g->h, fused);
+    else if (g->scenario == SCN_HEX_MEMORY || g->scenario == SCN_HEX_EXPLORE) launch_step_hex(v, sim, g->w, g->h, fused);
+    else launch_step(v, sim, g->w, g->h, fused);
+    if (prof) HIP_TRY(hipEventRecord(ev[1], sim));
+    if (own) { HIP_TRY(hipEventRecord(g->simDone, sim)); g->simDoneValid = true; }   // (not pipelined: stream order does it)
     // (every step kernel regenerates / swaps the next episode into the envs it finishes)
     // An env needs a fresh resident episode only at its NEXT reset, normally hundreds of steps away, and two are resident: the status
     // words are read back -- and the refill considered -- every statusPeriod-th step (16; 1 when episodes can be a few ticks long).
-    if (g->hostEpisodes()) { HIP_TRY(hipEventRecord(g->stepDone, g->stream)); g->stepDoneValid = true; }
+    if (g->hostEpisodes()) { HIP_TRY(hipEventRecord(g->stepDone, sim)); g->stepDoneValid = true; }
     if (++g->stepsSinceStatus >= g->statusPeriod) {   // (TowerBuilding regenerates finished envs in the kernel: only the error flags matter)
-        if (read_back_status(g)) return -1;
+        if (read_back_status(g, sim)) return -1;
         g->stepsSinceStatus = 0;
     }
-    if (prof) HIP_TRY(hipEventRecord(ev[2], g->stream));
-    if (render && launch_raster(g->gv, g->obs, g->w, g->h, g->stream, prof ? ev[3] : nullptr, g->fastPixels, /*setup_done=*/1)) return fail("mv_step: observation size above 1024x1024");
+    if (prof) HIP_TRY(hipEventRecord(ev[2], sim));
+    // ---- the caller's stream: the step's outputs, then the observation pass
+    if (own) HIP_TRY(hipStreamWaitEvent(g->stream, g->simDone, 0));
+    const PublishTo pub{g->gv.rewards, g->gv.done, g->gv.true_objective};
+    if (own && !render && publish_outputs(g, g->parity)) return -1;   // (with an observation pass, its first workgroups publish)
+    if (render && launch_raster(v, g->obs, g->w, g->h, g->stream, prof ? ev[3] : nullptr, g->fastPixels, /*setup_done=*/1, own ? &pub : nullptr)) return fail("mv_step: observation size above 1024x1024");
     if (prof) { HIP_TRY(hipEventRecord(ev[4], g->stream)); ++g->profCount; }
     HIP_TRY(hipGetLastError());
     g->mirrorsFresh = false;
@@ -801,6 +930,7 @@ int mv_step_no_render(mv_gym *g) { return step_impl(g, false); }
 int mv_synchronize(mv_gym *g)
 {
     if (check(g)) return -1;
+    HIP_TRY(hipStreamSynchronize(g->simStream));
     HIP_TRY(hipStreamSynchronize(g->stream));
     return 0;
 }
@@ -823,6 +953,7 @@ int mv_profile_begin(mv_gym *g, int32_t max_steps)
 int mv_profile_end(mv_gym *g, float *avg_ms4, int32_t *counts4)
 {
     if (check(g)) return -1;
+    HIP_TRY(hipStreamSynchronize(g->simStream));
     HIP_TRY(hipStreamSynchronize(g->stream));
     double sum[4] = {0, 0, 0, 0};
     for (int i = 0; i < g->profCount; ++i)
@@ -910,8 +1041,9 @@ int mv_draw_hires(mv_gym *g)
         HIP_TRY(hipMalloc((void **)&g->hiresObs, (size_t)g->N * g->A * g->renderW * g->renderH * 4));
         g->hiresW = g->renderW; g->hiresH = g->renderH;
     }
-    g->gv.lpt_parity ^= 1;
-    if (launch_raster(g->gv, g->hiresObs, g->hiresW, g->hiresH, g->stream, nullptr, g->fastPixels)) return fail("mv_draw_hires: render size above 1024x1024");
+    if (sim_join(g)) return -1;
+    g->hist3 = (g->hist3 + 1) % LPT_HISTS;
+    if (launch_raster(view(g, g->parity), g->hiresObs, g->hiresW, g->hiresH, g->stream, nullptr, g->fastPixels)) return fail("mv_draw_hires: render size above 1024x1024");
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -945,6 +1077,7 @@ int mv_get_reward_shaping(mv_gym *g, int32_t env, int32_t agent, const char *key
     const int k = shaping_index(g, key);
     if (k < 0) return fail(std::string("unknown reward shaping key ") + key);
     if (env < 0 || env >= g->N || agent < 0 || agent >= g->A) return fail("mv_get_reward_shaping: index out of range");
+    if (sim_join(g)) return -1;
     HIP_TRY(hipMemcpyAsync(out, &g->gv.agents[(size_t)env * g->A + agent].shaping[k], sizeof(float), hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
     return 0;
@@ -956,6 +1089,7 @@ int mv_set_reward_shaping(mv_gym *g, int32_t env, int32_t agent, const char *key
     const int k = shaping_index(g, key);
     if (k < 0) return fail(std::string("unknown reward shaping key ") + key);
     if (env < 0 || env >= g->N || agent < 0 || agent >= g->A) return fail("mv_set_reward_shaping: index out of range");
+    if (sim_join(g)) return -1;
     hipLaunchKernelGGL(set_shaping_kernel, dim3(1), dim3(1), 0, g->stream, g->gv.agents, env * g->A + agent, k, v);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -991,6 +1125,7 @@ int mv_debug_set_agent_pos(mv_gym *g, int32_t env, int32_t agent, float x, float
 {
     if (check(g)) return -1;
     if (env < 0 || env >= g->N || agent < 0 || agent >= g->A) return fail("mv_debug_set_agent_pos: index out of range");
+    if (sim_join(g)) return -1;
     hipLaunchKernelGGL(set_agent_pos_kernel, dim3(1), dim3(1), 0, g->stream, g->gv.agents, env * g->A + agent, x, y, z);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1002,6 +1137,7 @@ int mv_debug_snapshot(mv_gym *g, int32_t env, void *out)
 {
     if (check(g)) return -1;
     if (env < 0 || env >= g->N) return fail("mv_debug_snapshot: index out of range");
+    HIP_TRY(hipStreamSynchronize(g->simStream));
     HIP_TRY(hipStreamSynchronize(g->stream));
     EnvHeader h;
     std::vector<LayoutBox> boxes(g->gv.box_stride);

@@ -10,6 +10,10 @@ namespace mv {
 // recorded between the setup/sort kernels and the raster kernel; -1 if W/H are too large.  fast = 1: raster_fast_kernel
 // setup_done = 1: the frame lists were built by the step kernel (mv_frame.h), only the frame sort and the raster are launched.
 // (approximate reciprocals, persistent grid; pixels within the tolerance DESIGN.md states), 0: the bit-exact raster_kernel
-int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream, hipEvent_t between = nullptr, int fast = 1, int setup_done = 0);
+// publish (fast kernel only): the step's staged rewards / dones / true objectives (gv.rewards ...) are copied into these public arrays by the
+// first workgroups of the raster launch -- ordered, on `stream`, with the observations (pipelined steps, mv_api.hip)
+struct PublishTo { float *rewards; uint8_t *done; float *true_objective; };
+int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream, hipEvent_t between = nullptr, int fast = 1, int setup_done = 0,
+                  const PublishTo *publish = nullptr);
 
 }  // namespace mv

@@ -554,7 +554,25 @@ struct FastArgs {   // what raster_fast_kernel needs of the GymView (fewer live 
     const short4 *vis_rects;
     const int *hist, *list;   // this pass's cost histogram [256] and the per-bin frame lists [256][frames] (mv_frame.h)
     int num_agents, vis_stride, frames;
+    // pipelined steps: the step's staged outputs -> the public arrays, by the first ceil(pub_n / 256) workgroups (pub_n = 0: nothing to publish)
+    const float *stage_rewards, *stage_true;
+    const uint8_t *stage_done;
+    float *pub_rewards, *pub_true;
+    uint8_t *pub_done;
+    int pub_n;
 };
+
+// true_objective is only ever recorded by a finishing env (vector_env.cpp:96-101): the others keep the value of their last episode
+__device__ __forceinline__ void fast_publish(const FastArgs &fa)
+{
+    if (fa.pub_n == 0) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= fa.pub_n) return;
+    fa.pub_rewards[i] = fa.stage_rewards[i];
+    const int e = i / fa.num_agents;
+    if (fa.stage_done[e]) fa.pub_true[i] = fa.stage_true[i];
+    if (i < fa.pub_n / fa.num_agents) fa.pub_done[i] = fa.stage_done[i];
+}
 
 // a wave-uniform 64-bit value that came through LDS, back into SGPRs (so that loops over its bits are scalar loops)
 __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)
@@ -826,6 +844,7 @@ __global__ __launch_bounds__(256, WAVES) void raster_fast_kernel(FastArgs fa, ui
     float *s_colq = reinterpret_cast<float *>(s_rowq + H);    // dc.x^2   (last: keeps every table naturally aligned for odd W)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    fast_publish(fa);
     const FastFrame ff = fast_prologue<MAXVIS>(fa, W, H, split, s_vis, s_rect, s_hdr, s_col, s_row, s_rowq, s_colq);
     const int frame = ff.frame, part = ff.part, viewer = ff.viewer, nVis = ff.nVis;
 
@@ -928,7 +947,7 @@ __global__ __launch_bounds__(256, WAVES) void raster_fast_kernel(FastArgs fa, ui
     }
 }
 
-int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream, hipEvent_t between, int fast, int setup_done)
+int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream, hipEvent_t between, int fast, int setup_done, const PublishTo *publish)
 {
     if (W > MAX_W || H > MAX_H) return -1;
     static const int envSplit = getenv("MV_RASTER_SPLIT") ? atoi(getenv("MV_RASTER_SPLIT")) : 0;
@@ -948,6 +967,9 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
         FastArgs fa;
         fa.vis_hdr = gv.vis_hdr; fa.vis_prims = reinterpret_cast<const Prim *>(gv.vis_prims); fa.vis_rects = reinterpret_cast<const short4 *>(gv.vis_rects);
         fa.hist = gv.lpt_hist + gv.lpt_parity * LPT_BUCKETS; fa.list = gv.lpt_list; fa.num_agents = gv.num_agents; fa.vis_stride = gv.vis_stride; fa.frames = frames;
+        fa.stage_rewards = gv.rewards; fa.stage_true = gv.true_objective; fa.stage_done = gv.done;
+        fa.pub_rewards = publish ? publish->rewards : nullptr; fa.pub_true = publish ? publish->true_objective : nullptr; fa.pub_done = publish ? publish->done : nullptr;
+        fa.pub_n = publish ? frames : 0;
         // (Collect, measured and rejected: a 1024-entry launch for the frames above 256 visible primitives + a 256-entry launch for the rest,
         // 75 + 69 us against 107 us for the single 1024-entry launch: each launch pays its own tail, and the cones, not occupancy, dominate)
         const bool hexScen = gv.scenario == SCN_HEX_MEMORY || gv.scenario == SCN_HEX_EXPLORE;

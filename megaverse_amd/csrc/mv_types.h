@@ -22,7 +22,10 @@ enum : int {
     MAX_CAMS = MAX_AGENTS + HEX_FRAMES,   // frames of reference a box can live in besides the world: agent cameras, hex wall orientations
 };
 
-enum : int { FRAME_HDR_BYTES = 1024 };   // per-frame header of the observation pass (mv_raster.hip: FH_*)
+enum : int { FRAME_HDR_BYTES = 1024 };
+// Pipelining depth (mv_api.hip): a step's hand-over buffers -- frame lists, headers, cost lists, reward / done staging -- exist PIPE_BUFS times,
+// so that the step kernels may run up to PIPE_BUFS - 1 ticks ahead of the observation pass; cost histograms: one more (a pass clears the next)
+enum : int { PIPE_BUFS = 3, LPT_HISTS = PIPE_BUFS + 1 };   // per-frame header of the observation pass (mv_raster.hip: FH_*)
 
 // error flags a kernel raises in episode_status[N + 1]; mv_step reports them (mv_api.hip: check_status_flags)
 enum : int { ST_STARVED = 1, ST_CANDIDATES = 2, ST_VISIBLE = 4, ST_CHUNK = 8 };
@@ -144,9 +147,9 @@ struct GymView {
     int32_t vis_stride;        // 256, or 1024 for Collect
     int32_t *lpt_bucket;       // [N*A] cost bin of every frame (raster scheduling)
     int32_t *lpt_order;        // [N*A] frames sorted by cost bin, most expensive first (exact raster kernel)
-    int32_t *lpt_hist;         // [2][256] frames per cost bin, one histogram per pass parity (fast raster kernel)
+    int32_t *lpt_hist;         // [LPT_HISTS][256] frames per cost bin, rotating over the passes (fast raster kernel)
     int32_t *lpt_list;         // [256][N*A] the frames of every bin in arrival order
-    int32_t lpt_parity;        // which histogram this observation pass uses
+    int32_t lpt_parity;        // which of the histograms this observation pass uses
     uint8_t *vis_hdr;          // [N*A][FRAME_HDR_BYTES] per-frame header for raster_fast_kernel (cameras, light vectors, masks, count)
 };
 

@@ -51,6 +51,7 @@ SYMBOLS = [
     ("mv_set_reward_shaping", C.c_int, [_P, _I, _I, C.c_char_p, _F]),
     ("mv_synchronize", C.c_int, [_P]),
     ("mv_profile_begin", C.c_int, [_P, _I]), ("mv_profile_end", C.c_int, [_P, _P, _P]),
+    ("mv_set_pipelining", C.c_int, [_P, _I]), ("mv_get_pipelining", C.c_int, [_P]),
     ("mv_debug_set_agent_pos", C.c_int, [_P, _I, _I, _F, _F, _F]),
     ("mv_debug_snapshot_size", C.c_int, [_P]), ("mv_debug_snapshot", C.c_int, [_P, _I, _P]),
     ("mv_debug_rng", C.c_int, [_I, _U, _I, _P, _P, _I, _P]),
@@ -262,6 +263,13 @@ class MegaverseGym:
 
     def pixel_mode(self):
         return "fast" if self._lib.mv_get_pixel_mode(self._g) == 1 else "exact"
+
+    def set_pipelining(self, on):
+        """one-step-ahead pipelining of the step kernels against the observation pass (include/megaverse_hip.h); on by default"""
+        self._ck(self._lib.mv_set_pipelining(self._g, 1 if on else 0))
+
+    def pipelining(self):
+        return self._lib.mv_get_pipelining(self._g) == 1
 
     def set_stream(self, hip_stream):
         self._ck(self._lib.mv_set_stream(self._g, _P(int(hip_stream))))

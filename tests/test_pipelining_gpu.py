@@ -1,0 +1,103 @@
+"""One-step-ahead pipelining: the step kernels run on an internal stream and step t + 1 may overlap the observation pass
+of step t.  These tests drive the gym OPEN LOOP -- device-sampled actions, no host synchronisation between steps -- so that the overlap
+really happens, and check that nothing observable changed: the simulation is bit-identical to the oracle's, and what a consumer
+enqueued on the caller's stream between two steps reads (rewards, dones, true objectives, observations) is exactly step t's output."""
+import numpy as np
+import pytest
+
+import oracle_lib
+from hip_util import diff_snapshots, hip_snapshot
+from megaverse_amd.extension import MegaverseGym
+from megaverse_amd.rollout import action_masks, sample_actions
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
+
+
+class DevArr:
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def oracle_step(og, N, A, seed, st, render=False):
+    masks = action_masks(sample_actions(seed, st, N * A))
+    for e in range(N):
+        for a in range(A):
+            og.set_action_mask(e, a, int(masks[e * A + a]))
+    og.step() if render else og.step_norender()
+
+
+@pytest.mark.parametrize("scenario,A,params", [("TowerBuilding", 2, {"episodeLengthSec": -220.0}), ("Rearrange", 1, {"episodeLengthSec": 2.0}),
+                                              ("Collect", 3, {"episodeLengthSec": 5.0}), ("HexMemory", 2, {"episodeLengthSec": 3.0})])
+def test_open_loop_rollout_equals_the_oracle(hip, scenario, A, params):
+    """400 steps without a host sync, short episodes (auto-resets, refills from the feeder) -- then state, last outputs and pixels"""
+    import torch
+    N, W, H, STEPS = 12, 48, 32, 400
+    og = oracle_lib.OracleGym(scenario, W, H, N, A, 1, False, params)
+    hg = MegaverseGym(scenario, W, H, N, A, 2, False, params)
+    hg.set_pixel_mode("fast")
+    og.seed(5); hg.seed(5); og.reset(); hg.reset()
+    for st in range(STEPS):
+        hg.sample_random_actions(77, st)
+        hg.step()
+    for st in range(STEPS):
+        oracle_step(og, N, A, 77, st, render=(st == STEPS - 1))
+    hg.synchronize()
+    for e in range(N):
+        d = diff_snapshots(og.snapshot(e), hip_snapshot(hg, e), A)
+        assert not d, (e, d[:5])
+    assert og.get_last_rewards().tobytes() == hg.get_rewards_array().tobytes()
+    assert np.array_equal(np.array([og.is_done(e) for e in range(N)]), hg.get_dones().astype(bool))
+    fo = np.stack([og.get_observation(e, a) for e in range(N) for a in range(A)])
+    fh = np.stack([hg.get_observation(e, a) for e in range(N) for a in range(A)])
+    diff = np.abs(fo.astype(np.int16) - fh.astype(np.int16)).max(axis=-1)
+    assert (diff > 1).sum() <= max(2, 1e-4 * diff.size) and (diff > 0).sum() <= max(4, 5e-4 * diff.size)
+    og.close(); hg.close()
+
+
+def test_consumers_on_the_callers_stream_see_step_t_while_step_t_plus_1_runs(hip):
+    """every step: enqueue copies of the device-side rewards / dones / true objectives / observations on the caller's stream, step again
+    at once; afterwards every copy must be that step's value (rewards / dones bit-exact against the oracle, observations against a
+    synchronous replay of the same gym)"""
+    import torch
+    scenario, N, A, W, H, STEPS = "TowerBuilding", 64, 2, 64, 64, 150
+    params = {"episodeLengthSec": -220.0}   # TowerBuilding adds time per object: a few seconds in all
+
+    def replay(sync_every_step):
+        hg = MegaverseGym(scenario, W, H, N, A, 2, False, params)
+        hg.set_pixel_mode("fast")
+        stream = torch.cuda.Stream()
+        hg.set_stream(stream.cuda_stream)
+        hg.seed(9); hg.reset()
+        rew = torch.as_tensor(DevArr(hg.rewards_device_ptr(), (N * A,), "<f4"), device="cuda:0")
+        done = torch.as_tensor(DevArr(hg.dones_device_ptr(), (N,), "|u1"), device="cuda:0")
+        tru = torch.as_tensor(DevArr(hg.true_objectives_device_ptr(), (N * A,), "<f4"), device="cuda:0")
+        obs = torch.as_tensor(DevArr(hg.obs_device_ptr(), (N * A, H, W, 4), "|u1"), device="cuda:0")
+        out = []
+        with torch.cuda.stream(stream):
+            for st in range(STEPS):
+                hg.sample_random_actions(31, st)
+                hg.step()
+                out.append((rew.clone(), done.clone(), tru.clone(), obs.sum(dtype=torch.int64), obs[st % (N * A)].clone()))
+                if sync_every_step:
+                    hg.synchronize()
+        hg.synchronize(); torch.cuda.synchronize()
+        res = [tuple(t.cpu().numpy() for t in o) for o in out]
+        hg.close()
+        return res
+
+    piped, serial = replay(False), replay(True)
+    og = oracle_lib.OracleGym(scenario, W, H, N, A, 1, False, params)
+    og.seed(9); og.reset()
+    dones = 0
+    for st in range(STEPS):
+        oracle_step(og, N, A, 31, st)
+        r, d, t, osum, oframe = piped[st]
+        assert og.get_last_rewards().tobytes() == r.tobytes(), st
+        do = np.array([og.is_done(e) for e in range(N)])
+        assert np.array_equal(do, d.astype(bool)), st
+        dones += int(do.sum())
+        want_t = np.array([og.true_objective(e, a) for e in range(N) for a in range(A)], np.float32)
+        assert want_t.tobytes() == t.tobytes(), st
+        assert int(osum) == int(serial[st][3]) and np.array_equal(oframe, serial[st][4]), st
+    assert dones > N          # auto-resets happened while pipelined
+    og.close()
