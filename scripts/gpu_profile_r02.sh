@@ -1,5 +1,6 @@
 #!/bin/bash
 # Round-2 profile pass on the GPU box (via gpurun): gpu_profile_r02.sh <tag>
+#   (r02b: + HexMemory / HexExplore / Empty, the unpipelined headline, smoke())
 #   headline (TowerBuilding 1024x1 128x128): bench line (2000 steps) + rocprofv3 kernel stats + PMC passes (FETCH_SIZE, WRITE_SIZE, SQ, SQ2: separate runs)
 #   Collect 1024x1: bench + kernel stats + FETCH/WRITE/SQ passes;  other configs: bench + kernel stats
 # Summaries (CSV, from the rocpd databases with scripts/rocpd_summary.py) land in gpurun_out/<tag>/ and are copied into profiles/ by hand.
@@ -38,6 +39,15 @@ prof obstacles_hard_512 --scenario ObstaclesHard --envs-per-gpu 512
 prof tower_512x4 --agents 4 --envs-per-gpu 512
 prof rearrange --scenario Rearrange
 prof sokoban --scenario Sokoban
+prof hexmemory --scenario HexMemory
+prof hexexplore --scenario HexExplore
+cd $R; timeout 300 python bench.py --scenario Empty --no-cpu-baseline > $OUT/empty_bench.json 2> $OUT/empty_bench.err
+timeout 300 python bench.py --scenario Empty --envs-per-gpu 64 --obs 128 72 --no-cpu-baseline > $OUT/empty_64x128x72_bench.json 2> $OUT/empty_64_bench.err
+timeout 300 python bench.py --scenario Collect --envs-per-gpu 64 --obs 128 72 --no-cpu-baseline > $OUT/collect_64x128x72_bench.json 2> $OUT/collect_64_bench.err
+MV_PIPELINE=0 timeout 300 python bench.py --no-cpu-baseline > $OUT/tower_unpipelined_bench.json 2> $OUT/tower_unpipelined_bench.err
+cd /tmp; MV_PIPELINE=0 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/db_tower_unpipelined_stats -o run -- python $R/bench.py --steps 400 --warmup 50 --no-cpu-baseline --profile-steps 0 > $OUT/tower_unpipelined_stats.log 2>&1
+python $R/scripts/rocpd_summary.py $OUT/db_tower_unpipelined_stats/run_results.db > $OUT/tower_unpipelined_kernel_stats.csv 2>> $OUT/tower_unpipelined_stats.log
+cd $R; (timeout 900 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?" >> $OUT/smoke.log)
 cd $R; timeout 300 python bench.py --scenario Mixed --obs 64 64 --no-cpu-baseline > $OUT/mixed_64_bench.json 2> $OUT/mixed_64_bench.err
 timeout 300 python bench.py --envs-per-gpu 4096 --no-cpu-baseline > $OUT/tower_4096_bench.json 2> $OUT/tower_4096_bench.err
 timeout 300 python bench.py --obs 128 72 --no-cpu-baseline > $OUT/tower_128x72_bench.json 2> $OUT/tower_128x72_bench.err
