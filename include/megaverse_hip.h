@@ -66,6 +66,9 @@ int mv_set_actions_device(mv_gym *g, const int32_t *device_actions);
 /* benchmark policy: i.i.d. uniform per head, counter-based (seed, step, agent, head) -> action;
  * same stream as megaverse_amd.rollout.sample_actions() on the host */
 int mv_sample_random_actions(mv_gym *g, uint32_t seed, uint32_t step_index);
+/* step several gyms of one job with one call (no reference counterpart: its multi-task runs are separate processes,
+ * the scripts under megaverse_rl/runs): for each gym, optionally mv_sample_random_actions(seed, step_index), then mv_step / mv_step_no_render */
+int mv_step_many(mv_gym *const *gyms, int32_t n, int32_t render, int32_t sample, uint32_t seed, uint32_t step_index);
 
 int mv_step(mv_gym *g);                             /* step(), :118-121: VectorEnv::step incl. auto-reset + render */
 int mv_step_no_render(mv_gym *g);                   /* physics/logic/auto-reset only */

@@ -134,6 +134,7 @@ struct mv_gym {
     int *dStatus = nullptr, *hStatus = nullptr;     // [N + 2]: consumed per env, total, error flags (device, pinned mirror)
     int lastTotalSeen = 0;
     bool statusPending = false, refillForce = true;
+    int pendingAge = 0;                             // steps since the pending read-back was first looked for
     int stepsSinceStatus = 0;
     int spares = 2;                                 // resident episodes per env (ring); the host keeps uploaded <= consumed + spares
     int statusPeriod = 16;                          // steps between status read-backs (1 when episodes can be only a few ticks long)
@@ -639,6 +640,7 @@ int mv_seed(mv_gym *g, int32_t seed)
         HIP_TRY(hipStreamSynchronize(g->copyStream));
         HIP_TRY(hipMemcpy(g->hStatus, g->dStatus, (size_t)(g->N + 2) * sizeof(int), hipMemcpyDeviceToHost));   // the current counts, not the last periodic read-back
         g->statusPending = false;
+        g->pendingAge = 0;
         g->stepsSinceStatus = 0;
         std::vector<int> first(g->N);
         for (int i = 0; i < g->N; ++i) {
@@ -710,8 +712,17 @@ static int check_status_flags(mv_gym *g)
 static int refill_episodes(mv_gym *g)
 {
     if (g->statusPending) {
+        // The read-back was enqueued behind a step kernel the host is normally several ticks ahead of: waiting for it here would drain
+        // that run-ahead every statusPeriod steps.  With long episodes (period 16, two resident episodes per env) the words may arrive a few
+        // steps later: look again at the next step, but never let them age beyond 32 steps.
+        if (g->statusPeriod > 1 && g->pendingAge < 32 && hipEventQuery(g->statusCopied) == hipErrorNotReady) {
+            ++g->pendingAge;
+            return 0;
+        }
+        (void)hipGetLastError();
         HIP_TRY(hipEventSynchronize(g->statusCopied));
         g->statusPending = false;
+        g->pendingAge = 0;
     }
     const int N = g->N, K = g->spares;
     const bool starved = (g->hStatus[N + 1] & ST_STARVED) != 0;
@@ -783,6 +794,7 @@ int mv_reset(mv_gym *g)
         HIP_TRY(hipStreamSynchronize(g->copyStream));
         HIP_TRY(hipMemcpy(g->hStatus, g->dStatus, (size_t)(g->N + 2) * sizeof(int), hipMemcpyDeviceToHost));
         g->statusPending = false;
+        g->pendingAge = 0;
         g->stepsSinceStatus = 0;
         g->refillForce = true;
         if (refill_episodes(g)) return -1;              // every env has an unconsumed episode resident
@@ -926,6 +938,17 @@ static int step_impl(mv_gym *g, bool render)
 
 int mv_step(mv_gym *g) { return step_impl(g, true); }
 int mv_step_no_render(mv_gym *g) { return step_impl(g, false); }
+
+int mv_step_many(mv_gym *const *gyms, int32_t n, int32_t render, int32_t sample, uint32_t seed, uint32_t step_index)
+{   // several gyms of one job (MultiTaskGym: one per scenario, one stream each) stepped by one call: at eight sub-gyms the per-call cost of
+    // the language binding is a third of the step
+    if (!gyms || n < 0) return fail("mv_step_many: bad arguments");
+    for (int i = 0; i < n; ++i) {
+        if (sample && mv_sample_random_actions(gyms[i], seed, step_index)) return -1;
+        if (step_impl(gyms[i], render != 0)) return -1;
+    }
+    return 0;
+}
 
 int mv_synchronize(mv_gym *g)
 {

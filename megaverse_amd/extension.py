@@ -35,6 +35,7 @@ SYMBOLS = [
     ("mv_set_actions", C.c_int, [_P, _I, _I, _P, _I]),
     ("mv_set_actions_batched", C.c_int, [_P, _P]), ("mv_set_actions_device", C.c_int, [_P, _P]),
     ("mv_sample_random_actions", C.c_int, [_P, _U, _U]),
+    ("mv_step_many", C.c_int, [_P, _I, _I, _I, _U, _U]),
     ("mv_step", C.c_int, [_P]), ("mv_step_no_render", C.c_int, [_P]), ("mv_render", C.c_int, [_P]),
     ("mv_is_done", C.c_int, [_P, _I]), ("mv_get_dones", C.c_int, [_P, _P]),
     ("mv_get_last_rewards", C.c_int, [_P, _P]),
