@@ -30,6 +30,9 @@ def snap_dict(s, A):
     for f in ("pos", "basis", "pitch", "hv", "vvel", "carrying", "spawn", "total_reward"):
         d["agent_" + f] = np.stack([np.asarray(s["agents"][k][f]) for k in range(A)])
     d["chunk_sum"] = np.asarray(s["chunk"]).astype(np.int64).sum()
+    if int(s["hex_num_boxes"]):   # Hex scenarios: the maze's boxes and the collectables, the device's own 32-byte records
+        d["hex_boxes"] = s["hex_boxes"][: int(s["hex_num_boxes"])].copy()
+        d["hex_objs"] = s["hex_objs"][: int(s["hex_num_objs"])].copy()
     return d
 
 
@@ -86,3 +89,5 @@ if __name__ == "__main__":
     make("rearrange_a4", N=4, A=4, steps=1000, trace_every=100, W=64, H=64, scenario="Rearrange", seed=9)
     os.environ.setdefault("BOXOBAN_LEVELS", os.path.join(HERE, "boxoban"))   # synthetic levels in the public Boxoban text format
     make("sokoban_a2", N=6, A=2, steps=1300, trace_every=100, W=64, H=64, scenario="Sokoban", seed=4, action_seed=6)
+    make("hex_memory_a2", N=4, A=2, steps=900, trace_every=100, W=48, H=27, scenario="HexMemory", seed=8, action_seed=3, params={"episodeLengthSec": 4.0})
+    make("hex_explore_a3", N=4, A=3, steps=500, trace_every=100, W=48, H=27, scenario="HexExplore", seed=13, action_seed=9, params={"episodeLengthSec": 10.0})

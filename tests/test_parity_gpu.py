@@ -125,7 +125,7 @@ def test_auto_reset_parity_with_short_episodes(hip):
 
 
 @pytest.mark.parametrize("name", ["tower_a1", "tower_a4", "tower_short_episodes", "obstacles_hard_a2", "obstacles_easy_a1", "collect_a2", "rearrange_a4",
-                                  "sokoban_a2"])
+                                  "sokoban_a2", "hex_memory_a2", "hex_explore_a3"])
 def test_hip_reproduces_committed_golden(hip, name, monkeypatch):
     monkeypatch.setenv("BOXOBAN_LEVELS", os.path.join(GOLDEN, "boxoban"))
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
@@ -138,6 +138,9 @@ def test_hip_reproduces_committed_golden(hip, name, monkeypatch):
         s = hip_snapshot(hg, e)
         assert np.array_equal(s["objects"][: int(s["num_objects"])], z[f"reset_{e}_objects"])
         assert np.array_equal(s["boxes"][: int(s["num_boxes"])], z[f"reset_{e}_boxes"])
+        if f"reset_{e}_hex_boxes" in z:
+            assert s["hex_boxes"][: int(s["hex_num_boxes"])].tobytes() == z[f"reset_{e}_hex_boxes"].tobytes()
+            assert s["hex_objs"][: int(s["hex_num_objs"])].tobytes() == z[f"reset_{e}_hex_objs"].tobytes()
     assert np.array_equal(np.stack([hg.get_observation(e, a) for e in range(min(N, 4)) for a in range(A)]), z["reset_obs"])
     trace = []
     for st in range(steps):
