@@ -880,7 +880,7 @@ static int step_impl(mv_gym *g, bool render)
     if (own) {
         hipEvent_t mark = g->userMark[g->markCount % PIPE_BUFS];
         HIP_TRY(hipEventRecord(mark, g->stream));
-        if (g->simMustWaitUser) HIP_TRY(hipStreamWaitEvent(sim, mark, 0));
+        if (g->simMustWaitUser || !g->simOnOwnStream) HIP_TRY(hipStreamWaitEvent(sim, mark, 0));   // (or the last step ran on the caller's stream)
         else if (g->markCount >= PIPE_BUFS - 1) HIP_TRY(hipStreamWaitEvent(sim, g->userMark[(g->markCount - (PIPE_BUFS - 1)) % PIPE_BUFS], 0));
         ++g->markCount;
     } else {

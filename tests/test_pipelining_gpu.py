@@ -101,3 +101,28 @@ def test_consumers_on_the_callers_stream_see_step_t_while_step_t_plus_1_runs(hip
         assert int(osum) == int(serial[st][3]) and np.array_equal(oframe, serial[st][4]), st
     assert dones > N          # auto-resets happened while pipelined
     og.close()
+
+
+def test_switching_pixel_mode_and_pipelining_mid_run_changes_nothing(hip):
+    """exact steps run on the caller's stream, fast ones pipelined on the simulation stream: switching back and forth (and turning the
+    pipelining off and on) without a host sync in between must leave the simulation on the oracle's trajectory"""
+    N, A, W, H = 16, 2, 48, 32
+    og = oracle_lib.OracleGym("TowerBuilding", W, H, N, A, 1, False, {"episodeLengthSec": -220.0})
+    hg = MegaverseGym("TowerBuilding", W, H, N, A, 2, False, {"episodeLengthSec": -220.0})
+    og.seed(3); hg.seed(3); og.reset(); hg.reset()
+    st = 0
+    for phase in range(12):
+        mode = ("fast", "exact", "fast", "fast")[phase % 4]
+        hg.set_pixel_mode(mode)
+        hg.set_pipelining(phase % 3 != 2)
+        for _ in range(17):
+            hg.sample_random_actions(5, st)
+            hg.step() if (st % 3) else hg.step_no_render()
+            oracle_step(og, N, A, 5, st)
+            st += 1
+    hg.synchronize()
+    for e in range(N):
+        d = diff_snapshots(og.snapshot(e), hip_snapshot(hg, e), A)
+        assert not d, (e, d[:5])
+    assert og.get_last_rewards().tobytes() == hg.get_rewards_array().tobytes()
+    og.close(); hg.close()
