@@ -3172,5 +3172,14 @@ int mvo_hex_maze(int size, uint32_t seed, int *cells_out, int *border_counts, in
     return n;
 }
 void mvo_sincos(float x, float *s, float *c) { mv_sincos(x, s, c); }
+/* the level-file tokeniser (split_tokens) as a test hook: tokens joined by '\x1f'; returns their number */
+int mvo_split_tokens(const char *text, char delim, char *out, int cap)
+{
+    const std::vector<std::string> tokens = split_tokens(text, delim);
+    std::string joined;
+    for (size_t i = 0; i < tokens.size(); ++i) { if (i) joined += '\x1f'; joined += tokens[i]; }
+    if (cap > 0) { strncpy(out, joined.c_str(), size_t(cap) - 1); out[cap - 1] = 0; }
+    return int(tokens.size());
+}
 
 }  // extern "C"

@@ -8,7 +8,7 @@
  * restatement against the real reference functions.  Output goes to oracle/_ref/
  * (git-ignored, travels to the GPU box with the snapshot).
  *
- * Only util.hpp (+ macro.hpp), math_utils.hpp and the self-contained perlin_noise.hpp are buildable
+ * Only util.hpp (+ macro.hpp), math_utils.hpp, string_utils.{hpp,cpp} and the self-contained perlin_noise.hpp are buildable
  * this way: every other header on the hot path pulls in Magnum/Corrade/Bullet, which are not
  * vendored -- env/const.hpp (colours, parameter names) through util/magnum.hpp,
  * env/voxel_state.hpp through env/physics.hpp (btBulletDynamicsCommon.h), scenarios/const.hpp
@@ -19,6 +19,9 @@
 #include <util/util.hpp>
 #include <util/math_utils.hpp>
 #include <util/perlin_noise.hpp>
+#include <util/string_utils.hpp>   // splitString: compiled from the reference's util/src/string_utils.cpp (oracle/Makefile)
+
+#include <cstring>
 
 extern "C" {
 
@@ -60,4 +63,15 @@ void mvref_perlin_octave2_01(unsigned seed, const double *xs, const double *ys, 
     for (int i = 0; i < n; ++i) out[i] = perlin.accumulatedOctaveNoise2D_0_1(xs[i], ys[i], octaves);
 }
 
+
+/* splitString (util/src/string_utils.cpp:10-25, strtok_r: runs of separators collapse), as SokobanScenario::reloadLevels uses it on a
+ * level file (scenario_sokoban.cpp:90): the tokens joined by '\x1f' into out (at most cap bytes incl. the terminator); returns their number */
+int mvref_split_string(const char *text, const char *delims, char *out, int cap)
+{
+    const std::vector<std::string> tokens = Megaverse::splitString(text, delims);
+    std::string joined;
+    for (size_t i = 0; i < tokens.size(); ++i) { if (i) joined += '\x1f'; joined += tokens[i]; }
+    if (cap > 0) { std::strncpy(out, joined.c_str(), size_t(cap) - 1); out[cap - 1] = 0; }
+    return int(tokens.size());
+}
 }

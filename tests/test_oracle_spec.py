@@ -321,3 +321,23 @@ def test_oracle_reproduces_golden(name):
     g.render()
     assert np.array_equal(np.stack([g.get_observation(e, a) for e in range(min(N, 4)) for a in range(A)]), z["final_obs"])
     g.close()
+
+
+def test_level_file_tokeniser_matches_the_reference_split_string():
+    """SokobanScenario::reloadLevels splits a level file with splitString(content, "\\n") (scenario_sokoban.cpp:90,
+    util/src/string_utils.cpp:10-25: strtok_r, empty pieces never appear); the oracle's split_tokens against the reference function
+    compiled in place"""
+    import ctypes as C
+    ref = oracle_lib.ref_lib()
+    if ref is None or not hasattr(ref, "mvref_split_string"):
+        pytest.skip("oracle/_ref/libmv_ref_util.so is built from /root/reference (not present here)")
+    ref.mvref_split_string.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
+    mine = oracle_lib.lib().mvo_split_tokens
+    mine.argtypes = [C.c_char_p, C.c_char, C.c_char_p, C.c_int]
+    texts = ["; 0\n##########\n#  @ $ . #\n##########\n\n; 1\n####\n#@$.#\n", "\n\n\nabc\n\n\ndef\n", "no newline at all", "", "\n", "a\r\nb\r\n",
+             "; 3\n" + "#" * 40 + "\n" * 7 + "tail"]
+    for t in texts:
+        a, b = C.create_string_buffer(4096), C.create_string_buffer(4096)
+        na = ref.mvref_split_string(t.encode(), b"\n", a, 4096)
+        nb = mine(t.encode(), b"\n", b, 4096)
+        assert na == nb and a.value == b.value, (t, na, nb, a.value, b.value)
