@@ -107,7 +107,7 @@ int mv_get_pixel_mode(const mv_gym *g);
  * the arrays above ON THE CALLER'S STREAM, ordered with the observations, and a step never overwrites what a consumer enqueued
  * before the previous mv_step may still be reading.  mv_set_actions_device makes the next step wait (a policy in the loop is a true
  * dependency).  Off: everything runs on the caller's stream in order -- cheaper when several gyms already overlap each other
- * (MultiTaskGym) -- and the exact pixel mode always does.  Env var MV_PIPELINE=0|1 sets the default of new gyms. */
+ * (MultiTaskGym).  Env var MV_PIPELINE=0|1 sets the default of new gyms. */
 int mv_set_pipelining(mv_gym *g, int32_t on);
 int mv_get_pipelining(const mv_gym *g);
 

@@ -871,11 +871,11 @@ static int step_impl(mv_gym *g, bool render)
     if (refill_episodes(g)) return -1;
     // ---- what this step must wait for on the caller's stream.  Always: whatever was there when the step PIPE_BUFS - 1 calls ago began --
     // the observation pass and the consumers of the step that used this slot's buffers last.  Everything, when the caller's stream
-    // feeds the simulation (reset / render / device actions / test hooks since the last step) or when the observation pass reads
-    // simulator state itself (the exact raster kernel takes the cameras from the agent records).
-    // Not pipelined (mv_set_pipelining(0), or the exact pixel mode): the step runs on the caller's stream like everything else -- a hand-over
-    // between two hardware queues costs ~10 us each way, which only pays when something overlaps.
-    const bool own = g->pipelined && !(render && !g->fastPixels);
+    // feeds the simulation (reset / render / device actions / test hooks since the last step).  (Both raster kernels read nothing but the
+    // frame lists and headers of their tick: the simulator state may move on underneath them.)
+    // Not pipelined (mv_set_pipelining(0)): the step runs on the caller's stream like everything else -- a hand-over between two hardware
+    // queues costs ~10 us each way, which only pays when something overlaps.
+    const bool own = g->pipelined != 0;
     hipStream_t sim = own ? g->simStream : g->stream;
     if (own) {
         hipEvent_t mark = g->userMark[g->markCount % PIPE_BUFS];
@@ -928,8 +928,8 @@ static int step_impl(mv_gym *g, bool render)
     // ---- the caller's stream: the step's outputs, then the observation pass
     if (own) HIP_TRY(hipStreamWaitEvent(g->stream, g->simDone, 0));
     const PublishTo pub{g->gv.rewards, g->gv.done, g->gv.true_objective};
-    if (own && !render && publish_outputs(g, g->parity)) return -1;   // (with an observation pass, its first workgroups publish)
-    if (render && launch_raster(v, g->obs, g->w, g->h, g->stream, prof ? ev[3] : nullptr, g->fastPixels, /*setup_done=*/1, own ? &pub : nullptr)) return fail("mv_step: observation size above 1024x1024");
+    if (own && (!render || !g->fastPixels) && publish_outputs(g, g->parity)) return -1;   // (the fast observation pass publishes with its first workgroups)
+    if (render && launch_raster(v, g->obs, g->w, g->h, g->stream, prof ? ev[3] : nullptr, g->fastPixels, /*setup_done=*/1, own && g->fastPixels ? &pub : nullptr)) return fail("mv_step: observation size above 1024x1024");
     if (prof) { HIP_TRY(hipEventRecord(ev[4], g->stream)); ++g->profCount; }
     HIP_TRY(hipGetLastError());
     g->mirrorsFresh = false;

@@ -310,30 +310,18 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 && !SHAPES ? MV_RASTER_WAVES : M
     const int env = frame / A, viewer = frame - env * A;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    const AgentState *agents = gv.agents + (size_t)env * A;
-
-    // ---- cameras
-    if (tid < A) {
-        const AgentState a = agents[tid];
+    // ---- frames of reference: the cameras (and, Hex scenarios, the wall orientations) as the frame setup left them in the frame's header --
+    // the same values it built the list with, and nothing here reads simulator state that a later tick may already be changing (mv_api.hip)
+    if (tid < MAX_CAMS) {
+        const float *o = reinterpret_cast<const float *>(gv.vis_hdr + (size_t)frame * FRAME_HDR_BYTES) + FH_CAM + FH_CAM_STRIDE * tid;
         CamL cam;
-        cam.eye[0] = a.pos[0]; cam.eye[1] = (a.pos[1] + 0.05f) + 0.41f; cam.eye[2] = a.pos[2];
-        float sp, cp;
-        sincos_poly(a.pitch, sp, cp);
-        cam.c[0] = a.m00; cam.c[1] = a.m02 * sp; cam.c[2] = a.m02 * cp;
-        cam.c[3] = 0.0f;  cam.c[4] = cp;         cam.c[5] = -sp;
-        cam.c[6] = a.m20; cam.c[7] = a.m22 * sp; cam.c[8] = a.m22 * cp;
-        cam.origin[0] = cam.origin[1] = cam.origin[2] = 0.0f;
+        cam.eye[0] = o[0]; cam.eye[1] = o[1]; cam.eye[2] = o[2];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) cam.c[q] = o[3 + q];
+        cam.origin[0] = o[12]; cam.origin[1] = o[13]; cam.origin[2] = o[14];
         s_cam[tid] = cam;
     }
-    const bool hex = gv.scenario == SCN_HEX_MEMORY || gv.scenario == SCN_HEX_EXPLORE;
-    if (hex && tid >= MAX_AGENTS && tid < MAX_CAMS) s_cam[tid] = hex_frame(tid - MAX_AGENTS);
     __syncthreads();
-    if (tid < A || (hex && tid >= MAX_AGENTS && tid < MAX_CAMS)) {
-        const V3 ev = v3(s_cam[viewer].eye[0], s_cam[viewer].eye[1], s_cam[viewer].eye[2]);
-        const V3 ek = v3(s_cam[tid].eye[0], s_cam[tid].eye[1], s_cam[tid].eye[2]);
-        const V3 o = mat_tmul(s_cam[tid].c, ev - ek);
-        s_cam[tid].origin[0] = o.x; s_cam[tid].origin[1] = o.y; s_cam[tid].origin[2] = o.z;
-    }
     {   // separable ray terms: world dir = (c_k0*dc.x + c_k1*dc.y) + c_k2*(-1), dc = (xn*TAN, yn*TAN_Y, -1)
         const float *c = s_cam[viewer].c;
         for (int i = tid; i < W; i += 256) {
