@@ -1274,10 +1274,10 @@ int mv_debug_feeder_selftest(const char *scenario_name, int32_t num_envs, int32_
 {
     int scenario = SCN_TOWER;
     ObstacleConfig oc;
-    if (!scenario_name || !scenario_from_name(lower(scenario_name), scenario, oc) || scenario == SCN_TOWER || scenario == SCN_SOKOBAN || scenario == SCN_EMPTY ||
-        scenario == SCN_HEX_MEMORY || scenario == SCN_HEX_EXPLORE)
-        return fail("mv_debug_feeder_selftest: the Obstacles family, Collect and Rearrange");
-    const size_t bytes = scenario == SCN_COLLECT ? sizeof(CollectBlob) : scenario == SCN_REARRANGE ? sizeof(RearrangeBlob) : sizeof(EpisodeBlob);
+    if (!scenario_name || !scenario_from_name(lower(scenario_name), scenario, oc) || scenario == SCN_TOWER || scenario == SCN_SOKOBAN || scenario == SCN_EMPTY)
+        return fail("mv_debug_feeder_selftest: the Obstacles family, Collect, Rearrange, HexMemory and HexExplore");
+    const bool hex = scenario == SCN_HEX_MEMORY || scenario == SCN_HEX_EXPLORE;
+    const size_t bytes = scenario == SCN_COLLECT ? sizeof(CollectBlob) : scenario == SCN_REARRANGE ? sizeof(RearrangeBlob) : hex ? sizeof(HexBlob) : sizeof(EpisodeBlob);
     std::vector<uint8_t> slots((size_t)num_envs * bytes, 0), want(bytes);
     std::vector<uint32_t> seeds(num_envs);
     for (int i = 0; i < num_envs; ++i) seeds[i] = 1000u + 7u * (uint32_t)i;
@@ -1292,6 +1292,18 @@ int mv_debug_feeder_selftest(const char *scenario_name, int32_t num_envs, int32_
             const uint8_t *got = feeder.wait_ready(i, r, &used);
             if (!got) return fail("feeder selftest: episode not delivered");
             std::memset(want.data(), 0, bytes);
+            if (hex) {   // the box list comes last and only its used prefix is meaningful
+                HexBlob &b = *reinterpret_cast<HexBlob *>(want.data());
+                if (scenario == SCN_HEX_MEMORY) generate_hex_memory_episode(rng[i], num_agents, 60.0f, b);
+                else generate_hex_explore_episode(rng[i], num_agents, 60.0f, b);
+                b.seq = r;
+                const HexBlob &a = *reinterpret_cast<const HexBlob *>(got);
+                if (used != offsetof(HexBlob, boxes) + sizeof(HexRec) * (size_t)b.num_boxes || std::memcmp(&a, &b, offsetof(HexBlob, objs)) ||
+                    std::memcmp(a.objs, b.objs, sizeof(HexRec) * (size_t)b.num_objs) || std::memcmp(a.boxes, b.boxes, sizeof(HexRec) * (size_t)b.num_boxes))
+                    return fail("feeder selftest: Hex episode differs from sequential generation");
+                feeder.recycle(i, nullptr);
+                continue;
+            }
             if (scenario == SCN_REARRANGE) {
                 RearrangeBlob &b = *reinterpret_cast<RearrangeBlob *>(want.data());
                 generate_rearrange_episode(rng[i], num_agents, 60.0f, b);

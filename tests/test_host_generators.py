@@ -163,7 +163,7 @@ def test_episode_length_param_is_honoured():
     assert float(b["episode_len"]) == 500.0
 
 
-@pytest.mark.parametrize("scenario,threads", [("ObstaclesHard", 1), ("ObstaclesHard", 6), ("Collect", 4), ("Rearrange", 3)])
+@pytest.mark.parametrize("scenario,threads", [("ObstaclesHard", 1), ("ObstaclesHard", 6), ("Collect", 4), ("Rearrange", 3), ("HexMemory", 5), ("HexExplore", 2)])
 def test_background_feeder_delivers_each_envs_stream_in_order(scenario, threads):
     """the worker pool (mv_feeder.cpp) against straight sequential generation, 5 episodes x 24 envs, no device involved"""
     lib = ext.load_library()
