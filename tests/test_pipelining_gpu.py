@@ -126,3 +126,43 @@ def test_switching_pixel_mode_and_pipelining_mid_run_changes_nothing(hip):
         assert not d, (e, d[:5])
     assert og.get_last_rewards().tobytes() == hg.get_rewards_array().tobytes()
     og.close(); hg.close()
+
+
+def test_a_policy_in_the_loop_is_a_true_dependency(hip):
+    """actions computed ON THE DEVICE from the observations of the previous tick (torch ops on the caller's stream) and handed over with
+    set_actions_device: the next step must wait for them -- without any host synchronisation the rollout has to equal one that
+    synchronises after every call"""
+    import torch
+    scenario, N, A, W, H, STEPS = "ObstaclesEasy", 32, 2, 32, 32, 120
+    spaces = torch.tensor([3, 3, 3, 2, 2, 3], dtype=torch.int32, device="cuda:0")
+
+    def rollout(sync):
+        hg = MegaverseGym(scenario, W, H, N, A, 2, False, {})
+        hg.set_pixel_mode("fast")
+        stream = torch.cuda.Stream()
+        hg.set_stream(stream.cuda_stream)
+        hg.seed(17); hg.reset()
+        obs = torch.as_tensor(DevArr(hg.obs_device_ptr(), (N * A, H, W, 4), "|u1"), device="cuda:0")
+        keep = []
+        with torch.cuda.stream(stream):
+            for st in range(STEPS):
+                feat = obs.view(N * A, -1)[:, 37:37 + 6 * 97:97].to(torch.int32) + st   # six bytes of every frame
+                acts = (feat % spaces).contiguous()
+                keep.append(acts)                                                         # (alive until the kernels that read it ran)
+                hg.set_actions_device(acts.data_ptr())
+                hg.step()
+                if sync:
+                    hg.synchronize(); torch.cuda.synchronize()
+        hg.synchronize(); torch.cuda.synchronize()
+        snaps = [hip_snapshot(hg, e).copy() for e in range(N)]
+        frames = obs.cpu().numpy().copy()
+        acts_sum = int(torch.stack(keep).sum().item())
+        hg.close()
+        return snaps, frames, acts_sum
+
+    a, b = rollout(False), rollout(True)
+    assert a[2] == b[2]
+    assert all(x.tobytes() == y.tobytes() for x, y in zip(a[0], b[0]))
+    assert np.array_equal(a[1], b[1])
+    moved = sum(float(np.abs(s["agents"]["hv"][:A]).sum()) > 0 for s in a[0])
+    assert moved > 0          # the policy's actions did something
