@@ -1341,7 +1341,7 @@ int mv_debug_feeder_selftest(const char *scenario_name, int32_t num_envs, int32_
     return 0;
 }
 
-// Host-only test hook for the Sokoban generator (the scenario's kernels are not written yet): the first `n` episodes an env
+// Host-only test hook for the Sokoban generator: the first `n` episodes an env
 // seeded with env_seed generates from the level files under $BOXOBAN_LEVELS, as n consecutive SokobanBlob records.
 int mv_debug_generate_sokoban(int32_t num_agents, int32_t env_seed, int32_t n, float base_episode_len, void *out, int32_t out_bytes)
 {

@@ -6,10 +6,10 @@
 
 namespace mv {
 
-// frame setup + frame sort + raster of every agent's W x H observation into `obs` on `stream`; `between` (optional) is
-// recorded between the setup/sort kernels and the raster kernel; -1 if W/H are too large.  fast = 1: raster_fast_kernel
-// setup_done = 1: the frame lists were built by the step kernel (mv_frame.h), only the frame sort and the raster are launched.
-// (approximate reciprocals, persistent grid; pixels within the tolerance DESIGN.md states), 0: the bit-exact raster_kernel
+// frame setup (+ frame sort, exact mode) + raster of every agent's W x H observation into `obs` on `stream`; `between` (optional) is
+// recorded between the setup/sort kernels and the raster kernel; -1 if W/H are too large.  fast = 1: raster_fast_kernel (hardware
+// reciprocals, frames looked up from the cost bins in its prologue; pixels within the tolerance DESIGN.md states), 0: the bit-exact
+// raster_kernel behind frame_order_kernel.  setup_done = 1: the frame lists were built by the step kernel (mv_frame.h).
 // publish (fast kernel only): the step's staged rewards / dones / true objectives (gv.rewards ...) are copied into these public arrays by the
 // first workgroups of the raster launch -- ordered, on `stream`, with the observations (pipelined steps, mv_api.hip)
 struct PublishTo { float *rewards; uint8_t *done; float *true_objective; };

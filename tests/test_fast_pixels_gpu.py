@@ -1,4 +1,4 @@
-"""The default observation pass (MV_PIXELS_FAST: hardware rcp / rsqrt / log / exp, 24-bit depth keys, persistent tile queue)
+"""The default observation pass (MV_PIXELS_FAST: hardware rcp / rsqrt / log / exp, 32-bit depth keys with the list position in the low bits)
 against the CPU oracle, to the tolerance DESIGN.md "pixel tolerance" states -- north_star: "within stated fp32 tolerance for
 pixels".  The tolerance, per frame set compared:
   * at most PIX_GT1 of the pixels may differ from the oracle by more than 1 (of 255) in any channel: these are pixels whose
