@@ -264,6 +264,18 @@ def main():
         elapsed_no_gather = timed(step0, False)
         step0 += args.steps
 
+    # ---- transparency leg (N = 1): the same loop with the pipelining off -- step kernel and raster back to back on one stream
+    elapsed_unpipelined = None
+    pipelined = bool(not dry and not mixed and gym.pipelining())
+    if pipelined and world == 1:
+        gym.set_pipelining(False)
+        for i in range(min(args.warmup, 20)):
+            one_step(step0 + i, False)
+        step0 += min(args.warmup, 20)
+        elapsed_unpipelined = timed(step0, False)
+        step0 += args.steps
+        gym.set_pipelining(True)
+
     # ---- per-kernel profile: a separate, untimed loop with HIP events on the gym's stream
     prof = None
     if not dry and not mixed and args.profile_steps > 0:
@@ -303,9 +315,12 @@ def main():
                        "envs_per_gpu": n_env, "agents_per_env": A, "obs": [W, H], "gather_obs": bool(do_gather), "pixels": args.pixels,
                        # the step kernels of tick t + 1 / t + 2 overlap the observation pass of tick t (every tick is still
                        # stepped and rendered in full; MV_PIPELINE=0 runs the two kernels back to back on one stream)
-                       "pipelined": bool(not dry and not mixed and gym.pipelining()),
+                       "pipelined": pipelined,
                        "parallelism": f"env-shard x{world}"},
         }
+        if elapsed_unpipelined is not None:
+            line["value_unpipelined"] = total_obs / elapsed_unpipelined
+            line["ms_per_step_unpipelined"] = elapsed_unpipelined / args.steps * 1e3
         if dry:
             line["dry_run"] = True
         if do_gather:

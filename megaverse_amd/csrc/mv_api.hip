@@ -97,7 +97,7 @@ struct mv_gym {
     int pipelined = 1;                           // mv_set_pipelining / MV_PIPELINE: 0 = everything on the caller's stream, in order
     bool simOnOwnStream = false;                 // where the last step ran
     hipEvent_t userMark[PIPE_BUFS] = {};          // recorded on `stream` at the start of every mv_step, round-robin
-    int markCount = 0;
+    unsigned long long markCount = 0;             // (64 bits: a training run takes 2^31 steps in a day and a half)
     bool simMustWaitUser = true;                 // the caller's stream holds work the next step depends on (reset, render, device actions, ...)
     hipEvent_t simDone = nullptr;                // after the last kernel on simStream
     bool simDoneValid = false;
@@ -889,7 +889,6 @@ static int step_impl(mv_gym *g, bool render)
     }
     g->simMustWaitUser = false;
     g->simOnOwnStream = own;
-    if (!own && g->pipelined && g->lastUpload) HIP_TRY(hipStreamWaitEvent(sim, g->lastUpload, 0));
     if (g->actionsDirty) {
         const int s = g->stage;
         HIP_TRY(hipMemcpyAsync(g->gv.actions, g->hActions[s], (size_t)g->N * g->A * sizeof(int32_t), hipMemcpyHostToDevice, sim));
