@@ -716,6 +716,7 @@ static int refill_episodes(mv_gym *g)
         // that run-ahead every statusPeriod steps.  With long episodes (period 16, two resident episodes per env) the words may arrive a few
         // steps later: look again at the next step, but never let them age beyond 32 steps.
         if (g->statusPeriod > 1 && g->pendingAge < 32 && hipEventQuery(g->statusCopied) == hipErrorNotReady) {
+            (void)hipGetLastError();   // ("not ready" is an answer, not an error to report at the end of the step)
             ++g->pendingAge;
             return 0;
         }
