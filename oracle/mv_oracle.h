@@ -6,17 +6,21 @@
  * leg load liboracle (as the checker / the timed CPU baseline).
  *
  * What this is: a dependency-free CPU restatement of the reference's
- * VectorEnv::step() path for the TowerBuilding scenario
+ * VectorEnv::step() path for the scenarios TowerBuilding, Obstacles{Easy,Medium,Hard,Walls,Steps,Lava},
+ * Collect, Rearrange, Sokoban, HexMemory, HexExplore and Empty
  *   reference: src/libs/env/src/vector_env.cpp:89-120 (step/reset order)
  *              src/libs/env/src/env.cpp:57-152          (Env::reset/step)
  *              src/libs/env/src/kinematic_character_controller.cpp (controller)
- *              src/libs/scenarios/src/scenario_tower_building.cpp  (scenario)
+ *              src/libs/scenarios/src/scenario_*.cpp, component_*.{hpp,cpp}, platforms.hpp, layout_utils.cpp (scenarios)
+ *              src/libs/mazes/src (honeycomb maze + Kruskal, Hex scenarios)
  *              src/libs/magnum_rendering/src/magnum_env_renderer.cpp:158-340 (pixels)
  *
  * PARITY STATUS
- *   pinned   : RNG helpers randRange/frand/randomBool are checked against the
- *              reference's own util.hpp compiled in place (oracle/_ref, see
- *              oracle/Makefile) and against the C++ standard's mt19937
+ *   pinned   : RNG helpers randRange/frand/randomBool, triangularNumber, splitString, the
+ *              Perlin noise of Collect's landscape and the honeycomb maze generator are
+ *              checked against the reference's own util.hpp / math_utils.hpp /
+ *              string_utils.cpp / perlin_noise.hpp / mazes library compiled in place
+ *              (oracle/_ref, see oracle/Makefile), the RNG also against the C++ standard's mt19937
  *              known answer (10000th output == 4123659995); action-mask table,
  *              getCoords example (voxel_grid_tests.cpp:25), reward/episode
  *              formulas are spec-derived known answers (tests/test_oracle_spec.py).
