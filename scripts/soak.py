@@ -1,0 +1,46 @@
+"""Soak run (not a pytest): long open-loop rollouts with short episodes -- thousands of auto-resets, ring refills, status read-backs, the step
+kernels pipelined ahead of the raster -- twice per scenario; the two runs must end in the same state and the same observation slab, and
+nothing may raise.  python scripts/soak.py [steps]"""
+import os, sys, time
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import numpy as np
+import torch
+from megaverse_amd.extension import MegaverseGym
+from hip_util import hip_snapshot
+
+os.environ.setdefault("BOXOBAN_LEVELS", "tests/golden/boxoban")
+STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 30000
+CASES = [("TowerBuilding", 256, 2, {"episodeLengthSec": -215.0}), ("ObstaclesEasy", 256, 1, {}), ("Collect", 128, 2, {"episodeLengthSec": 3.0}),
+         ("Rearrange", 256, 1, {"episodeLengthSec": 1.0}), ("Sokoban", 128, 2, {"episodeLengthSec": 2.0}), ("HexMemory", 128, 2, {"episodeLengthSec": 2.0}),
+         ("HexExplore", 128, 1, {"episodeLengthSec": 4.0})]
+
+
+def run(scenario, N, A, params):
+    g = MegaverseGym(scenario, 64, 36, N, A, 8, False, params)
+    g.set_pixel_mode("fast")
+    obs = torch.zeros((N * A, 36, 64, 4), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    g.set_obs_buffer(obs.data_ptr())
+    g.seed(123); g.reset()
+    dones = 0
+    t0 = time.perf_counter()
+    for st in range(STEPS):
+        g.sample_random_actions(99, st)
+        g.step()
+        if st % 997 == 0:
+            dones += int(g.get_dones().sum())          # (a host read now and then: the mirrors path)
+    g.synchronize(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    snaps = b"".join(hip_snapshot(g, e).tobytes() for e in range(0, N, 7))
+    slab = obs.cpu().numpy().copy()
+    g.close()
+    return snaps, slab, dones, STEPS * N * A / dt
+
+
+for scenario, N, A, params in CASES:
+    a = run(scenario, N, A, params)
+    b = run(scenario, N, A, params)
+    same = a[0] == b[0] and np.array_equal(a[1], b[1])
+    print("%-14s %d steps x %d envs x %d agents: %s, sampled dones %d, %.2f M obs/s" % (scenario, STEPS, N, A, "identical" if same else "DIFFERENT", a[2], a[3] / 1e6), flush=True)
+    assert same, scenario
+print("soak ok")
