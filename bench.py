@@ -32,33 +32,78 @@ sys.path.insert(0, ROOT)
 METRIC = "agent observations/sec (whole node), TowerBuilding 128x128 obs, random policy"
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 XGMI_PEAK_GBS = 7 * 153.0      # 7 point-to-point links x ~153 GB/s per GPU
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2   # wave64 VALU instructions per second: 1024 SIMD-32s, 2 cycles per instruction (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(scenario, obs_w, obs_h, n_env, agents, budget_s=14.0):
-    """Oracle (CPU restatement, kind 'port') timed on this box's host cores on a bounded sample of the same
-    workload: same scenario / env count / obs size / seed / action stream, fewer steps."""
+def cpu_baseline(scenario, obs_w, obs_h, n_env, agents, policy="multidiscrete"):
+    """Oracle (CPU restatement, kind 'port') timed on this box's host cores on bounded samples of the same workload: same scenario /
+    obs size / seed / action stream.  Four legs, each the median of three repetitions:
+      all_threads   the full step (physics + logic + auto-reset + software raster) of all n_env envs, static block partition over every
+                    host thread like vector_env.cpp:65-87 -- this is `value`;
+      one_thread    the same on ONE pinned thread, on the first few envs of the batch (per-core figure);
+      physics_only  mvo_step_norender on all threads (what the reference's Bullet step costs in this restatement);
+      raster_only   mvo_render on all threads (the oracle's brute-force software raster: every primitive against every pixel --
+                    NOT the reference's GL renderer; a baseline, not a target).
+    Actions go in through ONE batched call per tick."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
     import oracle_lib
-    from megaverse_amd.rollout import sample_actions, action_masks
+    from megaverse_amd.rollout import sample_actions, action_masks, sample_single_bit_masks
     threads = max(1, os.cpu_count() or 1)
-    g = oracle_lib.OracleGym(scenario, obs_w, obs_h, n_env, agents, threads)
-    g.seed(42)
-    g.reset()
-    steps, t0 = 0, time.perf_counter()
-    while True:
-        masks = action_masks(sample_actions(1234, steps, n_env * agents))
-        for e in range(n_env):
-            for a in range(agents):
-                g.set_action_mask(e, a, int(masks[e * agents + a]))
-        g.step()
-        steps += 1
-        el = time.perf_counter() - t0
-        if (el > budget_s and steps >= 2) or steps >= 400:
-            break
-    g.close()
-    return {"value": n_env * agents * steps / el, "unit": "agent observations/sec", "cores": threads, "kind": "port",
-            "sample": f"oracle (CPU restatement, software raster) {scenario} num_envs={n_env} agents={agents} obs {obs_w}x{obs_h}, "
-                      f"{steps} steps in {el:.1f}s on {threads} threads (static block partition like vector_env.cpp:65-68)"}
+
+    def masks_of(step, n):
+        if policy == "single-bit":
+            return sample_single_bit_masks(1234, step, n * agents)
+        return action_masks(sample_actions(1234, step, n * agents))
+
+    def leg(n, T, what, budget_s, reps=3, pin=None):
+        old = None
+        if pin is not None and hasattr(os, "sched_setaffinity"):
+            old = os.sched_getaffinity(0)
+            os.sched_setaffinity(0, {sorted(old)[pin % len(old)]})
+        try:
+            g = oracle_lib.OracleGym(scenario, obs_w, obs_h, n, agents, T)
+            g.seed(42)
+            g.reset()
+            rates, steps_total, t_total, st = [], 0, 0.0, 0
+            for _ in range(reps):
+                steps, t0 = 0, time.perf_counter()
+                while True:
+                    if what != "raster":
+                        g.set_action_masks(masks_of(st, n))
+                    if what == "full":
+                        g.step()
+                    elif what == "physics":
+                        g.step_norender()
+                    else:
+                        g.render()
+                    steps += 1
+                    st += 1
+                    el = time.perf_counter() - t0
+                    if el > budget_s / reps or steps >= 400:
+                        break
+                rates.append(n * agents * steps / el)
+                steps_total += steps
+                t_total += el
+            g.close()
+        finally:
+            if old is not None:
+                os.sched_setaffinity(0, old)
+        return {"value": float(np.median(rates)), "unit": "agent observations/sec" if what != "physics" else "agent steps/sec", "threads": T, "envs": n,
+                "steps": steps_total, "seconds": round(t_total, 2), "median_of": reps}
+
+    n1 = max(1, min(n_env, 4))
+    legs = {"all_threads": leg(n_env, threads, "full", 9.0),
+            "one_thread": leg(n1, 1, "full", 6.0, pin=0),
+            "physics_only": leg(n_env, threads, "physics", 3.0),
+            "raster_only": leg(n_env, threads, "raster", 6.0)}
+    a = legs["all_threads"]
+    out = {"value": a["value"], "unit": "agent observations/sec", "cores": threads, "kind": "port",
+           "sample": f"oracle (CPU restatement of VectorEnv::step, software raster; NOT the reference binary) {scenario} num_envs={n_env} agents={agents} "
+                     f"obs {obs_w}x{obs_h}, policy {policy}: {a['steps']} steps in {a['seconds']} s on {threads} threads (static block partition like "
+                     f"vector_env.cpp:65-68), median of {a['median_of']}; one_thread = {n1} envs pinned to one core"}
+    out.update(legs)
+    return out
 
 
 def free_port():
@@ -153,6 +198,13 @@ def main():
     ap.add_argument("--no-gather-obs", action="store_true", help="N>1: skip the gather-on leg (value = the no-gather rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pixels", default="fast", choices=["fast", "exact"], help="observation arithmetic (DESIGN.md 'pixel tolerance')")
+    ap.add_argument("--policy", default="multidiscrete", choices=["multidiscrete", "single-bit"],
+                    help="random policy: uniform per head (action_space.sample(), megaverse_env.py:110-112) or the reference benchmark's "
+                         "Action(1 << randRange(0, 11)) (megaverse_test_app.cpp:140-147)")
+    ap.add_argument("--batch", type=int, default=8,
+                    help="ticks per stepping call (mv_step_n): every tick is stepped and rendered in full, the two stream hand-overs are paid once "
+                         "per call; 1 = one mv_step per tick.  N>1 with the gather on always steps tick by tick")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the single-step / unpipelined / closed-loop transparency legs")
     ap.add_argument("--profile-steps", type=int, default=256, help="steps of the untimed per-kernel profile loop (HIP events on the gym's stream)")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo run of the launcher + gather pipeline with a stand-in gym")
     args = ap.parse_args()
@@ -187,6 +239,9 @@ def main():
     n_env, A = args.envs_per_gpu, args.agents
     mixed = args.scenario.lower() == "mixed"
     frames = n_env * A
+    batch = max(1, args.batch)
+    os.environ.setdefault("MV_PIPE_BATCH", str(max(8, min(16, batch))))
+    batch = min(batch, int(os.environ["MV_PIPE_BATCH"]))
     if dry:
         gym = DryGym(rank)
     elif mixed:   # BASELINE.json configs[4]: the eight MEGAVERSE8 scenarios dealt round-robin by env index
@@ -199,9 +254,15 @@ def main():
                            device=local_rank, env_offset=rank * n_env, total_envs=world * n_env)
         gym.set_stream(torch.cuda.current_stream().cuda_stream)
         gym.set_pixel_mode(args.pixels)
+        gym.set_sample_policy(args.policy)
 
+    do_gather = world > 1 and not args.no_gather_obs
     gather = ObsGather(dist, torch, (frames, H, W, 4), world, device, cuda=not dry) if world > 1 else None
     slabs = gather.local if gather else [torch.zeros((frames, H, W, 4), dtype=torch.uint8, device=device)]
+    # batched stepping: tick j of a call renders into slab j of a ring, so that all `batch` observations of a call exist side by side when it
+    # is done (a k-step rollout buffer) -- the working set of the observation writes is batch x one slab, not one slab written over and over
+    batched = batch > 1 and not dry and not mixed
+    ring = torch.zeros((batch, frames, H, W, 4), dtype=torch.uint8, device=device) if batched else None
 
     def bind(b):
         if dry:
@@ -238,11 +299,21 @@ def main():
         if not dry:
             torch.cuda.synchronize()
 
-    def timed(first, with_gather):
+    def run_steps(first, n, with_gather, use_batch):
+        if use_batch and not with_gather:
+            i = 0
+            while i < n:
+                k = min(batch, n - i)
+                gym.step_n(k, args.policy, 1234, first + i)
+                i += k
+        else:
+            for i in range(n):
+                one_step(first + i, with_gather)
+
+    def timed(first, with_gather, use_batch):
         fence()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            one_step(first + i, with_gather)
+        run_steps(first, args.steps, with_gather, use_batch)
         fence()
         el = time.perf_counter() - t0
         t = torch.tensor([el], dtype=torch.float64, device=device)
@@ -250,44 +321,76 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    do_gather = world > 1 and not args.no_gather_obs
     step0 = 0
-    for i in range(args.warmup):
-        one_step(step0 + i, do_gather)
+    main_batched = batched and not do_gather
+    if main_batched:
+        gym.set_output_ring(batch, ring.data_ptr())
+    run_steps(step0, args.warmup, do_gather, main_batched)
     step0 += args.warmup
-    elapsed = timed(step0, do_gather)        # THE timed region: exactly --steps steps, no instrumentation
+    elapsed = timed(step0, do_gather, main_batched)        # THE timed region: exactly --steps steps, no instrumentation
     step0 += args.steps
     last_gathered = step0 - 1
     elapsed_no_gather = None
     if do_gather:                            # second leg, same step count, observations stay on the producing GPU
         bind(0)
-        elapsed_no_gather = timed(step0, False)
+        if batched:
+            gym.set_output_ring(batch, ring.data_ptr())
+        elapsed_no_gather = timed(step0, False, batched)
         step0 += args.steps
 
-    # ---- transparency leg (N = 1): the same loop with the pipelining off -- step kernel and raster back to back on one stream
-    elapsed_unpipelined = None
-    pipelined = bool(not dry and not mixed and gym.pipelining())
-    if pipelined and world == 1:
-        gym.set_pipelining(False)
-        for i in range(min(args.warmup, 20)):
-            one_step(step0 + i, False)
-        step0 += min(args.warmup, 20)
-        elapsed_unpipelined = timed(step0, False)
-        step0 += args.steps
-        gym.set_pipelining(True)
-
-    # ---- per-kernel profile: a separate, untimed loop with HIP events on the gym's stream
+    # ---- per-kernel profile: a separate, untimed loop with HIP events around every kernel, each interval on one stream
     prof = None
     if not dry and not mixed and args.profile_steps > 0:
         fence()
-        bind(0)
         gym.profile_begin(args.profile_steps)
-        for i in range(args.profile_steps):
-            one_step(step0 + i, False)
+        run_steps(step0, args.profile_steps, False, batched)
         prof = gym.profile_end()
         step0 += args.profile_steps
+    if batched:
+        gym.set_output_ring(0)
+        bind(0)
+
+    # ---- transparency legs (N = 1), same step count each, none of them is `value`:
+    #   single_step   one mv_step per tick (the r02 headline mode: every tick hands over between the two streams);
+    #   unpipelined   step kernel and raster back to back on one stream;
+    #   closed_loop   a policy in the loop: a device-side policy reads the observations of tick t and produces the actions of tick t + 1
+    #                 (torch ops on the gym's stream + mv_set_actions_device): nothing can overlap, this is what an RL learner gets
+    extra = {}
+    pipelined = bool(not dry and not mixed and gym.pipelining())
+    if not dry and not mixed and world == 1 and not args.no_extra_legs:
+        wu = min(args.warmup, 20)
+        if batched and pipelined:
+            run_steps(step0, wu, False, False); step0 += wu
+            extra["single_step"] = timed(step0, False, False); step0 += args.steps
+        if pipelined:
+            gym.set_pipelining(False)
+            run_steps(step0, wu, False, False); step0 += wu
+            extra["unpipelined"] = timed(step0, False, False); step0 += args.steps
+            gym.set_pipelining(True)
+        sizes = torch.tensor([3, 3, 3, 2, 2, 3], dtype=torch.int32, device=device)
+        acts = torch.zeros((frames, 6), dtype=torch.int32, device=device)
+        feat = slabs[0].view(frames, -1)[:, 37:37 + 6 * 97:97]   # six bytes of every frame
+
+        def policy_step(i):
+            acts.copy_(feat)                      # uint8 -> int32
+            acts.add_(i).remainder_(sizes)        # "policy": a function of the observation just rendered
+            gym.set_actions_device(acts.data_ptr())
+            gym.step()
+
+        for i in range(wu):
+            policy_step(step0 + i)
+        step0 += wu
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            policy_step(step0 + i)
+        fence()
+        extra["closed_loop"] = time.perf_counter() - t0
+        step0 += args.steps
 
     checksum = int(slabs[0][::97].to(torch.int64).sum().item())   # touch the result so nothing is optimised away
+    if ring is not None:
+        checksum += int(ring[:, ::97].to(torch.int64).sum().item())
     if dry and do_gather:   # every rank's shard of the last gathered step must have arrived, in rank order
         g0 = gather.out[last_gathered & 1]
         for r in range(world):
@@ -305,22 +408,24 @@ def main():
         # physics kernel (tick + frame setup, one launch), per env: header R+W + scene + movable boxes R+W + per agent (state R+W, action,
         # reward, objective) + done, + per frame the list the raster reads: 800 B header + ~30 visible primitives x 40 B
         step_bytes_per_env = 2 * 128 + scene_bytes + 2 * 320 + A * (2 * 128 + 4 + 4 + 4) + 1 + A * (800 + 30 * 40)
+        headline = args.scenario == "TowerBuilding" and (W, H) == (128, 128) and args.policy == "multidiscrete"
         line = {
-            "metric": METRIC if args.scenario == "TowerBuilding" and (W, H) == (128, 128) else METRIC.replace("TowerBuilding 128x128", f"{args.scenario} {W}x{H}"),
+            "metric": METRIC if headline else METRIC.replace("TowerBuilding 128x128", f"{args.scenario} {W}x{H}").replace("random policy", f"random policy ({args.policy})"),
             "value": total_obs / elapsed, "unit": "agent observations/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.scenario} num_envs={n_env} per GPU x {world} GPU(s), num_agents_per_env={A}, obs {W}x{H} RGBA8, "
-                                   "uniform random multi-discrete actions (device, counter-based), natural auto-resets, master seed 42",
-                       "envs_per_gpu": n_env, "agents_per_env": A, "obs": [W, H], "gather_obs": bool(do_gather), "pixels": args.pixels,
-                       # the step kernels of tick t + 1 / t + 2 overlap the observation pass of tick t (every tick is still
-                       # stepped and rendered in full; MV_PIPELINE=0 runs the two kernels back to back on one stream)
-                       "pipelined": pipelined,
+                                   f"uniform random {args.policy} actions (device, counter-based), natural auto-resets, master seed 42",
+                       "envs_per_gpu": n_env, "agents_per_env": A, "obs": [W, H], "gather_obs": bool(do_gather), "pixels": args.pixels, "policy": args.policy,
+                       # the step kernels run ahead of the observation passes on a stream of their own (every tick is still
+                       # stepped and rendered in full); ticks_per_call > 1: mv_step_n, the streams hand over once per call, tick j of a call
+                       # leaves its observations in slab j of a ring of that many slabs
+                       "pipelined": pipelined, "ticks_per_call": batch if main_batched else 1,
                        "parallelism": f"env-shard x{world}"},
         }
-        if elapsed_unpipelined is not None:
-            line["value_unpipelined"] = total_obs / elapsed_unpipelined
-            line["ms_per_step_unpipelined"] = elapsed_unpipelined / args.steps * 1e3
+        for key, el in extra.items():
+            line["value_" + key] = total_obs / el
+            line["ms_per_step_" + key] = el / args.steps * 1e3
         if dry:
             line["dry_run"] = True
         if do_gather:
@@ -330,35 +435,45 @@ def main():
             line["gather"] = {"collective": "all_gather_into_tensor (RCCL), double-buffered on a communication stream",
                               "bytes_received_per_gpu_per_step": (world - 1) * slab_bytes,
                               "achieved_GBps_per_gpu": (world - 1) * slab_bytes / (elapsed / args.steps) / 1e9,
-                              "xgmi_peak_GBps_per_gpu": XGMI_PEAK_GBS}
+                              "xgmi_peak_GBps_per_gpu": XGMI_PEAK_GBS,
+                              # what the links allow: every GPU receives (world - 1) shards per step over its 7 point-to-point links
+                              "xgmi_bound_ms_per_step": (world - 1) * slab_bytes / (XGMI_PEAK_GBS * 1e9) * 1e3}
         if prof is not None:
-            traffic = traffic_step = None
-            try:   # HBM bytes per launch from the committed PMC passes (profiles/), only for the profiled config
+            traffic = traffic_step = valu = None
+            try:   # per-launch PMC figures from the committed rocprofv3 passes (profiles/), only for the profiled config
                 pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
                 if pt["config"] == {"envs_per_gpu": n_env, "agents_per_env": A, "obs": [W, H]} and args.scenario == "TowerBuilding":
                     traffic = pt["kernels"].get("raster", {}).get("traffic_bytes_per_launch")
                     traffic_step = pt["kernels"].get("step", {}).get("traffic_bytes_per_launch")
+                    valu = pt["kernels"].get("raster", {}).get("valu")
             except Exception:  # noqa: BLE001
                 pass
             raster_ms, step_ms = prof["raster"][0], prof["step"][0]
             achieved = bytes_per_frame * frames / (raster_ms * 1e-3) / 1e9 if raster_ms > 0 else 0.0
             achieved_step = step_bytes_per_env * n_env / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
-            line["roofline"] = {"bound": "hbm", "kernel": "mv::raster_fast_kernel" if args.pixels == "fast" else "mv::raster_kernel",
+            line["roofline"] = {"bound": "valu", "kernel": "mv::raster_fast_kernel" if args.pixels == "fast" else "mv::raster_kernel",
                                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                 "avg_launch_ms": raster_ms, "launches_timed": prof["raster"][1], "algorithmic_bytes_per_launch": bytes_per_frame * frames,
-                                "note": "dominant kernel; per-launch time from HIP events in a separate untimed loop; traffic = HBM bytes/launch from "
-                                        "rocprofv3 PMC (profiles/pmc_traffic.json); ray casting is VALU/issue-bound, the HBM fraction is low by construction"}
-            line["roofline_physics"] = {"bound": "hbm", "kernel": "mv::step_kernel (voxel physics + scenario logic + auto-reset + frame setup)", "achieved": achieved_step,
+                                "note": "dominant kernel; achieved / peak / frac are the HBM figures (algorithmic bytes / launch time against 8 TB/s); "
+                                        "the kernel moves 1.01x its algorithmic bytes and is bound by VALU issue, see `valu`; per-launch time from HIP "
+                                        "events (same stream) in a separate untimed loop; traffic = HBM bytes/launch from rocprofv3 PMC"}
+            if valu and raster_ms > 0:   # wave64 VALU instructions issue over 2 cycles on a SIMD-32; 256 CUs x 4 SIMDs x 2.4 GHz
+                insts = valu["valu_insts_per_launch"]
+                line["roofline"]["valu"] = {"insts_per_launch": insts, "salu_insts_per_launch": valu.get("salu_insts_per_launch"),
+                                            "insts_per_64px_tile": insts / (frames * W * H / 64.0),
+                                            "issue_peak_insts_per_s": VALU_ISSUE_PEAK, "frac_of_issue_peak": insts / (raster_ms * 1e-3) / VALU_ISSUE_PEAK,
+                                            "source": valu.get("source")}
+            line["roofline_physics"] = {"bound": "latency", "kernel": "mv::step_kernel (voxel physics + scenario logic + auto-reset + frame setup)", "achieved": achieved_step,
                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_step / HBM_PEAK_GBS, "traffic": traffic_step,
                                         "avg_launch_ms": step_ms, "launches_timed": prof["step"][1], "algorithmic_bytes_per_launch": step_bytes_per_env * n_env,
                                         "note": "north_star's >=40 % HBM target names this kernel; its working set is 1.7 KB per env (the 16 KB voxel chunk "
                                                 "is not streamed), so it is latency-bound: one wave per env, launch length = slowest wave (DESIGN.md 3.1); "
-                                                "when pipelined it runs concurrently with the previous tick's raster, which stretches its launches"}
-            line["kernels"] = {"frame_setup_and_sort": {"avg_launch_ms": prof["setup"][0], "note": "frame sort only: the frame setup runs inside the step kernel"},
-                               "status_readback_gap": {"avg_launch_ms": prof["reset"][0]}}
+                                                "when pipelined it runs concurrently with the previous ticks' rasters, which stretches its launches"}
+            if args.pixels == "exact":
+                line["kernels"] = {"publish_and_frame_sort": {"avg_launch_ms": prof["setup"][0], "note": "exact pixel mode only; same-stream interval"}}
         line["checksum"] = checksum
         if world == 1 and not args.no_cpu_baseline and not mixed and not dry:   # (the CPU baseline runs one scenario per gym)
-            line["cpu_baseline"] = cpu_baseline(args.scenario, W, H, n_env, A)
+            line["cpu_baseline"] = cpu_baseline(args.scenario, W, H, n_env, A, args.policy)
         print(json.dumps(line), flush=True)
 
     gym.close()

@@ -8,6 +8,9 @@
  * (megaverse_amd/extension.py does exactly that).  Plain pointers and sizes only; no torch, no
  * STL, no exceptions.  Return value: 0 = ok, negative = error (mv_last_error() has the text);
  * the reference instead logs and calls exit(-1) (src/libs/util/src/tiny_logger.cpp:109-113).
+ * mv_step* / mv_reset may also return 1 = done, with a WARNING in mv_last_error(): a fixed capacity this build has and the
+ * reference has not (visible primitives per frame, collision candidates, the voxel chunk, an episode record, a starved episode
+ * ring) was hit since the last report.  The call did all of its work; the condition is reported once.
  *
  * Threading: like the reference every call is made from one host thread per gym.
  * All device work is enqueued on one HIP stream (mv_set_stream; default: the null stream);
@@ -46,6 +49,7 @@ typedef struct mv_config {
 } mv_config;
 
 const char *mv_last_error(void);
+int mv_device_count(void);   /* HIP devices this process can see (0 when there is none or the runtime cannot start) */
 
 /* MegaverseGym::MegaverseGym (megaverse.cpp:38-58) / close (:227-243).  mv_close is idempotent
  * and valid before the first reset (megaverse/tests/test_env.py:28-30). */
@@ -60,18 +64,36 @@ int mv_reset(mv_gym *g);                            /* reset(), :76-93 (+ first 
 
 /* setActions(), :100-116: multi-discrete -> Action bitmask for one agent (host staging) */
 int mv_set_actions(mv_gym *g, int32_t env_idx, int32_t agent_idx, const int32_t *actions, int32_t n);
-/* batched forms the reference lacks (SURVEY.md 3.2 hot loop iii): [N*A][6] multi-discrete */
+/* batched forms the reference lacks (SURVEY.md 3.2 hot loop iii): [N*A][6] multi-discrete.  The device form launches nothing: the buffer
+ * is read by the NEXT step kernel, in the order of the caller's stream (keep it unchanged until that mv_step has been enqueued). */
 int mv_set_actions_batched(mv_gym *g, const int32_t *host_actions);
 int mv_set_actions_device(mv_gym *g, const int32_t *device_actions);
 /* benchmark policy: i.i.d. uniform per head, counter-based (seed, step, agent, head) -> action;
  * same stream as megaverse_amd.rollout.sample_actions() on the host */
 int mv_sample_random_actions(mv_gym *g, uint32_t seed, uint32_t step_index);
+/* which generator mv_sample_random_actions / mv_step_n draw from: MV_POLICY_MULTIDISCRETE (default; = action_space.sample(),
+ * megaverse_env.py:110-112) or MV_POLICY_SINGLE_BIT = Action(1 << randRange(0, NumActions)), the reference's own benchmark policy
+ * (src/apps/megaverse_test_app.cpp:140-147); host twins: megaverse_amd/rollout.py */
+enum { MV_POLICY_NONE = 0, MV_POLICY_MULTIDISCRETE = 1, MV_POLICY_SINGLE_BIT = 2 };
+int mv_set_sample_policy(mv_gym *g, int32_t policy);
 /* step several gyms of one job with one call (no reference counterpart: its multi-task runs are separate processes,
  * the scripts under megaverse_rl/runs): for each gym, optionally mv_sample_random_actions(seed, step_index), then mv_step / mv_step_no_render */
 int mv_step_many(mv_gym *const *gyms, int32_t n, int32_t render, int32_t sample, uint32_t seed, uint32_t step_index);
 
 int mv_step(mv_gym *g);                             /* step(), :118-121: VectorEnv::step incl. auto-reset + render */
 int mv_step_no_render(mv_gym *g);                   /* physics/logic/auto-reset only */
+/* k open-loop ticks with one call = k iterations of the reference's benchmark loop body "for every agent setAction(random); venv.step()"
+ * (megaverse_test_app.cpp:140-147 + vector_env.cpp:89-108): tick j draws its actions from (policy, seed, first_step_index + j) inside the
+ * step kernel and renders every agent's observation.  Exactly the ticks k calls of mv_sample_random_actions + mv_step make -- but the
+ * simulation stream and the caller's stream hand over to each other once per call instead of once per tick.  policy
+ * MV_POLICY_NONE: the first tick acts on what mv_set_actions* left, the others on cleared actions.  The public arrays hold the LAST tick's
+ * outputs -- or, with mv_set_output_ring, every tick's.  k may exceed the internal batch (MV_PIPE_BATCH, default 8): the call splits it. */
+int mv_step_n(mv_gym *g, int32_t k, int32_t policy, uint32_t seed, uint32_t first_step_index);
+/* Rollout rings (no reference counterpart: its learner copies each step's observation out of the gym, megaverse_env.py:121-130): tick
+ * number t since this call leaves its observations in obs[t % count] ([count][N*A][h][w][4]), its rewards in rewards[t % count] ([count][N*A])
+ * and its dones in dones[t % count] ([count][N]); a NULL ring keeps that output where it was.  count = 0 switches back to the single
+ * slab / arrays.  Host getters (mv_get_observation, mv_get_last_rewards, ...) read the entry of the last tick. */
+int mv_set_output_ring(mv_gym *g, int32_t count, void *obs, float *rewards, uint8_t *dones);
 int mv_render(mv_gym *g);                           /* observation pass only */
 
 int mv_is_done(mv_gym *g, int32_t env_idx);         /* isDone(), :123-126 -> 0/1, <0 on error */
@@ -129,8 +151,8 @@ int mv_synchronize(mv_gym *g);
 /* In-stream kernel timing with HIP events on the gym's own stream (bench.py roofline leg, in a loop of its own: never inside
  * the timed region).  After mv_profile_begin the next max_steps calls of mv_step record events around the launches;
  * mv_profile_end synchronises and returns the mean milliseconds and sample count per interval: [0] step kernel (physics + logic +
- * auto-reset of finished envs + frame setup of the env's frames), [1] status read-back enqueue (every statusPeriod-th step),
- * [2] frame sort, [3] raster.  The counterpart in the reference is the TinyProfiler timers around venv.step()
+ * auto-reset of finished envs + frame setup of the env's frames), [1] always 0 (retired), [2] output publish + frame sort (exact
+ * pixel mode; ~0 in the fast mode), [3] raster.  Every interval is taken between two events of ONE stream.  The counterpart in the reference is the TinyProfiler timers around venv.step()
  * (src/apps/megaverse_test_app.cpp:68-74). */
 int mv_profile_begin(mv_gym *g, int32_t max_steps);
 int mv_profile_end(mv_gym *g, float *avg_ms4, int32_t *counts4);

@@ -44,10 +44,24 @@ __device__ __forceinline__ int sampled_action_mask(const GymView &gv, int env, i
     return action_mask_of(a);
 }
 
+// The reference's own benchmark policy (src/apps/megaverse_test_app.cpp:140-147): Action(1 << randRange(0, int(Action::NumActions))) per agent
+// and tick, NumActions = 11 (env.hpp:22-42; bit 0 is no action at all).  Same counter-based generator and keying as above; the host twin is
+// megaverse_amd/rollout.py:sample_single_bit_masks.
+__device__ __forceinline__ int sampled_single_bit_mask(const GymView &gv, int env, int agent)
+{
+    const uint32_t gid = (uint32_t)(gv.env_offset + env * gv.env_stride) * (uint32_t)gv.num_agents + (uint32_t)agent;
+    const uint32_t base = fmix32(fmix32(gv.sample_seed ^ fmix32(gv.sample_step + 0x9E3779B9u)) ^ (gid * 0x85EBCA6Bu + 1u));
+    const uint32_t hsh = fmix32(base + 6u * 0xC2B2AE35u);   // (a head index the multi-discrete policy does not use)
+    return 1 << (int)(((uint64_t)hsh * 11ull) >> 32);
+}
+
 // the action mask agent `agent` of env `env` acts on this tick
 __device__ __forceinline__ int action_of(const GymView &gv, int env, int agent)
 {
-    return gv.sample_on ? sampled_action_mask(gv, env, agent) : gv.actions[(size_t)env * gv.num_agents + agent];
+    if (gv.sample_on == POLICY_MULTIDISCRETE) return sampled_action_mask(gv, env, agent);
+    if (gv.sample_on == POLICY_SINGLE_BIT) return sampled_single_bit_mask(gv, env, agent);
+    const size_t i = (size_t)env * gv.num_agents + agent;
+    return gv.md_actions ? action_mask_of(gv.md_actions + i * 6) : gv.actions[i];
 }
 
 }  // namespace

@@ -80,12 +80,13 @@ static const char *SHAPING_KEYS_COLLECT[5] = {"teamSpirit", "collectSingleGood",
 static const float SHAPING_DEFAULT_COLLECT[5] = {0.0f, 1.0f, -1.0f, 5.0f, -0.5f};
 static const int ACTION_SPACE[6] = {3, 3, 3, 2, 2, 3};                          // env.cpp:33
 
-static_assert(PIPE_BUFS == 3, "userMark events are created one by one in mv_create");
+static_assert(PIPE_GROUPS == 3, "userMark events are created one by one in mv_create");
 struct mv_gym {
     int device = 0;
     int w = 0, h = 0, renderW = 768, renderH = 432;   // megaverse.cpp:261
     int N = 0, A = 0, envOffset = 0, envStride = 1, totalEnvs = 0;
     bool samplePending = false;                  // mv_sample_random_actions: the next step draws its own actions
+    int samplePolicy = POLICY_MULTIDISCRETE;     // mv_set_sample_policy: which generator mv_sample_random_actions requests
     bool closed = false, wasReset = false;
     hipStream_t stream = nullptr;                // the caller's stream: observation passes, published outputs, everything it may consume
     // One-step-ahead pipelining: the step kernels run on an internal stream.  A step only waits for what the caller had
@@ -93,17 +94,29 @@ struct mv_gym {
     // pass of step t whenever nothing on the caller's stream feeds it (device-sampled or host-provided actions).  Everything a step
     // hands to the observation pass or to the caller exists PIPE_BUFS times: frame lists / headers / cost lists, and the rewards /
     // dones / true objectives, which the observation pass (on the caller's stream) publishes into the stable public arrays.
+    // Slots: PIPE_GROUPS groups of `batch` hand-over buffers.  One call -- mv_step (one tick) or mv_step_n (up to `batch` ticks) -- takes the
+    // next group; its step kernels wait for the mark recorded PIPE_GROUPS - 1 calls ago.  With k ticks per call the two cross-queue
+    // hand-overs (mark -> simulation stream, simDone -> caller's stream, ~10 us of command-processor time each) are paid once per k ticks.
     hipStream_t simStream = nullptr;
     int pipelined = 1;                           // mv_set_pipelining / MV_PIPELINE: 0 = everything on the caller's stream, in order
     bool simOnOwnStream = false;                 // where the last step ran
-    hipEvent_t userMark[PIPE_BUFS] = {};          // recorded on `stream` at the start of every mv_step, round-robin
+    hipEvent_t userMark[PIPE_GROUPS] = {};       // recorded on `stream` at the start of every stepping call, round-robin
     unsigned long long markCount = 0;             // (64 bits: a training run takes 2^31 steps in a day and a half)
     bool simMustWaitUser = true;                 // the caller's stream holds work the next step depends on (reset, render, device actions, ...)
     hipEvent_t simDone = nullptr;                // after the last kernel on simStream
     bool simDoneValid = false;
-    int parity = 0, hist3 = 0;                   // hand-over buffer of the last step (of PIPE_BUFS); cost histogram (of LPT_HISTS) of the last pass
-    GymView gvp[PIPE_BUFS];                      // gv with the buffers of each slot swapped in
+    int batch = 8, slots = PIPE_GROUPS * 8, hists = PIPE_GROUPS * 8 + 1;   // slots per group (MV_PIPE_BATCH), slots, cost histograms
+    int group = 0;                               // slot group of the last stepping call
+    int parity = 0, hist3 = 0;                   // hand-over slot of the last tick; cost histogram of the last pass
+    std::vector<GymView> gvp;                    // [slots] gv with the buffers of each slot swapped in
     GymView gv{};
+    const int32_t *mdActions = nullptr;          // mv_set_actions_device: the caller's multi-discrete buffer, read by the next step kernel
+    // mv_set_output_ring: tick number t (since the ring was set) leaves its observations / rewards / dones in entry t % ringCount
+    int ringCount = 0;
+    unsigned long long ringTick = 0;
+    uint8_t *ringObs = nullptr, *ringDone = nullptr;
+    float *ringRewards = nullptr;
+    std::string warning;                         // soft conditions (capacity flags) of the last call: returned as 1, not as an error
     uint8_t *arena = nullptr;
     uint32_t *obs = nullptr, *ownedObs = nullptr, *hiresObs = nullptr;
     int hiresW = 0, hiresH = 0;
@@ -145,9 +158,11 @@ struct mv_gym {
     bool stepDoneValid = false;
     std::vector<hipEvent_t> uploadEvents;           // ring, one per upload batch
     hipEvent_t lastUpload = nullptr;                // the most recent batch (mv_reset: the caller's stream waits for it too)
+    bool uploadNotOnUser = false;                   // ... and a step that runs on the caller's stream has not waited for it yet
     size_t uploadRing = 0;
     // in-stream profiling
-    std::vector<hipEvent_t> profEvents;          // 5 per profiled step
+    std::vector<hipEvent_t> profEvents;          // 5 per profiled tick: [0] [1] around the step kernel (its stream), [2] [3] [4] before the
+                                                 // observation pass, between frame sort and raster, after the raster (the caller's stream)
     int profMax = 0, profCount = 0;
 };
 
@@ -178,6 +193,7 @@ __global__ void publish_kernel(const float *s_rew, const uint8_t *s_done, const 
     if (i < n_envs) done[i] = s_done[i];
 }
 
+__global__ void clear_flags_kernel(int *word, int reported) { atomicAnd(word, ~reported); }   // only the bits that were reported: a bit raised since stays
 __global__ void set_shaping_kernel(AgentState *agents, int idx, int key, float v) { agents[idx].shaping[key] = v; }
 __global__ void set_agent_pos_kernel(AgentState *agents, int idx, float x, float y, float z) { agents[idx].pos[0] = x; agents[idx].pos[1] = y; agents[idx].pos[2] = z; }
 
@@ -228,24 +244,42 @@ static int check(mv_gym *g)
     return 0;
 }
 
+// Where a tick's public outputs go: the observation slab and the reward / done arrays -- or, with mv_set_output_ring, entry (tick % count)
+// of the caller's rings.  true_objective is state (only a finishing env records it, vector_env.cpp:96-101): never ringed.
+struct OutPtrs { uint32_t *obs; float *rewards; uint8_t *done; };
+static OutPtrs outputs_of(const mv_gym *g, unsigned long long tick)
+{
+    OutPtrs o{g->obs, g->gv.rewards, g->gv.done};
+    if (g->ringCount > 0) {
+        const size_t r = (size_t)(tick % (unsigned long long)g->ringCount), NA = (size_t)g->N * g->A;
+        if (g->ringObs) o.obs = reinterpret_cast<uint32_t *>(g->ringObs + r * NA * (size_t)g->w * g->h * 4);
+        if (g->ringRewards) o.rewards = g->ringRewards + r * NA;
+        if (g->ringDone) o.done = g->ringDone + r * (size_t)g->N;
+    }
+    return o;
+}
+static OutPtrs last_outputs(const mv_gym *g) { return outputs_of(g, g->ringTick ? g->ringTick - 1 : 0); }   // of the last tick (reset / render / getters)
+
 static int refresh_mirrors(mv_gym *g)
 {
     if (g->mirrorsFresh) return 0;
     const size_t NA = (size_t)g->N * g->A;
-    HIP_TRY(hipMemcpyAsync(g->hRewards.data(), g->gv.rewards, NA * sizeof(float), hipMemcpyDeviceToHost, g->stream));
+    const OutPtrs o = last_outputs(g);
+    HIP_TRY(hipMemcpyAsync(g->hRewards.data(), o.rewards, NA * sizeof(float), hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(hipMemcpyAsync(g->hTrueObj.data(), g->gv.true_objective, NA * sizeof(float), hipMemcpyDeviceToHost, g->stream));
-    HIP_TRY(hipMemcpyAsync(g->hDone.data(), g->gv.done, (size_t)g->N, hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipMemcpyAsync(g->hDone.data(), o.done, (size_t)g->N, hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
     g->mirrorsFresh = true;
     return 0;
 }
 
-// the view a kernel launch gets: the buffers of step parity q, this pass's cost histogram, the action-sampling request
-static GymView view(const mv_gym *g, int q, bool direct = false)   // direct: the step writes the public output arrays itself (not pipelined)
+// the view a kernel launch gets: the buffers of slot q, this pass's cost histogram, the action-sampling request
+static GymView view(const mv_gym *g, int q, const OutPtrs *direct = nullptr)   // direct: the step writes the public output arrays itself (not pipelined)
 {
     GymView v = g->gvp[q];
-    if (direct) { v.rewards = g->gv.rewards; v.done = g->gv.done; v.true_objective = g->gv.true_objective; }
+    if (direct) { v.rewards = direct->rewards; v.done = direct->done; v.true_objective = g->gv.true_objective; }
     v.sample_on = g->gv.sample_on; v.sample_seed = g->gv.sample_seed; v.sample_step = g->gv.sample_step;
+    v.md_actions = nullptr;
     v.lpt_parity = g->hist3;
     return v;
 }
@@ -259,11 +293,11 @@ static int sim_join(mv_gym *g)
     return 0;
 }
 
-static int publish_outputs(mv_gym *g, int q)   // on the caller's stream
+static int publish_outputs(mv_gym *g, int q, const OutPtrs &o)   // on the caller's stream
 {
     const GymView &v = g->gvp[q];
     const int n = g->N * g->A;
-    hipLaunchKernelGGL(publish_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, v.rewards, v.done, v.true_objective, g->gv.rewards, g->gv.done,
+    hipLaunchKernelGGL(publish_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, v.rewards, v.done, v.true_objective, o.rewards, o.done,
                        g->gv.true_objective, g->N, g->A);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -272,6 +306,13 @@ static int publish_outputs(mv_gym *g, int q)   // on the caller's stream
 extern "C" {
 
 const char *mv_last_error(void) { return g_err.c_str(); }
+
+int mv_device_count(void)
+{
+    int n = 0;
+    if (hipInit(0) != hipSuccess || hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
 
 int mv_action_space_sizes(int32_t *out6)
 {
@@ -350,6 +391,12 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     g->gv.sample_on = 0; g->gv.sample_seed = g->gv.sample_step = 0;
     g->gv.env_offset = g->envOffset; g->gv.env_stride = g->envStride;
     g->totalEnvs = cfg->total_envs > 0 ? cfg->total_envs : cfg->num_envs;
+    if (const char *e = getenv("MV_PIPE_BATCH")) g->batch = std::min((int)PIPE_BATCH_MAX, std::max(1, atoi(e)));   // ticks per call of mv_step_n
+    g->slots = PIPE_GROUPS * g->batch;
+    g->hists = g->slots + 1;
+    g->gvp.resize((size_t)g->slots);
+    g->parity = g->slots - 1;
+    g->group = PIPE_GROUPS - 1;
     const size_t N = g->N, NA = (size_t)g->N * g->A;
 
     GymView &gv = g->gv;
@@ -378,10 +425,11 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     gv.spares = g->spares;
     const size_t szVisP = up(NA * (size_t)gv.vis_stride * 32), szVisR = up(NA * (size_t)gv.vis_stride * 8), szVisC = up(NA * sizeof(int32_t)),
                  szLpt = up(NA * sizeof(int32_t)) + up((NA + 1) * sizeof(int32_t)) + up(NA * (size_t)FRAME_HDR_BYTES) + up(256 * NA * sizeof(int32_t));
-    // per step parity (x 2): frame lists, headers, cost lists, and the staging copies of rewards / dones / true objectives
-    const size_t szParity = szVisP + szVisR + szVisC + szLpt + szRew + szDone + szObjv, szHist = up(LPT_HISTS * 256 * sizeof(int32_t));
+    // per slot: frame lists, headers, cost lists, and the staging copies of rewards / dones / true objectives
+    const size_t szParity = szVisP + szVisR + szVisC + szLpt + szRew + szDone + szObjv, szHist = up((size_t)g->hists * 256 * sizeof(int32_t));
+    gv.lpt_hists = g->hists;
     const size_t total = szHdr + szBoxes + szObj + szAg + szAct + szRew + szDone + szObjv + szMd + (hostEpisodes ? 0 : szChunk) + szObs + szTerrain +
-                         szRewObj + szHeight + szItems + szCells + szHexB + szHexO + szBlobs + szCnt + PIPE_BUFS * szParity + szHist;
+                         szRewObj + szHeight + szItems + szCells + szHexB + szHexO + szBlobs + szCnt + (size_t)g->slots * szParity + szHist;
     {
         hipError_t e_ = hipMalloc((void **)&g->arena, total);
         if (e_ != hipSuccess) { mv_destroy(g); return fail(std::string("hipMalloc arena: ") + hipGetErrorString(e_)); }
@@ -413,7 +461,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
         if (sokoban) { gv.soko_cells = p; p += szCells; }
         if (hex) { gv.hex_boxes = (HexRec *)p; p += szHexB; gv.hex_objs = (HexRec *)p; p += szHexO; }
         gv.lpt_hist = (int32_t *)p; p += szHist;
-        for (int q = 0; q < PIPE_BUFS; ++q) {   // gv.rewards / done / true_objective stay the public arrays; the slot views write their own
+        for (int q = 0; q < g->slots; ++q) {   // gv.rewards / done / true_objective stay the public arrays; the slot views write their own
             GymView &v = g->gvp[q];
             v = gv;
             v.vis_prims = p; p += szVisP;
@@ -521,7 +569,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     {
         std::vector<int32_t> iota(NA);
         for (size_t i = 0; i < NA; ++i) iota[i] = (int32_t)i;
-        for (int q = 0; q < PIPE_BUFS; ++q) (void)hipMemcpy(g->gvp[q].lpt_order, iota.data(), NA * sizeof(int32_t), hipMemcpyHostToDevice);   // identity until the first frame sort
+        for (int q = 0; q < g->slots; ++q) (void)hipMemcpy(g->gvp[q].lpt_order, iota.data(), NA * sizeof(int32_t), hipMemcpyHostToDevice);   // identity until the first frame sort
     }
     if (hipMemcpy(gv.hdr, hh.data(), N * sizeof(EnvHeader), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(gv.agents, ha.data(), NA * sizeof(AgentState), hipMemcpyHostToDevice) != hipSuccess) {
@@ -670,15 +718,16 @@ int mv_render(mv_gym *g)
     if (check(g)) return -1;
     HIP_TRY(hipSetDevice(g->device));
     if (sim_join(g)) return -1;
-    g->hist3 = (g->hist3 + 1) % LPT_HISTS;
-    if (launch_raster(view(g, g->parity), g->obs, g->w, g->h, g->stream, nullptr, g->fastPixels)) return fail("mv_render: observation size above 1024x1024");
+    g->hist3 = (g->hist3 + 1) % g->hists;
+    if (launch_raster(view(g, g->parity), last_outputs(g).obs, g->w, g->h, g->stream, nullptr, g->fastPixels)) return fail("mv_render: observation size above 1024x1024");
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 // ---- status flags ----------------------------------------------------------------------------------------------------
 // Kernels raise ST_* bits in status[N + 1], the host generators GEN_* bits (mv_gen.h); both are limits the reference does not
-// have.  They are reported ONCE, by the mv_step / mv_reset that sees them, and cleared: the gym stays usable.
+// have.  They are reported ONCE, by the mv_step / mv_reset that sees them, and cleared: the gym stays usable.  They are WARNINGS: the call
+// that reports one does all of its work and returns 1 instead of 0 (mv_last_error() has the text); -1 stays what it was, a real failure.
 static int check_status_flags(mv_gym *g)
 {
     const int N = g->N;
@@ -694,11 +743,22 @@ static int check_status_flags(mv_gym *g)
     if (gen & GEN_OBJECTS) msg += "more than 80 movable boxes in a generated episode; ";
     if (gen & GEN_REWARDS) msg += "more reward objects than an episode record holds (16, Collect 96); ";
     if (gen & GEN_COORDS) msg += "a generated level extends beyond +-127 voxels (int8 object coordinates); ";
-    if (flags) {   // clear the device word (and the mirror) so that the next step runs
+    if (flags) {   // clear the reported bits in the device word (and the mirror): a bit a kernel raised after this read-back is reported next time
         g->hStatus[N + 1] = 0;
-        HIP_TRY(hipMemsetAsync(g->dStatus + N + 1, 0, sizeof(int), g->simOnOwnStream ? g->simStream : g->stream));
+        hipLaunchKernelGGL(clear_flags_kernel, dim3(1), dim3(1), 0, g->simOnOwnStream ? g->simStream : g->stream, g->dStatus + N + 1, flags);
+        HIP_TRY(hipGetLastError());
     }
-    return fail("capacity limit hit: " + msg + "reported once, simulation continues");
+    if (!g->warning.empty()) g->warning += " | ";
+    g->warning += "capacity limit hit: " + msg + "reported once, this call did all of its work";
+    return 1;
+}
+// what a call that did its work returns: 0, or 1 with the warning text where mv_last_error() finds it
+static int finish_with_warning(mv_gym *g)
+{
+    if (g->warning.empty()) return 0;
+    g_err = g->warning;
+    g->warning.clear();
+    return 1;
 }
 
 // ---- episode refill protocol (host-generated scenarios) --------------------------------------------------------------
@@ -761,14 +821,15 @@ static int refill_episodes(mv_gym *g)
         if (!batch.empty()) {
             HIP_TRY(hipEventRecord(ev, g->copyStream));
             for (int i : batch) g->feeder->recycle(i, ev);   // regenerate a slot only once its upload has left it
-            HIP_TRY(hipStreamWaitEvent(g->pipelined ? g->simStream : g->stream, ev, 0));   // (mv_reset, and a step in the exact pixel mode, wait for lastUpload themselves)
+            HIP_TRY(hipStreamWaitEvent(g->simStream, ev, 0));   // (a step that runs on the caller's stream, and mv_reset, wait for lastUpload themselves)
             g->lastUpload = ev;
+            g->uploadNotOnUser = true;
         }
         g->deficit = deficit;
         g->lastTotalSeen = g->hStatus[N];
         g->refillForce = false;
     }
-    return check_status_flags(g);
+    return check_status_flags(g) < 0 ? -1 : 0;
 }
 
 // after a step / reset kernel: read the status words back without touching the step path
@@ -798,9 +859,10 @@ int mv_reset(mv_gym *g)
         g->pendingAge = 0;
         g->stepsSinceStatus = 0;
         g->refillForce = true;
-        if (refill_episodes(g)) return -1;              // every env has an unconsumed episode resident
+        if (refill_episodes(g) < 0) return -1;          // every env has an unconsumed episode resident
         if (g->lastUpload) HIP_TRY(hipStreamWaitEvent(g->stream, g->lastUpload, 0));
-        const GymView v = view(g, g->parity, true);
+        const OutPtrs outs = last_outputs(g);
+        const GymView v = view(g, g->parity, &outs);
         if (g->scenario == SCN_OBSTACLES || g->scenario == SCN_EMPTY) launch_reset_obstacles(v, (const EpisodeBlob *)g->dBlobs, g->dStatus, 1, g->stream);
         else if (g->scenario == SCN_REARRANGE) launch_reset_rearrange(v, (const RearrangeBlob *)g->dBlobs, g->dStatus, 1, g->stream);
         else if (g->scenario == SCN_SOKOBAN) launch_reset_sokoban(v, (const SokobanBlob *)g->dBlobs, g->dStatus, 1, g->stream);
@@ -809,12 +871,15 @@ int mv_reset(mv_gym *g)
         HIP_TRY(hipEventRecord(g->stepDone, g->stream));   // (the reset kernel reads the ring too)
         g->stepDoneValid = true;
         if (read_back_status(g, g->stream)) return -1;  // the second resident episodes go up with the next steps
-    } else
-        launch_reset(view(g, g->parity, true), 1, g->stream);
+    } else {
+        const OutPtrs outs = last_outputs(g);
+        launch_reset(view(g, g->parity, &outs), 1, g->stream);
+    }
     HIP_TRY(hipGetLastError());
     g->wasReset = true;
     g->mirrorsFresh = false;
-    return mv_render(g);
+    if (mv_render(g)) return -1;
+    return finish_with_warning(g);
 }
 
 int mv_set_actions(mv_gym *g, int32_t env, int32_t agent, const int32_t *actions, int32_t n)
@@ -848,10 +913,30 @@ int mv_set_actions_device(mv_gym *g, const int32_t *device_actions)
 {
     if (check(g)) return -1;
     HIP_TRY(hipSetDevice(g->device));
-    const int n = g->N * g->A;
-    hipLaunchKernelGGL(masks_from_multidiscrete_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, device_actions, g->gv.actions, n);
-    HIP_TRY(hipGetLastError());
+    if (!device_actions) return fail("mv_set_actions_device: null pointer");
+    // No launch here: the next step kernel converts multi-discrete -> bitmask itself (mv_actions.h: action_of), one kernel boundary less per
+    // tick of a policy in the loop.  The buffer is read when that step kernel runs, in the order of the caller's stream.
+    g->mdActions = device_actions;
     g->simMustWaitUser = true;   // the actions come from the caller's stream (a policy that read the last observations): a true dependency
+    return 0;
+}
+
+int mv_set_sample_policy(mv_gym *g, int32_t policy)
+{
+    if (check(g)) return -1;
+    if (policy != MV_POLICY_MULTIDISCRETE && policy != MV_POLICY_SINGLE_BIT) return fail("mv_set_sample_policy: MV_POLICY_MULTIDISCRETE (1) or MV_POLICY_SINGLE_BIT (2)");
+    g->samplePolicy = policy;
+    return 0;
+}
+
+int mv_set_output_ring(mv_gym *g, int32_t count, void *obs, float *rewards, uint8_t *dones)
+{
+    if (check(g)) return -1;
+    if (count < 0 || (count > 0 && !obs && !rewards && !dones)) return fail("mv_set_output_ring: count >= 0 and at least one ring required");
+    if (sim_join(g)) return -1;   // (ticks in flight keep the pointers they were given)
+    g->ringCount = count; g->ringTick = 0;
+    g->ringObs = count ? (uint8_t *)obs : nullptr; g->ringRewards = count ? rewards : nullptr; g->ringDone = count ? dones : nullptr;
+    g->mirrorsFresh = false;
     return 0;
 }
 
@@ -864,28 +949,44 @@ int mv_sample_random_actions(mv_gym *g, uint32_t seed, uint32_t step)
     return 0;
 }
 
-static int step_impl(mv_gym *g, bool render)
+static void launch_step_of(const mv_gym *g, const GymView &v, hipStream_t sim, int fused)
+{
+    if (g->scenario == SCN_OBSTACLES || g->scenario == SCN_EMPTY) launch_step_obstacles(v, sim, g->w, g->h, fused);
+    else if (g->scenario == SCN_COLLECT) launch_step_collect(v, sim, g->w, g->h, fused);
+    else if (g->scenario == SCN_REARRANGE) launch_step_rearrange(v, sim, g->w, g->h, fused);
+    else if (g->scenario == SCN_SOKOBAN) launch_step_sokoban(v, sim, g->w, g->h, fused);
+    else if (g->scenario == SCN_HEX_MEMORY || g->scenario == SCN_HEX_EXPLORE) launch_step_hex(v, sim, g->w, g->h, fused);
+    else launch_step(v, sim, g->w, g->h, fused);
+}
+
+// One stepping call = k ticks (mv_step: 1; mv_step_n: up to `batch`).  policy != POLICY_NONE: tick j draws its actions inside the step kernel
+// from (seed, first_index + j); POLICY_NONE: the first tick acts on what mv_set_actions* left, the following ones on cleared actions
+// (env.cpp:141-142 clears them after every tick).
+static int step_impl(mv_gym *g, bool render, int k, int policy, uint32_t seed, uint32_t first_index)
 {
     if (check(g)) return -1;
     if (!g->wasReset) return fail("mv_step: call mv_reset first");
+    if (k < 1 || k > g->batch) return fail("mv_step_n: 1 <= k <= " + std::to_string(g->batch) + " (MV_PIPE_BATCH) required");
     HIP_TRY(hipSetDevice(g->device));
-    if (refill_episodes(g)) return -1;
-    // ---- what this step must wait for on the caller's stream.  Always: whatever was there when the step PIPE_BUFS - 1 calls ago began --
-    // the observation pass and the consumers of the step that used this slot's buffers last.  Everything, when the caller's stream
+    if (refill_episodes(g) < 0) return -1;
+    // ---- what this call must wait for on the caller's stream.  Always: whatever was there when the call PIPE_GROUPS - 1 calls ago began --
+    // the observation passes and the consumers of the call that used this slot group last.  Everything, when the caller's stream
     // feeds the simulation (reset / render / device actions / test hooks since the last step).  (Both raster kernels read nothing but the
     // frame lists and headers of their tick: the simulator state may move on underneath them.)
-    // Not pipelined (mv_set_pipelining(0)): the step runs on the caller's stream like everything else -- a hand-over between two hardware
-    // queues costs ~10 us each way, which only pays when something overlaps.
-    const bool own = g->pipelined != 0;
+    // Not pipelined (mv_set_pipelining(0)), or ONE tick whose inputs come from the caller's stream (a policy in the loop: nothing can overlap,
+    // the two queue hand-overs, ~10 us each, would be pure cost): the step runs on the caller's stream like everything else.
+    const bool own = g->pipelined != 0 && !(g->simMustWaitUser && k == 1);
     hipStream_t sim = own ? g->simStream : g->stream;
     if (own) {
-        hipEvent_t mark = g->userMark[g->markCount % PIPE_BUFS];
+        hipEvent_t mark = g->userMark[g->markCount % PIPE_GROUPS];
         HIP_TRY(hipEventRecord(mark, g->stream));
         if (g->simMustWaitUser || !g->simOnOwnStream) HIP_TRY(hipStreamWaitEvent(sim, mark, 0));   // (or the last step ran on the caller's stream)
-        else if (g->markCount >= PIPE_BUFS - 1) HIP_TRY(hipStreamWaitEvent(sim, g->userMark[(g->markCount - (PIPE_BUFS - 1)) % PIPE_BUFS], 0));
+        else if (g->markCount >= PIPE_GROUPS - 1) HIP_TRY(hipStreamWaitEvent(sim, g->userMark[(g->markCount - (PIPE_GROUPS - 1)) % PIPE_GROUPS], 0));
         ++g->markCount;
     } else {
         if (g->simOnOwnStream && g->simDoneValid) HIP_TRY(hipStreamWaitEvent(sim, g->simDone, 0));   // the last step ran on the other stream
+        if (g->uploadNotOnUser && g->lastUpload) HIP_TRY(hipStreamWaitEvent(sim, g->lastUpload, 0));  // (episode uploads make the simulation stream wait)
+        g->uploadNotOnUser = false;
         g->markCount = 0;
     }
     g->simMustWaitUser = false;
@@ -899,55 +1000,93 @@ static int step_impl(mv_gym *g, bool render)
         std::memset(g->hActions[g->stage], 0, (size_t)g->N * g->A * sizeof(int32_t));   // actions are cleared every tick (env.cpp:141-142)
         g->actionsDirty = false;
     }
-    g->gv.sample_on = g->samplePending ? 1 : 0;
-    g->samplePending = false;
-    const bool prof = render && g->profCount < g->profMax;
-    hipEvent_t *ev = prof ? &g->profEvents[(size_t)g->profCount * 5] : nullptr;
-    if (prof) HIP_TRY(hipEventRecord(ev[0], sim));
     const int fused = render ? 1 : 0;   // the step kernel also builds the frame lists when an observation pass follows
-    g->parity = (g->parity + 1) % PIPE_BUFS;
-    if (render) g->hist3 = (g->hist3 + 1) % LPT_HISTS;   // (this pass's frame setup fills the next cost histogram and clears the one after)
-    const GymView v = view(g, g->parity, !own);
-    if (g->scenario == SCN_OBSTACLES || g->scenario == SCN_EMPTY) launch_step_obstacles(v, sim, g->w, g->h, fused);
-    else if (g->scenario == SCN_COLLECT) launch_step_collect(v, sim, g->w, g->h, fused);
-    else if (g->scenario == SCN_REARRANGE) launch_step_rearrange(v, sim, g->w, g->h, fused);
-    else if (g->scenario == SCN_SOKOBAN) launch_step_sokoban(v, sim, g->w, g->h, fused);
-    else if (g->scenario == SCN_HEX_MEMORY || g->scenario == SCN_HEX_EXPLORE) launch_step_hex(v, sim, g->w, g->h, fused);
-    else launch_step(v, sim, g->w, g->h, fused);
-    if (prof) HIP_TRY(hipEventRecord(ev[1], sim));
+    g->group = (g->group + 1) % PIPE_GROUPS;
+    GymView views[PIPE_BATCH_MAX];
+    OutPtrs outs[PIPE_BATCH_MAX];
+    hipEvent_t *evs[PIPE_BATCH_MAX];
+    // ---- the k step kernels, back to back on the simulation stream
+    for (int j = 0; j < k; ++j) {
+        const bool prof = render && g->profCount < g->profMax;
+        evs[j] = prof ? &g->profEvents[(size_t)g->profCount * 5] : nullptr;
+        if (prof) ++g->profCount;
+        if (policy != POLICY_NONE) { g->gv.sample_on = policy; g->gv.sample_seed = seed; g->gv.sample_step = first_index + (uint32_t)j; }
+        else { g->gv.sample_on = (j == 0 && g->samplePending) ? g->samplePolicy : (int)POLICY_NONE; }
+        g->parity = g->group * g->batch + j;
+        if (render) g->hist3 = (g->hist3 + 1) % g->hists;   // (this pass's frame setup fills the next cost histogram and clears the one after)
+        outs[j] = outputs_of(g, g->ringTick++);
+        views[j] = view(g, g->parity, own ? nullptr : &outs[j]);
+        if (j == 0 && g->gv.sample_on == POLICY_NONE) views[j].md_actions = g->mdActions;
+        if (evs[j]) HIP_TRY(hipEventRecord(evs[j][0], sim));
+        launch_step_of(g, views[j], sim, fused);
+        if (evs[j]) HIP_TRY(hipEventRecord(evs[j][1], sim));
+    }
+    g->samplePending = false;
+    g->mdActions = nullptr;
     if (own) { HIP_TRY(hipEventRecord(g->simDone, sim)); g->simDoneValid = true; }   // (not pipelined: stream order does it)
     // (every step kernel regenerates / swaps the next episode into the envs it finishes)
     // An env needs a fresh resident episode only at its NEXT reset, normally hundreds of steps away, and two are resident: the status
     // words are read back -- and the refill considered -- every statusPeriod-th step (16; 1 when episodes can be a few ticks long).
     if (g->hostEpisodes()) { HIP_TRY(hipEventRecord(g->stepDone, sim)); g->stepDoneValid = true; }
-    if (++g->stepsSinceStatus >= g->statusPeriod) {   // (TowerBuilding regenerates finished envs in the kernel: only the error flags matter)
+    g->stepsSinceStatus += k;
+    if (g->stepsSinceStatus >= g->statusPeriod) {   // (TowerBuilding regenerates finished envs in the kernel: only the error flags matter)
         if (read_back_status(g, sim)) return -1;
         g->stepsSinceStatus = 0;
     }
-    if (prof) HIP_TRY(hipEventRecord(ev[2], sim));
-    // ---- the caller's stream: the step's outputs, then the observation pass
+    // ---- the caller's stream: per tick the step's outputs, then the observation pass
     if (own) HIP_TRY(hipStreamWaitEvent(g->stream, g->simDone, 0));
-    const PublishTo pub{g->gv.rewards, g->gv.done, g->gv.true_objective};
-    if (own && (!render || !g->fastPixels) && publish_outputs(g, g->parity)) return -1;   // (the fast observation pass publishes with its first workgroups)
-    if (render && launch_raster(v, g->obs, g->w, g->h, g->stream, prof ? ev[3] : nullptr, g->fastPixels, /*setup_done=*/1, own && g->fastPixels ? &pub : nullptr)) return fail("mv_step: observation size above 1024x1024");
-    if (prof) { HIP_TRY(hipEventRecord(ev[4], g->stream)); ++g->profCount; }
+    for (int j = 0; j < k; ++j) {
+        if (evs[j]) HIP_TRY(hipEventRecord(evs[j][2], g->stream));
+        const PublishTo pub{outs[j].rewards, outs[j].done, g->gv.true_objective};
+        if (own && (!render || !g->fastPixels) && publish_outputs(g, g->group * g->batch + j, outs[j])) return -1;   // (the fast observation pass publishes with its first workgroups)
+        if (render && launch_raster(views[j], outs[j].obs, g->w, g->h, g->stream, evs[j] ? evs[j][3] : nullptr, g->fastPixels, /*setup_done=*/1, own && g->fastPixels ? &pub : nullptr))
+            return fail("mv_step: observation size above 1024x1024");
+        if (evs[j]) { if (!render) HIP_TRY(hipEventRecord(evs[j][3], g->stream)); HIP_TRY(hipEventRecord(evs[j][4], g->stream)); }
+    }
     HIP_TRY(hipGetLastError());
     g->mirrorsFresh = false;
-    return 0;
+    return finish_with_warning(g);
 }
 
-int mv_step(mv_gym *g) { return step_impl(g, true); }
-int mv_step_no_render(mv_gym *g) { return step_impl(g, false); }
+int mv_step(mv_gym *g) { return step_impl(g, true, 1, POLICY_NONE, 0, 0); }
+int mv_step_no_render(mv_gym *g) { return step_impl(g, false, 1, POLICY_NONE, 0, 0); }
+
+int mv_step_n(mv_gym *g, int32_t k, int32_t policy, uint32_t seed, uint32_t first_step_index)
+{
+    if (check(g)) return -1;
+    if (policy != MV_POLICY_NONE && policy != MV_POLICY_MULTIDISCRETE && policy != MV_POLICY_SINGLE_BIT) return fail("mv_step_n: unknown policy");
+    if (k < 1) return fail("mv_step_n: k >= 1 required");
+    int rc = 0;
+    // Episodes that can end within a few ticks (statusPeriod 1: the refill protocol looks at the consumed counts after every tick) are
+    // stepped one tick per call; otherwise `batch` ticks at a time.
+    const int chunk = g->statusPeriod <= 1 ? 1 : g->batch;
+    for (int done = 0; done < k; done += chunk) {
+        const int n = std::min(chunk, k - done);
+        const int r = step_impl(g, true, n, policy, seed, first_step_index + (uint32_t)done);
+        if (r < 0) return -1;
+        if (r > 0) { g->warning = g_err; rc = 1; }
+    }
+    if (rc) { g_err = g->warning; g->warning.clear(); }
+    return rc;
+}
 
 int mv_step_many(mv_gym *const *gyms, int32_t n, int32_t render, int32_t sample, uint32_t seed, uint32_t step_index)
 {   // several gyms of one job (MultiTaskGym: one per scenario, one stream each) stepped by one call: at eight sub-gyms the per-call cost of
-    // the language binding is a third of the step
+    // the language binding is a third of the step.  EVERY gym is stepped, whatever another one reports: a failure (or a warning) is
+    // collected and returned after the loop, so the sub-gyms never get out of step with each other.
     if (!gyms || n < 0) return fail("mv_step_many: bad arguments");
+    int rc = 0;
+    std::string msgs;
     for (int i = 0; i < n; ++i) {
-        if (sample && mv_sample_random_actions(gyms[i], seed, step_index)) return -1;
-        if (step_impl(gyms[i], render != 0)) return -1;
+        int r = sample ? mv_sample_random_actions(gyms[i], seed, step_index) : 0;
+        if (r == 0) r = step_impl(gyms[i], render != 0, 1, POLICY_NONE, 0, 0);
+        if (r != 0) {
+            msgs += (msgs.empty() ? "gym " : " | gym ") + std::to_string(i) + ": " + g_err;
+            if (r < 0 || rc == 0) rc = r < 0 ? -1 : 1;
+        }
     }
-    return 0;
+    if (rc) g_err = msgs;
+    return rc;
 }
 
 int mv_synchronize(mv_gym *g)
@@ -978,11 +1117,15 @@ int mv_profile_end(mv_gym *g, float *avg_ms4, int32_t *counts4)
     if (check(g)) return -1;
     HIP_TRY(hipStreamSynchronize(g->simStream));
     HIP_TRY(hipStreamSynchronize(g->stream));
+    // every interval lies on ONE stream: [0] step kernel = events 0 -> 1 (the stream the step ran on); [2] publish / frame sort = 2 -> 3 and
+    // [3] raster = 3 -> 4 (the caller's stream).  [1] (the old status read-back gap) is gone: it spanned two streams when pipelined.
     double sum[4] = {0, 0, 0, 0};
+    static const int FROM[4] = {0, -1, 2, 3};
     for (int i = 0; i < g->profCount; ++i)
         for (int k = 0; k < 4; ++k) {
+            if (FROM[k] < 0) continue;
             float ms = 0.0f;
-            HIP_TRY(hipEventElapsedTime(&ms, g->profEvents[(size_t)i * 5 + k], g->profEvents[(size_t)i * 5 + k + 1]));
+            HIP_TRY(hipEventElapsedTime(&ms, g->profEvents[(size_t)i * 5 + FROM[k]], g->profEvents[(size_t)i * 5 + FROM[k] + 1]));
             sum[k] += ms;
         }
     for (int k = 0; k < 4; ++k) {
@@ -1037,7 +1180,7 @@ int mv_get_observation(mv_gym *g, int32_t env, int32_t agent, uint8_t *out)
     if (check(g)) return -1;
     if (env < 0 || env >= g->N || agent < 0 || agent >= g->A) return fail("mv_get_observation: index out of range");
     const size_t frameBytes = (size_t)g->w * g->h * 4;
-    HIP_TRY(hipMemcpyAsync(out, (const uint8_t *)g->obs + ((size_t)env * g->A + agent) * frameBytes, frameBytes, hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipMemcpyAsync(out, (const uint8_t *)last_outputs(g).obs + ((size_t)env * g->A + agent) * frameBytes, frameBytes, hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
     return 0;
 }
@@ -1065,7 +1208,7 @@ int mv_draw_hires(mv_gym *g)
         g->hiresW = g->renderW; g->hiresH = g->renderH;
     }
     if (sim_join(g)) return -1;
-    g->hist3 = (g->hist3 + 1) % LPT_HISTS;
+    g->hist3 = (g->hist3 + 1) % g->hists;
     if (launch_raster(view(g, g->parity), g->hiresObs, g->hiresW, g->hiresH, g->stream, nullptr, g->fastPixels)) return fail("mv_draw_hires: render size above 1024x1024");
     HIP_TRY(hipGetLastError());
     return 0;

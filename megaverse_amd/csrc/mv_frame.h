@@ -468,13 +468,13 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
         gv.lpt_bucket[frame] = bin;   // (exact raster kernel: frame_order_kernel sorts on these)
         // fast raster kernel: the frame appends itself to its bin; every raster workgroup prefix-sums the 256 bin counts in its prologue
         // and looks its frame up -- no sort kernel, no launch boundary.  The order inside a bin is whatever the atomics made it: it only
-        // schedules.  LPT_HISTS histograms rotate: this pass's raster reads one while the setups of the next steps -- which may run
+        // schedules.  gv.lpt_hists histograms rotate: this pass's raster reads one while the setups of the next steps -- which may run
         // concurrently, on the simulation stream (mv_api.hip) -- fill the following ones, each clearing the one after its own.
         const int r = atomicAdd(&gv.lpt_hist[gv.lpt_parity * LPT_BUCKETS + bin], 1);
         gv.lpt_list[(size_t)bin * (gv.num_envs * gv.num_agents) + r] = frame;
     }
-    if (frame == 0)   // the histogram the NEXT pass fills: last read by the raster PIPE_BUFS passes ago, which this step waited for
-        for (int i = tid; i < LPT_BUCKETS; i += THREADS) gv.lpt_hist[((gv.lpt_parity + 1) % LPT_HISTS) * LPT_BUCKETS + i] = 0;
+    if (frame == 0)   // the histogram the NEXT pass fills: last read by a raster pass as many passes ago as there are slots, which this step waited for
+        for (int i = tid; i < LPT_BUCKETS; i += THREADS) gv.lpt_hist[((gv.lpt_parity + 1) % gv.lpt_hists) * LPT_BUCKETS + i] = 0;
     sync();   // the LDS scratch above is reused by the next frame of this workgroup (fused step + setup kernels)
 }
 

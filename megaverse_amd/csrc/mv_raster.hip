@@ -534,6 +534,9 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 && !SHAPES ? MV_RASTER_WAVES : M
 // =====================================================================================================================
 namespace {
 
+#ifndef MV_FAST_PPL_DEFAULT
+#define MV_FAST_PPL_DEFAULT 2   // pixels per lane of raster_fast_kernel (MV_FAST_PPL overrides at run time)
+#endif
 constexpr float SPEC_COS2 = 0.97f * 0.97f;
 
 struct FastArgs {   // what raster_fast_kernel needs of the GymView (fewer live SGPRs than the whole view)
@@ -785,10 +788,11 @@ __device__ __forceinline__ FastFrame fast_prologue(const FastArgs &fa, int W, in
     return FastFrame{frame, part, viewer, nVis};
 }
 
-// the boxes of one frame of reference among list positions 64 k .. 64 k + 63 (mask m) against this lane's ray, given the ray's inverse
-// direction in that frame: the next record is fetched from LDS while the current one is intersected
-template <unsigned POS_MASK>
-__device__ __forceinline__ void box_run(unsigned long long m, int k, V3 inv, const float4 *s_vis, unsigned &best)
+// the boxes of one frame of reference among list positions 64 k .. 64 k + 63 (mask m) against this lane's NP rays, given each ray's inverse
+// direction in that frame: the next record is fetched from LDS while the current one is intersected (with NP = 2 a record fetched once serves
+// two pixels, and the two slab tests are independent instruction chains)
+template <unsigned POS_MASK, int NP>
+__device__ __forceinline__ void box_run(unsigned long long m, int k, const V3 (&inv)[NP], const float4 *s_vis, unsigned (&best)[NP])
 {
     if (!m) return;
     int p0 = __ffsll((long long)m) - 1 + 64 * k, p1 = 0;
@@ -797,11 +801,13 @@ __device__ __forceinline__ void box_run(unsigned long long m, int k, V3 inv, con
     for (;;) {
         bool more = m != 0ull;
         if (more) { p1 = __ffsll((long long)m) - 1 + 64 * k; m &= m - 1; lo1 = s_vis[2 * p1]; hi1 = s_vis[2 * p1 + 1]; }
-        best = min(best, box_key<POS_MASK>(inv, lo0, hi0, p0));
+#pragma unroll
+        for (int j = 0; j < NP; ++j) best[j] = min(best[j], box_key<POS_MASK>(inv[j], lo0, hi0, p0));
         if (!more) break;
         more = m != 0ull;
         if (more) { p0 = __ffsll((long long)m) - 1 + 64 * k; m &= m - 1; lo0 = s_vis[2 * p0]; hi0 = s_vis[2 * p0 + 1]; }
-        best = min(best, box_key<POS_MASK>(inv, lo1, hi1, p1));
+#pragma unroll
+        for (int j = 0; j < NP; ++j) best[j] = min(best[j], box_key<POS_MASK>(inv[j], lo1, hi1, p1));
         if (!more) break;
     }
 }
@@ -815,16 +821,20 @@ __device__ __forceinline__ void box_run(unsigned long long m, int k, V3 inv, con
 // (Measured and rejected for these long lists, ~700 primitives per frame: a two-level variant -- a wave culls the list against a block of 2 x 2
 // tiles once and its tiles only look at the survivors -- 164 / 187 us against 170 / 189 us at 128 x 128 and slower at 64 x 64: the time
 // goes into intersecting the ~19 boxes that survive per tile, not into the rectangle tests.)
-template <int MAXVIS, bool SHAPES, int WAVES, bool HEXF = false>   // WAVES: waves per SIMD the variant is compiled for (register budget 512 / WAVES)
+// NP (pixels per lane): a wave's tile is 16 x (4 NP) pixels, lane (lx, ly) traces rows ty0 + ly, ty0 + ly + 4, ...  With NP = 2 the culling
+// ballots, the scalar loop control, the LDS fetch of every surviving record and the column terms of the ray are paid once per two pixels,
+// and the two pixels' dependency chains (rcp -> slab test -> key, shading) interleave; per-pixel arithmetic is unchanged, and culling being
+// conservative the pixels are identical to NP = 1 (tests/test_fast_pixels_gpu.py: test_pixels_per_lane_variants_agree).
+template <int MAXVIS, bool SHAPES, int WAVES, bool HEXF = false, int NP = 1>   // WAVES: waves per SIMD the variant is compiled for (register budget 512 / WAVES)
 __global__ __launch_bounds__(256, WAVES) void raster_fast_kernel(FastArgs fa, uint32_t *obs, int W, int H, int split)
 {
-    constexpr int ROUNDS = MAXVIS / 64;
     constexpr unsigned POS_MASK = MAXVIS - 1;
+    constexpr int TH = TILE_H * NP;           // tile height
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     __shared__ float4 s_vis[2 * MAXVIS];      // Prim records as (lo, meta) (hi, colour)
     __shared__ short4 s_rect[MAXVIS];
     __shared__ __attribute__((aligned(16))) float s_hdr[FH_FLOATS];
-    static_assert(ROUNDS <= 16, "world-box masks: 16 x 64 positions");
+    static_assert(MAXVIS / 64 <= 16, "world-box masks: 16 x 64 positions");
 
     float4 *s_col = reinterpret_cast<float4 *>(s_dyn);   // per column i: (dc.x, c00*dc.x, c10*dc.x, c20*dc.x)
     float4 *s_row = s_col + W;                            // per row j:    (dc.y, c01*dc.y, c11*dc.y, c21*dc.y)
@@ -839,24 +849,30 @@ __global__ __launch_bounds__(256, WAVES) void raster_fast_kernel(FastArgs fa, ui
     const float *camv = s_hdr + FH_CAM + FH_CAM_STRIDE * viewer;   // eye(3) c(9) origin(3)
     const float nzm0 = uniform_f32(-camv[3 + 2]), nzm1 = uniform_f32(-camv[3 + 5]), nzm2 = uniform_f32(-camv[3 + 8]);
     uint32_t *out = obs + (size_t)frame * W * H;
-    const int tilesX = (W + TILE_W - 1) / TILE_W, tilesY = (H + TILE_H - 1) / TILE_H;
+    const int tilesX = (W + TILE_W - 1) / TILE_W, tilesY = (H + TH - 1) / TH;
     const int numTiles = tilesX * tilesY;
     const int lx = lane & (TILE_W - 1), ly = lane / TILE_W;
 
     int tx = part * 4 + wave, ty = 0;   // tile = ty * tilesX + tx, advanced without a division
     for (int tile = part * 4 + wave; tile < numTiles; tile += 4 * split, tx += 4 * split) {
         while (tx >= tilesX) { tx -= tilesX; ++ty; }
-        const int tx0 = tx * TILE_W, ty0 = ty * TILE_H;
-        const int tx1 = min(tx0 + TILE_W, W) - 1, ty1 = min(ty0 + TILE_H, H) - 1;
-        const int px = tx0 + lx, py = ty0 + ly;
-        const bool inside = px < W && py < H;
-        const int pxc = min(px, W - 1), pyc = min(py, H - 1);
-        V3 dw = v3(0, 0, 0), inv = v3(0, 0, 0);
-        float ihx0 = 0.0f, ihz0 = 0.0f, ihx1 = 0.0f, ihz1 = 0.0f;   // HEXF: 1 / (ray direction x, z) in wall frames 0 and 1
-        float dcx = 0.0f, dcy = 0.0f, a2 = 0.0f, ldc = 0.0f;
-        bool rayReady = false;   // wave-uniform: the ray is set up when the first primitive survives the culling
-        unsigned best = ~0u;
-        V3 bn = v3(0, 0, 0);     // normal of the best hit when it is not a box (boxes recover theirs from the entry axis)
+        const int tx0 = tx * TILE_W, ty0 = ty * TH;
+        const int tx1 = min(tx0 + TILE_W, W) - 1, ty1 = min(ty0 + TH, H) - 1;
+        const int px = tx0 + lx, py0 = ty0 + ly;
+        const int pxc = min(px, W - 1);
+        V3 dw[NP], inv[NP];
+        V3 ih0[NP], ih1[NP], ih2[NP];   // HEXF: the ray's inverse direction in wall frames 0, 1, 2
+        float dcx = 0.0f, dcy[NP], a2[NP], ldc[NP];
+        unsigned best[NP];
+        V3 bn[NP];                       // normal of the best hit when it is not a box (boxes recover theirs from the entry axis)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            dw[j] = inv[j] = bn[j] = v3(0, 0, 0);
+            ih0[j] = ih1[j] = ih2[j] = v3(0, 0, 0);
+            dcy[j] = a2[j] = ldc[j] = 0.0f;
+            best[j] = ~0u;
+        }
+        bool rayReady = false;   // wave-uniform: the rays are set up when the first primitive survives the culling
 #pragma unroll 1
         for (int k = 0; k * 64 < nVis; ++k) {
             // ---- tile culling: one primitive per lane, four integer compares against its screen rectangle
@@ -868,70 +884,62 @@ __global__ __launch_bounds__(256, WAVES) void raster_fast_kernel(FastArgs fa, ui
             if (mvis == 0ull) continue;
             if (!rayReady) {
                 rayReady = true;
-                const float4 cx = s_col[pxc], ry = s_row[pyc];
-                const float2 rq = s_rowq[pyc];
-                dcx = cx.x; dcy = ry.x;
-                dw = v3((cx.y + ry.y) + nzm0, (cx.z + ry.z) + nzm1, (cx.w + ry.w) + nzm2);
-                inv = v3(__builtin_amdgcn_rcpf(dw.x), __builtin_amdgcn_rcpf(dw.y), __builtin_amdgcn_rcpf(dw.z));
-                a2 = s_colq[pxc] + rq.x; ldc = rq.y;
-                if (HEXF) {   // (same products and sums as mat_tmul with the frame's matrix: c x + (-s) z, s x + c z)
-                    const float cx8 = 0.8660254f * dw.x, cz8 = 0.8660254f * dw.z, hx5 = 0.5f * dw.x, hz5 = 0.5f * dw.z;
-                    ihx0 = __builtin_amdgcn_rcpf(cx8 - hz5); ihz0 = __builtin_amdgcn_rcpf(hx5 + cz8);
-                    ihx1 = __builtin_amdgcn_rcpf(cx8 + hz5); ihz1 = __builtin_amdgcn_rcpf(cz8 - hx5);
+                const float4 cx = s_col[pxc];
+                const float cq = s_colq[pxc];
+                dcx = cx.x;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    const int pyc = min(py0 + TILE_H * j, H - 1);
+                    const float4 ry = s_row[pyc];
+                    const float2 rq = s_rowq[pyc];
+                    dcy[j] = ry.x;
+                    dw[j] = v3((cx.y + ry.y) + nzm0, (cx.z + ry.z) + nzm1, (cx.w + ry.w) + nzm2);
+                    inv[j] = v3(__builtin_amdgcn_rcpf(dw[j].x), __builtin_amdgcn_rcpf(dw[j].y), __builtin_amdgcn_rcpf(dw[j].z));
+                    a2[j] = cq + rq.x; ldc[j] = rq.y;
+                    if (HEXF) {   // (same products and sums as mat_tmul with the frame's matrix: c x + (-s) z, s x + c z)
+                        const float cx8 = 0.8660254f * dw[j].x, cz8 = 0.8660254f * dw[j].z, hx5 = 0.5f * dw[j].x, hz5 = 0.5f * dw[j].z;
+                        ih0[j] = v3(__builtin_amdgcn_rcpf(cx8 - hz5), inv[j].y, __builtin_amdgcn_rcpf(hx5 + cz8));
+                        ih1[j] = v3(__builtin_amdgcn_rcpf(cx8 + hz5), inv[j].y, __builtin_amdgcn_rcpf(cz8 - hx5));
+                        ih2[j] = v3(0.0f - inv[j].z, inv[j].y, inv[j].x);   // 90 degrees: (x, z) -> (-z, x)
+                    }
                 }
             }
+            unsigned long long rest;
             if (HEXF) {
                 const unsigned ml = __float_as_uint(s_vis[2 * cpos].w);   // this lane's primitive: kind | frame << 4 | slot << 8
                 const bool box = v && (ml & 15u) == (unsigned)PRIM_BOX;
                 const unsigned fl = (ml >> 4) & 15u;
                 const unsigned long long m0 = __ballot(box && fl == 0u), m1 = __ballot(box && fl == (unsigned)MAX_AGENTS + 1u),
                                          m2 = __ballot(box && fl == (unsigned)MAX_AGENTS + 2u), m3 = __ballot(box && fl == (unsigned)MAX_AGENTS + 3u);
-                box_run<POS_MASK>(m0, k, inv, s_vis, best);
-                box_run<POS_MASK>(m1, k, v3(ihx0, inv.y, ihz0), s_vis, best);
-                box_run<POS_MASK>(m2, k, v3(ihx1, inv.y, ihz1), s_vis, best);
-                box_run<POS_MASK>(m3, k, v3(0.0f - inv.z, inv.y, inv.x), s_vis, best);   // 90 degrees: (x, z) -> (-z, x)
-                unsigned long long rest = mvis & ~(m0 | m1 | m2 | m3);
-                while (rest) {   // camera-attached boxes, capsules, cones, scaled shapes
-                    const int pos = __ffsll((long long)rest) - 1 + 64 * k;
-                    rest &= rest - 1;
-                    V3 n = v3(0, 0, 0);
-                    const unsigned key = fast_other<SHAPES, POS_MASK>(pos, s_vis, s_hdr, camv, viewer, dw, dcx, dcy, n);
-                    if (key < best) { best = key; bn = n; }
-                }
-                continue;
-            }
-            const unsigned long long wb = uniform_u64(*reinterpret_cast<const unsigned long long *>(s_hdr + FH_WB + 2 * k));
-            // ---- world-frame boxes: the next primitive's record is fetched from LDS while the current one is intersected
-            unsigned long long m = mvis & wb;
-            if (m) {
-                int p0 = __ffsll((long long)m) - 1 + 64 * k, p1 = 0;
-                m &= m - 1;
-                float4 lo0 = s_vis[2 * p0], hi0 = s_vis[2 * p0 + 1], lo1 = lo0, hi1 = hi0;
-                for (;;) {
-                    bool more = m != 0ull;
-                    if (more) { p1 = __ffsll((long long)m) - 1 + 64 * k; m &= m - 1; lo1 = s_vis[2 * p1]; hi1 = s_vis[2 * p1 + 1]; }
-                    best = min(best, box_key<POS_MASK>(inv, lo0, hi0, p0));
-                    if (!more) break;
-                    more = m != 0ull;
-                    if (more) { p0 = __ffsll((long long)m) - 1 + 64 * k; m &= m - 1; lo0 = s_vis[2 * p0]; hi0 = s_vis[2 * p0 + 1]; }
-                    best = min(best, box_key<POS_MASK>(inv, lo1, hi1, p1));
-                    if (!more) break;
-                }
+                box_run<POS_MASK, NP>(m0, k, inv, s_vis, best);
+                box_run<POS_MASK, NP>(m1, k, ih0, s_vis, best);
+                box_run<POS_MASK, NP>(m2, k, ih1, s_vis, best);
+                box_run<POS_MASK, NP>(m3, k, ih2, s_vis, best);
+                rest = mvis & ~(m0 | m1 | m2 | m3);
+            } else {
+                // ---- world-frame boxes (a bit mask from the frame header): the next record is fetched from LDS while the current one is intersected
+                const unsigned long long wb = uniform_u64(*reinterpret_cast<const unsigned long long *>(s_hdr + FH_WB + 2 * k));
+                box_run<POS_MASK, NP>(mvis & wb, k, inv, s_vis, best);
+                rest = mvis & ~wb;
             }
             // ---- everything else: camera-attached boxes, capsules, cones, scaled shapes
-            m = mvis & ~wb;
-            while (m) {
-                const int bit = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const int pos = bit + 64 * k;
-                V3 n = v3(0, 0, 0);
-                const unsigned key = fast_other<SHAPES, POS_MASK>(pos, s_vis, s_hdr, camv, viewer, dw, dcx, dcy, n);
-                if (key < best) { best = key; bn = n; }
+            while (rest) {
+                const int pos = __ffsll((long long)rest) - 1 + 64 * k;
+                rest &= rest - 1;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    V3 n = v3(0, 0, 0);
+                    const unsigned key = fast_other<SHAPES, POS_MASK>(pos, s_vis, s_hdr, camv, viewer, dw[j], dcx, dcy[j], n);
+                    if (key < best[j]) { best[j] = key; bn[j] = n; }
+                }
             }
         }
-
-        const unsigned rgba = fast_shade<SHAPES, POS_MASK>(best, bn, s_vis, s_hdr, camv, viewer, dw, inv, dcx, dcy, a2, ldc);
-        if (inside) out[(unsigned)(py * W + px)] = rgba;   // (32-bit offset from the frame's base: scalar-base addressing)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const unsigned rgba = fast_shade<SHAPES, POS_MASK>(best[j], bn[j], s_vis, s_hdr, camv, viewer, dw[j], inv[j], dcx, dcy[j], a2[j], ldc[j]);
+            const int py = py0 + TILE_H * j;
+            if (px < W && py < H) out[(unsigned)(py * W + px)] = rgba;   // (32-bit offset from the frame's base: scalar-base addressing)
+        }
     }
 }
 
@@ -946,10 +954,16 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
     if (between) (void)hipEventRecord(between, stream);
     if (fast) {
         const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)W * sizeof(float) + (size_t)H * sizeof(float2);
+        // pixels per lane (tile 16 x 4 NP): MV_FAST_PPL = 1 | 2 (read at every launch: the variants are compared within one process by
+        // tests/test_fast_pixels_gpu.py)
+        const char *pplEnv = getenv("MV_FAST_PPL");
+        const int pplSel = pplEnv ? atoi(pplEnv) : MV_FAST_PPL_DEFAULT;
+        const int np = pplSel >= 2 ? 2 : 1;
+        const int ftiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H * np - 1) / (TILE_H * np));
         int split = envSplit > 0 ? envSplit : 4;
-        while (split > 1 && tiles < 4 * split * 2) split >>= 1;   // keep at least two tiles per wave
+        while (split > 1 && ftiles < 4 * split * 2) split >>= 1;   // keep at least two tiles per wave
         // variants: [0] <=256 visible primitives, [1] + scaled shapes (Rearrange), [2] <=1024 (Collect), [3] <=1024 + scaled shapes (Hex*); the
-        // small ones are built for 8 and for 6 waves per SIMD (64 / 80 VGPRs), MV_FAST_WAVES picks
+        // small ones are built for 8 and for 6 waves per SIMD (64 / 80 VGPRs), MV_FAST_WAVES picks (two pixels per lane: 7 / 6 waves)
         static const int wavesSel = getenv("MV_FAST_WAVES") ? atoi(getenv("MV_FAST_WAVES")) : 8;
         using KernelFn = void (*)(FastArgs, uint32_t *, int, int, int);
         FastArgs fa;
@@ -961,9 +975,15 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
         // (Collect, measured and rejected: a 1024-entry launch for the frames above 256 visible primitives + a 256-entry launch for the rest,
         // 75 + 69 us against 107 us for the single 1024-entry launch: each launch pays its own tail, and the cones, not occupancy, dominate)
         const bool hexScen = gv.scenario == SCN_HEX_MEMORY || gv.scenario == SCN_HEX_EXPLORE;
-        KernelFn fn = hexScen ? raster_fast_kernel<VIS_LARGE, true, 3, true> : gv.vis_stride > VIS_SMALL ? raster_fast_kernel<VIS_LARGE, false, 3>
-                    : gv.scenario == SCN_REARRANGE ? (wavesSel >= 8 ? raster_fast_kernel<VIS_SMALL, true, 8> : raster_fast_kernel<VIS_SMALL, true, 6>)
-                                                   : (wavesSel >= 8 ? raster_fast_kernel<VIS_SMALL, false, 8> : raster_fast_kernel<VIS_SMALL, false, 6>);
+        KernelFn fn;
+        if (np == 2)   // (the small variants: 72 VGPRs / 7 waves, 80 / 6; at 64 they would spill)
+            fn = hexScen ? raster_fast_kernel<VIS_LARGE, true, 3, true, 2> : gv.vis_stride > VIS_SMALL ? raster_fast_kernel<VIS_LARGE, false, 3, false, 2>
+               : gv.scenario == SCN_REARRANGE ? (wavesSel >= 7 ? raster_fast_kernel<VIS_SMALL, true, 7, false, 2> : raster_fast_kernel<VIS_SMALL, true, 6, false, 2>)
+                                              : (wavesSel >= 7 ? raster_fast_kernel<VIS_SMALL, false, 7, false, 2> : raster_fast_kernel<VIS_SMALL, false, 6, false, 2>);
+        else
+            fn = hexScen ? raster_fast_kernel<VIS_LARGE, true, 3, true> : gv.vis_stride > VIS_SMALL ? raster_fast_kernel<VIS_LARGE, false, 3>
+               : gv.scenario == SCN_REARRANGE ? (wavesSel >= 8 ? raster_fast_kernel<VIS_SMALL, true, 8> : raster_fast_kernel<VIS_SMALL, true, 6>)
+                                              : (wavesSel >= 8 ? raster_fast_kernel<VIS_SMALL, false, 8> : raster_fast_kernel<VIS_SMALL, false, 6>);
         hipLaunchKernelGGL(fn, dim3(frames * split), dim3(256), dyn, stream, fa, obs, W, H, split);
         return 0;
     }

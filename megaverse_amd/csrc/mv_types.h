@@ -23,9 +23,13 @@ enum : int {
 };
 
 enum : int { FRAME_HDR_BYTES = 1024 };
-// Pipelining depth (mv_api.hip): a step's hand-over buffers -- frame lists, headers, cost lists, reward / done staging -- exist PIPE_BUFS times,
-// so that the step kernels may run up to PIPE_BUFS - 1 ticks ahead of the observation pass; cost histograms: one more (a pass clears the next)
-enum : int { PIPE_BUFS = 3, LPT_HISTS = PIPE_BUFS + 1 };   // per-frame header of the observation pass (mv_raster.hip: FH_*)
+// Pipelining (mv_api.hip): a step's hand-over buffers -- frame lists, headers, cost lists, reward / done staging -- exist once per SLOT.
+// Slots come in PIPE_GROUPS groups of `batch` slots: one call (mv_step: one tick, mv_step_n: up to `batch` ticks) takes the next group, and
+// its step kernels may run while the observation passes of the previous PIPE_GROUPS - 1 calls are still reading theirs.  Cost histograms:
+// one more than there are slots (a pass clears the next; GymView::lpt_hists).
+enum : int { PIPE_GROUPS = 3, PIPE_BATCH_MAX = 16 };
+// where a tick's actions come from (GymView::sample_on): the action array, or drawn inside the step kernel (mv_actions.h)
+enum : int { POLICY_NONE = 0, POLICY_MULTIDISCRETE = 1, POLICY_SINGLE_BIT = 2 };
 
 // error flags a kernel raises in episode_status[N + 1]; mv_step reports them (mv_api.hip: check_status_flags)
 enum : int { ST_STARVED = 1, ST_CANDIDATES = 2, ST_VISIBLE = 4, ST_CHUNK = 8 };
@@ -118,7 +122,7 @@ struct GymView {
     int32_t box_stride, reward_stride;   // MAX_BOXES / MAX_REWARDS, or the COLLECT_ sizes
     int32_t scenario;                    // SCN_*: one scenario per gym
     int32_t env_offset, env_stride;      // job-wide index of local env j = env_offset + j * env_stride
-    int32_t sample_on;                   // 1: this tick's actions are drawn inside the step kernel (mv_actions.h)
+    int32_t sample_on;                   // POLICY_*: != 0: this tick's actions are drawn inside the step kernel (mv_actions.h)
     uint32_t sample_seed, sample_step;
     EnvHeader *hdr;            // [N]
     LayoutBox *boxes;          // [N][box_stride]
@@ -137,6 +141,7 @@ struct GymView {
                                // number q (1-based) of an env lives in ring slot (q - 1) % spares
     int32_t spares;            // resident episodes per env (2: a second reset can follow the first before the host has refilled)
     int32_t *actions;          // [N][A] bitmasks
+    const int32_t *md_actions; // != null: this tick's actions as multi-discrete [N*A][6] in the caller's device buffer (mv_set_actions_device)
     float *rewards;            // [N*A] as reported by get_last_rewards (0 on done steps)
     uint8_t *done;             // [N]
     float *true_objective;     // [N*A]
@@ -147,7 +152,8 @@ struct GymView {
     int32_t vis_stride;        // 256, or 1024 for Collect
     int32_t *lpt_bucket;       // [N*A] cost bin of every frame (raster scheduling)
     int32_t *lpt_order;        // [N*A] frames sorted by cost bin, most expensive first (exact raster kernel)
-    int32_t *lpt_hist;         // [LPT_HISTS][256] frames per cost bin, rotating over the passes (fast raster kernel)
+    int32_t *lpt_hist;         // [lpt_hists][256] frames per cost bin, rotating over the passes (fast raster kernel)
+    int32_t lpt_hists;         // number of histograms (slots + 1)
     int32_t *lpt_list;         // [256][N*A] the frames of every bin in arrival order
     int32_t lpt_parity;        // which of the histograms this observation pass uses
     uint8_t *vis_hdr;          // [N*A][FRAME_HDR_BYTES] per-frame header for raster_fast_kernel (cameras, light vectors, masks, count)

@@ -7,6 +7,7 @@ no CPU fallback: if the shared library or a HIP device is missing, construction 
 """
 import ctypes as C
 import os
+import warnings
 
 import numpy as np
 
@@ -27,7 +28,7 @@ class _Config(C.Structure):
 # every symbol include/megaverse_hip.h declares: (name, restype, argtypes)
 _P, _I, _U, _F = C.c_void_p, C.c_int32, C.c_uint32, C.c_float
 SYMBOLS = [
-    ("mv_last_error", C.c_char_p, []),
+    ("mv_last_error", C.c_char_p, []), ("mv_device_count", C.c_int, []),
     ("mv_create", C.c_int, [C.POINTER(_Config), C.POINTER(_P)]),
     ("mv_close", C.c_int, [_P]), ("mv_destroy", C.c_int, [_P]),
     ("mv_num_agents", C.c_int, [_P]), ("mv_action_space_sizes", C.c_int, [_P]),
@@ -37,6 +38,8 @@ SYMBOLS = [
     ("mv_sample_random_actions", C.c_int, [_P, _U, _U]),
     ("mv_step_many", C.c_int, [_P, _I, _I, _I, _U, _U]),
     ("mv_step", C.c_int, [_P]), ("mv_step_no_render", C.c_int, [_P]), ("mv_render", C.c_int, [_P]),
+    ("mv_step_n", C.c_int, [_P, _I, _I, _U, _U]), ("mv_set_sample_policy", C.c_int, [_P, _I]),
+    ("mv_set_output_ring", C.c_int, [_P, _I, _P, _P, _P]),
     ("mv_is_done", C.c_int, [_P, _I]), ("mv_get_dones", C.c_int, [_P, _P]),
     ("mv_get_last_rewards", C.c_int, [_P, _P]),
     ("mv_true_objective", C.c_int, [_P, _I, _I, C.POINTER(_F)]), ("mv_get_true_objectives", C.c_int, [_P, _P]),
@@ -126,6 +129,14 @@ class MegaverseGym:
             raise RuntimeError(self._lib.mv_last_error().decode())
         return rc
 
+    def _ckw(self, rc):
+        """stepping calls: 1 = done, with a warning (a capacity limit was hit and is reported once; include/megaverse_hip.h)"""
+        if rc < 0:
+            raise RuntimeError(self._lib.mv_last_error().decode())
+        if rc > 0:
+            warnings.warn(self._lib.mv_last_error().decode(), RuntimeWarning, stacklevel=3)
+        return rc
+
     # ---- the reference's method table ----
     def num_agents(self):
         return self.num_agents_per_env
@@ -139,14 +150,14 @@ class MegaverseGym:
         self._ck(self._lib.mv_seed(self._g, int(seed)))
 
     def reset(self):
-        self._ck(self._lib.mv_reset(self._g))
+        self._ckw(self._lib.mv_reset(self._g))
 
     def set_actions(self, env_idx, agent_idx, actions):
         arr = (C.c_int32 * len(actions))(*[int(a) for a in actions])
         self._ck(self._lib.mv_set_actions(self._g, int(env_idx), int(agent_idx), arr, len(actions)))
 
     def step(self):
-        self._ck(self._lib.mv_step(self._g))
+        self._ckw(self._lib.mv_step(self._g))
 
     def is_done(self, env_idx):
         return bool(self._ck(self._lib.mv_is_done(self._g, int(env_idx))))
@@ -219,7 +230,21 @@ class MegaverseGym:
         self._ck(self._lib.mv_sample_random_actions(self._g, int(seed) & 0xFFFFFFFF, int(step_index) & 0xFFFFFFFF))
 
     def step_no_render(self):
-        self._ck(self._lib.mv_step_no_render(self._g))
+        self._ckw(self._lib.mv_step_no_render(self._g))
+
+    POLICIES = {"none": 0, "multidiscrete": 1, "single-bit": 2}
+
+    def step_n(self, k, policy="multidiscrete", seed=0, first_step_index=0):
+        """k open-loop ticks (each stepped and rendered) with one call; tick j draws its actions from (policy, seed, first_step_index + j)"""
+        self._ckw(self._lib.mv_step_n(self._g, int(k), int(self.POLICIES.get(policy, policy)), int(seed) & 0xFFFFFFFF, int(first_step_index) & 0xFFFFFFFF))
+
+    def set_sample_policy(self, policy):
+        """'multidiscrete' (action_space.sample()) or 'single-bit' (the reference's megaverse_test_app policy) for sample_random_actions"""
+        self._ck(self._lib.mv_set_sample_policy(self._g, int(self.POLICIES.get(policy, policy))))
+
+    def set_output_ring(self, count, obs_ptr=0, rewards_ptr=0, dones_ptr=0):
+        """tick t leaves its outputs in entry t % count of the given device rings (0 = keep that output in its single array)"""
+        self._ck(self._lib.mv_set_output_ring(self._g, int(count), _P(int(obs_ptr) or None), _P(int(rewards_ptr) or None), _P(int(dones_ptr) or None)))
 
     def render(self):
         self._ck(self._lib.mv_render(self._g))

@@ -100,9 +100,13 @@ class MultiTaskGym:
             self._handles = (C.c_void_p * len(self.gyms))(*[g._g for g in self.gyms])
         lib = self.gyms[0]._lib
         seed, idx = self._sample if self._sample else (0, 0)
-        if lib.mv_step_many(self._handles, len(self.gyms), 1, 1 if self._sample else 0, seed, idx):
+        rc = lib.mv_step_many(self._handles, len(self.gyms), 1, 1 if self._sample else 0, seed, idx)
+        self._sample = None   # (every sub-gym was stepped, whatever one of them reports: nothing to retry)
+        if rc < 0:
             raise RuntimeError(lib.mv_last_error().decode())
-        self._sample = None
+        if rc > 0:
+            import warnings
+            warnings.warn(lib.mv_last_error().decode(), RuntimeWarning, stacklevel=2)
 
     def synchronize(self):
         for g in self.gyms:

@@ -30,6 +30,15 @@ void check(int rc)
     if (rc < 0) throw std::runtime_error(mv_last_error());
 }
 
+// mv_step / mv_reset: 1 = done, with a warning (a capacity limit of this build was hit and reported once; include/megaverse_hip.h)
+void check_or_warn(int rc)
+{
+    check(rc);
+    if (rc > 0 && PyErr_WarnEx(PyExc_RuntimeWarning, mv_last_error(), 1) < 0) throw py::error_already_set();
+}
+
+int visible_device_count();
+
 class Gym {
 public:
     Gym(const std::string &scenario, int w, int h, int num_envs, int num_agents_per_env, int num_simulation_threads, bool use_vulkan,
@@ -45,12 +54,19 @@ public:
         cfg.num_envs = num_envs; cfg.num_agents_per_env = num_agents_per_env;
         cfg.num_simulation_threads = num_simulation_threads; cfg.use_vulkan = use_vulkan ? 1 : 0;
         // The reference's constructor has no device or shard argument (one process = one GPU's worth of envs there too, chosen by
-        // CUDA_VISIBLE_DEVICES).  Through this module the process environment decides: MV_DEVICE, else LOCAL_RANK (torchrun), else 0;
-        // MV_ENV_OFFSET / MV_TOTAL_ENVS place this process's envs in a job-wide seed stream (include/megaverse_hip.h: mv_config).
+        // CUDA_VISIBLE_DEVICES).  Through this module the process environment decides: MV_DEVICE (taken as is), else LOCAL_RANK (torchrun)
+        // modulo the number of devices this process can see -- a launcher that also masks devices per rank (HIP_VISIBLE_DEVICES = one GPU
+        // with LOCAL_RANK = k) leaves exactly one, ordinal 0 --, else 0.
+        // MV_ENV_OFFSET / MV_TOTAL_ENVS / MV_ENV_STRIDE place this process's envs in a job-wide seed stream (include/megaverse_hip.h:
+        // mv_config): a contiguous block, or -- stride k > 1 -- every k-th env from the offset (a multi-task job that deals its scenarios
+        // round-robin by env index, one gym per scenario).
         auto env_int = [](const char *name, int fallback) { const char *v = std::getenv(name); return v && *v ? std::atoi(v) : fallback; };
-        cfg.device = env_int("MV_DEVICE", env_int("LOCAL_RANK", 0));
+        const int ndev = visible_device_count();
+        const int local_rank = env_int("LOCAL_RANK", 0);
+        cfg.device = env_int("MV_DEVICE", ndev > 0 && local_rank >= 0 ? local_rank % ndev : 0);
         cfg.env_offset = env_int("MV_ENV_OFFSET", 0);
         cfg.total_envs = env_int("MV_TOTAL_ENVS", 0);
+        cfg.env_stride = env_int("MV_ENV_STRIDE", 1);
         cfg.param_keys = keys.data(); cfg.param_vals = vals.data(); cfg.num_params = int(keys.size());
         check(mv_create(&cfg, &gym_));
     }
@@ -66,13 +82,13 @@ public:
         return std::vector<int>(sizes, sizes + 6);
     }
     void seed(int value) { check(mv_seed(gym_, value)); }
-    void reset() { check(mv_reset(gym_)); }
+    void reset() { check_or_warn(mv_reset(gym_)); }
     void set_actions(int env, int agent, const std::vector<int> &actions)
     {
         std::vector<int32_t> a(actions.begin(), actions.end());
         check(mv_set_actions(gym_, env, agent, a.data(), int(a.size())));
     }
-    void step() { check(mv_step(gym_)); }
+    void step() { check_or_warn(mv_step(gym_)); }
     bool is_done(int env)
     {
         const int rc = mv_is_done(gym_, env);
@@ -145,6 +161,8 @@ private:
     mv_gym *gym_ = nullptr;
     int w_, h_, envs_, agents_, render_w_ = 768, render_h_ = 432;   // default hires size: megaverse.cpp:261
 };
+
+int visible_device_count() { return mv_device_count(); }
 
 }  // namespace
 

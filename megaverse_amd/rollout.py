@@ -35,6 +35,18 @@ def sample_actions(seed, step, num_agents, agent_offset=0):
     return out
 
 
+def sample_single_bit_masks(seed, step, num_agents, agent_offset=0):
+    """-> int32 [num_agents] Action bitmasks of the reference's own benchmark policy, Action(1 << randRange(0, NumActions)) with
+    NumActions = 11 (src/apps/megaverse_test_app.cpp:140-147); the device twin is mv_actions.h: sampled_single_bit_mask."""
+    seed = np.uint64(int(seed) & 0xFFFFFFFF)
+    step = np.uint64(int(step) & 0xFFFFFFFF)
+    ids = (np.arange(num_agents, dtype=np.uint64) + np.uint64(agent_offset)) & _M
+    s = _fmix32(seed ^ _fmix32((step + np.uint64(0x9E3779B9)) & _M))
+    base = _fmix32(s ^ ((ids * np.uint64(0x85EBCA6B) + np.uint64(1)) & _M))
+    h = _fmix32((base + np.uint64(6) * np.uint64(0xC2B2AE35)) & _M)
+    return (np.int32(1) << ((h * np.uint64(11)) >> np.uint64(32)).astype(np.int32)).astype(np.int32)
+
+
 def action_masks(actions):
     """multi-discrete [.., 6] -> Action bitmasks (reference: megaverse.cpp:100-116)."""
     a = np.asarray(actions, dtype=np.int64)

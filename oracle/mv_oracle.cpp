@@ -2984,6 +2984,11 @@ int mvo_action_mask(const int *actions, int n)
 
 void mvo_set_actions(mvo_gym *g, int env, int agent, const int *actions, int n) { g->envs[env]->agents[agent].action = mvo_action_mask(actions, n); }
 void mvo_set_action_mask(mvo_gym *g, int env, int agent, int mask) { g->envs[env]->agents[agent].action = mask; }
+void mvo_set_action_masks(mvo_gym *g, const int *masks)   // [N*A] env-major, one call per tick (bench.py's CPU baseline)
+{
+    for (int e = 0; e < g->numEnvs; ++e)
+        for (int a = 0; a < g->numAgents; ++a) g->envs[e]->agents[a].action = masks[(size_t)e * g->numAgents + a];
+}
 void mvo_step(mvo_gym *g) { g->step(true); }
 void mvo_step_norender(mvo_gym *g) { g->step(false); }
 void mvo_render(mvo_gym *g) { g->render(); }

@@ -51,6 +51,7 @@ void mvo_seed(mvo_gym *g, int seed);
 void mvo_reset(mvo_gym *g);
 void mvo_set_actions(mvo_gym *g, int env_idx, int agent_idx, const int *actions, int n);
 void mvo_set_action_mask(mvo_gym *g, int env_idx, int agent_idx, int mask);
+void mvo_set_action_masks(mvo_gym *g, const int *masks); /* [N*A] env-major */
 void mvo_step(mvo_gym *g);
 /* physics+logic+auto-reset only, no rendering (for long rollouts in tests) */
 void mvo_step_norender(mvo_gym *g);

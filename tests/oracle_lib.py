@@ -66,6 +66,7 @@ def lib():
         L.mvo_get_reward_shaping.restype = C.c_float
         L.mvo_set_reward_shaping.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_float]
         L.mvo_debug_set_agent_pos.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float]
+        L.mvo_set_action_masks.argtypes = [C.c_void_p, C.c_void_p]
         L.mvo_snapshot_size.argtypes = [C.c_void_p]
         L.mvo_snapshot.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.mvo_mt19937_nth.argtypes = [C.c_uint32, C.c_int]
@@ -123,6 +124,11 @@ class OracleGym:
         self.L.mvo_set_actions(self.g, env_idx, agent_idx, arr, len(actions))
 
     def set_action_mask(self, env_idx, agent_idx, mask): self.L.mvo_set_action_mask(self.g, env_idx, agent_idx, int(mask))
+
+    def set_action_masks(self, masks):
+        m = np.ascontiguousarray(masks, dtype=np.int32).reshape(self.num_envs * self.num_agents_per_env)
+        self.L.mvo_set_action_masks(self.g, m.ctypes.data)
+
     def step(self): self.L.mvo_step(self.g)
     def step_norender(self): self.L.mvo_step_norender(self.g)
     def render(self): self.L.mvo_render(self.g)

@@ -44,10 +44,29 @@ def pair(scenario, N, A, W, H, seed, params=None):
     return og, hg
 
 
+@pytest.fixture(autouse=True)
+def _boxoban(monkeypatch):
+    import os
+    monkeypatch.setenv("BOXOBAN_LEVELS", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "boxoban"))   # Sokoban: synthetic levels
+
+
 @pytest.mark.parametrize("scenario,A", [("TowerBuilding", 1), ("TowerBuilding", 4), ("ObstaclesHard", 2), ("ObstaclesEasy", 1),
                                         ("Collect", 2), ("Rearrange", 3), ("HexMemory", 2), ("HexExplore", 1)])
 @pytest.mark.parametrize("W,H", [(128, 128), (128, 72), (64, 64), (48, 20)])
 def test_fast_pixels_within_tolerance(hip, scenario, A, W, H):
+    _fast_vs_oracle(scenario, A, W, H)
+
+
+# the scenarios the matrix above leaves out (wall caps / goal pads / pushable boxes of Sokoban, the bare Empty room, the other
+# Obstacles variants' walls, steps and lava slabs), at the headline size and at a ragged one
+@pytest.mark.parametrize("scenario,A", [("Sokoban", 2), ("Empty", 2), ("ObstaclesMedium", 1), ("ObstaclesWalls", 2), ("ObstaclesSteps", 1),
+                                        ("ObstaclesLava", 2)])
+@pytest.mark.parametrize("W,H", [(128, 128), (48, 20)])
+def test_fast_pixels_within_tolerance_other_scenarios(hip, scenario, A, W, H):
+    _fast_vs_oracle(scenario, A, W, H)
+
+
+def _fast_vs_oracle(scenario, A, W, H):
     N = 8 if (W, H) == (128, 128) else 4
     og, hg = pair(scenario, N, A, W, H, seed=11)
     ref, got = [frames(og, N, A)], [frames(hg, N, A)]
@@ -93,6 +112,26 @@ def test_fast_equals_exact_within_tolerance_at_full_size(hip, scenario, N, A, W,
     exact, fast = slab("exact"), slab("fast")
     assert exact[..., :3].max() > 0
     compare(exact, fast, f"{scenario} {N}x{A} {W}x{H} exact vs fast")
+    g.close()
+
+
+@pytest.mark.parametrize("scenario,N,A,W,H", [("TowerBuilding", 64, 1, 128, 128), ("TowerBuilding", 16, 4, 128, 72), ("ObstaclesHard", 32, 2, 64, 64),
+                                              ("Rearrange", 16, 2, 128, 128), ("Collect", 16, 2, 128, 128), ("HexMemory", 8, 2, 128, 128),
+                                              ("HexExplore", 8, 1, 50, 30), ("Sokoban", 16, 1, 33, 17)])
+def test_pixels_per_lane_variants_agree(hip, monkeypatch, scenario, N, A, W, H):
+    """raster_fast_kernel with one and with two pixels per lane (tiles of 16 x 4 / 16 x 8 pixels): the per-pixel arithmetic is the same and
+    the culling is conservative, so every byte of the slab must be equal (MV_FAST_PPL is read at every launch)."""
+    g = MegaverseGym(scenario, W, H, N, A, 2, False, {})
+    g.set_pixel_mode("fast"); g.seed(5); g.reset()
+    for st in range(30):
+        g.sample_random_actions(77, st); g.step_no_render()
+    got = {}
+    for ppl in ("1", "2"):
+        monkeypatch.setenv("MV_FAST_PPL", ppl)
+        g.render()
+        got[ppl] = frames(g, N, A)
+    assert got["1"][..., :3].max() > 0
+    assert np.array_equal(got["1"], got["2"]), f"{scenario}: {int((got['1'] != got['2']).any(axis=-1).sum())} pixels differ between 1 and 2 pixels per lane"
     g.close()
 
 

@@ -166,3 +166,139 @@ def test_a_policy_in_the_loop_is_a_true_dependency(hip):
     assert np.array_equal(a[1], b[1])
     moved = sum(float(np.abs(s["agents"]["hv"][:A]).sum()) > 0 for s in a[0])
     assert moved > 0          # the policy's actions did something
+
+
+def _boxoban(monkeypatch):
+    import os
+    monkeypatch.setenv("BOXOBAN_LEVELS", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "boxoban"))
+
+
+@pytest.mark.parametrize("scenario,A,params", [("TowerBuilding", 1, {"episodeLengthSec": -200.0}), ("TowerBuilding", 3, {}), ("ObstaclesHard", 2, {}),
+                                              ("Collect", 1, {"episodeLengthSec": 6.0}), ("Sokoban", 2, {}), ("HexExplore", 1, {}),
+                                              ("Rearrange", 2, {"episodeLengthSec": 0.3})])
+def test_step_n_equals_k_single_steps(hip, monkeypatch, scenario, A, params):
+    """mv_step_n(k) = k x (mv_sample_random_actions + mv_step): same ticks, same order, one queue hand-over per call instead of per tick.
+    Chunks of every size up to the batch (and beyond: the call splits them), natural auto-resets, no host sync in between; then state,
+    outputs and the whole observation slab must be equal byte for byte.  (Rearrange with 0.3 s episodes: the refill protocol reads the
+    consumed counts after every tick, and mv_step_n falls back to one tick per hand-over.)"""
+    _boxoban(monkeypatch)
+    N, W, H = 24, 64, 48
+    chunks = [1, 8, 3, 5, 8, 8, 2, 16, 7, 8, 19, 8, 1, 6]
+    total = sum(chunks)
+
+    def make():
+        g = MegaverseGym(scenario, W, H, N, A, 2, False, params)
+        g.set_pixel_mode("fast"); g.seed(21); g.reset()
+        return g
+
+    a, b = make(), make()
+    for st in range(total):
+        a.sample_random_actions(99, st); a.step()
+    st = 0
+    for k in chunks:
+        b.step_n(k, "multidiscrete", 99, st)
+        st += k
+    a.synchronize(); b.synchronize()
+    for e in range(N):
+        assert a.debug_snapshot_bytes(e).tobytes() == b.debug_snapshot_bytes(e).tobytes(), e
+    assert a.get_rewards_array().tobytes() == b.get_rewards_array().tobytes()
+    assert np.array_equal(a.get_dones(), b.get_dones())
+    assert a.get_true_objectives().tobytes() == b.get_true_objectives().tobytes()
+    fa = np.stack([a.get_observation(e, k) for e in range(N) for k in range(A)])
+    fb = np.stack([b.get_observation(e, k) for e in range(N) for k in range(A)])
+    assert fa[..., :3].max() > 0 and np.array_equal(fa, fb)
+    a.close(); b.close()
+
+
+def test_step_n_against_the_oracle(hip):
+    """the batched call against the CPU oracle directly (not only against the single-step path): state, rewards, dones after 200 ticks with resets"""
+    scenario, N, A, W, H = "TowerBuilding", 16, 2, 48, 32
+    params = {"episodeLengthSec": -220.0}
+    og = oracle_lib.OracleGym(scenario, W, H, N, A, 1, False, params)
+    hg = MegaverseGym(scenario, W, H, N, A, 2, False, params)
+    og.seed(4); hg.seed(4); og.reset(); hg.reset()
+    for first in range(0, 200, 8):
+        hg.step_n(8, "multidiscrete", 55, first)
+    for st in range(200):
+        oracle_step(og, N, A, 55, st, render=(st == 199))
+    hg.synchronize()
+    for e in range(N):
+        d = diff_snapshots(og.snapshot(e), hip_snapshot(hg, e), A)
+        assert not d, (e, d[:5])
+    assert og.get_last_rewards().tobytes() == hg.get_rewards_array().tobytes()
+    assert np.array_equal(np.array([og.is_done(e) for e in range(N)]), hg.get_dones().astype(bool))
+    for e in range(N):   # (new gyms of this test session render with the exact pixel arithmetic: bit for bit)
+        for a in range(A):
+            assert np.array_equal(og.get_observation(e, a), hg.get_observation(e, a))
+    og.close(); hg.close()
+
+
+def test_output_ring_keeps_every_tick_of_a_batch(hip):
+    """mv_set_output_ring: tick t leaves observations / rewards / dones in entry t % count -- a k-step rollout buffer filled by one call.
+    Every entry must equal what a gym stepped tick by tick reported at that tick."""
+    import torch
+    scenario, N, A, W, H, K = "ObstaclesEasy", 16, 2, 40, 24, 8
+    obs = torch.zeros((K, N * A, H, W, 4), dtype=torch.uint8, device="cuda:0")
+    rew = torch.full((K, N * A), -7.0, dtype=torch.float32, device="cuda:0")
+    don = torch.full((K, N), 9, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+
+    def make():
+        g = MegaverseGym(scenario, W, H, N, A, 2, False, {})
+        g.set_pixel_mode("fast"); g.seed(8); g.reset()
+        return g
+
+    ref, ring = make(), make()
+    ring.set_output_ring(K, obs.data_ptr(), rew.data_ptr(), don.data_ptr())
+    want = []
+    for st in range(3 * K):
+        ref.sample_random_actions(12, st); ref.step()
+        want.append((np.stack([ref.get_observation(e, a) for e in range(N) for a in range(A)]), ref.get_rewards_array().copy(), ref.get_dones().copy()))
+    for first in range(0, 3 * K, K):
+        ring.step_n(K, "multidiscrete", 12, first)
+        ring.synchronize(); torch.cuda.synchronize()
+        o, r, d = obs.cpu().numpy(), rew.cpu().numpy(), don.cpu().numpy()
+        for j in range(K):
+            wo, wr, wd = want[first + j]
+            assert np.array_equal(o[j], wo), (first, j)
+            assert wr.tobytes() == r[j].tobytes() and np.array_equal(wd, d[j]), (first, j)
+    # the host getters read the entry of the last tick
+    assert np.array_equal(ring.get_observation(3, 1), want[-1][0][3 * A + 1])
+    assert ring.get_rewards_array().tobytes() == want[-1][1].tobytes()
+    # back to the single slab
+    ring.set_output_ring(0)
+    ring.sample_random_actions(12, 3 * K); ring.step()
+    ref.sample_random_actions(12, 3 * K); ref.step()
+    assert np.array_equal(ring.get_observation(0, 0), ref.get_observation(0, 0))
+    ref.close(); ring.close()
+
+
+@pytest.mark.parametrize("batched", [False, True])
+def test_single_bit_policy_equals_host_stream(hip, batched):
+    """the reference's own benchmark policy, Action(1 << randRange(0, NumActions)) (megaverse_test_app.cpp:140-147), drawn inside the step
+    kernel == the host twin (rollout.sample_single_bit_masks) fed to the oracle mask by mask"""
+    from megaverse_amd.rollout import sample_single_bit_masks
+    scenario, N, A, W, H, STEPS = "TowerBuilding", 12, 2, 32, 32, 160
+    og = oracle_lib.OracleGym(scenario, W, H, N, A, 1, False, {})
+    hg = MegaverseGym(scenario, W, H, N, A, 2, False, {})
+    og.seed(2); hg.seed(2); og.reset(); hg.reset()
+    hg.set_sample_policy("single-bit")
+    seen = set()
+    for st in range(STEPS):
+        masks = sample_single_bit_masks(41, st, N * A)
+        seen.update(int(m) for m in masks)
+        for e in range(N):
+            for a in range(A):
+                og.set_action_mask(e, a, int(masks[e * A + a]))
+        og.step_norender()
+    if batched:
+        for first in range(0, STEPS, 8):
+            hg.step_n(8, "single-bit", 41, first)
+    else:
+        for st in range(STEPS):
+            hg.sample_random_actions(41, st); hg.step_no_render()
+    assert seen == {1 << b for b in range(11)}
+    for e in range(N):
+        d = diff_snapshots(og.snapshot(e), hip_snapshot(hg, e), A)
+        assert not d, (e, d[:5])
+    og.close(); hg.close()

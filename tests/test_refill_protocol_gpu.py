@@ -65,17 +65,21 @@ def test_back_to_back_resets_obstacles():
 
 def test_starvation_is_reported_once_and_recovered(monkeypatch):
     """Forced: 3-tick episodes with the status read back only every 16th step.  The reference would reset inline; here the first
-    mv_step that sees the flag raises once, uploads synchronously, and the gym keeps working (it used to be dead for good)."""
+    mv_step that sees the flag WARNS once (return code 1 -> RuntimeWarning; the step itself is done like any other), uploads
+    synchronously, and the gym keeps working."""
+    import warnings
     monkeypatch.setenv("MV_STATUS_PERIOD", "16")
     g = MegaverseGym("Rearrange", 32, 32, 6, 1, 1, False, {"episodeLengthSec": 0.19})
     g.seed(3); g.reset()
     errors = 0
     for st in range(200):
         g.sample_random_actions(1, st)
-        try:
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
             g.step()
-        except RuntimeError as e:
-            assert "capacity limit hit" in str(e) and "repeated its done step" in str(e)
+        for w in caught:
+            assert issubclass(w.category, RuntimeWarning)
+            assert "capacity limit hit" in str(w.message) and "repeated its done step" in str(w.message)
             errors += 1
     assert 1 <= errors < 60, errors
     monkeypatch.delenv("MV_STATUS_PERIOD")
