@@ -160,6 +160,10 @@ int mv_profile_end(mv_gym *g, float *avg_ms4, int32_t *counts4);
 /* test hooks: packed state snapshot of one env (layout in DESIGN.md, same bytes as the oracle's
  * mvo_snapshot) and the raw device RNG streams */
 int mv_debug_set_agent_pos(mv_gym *g, int32_t env_idx, int32_t agent_idx, float x, float y, float z); /* teleport (fall-detection tests) */
+/* scripted single-step physics cases (tests/test_canonical_poses*.py): the yaw basis from (cos, sin) as DefaultKinematicAgent's spawn builds it
+ * (agent.cpp:42-46), and the controller's velocities */
+int mv_debug_set_agent_yaw(mv_gym *g, int32_t env_idx, int32_t agent_idx, float c, float s);
+int mv_debug_set_agent_velocity(mv_gym *g, int32_t env_idx, int32_t agent_idx, float hvx, float hvz, float vvel);
 int mv_debug_snapshot_size(const mv_gym *g);
 int mv_debug_snapshot(mv_gym *g, int32_t env_idx, void *out_host);
 int mv_debug_rng(int32_t device, uint32_t seed, int32_t what, const int32_t *lo, const int32_t *hi, int32_t n, void *out_host);

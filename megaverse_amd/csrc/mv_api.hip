@@ -196,6 +196,8 @@ __global__ void publish_kernel(const float *s_rew, const uint8_t *s_done, const 
 __global__ void clear_flags_kernel(int *word, int reported) { atomicAnd(word, ~reported); }   // only the bits that were reported: a bit raised since stays
 __global__ void set_shaping_kernel(AgentState *agents, int idx, int key, float v) { agents[idx].shaping[key] = v; }
 __global__ void set_agent_pos_kernel(AgentState *agents, int idx, float x, float y, float z) { agents[idx].pos[0] = x; agents[idx].pos[1] = y; agents[idx].pos[2] = z; }
+__global__ void set_agent_yaw_kernel(AgentState *agents, int idx, float c, float s) { agents[idx].m00 = c; agents[idx].m02 = s; agents[idx].m20 = -s; agents[idx].m22 = c; }
+__global__ void set_agent_velocity_kernel(AgentState *agents, int idx, float hvx, float hvz, float vvel) { agents[idx].hvx = hvx; agents[idx].hvz = hvz; agents[idx].vvel = vvel; }
 
 __global__ void debug_rng_kernel(uint32_t seed, int what, const int32_t *lo, const int32_t *hi, int n, void *out)
 {
@@ -1293,6 +1295,26 @@ int mv_debug_set_agent_pos(mv_gym *g, int32_t env, int32_t agent, float x, float
     if (env < 0 || env >= g->N || agent < 0 || agent >= g->A) return fail("mv_debug_set_agent_pos: index out of range");
     if (sim_join(g)) return -1;
     hipLaunchKernelGGL(set_agent_pos_kernel, dim3(1), dim3(1), 0, g->stream, g->gv.agents, env * g->A + agent, x, y, z);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int mv_debug_set_agent_yaw(mv_gym *g, int32_t env, int32_t agent, float c, float s)
+{
+    if (check(g)) return -1;
+    if (env < 0 || env >= g->N || agent < 0 || agent >= g->A) return fail("mv_debug_set_agent_yaw: index out of range");
+    if (sim_join(g)) return -1;
+    hipLaunchKernelGGL(set_agent_yaw_kernel, dim3(1), dim3(1), 0, g->stream, g->gv.agents, env * g->A + agent, c, s);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int mv_debug_set_agent_velocity(mv_gym *g, int32_t env, int32_t agent, float hvx, float hvz, float vvel)
+{
+    if (check(g)) return -1;
+    if (env < 0 || env >= g->N || agent < 0 || agent >= g->A) return fail("mv_debug_set_agent_velocity: index out of range");
+    if (sim_join(g)) return -1;
+    hipLaunchKernelGGL(set_agent_velocity_kernel, dim3(1), dim3(1), 0, g->stream, g->gv.agents, env * g->A + agent, hvx, hvz, vvel);
     HIP_TRY(hipGetLastError());
     return 0;
 }

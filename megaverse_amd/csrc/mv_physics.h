@@ -114,34 +114,108 @@ __device__ __forceinline__ Closest closest(const Col &col, V3 p)
     return closest_capsule(p, col.lo, col.hi.x, 2 * CAP_R);
 }
 
-// conservative advancement of the capsule along d against one collider
+// The same closest-point query without the normalisation: v = p minus the collider's closest point (NOT unit), d = |v|, dist = the signed
+// surface distance.  Centre inside the (grown) box / on the capsule's axis: v = the unit exit normal, d = 1.  closest().n == v * (1 / d).
+struct Raw {
+    V3 v;
+    float d, dist;
+};
+
+__device__ __forceinline__ Raw raw_box(V3 p, V3 lo, V3 hi, float r)
+{
+    const float qx = fmin_sel(fmax_sel(p.x, lo.x), hi.x);
+    const float qy = fmin_sel(fmax_sel(p.y, lo.y), hi.y);
+    const float qz = fmin_sel(fmax_sel(p.z, lo.z), hi.z);
+    const V3 v = v3(p.x - qx, p.y - qy, p.z - qz);
+    const float d2 = len2(v);
+    Raw c;
+    if (d2 > 0.0f) {
+        c.d = sqrtf(d2);
+        c.dist = c.d - r;
+        c.v = v;
+    } else {
+        float m = p.x - lo.x; V3 n = v3(-1, 0, 0);
+        float t = hi.x - p.x; if (t < m) { m = t; n = v3(1, 0, 0); }
+        t = p.y - lo.y; if (t < m) { m = t; n = v3(0, -1, 0); }
+        t = hi.y - p.y; if (t < m) { m = t; n = v3(0, 1, 0); }
+        t = p.z - lo.z; if (t < m) { m = t; n = v3(0, 0, -1); }
+        t = hi.z - p.z; if (t < m) { m = t; n = v3(0, 0, 1); }
+        c.d = 1.0f;
+        c.dist = -m - r;
+        c.v = n;
+    }
+    return c;
+}
+
+__device__ __forceinline__ Raw raw_capsule(V3 p, V3 centre, float halfLen, float r)
+{
+    const float qy = fmin_sel(fmax_sel(p.y, centre.y - halfLen), centre.y + halfLen);
+    const V3 v = v3(p.x - centre.x, p.y - qy, p.z - centre.z);
+    const float d2 = len2(v);
+    Raw c;
+    if (d2 > 1e-12f) {
+        c.d = sqrtf(d2);
+        c.dist = c.d - r;
+        c.v = v;
+    } else {
+        c.d = 1.0f;
+        c.dist = -r;
+        c.v = v3(1, 0, 0);
+    }
+    return c;
+}
+
+// conservative advancement of the capsule along d against one collider ([3P] btContinuousConvexCollision::calcTimeOfImpact for a
+// translating shape with exact closest points).  Bullet advances by dist / (-(d . n)) with the unit normal n = v / |v|; here the same
+// quotient is formed as (dist |v|) / (-(d . v)): ONE correctly rounded divide per iteration instead of two (1 / |v| and the quotient),
+// the normal is normalised once, on a hit.  A box in a hex wall frame (OBB builds) is cast in that frame: start and direction are rotated
+// in once, the normal is rotated back once.  (The CPU restatement the parity tests compare with forms the same operations in the same order.)
 template <bool OBB = false>
 __device__ __forceinline__ bool convex_cast(const Col &col, V3 p, V3 d, float &fraction, V3 &normal)
 {
+    const bool boxLike = col.kind != 2;
+    const int fr = col.kind - 3;
+    if (OBB && col.kind >= 3) { p = hex_to_local(fr, p); d = hex_to_local(fr, d); }
     float lambda = 0.0f, lastLambda = 0.0f;
     int numIter = 0;
-    Closest c = closest<OBB>(col, p);
+    Raw c = boxLike ? raw_box(p, col.lo, col.hi, CAP_R) : raw_capsule(p, col.lo, col.hi.x, 2 * CAP_R);
     float dist = c.dist + ALLOWED_CCD_PEN;
-    V3 n = c.n;
-    float proj = -dot(d, n);
-    if (proj <= SIMD_EPS) return false;
+    float proj = -dot(d, c.v);   // |v| times Bullet's projected velocity
+    if (proj <= SIMD_EPS * c.d) return false;
     while (dist > CAST_RADIUS) {
-        proj = -dot(d, n);
-        if (proj <= SIMD_EPS) return false;
-        lambda = lambda + dist / proj;
+        proj = -dot(d, c.v);
+        if (proj <= SIMD_EPS * c.d) return false;
+        lambda = lambda + (dist * c.d) / proj;
         if (lambda > 1.0f) return false;
         if (lambda < 0.0f) return false;
         if (lambda <= lastLambda) return false;
         lastLambda = lambda;
         const V3 x = v3(p.x + lambda * d.x, p.y + lambda * d.y, p.z + lambda * d.z);
-        c = closest<OBB>(col, x);
+        c = boxLike ? raw_box(x, col.lo, col.hi, CAP_R) : raw_capsule(x, col.lo, col.hi.x, 2 * CAP_R);
         dist = c.dist + ALLOWED_CCD_PEN;
-        n = c.n;
         if (++numIter > CAST_MAX_ITER) return false;
     }
     fraction = lambda;
+    const float inv = 1.0f / c.d;
+    V3 n = c.v * inv;
+    if (OBB && col.kind >= 3) n = hex_to_world(fr, n);
     normal = n;
     return true;
+}
+
+// Can the cast against a box-like collider hit at all?  A hit needs the capsule surface within CAST_RADIUS - ALLOWED_CCD_PEN (< 0: 0.039 deep)
+// of the collider somewhere on the path, i.e. the centre within CAP_R - 0.039 of the (grown) box: impossible when the path's bounding box,
+// widened by the full CAP_R, misses the box.  Exact (it only ever skips casts that return false), and it keeps the correctly rounded sqrt and
+// divide of a first iteration away from the many colliders that are nowhere near the agent.
+template <bool OBB = false>
+__device__ __forceinline__ bool cast_can_hit(const Col &col, V3 p, V3 d)
+{
+    if (col.kind == 2) return true;
+    if (OBB && col.kind >= 3) { p = hex_to_local(col.kind - 3, p); d = hex_to_local(col.kind - 3, d); }
+    const V3 q = v3(p.x + d.x, p.y + d.y, p.z + d.z);
+    return fmin_sel(p.x, q.x) - CAP_R <= col.hi.x && fmax_sel(p.x, q.x) + CAP_R >= col.lo.x &&
+           fmin_sel(p.y, q.y) - CAP_R <= col.hi.y && fmax_sel(p.y, q.y) + CAP_R >= col.lo.y &&
+           fmin_sel(p.z, q.z) - CAP_R <= col.hi.z && fmax_sel(p.z, q.z) + CAP_R >= col.lo.z;
 }
 
 // closest accepted hit over all colliders of the wave; ties resolved towards the lowest slot
@@ -157,7 +231,7 @@ __device__ __forceinline__ bool sweep(const Col (&col)[NC], V3 from, V3 to, V3 u
     for (int k = 0; k < NC; ++k) nn[k] = v3(0, 0, 0);
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
-        if (col[k].kind != 0) {
+        if (col[k].kind != 0 && cast_can_hit<OBB>(col[k], from, d)) {
             float f; V3 n;
             if (convex_cast<OBB>(col[k], from, d, f, n) && (len2(n) > 0.0001f) && (f < 1.0f) && !(dot(up, n) < minSlopeDot)) {
                 const unsigned long long kk = ((unsigned long long)__float_as_uint(f) << 32) | (unsigned)(lane + 64 * k);
@@ -179,20 +253,21 @@ __device__ __forceinline__ bool sweep(const Col (&col)[NC], V3 from, V3 to, V3 u
     return true;
 }
 
-// push out of the first (lowest slot) collider that is penetrated deeper than MAX_PEN_DEPTH
+// push out of the first (lowest slot) collider that is penetrated deeper than MAX_PEN_DEPTH.  Every lane only needs the signed distance of
+// its colliders; the contact normal is normalised for the winner alone (one divide per call; same values as closest().n)
 template <int NC, bool OBB = false>
 __device__ __forceinline__ bool recover_from_penetration(const Col (&col)[NC], V3 &pos)
 {
-    Closest c[NC];
+    Raw c[NC];
     bool pen[NC];
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
         pen[k] = false;
-        c[k].dist = 0.0f; c[k].n = v3(0, 0, 0);
-        if (col[k].kind != 0) {
-            c[k] = closest<OBB>(col[k], pos);
-            pen[k] = c[k].dist < -MAX_PEN_DEPTH;
-        }
+        c[k].dist = 0.0f; c[k].d = 1.0f; c[k].v = v3(0, 0, 0);
+        if (col[k].kind == 1) c[k] = raw_box(pos, col[k].lo, col[k].hi, CAP_R);
+        else if (OBB && col[k].kind >= 3) c[k] = raw_box(hex_to_local(col[k].kind - 3, pos), col[k].lo, col[k].hi, CAP_R);
+        else if (col[k].kind == 2) c[k] = raw_capsule(pos, col[k].lo, col[k].hi.x, 2 * CAP_R);
+        if (col[k].kind != 0) pen[k] = c[k].dist < -MAX_PEN_DEPTH;
     }
     // lowest slot first: slot = lane + 64 * k
     int which = -1, src = 0;
@@ -202,12 +277,17 @@ __device__ __forceinline__ bool recover_from_penetration(const Col (&col)[NC], V
         if (m != 0ull) { which = k; src = __ffsll((long long)m) - 1; }
     }
     if (which < 0) return false;
-    Closest w = c[0];
+    Raw w = c[0];
+    int kind = col[0].kind;
 #pragma unroll
     for (int k = 1; k < NC; ++k)
-        if (which == k) w = c[k];
-    const float dist = bcast_f(w.dist, src);
-    const V3 n = v3(bcast_f(w.n.x, src), bcast_f(w.n.y, src), bcast_f(w.n.z, src));
+        if (which == k) { w = c[k]; kind = col[k].kind; }
+    const float dist = bcast_f(w.dist, src), d = bcast_f(w.d, src);
+    const V3 v = v3(bcast_f(w.v.x, src), bcast_f(w.v.y, src), bcast_f(w.v.z, src));
+    kind = __shfl(kind, src, 64);
+    const float inv = 1.0f / d;
+    V3 n = v * inv;
+    if (OBB && kind >= 3) n = hex_to_world(kind - 3, n);
     const float push = -dist;
     pos = v3(pos.x + n.x * push, pos.y + n.y * push, pos.z + n.z * push);
     return true;

@@ -317,10 +317,12 @@ __device__ __forceinline__ void tower_tick(const GymView &gv, const int env)
     // ---- VectorEnv::step's auto-reset (vector_env.cpp:93-105): the wave of a finished env regenerates it right here.  About one
     // env in two thousand finishes per tick and its wave is not the slowest of the launch even with the generator on top, so
     // this costs nothing, where a separate "reset whoever is done" launch cost 4-7 us per step.
+#ifndef MV_EXP_NO_AUTO_RESET   // (timing experiments only: what the generator's 20 KB of LDS cost the kernels that run beside this one)
     if (h.done) {
         wave_sync();   // one wave per env: orders the stores above before the generator's
         reset_env(gv, env, 0);
     }
+#endif
 }
 
 // One workgroup per env: wave 0 runs the tick (one wave per env: physics, scenario logic, auto-reset), the others wait at the barrier;

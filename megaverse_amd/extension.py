@@ -57,6 +57,7 @@ SYMBOLS = [
     ("mv_profile_begin", C.c_int, [_P, _I]), ("mv_profile_end", C.c_int, [_P, _P, _P]),
     ("mv_set_pipelining", C.c_int, [_P, _I]), ("mv_get_pipelining", C.c_int, [_P]),
     ("mv_debug_set_agent_pos", C.c_int, [_P, _I, _I, _F, _F, _F]),
+    ("mv_debug_set_agent_yaw", C.c_int, [_P, _I, _I, _F, _F]), ("mv_debug_set_agent_velocity", C.c_int, [_P, _I, _I, _F, _F, _F]),
     ("mv_debug_snapshot_size", C.c_int, [_P]), ("mv_debug_snapshot", C.c_int, [_P, _I, _P]),
     ("mv_debug_rng", C.c_int, [_I, _U, _I, _P, _P, _I, _P]),
     ("mv_debug_math", C.c_int, [_I, _I, _P, _P, _I, _P]),
@@ -312,6 +313,12 @@ class MegaverseGym:
 
     def debug_set_agent_pos(self, env_idx, agent_idx, x, y, z):
         self._ck(self._lib.mv_debug_set_agent_pos(self._g, int(env_idx), int(agent_idx), float(x), float(y), float(z)))
+
+    def debug_set_agent_yaw(self, env_idx, agent_idx, c, s):
+        self._ck(self._lib.mv_debug_set_agent_yaw(self._g, int(env_idx), int(agent_idx), float(c), float(s)))
+
+    def debug_set_agent_velocity(self, env_idx, agent_idx, hvx, hvz, vvel):
+        self._ck(self._lib.mv_debug_set_agent_velocity(self._g, int(env_idx), int(agent_idx), float(hvx), float(hvz), float(vvel)))
 
     def debug_snapshot_bytes(self, env_idx):
         n = self._lib.mv_debug_snapshot_size(self._g)

@@ -1680,33 +1680,91 @@ static Closest closest(const Collider &col, V3 p, float rBox, float rCap)
     return closest_capsule(p, col.lo, col.hi.x, rCap);
 }
 
+// The closest-point query without the normalisation: v = p minus the collider's closest point (not unit), d = |v|, dist = the signed surface
+// distance; centre inside the grown box / on the capsule's axis: v = the unit exit normal, d = 1.  closest().n == v * (1 / d).
+struct Raw {
+    V3 v;
+    float d, dist;
+};
+
+static Raw raw_box(V3 p, V3 lo, V3 hi, float r)
+{
+    const float qx = std::min(std::max(p.x, lo.x), hi.x);
+    const float qy = std::min(std::max(p.y, lo.y), hi.y);
+    const float qz = std::min(std::max(p.z, lo.z), hi.z);
+    const V3 v = v3(p.x - qx, p.y - qy, p.z - qz);
+    const float d2 = len2(v);
+    Raw c;
+    if (d2 > 0.0f) {
+        c.d = sqrtf(d2);
+        c.dist = c.d - r;
+        c.v = v;
+    } else {
+        float m = p.x - lo.x; V3 n = v3(-1, 0, 0);
+        float t = hi.x - p.x; if (t < m) { m = t; n = v3(1, 0, 0); }
+        t = p.y - lo.y; if (t < m) { m = t; n = v3(0, -1, 0); }
+        t = hi.y - p.y; if (t < m) { m = t; n = v3(0, 1, 0); }
+        t = p.z - lo.z; if (t < m) { m = t; n = v3(0, 0, -1); }
+        t = hi.z - p.z; if (t < m) { m = t; n = v3(0, 0, 1); }
+        c.d = 1.0f;
+        c.dist = -m - r;
+        c.v = n;
+    }
+    return c;
+}
+
+static Raw raw_capsule(V3 p, V3 centre, float halfLen, float r)
+{
+    const float qy = std::min(std::max(p.y, centre.y - halfLen), centre.y + halfLen);
+    const V3 v = v3(p.x - centre.x, p.y - qy, p.z - centre.z);
+    const float d2 = len2(v);
+    Raw c;
+    if (d2 > 1e-12f) {
+        c.d = sqrtf(d2);
+        c.dist = c.d - r;
+        c.v = v;
+    } else {
+        c.d = 1.0f;
+        c.dist = -r;
+        c.v = v3(1, 0, 0);
+    }
+    return c;
+}
+
 // [3P] Bullet 2.89 btContinuousConvexCollision::calcTimeOfImpact restated for a translating
 // convex shape with exact closest points (conservative advancement).  Call sites in the
 // reference: kinematic_character_controller.cpp:252,363,425 (ghost convexSweepTest).
+// Bullet advances by dist / (-(d . n)) with the unit normal n = v / |v|; the same quotient is formed here as (dist |v|) / (-(d . v)) -- one
+// correctly rounded divide per iteration instead of two -- and the normal is normalised once, on a hit (the device's slowest tick is a
+// grazing cast that runs all 64 iterations).  A box in a hex wall frame is cast in that frame (start and direction rotated in once, the
+// normal rotated back once).  megaverse_amd/csrc/mv_physics.h: convex_cast is the same arithmetic, operation for operation.
 static bool convex_cast(const Collider &col, V3 p, V3 d, float *fraction, V3 *normal)
 {
+    const bool boxLike = col.kind != 2;
+    if (col.kind == 3) { p = hex_to_local(col.frame, p); d = hex_to_local(col.frame, d); }
     float lambda = 0.0f, lastLambda = 0.0f;
     int numIter = 0;
-    Closest c = closest(col, p, CAP_R, 2 * CAP_R);
+    Raw c = boxLike ? raw_box(p, col.lo, col.hi, CAP_R) : raw_capsule(p, col.lo, col.hi.x, 2 * CAP_R);
     float dist = c.dist + ALLOWED_CCD_PEN;
-    V3 n = c.n;
-    float proj = -dot(d, n);
-    if (proj <= SIMD_EPS) return false;
+    float proj = -dot(d, c.v);   // |v| times Bullet's projected velocity
+    if (proj <= SIMD_EPS * c.d) return false;
     while (dist > CAST_RADIUS) {
-        proj = -dot(d, n);
-        if (proj <= SIMD_EPS) return false;
-        lambda = lambda + dist / proj;
+        proj = -dot(d, c.v);
+        if (proj <= SIMD_EPS * c.d) return false;
+        lambda = lambda + (dist * c.d) / proj;
         if (lambda > 1.0f) return false;
         if (lambda < 0.0f) return false;
         if (lambda <= lastLambda) return false;
         lastLambda = lambda;
         const V3 x = v3(p.x + lambda * d.x, p.y + lambda * d.y, p.z + lambda * d.z);
-        c = closest(col, x, CAP_R, 2 * CAP_R);
+        c = boxLike ? raw_box(x, col.lo, col.hi, CAP_R) : raw_capsule(x, col.lo, col.hi.x, 2 * CAP_R);
         dist = c.dist + ALLOWED_CCD_PEN;
-        n = c.n;
         if (++numIter > CAST_MAX_ITER) return false;
     }
     *fraction = lambda;
+    const float inv = 1.0f / c.d;
+    V3 n = c.v * inv;
+    if (col.kind == 3) n = hex_to_world(col.frame, n);
     *normal = n;
     return true;
 }
@@ -3049,6 +3107,17 @@ struct SnapHeader {
 
 /* test hook: put an agent somewhere (e.g. below the fall-detection threshold, component_fall_detection.hpp:33-55) */
 void mvo_debug_set_agent_pos(mvo_gym *g, int env, int agent, float x, float y, float z) { g->envs[env]->agents[agent].pos = v3(x, y, z); }
+/* test hooks for the canonical-pose tests: the yaw basis from (cos, sin) exactly like spawn_agents builds it, and the velocities */
+void mvo_debug_set_agent_yaw(mvo_gym *g, int env, int agent, float c, float s)
+{
+    Agent &a = g->envs[env]->agents[agent];
+    a.m00 = c; a.m02 = s; a.m20 = -s; a.m22 = c;
+}
+void mvo_debug_set_agent_velocity(mvo_gym *g, int env, int agent, float hvx, float hvz, float vvel)
+{
+    Agent &a = g->envs[env]->agents[agent];
+    a.hvx = hvx; a.hvz = hvz; a.vvel = vvel;
+}
 
 int mvo_snapshot_size(mvo_gym *) { return (int)sizeof(SnapHeader); }
 

@@ -67,6 +67,8 @@ void mvo_set_reward_shaping(mvo_gym *g, int env_idx, int agent_idx, const char *
 /* Packed state snapshot, layout documented in DESIGN.md ("snapshot format");
  * identical to what mv_debug_snapshot() of the HIP library writes. */
 void mvo_debug_set_agent_pos(mvo_gym *g, int env_idx, int agent_idx, float x, float y, float z); /* test hook: teleport */
+void mvo_debug_set_agent_yaw(mvo_gym *g, int env_idx, int agent_idx, float c, float s);           /* test hook: yaw basis from (cos, sin) */
+void mvo_debug_set_agent_velocity(mvo_gym *g, int env_idx, int agent_idx, float hvx, float hvz, float vvel);
 int mvo_snapshot_size(mvo_gym *g);
 void mvo_snapshot(mvo_gym *g, int env_idx, void *out);
 

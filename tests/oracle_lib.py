@@ -66,6 +66,8 @@ def lib():
         L.mvo_get_reward_shaping.restype = C.c_float
         L.mvo_set_reward_shaping.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_float]
         L.mvo_debug_set_agent_pos.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float]
+        L.mvo_debug_set_agent_yaw.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]
+        L.mvo_debug_set_agent_velocity.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float]
         L.mvo_set_action_masks.argtypes = [C.c_void_p, C.c_void_p]
         L.mvo_snapshot_size.argtypes = [C.c_void_p]
         L.mvo_snapshot.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -162,6 +164,8 @@ class OracleGym:
             self.L.mvo_set_reward_shaping(self.g, env_idx, agent_idx, k.encode(), float(v))
 
     def debug_set_agent_pos(self, env_idx, agent_idx, x, y, z): self.L.mvo_debug_set_agent_pos(self.g, env_idx, agent_idx, x, y, z)
+    def debug_set_agent_yaw(self, env_idx, agent_idx, c, s): self.L.mvo_debug_set_agent_yaw(self.g, env_idx, agent_idx, c, s)
+    def debug_set_agent_velocity(self, env_idx, agent_idx, hvx, hvz, vvel): self.L.mvo_debug_set_agent_velocity(self.g, env_idx, agent_idx, hvx, hvz, vvel)
 
     def snapshot(self, env_idx):
         assert self.L.mvo_snapshot_size(self.g) == SNAP.itemsize, (self.L.mvo_snapshot_size(self.g), SNAP.itemsize)
