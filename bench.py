@@ -106,6 +106,44 @@ def cpu_baseline(scenario, obs_w, obs_h, n_env, agents, policy="multidiscrete"):
     return out
 
 
+def cpu_baseline_mixed(scenarios, obs_w, obs_h, n_env, agents):
+    """configs[4]: the oracle has one scenario per gym, like the reference (megaverse_env.py:27-39): one oracle gym per scenario with
+    n_env / len(scenarios) envs each, stepped one after the other on all host threads; median of three repetitions of the whole round"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib
+    from megaverse_amd.rollout import sample_actions, action_masks
+    threads = max(1, os.cpu_count() or 1)
+    per = n_env // len(scenarios)
+    gyms = []
+    for name in scenarios:
+        g = oracle_lib.OracleGym(name, obs_w, obs_h, per, agents, threads)
+        g.seed(42)
+        g.reset()
+        gyms.append(g)
+    rates, st, steps_total, t_total = [], 0, 0, 0.0
+    for _ in range(3):
+        steps, t0 = 0, time.perf_counter()
+        while True:
+            masks = action_masks(sample_actions(1234, st, per * agents))
+            for g in gyms:
+                g.set_action_masks(masks)
+                g.step()
+            steps += 1
+            st += 1
+            el = time.perf_counter() - t0
+            if el > 4.0 or steps >= 400:
+                break
+        rates.append(per * len(scenarios) * agents * steps / el)
+        steps_total += steps
+        t_total += el
+    for g in gyms:
+        g.close()
+    return {"value": float(np.median(rates)), "unit": "agent observations/sec", "cores": threads, "kind": "port",
+            "sample": f"oracle (CPU restatement, software raster; NOT the reference binary): {len(scenarios)} gyms ({', '.join(scenarios)}) x {per} envs, agents={agents}, "
+                      f"obs {obs_w}x{obs_h}, stepped one after the other on {threads} threads: {steps_total} rounds in {t_total:.1f} s, median of 3"}
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -261,8 +299,8 @@ def main():
     slabs = gather.local if gather else [torch.zeros((frames, H, W, 4), dtype=torch.uint8, device=device)]
     # batched stepping: tick j of a call renders into slab j of a ring, so that all `batch` observations of a call exist side by side when it
     # is done (a k-step rollout buffer) -- the working set of the observation writes is batch x one slab, not one slab written over and over
-    batched = batch > 1 and not dry and not mixed
-    ring = torch.zeros((batch, frames, H, W, 4), dtype=torch.uint8, device=device) if batched else None
+    batched = batch > 1 and not dry
+    ring = torch.zeros((batch, frames, H, W, 4), dtype=torch.uint8, device=device) if batched and not mixed else None   # (Mixed: one slab, no ring)
 
     def bind(b):
         if dry:
@@ -285,8 +323,8 @@ def main():
         gym.sample_random_actions(1234, i)
         gym.step()
         if with_gather:
-            if mixed:
-                gym.synchronize()   # (one stream per scenario: join them before the collective reads the slab)
+            if mixed and not gym.union:
+                gym.synchronize()   # (round-2 scheme, one stream per scenario: join them before the collective reads the slab)
             gather.after_render(b)
 
     def fence():
@@ -323,7 +361,7 @@ def main():
 
     step0 = 0
     main_batched = batched and not do_gather
-    if main_batched:
+    if main_batched and ring is not None:
         gym.set_output_ring(batch, ring.data_ptr())
     run_steps(step0, args.warmup, do_gather, main_batched)
     step0 += args.warmup
@@ -333,20 +371,22 @@ def main():
     elapsed_no_gather = None
     if do_gather:                            # second leg, same step count, observations stay on the producing GPU
         bind(0)
-        if batched:
+        if batched and ring is not None:
             gym.set_output_ring(batch, ring.data_ptr())
         elapsed_no_gather = timed(step0, False, batched)
         step0 += args.steps
 
     # ---- per-kernel profile: a separate, untimed loop with HIP events around every kernel, each interval on one stream
     prof = None
-    if not dry and not mixed and args.profile_steps > 0:
+    if not dry and args.profile_steps > 0:
         fence()
         gym.profile_begin(args.profile_steps)
         run_steps(step0, args.profile_steps, False, batched)
         prof = gym.profile_end()
+        if mixed:
+            prof = prof[0]   # (the union launches are timed on the group leader's events)
         step0 += args.profile_steps
-    if batched:
+    if batched and ring is not None:
         gym.set_output_ring(0)
         bind(0)
 
@@ -356,7 +396,10 @@ def main():
     #   closed_loop   a policy in the loop: a device-side policy reads the observations of tick t and produces the actions of tick t + 1
     #                 (torch ops on the gym's stream + mv_set_actions_device): nothing can overlap, this is what an RL learner gets
     extra = {}
-    pipelined = bool(not dry and not mixed and gym.pipelining())
+    pipelined = bool(not dry and (gym.gyms[0].pipelining() if mixed else gym.pipelining()))
+    if mixed and world == 1 and not args.no_extra_legs and batched:   # Mixed: one group step per tick (the hand-overs paid every tick)
+        run_steps(step0, min(args.warmup, 20), False, False); step0 += min(args.warmup, 20)
+        extra["single_step"] = timed(step0, False, False); step0 += args.steps
     if not dry and not mixed and world == 1 and not args.no_extra_legs:
         wu = min(args.warmup, 20)
         if batched and pipelined:
@@ -404,6 +447,8 @@ def main():
         # layout boxes, 80 movable boxes 320 B, agents 128 B each).  Obstacles: 128 layout boxes 4096 B + 16 terrain boxes 512 B + 16
         # reward objects 64 B; Collect: ~75 merged slabs on average (3000 generated landscapes) * 32 B + 96 diamonds * 4 B
         scene_bytes = (4096 + 512 + 64) if obst else (75 * 32 + 96 * 4) if collect else 512
+        if mixed:   # mean over the eight scenarios: TowerBuilding 512, 2 x Obstacles 4672, Collect 2784, Sokoban ~1300 (slabs + cell map), Rearrange ~600,
+            scene_bytes = (512 + 2 * 4672 + 2784 + 1300 + 600 + 2 * 700 * 32) // 8   # 2 x Hex ~700 boxes x 32 B
         bytes_per_frame = W * H * 4 + 128 + scene_bytes + 320 + 128 * A
         # physics kernel (tick + frame setup, one launch), per env: header R+W + scene + movable boxes R+W + per agent (state R+W, action,
         # reward, objective) + done, + per frame the list the raster reads: 800 B header + ~30 visible primitives x 40 B
@@ -421,6 +466,8 @@ def main():
                        # stepped and rendered in full); ticks_per_call > 1: mv_step_n, the streams hand over once per call, tick j of a call
                        # leaves its observations in slab j of a ring of that many slabs
                        "pipelined": pipelined, "ticks_per_call": batch if main_batched else 1,
+                       **({"launches_per_tick": 3, "scenarios": "TowerBuilding, ObstaclesEasy, ObstaclesHard, Collect, Sokoban, HexMemory, HexExplore, Rearrange dealt round-robin "
+                                                              "by env index (one gym per scenario, stepped as one mv_group)"} if mixed else {}),
                        "parallelism": f"env-shard x{world}"},
         }
         for key, el in extra.items():
@@ -451,7 +498,7 @@ def main():
             raster_ms, step_ms = prof["raster"][0], prof["step"][0]
             achieved = bytes_per_frame * frames / (raster_ms * 1e-3) / 1e9 if raster_ms > 0 else 0.0
             achieved_step = step_bytes_per_env * n_env / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
-            line["roofline"] = {"bound": "valu", "kernel": "mv::raster_fast_kernel" if args.pixels == "fast" else "mv::raster_kernel",
+            line["roofline"] = {"bound": "valu", "kernel": ("mv::raster_fast_union_kernel x 2 (short-list + long-list variant)" if mixed else "mv::raster_fast_kernel") if args.pixels == "fast" else "mv::raster_kernel",
                                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                 "avg_launch_ms": raster_ms, "launches_timed": prof["raster"][1], "algorithmic_bytes_per_launch": bytes_per_frame * frames,
                                 "note": "dominant kernel; achieved / peak / frac are the HBM figures (algorithmic bytes / launch time against 8 TB/s); "
@@ -463,7 +510,7 @@ def main():
                                             "insts_per_64px_tile": insts / (frames * W * H / 64.0),
                                             "issue_peak_insts_per_s": VALU_ISSUE_PEAK, "frac_of_issue_peak": insts / (raster_ms * 1e-3) / VALU_ISSUE_PEAK,
                                             "source": valu.get("source")}
-            line["roofline_physics"] = {"bound": "latency", "kernel": "mv::step_kernel (voxel physics + scenario logic + auto-reset + frame setup)", "achieved": achieved_step,
+            line["roofline_physics"] = {"bound": "latency", "kernel": ("mv::step_union_kernel" if mixed else "mv::step_kernel") + " (voxel physics + scenario logic + auto-reset + frame setup)", "achieved": achieved_step,
                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_step / HBM_PEAK_GBS, "traffic": traffic_step,
                                         "avg_launch_ms": step_ms, "launches_timed": prof["step"][1], "algorithmic_bytes_per_launch": step_bytes_per_env * n_env,
                                         "note": "north_star's >=40 % HBM target names this kernel; its working set is 1.7 KB per env (the 16 KB voxel chunk "
@@ -472,8 +519,12 @@ def main():
             if args.pixels == "exact":
                 line["kernels"] = {"publish_and_frame_sort": {"avg_launch_ms": prof["setup"][0], "note": "exact pixel mode only; same-stream interval"}}
         line["checksum"] = checksum
-        if world == 1 and not args.no_cpu_baseline and not mixed and not dry:   # (the CPU baseline runs one scenario per gym)
-            line["cpu_baseline"] = cpu_baseline(args.scenario, W, H, n_env, A, args.policy)
+        if world == 1 and not args.no_cpu_baseline and not dry:
+            if mixed:
+                from megaverse_amd.multitask import MEGAVERSE_IN_SCOPE as _MT
+                line["cpu_baseline"] = cpu_baseline_mixed(_MT, W, H, n_env, A)
+            else:
+                line["cpu_baseline"] = cpu_baseline(args.scenario, W, H, n_env, A, args.policy)
         print(json.dumps(line), flush=True)
 
     gym.close()

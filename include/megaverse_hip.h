@@ -80,6 +80,17 @@ int mv_set_sample_policy(mv_gym *g, int32_t policy);
  * the scripts under megaverse_rl/runs): for each gym, optionally mv_sample_random_actions(seed, step_index), then mv_step / mv_step_no_render */
 int mv_step_many(mv_gym *const *gyms, int32_t n, int32_t render, int32_t sample, uint32_t seed, uint32_t step_index);
 
+/* Groups: up to 8 gyms of one job -- one per scenario of a multi-task batch, the reference's layout (megaverse/megaverse_env.py:27-39: one
+ * MegaverseGym per task) -- stepped TOGETHER: one step launch and at most two observation launches per tick for all of them, on one
+ * shared pair of streams (BASELINE.json configs[4]: scenarios dealt round-robin over the envs of one batch; every gym keeps its env_offset /
+ * env_stride, so seeds and sampled actions are the job-wide ones).  The members must share device, observation size, agents per env and
+ * stream.  While grouped a gym is stepped through the group only; everything else (reset, seed, getters, shaping) stays per gym.
+ * mv_group_step: k ticks like mv_step_n (render = 0: no observation pass).  Closing a member dissolves the group. */
+typedef struct mv_group mv_group;
+int mv_group_create(mv_gym *const *gyms, int32_t n, mv_group **out);
+int mv_group_step(mv_group *grp, int32_t k, int32_t render, int32_t policy, uint32_t seed, uint32_t first_step_index);
+int mv_group_destroy(mv_group *grp);
+
 int mv_step(mv_gym *g);                             /* step(), :118-121: VectorEnv::step incl. auto-reset + render */
 int mv_step_no_render(mv_gym *g);                   /* physics/logic/auto-reset only */
 /* k open-loop ticks with one call = k iterations of the reference's benchmark loop body "for every agent setAction(random); venv.step()"

@@ -24,6 +24,7 @@
 #include "mv_math.h"
 #include "mv_rng.h"
 #include "mv_types.h"
+#include "mv_union.h"
 
 namespace mv {
 void launch_reset(const GymView &gv, int force_all, hipStream_t stream);
@@ -81,6 +82,10 @@ static const float SHAPING_DEFAULT_COLLECT[5] = {0.0f, 1.0f, -1.0f, 5.0f, -0.5f}
 static const int ACTION_SPACE[6] = {3, 3, 3, 2, 2, 3};                          // env.cpp:33
 
 static_assert(PIPE_GROUPS == 3, "userMark events are created one by one in mv_create");
+struct mv_gym;
+struct mv_group {
+    std::vector<mv_gym *> gyms;   // gyms[0] is the leader; empty once a member was closed
+};
 struct mv_gym {
     int device = 0;
     int w = 0, h = 0, renderW = 768, renderH = 432;   // megaverse.cpp:261
@@ -117,6 +122,10 @@ struct mv_gym {
     uint8_t *ringObs = nullptr, *ringDone = nullptr;
     float *ringRewards = nullptr;
     std::string warning;                         // soft conditions (capacity flags) of the last call: returned as 1, not as an error
+    // mv_group: the gyms of a group share the leader's simulation stream and events; a member keeps its own handles here until it leaves
+    mv_group *inGroup = nullptr;
+    hipStream_t ownSimStream = nullptr;
+    hipEvent_t ownUserMark[PIPE_GROUPS] = {}, ownSimDone = nullptr, ownStepDone = nullptr;
     uint8_t *arena = nullptr;
     uint32_t *obs = nullptr, *ownedObs = nullptr, *hiresObs = nullptr;
     int hiresW = 0, hiresH = 0;
@@ -348,6 +357,18 @@ static bool scenario_from_name(const std::string &scen, int &scenario, ObstacleC
     return true;
 }
 
+// the simulation stream; MV_SIM_PRIORITY=low|high gives its queue another priority than the caller's (an experiment knob: measured, no gain)
+static hipError_t create_sim_stream(hipStream_t *s)
+{
+    const char *e = getenv("MV_SIM_PRIORITY");
+    if (e && *e) {
+        int lo = 0, hi = 0;   // (numerically: lowest priority = `lo`, the larger value)
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+            return hipStreamCreateWithPriority(s, hipStreamNonBlocking, std::string(e) == "low" ? lo : hi);
+    }
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+
 extern "C" {
 
 int mv_create(const mv_config *cfg, mv_gym **out)
@@ -509,7 +530,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     {   // status words (episodes consumed, error flags) travel back on a side stream for every scenario
         bool ok = hipHostMalloc((void **)&g->hStatus, (N + 2) * sizeof(int), hipHostMallocDefault) == hipSuccess &&
                   hipStreamCreateWithFlags(&g->copyStream, hipStreamNonBlocking) == hipSuccess &&
-                  hipStreamCreateWithFlags(&g->simStream, hipStreamNonBlocking) == hipSuccess &&
+                  create_sim_stream(&g->simStream) == hipSuccess &&
                   hipEventCreateWithFlags(&g->userMark[0], hipEventDisableTiming) == hipSuccess &&
                   hipEventCreateWithFlags(&g->userMark[1], hipEventDisableTiming) == hipSuccess &&
                   hipEventCreateWithFlags(&g->userMark[2], hipEventDisableTiming) == hipSuccess &&
@@ -582,10 +603,17 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     return 0;
 }
 
+static void group_detach(mv_gym *g);
+
 int mv_close(mv_gym *g)
 {
     if (!g || g->closed) return 0;
     (void)hipSetDevice(g->device);
+    if (g->inGroup) {   // a member leaves: everything the group has in flight first, then every member gets its own stream and events back
+        (void)hipStreamSynchronize(g->simStream);
+        (void)hipStreamSynchronize(g->stream);
+        group_detach(g);
+    }
     // order: nothing may still target the arena (episode uploads / status read-backs on the copy stream, kernels on the step
     // stream) or the pinned slots (feeder workers) when they are freed.  The step stream may be caller-owned and already gone:
     // its errors are ignored, the device-wide synchronise below covers whatever was enqueued on it.
@@ -638,6 +666,7 @@ int mv_num_agents(const mv_gym *g) { return g ? g->A : -1; }
 int mv_set_stream(mv_gym *g, void *s)
 {
     if (check(g)) return -1;
+    if (g->inGroup) return fail("mv_set_stream: the gym belongs to a group (set the stream before mv_group_create)");
     HIP_TRY(hipStreamSynchronize(g->simStream));
     HIP_TRY(hipStreamSynchronize(g->stream));
     g->stream = (hipStream_t)s;
@@ -666,6 +695,7 @@ int mv_get_pixel_mode(const mv_gym *g) { return g ? g->fastPixels : -1; }
 int mv_set_pipelining(mv_gym *g, int32_t on)
 {
     if (check(g)) return -1;
+    if (g->inGroup) return fail("mv_set_pipelining: the gym belongs to a group (set it before mv_group_create)");
     if (sim_join(g)) return -1;
     g->pipelined = on != 0;
     return 0;
@@ -961,93 +991,161 @@ static void launch_step_of(const mv_gym *g, const GymView &v, hipStream_t sim, i
     else launch_step(v, sim, g->w, g->h, fused);
 }
 
-// One stepping call = k ticks (mv_step: 1; mv_step_n: up to `batch`).  policy != POLICY_NONE: tick j draws its actions inside the step kernel
+// One stepping call = k ticks (mv_step: 1; mv_step_n: up to `batch`) of n gyms that share one pair of streams (n = 1: a gym on its own;
+// n > 1: an mv_group, stepped by union launches).  gs[0] is the leader: the stream state that changes with every call -- marks, which stream
+// the last step ran on -- is kept on it and mirrored to the others.  policy != POLICY_NONE: tick j draws its actions inside the step kernel
 // from (seed, first_index + j); POLICY_NONE: the first tick acts on what mv_set_actions* left, the following ones on cleared actions
 // (env.cpp:141-142 clears them after every tick).
-static int step_impl(mv_gym *g, bool render, int k, int policy, uint32_t seed, uint32_t first_index)
+static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, uint32_t seed, uint32_t first_index)
 {
-    if (check(g)) return -1;
-    if (!g->wasReset) return fail("mv_step: call mv_reset first");
-    if (k < 1 || k > g->batch) return fail("mv_step_n: 1 <= k <= " + std::to_string(g->batch) + " (MV_PIPE_BATCH) required");
-    HIP_TRY(hipSetDevice(g->device));
-    if (refill_episodes(g) < 0) return -1;
+    mv_gym *const L = gs[0];
+    int batch = L->batch;
+    bool mustWait = false, allFast = true, anyHostEpisodes = false;
+    for (int i = 0; i < n; ++i) {
+        mv_gym *g = gs[i];
+        if (check(g)) return -1;
+        if (!g->wasReset) return fail("mv_step: call mv_reset first");
+        batch = std::min(batch, g->batch);
+        mustWait = mustWait || g->simMustWaitUser;
+        allFast = allFast && g->fastPixels != 0;
+        anyHostEpisodes = anyHostEpisodes || g->hostEpisodes();
+    }
+    if (k < 1 || k > batch) return fail("mv_step_n: 1 <= k <= " + std::to_string(batch) + " (MV_PIPE_BATCH) required");
+    HIP_TRY(hipSetDevice(L->device));
+    for (int i = 0; i < n; ++i)
+        if (refill_episodes(gs[i]) < 0) return -1;
     // ---- what this call must wait for on the caller's stream.  Always: whatever was there when the call PIPE_GROUPS - 1 calls ago began --
     // the observation passes and the consumers of the call that used this slot group last.  Everything, when the caller's stream
     // feeds the simulation (reset / render / device actions / test hooks since the last step).  (Both raster kernels read nothing but the
     // frame lists and headers of their tick: the simulator state may move on underneath them.)
     // Not pipelined (mv_set_pipelining(0)), or ONE tick whose inputs come from the caller's stream (a policy in the loop: nothing can overlap,
     // the two queue hand-overs, ~10 us each, would be pure cost): the step runs on the caller's stream like everything else.
-    const bool own = g->pipelined != 0 && !(g->simMustWaitUser && k == 1);
-    hipStream_t sim = own ? g->simStream : g->stream;
+    const bool own = L->pipelined != 0 && !(mustWait && k == 1);
+    hipStream_t sim = own ? L->simStream : L->stream;
     if (own) {
-        hipEvent_t mark = g->userMark[g->markCount % PIPE_GROUPS];
-        HIP_TRY(hipEventRecord(mark, g->stream));
-        if (g->simMustWaitUser || !g->simOnOwnStream) HIP_TRY(hipStreamWaitEvent(sim, mark, 0));   // (or the last step ran on the caller's stream)
-        else if (g->markCount >= PIPE_GROUPS - 1) HIP_TRY(hipStreamWaitEvent(sim, g->userMark[(g->markCount - (PIPE_GROUPS - 1)) % PIPE_GROUPS], 0));
-        ++g->markCount;
+        hipEvent_t mark = L->userMark[L->markCount % PIPE_GROUPS];
+        HIP_TRY(hipEventRecord(mark, L->stream));
+        if (mustWait || !L->simOnOwnStream) HIP_TRY(hipStreamWaitEvent(sim, mark, 0));   // (or the last step ran on the caller's stream)
+        else if (L->markCount >= PIPE_GROUPS - 1) HIP_TRY(hipStreamWaitEvent(sim, L->userMark[(L->markCount - (PIPE_GROUPS - 1)) % PIPE_GROUPS], 0));
+        ++L->markCount;
     } else {
-        if (g->simOnOwnStream && g->simDoneValid) HIP_TRY(hipStreamWaitEvent(sim, g->simDone, 0));   // the last step ran on the other stream
-        if (g->uploadNotOnUser && g->lastUpload) HIP_TRY(hipStreamWaitEvent(sim, g->lastUpload, 0));  // (episode uploads make the simulation stream wait)
-        g->uploadNotOnUser = false;
-        g->markCount = 0;
+        if (L->simOnOwnStream && L->simDoneValid) HIP_TRY(hipStreamWaitEvent(sim, L->simDone, 0));   // the last step ran on the other stream
+        for (int i = 0; i < n; ++i) {   // (episode uploads make the simulation stream wait)
+            if (gs[i]->uploadNotOnUser && gs[i]->lastUpload) HIP_TRY(hipStreamWaitEvent(sim, gs[i]->lastUpload, 0));
+            gs[i]->uploadNotOnUser = false;
+        }
+        L->markCount = 0;
     }
-    g->simMustWaitUser = false;
-    g->simOnOwnStream = own;
-    if (g->actionsDirty) {
-        const int s = g->stage;
-        HIP_TRY(hipMemcpyAsync(g->gv.actions, g->hActions[s], (size_t)g->N * g->A * sizeof(int32_t), hipMemcpyHostToDevice, sim));
-        HIP_TRY(hipEventRecord(g->actionsCopied[s], sim));
-        g->stage = 1 - s;
-        HIP_TRY(hipEventSynchronize(g->actionsCopied[g->stage]));   // long done: recorded one step ago
-        std::memset(g->hActions[g->stage], 0, (size_t)g->N * g->A * sizeof(int32_t));   // actions are cleared every tick (env.cpp:141-142)
-        g->actionsDirty = false;
+    for (int i = 0; i < n; ++i) {
+        mv_gym *g = gs[i];
+        g->simMustWaitUser = false;
+        g->simOnOwnStream = own;
+        g->markCount = L->markCount;
+        if (g->actionsDirty) {
+            const int s = g->stage;
+            HIP_TRY(hipMemcpyAsync(g->gv.actions, g->hActions[s], (size_t)g->N * g->A * sizeof(int32_t), hipMemcpyHostToDevice, sim));
+            HIP_TRY(hipEventRecord(g->actionsCopied[s], sim));
+            g->stage = 1 - s;
+            HIP_TRY(hipEventSynchronize(g->actionsCopied[g->stage]));   // long done: recorded one step ago
+            std::memset(g->hActions[g->stage], 0, (size_t)g->N * g->A * sizeof(int32_t));   // actions are cleared every tick (env.cpp:141-142)
+            g->actionsDirty = false;
+        }
+        g->group = (g->group + 1) % PIPE_GROUPS;
     }
     const int fused = render ? 1 : 0;   // the step kernel also builds the frame lists when an observation pass follows
-    g->group = (g->group + 1) % PIPE_GROUPS;
-    GymView views[PIPE_BATCH_MAX];
-    OutPtrs outs[PIPE_BATCH_MAX];
+    std::vector<GymView> views((size_t)n * k);
+    std::vector<OutPtrs> outs((size_t)n * k);
     hipEvent_t *evs[PIPE_BATCH_MAX];
     // ---- the k step kernels, back to back on the simulation stream
     for (int j = 0; j < k; ++j) {
-        const bool prof = render && g->profCount < g->profMax;
-        evs[j] = prof ? &g->profEvents[(size_t)g->profCount * 5] : nullptr;
-        if (prof) ++g->profCount;
-        if (policy != POLICY_NONE) { g->gv.sample_on = policy; g->gv.sample_seed = seed; g->gv.sample_step = first_index + (uint32_t)j; }
-        else { g->gv.sample_on = (j == 0 && g->samplePending) ? g->samplePolicy : (int)POLICY_NONE; }
-        g->parity = g->group * g->batch + j;
-        if (render) g->hist3 = (g->hist3 + 1) % g->hists;   // (this pass's frame setup fills the next cost histogram and clears the one after)
-        outs[j] = outputs_of(g, g->ringTick++);
-        views[j] = view(g, g->parity, own ? nullptr : &outs[j]);
-        if (j == 0 && g->gv.sample_on == POLICY_NONE) views[j].md_actions = g->mdActions;
+        const bool prof = render && L->profCount < L->profMax;
+        evs[j] = prof ? &L->profEvents[(size_t)L->profCount * 5] : nullptr;
+        if (prof) ++L->profCount;
+        UnionStepArgs ua;
+        ua.n = n;
+        int envs = 0;
+        for (int i = 0; i < n; ++i) {
+            mv_gym *g = gs[i];
+            if (policy != POLICY_NONE) { g->gv.sample_on = policy; g->gv.sample_seed = seed; g->gv.sample_step = first_index + (uint32_t)j; }
+            else { g->gv.sample_on = (j == 0 && g->samplePending) ? g->samplePolicy : (int)POLICY_NONE; }
+            g->parity = g->group * g->batch + j;
+            if (render) g->hist3 = (g->hist3 + 1) % g->hists;   // (this pass's frame setup fills the next cost histogram and clears the one after)
+            OutPtrs &o = outs[(size_t)j * n + i];
+            o = outputs_of(g, g->ringTick++);
+            GymView &v = views[(size_t)j * n + i];
+            v = view(g, g->parity, own ? nullptr : &o);
+            if (j == 0 && g->gv.sample_on == POLICY_NONE) v.md_actions = g->mdActions;
+            if (n > 1) { ua.first[i] = envs; ua.gv[i] = v; envs += g->N; }
+        }
         if (evs[j]) HIP_TRY(hipEventRecord(evs[j][0], sim));
-        launch_step_of(g, views[j], sim, fused);
+        if (n == 1) launch_step_of(L, views[(size_t)j * n], sim, fused);
+        else {
+            for (int i = n; i <= MAX_UNION; ++i) ua.first[i] = envs;
+            launch_step_union(ua, sim, L->w, L->h, fused);
+        }
         if (evs[j]) HIP_TRY(hipEventRecord(evs[j][1], sim));
     }
-    g->samplePending = false;
-    g->mdActions = nullptr;
-    if (own) { HIP_TRY(hipEventRecord(g->simDone, sim)); g->simDoneValid = true; }   // (not pipelined: stream order does it)
+    if (own) HIP_TRY(hipEventRecord(L->simDone, sim));   // (not pipelined: stream order does it)
     // (every step kernel regenerates / swaps the next episode into the envs it finishes)
     // An env needs a fresh resident episode only at its NEXT reset, normally hundreds of steps away, and two are resident: the status
     // words are read back -- and the refill considered -- every statusPeriod-th step (16; 1 when episodes can be a few ticks long).
-    if (g->hostEpisodes()) { HIP_TRY(hipEventRecord(g->stepDone, sim)); g->stepDoneValid = true; }
-    g->stepsSinceStatus += k;
-    if (g->stepsSinceStatus >= g->statusPeriod) {   // (TowerBuilding regenerates finished envs in the kernel: only the error flags matter)
-        if (read_back_status(g, sim)) return -1;
-        g->stepsSinceStatus = 0;
+    if (anyHostEpisodes) HIP_TRY(hipEventRecord(L->stepDone, sim));   // (the gyms of a group share the leader's event)
+    for (int i = 0; i < n; ++i) {
+        mv_gym *g = gs[i];
+        g->samplePending = false;
+        g->mdActions = nullptr;
+        if (own) g->simDoneValid = true;
+        if (anyHostEpisodes) g->stepDoneValid = true;
+        g->stepsSinceStatus += k;
+        if (g->stepsSinceStatus >= g->statusPeriod) {   // (TowerBuilding regenerates finished envs in the kernel: only the error flags matter)
+            if (read_back_status(g, sim)) return -1;
+            g->stepsSinceStatus = 0;
+        }
+        g->mirrorsFresh = false;
     }
     // ---- the caller's stream: per tick the step's outputs, then the observation pass
-    if (own) HIP_TRY(hipStreamWaitEvent(g->stream, g->simDone, 0));
+    if (own) HIP_TRY(hipStreamWaitEvent(L->stream, L->simDone, 0));
+    std::vector<PublishTo> pubs((size_t)n);
+    std::vector<uint32_t *> obsPtrs((size_t)n);
     for (int j = 0; j < k; ++j) {
-        if (evs[j]) HIP_TRY(hipEventRecord(evs[j][2], g->stream));
-        const PublishTo pub{outs[j].rewards, outs[j].done, g->gv.true_objective};
-        if (own && (!render || !g->fastPixels) && publish_outputs(g, g->group * g->batch + j, outs[j])) return -1;   // (the fast observation pass publishes with its first workgroups)
-        if (render && launch_raster(views[j], outs[j].obs, g->w, g->h, g->stream, evs[j] ? evs[j][3] : nullptr, g->fastPixels, /*setup_done=*/1, own && g->fastPixels ? &pub : nullptr))
-            return fail("mv_step: observation size above 1024x1024");
-        if (evs[j]) { if (!render) HIP_TRY(hipEventRecord(evs[j][3], g->stream)); HIP_TRY(hipEventRecord(evs[j][4], g->stream)); }
+        if (evs[j]) HIP_TRY(hipEventRecord(evs[j][2], L->stream));
+        for (int i = 0; i < n; ++i) {
+            const OutPtrs &o = outs[(size_t)j * n + i];
+            pubs[i] = PublishTo{o.rewards, o.done, gs[i]->gv.true_objective};
+            obsPtrs[i] = o.obs;
+            if (own && (!render || !allFast) && publish_outputs(gs[i], gs[i]->group * gs[i]->batch + j, o)) return -1;   // (the fast observation pass publishes with its first workgroups)
+        }
+        if (render) {
+            const bool pubInRaster = own && allFast;
+            if (n > 1 && allFast) {
+                if (launch_raster_union(&views[(size_t)j * n], obsPtrs.data(), pubInRaster ? pubs.data() : nullptr, n, L->w, L->h, L->stream, evs[j] ? evs[j][3] : nullptr))
+                    return fail("mv_step: observation size above 1024x1024");
+            } else {
+                for (int i = 0; i < n; ++i)
+                    if (launch_raster(views[(size_t)j * n + i], obsPtrs[i], L->w, L->h, L->stream, evs[j] && i == 0 ? evs[j][3] : nullptr, gs[i]->fastPixels, /*setup_done=*/1,
+                                      pubInRaster ? &pubs[i] : nullptr))
+                        return fail("mv_step: observation size above 1024x1024");
+            }
+        }
+        if (evs[j]) HIP_TRY(hipEventRecord(evs[j][4], L->stream));
     }
     HIP_TRY(hipGetLastError());
-    g->mirrorsFresh = false;
-    return finish_with_warning(g);
+    int rc = 0;
+    std::string text;
+    for (int i = 0; i < n; ++i)
+        if (!gs[i]->warning.empty()) {
+            text += (text.empty() ? "" : " | ") + (n > 1 ? "gym " + std::to_string(i) + ": " : std::string()) + gs[i]->warning;
+            gs[i]->warning.clear();
+            rc = 1;
+        }
+    if (rc) g_err = text;
+    return rc;
+}
+
+static int step_impl(mv_gym *g, bool render, int k, int policy, uint32_t seed, uint32_t first_index)
+{
+    if (g && g->inGroup) return fail("this gym belongs to an mv_group: step the group (mv_group_step)");
+    return step_gyms(&g, 1, render, k, policy, seed, first_index);
 }
 
 int mv_step(mv_gym *g) { return step_impl(g, true, 1, POLICY_NONE, 0, 0); }
@@ -1069,6 +1167,89 @@ int mv_step_n(mv_gym *g, int32_t k, int32_t policy, uint32_t seed, uint32_t firs
         if (r > 0) { g->warning = g_err; rc = 1; }
     }
     if (rc) { g_err = g->warning; g->warning.clear(); }
+    return rc;
+}
+
+// ---- groups: several gyms of one job stepped with union launches (mv_step_union.hip, mv_raster.hip: launch_raster_union)
+static void group_detach(mv_gym *g)
+{   // back to the gym's own simulation stream and events (they were kept aside while it was a member)
+    if (!g->inGroup) return;
+    mv_group *grp = g->inGroup;
+    for (mv_gym *m : grp->gyms) {
+        if (m != grp->gyms[0]) {
+            m->simStream = m->ownSimStream; m->simDone = m->ownSimDone; m->stepDone = m->ownStepDone;
+            for (int q = 0; q < PIPE_GROUPS; ++q) m->userMark[q] = m->ownUserMark[q];
+        }
+        m->inGroup = nullptr;
+        m->simMustWaitUser = true; m->simOnOwnStream = false; m->simDoneValid = false; m->stepDoneValid = false; m->markCount = 0;
+    }
+    grp->gyms.clear();   // (the handle stays valid until mv_group_destroy; stepping it is an error from now on)
+}
+
+int mv_group_create(mv_gym *const *gyms, int32_t n, mv_group **out)
+{
+    if (!gyms || !out || n < 1 || n > MAX_UNION) return fail("mv_group_create: 1 <= n <= 8 gyms required");
+    *out = nullptr;
+    mv_gym *L = gyms[0];
+    for (int i = 0; i < n; ++i) {
+        mv_gym *g = gyms[i];
+        if (check(g)) return -1;
+        if (g->inGroup) return fail("mv_group_create: a gym already belongs to a group");
+        for (int j = 0; j < i; ++j) if (gyms[j] == g) return fail("mv_group_create: the same gym twice");
+        if (g->device != L->device || g->w != L->w || g->h != L->h || g->A != L->A || g->stream != L->stream || g->batch != L->batch || g->pipelined != L->pipelined)
+            return fail("mv_group_create: the gyms of a group share device, observation size, agents per env, stream (mv_set_stream first), batch and pipelining");
+    }
+    HIP_TRY(hipSetDevice(L->device));
+    for (int i = 0; i < n; ++i) {   // nothing in flight on the streams a member is about to leave
+        HIP_TRY(hipStreamSynchronize(gyms[i]->simStream));
+        HIP_TRY(hipStreamSynchronize(gyms[i]->stream));
+    }
+    mv_group *grp = new mv_group();
+    grp->gyms.assign(gyms, gyms + n);
+    for (int i = 0; i < n; ++i) {
+        mv_gym *g = gyms[i];
+        g->inGroup = grp;
+        if (i > 0) {
+            g->ownSimStream = g->simStream; g->ownSimDone = g->simDone; g->ownStepDone = g->stepDone;
+            g->simStream = L->simStream; g->simDone = L->simDone; g->stepDone = L->stepDone;
+            for (int q = 0; q < PIPE_GROUPS; ++q) { g->ownUserMark[q] = g->userMark[q]; g->userMark[q] = L->userMark[q]; }
+        }
+        g->simMustWaitUser = true; g->simOnOwnStream = false; g->simDoneValid = false; g->stepDoneValid = false; g->markCount = 0;
+    }
+    *out = grp;
+    return 0;
+}
+
+int mv_group_destroy(mv_group *grp)
+{
+    if (!grp) return 0;
+    if (!grp->gyms.empty()) {
+        mv_gym *L = grp->gyms[0];
+        (void)hipSetDevice(L->device);
+        (void)hipStreamSynchronize(L->simStream);
+        (void)hipStreamSynchronize(L->stream);
+        group_detach(L);
+    }
+    delete grp;
+    return 0;
+}
+
+int mv_group_step(mv_group *grp, int32_t k, int32_t render, int32_t policy, uint32_t seed, uint32_t first_step_index)
+{
+    if (!grp || grp->gyms.empty()) return fail("mv_group_step: the group is gone (a member was closed)");
+    if (policy != MV_POLICY_NONE && policy != MV_POLICY_MULTIDISCRETE && policy != MV_POLICY_SINGLE_BIT) return fail("mv_group_step: unknown policy");
+    if (k < 1) return fail("mv_group_step: k >= 1 required");
+    int chunk = grp->gyms[0]->batch;
+    for (mv_gym *g : grp->gyms)
+        if (!g->closed && g->statusPeriod <= 1) chunk = 1;   // (episodes of a few ticks: the refill protocol looks at the consumed counts after every tick)
+    int rc = 0;
+    std::string text;
+    for (int done = 0; done < k; done += chunk) {
+        const int r = step_gyms(grp->gyms.data(), (int)grp->gyms.size(), render != 0, std::min(chunk, k - done), policy, seed, first_step_index + (uint32_t)done);
+        if (r < 0) return -1;
+        if (r > 0) { text += (text.empty() ? "" : " | ") + g_err; rc = 1; }
+    }
+    if (rc) g_err = text;
     return rc;
 }
 

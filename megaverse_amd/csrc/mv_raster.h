@@ -16,4 +16,8 @@ struct PublishTo { float *rewards; uint8_t *done; float *true_objective; };
 int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream, hipEvent_t between = nullptr, int fast = 1, int setup_done = 0,
                   const PublishTo *publish = nullptr);
 
+// the fast observation pass of n gyms of one job (frame lists already built by their step kernels) with at most two launches; publish: n
+// entries or null; -1 if W / H / n are too large
+int launch_raster_union(const GymView *views, uint32_t *const *obs, const PublishTo *publish, int n, int W, int H, hipStream_t stream, hipEvent_t between = nullptr);
+
 }  // namespace mv

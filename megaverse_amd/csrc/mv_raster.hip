@@ -38,6 +38,7 @@
 #include "mv_raster.h"
 #include "mv_rearrange.h"
 #include "mv_types.h"
+#include "mv_union.h"
 
 namespace mv {
 
@@ -554,10 +555,10 @@ struct FastArgs {   // what raster_fast_kernel needs of the GymView (fewer live 
 };
 
 // true_objective is only ever recorded by a finishing env (vector_env.cpp:96-101): the others keep the value of their last episode
-__device__ __forceinline__ void fast_publish(const FastArgs &fa)
+__device__ __forceinline__ void fast_publish(const FastArgs &fa, int blk)
 {
     if (fa.pub_n == 0) return;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blk * 256 + threadIdx.x;
     if (i >= fa.pub_n) return;
     fa.pub_rewards[i] = fa.stage_rewards[i];
     const int e = i / fa.num_agents;
@@ -728,14 +729,14 @@ struct FastFrame { int frame, part, viewer, nVis; };
 // one barrier.  Workgroup ids are dealt round-robin over the 8 XCDs; the `split` parts of one frame get ids that are congruent mod 8 so that they
 // share one XCD's L2 (the frame's list is read `split` times, neighbouring tiles write neighbouring lines).
 template <int MAXVIS>
-__device__ __forceinline__ FastFrame fast_prologue(const FastArgs &fa, int W, int H, int split, float4 *s_vis, short4 *s_rect, float *s_hdr, float4 *s_col,
+__device__ __forceinline__ FastFrame fast_prologue(const FastArgs &fa, int blk, int W, int H, int split, float4 *s_vis, short4 *s_rect, float *s_hdr, float4 *s_col,
                                                    float4 *s_row, float2 *s_rowq, float *s_colq)
 {
     const int A = fa.num_agents;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int position, part;
     {
-        const int per = 8 * split, group = blockIdx.x / per, r = blockIdx.x - group * per;
+        const int per = 8 * split, group = blk / per, r = blk - group * per;   // blk: this workgroup's index within its gym's part of the grid
         position = group * 8 + (r & 7); part = r >> 3;
         const int frames = fa.frames;
         if (group * 8 + 8 > frames) { const int nf = frames - group * 8; position = group * 8 + r % nf; part = r / nf; }
@@ -825,8 +826,8 @@ __device__ __forceinline__ void box_run(unsigned long long m, int k, const V3 (&
 // ballots, the scalar loop control, the LDS fetch of every surviving record and the column terms of the ray are paid once per two pixels,
 // and the two pixels' dependency chains (rcp -> slab test -> key, shading) interleave; per-pixel arithmetic is unchanged, and culling being
 // conservative the pixels are identical to NP = 1 (tests/test_fast_pixels_gpu.py: test_pixels_per_lane_variants_agree).
-template <int MAXVIS, bool SHAPES, int WAVES, bool HEXF = false, int NP = 1>   // WAVES: waves per SIMD the variant is compiled for (register budget 512 / WAVES)
-__global__ __launch_bounds__(256, WAVES) void raster_fast_kernel(FastArgs fa, uint32_t *obs, int W, int H, int split)
+template <int MAXVIS, bool SHAPES, bool HEXF, int NP>
+__device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *obs, int W, int H, int split, int blk)
 {
     constexpr unsigned POS_MASK = MAXVIS - 1;
     constexpr int TH = TILE_H * NP;           // tile height
@@ -842,8 +843,8 @@ __global__ __launch_bounds__(256, WAVES) void raster_fast_kernel(FastArgs fa, ui
     float *s_colq = reinterpret_cast<float *>(s_rowq + H);    // dc.x^2   (last: keeps every table naturally aligned for odd W)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    fast_publish(fa);
-    const FastFrame ff = fast_prologue<MAXVIS>(fa, W, H, split, s_vis, s_rect, s_hdr, s_col, s_row, s_rowq, s_colq);
+    fast_publish(fa, blk);
+    const FastFrame ff = fast_prologue<MAXVIS>(fa, blk, W, H, split, s_vis, s_rect, s_hdr, s_col, s_row, s_rowq, s_colq);
     const int frame = ff.frame, part = ff.part, viewer = ff.viewer, nVis = ff.nVis;
 
     const float *camv = s_hdr + FH_CAM + FH_CAM_STRIDE * viewer;   // eye(3) c(9) origin(3)
@@ -943,6 +944,85 @@ __global__ __launch_bounds__(256, WAVES) void raster_fast_kernel(FastArgs fa, ui
     }
 }
 
+template <int MAXVIS, bool SHAPES, int WAVES, bool HEXF = false, int NP = 1>   // WAVES: waves per SIMD the variant is compiled for (register budget 512 / WAVES)
+__global__ __launch_bounds__(256, WAVES) void raster_fast_kernel(FastArgs fa, uint32_t *obs, int W, int H, int split)
+{
+    raster_fast_body<MAXVIS, SHAPES, HEXF, NP>(fa, obs, W, H, split, (int)blockIdx.x);
+}
+
+// The observation pass of several gyms of one job with one launch (mv_group): workgroup b belongs to gym s with first[s] <= b < first[s + 1]
+// and is workgroup b - first[s] of that gym's own grid -- its frame lists, cost bins, header slab, observation slab.  One variant serves
+// every gym of the launch: the caller groups the gyms by the variant that can draw them (below).
+struct UnionRasterArgs {
+    int32_t n;
+    int32_t first[MAX_UNION + 1];
+    uint32_t *obs[MAX_UNION];
+    FastArgs fa[MAX_UNION];
+};
+
+template <int MAXVIS, bool SHAPES, int WAVES, bool HEXF, int NP>
+__global__ __launch_bounds__(256, WAVES) void raster_fast_union_kernel(UnionRasterArgs ua, int W, int H, int split)
+{
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_UNION; ++i)
+        if (i < ua.n && (int)blockIdx.x >= ua.first[i]) s = i;
+    raster_fast_body<MAXVIS, SHAPES, HEXF, NP>(ua.fa[s], ua.obs[s], W, H, split, (int)blockIdx.x - ua.first[s]);
+}
+
+static FastArgs fast_args_of(const GymView &gv, const PublishTo *publish)
+{
+    const int frames = gv.num_envs * gv.num_agents;
+    FastArgs fa;
+    fa.vis_hdr = gv.vis_hdr; fa.vis_prims = reinterpret_cast<const Prim *>(gv.vis_prims); fa.vis_rects = reinterpret_cast<const short4 *>(gv.vis_rects);
+    fa.hist = gv.lpt_hist + gv.lpt_parity * LPT_BUCKETS; fa.list = gv.lpt_list; fa.num_agents = gv.num_agents; fa.vis_stride = gv.vis_stride; fa.frames = frames;
+    fa.stage_rewards = gv.rewards; fa.stage_true = gv.true_objective; fa.stage_done = gv.done;
+    fa.pub_rewards = publish ? publish->rewards : nullptr; fa.pub_true = publish ? publish->true_objective : nullptr; fa.pub_done = publish ? publish->done : nullptr;
+    fa.pub_n = publish ? frames : 0;
+    return fa;
+}
+
+static int fast_split(int W, int H, int np)
+{
+    static const int envSplit = getenv("MV_RASTER_SPLIT") ? atoi(getenv("MV_RASTER_SPLIT")) : 0;
+    const int ftiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H * np - 1) / (TILE_H * np));
+    int split = envSplit > 0 ? envSplit : 4;
+    while (split > 1 && ftiles < 4 * split * 2) split >>= 1;   // keep at least two tiles per wave
+    return split;
+}
+
+// Fast observation pass of n gyms (already set up by their step kernels) with at most two launches: the gyms whose frames hold up to 256
+// visible primitives (TowerBuilding, the Obstacles family, Empty, Sokoban, Rearrange: the small variant with scaled shapes) and the ones with
+// up to 1024 (Collect, HexMemory, HexExplore: the large variant with the wall-frame box runs; a Collect frame has no wall-frame boxes and
+// takes the same path as in its own variant: its world boxes through the box runs, its cones through the general loop).  Pixels are the ones
+// each gym's own launch produces, byte for byte (same per-pixel arithmetic; tests/test_multitask_gpu.py).
+int launch_raster_union(const GymView *views, uint32_t *const *obs, const PublishTo *publish, int n, int W, int H, hipStream_t stream, hipEvent_t between)
+{
+    if (W > MAX_W || H > MAX_H || n > MAX_UNION) return -1;
+    const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)W * sizeof(float) + (size_t)H * sizeof(float2);
+    const int split = fast_split(W, H, 2);
+    if (between) (void)hipEventRecord(between, stream);
+    for (int large = 1; large >= 0; --large) {   // the expensive frames first
+        UnionRasterArgs ua;
+        ua.n = 0;
+        int wgs = 0;
+        for (int i = 0; i < n; ++i) {
+            const bool isLarge = views[i].vis_stride > VIS_SMALL;
+            if (isLarge != (large != 0)) continue;
+            ua.first[ua.n] = wgs;
+            ua.obs[ua.n] = obs[i];
+            ua.fa[ua.n] = fast_args_of(views[i], publish ? &publish[i] : nullptr);
+            wgs += views[i].num_envs * views[i].num_agents * split;
+            ++ua.n;
+        }
+        if (!ua.n) continue;
+        for (int i = ua.n; i <= MAX_UNION; ++i) ua.first[i] = wgs;
+        if (large) hipLaunchKernelGGL((raster_fast_union_kernel<VIS_LARGE, true, 3, true, 2>), dim3(wgs), dim3(256), dyn, stream, ua, W, H, split);
+        else hipLaunchKernelGGL((raster_fast_union_kernel<VIS_SMALL, true, 6, false, 2>), dim3(wgs), dim3(256), dyn, stream, ua, W, H, split);
+    }
+    return 0;
+}
+
 int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream, hipEvent_t between, int fast, int setup_done, const PublishTo *publish)
 {
     if (W > MAX_W || H > MAX_H) return -1;
@@ -959,26 +1039,19 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
         const char *pplEnv = getenv("MV_FAST_PPL");
         const int pplSel = pplEnv ? atoi(pplEnv) : MV_FAST_PPL_DEFAULT;
         const int np = pplSel >= 2 ? 2 : 1;
-        const int ftiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H * np - 1) / (TILE_H * np));
-        int split = envSplit > 0 ? envSplit : 4;
-        while (split > 1 && ftiles < 4 * split * 2) split >>= 1;   // keep at least two tiles per wave
+        const int split = fast_split(W, H, np);
         // variants: [0] <=256 visible primitives, [1] + scaled shapes (Rearrange), [2] <=1024 (Collect), [3] <=1024 + scaled shapes (Hex*); the
         // small ones are built for 8 and for 6 waves per SIMD (64 / 80 VGPRs), MV_FAST_WAVES picks (two pixels per lane: 7 / 6 waves)
         static const int wavesSel = getenv("MV_FAST_WAVES") ? atoi(getenv("MV_FAST_WAVES")) : 8;
         using KernelFn = void (*)(FastArgs, uint32_t *, int, int, int);
-        FastArgs fa;
-        fa.vis_hdr = gv.vis_hdr; fa.vis_prims = reinterpret_cast<const Prim *>(gv.vis_prims); fa.vis_rects = reinterpret_cast<const short4 *>(gv.vis_rects);
-        fa.hist = gv.lpt_hist + gv.lpt_parity * LPT_BUCKETS; fa.list = gv.lpt_list; fa.num_agents = gv.num_agents; fa.vis_stride = gv.vis_stride; fa.frames = frames;
-        fa.stage_rewards = gv.rewards; fa.stage_true = gv.true_objective; fa.stage_done = gv.done;
-        fa.pub_rewards = publish ? publish->rewards : nullptr; fa.pub_true = publish ? publish->true_objective : nullptr; fa.pub_done = publish ? publish->done : nullptr;
-        fa.pub_n = publish ? frames : 0;
+        const FastArgs fa = fast_args_of(gv, publish);
         // (Collect, measured and rejected: a 1024-entry launch for the frames above 256 visible primitives + a 256-entry launch for the rest,
         // 75 + 69 us against 107 us for the single 1024-entry launch: each launch pays its own tail, and the cones, not occupancy, dominate)
         const bool hexScen = gv.scenario == SCN_HEX_MEMORY || gv.scenario == SCN_HEX_EXPLORE;
         KernelFn fn;
         if (np == 2)   // (the small variants: 72 VGPRs / 7 waves, 80 / 6; at 64 they would spill)
             fn = hexScen ? raster_fast_kernel<VIS_LARGE, true, 3, true, 2> : gv.vis_stride > VIS_SMALL ? raster_fast_kernel<VIS_LARGE, false, 3, false, 2>
-               : gv.scenario == SCN_REARRANGE ? (wavesSel >= 7 ? raster_fast_kernel<VIS_SMALL, true, 7, false, 2> : raster_fast_kernel<VIS_SMALL, true, 6, false, 2>)
+               : gv.scenario == SCN_REARRANGE ? raster_fast_kernel<VIS_SMALL, true, 6, false, 2>   // (with the scaled shapes 72 VGPRs would spill)
                                               : (wavesSel >= 7 ? raster_fast_kernel<VIS_SMALL, false, 7, false, 2> : raster_fast_kernel<VIS_SMALL, false, 6, false, 2>);
         else
             fn = hexScen ? raster_fast_kernel<VIS_LARGE, true, 3, true> : gv.vis_stride > VIS_SMALL ? raster_fast_kernel<VIS_LARGE, false, 3>

@@ -1,4 +1,5 @@
 // megaverse_amd/csrc/mv_step.hip -- one simulation tick for every env: actions -> kinematic
+// The tick itself (physics, scenario logic, episode swap-in) lives in mv_tick_tower.h; this file holds the kernels and their launchers.
 // character physics -> TowerBuilding scenario logic -> timers/done.
 //
 // Replaces, per env (reference paths relative to src/libs):
@@ -24,306 +25,11 @@
 
 #include <algorithm>
 
-#include "mv_actions.h"
-#include "mv_agents.h"
-#include "mv_frame.h"
-#include "mv_math.h"
-#include "mv_physics.h"
-#include "mv_reset_device.h"
-#include "mv_types.h"
+#include "mv_tick_tower.h"
 
 namespace mv {
 
-namespace {
-
-// the wave's view of the movable boxes: lane l owns object l-16 (l>=16) and object 48+l (l<32)
-struct ObjRegs {
-    int x[2], y[2], z[2], state[2];
-    bool valid[2];
-};
-
-__device__ __forceinline__ int object_at(const ObjRegs &o, int x, int y, int z)
-{
-    const int lane = lane_id();
-    const bool h0 = o.valid[0] && o.state[0] == 0 && o.x[0] == x && o.y[0] == y && o.z[0] == z;
-    const bool h1 = o.valid[1] && o.state[1] == 0 && o.x[1] == x && o.y[1] == y && o.z[1] == z;
-    const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
-    (void)lane;
-    if (m0) return (__ffsll((long long)m0) - 1) - 16;
-    if (m1) return 48 + (__ffsll((long long)m1) - 1);
-    return -1;
-}
-
-// placed objects of column (x,z) as a bit set over y: bit (y+32), y in [-32,31]
-__device__ __forceinline__ unsigned long long column_objects(const ObjRegs &o, int x, int z)
-{
-    unsigned long long m = 0ull;
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-        if (o.valid[k] && o.state[k] == 0 && o.x[k] == x && o.z[k] == z && o.y[k] >= -32 && o.y[k] < 32) m |= 1ull << (o.y[k] + 32);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)m, off, 64);
-        const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(m >> 32), off, 64);
-        m |= ((unsigned long long)hi << 32) | lo;
-    }
-    return m;
-}
-
-// The fields of EnvHeader a tick reads or writes, as scalars.  Copying the whole 128-byte record made
-// hipcc keep its array members in an LDS "promoted alloca", which in turn made every wave read the
-// workgroup size from the AQL dispatch packet in host memory: 16-20 us of a 35 us kernel.
-struct Hdr {
-    int num_objects, num_boxes, num_frames, done, highest_tower;
-    int bz0, bz1, bz2, bz3;
-    float episode_sec, episode_len, bz_reward, bar_half_width, p_vertical_look_limit;
-};
-
-__device__ __forceinline__ bool in_zone(const Hdr &h, int x, int z) { return x >= h.bz0 && x < h.bz1 && z >= h.bz2 && z < h.bz3; }
-
-// sum over objects in index order (float addition order is part of the contract)
-__device__ __forceinline__ float tower_reward(const Hdr &h, const ObjRegs &o)
-{
-    float term[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-        term[k] = (o.valid[k] && o.state[k] == 0 && in_zone(h, o.x[k], o.z[k])) ? building_reward_coeff(o.y[k]) : 0.0f;
-    float r = 0.0f;
-    for (int i = 0; i < h.num_objects; ++i) {
-        const float t = (i < 48) ? bcast_f(term[0], 16 + i) : bcast_f(term[1], i - 48);
-        r += t;
-    }
-    return r;
-}
-
-__device__ __forceinline__ void voxel_of(V3 p, int out[3])
-{
-    out[0] = (int)floorf(p.x); out[1] = (int)floorf(p.y); out[2] = (int)floorf(p.z);
-}
-
-__device__ __forceinline__ bool in_chunk(int x, int y, int z) { return x >= 0 && x < CX && y >= 0 && y < CY && z >= 0 && z < CZ; }
-
-}  // namespace
-
-template <int A_MAX>
-__device__ __forceinline__ void tower_tick(const GymView &gv, const int env)
-{
-    const int lane = lane_id();
-    if (env >= gv.num_envs) return;
-    const int A = gv.num_agents;
-
-    const EnvHeader *gh = gv.hdr + env;
-    Hdr h;
-    h.num_objects = gh->num_objects; h.num_boxes = gh->num_boxes; h.num_frames = gh->num_frames; h.done = gh->done;
-    h.highest_tower = gh->highest_tower;
-    h.bz0 = gh->bz[0]; h.bz1 = gh->bz[1]; h.bz2 = gh->bz[2]; h.bz3 = gh->bz[3];
-    h.episode_sec = gh->episode_sec; h.episode_len = gh->episode_len; h.bz_reward = gh->bz_reward;
-    h.bar_half_width = gh->bar_half_width; h.p_vertical_look_limit = gh->p_vertical_look_limit;
-    uint8_t *chunk = gv.chunk + (size_t)env * CHUNK_BYTES;
-    auto vox = [&](int x, int y, int z) -> unsigned { return in_chunk(x, y, z) ? (unsigned)chunk[(y * CZ + z) * CX + x] : 0u; };
-
-    // ---- wave-resident scene: two colliders + two movable boxes per lane
-    Col col[2];
-    ObjRegs ob;
-    col[0].kind = 0; col[1].kind = 0;
-    col[0].lo = col[0].hi = col[1].lo = col[1].hi = v3(0, 0, 0);
-    const MovableObject *gobj = gv.objects + (size_t)env * MAX_OBJECTS;
-    const int oi[2] = {lane - 16, lane < 32 ? 48 + lane : -1};
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        ob.valid[k] = oi[k] >= 0 && oi[k] < h.num_objects;
-        ob.x[k] = ob.y[k] = ob.z[k] = 0; ob.state[k] = 0;
-        if (ob.valid[k]) {
-            const MovableObject o = gobj[oi[k]];
-            ob.x[k] = o.x; ob.y[k] = o.y; ob.z[k] = o.z; ob.state[k] = o.state;
-        }
-    }
-    auto object_collider = [&](int k) {
-        if (ob.valid[k] && ob.state[k] == 0) {
-            const float cx = float(ob.x[k]) + 0.5f, cy = float(ob.y[k]) + 0.5f + OBJ_COLL_YOFF, cz = float(ob.z[k]) + 0.5f;
-            col[k].kind = 1;
-            col[k].lo = v3(cx - OBJ_COLL_HALF, (cy - OBJ_COLL_HALF) - CAP_HH, cz - OBJ_COLL_HALF);
-            col[k].hi = v3(cx + OBJ_COLL_HALF, (cy + OBJ_COLL_HALF) + CAP_HH, cz + OBJ_COLL_HALF);
-        } else col[k].kind = 0;
-    };
-    if (lane < TOWER_BOXES) {
-        if (lane < h.num_boxes) {
-            const LayoutBox b = gv.boxes[(size_t)env * MAX_BOXES + lane];
-            if (b.type & VX_SOLID) {
-                col[0].kind = 1;
-                col[0].lo = v3(float(b.min[0]), float(b.min[1]) - CAP_HH, float(b.min[2]));
-                col[0].hi = v3(float(b.max[0]), float(b.max[1]) + CAP_HH, float(b.max[2]));
-            }
-        }
-    } else object_collider(0);
-    if (lane < 32) object_collider(1);
-
-    // ---- agents: records in LDS (mv_agents.h), one agent's physics fields in registers at a time
-    __shared__ AgentState s_ag[A_MAX];
-    __shared__ int s_act[A_MAX];
-    agents_load(gv, env, A, s_ag, s_act);
-    const float dt = DT;
-
-    // ---- actions -> intents (env.cpp:89-122): agents are independent here, one lane each
-    if (lane < A) {
-        AgentState a;
-        phys_load(a, s_ag[lane]);
-        apply_actions(a, s_act[lane], dt, h.p_vertical_look_limit);
-        phys_store(s_ag[lane], a);
-    }
-    wave_sync();
-
-    // ---- physics, agent by agent (controllers run in addAction order, env.cpp:126)
-#pragma unroll 1
-    for (int i = 0; i < A; ++i) {
-        if (A_MAX > 1 && lane >= 32 && lane < 32 + MAX_AGENTS) {   // capsule colliders of the other agents
-            const int j = lane - 32;
-            col[1].kind = 0;
-            if (j < A && j != i) {
-                col[1].kind = 2;
-                col[1].lo = v3(s_ag[j].pos[0], s_ag[j].pos[1], s_ag[j].pos[2]);
-                col[1].hi = v3(2 * CAP_HH, 0.0f, 0.0f);
-            }
-        }
-        AgentState a;
-        phys_load(a, s_ag[i]);
-        player_step(a, col, dt);
-        if (lane == 0) phys_store(s_ag[i], a);
-        wave_sync();
-    }
-
-    // ---- scenario step: interact (component_object_stacking.hpp:45-168)
-#pragma unroll 1
-    for (int i = 0; i < A; ++i) {
-        if (!(s_act[i] & ACT_INTERACT)) continue;
-        AgentState a;
-        phys_load(a, s_ag[i]);
-        const int carrying = s_ag[i].carrying;
-        const Cam cam = camera_of(a);
-        if (carrying >= 0) {
-            const V3 t = cam_to_world(cam, v3(0.0f, -0.44f + -0.3f, -1.0f));
-            int vx[3];
-            voxel_of(t, vx);
-            bool collidesWithAgent = false;
-            for (int j = 0; j < A; ++j)
-                if (j != i) {
-                    int c[3];
-                    voxel_of(v3(s_ag[j].pos[0], s_ag[j].pos[1] + 0.05f, s_ag[j].pos[2]), c);
-                    if (c[0] == vx[0] && c[1] == vx[1] && c[2] == vx[2]) collidesWithAgent = true;
-                }
-            const bool placeable = vx[0] >= 0 && vx[0] < CX && vx[2] >= 0 && vx[2] < CZ && vx[1] < CY;
-            const unsigned long long colObj = column_objects(ob, vx[0], vx[2]);   // wave op, outside the loop
-            auto has_obj = [&](int y) { return in_chunk(vx[0], y, vx[2]) && ((colObj >> (y + 32)) & 1ull); };
-            const bool empty = !(vox(vx[0], vx[1], vx[2]) & VX_SOLID) && !has_obj(vx[1]);
-            // the reference's grid is unbounded; a placement this build's 32 x 16 x 32 chunk cannot hold is refused AND reported
-            if (!placeable && !collidesWithAgent && in_zone(h, vx[0], vx[2]) && lane == 0) atomicOr(&gv.episode_status[gv.num_envs + 1], (int)ST_CHUNK);
-            if (placeable && empty && !collidesWithAgent && in_zone(h, vx[0], vx[2])) {
-                for (;;) {
-                    const int by = vx[1] - 1;
-                    if (by < -30) break;
-                    if ((vox(vx[0], by, vx[2]) & VX_SOLID) || has_obj(by)) break;
-                    vx[1] = by;
-                }
-                const int oidx = carrying;
-#pragma unroll
-                for (int k = 0; k < 2; ++k)
-                    if (oi[k] == oidx) { ob.x[k] = vx[0]; ob.y[k] = vx[1]; ob.z[k] = vx[2]; ob.state[k] = 0; }
-                if (lane == 0 && in_chunk(vx[0], vx[1], vx[2])) chunk[(vx[1] * CZ + vx[2]) * CX + vx[0]] |= VX_OBJECT;
-                if (lane == 0) s_ag[i].carrying = -1;
-                const float newReward = tower_reward(h, ob);
-                const float delta = newReward - h.bz_reward;
-                h.bz_reward = newReward;
-                wave_sync();
-                reward_team_lds(s_ag, A, 3, i, delta);
-                h.highest_tower = max(h.highest_tower, vx[1] - 1 + 1);
-            }
-        } else {
-            const V3 pickup = cam_to_world(cam, v3(0.0f, -0.44f, -1.0f));
-            int vx[3];
-            voxel_of(pickup, vx);
-            // maxPickupHeight == 1: try the voxel, then the one above; an object with another one
-            // on top of it cannot be taken (component_object_stacking.hpp:131-167)
-            const int o0 = object_at(ob, vx[0], vx[1], vx[2]);
-            const int o1 = object_at(ob, vx[0], vx[1] + 1, vx[2]);
-            const int o2 = object_at(ob, vx[0], vx[1] + 2, vx[2]);
-            int oidx = -1, py = vx[1];
-            if (o0 >= 0 && o1 < 0) { oidx = o0; py = vx[1]; }
-            else if (o1 >= 0 && o2 < 0) { oidx = o1; py = vx[1] + 1; }
-            if (oidx >= 0) {
-#pragma unroll
-                for (int k = 0; k < 2; ++k)
-                    if (oi[k] == oidx) ob.state[k] = 1 + i;
-                if (lane == 0 && in_chunk(vx[0], py, vx[2])) chunk[(py * CZ + vx[2]) * CX + vx[0]] &= (uint8_t)~VX_OBJECT;
-                const int pickedBefore = s_ag[i].picked_up;
-                wave_sync();
-                if (lane == 0) { s_ag[i].carrying = oidx; s_ag[i].picked_up = 1; }
-                wave_sync();
-                if (!pickedBefore) reward_agent_lds(s_ag, 1, i, 1);
-            }
-        }
-    }
-    wave_sync();
-
-    // ---- fall detection (component_fall_detection.hpp:33-55): one lane per agent
-    if (lane < A) {
-        AgentState &a = s_ag[lane];
-        if (a.pos[1] + 0.05f < -20.0f) {
-            int p[3] = {a.spawn[0], a.spawn[1], a.spawn[2]};
-            while ((vox(p[0], p[1], p[2]) & VX_SOLID) && p[1] < 1000) ++p[1];
-            a.pos[0] = float(p[0]) + 0.5f; a.pos[1] = float(p[1]) + 0.5f; a.pos[2] = float(p[2]) + 0.5f;
-            a.m00 = 1.0f; a.m02 = 0.0f; a.m20 = 0.0f; a.m22 = 1.0f;
-            a.hvx = 0.0f; a.hvz = 0.0f; a.vvel = 0.0f;
-        }
-    }
-    wave_sync();
-
-    // ---- building-zone visit shaping (scenario_tower_building.cpp:184-198), in agent order
-#pragma unroll 1
-    for (int i = 0; i < A; ++i) {
-        if (s_ag[i].carrying < 0) continue;
-        int vx[3];
-        voxel_of(v3(s_ag[i].pos[0], s_ag[i].pos[1] + 0.05f, s_ag[i].pos[2]), vx);
-        if (in_zone(h, vx[0], vx[2]) && !s_ag[i].visited_zone) {
-            wave_sync();
-            if (lane == 0) s_ag[i].visited_zone = 1;
-            reward_team_lds(s_ag, A, 2, i, 1);
-        }
-    }
-
-    // ---- timers / done (env.cpp:133-151)
-    h.episode_sec += dt;
-    h.bar_half_width = fmax_sel(0.0f, (h.episode_len - h.episode_sec) / h.episode_len) * 0.24f;
-    if (h.episode_sec >= h.episode_len) h.done = 1;
-    ++h.num_frames;
-
-    // ---- write back
-    MovableObject *gobjw = gv.objects + (size_t)env * MAX_OBJECTS;
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-        if (ob.valid[k]) {
-            MovableObject o;
-            o.x = (int8_t)ob.x[k]; o.y = (int8_t)ob.y[k]; o.z = (int8_t)ob.z[k]; o.state = (int8_t)ob.state[k];
-            gobjw[oi[k]] = o;
-        }
-    if (lane == 0) {
-        EnvHeader *wh = gv.hdr + env;
-        wh->num_frames = h.num_frames; wh->done = h.done; wh->highest_tower = h.highest_tower;
-        wh->episode_sec = h.episode_sec; wh->bz_reward = h.bz_reward; wh->bar_half_width = h.bar_half_width;
-        gv.done[env] = (uint8_t)h.done;
-    }
-    agents_store(gv, env, A, s_ag);
-    if (h.done && lane < A) gv.true_objective[(size_t)env * A + lane] = float(h.highest_tower);   // vector_env.cpp:97-98
-
-    // ---- VectorEnv::step's auto-reset (vector_env.cpp:93-105): the wave of a finished env regenerates it right here.  About one
-    // env in two thousand finishes per tick and its wave is not the slowest of the launch even with the generator on top, so
-    // this costs nothing, where a separate "reset whoever is done" launch cost 4-7 us per step.
-#ifndef MV_EXP_NO_AUTO_RESET   // (timing experiments only: what the generator's 20 KB of LDS cost the kernels that run beside this one)
-    if (h.done) {
-        wave_sync();   // one wave per env: orders the stores above before the generator's
-        reset_env(gv, env, 0);
-    }
-#endif
-}
+using namespace tick_tower;
 
 // One workgroup per env: wave 0 runs the tick (one wave per env: physics, scenario logic, auto-reset), the others wait at the barrier;
 // then the workgroup builds the lists of the env's frames (mv_frame.h).  `render` = 0: mv_step_no_render.

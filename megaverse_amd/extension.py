@@ -37,6 +37,7 @@ SYMBOLS = [
     ("mv_set_actions_batched", C.c_int, [_P, _P]), ("mv_set_actions_device", C.c_int, [_P, _P]),
     ("mv_sample_random_actions", C.c_int, [_P, _U, _U]),
     ("mv_step_many", C.c_int, [_P, _I, _I, _I, _U, _U]),
+    ("mv_group_create", C.c_int, [_P, _I, C.POINTER(_P)]), ("mv_group_step", C.c_int, [_P, _I, _I, _I, _U, _U]), ("mv_group_destroy", C.c_int, [_P]),
     ("mv_step", C.c_int, [_P]), ("mv_step_no_render", C.c_int, [_P]), ("mv_render", C.c_int, [_P]),
     ("mv_step_n", C.c_int, [_P, _I, _I, _U, _U]), ("mv_set_sample_policy", C.c_int, [_P, _I]),
     ("mv_set_output_ring", C.c_int, [_P, _I, _P, _P, _P]),
@@ -94,6 +95,39 @@ def load_library():
             fn.restype, fn.argtypes = res, args
         _LIB = lib
     return _LIB
+
+
+class GymGroup:
+    """mv_group: up to eight gyms of one job stepped with union launches (one step launch, at most two observation launches per tick).
+    The gyms must share device, observation size, agents per env and stream (set_stream first)."""
+
+    def __init__(self, gyms):
+        self._lib = load_library()
+        self.gyms = list(gyms)
+        handles = (_P * len(self.gyms))(*[g._g for g in self.gyms])
+        h = _P()
+        if self._lib.mv_group_create(handles, len(self.gyms), C.byref(h)) != 0:
+            raise RuntimeError("mv_group_create: " + self._lib.mv_last_error().decode())
+        self._h = h
+
+    def step(self, k=1, render=True, policy="none", seed=0, first_step_index=0):
+        rc = self._lib.mv_group_step(self._h, int(k), 1 if render else 0, int(MegaverseGym.POLICIES.get(policy, policy)), int(seed) & 0xFFFFFFFF,
+                                     int(first_step_index) & 0xFFFFFFFF)
+        if rc < 0:
+            raise RuntimeError(self._lib.mv_last_error().decode())
+        if rc > 0:
+            warnings.warn(self._lib.mv_last_error().decode(), RuntimeWarning, stacklevel=2)
+
+    def close(self):
+        if self._h is not None:
+            self._lib.mv_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 _log_level = 2

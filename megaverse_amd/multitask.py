@@ -2,17 +2,22 @@
 
 Reference: megaverse/megaverse_env.py:11-39.  The reference runs a multi-task job as one MegaverseGym per scenario
 (``make_env_multitask`` picks ``tasks[task_idx % len(tasks)]`` per worker); BASELINE.json configs[4] deals the scenarios
-round-robin by env index.  ``MultiTaskGym`` owns one HIP gym per scenario, each on its own stream so that the GPU
-overlaps their kernels (a latency-bound physics launch of one scenario runs under the raster of another), and all of
-them write into ONE observation slab, scenario-major: frames of scenario k are rows [k * n_k * A, (k + 1) * n_k * A).
+round-robin by env index.  ``MultiTaskGym`` owns one HIP gym per scenario -- own state, own episode feeder -- and steps them
+as ONE group (``mv_group``): one step launch whose workgroups run their own scenario's tick, at most two observation launches
+(the short-list and the long-list raster variant), one pair of streams, pipelined like a single gym; three launches per tick
+instead of sixteen.  All of them write into ONE observation slab, scenario-major: frames of scenario k are rows
+[k * n_k * A, (k + 1) * n_k * A).  (``MV_MULTITASK_UNION=0``: the round-2 scheme, one stream per scenario and one launch pair
+per gym, kept for comparison.)
 
 Global env index i  <->  (scenario i % S, local env i // S).  Seeds and the benchmark's random actions are drawn per
 GLOBAL env index (mv_config.env_stride), so the job is bit-identical to S separately seeded single-scenario jobs that
 share one master stream -- and every sub-gym is bit-exact against the oracle by the single-scenario parity tests.
 """
+import os
+
 import numpy as np
 
-from .extension import MegaverseGym
+from .extension import GymGroup, MegaverseGym
 
 # megaverse_env.py:18-21 of the reference: the eight scenarios of its multi-task benchmark, all available on the HIP path
 # (Sokoban reads Boxoban level files: $BOXOBAN_LEVELS, as in the reference)
@@ -33,8 +38,11 @@ class MultiTaskGym:
         self.gyms = [MegaverseGym(name, w, h, self.per_task, num_agents_per_env, num_simulation_threads, False, float_params or {},
                                   device=device, env_offset=env_offset + k, total_envs=total, env_stride=S)
                      for k, name in enumerate(self.scenarios)]
-        for g in self.gyms:   # the sub-gyms already overlap each other, one stream each: a second (simulation) stream per gym only
-            g.set_pipelining(False)   # oversubscribes the hardware queues (measured: 8 gyms, 64 x 64: 3.5 M vs 6.0 M obs/s)
+        self.union = os.environ.get("MV_MULTITASK_UNION", "1") != "0" and len(self.gyms) <= 8
+        if not self.union:
+            for g in self.gyms:   # the sub-gyms overlap each other, one stream each: a second (simulation) stream per gym only
+                g.set_pipelining(False)   # oversubscribes the hardware queues (measured: 8 gyms, 64 x 64: 3.5 M vs 6.0 M obs/s)
+        self._group = None
         self._streams = None
         self._obs = None
         self._handles = None
@@ -51,7 +59,13 @@ class MultiTaskGym:
         import torch
         A, n = self.num_agents_per_env, self.per_task
         assert tuple(obs.shape) == (self.num_envs * A, self.h, self.w, 4) and obs.dtype == torch.uint8 and obs.is_contiguous()
-        if self._streams is None:
+        if self.union:
+            if self._group is None:   # one stream for all of them: torch's current one
+                cur = torch.cuda.current_stream(obs.device).cuda_stream
+                for g in self.gyms:
+                    g.set_stream(cur)
+                self._group = GymGroup(self.gyms)
+        elif self._streams is None:
             self._streams = [torch.cuda.Stream(device=obs.device) for _ in self.gyms]
             for k, g in enumerate(self.gyms):
                 g.set_stream(self._streams[k].cuda_stream)
@@ -94,8 +108,22 @@ class MultiTaskGym:
     def sample_random_actions(self, seed, step_index):
         self._sample = (int(seed) & 0xFFFFFFFF, int(step_index) & 0xFFFFFFFF)   # drawn inside the next step (one C call for all sub-gyms)
 
+    def _ensure_group(self):
+        if self.union and self._group is None:
+            self._group = GymGroup(self.gyms)
+        return self._group
+
+    def step_n(self, k, policy="multidiscrete", seed=0, first_step_index=0):
+        """k open-loop ticks of every scenario with one call (union launches; mv_group_step)"""
+        self._ensure_group().step(k, True, policy, seed, first_step_index)
+
     def step(self):
         import ctypes as C
+        if self.union:
+            seed, idx = self._sample if self._sample else (0, 0)
+            self._ensure_group().step(1, True, "multidiscrete" if self._sample else "none", seed, idx)
+            self._sample = None
+            return
         if self._handles is None:
             self._handles = (C.c_void_p * len(self.gyms))(*[g._g for g in self.gyms])
         lib = self.gyms[0]._lib
@@ -140,5 +168,8 @@ class MultiTaskGym:
         return [g.profile_end() for g in self.gyms]
 
     def close(self):
+        if self._group is not None:
+            self._group.close()
+            self._group = None
         for g in self.gyms:
             g.close()

@@ -54,3 +54,75 @@ def test_multitask_equals_per_scenario_oracles(hip, monkeypatch):
     for og in ogs:
         og.close()
     mt.close()
+
+
+@pytest.mark.parametrize("A,W,H", [(1, 64, 64), (2, 48, 32)])
+def test_union_launches_equal_one_launch_per_gym(hip, monkeypatch, A, W, H):
+    """mv_group (one step launch for all eight scenarios, two observation launches: the short-list and the long-list raster variant) against
+    the same eight gyms stepped one by one on their own streams (MV_MULTITASK_UNION=0): state of every env, rewards, dones and every byte of
+    the shared observation slab must be equal -- in the product's default mode (fast pixels, pipelined), single ticks and batched ones."""
+    import os
+    import torch
+    monkeypatch.setenv("BOXOBAN_LEVELS", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "boxoban"))
+    N, S = 32, len(MEGAVERSE_IN_SCOPE)
+
+    def make(union):
+        monkeypatch.setenv("MV_MULTITASK_UNION", "1" if union else "0")
+        mt = MultiTaskGym(MEGAVERSE_IN_SCOPE, W, H, N, A, 2)
+        mt.set_pixel_mode("fast")
+        obs = mt.attach("cuda:0")
+        mt.seed(5); mt.reset()
+        return mt, obs
+
+    a, oa = make(True)
+    b, ob = make(False)
+    assert a.union and not b.union
+
+    def same(tag):
+        a.synchronize(); b.synchronize(); torch.cuda.synchronize()
+        for k in range(S):
+            for j in range(N // S):
+                assert a.gyms[k].debug_snapshot_bytes(j).tobytes() == b.gyms[k].debug_snapshot_bytes(j).tobytes(), (tag, MEGAVERSE_IN_SCOPE[k], j)
+            assert a.gyms[k].get_rewards_array().tobytes() == b.gyms[k].get_rewards_array().tobytes(), (tag, k)
+            assert np.array_equal(a.gyms[k].get_dones(), b.gyms[k].get_dones()), (tag, k)
+        sa, sb = oa.cpu().numpy(), ob.cpu().numpy()
+        assert sa[..., :3].max() > 0
+        assert np.array_equal(sa, sb), (tag, int((sa != sb).any(axis=-1).sum()), "pixels differ")
+
+    same("reset")
+    st = 0
+    for _ in range(30):
+        a.sample_random_actions(9, st); a.step()
+        b.sample_random_actions(9, st); b.step()
+        st += 1
+    same("30 single ticks")
+    for k in (8, 3, 8, 5):
+        a.step_n(k, "multidiscrete", 9, st)
+        for j in range(k):
+            b.sample_random_actions(9, st + j); b.step()
+        st += k
+    same("batched ticks")
+    a.close(); b.close()
+
+
+def test_a_grouped_gym_is_stepped_through_its_group_only(hip, monkeypatch):
+    import os
+    monkeypatch.setenv("BOXOBAN_LEVELS", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "boxoban"))
+    from megaverse_amd.extension import GymGroup, MegaverseGym
+    g1 = MegaverseGym("TowerBuilding", 32, 32, 4, 1, 1, False, {})
+    g2 = MegaverseGym("Collect", 32, 32, 4, 1, 1, False, {})
+    g3 = MegaverseGym("Collect", 48, 32, 4, 1, 1, False, {})
+    for g in (g1, g2, g3):
+        g.seed(1); g.reset()
+    with pytest.raises(RuntimeError, match="share device, observation size"):
+        GymGroup([g1, g3])
+    grp = GymGroup([g1, g2])
+    with pytest.raises(RuntimeError, match="belongs to an mv_group"):
+        g1.step()
+    grp.step(4, True, "multidiscrete", 3, 0)
+    g2.close()                      # a member leaves: the group is dissolved, the other gym works on its own again
+    with pytest.raises(RuntimeError, match="group is gone"):
+        grp.step()
+    g1.sample_random_actions(3, 4); g1.step()
+    assert g1.get_dones().shape == (4,)
+    grp.close(); g1.close(); g3.close()
