@@ -245,6 +245,11 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the single-step / unpipelined / closed-loop transparency legs")
     ap.add_argument("--profile-steps", type=int, default=256, help="steps of the untimed per-kernel profile loop (HIP events on the gym's stream)")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo run of the launcher + gather pipeline with a stand-in gym")
+    ap.add_argument("--single-device", action="store_true",
+                    help="N>1 on a box with ONE GPU (tests): every rank runs its real env shard on device 0, the observation slabs are gathered over gloo from "
+                         "host copies -- the launcher, the sharding (env_offset / total_envs) and ObsGather as in a real run, no xGMI")
+    ap.add_argument("--check-gather", action="store_true",
+                    help="after the timed loop rank 0 replays the whole job in ONE gym of N x envs-per-gpu envs and compares its slab with the gathered one")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -259,14 +264,17 @@ def main():
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dry = args.dry_run
+    single = args.single_device and not dry
     if not dry and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    if single:
+        local_rank = 0
     device = "cpu" if dry else f"cuda:{local_rank}"
     if not dry:
         torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if dry:
+        if dry or single:
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device(device))
@@ -295,8 +303,11 @@ def main():
         gym.set_sample_policy(args.policy)
 
     do_gather = world > 1 and not args.no_gather_obs
-    gather = ObsGather(dist, torch, (frames, H, W, 4), world, device, cuda=not dry) if world > 1 else None
-    slabs = gather.local if gather else [torch.zeros((frames, H, W, 4), dtype=torch.uint8, device=device)]
+    gather = ObsGather(dist, torch, (frames, H, W, 4), world, "cpu" if single else device, cuda=not dry and not single) if world > 1 else None
+    if gather and single:   # the gym renders into device slabs; their host copies are what gloo gathers
+        slabs = [torch.zeros((frames, H, W, 4), dtype=torch.uint8, device=device) for _ in range(2)]
+    else:
+        slabs = gather.local if gather else [torch.zeros((frames, H, W, 4), dtype=torch.uint8, device=device)]
     # batched stepping: tick j of a call renders into slab j of a ring, so that all `batch` observations of a call exist side by side when it
     # is done (a k-step rollout buffer) -- the working set of the observation writes is batch x one slab, not one slab written over and over
     batched = batch > 1 and not dry
@@ -325,6 +336,8 @@ def main():
         if with_gather:
             if mixed and not gym.union:
                 gym.synchronize()   # (round-2 scheme, one stream per scenario: join them before the collective reads the slab)
+            if single:
+                gather.local[b].copy_(slabs[b])   # (device -> host on the gym's stream, synchronous)
             gather.after_render(b)
 
     def fence():
@@ -354,7 +367,7 @@ def main():
         run_steps(first, args.steps, with_gather, use_batch)
         fence()
         el = time.perf_counter() - t0
-        t = torch.tensor([el], dtype=torch.float64, device=device)
+        t = torch.tensor([el], dtype=torch.float64, device="cpu" if (dry or single) else device)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
@@ -439,6 +452,23 @@ def main():
         for r in range(world):
             assert int(g0[r * frames, 0, 0, 0]) == (r * 31 + last_gathered) % 251, "gathered slab does not hold rank %d's shard" % r
 
+    gather_check = None
+    if args.check_gather and do_gather and not dry and not mixed and rank == 0:
+        # the whole job in one gym: world x envs_per_gpu envs, the same master seed, the same (seed, step) action stream
+        from megaverse_amd.extension import MegaverseGym as _G
+        big = _G(args.scenario, W, H, world * n_env, A, 8, False, {}, device=local_rank)
+        big.set_pixel_mode(args.pixels)
+        big.set_sample_policy(args.policy)
+        whole = torch.zeros((world * frames, H, W, 4), dtype=torch.uint8, device=device)
+        big.set_obs_buffer(whole.data_ptr())
+        big.seed(42); big.reset()
+        for i in range(last_gathered + 1):
+            big.sample_random_actions(1234, i); big.step()
+        big.synchronize(); torch.cuda.synchronize()
+        got = gather.out[last_gathered & 1].cpu()
+        gather_check = bool(torch.equal(got, whole.cpu())) and int(got[..., :3].max()) > 0
+        big.close()
+
     if rank == 0:
         total_obs = world * frames * args.steps
         obst = args.scenario.lower().startswith("obstacles")
@@ -475,6 +505,10 @@ def main():
             line["ms_per_step_" + key] = el / args.steps * 1e3
         if dry:
             line["dry_run"] = True
+        if single:
+            line["single_device"] = True
+        if gather_check is not None:
+            line["gather_check"] = gather_check
         if do_gather:
             slab_bytes = frames * H * W * 4
             line["value_no_gather"] = total_obs / elapsed_no_gather

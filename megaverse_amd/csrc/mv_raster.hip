@@ -982,11 +982,15 @@ static FastArgs fast_args_of(const GymView &gv, const PublishTo *publish)
     return fa;
 }
 
-static int fast_split(int W, int H, int np)
+// Workgroups per frame of the fast kernels.  One pixel per lane: 4 (r02 sweeps: 4 and 8 best).  Two pixels per lane (half as many tiles, a
+// prologue per workgroup): measured on 1024 frames of 128 x 128, 2: 58.0 us, 4: 61.3, 8: 69.7 -- and on the 384 / 640 frames of a Mixed group's
+// two launches 4 beats 2 (6.4 M against 4.4 M obs/s at 128 x 128; 8.7 M against 8.0 M at 64 x 64): enough workgroups to fill the chip once
+// (~2048), at most 4, at least 2 tiles per wave.  MV_RASTER_SPLIT overrides.
+static int fast_split(int W, int H, int np, int frames)
 {
     static const int envSplit = getenv("MV_RASTER_SPLIT") ? atoi(getenv("MV_RASTER_SPLIT")) : 0;
     const int ftiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H * np - 1) / (TILE_H * np));
-    int split = envSplit > 0 ? envSplit : 4;
+    int split = envSplit > 0 ? envSplit : np >= 2 ? std::min(4, std::max(2, (2048 + frames - 1) / std::max(frames, 1))) : 4;
     while (split > 1 && ftiles < 4 * split * 2) split >>= 1;   // keep at least two tiles per wave
     return split;
 }
@@ -1000,12 +1004,16 @@ int launch_raster_union(const GymView *views, uint32_t *const *obs, const Publis
 {
     if (W > MAX_W || H > MAX_H || n > MAX_UNION) return -1;
     const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)W * sizeof(float) + (size_t)H * sizeof(float2);
-    const int split = fast_split(W, H, 2);
+    const char *pplEnv = getenv("MV_FAST_PPL");
+    const int np = (pplEnv ? atoi(pplEnv) : MV_FAST_PPL_DEFAULT) >= 2 ? 2 : 1;
+    int unionFrames[2] = {0, 0};
+    for (int i = 0; i < n; ++i) unionFrames[views[i].vis_stride > VIS_SMALL ? 1 : 0] += views[i].num_envs * views[i].num_agents;
     if (between) (void)hipEventRecord(between, stream);
     for (int large = 1; large >= 0; --large) {   // the expensive frames first
         UnionRasterArgs ua;
         ua.n = 0;
         int wgs = 0;
+        const int split = fast_split(W, H, np, unionFrames[large]);
         for (int i = 0; i < n; ++i) {
             const bool isLarge = views[i].vis_stride > VIS_SMALL;
             if (isLarge != (large != 0)) continue;
@@ -1017,8 +1025,13 @@ int launch_raster_union(const GymView *views, uint32_t *const *obs, const Publis
         }
         if (!ua.n) continue;
         for (int i = ua.n; i <= MAX_UNION; ++i) ua.first[i] = wgs;
-        if (large) hipLaunchKernelGGL((raster_fast_union_kernel<VIS_LARGE, true, 3, true, 2>), dim3(wgs), dim3(256), dyn, stream, ua, W, H, split);
-        else hipLaunchKernelGGL((raster_fast_union_kernel<VIS_SMALL, true, 6, false, 2>), dim3(wgs), dim3(256), dyn, stream, ua, W, H, split);
+        if (np == 2) {
+            if (large) hipLaunchKernelGGL((raster_fast_union_kernel<VIS_LARGE, true, 3, true, 2>), dim3(wgs), dim3(256), dyn, stream, ua, W, H, split);
+            else hipLaunchKernelGGL((raster_fast_union_kernel<VIS_SMALL, true, 6, false, 2>), dim3(wgs), dim3(256), dyn, stream, ua, W, H, split);
+        } else {
+            if (large) hipLaunchKernelGGL((raster_fast_union_kernel<VIS_LARGE, true, 3, true, 1>), dim3(wgs), dim3(256), dyn, stream, ua, W, H, split);
+            else hipLaunchKernelGGL((raster_fast_union_kernel<VIS_SMALL, true, 8, false, 1>), dim3(wgs), dim3(256), dyn, stream, ua, W, H, split);
+        }
     }
     return 0;
 }
@@ -1039,7 +1052,7 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
         const char *pplEnv = getenv("MV_FAST_PPL");
         const int pplSel = pplEnv ? atoi(pplEnv) : MV_FAST_PPL_DEFAULT;
         const int np = pplSel >= 2 ? 2 : 1;
-        const int split = fast_split(W, H, np);
+        const int split = fast_split(W, H, np, frames);
         // variants: [0] <=256 visible primitives, [1] + scaled shapes (Rearrange), [2] <=1024 (Collect), [3] <=1024 + scaled shapes (Hex*); the
         // small ones are built for 8 and for 6 waves per SIMD (64 / 80 VGPRs), MV_FAST_WAVES picks (two pixels per lane: 7 / 6 waves)
         static const int wavesSel = getenv("MV_FAST_WAVES") ? atoi(getenv("MV_FAST_WAVES")) : 8;

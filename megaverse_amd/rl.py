@@ -63,8 +63,14 @@ class Wrapper:
 
     @property
     def episode_rewards(self):
-        """per-agent return of the running episodes (the reference keeps a Python list; here a float64 vector)"""
-        return self._returns.tolist()
+        """per-agent return of the running episodes: the reference keeps a mutable Python list (megaverse_utils.py:41,58); here THE float64
+        vector itself -- `w.episode_rewards[i] = 0` and `w.episode_rewards[i] += r` write through like they do there"""
+        return self._returns
+
+    @episode_rewards.setter
+    def episode_rewards(self, values):
+        import numpy as np
+        self._returns[:] = np.asarray(values, dtype=np.float64)
 
     def _finish_episodes(self, rewards, dones, infos):
         """Vectorised episode statistics (what megaverse_utils.py:61-86 does agent by agent): add the step's rewards to the running

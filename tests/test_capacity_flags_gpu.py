@@ -1,0 +1,145 @@
+"""Every fixed capacity this build has and the reference has not (its grids and draw lists are unbounded: voxel_grid.hpp:57-165,
+magnum_env_renderer.cpp:256-340) raises a flag; the next mv_step / mv_reset that sees it WARNS once (return code 1 -> RuntimeWarning),
+does its work all the same, and the gym keeps running.  One test per flag (ST_STARVED: tests/test_refill_protocol_gpu.py):
+  ST_CHUNK       an object placed above the 32 x 16 x 32 voxel chunk;
+  ST_CANDIDATES  more than 128 collision candidates around one Collect agent (a path that sweeps the whole landscape);
+  ST_VISIBLE     more than 1024 visible primitives in a Hex frame (the largest maze found, seen from outside) -- and the same mazes from
+                 their rim, looking in, stay below the cap;
+  GEN_*          a generated Obstacles level beyond an episode record's arrays (an absurd platform count)."""
+import ctypes as C
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from canonical import FWD, REST_ON, find_isolated_box, pose, yaw_cs
+from hip_util import hip_snapshot
+from megaverse_amd.extension import MegaverseGym, load_library
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
+INTERACT = [0, 0, 0, 0, 1, 0]
+
+
+def steps_collecting_warnings(g, n, seed=0, first=0, render=False, sample=True):
+    msgs = []
+    for st in range(n):
+        if sample:
+            g.sample_random_actions(seed, first + st)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            g.step() if render else g.step_no_render()
+        msgs += [str(w.message) for w in caught if issubclass(w.category, RuntimeWarning)]
+    return msgs
+
+
+def env_seeds(master, n):
+    """MegaverseGym::seed (megaverse.cpp:60-69): one randRange(0, 1 << 30) per env from mt19937(master)"""
+    lo, hi, out = np.zeros(n, np.int32), np.full(n, 1 << 30, np.int32), np.zeros(n, np.int32)
+    oracle_lib.lib().mvo_rand_range_seq(int(master), lo.ctypes.data, hi.ctypes.data, n, out.ctypes.data)
+    return out
+
+
+def first_episode_counts(scenario, env_seed, A=1):
+    """(num_boxes, ...) of the first episode an env with this seed generates, from the host generator (no device)"""
+    lib = load_library()
+    size = lib.mv_debug_generate_episode(scenario.encode(), A, 0, 1, 60.0, None, 0)
+    buf = np.zeros(size, np.uint8)
+    assert lib.mv_debug_generate_episode(scenario.encode(), A, int(env_seed), 1, 60.0, buf.ctypes.data, size) == size
+    return buf.view(np.int32)[:6]
+
+
+def test_chunk_overflow_is_reported_once(hip):
+    N = 64
+    g = MegaverseGym("TowerBuilding", 32, 32, N, 1, 1, False, {})
+    g.seed(3); g.reset()
+    e, (ox, oz) = next((e, b) for e in range(N) for b in [find_isolated_box(hip_snapshot(g, e))] if b)
+    pose(g, e, 0, ox + 1.5, REST_ON(1.0), oz + 0.5, np.pi / 2)   # one unit from the box's centre, facing it
+    g.set_actions(e, 0, INTERACT); g.step_no_render()
+    assert int(hip_snapshot(g, e)["agents"][0]["carrying"]) >= 0          # picked up (component_object_stacking.hpp:131-167)
+    bz = hip_snapshot(g, e)["bz"]
+    pose(g, e, 0, 0.5 * (bz[0] + bz[1]) + 1.0, 20.0, 0.5 * (bz[2] + bz[3]), np.pi / 2)   # high above the building zone: voxel y >= 16
+    g.set_actions(e, 0, INTERACT)
+    msgs = steps_collecting_warnings(g, 1, sample=False)
+    assert int(hip_snapshot(g, e)["agents"][0]["carrying"]) >= 0          # the placement was refused
+    msgs += steps_collecting_warnings(g, 60, seed=1)
+    assert len(msgs) == 1 and "32 x 16 x 32" in msgs[0] and "reported once" in msgs[0], msgs
+    assert not steps_collecting_warnings(g, 40, seed=1, first=60)          # ... and only once; the gym is alive
+    g.close()
+
+
+def test_candidate_overflow_is_reported_once(hip):
+    # a landscape with many merged slabs, and an agent whose one-tick path crosses all of it
+    seeds = env_seeds(11, 64)
+    counts = [int(first_episode_counts("Collect", s)[1]) for s in seeds]
+    e = int(np.argmax(counts))
+    assert counts[e] > 160, counts[e]
+    g = MegaverseGym("Collect", 32, 32, 64, 1, 2, False, {})
+    g.seed(11); g.reset()
+    assert int(hip_snapshot(g, e)["num_boxes"]) == counts[e]
+    g.debug_set_agent_pos(e, 0, 1.5, 12.0, 1.5)
+    g.debug_set_agent_velocity(e, 0, 600.0, 600.0, 0.0)                    # 40 units per tick along the diagonal
+    msgs = steps_collecting_warnings(g, 60, seed=2)
+    assert len(msgs) == 1 and "candidate list overflow" in msgs[0], msgs
+    assert not steps_collecting_warnings(g, 40, seed=2, first=60)
+    g.close()
+
+
+def test_visible_primitive_cap(hip):
+    # the largest mazes among 4096 generated ones
+    best = []
+    for master in range(1, 65):
+        for e, s in enumerate(env_seeds(master, 64)):
+            best.append((int(first_episode_counts("HexMemory", s)[1]), master, e))
+    best.sort(reverse=True)
+    assert best[0][0] > 800, best[0]
+    natural, forced = [], []
+    for nb, master, e in best[:3]:
+        g = MegaverseGym("HexMemory", 128, 72, e + 1, 1, 2, False, {})
+        g.set_pixel_mode("fast")
+        g.seed(master); g.reset()
+        s = hip_snapshot(g, e)
+        assert int(s["hex_num_boxes"]) == nb
+        floor = s["hex_boxes"][0]
+        R = float(max(abs(floor["a"][0]), abs(floor["b"][0]), abs(floor["a"][2]), abs(floor["b"][2])))
+        y = float(floor["b"][1]) + 0.9
+        # from the rim, looking at the centre (forward = (-sin psi, 0, -cos psi)): what an agent standing in a rim cell can see at most
+        for k in range(12):
+            ang = 2 * np.pi * k / 12
+            x, z = 0.85 * R * np.cos(ang), 0.85 * R * np.sin(ang)
+            c, sn = yaw_cs(np.arctan2(x, z))
+            g.debug_set_agent_pos(e, 0, x, y, z); g.debug_set_agent_yaw(e, 0, c, sn); g.debug_set_agent_velocity(e, 0, 0, 0, 0)
+            g.render()
+        g.debug_set_agent_pos(e, 0, 0.0, y, 0.0)
+        natural += steps_collecting_warnings(g, 60, seed=4)
+        # from far outside, the whole maze inside the field of view: every box and collectable is "visible"
+        c, sn = yaw_cs(np.pi / 2)
+        g.debug_set_agent_pos(e, 0, 3.0 * R, y + 4.0, 0.0); g.debug_set_agent_yaw(e, 0, c, sn)
+        g.render()
+        g.debug_set_agent_pos(e, 0, 0.0, y, 0.0)
+        forced.append((nb + 3 * int(s["hex_num_objs"]), steps_collecting_warnings(g, 60, seed=4, first=60)))
+        assert not steps_collecting_warnings(g, 30, seed=4, first=120)
+        g.close()
+    print("largest mazes (boxes, master seed, env):", best[:3], "slots seen from outside / warnings:", [(n, len(m)) for n, m in forced])
+    assert not natural, natural                                            # the cap holds for every rim view of the largest mazes found
+    for slots, msgs in forced:
+        if slots > 1024 + 8:
+            assert len(msgs) == 1 and "visible primitives" in msgs[0], (slots, msgs)
+    assert any(slots > 1024 + 8 for slots, _ in forced)
+
+
+def test_generator_overflow_is_reported_once(hip):
+    # 40 platforms in a row: more merged slabs / terrain boxes / movable boxes than an episode record holds, coordinates beyond int8
+    params = {"obstaclesMinNumPlatforms": 40.0, "obstaclesMaxNumPlatforms": 40.0}
+    g = MegaverseGym("ObstaclesHard", 32, 32, 8, 1, 2, False, params)
+    g.seed(5)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        g.reset()
+    msgs = [str(w.message) for w in caught if issubclass(w.category, RuntimeWarning)]
+    msgs += steps_collecting_warnings(g, 40, seed=6)
+    assert msgs and all("capacity limit hit" in m for m in msgs), msgs
+    assert any(("generated" in m) or ("terrain boxes" in m) or ("movable boxes" in m) for m in msgs), msgs
+    assert g.get_dones().shape == (8,)
+    g.close()

@@ -178,3 +178,37 @@ def test_pybind_flavour_equals_ctypes_flavour(hip):
     a.draw_hires()
     assert a.get_hires_observation(0, 0).shape == (432, 768, 4)
     a.close(); b.close()
+
+
+def test_pybind_flavour_places_its_envs_from_the_environment(hip, monkeypatch):
+    """The reference's constructor has no shard argument; through the reference-named module the process environment places the gym in the
+    job: MV_ENV_OFFSET / MV_TOTAL_ENVS / MV_ENV_STRIDE (a round-robin multi-task job: every k-th env from an offset) and MV_DEVICE /
+    LOCAL_RANK (the latter modulo the visible device count: LOCAL_RANK=5 on a one-GPU box is device 0).  Same envs, same observations as
+    the ctypes binding with the explicit arguments."""
+    from megaverse_amd import build
+    build.build_pybind()
+    from megaverse_amd.pybind import megaverse as m
+    from megaverse_amd.extension import MegaverseGym
+    from megaverse_amd.rollout import sample_actions
+    N, A, total, stride, offset = 4, 1, 24, 3, 2
+    monkeypatch.setenv("MV_ENV_OFFSET", str(offset)); monkeypatch.setenv("MV_TOTAL_ENVS", str(total)); monkeypatch.setenv("MV_ENV_STRIDE", str(stride))
+    monkeypatch.delenv("MV_DEVICE", raising=False); monkeypatch.setenv("LOCAL_RANK", "5")
+    a = m.MegaverseGym("TowerBuilding", 40, 24, N, A, 1, False, {})
+    for k in ("MV_ENV_OFFSET", "MV_TOTAL_ENVS", "MV_ENV_STRIDE", "LOCAL_RANK"):
+        monkeypatch.delenv(k)
+    b = MegaverseGym("TowerBuilding", 40, 24, N, A, 1, False, {}, env_offset=offset, total_envs=total, env_stride=stride)
+    whole = MegaverseGym("TowerBuilding", 40, 24, total, A, 1, False, {})
+    for g in (a, b, whole):
+        g.seed(9); g.reset()
+    for j in range(N):   # local env j is job-wide env offset + j * stride
+        assert np.array_equal(a.get_observation(j, 0), whole.get_observation(offset + j * stride, 0))
+        assert np.array_equal(a.get_observation(j, 0), b.get_observation(j, 0))
+    for st in range(10):
+        acts = sample_actions(3, st, N * A)
+        for e in range(N):
+            a.set_actions(e, 0, [int(v) for v in acts[e]])
+        b.set_actions_batched(acts)
+        a.step(); b.step()
+    for j in range(N):
+        assert np.array_equal(a.get_observation(j, 0), b.get_observation(j, 0))
+    a.close(); b.close(); whole.close()

@@ -97,5 +97,10 @@ def test_rl_wrapper_bookkeeping_on_a_stub_env():
                 assert env.get_current_reward_shaping(i) == {"teamSpirit": 0.25, "collectAll": 5.0}
         else:
             assert infos == [{}] * 4
-    assert env.episode_rewards == [0, 0, 0, 0]
+    assert list(env.episode_rewards) == [0, 0, 0, 0]
+    env.step(None)
+    env.episode_rewards[1] = 7.0                      # the reference's list is mutable (megaverse_utils.py:41): writes go through
+    assert list(env.episode_rewards) == [0.5, 7.0, 0.0, 2.0]
+    env.episode_rewards = [0, 0, 0, 0]
+    assert list(env.episode_rewards) == [0, 0, 0, 0]
     env.close()
