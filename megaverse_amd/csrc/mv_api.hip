@@ -444,7 +444,8 @@ int mv_create(const mv_config *cfg, mv_gym **out)
                  szRewObj = hostEpisodes ? up(N * (size_t)gv.reward_stride * sizeof(MovableObject)) : 0,
                  szHeight = collect ? up(N * (size_t)HM_BYTES) : 0, szItems = rearrange ? up(N * MAX_ITEMS * sizeof(ArrangementItem)) : 0, szCells = sokoban ? up(N * (size_t)(SOKO_DIM * SOKO_DIM)) : 0,
                  szHexB = hex ? up(N * (size_t)HEX_MAX_BOXES * sizeof(HexRec)) : 0, szHexO = hex ? up(N * (size_t)HEX_MAX_OBJS * sizeof(HexRec)) : 0, szBlobs = up(N * g->blobBytes * (size_t)g->spares), szCnt = up((N + 2) * sizeof(int32_t));
-    gv.vis_stride = collect || hex ? 1024 : 256;
+    gv.vis_stride = hex ? 2048 : collect ? 1024 : 256;
+    if (const char *e = getenv("MV_DEBUG_VIS_STRIDE")) gv.vis_stride = std::min(gv.vis_stride, std::max(8, atoi(e)));   // (tests: provoke ST_VISIBLE)
     gv.spares = g->spares;
     const size_t szVisP = up(NA * (size_t)gv.vis_stride * 32), szVisR = up(NA * (size_t)gv.vis_stride * 8), szVisC = up(NA * sizeof(int32_t)),
                  szLpt = up(NA * sizeof(int32_t)) + up((NA + 1) * sizeof(int32_t)) + up(NA * (size_t)FRAME_HDR_BYTES) + up(256 * NA * sizeof(int32_t));
@@ -763,12 +764,12 @@ int mv_render(mv_gym *g)
 static int check_status_flags(mv_gym *g)
 {
     const int N = g->N;
-    const int flags = g->hStatus[N + 1], gen = g->hostEpisodes() ? generator_overflow_take() : 0;
+    const int flags = g->hStatus[N + 1], gen = g->feeder ? g->feeder->take_overflow() : 0;
     if (!flags && !gen) return 0;
     std::string msg;
     if (flags & ST_STARVED) msg += "an env finished again before its next episode was resident (it repeated its done step; the next episodes are being uploaded now); ";
     if (flags & ST_CANDIDATES) msg += "collision candidate list overflow (more than 128 bodies around one agent); ";
-    if (flags & ST_VISIBLE) msg += "a frame had more visible primitives than the raster keeps (256; Collect, Hex* 1024): the excess was not drawn; ";
+    if (flags & ST_VISIBLE) msg += "a frame had more visible primitives than the raster keeps (256; Collect 1024; Hex* 2048): the excess was not drawn; ";
     if (flags & ST_CHUNK) msg += "an object placement outside the 32 x 16 x 32 voxel chunk was refused (the reference's grid is unbounded); ";
     if (gen & GEN_SLABS) msg += "a generated layout merged into more slabs than an episode record holds (128, Collect 1024): the excess was dropped; ";
     if (gen & GEN_TERRAIN) msg += "more than 16 terrain boxes in a generated episode; ";

@@ -113,6 +113,7 @@ void EpisodeFeeder::generate(int env)
         b.seq = seq;
         used = offsetof(CollectBlob, boxes) + size_t(b.num_boxes) * sizeof(LayoutBox);   // the slab list is last: used prefix only
     }
+    if (const int f = generator_overflow_take()) overflow_.fetch_or(f, std::memory_order_relaxed);   // (raised on this worker thread)
     used_bytes_[env] = used;
     ready_seq_[env].store(seq, std::memory_order_release);
 }

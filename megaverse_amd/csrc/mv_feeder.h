@@ -48,6 +48,7 @@ public:
 
     int num_threads() const { return int(workers_.size()); }
     bool failed() const { return failed_.load(std::memory_order_acquire); }   // a generator gave up (Sokoban: unreadable level file)
+    int take_overflow() { return overflow_.exchange(0, std::memory_order_relaxed); }   // GEN_* flags this feeder's generators raised since the last call
 
 private:
     struct Task { int env; hipEvent_t after; };
@@ -70,6 +71,7 @@ private:
     bool stop_ = false;
     std::vector<std::thread> workers_;
     std::atomic<bool> failed_{false};
+    std::atomic<int> overflow_{0};
     // Sokoban keeps state across episodes and across Env::seed: the shuffled rest of the level file picked last
     // (SokobanScenario::levels).  Episodes generated ahead of a re-seed are dropped, so what they took from that list is put back.
     struct SokoUndo { bool reloaded; std::vector<std::string> level; };

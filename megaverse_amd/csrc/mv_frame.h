@@ -33,7 +33,8 @@ constexpr int PPL = MV_RASTER_PPL;   // pixels per lane in the raster kernel: a 
 #ifndef MV_RASTER_WAVES
 #define MV_RASTER_WAVES 7   // waves per SIMD the small variant is compiled for (register budget 512 / n)
 #endif
-constexpr int VIS_SMALL = 256, VIS_LARGE = 1024;   // visible primitives kept per frame (TowerBuilding <= 121 slots, Obstacles <= 280; Collect up to ~1300)
+constexpr int VIS_SMALL = 256, VIS_LARGE = 1024, VIS_XL = 2048;   // visible primitives kept per frame (TowerBuilding <= 121 slots, Obstacles <= 280;
+                                                                  // Collect up to ~1300; a Hex maze seen from its rim: > 1024 of its <= 2146 slots)
 constexpr int LPT_BUCKETS = 256;
 constexpr float CLIP_W = 0.005f;       // NEAR_Z / 2: boxes are clipped against this depth before projecting
 constexpr int MAX_W = 1024, MAX_H = 1024;
@@ -432,7 +433,7 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
             }
             vis[pos] = p;
             rects[pos] = make_short4((short)rect[0], (short)rect[1], (short)rect[2], (short)rect[3]);
-            if (kind == PRIM_BOX && fr == 0) atomicOr(&s_wbits[pos >> 5], 1u << (pos & 31));
+            if (kind == PRIM_BOX && fr == 0 && pos < 1024) atomicOr(&s_wbits[pos >> 5], 1u << (pos & 31));   // (the header's masks: the short-list raster)
             myCost += ((rect[1] / TILE_W) - (rect[0] / TILE_W) + 1) * ((rect[3] / TILE_H) - (rect[2] / TILE_H) + 1);
         }
     }

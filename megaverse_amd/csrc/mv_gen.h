@@ -21,7 +21,7 @@ struct ObstacleConfig {
 // a flag here; mv_step / mv_reset report it (mv_api.hip: check_status_flags).  Process-wide, cleared when reported.
 enum : int { GEN_SLABS = 1, GEN_TERRAIN = 2, GEN_OBJECTS = 4, GEN_REWARDS = 8, GEN_COORDS = 16 };
 void generator_overflow_raise(int flags);
-int generator_overflow_take();   // returns the flags raised since the last call and clears them
+int generator_overflow_take();   // returns the flags raised ON THIS THREAD since the last call and clears them
 
 // Advances `rng` exactly like Env::reset + ObstaclesScenario::reset + spawnAgents and fills `out`.
 void generate_obstacles_episode(std::mt19937 &rng, const ObstacleConfig &cfg, int num_agents, float base_episode_len, EpisodeBlob &out);

@@ -30,9 +30,11 @@
 
 namespace mv {
 
-static std::atomic<int> g_generator_overflow{0};
-void generator_overflow_raise(int flags) { g_generator_overflow.fetch_or(flags, std::memory_order_relaxed); }
-int generator_overflow_take() { return g_generator_overflow.exchange(0, std::memory_order_relaxed); }
+// per THREAD: a generator runs on a feeder worker (EpisodeFeeder::generate collects the flags into its own gym's feeder afterwards) or on
+// the caller's thread (mv_debug_generate_episode) -- one gym's oversized level is never reported by another gym
+static thread_local int t_generator_overflow = 0;
+void generator_overflow_raise(int flags) { t_generator_overflow |= flags; }
+int generator_overflow_take() { const int f = t_generator_overflow; t_generator_overflow = 0; return f; }
 static inline bool fits_i8(int v) { return v >= -128 && v <= 127; }
 
 

@@ -281,7 +281,7 @@ __global__ __launch_bounds__(1024) void frame_order_kernel(GymView gv, int frame
 }
 
 template <int MAXVIS, bool SHAPES>   // SHAPES: the frame may hold scaled spheres / capsules / cylinders (Rearrange)
-__global__ __launch_bounds__(256, MAXVIS <= 256 && !SHAPES ? MV_RASTER_WAVES : MAXVIS <= 256 ? 5 : 2) void raster_kernel(GymView gv, uint32_t *obs, int W, int H, int split, const int *order)
+__global__ __launch_bounds__(256, MAXVIS <= 256 && !SHAPES ? MV_RASTER_WAVES : MAXVIS <= 256 ? 5 : MAXVIS <= 1024 ? 2 : 1) void raster_kernel(GymView gv, uint32_t *obs, int W, int H, int split, const int *order)
 {
     constexpr int ROUNDS = MAXVIS / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // column/row ray tables
@@ -535,6 +535,13 @@ __global__ __launch_bounds__(256, MAXVIS <= 256 && !SHAPES ? MV_RASTER_WAVES : M
 // =====================================================================================================================
 namespace {
 
+#ifndef MV_GLIST_WAVES_NP2
+#define MV_GLIST_WAVES_NP2 5   // waves per SIMD the long-list variants are compiled for (two pixels per lane / one)
+#endif
+#ifndef MV_GLIST_WAVES_NP1
+#define MV_GLIST_WAVES_NP1 6
+#endif
+constexpr int GLIST_WAVES_NP2 = MV_GLIST_WAVES_NP2, GLIST_WAVES_NP1 = MV_GLIST_WAVES_NP1;
 #ifndef MV_FAST_PPL_DEFAULT
 #define MV_FAST_PPL_DEFAULT 2   // pixels per lane of raster_fast_kernel (MV_FAST_PPL overrides at run time)
 #endif
@@ -635,13 +642,12 @@ namespace {
 
 // one primitive that is not an axis-aligned box of the world frame -- a camera-attached box, a capsule, a cone, a scaled shape -- against this
 // lane's ray: its depth key (or ~0u), and for the curved ones the normal in the primitive's frame
-template <bool SHAPES, unsigned POS_MASK>
-__device__ __forceinline__ unsigned fast_other(int pos, const float4 *s_vis, const float *s_hdr, const float *camv, int viewer, V3 dw, float dcx, float dcy, V3 &n)
+template <bool SHAPES>
+__device__ __forceinline__ bool other_rec(const float4 lo, const float4 hi, const float *s_hdr, const float *camv, int viewer, V3 dw, float dcx, float dcy, float &t, V3 &n)
 {
-    const float4 lo = s_vis[2 * pos], hi = s_vis[2 * pos + 1];
     const unsigned meta = __builtin_amdgcn_readfirstlane(__float_as_uint(lo.w));
     const int qkind = meta & 15, qfr = (meta >> 4) & 15;
-    float t = 0.0f;
+    t = 0.0f;
     n = v3(0, 0, 0);
     bool hit;
     if (qkind == PRIM_BOX) {
@@ -657,19 +663,25 @@ __device__ __forceinline__ unsigned fast_other(int pos, const float4 *s_vis, con
             hit = ray_scaled_shape<true>(qkind, df, v3(lo.x, lo.y, lo.z), v3(hi.x, hi.y, hi.z), t, n);
         } else hit = false;
     }
-    const unsigned key = hit_key<POS_MASK>(hit && t >= NEAR_Z && t <= FAR_Z, t, pos);
-    return key;
+    return hit && t >= NEAR_Z && t <= FAR_Z;
+}
+
+template <bool SHAPES, unsigned POS_MASK>
+__device__ __forceinline__ unsigned fast_other(int pos, const float4 *s_vis, const float *s_hdr, const float *camv, int viewer, V3 dw, float dcx, float dcy, V3 &n)
+{
+    float t;
+    const bool hit = other_rec<SHAPES>(s_vis[2 * pos], s_vis[2 * pos + 1], s_hdr, camv, viewer, dw, dcx, dcy, t, n);
+    return hit_key<POS_MASK>(hit, t, pos);
 }
 
 // Phong (Magnum Shaders::Phong, uniforms of magnum_env_renderer.cpp:200-203) for the winning hit of a pixel; 0xff000000 when there is none
-template <bool SHAPES, unsigned POS_MASK>
-__device__ __forceinline__ unsigned fast_shade(unsigned best, V3 bn, const float4 *s_vis, const float *s_hdr, const float *camv, int viewer, V3 dw, V3 inv, float dcx, float dcy, float a2, float ldc)
+// the winning primitive's record (lo, hi) and -- for the curved kinds -- the depth and normal kept with the hit -> the pixel's colour
+template <bool SHAPES>
+__device__ __forceinline__ unsigned shade_rec(const float4 lo, const float4 hi, float tkey, V3 bn, const float *s_hdr, const float *camv, int viewer, V3 dw, V3 inv, float dcx, float dcy, float a2, float ldc)
 {
-    unsigned rgba = 0xff000000u;
-    if (best <= (KEY_FAR | POS_MASK)) {   // a hit between the near and the far plane
+    unsigned rgba;
+    {
         const V3 dc = v3(dcx, dcy, -1.0f);
-        const int pos = (int)(best & POS_MASK);
-        const float4 lo = s_vis[2 * pos], hi = s_vis[2 * pos + 1];
         const unsigned meta = __float_as_uint(lo.w), color = __float_as_uint(hi.w);
         const int qkind = meta & 15, qfr = (meta >> 4) & 15;
         float t, ndl, nv;   // depth; N . (L - P) and N . (-P), both unnormalised in (L - P) / P
@@ -687,8 +699,8 @@ __device__ __forceinline__ unsigned fast_shade(unsigned best, V3 bn, const float
             const float lk = s_hdr[FH_LREL + 4 * qfr + axis];
             nv = t * __builtin_fabsf(dk);                                                      // plane offset along the outward normal
             ndl = nv - __uint_as_float(__float_as_uint(lk) ^ (__float_as_uint(dk) & 0x80000000u));   // sgn (Lrel_k - t d_k), sgn = -sign(d_k)
-        } else {   // capsules, cones, scaled shapes: the normal was kept with the hit (depth: the key's, 2^-15 relative)
-            t = __uint_as_float((best & ~POS_MASK) + KEY_NEAR);
+        } else {   // capsules, cones, scaled shapes: the normal was kept with the hit (depth: the key's)
+            t = tkey;
             V3 N;
             lds_float *cc = local_lds(camv + 3);
             if (!SHAPES || qkind < PRIM_SPHERE_S || qfr == 0) N = lds_tmul(cc, bn);
@@ -723,14 +735,27 @@ __device__ __forceinline__ unsigned fast_shade(unsigned best, V3 bn, const float
     return rgba;
 }
 
+template <bool SHAPES, unsigned POS_MASK>
+__device__ __forceinline__ unsigned fast_shade(unsigned best, V3 bn, const float4 *s_vis, const float *s_hdr, const float *camv, int viewer, V3 dw, V3 inv, float dcx, float dcy, float a2, float ldc)
+{
+    unsigned rgba = 0xff000000u;
+    if (best <= (KEY_FAR | POS_MASK)) {   // a hit between the near and the far plane
+        const int pos = (int)(best & POS_MASK);
+        rgba = shade_rec<SHAPES>(s_vis[2 * pos], s_vis[2 * pos + 1], __uint_as_float((best & ~POS_MASK) + KEY_NEAR), bn, s_hdr, camv, viewer, dw, inv, dcx, dcy, a2, ldc);
+    }
+    return rgba;
+}
+
 struct FastFrame { int frame, part, viewer, nVis; };
 
 // The fast kernels' prologue: which frame is this workgroup's, then copies (header, list, rectangles) + the separable ray tables; ends with the
 // one barrier.  Workgroup ids are dealt round-robin over the 8 XCDs; the `split` parts of one frame get ids that are congruent mod 8 so that they
 // share one XCD's L2 (the frame's list is read `split` times, neighbouring tiles write neighbouring lines).
-template <int MAXVIS>
+// GLIST: the records stay in global memory (the tile loop fetches the surviving ones with scalar loads); LDS gets the rectangles and one class
+// byte per primitive instead: 0 a box in the world frame, 1..3 a box in hex wall frame 0..2, 4 anything else
+template <int MAXVIS, bool GLIST = false>
 __device__ __forceinline__ FastFrame fast_prologue(const FastArgs &fa, int blk, int W, int H, int split, float4 *s_vis, short4 *s_rect, float *s_hdr, float4 *s_col,
-                                                   float4 *s_row, float2 *s_rowq, float *s_colq)
+                                                   float4 *s_row, float2 *s_rowq, float *s_colq, unsigned char *s_cls = nullptr)
 {
     const int A = fa.num_agents;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -769,7 +794,13 @@ __device__ __forceinline__ FastFrame fast_prologue(const FastArgs &fa, int blk, 
     if (tid < FH_FLOATS) s_hdr[tid] = gh[tid];
     {
         const float4 *src = reinterpret_cast<const float4 *>(fa.vis_prims + (size_t)frame * fa.vis_stride);
-        for (int i = tid; i < nVis * 2; i += 256) s_vis[i] = src[i];
+        if (!GLIST) for (int i = tid; i < nVis * 2; i += 256) s_vis[i] = src[i];
+        else
+            for (int i = tid; i < nVis; i += 256) {
+                const unsigned ml = __float_as_uint(reinterpret_cast<const float *>(src)[8 * i + 3]);   // kind | frame << 4 | slot << 8
+                const unsigned fl = (ml >> 4) & 15u;
+                s_cls[i] = (ml & 15u) != (unsigned)PRIM_BOX ? 4 : fl == 0u ? 0 : fl > (unsigned)MAX_AGENTS ? (unsigned char)(fl - (unsigned)MAX_AGENTS) : 4;
+            }
         const short4 *rs = fa.vis_rects + (size_t)frame * fa.vis_stride;
         for (int i = tid; i < nVis; i += 256) s_rect[i] = rs[i];
         const float *c = gh + FH_CAM + FH_CAM_STRIDE * viewer + 3;   // (same arithmetic as the exact kernel: rays are bit-identical)
@@ -944,6 +975,180 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
     }
 }
 
+// ---- the long-list variant ("global list"): Collect and the Hex scenarios ---------------------------------------------------------------------------
+// A frame of these scenarios holds hundreds of visible primitives (a Hex maze seen from its rim: more than a thousand).  Keeping their 32-byte
+// records in LDS cost 32 KB per workgroup -- three waves per SIMD, and a hard cap of 1024.  Here LDS holds only what the CULLING needs, 8 bytes of
+// screen rectangle and one class byte per primitive (18 KB for 2048 of them): the records stay where the frame setup wrote them, and the few that
+// survive a tile's culling are fetched through the SCALAR cache -- their list position is wave-uniform, a record is eight SGPRs that feed the
+// slab test's multiplies directly (no VGPRs, no LDS bandwidth, no prologue copy of the list).  Twice the occupancy hides the longer fetch.
+// The nearest hit is kept as a 64-bit (depth bits, list position) pair compared as one unsigned: full 24-bit depth precision at any list
+// length (the short-list variants pack both into 32 bits), exact ties resolve to the earlier drawable like everywhere else.
+typedef __attribute__((address_space(4))) const float cfloat;   // constant address space: loads from uniform addresses become s_load
+__device__ __forceinline__ float4 rec4(cfloat *p, int i) { return make_float4(p[4 * i], p[4 * i + 1], p[4 * i + 2], p[4 * i + 3]); }   // (one s_load_dwordx4)
+
+struct Key2 { unsigned d, p; };   // depth bits minus KEY_NEAR (> KEY_FAR: not a hit), list position
+
+__device__ __forceinline__ void key2_min(Key2 &best, bool valid, unsigned d, unsigned p)
+{
+    const unsigned long long a = ((unsigned long long)d << 32) | p, b = ((unsigned long long)best.d << 32) | best.p;
+    const bool less = valid && a < b;
+    best.d = less ? d : best.d;
+    best.p = less ? p : best.p;
+}
+
+template <int NP>
+__device__ __forceinline__ void box_test_g(const V3 (&inv)[NP], const float4 lo, const float4 hi, int pos, Key2 (&best)[NP])
+{
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const float t1x = lo.x * inv[j].x, t2x = hi.x * inv[j].x, t1y = lo.y * inv[j].y, t2y = hi.y * inv[j].y, t1z = lo.z * inv[j].z, t2z = hi.z * inv[j].z;
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)), __builtin_fminf(t1z, t2z));
+        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)), __builtin_fmaxf(t1z, t2z));
+        key2_min(best[j], tn <= tf, __float_as_uint(tn) - KEY_NEAR, (unsigned)pos);
+    }
+}
+
+// the boxes of one frame of reference among list positions 64 k .. 64 k + 63 (mask m): the next record is requested while the current one is tested
+template <int NP>
+__device__ __forceinline__ void box_run_g(unsigned long long m, int k, const V3 (&inv)[NP], cfloat *cp, Key2 (&best)[NP])
+{
+    if (!m) return;
+    int p0 = __ffsll((long long)m) - 1 + 64 * k, p1 = 0;
+    m &= m - 1;
+    float4 lo0 = rec4(cp, 2 * p0), hi0 = rec4(cp, 2 * p0 + 1), lo1 = lo0, hi1 = hi0;
+    for (;;) {
+        bool more = m != 0ull;
+        if (more) { p1 = __ffsll((long long)m) - 1 + 64 * k; m &= m - 1; lo1 = rec4(cp, 2 * p1); hi1 = rec4(cp, 2 * p1 + 1); }
+        box_test_g<NP>(inv, lo0, hi0, p0, best);
+        if (!more) break;
+        more = m != 0ull;
+        if (more) { p0 = __ffsll((long long)m) - 1 + 64 * k; m &= m - 1; lo0 = rec4(cp, 2 * p0); hi0 = rec4(cp, 2 * p0 + 1); }
+        box_test_g<NP>(inv, lo1, hi1, p1, best);
+        if (!more) break;
+    }
+}
+
+template <int MAXVIS, bool SHAPES, bool HEXF, int NP>
+__device__ __forceinline__ void raster_glist_body(const FastArgs &fa, uint32_t *obs, int W, int H, int split, int blk)
+{
+    constexpr int TH = TILE_H * NP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    __shared__ short4 s_rect[MAXVIS];
+    __shared__ unsigned char s_cls[MAXVIS];
+    __shared__ __attribute__((aligned(16))) float s_hdr[FH_FLOATS];
+
+    float4 *s_col = reinterpret_cast<float4 *>(s_dyn);
+    float4 *s_row = s_col + W;
+    float2 *s_rowq = reinterpret_cast<float2 *>(s_row + H);
+    float *s_colq = reinterpret_cast<float *>(s_rowq + H);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    fast_publish(fa, blk);
+    const FastFrame ff = fast_prologue<MAXVIS, true>(fa, blk, W, H, split, nullptr, s_rect, s_hdr, s_col, s_row, s_rowq, s_colq, s_cls);
+    const int frame = ff.frame, part = ff.part, viewer = ff.viewer, nVis = ff.nVis;
+    const float4 *gp = reinterpret_cast<const float4 *>(fa.vis_prims + (size_t)frame * fa.vis_stride);   // this frame's records
+    cfloat *cp = (cfloat *)gp;
+
+    const float *camv = s_hdr + FH_CAM + FH_CAM_STRIDE * viewer;
+    const float nzm0 = uniform_f32(-camv[3 + 2]), nzm1 = uniform_f32(-camv[3 + 5]), nzm2 = uniform_f32(-camv[3 + 8]);
+    uint32_t *out = obs + (size_t)frame * W * H;
+    const int tilesX = (W + TILE_W - 1) / TILE_W, tilesY = (H + TH - 1) / TH;
+    const int numTiles = tilesX * tilesY;
+    const int lx = lane & (TILE_W - 1), ly = lane / TILE_W;
+
+    int tx = part * 4 + wave, ty = 0;
+    for (int tile = part * 4 + wave; tile < numTiles; tile += 4 * split, tx += 4 * split) {
+        while (tx >= tilesX) { tx -= tilesX; ++ty; }
+        const int tx0 = tx * TILE_W, ty0 = ty * TH;
+        const int tx1 = min(tx0 + TILE_W, W) - 1, ty1 = min(ty0 + TH, H) - 1;
+        const int px = tx0 + lx, py0 = ty0 + ly;
+        const int pxc = min(px, W - 1);
+        V3 dw[NP], inv[NP], ih0[NP], ih1[NP], ih2[NP], bn[NP];
+        float dcx = 0.0f, dcy[NP], a2[NP], ldc[NP];
+        Key2 best[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            dw[j] = inv[j] = bn[j] = ih0[j] = ih1[j] = ih2[j] = v3(0, 0, 0);
+            dcy[j] = a2[j] = ldc[j] = 0.0f;
+            best[j].d = ~0u; best[j].p = 0u;
+        }
+        bool rayReady = false;
+#pragma unroll 1
+        for (int k = 0; k * 64 < nVis; ++k) {
+            const int cpos = min(lane + 64 * k, nVis - 1);
+            const uint2 rr = *reinterpret_cast<const uint2 *>(&s_rect[cpos]);
+            const bool v = (lane + 64 * k < nVis) & ((int)(rr.x & 0xffffu) <= tx1) & ((int)(rr.x >> 16) >= tx0) & ((int)(rr.y & 0xffffu) <= ty1) &
+                           ((int)(rr.y >> 16) >= ty0);
+            const unsigned long long mvis = __ballot(v);
+            if (mvis == 0ull) continue;
+            if (!rayReady) {
+                rayReady = true;
+                const float4 cx = s_col[pxc];
+                const float cq = s_colq[pxc];
+                dcx = cx.x;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    const int pyc = min(py0 + TILE_H * j, H - 1);
+                    const float4 ry = s_row[pyc];
+                    const float2 rq = s_rowq[pyc];
+                    dcy[j] = ry.x;
+                    dw[j] = v3((cx.y + ry.y) + nzm0, (cx.z + ry.z) + nzm1, (cx.w + ry.w) + nzm2);
+                    inv[j] = v3(__builtin_amdgcn_rcpf(dw[j].x), __builtin_amdgcn_rcpf(dw[j].y), __builtin_amdgcn_rcpf(dw[j].z));
+                    a2[j] = cq + rq.x; ldc[j] = rq.y;
+                    if (HEXF) {   // (same products and sums as mat_tmul with the frame's matrix: c x + (-s) z, s x + c z)
+                        const float cx8 = 0.8660254f * dw[j].x, cz8 = 0.8660254f * dw[j].z, hx5 = 0.5f * dw[j].x, hz5 = 0.5f * dw[j].z;
+                        ih0[j] = v3(__builtin_amdgcn_rcpf(cx8 - hz5), inv[j].y, __builtin_amdgcn_rcpf(hx5 + cz8));
+                        ih1[j] = v3(__builtin_amdgcn_rcpf(cx8 + hz5), inv[j].y, __builtin_amdgcn_rcpf(cz8 - hx5));
+                        ih2[j] = v3(0.0f - inv[j].z, inv[j].y, inv[j].x);   // 90 degrees: (x, z) -> (-z, x)
+                    }
+                }
+            }
+            const unsigned cl = s_cls[cpos];
+            const unsigned long long m0 = __ballot(v && cl == 0u);
+            unsigned long long boxes = m0;
+            box_run_g<NP>(m0, k, inv, cp, best);
+            if (HEXF) {
+                const unsigned long long m1 = __ballot(v && cl == 1u), m2 = __ballot(v && cl == 2u), m3 = __ballot(v && cl == 3u);
+                box_run_g<NP>(m1, k, ih0, cp, best);
+                box_run_g<NP>(m2, k, ih1, cp, best);
+                box_run_g<NP>(m3, k, ih2, cp, best);
+                boxes |= m1 | m2 | m3;
+            }
+            unsigned long long rest = mvis & ~boxes;   // camera-attached boxes, capsules, cones, scaled shapes (and, not HEXF, wall-frame boxes)
+            while (rest) {
+                const int pos = __ffsll((long long)rest) - 1 + 64 * k;
+                rest &= rest - 1;
+                const float4 lo = rec4(cp, 2 * pos), hi = rec4(cp, 2 * pos + 1);
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    V3 n = v3(0, 0, 0);
+                    float t;
+                    const bool hit = other_rec<SHAPES>(lo, hi, s_hdr, camv, viewer, dw[j], dcx, dcy[j], t, n);
+                    const unsigned d = __float_as_uint(t) - KEY_NEAR;
+                    const bool less = hit && (d < best[j].d || (d == best[j].d && (unsigned)pos < best[j].p));
+                    if (less) { best[j].d = d; best[j].p = (unsigned)pos; bn[j] = n; }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            unsigned rgba = 0xff000000u;
+            if (best[j].d <= KEY_FAR) {   // a hit between the near and the far plane: the winner's record, one 32-byte read per lane
+                const float4 lo = gp[2 * best[j].p], hi = gp[2 * best[j].p + 1];
+                rgba = shade_rec<SHAPES>(lo, hi, __uint_as_float(best[j].d + KEY_NEAR), bn[j], s_hdr, camv, viewer, dw[j], inv[j], dcx, dcy[j], a2[j], ldc[j]);
+            }
+            const int py = py0 + TILE_H * j;
+            if (px < W && py < H) out[(unsigned)(py * W + px)] = rgba;
+        }
+    }
+}
+
+template <int MAXVIS, bool SHAPES, int WAVES, bool HEXF, int NP>
+__global__ __launch_bounds__(256, WAVES) void raster_glist_kernel(FastArgs fa, uint32_t *obs, int W, int H, int split)
+{
+    raster_glist_body<MAXVIS, SHAPES, HEXF, NP>(fa, obs, W, H, split, (int)blockIdx.x);
+}
+
 template <int MAXVIS, bool SHAPES, int WAVES, bool HEXF = false, int NP = 1>   // WAVES: waves per SIMD the variant is compiled for (register budget 512 / WAVES)
 __global__ __launch_bounds__(256, WAVES) void raster_fast_kernel(FastArgs fa, uint32_t *obs, int W, int H, int split)
 {
@@ -970,6 +1175,16 @@ __global__ __launch_bounds__(256, WAVES) void raster_fast_union_kernel(UnionRast
     raster_fast_body<MAXVIS, SHAPES, HEXF, NP>(ua.fa[s], ua.obs[s], W, H, split, (int)blockIdx.x - ua.first[s]);
 }
 
+template <int MAXVIS, bool SHAPES, int WAVES, bool HEXF, int NP>
+__global__ __launch_bounds__(256, WAVES) void raster_glist_union_kernel(UnionRasterArgs ua, int W, int H, int split)
+{
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_UNION; ++i)
+        if (i < ua.n && (int)blockIdx.x >= ua.first[i]) s = i;
+    raster_glist_body<MAXVIS, SHAPES, HEXF, NP>(ua.fa[s], ua.obs[s], W, H, split, (int)blockIdx.x - ua.first[s]);
+}
+
 static FastArgs fast_args_of(const GymView &gv, const PublishTo *publish)
 {
     const int frames = gv.num_envs * gv.num_agents;
@@ -980,6 +1195,16 @@ static FastArgs fast_args_of(const GymView &gv, const PublishTo *publish)
     fa.pub_rewards = publish ? publish->rewards : nullptr; fa.pub_true = publish ? publish->true_objective : nullptr; fa.pub_done = publish ? publish->done : nullptr;
     fa.pub_n = publish ? frames : 0;
     return fa;
+}
+
+// Pixels per lane of the fast kernels (tile 16 x 4 NP): two from 8192 pixels per frame up; below that (64 x 64) the larger tiles cull worse than
+// the shared work saves (Mixed 64 x 64: 9.7 M obs/s with one, 7.7 M with two; Collect 13.6 / 13.1, HexMemory 8.2 / 8.4).  MV_FAST_PPL = 1 | 2
+// overrides (read at every launch: the variants are compared within one process by tests/test_fast_pixels_gpu.py).
+static int fast_pixels_per_lane(int W, int H)
+{
+    const char *e = getenv("MV_FAST_PPL");
+    if (e && *e) return atoi(e) >= 2 ? 2 : 1;
+    return MV_FAST_PPL_DEFAULT >= 2 && W * H >= 8192 ? 2 : 1;
 }
 
 // Workgroups per frame of the fast kernels.  One pixel per lane: 4 (r02 sweeps: 4 and 8 best).  Two pixels per lane (half as many tiles, a
@@ -1004,8 +1229,7 @@ int launch_raster_union(const GymView *views, uint32_t *const *obs, const Publis
 {
     if (W > MAX_W || H > MAX_H || n > MAX_UNION) return -1;
     const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)W * sizeof(float) + (size_t)H * sizeof(float2);
-    const char *pplEnv = getenv("MV_FAST_PPL");
-    const int np = (pplEnv ? atoi(pplEnv) : MV_FAST_PPL_DEFAULT) >= 2 ? 2 : 1;
+    const int np = fast_pixels_per_lane(W, H);
     int unionFrames[2] = {0, 0};
     for (int i = 0; i < n; ++i) unionFrames[views[i].vis_stride > VIS_SMALL ? 1 : 0] += views[i].num_envs * views[i].num_agents;
     if (between) (void)hipEventRecord(between, stream);
@@ -1026,10 +1250,10 @@ int launch_raster_union(const GymView *views, uint32_t *const *obs, const Publis
         if (!ua.n) continue;
         for (int i = ua.n; i <= MAX_UNION; ++i) ua.first[i] = wgs;
         if (np == 2) {
-            if (large) hipLaunchKernelGGL((raster_fast_union_kernel<VIS_LARGE, true, 3, true, 2>), dim3(wgs), dim3(256), dyn, stream, ua, W, H, split);
+            if (large) hipLaunchKernelGGL((raster_glist_union_kernel<VIS_XL, true, GLIST_WAVES_NP2, true, 2>), dim3(wgs), dim3(256), dyn, stream, ua, W, H, split);
             else hipLaunchKernelGGL((raster_fast_union_kernel<VIS_SMALL, true, 6, false, 2>), dim3(wgs), dim3(256), dyn, stream, ua, W, H, split);
         } else {
-            if (large) hipLaunchKernelGGL((raster_fast_union_kernel<VIS_LARGE, true, 3, true, 1>), dim3(wgs), dim3(256), dyn, stream, ua, W, H, split);
+            if (large) hipLaunchKernelGGL((raster_glist_union_kernel<VIS_XL, true, GLIST_WAVES_NP1, true, 1>), dim3(wgs), dim3(256), dyn, stream, ua, W, H, split);
             else hipLaunchKernelGGL((raster_fast_union_kernel<VIS_SMALL, true, 8, false, 1>), dim3(wgs), dim3(256), dyn, stream, ua, W, H, split);
         }
     }
@@ -1047,11 +1271,7 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
     if (between) (void)hipEventRecord(between, stream);
     if (fast) {
         const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)W * sizeof(float) + (size_t)H * sizeof(float2);
-        // pixels per lane (tile 16 x 4 NP): MV_FAST_PPL = 1 | 2 (read at every launch: the variants are compared within one process by
-        // tests/test_fast_pixels_gpu.py)
-        const char *pplEnv = getenv("MV_FAST_PPL");
-        const int pplSel = pplEnv ? atoi(pplEnv) : MV_FAST_PPL_DEFAULT;
-        const int np = pplSel >= 2 ? 2 : 1;
+        const int np = fast_pixels_per_lane(W, H);
         const int split = fast_split(W, H, np, frames);
         // variants: [0] <=256 visible primitives, [1] + scaled shapes (Rearrange), [2] <=1024 (Collect), [3] <=1024 + scaled shapes (Hex*); the
         // small ones are built for 8 and for 6 waves per SIMD (64 / 80 VGPRs), MV_FAST_WAVES picks (two pixels per lane: 7 / 6 waves)
@@ -1063,11 +1283,11 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
         const bool hexScen = gv.scenario == SCN_HEX_MEMORY || gv.scenario == SCN_HEX_EXPLORE;
         KernelFn fn;
         if (np == 2)   // (the small variants: 72 VGPRs / 7 waves, 80 / 6; at 64 they would spill)
-            fn = hexScen ? raster_fast_kernel<VIS_LARGE, true, 3, true, 2> : gv.vis_stride > VIS_SMALL ? raster_fast_kernel<VIS_LARGE, false, 3, false, 2>
+            fn = hexScen ? raster_glist_kernel<VIS_XL, true, GLIST_WAVES_NP2, true, 2> : gv.vis_stride > VIS_SMALL ? raster_glist_kernel<VIS_LARGE, false, GLIST_WAVES_NP2, false, 2>
                : gv.scenario == SCN_REARRANGE ? raster_fast_kernel<VIS_SMALL, true, 6, false, 2>   // (with the scaled shapes 72 VGPRs would spill)
                                               : (wavesSel >= 7 ? raster_fast_kernel<VIS_SMALL, false, 7, false, 2> : raster_fast_kernel<VIS_SMALL, false, 6, false, 2>);
         else
-            fn = hexScen ? raster_fast_kernel<VIS_LARGE, true, 3, true> : gv.vis_stride > VIS_SMALL ? raster_fast_kernel<VIS_LARGE, false, 3>
+            fn = hexScen ? raster_glist_kernel<VIS_XL, true, GLIST_WAVES_NP1, true, 1> : gv.vis_stride > VIS_SMALL ? raster_glist_kernel<VIS_LARGE, false, GLIST_WAVES_NP1, false, 1>
                : gv.scenario == SCN_REARRANGE ? (wavesSel >= 8 ? raster_fast_kernel<VIS_SMALL, true, 8> : raster_fast_kernel<VIS_SMALL, true, 6>)
                                               : (wavesSel >= 8 ? raster_fast_kernel<VIS_SMALL, false, 8> : raster_fast_kernel<VIS_SMALL, false, 6>);
         hipLaunchKernelGGL(fn, dim3(frames * split), dim3(256), dyn, stream, fa, obs, W, H, split);
@@ -1077,7 +1297,7 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
     int split = envSplit > 0 ? envSplit : 4;
     while (split > 1 && tiles < 4 * split * 2) split >>= 1;   // keep at least two tiles per wave
     const dim3 grid(frames * split), block(256);
-    if (gv.scenario == SCN_HEX_MEMORY || gv.scenario == SCN_HEX_EXPLORE) hipLaunchKernelGGL((raster_kernel<VIS_LARGE, true>), grid, block, dyn, stream, gv, obs, W, H, split, gv.lpt_order);
+    if (gv.scenario == SCN_HEX_MEMORY || gv.scenario == SCN_HEX_EXPLORE) hipLaunchKernelGGL((raster_kernel<VIS_XL, true>), grid, block, dyn, stream, gv, obs, W, H, split, gv.lpt_order);
     else if (gv.vis_stride > VIS_SMALL) hipLaunchKernelGGL((raster_kernel<VIS_LARGE, false>), grid, block, dyn, stream, gv, obs, W, H, split, gv.lpt_order);
     else if (gv.scenario == SCN_REARRANGE) hipLaunchKernelGGL((raster_kernel<VIS_SMALL, true>), grid, block, dyn, stream, gv, obs, W, H, split, gv.lpt_order);
     else hipLaunchKernelGGL((raster_kernel<VIS_SMALL, false>), grid, block, dyn, stream, gv, obs, W, H, split, gv.lpt_order);

@@ -3,8 +3,8 @@ magnum_env_renderer.cpp:256-340) raises a flag; the next mv_step / mv_reset that
 does its work all the same, and the gym keeps running.  One test per flag (ST_STARVED: tests/test_refill_protocol_gpu.py):
   ST_CHUNK       an object placed above the 32 x 16 x 32 voxel chunk;
   ST_CANDIDATES  more than 128 collision candidates around one Collect agent (a path that sweeps the whole landscape);
-  ST_VISIBLE     more than 1024 visible primitives in a Hex frame (the largest maze found, seen from outside) -- and the same mazes from
-                 their rim, looking in, stay below the cap;
+  ST_VISIBLE     more visible primitives in a frame than the raster keeps (a test-only override lowers the cap); and the real cap of the Hex
+                 scenarios (2048) holds for the largest mazes found, from their rim and from outside;
   GEN_*          a generated Obstacles level beyond an episode record's arrays (an absurd platform count)."""
 import ctypes as C
 import os
@@ -78,55 +78,64 @@ def test_candidate_overflow_is_reported_once(hip):
     g = MegaverseGym("Collect", 32, 32, 64, 1, 2, False, {})
     g.seed(11); g.reset()
     assert int(hip_snapshot(g, e)["num_boxes"]) == counts[e]
-    g.debug_set_agent_pos(e, 0, 1.5, 12.0, 1.5)
-    g.debug_set_agent_velocity(e, 0, 600.0, 600.0, 0.0)                    # 40 units per tick along the diagonal
+    g.debug_set_agent_pos(e, 0, 1.5, 3.0, 1.5)                             # among the hills,
+    g.debug_set_agent_velocity(e, 0, 600.0, 600.0, -55.0)                  # 40 units per tick along the diagonal, falling at the terminal speed
     msgs = steps_collecting_warnings(g, 60, seed=2)
     assert len(msgs) == 1 and "candidate list overflow" in msgs[0], msgs
     assert not steps_collecting_warnings(g, 40, seed=2, first=60)
     g.close()
 
 
-def test_visible_primitive_cap(hip):
-    # the largest mazes among 4096 generated ones
+def test_visible_primitive_cap_holds_for_the_largest_mazes(hip):
+    """A Hex maze has up to 2146 drawable slots.  Round 2 kept 1024 visible ones per frame -- and this very test found rim views of the largest
+    mazes that exceed it.  The long-list raster now keeps 2048: every view from the rim of the three largest of 4096 generated mazes, and the
+    whole maze seen from outside (every slot inside the field of view), must stay below the cap."""
     best = []
     for master in range(1, 65):
         for e, s in enumerate(env_seeds(master, 64)):
             best.append((int(first_episode_counts("HexMemory", s)[1]), master, e))
     best.sort(reverse=True)
     assert best[0][0] > 800, best[0]
-    natural, forced = [], []
+    msgs, slots = [], []
     for nb, master, e in best[:3]:
         g = MegaverseGym("HexMemory", 128, 72, e + 1, 1, 2, False, {})
         g.set_pixel_mode("fast")
         g.seed(master); g.reset()
         s = hip_snapshot(g, e)
         assert int(s["hex_num_boxes"]) == nb
+        slots.append(nb + 3 * int(s["hex_num_objs"]))
         floor = s["hex_boxes"][0]
         R = float(max(abs(floor["a"][0]), abs(floor["b"][0]), abs(floor["a"][2]), abs(floor["b"][2])))
         y = float(floor["b"][1]) + 0.9
-        # from the rim, looking at the centre (forward = (-sin psi, 0, -cos psi)): what an agent standing in a rim cell can see at most
-        for k in range(12):
+        for k in range(12):   # from the rim, looking at the centre (forward = (-sin psi, 0, -cos psi))
             ang = 2 * np.pi * k / 12
             x, z = 0.85 * R * np.cos(ang), 0.85 * R * np.sin(ang)
             c, sn = yaw_cs(np.arctan2(x, z))
             g.debug_set_agent_pos(e, 0, x, y, z); g.debug_set_agent_yaw(e, 0, c, sn); g.debug_set_agent_velocity(e, 0, 0, 0, 0)
             g.render()
-        g.debug_set_agent_pos(e, 0, 0.0, y, 0.0)
-        natural += steps_collecting_warnings(g, 60, seed=4)
-        # from far outside, the whole maze inside the field of view: every box and collectable is "visible"
-        c, sn = yaw_cs(np.pi / 2)
+        c, sn = yaw_cs(np.pi / 2)   # from far outside: the whole maze inside the field of view
         g.debug_set_agent_pos(e, 0, 3.0 * R, y + 4.0, 0.0); g.debug_set_agent_yaw(e, 0, c, sn)
         g.render()
+        assert g.get_observation(e, 0)[..., :3].max() > 0
         g.debug_set_agent_pos(e, 0, 0.0, y, 0.0)
-        forced.append((nb + 3 * int(s["hex_num_objs"]), steps_collecting_warnings(g, 60, seed=4, first=60)))
-        assert not steps_collecting_warnings(g, 30, seed=4, first=120)
+        msgs += steps_collecting_warnings(g, 60, seed=4)
         g.close()
-    print("largest mazes (boxes, master seed, env):", best[:3], "slots seen from outside / warnings:", [(n, len(m)) for n, m in forced])
-    assert not natural, natural                                            # the cap holds for every rim view of the largest mazes found
-    for slots, msgs in forced:
-        if slots > 1024 + 8:
-            assert len(msgs) == 1 and "visible primitives" in msgs[0], (slots, msgs)
-    assert any(slots > 1024 + 8 for slots, _ in forced)
+    print("largest mazes (boxes, master seed, env):", best[:3], "drawable slots:", slots)
+    assert max(slots) > 1024 and not msgs, (slots, msgs)
+
+
+def test_visible_overflow_is_reported_once(hip, monkeypatch):
+    # the real caps (256 / 1024 / 2048 visible primitives per frame) are out of reach of generated levels: a test-only override lowers this gym's
+    monkeypatch.setenv("MV_DEBUG_VIS_STRIDE", "24")
+    g = MegaverseGym("TowerBuilding", 64, 64, 32, 1, 1, False, {})
+    monkeypatch.delenv("MV_DEBUG_VIS_STRIDE")
+    g.set_pixel_mode("fast")
+    g.seed(3); g.reset()
+    msgs = steps_collecting_warnings(g, 80, seed=5, render=True)
+    assert len(msgs) >= 1 and all("visible primitives" in m for m in msgs), msgs
+    assert len(msgs) <= 8                                                   # once per status read-back that saw it (every 16th step), not once per frame
+    assert g.get_observation(0, 0)[..., :3].max() > 0                       # the gym keeps rendering (the excess primitives are not drawn)
+    g.close()
 
 
 def test_generator_overflow_is_reported_once(hip):
