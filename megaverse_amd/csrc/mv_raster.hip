@@ -1200,11 +1200,13 @@ static FastArgs fast_args_of(const GymView &gv, const PublishTo *publish)
 // Pixels per lane of the fast kernels (tile 16 x 4 NP): two from 8192 pixels per frame up; below that (64 x 64) the larger tiles cull worse than
 // the shared work saves (Mixed 64 x 64: 9.7 M obs/s with one, 7.7 M with two; Collect 13.6 / 13.1, HexMemory 8.2 / 8.4).  MV_FAST_PPL = 1 | 2
 // overrides (read at every launch: the variants are compared within one process by tests/test_fast_pixels_gpu.py).
-static int fast_pixels_per_lane(int W, int H)
+// The long-list variants (Collect, Hex*) always take one: their two-pixel builds need 78-95 VGPRs, and with the records coming through the
+// scalar cache occupancy is worth more (Collect 128 x 128: 97.6 us with one, 146 with two; HexMemory 155 / 171).
+static int fast_pixels_per_lane(int W, int H, bool longList = false)
 {
     const char *e = getenv("MV_FAST_PPL");
     if (e && *e) return atoi(e) >= 2 ? 2 : 1;
-    return MV_FAST_PPL_DEFAULT >= 2 && W * H >= 8192 ? 2 : 1;
+    return !longList && MV_FAST_PPL_DEFAULT >= 2 && W * H >= 8192 ? 2 : 1;
 }
 
 // Workgroups per frame of the fast kernels.  One pixel per lane: 4 (r02 sweeps: 4 and 8 best).  Two pixels per lane (half as many tiles, a
@@ -1237,7 +1239,8 @@ int launch_raster_union(const GymView *views, uint32_t *const *obs, const Publis
         UnionRasterArgs ua;
         ua.n = 0;
         int wgs = 0;
-        const int split = fast_split(W, H, np, unionFrames[large]);
+        const int lnp = large ? fast_pixels_per_lane(W, H, true) : np;
+        const int split = fast_split(W, H, lnp, unionFrames[large]);
         for (int i = 0; i < n; ++i) {
             const bool isLarge = views[i].vis_stride > VIS_SMALL;
             if (isLarge != (large != 0)) continue;
@@ -1249,11 +1252,11 @@ int launch_raster_union(const GymView *views, uint32_t *const *obs, const Publis
         }
         if (!ua.n) continue;
         for (int i = ua.n; i <= MAX_UNION; ++i) ua.first[i] = wgs;
-        if (np == 2) {
-            if (large) hipLaunchKernelGGL((raster_glist_union_kernel<VIS_XL, true, GLIST_WAVES_NP2, true, 2>), dim3(wgs), dim3(256), dyn, stream, ua, W, H, split);
-            else hipLaunchKernelGGL((raster_fast_union_kernel<VIS_SMALL, true, 6, false, 2>), dim3(wgs), dim3(256), dyn, stream, ua, W, H, split);
+        if (large) {
+            if (lnp == 2) hipLaunchKernelGGL((raster_glist_union_kernel<VIS_XL, true, GLIST_WAVES_NP2, true, 2>), dim3(wgs), dim3(256), dyn, stream, ua, W, H, split);
+            else hipLaunchKernelGGL((raster_glist_union_kernel<VIS_XL, true, GLIST_WAVES_NP1, true, 1>), dim3(wgs), dim3(256), dyn, stream, ua, W, H, split);
         } else {
-            if (large) hipLaunchKernelGGL((raster_glist_union_kernel<VIS_XL, true, GLIST_WAVES_NP1, true, 1>), dim3(wgs), dim3(256), dyn, stream, ua, W, H, split);
+            if (lnp == 2) hipLaunchKernelGGL((raster_fast_union_kernel<VIS_SMALL, true, 6, false, 2>), dim3(wgs), dim3(256), dyn, stream, ua, W, H, split);
             else hipLaunchKernelGGL((raster_fast_union_kernel<VIS_SMALL, true, 8, false, 1>), dim3(wgs), dim3(256), dyn, stream, ua, W, H, split);
         }
     }
@@ -1271,7 +1274,7 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
     if (between) (void)hipEventRecord(between, stream);
     if (fast) {
         const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)W * sizeof(float) + (size_t)H * sizeof(float2);
-        const int np = fast_pixels_per_lane(W, H);
+        const int np = fast_pixels_per_lane(W, H, gv.vis_stride > VIS_SMALL);
         const int split = fast_split(W, H, np, frames);
         // variants: [0] <=256 visible primitives, [1] + scaled shapes (Rearrange), [2] <=1024 (Collect), [3] <=1024 + scaled shapes (Hex*); the
         // small ones are built for 8 and for 6 waves per SIMD (64 / 80 VGPRs), MV_FAST_WAVES picks (two pixels per lane: 7 / 6 waves)
