@@ -1209,16 +1209,20 @@ static int fast_pixels_per_lane(int W, int H, bool longList = false)
     return !longList && MV_FAST_PPL_DEFAULT >= 2 && W * H >= 8192 ? 2 : 1;
 }
 
-// Workgroups per frame of the fast kernels.  One pixel per lane: 4 (r02 sweeps: 4 and 8 best).  Two pixels per lane (half as many tiles, a
-// prologue per workgroup): measured on 1024 frames of 128 x 128, 2: 58.0 us, 4: 61.3, 8: 69.7 -- and on the 384 / 640 frames of a Mixed group's
-// two launches 4 beats 2 (6.4 M against 4.4 M obs/s at 128 x 128; 8.7 M against 8.0 M at 64 x 64): enough workgroups to fill the chip once
-// (~2048), at most 4, at least 2 tiles per wave.  MV_RASTER_SPLIT overrides.
-static int fast_split(int W, int H, int np, int frames)
+// Workgroups per frame of the fast kernels.  One pixel per lane: 4 (r02 sweeps: 4 and 8 best at 1024 frames).  Two pixels per lane (half as many
+// tiles, a prologue per workgroup): measured on 1024 frames of 128 x 128, 2: 58.0 us, 4: 61.3, 8: 69.7.  With FEW frames in a launch (a Mixed
+// group's two launches: 384 / 640 frames) a launch lasts as long as its slowest frame -- kernel traces: 128 HexMemory frames of 64 x 64 take
+// 43 us, 1024 of them 84 -- so the frame is cut into more pieces: enough workgroups to fill the chip about twice (4096 / 2048), at most 16 / 8,
+// at least one (long lists) / two tiles per wave.  MV_RASTER_SPLIT overrides.
+static int fast_split(int W, int H, int np, int frames, bool longList = false)
 {
     static const int envSplit = getenv("MV_RASTER_SPLIT") ? atoi(getenv("MV_RASTER_SPLIT")) : 0;
     const int ftiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H * np - 1) / (TILE_H * np));
-    int split = envSplit > 0 ? envSplit : np >= 2 ? std::min(4, std::max(2, (2048 + frames - 1) / std::max(frames, 1))) : 4;
-    while (split > 1 && ftiles < 4 * split * 2) split >>= 1;   // keep at least two tiles per wave
+    const int want = ((np >= 2 ? 2048 : 4096) + frames - 1) / std::max(frames, 1), lo = np >= 2 ? 2 : 4, hi = np >= 2 ? 8 : 16;
+    int split = lo;
+    while (split < hi && split < want) split <<= 1;
+    if (envSplit > 0) split = envSplit;
+    while (split > 1 && ftiles < 4 * split * (longList ? 1 : 2)) split >>= 1;
     return split;
 }
 
@@ -1240,7 +1244,7 @@ int launch_raster_union(const GymView *views, uint32_t *const *obs, const Publis
         ua.n = 0;
         int wgs = 0;
         const int lnp = large ? fast_pixels_per_lane(W, H, true) : np;
-        const int split = fast_split(W, H, lnp, unionFrames[large]);
+        const int split = fast_split(W, H, lnp, unionFrames[large], large != 0);
         for (int i = 0; i < n; ++i) {
             const bool isLarge = views[i].vis_stride > VIS_SMALL;
             if (isLarge != (large != 0)) continue;
@@ -1275,7 +1279,7 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
     if (fast) {
         const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)W * sizeof(float) + (size_t)H * sizeof(float2);
         const int np = fast_pixels_per_lane(W, H, gv.vis_stride > VIS_SMALL);
-        const int split = fast_split(W, H, np, frames);
+        const int split = fast_split(W, H, np, frames, gv.vis_stride > VIS_SMALL);
         // variants: [0] <=256 visible primitives, [1] + scaled shapes (Rearrange), [2] <=1024 (Collect), [3] <=1024 + scaled shapes (Hex*); the
         // small ones are built for 8 and for 6 waves per SIMD (64 / 80 VGPRs), MV_FAST_WAVES picks (two pixels per lane: 7 / 6 waves)
         static const int wavesSel = getenv("MV_FAST_WAVES") ? atoi(getenv("MV_FAST_WAVES")) : 8;
