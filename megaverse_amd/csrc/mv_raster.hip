@@ -1008,45 +1008,24 @@ __device__ __forceinline__ void box_test_g(const V3 (&inv)[NP], const float4 lo,
     }
 }
 
-// All boxes of list positions 64 k .. 64 k + 63 that survived the culling (mask mAll; m1 / m2 / m3: the ones that live in hex wall frame 0 / 1 / 2),
-// in list order, as ONE stream of scalar fetches with three records in flight: a fetch that misses the scalar cache takes ~250 cycles, a slab
-// test 50-100, so the depth -- not the test -- sets the pace (one run per frame of reference, each paying a full fetch for its first box, made
-// a 64 x 64 HexMemory tile cost ~5 us).  Which inverse direction a box is tested with is a scalar decision on its bit.
-template <int NP, bool HEXF>
-__device__ __forceinline__ void box_stream_g(unsigned long long mAll, unsigned long long m1, unsigned long long m2, unsigned long long m3, int k,
-                                             const V3 (&inv)[NP], const V3 (&ih0)[NP], const V3 (&ih1)[NP], const V3 (&ih2)[NP], cfloat *cp, Key2 (&best)[NP])
+// the boxes of one frame of reference among list positions 64 k .. 64 k + 63 (mask m): the next record is requested while the current one is tested
+template <int NP>
+__device__ __forceinline__ void box_run_g(unsigned long long m, int k, const V3 (&inv)[NP], cfloat *cp, Key2 (&best)[NP])
 {
-    if (!mAll) return;
-    int b0 = -1, b1 = -1, b2 = -1;
-    float4 lo0 = make_float4(0, 0, 0, 0), hi0 = lo0, lo1 = lo0, hi1 = lo0, lo2 = lo0, hi2 = lo0;
-#define MV_FETCH(B, LO, HI) { B = __ffsll((long long)mAll) - 1; mAll &= mAll - 1; LO = rec4(cp, 2 * (B + 64 * k)); HI = rec4(cp, 2 * (B + 64 * k) + 1); }
-#define MV_TEST(B, LO, HI)                                                                                          \
-    {                                                                                                               \
-        const unsigned long long bm = 1ull << B;                                                                    \
-        if (!HEXF || !(bm & (m1 | m2 | m3))) box_test_g<NP>(inv, LO, HI, B + 64 * k, best);                         \
-        else if (bm & m1) box_test_g<NP>(ih0, LO, HI, B + 64 * k, best);                                            \
-        else if (bm & m2) box_test_g<NP>(ih1, LO, HI, B + 64 * k, best);                                            \
-        else box_test_g<NP>(ih2, LO, HI, B + 64 * k, best);                                                         \
-    }
-    MV_FETCH(b0, lo0, hi0)
-    if (mAll) MV_FETCH(b1, lo1, hi1)
-    if (mAll) MV_FETCH(b2, lo2, hi2)
+    if (!m) return;
+    int p0 = __ffsll((long long)m) - 1 + 64 * k, p1 = 0;
+    m &= m - 1;
+    float4 lo0 = rec4(cp, 2 * p0), hi0 = rec4(cp, 2 * p0 + 1), lo1 = lo0, hi1 = hi0;
     for (;;) {
-        MV_TEST(b0, lo0, hi0)
-        b0 = -1;
-        if (mAll) MV_FETCH(b0, lo0, hi0)
-        if (b1 < 0) break;
-        MV_TEST(b1, lo1, hi1)
-        b1 = -1;
-        if (mAll) MV_FETCH(b1, lo1, hi1)
-        if (b2 < 0) break;
-        MV_TEST(b2, lo2, hi2)
-        b2 = -1;
-        if (mAll) MV_FETCH(b2, lo2, hi2)
-        if (b0 < 0) break;
+        bool more = m != 0ull;
+        if (more) { p1 = __ffsll((long long)m) - 1 + 64 * k; m &= m - 1; lo1 = rec4(cp, 2 * p1); hi1 = rec4(cp, 2 * p1 + 1); }
+        box_test_g<NP>(inv, lo0, hi0, p0, best);
+        if (!more) break;
+        more = m != 0ull;
+        if (more) { p0 = __ffsll((long long)m) - 1 + 64 * k; m &= m - 1; lo0 = rec4(cp, 2 * p0); hi0 = rec4(cp, 2 * p0 + 1); }
+        box_test_g<NP>(inv, lo1, hi1, p1, best);
+        if (!more) break;
     }
-#undef MV_FETCH
-#undef MV_TEST
 }
 
 template <int MAXVIS, bool SHAPES, bool HEXF, int NP>
@@ -1125,31 +1104,29 @@ __device__ __forceinline__ void raster_glist_body(const FastArgs &fa, uint32_t *
                 }
             }
             const unsigned cl = s_cls[cpos];
-            unsigned long long boxes = __ballot(v && cl == 0u), m1 = 0ull, m2 = 0ull, m3 = 0ull;
+            const unsigned long long m0 = __ballot(v && cl == 0u);
+            unsigned long long boxes = m0;
+            box_run_g<NP>(m0, k, inv, cp, best);
             if (HEXF) {
-                m1 = __ballot(v && cl == 1u); m2 = __ballot(v && cl == 2u); m3 = __ballot(v && cl == 3u);
+                const unsigned long long m1 = __ballot(v && cl == 1u), m2 = __ballot(v && cl == 2u), m3 = __ballot(v && cl == 3u);
+                box_run_g<NP>(m1, k, ih0, cp, best);
+                box_run_g<NP>(m2, k, ih1, cp, best);
+                box_run_g<NP>(m3, k, ih2, cp, best);
                 boxes |= m1 | m2 | m3;
             }
-            box_stream_g<NP, HEXF>(boxes, m1, m2, m3, k, inv, ih0, ih1, ih2, cp, best);
             unsigned long long rest = mvis & ~boxes;   // camera-attached boxes, capsules, cones, scaled shapes (and, not HEXF, wall-frame boxes)
-            if (rest) {   // (the next record is requested while the current primitive is intersected)
-                int pos = __ffsll((long long)rest) - 1 + 64 * k, pn = 0;
+            while (rest) {
+                const int pos = __ffsll((long long)rest) - 1 + 64 * k;
                 rest &= rest - 1;
-                float4 lo = rec4(cp, 2 * pos), hi = rec4(cp, 2 * pos + 1), lon = lo, hin = hi;
-                for (;;) {
-                    const bool more = rest != 0ull;
-                    if (more) { pn = __ffsll((long long)rest) - 1 + 64 * k; rest &= rest - 1; lon = rec4(cp, 2 * pn); hin = rec4(cp, 2 * pn + 1); }
+                const float4 lo = rec4(cp, 2 * pos), hi = rec4(cp, 2 * pos + 1);
 #pragma unroll
-                    for (int j = 0; j < NP; ++j) {
-                        V3 n = v3(0, 0, 0);
-                        float t;
-                        const bool hit = other_rec<SHAPES>(lo, hi, s_hdr, camv, viewer, dw[j], dcx, dcy[j], t, n);
-                        const unsigned d = __float_as_uint(t) - KEY_NEAR;
-                        const bool less = hit && (d < best[j].d || (d == best[j].d && (unsigned)pos < best[j].p));
-                        if (less) { best[j].d = d; best[j].p = (unsigned)pos; bn[j] = n; }
-                    }
-                    if (!more) break;
-                    pos = pn; lo = lon; hi = hin;
+                for (int j = 0; j < NP; ++j) {
+                    V3 n = v3(0, 0, 0);
+                    float t;
+                    const bool hit = other_rec<SHAPES>(lo, hi, s_hdr, camv, viewer, dw[j], dcx, dcy[j], t, n);
+                    const unsigned d = __float_as_uint(t) - KEY_NEAR;
+                    const bool less = hit && (d < best[j].d || (d == best[j].d && (unsigned)pos < best[j].p));
+                    if (less) { best[j].d = d; best[j].p = (unsigned)pos; bn[j] = n; }
                 }
             }
         }
