@@ -85,10 +85,6 @@ static_assert(PIPE_GROUPS == 3, "userMark events are created one by one in mv_cr
 struct mv_gym;
 struct mv_group {
     std::vector<mv_gym *> gyms;   // gyms[0] is the leader; empty once a member was closed
-    // the long-list observation launches of a call run on a stream of their own, beside the short-list ones on the caller's stream (each launch
-    // of a Mixed tick holds too few frames to fill the chip); both are ordered against the caller's stream by these events, once per call
-    hipStream_t auxStream = nullptr;
-    hipEvent_t auxGo = nullptr, auxDone = nullptr;
 };
 struct mv_gym {
     int device = 0;
@@ -1110,9 +1106,6 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
     }
     // ---- the caller's stream: per tick the step's outputs, then the observation pass
     if (own) HIP_TRY(hipStreamWaitEvent(L->stream, L->simDone, 0));
-    mv_group *grp = L->inGroup;
-    const bool useAux = n > 1 && render && allFast && grp && grp->auxStream && !evs[0];   // (profiled ticks stay on one stream: per-kernel intervals)
-    if (useAux) { HIP_TRY(hipEventRecord(grp->auxGo, L->stream)); HIP_TRY(hipStreamWaitEvent(grp->auxStream, grp->auxGo, 0)); }
     std::vector<PublishTo> pubs((size_t)n);
     std::vector<uint32_t *> obsPtrs((size_t)n);
     for (int j = 0; j < k; ++j) {
@@ -1126,8 +1119,7 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
         if (render) {
             const bool pubInRaster = own && allFast;
             if (n > 1 && allFast) {
-                if (launch_raster_union(&views[(size_t)j * n], obsPtrs.data(), pubInRaster ? pubs.data() : nullptr, n, L->w, L->h, L->stream, evs[j] ? evs[j][3] : nullptr,
-                                        useAux ? grp->auxStream : nullptr))
+                if (launch_raster_union(&views[(size_t)j * n], obsPtrs.data(), pubInRaster ? pubs.data() : nullptr, n, L->w, L->h, L->stream, evs[j] ? evs[j][3] : nullptr))
                     return fail("mv_step: observation size above 1024x1024");
             } else {
                 for (int i = 0; i < n; ++i)
@@ -1138,7 +1130,6 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
         }
         if (evs[j]) HIP_TRY(hipEventRecord(evs[j][4], L->stream));
     }
-    if (useAux) { HIP_TRY(hipEventRecord(grp->auxDone, grp->auxStream)); HIP_TRY(hipStreamWaitEvent(L->stream, grp->auxDone, 0)); }
     HIP_TRY(hipGetLastError());
     int rc = 0;
     std::string text;
@@ -1216,12 +1207,6 @@ int mv_group_create(mv_gym *const *gyms, int32_t n, mv_group **out)
     }
     mv_group *grp = new mv_group();
     grp->gyms.assign(gyms, gyms + n);
-    if (!(getenv("MV_GROUP_AUX_STREAM") && atoi(getenv("MV_GROUP_AUX_STREAM")) == 0)) {
-        const bool ok = hipStreamCreateWithFlags(&grp->auxStream, hipStreamNonBlocking) == hipSuccess &&
-                        hipEventCreateWithFlags(&grp->auxGo, hipEventDisableTiming) == hipSuccess &&
-                        hipEventCreateWithFlags(&grp->auxDone, hipEventDisableTiming) == hipSuccess;
-        if (!ok) { (void)hipGetLastError(); grp->auxStream = nullptr; }   // (without it the two launches simply share the caller's stream)
-    }
     for (int i = 0; i < n; ++i) {
         mv_gym *g = gyms[i];
         g->inGroup = grp;
@@ -1246,9 +1231,6 @@ int mv_group_destroy(mv_group *grp)
         (void)hipStreamSynchronize(L->stream);
         group_detach(L);
     }
-    if (grp->auxStream) { (void)hipStreamSynchronize(grp->auxStream); (void)hipStreamDestroy(grp->auxStream); }
-    if (grp->auxGo) (void)hipEventDestroy(grp->auxGo);
-    if (grp->auxDone) (void)hipEventDestroy(grp->auxDone);
     delete grp;
     return 0;
 }

@@ -18,8 +18,6 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
 
 // the fast observation pass of n gyms of one job (frame lists already built by their step kernels) with at most two launches; publish: n
 // entries or null; -1 if W / H / n are too large
-// longListStream != null: the long-list launch (Collect, Hex*) goes to that stream, the short-list one to `stream` (the caller orders both)
-int launch_raster_union(const GymView *views, uint32_t *const *obs, const PublishTo *publish, int n, int W, int H, hipStream_t stream, hipEvent_t between = nullptr,
-                        hipStream_t longListStream = nullptr);
+int launch_raster_union(const GymView *views, uint32_t *const *obs, const PublishTo *publish, int n, int W, int H, hipStream_t stream, hipEvent_t between = nullptr);
 
 }  // namespace mv

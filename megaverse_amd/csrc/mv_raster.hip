@@ -1231,8 +1231,7 @@ static int fast_split(int W, int H, int np, int frames, bool longList = false)
 // up to 1024 (Collect, HexMemory, HexExplore: the large variant with the wall-frame box runs; a Collect frame has no wall-frame boxes and
 // takes the same path as in its own variant: its world boxes through the box runs, its cones through the general loop).  Pixels are the ones
 // each gym's own launch produces, byte for byte (same per-pixel arithmetic; tests/test_multitask_gpu.py).
-int launch_raster_union(const GymView *views, uint32_t *const *obs, const PublishTo *publish, int n, int W, int H, hipStream_t stream, hipEvent_t between,
-                        hipStream_t longListStream)
+int launch_raster_union(const GymView *views, uint32_t *const *obs, const PublishTo *publish, int n, int W, int H, hipStream_t stream, hipEvent_t between)
 {
     if (W > MAX_W || H > MAX_H || n > MAX_UNION) return -1;
     const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)W * sizeof(float) + (size_t)H * sizeof(float2);
@@ -1257,10 +1256,9 @@ int launch_raster_union(const GymView *views, uint32_t *const *obs, const Publis
         }
         if (!ua.n) continue;
         for (int i = ua.n; i <= MAX_UNION; ++i) ua.first[i] = wgs;
-        if (large) {   // (on a stream of its own when the caller gave one: the two launches of a tick fill the chip together, each alone does not)
-            hipStream_t ls = longListStream ? longListStream : stream;
-            if (lnp == 2) hipLaunchKernelGGL((raster_glist_union_kernel<VIS_XL, true, GLIST_WAVES_NP2, true, 2>), dim3(wgs), dim3(256), dyn, ls, ua, W, H, split);
-            else hipLaunchKernelGGL((raster_glist_union_kernel<VIS_XL, true, GLIST_WAVES_NP1, true, 1>), dim3(wgs), dim3(256), dyn, ls, ua, W, H, split);
+        if (large) {
+            if (lnp == 2) hipLaunchKernelGGL((raster_glist_union_kernel<VIS_XL, true, GLIST_WAVES_NP2, true, 2>), dim3(wgs), dim3(256), dyn, stream, ua, W, H, split);
+            else hipLaunchKernelGGL((raster_glist_union_kernel<VIS_XL, true, GLIST_WAVES_NP1, true, 1>), dim3(wgs), dim3(256), dyn, stream, ua, W, H, split);
         } else {
             if (lnp == 2) hipLaunchKernelGGL((raster_fast_union_kernel<VIS_SMALL, true, 6, false, 2>), dim3(wgs), dim3(256), dyn, stream, ua, W, H, split);
             else hipLaunchKernelGGL((raster_fast_union_kernel<VIS_SMALL, true, 8, false, 1>), dim3(wgs), dim3(256), dyn, stream, ua, W, H, split);
