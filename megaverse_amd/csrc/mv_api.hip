@@ -110,6 +110,7 @@ struct mv_gym {
     bool simMustWaitUser = true;                 // the caller's stream holds work the next step depends on (reset, render, device actions, ...)
     hipEvent_t simDone = nullptr;                // after the last kernel on simStream
     bool simDoneValid = false;
+    std::vector<hipEvent_t> tickDone;            // a batched call that finds the caller's stream idle hands over tick by tick (created on first use)
     int batch = 8, slots = PIPE_GROUPS * 8, hists = PIPE_GROUPS * 8 + 1;   // slots per group (MV_PIPE_BATCH), slots, cost histograms
     int group = 0;                               // slot group of the last stepping call
     int parity = 0, hist3 = 0;                   // hand-over slot of the last tick; cost histogram of the last pass
@@ -637,6 +638,8 @@ int mv_close(mv_gym *g)
     if (g->copyStream) (void)hipStreamDestroy(g->copyStream);
     if (g->simStream) (void)hipStreamDestroy(g->simStream);
     for (hipEvent_t &e : g->userMark) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    for (hipEvent_t e : g->tickDone) (void)hipEventDestroy(e);
+    g->tickDone.clear();
     if (g->simDone) (void)hipEventDestroy(g->simDone);
     g->simStream = nullptr; g->simDone = nullptr;
     g->hBlobs = nullptr; g->hStatus = nullptr; g->resetDone = g->stepDone = g->statusCopied = nullptr; g->copyStream = nullptr; g->dBlobs = nullptr; g->dStatus = nullptr;
@@ -1054,6 +1057,21 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
         g->group = (g->group + 1) % PIPE_GROUPS;
     }
     const int fused = render ? 1 : 0;   // the step kernel also builds the frame lists when an observation pass follows
+    // A batched call normally hands over ONCE: all k step kernels, then all k observation passes.  That is right while the caller's stream
+    // still has the previous calls' passes to work off -- and wrong when it is idle (the first call after a synchronisation: the first pass
+    // would wait for k step kernels instead of one; on a 20-step run that is a fifth of the time).  An idle caller's stream gets the ticks one
+    // by one: tick j's pass waits for tick j's step kernel only.
+    bool fine = false;
+    if (own && k > 1 && render) {
+        fine = hipStreamQuery(L->stream) == hipSuccess;
+        (void)hipGetLastError();   // ("not ready" is an answer)
+        if (fine)
+            while ((int)L->tickDone.size() < k) {
+                hipEvent_t e;
+                HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                L->tickDone.push_back(e);
+            }
+    }
     std::vector<GymView> views((size_t)n * k);
     std::vector<OutPtrs> outs((size_t)n * k);
     hipEvent_t *evs[PIPE_BATCH_MAX];
@@ -1085,6 +1103,7 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
             launch_step_union(ua, sim, L->w, L->h, fused);
         }
         if (evs[j]) HIP_TRY(hipEventRecord(evs[j][1], sim));
+        if (fine) HIP_TRY(hipEventRecord(L->tickDone[j], sim));
     }
     if (own) HIP_TRY(hipEventRecord(L->simDone, sim));   // (not pipelined: stream order does it)
     // (every step kernel regenerates / swaps the next episode into the envs it finishes)
@@ -1105,10 +1124,11 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
         g->mirrorsFresh = false;
     }
     // ---- the caller's stream: per tick the step's outputs, then the observation pass
-    if (own) HIP_TRY(hipStreamWaitEvent(L->stream, L->simDone, 0));
+    if (own && !fine) HIP_TRY(hipStreamWaitEvent(L->stream, L->simDone, 0));
     std::vector<PublishTo> pubs((size_t)n);
     std::vector<uint32_t *> obsPtrs((size_t)n);
     for (int j = 0; j < k; ++j) {
+        if (fine) HIP_TRY(hipStreamWaitEvent(L->stream, L->tickDone[j], 0));
         if (evs[j]) HIP_TRY(hipEventRecord(evs[j][2], L->stream));
         for (int i = 0; i < n; ++i) {
             const OutPtrs &o = outs[(size_t)j * n + i];
