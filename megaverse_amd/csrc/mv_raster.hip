@@ -857,15 +857,20 @@ __device__ __forceinline__ void box_run(unsigned long long m, int k, const V3 (&
 // ballots, the scalar loop control, the LDS fetch of every surviving record and the column terms of the ray are paid once per two pixels,
 // and the two pixels' dependency chains (rcp -> slab test -> key, shading) interleave; per-pixel arithmetic is unchanged, and culling being
 // conservative the pixels are identical to NP = 1 (tests/test_fast_pixels_gpu.py: test_pixels_per_lane_variants_agree).
+// LDS of the two bodies below comes from their kernel (one buffer, carved here), so that a kernel which holds both (raster_union_all_kernel)
+// pays for the larger of the two, not for their sum
+constexpr int fast_lds_bytes(int maxvis) { return 40 * maxvis + 4 * FH_FLOATS; }    // records 32 B + rectangles 8 B per primitive, frame header
+constexpr int glist_lds_bytes(int maxvis) { return 9 * maxvis + 4 * FH_FLOATS; }    // rectangles 8 B + class 1 B per primitive, frame header
+
 template <int MAXVIS, bool SHAPES, bool HEXF, int NP>
-__device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *obs, int W, int H, int split, int blk)
+__device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *obs, int W, int H, int split, int blk, unsigned char *lds)
 {
     constexpr unsigned POS_MASK = MAXVIS - 1;
     constexpr int TH = TILE_H * NP;           // tile height
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
-    __shared__ float4 s_vis[2 * MAXVIS];      // Prim records as (lo, meta) (hi, colour)
-    __shared__ short4 s_rect[MAXVIS];
-    __shared__ __attribute__((aligned(16))) float s_hdr[FH_FLOATS];
+    float4 *s_vis = reinterpret_cast<float4 *>(lds);                  // [2 * MAXVIS] Prim records as (lo, meta) (hi, colour)
+    short4 *s_rect = reinterpret_cast<short4 *>(lds + 32 * MAXVIS);   // [MAXVIS]
+    float *s_hdr = reinterpret_cast<float *>(lds + 40 * MAXVIS);      // [FH_FLOATS]
     static_assert(MAXVIS / 64 <= 16, "world-box masks: 16 x 64 positions");
 
     float4 *s_col = reinterpret_cast<float4 *>(s_dyn);   // per column i: (dc.x, c00*dc.x, c10*dc.x, c20*dc.x)
@@ -1029,13 +1034,13 @@ __device__ __forceinline__ void box_run_g(unsigned long long m, int k, const V3 
 }
 
 template <int MAXVIS, bool SHAPES, bool HEXF, int NP>
-__device__ __forceinline__ void raster_glist_body(const FastArgs &fa, uint32_t *obs, int W, int H, int split, int blk)
+__device__ __forceinline__ void raster_glist_body(const FastArgs &fa, uint32_t *obs, int W, int H, int split, int blk, unsigned char *lds)
 {
     constexpr int TH = TILE_H * NP;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
-    __shared__ short4 s_rect[MAXVIS];
-    __shared__ unsigned char s_cls[MAXVIS];
-    __shared__ __attribute__((aligned(16))) float s_hdr[FH_FLOATS];
+    short4 *s_rect = reinterpret_cast<short4 *>(lds);                 // [MAXVIS]
+    float *s_hdr = reinterpret_cast<float *>(lds + 8 * MAXVIS);       // [FH_FLOATS]
+    unsigned char *s_cls = lds + 8 * MAXVIS + 4 * FH_FLOATS;          // [MAXVIS]
 
     float4 *s_col = reinterpret_cast<float4 *>(s_dyn);
     float4 *s_row = s_col + W;
@@ -1146,13 +1151,15 @@ __device__ __forceinline__ void raster_glist_body(const FastArgs &fa, uint32_t *
 template <int MAXVIS, bool SHAPES, int WAVES, bool HEXF, int NP>
 __global__ __launch_bounds__(256, WAVES) void raster_glist_kernel(FastArgs fa, uint32_t *obs, int W, int H, int split)
 {
-    raster_glist_body<MAXVIS, SHAPES, HEXF, NP>(fa, obs, W, H, split, (int)blockIdx.x);
+    __shared__ __attribute__((aligned(16))) unsigned char s_buf[glist_lds_bytes(MAXVIS)];
+    raster_glist_body<MAXVIS, SHAPES, HEXF, NP>(fa, obs, W, H, split, (int)blockIdx.x, s_buf);
 }
 
 template <int MAXVIS, bool SHAPES, int WAVES, bool HEXF = false, int NP = 1>   // WAVES: waves per SIMD the variant is compiled for (register budget 512 / WAVES)
 __global__ __launch_bounds__(256, WAVES) void raster_fast_kernel(FastArgs fa, uint32_t *obs, int W, int H, int split)
 {
-    raster_fast_body<MAXVIS, SHAPES, HEXF, NP>(fa, obs, W, H, split, (int)blockIdx.x);
+    __shared__ __attribute__((aligned(16))) unsigned char s_buf[fast_lds_bytes(MAXVIS)];
+    raster_fast_body<MAXVIS, SHAPES, HEXF, NP>(fa, obs, W, H, split, (int)blockIdx.x, s_buf);
 }
 
 // The observation pass of several gyms of one job with one launch (mv_group): workgroup b belongs to gym s with first[s] <= b < first[s + 1]
@@ -1172,7 +1179,8 @@ __global__ __launch_bounds__(256, WAVES) void raster_fast_union_kernel(UnionRast
 #pragma unroll
     for (int i = 1; i < MAX_UNION; ++i)
         if (i < ua.n && (int)blockIdx.x >= ua.first[i]) s = i;
-    raster_fast_body<MAXVIS, SHAPES, HEXF, NP>(ua.fa[s], ua.obs[s], W, H, split, (int)blockIdx.x - ua.first[s]);
+    __shared__ __attribute__((aligned(16))) unsigned char s_buf[fast_lds_bytes(MAXVIS)];
+    raster_fast_body<MAXVIS, SHAPES, HEXF, NP>(ua.fa[s], ua.obs[s], W, H, split, (int)blockIdx.x - ua.first[s], s_buf);
 }
 
 template <int MAXVIS, bool SHAPES, int WAVES, bool HEXF, int NP>
@@ -1182,7 +1190,33 @@ __global__ __launch_bounds__(256, WAVES) void raster_glist_union_kernel(UnionRas
 #pragma unroll
     for (int i = 1; i < MAX_UNION; ++i)
         if (i < ua.n && (int)blockIdx.x >= ua.first[i]) s = i;
-    raster_glist_body<MAXVIS, SHAPES, HEXF, NP>(ua.fa[s], ua.obs[s], W, H, split, (int)blockIdx.x - ua.first[s]);
+    __shared__ __attribute__((aligned(16))) unsigned char s_buf[glist_lds_bytes(MAXVIS)];
+    raster_glist_body<MAXVIS, SHAPES, HEXF, NP>(ua.fa[s], ua.obs[s], W, H, split, (int)blockIdx.x - ua.first[s], s_buf);
+}
+
+// Both list lengths in ONE launch: the short-list body (records in LDS) for the gyms with up to 256 visible primitives per frame, the long-list
+// body (records through the scalar cache) for the others; which one a workgroup runs is decided by its gym (`large` bit per gym).  Each of a
+// Mixed group's two launches holds too few frames to fill the chip and lasts as long as its heaviest frame: one launch fills it once and has
+// one tail.  The workgroups of the long-list gyms come first (the expensive frames).  split: per list length (a long-list frame is cut into
+// more pieces).
+struct UnionRasterAllArgs {
+    UnionRasterArgs u;
+    int32_t large[MAX_UNION];
+    int32_t split_small, split_large;
+};
+
+template <int WAVES, int NPS>
+__global__ __launch_bounds__(256, WAVES) void raster_union_all_kernel(UnionRasterAllArgs a, int W, int H)
+{
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_UNION; ++i)
+        if (i < a.u.n && (int)blockIdx.x >= a.u.first[i]) s = i;
+    constexpr int LDS = fast_lds_bytes(VIS_SMALL) > glist_lds_bytes(VIS_XL) ? fast_lds_bytes(VIS_SMALL) : glist_lds_bytes(VIS_XL);
+    __shared__ __attribute__((aligned(16))) unsigned char s_buf[LDS];
+    const int blk = (int)blockIdx.x - a.u.first[s];
+    if (a.large[s]) raster_glist_body<VIS_XL, true, true, 1>(a.u.fa[s], a.u.obs[s], W, H, a.split_large, blk, s_buf);
+    else raster_fast_body<VIS_SMALL, true, false, NPS>(a.u.fa[s], a.u.obs[s], W, H, a.split_small, blk, s_buf);
 }
 
 static FastArgs fast_args_of(const GymView &gv, const PublishTo *publish)
@@ -1239,6 +1273,29 @@ int launch_raster_union(const GymView *views, uint32_t *const *obs, const Publis
     int unionFrames[2] = {0, 0};
     for (int i = 0; i < n; ++i) unionFrames[views[i].vis_stride > VIS_SMALL ? 1 : 0] += views[i].num_envs * views[i].num_agents;
     if (between) (void)hipEventRecord(between, stream);
+    static const int oneLaunch = getenv("MV_UNION_ONE_LAUNCH") ? atoi(getenv("MV_UNION_ONE_LAUNCH")) : 1;
+    if (oneLaunch && unionFrames[0] > 0 && unionFrames[1] > 0) {   // both list lengths present: one launch for all gyms (raster_union_all_kernel)
+        UnionRasterAllArgs a;
+        a.u.n = 0;
+        a.split_small = fast_split(W, H, np, unionFrames[0] + unionFrames[1], false);
+        a.split_large = fast_split(W, H, 1, unionFrames[0] + unionFrames[1], true);
+        int wgs = 0;
+        for (int large = 1; large >= 0; --large)
+            for (int i = 0; i < n; ++i) {
+                if ((views[i].vis_stride > VIS_SMALL) != (large != 0)) continue;
+                a.u.first[a.u.n] = wgs;
+                a.u.obs[a.u.n] = obs[i];
+                a.u.fa[a.u.n] = fast_args_of(views[i], publish ? &publish[i] : nullptr);
+                a.large[a.u.n] = large;
+                wgs += views[i].num_envs * views[i].num_agents * (large ? a.split_large : a.split_small);
+                ++a.u.n;
+            }
+        for (int i = a.u.n; i <= MAX_UNION; ++i) a.u.first[i] = wgs;
+        for (int i = a.u.n; i < MAX_UNION; ++i) a.large[i] = 0;
+        if (np == 2) hipLaunchKernelGGL((raster_union_all_kernel<6, 2>), dim3(wgs), dim3(256), dyn, stream, a, W, H);
+        else hipLaunchKernelGGL((raster_union_all_kernel<8, 1>), dim3(wgs), dim3(256), dyn, stream, a, W, H);
+        return 0;
+    }
     for (int large = 1; large >= 0; --large) {   // the expensive frames first
         UnionRasterArgs ua;
         ua.n = 0;
