@@ -52,16 +52,7 @@ __device__ __forceinline__ bool test(const Bits128 &b, int y)
     if (i < 0 || i >= 128) return false;
     return i < 64 ? ((b.lo >> i) & 1ull) : ((b.hi >> (i - 64)) & 1ull);
 }
-__device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long m)
-{
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)m, off, 64);
-        const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(m >> 32), off, 64);
-        m |= ((unsigned long long)hi << 32) | lo;
-    }
-    return m;
-}
+// (wave_or_u64: mv_math.h, the DPP reduction)
 
 // placed movable boxes of column (x, z)
 __device__ __forceinline__ Bits128 column_objects(const Objs &o, int x, int z)

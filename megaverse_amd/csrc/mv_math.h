@@ -82,19 +82,42 @@ __device__ __forceinline__ void wave_sync()
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
-__device__ __forceinline__ float bcast_f(float v, int src_lane) { return __shfl(v, src_lane, 64); }
-__device__ __forceinline__ int bcast_i(int v, int src_lane) { return __shfl(v, src_lane, 64); }
-
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+// value of lane `src_lane`, which every caller passes wave-uniform (a lane found by a ballot, a loop counter): one v_readlane_b32 instead of
+// a ds_bpermute_b32 round trip through the LDS crossbar (~100 cycles on the tick's critical path, three to five of them per sweep)
+__device__ __forceinline__ float bcast_f(float v, int src_lane)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, off, 64);
-        const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), off, 64);
-        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-        v = (o < v) ? o : v;
-    }
-    return v;
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), __builtin_amdgcn_readfirstlane(src_lane)));
+}
+__device__ __forceinline__ int bcast_i(int v, int src_lane) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src_lane)); }
+
+// Wave-wide reductions over all 64 lanes (the callers run with a full exec mask) on the DPP path: within quads, within rows of 16 (rotations),
+// then across rows (row_bcast:15, row_bcast:31); lane 63 ends up with the result.  Six VALU steps of a few cycles each -- the __shfl_xor
+// butterfly they replace is six dependent LDS-crossbar round trips.  (old == src: a lane without a source for the row broadcasts keeps its value.)
+#define MV_DPP(v, ctrl) __builtin_amdgcn_update_dpp((int)(v), (int)(v), ctrl, 0xf, 0xf, false)
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+    v = min(v, (unsigned)MV_DPP(v, 0xb1));    // quad_perm:[1,0,3,2]
+    v = min(v, (unsigned)MV_DPP(v, 0x4e));    // quad_perm:[2,3,0,1]
+    v = min(v, (unsigned)MV_DPP(v, 0x124));   // row_ror:4
+    v = min(v, (unsigned)MV_DPP(v, 0x128));   // row_ror:8
+    v = min(v, (unsigned)MV_DPP(v, 0x142));   // row_bcast:15
+    v = min(v, (unsigned)MV_DPP(v, 0x143));   // row_bcast:31
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned wave_or_u32(unsigned v)
+{
+    v |= (unsigned)MV_DPP(v, 0xb1);
+    v |= (unsigned)MV_DPP(v, 0x4e);
+    v |= (unsigned)MV_DPP(v, 0x124);
+    v |= (unsigned)MV_DPP(v, 0x128);
+    v |= (unsigned)MV_DPP(v, 0x142);
+    v |= (unsigned)MV_DPP(v, 0x143);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+#undef MV_DPP
+__device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v)
+{
+    return ((unsigned long long)wave_or_u32((unsigned)(v >> 32)) << 32) | wave_or_u32((unsigned)v);
 }
 
 }  // namespace mv

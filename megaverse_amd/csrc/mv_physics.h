@@ -223,33 +223,40 @@ template <int NC, bool OBB = false>
 __device__ __forceinline__ bool sweep(const Col (&col)[NC], V3 from, V3 to, V3 up, float minSlopeDot, float &fraction,
                                       V3 &normal)
 {
-    const int lane = lane_id();
     const V3 d = to - from;
-    unsigned long long key = ~0ull;
+    unsigned fb[NC];   // hit fraction bits of this lane's collider k (a fraction is in [0, 1): its bits order like the value), ~0: no accepted hit
     V3 nn[NC];
 #pragma unroll
-    for (int k = 0; k < NC; ++k) nn[k] = v3(0, 0, 0);
+    for (int k = 0; k < NC; ++k) { nn[k] = v3(0, 0, 0); fb[k] = ~0u; }
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
         if (col[k].kind != 0 && cast_can_hit<OBB>(col[k], from, d)) {
             float f; V3 n;
             if (convex_cast<OBB>(col[k], from, d, f, n) && (len2(n) > 0.0001f) && (f < 1.0f) && !(dot(up, n) < minSlopeDot)) {
-                const unsigned long long kk = ((unsigned long long)__float_as_uint(f) << 32) | (unsigned)(lane + 64 * k);
-                key = kk < key ? kk : key;
+                fb[k] = __float_as_uint(f);
                 nn[k] = n;
             }
         }
     }
-    const unsigned long long win = wave_min_u64(key);
-    if (win == ~0ull) { fraction = 1.0f; return false; }
-    const int slot = (int)(win & 0xffffffffu);
-    const int src = slot & 63;
+    // the closest hit of the wave; ties resolve towards the lowest slot (slot = lane + 64 k: the serial order of the reference's callback):
+    // smallest fraction first (one DPP reduction), then the first k that holds it, then the first lane of that k (ballots)
+    unsigned mine = fb[0];
+#pragma unroll
+    for (int k = 1; k < NC; ++k) mine = min(mine, fb[k]);
+    const unsigned fmin = wave_min_u32(mine);
+    if (fmin == ~0u) { fraction = 1.0f; return false; }
+    int which = 0, src = 0;
+#pragma unroll
+    for (int k = NC - 1; k >= 0; --k) {
+        const unsigned long long m = __ballot(fb[k] == fmin);
+        if (m != 0ull) { which = k; src = __ffsll((long long)m) - 1; }
+    }
     V3 cand = nn[0];
 #pragma unroll
     for (int k = 1; k < NC; ++k)
-        if ((slot >> 6) == k) cand = nn[k];
+        if (which == k) cand = nn[k];
     normal = v3(bcast_f(cand.x, src), bcast_f(cand.y, src), bcast_f(cand.z, src));
-    fraction = __uint_as_float((unsigned)(win >> 32));
+    fraction = __uint_as_float(fmin);
     return true;
 }
 
@@ -284,7 +291,7 @@ __device__ __forceinline__ bool recover_from_penetration(const Col (&col)[NC], V
         if (which == k) { w = c[k]; kind = col[k].kind; }
     const float dist = bcast_f(w.dist, src), d = bcast_f(w.d, src);
     const V3 v = v3(bcast_f(w.v.x, src), bcast_f(w.v.y, src), bcast_f(w.v.z, src));
-    kind = __shfl(kind, src, 64);
+    kind = bcast_i(kind, src);
     const float inv = 1.0f / d;
     V3 n = v * inv;
     if (OBB && kind >= 3) n = hex_to_world(kind - 3, n);

@@ -250,9 +250,7 @@ __device__ __forceinline__ void hex_tick(const GymView &gv, const int env)
                 }
             }
             for (;;) {
-                unsigned m = min(key[0], key[1]);
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, off, 64));
+                const unsigned m = wave_min_u32(min(key[0], key[1]));
                 if (m == ~0u) break;
                 const int oi = (int)(m & 127u);
                 const int good = (__shfl(oi < 64 ? ometa[0] : ometa[1], oi & 63, 64) >> 4) & 1;

@@ -65,13 +65,7 @@ __device__ __forceinline__ unsigned long long column_objects(const ObjRegs &o, i
 #pragma unroll
     for (int k = 0; k < 2; ++k)
         if (o.valid[k] && o.state[k] == 0 && o.x[k] == x && o.z[k] == z && o.y[k] >= -32 && o.y[k] < 32) m |= 1ull << (o.y[k] + 32);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)m, off, 64);
-        const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(m >> 32), off, 64);
-        m |= ((unsigned long long)hi << 32) | lo;
-    }
-    return m;
+    return wave_or_u64(m);
 }
 
 // The fields of EnvHeader a tick reads or writes, as scalars.  Copying the whole 128-byte record made
