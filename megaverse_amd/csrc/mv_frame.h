@@ -79,6 +79,9 @@ __device__ __forceinline__ V3 mat_tmul(const float *m, V3 v)
 // the plane (the floor under the viewer, a wall beside it): the corners in front plus the points where the 12
 // edges pierce the plane -- the convex hull of those is the clipped box, so its projection is bounded by theirs.
 //   returns 0: nothing in front of the plane, 1: rect valid (pixels, one pixel of slack on every side)
+// The rectangle only ever CULLS (both raster kernels intersect every primitive whose rectangle meets a tile; the pixels do not depend on it
+// beyond that), and it carries a pixel of slack: its up to twenty reciprocals are the hardware's 1-ulp v_rcp_f32, not correctly rounded
+// divides (each a chain of ~12 dependent instructions on the step kernel's critical path).
 __device__ __forceinline__ int screen_rect(const float *blo, const float *bhi, int fr, const CamL *cams, int viewer, int W, int H,
                                            int rect[4])
 {
@@ -102,7 +105,7 @@ __device__ __forceinline__ int screen_rect(const float *blo, const float *bhi, i
 #pragma unroll
     for (int c = 0; c < 8; ++c)
         if (cw[c] >= CLIP_W) {
-            const float iw = 1.0f / cw[c];
+            const float iw = __builtin_amdgcn_rcpf(cw[c]);
             const float xn = cx[c] * iw, yn = cy[c] * iw;
             xmin = fminf(xmin, xn); xmax = fmaxf(xmax, xn); ymin = fminf(ymin, yn); ymax = fmaxf(ymax, yn);
         }
@@ -114,7 +117,7 @@ __device__ __forceinline__ int screen_rect(const float *blo, const float *bhi, i
                 const int d = c | (1 << axis);
                 if (d == c) continue;
                 if ((cw[c] >= CLIP_W) != (cw[d] >= CLIP_W)) {
-                    const float t = (CLIP_W - cw[c]) / (cw[d] - cw[c]);
+                    const float t = (CLIP_W - cw[c]) * __builtin_amdgcn_rcpf(cw[d] - cw[c]);
                     const float xn = (cx[c] + t * (cx[d] - cx[c])) * (1.0f / CLIP_W), yn = (cy[c] + t * (cy[d] - cy[c])) * (1.0f / CLIP_W);
                     xmin = fminf(xmin, xn); xmax = fmaxf(xmax, xn); ymin = fminf(ymin, yn); ymax = fmaxf(ymax, yn);
                 }
