@@ -897,33 +897,18 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
         const int tx1 = min(tx0 + TILE_W, W) - 1, ty1 = min(ty0 + TH, H) - 1;
         const int px = tx0 + lx, py0 = ty0 + ly;
         const int pxc = min(px, W - 1);
-        // LEAN (two pixels per lane): only the inverse direction, the best key and the kept normal live across the primitive loop; the ray
-        // direction and the per-row shading constants are re-derived from the LDS tables where they are needed (shading; the rare primitives
-        // that are not world-frame boxes) -- 12 VGPRs less, which is the difference between 7 and 8 waves per SIMD
-        constexpr bool LEAN = NP > 1;
-        static_assert(!HEXF, "wall-frame boxes: the long-list variant (raster_glist_body)");
         V3 dw[NP], inv[NP];
+        V3 ih0[NP], ih1[NP], ih2[NP];   // HEXF: the ray's inverse direction in wall frames 0, 1, 2
         float dcx = 0.0f, dcy[NP], a2[NP], ldc[NP];
         unsigned best[NP];
         V3 bn[NP];                       // normal of the best hit when it is not a box (boxes recover theirs from the entry axis)
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             dw[j] = inv[j] = bn[j] = v3(0, 0, 0);
+            ih0[j] = ih1[j] = ih2[j] = v3(0, 0, 0);
             dcy[j] = a2[j] = ldc[j] = 0.0f;
             best[j] = ~0u;
         }
-        // pixel j's ray direction (bit-identical to the exact kernel's) and, WITH_Q, its shading constants, from the column / row tables
-        auto ray_of = [&](int j, V3 &dwj, float &dcxj, float &dcyj, float &a2j, float &ldcj, bool with_q) {
-            const int pyc = min(py0 + TILE_H * j, H - 1);
-            lds_float *c = local_lds(reinterpret_cast<const float *>(s_col + pxc)), *r = local_lds(reinterpret_cast<const float *>(s_row + pyc));
-            const float4 cx = make_float4(c[0], c[1], c[2], c[3]), ry = make_float4(r[0], r[1], r[2], r[3]);   // (one ds_read_b128 each)
-            dcxj = cx.x; dcyj = ry.x;
-            dwj = v3((cx.y + ry.y) + nzm0, (cx.z + ry.z) + nzm1, (cx.w + ry.w) + nzm2);
-            if (with_q) {
-                lds_float *q = local_lds(reinterpret_cast<const float *>(s_rowq + pyc));
-                a2j = *local_lds(s_colq + pxc) + q[0]; ldcj = q[1];
-            }
-        };
         bool rayReady = false;   // wave-uniform: the rays are set up when the first primitive survives the culling
 #pragma unroll 1
         for (int k = 0; k * 64 < nVis; ++k) {
@@ -936,33 +921,44 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
             if (mvis == 0ull) continue;
             if (!rayReady) {
                 rayReady = true;
-                if (LEAN) {
+                const float4 cx = s_col[pxc];
+                const float cq = s_colq[pxc];
+                dcx = cx.x;
 #pragma unroll
-                    for (int j = 0; j < NP; ++j) {
-                        V3 d; float x, y, q0 = 0.0f, q1 = 0.0f;
-                        ray_of(j, d, x, y, q0, q1, false);
-                        inv[j] = v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-                    }
-                } else {
-                    const float4 cx = s_col[pxc];
-                    const float cq = s_colq[pxc];
-                    dcx = cx.x;
-#pragma unroll
-                    for (int j = 0; j < NP; ++j) {
-                        const int pyc = min(py0 + TILE_H * j, H - 1);
-                        const float4 ry = s_row[pyc];
-                        const float2 rq = s_rowq[pyc];
-                        dcy[j] = ry.x;
-                        dw[j] = v3((cx.y + ry.y) + nzm0, (cx.z + ry.z) + nzm1, (cx.w + ry.w) + nzm2);
-                        inv[j] = v3(__builtin_amdgcn_rcpf(dw[j].x), __builtin_amdgcn_rcpf(dw[j].y), __builtin_amdgcn_rcpf(dw[j].z));
-                        a2[j] = cq + rq.x; ldc[j] = rq.y;
+                for (int j = 0; j < NP; ++j) {
+                    const int pyc = min(py0 + TILE_H * j, H - 1);
+                    const float4 ry = s_row[pyc];
+                    const float2 rq = s_rowq[pyc];
+                    dcy[j] = ry.x;
+                    dw[j] = v3((cx.y + ry.y) + nzm0, (cx.z + ry.z) + nzm1, (cx.w + ry.w) + nzm2);
+                    inv[j] = v3(__builtin_amdgcn_rcpf(dw[j].x), __builtin_amdgcn_rcpf(dw[j].y), __builtin_amdgcn_rcpf(dw[j].z));
+                    a2[j] = cq + rq.x; ldc[j] = rq.y;
+                    if (HEXF) {   // (same products and sums as mat_tmul with the frame's matrix: c x + (-s) z, s x + c z)
+                        const float cx8 = 0.8660254f * dw[j].x, cz8 = 0.8660254f * dw[j].z, hx5 = 0.5f * dw[j].x, hz5 = 0.5f * dw[j].z;
+                        ih0[j] = v3(__builtin_amdgcn_rcpf(cx8 - hz5), inv[j].y, __builtin_amdgcn_rcpf(hx5 + cz8));
+                        ih1[j] = v3(__builtin_amdgcn_rcpf(cx8 + hz5), inv[j].y, __builtin_amdgcn_rcpf(cz8 - hx5));
+                        ih2[j] = v3(0.0f - inv[j].z, inv[j].y, inv[j].x);   // 90 degrees: (x, z) -> (-z, x)
                     }
                 }
             }
-            // ---- world-frame boxes (a bit mask from the frame header): the next record is fetched from LDS while the current one is intersected
-            const unsigned long long wb = uniform_u64(*reinterpret_cast<const unsigned long long *>(s_hdr + FH_WB + 2 * k));
-            box_run<POS_MASK, NP>(mvis & wb, k, inv, s_vis, best);
-            unsigned long long rest = mvis & ~wb;
+            unsigned long long rest;
+            if (HEXF) {
+                const unsigned ml = __float_as_uint(s_vis[2 * cpos].w);   // this lane's primitive: kind | frame << 4 | slot << 8
+                const bool box = v && (ml & 15u) == (unsigned)PRIM_BOX;
+                const unsigned fl = (ml >> 4) & 15u;
+                const unsigned long long m0 = __ballot(box && fl == 0u), m1 = __ballot(box && fl == (unsigned)MAX_AGENTS + 1u),
+                                         m2 = __ballot(box && fl == (unsigned)MAX_AGENTS + 2u), m3 = __ballot(box && fl == (unsigned)MAX_AGENTS + 3u);
+                box_run<POS_MASK, NP>(m0, k, inv, s_vis, best);
+                box_run<POS_MASK, NP>(m1, k, ih0, s_vis, best);
+                box_run<POS_MASK, NP>(m2, k, ih1, s_vis, best);
+                box_run<POS_MASK, NP>(m3, k, ih2, s_vis, best);
+                rest = mvis & ~(m0 | m1 | m2 | m3);
+            } else {
+                // ---- world-frame boxes (a bit mask from the frame header): the next record is fetched from LDS while the current one is intersected
+                const unsigned long long wb = uniform_u64(*reinterpret_cast<const unsigned long long *>(s_hdr + FH_WB + 2 * k));
+                box_run<POS_MASK, NP>(mvis & wb, k, inv, s_vis, best);
+                rest = mvis & ~wb;
+            }
             // ---- everything else: camera-attached boxes, capsules, cones, scaled shapes
             while (rest) {
                 const int pos = __ffsll((long long)rest) - 1 + 64 * k;
@@ -970,20 +966,14 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
 #pragma unroll
                 for (int j = 0; j < NP; ++j) {
                     V3 n = v3(0, 0, 0);
-                    V3 dwj = dw[j];
-                    float dcxj = dcx, dcyj = dcy[j], q0 = 0.0f, q1 = 0.0f;
-                    if (LEAN) ray_of(j, dwj, dcxj, dcyj, q0, q1, false);
-                    const unsigned key = fast_other<SHAPES, POS_MASK>(pos, s_vis, s_hdr, camv, viewer, dwj, dcxj, dcyj, n);
+                    const unsigned key = fast_other<SHAPES, POS_MASK>(pos, s_vis, s_hdr, camv, viewer, dw[j], dcx, dcy[j], n);
                     if (key < best[j]) { best[j] = key; bn[j] = n; }
                 }
             }
         }
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
-            V3 dwj = dw[j];
-            float dcxj = dcx, dcyj = dcy[j], a2j = a2[j], ldcj = ldc[j];
-            if (LEAN) ray_of(j, dwj, dcxj, dcyj, a2j, ldcj, true);
-            const unsigned rgba = fast_shade<SHAPES, POS_MASK>(best[j], bn[j], s_vis, s_hdr, camv, viewer, dwj, inv[j], dcxj, dcyj, a2j, ldcj);
+            const unsigned rgba = fast_shade<SHAPES, POS_MASK>(best[j], bn[j], s_vis, s_hdr, camv, viewer, dw[j], inv[j], dcx, dcy[j], a2[j], ldc[j]);
             const int py = py0 + TILE_H * j;
             if (px < W && py < H) out[(unsigned)(py * W + px)] = rgba;   // (32-bit offset from the frame's base: scalar-base addressing)
         }
@@ -1359,7 +1349,7 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
         if (np == 2)   // (the small variants: 72 VGPRs / 7 waves, 80 / 6; at 64 they would spill)
             fn = hexScen ? raster_glist_kernel<VIS_XL, true, GLIST_WAVES_NP2, true, 2> : gv.vis_stride > VIS_SMALL ? raster_glist_kernel<VIS_LARGE, false, GLIST_WAVES_NP2, false, 2>
                : gv.scenario == SCN_REARRANGE ? raster_fast_kernel<VIS_SMALL, true, 6, false, 2>   // (with the scaled shapes 72 VGPRs would spill)
-                                              : (wavesSel >= 7 ? raster_fast_kernel<VIS_SMALL, false, 8, false, 2> : raster_fast_kernel<VIS_SMALL, false, 7, false, 2>);
+                                              : (wavesSel >= 7 ? raster_fast_kernel<VIS_SMALL, false, 7, false, 2> : raster_fast_kernel<VIS_SMALL, false, 6, false, 2>);
         else
             fn = hexScen ? raster_glist_kernel<VIS_XL, true, GLIST_WAVES_NP1, true, 1> : gv.vis_stride > VIS_SMALL ? raster_glist_kernel<VIS_LARGE, false, GLIST_WAVES_NP1, false, 1>
                : gv.scenario == SCN_REARRANGE ? (wavesSel >= 8 ? raster_fast_kernel<VIS_SMALL, true, 8> : raster_fast_kernel<VIS_SMALL, true, 6>)
