@@ -195,7 +195,7 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
         cam.origin[0] = cam.origin[1] = cam.origin[2] = 0.0f;
         s_cam[tid] = cam;
     }
-    const int scen = uload(&hdr->scenario);   // (uload: per-env record fields on the vector path, mv_math.h)
+    const int scen = hdr->scenario;
     const bool hex = scen == SCN_HEX_MEMORY || scen == SCN_HEX_EXPLORE;
     if (hex && tid >= MAX_AGENTS && tid < MAX_CAMS) s_cam[tid] = hex_frame(tid - MAX_AGENTS);
     sync();
@@ -208,16 +208,15 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
     // ---- primitive slots, packed (slot order == the order the reference emits drawables == depth-tie order):
     //   layout slabs | terrain slabs (TowerBuilding: the building zone; Rearrange: static boxes + target items) | movable boxes / items
     //   | 2 cones per diamond | 3 per agent
-    const int nLayout = uload(&hdr->num_boxes);
+    const int nLayout = hdr->num_boxes;
     const bool rearrange = scen == SCN_REARRANGE;   // its "terrain" slots: 9 static boxes, then the target arrangement's items
     const bool sokoban = scen == SCN_SOKOBAN;       // its "terrain" slots: one per level cell (wall cap / goal pad / nothing), x-major
-    const int sokoW = sokoban ? max(uload(&hdr->W), 1) : 1;
-    const int hNumTerrain = uload(&hdr->num_terrain), hNumObjects = uload(&hdr->num_objects), hNumRewards = uload(&hdr->num_rewards);
-    const int slotTerrain = nLayout, nTerrainSlots = scen == SCN_TOWER ? 1 : rearrange ? NUM_STATIC + hNumTerrain
-                                                   : sokoban ? uload(&hdr->L) * sokoW : hex ? 0 : hNumTerrain;
+    const int sokoW = sokoban ? max(hdr->W, 1) : 1;
+    const int slotTerrain = nLayout, nTerrainSlots = scen == SCN_TOWER ? 1 : rearrange ? NUM_STATIC + hdr->num_terrain
+                                                   : sokoban ? hdr->L * sokoW : hex ? 0 : hdr->num_terrain;
     const int slotObjects = slotTerrain + nTerrainSlots;
     // (Hex*: layout slots = the maze's boxes, no terrain / movable boxes, three slots per collectable: a pillar is three cylinders)
-    const int slotRewards = slotObjects + hNumObjects, nRewardSlots = scen == SCN_TOWER ? 0 : hex ? 3 * hNumRewards : 2 * hNumRewards;
+    const int slotRewards = slotObjects + hdr->num_objects, nRewardSlots = scen == SCN_TOWER ? 0 : hex ? 3 * hdr->num_rewards : 2 * hdr->num_rewards;
     const int slotAgents = slotRewards + nRewardSlots;
     const int numSlots = slotAgents + 3 * A;
     const LayoutBox *gboxes = gv.boxes + (size_t)env * gv.box_stride;
@@ -248,7 +247,7 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
                     if (sokoban) {   // addBoundingBoxes scales by the voxel size, 2 (layout_utils.cpp:22-34, scenario_sokoban.cpp:104-120)
                         lo[0] *= 2.0f; lo[1] *= 2.0f; lo[2] *= 2.0f; hi[0] *= 2.0f; hi[1] *= 2.0f; hi[2] *= 2.0f;
                     }
-                    color = (unsigned)(b.slot == 0 ? *vector_path(&hdr->layout_color) : *vector_path(&hdr->wall_color));
+                    color = (unsigned)(b.slot == 0 ? hdr->layout_color : hdr->wall_color);
                 }
             } else if (slot < slotObjects) {
                 if (rearrange) {
@@ -283,9 +282,8 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
                     }
                 } else if (scen == SCN_TOWER) {   // building-zone slab (layout_utils.cpp:53-68)
                     kind = PRIM_BOX;
-                    const int *bz = vector_path(&hdr->bz[0]);
-                    lo[0] = float(bz[0]); lo[1] = 1.0f; lo[2] = float(bz[2]);
-                    hi[0] = float(bz[1]); hi[1] = 1.0f + 0.05f; hi[2] = float(bz[3]);
+                    lo[0] = float(hdr->bz[0]); lo[1] = 1.0f; lo[2] = float(hdr->bz[2]);
+                    hi[0] = float(hdr->bz[1]); hi[1] = 1.0f + 0.05f; hi[2] = float(hdr->bz[3]);
                     color = 0x555555u;
                 } else {                   // exit pad / lava: 0.05-thick slab on the box's floor
                     const TerrainBox t = gv.terrain[(size_t)env * MAX_TERRAIN + (slot - slotTerrain)];
@@ -379,7 +377,7 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
                     hi[0] = 0.25f; hi[1] = 0.12f; hi[2] = -0.19f + 0.2f;
                     color = 0x2c3e50u;
                 } else if (part == 2) {
-                    const float bw = *vector_path(&hdr->bar_half_width);
+                    const float bw = hdr->bar_half_width;
                     kind = PRIM_BOX; fr = 1 + k;
                     lo[0] = -bw; lo[1] = -0.131f - 0.0015f; lo[2] = -0.2f - 0.001f;
                     hi[0] = bw; hi[1] = -0.131f + 0.0015f; hi[2] = -0.2f + 0.001f;

@@ -68,9 +68,6 @@ __device__ __forceinline__ T *vector_path(T *p)
     asm volatile("" : "+v"(p));
     return p;
 }
-// one field of a per-env record: fetched on the vector path, handed back wave-uniform (an SGPR: loop bounds and branches on it stay scalar)
-__device__ __forceinline__ int uload(const int *p) { return __builtin_amdgcn_readfirstlane(*vector_path(p)); }
-__device__ __forceinline__ float uload(const float *p) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(*vector_path(p)))); }
 
 // ---- wave64 helpers ------------------------------------------------------------------------
 // Ordering point for LDS / global traffic ONE wavefront exchanges between its own lanes: what __syncthreads() is to a one-wave

@@ -111,13 +111,11 @@ __device__ __forceinline__ void tower_tick(const GymView &gv, const int env)
 
     const EnvHeader *gh = gv.hdr + env;
     Hdr h;
-    // (uload: the vector path.  The env's header has a wave-uniform address, which hipcc would fetch with s_load -- and a thousand waves each
-    // missing the scalar cache on a private record queue up behind each other: mv_math.h)
-    h.num_objects = uload(&gh->num_objects); h.num_boxes = uload(&gh->num_boxes); h.num_frames = uload(&gh->num_frames); h.done = uload(&gh->done);
-    h.highest_tower = uload(&gh->highest_tower);
-    h.bz0 = uload(&gh->bz[0]); h.bz1 = uload(&gh->bz[1]); h.bz2 = uload(&gh->bz[2]); h.bz3 = uload(&gh->bz[3]);
-    h.episode_sec = uload(&gh->episode_sec); h.episode_len = uload(&gh->episode_len); h.bz_reward = uload(&gh->bz_reward);
-    h.bar_half_width = uload(&gh->bar_half_width); h.p_vertical_look_limit = uload(&gh->p_vertical_look_limit);
+    h.num_objects = gh->num_objects; h.num_boxes = gh->num_boxes; h.num_frames = gh->num_frames; h.done = gh->done;
+    h.highest_tower = gh->highest_tower;
+    h.bz0 = gh->bz[0]; h.bz1 = gh->bz[1]; h.bz2 = gh->bz[2]; h.bz3 = gh->bz[3];
+    h.episode_sec = gh->episode_sec; h.episode_len = gh->episode_len; h.bz_reward = gh->bz_reward;
+    h.bar_half_width = gh->bar_half_width; h.p_vertical_look_limit = gh->p_vertical_look_limit;
     uint8_t *chunk = gv.chunk + (size_t)env * CHUNK_BYTES;
     auto vox = [&](int x, int y, int z) -> unsigned { return in_chunk(x, y, z) ? (unsigned)chunk[(y * CZ + z) * CX + x] : 0u; };
 
