@@ -890,6 +890,14 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
     const int numTiles = tilesX * tilesY;
     const int lx = lane & (TILE_W - 1), ly = lane / TILE_W;
 
+    // What the first round of 64 list positions needs is the same for every tile of the frame: this lane's primitive's rectangle and the
+    // world-box mask stay in registers (two VGPRs, two SGPRs) instead of costing two dependent LDS round trips per tile (most frames of the
+    // short-list scenarios hold fewer than 64 visible primitives: their only round)
+    // (the rectangle only in the one-pixel build: the two-pixel one has no VGPRs to spare at 7 waves per SIMD)
+    uint2 rr0 = make_uint2(0u, 0u);
+    if (NP == 1) rr0 = *reinterpret_cast<const uint2 *>(&s_rect[min(lane, max(nVis - 1, 0))]);
+    const unsigned long long wb0 = uniform_u64(*reinterpret_cast<const unsigned long long *>(s_hdr + FH_WB));
+
     int tx = part * 4 + wave, ty = 0;   // tile = ty * tilesX + tx, advanced without a division
     for (int tile = part * 4 + wave; tile < numTiles; tile += 4 * split, tx += 4 * split) {
         while (tx >= tilesX) { tx -= tilesX; ++ty; }
@@ -914,7 +922,7 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
         for (int k = 0; k * 64 < nVis; ++k) {
             // ---- tile culling: one primitive per lane, four integer compares against its screen rectangle
             const int cpos = min(lane + 64 * k, nVis - 1);
-            const uint2 rr = *reinterpret_cast<const uint2 *>(&s_rect[cpos]);   // one 8-byte read; x0 | x1 << 16, y0 | y1 << 16 (all >= 0)
+            const uint2 rr = (NP == 1 && k == 0) ? rr0 : *reinterpret_cast<const uint2 *>(&s_rect[cpos]);   // one 8-byte read; x0 | x1 << 16, y0 | y1 << 16 (all >= 0)
             const bool v = (lane + 64 * k < nVis) & ((int)(rr.x & 0xffffu) <= tx1) & ((int)(rr.x >> 16) >= tx0) & ((int)(rr.y & 0xffffu) <= ty1) &
                            ((int)(rr.y >> 16) >= ty0);
             const unsigned long long mvis = __ballot(v);
@@ -955,7 +963,7 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
                 rest = mvis & ~(m0 | m1 | m2 | m3);
             } else {
                 // ---- world-frame boxes (a bit mask from the frame header): the next record is fetched from LDS while the current one is intersected
-                const unsigned long long wb = uniform_u64(*reinterpret_cast<const unsigned long long *>(s_hdr + FH_WB + 2 * k));
+                const unsigned long long wb = k == 0 ? wb0 : uniform_u64(*reinterpret_cast<const unsigned long long *>(s_hdr + FH_WB + 2 * k));
                 box_run<POS_MASK, NP>(mvis & wb, k, inv, s_vis, best);
                 rest = mvis & ~wb;
             }
