@@ -167,8 +167,10 @@ class ObsGather:
     slab; before slab b is rendered into again the compute stream waits for its gather.  CPU / gloo (dry run): same bookkeeping
     with async work handles."""
 
-    def __init__(self, dist, torch, local_shape, world, device, cuda):
-        self.dist, self.torch, self.cuda = dist, torch, cuda
+    def __init__(self, dist, torch, local_shape, world, device, cuda, mode="allgather"):
+        self.dist, self.torch, self.cuda, self.mode, self.world = dist, torch, cuda, mode, world
+        self.rank = dist.get_rank() if world > 1 else 0
+        self.n_local = local_shape[0]
         self.local = [torch.zeros(local_shape, dtype=torch.uint8, device=device) for _ in range(2)]
         self.out = [torch.zeros((world * local_shape[0],) + tuple(local_shape[1:]), dtype=torch.uint8, device=device) for _ in range(2)]
         self.work = [None, None]
@@ -183,8 +185,24 @@ class ObsGather:
             if self.gathered[b] is not None:
                 self.torch.cuda.current_stream().wait_event(self.gathered[b])
         elif self.work[b] is not None:
-            self.work[b].wait()
+            for w in self.work[b]:
+                w.wait()
             self.work[b] = None
+
+    def _collective(self, b):
+        """all_gather_into_tensor (RCCL picks the algorithm: a ring is bound by ONE xGMI link), or -- mode "p2p" -- the direct shape SURVEY.md
+        8e asks for: every GPU sends its shard to each of its peers and receives theirs, one grouped batch of point-to-point operations
+        (ncclGroupStart / ncclSend / ncclRecv under RCCL), so that all 7 links of the fully connected node carry one shard each"""
+        if self.mode != "p2p":
+            return [self.dist.all_gather_into_tensor(self.out[b], self.local[b], async_op=True)]
+        n, out = self.n_local, self.out[b]
+        out[self.rank * n:(self.rank + 1) * n].copy_(self.local[b], non_blocking=True)
+        ops = []
+        for k in range(1, self.world):   # (staggered peers: rank r sends to r + k while it receives from r - k)
+            to, frm = (self.rank + k) % self.world, (self.rank - k) % self.world
+            ops.append(self.dist.P2POp(self.dist.isend, self.local[b], to))
+            ops.append(self.dist.P2POp(self.dist.irecv, out[frm * n:(frm + 1) * n], frm))
+        return self.dist.batch_isend_irecv(ops)
 
     def after_render(self, b):
         if self.cuda:
@@ -192,13 +210,13 @@ class ObsGather:
             self.rendered[b].record(cur)
             with self.torch.cuda.stream(self.comm):
                 self.comm.wait_event(self.rendered[b])
-                w = self.dist.all_gather_into_tensor(self.out[b], self.local[b], async_op=True)
-                w.wait()   # orders the communication stream after the collective; the host does not block
+                for w in self._collective(b):
+                    w.wait()   # orders the communication stream after the collective; the host does not block
                 ev = self.torch.cuda.Event()
                 ev.record(self.comm)
                 self.gathered[b] = ev
         else:
-            self.work[b] = self.dist.all_gather_into_tensor(self.out[b], self.local[b], async_op=True)
+            self.work[b] = self._collective(b)
 
     def drain(self):
         if self.cuda:
@@ -206,7 +224,8 @@ class ObsGather:
         else:
             for b in range(2):
                 if self.work[b] is not None:
-                    self.work[b].wait()
+                    for w in self.work[b]:
+                        w.wait()
                     self.work[b] = None
 
 
@@ -234,6 +253,9 @@ def main():
                     help="TowerBuilding (headline), Obstacles{Easy,Medium,Hard,Walls,Steps,Lava}, Collect, Rearrange, Sokoban, HexMemory, HexExplore, Empty, or Mixed (configs[4])")
     ap.add_argument("--obs", type=int, nargs=2, default=[128, 128], metavar=("W", "H"))
     ap.add_argument("--no-gather-obs", action="store_true", help="N>1: skip the gather-on leg (value = the no-gather rate)")
+    ap.add_argument("--gather", default="allgather", choices=["allgather", "p2p"],
+                    help="N>1: how the observation slabs are assembled: one all_gather_into_tensor (RCCL's choice of algorithm) or grouped point-to-point "
+                         "sends / receives, one shard per peer link (the fully connected xGMI shape)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pixels", default="fast", choices=["fast", "exact"], help="observation arithmetic (DESIGN.md 'pixel tolerance')")
     ap.add_argument("--policy", default="multidiscrete", choices=["multidiscrete", "single-bit"],
@@ -306,7 +328,7 @@ def main():
         gym.set_sample_policy(args.policy)
 
     do_gather = world > 1 and not args.no_gather_obs
-    gather = ObsGather(dist, torch, (frames, H, W, 4), world, "cpu" if single else device, cuda=not dry and not single) if world > 1 else None
+    gather = ObsGather(dist, torch, (frames, H, W, 4), world, "cpu" if single else device, cuda=not dry and not single, mode=args.gather) if world > 1 else None
     if gather and single:   # the gym renders into device slabs; their host copies are what gloo gathers
         slabs = [torch.zeros((frames, H, W, 4), dtype=torch.uint8, device=device) for _ in range(2)]
     else:
@@ -516,7 +538,8 @@ def main():
             slab_bytes = frames * H * W * 4
             line["value_no_gather"] = total_obs / elapsed_no_gather
             line["ms_per_step_no_gather"] = elapsed_no_gather / args.steps * 1e3
-            line["gather"] = {"collective": "all_gather_into_tensor (RCCL), double-buffered on a communication stream",
+            line["gather"] = {"collective": ("all_gather_into_tensor (RCCL)" if args.gather == "allgather" else "grouped isend / irecv, one shard per peer (RCCL point-to-point)") +
+                                            ", double-buffered on a communication stream",
                               "bytes_received_per_gpu_per_step": (world - 1) * slab_bytes,
                               "achieved_GBps_per_gpu": (world - 1) * slab_bytes / (elapsed / args.steps) / 1e9,
                               "xgmi_peak_GBps_per_gpu": XGMI_PEAK_GBS,

@@ -306,8 +306,8 @@ template <int NC, bool OBB = false>
 __device__ __forceinline__ void recover_up_to_5(const Col (&col)[NC], V3 &pos)
 {
     bool more = true;
-#pragma unroll
-    for (int it = 0; it < 5; ++it)
+#pragma unroll 1
+    for (int it = 0; it < 5; ++it)   // (a counted loop, not five copies: the tick's code is ~100 KB as it is; `more` is wave-uniform)
         if (more) more = recover_from_penetration<NC, OBB>(col, pos);
 }
 

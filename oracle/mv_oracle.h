@@ -24,10 +24,18 @@
  *              known answer (10000th output == 4123659995); action-mask table,
  *              getCoords example (voxel_grid_tests.cpp:25), reward/episode
  *              formulas are spec-derived known answers (tests/test_oracle_spec.py).
+ *              Round 3: canonical-pose controller cases whose outcome is derived BY HAND from
+ *              the cited lines of kinematic_character_controller.cpp / agent.cpp (wall slide at
+ *              30 / 45 / 60 degrees, a box that is no step but can be jumped on, ledges below the
+ *              step height walked up, two agents head-on in controller order) and asserted on
+ *              this oracle with a stated tolerance: tests/test_canonical_poses.py.
  *   UNPINNED : physics trajectories and pixels.  The reference delegates them to
  *              Bullet 2.89 and Magnum/OpenGL, neither of which is vendored in
  *              /root/reference nor installed here, and the reference's tests hold
  *              no golden vector for them.  "parity unpinned".
+ *              (The restated convex cast forms Bullet's advancement dist / (-(d . n)) as
+ *              (dist |v|) / (-(d . v)), one divide per iteration -- round 3, together with
+ *              the device code, operation for operation.)
  */
 #ifndef MV_ORACLE_H
 #define MV_ORACLE_H

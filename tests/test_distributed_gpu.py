@@ -15,12 +15,12 @@ pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("scenario,agents", [("TowerBuilding", 2), ("ObstaclesHard", 1)])
-def test_two_ranks_of_real_gyms_gather_the_single_gym_slab(hip, scenario, agents):
+@pytest.mark.parametrize("scenario,agents,mode", [("TowerBuilding", 2, "allgather"), ("ObstaclesHard", 1, "p2p")])
+def test_two_ranks_of_real_gyms_gather_the_single_gym_slab(hip, scenario, agents, mode):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MV_PIXEL_MODE")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-device", "--check-gather", "--scenario", scenario,
                           "--agents", str(agents), "--envs-per-gpu", "12", "--obs", "48", "32", "--steps", "9", "--warmup", "4", "--no-cpu-baseline",
-                          "--profile-steps", "0", "--no-extra-legs"], capture_output=True, text=True, timeout=500, env=env)
+                          "--profile-steps", "0", "--no-extra-legs", "--gather", mode], capture_output=True, text=True, timeout=500, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout
