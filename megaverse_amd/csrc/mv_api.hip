@@ -501,6 +501,11 @@ int mv_create(const mv_config *cfg, mv_gym **out)
             v.true_objective = (float *)p; p += szObjv;
         }
     }
+    if (getenv("MV_TICK_TIMING") && atoi(getenv("MV_TICK_TIMING"))) {   // (an instrumented build, -DMV_TICK_TIMING: phase cycle sums, printed by mv_close)
+        if (hipMalloc((void **)&g->gv.dbg, N * 16 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemset(g->gv.dbg, 0, N * 16 * sizeof(unsigned long long));
+        else g->gv.dbg = nullptr;
+        for (int q = 0; q < g->slots; ++q) g->gvp[q].dbg = g->gv.dbg;
+    }
     if (const char *e = getenv("MV_PIXEL_MODE")) g->fastPixels = lower(e) == "exact" ? 0 : 1;
     if (const char *e = getenv("MV_PIPELINE")) g->pipelined = atoi(e) != 0;
     g->obs = g->ownedObs;
@@ -626,6 +631,18 @@ int mv_close(mv_gym *g)
     (void)hipDeviceSynchronize();
     g->feeder.reset();   // joins the workers before their slots go away
     GymView &gv = g->gv;
+    if (gv.dbg) {   // tick phase timing of an instrumented build: per slot the mean over envs of the summed cycles, and the largest env
+        std::vector<unsigned long long> h((size_t)g->N * 16);
+        if (hipMemcpy(h.data(), gv.dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+            static const char *names[8] = {"loads", "actions", "physics", "interact", "fall/zone/timers", "write-back", "tick (both waves, to the barrier)", "frame setup (both waves)"};
+            for (int k = 0; k < 8; ++k) {
+                double sum = 0.0; unsigned long long mx = 0;
+                for (int e = 0; e < g->N; ++e) { sum += (double)h[(size_t)e * 16 + k]; mx = std::max(mx, h[(size_t)e * 16 + k]); }
+                std::fprintf(stderr, "[mv tick timing] %-36s mean %.0f cycles per env (all steps summed), max env %llu\n", names[k], sum / g->N, mx);
+            }
+        }
+        (void)hipFree(gv.dbg);
+    }
     if (g->arena) (void)hipFree(g->arena);
     if (g->hiresObs) (void)hipFree(g->hiresObs);
     if (g->hBlobs) (void)hipHostFree(g->hBlobs);

@@ -120,4 +120,19 @@ __device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v)
     return ((unsigned long long)wave_or_u32((unsigned)(v >> 32)) << 32) | wave_or_u32((unsigned)v);
 }
 
+// Phase timing of a tick (an instrumented build only: -DMV_TICK_TIMING; results are printed by mv_close): MV_T(k) adds the shader cycles
+// since the previous mark to slot k of the env's record
+#ifdef MV_TICK_TIMING
+#define MV_T_BEGIN unsigned long long mv_t_last_ = __builtin_amdgcn_s_memtime();
+#define MV_T(k)                                                                                     \
+    do {                                                                                            \
+        const unsigned long long mv_t_now_ = __builtin_amdgcn_s_memtime();                          \
+        if (gv.dbg && (threadIdx.x & 63) == 0) gv.dbg[(size_t)env * 16 + (k)] += mv_t_now_ - mv_t_last_;   \
+        mv_t_last_ = mv_t_now_;                                                                     \
+    } while (0)
+#else
+#define MV_T_BEGIN
+#define MV_T(k) do { } while (0)
+#endif
+
 }  // namespace mv

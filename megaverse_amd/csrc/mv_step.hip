@@ -43,10 +43,13 @@ __global__ __launch_bounds__(256) void step_kernel(GymView gv, int W, int H, int
 {
     __shared__ FrameScratch s_fs[A_MAX == 1 ? 1 : 4];
     const int env = blockIdx.x;
+    MV_T_BEGIN
     if (threadIdx.x < 64) tower_tick<A_MAX>(gv, env);
     if (!render) return;
     __syncthreads();   // the tick's stores (same CU: same L1) before the frame setup's loads
+    MV_T(6);           // the whole tick as wave 0 saw it (incl. the generator of a finished env), up to the barrier
     if (A_MAX == 1) frame_setup_body<STEP_THREADS, false>(gv, env, W, H, s_fs[0]);
+    if (A_MAX == 1) MV_T(7);   // frame setup
     else {
         const int A = gv.num_agents, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
         for (int a = wave; a < A; a += nw) frame_setup_body<64, true>(gv, env * A + a, W, H, s_fs[wave]);

@@ -109,6 +109,7 @@ __device__ __forceinline__ void tower_tick(const GymView &gv, const int env)
     if (env >= gv.num_envs) return;
     const int A = gv.num_agents;
 
+    MV_T_BEGIN
     const EnvHeader *gh = gv.hdr + env;
     Hdr h;
     h.num_objects = gh->num_objects; h.num_boxes = gh->num_boxes; h.num_frames = gh->num_frames; h.done = gh->done;
@@ -159,6 +160,7 @@ __device__ __forceinline__ void tower_tick(const GymView &gv, const int env)
     __shared__ AgentState s_ag[A_MAX];
     __shared__ int s_act[A_MAX];
     agents_load(gv, env, A, s_ag, s_act);
+    MV_T(0);   // loads
     const float dt = DT;
 
     // ---- actions -> intents (env.cpp:89-122): agents are independent here, one lane each
@@ -170,6 +172,7 @@ __device__ __forceinline__ void tower_tick(const GymView &gv, const int env)
     }
     wave_sync();
 
+    MV_T(1);   // actions -> intents
     // ---- physics, agent by agent (controllers run in addAction order, env.cpp:126)
 #pragma unroll 1
     for (int i = 0; i < A; ++i) {
@@ -189,6 +192,7 @@ __device__ __forceinline__ void tower_tick(const GymView &gv, const int env)
         wave_sync();
     }
 
+    MV_T(2);   // physics
     // ---- scenario step: interact (component_object_stacking.hpp:45-168)
 #pragma unroll 1
     for (int i = 0; i < A; ++i) {
@@ -261,6 +265,7 @@ __device__ __forceinline__ void tower_tick(const GymView &gv, const int env)
     }
     wave_sync();
 
+    MV_T(3);   // interact
     // ---- fall detection (component_fall_detection.hpp:33-55): one lane per agent
     if (lane < A) {
         AgentState &a = s_ag[lane];
@@ -293,6 +298,7 @@ __device__ __forceinline__ void tower_tick(const GymView &gv, const int env)
     if (h.episode_sec >= h.episode_len) h.done = 1;
     ++h.num_frames;
 
+    MV_T(4);   // fall detection, zone shaping, timers
     // ---- write back
     MovableObject *gobjw = gv.objects + (size_t)env * MAX_OBJECTS;
 #pragma unroll
@@ -311,6 +317,7 @@ __device__ __forceinline__ void tower_tick(const GymView &gv, const int env)
     agents_store(gv, env, A, s_ag);
     if (h.done && lane < A) gv.true_objective[(size_t)env * A + lane] = float(h.highest_tower);   // vector_env.cpp:97-98
 
+    MV_T(5);   // write back
     // ---- VectorEnv::step's auto-reset (vector_env.cpp:93-105): the wave of a finished env regenerates it right here.  About one
     // env in two thousand finishes per tick and its wave is not the slowest of the launch even with the generator on top, so
     // this costs nothing, where a separate "reset whoever is done" launch cost 4-7 us per step.
