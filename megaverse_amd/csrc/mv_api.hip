@@ -502,7 +502,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
         }
     }
     if (getenv("MV_TICK_TIMING") && atoi(getenv("MV_TICK_TIMING"))) {   // (an instrumented build, -DMV_TICK_TIMING: phase cycle sums, printed by mv_close)
-        if (hipMalloc((void **)&g->gv.dbg, N * 16 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemset(g->gv.dbg, 0, N * 16 * sizeof(unsigned long long));
+        if (hipMalloc((void **)&g->gv.dbg, N * 64 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemset(g->gv.dbg, 0, N * 64 * sizeof(unsigned long long));
         else g->gv.dbg = nullptr;
         for (int q = 0; q < g->slots; ++q) g->gvp[q].dbg = g->gv.dbg;
     }
@@ -631,14 +631,48 @@ int mv_close(mv_gym *g)
     (void)hipDeviceSynchronize();
     g->feeder.reset();   // joins the workers before their slots go away
     GymView &gv = g->gv;
-    if (gv.dbg) {   // tick phase timing of an instrumented build: per slot the mean over envs of the summed cycles, and the largest env
-        std::vector<unsigned long long> h((size_t)g->N * 16);
+    if (gv.dbg) {   // tick phase timing of an instrumented build.  Per env 64 counters: 0..15 sums over all ticks (0..7 phase cycles, 8..12 cast statistics),
+                    // 16..31 the same of the last tick, 32..47 of the env's longest tick, 48..55 launch lifetimes on the 100 MHz clock (mv_step.hip)
+        const int N = g->N;
+        std::vector<unsigned long long> h((size_t)N * 64);
         if (hipMemcpy(h.data(), gv.dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+            auto at = [&](int e, int k) { return h[(size_t)e * 64 + k]; };
             static const char *names[8] = {"loads", "actions", "physics", "interact", "fall/zone/timers", "write-back", "tick (both waves, to the barrier)", "frame setup (both waves)"};
             for (int k = 0; k < 8; ++k) {
                 double sum = 0.0; unsigned long long mx = 0;
-                for (int e = 0; e < g->N; ++e) { sum += (double)h[(size_t)e * 16 + k]; mx = std::max(mx, h[(size_t)e * 16 + k]); }
-                std::fprintf(stderr, "[mv tick timing] %-36s mean %.0f cycles per env (all steps summed), max env %llu\n", names[k], sum / g->N, mx);
+                for (int e = 0; e < N; ++e) { sum += (double)at(e, k); mx = std::max(mx, at(e, k)); }
+                std::fprintf(stderr, "[mv tick timing] %-36s mean %.0f cycles per env (all steps summed), max env %llu\n", names[k], sum / N, mx);
+            }
+            double cs[5] = {0, 0, 0, 0, 0};
+            for (int e = 0; e < N; ++e) for (int k = 0; k < 5; ++k) cs[k] += (double)at(e, 8 + k);
+            std::fprintf(stderr, "[mv tick timing] casts, all ticks of all envs: %.0f sweeps, %.0f casts started, %.0f wave iterations slot by slot, %.0f if a lane's casts were queued\n", cs[0], cs[4], cs[1], cs[2]);
+            const bool tickOnly = at(0, 49) != 0;
+            if (tickOnly) {
+                int worst = 0; double mxsum = 0.0, wi[5] = {0, 0, 0, 0, 0};
+                for (int e = 0; e < N; ++e) {
+                    mxsum += (double)at(e, 54);
+                    if (at(e, 54) > at(worst, 54)) worst = e;
+                    for (int k = 0; k < 5; ++k) wi[k] += (double)at(e, 32 + 8 + k);
+                }
+                std::fprintf(stderr, "[mv tick timing] longest tick of an env: %.2f us on average over envs, with on average %.1f sweeps, %.1f casts, %.1f wave iterations (%.1f queued), longest cast %.1f\n",
+                             mxsum / N * 0.01, wi[0] / N, wi[4] / N, wi[1] / N, wi[2] / N, wi[3] / N);
+                std::fprintf(stderr, "[mv tick timing] the longest of all (env %d, %.2f us), cycles per phase: loads %llu actions %llu physics %llu interact %llu fall %llu write-back %llu; %llu sweeps, %llu casts, %llu wave iterations (%llu queued), longest cast %llu\n",
+                             worst, (double)at(worst, 54) * 0.01, at(worst, 32), at(worst, 33), at(worst, 34), at(worst, 35), at(worst, 36), at(worst, 37),
+                             at(worst, 40), at(worst, 44), at(worst, 41), at(worst, 42), at(worst, 43));
+                double rl = 0.0, rc = 0.0;
+                for (int e = 0; e < N; ++e) { rl += (double)at(e, 52); rc += (double)at(e, 53); }
+                std::fprintf(stderr, "[mv tick timing] tick-only launches: %.0f ticks regenerated their env and lived %.2f us on average\n", rc, rc > 0 ? rl / rc * 0.01 : 0.0);
+            }
+            {   // {sum of wave-0 lifetimes, launches, start and end of the last one}
+                const int b = tickOnly ? 48 : 52;
+                double life = 0.0, cnt = 0.0; unsigned long long s0 = ~0ull, s1 = 0, e1 = 0;
+                for (int e = 0; e < N; ++e) {
+                    life += (double)at(e, b); cnt += (double)at(e, b + 1);
+                    if (at(e, b + 1)) { s0 = std::min(s0, at(e, b + 2)); s1 = std::max(s1, at(e, b + 2)); e1 = std::max(e1, at(e, b + 3)); }
+                }
+                if (cnt > 0)
+                    std::fprintf(stderr, "[mv tick timing] %s launches: wave 0 lives %.2f us on average; last launch: starts spread over %.2f us, first start to last end %.2f us\n",
+                                 tickOnly ? "tick-only" : "fused", life / cnt * 0.01, (double)(s1 - s0) * 0.01, (double)(e1 - s0) * 0.01);
             }
         }
         (void)hipFree(gv.dbg);

@@ -127,7 +127,10 @@ __device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v)
 #define MV_T(k)                                                                                     \
     do {                                                                                            \
         const unsigned long long mv_t_now_ = __builtin_amdgcn_s_memtime();                          \
-        if (gv.dbg && (threadIdx.x & 63) == 0) gv.dbg[(size_t)env * 16 + (k)] += mv_t_now_ - mv_t_last_;   \
+        if (gv.dbg && (threadIdx.x & 63) == 0) {                                                    \
+            gv.dbg[(size_t)env * 64 + (k)] += mv_t_now_ - mv_t_last_;                               \
+            gv.dbg[(size_t)env * 64 + 16 + (k)] = mv_t_now_ - mv_t_last_;                           \
+        }                                                                                           \
         mv_t_last_ = mv_t_now_;                                                                     \
     } while (0)
 #else

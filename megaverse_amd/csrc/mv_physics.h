@@ -170,8 +170,14 @@ __device__ __forceinline__ Raw raw_capsule(V3 p, V3 centre, float halfLen, float
 // quotient is formed as (dist |v|) / (-(d . v)): ONE correctly rounded divide per iteration instead of two (1 / |v| and the quotient),
 // the normal is normalised once, on a hit.  A box in a hex wall frame (OBB builds) is cast in that frame: start and direction are rotated
 // in once, the normal is rotated back once.  (The CPU restatement the parity tests compare with forms the same operations in the same order.)
+#ifdef MV_TICK_TIMING
+__shared__ unsigned s_cast_dbg[8];
+#define MV_CAST_ITERS(n) do { if (iters) *iters = (n); } while (0)
+#else
+#define MV_CAST_ITERS(n) do { } while (0)
+#endif
 template <bool OBB = false>
-__device__ __forceinline__ bool convex_cast(const Col &col, V3 p, V3 d, float &fraction, V3 &normal)
+__device__ __forceinline__ bool convex_cast(const Col &col, V3 p, V3 d, float &fraction, V3 &normal, int *iters = nullptr)
 {
     const bool boxLike = col.kind != 2;
     const int fr = col.kind - 3;
@@ -193,6 +199,7 @@ __device__ __forceinline__ bool convex_cast(const Col &col, V3 p, V3 d, float &f
         const V3 x = v3(p.x + lambda * d.x, p.y + lambda * d.y, p.z + lambda * d.z);
         c = boxLike ? raw_box(x, col.lo, col.hi, CAP_R) : raw_capsule(x, col.lo, col.hi.x, 2 * CAP_R);
         dist = c.dist + ALLOWED_CCD_PEN;
+        MV_CAST_ITERS(numIter + 1);
         if (++numIter > CAST_MAX_ITER) return false;
     }
     fraction = lambda;
@@ -228,16 +235,38 @@ __device__ __forceinline__ bool sweep(const Col (&col)[NC], V3 from, V3 to, V3 u
     V3 nn[NC];
 #pragma unroll
     for (int k = 0; k < NC; ++k) { nn[k] = v3(0, 0, 0); fb[k] = ~0u; }
+#ifdef MV_TICK_TIMING
+    int its[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) its[k] = 0;
+#define MV_ITS_ARG , &its[k]
+#else
+#define MV_ITS_ARG
+#endif
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
         if (col[k].kind != 0 && cast_can_hit<OBB>(col[k], from, d)) {
             float f; V3 n;
-            if (convex_cast<OBB>(col[k], from, d, f, n) && (len2(n) > 0.0001f) && (f < 1.0f) && !(dot(up, n) < minSlopeDot)) {
+            if (convex_cast<OBB>(col[k], from, d, f, n MV_ITS_ARG) && (len2(n) > 0.0001f) && (f < 1.0f) && !(dot(up, n) < minSlopeDot)) {
                 fb[k] = __float_as_uint(f);
                 nn[k] = n;
             }
         }
     }
+#undef MV_ITS_ARG
+#ifdef MV_TICK_TIMING
+    {   // s_cast_dbg: [0] sweeps, [1] sum over sweeps of the per-slot longest casts (what the wave iterates today), [2] sum over sweeps of the longest
+        // per-lane total (what it would iterate with the lanes' casts queued), [3] the longest single cast, [4] casts started
+        unsigned serial = 0, lanesum = 0, started = 0;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) { serial += ~wave_min_u32(~(unsigned)its[k]); lanesum += (unsigned)its[k]; started += (unsigned)__popcll(__ballot(its[k] > 0)); }
+        const unsigned queued = ~wave_min_u32(~lanesum);
+        unsigned longest = 0;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) longest = max(longest, ~wave_min_u32(~(unsigned)its[k]));
+        if (lane_id() == 0) { s_cast_dbg[0] += 1; s_cast_dbg[1] += serial; s_cast_dbg[2] += queued; s_cast_dbg[3] = max(s_cast_dbg[3], longest); s_cast_dbg[4] += started; }
+    }
+#endif
     // the closest hit of the wave; ties resolve towards the lowest slot (slot = lane + 64 k: the serial order of the reference's callback):
     // smallest fraction first (one DPP reduction), then the first k that holds it, then the first lane of that k (ballots)
     unsigned mine = fb[0];
@@ -387,6 +416,7 @@ __device__ __forceinline__ void player_step(AgentState &a, const Col (&col)[NC],
 #pragma unroll 1
         for (int it = 0; it < 10; ++it) {   // "int maxIter = 10; while (maxIter-- > 0)" with breaks -> flag
             if (active) {
+                const V3 before = target;
                 const V3 negDir = cur - target;
                 float f = 1.0f; V3 n = v3(0, 0, 0);
                 bool hit = false;
@@ -410,6 +440,13 @@ __device__ __forceinline__ void player_step(AgentState &a, const Col (&col)[NC],
                         cd = cd * (1.0f / sqrtf(dist2));
                         if (dot(cd, hv) <= 0.0f) { target = cur; active = false; }
                     } else { target = cur; active = false; }
+                    // An iteration is a pure function of `target` (cur and the colliders do not change in this loop): once it maps the target
+                    // onto itself, bit for bit, the remaining iterations would all do the same.  An agent pushing into a wall or a corner gets
+                    // there after two or three iterations and would otherwise sweep ten times (2 % of the ticks, i.e. some env of every launch,
+                    // and the launch lasts as long as its slowest tick).  The CPU restatement runs the plain loop; the parity tests compare.
+                    if (__float_as_uint(target.x) == __float_as_uint(before.x) && __float_as_uint(target.y) == __float_as_uint(before.y) &&
+                        __float_as_uint(target.z) == __float_as_uint(before.z))
+                        active = false;
                 }
             }
         }

@@ -173,6 +173,10 @@ __device__ __forceinline__ void tower_tick(const GymView &gv, const int env)
     wave_sync();
 
     MV_T(1);   // actions -> intents
+#ifdef MV_TICK_TIMING
+    if (lane < 8) s_cast_dbg[lane] = 0;
+    wave_sync();
+#endif
     // ---- physics, agent by agent (controllers run in addAction order, env.cpp:126)
 #pragma unroll 1
     for (int i = 0; i < A; ++i) {
@@ -192,6 +196,10 @@ __device__ __forceinline__ void tower_tick(const GymView &gv, const int env)
         wave_sync();
     }
 
+#ifdef MV_TICK_TIMING
+    if (gv.dbg && lane == 0)
+        for (int k = 0; k < 5; ++k) { gv.dbg[(size_t)env * 64 + 16 + 8 + k] = s_cast_dbg[k]; gv.dbg[(size_t)env * 64 + 8 + k] += s_cast_dbg[k]; }
+#endif
     MV_T(2);   // physics
     // ---- scenario step: interact (component_object_stacking.hpp:45-168)
 #pragma unroll 1

@@ -157,7 +157,7 @@ struct GymView {
     int32_t *lpt_list;         // [256][N*A] the frames of every bin in arrival order
     int32_t lpt_parity;        // which of the histograms this observation pass uses
     uint8_t *vis_hdr;          // [N*A][FRAME_HDR_BYTES] per-frame header for raster_fast_kernel (cameras, light vectors, masks, count)
-    unsigned long long *dbg;   // null, or (builds with -DMV_TICK_TIMING, MV_TICK_TIMING=1) [N][16] phase cycle sums of the TowerBuilding tick
+    unsigned long long *dbg;   // null, or (builds with -DMV_TICK_TIMING, MV_TICK_TIMING=1) [N][64] counters of the TowerBuilding tick
 };
 
 // One host-generated episode (Obstacles family): everything Env::reset produces, ready to be swapped in by

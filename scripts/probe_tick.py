@@ -14,16 +14,17 @@ os.environ.setdefault("BOXOBAN_LEVELS", os.path.join(os.path.dirname(os.path.dir
 g = MegaverseGym(scenario, 128, 128, n, a, 8, False, {})
 g.set_pixel_mode("fast")
 g.set_pipelining(False)
+mode = os.environ.get("PROBE_MODE", "both")   # tick | fused | both
 g.seed(42)
 g.reset()
-for st in range(300):
+for st in range(300 if mode != "fused" else 0):
     g.sample_random_actions(1234, st)
     g.step_no_render()
 g.synchronize()
-for st in range(100):
+for st in range(100 if mode == "both" else 0):
     g.render()
 g.synchronize()
-for st in range(300, 500):
+for st in range(300, 500 if mode != "tick" else 300):
     g.sample_random_actions(1234, st)
     g.step()
 g.synchronize()

@@ -120,3 +120,14 @@ def head_on(g, e, y, ticks=20):
         act(g, e, 1, FWD)
         tick(g)
         yield
+
+
+def corner_push(g, e, W, ticks=30):
+    """walk diagonally into the corner of the walls x in [0, 1) and z in [W - 1, W): the forward-and-strafe loop slides along one wall into
+    the other and back until its target stops changing or its ten iterations are used up (kinematic_character_controller.cpp:331-420) --
+    the ticks with the most sweeps there are"""
+    pose(g, e, 0, 2.5, REST_ON(1.0), W - 3.0, 3 * np.pi / 4 + 0.1)   # forward = (-sin, 0, -cos): towards -x and +z, 5.7 degrees off the diagonal
+    for _ in range(ticks):
+        act(g, e, 0, FWD)
+        tick(g)
+        yield

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import oracle_lib
-from canonical import CCD, HH, R, REST_ON, box_block_then_jump, find_isolated_box, find_wall_strip, head_on, slide_fixed_point, stairs, wall_slide
+from canonical import CCD, HH, R, REST_ON, box_block_then_jump, corner_push, find_isolated_box, find_wall_strip, head_on, slide_fixed_point, stairs, wall_slide
 
 
 def agent(g, e, a=0):
@@ -40,6 +40,20 @@ def test_wall_slide_keeps_the_tangential_component(tower, deg):
     assert abs(speeds[-1][0]) < 1e-4
     assert abs(-speeds[-1][1] - slide_fixed_point(deg)) < 2e-3 * slide_fixed_point(deg), (speeds[-1], slide_fixed_point(deg))
     assert abs(float(agent(tower, e)["pos"][1]) - REST_ON(1.0)) < 1e-4   # still on the floor
+
+
+def test_corner_push_comes_to_rest_in_the_corner(tower):
+    e = next(e for e in range(64) if find_wall_strip(tower.snapshot(e)))
+    W = int(tower.snapshot(e)["W"])
+    trace = []
+    for _ in corner_push(tower, e, W):
+        a = agent(tower, e)
+        trace.append((float(a["pos"][0]), float(a["pos"][2]), float(a["hv"][0]), float(a["hv"][1]), float(a["pos"][1])))
+    # blocked 0.04 inside both nominal contacts (faces x = 1 and z = W - 1), at rest, still on the floor
+    x, z, hvx, hvz, y = trace[-1]
+    assert abs(x - (1.0 + R - CCD)) < 2.5e-3 and abs(z - (W - 1.0 - R + CCD)) < 2.5e-3, (x, z, W)
+    assert abs(hvx) < 1e-3 and abs(hvz) < 1e-3 and abs(y - REST_ON(1.0)) < 1e-4
+    assert max(abs(t[0] - x) + abs(t[1] - z) for t in trace[-8:]) < 1e-4
 
 
 def test_a_box_is_not_a_step_but_a_jump_clears_it(tower):

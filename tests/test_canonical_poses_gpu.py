@@ -3,7 +3,7 @@ state must equal the oracle's bit for bit.  (What the outcomes must be is assert
 import numpy as np
 import pytest
 
-from canonical import box_block_then_jump, find_isolated_box, find_wall_strip, head_on, stairs, wall_slide
+from canonical import box_block_then_jump, corner_push, find_isolated_box, find_wall_strip, head_on, stairs, wall_slide
 from hip_util import diff_snapshots, hip_snapshot, make_pair
 
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
@@ -25,6 +25,16 @@ def test_wall_slide_bit_exact(hip, deg):
     e = next(e for e in range(64) if find_wall_strip(og.snapshot(e)))
     W = int(og.snapshot(e)["W"])
     lockstep(og, hg, e, 1, wall_slide(og, e, W, deg), wall_slide(hg, e, W, deg))
+    og.close(); hg.close()
+
+
+def test_corner_push_bit_exact(hip):
+    """the ticks whose forward-and-strafe loop runs longest; the HIP path leaves that loop once the target repeats bit for bit (mv_physics.h),
+    the oracle runs all its iterations"""
+    og, hg = make_pair(64, 1, 16, 16, seed=3)
+    e = next(e for e in range(64) if find_wall_strip(og.snapshot(e)))
+    W = int(og.snapshot(e)["W"])
+    lockstep(og, hg, e, 1, corner_push(og, e, W), corner_push(hg, e, W))
     og.close(); hg.close()
 
 
