@@ -453,8 +453,7 @@ def main():
         feat = slabs[0].view(frames, -1)[:, 37:37 + 6 * 97:97]   # six bytes of every frame
 
         def policy_step(i):
-            acts.copy_(feat)                      # uint8 -> int32
-            acts.add_(i).remainder_(sizes)        # "policy": a function of the observation just rendered
+            torch.remainder(feat, sizes, out=acts)   # "policy": ONE kernel, a function of the observation just rendered (uint8 pixels -> int32 actions)
             gym.set_actions_device(acts.data_ptr())
             gym.step()
 
@@ -468,6 +467,51 @@ def main():
         fence()
         extra["closed_loop"] = time.perf_counter() - t0
         step0 += args.steps
+
+        # closed_loop_double_buffered: the same policy-in-the-loop, with the envs in two halves that take turns (Sample Factory's double-buffered
+        # sampling, which is how the reference's own learner drives it: while one half's observations are rendered and go through the policy,
+        # the other half steps).  Two gyms of n_env / 2 envs, each with its own stream; a half's chain policy -> step -> raster stays in order
+        # on its stream, the two chains overlap on the device.  The same number of agent observations per tick as every other leg.
+        if n_env % 2 == 0 and n_env >= 2:
+            from megaverse_amd.extension import MegaverseGym as _G
+            half_frames = frames // 2
+            halves = []
+            for hidx in range(2):
+                st = torch.cuda.Stream(device=device)
+                hg = _G(args.scenario, W, H, n_env // 2, A, 8, False, {}, device=local_rank, env_offset=hidx * (n_env // 2), total_envs=n_env)
+                hg.set_stream(st.cuda_stream)
+                hg.set_pixel_mode(args.pixels)
+                slab = torch.zeros((half_frames, H, W, 4), dtype=torch.uint8, device=device)
+                hg.set_obs_buffer(slab.data_ptr())
+                hg.seed(42 + hidx); hg.reset()
+                halves.append((hg, st, slab, slab.view(half_frames, -1)[:, 37:37 + 6 * 97:97], torch.zeros((half_frames, 6), dtype=torch.int32, device=device)))
+            torch.cuda.synchronize()
+
+            def half_step(hidx, i):
+                hg, st, _, hfeat, hacts = halves[hidx]
+                torch.cuda.set_stream(st)
+                torch.remainder(hfeat, sizes, out=hacts)
+                hg.set_actions_device(hacts.data_ptr())
+                hg.step()
+
+            main_stream = torch.cuda.current_stream()
+            for i in range(wu):
+                half_step(0, step0 + i); half_step(1, step0 + i)
+            step0 += wu
+            torch.cuda.set_stream(main_stream)
+            fence()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                half_step(0, step0 + i); half_step(1, step0 + i)
+            t_enq = time.perf_counter() - t0
+            torch.cuda.set_stream(main_stream)
+            fence()
+            extra["closed_loop_double_buffered"] = time.perf_counter() - t0
+            host_enqueue_ms = t_enq / args.steps * 1e3   # (when this is close to the leg's ms per step, the Python loop is the bound, not the device)
+            step0 += args.steps
+            checksum_halves = sum(int(h[2][::97].to(torch.int64).sum().item()) for h in halves)
+            for h in halves:
+                h[0].close()
 
     checksum = int(slabs[0][::97].to(torch.int64).sum().item())   # touch the result so nothing is optimised away
     if ring is not None:
@@ -521,13 +565,15 @@ def main():
                        # stepped and rendered in full); ticks_per_call > 1: mv_step_n, the streams hand over once per call, tick j of a call
                        # leaves its observations in slab j of a ring of that many slabs
                        "pipelined": pipelined, "ticks_per_call": batch if main_batched else 1,
-                       **({"launches_per_tick": 3, "scenarios": "TowerBuilding, ObstaclesEasy, ObstaclesHard, Collect, Sokoban, HexMemory, HexExplore, Rearrange dealt round-robin "
-                                                              "by env index (one gym per scenario, stepped as one mv_group)"} if mixed else {}),
+                       **({"launches_per_tick": 2, "scenarios": "TowerBuilding, ObstaclesEasy, ObstaclesHard, Collect, Sokoban, HexMemory, HexExplore, Rearrange dealt round-robin "
+                                                              "by env index (one gym per scenario, stepped as one mv_group: one step launch and one raster launch per tick)"} if mixed else {}),
                        "parallelism": f"env-shard x{world}"},
         }
         for key, el in extra.items():
             line["value_" + key] = total_obs / el
             line["ms_per_step_" + key] = el / args.steps * 1e3
+        if "closed_loop_double_buffered" in extra:
+            line["host_enqueue_ms_per_step_closed_loop_double_buffered"] = host_enqueue_ms
         if dry:
             line["dry_run"] = True
         if single:

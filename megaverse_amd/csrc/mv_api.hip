@@ -105,12 +105,12 @@ struct mv_gym {
     hipStream_t simStream = nullptr;
     int pipelined = 1;                           // mv_set_pipelining / MV_PIPELINE: 0 = everything on the caller's stream, in order
     bool simOnOwnStream = false;                 // where the last step ran
-    hipEvent_t userMark[PIPE_GROUPS] = {};       // recorded on `stream` at the start of every stepping call, round-robin
+    hipEvent_t userMark[PIPE_GROUPS] = {};       // completed when the last observation pass of a stepping call is, round-robin over the calls
+    hipEvent_t userNow = nullptr;                // recorded on `stream` when the simulation must wait for all of it
     unsigned long long markCount = 0;             // (64 bits: a training run takes 2^31 steps in a day and a half)
     bool simMustWaitUser = true;                 // the caller's stream holds work the next step depends on (reset, render, device actions, ...)
     hipEvent_t simDone = nullptr;                // after the last kernel on simStream
     bool simDoneValid = false;
-    std::vector<hipEvent_t> tickDone;            // a batched call that finds the caller's stream idle hands over tick by tick (created on first use)
     int batch = 8, slots = PIPE_GROUPS * 8, hists = PIPE_GROUPS * 8 + 1;   // slots per group (MV_PIPE_BATCH), slots, cost histograms
     int group = 0;                               // slot group of the last stepping call
     int parity = 0, hist3 = 0;                   // hand-over slot of the last tick; cost histogram of the last pass
@@ -541,6 +541,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
                   hipEventCreateWithFlags(&g->userMark[0], hipEventDisableTiming) == hipSuccess &&
                   hipEventCreateWithFlags(&g->userMark[1], hipEventDisableTiming) == hipSuccess &&
                   hipEventCreateWithFlags(&g->userMark[2], hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&g->userNow, hipEventDisableTiming) == hipSuccess &&
                   hipEventCreateWithFlags(&g->simDone, hipEventDisableTiming) == hipSuccess &&
                   hipEventCreateWithFlags(&g->resetDone, hipEventDisableTiming) == hipSuccess &&
                   hipEventCreateWithFlags(&g->stepDone, hipEventDisableTiming) == hipSuccess &&
@@ -689,8 +690,8 @@ int mv_close(mv_gym *g)
     if (g->copyStream) (void)hipStreamDestroy(g->copyStream);
     if (g->simStream) (void)hipStreamDestroy(g->simStream);
     for (hipEvent_t &e : g->userMark) { if (e) (void)hipEventDestroy(e); e = nullptr; }
-    for (hipEvent_t e : g->tickDone) (void)hipEventDestroy(e);
-    g->tickDone.clear();
+    if (g->userNow) (void)hipEventDestroy(g->userNow);
+    g->userNow = nullptr;
     if (g->simDone) (void)hipEventDestroy(g->simDone);
     g->simStream = nullptr; g->simDone = nullptr;
     g->hBlobs = nullptr; g->hStatus = nullptr; g->resetDone = g->stepDone = g->statusCopied = nullptr; g->copyStream = nullptr; g->dBlobs = nullptr; g->dStatus = nullptr;
@@ -1078,11 +1079,13 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
     const bool own = L->pipelined != 0 && !(mustWait && k == 1);
     hipStream_t sim = own ? L->simStream : L->stream;
     if (own) {
-        hipEvent_t mark = L->userMark[L->markCount % PIPE_GROUPS];
-        HIP_TRY(hipEventRecord(mark, L->stream));
-        if (mustWait || !L->simOnOwnStream) HIP_TRY(hipStreamWaitEvent(sim, mark, 0));   // (or the last step ran on the caller's stream)
-        else if (L->markCount >= PIPE_GROUPS - 1) HIP_TRY(hipStreamWaitEvent(sim, L->userMark[(L->markCount - (PIPE_GROUPS - 1)) % PIPE_GROUPS], 0));
-        ++L->markCount;
+        // The simulation stream may reuse a slot group once the observation passes that read it are done: the END of the call PIPE_GROUPS calls
+        // ago (userMark, completed by that call's last pass, see below).  When the caller's stream feeds the simulation (reset / render / device
+        // actions / test hooks since the last step), or the last step ran there: everything enqueued on it so far.
+        if (mustWait || !L->simOnOwnStream) {
+            HIP_TRY(hipEventRecord(L->userNow, L->stream));
+            HIP_TRY(hipStreamWaitEvent(sim, L->userNow, 0));
+        } else if (L->markCount >= PIPE_GROUPS) HIP_TRY(hipStreamWaitEvent(sim, L->userMark[L->markCount % PIPE_GROUPS], 0));
     } else {
         if (L->simOnOwnStream && L->simDoneValid) HIP_TRY(hipStreamWaitEvent(sim, L->simDone, 0));   // the last step ran on the other stream
         for (int i = 0; i < n; ++i) {   // (episode uploads make the simulation stream wait)
@@ -1108,21 +1111,9 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
         g->group = (g->group + 1) % PIPE_GROUPS;
     }
     const int fused = render ? 1 : 0;   // the step kernel also builds the frame lists when an observation pass follows
-    // A batched call normally hands over ONCE: all k step kernels, then all k observation passes.  That is right while the caller's stream
-    // still has the previous calls' passes to work off -- and wrong when it is idle (the first call after a synchronisation: the first pass
-    // would wait for k step kernels instead of one; on a 20-step run that is a fifth of the time).  An idle caller's stream gets the ticks one
-    // by one: tick j's pass waits for tick j's step kernel only.
-    bool fine = false;
-    if (own && k > 1 && render) {
-        fine = hipStreamQuery(L->stream) == hipSuccess;
-        (void)hipGetLastError();   // ("not ready" is an answer)
-        if (fine)
-            while ((int)L->tickDone.size() < k) {
-                hipEvent_t e;
-                HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-                L->tickDone.push_back(e);
-            }
-    }
+    // A batched call hands over ONCE: all k step kernels, then all k observation passes.  (Handing over tick by tick when the caller's stream is
+    // found idle -- the first call after a synchronisation -- was built and measured on 20-step runs: 15.0-15.6 M obs/s against 16.2 M without;
+    // short runs use short calls instead, bench.py's --batch.)
     std::vector<GymView> views((size_t)n * k);
     std::vector<OutPtrs> outs((size_t)n * k);
     hipEvent_t *evs[PIPE_BATCH_MAX];
@@ -1154,7 +1145,6 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
             launch_step_union(ua, sim, L->w, L->h, fused);
         }
         if (evs[j]) HIP_TRY(hipEventRecord(evs[j][1], sim));
-        if (fine) HIP_TRY(hipEventRecord(L->tickDone[j], sim));
     }
     if (own) HIP_TRY(hipEventRecord(L->simDone, sim));   // (not pipelined: stream order does it)
     // (every step kernel regenerates / swaps the next episode into the envs it finishes)
@@ -1175,11 +1165,10 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
         g->mirrorsFresh = false;
     }
     // ---- the caller's stream: per tick the step's outputs, then the observation pass
-    if (own && !fine) HIP_TRY(hipStreamWaitEvent(L->stream, L->simDone, 0));
+    if (own) HIP_TRY(hipStreamWaitEvent(L->stream, L->simDone, 0));
     std::vector<PublishTo> pubs((size_t)n);
     std::vector<uint32_t *> obsPtrs((size_t)n);
     for (int j = 0; j < k; ++j) {
-        if (fine) HIP_TRY(hipStreamWaitEvent(L->stream, L->tickDone[j], 0));
         if (evs[j]) HIP_TRY(hipEventRecord(evs[j][2], L->stream));
         for (int i = 0; i < n; ++i) {
             const OutPtrs &o = outs[(size_t)j * n + i];
@@ -1187,19 +1176,25 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
             obsPtrs[i] = o.obs;
             if (own && (!render || !allFast) && publish_outputs(gs[i], gs[i]->group * gs[i]->batch + j, o)) return -1;   // (the fast observation pass publishes with its first workgroups)
         }
+        // the call's last pass completes this call's mark (what the simulation stream waits for before it reuses the slot group)
+        hipEvent_t mark = own && j == k - 1 ? L->userMark[L->markCount % PIPE_GROUPS] : nullptr;
         if (render) {
             const bool pubInRaster = own && allFast;
             if (n > 1 && allFast) {
-                if (launch_raster_union(&views[(size_t)j * n], obsPtrs.data(), pubInRaster ? pubs.data() : nullptr, n, L->w, L->h, L->stream, evs[j] ? evs[j][3] : nullptr))
+                if (launch_raster_union(&views[(size_t)j * n], obsPtrs.data(), pubInRaster ? pubs.data() : nullptr, n, L->w, L->h, L->stream, evs[j] ? evs[j][3] : nullptr, mark))
                     return fail("mv_step: observation size above 1024x1024");
             } else {
                 for (int i = 0; i < n; ++i)
                     if (launch_raster(views[(size_t)j * n + i], obsPtrs[i], L->w, L->h, L->stream, evs[j] && i == 0 ? evs[j][3] : nullptr, gs[i]->fastPixels, /*setup_done=*/1,
-                                      pubInRaster ? &pubs[i] : nullptr))
+                                      pubInRaster ? &pubs[i] : nullptr, i == n - 1 ? mark : nullptr))
                         return fail("mv_step: observation size above 1024x1024");
             }
-        }
+        } else if (mark) HIP_TRY(hipEventRecord(mark, L->stream));
         if (evs[j]) HIP_TRY(hipEventRecord(evs[j][4], L->stream));
+    }
+    if (own) {
+        ++L->markCount;
+        for (int i = 0; i < n; ++i) gs[i]->markCount = L->markCount;
     }
     HIP_TRY(hipGetLastError());
     int rc = 0;

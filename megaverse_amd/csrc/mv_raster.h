@@ -13,11 +13,14 @@ namespace mv {
 // publish (fast kernel only): the step's staged rewards / dones / true objectives (gv.rewards ...) are copied into these public arrays by the
 // first workgroups of the raster launch -- ordered, on `stream`, with the observations (pipelined steps, mv_api.hip)
 struct PublishTo { float *rewards; uint8_t *done; float *true_objective; };
+// done: an event that completes when the pass does.  The fast kernels carry it as the completion signal of their own dispatch packet
+// (hipExtLaunchKernelGGL's stop event) -- a separate hipEventRecord is one more packet the queue works off between two passes, ~5 us.
 int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream, hipEvent_t between = nullptr, int fast = 1, int setup_done = 0,
-                  const PublishTo *publish = nullptr);
+                  const PublishTo *publish = nullptr, hipEvent_t done = nullptr);
 
 // the fast observation pass of n gyms of one job (frame lists already built by their step kernels) with at most two launches; publish: n
 // entries or null; -1 if W / H / n are too large
-int launch_raster_union(const GymView *views, uint32_t *const *obs, const PublishTo *publish, int n, int W, int H, hipStream_t stream, hipEvent_t between = nullptr);
+int launch_raster_union(const GymView *views, uint32_t *const *obs, const PublishTo *publish, int n, int W, int H, hipStream_t stream, hipEvent_t between = nullptr,
+                        hipEvent_t done = nullptr);
 
 }  // namespace mv

@@ -28,6 +28,7 @@
 // equal-depth hits resolve to the lowest slot, so the image equals brute force over all primitives
 // in slot order - which is what the CPU oracle does and the parity tests compare bit for bit.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <math.h>
 #include <stdlib.h>
 
@@ -1273,7 +1274,19 @@ static int fast_split(int W, int H, int np, int frames, bool longList = false)
 // up to 1024 (Collect, HexMemory, HexExplore: the large variant with the wall-frame box runs; a Collect frame has no wall-frame boxes and
 // takes the same path as in its own variant: its world boxes through the box runs, its cones through the general loop).  Pixels are the ones
 // each gym's own launch produces, byte for byte (same per-pixel arithmetic; tests/test_multitask_gpu.py).
-int launch_raster_union(const GymView *views, uint32_t *const *obs, const PublishTo *publish, int n, int W, int H, hipStream_t stream, hipEvent_t between)
+// a launch whose completion signal is `done` (null: a plain launch); MV_ATTACH_DONE=0: launch, then record (comparisons)
+template <class K, class... A>
+static void launch_done(K kernel, dim3 grid, dim3 block, size_t dyn, hipStream_t stream, hipEvent_t done, A... args)
+{
+    static const bool attach = !(getenv("MV_ATTACH_DONE") && atoi(getenv("MV_ATTACH_DONE")) == 0);
+    if (done && attach) hipExtLaunchKernelGGL(kernel, grid, block, dyn, stream, nullptr, done, 0, args...);
+    else {
+        hipLaunchKernelGGL(kernel, grid, block, dyn, stream, args...);
+        if (done) (void)hipEventRecord(done, stream);
+    }
+}
+
+int launch_raster_union(const GymView *views, uint32_t *const *obs, const PublishTo *publish, int n, int W, int H, hipStream_t stream, hipEvent_t between, hipEvent_t done)
 {
     if (W > MAX_W || H > MAX_H || n > MAX_UNION) return -1;
     const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)W * sizeof(float) + (size_t)H * sizeof(float2);
@@ -1300,8 +1313,8 @@ int launch_raster_union(const GymView *views, uint32_t *const *obs, const Publis
             }
         for (int i = a.u.n; i <= MAX_UNION; ++i) a.u.first[i] = wgs;
         for (int i = a.u.n; i < MAX_UNION; ++i) a.large[i] = 0;
-        if (np == 2) hipLaunchKernelGGL((raster_union_all_kernel<6, 2>), dim3(wgs), dim3(256), dyn, stream, a, W, H);
-        else hipLaunchKernelGGL((raster_union_all_kernel<8, 1>), dim3(wgs), dim3(256), dyn, stream, a, W, H);
+        if (np == 2) launch_done(raster_union_all_kernel<6, 2>, dim3(wgs), dim3(256), dyn, stream, done, a, W, H);
+        else launch_done(raster_union_all_kernel<8, 1>, dim3(wgs), dim3(256), dyn, stream, done, a, W, H);
         return 0;
     }
     for (int large = 1; large >= 0; --large) {   // the expensive frames first
@@ -1329,10 +1342,11 @@ int launch_raster_union(const GymView *views, uint32_t *const *obs, const Publis
             else hipLaunchKernelGGL((raster_fast_union_kernel<VIS_SMALL, true, 8, false, 1>), dim3(wgs), dim3(256), dyn, stream, ua, W, H, split);
         }
     }
+    if (done) (void)hipEventRecord(done, stream);   // (one or two launches: recorded behind them)
     return 0;
 }
 
-int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream, hipEvent_t between, int fast, int setup_done, const PublishTo *publish)
+int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream, hipEvent_t between, int fast, int setup_done, const PublishTo *publish, hipEvent_t done)
 {
     if (W > MAX_W || H > MAX_H) return -1;
     static const int envSplit = getenv("MV_RASTER_SPLIT") ? atoi(getenv("MV_RASTER_SPLIT")) : 0;
@@ -1362,7 +1376,7 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
             fn = hexScen ? raster_glist_kernel<VIS_XL, true, GLIST_WAVES_NP1, true, 1> : gv.vis_stride > VIS_SMALL ? raster_glist_kernel<VIS_LARGE, false, GLIST_WAVES_NP1, false, 1>
                : gv.scenario == SCN_REARRANGE ? (wavesSel >= 8 ? raster_fast_kernel<VIS_SMALL, true, 8> : raster_fast_kernel<VIS_SMALL, true, 6>)
                                               : (wavesSel >= 8 ? raster_fast_kernel<VIS_SMALL, false, 8> : raster_fast_kernel<VIS_SMALL, false, 6>);
-        hipLaunchKernelGGL(fn, dim3(frames * split), dim3(256), dyn, stream, fa, obs, W, H, split);
+        launch_done(fn, dim3(frames * split), dim3(256), dyn, stream, done, fa, obs, W, H, split);
         return 0;
     }
     const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)(W + H) * sizeof(float);
@@ -1373,6 +1387,7 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
     else if (gv.vis_stride > VIS_SMALL) hipLaunchKernelGGL((raster_kernel<VIS_LARGE, false>), grid, block, dyn, stream, gv, obs, W, H, split, gv.lpt_order);
     else if (gv.scenario == SCN_REARRANGE) hipLaunchKernelGGL((raster_kernel<VIS_SMALL, true>), grid, block, dyn, stream, gv, obs, W, H, split, gv.lpt_order);
     else hipLaunchKernelGGL((raster_kernel<VIS_SMALL, false>), grid, block, dyn, stream, gv, obs, W, H, split, gv.lpt_order);
+    if (done) (void)hipEventRecord(done, stream);
     return 0;
 }
 
