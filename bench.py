@@ -615,6 +615,9 @@ def main():
                 line["roofline"]["valu"] = {"insts_per_launch": insts, "salu_insts_per_launch": valu.get("salu_insts_per_launch"),
                                             "insts_per_64px_tile": insts / (frames * W * H / 64.0),
                                             "issue_peak_insts_per_s": VALU_ISSUE_PEAK, "frac_of_issue_peak": insts / (raster_ms * 1e-3) / VALU_ISSUE_PEAK,
+                                            # scripts/probe_valu.hip on this part (profiles/README.md): a SIMD with 8 waves of back-to-back v_fma / v_mul
+                                            # retires one per 1.11 ns (the clock under an all-VALU load is below 2.4 GHz); min / max / cndmask / max3 cost more
+                                            "probed_ns_per_fma_per_simd": 1.11, "frac_of_probed_fma_rate": insts * 1.11e-9 / 1024.0 / (raster_ms * 1e-3),
                                             "source": valu.get("source")}
             line["roofline_physics"] = {"bound": "latency", "kernel": ("mv::step_union_kernel" if mixed else "mv::step_kernel") + " (voxel physics + scenario logic + auto-reset + frame setup)", "achieved": achieved_step,
                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_step / HBM_PEAK_GBS, "traffic": traffic_step,

@@ -68,6 +68,28 @@ $B --scenario Mixed --obs 64 64 --envs-per-gpu 2048 > $OUT/mixed_64_n2048_bench.
 cd /tmp; MV_PIPELINE=0 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/db_tu -o run -- python $R/bench.py --steps 400 --warmup 50 --no-cpu-baseline --profile-steps 0 --no-extra-legs --batch 1 > $OUT/tower_unpipelined_stats.log 2>&1
 python $R/scripts/rocpd_summary.py $OUT/db_tu/run_results.db > $OUT/tower_unpipelined_kernel_stats.csv 2>> $OUT/tower_unpipelined_stats.log
 rm -rf $OUT/db_tu
+unpip() {   # unpip <name> <bench args...>: kernel table with the pipelining off (every kernel alone on the device)
+  local N=$1; shift
+  cd /tmp; MV_PIPELINE=0 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/db_u -o run -- python $R/bench.py "$@" --steps 400 --warmup 50 --no-cpu-baseline --profile-steps 0 --no-extra-legs --batch 1 > $OUT/${N}_unpipelined_stats.log 2>&1
+  python $R/scripts/rocpd_summary.py $OUT/db_u/run_results.db > $OUT/${N}_unpipelined_kernel_stats.csv 2>> $OUT/${N}_unpipelined_stats.log
+  rm -rf $OUT/db_u
+}
+unpip tower_512x4 --agents 4 --envs-per-gpu 512
+unpip obstacles_hard_512 --scenario ObstaclesHard --envs-per-gpu 512
+# where a tick's time goes (an instrumented build of the library, -DMV_TICK_TIMING): phase cycles, cast statistics, launch lifetimes
+if [ -f $R/megaverse_amd/_variants/libmv_ticktiming.so ]; then
+  cd $R
+  (export MV_TICK_TIMING=1 MV_LIB_PATH=$R/megaverse_amd/_variants/libmv_ticktiming.so
+   PROBE_MODE=tick python scripts/probe_tick.py TowerBuilding 1024 1 2>&1 | grep "tick timing" > $OUT/tick_timing_tower_tick_only.txt
+   PROBE_MODE=fused python scripts/probe_tick.py TowerBuilding 1024 1 2>&1 | grep "tick timing" > $OUT/tick_timing_tower_fused.txt)
+fi
+# timelines (kernel start / duration / queue): the driver-style 20-step run and the double-buffered closed loop
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace -d $OUT/db_t20 -o run -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs --profile-steps 0 > $OUT/timeline_20_steps.log 2>&1
+python $R/scripts/kernel_timeline.py $OUT/db_t20/run_results.db 62 0 > $OUT/timeline_20_steps.txt 2>> $OUT/timeline_20_steps.log
+timeout 300 rocprofv3 --kernel-trace -d $OUT/db_dbuf -o run -- python $R/scripts/probe_double_buffer.py 1024 100 > $OUT/timeline_double_buffered.log 2>&1
+python $R/scripts/kernel_timeline.py $OUT/db_dbuf/run_results.db 36 > $OUT/timeline_double_buffered.txt 2>> $OUT/timeline_double_buffered.log
+rm -rf $OUT/db_t20 $OUT/db_dbuf
 cd $R; (timeout 900 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?" >> $OUT/smoke.log)
 find $OUT -name "*.db" -delete
 ls $OUT

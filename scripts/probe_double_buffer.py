@@ -24,7 +24,7 @@ main = torch.cuda.current_stream()
 
 
 main = torch.cuda.current_stream()
-TOKEN = os.environ.get("TOKEN", "1") == "1"   # the two halves' observation passes take turns (events), so that one half steps while the other renders
+TOKEN = os.environ.get("TOKEN", "0") == "1"   # the two halves' observation passes take turns (events), so that one half steps while the other renders
 done = [torch.cuda.Event(), torch.cuda.Event()]
 done[1].record(main)
 
