@@ -449,9 +449,9 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     if (const char *e = getenv("MV_DEBUG_VIS_STRIDE")) gv.vis_stride = std::min(gv.vis_stride, std::max(8, atoi(e)));   // (tests: provoke ST_VISIBLE)
     gv.spares = g->spares;
     const size_t szVisP = up(NA * (size_t)gv.vis_stride * 32), szVisR = up(NA * (size_t)gv.vis_stride * 8), szVisC = up(NA * sizeof(int32_t)),
-                 szLpt = up(NA * sizeof(int32_t)) + up((NA + 1) * sizeof(int32_t)) + up(NA * (size_t)FRAME_HDR_BYTES) + up(256 * NA * sizeof(int32_t));
+                 szLpt = up(NA * sizeof(int32_t)) + up((NA + 1) * sizeof(int32_t)) + up(NA * (size_t)FRAME_HDR_BYTES) + up((size_t)LPT_BUCKETS * LPT_SUBS * lpt_sub_capacity(NA) * sizeof(int32_t));
     // per slot: frame lists, headers, cost lists, and the staging copies of rewards / dones / true objectives
-    const size_t szParity = szVisP + szVisR + szVisC + szLpt + szRew + szDone + szObjv, szHist = up((size_t)g->hists * 256 * sizeof(int32_t));
+    const size_t szParity = szVisP + szVisR + szVisC + szLpt + szRew + szDone + szObjv, szHist = up((size_t)g->hists * LPT_BUCKETS * LPT_SUBS * sizeof(int32_t));
     gv.lpt_hists = g->hists;
     const size_t total = szHdr + szBoxes + szObj + szAg + szAct + szRew + szDone + szObjv + szMd + (hostEpisodes ? 0 : szChunk) + szObs + szTerrain +
                          szRewObj + szHeight + szItems + szCells + szHexB + szHexO + szBlobs + szCnt + (size_t)g->slots * szParity + szHist;
@@ -495,7 +495,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
             v.lpt_bucket = (int32_t *)p; p += up(NA * sizeof(int32_t));
             v.lpt_order = (int32_t *)p; p += up((NA + 1) * sizeof(int32_t));
             v.vis_hdr = p; p += up(NA * (size_t)FRAME_HDR_BYTES);
-            v.lpt_list = (int32_t *)p; p += up(256 * NA * sizeof(int32_t));
+            v.lpt_list = (int32_t *)p; p += up((size_t)LPT_BUCKETS * LPT_SUBS * lpt_sub_capacity(NA) * sizeof(int32_t));
             v.rewards = (float *)p; p += szRew;
             v.done = p; p += szDone;
             v.true_objective = (float *)p; p += szObjv;
@@ -643,6 +643,14 @@ int mv_close(mv_gym *g)
                 double sum = 0.0; unsigned long long mx = 0;
                 for (int e = 0; e < N; ++e) { sum += (double)at(e, k); mx = std::max(mx, at(e, k)); }
                 std::fprintf(stderr, "[mv tick timing] %-36s mean %.0f cycles per env (all steps summed), max env %llu\n", names[k], sum / N, mx);
+            }
+            {   // frame setup phases (thread 0 of the workgroup), slots 56..61
+                static const char *fn[6] = {"cameras", "slot records", "screen rectangles", "list positions", "records written", "header + cost bin"};
+                for (int k = 0; k < 6; ++k) {
+                    double sum = 0.0;
+                    for (int e = 0; e < N; ++e) sum += (double)at(e, 56 + k);
+                    std::fprintf(stderr, "[mv tick timing] frame setup: %-20s mean %.0f cycles per env (all frames summed)\n", fn[k], sum / N);
+                }
             }
             double cs[5] = {0, 0, 0, 0, 0};
             for (int e = 0; e < N; ++e) for (int k = 0; k < 5; ++k) cs[k] += (double)at(e, 8 + k);

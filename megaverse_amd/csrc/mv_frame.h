@@ -35,7 +35,7 @@ constexpr int PPL = MV_RASTER_PPL;   // pixels per lane in the raster kernel: a 
 #endif
 constexpr int VIS_SMALL = 256, VIS_LARGE = 1024, VIS_XL = 2048;   // visible primitives kept per frame (TowerBuilding <= 121 slots, Obstacles <= 280;
                                                                   // Collect up to ~1300; a Hex maze seen from its rim: > 1024 of its <= 2146 slots)
-constexpr int LPT_BUCKETS = 256;
+// (LPT_BUCKETS, LPT_SUBS, lpt_sub_capacity: mv_types.h)
 constexpr float CLIP_W = 0.005f;       // NEAR_Z / 2: boxes are clipped against this depth before projecting
 constexpr int MAX_W = 1024, MAX_H = 1024;
 
@@ -160,11 +160,24 @@ struct FrameScratch {
 // ---- pass 1: which primitives can this camera see, and where on the screen?  THREADS (64, 128, 256) threads work on one frame:
 // a whole workgroup (WAVE_LOCAL = false, barriers are __syncthreads()), or -- THREADS = 64, WAVE_LOCAL = true -- one wavefront of a
 // workgroup whose other waves are busy with other frames (ordering points are wave_sync()).
+#ifdef MV_TICK_TIMING
+#define MV_TF(k)                                                                                              \
+    do {                                                                                                      \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                         \
+        if (gv.dbg && threadIdx.x == 0) gv.dbg[(size_t)(frame / gv.num_agents) * 64 + 56 + (k)] += now_ - tf_last_;   \
+        tf_last_ = now_;                                                                                      \
+    } while (0)
+#else
+#define MV_TF(k) do { } while (0)
+#endif
 template <int THREADS, bool WAVE_LOCAL>
 __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int frame, const int W, const int H, FrameScratch &fs)
 {
     static_assert(!WAVE_LOCAL || THREADS == 64, "a wave-local frame setup is one wavefront");
     auto sync = [] { if (WAVE_LOCAL) wave_sync(); else __syncthreads(); };
+#ifdef MV_TICK_TIMING
+    unsigned long long tf_last_ = __builtin_amdgcn_s_memtime();
+#endif
     CamL *const s_cam = fs.cam;
     int &s_cost = fs.cost;
     int *const s_cnt = fs.cnt;
@@ -205,6 +218,7 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
         const V3 o = mat_tmul(s_cam[tid].c, ev - ek);
         s_cam[tid].origin[0] = o.x; s_cam[tid].origin[1] = o.y; s_cam[tid].origin[2] = o.z;
     }
+    MV_TF(0);   // cameras
     // ---- primitive slots, packed (slot order == the order the reference emits drawables == depth-tie order):
     //   layout slabs | terrain slabs (TowerBuilding: the building zone; Rearrange: static boxes + target items) | movable boxes / items
     //   | 2 cones per diamond | 3 per agent
@@ -385,6 +399,7 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
                 }
             }
         }
+        MV_TF(1);   // the slots' records
         // frame-level visibility
         int cls = 0;
         int rect[4] = {0, 0, 0, 0};
@@ -406,6 +421,7 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
             }
             cls = screen_rect(blo, bhi, fr, s_cam, viewer, W, H, rect);
         }
+        MV_TF(2);   // screen rectangles
         const unsigned long long mV = __ballot(cls != 0);
         int *cnt = s_cnt + (rd & 1) * 4;   // double-buffered: one barrier per round
         if (lane == 0) cnt[wave] = __popcll(mV);
@@ -418,6 +434,7 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
         }
         nVis += tot;
         pos += __popcll(mV & ((1ull << lane) - 1ull));
+        MV_TF(3);   // list positions (barrier)
         if (cls != 0 && pos >= maxVis) atomicOr(&gv.episode_status[gv.num_envs + 1], (int)ST_VISIBLE);   // dropped -- and reported by mv_step
         if (cls != 0 && pos < maxVis) {   // at most vis_stride visible primitives per frame
             Prim p;
@@ -440,8 +457,26 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
             myCost += ((rect[1] / TILE_W) - (rect[0] / TILE_W) + 1) * ((rect[3] / TILE_H) - (rect[2] / TILE_H) + 1);
         }
     }
+    MV_TF(4);   // records and rectangles written
     if (myCost) atomicAdd(&s_cost, myCost);
     sync();
+    // The frame appends itself to its cost bin with a RETURNING atomic (its place in the bin's list), a round trip to L2 that nothing else in this
+    // kernel waits for: issued first, the header's stores go out while it is in flight, the dependent store comes last.
+    int binPlace = 0, bin = 0;
+    if (tid == 0) {
+        gv.vis_count[frame] = min(nVis, maxVis);
+        // longest-processing-time-first scheduling of the raster pass: frames are binned by estimated cost, the raster
+        // kernel takes them from the most expensive bin down (frames differ several-fold in cost; starting the heavy
+        // ones first keeps the tail of the launch short); frame_order_kernel turns the bins into a permutation
+        const int tiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H);
+        bin = min(LPT_BUCKETS - 1, (16 * s_cost) / max(tiles, 1));   // 1/16 of "one primitive on every tile"
+        gv.lpt_bucket[frame] = bin;   // (exact raster kernel: frame_order_kernel sorts on these)
+        // fast raster kernel: the frame appends itself to its bin; every raster workgroup prefix-sums the 256 bin counts in its prologue
+        // and looks its frame up -- no sort kernel, no launch boundary.  The order inside a bin is whatever the atomics made it: it only
+        // schedules.  gv.lpt_hists histograms rotate: this pass's raster reads one while the setups of the next steps -- which may run
+        // concurrently, on the simulation stream (mv_api.hip) -- fill the following ones, each clearing the one after its own.
+        binPlace = atomicAdd(&gv.lpt_hist[(gv.lpt_parity * LPT_BUCKETS + bin) * LPT_SUBS + (frame & (LPT_SUBS - 1))], 1);
+    }
     {   // frame header
         float *fh = reinterpret_cast<float *>(gv.vis_hdr + (size_t)frame * FRAME_HDR_BYTES);
         if (tid == 0) fh[FH_COUNT] = __int_as_float(min(nVis, maxVis));
@@ -462,23 +497,10 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
         }
         if (tid < 32) fh[FH_WB + tid] = __uint_as_float(s_wbits[tid]);
     }
-    if (tid == 0) {
-        gv.vis_count[frame] = min(nVis, maxVis);
-        // longest-processing-time-first scheduling of the raster pass: frames are binned by estimated cost, the raster
-        // kernel takes them from the most expensive bin down (frames differ several-fold in cost; starting the heavy
-        // ones first keeps the tail of the launch short); frame_order_kernel turns the bins into a permutation
-        const int tiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H);
-        const int bin = min(LPT_BUCKETS - 1, (16 * s_cost) / max(tiles, 1));   // 1/16 of "one primitive on every tile"
-        gv.lpt_bucket[frame] = bin;   // (exact raster kernel: frame_order_kernel sorts on these)
-        // fast raster kernel: the frame appends itself to its bin; every raster workgroup prefix-sums the 256 bin counts in its prologue
-        // and looks its frame up -- no sort kernel, no launch boundary.  The order inside a bin is whatever the atomics made it: it only
-        // schedules.  gv.lpt_hists histograms rotate: this pass's raster reads one while the setups of the next steps -- which may run
-        // concurrently, on the simulation stream (mv_api.hip) -- fill the following ones, each clearing the one after its own.
-        const int r = atomicAdd(&gv.lpt_hist[gv.lpt_parity * LPT_BUCKETS + bin], 1);
-        gv.lpt_list[(size_t)bin * (gv.num_envs * gv.num_agents) + r] = frame;
-    }
+    if (tid == 0) gv.lpt_list[(size_t)(bin * LPT_SUBS + (frame & (LPT_SUBS - 1))) * lpt_sub_capacity(gv.num_envs * gv.num_agents) + binPlace] = frame;
     if (frame == 0)   // the histogram the NEXT pass fills: last read by a raster pass as many passes ago as there are slots, which this step waited for
-        for (int i = tid; i < LPT_BUCKETS; i += THREADS) gv.lpt_hist[((gv.lpt_parity + 1) % gv.lpt_hists) * LPT_BUCKETS + i] = 0;
+        for (int i = tid; i < LPT_BUCKETS * LPT_SUBS; i += THREADS) gv.lpt_hist[((gv.lpt_parity + 1) % gv.lpt_hists) * (LPT_BUCKETS * LPT_SUBS) + i] = 0;
+    MV_TF(5);   // header, cost bin
     sync();   // the LDS scratch above is reused by the next frame of this workgroup (fused step + setup kernels)
 }
 

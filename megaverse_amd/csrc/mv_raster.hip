@@ -552,7 +552,7 @@ struct FastArgs {   // what raster_fast_kernel needs of the GymView (fewer live 
     const unsigned char *vis_hdr;
     const Prim *vis_prims;
     const short4 *vis_rects;
-    const int *hist, *list;   // this pass's cost histogram [256] and the per-bin frame lists [256][frames] (mv_frame.h)
+    const int *hist, *list;   // this pass's cost histogram [256][LPT_SUBS] and the frame lists per bin and sub-list (mv_frame.h)
     int num_agents, vis_stride, frames;
     // pipelined steps: the step's staged outputs -> the public arrays, by the first ceil(pub_n / 256) workgroups (pub_n = 0: nothing to publish)
     const float *stage_rewards, *stage_true;
@@ -771,7 +771,9 @@ __device__ __forceinline__ FastFrame fast_prologue(const FastArgs &fa, int blk, 
     // counts (bin 255 first) and take entry (position - start) of the bin whose range holds `position`
     __shared__ int s_wsum[4], s_frame;
     {
-        const int h = fa.hist[LPT_BUCKETS - 1 - tid];
+        static_assert(LPT_SUBS == 4, "the bin's counters are read as one int4");
+        const int4 c0 = *reinterpret_cast<const int4 *>(fa.hist + (LPT_BUCKETS - 1 - tid) * LPT_SUBS);   // the bin's LPT_SUBS counters
+        const int h = (c0.x + c0.y) + (c0.z + c0.w);
         int x = h;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -783,7 +785,14 @@ __device__ __forceinline__ FastFrame fast_prologue(const FastArgs &fa, int blk, 
         int base = 0;
         for (int w = 0; w < wave; ++w) base += s_wsum[w];
         const int end = base + x, start = end - h;
-        if (position >= start && position < end) s_frame = fa.list[(size_t)(LPT_BUCKETS - 1 - tid) * fa.frames + (position - start)];
+        if (position >= start && position < end) {   // the bin's lists one after the other
+            const int cs[LPT_SUBS] = {c0.x, c0.y, c0.z, c0.w};
+            int off = position - start, sub = 0;
+#pragma unroll
+            for (int q = 0; q < LPT_SUBS - 1; ++q)
+                if (sub == q && off >= cs[q]) { off -= cs[q]; sub = q + 1; }
+            s_frame = fa.list[(size_t)((LPT_BUCKETS - 1 - tid) * LPT_SUBS + sub) * lpt_sub_capacity(fa.frames) + off];
+        }
         __syncthreads();
     }
     const int frame = __builtin_amdgcn_readfirstlane(s_frame);
@@ -1233,7 +1242,7 @@ static FastArgs fast_args_of(const GymView &gv, const PublishTo *publish)
     const int frames = gv.num_envs * gv.num_agents;
     FastArgs fa;
     fa.vis_hdr = gv.vis_hdr; fa.vis_prims = reinterpret_cast<const Prim *>(gv.vis_prims); fa.vis_rects = reinterpret_cast<const short4 *>(gv.vis_rects);
-    fa.hist = gv.lpt_hist + gv.lpt_parity * LPT_BUCKETS; fa.list = gv.lpt_list; fa.num_agents = gv.num_agents; fa.vis_stride = gv.vis_stride; fa.frames = frames;
+    fa.hist = gv.lpt_hist + gv.lpt_parity * (LPT_BUCKETS * LPT_SUBS); fa.list = gv.lpt_list; fa.num_agents = gv.num_agents; fa.vis_stride = gv.vis_stride; fa.frames = frames;
     fa.stage_rewards = gv.rewards; fa.stage_true = gv.true_objective; fa.stage_done = gv.done;
     fa.pub_rewards = publish ? publish->rewards : nullptr; fa.pub_true = publish ? publish->true_objective : nullptr; fa.pub_done = publish ? publish->done : nullptr;
     fa.pub_n = publish ? frames : 0;

@@ -116,6 +116,14 @@ struct alignas(16) AgentState {   // 128 B
 };
 static_assert(sizeof(AgentState) == 128, "AgentState must be 128 B");
 
+// ---- cost bins of the observation pass (mv_frame.h fills them, mv_raster.hip reads them, mv_api.hip sizes them)
+constexpr int LPT_BUCKETS = 256;
+// Every cost bin has LPT_SUBS counters and lists, picked by frame index: the frames of a launch finish together and most of them fall into
+// the same three or four bins -- one counter per bin made their returning atomics queue up at one L2 address (measured: 1.3 us of a 7 us frame setup).
+constexpr int LPT_SUBS = 4;   // (one 16-byte read per bin in the raster prologue; 8 measured: the step kernel no faster, the prologue slower)
+__host__ __device__ constexpr int lpt_sub_capacity(int frames) { return (frames + LPT_SUBS - 1) / LPT_SUBS; }   // frames that can share one (bin, sub) list
+
+
 // Everything a kernel needs, passed by value.
 struct GymView {
     int32_t num_envs, num_agents;
@@ -152,9 +160,9 @@ struct GymView {
     int32_t vis_stride;        // 256, or 1024 for Collect
     int32_t *lpt_bucket;       // [N*A] cost bin of every frame (raster scheduling)
     int32_t *lpt_order;        // [N*A] frames sorted by cost bin, most expensive first (exact raster kernel)
-    int32_t *lpt_hist;         // [lpt_hists][256] frames per cost bin, rotating over the passes (fast raster kernel)
+    int32_t *lpt_hist;         // [lpt_hists][256][LPT_SUBS] frames per cost bin and sub-list, rotating over the passes (fast raster kernel)
     int32_t lpt_hists;         // number of histograms (slots + 1)
-    int32_t *lpt_list;         // [256][N*A] the frames of every bin in arrival order
+    int32_t *lpt_list;         // [256][LPT_SUBS][ceil(N*A / LPT_SUBS)] the frames of every bin's sub-lists in arrival order
     int32_t lpt_parity;        // which of the histograms this observation pass uses
     uint8_t *vis_hdr;          // [N*A][FRAME_HDR_BYTES] per-frame header for raster_fast_kernel (cameras, light vectors, masks, count)
     unsigned long long *dbg;   // null, or (builds with -DMV_TICK_TIMING, MV_TICK_TIMING=1) [N][64] counters of the TowerBuilding tick
