@@ -24,10 +24,16 @@ def run(scenario, N, A, params):
     g.seed(123); g.reset()
     dones = 0
     t0 = time.perf_counter()
-    for st in range(STEPS):
-        g.sample_random_actions(99, st)
-        g.step()
-        if st % 997 == 0:
+    st = 0
+    while st < STEPS:
+        if (st // 64) % 2 == 0 or st + 4 > STEPS:     # blocks of single ticks ...
+            g.sample_random_actions(99, st)
+            g.step()
+            st += 1
+        else:                                          # ... and blocks of batched calls (same action stream: tick j of a call draws from (seed, st + j))
+            g.step_n(4, "multidiscrete", 99, st)
+            st += 4
+        if st % 997 < 4:
             dones += int(g.get_dones().sum())          # (a host read now and then: the mirrors path)
     g.synchronize(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
