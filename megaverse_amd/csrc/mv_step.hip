@@ -60,16 +60,17 @@ __global__ __launch_bounds__(256) void step_kernel(GymView gv, int W, int H, int
     if (!render) return;
     __syncthreads();   // the tick's stores (same CU: same L1) before the frame setup's loads
     MV_T(6);           // the whole tick as wave 0 saw it (incl. the generator of a finished env), up to the barrier
-    if (A_MAX == 1) frame_setup_body<STEP_THREADS, false>(gv, env, W, H, s_fs[0]);
-    if (A_MAX == 1) MV_T(7);   // frame setup
+    if (A_MAX == 1) {
+        frame_setup_body<STEP_THREADS, false>(gv, env, W, H, s_fs[0]);
+        MV_T(7);   // frame setup
 #ifdef MV_TICK_TIMING
-    if (gv.dbg && threadIdx.x == 0) {
-        const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
-        unsigned long long *d = gv.dbg + (size_t)env * 64;
-        if (!d[49]) { d[52] += rt1 - rt0; d[53] += 1; d[54] = rt0; d[55] = rt1; }
-    }
+        if (gv.dbg && threadIdx.x == 0) {
+            const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+            unsigned long long *d = gv.dbg + (size_t)env * 64;
+            if (!d[49]) { d[52] += rt1 - rt0; d[53] += 1; d[54] = rt0; d[55] = rt1; }
+        }
 #endif
-    else {
+    } else {
         const int A = gv.num_agents, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
         for (int a = wave; a < A; a += nw) frame_setup_body<64, true>(gv, env * A + a, W, H, s_fs[wave]);
     }
