@@ -107,6 +107,7 @@ struct mv_gym {
     bool simOnOwnStream = false;                 // where the last step ran
     hipEvent_t userMark[PIPE_GROUPS] = {};       // completed when the last observation pass of a stepping call is, round-robin over the calls
     hipEvent_t userNow = nullptr;                // recorded on `stream` when the simulation must wait for all of it
+    long dbgCalls = 0;                           // (instrumented builds)
     unsigned long long markCount = 0;             // (64 bits: a training run takes 2^31 steps in a day and a half)
     bool simMustWaitUser = true;                 // the caller's stream holds work the next step depends on (reset, render, device actions, ...)
     hipEvent_t simDone = nullptr;                // after the last kernel on simStream
@@ -1119,6 +1120,10 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
         g->group = (g->group + 1) % PIPE_GROUPS;
     }
     const int fused = render ? 1 : 0;   // the step kernel also builds the frame lists when an observation pass follows
+    if (L->gv.dbg) {   // (instrumented builds: MV_TICK_TIMING_SKIP=n starts the statistics after n stepping calls -- the steady state, not the first ticks of fresh episodes)
+        static const long skip = getenv("MV_TICK_TIMING_SKIP") ? atol(getenv("MV_TICK_TIMING_SKIP")) : 0;
+        if (skip > 0 && ++L->dbgCalls == skip) HIP_TRY(hipMemsetAsync(L->gv.dbg, 0, (size_t)L->N * 64 * sizeof(unsigned long long), sim));
+    }
     // A batched call hands over ONCE: all k step kernels, then all k observation passes.  (Handing over tick by tick when the caller's stream is
     // found idle -- the first call after a synchronisation -- was built and measured on 20-step runs: 15.0-15.6 M obs/s against 16.2 M without;
     // short runs use short calls instead, bench.py's --batch.)

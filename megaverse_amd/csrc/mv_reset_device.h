@@ -45,6 +45,7 @@ __device__ __forceinline__ void reset_env(const GymView &gv, int env, int force_
     EnvHeader *hdr = gv.hdr + env;
     __shared__ __attribute__((aligned(16))) uint32_t s_mt[624];
     __shared__ __attribute__((aligned(16))) uint16_t s_cand[32 * 32];
+    __shared__ __attribute__((aligned(16))) uint16_t s_steps[32 * 32];   // the shuffle's swap partners
     __shared__ __attribute__((aligned(16))) uint8_t s_chunk[CHUNK_BYTES];
     __shared__ MovableObject s_obj[MAX_OBJECTS];
 
@@ -75,13 +76,16 @@ __device__ __forceinline__ void reset_env(const GymView &gv, int env, int force_
     const int matX = rand_range(g, 1, length - matL - 1), matZ = rand_range(g, 1, width - matW - 1);
 
     // spawn candidates x-major (:41-44), shuffled (:46)
+    // (only the first A + 25 entries of the shuffled list are ever used -- agents, then the random objects: they are computed directly,
+    // mv_rng.h: shuffle_prefix_u16; the full shuffle remains for the rare draw the direct form cannot take)
     const int nz = width - 2, ncand = (length - 2) * nz;
-    for (int i = lane; i < ncand; i += 64) {
-        const int x = 1 + i / nz, z = 1 + i % nz;
-        s_cand[i] = (uint16_t)((x << 8) | z);
+    auto candidate = [nz](int i) { const int x = 1 + i / nz, z = 1 + i % nz; return (uint16_t)((x << 8) | z); };
+    static_assert(MAX_AGENTS + 25 <= 64, "one lane per entry of the shuffled prefix");
+    if (!shuffle_prefix_u16(g, ncand, min(ncand, (int)MAX_AGENTS + 25), s_steps, s_cand, candidate)) {
+        for (int i = lane; i < ncand; i += 64) s_cand[i] = candidate(i);
+        wave_sync();
+        shuffle_u16(g, s_cand, ncand);
     }
-    wave_sync();
-    shuffle_u16(g, s_cand, ncand);
 
     const int nSpawn = min(A, ncand);
     const int maxRandomObjects = min(ncand - A, 25);

@@ -140,4 +140,63 @@ __device__ __forceinline__ void shuffle_u16(Mt19937 &g, uint16_t *a, int n)
     }
 }
 
+// std::shuffle of the n items item(0) .. item(n - 1) when only the FIRST `need` (<= 64) entries of the result are looked at afterwards: the same
+// permutation as shuffle_u16, without its chain of n dependent LDS swaps (two round trips each: ~75 us for the 600 spawn candidates of a large room,
+// and a launch lasts as long as its slowest env).
+//   1. The swap partners of all steps come from consecutive generator outputs (step i swaps positions i and j_i <= i; two steps share a draw): one
+//      draw per lane, 64 at a time, written to `steps`.  That needs every draw to be accepted at once (Lemire's method rejects ~range / 2^32 of
+//      them) and the outputs to come from the current state (no regeneration in between): otherwise -> false, nothing consumed, and the caller
+//      runs shuffle_u16.
+//   2. Entry p of the result is found by walking the steps BACKWARDS from position p -- "who was here before step i" -- down to the original index;
+//      one lane per entry, all lanes read the same step (an LDS broadcast).
+// `steps`: n 16-bit words of LDS; out[p], p < need, receives item(original index).
+template <class Item>
+__device__ __forceinline__ bool shuffle_prefix_u16(Mt19937 &g, int n, int need, uint16_t *steps, uint16_t *out, Item item)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    if (n <= 1 || need > 64) return false;
+    if (g.idx >= 624) mt_twist(g);   // (what the first draw would do)
+    const int single = (n % 2) == 0 ? 1 : 0;          // an even n starts with one step of its own (i = 1)
+    const int pairs = (n - 1 - single + 1) / 2;       // then two steps per draw: (i, i + 1), i = 1 + single, 3 + single, ...; the last pair may hold one step
+    const int draws = single + pairs;
+    if (g.idx + draws > 624) return false;
+    bool redo = false;
+    for (int base = 0; base < draws; base += 64) {
+        const int d = base + lane;
+        if (d < draws) {
+            uint32_t y = g.mt[g.idx + d];
+            y ^= y >> 11;
+            y ^= (y << 7) & 0x9d2c5680u;
+            y ^= (y << 15) & 0xefc60000u;
+            y ^= y >> 18;
+            if (d < single) {
+                const uint64_t product = (uint64_t)y * 2ull;
+                redo = redo || (uint32_t)product < 2u;
+                steps[1] = (uint16_t)(product >> 32);
+            } else {
+                const int i = 1 + single + 2 * (d - single);
+                const uint32_t r = (uint32_t)i + 1u, range = r * (r + 1u);
+                const uint64_t product = (uint64_t)y * (uint64_t)range;
+                redo = redo || (uint32_t)product < range;   // (mt_below would look at its threshold now, and perhaps draw again)
+                const uint32_t x = (uint32_t)(product >> 32);
+                const uint32_t p0 = x / (r + 1u), p1 = x - p0 * (r + 1u);
+                steps[i] = (uint16_t)p0;
+                if (i + 1 < n) steps[i + 1] = (uint16_t)p1;
+            }
+        }
+    }
+    if (__ballot(redo) != 0ull) return false;
+    wave_sync();
+    int p = lane;
+#pragma unroll 8
+    for (int i = n - 1; i >= 1; --i) {
+        const int j = (int)steps[i];
+        p = p == i ? j : (p == j ? i : p);
+    }
+    if (lane < need) out[lane] = item(p);
+    g.idx += draws;
+    wave_sync();
+    return true;
+}
+
 }  // namespace mv

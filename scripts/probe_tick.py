@@ -17,6 +17,9 @@ g.set_pipelining(False)
 mode = os.environ.get("PROBE_MODE", "both")   # tick | fused | both
 g.seed(42)
 g.reset()
+for st in range(int(os.environ.get("PROBE_WARM", "0"))):   # (with MV_TICK_TIMING_SKIP set to the same number: statistics of the steady state)
+    g.sample_random_actions(1234, 100000 + st)
+    g.step_no_render()
 for st in range(300 if mode != "fused" else 0):
     g.sample_random_actions(1234, st)
     g.step_no_render()
