@@ -51,6 +51,21 @@ def test_reset_parity(hip, A, seed):
     og.close(); hg.close()
 
 
+def test_many_resets_parity(hip):
+    """2 400 generated episodes against the oracle's.  The kernel computes the used prefix of the shuffled spawn list directly (mv_rng.h:
+    shuffle_prefix_u16) and falls back to the full std::shuffle when one of the ~320 draws is not accepted at once (Lemire's rejection: about one
+    episode in a hundred): both paths come up here, the oracle always runs the plain shuffle."""
+    N, A = 600, 2
+    og, hg = make_pair(N, A, 16, 16, seed=5)
+    for rnd in range(4):
+        if rnd:
+            og.reset(); hg.reset()
+        for e in range(N):
+            d = diff_snapshots(og.snapshot(e), hip_snapshot(hg, e), A)
+            assert not d, (rnd, e, d[:5])
+    og.close(); hg.close()
+
+
 @pytest.mark.parametrize("W,H", [(128, 128), (128, 72), (64, 64), (48, 20)])
 def test_pixel_parity_after_reset_and_rollout(hip, W, H):
     N, A = 6, 2
