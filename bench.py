@@ -167,12 +167,16 @@ class ObsGather:
     slab; before slab b is rendered into again the compute stream waits for its gather.  CPU / gloo (dry run): same bookkeeping
     with async work handles."""
 
-    def __init__(self, dist, torch, local_shape, world, device, cuda, mode="allgather"):
+    def __init__(self, dist, torch, local_shape, world, device, cuda, mode="allgather", channels=4):
         self.dist, self.torch, self.cuda, self.mode, self.world = dist, torch, cuda, mode, world
         self.rank = dist.get_rank() if world > 1 else 0
         self.n_local = local_shape[0]
         self.local = [torch.zeros(local_shape, dtype=torch.uint8, device=device) for _ in range(2)]
-        self.out = [torch.zeros((world * local_shape[0],) + tuple(local_shape[1:]), dtype=torch.uint8, device=device) for _ in range(2)]
+        # channels = 3: what travels is R, G, B (alpha is 255 everywhere): a packing kernel on the communication stream, 3/4 of the link traffic
+        self.channels = channels
+        sent_shape = tuple(local_shape[:-1]) + (channels,)
+        self.sent = self.local if channels == 4 else [torch.zeros(sent_shape, dtype=torch.uint8, device=device) for _ in range(2)]
+        self.out = [torch.zeros((world * local_shape[0],) + sent_shape[1:], dtype=torch.uint8, device=device) for _ in range(2)]
         self.work = [None, None]
         if cuda:
             self.comm = torch.cuda.Stream(device=device)
@@ -193,14 +197,16 @@ class ObsGather:
         """all_gather_into_tensor (RCCL picks the algorithm: a ring is bound by ONE xGMI link), or -- mode "p2p" -- the direct shape SURVEY.md
         8e asks for: every GPU sends its shard to each of its peers and receives theirs, one grouped batch of point-to-point operations
         (ncclGroupStart / ncclSend / ncclRecv under RCCL), so that all 7 links of the fully connected node carry one shard each"""
+        if self.channels != 4:
+            self.sent[b].copy_(self.local[b][..., :self.channels])
         if self.mode != "p2p":
-            return [self.dist.all_gather_into_tensor(self.out[b], self.local[b], async_op=True)]
+            return [self.dist.all_gather_into_tensor(self.out[b], self.sent[b], async_op=True)]
         n, out = self.n_local, self.out[b]
-        out[self.rank * n:(self.rank + 1) * n].copy_(self.local[b], non_blocking=True)
+        out[self.rank * n:(self.rank + 1) * n].copy_(self.sent[b], non_blocking=True)
         ops = []
         for k in range(1, self.world):   # (staggered peers: rank r sends to r + k while it receives from r - k)
             to, frm = (self.rank + k) % self.world, (self.rank - k) % self.world
-            ops.append(self.dist.P2POp(self.dist.isend, self.local[b], to))
+            ops.append(self.dist.P2POp(self.dist.isend, self.sent[b], to))
             ops.append(self.dist.P2POp(self.dist.irecv, out[frm * n:(frm + 1) * n], frm))
         return self.dist.batch_isend_irecv(ops)
 
@@ -256,6 +262,8 @@ def main():
     ap.add_argument("--gather", default="allgather", choices=["allgather", "p2p"],
                     help="N>1: how the observation slabs are assembled: one all_gather_into_tensor (RCCL's choice of algorithm) or grouped point-to-point "
                          "sends / receives, one shard per peer link (the fully connected xGMI shape)")
+    ap.add_argument("--gather-format", default="rgba", choices=["rgba", "rgb"],
+                    help="N>1: what the gather moves: the slab as rendered, or R, G, B packed on the communication stream (alpha is 255 everywhere): 3/4 of the bytes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pixels", default="fast", choices=["fast", "exact"], help="observation arithmetic (DESIGN.md 'pixel tolerance')")
     ap.add_argument("--policy", default="multidiscrete", choices=["multidiscrete", "single-bit"],
@@ -328,7 +336,8 @@ def main():
         gym.set_sample_policy(args.policy)
 
     do_gather = world > 1 and not args.no_gather_obs
-    gather = ObsGather(dist, torch, (frames, H, W, 4), world, "cpu" if single else device, cuda=not dry and not single, mode=args.gather) if world > 1 else None
+    gather = ObsGather(dist, torch, (frames, H, W, 4), world, "cpu" if single else device, cuda=not dry and not single, mode=args.gather,
+                       channels=3 if args.gather_format == "rgb" else 4) if world > 1 else None
     if gather and single:   # the gym renders into device slabs; their host copies are what gloo gathers
         slabs = [torch.zeros((frames, H, W, 4), dtype=torch.uint8, device=device) for _ in range(2)]
     else:
@@ -535,7 +544,7 @@ def main():
             big.sample_random_actions(1234, i); big.step()
         big.synchronize(); torch.cuda.synchronize()
         got = gather.out[last_gathered & 1].cpu()
-        gather_check = bool(torch.equal(got, whole.cpu())) and int(got[..., :3].max()) > 0
+        gather_check = bool(torch.equal(got, whole.cpu()[..., :got.shape[-1]])) and int(got[..., :3].max()) > 0
         big.close()
 
     if rank == 0:
@@ -581,7 +590,7 @@ def main():
         if gather_check is not None:
             line["gather_check"] = gather_check
         if do_gather:
-            slab_bytes = frames * H * W * 4
+            slab_bytes = frames * H * W * gather.channels
             line["value_no_gather"] = total_obs / elapsed_no_gather
             line["ms_per_step_no_gather"] = elapsed_no_gather / args.steps * 1e3
             line["gather"] = {"collective": ("all_gather_into_tensor (RCCL)" if args.gather == "allgather" else "grouped isend / irecv, one shard per peer (RCCL point-to-point)") +

@@ -15,17 +15,17 @@ pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("scenario,agents,mode", [("TowerBuilding", 2, "allgather"), ("ObstaclesHard", 1, "p2p")])
-def test_two_ranks_of_real_gyms_gather_the_single_gym_slab(hip, scenario, agents, mode):
+@pytest.mark.parametrize("scenario,agents,mode,fmt", [("TowerBuilding", 2, "allgather", "rgba"), ("ObstaclesHard", 1, "p2p", "rgba"), ("TowerBuilding", 1, "p2p", "rgb")])
+def test_two_ranks_of_real_gyms_gather_the_single_gym_slab(hip, scenario, agents, mode, fmt):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MV_PIXEL_MODE")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-device", "--check-gather", "--scenario", scenario,
                           "--agents", str(agents), "--envs-per-gpu", "12", "--obs", "48", "32", "--steps", "9", "--warmup", "4", "--no-cpu-baseline",
-                          "--profile-steps", "0", "--no-extra-legs", "--gather", mode], capture_output=True, text=True, timeout=500, env=env)
+                          "--profile-steps", "0", "--no-extra-legs", "--gather", mode, "--gather-format", fmt], capture_output=True, text=True, timeout=500, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["single_device"] is True and rec["config"]["gather_obs"] is True
     assert rec["gather_check"] is True, rec
-    assert rec["gather"]["bytes_received_per_gpu_per_step"] == 12 * agents * 48 * 32 * 4
+    assert rec["gather"]["bytes_received_per_gpu_per_step"] == 12 * agents * 48 * 32 * (3 if fmt == "rgb" else 4)
     assert rec["value"] > 0 and rec["value_no_gather"] > 0
