@@ -272,9 +272,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0,
                     help="ticks per stepping call (mv_step_n): every tick is stepped and rendered in full, the two stream hand-overs are paid once "
                          "per call; 1 = one mv_step per tick; 0 (default) = 8 for runs of 200 steps and more, 2 below that -- the observation passes of a "
-                         "call start when its last step kernel is done, so a run pays about one call of step kernels (k x 30 us) before its passes "
-                         "stream: measured on 20-step runs 15.8 M obs/s with 1 or 2 ticks per call, 15.3 M with 4, 14.3 M with 8; 2000-step runs 15.6 M / "
-                         "17.4 M with 1 / 8.  N>1 with the gather on always steps tick by tick")
+                         "call start when its last step kernel is done, so a run pays about one call of step kernels (k x 20 us) before its passes "
+                         "stream: measured on 20-step runs 16.4 M obs/s with 2 ticks per call (r03a: 15.3 M with 4, 14.3 M with 8); 2000-step runs 17.1 M / "
+                         "17.8 M with 1 / 8.  N>1 with the gather on always steps tick by tick")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the single-step / unpipelined / closed-loop transparency legs")
     ap.add_argument("--profile-steps", type=int, default=256, help="steps of the untimed per-kernel profile loop (HIP events on the gym's stream)")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo run of the launcher + gather pipeline with a stand-in gym")
