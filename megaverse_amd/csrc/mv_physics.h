@@ -375,13 +375,20 @@ __device__ __forceinline__ V3 lerp3(V3 a, V3 b, float rt)
 }
 
 // preStep + playerStep of the controller for one agent
+// reach2 (optional): the largest squared HORIZONTAL distance from the start position of any point the controller sweeps between or stands on this
+// tick -- every sweep runs between two of the points recorded here, so the capsule's axis never leaves that circle (mv_tick_tower.h: which agents of
+// an env can run their controllers at the same time).  Recording it changes nothing else.
 template <int NC, bool OBB = false>
-__device__ __forceinline__ void player_step(AgentState &a, const Col (&col)[NC], float dt)
+__device__ __forceinline__ void player_step(AgentState &a, const Col (&col)[NC], float dt, float *reach2 = nullptr)
 {
     V3 cur = v3(a.pos[0], a.pos[1], a.pos[2]);
     V3 target = cur;
     const V3 original = cur;
     const V3 UP = v3(0, 1, 0);
+    float r2 = 0.0f;
+    auto reached = [&](V3 p) {
+        if (reach2) { const float dx = p.x - original.x, dz = p.z - original.z; r2 = fmax_sel(r2, dx * dx + dz * dz); }
+    };
 
     const bool wasOnGround = on_ground(a);
     a.vvel -= GRAVITY * dt;
@@ -408,10 +415,12 @@ __device__ __forceinline__ void player_step(AgentState &a, const Col (&col)[NC],
             cur = target;
         }
     }
+    reached(cur);
 
     {   // stepForwardAndStrafe
         const V3 hv = v3(a.hvx, 0.0f, a.hvz);
         target = v3(cur.x + hv.x * dt, cur.y + hv.y * dt, cur.z + hv.z * dt);
+        reached(target);
         bool active = true;
 #pragma unroll 1
         for (int it = 0; it < 10; ++it) {   // "int maxIter = 10; while (maxIter-- > 0)" with breaks -> flag
@@ -447,6 +456,7 @@ __device__ __forceinline__ void player_step(AgentState &a, const Col (&col)[NC],
                     if (__float_as_uint(target.x) == __float_as_uint(before.x) && __float_as_uint(target.y) == __float_as_uint(before.y) &&
                         __float_as_uint(target.z) == __float_as_uint(before.z))
                         active = false;
+                    reached(target);
                 }
             }
         }
@@ -464,10 +474,13 @@ __device__ __forceinline__ void player_step(AgentState &a, const Col (&col)[NC],
         } else cur = target;
     }
 
+    reached(cur);
     a.hvx = (cur.x - original.x) / dt;
     a.hvz = (cur.z - original.z) / dt;
 
     recover_up_to_5<NC, OBB>(col, cur);
+    reached(cur);
+    if (reach2) *reach2 = r2;
     a.pos[0] = cur.x; a.pos[1] = cur.y; a.pos[2] = cur.z;
 
     const float speed = sqrtf(a.hvx * a.hvx + a.hvz * a.hvz);

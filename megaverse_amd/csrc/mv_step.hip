@@ -31,7 +31,8 @@ namespace mv {
 
 using namespace tick_tower;
 
-// One workgroup per env: wave 0 runs the tick (one wave per env: physics, scenario logic, auto-reset), the others wait at the barrier;
+// One workgroup per env: wave 0 runs the tick (one wave per env: physics, scenario logic, auto-reset), the others wait at the barrier (several
+// agents: they take their share of the character controllers first);
 // then the workgroup builds the lists of the env's frames (mv_frame.h).  `render` = 0: mv_step_no_render.
 //   one agent:  STEP_THREADS (128) threads work on the env's one frame together.  The tick needs ~150 VGPRs, i.e. 3 waves per SIMD: with
 //               2 waves per env 1024 envs are resident at once (with 4 they take two rounds, and a launch lasts as long as its slowest
@@ -47,7 +48,8 @@ __global__ __launch_bounds__(256) void step_kernel(GymView gv, int W, int H, int
 #ifdef MV_TICK_TIMING
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
 #endif
-    if (threadIdx.x < 64) tower_tick<A_MAX>(gv, env);
+    if (A_MAX > 1) tower_tick<A_MAX, (A_MAX > 1)>(gv, env);   // (several agents: every wave takes part, the controllers are shared out, mv_tick_tower.h)
+    else if (threadIdx.x < 64) tower_tick<A_MAX>(gv, env);
 #ifdef MV_TICK_TIMING
     if (!render && gv.dbg && threadIdx.x == 0) {
         const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();

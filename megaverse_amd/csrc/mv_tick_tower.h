@@ -102,12 +102,25 @@ __device__ __forceinline__ void voxel_of(V3 p, int out[3])
 __device__ __forceinline__ bool in_chunk(int x, int y, int z) { return x >= 0 && x < CX && y >= 0 && y < CY && z >= 0 && z < CZ; }
 
 
-template <int A_MAX>
+// PAR (A_MAX > 1, mv_step.hip): called by ALL waves of the env's workgroup.  The controllers of one env run in action order because agents collide
+// with each other (env.cpp:126) -- but two agents that cannot come within a capsule's width of each other this tick do not care about the order, nor
+// about each other's position at all.  With PAR the waves share the agents out:
+//   * an agent with a neighbour inside (its and the neighbour's speed) x dt + a capsule's width + 0.5 is "near": the near agents run one after the
+//     other, in index order, on wave 0, and see each other's positions as the sequential loop would;
+//   * every other agent runs on whichever wave has least to do, against the PRE-tick positions of all others (which it will not meet);
+//   * every controller records how far it really reached (player_step's reach2); afterwards wave 0 checks every pair that was run apart:
+//     |pre_i - pre_j| > reach_i + reach_j + a capsule's width + 0.1 (horizontally) -- within those circles neither capsule ever enters the other's
+//     sweeps or depenetration, so the results ARE the sequential loop's.  Should a pair fail (a depenetration push longer than the margin), the
+//     env's agents are restored and stepped again in a row.
+// A launch lasts as long as its slowest env: that used to be A controllers in a row, now the env with the largest group of near agents.
+template <int A_MAX, bool PAR = false>
 __device__ __forceinline__ void tower_tick(const GymView &gv, const int env)
 {
+    static_assert(!PAR || A_MAX > 1, "one agent: nothing to share out");
     const int lane = lane_id();
     if (env >= gv.num_envs) return;
     const int A = gv.num_agents;
+    const int wave = PAR ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
 
     MV_T_BEGIN
     const EnvHeader *gh = gv.hdr + env;
@@ -159,41 +172,114 @@ __device__ __forceinline__ void tower_tick(const GymView &gv, const int env)
     // ---- agents: records in LDS (mv_agents.h), one agent's physics fields in registers at a time
     __shared__ AgentState s_ag[A_MAX];
     __shared__ int s_act[A_MAX];
-    agents_load(gv, env, A, s_ag, s_act);
-    MV_T(0);   // loads
     const float dt = DT;
-
-    // ---- actions -> intents (env.cpp:89-122): agents are independent here, one lane each
-    if (lane < A) {
-        AgentState a;
-        phys_load(a, s_ag[lane]);
-        apply_actions(a, s_act[lane], dt, h.p_vertical_look_limit);
-        phys_store(s_ag[lane], a);
-    }
-    wave_sync();
-
-    MV_T(1);   // actions -> intents
+    if (!PAR || wave == 0) {
+        agents_load(gv, env, A, s_ag, s_act);
+        MV_T(0);   // loads
+        // ---- actions -> intents (env.cpp:89-122): agents are independent here, one lane each
+        if (lane < A) {
+            AgentState a;
+            phys_load(a, s_ag[lane]);
+            apply_actions(a, s_act[lane], dt, h.p_vertical_look_limit);
+            phys_store(s_ag[lane], a);
+        }
+        wave_sync();
+        MV_T(1);   // actions -> intents
 #ifdef MV_TICK_TIMING
-    if (lane < 8) s_cast_dbg[lane] = 0;
-    wave_sync();
+        if (lane < 8) s_cast_dbg[lane] = 0;
+        wave_sync();
 #endif
-    // ---- physics, agent by agent (controllers run in addAction order, env.cpp:126)
-#pragma unroll 1
-    for (int i = 0; i < A; ++i) {
-        if (A_MAX > 1 && lane >= 32 && lane < 32 + MAX_AGENTS) {   // capsule colliders of the other agents
+    }
+    // the other agents' capsules as colliders (lanes 32 .. 32 + MAX_AGENTS of the second collider slot): `live` = bit set of the agents whose CURRENT
+    // record counts, the others are taken where the tick found them
+    __shared__ float s_pre[A_MAX][4];   // PAR: x, y, z before the controllers ran, speed x dt
+    auto capsules_for = [&](int i, unsigned live) {
+        if (A_MAX > 1 && lane >= 32 && lane < 32 + MAX_AGENTS) {
             const int j = lane - 32;
             col[1].kind = 0;
             if (j < A && j != i) {
                 col[1].kind = 2;
-                col[1].lo = v3(s_ag[j].pos[0], s_ag[j].pos[1], s_ag[j].pos[2]);
+                col[1].lo = (!PAR || ((live >> j) & 1u)) ? v3(s_ag[j].pos[0], s_ag[j].pos[1], s_ag[j].pos[2]) : v3(s_pre[j][0], s_pre[j][1], s_pre[j][2]);
                 col[1].hi = v3(2 * CAP_HH, 0.0f, 0.0f);
             }
         }
-        AgentState a;
-        phys_load(a, s_ag[i]);
-        player_step(a, col, dt);
-        if (lane == 0) phys_store(s_ag[i], a);
-        wave_sync();
+    };
+    // ---- physics, agent by agent (controllers run in addAction order, env.cpp:126)
+    auto controllers_in_a_row = [&]() {
+#pragma unroll 1
+        for (int i = 0; i < A; ++i) {
+            capsules_for(i, ~0u);
+            AgentState a;
+            phys_load(a, s_ag[i]);
+            player_step(a, col, dt);
+            if (lane == 0) phys_store(s_ag[i], a);
+            wave_sync();
+        }
+    };
+    if (!PAR) controllers_in_a_row();
+    else {
+        __shared__ AgentState s_ag0[A_MAX];   // the records as the controllers found them (a failed check steps the env again from these)
+        __shared__ float s_reach[A_MAX];
+        const int nw = (int)(blockDim.x >> 6);
+        if (wave == 0) {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(s_ag);
+            uint32_t *dst = reinterpret_cast<uint32_t *>(s_ag0);
+            for (int q = lane; q < A * AGENT_DWORDS; q += 64) dst[q] = src[q];
+            if (lane < A) {
+                const AgentState &g = s_ag[lane];
+                s_pre[lane][0] = g.pos[0]; s_pre[lane][1] = g.pos[1]; s_pre[lane][2] = g.pos[2];
+                s_pre[lane][3] = sqrtf(g.hvx * g.hvx + g.hvz * g.hvz) * dt;
+            }
+        }
+        __syncthreads();
+        // who is near whom, and who runs where: the same small scalar computation on every wave
+        const float WIDTH = 2.0f * CAP_R;
+        unsigned nearMask = 0u;
+        for (int i = 0; i < A; ++i)
+            for (int j = i + 1; j < A; ++j) {
+                const float dx = s_pre[i][0] - s_pre[j][0], dz = s_pre[i][2] - s_pre[j][2], r = (s_pre[i][3] + s_pre[j][3]) + (WIDTH + 0.5f);
+                if (dx * dx + dz * dz <= r * r) nearMask |= (1u << i) | (1u << j);
+            }
+        nearMask = (unsigned)__builtin_amdgcn_readfirstlane((int)nearMask);
+        int l0 = __popc(nearMask), l1 = 0, l2 = 0, l3 = 0;   // agents per wave (at most four waves)
+        unsigned mine = wave == 0 ? nearMask : 0u;
+        for (int i = 0; i < A; ++i) {
+            if ((nearMask >> i) & 1u) continue;
+            int w = 0, least = l0;   // the least busy wave; ties: the higher one -- wave 0 has the rest of the tick to itself
+            if (nw > 1 && l1 <= least) { w = 1; least = l1; }
+            if (nw > 2 && l2 <= least) { w = 2; least = l2; }
+            if (nw > 3 && l3 <= least) { w = 3; least = l3; }
+            l0 += w == 0; l1 += w == 1; l2 += w == 2; l3 += w == 3;
+            if (w == wave) mine |= 1u << i;
+        }
+#pragma unroll 1
+        for (int i = 0; i < A; ++i) {
+            if (!((mine >> i) & 1u)) continue;   // (wave-uniform)
+            const bool near = (nearMask >> i) & 1u;
+            capsules_for(i, near ? nearMask : 0u);
+            AgentState a;
+            phys_load(a, s_ag[i]);
+            float r2 = 0.0f;
+            player_step(a, col, dt, &r2);
+            if (lane == 0) { phys_store(s_ag[i], a); s_reach[i] = sqrtf(r2); }
+            wave_sync();
+        }
+        __syncthreads();
+        if (wave != 0) return;   // (the kernel's barrier is next)
+        bool apart = true;   // every pair that did not run in sequence stayed out of each other's way
+        for (int i = 0; i < A; ++i)
+            for (int j = i + 1; j < A; ++j) {
+                if (((nearMask >> i) & 1u) && ((nearMask >> j) & 1u)) continue;
+                const float dx = s_pre[i][0] - s_pre[j][0], dz = s_pre[i][2] - s_pre[j][2], r = (s_reach[i] + s_reach[j]) + (WIDTH + 0.1f);
+                if (!(dx * dx + dz * dz > r * r)) apart = false;
+            }
+        if (__ballot(!apart) != 0ull) {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(s_ag0);
+            uint32_t *dst = reinterpret_cast<uint32_t *>(s_ag);
+            for (int q = lane; q < A * AGENT_DWORDS; q += 64) dst[q] = src[q];
+            wave_sync();
+            controllers_in_a_row();
+        }
     }
 
 #ifdef MV_TICK_TIMING
