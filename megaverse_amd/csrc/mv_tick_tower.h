@@ -273,7 +273,7 @@ __device__ __forceinline__ void tower_tick(const GymView &gv, const int env)
                 const float dx = s_pre[i][0] - s_pre[j][0], dz = s_pre[i][2] - s_pre[j][2], r = (s_reach[i] + s_reach[j]) + (WIDTH + 0.1f);
                 if (!(dx * dx + dz * dz > r * r)) apart = false;
             }
-        if (__ballot(!apart) != 0ull) {
+        if (__ballot(!apart) != 0ull || gv.debug_redo) {
             const uint32_t *src = reinterpret_cast<const uint32_t *>(s_ag0);
             uint32_t *dst = reinterpret_cast<uint32_t *>(s_ag);
             for (int q = lane; q < A * AGENT_DWORDS; q += 64) dst[q] = src[q];

@@ -166,6 +166,7 @@ struct GymView {
     int32_t lpt_parity;        // which of the histograms this observation pass uses
     uint8_t *vis_hdr;          // [N*A][FRAME_HDR_BYTES] per-frame header for raster_fast_kernel (cameras, light vectors, masks, count)
     unsigned long long *dbg;   // null, or (builds with -DMV_TICK_TIMING, MV_TICK_TIMING=1) [N][64] counters of the TowerBuilding tick
+    int32_t debug_redo;        // tests (MV_DEBUG_FORCE_REDO=1): the multi-agent tick takes its "check failed" path every time
 };
 
 // One host-generated episode (Obstacles family): everything Env::reset produces, ready to be swapped in by

@@ -113,6 +113,26 @@ def test_rollout_parity(hip, A, N, steps):
     og.close(); hg.close()
 
 
+@pytest.mark.parametrize("A,N,steps,redo", [(8, 16, 400, False), (4, 8, 300, True), (3, 8, 300, False)])
+def test_multi_agent_controllers_shared_out(hip, monkeypatch, A, N, steps, redo):
+    """Several agents per env: the kernel runs the controllers of agents that cannot meet on different waves, near ones in sequence, and checks
+    afterwards (mv_tick_tower.h); the oracle runs them in a row.  Eight agents in one room: clusters all the time; MV_DEBUG_FORCE_REDO: the
+    "check failed" path -- restore the agents, step them in a row -- on every tick."""
+    if redo:
+        monkeypatch.setenv("MV_DEBUG_FORCE_REDO", "1")
+    og, hg = make_pair(N, A, 16, 16, seed=77)
+    for st in range(steps):
+        set_same_actions(og, hg, N, A, 4321, st)
+        og.step_norender(); hg.step_no_render()
+        ro, rh = og.get_last_rewards(), hg.get_rewards_array()
+        assert np.array_equal(ro.view(np.uint32), rh.view(np.uint32)), (st, ro, rh)
+        if st % 50 == 49 or st == steps - 1:
+            for e in range(N):
+                d = diff_snapshots(og.snapshot(e), hip_snapshot(hg, e), A)
+                assert not d, (st, e, d[:5])
+    og.close(); hg.close()
+
+
 def test_auto_reset_parity_with_short_episodes(hip):
     # negative base episode length -> many envs finish on every tick: stresses done/true_objective/reset ordering
     N, A = 12, 2
