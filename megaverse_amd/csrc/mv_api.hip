@@ -30,7 +30,7 @@ namespace mv {
 void launch_reset(const GymView &gv, int force_all, hipStream_t stream);
 // step kernels: one 256-thread workgroup per env = the tick (wave 0) + the frame setup of the env's frames for a W x H observation
 // (render = 0: tick only)
-void launch_step(const GymView &gv, hipStream_t stream, int W, int H, int render);
+void launch_step(const GymView &gv, hipStream_t stream, int W, int H, int render, hipEvent_t done = nullptr);
 void launch_step_obstacles(const GymView &gv, hipStream_t stream, int W, int H, int render);
 void launch_reset_obstacles(const GymView &gv, const EpisodeBlob *blobs, int *status, int force_all, hipStream_t stream);
 void launch_step_rearrange(const GymView &gv, hipStream_t stream, int W, int H, int render);
@@ -1047,14 +1047,16 @@ int mv_sample_random_actions(mv_gym *g, uint32_t seed, uint32_t step)
     return 0;
 }
 
-static void launch_step_of(const mv_gym *g, const GymView &v, hipStream_t sim, int fused)
+// -> whether `done` rides on the launch (TowerBuilding's launcher); otherwise the caller records it
+static bool launch_step_of(const mv_gym *g, const GymView &v, hipStream_t sim, int fused, hipEvent_t done = nullptr)
 {
     if (g->scenario == SCN_OBSTACLES || g->scenario == SCN_EMPTY) launch_step_obstacles(v, sim, g->w, g->h, fused);
     else if (g->scenario == SCN_COLLECT) launch_step_collect(v, sim, g->w, g->h, fused);
     else if (g->scenario == SCN_REARRANGE) launch_step_rearrange(v, sim, g->w, g->h, fused);
     else if (g->scenario == SCN_SOKOBAN) launch_step_sokoban(v, sim, g->w, g->h, fused);
     else if (g->scenario == SCN_HEX_MEMORY || g->scenario == SCN_HEX_EXPLORE) launch_step_hex(v, sim, g->w, g->h, fused);
-    else launch_step(v, sim, g->w, g->h, fused);
+    else { launch_step(v, sim, g->w, g->h, fused, done); return done != nullptr; }
+    return false;
 }
 
 // One stepping call = k ticks (mv_step: 1; mv_step_n: up to `batch`) of n gyms that share one pair of streams (n = 1: a gym on its own;
@@ -1132,6 +1134,7 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
     std::vector<OutPtrs> outs((size_t)n * k);
     hipEvent_t *evs[PIPE_BATCH_MAX];
     // ---- the k step kernels, back to back on the simulation stream
+    bool simDoneRodeAlong = false;   // (the last step kernel's dispatch packet completes simDone itself)
     for (int j = 0; j < k; ++j) {
         const bool prof = render && L->profCount < L->profMax;
         evs[j] = prof ? &L->profEvents[(size_t)L->profCount * 5] : nullptr;
@@ -1153,14 +1156,16 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
             if (n > 1) { ua.first[i] = envs; ua.gv[i] = v; envs += g->N; }
         }
         if (evs[j]) HIP_TRY(hipEventRecord(evs[j][0], sim));
-        if (n == 1) launch_step_of(L, views[(size_t)j * n], sim, fused);
+        bool simDoneRides = false;
+        if (n == 1) simDoneRides = launch_step_of(L, views[(size_t)j * n], sim, fused, own && j == k - 1 && !evs[j] ? L->simDone : nullptr);
         else {
             for (int i = n; i <= MAX_UNION; ++i) ua.first[i] = envs;
             launch_step_union(ua, sim, L->w, L->h, fused);
         }
         if (evs[j]) HIP_TRY(hipEventRecord(evs[j][1], sim));
+        simDoneRodeAlong = simDoneRodeAlong || simDoneRides;
     }
-    if (own) HIP_TRY(hipEventRecord(L->simDone, sim));   // (not pipelined: stream order does it)
+    if (own && !simDoneRodeAlong) HIP_TRY(hipEventRecord(L->simDone, sim));   // (not pipelined: stream order does it)
     // (every step kernel regenerates / swaps the next episode into the envs it finishes)
     // An env needs a fresh resident episode only at its NEXT reset, normally hundreds of steps away, and two are resident: the status
     // words are read back -- and the refill considered -- every statusPeriod-th step (16; 1 when episodes can be a few ticks long).

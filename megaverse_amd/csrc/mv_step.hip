@@ -22,6 +22,7 @@
 // lookups are ballot + find-first-lane.  Agents inside an env are order dependent (they collide
 // with each other and share voxels) so they run one after another with wave-uniform state.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 
@@ -78,11 +79,12 @@ __global__ __launch_bounds__(256) void step_kernel(GymView gv, int W, int H, int
     }
 }
 
-void launch_step(const GymView &gv, hipStream_t stream, int W, int H, int render)
+// done: an event that completes with the launch, carried by its dispatch packet (cf. mv_raster.h)
+void launch_step(const GymView &gv, hipStream_t stream, int W, int H, int render, hipEvent_t done)
 {
     const dim3 grid(gv.num_envs), block(gv.num_agents == 1 ? STEP_THREADS : 64 * std::min(gv.num_agents, 4));
-    if (gv.num_agents == 1) hipLaunchKernelGGL(step_kernel<1>, grid, block, 0, stream, gv, W, H, render);
-    else hipLaunchKernelGGL(step_kernel<MAX_AGENTS>, grid, block, 0, stream, gv, W, H, render);   // (agent loops are real loops: one multi-agent build)
+    if (gv.num_agents == 1) hipExtLaunchKernelGGL(step_kernel<1>, grid, block, 0, stream, nullptr, done, 0, gv, W, H, render);
+    else hipExtLaunchKernelGGL(step_kernel<MAX_AGENTS>, grid, block, 0, stream, nullptr, done, 0, gv, W, H, render);   // (agent loops are real loops: one multi-agent build)
 }
 
 }  // namespace mv
