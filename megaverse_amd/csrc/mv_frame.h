@@ -88,17 +88,28 @@ __device__ __forceinline__ int screen_rect(const float *blo, const float *bhi, i
     const CamL &cv = cams[viewer];
     float cx[8], cy[8], cw[8];
     float wmin = INFINITY, wmax = -INFINITY;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        V3 v = v3((c & 1) ? bhi[0] : blo[0], (c & 2) ? bhi[1] : blo[1], (c & 4) ? bhi[2] : blo[2]);
-        if (fr == 0) v = mat_tmul(cv.c, v - v3(cv.eye[0], cv.eye[1], cv.eye[2]));
-        else if (fr != 1 + viewer) {
+    // The eight corners in the viewer's camera space: the min corner and the three edge vectors go through the frame's transform once, the
+    // corners are sums of those (an affine map of a box: 51 operations instead of 8 x 18 -- or 8 x 54 under divergence, when the lanes of a wave hold
+    // primitives of different frames).  The rectangle is a conservative bound with a pixel of slack: the last bits of the corners do not matter.
+    V3 base = v3(blo[0], blo[1], blo[2]);
+    V3 ex = v3(bhi[0] - blo[0], 0.0f, 0.0f), ey = v3(0.0f, bhi[1] - blo[1], 0.0f), ez = v3(0.0f, 0.0f, bhi[2] - blo[2]);
+    if (fr != 1 + viewer) {   // (the viewer's own frame: already camera space)
+        if (fr != 0) {        // another camera's / a wall's frame -> world
             const CamL &ck = cams[fr - 1];
-            const V3 wpos = mat_mul(ck.c, v) + v3(ck.eye[0], ck.eye[1], ck.eye[2]);
-            v = mat_tmul(cv.c, wpos - v3(cv.eye[0], cv.eye[1], cv.eye[2]));
+            base = mat_mul(ck.c, base) + v3(ck.eye[0], ck.eye[1], ck.eye[2]);
+            ex = mat_mul(ck.c, ex); ey = mat_mul(ck.c, ey); ez = mat_mul(ck.c, ez);
         }
-        cx[c] = v.x; cy[c] = v.y; cw[c] = -v.z;
-        wmin = fminf(wmin, cw[c]); wmax = fmaxf(wmax, cw[c]);
+        base = mat_tmul(cv.c, base - v3(cv.eye[0], cv.eye[1], cv.eye[2]));
+        ex = mat_tmul(cv.c, ex); ey = mat_tmul(cv.c, ey); ez = mat_tmul(cv.c, ez);
+    }
+    {
+        const V3 c0 = base, c1 = base + ex, c2 = base + ey, c3 = c1 + ey;
+        const V3 cs[8] = {c0, c1, c2, c3, c0 + ez, c1 + ez, c2 + ez, c3 + ez};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            cx[c] = cs[c].x; cy[c] = cs[c].y; cw[c] = -cs[c].z;
+            wmin = fminf(wmin, cw[c]); wmax = fmaxf(wmax, cw[c]);
+        }
     }
     if (wmax < CLIP_W) return 0;
     float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;

@@ -140,14 +140,20 @@ __device__ __forceinline__ void tower_tick(const GymView &gv, const int env)
     col[0].lo = col[0].hi = col[1].lo = col[1].hi = v3(0, 0, 0);
     const MovableObject *gobj = gv.objects + (size_t)env * MAX_OBJECTS;
     const int oi[2] = {lane - 16, lane < 32 ? 48 + lane : -1};
+    // (the records are loaded whether or not the header's counts will keep them -- every env owns MAX_OBJECTS / MAX_BOXES entries --: the loads go out
+    // together with the header's instead of one memory round trip behind it)
+    static_assert(48 + 32 <= MAX_OBJECTS && TOWER_BOXES <= MAX_BOXES, "lane -> record mapping");
+    MovableObject po[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        if (oi[k] >= 0) po[k] = gobj[oi[k]];
+    LayoutBox pb{{0, 0, 0}, 0, {0, 0, 0}, 0};
+    if (lane < TOWER_BOXES) pb = gv.boxes[(size_t)env * MAX_BOXES + lane];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         ob.valid[k] = oi[k] >= 0 && oi[k] < h.num_objects;
         ob.x[k] = ob.y[k] = ob.z[k] = 0; ob.state[k] = 0;
-        if (ob.valid[k]) {
-            const MovableObject o = gobj[oi[k]];
-            ob.x[k] = o.x; ob.y[k] = o.y; ob.z[k] = o.z; ob.state[k] = o.state;
-        }
+        if (ob.valid[k]) { ob.x[k] = po[k].x; ob.y[k] = po[k].y; ob.z[k] = po[k].z; ob.state[k] = po[k].state; }
     }
     auto object_collider = [&](int k) {
         if (ob.valid[k] && ob.state[k] == 0) {
@@ -159,7 +165,7 @@ __device__ __forceinline__ void tower_tick(const GymView &gv, const int env)
     };
     if (lane < TOWER_BOXES) {
         if (lane < h.num_boxes) {
-            const LayoutBox b = gv.boxes[(size_t)env * MAX_BOXES + lane];
+            const LayoutBox b = pb;
             if (b.type & VX_SOLID) {
                 col[0].kind = 1;
                 col[0].lo = v3(float(b.min[0]), float(b.min[1]) - CAP_HH, float(b.min[2]));
