@@ -1,36 +1,15 @@
 #!/bin/bash
-# round 3, fourth GPU pass: where the Mixed observation time goes (kernel trace), raster split sweep at 64x64
+# round 3, last pass (after the r03c profile: shared-out controllers, simDone on the dispatch packet, box corners as sums, records loaded beside the header):
+# headline bench (all legs + CPU baseline), the driver's short form, kernel tables pipelined and unpipelined
 cd /tmp && export TMPDIR=/tmp
-R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/${1:-r03d}
-mkdir -p $OUT
-cd $R
-export BOXOBAN_LEVELS=$R/tests/golden/boxoban
-B="python bench.py --steps 600 --warmup 50 --no-cpu-baseline --profile-steps 64 --no-extra-legs"
-for sp in 1 2 4; do
-  MV_RASTER_SPLIT=$sp timeout 300 $B --scenario Mixed --obs 64 64 > $OUT/bench_mixed64_split$sp.json 2> $OUT/bench_mixed64_split$sp.err
-done
-for sc in HexMemory Collect TowerBuilding; do
-  for sp in 1 2 4; do
-    MV_RASTER_SPLIT=$sp timeout 300 $B --scenario $sc --obs 64 64 > $OUT/bench_${sc}64_split$sp.json 2> $OUT/bench_${sc}64_split$sp.err
-  done
-done
-MV_RASTER_SPLIT=2 timeout 300 $B --scenario Mixed --obs 128 128 > $OUT/bench_mixed128_split2.json 2> $OUT/bench_mixed128_split2.err
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r03d; mkdir -p $O
+cd $R; timeout 600 python bench.py > $O/tower_bench.json 2> $O/tower_bench.err
+timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/tower_bench_driver_style.json 2> $O/tower_bench_driver_style.err
 cd /tmp
-for sp in 1 4; do
-MV_RASTER_SPLIT=$sp MV_PIPELINE=0 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/db_mixed_$sp -o run -- python $R/bench.py --scenario Mixed --obs 64 64 --steps 200 --warmup 20 --no-cpu-baseline --profile-steps 0 --no-extra-legs --batch 1 > $OUT/mixed_stats_$sp.log 2>&1
-python $R/scripts/rocpd_summary.py $OUT/db_mixed_$sp/run_results.db > $OUT/mixed64_unpipelined_split${sp}_kernel_stats.csv 2>> $OUT/mixed_stats_$sp.log
-done
-rm -rf $OUT/db_*
-cd $R
-python - <<PY
-import json,glob,os
-for f in sorted(glob.glob("$OUT/bench_*.json")):
-    try:
-        l=json.loads(open(f).read().strip().splitlines()[-1])
-        r=l.get("roofline",{}); p=l.get("roofline_physics",{})
-        print(os.path.basename(f), "%.2fM %.4fms"%(l["value"]/1e6,l["ms_per_step"]), "raster %.4f step %.4f"%(r.get("avg_launch_ms",0),p.get("avg_launch_ms",0)))
-    except Exception as e:
-        print(os.path.basename(f), "ERR", e, open(f.replace(".json",".err")).read()[-600:])
-PY
-head -8 $OUT/mixed64_unpipelined_split*_kernel_stats.csv
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/db1 -o run -- python $R/bench.py --steps 400 --warmup 50 --no-cpu-baseline --profile-steps 0 --no-extra-legs > $O/l1.log 2>&1
+python $R/scripts/rocpd_summary.py $O/db1/run_results.db > $O/tower_kernel_stats.csv
+MV_PIPELINE=0 timeout 300 rocprofv3 --kernel-trace --stats -d $O/db2 -o run -- python $R/bench.py --steps 400 --warmup 50 --no-cpu-baseline --profile-steps 0 --no-extra-legs --batch 1 > $O/l2.log 2>&1
+python $R/scripts/rocpd_summary.py $O/db2/run_results.db > $O/tower_unpipelined_kernel_stats.csv
+rm -rf $O/db1 $O/db2
+for f in tower_bench tower_bench_driver_style; do tail -1 $O/$f.json | python -c "import json,sys; l=json.loads(sys.stdin.read()); print('$f', round(l['value']/1e6,2), round(l['ms_per_step']*1e3,2), {k[6:]:round(v/1e6,2) for k,v in l.items() if k.startswith('value_')})"; done
+sed -n 3,4p $O/tower_kernel_stats.csv | cut -c1-120; sed -n 3,4p $O/tower_unpipelined_kernel_stats.csv | cut -c1-120
