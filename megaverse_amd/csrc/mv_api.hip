@@ -887,6 +887,7 @@ static int refill_episodes(mv_gym *g)
     const bool starved = (g->hStatus[N + 1] & ST_STARVED) != 0;
     if (starved && g->hostEpisodes()) {   // recover: take the current counts and upload synchronously below
         HIP_TRY(hipStreamSynchronize(g->simStream));
+        if (!g->simOnOwnStream) HIP_TRY(hipStreamSynchronize(g->stream));   // (closed-loop / unpipelined steps run on the caller's stream, which may be a non-blocking one)
         HIP_TRY(hipStreamSynchronize(g->copyStream));
         const int keep = g->hStatus[N + 1];
         HIP_TRY(hipMemcpy(g->hStatus, g->dStatus, (size_t)(N + 2) * sizeof(int), hipMemcpyDeviceToHost));
@@ -941,11 +942,27 @@ static int read_back_status(mv_gym *g, hipStream_t after)
     return 0;
 }
 
+// mv_set_actions_device keeps the caller's multi-discrete buffer until the next step kernel reads it.  Whatever else touches the actions or
+// comes between the two -- a reset, a host-side setter -- first turns the pending buffer into bitmasks (on the caller's stream, where the
+// buffer's producer ran), so that the buffer is read NOW, while it is certainly alive, and the last writer wins as it did when
+// mv_set_actions_device converted at once.
+static int flush_device_actions(mv_gym *g)
+{
+    if (!g->mdActions) return 0;
+    const int n = g->N * g->A;
+    hipLaunchKernelGGL(masks_from_multidiscrete_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, g->mdActions, g->gv.actions, n);
+    HIP_TRY(hipGetLastError());
+    g->mdActions = nullptr;
+    g->simMustWaitUser = true;
+    return 0;
+}
+
 int mv_reset(mv_gym *g)
 {   // MegaverseGym::reset (megaverse.cpp:76-93) -> VectorEnv::reset (vector_env.cpp:110-120)
     if (check(g)) return -1;
     HIP_TRY(hipSetDevice(g->device));
     if (sim_join(g)) return -1;
+    if (flush_device_actions(g)) return -1;   // (a buffer handed over before the reset is read now, not by whatever step comes after it)
     if (g->hostEpisodes()) {
         // the periodic status read-back may be up to 15 ticks old: an env that auto-reset since then has consumed its
         // resident episode without the host knowing -- take the current counts before deciding what to upload
@@ -984,6 +1001,10 @@ int mv_set_actions(mv_gym *g, int32_t env, int32_t agent, const int32_t *actions
 {
     if (check(g)) return -1;
     if (env < 0 || env >= g->N || agent < 0 || agent >= g->A) return fail("mv_set_actions: index out of range");
+    if (g->mdActions) {   // device actions pending: they are converted now, and the host's (uploaded by the next step) then win, as the last writer
+        HIP_TRY(hipSetDevice(g->device));
+        if (flush_device_actions(g)) return -1;
+    }
     int idx = 0, mask = 0;
     for (int i = 0; i < n && i < 6; ++i) {
         if (actions[i] > 0) mask |= 1 << (idx + actions[i]);
@@ -999,6 +1020,7 @@ int mv_set_actions_batched(mv_gym *g, const int32_t *host_actions)
     if (check(g)) return -1;
     HIP_TRY(hipSetDevice(g->device));
     const int n = g->N * g->A;
+    g->mdActions = nullptr;   // (this call sets every agent's action: a pending device buffer is superseded, and no longer referenced)
     HIP_TRY(hipMemcpyAsync(g->dMultiDiscrete, host_actions, (size_t)n * 6 * sizeof(int32_t), hipMemcpyHostToDevice, g->stream));
     hipLaunchKernelGGL(masks_from_multidiscrete_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, g->dMultiDiscrete, g->gv.actions, n);
     HIP_TRY(hipGetLastError());
@@ -1250,7 +1272,7 @@ int mv_step_n(mv_gym *g, int32_t k, int32_t policy, uint32_t seed, uint32_t firs
         const int n = std::min(chunk, k - done);
         const int r = step_impl(g, true, n, policy, seed, first_step_index + (uint32_t)done);
         if (r < 0) return -1;
-        if (r > 0) { g->warning = g_err; rc = 1; }
+        if (r > 0) { g->warning += (g->warning.empty() ? "" : " | ") + g_err; rc = 1; }   // (every chunk's warning text is kept)
     }
     if (rc) { g_err = g->warning; g->warning.clear(); }
     return rc;

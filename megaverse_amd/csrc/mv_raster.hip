@@ -560,6 +560,7 @@ struct FastArgs {   // what raster_fast_kernel needs of the GymView (fewer live 
     float *pub_rewards, *pub_true;
     uint8_t *pub_done;
     int pub_n;
+    int planar;   // 1: tiles that one face of one world box covers take the planar path (planar_tile); 0: every tile takes the general one (MV_PLANAR=0, comparisons)
 };
 
 // true_objective is only ever recorded by a finishing env (vector_env.cpp:96-101): the others keep the value of their last episode
@@ -675,6 +676,33 @@ __device__ __forceinline__ unsigned fast_other(int pos, const float4 *s_vis, con
     return hit_key<POS_MASK>(hit, t, pos);
 }
 
+// The part of Phong every kind of hit shares: depth t along the pixel's ray, N . (L - P) and N . (-P) (both unnormalised in (L - P) / P), the
+// pixel's dc . dc and L . dc, the colour's bytes as floats -> RGBA8.  (One function for the general and the planar-tile path: the same
+// operations in the same order, so a tile drawn by either has the same bytes.)
+__device__ __forceinline__ unsigned phong_tail(float t, float ndl, float nv, float a2, float ldc, float cr, float cg, float cb)
+{
+    // |L - P|^2 = |L|^2 - 2 t (L . dc) + t^2 (dc . dc)
+    const float ta = t * a2;
+    const float len2LP = __builtin_fmaf(t, ta - 2.0f * ldc, 20.0f);
+    const float rs = __builtin_amdgcn_rsqf(len2LP);
+    const float intensity = __builtin_fmaxf(0.0f, ndl * rs);
+    float spec255 = 0.0f;
+    if (intensity > 0.001f) {
+        // V . R with V = -P unnormalised: 2 (N . Ld)(N . -P) + Ld . P
+        const float vr = __builtin_fmaf(2.0f * intensity, nv, (t * (ldc - ta)) * rs);
+        const float p2 = t * ta;   // |P|^2
+        if (vr > 0.0f && vr * vr > SPEC_COS2 * p2) {
+            const float cosv = __builtin_fminf(vr * __builtin_amdgcn_rsqf(p2), 1.0f);
+            spec255 = 255.0f * __builtin_amdgcn_exp2f(300.0f * __builtin_amdgcn_logf(cosv));
+        }
+    }
+    const float AMB = float(0x55) / 255.0f, DIFL = (float(0xbb) / 255.0f) * (float(0xaa) / 255.0f);
+    const float sc = __builtin_fmaf(DIFL, intensity, AMB);
+    const float r8 = __builtin_fmaf(cr, sc, spec255), g8 = __builtin_fmaf(cg, sc, spec255), b8 = __builtin_fmaf(cb, sc, spec255);
+    // v_cvt_pk_u8_f32: round to nearest (even on ties; the exact kernel rounds ties up: they do not occur), saturate, insert the byte
+    return __builtin_amdgcn_cvt_pk_u8_f32(b8, 2, __builtin_amdgcn_cvt_pk_u8_f32(g8, 1, __builtin_amdgcn_cvt_pk_u8_f32(r8, 0, 0xff000000u)));
+}
+
 // Phong (Magnum Shaders::Phong, uniforms of magnum_env_renderer.cpp:200-203) for the winning hit of a pixel; 0xff000000 when there is none
 // the winning primitive's record (lo, hi) and -- for the curved kinds -- the depth and normal kept with the hit -> the pixel's colour
 template <bool SHAPES>
@@ -711,27 +739,7 @@ __device__ __forceinline__ unsigned shade_rec(const float4 lo, const float4 hi, 
             nv = -dot(N, P);
             ndl = dot(N, v3(0.0f - P.x, 4.0f - P.y, 2.0f - P.z));
         }
-        // |L - P|^2 = |L|^2 - 2 t (L . dc) + t^2 (dc . dc)
-        const float ta = t * a2;
-        const float len2LP = __builtin_fmaf(t, ta - 2.0f * ldc, 20.0f);
-        const float rs = __builtin_amdgcn_rsqf(len2LP);
-        const float intensity = __builtin_fmaxf(0.0f, ndl * rs);
-        float spec255 = 0.0f;
-        if (intensity > 0.001f) {
-            // V . R with V = -P unnormalised: 2 (N . Ld)(N . -P) + Ld . P
-            const float vr = __builtin_fmaf(2.0f * intensity, nv, (t * (ldc - ta)) * rs);
-            const float p2 = t * ta;   // |P|^2
-            if (vr > 0.0f && vr * vr > SPEC_COS2 * p2) {
-                const float cosv = __builtin_fminf(vr * __builtin_amdgcn_rsqf(p2), 1.0f);
-                spec255 = 255.0f * __builtin_amdgcn_exp2f(300.0f * __builtin_amdgcn_logf(cosv));
-            }
-        }
-        const float AMB = float(0x55) / 255.0f, DIFL = (float(0xbb) / 255.0f) * (float(0xaa) / 255.0f);
-        const float sc = __builtin_fmaf(DIFL, intensity, AMB);
-        const float r8 = __builtin_fmaf(float((color >> 16) & 255u), sc, spec255), g8 = __builtin_fmaf(float((color >> 8) & 255u), sc, spec255),
-                    b8 = __builtin_fmaf(float(color & 255u), sc, spec255);
-        // v_cvt_pk_u8_f32: round to nearest (even on ties; the exact kernel rounds ties up: they do not occur), saturate, insert the byte
-        rgba = __builtin_amdgcn_cvt_pk_u8_f32(b8, 2, __builtin_amdgcn_cvt_pk_u8_f32(g8, 1, __builtin_amdgcn_cvt_pk_u8_f32(r8, 0, 0xff000000u)));
+        rgba = phong_tail(t, ndl, nv, a2, ldc, float((color >> 16) & 255u), float((color >> 8) & 255u), float(color & 255u));
     }
     return rgba;
 }
@@ -856,6 +864,156 @@ __device__ __forceinline__ void box_run(unsigned long long m, int k, const V3 (&
 
 }  // namespace
 
+// ---- planar tiles ------------------------------------------------------------------------------------------------------------------------
+// Half of a TowerBuilding frame's non-empty tiles show ONE face of ONE axis-aligned world box (floor, a wall, the side of a near box) and
+// nothing else -- and the general path still pays a full ray (three v_rcp_f32), a slab test per culling survivor and the entry-axis selects
+// of the shading for every pixel of them.  Before a wave sets up any ray it therefore CLASSIFIES its tile (when the frame's list fits one
+// culling round, every survivor is a world box and there are at most four of them): for a ray o + t d that enters a box through its face on
+// axis k (plane offset p_k, front-facing: sign(p_k) d_k > 0) the hit lies inside the face's edge on axis m at bound b_m iff
+//     sign(p_k) (p_k d_m - b_m d_k) >= 0      (lo edge; reversed for the hi edge),
+// and d is an AFFINE function of the pixel (mv_frame.h: dw = col[i] + row[j] + c2), so each such expression takes its extremes over a tile at
+// the tile's four corner pixels.  Lane 16 s + q looks at survivor s: q = 4 f + e < 12 is edge e of candidate face f (the face of axis f the
+// eye is outside of, if any), q = 12 + f is that face's facing / depth-range test; all four corners per lane, against a margin that is
+// two orders of magnitude above the rounding of either arithmetic (PLANAR_MARGIN) and ~1 % of a pixel.  Three ballots and ~40 scalar bit
+// operations later the wave knows, for every survivor, "every ray of the tile enters through face f" / "no ray of the tile can hit it":
+//   * exactly one survivor can be hit and one of its faces covers the tile: planar_tile() -- one v_rcp_f32 per pixel, t = p_k / d_k is the
+//     same product the slab test forms, the face constants are wave-uniform, and the shared phong_tail() makes the bytes identical to the
+//     general path's (tests/test_fast_pixels_gpu.py: test_planar_tiles_change_no_byte);
+//   * no survivor can be hit: the clear colour;
+//   * otherwise the general path, minus the survivors that cannot be hit.
+// Reference for what is drawn: magnum_env_renderer.cpp:288-330 (depth-tested, back-face-culled boxes), :200-203 (Phong uniforms).
+constexpr float PLANAR_MARGIN = 2e-4f;
+
+struct TileClass { int kind, pos, axis; float plane; };
+
+// corner: this wave's 16 floats of LDS scratch.  mvis: the culling survivors (<= 4, all world boxes, list positions < 64); refined in place.
+__device__ __forceinline__ TileClass classify_tile(unsigned long long &mvis, const float4 *s_vis, const float4 *s_col, const float4 *s_row, float nz0, float nz1,
+                                                   float nz2, float *corner, int tx0, int tx1, int ty0, int ty1)
+{
+    // the survivors' list positions (wave-uniform)
+    const int n = __popcll(mvis);
+    unsigned long long m = mvis;
+    const int p0 = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    const int p1 = m ? __ffsll((long long)m) - 1 : p0;
+    m &= m - 1;
+    const int p2 = m ? __ffsll((long long)m) - 1 : p0;
+    m &= m - 1;
+    const int p3 = m ? __ffsll((long long)m) - 1 : p0;
+    // Per-lane constants.  Which lanes are facing lanes / hi-side edges / survivor s / corner-ray producers are CONSTANT lane masks (inverse
+    // ballots: a select by one costs no VGPR and no compare).  The lane's axes k and m are needed as LDS addresses; they are derived from the
+    // lane id HERE, for every tile (two-bit table look-ups in 32-bit literals, ~8 instructions): held in registers across the tile loop they
+    // would take from the general path the registers it needs at seven waves per SIMD (the compiler spilled them, with a vmcnt(0) wait per reload)
+    int l;   // the lane id (volatile: two instructions per tile, not a register -- or a spill slot -- across the tile loop)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    const bool facing = __builtin_amdgcn_inverse_ballot_w64(0xf000f000f000f000ull), hiSide = __builtin_amdgcn_inverse_ballot_w64(0xaaaaaaaaaaaaaaaaull);
+    const bool sv0 = __builtin_amdgcn_inverse_ballot_w64(0xffffull), sv1 = __builtin_amdgcn_inverse_ballot_w64(0xffff0000ull),
+               sv2 = __builtin_amdgcn_inverse_ballot_w64(0xffff00000000ull);
+    int mypos = p3;
+    mypos = sv2 ? p2 : mypos;
+    mypos = sv1 ? p1 : mypos;
+    mypos = sv0 ? p0 : mypos;
+    // lane 16 s + q: q = 4 f + e < 12: edge e of face f (axis k = f; e >> 1 picks m among the two other axes, e & 1 the hi bound); q = 12 + f: the
+    // facing lane of face f.  k(q) = 0000 1111 2222 012(2), m(q) likewise (1 1 2 2, 2 2 0 0, 0 0 1 1, - - - -), two bits per q
+    const int q2 = (l & 15) << 1;
+    const int ck = (int)((0xa4aa5500u >> q2) & 3u), cm = (int)((0x59500aa5u >> q2) & 3u);
+    const int cb = cm + ((l & 1) << 2);   // the bound's place in the record: m, + 4 on the hi side
+    const unsigned long long validMask = (n >= 4 ? ~0ull : (1ull << (16 * n)) - 1ull) & 0x7fff7fff7fff7fffull;   // survivor s < n, lane q < 15
+    // the rays of the tile's four corner pixels, world axes: the same sums the pixels' own rays are (fast_prologue's tables)
+    {
+        const bool cr = __builtin_amdgcn_inverse_ballot_w64(0xaaaull), ct = __builtin_amdgcn_inverse_ballot_w64(0xcccull);   // lane 4 a + c: corner c (bit 0: right, bit 1: top), axis a
+        const bool a0 = __builtin_amdgcn_inverse_ballot_w64(0xfull), a1 = __builtin_amdgcn_inverse_ballot_w64(0xf0ull), prod = __builtin_amdgcn_inverse_ballot_w64(0xfffull);
+        const int xc = cr ? tx1 : tx0, yc = ct ? ty1 : ty0;
+        float nz = nz2;
+        nz = a1 ? nz1 : nz;
+        nz = a0 ? nz0 : nz;
+        const int ax = min(l >> 2, 2) + 1;
+        const float dcorner = (reinterpret_cast<const float *>(s_col)[4 * xc + ax] + reinterpret_cast<const float *>(s_row)[4 * yc + ax]) + nz;
+        if (prod) corner[l] = dcorner;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (a wave's LDS operations execute in order: only the compiler has to keep them so)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const float *rec = reinterpret_cast<const float *>(s_vis) + 8 * mypos;
+    const float lok = rec[ck], hik = rec[4 + ck];
+    const float b = rec[cb];
+    const float4 Dk = *reinterpret_cast<const float4 *>(corner + 4 * ck), Dm = *reinterpret_cast<const float4 *>(corner + 4 * cm);
+    const bool cand = lok > 0.0f || hik < 0.0f;    // the eye is outside the box along k: the face towards it can be entered
+    const float p = lok > 0.0f ? lok : hik;
+    const float sg = p > 0.0f ? 1.0f : -1.0f;
+    // edge lanes: g = +-sg (p d_m - b d_k); facing lanes: g = sg d_k
+    const float ps = facing ? 0.0f : (hiSide ? -sg : sg) * p, bs = facing ? -sg : (hiSide ? -sg : sg) * b;
+    const float g0 = __builtin_fmaf(ps, Dm.x, -(bs * Dk.x)), g1 = __builtin_fmaf(ps, Dm.y, -(bs * Dk.y)), g2 = __builtin_fmaf(ps, Dm.z, -(bs * Dk.z)),
+                g3 = __builtin_fmaf(ps, Dm.w, -(bs * Dk.w));
+    const float gmin = __builtin_fminf(__builtin_fminf(g0, g1), __builtin_fminf(g2, g3)), gmax = __builtin_fmaxf(__builtin_fmaxf(g0, g1), __builtin_fmaxf(g2, g3));
+    const float ap = __builtin_fabsf(p);
+    // facing lanes also keep the face's depth t = |p| / (sg d_k) inside [2 NEAR_Z, FAR_Z / 2] (the planar path has no range test per pixel)
+    const float thrI = facing ? ap * (2.0f / FAR_Z) : PLANAR_MARGIN * (ap + __builtin_fabsf(b));
+    const float thrM = facing ? 0.0f : -thrI;
+    const unsigned long long I = __ballot(cand && gmin >= thrI) & validMask;       // edge: inside at all four corners; facing: front-facing, not too far
+    const unsigned long long M = __ballot(!cand || gmax <= thrM) & validMask;      // edge: outside at all four corners; facing: never front-facing / no such face
+    const unsigned long long Nr = __ballot(gmax <= ap * (0.5f / NEAR_Z));       // facing: not too near
+    constexpr unsigned long long Q0 = 0x0001000100010001ull;   // bit 0 of every survivor's sixteen
+    constexpr unsigned long long FACES = Q0 | (Q0 << 4) | (Q0 << 8);
+    unsigned long long X = I & (I >> 1);   // bit 4 f: all four edges of face f
+    X &= X >> 2;
+    unsigned long long Y = M | (M >> 1);   // bit 4 f: any edge of face f
+    Y |= Y >> 2;
+    const unsigned long long Fa = ((I >> 12) & Q0) | ((I >> 9) & (Q0 << 4)) | ((I >> 6) & (Q0 << 8));     // the facing lanes' bits, moved to bit 4 f
+    const unsigned long long Fm = ((M >> 12) & Q0) | ((M >> 9) & (Q0 << 4)) | ((M >> 6) & (Q0 << 8));
+    const unsigned long long Fn = ((Nr >> 12) & Q0) | ((Nr >> 9) & (Q0 << 4)) | ((Nr >> 6) & (Q0 << 8));
+    const unsigned long long insideF = X & Fa & Fn & FACES;           // every ray of the tile enters through face f
+    const unsigned long long missF = (Fm | (Fa & Y)) & FACES;         // no ray of the tile enters through face f
+    const unsigned long long missS = missF & (missF >> 4) & (missF >> 8) & Q0;
+    const unsigned long long validS = n >= 4 ? Q0 : Q0 & ((1ull << (16 * n)) - 1ull);
+    const unsigned long long live = validS & ~missS;
+    TileClass tc;
+    tc.kind = 0; tc.pos = 0; tc.axis = 0; tc.plane = 0.0f;
+    if (live == 0ull) { tc.kind = 2; return tc; }
+    if ((live & (live - 1)) == 0ull) {   // one survivor left
+        const int sl = (__ffsll((long long)live) - 1) >> 4;
+        const unsigned faces = (unsigned)(insideF >> (16 * sl)) & 0x111u;
+        if (faces) {
+            const int f = (__ffs((int)faces) - 1) >> 2;
+            tc.kind = 1;
+            tc.pos = sl == 0 ? p0 : sl == 1 ? p1 : sl == 2 ? p2 : p3;
+            tc.axis = f;
+            tc.plane = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p), 16 * sl + 12 + f));
+            return tc;
+        }
+    }
+    if (missS & 1ull) mvis &= ~(1ull << p0);
+    if (missS & (1ull << 16)) mvis &= ~(1ull << p1);
+    if (missS & (1ull << 32)) mvis &= ~(1ull << p2);
+    if (missS & (1ull << 48)) mvis &= ~(1ull << p3);
+    return tc;
+}
+
+// the pixels of a tile that face `k` (plane offset `plane` from the eye along world axis k) of the world box at list position `pos` covers
+template <int NP>
+__device__ __forceinline__ void planar_tile(int pos, int k, float plane, const float4 *s_vis, const float *s_hdr, const float4 *s_col, const float4 *s_row,
+                                            const float2 *s_rowq, const float *s_colq, float nzk, int px, int py0, int W, int H, uint32_t *out)
+{
+    const unsigned color = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_uint(reinterpret_cast<const float *>(s_vis)[8 * pos + 7]));
+    const float cr = float((color >> 16) & 255u), cg = float((color >> 8) & 255u), cb = float(color & 255u);
+    const float lk = uniform_f32(s_hdr[FH_LREL + k]);   // the light along k, relative to the eye (frame 0: world axes)
+    const float lks = plane > 0.0f ? lk : 0.0f - lk;    // sgn (Lrel_k - t d_k) = t |d_k| - (d_k < 0 ? -Lrel_k : Lrel_k), and d_k has the plane offset's sign
+    const int pxc = min(px, W - 1);
+    const float colk = reinterpret_cast<const float *>(s_col)[4 * pxc + 1 + k];
+    const float cq = s_colq[pxc];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int py = py0 + TILE_H * j, pyc = min(py, H - 1);
+        const float rowk = reinterpret_cast<const float *>(s_row)[4 * pyc + 1 + k];
+        const float2 rq = s_rowq[pyc];
+        const float dk = (colk + rowk) + nzk;                 // the ray's component along k: the same sum the general path forms
+        const float t = plane * __builtin_amdgcn_rcpf(dk);    // == min(lo_k inv_k, hi_k inv_k) of the slab test
+        const float nv = t * __builtin_fabsf(dk);
+        const unsigned rgba = phong_tail(t, nv - lks, nv, cq + rq.x, rq.y, cr, cg, cb);
+        if (px < W && py < H) out[(unsigned)(py * W + px)] = rgba;
+    }
+}
+
 // HEXF (Hex scenarios): most primitives are boxes in one of the three wall frames (header records 8..10: rotations about Y by +30, -30, 90
 // degrees around the world origin).  The ray's inverse direction in each of them is set up once per pixel -- four v_rcp_f32, the 90 degree
 // frame only permutes the world one -- and their boxes run through the same prefetching loop as the world's; which list positions hold a box
@@ -908,6 +1066,11 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
     if (NP == 1) rr0 = *reinterpret_cast<const uint2 *>(&s_rect[min(lane, max(nVis - 1, 0))]);
     const unsigned long long wb0 = uniform_u64(*reinterpret_cast<const unsigned long long *>(s_hdr + FH_WB));
 
+    // planar tiles (classify_tile): only where the frame's whole list is one culling round
+    constexpr bool PLANAR = !HEXF;
+    __shared__ __attribute__((aligned(16))) float s_corner[4][16];   // per wave: the rays of the tile's corner pixels
+    const bool planar = PLANAR && fa.planar && nVis <= 64;   // (wave-uniform)
+
     int tx = part * 4 + wave, ty = 0;   // tile = ty * tilesX + tx, advanced without a division
     for (int tile = part * 4 + wave; tile < numTiles; tile += 4 * split, tx += 4 * split) {
         while (tx >= tilesX) { tx -= tilesX; ++ty; }
@@ -915,6 +1078,33 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
         const int tx1 = min(tx0 + TILE_W, W) - 1, ty1 = min(ty0 + TH, H) - 1;
         const int px = tx0 + lx, py0 = ty0 + ly;
         const int pxc = min(px, W - 1);
+        // ---- tile culling, first round of 64 list positions: one primitive per lane, four integer compares against its screen rectangle
+        unsigned long long mv0;
+        {
+            const int cpos = min(lane, max(nVis - 1, 0));
+            const uint2 rr = NP == 1 ? rr0 : *reinterpret_cast<const uint2 *>(&s_rect[cpos]);   // one 8-byte read; x0 | x1 << 16, y0 | y1 << 16 (all >= 0)
+            const bool v = (lane < nVis) & ((int)(rr.x & 0xffffu) <= tx1) & ((int)(rr.x >> 16) >= tx0) & ((int)(rr.y & 0xffffu) <= ty1) & ((int)(rr.y >> 16) >= ty0);
+            mv0 = __ballot(v);
+        }
+        if (planar) {
+            int kind = mv0 == 0ull ? 2 : 0;
+            if (mv0 != 0ull && (mv0 & ~wb0) == 0ull && __popcll(mv0) <= 4) {
+                const TileClass tc = classify_tile(mv0, s_vis, s_col, s_row, nzm0, nzm1, nzm2, s_corner[wave], tx0, tx1, ty0, ty1);
+                kind = tc.kind;
+                if (kind == 1) {
+                    planar_tile<NP>(tc.pos, tc.axis, tc.plane, s_vis, s_hdr, s_col, s_row, s_rowq, s_colq, tc.axis == 0 ? nzm0 : tc.axis == 1 ? nzm1 : nzm2, px, py0, W, H, out);
+                    continue;
+                }
+            }
+            if (kind == 2) {   // nothing can be seen through this tile: the clear colour
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    const int py = py0 + TILE_H * j;
+                    if (px < W && py < H) out[(unsigned)(py * W + px)] = 0xff000000u;
+                }
+                continue;
+            }
+        }
         V3 dw[NP], inv[NP];
         V3 ih0[NP], ih1[NP], ih2[NP];   // HEXF: the ray's inverse direction in wall frames 0, 1, 2
         float dcx = 0.0f, dcy[NP], a2[NP], ldc[NP];
@@ -930,12 +1120,15 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
         bool rayReady = false;   // wave-uniform: the rays are set up when the first primitive survives the culling
 #pragma unroll 1
         for (int k = 0; k * 64 < nVis; ++k) {
-            // ---- tile culling: one primitive per lane, four integer compares against its screen rectangle
+            // ---- tile culling (the first round's: above)
             const int cpos = min(lane + 64 * k, nVis - 1);
-            const uint2 rr = (NP == 1 && k == 0) ? rr0 : *reinterpret_cast<const uint2 *>(&s_rect[cpos]);   // one 8-byte read; x0 | x1 << 16, y0 | y1 << 16 (all >= 0)
-            const bool v = (lane + 64 * k < nVis) & ((int)(rr.x & 0xffffu) <= tx1) & ((int)(rr.x >> 16) >= tx0) & ((int)(rr.y & 0xffffu) <= ty1) &
-                           ((int)(rr.y >> 16) >= ty0);
-            const unsigned long long mvis = __ballot(v);
+            unsigned long long mvis = mv0;
+            bool v = (mv0 >> lane) & 1ull;
+            if (k > 0) {
+                const uint2 rr = *reinterpret_cast<const uint2 *>(&s_rect[cpos]);
+                v = (lane + 64 * k < nVis) & ((int)(rr.x & 0xffffu) <= tx1) & ((int)(rr.x >> 16) >= tx0) & ((int)(rr.y & 0xffffu) <= ty1) & ((int)(rr.y >> 16) >= ty0);
+                mvis = __ballot(v);
+            }
             if (mvis == 0ull) continue;
             if (!rayReady) {
                 rayReady = true;
@@ -1246,6 +1439,8 @@ static FastArgs fast_args_of(const GymView &gv, const PublishTo *publish)
     fa.stage_rewards = gv.rewards; fa.stage_true = gv.true_objective; fa.stage_done = gv.done;
     fa.pub_rewards = publish ? publish->rewards : nullptr; fa.pub_true = publish ? publish->true_objective : nullptr; fa.pub_done = publish ? publish->done : nullptr;
     fa.pub_n = publish ? frames : 0;
+    const char *pe = getenv("MV_PLANAR");   // (read at every launch: the two paths are compared within one process by tests/test_fast_pixels_gpu.py)
+    fa.planar = !(pe && *pe && atoi(pe) == 0);
     return fa;
 }
 

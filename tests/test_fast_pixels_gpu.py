@@ -135,6 +135,39 @@ def test_pixels_per_lane_variants_agree(hip, monkeypatch, scenario, N, A, W, H):
     g.close()
 
 
+@pytest.mark.parametrize("scenario,N,A,W,H,ppl", [("TowerBuilding", 1024, 1, 128, 128, "2"), ("TowerBuilding", 256, 4, 128, 128, "2"), ("TowerBuilding", 128, 1, 128, 72, "1"),
+                                                  ("TowerBuilding", 64, 2, 64, 64, ""), ("ObstaclesHard", 256, 2, 128, 128, ""), ("ObstaclesLava", 64, 1, 50, 30, "2"),
+                                                  ("Sokoban", 128, 1, 128, 128, ""), ("Rearrange", 64, 2, 128, 128, ""), ("Empty", 64, 1, 33, 17, "1"),
+                                                  ("Empty", 128, 2, 128, 128, "")])
+def test_planar_tiles_change_no_byte(hip, monkeypatch, scenario, N, A, W, H, ppl):
+    """raster_fast_kernel's planar-tile path (a tile that one face of one world box covers: one reciprocal per pixel, face constants wave-uniform)
+    against the general path (MV_PLANAR=0, read at every launch) on the same state: the classification has a margin far above the rounding of
+    either arithmetic and the planar path forms the same products, so every byte of the slab must be equal -- at BASELINE's sizes, several
+    times along a rollout with natural resets (camera poses: looking at walls, the floor, into corners, over boxes)."""
+    import torch
+    if ppl:
+        monkeypatch.setenv("MV_FAST_PPL", ppl)
+    g = MegaverseGym(scenario, W, H, N, A, 2, False, {})
+    obs = torch.zeros((N * A, H, W, 4), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    g.set_obs_buffer(obs.data_ptr())
+    g.set_pixel_mode("fast"); g.seed(21); g.reset()
+    for rnd in range(4):
+        for st in range(25):
+            g.sample_random_actions(31, 25 * rnd + st); g.step_no_render()
+        got = {}
+        for planar in ("0", "1"):
+            monkeypatch.setenv("MV_PLANAR", planar)
+            obs.zero_(); torch.cuda.synchronize()
+            g.render(); g.synchronize()
+            got[planar] = obs.cpu().numpy().copy()
+        assert got["0"][..., :3].max() > 0 and got["0"][..., 3].min() == 255
+        bad = (got["0"] != got["1"]).any(axis=-1)
+        assert not bad.any(), (f"{scenario} round {rnd}: {int(bad.sum())} pixels differ between the planar and the general path, first at "
+                               f"{np.argwhere(bad)[:4].tolist()}")
+    g.close()
+
+
 def test_fast_mode_is_deterministic(hip):
     N, A = 16, 2
     def run():
