@@ -867,133 +867,141 @@ __device__ __forceinline__ void box_run(unsigned long long m, int k, const V3 (&
 // ---- planar tiles ------------------------------------------------------------------------------------------------------------------------
 // Half of a TowerBuilding frame's non-empty tiles show ONE face of ONE axis-aligned world box (floor, a wall, the side of a near box) and
 // nothing else -- and the general path still pays a full ray (three v_rcp_f32), a slab test per culling survivor and the entry-axis selects
-// of the shading for every pixel of them.  Before a wave sets up any ray it therefore CLASSIFIES its tile (when the frame's list fits one
-// culling round, every survivor is a world box and there are at most four of them): for a ray o + t d that enters a box through its face on
-// axis k (plane offset p_k, front-facing: sign(p_k) d_k > 0) the hit lies inside the face's edge on axis m at bound b_m iff
-//     sign(p_k) (p_k d_m - b_m d_k) >= 0      (lo edge; reversed for the hi edge),
-// and d is an AFFINE function of the pixel (mv_frame.h: dw = col[i] + row[j] + c2), so each such expression takes its extremes over a tile at
-// the tile's four corner pixels.  Lane 16 s + q looks at survivor s: q = 4 f + e < 12 is edge e of candidate face f (the face of axis f the
-// eye is outside of, if any), q = 12 + f is that face's facing / depth-range test; all four corners per lane, against a margin that is
-// two orders of magnitude above the rounding of either arithmetic (PLANAR_MARGIN) and ~1 % of a pixel.  Three ballots and ~40 scalar bit
-// operations later the wave knows, for every survivor, "every ray of the tile enters through face f" / "no ray of the tile can hit it":
-//   * exactly one survivor can be hit and one of its faces covers the tile: planar_tile() -- one v_rcp_f32 per pixel, t = p_k / d_k is the
-//     same product the slab test forms, the face constants are wave-uniform, and the shared phong_tail() makes the bytes identical to the
-//     general path's (tests/test_fast_pixels_gpu.py: test_planar_tiles_change_no_byte);
-//   * no survivor can be hit: the clear colour;
-//   * otherwise the general path, minus the survivors that cannot be hit.
+// of the shading for every pixel of them.  So the workgroup CLASSIFIES its tiles before it draws any (classify_tiles, when the frame's list is
+// one culling round): for a ray o + t d that enters a box through its face on axis k (plane offset p_k from the eye, the eye outside) the
+// hit lies inside the face's edge on axis m at bound b_m iff
+//     g = sign(p_k) (p_k d_m - b_m d_k) >= 0      (lo edge; the opposite sign for the hi edge),
+// and if all four hold the face is front-facing (behind the eye at most one of an axis' two edge conditions can hold); g < 0 for one edge means
+// "not through this face" whatever the facing.  d is an AFFINE function of the pixel (mv_frame.h: dw = col[i] + row[j] - c2), so every g is
+// an edge function a i + b j + c of the pixel coordinates -- the trivial accept / trivial reject of a tile against a convex polygon:
+// its minimum over a tile is its value at one corner, min and max differ by a per-edge constant.
+//   * sixteen lanes per box compute its (up to) twelve edge functions -- three candidate faces (those the eye is outside of) x four edges --
+//     with a margin two orders of magnitude above the rounding of either arithmetic (PLANAR_MARGIN, ~1 % of a pixel) folded in;
+//   * then ONE LANE PER TILE tests its tile against them: two v_fma_f32 and two compares per edge (a wave per tile, with a lane per edge and the
+//     verdict assembled from ballots, was built first and measured: 19.8 M instead of 10.7 M scalar instructions per launch, 60.8 us
+//     instead of 53.7 -- profiles/r04a_wave_per_tile_*); the four waves share the list out among them and merge per tile in LDS:
+//     the boxes (and other primitives) the tile's pixels can hit at all -- which replaces the rectangle culling of the tile loop --
+//     and whether one face covers the tile.
+// A tile with one possible hit whose face covers it is drawn by planar_tile(): one v_rcp_f32 per pixel, t = p_k / d_k is the same product
+// the slab test forms, the face constants are wave-uniform, and the shared phong_tail() makes the bytes identical to the general path's
+// (tests/test_fast_pixels_gpu.py: test_planar_tiles_change_no_byte); a tile nothing can be hit through is cleared; the others take
+// the general path with the refined survivor mask.
 // Reference for what is drawn: magnum_env_renderer.cpp:288-330 (depth-tested, back-face-culled boxes), :200-203 (Phong uniforms).
 constexpr float PLANAR_MARGIN = 2e-4f;
+constexpr int CLS_MAX_TILES = 64;   // tiles of one workgroup that can be classified (LDS: 16 B each); more (small splits, hires frames): the general path throughout
 
-struct TileClass { int kind, pos, axis; float plane; };
-
-// corner: this wave's 16 floats of LDS scratch.  mvis: the culling survivors (<= 4, all world boxes, list positions < 64); refined in place.
-__device__ __forceinline__ TileClass classify_tile(unsigned long long &mvis, const float4 *s_vis, const float4 *s_col, const float4 *s_row, float nz0, float nz1,
-                                                   float nz2, float *corner, int tx0, int tx1, int ty0, int ty1)
+// s_tile[u] of the workgroup's u-th tile (u = 4 j + w is tile (j split + part) 4 + w of the frame, the tile loop's order): x, y = the list positions
+// (< 64) its pixels can hit, z = axis + 1 of the covering face when a world box's face covers the tile (only ever read when exactly one bit
+// of the mask is set).  s_line[64 wave + 16 s + 4 f + e]: edge e of face f of the s-th box of the wave's current round as (a, b, c_in, span):
+// inside at every pixel of the tile <=> a x0 + b y0 + c_in >= 0 at the tile's first pixel (x0, y0); outside at every pixel <=> that + span <= 0.
+// Called by all 256 threads after the prologue's barrier (s_vis, s_rect, the header are in LDS); ends with a barrier.
+template <int TH>
+__device__ __forceinline__ void classify_tiles(uint4 *s_tile, float4 *s_line, const float4 *s_vis, const short4 *s_rect, const float *camv, int nVis, unsigned long long wb0,
+                                               int W, int H, int part, int split, int tilesX, int numTiles, int perWG)
 {
-    // the survivors' list positions (wave-uniform)
-    const int n = __popcll(mvis);
-    unsigned long long m = mvis;
-    const int p0 = __ffsll((long long)m) - 1;
-    m &= m - 1;
-    const int p1 = m ? __ffsll((long long)m) - 1 : p0;
-    m &= m - 1;
-    const int p2 = m ? __ffsll((long long)m) - 1 : p0;
-    m &= m - 1;
-    const int p3 = m ? __ffsll((long long)m) - 1 : p0;
-    // Per-lane constants.  Which lanes are facing lanes / hi-side edges / survivor s / corner-ray producers are CONSTANT lane masks (inverse
-    // ballots: a select by one costs no VGPR and no compare).  The lane's axes k and m are needed as LDS addresses; they are derived from the
-    // lane id HERE, for every tile (two-bit table look-ups in 32-bit literals, ~8 instructions): held in registers across the tile loop they
-    // would take from the general path the registers it needs at seven waves per SIMD (the compiler spilled them, with a vmcnt(0) wait per reload)
-    int l;   // the lane id (volatile: two instructions per tile, not a register -- or a spill slot -- across the tile loop)
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-    const bool facing = __builtin_amdgcn_inverse_ballot_w64(0xf000f000f000f000ull), hiSide = __builtin_amdgcn_inverse_ballot_w64(0xaaaaaaaaaaaaaaaaull);
-    const bool sv0 = __builtin_amdgcn_inverse_ballot_w64(0xffffull), sv1 = __builtin_amdgcn_inverse_ballot_w64(0xffff0000ull),
-               sv2 = __builtin_amdgcn_inverse_ballot_w64(0xffff00000000ull);
-    int mypos = p3;
-    mypos = sv2 ? p2 : mypos;
-    mypos = sv1 ? p1 : mypos;
-    mypos = sv0 ? p0 : mypos;
-    // lane 16 s + q: q = 4 f + e < 12: edge e of face f (axis k = f; e >> 1 picks m among the two other axes, e & 1 the hi bound); q = 12 + f: the
-    // facing lane of face f.  k(q) = 0000 1111 2222 012(2), m(q) likewise (1 1 2 2, 2 2 0 0, 0 0 1 1, - - - -), two bits per q
-    const int q2 = (l & 15) << 1;
-    const int ck = (int)((0xa4aa5500u >> q2) & 3u), cm = (int)((0x59500aa5u >> q2) & 3u);
-    const int cb = cm + ((l & 1) << 2);   // the bound's place in the record: m, + 4 on the hi side
-    const unsigned long long validMask = (n >= 4 ? ~0ull : (1ull << (16 * n)) - 1ull) & 0x7fff7fff7fff7fffull;   // survivor s < n, lane q < 15
-    // the rays of the tile's four corner pixels, world axes: the same sums the pixels' own rays are (fast_prologue's tables)
-    {
-        const bool cr = __builtin_amdgcn_inverse_ballot_w64(0xaaaull), ct = __builtin_amdgcn_inverse_ballot_w64(0xcccull);   // lane 4 a + c: corner c (bit 0: right, bit 1: top), axis a
-        const bool a0 = __builtin_amdgcn_inverse_ballot_w64(0xfull), a1 = __builtin_amdgcn_inverse_ballot_w64(0xf0ull), prod = __builtin_amdgcn_inverse_ballot_w64(0xfffull);
-        const int xc = cr ? tx1 : tx0, yc = ct ? ty1 : ty0;
-        float nz = nz2;
-        nz = a1 ? nz1 : nz;
-        nz = a0 ? nz0 : nz;
-        const int ax = min(l >> 2, 2) + 1;
-        const float dcorner = (reinterpret_cast<const float *>(s_col)[4 * xc + ax] + reinterpret_cast<const float *>(s_row)[4 * yc + ax]) + nz;
-        if (prod) corner[l] = dcorner;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (a wave's LDS operations execute in order: only the compiler has to keep them so)
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const float *rec = reinterpret_cast<const float *>(s_vis) + 8 * mypos;
-    const float lok = rec[ck], hik = rec[4 + ck];
-    const float b = rec[cb];
-    const float4 Dk = *reinterpret_cast<const float4 *>(corner + 4 * ck), Dm = *reinterpret_cast<const float4 *>(corner + 4 * cm);
-    const bool cand = lok > 0.0f || hik < 0.0f;    // the eye is outside the box along k: the face towards it can be entered
-    const float p = lok > 0.0f ? lok : hik;
-    const float sg = p > 0.0f ? 1.0f : -1.0f;
-    // edge lanes: g = +-sg (p d_m - b d_k); facing lanes: g = sg d_k
-    const float ps = facing ? 0.0f : (hiSide ? -sg : sg) * p, bs = facing ? -sg : (hiSide ? -sg : sg) * b;
-    const float g0 = __builtin_fmaf(ps, Dm.x, -(bs * Dk.x)), g1 = __builtin_fmaf(ps, Dm.y, -(bs * Dk.y)), g2 = __builtin_fmaf(ps, Dm.z, -(bs * Dk.z)),
-                g3 = __builtin_fmaf(ps, Dm.w, -(bs * Dk.w));
-    const float gmin = __builtin_fminf(__builtin_fminf(g0, g1), __builtin_fminf(g2, g3)), gmax = __builtin_fmaxf(__builtin_fmaxf(g0, g1), __builtin_fmaxf(g2, g3));
-    const float ap = __builtin_fabsf(p);
-    // facing lanes also keep the face's depth t = |p| / (sg d_k) inside [2 NEAR_Z, FAR_Z / 2] (the planar path has no range test per pixel)
-    const float thrI = facing ? ap * (2.0f / FAR_Z) : PLANAR_MARGIN * (ap + __builtin_fabsf(b));
-    const float thrM = facing ? 0.0f : -thrI;
-    const unsigned long long I = __ballot(cand && gmin >= thrI) & validMask;       // edge: inside at all four corners; facing: front-facing, not too far
-    const unsigned long long M = __ballot(!cand || gmax <= thrM) & validMask;      // edge: outside at all four corners; facing: never front-facing / no such face
-    const unsigned long long Nr = __ballot(gmax <= ap * (0.5f / NEAR_Z));       // facing: not too near
-    constexpr unsigned long long Q0 = 0x0001000100010001ull;   // bit 0 of every survivor's sixteen
-    constexpr unsigned long long FACES = Q0 | (Q0 << 4) | (Q0 << 8);
-    unsigned long long X = I & (I >> 1);   // bit 4 f: all four edges of face f
-    X &= X >> 2;
-    unsigned long long Y = M | (M >> 1);   // bit 4 f: any edge of face f
-    Y |= Y >> 2;
-    const unsigned long long Fa = ((I >> 12) & Q0) | ((I >> 9) & (Q0 << 4)) | ((I >> 6) & (Q0 << 8));     // the facing lanes' bits, moved to bit 4 f
-    const unsigned long long Fm = ((M >> 12) & Q0) | ((M >> 9) & (Q0 << 4)) | ((M >> 6) & (Q0 << 8));
-    const unsigned long long Fn = ((Nr >> 12) & Q0) | ((Nr >> 9) & (Q0 << 4)) | ((Nr >> 6) & (Q0 << 8));
-    const unsigned long long insideF = X & Fa & Fn & FACES;           // every ray of the tile enters through face f
-    const unsigned long long missF = (Fm | (Fa & Y)) & FACES;         // no ray of the tile enters through face f
-    const unsigned long long missS = missF & (missF >> 4) & (missF >> 8) & Q0;
-    const unsigned long long validS = n >= 4 ? Q0 : Q0 & ((1ull << (16 * n)) - 1ull);
-    const unsigned long long live = validS & ~missS;
-    TileClass tc;
-    tc.kind = 0; tc.pos = 0; tc.axis = 0; tc.plane = 0.0f;
-    if (live == 0ull) { tc.kind = 2; return tc; }
-    if ((live & (live - 1)) == 0ull) {   // one survivor left
-        const int sl = (__ffsll((long long)live) - 1) >> 4;
-        const unsigned faces = (unsigned)(insideF >> (16 * sl)) & 0x111u;
-        if (faces) {
-            const int f = (__ffs((int)faces) - 1) >> 2;
-            tc.kind = 1;
-            tc.pos = sl == 0 ? p0 : sl == 1 ? p1 : sl == 2 ? p2 : p3;
-            tc.axis = f;
-            tc.plane = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p), 16 * sl + 12 + f));
-            return tc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < CLS_MAX_TILES) s_tile[tid] = make_uint4(0u, 0u, 0u, 0u);
+    // the ray's world components as affine functions of the pixel: d_a(i, j) = A_a i + B_a j + C_a  (dc = (((i + .5) / W) 2 - 1) TAN, ..., -1)
+    const float sx = 2.0f * TAN_HALF_FOV / float(W), ox = (1.0f / float(W) - 1.0f) * TAN_HALF_FOV;
+    const float sy = 2.0f * TAN_HALF_FOV_Y / float(H), oy = (1.0f / float(H) - 1.0f) * TAN_HALF_FOV_Y;
+    // this lane as an edge task: lane 16 s + q, q = 4 f + e: face axis k = f, edge axis m one of the two others (e >> 1), hi bound (e & 1)
+    const int q = lane & 15, es = lane >> 4;
+    const int ek = min(q >> 2, 2);
+    int em = ek + 1 + ((q >> 1) & 1);
+    em = em >= 3 ? em - 3 : em;
+    const bool ehi = q & 1, eactive = q < 12;
+    const float Ak = camv[3 + 3 * ek] * sx, Bk = camv[4 + 3 * ek] * sy, Ck = (camv[3 + 3 * ek] * ox + camv[4 + 3 * ek] * oy) - camv[5 + 3 * ek];
+    const float Am = camv[3 + 3 * em] * sx, Bm = camv[4 + 3 * em] * sy, Cm = (camv[3 + 3 * em] * ox + camv[4 + 3 * em] * oy) - camv[5 + 3 * em];
+    float4 *myLines = s_line + 64 * wave;
+    constexpr float WX = float(TILE_W - 1), WY = float(TH - 1);
+    __syncthreads();   // s_tile cleared
+    for (int u0 = 0; u0 < perWG; u0 += 64) {   // (perWG <= CLS_MAX_TILES = 64: one pass)
+        // this lane as a tile
+        const int u = u0 + lane;
+        const int tile = ((u >> 2) * split + part) * 4 + (u & 3);
+        const bool tvalid = u < perWG && tile < numTiles;
+        const int tyi = tile / tilesX, txi = tile - tyi * tilesX;
+        const int x0 = txi * TILE_W, y0 = tyi * TH;
+        const int x1 = min(x0 + TILE_W, W) - 1, y1 = min(y0 + TH, H) - 1;
+        const float fx0 = float(x0), fy0 = float(y0);
+        unsigned mlo = 0u, mhi = 0u, cover = 0u;
+        for (int base = 4 * wave; base < nVis; base += 16) {   // the waves share the list out: four positions per wave and round
+            // ---- the edge functions of this round's boxes (sixteen lanes per box)
+            const int P = min(base + es, nVis - 1);
+            const bool isBox = base + es < nVis && ((wb0 >> P) & 1ull) != 0ull;
+            const float4 lo4 = s_vis[2 * P], hi4 = s_vis[2 * P + 1];
+            const float lok = ek == 0 ? lo4.x : ek == 1 ? lo4.y : lo4.z, hik = ek == 0 ? hi4.x : ek == 1 ? hi4.y : hi4.z;
+            const float lom = em == 0 ? lo4.x : em == 1 ? lo4.y : lo4.z, him = em == 0 ? hi4.x : em == 1 ? hi4.y : hi4.z;
+            const float bnd = ehi ? him : lom;
+            const bool cand = isBox && eactive && (lok > 0.0f || hik < 0.0f);   // the eye is outside the box along k: the face towards it can be entered
+            const float pk = lok > 0.0f ? lok : hik;
+            // a covering face is drawn without a range test per pixel: its depth |hit| / |d| lies in [|p| / 1.69, |hit|_1] (|d| in [1, 1.69])
+            const float far1 = (__builtin_fmaxf(__builtin_fabsf(lo4.x), __builtin_fabsf(hi4.x)) + __builtin_fmaxf(__builtin_fabsf(lo4.y), __builtin_fabsf(hi4.y))) +
+                               __builtin_fmaxf(__builtin_fabsf(lo4.z), __builtin_fabsf(hi4.z));
+            const bool coverOK = cand && __builtin_fabsf(pk) >= 4.0f * NEAR_Z && far1 <= 0.5f * FAR_Z;
+            const float sg = ((pk > 0.0f) != ehi) ? 1.0f : -1.0f;   // sign(p), reversed for the hi edge
+            const float ea = sg * (pk * Am - bnd * Ak), eb = sg * (pk * Bm - bnd * Bk), ec = sg * (pk * Cm - bnd * Ck);
+            const float mg = PLANAR_MARGIN * (__builtin_fabsf(pk) + __builtin_fabsf(bnd));
+            const float cin = ((ec + __builtin_fminf(0.0f, ea * WX)) + __builtin_fminf(0.0f, eb * WY)) - mg;
+            const float span = (__builtin_fabsf(ea) * WX + __builtin_fabsf(eb) * WY) + 2.0f * mg;
+            myLines[lane] = cand ? make_float4(ea, eb, cin, span) : make_float4(0.0f, 0.0f, -1.0f, 0.0f);   // (no such face: never inside, always outside)
+            const unsigned long long candMask = __ballot(cand), coverMask = __ballot(coverOK);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (a wave's LDS operations execute in order: only the compiler has to keep them so)
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- every tile against them
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                const int Q = base + sl;
+                if (Q >= nVis) break;
+                const uint2 rr = *reinterpret_cast<const uint2 *>(&s_rect[Q]);   // x0 | x1 << 16, y0 | y1 << 16
+                const bool ov = tvalid & ((int)(rr.x & 0xffffu) <= x1) & ((int)(rr.x >> 16) >= x0) & ((int)(rr.y & 0xffffu) <= y1) & ((int)(rr.y >> 16) >= y0);
+                if (!__any(ov)) continue;
+                bool hit = ov;
+                unsigned cov = 0u;
+                if ((wb0 >> Q) & 1ull) {   // an axis-aligned box of the world frame: through which face, if any?
+                    bool missAll = true;
+#pragma unroll
+                    for (int f = 0; f < 3; ++f) {
+                        if (!((candMask >> (16 * sl + 4 * f)) & 1ull)) continue;   // (no face towards the eye on this axis)
+                        bool ins = true, mis = false;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float4 L = myLines[16 * sl + 4 * f + e];
+                            const float g = __builtin_fmaf(L.x, fx0, __builtin_fmaf(L.y, fy0, L.z));
+                            ins = ins && g >= 0.0f;
+                            mis = mis || g + L.w <= 0.0f;
+                        }
+                        if (ins && ((coverMask >> (16 * sl + 4 * f)) & 1ull)) cov = (unsigned)f + 1u;
+                        missAll = missAll && mis;
+                    }
+                    hit = ov && !missAll;
+                }
+                if (hit) {
+                    if (Q < 32) mlo |= 1u << Q; else mhi |= 1u << (Q - 32);
+                    cover |= cov;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (the next round's lines are written after this round's were read)
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (tvalid) {
+            if (mlo) atomicOr(&s_tile[u].x, mlo);
+            if (mhi) atomicOr(&s_tile[u].y, mhi);
+            if (cover) atomicOr(&s_tile[u].z, cover);
         }
     }
-    if (missS & 1ull) mvis &= ~(1ull << p0);
-    if (missS & (1ull << 16)) mvis &= ~(1ull << p1);
-    if (missS & (1ull << 32)) mvis &= ~(1ull << p2);
-    if (missS & (1ull << 48)) mvis &= ~(1ull << p3);
-    return tc;
+    __syncthreads();
 }
 
-// the pixels of a tile that face `k` (plane offset `plane` from the eye along world axis k) of the world box at list position `pos` covers
+// the pixels of a tile that the face of axis k (the one towards the eye) of the world box at list position `pos` covers
 template <int NP>
-__device__ __forceinline__ void planar_tile(int pos, int k, float plane, const float4 *s_vis, const float *s_hdr, const float4 *s_col, const float4 *s_row,
+__device__ __forceinline__ void planar_tile(int pos, int k, const float4 *s_vis, const float *s_hdr, const float4 *s_col, const float4 *s_row,
                                             const float2 *s_rowq, const float *s_colq, float nzk, int px, int py0, int W, int H, uint32_t *out)
 {
+    const float lok = uniform_f32(reinterpret_cast<const float *>(s_vis)[8 * pos + k]), hik = uniform_f32(reinterpret_cast<const float *>(s_vis)[8 * pos + 4 + k]);
+    const float plane = lok > 0.0f ? lok : hik;   // the face towards the eye
     const unsigned color = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_uint(reinterpret_cast<const float *>(s_vis)[8 * pos + 7]));
     const float cr = float((color >> 16) & 255u), cg = float((color >> 8) & 255u), cb = float(color & 255u);
     const float lk = uniform_f32(s_hdr[FH_LREL + k]);   // the light along k, relative to the eye (frame 0: world axes)
@@ -1030,7 +1038,7 @@ __device__ __forceinline__ void planar_tile(int pos, int k, float plane, const f
 constexpr int fast_lds_bytes(int maxvis) { return 40 * maxvis + 4 * FH_FLOATS; }    // records 32 B + rectangles 8 B per primitive, frame header
 constexpr int glist_lds_bytes(int maxvis) { return 9 * maxvis + 4 * FH_FLOATS; }    // rectangles 8 B + class 1 B per primitive, frame header
 
-template <int MAXVIS, bool SHAPES, bool HEXF, int NP>
+template <int MAXVIS, bool SHAPES, bool HEXF, int NP, bool CLS = true>   // CLS: with the tile classification (its tables cost 5 KB of LDS)
 __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *obs, int W, int H, int split, int blk, unsigned char *lds)
 {
     constexpr unsigned POS_MASK = MAXVIS - 1;
@@ -1066,37 +1074,29 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
     if (NP == 1) rr0 = *reinterpret_cast<const uint2 *>(&s_rect[min(lane, max(nVis - 1, 0))]);
     const unsigned long long wb0 = uniform_u64(*reinterpret_cast<const unsigned long long *>(s_hdr + FH_WB));
 
-    // planar tiles (classify_tile): only where the frame's whole list is one culling round
-    constexpr bool PLANAR = !HEXF;
-    __shared__ __attribute__((aligned(16))) float s_corner[4][16];   // per wave: the rays of the tile's corner pixels
-    const bool planar = PLANAR && fa.planar && nVis <= 64;   // (wave-uniform)
+    // planar tiles (classify_tiles): where the frame's whole list is one culling round and the workgroup's share of the tiles fits the table
+    constexpr bool PLANAR = !HEXF && CLS;
+    __shared__ uint4 s_tile[PLANAR ? CLS_MAX_TILES : 1];
+    __shared__ float4 s_line[PLANAR ? 256 : 1];
+    const int perWG = (numTiles - part * 4 + 4 * split - 1) / (4 * split) * 4;   // this workgroup's tiles, rounded up to four per turn of its waves
+    const bool cls = PLANAR && fa.planar && nVis <= 64 && perWG <= CLS_MAX_TILES && perWG >= 32;   // (uniform over the workgroup; few tiles do not repay the pass over the list)
+    if (PLANAR && cls) classify_tiles<TH>(s_tile, s_line, s_vis, s_rect, camv, nVis, wb0, W, H, part, split, tilesX, numTiles, perWG);
 
     int tx = part * 4 + wave, ty = 0;   // tile = ty * tilesX + tx, advanced without a division
-    for (int tile = part * 4 + wave; tile < numTiles; tile += 4 * split, tx += 4 * split) {
+    int u = wave;                       // the tile's place in s_tile
+    for (int tile = part * 4 + wave; tile < numTiles; tile += 4 * split, tx += 4 * split, u += 4) {
         while (tx >= tilesX) { tx -= tilesX; ++ty; }
         const int tx0 = tx * TILE_W, ty0 = ty * TH;
         const int tx1 = min(tx0 + TILE_W, W) - 1, ty1 = min(ty0 + TH, H) - 1;
         const int px = tx0 + lx, py0 = ty0 + ly;
         const int pxc = min(px, W - 1);
-        // ---- tile culling, first round of 64 list positions: one primitive per lane, four integer compares against its screen rectangle
+        // ---- which primitives can this tile's pixels hit?  (first round of 64 list positions)
         unsigned long long mv0;
-        {
-            const int cpos = min(lane, max(nVis - 1, 0));
-            const uint2 rr = NP == 1 ? rr0 : *reinterpret_cast<const uint2 *>(&s_rect[cpos]);   // one 8-byte read; x0 | x1 << 16, y0 | y1 << 16 (all >= 0)
-            const bool v = (lane < nVis) & ((int)(rr.x & 0xffffu) <= tx1) & ((int)(rr.x >> 16) >= tx0) & ((int)(rr.y & 0xffffu) <= ty1) & ((int)(rr.y >> 16) >= ty0);
-            mv0 = __ballot(v);
-        }
-        if (planar) {
-            int kind = mv0 == 0ull ? 2 : 0;
-            if (mv0 != 0ull && (mv0 & ~wb0) == 0ull && __popcll(mv0) <= 4) {
-                const TileClass tc = classify_tile(mv0, s_vis, s_col, s_row, nzm0, nzm1, nzm2, s_corner[wave], tx0, tx1, ty0, ty1);
-                kind = tc.kind;
-                if (kind == 1) {
-                    planar_tile<NP>(tc.pos, tc.axis, tc.plane, s_vis, s_hdr, s_col, s_row, s_rowq, s_colq, tc.axis == 0 ? nzm0 : tc.axis == 1 ? nzm1 : nzm2, px, py0, W, H, out);
-                    continue;
-                }
-            }
-            if (kind == 2) {   // nothing can be seen through this tile: the clear colour
+        if (PLANAR && cls) {   // classified: the answer is in the table, with the face that covers the tile if one does
+            const uint4 tc = s_tile[u];
+            mv0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(tc.y) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(tc.x);
+            const unsigned cover = (unsigned)__builtin_amdgcn_readfirstlane(tc.z);
+            if (mv0 == 0ull) {   // nothing: the clear colour
 #pragma unroll
                 for (int j = 0; j < NP; ++j) {
                     const int py = py0 + TILE_H * j;
@@ -1104,6 +1104,18 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
                 }
                 continue;
             }
+            if ((mv0 & (mv0 - 1ull)) == 0ull && cover != 0u) {   // one box, and one of its faces covers the tile
+                const int k = (int)cover - 1;
+                planar_tile<NP>(__ffsll((long long)mv0) - 1, k, s_vis, s_hdr, s_col, s_row, s_rowq, s_colq, k == 0 ? nzm0 : k == 1 ? nzm1 : nzm2, px, py0, W, H, out);
+                continue;
+            }
+        } else {   // tile culling: one primitive per lane, four integer compares against its screen rectangle
+            int l2 = lane;
+            asm volatile("" : "+v"(l2));   // (the rectangle's address is formed here, per tile: kept across the loop it was spilled at seven waves per SIMD)
+            const int cpos = min(l2, max(nVis - 1, 0));
+            const uint2 rr = NP == 1 ? rr0 : *reinterpret_cast<const uint2 *>(&s_rect[cpos]);   // one 8-byte read; x0 | x1 << 16, y0 | y1 << 16 (all >= 0)
+            const bool v = (lane < nVis) & ((int)(rr.x & 0xffffu) <= tx1) & ((int)(rr.x >> 16) >= tx0) & ((int)(rr.y & 0xffffu) <= ty1) & ((int)(rr.y >> 16) >= ty0);
+            mv0 = __ballot(v);
         }
         V3 dw[NP], inv[NP];
         V3 ih0[NP], ih1[NP], ih2[NP];   // HEXF: the ray's inverse direction in wall frames 0, 1, 2
@@ -1427,7 +1439,7 @@ __global__ __launch_bounds__(256, WAVES) void raster_union_all_kernel(UnionRaste
     __shared__ __attribute__((aligned(16))) unsigned char s_buf[LDS];
     const int blk = (int)blockIdx.x - a.u.first[s];
     if (a.large[s]) raster_glist_body<VIS_XL, true, true, 1>(a.u.fa[s], a.u.obs[s], W, H, a.split_large, blk, s_buf);
-    else raster_fast_body<VIS_SMALL, true, false, NPS>(a.u.fa[s], a.u.obs[s], W, H, a.split_small, blk, s_buf);
+    else raster_fast_body<VIS_SMALL, true, false, NPS, false>(a.u.fa[s], a.u.obs[s], W, H, a.split_small, blk, s_buf);   // (no tile classification: this kernel's LDS is the long-list body's, and occupancy is what it lives on)
 }
 
 static FastArgs fast_args_of(const GymView &gv, const PublishTo *publish)

@@ -150,7 +150,9 @@ def main():
     ys = ((np.arange(H) + 0.5) / H * 2 - 1) * TAN_Y
     stat = dict(tiles=0, empty=0, true_planar=0, planar_single=0, planar_multi=0, general=0, surv_hist=np.zeros(12, int),
                 general_surv=0, general_surv_refined=0, other_block=0, nvis=[], bg_pixels=0, classified_tiles=0)
+    frame_costs = []
     for e in range(N):
+        fc = 0.0
         s = g.snapshot(e)
         eye, c = camera(s["agents"][0])
         world, camf = prims_of(s)
@@ -181,6 +183,7 @@ def main():
                 stat["tiles"] += 1
                 if not surv:
                     stat["empty"] += 1
+                    fc += 5
                     continue
                 stat["surv_hist"][min(len(surv), 11)] += 1
                 w_t, a_t = who[ty0:ty0 + TH, tx0:tx0 + TW], axis[ty0:ty0 + TH, tx0:tx0 + TW]
@@ -192,6 +195,7 @@ def main():
                     stat["other_block"] += 1
                     stat["general"] += 1
                     stat["general_surv"] += len(surv); stat["general_surv_refined"] += len(surv)
+                    fc += 250 + 44 * len(surv) + 60
                     continue
                 stat["classified_tiles"] += 1
                 res = [classify_tile(prl[i][1], prl[i][2], c, (xs[tx0], xs[tx1]), (ys[ty0], ys[ty1])) for i in surv]
@@ -199,6 +203,7 @@ def main():
                 if len(notmiss) == 1 and notmiss[0][1][0] == "inside":
                     assert one and w_t[0, 0] == notmiss[0][0] and a_t[0, 0] == notmiss[0][1][1], (e, tx0, ty0)
                     stat["planar_single" if len(surv) == 1 else "planar_multi"] += 1
+                    fc += 80
                 else:
                     for i, r in zip(surv, res):   # a 'miss' must be a true miss
                         if r[0] == "miss":
@@ -206,6 +211,10 @@ def main():
                     stat["general"] += 1
                     stat["general_surv"] += len(surv)
                     stat["general_surv_refined"] += len(notmiss)
+                    fc += (250 + 44 * len(notmiss)) if notmiss else 5
+        frame_costs.append(fc)
+    fcs = np.array(frame_costs)
+    print(f"per-frame cost estimate (VALU per wave-tile units): mean {fcs.mean():.0f} p10 {np.percentile(fcs,10):.0f} p50 {np.percentile(fcs,50):.0f} p90 {np.percentile(fcs,90):.0f} p99 {np.percentile(fcs,99):.0f} max {fcs.max():.0f}")
     T = stat["tiles"]
     print(f"NP={NP} frames={N} tiles={T} empty={stat['empty'] / T:.3f} visible prims/frame mean {np.mean(stat['nvis']):.1f} max {np.max(stat['nvis'])}")
     print(f"background pixel fraction {stat['bg_pixels'] / (N * W * H):.3f}")
