@@ -31,6 +31,7 @@ void launch_reset(const GymView &gv, int force_all, hipStream_t stream);
 // step kernels: one 256-thread workgroup per env = the tick (wave 0) + the frame setup of the env's frames for a W x H observation
 // (render = 0: tick only)
 void launch_step(const GymView &gv, hipStream_t stream, int W, int H, int render, hipEvent_t done = nullptr);
+void launch_step_ticks(const GymView *views, int k, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);   // k ticks + frame setups of every env, one launch (mv_step.hip)
 void launch_step_obstacles(const GymView &gv, hipStream_t stream, int W, int H, int render);
 void launch_reset_obstacles(const GymView &gv, const EpisodeBlob *blobs, int *status, int force_all, hipStream_t stream);
 void launch_step_rearrange(const GymView &gv, hipStream_t stream, int W, int H, int render);
@@ -1157,6 +1158,11 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
     hipEvent_t *evs[PIPE_BATCH_MAX];
     // ---- the k step kernels, back to back on the simulation stream
     bool simDoneRodeAlong = false;   // (the last step kernel's dispatch packet completes simDone itself)
+    // One TowerBuilding gym, several rendered ticks with device-drawn actions, nothing timed per tick: ONE step launch runs the k ticks of every
+    // env (launch_step_ticks; MV_STEP_TICKS=0: k launches).  Its views are collected in the loop below.
+    static const bool ticksOff = getenv("MV_STEP_TICKS") && atoi(getenv("MV_STEP_TICKS")) == 0;
+    const bool multiTick = !ticksOff && n == 1 && L->A == 1 && k >= 2 && k <= MAX_STEP_TICKS && render && policy != POLICY_NONE && L->scenario == SCN_TOWER &&   // (several agents per env: measured slower, 16.3 against 19.6 M obs/s at 512 x 4 -- four waves of ~180 VGPRs per env resident for the whole call)
+                           !(L->profCount < L->profMax) && !L->gv.dbg;
     for (int j = 0; j < k; ++j) {
         const bool prof = render && L->profCount < L->profMax;
         evs[j] = prof ? &L->profEvents[(size_t)L->profCount * 5] : nullptr;
@@ -1179,7 +1185,20 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
         }
         if (evs[j]) HIP_TRY(hipEventRecord(evs[j][0], sim));
         bool simDoneRides = false;
-        if (n == 1) simDoneRides = launch_step_of(L, views[(size_t)j * n], sim, fused, own && j == k - 1 && !evs[j] ? L->simDone : nullptr);
+        if (multiTick) {
+            views[(size_t)j].lpt_no_clear = 1;
+            if (j == k - 1) {
+                // the cost histograms of this call's later passes and of the pass after it (each pass's frame setup otherwise clears the next one's)
+                const int hists = L->hists, h0 = views[0].lpt_parity;
+                const size_t hb = (size_t)LPT_BUCKETS * LPT_SUBS * sizeof(int32_t);
+                const int a0 = (h0 + 1) % hists, cnt = k;
+                const int firstPart = std::min(cnt, hists - a0);
+                HIP_TRY(hipMemsetAsync(reinterpret_cast<uint8_t *>(L->gv.lpt_hist) + (size_t)a0 * hb, 0, (size_t)firstPart * hb, sim));
+                if (cnt > firstPart) HIP_TRY(hipMemsetAsync(L->gv.lpt_hist, 0, (size_t)(cnt - firstPart) * hb, sim));
+                launch_step_ticks(views.data(), k, sim, L->w, L->h, own ? L->simDone : nullptr);
+                simDoneRides = own;
+            }
+        } else if (n == 1) simDoneRides = launch_step_of(L, views[(size_t)j * n], sim, fused, own && j == k - 1 && !evs[j] ? L->simDone : nullptr);
         else {
             for (int i = n; i <= MAX_UNION; ++i) ua.first[i] = envs;
             launch_step_union(ua, sim, L->w, L->h, fused);
@@ -1209,6 +1228,14 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
     if (own) HIP_TRY(hipStreamWaitEvent(L->stream, L->simDone, 0));
     std::vector<PublishTo> pubs((size_t)n);
     std::vector<uint32_t *> obsPtrs((size_t)n);
+    // One gym, several ticks, every tick's observations in a slab of its own (an output ring at least k deep), nothing timed per tick: the
+    // observation passes of up to MAX_UNION ticks go out as ONE launch (launch_raster_batch: the next tick's expensive frames fill the tail of
+    // the previous tick's pass).  The ticks are collected below and launched at the end of their chunk.
+    bool batchRaster = render && allFast && n == 1 && k >= 2 && L->ringObs && L->ringCount >= k;
+    for (int j = 0; j < k; ++j) batchRaster = batchRaster && !evs[j];
+    std::vector<PublishTo> chunkPubs;
+    std::vector<uint32_t *> chunkObs;
+    int chunkFirst = 0;
     for (int j = 0; j < k; ++j) {
         if (evs[j]) HIP_TRY(hipEventRecord(evs[j][2], L->stream));
         for (int i = 0; i < n; ++i) {
@@ -1219,7 +1246,24 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
         }
         // the call's last pass completes this call's mark (what the simulation stream waits for before it reuses the slot group)
         hipEvent_t mark = own && j == k - 1 ? L->userMark[L->markCount % PIPE_GROUPS] : nullptr;
-        if (render) {
+        if (render && batchRaster) {
+            const bool pubInRaster = own;
+            chunkPubs.push_back(pubs[0]);
+            chunkObs.push_back(obsPtrs[0]);
+            static const int chunkMax = getenv("MV_RASTER_BATCH") ? std::min((int)MAX_UNION, std::max(1, atoi(getenv("MV_RASTER_BATCH")))) : (int)MAX_UNION;   // (0: off, launch_raster_batch declines)
+            if (j == k - 1 || (int)chunkObs.size() >= chunkMax) {
+                const int cn = (int)chunkObs.size();
+                int r = cn >= 2 ? launch_raster_batch(&views[(size_t)chunkFirst], chunkObs.data(), pubInRaster ? chunkPubs.data() : nullptr, cn, L->w, L->h, L->stream, mark) : 1;
+                if (r < 0) return fail("mv_step: observation size above 1024x1024");
+                if (r == 1)   // (not applicable to this gym -- long lists -- or a chunk of one tick: tick by tick)
+                    for (int q = 0; q < cn; ++q)
+                        if (launch_raster(views[(size_t)chunkFirst + q], chunkObs[q], L->w, L->h, L->stream, nullptr, 1, /*setup_done=*/1, pubInRaster ? &chunkPubs[q] : nullptr,
+                                          q == cn - 1 ? mark : nullptr))
+                            return fail("mv_step: observation size above 1024x1024");
+                chunkFirst = j + 1;
+                chunkPubs.clear(); chunkObs.clear();
+            }
+        } else if (render) {
             const bool pubInRaster = own && allFast;
             if (n > 1 && allFast) {
                 if (launch_raster_union(&views[(size_t)j * n], obsPtrs.data(), pubInRaster ? pubs.data() : nullptr, n, L->w, L->h, L->stream, evs[j] ? evs[j][3] : nullptr, mark))

@@ -509,7 +509,7 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
         if (tid < 32) fh[FH_WB + tid] = __uint_as_float(s_wbits[tid]);
     }
     if (tid == 0) gv.lpt_list[(size_t)(bin * LPT_SUBS + (frame & (LPT_SUBS - 1))) * lpt_sub_capacity(gv.num_envs * gv.num_agents) + binPlace] = frame;
-    if (frame == 0)   // the histogram the NEXT pass fills: last read by a raster pass as many passes ago as there are slots, which this step waited for
+    if (frame == 0 && !gv.lpt_no_clear)   // the histogram the NEXT pass fills: last read by a raster pass as many passes ago as there are slots, which this step waited for
         for (int i = tid; i < LPT_BUCKETS * LPT_SUBS; i += THREADS) gv.lpt_hist[((gv.lpt_parity + 1) % gv.lpt_hists) * (LPT_BUCKETS * LPT_SUBS) + i] = 0;
     MV_TF(5);   // header, cost bin
     sync();   // the LDS scratch above is reused by the next frame of this workgroup (fused step + setup kernels)

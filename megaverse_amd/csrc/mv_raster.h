@@ -23,4 +23,8 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
 int launch_raster_union(const GymView *views, uint32_t *const *obs, const PublishTo *publish, int n, int W, int H, hipStream_t stream, hipEvent_t between = nullptr,
                         hipEvent_t done = nullptr);
 
+// the fast observation passes of k ticks of ONE gym (a batched call; views[j] / obs[j] / publish[j] of tick j, the observation slabs distinct) with one
+// launch: the next tick's expensive frames run in the tail of the previous tick's pass; 0: launched, 1: not applicable (the caller launches tick by tick)
+int launch_raster_batch(const GymView *views, uint32_t *const *obs, const PublishTo *publish, int k, int W, int H, hipStream_t stream, hipEvent_t done = nullptr);
+
 }  // namespace mv

@@ -45,6 +45,9 @@ __global__ __launch_bounds__(256) void step_kernel(GymView gv, int W, int H, int
 {
     __shared__ FrameScratch s_fs[A_MAX == 1 ? 1 : 4];
     const int env = blockIdx.x;
+#ifdef MV_STEP_PRIO
+    __builtin_amdgcn_s_setprio(MV_STEP_PRIO);
+#endif
     MV_T_BEGIN
 #ifdef MV_TICK_TIMING
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
@@ -77,6 +80,57 @@ __global__ __launch_bounds__(256) void step_kernel(GymView gv, int W, int H, int
         const int A = gv.num_agents, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
         for (int a = wave; a < A; a += nw) frame_setup_body<64, true>(gv, env * A + a, W, H, s_fs[wave]);
     }
+}
+
+// k consecutive ticks of every env with ONE launch (a batched open-loop call, mv_step_n with a device-side random policy): the envs are
+// independent and every tick draws its own actions, so nothing orders env A's tick j + 1 behind env B's tick j -- only k launches did, each as
+// long as its slowest env, and each having to find room for 1024 two-wave workgroups of ~150 VGPRs beside the observation pass of the previous
+// call (kernel traces, r04l: 70-190 us per step kernel while a pass runs, 20 us alone; the chain of step kernels, not the pass, set the pipelined
+// rate).  Here an env's workgroup becomes resident once and runs tick, frame setup (into slot j's lists), tick, ...: gv[j] is tick j's view
+// (its hand-over slot, its staging outputs, its action index, its cost histogram).  The histograms are cleared by the host before the launch
+// (lpt_no_clear): inside one launch env 0's "clear the next pass's histogram" would race with the envs that are a tick ahead.
+struct StepTicksArgs {
+    int32_t n;
+    GymView gv[MAX_STEP_TICKS];
+};
+
+// One agent: ONE wave per env (the single-tick kernel's second wave only helps with the frame setup, and idles through the tick): the
+// workgroups stay resident for the whole call beside the observation passes of the previous one, and every wave of ~150 VGPRs they hold is
+// two or three waves the pass cannot have (measured: 21.1 M obs/s with two waves per env, 22.3 M with one).
+template <int A_MAX>
+__global__ __launch_bounds__(A_MAX == 1 ? 64 : 256) void step_ticks_kernel(StepTicksArgs a, int W, int H)
+{
+    __shared__ FrameScratch s_fs[A_MAX == 1 ? 1 : 4];
+    const int env = blockIdx.x;
+#ifdef MV_STEP_PRIO
+    __builtin_amdgcn_s_setprio(MV_STEP_PRIO);
+#endif
+    for (int j = 0; j < a.n; ++j) {
+        const GymView &gv = a.gv[j];
+        if (A_MAX == 1) {
+            tower_tick<A_MAX>(gv, env);
+            wave_sync();   // the tick's stores before the frame setup's loads (one wave: no barrier needed)
+            frame_setup_body<64, true>(gv, env, W, H, s_fs[0]);
+        } else {
+            tower_tick<A_MAX, (A_MAX > 1)>(gv, env);
+            __syncthreads();   // the tick's stores (same CU: same L1) before the frame setup's loads
+            const int A = gv.num_agents, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+            for (int q = wave; q < A; q += nw) frame_setup_body<64, true>(gv, env * A + q, W, H, s_fs[wave]);
+            __syncthreads();   // every frame of the env is set up (the state they read) before the next tick changes it
+        }
+    }
+}
+
+void launch_step_ticks(const GymView *views, int k, hipStream_t stream, int W, int H, hipEvent_t done)
+{
+    StepTicksArgs a;
+    a.n = k;
+    for (int j = 0; j < k; ++j) a.gv[j] = views[j];
+    for (int j = k; j < MAX_STEP_TICKS; ++j) a.gv[j] = views[k - 1];
+    const GymView &gv = views[0];
+    const dim3 grid(gv.num_envs), block(gv.num_agents == 1 ? 64 : 64 * std::min(gv.num_agents, 4));
+    if (gv.num_agents == 1) hipExtLaunchKernelGGL(step_ticks_kernel<1>, grid, block, 0, stream, nullptr, done, 0, a, W, H);
+    else hipExtLaunchKernelGGL(step_ticks_kernel<MAX_AGENTS>, grid, block, 0, stream, nullptr, done, 0, a, W, H);
 }
 
 // done: an event that completes with the launch, carried by its dispatch packet (cf. mv_raster.h)

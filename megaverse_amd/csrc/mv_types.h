@@ -117,6 +117,7 @@ struct alignas(16) AgentState {   // 128 B
 static_assert(sizeof(AgentState) == 128, "AgentState must be 128 B");
 
 // ---- cost bins of the observation pass (mv_frame.h fills them, mv_raster.hip reads them, mv_api.hip sizes them)
+constexpr int MAX_STEP_TICKS = 8;   // ticks of one multi-tick step launch (mv_step.hip: step_ticks_kernel; the views travel as kernel arguments)
 constexpr int LPT_BUCKETS = 256;
 // Every cost bin has LPT_SUBS counters and lists, picked by frame index: the frames of a launch finish together and most of them fall into
 // the same three or four bins -- one counter per bin made their returning atomics queue up at one L2 address (measured: 1.3 us of a 7 us frame setup).
@@ -167,6 +168,7 @@ struct GymView {
     uint8_t *vis_hdr;          // [N*A][FRAME_HDR_BYTES] per-frame header for raster_fast_kernel (cameras, light vectors, masks, count)
     unsigned long long *dbg;   // null, or (builds with -DMV_TICK_TIMING, MV_TICK_TIMING=1) [N][64] counters of the TowerBuilding tick
     int32_t debug_redo;        // tests (MV_DEBUG_FORCE_REDO=1): the multi-agent tick takes its "check failed" path every time
+    int32_t lpt_no_clear;      // 1: the frame setup does not clear the cost histogram of the next pass (a multi-tick step launch: cleared up front, mv_step.hip)
 };
 
 // One host-generated episode (Obstacles family): everything Env::reset produces, ready to be swapped in by

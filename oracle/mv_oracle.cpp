@@ -3051,6 +3051,12 @@ void mvo_step(mvo_gym *g) { g->step(true); }
 void mvo_step_norender(mvo_gym *g) { g->step(false); }
 void mvo_render(mvo_gym *g) { g->render(); }
 int mvo_is_done(mvo_gym *g, int env) { return g->done[env]; }
+void mvo_get_dones(mvo_gym *g, uint8_t *out) { for (int i = 0; i < g->numEnvs; ++i) out[i] = g->done[i]; }   /* all envs' done flags with one call (full-size parity tests) */
+void mvo_render_env(mvo_gym *g, int env)   /* the frames of ONE env's agents (full-size parity tests sample a few envs: the brute-force raster of all 1024 would take minutes) */
+{
+    for (int a = 0; a < g->numAgents; ++a)
+        render_agent(*g->envs[env], a, g->w, g->h, g->obs.data() + (size_t(env) * g->numAgents + a) * size_t(g->w) * g->h * 4);
+}
 
 void mvo_get_last_rewards(mvo_gym *g, float *out)
 {   // megaverse.cpp:128-137 (read after the auto-reset zero-filled them)

@@ -64,6 +64,8 @@ void mvo_step(mvo_gym *g);
 /* physics+logic+auto-reset only, no rendering (for long rollouts in tests) */
 void mvo_step_norender(mvo_gym *g);
 void mvo_render(mvo_gym *g);
+void mvo_render_env(mvo_gym *g, int env_idx);   /* only this env's agents' frames */
+void mvo_get_dones(mvo_gym *g, uint8_t *out);    /* [N] */
 
 int mvo_is_done(mvo_gym *g, int env_idx);
 void mvo_get_last_rewards(mvo_gym *g, float *out); /* [N*A] env-major */

@@ -57,6 +57,8 @@ def lib():
         L.mvo_set_actions.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
         L.mvo_set_action_mask.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.mvo_is_done.argtypes = [C.c_void_p, C.c_int]
+        L.mvo_get_dones.argtypes = [C.c_void_p, C.c_void_p]
+        L.mvo_render_env.argtypes = [C.c_void_p, C.c_int]
         L.mvo_get_last_rewards.argtypes = [C.c_void_p, C.c_void_p]
         L.mvo_true_objective.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.mvo_true_objective.restype = C.c_float
@@ -135,6 +137,13 @@ class OracleGym:
     def step_norender(self): self.L.mvo_step_norender(self.g)
     def render(self): self.L.mvo_render(self.g)
     def is_done(self, env_idx): return bool(self.L.mvo_is_done(self.g, env_idx))
+
+    def get_dones(self):
+        out = np.empty(self.num_envs, np.uint8)
+        self.L.mvo_get_dones(self.g, out.ctypes.data)
+        return out
+
+    def render_env(self, env_idx): self.L.mvo_render_env(self.g, int(env_idx))
 
     def get_last_rewards(self):
         out = np.zeros(self.num_envs * self.num_agents_per_env, np.float32)

@@ -96,7 +96,7 @@ def test_fast_hires_within_tolerance(hip):
                                               ("ObstaclesHard", 512, 1, 128, 128), ("Collect", 256, 1, 64, 64),
                                               ("HexMemory", 256, 2, 64, 64)])
 def test_fast_equals_exact_within_tolerance_at_full_size(hip, scenario, N, A, W, H):
-    """BASELINE.json sizes (the oracle is too slow there): the same gym rendered by both kernels after a rollout with natural
+    """BASELINE.json sizes, the whole slab (against the oracle's raster: sampled envs, tests/test_full_size_oracle_gpu.py): the same gym rendered by both kernels after a rollout with natural
     auto-resets; every frame of the slab compared."""
     import torch
     g = MegaverseGym(scenario, W, H, N, A, 4, False, {})

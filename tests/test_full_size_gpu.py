@@ -1,6 +1,6 @@
 """BASELINE.json configs[2], [3], [4] at their per-GPU sizes (configs[1] is test_parity_gpu.py::test_full_size_properties_1024_envs).
-The oracle is too slow at these sizes, so size-independent properties are checked on the product alone, in the default (fast) pixel
-mode the bench times: two identical runs are bit-identical (state, rewards, dones, whole observation slab), natural and forced
+The direct comparison with the oracle at these sizes is tests/test_full_size_oracle_gpu.py; here size-independent properties are checked on the
+product alone, in the default (fast) pixel mode the bench times: two identical runs are bit-identical (state, rewards, dones, whole observation slab), natural and forced
 resets happen, rewards are 0 on done steps, every frame is written (alpha 255) and all but a few show something, agents stay inside their world,
 and the exact and the fast observation pass agree to DESIGN.md's pixel tolerance on the final state."""
 import numpy as np

@@ -1,8 +1,8 @@
 """GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same seeded
 inputs.  Bar: bit-exact for every piece of discrete AND fp32 state, rewards, dones, and RGBA8 pixels
 (the library is built with -ffp-contract=off so that this is achievable; DESIGN.md "numerics").
-At BASELINE.json's full size (1024 envs) the oracle is too slow, so size-independent properties are
-checked instead."""
+At BASELINE.json's full size the oracle is compared directly in tests/test_full_size_oracle_gpu.py (its physics costs ~5 ms per 1024-env tick);
+test_full_size_properties_1024_envs below adds size-independent properties of the product alone."""
 import ctypes as C
 import os
 
