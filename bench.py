@@ -35,42 +35,85 @@ XGMI_PEAK_GBS = 7 * 153.0      # 7 point-to-point links x ~153 GB/s per GPU
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2   # wave64 VALU instructions per second: 1024 SIMD-32s, 2 cycles per instruction (MI355X_MICROARCH.md)
 
 
+def kernel_sources_sha16():
+    """sha256 (first 16 hex digits) of the kernel sources: profiles/pmc_traffic.json carries the hash of the tree its counter passes ran on, and
+    the bench line prints counter-derived figures only for the very same sources (the GPU box has no .git to ask for a revision)"""
+    import hashlib
+    d = os.path.join(ROOT, "megaverse_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def host_threads():
+    """-> (threads the CPU baseline may use, note): the CPUs this process may run on, capped by the container's CPU-time quota (cgroup cpu.max /
+    cfs_quota_us): a box that shows 256 CPUs under a quota of 16 CPUs' time runs 256 pinned threads SLOWER than one (measured, r04s: physics
+    309 k steps/s on 1 thread, 2.8 M on 16, 94 k on 256)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    note = f"{n} CPUs visible"
+    quota = None
+    try:
+        a, b = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if a != "max":
+            quota = float(a) / float(b)
+    except Exception:  # noqa: BLE001
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            if q > 0:
+                quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        except Exception:  # noqa: BLE001
+            pass
+    if quota:
+        note += f", cgroup CPU quota {quota:g}"
+        n = max(1, min(n, int(quota + 0.5)))
+    return max(1, n), note
+
+
 def cpu_baseline(scenario, obs_w, obs_h, n_env, agents, policy="multidiscrete"):
     """Oracle (CPU restatement, kind 'port') timed on this box's host cores on bounded samples of the same workload: same scenario /
-    obs size / seed / action stream.  Four legs, each the median of three repetitions:
-      all_threads   the full step (physics + logic + auto-reset + software raster) of all n_env envs, static block partition over every
-                    host thread like vector_env.cpp:65-87 -- this is `value`;
-      one_thread    the same on ONE pinned thread, on the first few envs of the batch (per-core figure);
-      physics_only  mvo_step_norender on all threads (what the reference's Bullet step costs in this restatement);
-      raster_only   mvo_render on all threads (the oracle's brute-force software raster: every primitive against every pixel --
-                    NOT the reference's GL renderer; a baseline, not a target).
+    obs size / seed / action stream.  The oracle runs as BASELINE.md 3 plans it: the reference's persistent worker pool (vector_env.cpp:16-40,
+    71-87: static block partition, the caller takes block 0 and spins on an atomic count), threads pinned one per allowed CPU (MVO_PIN=1),
+    the tile-culled software raster (mvo_set_raster(1): the brute-force checker's image byte for byte, tests/test_oracle_properties.py).
+    Legs, each the median of three repetitions after 20 warm-up ticks, each bounded in time so that the default bench run stays within minutes:
+      all_threads        the full step (physics + logic + auto-reset + software raster) of all n_env envs on every host thread -- this is `value`;
+      one_thread         the same on ONE pinned thread, on the first few envs of the batch (per-core figure);
+      physics_only       mvo_step_norender on all threads; physics_one_thread the same on one thread, all n_env envs: their ratio is printed as
+                         physics_scaling = rate(all) / (threads x rate(1)) (the serial auto-reset section and the memory system bound it);
+      raster_only        mvo_render on all threads (a software raster -- NOT the reference's GL renderer; a baseline, not a target).
     Actions go in through ONE batched call per tick."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib
     from megaverse_amd.rollout import sample_actions, action_masks, sample_single_bit_masks
-    threads = max(1, os.cpu_count() or 1)
+    os.environ["MVO_PIN"] = "1"
+    threads, quota_note = host_threads()
 
     def masks_of(step, n):
         if policy == "single-bit":
             return sample_single_bit_masks(1234, step, n * agents)
         return action_masks(sample_actions(1234, step, n * agents))
 
-    def leg(n, T, what, budget_s, reps=3, pin=None):
+    def leg(n, T, what, budget_s, reps=3, pin=None, warm=20):
         old = None
         if pin is not None and hasattr(os, "sched_setaffinity"):
             old = os.sched_getaffinity(0)
             os.sched_setaffinity(0, {sorted(old)[pin % len(old)]})
         try:
             g = oracle_lib.OracleGym(scenario, obs_w, obs_h, n, agents, T)
+            g.set_raster(True)
             g.seed(42)
             g.reset()
-            rates, steps_total, t_total, st = [], 0, 0.0, 0
+            masks = [masks_of(st, n) for st in range(warm + 64)]   # (drawn ahead: the numpy action sampler is not part of what is timed)
+            for st in range(warm):
+                g.set_action_masks(masks[st]); g.step_norender()
+            rates, steps_total, t_total, st = [], 0, 0.0, warm
             for _ in range(reps):
                 steps, t0 = 0, time.perf_counter()
                 while True:
                     if what != "raster":
-                        g.set_action_masks(masks_of(st, n))
+                        g.set_action_masks(masks[warm + (st % 64)])
                     if what == "full":
                         g.step()
                     elif what == "physics":
@@ -80,7 +123,7 @@ def cpu_baseline(scenario, obs_w, obs_h, n_env, agents, policy="multidiscrete"):
                     steps += 1
                     st += 1
                     el = time.perf_counter() - t0
-                    if el > budget_s / reps or steps >= 400:
+                    if el > budget_s / reps or steps >= 700:
                         break
                 rates.append(n * agents * steps / el)
                 steps_total += steps
@@ -90,18 +133,20 @@ def cpu_baseline(scenario, obs_w, obs_h, n_env, agents, policy="multidiscrete"):
             if old is not None:
                 os.sched_setaffinity(0, old)
         return {"value": float(np.median(rates)), "unit": "agent observations/sec" if what != "physics" else "agent steps/sec", "threads": T, "envs": n,
-                "steps": steps_total, "seconds": round(t_total, 2), "median_of": reps}
+                "steps": steps_total, "seconds": round(t_total, 2), "median_of": reps, "warmup_ticks": warm}
 
     n1 = max(1, min(n_env, 4))
-    legs = {"all_threads": leg(n_env, threads, "full", 9.0),
-            "one_thread": leg(n1, 1, "full", 6.0, pin=0),
+    legs = {"all_threads": leg(n_env, threads, "full", 8.0),
+            "one_thread": leg(n1, 1, "full", 4.0, pin=0),
             "physics_only": leg(n_env, threads, "physics", 3.0),
-            "raster_only": leg(n_env, threads, "raster", 6.0)}
+            "physics_one_thread": leg(n_env, 1, "physics", 3.0, pin=0),
+            "raster_only": leg(n_env, threads, "raster", 4.0)}
     a = legs["all_threads"]
     out = {"value": a["value"], "unit": "agent observations/sec", "cores": threads, "kind": "port",
-           "sample": f"oracle (CPU restatement of VectorEnv::step, software raster; NOT the reference binary) {scenario} num_envs={n_env} agents={agents} "
-                     f"obs {obs_w}x{obs_h}, policy {policy}: {a['steps']} steps in {a['seconds']} s on {threads} threads (static block partition like "
-                     f"vector_env.cpp:65-68), median of {a['median_of']}; one_thread = {n1} envs pinned to one core"}
+           "physics_scaling": legs["physics_only"]["value"] / (threads * legs["physics_one_thread"]["value"]),
+           "sample": f"oracle (CPU restatement of VectorEnv::step with a tile-culled software raster; NOT the reference binary) {scenario} num_envs={n_env} agents={agents} "
+                     f"obs {obs_w}x{obs_h}, policy {policy}: {a['steps']} steps in {a['seconds']} s on {threads} pinned threads ({quota_note}; persistent worker pool, static block "
+                     f"partition, caller participates: vector_env.cpp:16-40,65-87), 20 warm-up ticks, median of {a['median_of']}; one_thread = {n1} envs pinned to one core"}
     out.update(legs)
     return out
 
@@ -113,11 +158,12 @@ def cpu_baseline_mixed(scenarios, obs_w, obs_h, n_env, agents):
     import numpy as np
     import oracle_lib
     from megaverse_amd.rollout import sample_actions, action_masks
-    threads = max(1, os.cpu_count() or 1)
+    threads, _ = host_threads()
     per = n_env // len(scenarios)
     gyms = []
     for name in scenarios:
         g = oracle_lib.OracleGym(name, obs_w, obs_h, per, agents, threads)
+        g.set_raster(True)   # (the tile-culled software raster: the brute-force checker's image, several times faster)
         g.seed(42)
         g.reset()
         gyms.append(g)
@@ -262,7 +308,7 @@ def main():
     ap.add_argument("--gather", default="allgather", choices=["allgather", "p2p"],
                     help="N>1: how the observation slabs are assembled: one all_gather_into_tensor (RCCL's choice of algorithm) or grouped point-to-point "
                          "sends / receives, one shard per peer link (the fully connected xGMI shape)")
-    ap.add_argument("--gather-format", default="rgba", choices=["rgba", "rgb"],
+    ap.add_argument("--gather-format", default="rgb", choices=["rgba", "rgb"],
                     help="N>1: what the gather moves: the slab as rendered, or R, G, B packed on the communication stream (alpha is 255 everywhere): 3/4 of the bytes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pixels", default="fast", choices=["fast", "exact"], help="observation arithmetic (DESIGN.md 'pixel tolerance')")
@@ -422,6 +468,18 @@ def main():
             gym.set_output_ring(batch, ring.data_ptr())
         elapsed_no_gather = timed(step0, False, batched)
         step0 += args.steps
+    # N > 1: the one-GPU rate measured INSIDE this process group -- rank 0 steps alone while the other ranks wait at the barrier -- so that the
+    # line can state its own efficiencies (per-GPU rate / solo rate) instead of leaving them to a comparison with another run
+    elapsed_solo = None
+    if world > 1 and not dry:
+        fence()
+        if rank == 0:
+            t0 = time.perf_counter()
+            run_steps(step0, args.steps, False, batched)
+            torch.cuda.synchronize()
+            elapsed_solo = time.perf_counter() - t0
+        step0 += args.steps
+        fence()
 
     # ---- per-kernel profile: a separate, untimed loop with HIP events around every kernel, each interval on one stream
     prof = None
@@ -589,6 +647,14 @@ def main():
             line["single_device"] = True
         if gather_check is not None:
             line["gather_check"] = gather_check
+        if world > 1:
+            line["distributed"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks_per_gpu": 1 if not single else world}
+        if elapsed_solo is not None:
+            solo = frames * args.steps / elapsed_solo
+            line["value_solo_rank0"] = solo   # one GPU of this node alone, same process group (the others idle at a barrier)
+            line["value_efficiency"] = (total_obs / elapsed) / world / solo
+            if elapsed_no_gather is not None:
+                line["value_no_gather_efficiency"] = (total_obs / elapsed_no_gather) / world / solo
         if do_gather:
             slab_bytes = frames * H * W * gather.channels
             line["value_no_gather"] = total_obs / elapsed_no_gather
@@ -604,7 +670,8 @@ def main():
             traffic = traffic_step = valu = None
             try:   # per-launch PMC figures from the committed rocprofv3 passes (profiles/), only for the profiled config
                 pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-                if pt["config"] == {"envs_per_gpu": n_env, "agents_per_env": A, "obs": [W, H]} and args.scenario == "TowerBuilding":
+                pmc_stale = pt.get("source_sha16") != kernel_sources_sha16()   # counters of other sources are not this run's: traffic / valu stay null
+                if not pmc_stale and pt["config"] == {"envs_per_gpu": n_env, "agents_per_env": A, "obs": [W, H]} and args.scenario == "TowerBuilding":
                     traffic = pt["kernels"].get("raster", {}).get("traffic_bytes_per_launch")
                     traffic_step = pt["kernels"].get("step", {}).get("traffic_bytes_per_launch")
                     valu = pt["kernels"].get("raster", {}).get("valu")
@@ -613,12 +680,19 @@ def main():
             raster_ms, step_ms = prof["raster"][0], prof["step"][0]
             achieved = bytes_per_frame * frames / (raster_ms * 1e-3) / 1e9 if raster_ms > 0 else 0.0
             achieved_step = step_bytes_per_env * n_env / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
-            line["roofline"] = {"bound": "valu", "kernel": ("mv::raster_fast_union_kernel x 2 (short-list + long-list variant)" if mixed else "mv::raster_fast_kernel") if args.pixels == "fast" else "mv::raster_kernel",
+            long_list = args.scenario.lower() in ("collect", "hexmemory", "hexexplore")
+            batch_raster = batched and not mixed and not long_list and args.pixels == "fast"   # the k passes of a call as ONE launch (mv_raster.hip: raster_fast_batch_kernel)
+            batch_step = batched and not mixed and args.scenario == "TowerBuilding" and A == 1     # the k ticks of a call as ONE launch (mv_step.hip: step_ticks_kernel)
+            line["roofline"] = {"bound": "valu", "kernel": ("mv::raster_fast_union_kernel x 2 (short-list + long-list variant)" if mixed else
+                                                          "mv::raster_fast_batch_kernel (the %d observation passes of a call in one launch; every figure here is PER TICK)" % batch if batch_raster
+                                                          else "mv::raster_glist_kernel" if long_list else "mv::raster_fast_kernel") if args.pixels == "fast" else "mv::raster_kernel",
+                                "ticks_per_launch": batch if batch_raster else 1,
                                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                 "avg_launch_ms": raster_ms, "launches_timed": prof["raster"][1], "algorithmic_bytes_per_launch": bytes_per_frame * frames,
-                                "note": "dominant kernel; achieved / peak / frac are the HBM figures (algorithmic bytes / launch time against 8 TB/s); "
-                                        "the kernel moves 1.01x its algorithmic bytes and is bound by VALU issue, see `valu`; per-launch time from HIP "
-                                        "events (same stream) in a separate untimed loop; traffic = HBM bytes/launch from rocprofv3 PMC"}
+                                "note": "dominant kernel; achieved / peak / frac are the HBM figures (algorithmic bytes per tick / launch time per tick against 8 TB/s); "
+                                        "the kernel moves ~1.0x its algorithmic bytes and is bound by VALU issue, see `valu`; launch time from HIP events "
+                                        "(same stream, around the launch the product runs: a batched call's one launch / its ticks) in a separate untimed loop; "
+                                        "traffic = HBM bytes per tick from rocprofv3 PMC passes of the same kernel sources (null otherwise)"}
             if valu and raster_ms > 0:   # wave64 VALU instructions issue over 2 cycles on a SIMD-32; 256 CUs x 4 SIMDs x 2.4 GHz
                 insts = valu["valu_insts_per_launch"]
                 line["roofline"]["valu"] = {"insts_per_launch": insts, "salu_insts_per_launch": valu.get("salu_insts_per_launch"),
@@ -628,7 +702,8 @@ def main():
                                             # retires one per 1.11 ns (the clock under an all-VALU load is below 2.4 GHz); min / max / cndmask / max3 cost more
                                             "probed_ns_per_fma_per_simd": 1.11, "frac_of_probed_fma_rate": insts * 1.11e-9 / 1024.0 / (raster_ms * 1e-3),
                                             "source": valu.get("source")}
-            line["roofline_physics"] = {"bound": "latency", "kernel": ("mv::step_union_kernel" if mixed else "mv::step_kernel") + " (voxel physics + scenario logic + auto-reset + frame setup)", "achieved": achieved_step,
+            line["roofline_physics"] = {"bound": "latency", "kernel": ("mv::step_union_kernel" if mixed else "mv::step_ticks_kernel (the %d ticks of a call in one launch; per tick)" % batch if batch_step else "mv::step_kernel") +
+                                                              " (voxel physics + scenario logic + auto-reset + frame setup)", "ticks_per_launch": batch if batch_step else 1, "achieved": achieved_step,
                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_step / HBM_PEAK_GBS, "traffic": traffic_step,
                                         "avg_launch_ms": step_ms, "launches_timed": prof["step"][1], "algorithmic_bytes_per_launch": step_bytes_per_env * n_env,
                                         "note": "north_star's >=40 % HBM target names this kernel; its working set is 1.7 KB per env (the 16 KB voxel chunk "

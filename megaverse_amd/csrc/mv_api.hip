@@ -176,6 +176,7 @@ struct mv_gym {
     std::vector<hipEvent_t> profEvents;          // 5 per profiled tick: [0] [1] around the step kernel (its stream), [2] [3] [4] before the
                                                  // observation pass, between frame sort and raster, after the raster (the caller's stream)
     int profMax = 0, profCount = 0;
+    std::vector<int> profTicks;                  // ticks an entry covers: 1, or the k ticks of a batched call whose launches are timed as a whole
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1161,12 +1162,23 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
     // One TowerBuilding gym, several rendered ticks with device-drawn actions, nothing timed per tick: ONE step launch runs the k ticks of every
     // env (launch_step_ticks; MV_STEP_TICKS=0: k launches).  Its views are collected in the loop below.
     static const bool ticksOff = getenv("MV_STEP_TICKS") && atoi(getenv("MV_STEP_TICKS")) == 0;
-    const bool multiTick = !ticksOff && n == 1 && L->A == 1 && k >= 2 && k <= MAX_STEP_TICKS && render && policy != POLICY_NONE && L->scenario == SCN_TOWER &&   // (several agents per env: measured slower, 16.3 against 19.6 M obs/s at 512 x 4 -- four waves of ~180 VGPRs per env resident for the whole call)
-                           !(L->profCount < L->profMax) && !L->gv.dbg;
+    const bool canMultiTick = !ticksOff && n == 1 && L->A == 1 && k >= 2 && k <= MAX_STEP_TICKS && render && policy != POLICY_NONE && L->scenario == SCN_TOWER &&   // (several agents per env: measured slower, 16.3 against 19.6 M obs/s at 512 x 4 -- four waves of ~180 VGPRs per env resident for the whole call)
+                              !L->gv.dbg;
+    const bool canBatchRaster = render && allFast && n == 1 && k >= 2 && L->ringObs && L->ringCount >= k;
+    // timing (mv_profile_begin): a batched call that takes both one-launch paths is timed as a whole -- one entry, events around the step
+    // launch and around the raster launch, k ticks -- so that the figures are those of the launches the product runs; otherwise tick by tick
+    const bool profiling = render && L->profCount < L->profMax;
+    hipEvent_t *callEv = nullptr;
+    if (profiling && canMultiTick && canBatchRaster && k <= MAX_UNION) {
+        callEv = &L->profEvents[(size_t)L->profCount * 5];
+        L->profTicks[(size_t)L->profCount] = k;
+        ++L->profCount;
+    }
+    const bool multiTick = canMultiTick && (!profiling || callEv);
     for (int j = 0; j < k; ++j) {
-        const bool prof = render && L->profCount < L->profMax;
+        const bool prof = !callEv && render && L->profCount < L->profMax;
         evs[j] = prof ? &L->profEvents[(size_t)L->profCount * 5] : nullptr;
-        if (prof) ++L->profCount;
+        if (prof) { L->profTicks[(size_t)L->profCount] = 1; ++L->profCount; }
         UnionStepArgs ua;
         ua.n = n;
         int envs = 0;
@@ -1195,8 +1207,10 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
                 const int firstPart = std::min(cnt, hists - a0);
                 HIP_TRY(hipMemsetAsync(reinterpret_cast<uint8_t *>(L->gv.lpt_hist) + (size_t)a0 * hb, 0, (size_t)firstPart * hb, sim));
                 if (cnt > firstPart) HIP_TRY(hipMemsetAsync(L->gv.lpt_hist, 0, (size_t)(cnt - firstPart) * hb, sim));
-                launch_step_ticks(views.data(), k, sim, L->w, L->h, own ? L->simDone : nullptr);
-                simDoneRides = own;
+                if (callEv) HIP_TRY(hipEventRecord(callEv[0], sim));
+                launch_step_ticks(views.data(), k, sim, L->w, L->h, own && !callEv ? L->simDone : nullptr);
+                if (callEv) HIP_TRY(hipEventRecord(callEv[1], sim));
+                simDoneRides = own && !callEv;
             }
         } else if (n == 1) simDoneRides = launch_step_of(L, views[(size_t)j * n], sim, fused, own && j == k - 1 && !evs[j] ? L->simDone : nullptr);
         else {
@@ -1231,7 +1245,7 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
     // One gym, several ticks, every tick's observations in a slab of its own (an output ring at least k deep), nothing timed per tick: the
     // observation passes of up to MAX_UNION ticks go out as ONE launch (launch_raster_batch: the next tick's expensive frames fill the tail of
     // the previous tick's pass).  The ticks are collected below and launched at the end of their chunk.
-    bool batchRaster = render && allFast && n == 1 && k >= 2 && L->ringObs && L->ringCount >= k;
+    bool batchRaster = canBatchRaster;
     for (int j = 0; j < k; ++j) batchRaster = batchRaster && !evs[j];
     std::vector<PublishTo> chunkPubs;
     std::vector<uint32_t *> chunkObs;
@@ -1253,6 +1267,7 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
             static const int chunkMax = getenv("MV_RASTER_BATCH") ? std::min((int)MAX_UNION, std::max(1, atoi(getenv("MV_RASTER_BATCH")))) : (int)MAX_UNION;   // (0: off, launch_raster_batch declines)
             if (j == k - 1 || (int)chunkObs.size() >= chunkMax) {
                 const int cn = (int)chunkObs.size();
+                if (callEv) { HIP_TRY(hipEventRecord(callEv[2], L->stream)); HIP_TRY(hipEventRecord(callEv[3], L->stream)); }
                 int r = cn >= 2 ? launch_raster_batch(&views[(size_t)chunkFirst], chunkObs.data(), pubInRaster ? chunkPubs.data() : nullptr, cn, L->w, L->h, L->stream, mark) : 1;
                 if (r < 0) return fail("mv_step: observation size above 1024x1024");
                 if (r == 1)   // (not applicable to this gym -- long lists -- or a chunk of one tick: tick by tick)
@@ -1260,6 +1275,7 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
                         if (launch_raster(views[(size_t)chunkFirst + q], chunkObs[q], L->w, L->h, L->stream, nullptr, 1, /*setup_done=*/1, pubInRaster ? &chunkPubs[q] : nullptr,
                                           q == cn - 1 ? mark : nullptr))
                             return fail("mv_step: observation size above 1024x1024");
+                if (callEv) HIP_TRY(hipEventRecord(callEv[4], L->stream));
                 chunkFirst = j + 1;
                 chunkPubs.clear(); chunkObs.clear();
             }
@@ -1442,6 +1458,7 @@ int mv_profile_begin(mv_gym *g, int32_t max_steps)
         HIP_TRY(hipEventCreate(&e));
         g->profEvents.push_back(e);
     }
+    g->profTicks.assign((size_t)max_steps, 1);
     g->profMax = max_steps;
     g->profCount = 0;
     return 0;
@@ -1463,9 +1480,11 @@ int mv_profile_end(mv_gym *g, float *avg_ms4, int32_t *counts4)
             HIP_TRY(hipEventElapsedTime(&ms, g->profEvents[(size_t)i * 5 + FROM[k]], g->profEvents[(size_t)i * 5 + FROM[k] + 1]));
             sum[k] += ms;
         }
+    int ticks = 0;   // (an entry of a batched call covers its k ticks: the averages are per tick)
+    for (int i = 0; i < g->profCount; ++i) ticks += g->profTicks[(size_t)i];
     for (int k = 0; k < 4; ++k) {
-        avg_ms4[k] = g->profCount ? (float)(sum[k] / g->profCount) : 0.0f;
-        counts4[k] = g->profCount;
+        avg_ms4[k] = ticks ? (float)(sum[k] / ticks) : 0.0f;
+        counts4[k] = ticks;
     }
     g->profMax = 0;
     g->profCount = 0;

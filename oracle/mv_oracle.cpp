@@ -32,6 +32,10 @@
 #include <string>
 #include <thread>
 #include <vector>
+#ifdef __linux__
+#include <pthread.h>
+#include <sched.h>
+#endif
 
 namespace mvo {
 
@@ -2783,7 +2787,59 @@ static inline uint8_t to_u8(float v)
     return (uint8_t)(int)floorf(v * 255.0f + 0.5f);
 }
 
-static void render_agent(const Env &e, int viewer, int W, int H, uint8_t *out)
+// Conservative screen rectangle of a primitive's bounding box for the tiled raster below: the projection of the part of the box in front of the
+// plane w = NEAR_Z / 2 (camera depth) -- the corners in front of it plus the points where the box's edges pierce it -- widened by a pixel and a
+// half.  It only ever culls; the pixels do not depend on it (the HIP frame setup has a rectangle of its own, mv_frame.h, for the same purpose).
+struct ScreenRect { int x0, x1, y0, y1; bool any; };
+
+static ScreenRect prim_screen_rect(const Prim &p, const Cam *cams, int viewer, int W, int H)
+{
+    V3 lo = p.lo, hi = p.hi;
+    if (p.kind == 2) { const float r = p.hi.x, hl = p.hi.y; lo = v3(p.lo.x - r, p.lo.y - (hl + r), p.lo.z - r); hi = v3(p.lo.x + r, p.lo.y + (hl + r), p.lo.z + r); }
+    else if (p.kind == 3) {
+        const float r = p.hi.x, h = p.hi.y;
+        lo = v3(p.lo.x - r, p.hi.z > 0.0f ? p.lo.y - h : p.lo.y, p.lo.z - r);
+        hi = v3(p.lo.x + r, p.hi.z > 0.0f ? p.lo.y : p.lo.y + h, p.lo.z + r);
+    } else if (p.kind >= 4) {
+        const float ey = p.kind == 5 ? p.hi.y * 2.0f : p.kind == 6 ? p.hi.y * 0.5f : p.hi.y;
+        lo = v3(p.lo.x - p.hi.x, p.lo.y - ey, p.lo.z - p.hi.z); hi = v3(p.lo.x + p.hi.x, p.lo.y + ey, p.lo.z + p.hi.z);
+    }
+    const Cam &cv = cams[viewer];
+    double cx[8], cy[8], cw[8];
+    for (int c = 0; c < 8; ++c) {
+        V3 q = v3((c & 1) ? hi.x : lo.x, (c & 2) ? hi.y : lo.y, (c & 4) ? hi.z : lo.z);
+        if (p.frame != viewer) {
+            if (p.frame >= MAX_AGENTS) q = hex_to_world(p.frame - MAX_AGENTS, q);
+            else if (p.frame >= 0) q = cam_to_world(cams[p.frame], q);
+            q = mat_tmul(cv.c, q - cv.eye);
+        }
+        cx[c] = q.x; cy[c] = q.y; cw[c] = -double(q.z);
+    }
+    const double clipW = 0.5 * NEAR_Z;
+    double xmin = 1e30, xmax = -1e30, ymin = 1e30, ymax = -1e30;
+    bool any = false;
+    auto add = [&](double x, double y, double w) { x /= w; y /= w; xmin = std::min(xmin, x); xmax = std::max(xmax, x); ymin = std::min(ymin, y); ymax = std::max(ymax, y); any = true; };
+    for (int c = 0; c < 8; ++c) if (cw[c] >= clipW) add(cx[c], cy[c], cw[c]);
+    for (int axis = 0; axis < 3; ++axis)
+        for (int c = 0; c < 8; ++c) {
+            const int d = c | (1 << axis);
+            if (d == c || (cw[c] >= clipW) == (cw[d] >= clipW)) continue;
+            const double t = (clipW - cw[c]) / (cw[d] - cw[c]);
+            add(cx[c] + t * (cx[d] - cx[c]), cy[c] + t * (cy[d] - cy[c]), clipW);
+        }
+    ScreenRect r{0, 0, 0, 0, false};
+    if (!any) return r;
+    xmin = std::max(xmin / TAN_HALF_FOV, -4.0); xmax = std::min(xmax / TAN_HALF_FOV, 4.0);
+    ymin = std::max(ymin / TAN_HALF_FOV_Y, -4.0); ymax = std::min(ymax / TAN_HALF_FOV_Y, 4.0);
+    const double fx0 = (xmin * 0.5 + 0.5) * W - 1.5, fx1 = (xmax * 0.5 + 0.5) * W + 0.5, fy0 = (ymin * 0.5 + 0.5) * H - 1.5, fy1 = (ymax * 0.5 + 0.5) * H + 0.5;
+    if (fx1 < 0.0 || fy1 < 0.0 || fx0 > W || fy0 > H) return r;
+    r.x0 = (int)std::floor(std::max(fx0, 0.0)); r.x1 = (int)std::ceil(std::min(fx1, double(W - 1)));
+    r.y0 = (int)std::floor(std::max(fy0, 0.0)); r.y1 = (int)std::ceil(std::min(fy1, double(H - 1)));
+    r.any = true;
+    return r;
+}
+
+static void render_agent(const Env &e, int viewer, int W, int H, uint8_t *out, bool tiled = false)
 {
     std::vector<Prim> prims;
     build_prims(e, viewer, prims);
@@ -2801,16 +2857,16 @@ static void render_agent(const Env &e, int viewer, int W, int H, uint8_t *out)
     const V3 LIGHT = v3(0.0f, 4.0f, 2.0f);
     const float AMB = float(0x55) / 255.0f, DIF = float(0xbb) / 255.0f, LCOL = float(0xaa) / 255.0f;
 
-    for (int j = 0; j < H; ++j)
-        for (int i = 0; i < W; ++i) {
+    // one pixel against the primitives list[0 .. n) (indices into prims, ascending: ties keep the draw order)
+    auto pixel = [&](int i, int j, const int *list, int n) {
             const float xn = ((float(i) + 0.5f) / float(W)) * 2.0f - 1.0f;
             const float yn = ((float(j) + 0.5f) / float(H)) * 2.0f - 1.0f;
             const V3 dc = v3(xn * TAN_HALF_FOV, yn * TAN_HALF_FOV_Y, -1.0f);
             const V3 dw = mat_mul(cam.c, dc);
 
             float best = INFINITY; V3 bestN = v3(0, 0, 0); unsigned bestColor = 0; bool any = false;
-            for (size_t pi = 0; pi < prims.size(); ++pi) {
-                const Prim &p = prims[pi];
+            for (int li = 0; li < n; ++li) {
+                const Prim &p = prims[(size_t)list[li]];
                 float t; V3 n;  // n ends up in the viewer's camera space
                 bool hit;
                 if (p.kind == 2) {
@@ -2848,7 +2904,7 @@ static void render_agent(const Env &e, int viewer, int W, int H, uint8_t *out)
             }
 
             uint8_t *px = out + (size_t(j) * W + i) * 4;
-            if (!any) { px[0] = px[1] = px[2] = 0; px[3] = 255; continue; }
+            if (!any) { px[0] = px[1] = px[2] = 0; px[3] = 255; return; }
             const V3 P = dc * best;  // camera-space position
             V3 Ld = LIGHT - P;
             Ld = Ld * (1.0f / sqrtf(len2(Ld)));
@@ -2870,6 +2926,31 @@ static void render_agent(const Env &e, int viewer, int W, int H, uint8_t *out)
                 px[ch] = to_u8(v);
             }
             px[3] = 255;
+    };
+
+    std::vector<int> all(prims.size());
+    std::iota(all.begin(), all.end(), 0);
+    if (!tiled) {   // the checker: every primitive against every pixel
+        for (int j = 0; j < H; ++j)
+            for (int i = 0; i < W; ++i) pixel(i, j, all.data(), (int)all.size());
+        return;
+    }
+    // the timing leg (bench.py cpu_baseline): 16 x 16 tiles, each against the primitives whose conservative screen rectangle meets it.  Culling only
+    // removes primitives no pixel of the tile can hit, the lists stay in draw order: the image is the brute-force one, byte for byte
+    // (tests/test_oracle_properties.py: test_tiled_raster_equals_brute_force)
+    std::vector<ScreenRect> rects(prims.size());
+    for (size_t pi = 0; pi < prims.size(); ++pi) rects[pi] = prim_screen_rect(prims[pi], cams, viewer, W, H);
+    std::vector<int> list;
+    for (int ty = 0; ty < H; ty += 16)
+        for (int tx = 0; tx < W; tx += 16) {
+            const int x1 = std::min(tx + 16, W) - 1, y1 = std::min(ty + 16, H) - 1;
+            list.clear();
+            for (size_t pi = 0; pi < prims.size(); ++pi) {
+                const ScreenRect &r = rects[pi];
+                if (r.any && r.x0 <= x1 && r.x1 >= tx && r.y0 <= y1 && r.y1 >= ty) list.push_back((int)pi);
+            }
+            for (int j = ty; j <= y1; ++j)
+                for (int i = tx; i <= x1; ++i) pixel(i, j, list.data(), (int)list.size());
         }
 }
 
@@ -2878,6 +2959,7 @@ static void render_agent(const Env &e, int viewer, int W, int H, uint8_t *out)
 // ------------------------------------------------------------------------------------------------
 struct Gym {
     int w, h, numEnvs, numAgents, numThreads;
+    bool tiledRaster = false;   // mvo_set_raster: 1 = the tiled software raster (same image; the timing leg), 0 = every primitive against every pixel
     std::vector<std::unique_ptr<Env>> envs;
     std::vector<uint8_t> done;
     std::vector<float> trueObjective;
@@ -2885,25 +2967,95 @@ struct Gym {
     std::vector<std::string> sokoFiles;   // Sokoban: the level files found at construction (scenario_sokoban.cpp:40-78)
     Rng rng{std::random_device{}()};  // megaverse.cpp:253
 
+    // ---- the worker pool of VectorEnv (vector_env.cpp:5-40,58-87): numThreads - 1 PERSISTENT background threads + the caller; a task is handed out
+    // under a mutex + condition variable (one generation counter instead of the reference's per-thread task slots), every thread works through
+    // its static block of envs (envsPerThread = ceil(numEnvs / numThreads), :12,65-68), the caller takes block 0 and then spins on an atomic
+    // count of finished workers (:84-86 "just waiting on an atomic").  Started on first use; pinned one worker per allowed CPU (round-robin)
+    // when MVO_PIN=1 (bench.py's cpu_baseline sets it: BASELINE.md 3).  Spawning and joining std::threads on EVERY call -- what this was until
+    // round 3 -- cost more than the step itself beyond a few threads (T=1 4.9 ms, T=8 5.5 ms per 1024-env tick).
+    std::vector<std::thread> pool;
+    std::mutex poolMutex;
+    std::condition_variable poolCv;
+    std::function<void(int)> poolTask;
+    unsigned long long poolGen = 0;
+    bool poolStop = false;
+    int poolT = 1;
+    std::atomic<int> poolReady{0};
+
+    void pool_block(int t)
+    {
+        const int per = numEnvs / poolT + (numEnvs % poolT != 0);
+        const int s = t * per, en = std::min(s + per, numEnvs);
+        for (int i = s; i < en; ++i) poolTask(i);
+    }
+
+    void pool_start()
+    {
+        poolT = std::max(1, std::min(numThreads, numEnvs));
+        std::vector<int> cpus;
+#ifdef __linux__
+        if (const char *pin = getenv("MVO_PIN"); pin && atoi(pin)) {
+            cpu_set_t set;
+            if (sched_getaffinity(0, sizeof(set), &set) == 0)
+                for (int c = 0; c < CPU_SETSIZE; ++c) if (CPU_ISSET(c, &set)) cpus.push_back(c);
+        }
+#endif
+        for (int t = 1; t < poolT; ++t) {
+            pool.emplace_back([this, t] {
+                unsigned long long seen = 0;
+                for (;;) {
+                    {
+                        std::unique_lock<std::mutex> lock(poolMutex);
+                        poolCv.wait(lock, [&] { return poolStop || poolGen != seen; });
+                        if (poolStop) return;
+                        seen = poolGen;
+                    }
+                    pool_block(t);
+                    poolReady.fetch_add(1, std::memory_order_release);
+                }
+            });
+#ifdef __linux__
+            if (!cpus.empty()) {
+                cpu_set_t one; CPU_ZERO(&one); CPU_SET(cpus[(size_t)t % cpus.size()], &one);
+                pthread_setaffinity_np(pool.back().native_handle(), sizeof(one), &one);
+            }
+#endif
+        }
+    }
+
+    void pool_stop()
+    {
+        {
+            std::lock_guard<std::mutex> lock(poolMutex);
+            poolStop = true;
+        }
+        poolCv.notify_all();
+        for (auto &t : pool) t.join();
+        pool.clear();
+    }
+
     template <typename F> void parallel_envs(F f)
-    {   // vector_env.cpp:12,65-68 static block partition, caller participates
-        const int T = std::max(1, std::min(numThreads, numEnvs));
-        const int per = numEnvs / T + (numEnvs % T != 0);
-        std::vector<std::thread> th;
-        auto work = [&](int t) {
-            const int s = t * per, en = std::min(s + per, numEnvs);
-            for (int i = s; i < en; ++i) f(i);
-        };
-        for (int t = 1; t < T; ++t) th.emplace_back(work, t);
-        work(0);
-        for (auto &x : th) x.join();
+    {
+        if (pool.empty() && poolT == 1 && numThreads > 1 && numEnvs > 1) pool_start();
+        poolTask = f;
+        if (poolT == 1) { pool_block(0); return; }
+        poolReady.store(0, std::memory_order_relaxed);
+        {
+            std::lock_guard<std::mutex> lock(poolMutex);
+            ++poolGen;
+        }
+        poolCv.notify_all();
+        pool_block(0);
+        int spins = 0;
+        while (poolReady.load(std::memory_order_acquire) < poolT - 1)
+            if (++spins > 20000) std::this_thread::yield();   // (more threads than cores: do not starve the workers)
     }
 
     void render()
     {
         parallel_envs([&](int i) {
             for (int a = 0; a < numAgents; ++a)
-                render_agent(*envs[i], a, w, h, obs.data() + (size_t(i) * numAgents + a) * size_t(w) * h * 4);
+                render_agent(*envs[i], a, w, h, obs.data() + (size_t(i) * numAgents + a) * size_t(w) * h * 4, tiledRaster);
         });
     }
 
@@ -3012,7 +3164,7 @@ mvo_gym *mvo_create(const char *scenario, int w, int h, int num_envs, int num_ag
     return g;
 }
 
-void mvo_close(mvo_gym *g) { delete g; }
+void mvo_close(mvo_gym *g) { if (g) { g->pool_stop(); delete g; } }
 
 void mvo_seed(mvo_gym *g, int seed)
 {   // megaverse.cpp:60-69
@@ -3050,6 +3202,7 @@ void mvo_set_action_masks(mvo_gym *g, const int *masks)   // [N*A] env-major, on
 void mvo_step(mvo_gym *g) { g->step(true); }
 void mvo_step_norender(mvo_gym *g) { g->step(false); }
 void mvo_render(mvo_gym *g) { g->render(); }
+void mvo_set_raster(mvo_gym *g, int tiled) { g->tiledRaster = tiled != 0; }
 int mvo_is_done(mvo_gym *g, int env) { return g->done[env]; }
 void mvo_get_dones(mvo_gym *g, uint8_t *out) { for (int i = 0; i < g->numEnvs; ++i) out[i] = g->done[i]; }   /* all envs' done flags with one call (full-size parity tests) */
 void mvo_render_env(mvo_gym *g, int env)   /* the frames of ONE env's agents (full-size parity tests sample a few envs: the brute-force raster of all 1024 would take minutes) */

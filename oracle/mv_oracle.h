@@ -64,6 +64,7 @@ void mvo_step(mvo_gym *g);
 /* physics+logic+auto-reset only, no rendering (for long rollouts in tests) */
 void mvo_step_norender(mvo_gym *g);
 void mvo_render(mvo_gym *g);
+void mvo_set_raster(mvo_gym *g, int tiled);      /* 1: tile-culled software raster (byte-identical image; bench.py's timing leg), 0 (default): brute force */
 void mvo_render_env(mvo_gym *g, int env_idx);   /* only this env's agents' frames */
 void mvo_get_dones(mvo_gym *g, uint8_t *out);    /* [N] */
 

@@ -30,26 +30,35 @@ def pick(d, needle):
 
 def main():
     tag = sys.argv[1]
+    ticks = int(sys.argv[2]) if len(sys.argv) > 2 else 8   # ticks per launch of the batched kernels (bench.py's default): their counters are divided by it
+    sys.path.insert(0, ROOT)
+    from bench import kernel_sources_sha16
     P = lambda n: os.path.join(ROOT, "profiles", f"{tag}_pmc_{n}.csv")
     wr, fe, sq, sq2 = counters(P("WRITE_SIZE")), counters(P("FETCH_SIZE")), counters(P("SQ")), counters(P("SQ2"))
     out = {"source": f"profiles/{tag}_pmc_WRITE_SIZE.csv + {tag}_pmc_FETCH_SIZE.csv + {tag}_pmc_SQ.csv + {tag}_pmc_SQ2.csv (rocprofv3 --pmc, separate passes, mean "
                      "per dispatch; FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section; unit KB)",
+           "source_sha16": kernel_sources_sha16(),   # bench.py prints these figures only while the kernel sources are the ones the passes ran on
            "config": {"envs_per_gpu": 1024, "agents_per_env": 1, "obs": [128, 128]}, "kernels": {}}
-    for key, needle in (("raster", "raster_fast_kernel"), ("step", "step_kernel")):
-        kn, w = pick(wr, needle)
+    # the batched kernels (k ticks per launch) when the passes ran bench.py's default call size, else the per-tick kernels; everything PER TICK
+    for key, needles in (("raster", (("raster_fast_batch_kernel", ticks), ("raster_fast_kernel", 1))), ("step", (("step_ticks_kernel", ticks), ("step_kernel", 1)))):
+        for needle, div in needles:
+            kn, w = pick(wr, needle)
+            if w:
+                break
         _, f = pick(fe, needle)
         _, s1 = pick(sq, needle)
         _, s2 = pick(sq2, needle)
         if not w or not f:
             continue
-        wb, fb = w["WRITE_SIZE"][1] * 1024.0, f["FETCH_SIZE"][1] * 1024.0 * 2.0
-        e = {"kernel": kn, "write_bytes": wb, "fetch_bytes": fb, "traffic_bytes_per_launch": wb + fb, "launches": w["WRITE_SIZE"][0]}
+        wb, fb = w["WRITE_SIZE"][1] * 1024.0 / div, f["FETCH_SIZE"][1] * 1024.0 * 2.0 / div
+        e = {"kernel": kn, "ticks_per_launch": div, "write_bytes": wb, "fetch_bytes": fb, "traffic_bytes_per_launch": wb + fb, "launches": w["WRITE_SIZE"][0]}
         if s1:
-            e["valu"] = {"valu_insts_per_launch": s1["SQ_INSTS_VALU"][1], "salu_insts_per_launch": s2.get("SQ_INSTS_SALU", (0, None))[1],
-                         "lds_insts_per_launch": s1.get("SQ_INSTS_LDS", (0, None))[1], "wave_cycles": s1.get("SQ_WAVE_CYCLES", (0, None))[1],
-                         "wait_inst_any": s1.get("SQ_WAIT_INST_ANY", (0, None))[1], "wait_any": s2.get("SQ_WAIT_ANY", (0, None))[1],
-                         "active_inst_any": s2.get("SQ_ACTIVE_INST_ANY", (0, None))[1], "source": f"profiles/{tag}_pmc_SQ.csv, {tag}_pmc_SQ2.csv"}
-        out["kernels"][key] = e
+            per = lambda d, k: (d[k][1] / div) if k in d else None
+            e["valu"] = {"valu_insts_per_launch": per(s1, "SQ_INSTS_VALU"), "salu_insts_per_launch": per(s2, "SQ_INSTS_SALU"),
+                         "lds_insts_per_launch": per(s1, "SQ_INSTS_LDS"), "wave_cycles": per(s1, "SQ_WAVE_CYCLES"),
+                         "wait_inst_any": per(s1, "SQ_WAIT_INST_ANY"), "wait_any": per(s2, "SQ_WAIT_ANY"),
+                         "active_inst_any": per(s2, "SQ_ACTIVE_INST_ANY"), "source": f"profiles/{tag}_pmc_SQ.csv, {tag}_pmc_SQ2.csv"}
+        out["kernels"][key] = e   # ("per launch" in the field names: per TICK, the launch of the per-tick kernels)
     json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 

@@ -59,6 +59,7 @@ def lib():
         L.mvo_is_done.argtypes = [C.c_void_p, C.c_int]
         L.mvo_get_dones.argtypes = [C.c_void_p, C.c_void_p]
         L.mvo_render_env.argtypes = [C.c_void_p, C.c_int]
+        L.mvo_set_raster.argtypes = [C.c_void_p, C.c_int]
         L.mvo_get_last_rewards.argtypes = [C.c_void_p, C.c_void_p]
         L.mvo_true_objective.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.mvo_true_objective.restype = C.c_float
@@ -144,6 +145,7 @@ class OracleGym:
         return out
 
     def render_env(self, env_idx): self.L.mvo_render_env(self.g, int(env_idx))
+    def set_raster(self, tiled): self.L.mvo_set_raster(self.g, 1 if tiled else 0)
 
     def get_last_rewards(self):
         out = np.zeros(self.num_envs * self.num_agents_per_env, np.float32)

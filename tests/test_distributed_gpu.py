@@ -29,3 +29,8 @@ def test_two_ranks_of_real_gyms_gather_the_single_gym_slab(hip, scenario, agents
     assert rec["gather_check"] is True, rec
     assert rec["gather"]["bytes_received_per_gpu_per_step"] == 12 * agents * 48 * 32 * (3 if fmt == "rgb" else 4)
     assert rec["value"] > 0 and rec["value_no_gather"] > 0
+    # the line states what it ran under and its own efficiencies: per-GPU rate / the rate of rank 0 alone in the same process group
+    assert rec["distributed"]["world_size"] == 2 and rec["distributed"]["backend"] == "gloo"   # (gloo: two ranks cannot share one GPU under RCCL)
+    assert rec["value_solo_rank0"] > 0 and 0 < rec["value_efficiency"] and 0 < rec["value_no_gather_efficiency"]
+    assert abs(rec["value_efficiency"] - rec["value"] / 2 / rec["value_solo_rank0"]) < 1e-9
+    assert rec["gather"]["xgmi_bound_ms_per_step"] > 0

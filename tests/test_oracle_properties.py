@@ -91,3 +91,27 @@ def test_collect_rewards_are_integers_of_the_shaping_table_and_diamonds_only_dis
                 assert all(b == a or b == 0 for a, b in zip(prev[1], state)), (st, e)        # collected diamonds never come back
             seen[e] = (int(s["num_frames"]), state)
             assert int(s["solved"]) in (0, 1) and (int(s["solved"]) == 0 or int(s["highest_tower"]) >= int(s["num_platforms"]))
+
+
+@pytest.mark.parametrize("scenario,A,W,H", [("TowerBuilding", 2, 64, 64), ("ObstaclesHard", 1, 64, 36), ("Collect", 2, 48, 48), ("Rearrange", 2, 64, 64),
+                                            ("Sokoban", 1, 64, 64), ("HexMemory", 2, 40, 24), ("HexExplore", 1, 40, 24), ("Empty", 2, 33, 17)])
+def test_tiled_raster_equals_brute_force(scenario, A, W, H, monkeypatch):
+    """the tile-culled software raster bench.py times as the CPU baseline's raster leg draws the image of the brute-force checker, byte for byte:
+    the culling rectangles are conservative, the per-pixel arithmetic and the draw order are the same code"""
+    import os
+    monkeypatch.setenv("BOXOBAN_LEVELS", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "boxoban"))
+    from megaverse_amd.rollout import action_masks, sample_actions
+    N = 4
+    g = oracle_lib.OracleGym(scenario, W, H, N, A, 2, False, {})
+    g.seed(9); g.reset()
+    for rnd in range(3):
+        for st in range(15):
+            g.set_action_masks(action_masks(sample_actions(3, 15 * rnd + st, N * A)))
+            g.step_norender()
+        g.set_raster(False); g.render()
+        brute = np.stack([g.get_observation(e, a).copy() for e in range(N) for a in range(A)])
+        g.set_raster(True); g.render()
+        tiled = np.stack([g.get_observation(e, a).copy() for e in range(N) for a in range(A)])
+        assert brute[..., :3].max() > 0
+        assert np.array_equal(brute, tiled), f"{scenario} round {rnd}: {int((brute != tiled).any(axis=-1).sum())} pixels differ"
+    g.close()
