@@ -575,7 +575,7 @@ struct FastArgs {   // what raster_fast_kernel needs of the GymView (fewer live 
 __device__ __forceinline__ void fast_publish(const FastArgs &fa, int blk)
 {
     if (fa.pub_n == 0) return;
-    const int i = blk * 256 + threadIdx.x;
+    const int i = blk * (int)blockDim.x + (int)threadIdx.x;
     if (i >= fa.pub_n) return;
     fa.pub_rewards[i] = fa.stage_rewards[i];
     const int e = i / fa.num_agents;
@@ -778,7 +778,7 @@ __host__ __device__ inline int graded_workgroups(int frames, int div) { return 2
 // share one XCD's L2 (the frame's list is read `split` times, neighbouring tiles write neighbouring lines).
 // GLIST: the records stay in global memory (the tile loop fetches the surviving ones with scalar loads); LDS gets the rectangles and one class
 // byte per primitive instead: 0 a box in the world frame, 1..3 a box in hex wall frame 0..2, 4 anything else
-template <int MAXVIS, bool GLIST = false>
+template <int MAXVIS, bool GLIST = false, int NT = 256>   // NT: threads of the workgroup (256, or 512: a whole frame per workgroup, raster_fast_body)
 __device__ __forceinline__ FastFrame fast_prologue(const FastArgs &fa, int blk, int W, int H, int split, float4 *s_vis, short4 *s_rect, float *s_hdr, float4 *s_col,
                                                    float4 *s_row, float2 *s_rowq, float *s_colq, unsigned char *s_cls = nullptr)
 {
@@ -803,7 +803,8 @@ __device__ __forceinline__ FastFrame fast_prologue(const FastArgs &fa, int blk, 
     if (fa.nosort) { if (tid == 0) s_frame = position; __syncthreads(); }
     else {
         static_assert(LPT_SUBS == 4, "the bin's counters are read as one int4");
-        const int4 c0 = *reinterpret_cast<const int4 *>(fa.hist + (LPT_BUCKETS - 1 - tid) * LPT_SUBS);   // the bin's LPT_SUBS counters
+        const bool binThread = NT == 256 || tid < LPT_BUCKETS;   // (one thread per cost bin; a 512-thread workgroup's other waves only keep the barriers company)
+        const int4 c0 = binThread ? *reinterpret_cast<const int4 *>(fa.hist + (LPT_BUCKETS - 1 - tid) * LPT_SUBS) : make_int4(0, 0, 0, 0);   // the bin's LPT_SUBS counters
         const int h = (c0.x + c0.y) + (c0.z + c0.w);
         int x = h;
 #pragma unroll
@@ -811,12 +812,12 @@ __device__ __forceinline__ FastFrame fast_prologue(const FastArgs &fa, int blk, 
             const int y = __shfl_up(x, off, 64);
             if (lane >= off) x += y;
         }
-        if (lane == 63) s_wsum[wave] = x;
+        if (lane == 63 && binThread) s_wsum[wave] = x;
         __syncthreads();
         int base = 0;
-        for (int w = 0; w < wave; ++w) base += s_wsum[w];
+        for (int w = 0; w < wave && w < 4; ++w) base += s_wsum[w];
         const int end = base + x, start = end - h;
-        if (position >= start && position < end) {   // the bin's lists one after the other
+        if (binThread && position >= start && position < end) {   // the bin's lists one after the other
             const int cs[LPT_SUBS] = {c0.x, c0.y, c0.z, c0.w};
             int off = position - start, sub = 0;
 #pragma unroll
@@ -835,22 +836,22 @@ __device__ __forceinline__ FastFrame fast_prologue(const FastArgs &fa, int blk, 
     if (tid < FH_FLOATS) s_hdr[tid] = gh[tid];
     {
         const float4 *src = reinterpret_cast<const float4 *>(fa.vis_prims + (size_t)frame * fa.vis_stride);
-        if (!GLIST) for (int i = tid; i < nVis * 2; i += 256) s_vis[i] = src[i];
+        if (!GLIST) for (int i = tid; i < nVis * 2; i += NT) s_vis[i] = src[i];
         else
-            for (int i = tid; i < nVis; i += 256) {
+            for (int i = tid; i < nVis; i += NT) {
                 const unsigned ml = __float_as_uint(reinterpret_cast<const float *>(src)[8 * i + 3]);   // kind | frame << 4 | slot << 8
                 const unsigned fl = (ml >> 4) & 15u;
                 s_cls[i] = (ml & 15u) != (unsigned)PRIM_BOX ? 4 : fl == 0u ? 0 : fl > (unsigned)MAX_AGENTS ? (unsigned char)(fl - (unsigned)MAX_AGENTS) : 4;
             }
         const short4 *rs = fa.vis_rects + (size_t)frame * fa.vis_stride;
-        for (int i = tid; i < nVis; i += 256) s_rect[i] = rs[i];
+        for (int i = tid; i < nVis; i += NT) s_rect[i] = rs[i];
         const float *c = gh + FH_CAM + FH_CAM_STRIDE * viewer + 3;   // (same arithmetic as the exact kernel: rays are bit-identical)
-        for (int i = tid; i < W; i += 256) {
+        for (int i = tid; i < W; i += NT) {
             const float dcx = (((float(i) + 0.5f) / float(W)) * 2.0f - 1.0f) * TAN_HALF_FOV;
             s_col[i] = make_float4(dcx, c[0] * dcx, c[3] * dcx, c[6] * dcx);
             s_colq[i] = dcx * dcx;
         }
-        for (int j = tid; j < H; j += 256) {
+        for (int j = tid; j < H; j += NT) {
             const float dcy = (((float(j) + 0.5f) / float(H)) * 2.0f - 1.0f) * TAN_HALF_FOV_Y;
             s_row[j] = make_float4(dcy, c[1] * dcy, c[4] * dcy, c[7] * dcy);
             s_rowq[j] = make_float2(dcy * dcy + 1.0f, 4.0f * dcy - 2.0f);
@@ -918,10 +919,12 @@ constexpr int CLS_MAX_TILES = 128;   // tiles of one workgroup that can be class
 // of the mask is set).  s_line[64 wave + 16 s + 4 f + e]: edge e of face f of the s-th box of the wave's current round as (a, b, c_in, span):
 // inside at every pixel of the tile <=> a x0 + b y0 + c_in >= 0 at the tile's first pixel (x0, y0); outside at every pixel <=> that + span <= 0.
 // Called by all 256 threads after the prologue's barrier (s_vis, s_rect, the header are in LDS); ends with a barrier.
-template <int TH>
+template <int TH, int NT>
 __device__ __forceinline__ void classify_tiles(uint4 *s_tile, float4 *s_line, const float4 *s_vis, const short4 *s_rect, const float *camv, int nVis, unsigned long long wb0,
                                                int W, int H, int part, int split, int tilesX, int numTiles, int perWG)
 {
+    constexpr int NW = NT / 64;        // waves of the workgroup
+    constexpr int PPR = 16 / NW;       // list positions per wave and round (256 edge-function slots in all: 4 with four waves, 2 with eight)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid < CLS_MAX_TILES) s_tile[tid] = make_uint4(0u, 0u, 0u, 0u);
     // the ray's world components as affine functions of the pixel: d_a(i, j) = A_a i + B_a j + C_a  (dc = (((i + .5) / W) 2 - 1) TAN, ..., -1)
@@ -935,54 +938,64 @@ __device__ __forceinline__ void classify_tiles(uint4 *s_tile, float4 *s_line, co
     const bool ehi = q & 1, eactive = q < 12;
     const float Ak = camv[3 + 3 * ek] * sx, Bk = camv[4 + 3 * ek] * sy, Ck = (camv[3 + 3 * ek] * ox + camv[4 + 3 * ek] * oy) - camv[5 + 3 * ek];
     const float Am = camv[3 + 3 * em] * sx, Bm = camv[4 + 3 * em] * sy, Cm = (camv[3 + 3 * em] * ox + camv[4 + 3 * em] * oy) - camv[5 + 3 * em];
-    float4 *myLines = s_line + 64 * wave;
+    float4 *myLines = s_line + 16 * PPR * wave;
     constexpr float WX = float(TILE_W - 1), WY = float(TH - 1);
     __syncthreads();   // s_tile cleared
-    for (int u0 = 0; u0 < perWG; u0 += 64) {   // (64 tiles at a time)
-        // this lane as a tile
-        const int u = u0 + lane;
-        const int tile = ((u >> 2) * split + part) * 4 + (u & 3);
-        const bool tvalid = u < perWG && tile < numTiles;
-        const int tyi = tile / tilesX, txi = tile - tyi * tilesX;
-        const int x0 = txi * TILE_W, y0 = tyi * TH;
-        const int x1 = min(x0 + TILE_W, W) - 1, y1 = min(y0 + TH, H) - 1;
-        const float fx0 = float(x0), fy0 = float(y0);
-        unsigned mlo = 0u, mhi = 0u, cover = 0u;
-        for (int base = 4 * wave; base < nVis; base += 16) {   // the waves share the list out: four positions per wave and round
-            // ---- the edge functions of this round's boxes (sixteen lanes per box)
-            const int P = min(base + es, nVis - 1);
-            const bool isBox = base + es < nVis && ((wb0 >> P) & 1ull) != 0ull;
-            const float4 lo4 = s_vis[2 * P], hi4 = s_vis[2 * P + 1];
-            const float lok = ek == 0 ? lo4.x : ek == 1 ? lo4.y : lo4.z, hik = ek == 0 ? hi4.x : ek == 1 ? hi4.y : hi4.z;
-            const float lom = em == 0 ? lo4.x : em == 1 ? lo4.y : lo4.z, him = em == 0 ? hi4.x : em == 1 ? hi4.y : hi4.z;
-            const float bnd = ehi ? him : lom;
-            const bool cand = isBox && eactive && (lok > 0.0f || hik < 0.0f);   // the eye is outside the box along k: the face towards it can be entered
-            const float pk = lok > 0.0f ? lok : hik;
-            // a covering face is drawn without a range test per pixel: its depth |hit| / |d| lies in [|p| / 1.69, |hit|_1] (|d| in [1, 1.69])
-            const float far1 = (__builtin_fmaxf(__builtin_fabsf(lo4.x), __builtin_fabsf(hi4.x)) + __builtin_fmaxf(__builtin_fabsf(lo4.y), __builtin_fabsf(hi4.y))) +
-                               __builtin_fmaxf(__builtin_fabsf(lo4.z), __builtin_fabsf(hi4.z));
-            const bool coverOK = cand && __builtin_fabsf(pk) >= 4.0f * NEAR_Z && far1 <= 0.5f * FAR_Z;
-            const float sg = ((pk > 0.0f) != ehi) ? 1.0f : -1.0f;   // sign(p), reversed for the hi edge
-            const float ea = sg * (pk * Am - bnd * Ak), eb = sg * (pk * Bm - bnd * Bk), ec = sg * (pk * Cm - bnd * Ck);
-            const float mg = PLANAR_MARGIN * (__builtin_fabsf(pk) + __builtin_fabsf(bnd));
-            const float cin = ((ec + __builtin_fminf(0.0f, ea * WX)) + __builtin_fminf(0.0f, eb * WY)) - mg;
-            const float span = (__builtin_fabsf(ea) * WX + __builtin_fabsf(eb) * WY) + 2.0f * mg;
-            myLines[lane] = cand ? make_float4(ea, eb, cin, span) : make_float4(0.0f, 0.0f, -1.0f, 0.0f);   // (no such face: never inside, always outside)
-            const unsigned long long candMask = __ballot(cand), coverMask = __ballot(coverOK);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (a wave's LDS operations execute in order: only the compiler has to keep them so)
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // ---- every tile against them
+    // this lane as a tile: one per chunk of 64 local tiles (a whole 128-tile frame per workgroup: two)
+    constexpr int CH = CLS_MAX_TILES / 64;
+    int tX0[CH], tY0[CH], tX1[CH], tY1[CH];
+    bool tvalid[CH];
+    unsigned mlo[CH], mhi[CH], cover[CH];
 #pragma unroll
-            for (int sl = 0; sl < 4; ++sl) {
-                const int Q = base + sl;
-                if (Q >= nVis) break;
-                const uint2 rr = *reinterpret_cast<const uint2 *>(&s_rect[Q]);   // x0 | x1 << 16, y0 | y1 << 16
-                const bool ov = tvalid & ((int)(rr.x & 0xffffu) <= x1) & ((int)(rr.x >> 16) >= x0) & ((int)(rr.y & 0xffffu) <= y1) & ((int)(rr.y >> 16) >= y0);
+    for (int c = 0; c < CH; ++c) {
+        const int u = 64 * c + lane;
+        const int tile = ((u >> 2) * split + part) * 4 + (u & 3);
+        tvalid[c] = u < perWG && tile < numTiles;
+        const int tyi = tile / tilesX, txi = tile - tyi * tilesX;
+        tX0[c] = txi * TILE_W; tY0[c] = tyi * TH;
+        tX1[c] = min(tX0[c] + TILE_W, W) - 1; tY1[c] = min(tY0[c] + TH, H) - 1;
+        mlo[c] = mhi[c] = cover[c] = 0u;
+    }
+    for (int base = PPR * wave; base < nVis; base += 16) {   // the waves share the list out: PPR positions per wave and round
+        // ---- the edge functions of this round's boxes (sixteen lanes per box)
+        const int P = min(base + min(es, PPR - 1), nVis - 1);
+        const bool isBox = es < PPR && base + es < nVis && ((wb0 >> P) & 1ull) != 0ull;
+        const float4 lo4 = s_vis[2 * P], hi4 = s_vis[2 * P + 1];
+        const float lok = ek == 0 ? lo4.x : ek == 1 ? lo4.y : lo4.z, hik = ek == 0 ? hi4.x : ek == 1 ? hi4.y : hi4.z;
+        const float lom = em == 0 ? lo4.x : em == 1 ? lo4.y : lo4.z, him = em == 0 ? hi4.x : em == 1 ? hi4.y : hi4.z;
+        const float bnd = ehi ? him : lom;
+        const bool cand = isBox && eactive && (lok > 0.0f || hik < 0.0f);   // the eye is outside the box along k: the face towards it can be entered
+        const float pk = lok > 0.0f ? lok : hik;
+        // a covering face is drawn without a range test per pixel: its depth |hit| / |d| lies in [|p| / 1.69, |hit|_1] (|d| in [1, 1.69])
+        const float far1 = (__builtin_fmaxf(__builtin_fabsf(lo4.x), __builtin_fabsf(hi4.x)) + __builtin_fmaxf(__builtin_fabsf(lo4.y), __builtin_fabsf(hi4.y))) +
+                           __builtin_fmaxf(__builtin_fabsf(lo4.z), __builtin_fabsf(hi4.z));
+        const bool coverOK = cand && __builtin_fabsf(pk) >= 4.0f * NEAR_Z && far1 <= 0.5f * FAR_Z;
+        const float sg = ((pk > 0.0f) != ehi) ? 1.0f : -1.0f;   // sign(p), reversed for the hi edge
+        const float ea = sg * (pk * Am - bnd * Ak), eb = sg * (pk * Bm - bnd * Bk), ec = sg * (pk * Cm - bnd * Ck);
+        const float mg = PLANAR_MARGIN * (__builtin_fabsf(pk) + __builtin_fabsf(bnd));
+        const float cin = ((ec + __builtin_fminf(0.0f, ea * WX)) + __builtin_fminf(0.0f, eb * WY)) - mg;
+        const float span = (__builtin_fabsf(ea) * WX + __builtin_fabsf(eb) * WY) + 2.0f * mg;
+        if (es < PPR) myLines[lane] = cand ? make_float4(ea, eb, cin, span) : make_float4(0.0f, 0.0f, -1.0f, 0.0f);   // (no such face: never inside, always outside)
+        const unsigned long long candMask = __ballot(cand), coverMask = __ballot(coverOK);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (a wave's LDS operations execute in order: only the compiler has to keep them so)
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- every tile against them
+#pragma unroll
+        for (int sl = 0; sl < PPR; ++sl) {
+            const int Q = base + sl;
+            if (Q >= nVis) break;
+            const uint2 rr = *reinterpret_cast<const uint2 *>(&s_rect[Q]);   // x0 | x1 << 16, y0 | y1 << 16
+            const bool worldBox = (wb0 >> Q) & 1ull;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if (64 * c >= perWG) break;
+                const bool ov = tvalid[c] & ((int)(rr.x & 0xffffu) <= tX1[c]) & ((int)(rr.x >> 16) >= tX0[c]) & ((int)(rr.y & 0xffffu) <= tY1[c]) & ((int)(rr.y >> 16) >= tY0[c]);
                 if (!__any(ov)) continue;
                 bool hit = ov;
                 unsigned cov = 0u;
-                if ((wb0 >> Q) & 1ull) {   // an axis-aligned box of the world frame: through which face, if any?
+                if (worldBox) {   // an axis-aligned box of the world frame: through which face, if any?
+                    const float fx0 = float(tX0[c]), fy0 = float(tY0[c]);
                     bool missAll = true;
 #pragma unroll
                     for (int f = 0; f < 3; ++f) {
@@ -1001,20 +1014,23 @@ __device__ __forceinline__ void classify_tiles(uint4 *s_tile, float4 *s_line, co
                     hit = ov && !missAll;
                 }
                 if (hit) {
-                    if (Q < 32) mlo |= 1u << Q; else mhi |= 1u << (Q - 32);
-                    cover |= cov;
+                    if (Q < 32) mlo[c] |= 1u << Q; else mhi[c] |= 1u << (Q - 32);
+                    cover[c] |= cov;
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (the next round's lines are written after this round's were read)
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        if (tvalid) {
-            if (mlo) atomicOr(&s_tile[u].x, mlo);
-            if (mhi) atomicOr(&s_tile[u].y, mhi);
-            if (cover) atomicOr(&s_tile[u].z, cover);
-        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (the next round's lines are written after this round's were read)
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+        if (tvalid[c]) {
+            const int u = 64 * c + lane;
+            if (mlo[c]) atomicOr(&s_tile[u].x, mlo[c]);
+            if (mhi[c]) atomicOr(&s_tile[u].y, mhi[c]);
+            if (cover[c]) atomicOr(&s_tile[u].z, cover[c]);
+        }
     __syncthreads();
 }
 
@@ -1061,7 +1077,9 @@ __device__ __forceinline__ void planar_tile(int pos, int k, const float4 *s_vis,
 constexpr int fast_lds_bytes(int maxvis) { return 40 * maxvis + 4 * FH_FLOATS; }    // records 32 B + rectangles 8 B per primitive, frame header
 constexpr int glist_lds_bytes(int maxvis) { return 9 * maxvis + 4 * FH_FLOATS; }    // rectangles 8 B + class 1 B per primitive, frame header
 
-template <int MAXVIS, bool SHAPES, bool HEXF, int NP, bool CLS = true>   // CLS: with the tile classification (its tables cost 5 KB of LDS)
+// NT = 512 (MV_RASTER_WIDE=1, an experiment): ONE eight-wave workgroup per frame (the launch's split is 1): prologue and classification once per
+// frame instead of once per half frame, the eight waves share the frame's tiles out among them.  Measured slower (wide_workgroups below).
+template <int MAXVIS, bool SHAPES, bool HEXF, int NP, bool CLS = true, int NT = 256>   // CLS: with the tile classification
 __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *obs, int W, int H, int split, int blk, unsigned char *lds)
 {
     constexpr unsigned POS_MASK = MAXVIS - 1;
@@ -1086,7 +1104,7 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
 #define RT_MARK(i) do { } while (0)
 #endif
     fast_publish(fa, blk);
-    const FastFrame ff = fast_prologue<MAXVIS>(fa, blk, W, H, split, s_vis, s_rect, s_hdr, s_col, s_row, s_rowq, s_colq);
+    const FastFrame ff = fast_prologue<MAXVIS, false, NT>(fa, blk, W, H, split, s_vis, s_rect, s_hdr, s_col, s_row, s_rowq, s_colq);
     RT_MARK(1);
     const int frame = ff.frame, part = ff.part, viewer = ff.viewer, nVis = ff.nVis;
     split = ff.split;   // (graded split: this workgroup's frame may be cut into more or fewer pieces than the launch's nominal number)
@@ -1115,8 +1133,8 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
     const int perWG = (numTiles - part * 4 + 4 * split - 1) / (4 * split) * 4;   // this workgroup's tiles, rounded up to four per turn of its waves
     const bool cls = PLANAR && fa.planar && nVis <= 64 && perWG <= CLS_MAX_TILES && perWG >= 32;   // (uniform over the workgroup; few tiles do not repay the pass over the list)
     __shared__ int s_next;   // the tile loop's hand-out counter (below)
-    if (tid == 0) s_next = 4;
-    if (PLANAR && cls) classify_tiles<TH>(s_tile, s_line, s_vis, s_rect, camv, nVis, wb0, W, H, part, split, tilesX, numTiles, perWG);   // (ends with a barrier)
+    if (tid == 0) s_next = NT / 64;
+    if (PLANAR && cls) classify_tiles<TH, NT>(s_tile, s_line, s_vis, s_rect, camv, nVis, wb0, W, H, part, split, tilesX, numTiles, perWG);   // (ends with a barrier)
     else __syncthreads();
     RT_MARK(2);
 
@@ -1246,8 +1264,8 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
         }
     }
 #ifdef MV_RASTER_TIMING
-    if (fa.rdbg && lane == 0 && blk < 16384) {
-        unsigned long long *o = fa.rdbg + ((size_t)blk * 4 + wave) * 8;
+    if (fa.rdbg && lane == 0 && blk < 16384 / (NT / 256)) {
+        unsigned long long *o = fa.rdbg + ((size_t)blk * (NT / 64) + wave) * 8;
         o[0] = rt_[0]; o[1] = rt_[1]; o[2] = rt_[2]; o[3] = __builtin_amdgcn_s_memtime(); o[4] = rt_[5]; o[5] = __builtin_amdgcn_s_memrealtime();
         o[6] = (unsigned long long)nVis | ((unsigned long long)(cls ? 1 : 0) << 32); o[7] = (unsigned long long)ff.frame;
     }
@@ -1430,11 +1448,11 @@ __global__ __launch_bounds__(256, WAVES) void raster_glist_kernel(FastArgs fa, u
     raster_glist_body<MAXVIS, SHAPES, HEXF, NP>(fa, obs, W, H, split, (int)blockIdx.x, s_buf);
 }
 
-template <int MAXVIS, bool SHAPES, int WAVES, bool HEXF = false, int NP = 1>   // WAVES: waves per SIMD the variant is compiled for (register budget 512 / WAVES)
-__global__ __launch_bounds__(256, WAVES) void raster_fast_kernel(FastArgs fa, uint32_t *obs, int W, int H, int split)
+template <int MAXVIS, bool SHAPES, int WAVES, bool HEXF = false, int NP = 1, int NT = 256>   // WAVES: waves per SIMD the variant is compiled for (register budget 512 / WAVES)
+__global__ __launch_bounds__(NT, WAVES) void raster_fast_kernel(FastArgs fa, uint32_t *obs, int W, int H, int split)
 {
     __shared__ __attribute__((aligned(16))) unsigned char s_buf[fast_lds_bytes(MAXVIS)];
-    raster_fast_body<MAXVIS, SHAPES, HEXF, NP>(fa, obs, W, H, split, (int)blockIdx.x, s_buf);
+    raster_fast_body<MAXVIS, SHAPES, HEXF, NP, true, NT>(fa, obs, W, H, split, (int)blockIdx.x, s_buf);
 }
 
 // The observation pass of several gyms of one job with one launch (mv_group): workgroup b belongs to gym s with first[s] <= b < first[s + 1]
@@ -1464,8 +1482,8 @@ __global__ __launch_bounds__(256, WAVES) void raster_fast_union_kernel(UnionRast
 // next tick's expensive frames start in that tail, and there is one tail per call instead of one per tick.  The step's staged outputs of ALL k
 // ticks are published by the first workgroups, element by element in tick order (true_objective is only ever written by a finishing env:
 // what a later tick does not touch keeps the earlier tick's value, as with one launch per tick).
-template <int MAXVIS, bool SHAPES, int WAVES, int NP>
-__global__ __launch_bounds__(256, WAVES) void raster_fast_batch_kernel(UnionRasterArgs ua, int W, int H, int split)
+template <int MAXVIS, bool SHAPES, int WAVES, int NP, int NT = 256>
+__global__ __launch_bounds__(NT, WAVES) void raster_fast_batch_kernel(UnionRasterArgs ua, int W, int H, int split)
 {
     int s = 0;
 #pragma unroll
@@ -1476,7 +1494,7 @@ __global__ __launch_bounds__(256, WAVES) void raster_fast_batch_kernel(UnionRast
     __shared__ __attribute__((aligned(16))) unsigned char s_buf[fast_lds_bytes(MAXVIS)];
     FastArgs fa = ua.fa[s];
     fa.pub_n = 0;
-    raster_fast_body<MAXVIS, SHAPES, false, NP>(fa, ua.obs[s], W, H, split, (int)blockIdx.x - ua.first[s], s_buf);
+    raster_fast_body<MAXVIS, SHAPES, false, NP, true, NT>(fa, ua.obs[s], W, H, split, (int)blockIdx.x - ua.first[s], s_buf);
 }
 
 template <int MAXVIS, bool SHAPES, int WAVES, bool HEXF, int NP>
@@ -1547,6 +1565,24 @@ static void rdbg_dump()
     std::sort(spread.begin(), spread.end());
     if (!spread.empty()) fprintf(stderr, "raster timing: within a workgroup, last wave's end - first wave's end (us): mean %.1f p50 %.1f p90 %.1f max %.1f\n",
                                  std::accumulate(spread.begin(), spread.end(), 0.0) / spread.size(), spread[spread.size() / 2], spread[spread.size() * 9 / 10], spread.back());
+    {   // the longest-lived waves: where in the cost order was their workgroup (blk = its index in the launch), how long is their frame's list?
+        std::vector<std::pair<double, size_t>> byLife;
+        for (size_t w = 0; w < (size_t)16384 * 4; ++w) { const unsigned long long *o = &h[w * 8]; if (o[0]) byLife.push_back({double(o[5] - o[4]) * 0.01, w}); }
+        std::sort(byLife.begin(), byLife.end(), [](auto &a, auto &b) { return a.first > b.first; });
+        for (size_t q = 0; q < std::min<size_t>(byLife.size(), 12); q += 1) {
+            const size_t w = byLife[q].second; const unsigned long long *o = &h[w * 8];
+            fprintf(stderr, "raster timing: long wave #%zu: life %.1f us (start +%.1f us), workgroup %zu of the launch, frame %llu, nVis %llu, classified %llu, cycles prologue %llu cls %llu tiles %llu\n", q,
+                    byLife[q].first, double(o[4] - r0) * 0.01, w / 4, o[7], o[6] & 0xffffffffull, o[6] >> 32, o[1] - o[0], o[2] - o[1], o[3] - o[2]);
+        }
+        // mean life by decile of the launch order
+        const size_t nw = byLife.size();
+        std::vector<double> sum(10, 0.0); std::vector<int> cnt(10, 0);
+        size_t maxw = 0; for (auto &p : byLife) maxw = std::max(maxw, p.second);
+        for (auto &p : byLife) { const int d = (int)std::min<size_t>(9, p.second * 10 / (maxw + 1)); sum[d] += p.first; ++cnt[d]; }
+        fprintf(stderr, "raster timing: mean wave life by decile of the launch order (us):");
+        for (int d = 0; d < 10; ++d) fprintf(stderr, " %.1f", cnt[d] ? sum[d] / cnt[d] : 0.0);
+        fprintf(stderr, "  (%zu waves)\n", nw);
+    }
     std::sort(life.begin(), life.end()); std::sort(endAt.begin(), endAt.end());
     auto pct = [](const std::vector<double> &v, double p) { return v[std::min(v.size() - 1, (size_t)(p * v.size()))]; };
     fprintf(stderr, "raster timing (last launch, %zu waves): cycles per wave: prologue %.0f, classification %.0f, tile loop %.0f | wave life us: mean %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f | "
@@ -1685,6 +1721,15 @@ int launch_raster_union(const GymView *views, uint32_t *const *obs, const Publis
 // the fast observation passes of k ticks of one gym (views[j]: the slot tick j's step kernel filled; obs[j] / publish[j]: where tick j's
 // outputs go, which must differ from tick to tick -- an output ring -- for the observations) with one launch; 1: not this gym (long lists, hires
 // sizes, k out of range): the caller launches tick by tick
+// Eight-wave workgroups (one per frame) where the launch would cut every frame into two four-wave ones (two pixels per lane, nominal split 2):
+// MV_RASTER_WIDE=1.  Off by default: measured r04v, the kernel alone 51.2 us against 49.6 (the classification per wave only went from 11.3 k to
+// 9.6 k cycles, and a second round made of whole frames is a longer tail), the pipelined headline 19.7 M obs/s against 22.2 M.
+static bool wide_workgroups(int split, int np)
+{
+    static const bool on = getenv("MV_RASTER_WIDE") && atoi(getenv("MV_RASTER_WIDE")) != 0;
+    return on && split == 2 && np == 2;
+}
+
 // MV_RASTER_LDS_PAD=bytes: dynamic LDS the fast kernels ask for beyond their tables (an experiment knob: caps their workgroups per CU, leaving registers to the step kernels that run beside them)
 static size_t lds_pad()
 {
@@ -1701,7 +1746,10 @@ int launch_raster_batch(const GymView *views, uint32_t *const *obs, const Publis
     if (off) return 1;
     const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)W * sizeof(float) + (size_t)H * sizeof(float2) + lds_pad();
     const int frames = gv.num_envs * gv.num_agents;
-    const int np = fast_pixels_per_lane(W, H), split = fast_split(W, H, np, frames);
+    const int np = fast_pixels_per_lane(W, H);
+    int split = fast_split(W, H, np, frames);
+    const bool wide = wide_workgroups(split, np);   // a whole frame per eight-wave workgroup instead of two halves
+    if (wide) split = 1;
     UnionRasterArgs ua;
     ua.n = k;
     for (int j = 0; j < k; ++j) {
@@ -1710,9 +1758,12 @@ int launch_raster_batch(const GymView *views, uint32_t *const *obs, const Publis
         ua.fa[j] = fast_args_of(views[j], publish ? &publish[j] : nullptr);
     }
     for (int j = k; j <= MAX_UNION; ++j) ua.first[j] = k * frames * split;
-    const dim3 grid(k * frames * split), block(256);
+    const dim3 grid(k * frames * split), block(wide ? 512 : 256);
     const bool shapes = gv.scenario == SCN_REARRANGE;
-    if (np == 2) {
+    if (wide) {
+        if (shapes) launch_done(raster_fast_batch_kernel<VIS_SMALL, true, 6, 2, 512>, grid, block, dyn, stream, done, ua, W, H, split);
+        else launch_done(raster_fast_batch_kernel<VIS_SMALL, false, 7, 2, 512>, grid, block, dyn, stream, done, ua, W, H, split);
+    } else if (np == 2) {
         if (shapes) launch_done(raster_fast_batch_kernel<VIS_SMALL, true, 6, 2>, grid, block, dyn, stream, done, ua, W, H, split);
         else launch_done(raster_fast_batch_kernel<VIS_SMALL, false, 7, 2>, grid, block, dyn, stream, done, ua, W, H, split);
     } else {
@@ -1758,6 +1809,11 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
         const int ftiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H * np - 1) / (TILE_H * np));
         static const int gradedDiv = getenv("MV_RASTER_GRADED_DIV") ? std::max(2, atoi(getenv("MV_RASTER_GRADED_DIV"))) : 8;
         fg.graded = gradedEnv && gv.vis_stride <= VIS_SMALL && split == 2 && ftiles >= 32 && graded_heavy(frames, gradedDiv) > 0 ? gradedDiv : 0;
+        if (!fg.graded && wide_workgroups(split, np) && gv.vis_stride <= VIS_SMALL && !hexScen) {   // a whole frame per eight-wave workgroup
+            const KernelFn wfn = gv.scenario == SCN_REARRANGE ? raster_fast_kernel<VIS_SMALL, true, 6, false, 2, 512> : raster_fast_kernel<VIS_SMALL, false, 7, false, 2, 512>;
+            launch_done(wfn, dim3(frames), dim3(512), dyn, stream, done, fg, obs, W, H, 1);
+            return 0;
+        }
         launch_done(fn, dim3(fg.graded ? graded_workgroups(frames, fg.graded) : frames * split), dim3(256), dyn, stream, done, fg, obs, W, H, split);
         return 0;
     }
