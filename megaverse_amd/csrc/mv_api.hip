@@ -33,6 +33,7 @@ void launch_reset(const GymView &gv, int force_all, hipStream_t stream);
 void launch_step(const GymView &gv, hipStream_t stream, int W, int H, int render, hipEvent_t done = nullptr);
 void launch_step_ticks(const GymView *views, int k, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);   // k ticks + frame setups of every env, one launch (mv_step.hip)
 void launch_step_obstacles(const GymView &gv, hipStream_t stream, int W, int H, int render);
+void launch_step_obstacles_ticks(const GymView *views, int k, hipStream_t stream, int W, int H);   // k ticks + frame setups of every env (one agent), one launch
 void launch_reset_obstacles(const GymView &gv, const EpisodeBlob *blobs, int *status, int force_all, hipStream_t stream);
 void launch_step_rearrange(const GymView &gv, hipStream_t stream, int W, int H, int render);
 void launch_reset_rearrange(const GymView &gv, const RearrangeBlob *blobs, int *status, int force_all, hipStream_t stream);
@@ -1162,9 +1163,11 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
     // One TowerBuilding gym, several rendered ticks with device-drawn actions, nothing timed per tick: ONE step launch runs the k ticks of every
     // env (launch_step_ticks; MV_STEP_TICKS=0: k launches).  Its views are collected in the loop below.
     static const bool ticksOff = getenv("MV_STEP_TICKS") && atoi(getenv("MV_STEP_TICKS")) == 0;
-    const bool canMultiTick = !ticksOff && n == 1 && L->A == 1 && k >= 2 && k <= MAX_STEP_TICKS && render && policy != POLICY_NONE && L->scenario == SCN_TOWER &&   // (several agents per env: measured slower, 16.3 against 19.6 M obs/s at 512 x 4 -- four waves of ~180 VGPRs per env resident for the whole call)
+    const bool obstFamily = L->scenario == SCN_OBSTACLES || L->scenario == SCN_EMPTY;
+    const bool canMultiTick = !ticksOff && n == 1 && L->A == 1 && k >= 2 && k <= MAX_STEP_TICKS && render && policy != POLICY_NONE && (L->scenario == SCN_TOWER || (obstFamily && L->N >= 768)) &&   // (Obstacles at 512 envs: 11.6 against 12.0 M obs/s, at 1024: 16.9 against 16.1)   // (several agents per env: measured slower, 16.3 against 19.6 M obs/s at 512 x 4 -- four waves of ~180 VGPRs per env resident for the whole call)
                               !L->gv.dbg;
-    const bool canBatchRaster = render && allFast && n == 1 && k >= 2 && L->ringObs && L->ringCount >= k;
+    // (the one-launch observation passes only beside the one-launch step: k separate step kernels starve beside a pass that long -- 70-190 us each, r04l)
+    const bool canBatchRaster = canMultiTick && render && allFast && n == 1 && k >= 2 && L->ringObs && L->ringCount >= k;
     // timing (mv_profile_begin): a batched call that takes both one-launch paths is timed as a whole -- one entry, events around the step
     // launch and around the raster launch, k ticks -- so that the figures are those of the launches the product runs; otherwise tick by tick
     const bool profiling = render && L->profCount < L->profMax;
@@ -1208,9 +1211,10 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
                 HIP_TRY(hipMemsetAsync(reinterpret_cast<uint8_t *>(L->gv.lpt_hist) + (size_t)a0 * hb, 0, (size_t)firstPart * hb, sim));
                 if (cnt > firstPart) HIP_TRY(hipMemsetAsync(L->gv.lpt_hist, 0, (size_t)(cnt - firstPart) * hb, sim));
                 if (callEv) HIP_TRY(hipEventRecord(callEv[0], sim));
-                launch_step_ticks(views.data(), k, sim, L->w, L->h, own && !callEv ? L->simDone : nullptr);
+                if (obstFamily) launch_step_obstacles_ticks(views.data(), k, sim, L->w, L->h);
+                else launch_step_ticks(views.data(), k, sim, L->w, L->h, own && !callEv ? L->simDone : nullptr);
                 if (callEv) HIP_TRY(hipEventRecord(callEv[1], sim));
-                simDoneRides = own && !callEv;
+                simDoneRides = own && !callEv && !obstFamily;
             }
         } else if (n == 1) simDoneRides = launch_step_of(L, views[(size_t)j * n], sim, fused, own && j == k - 1 && !evs[j] ? L->simDone : nullptr);
         else {

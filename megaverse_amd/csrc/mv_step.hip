@@ -89,11 +89,6 @@ __global__ __launch_bounds__(256) void step_kernel(GymView gv, int W, int H, int
 // rate).  Here an env's workgroup becomes resident once and runs tick, frame setup (into slot j's lists), tick, ...: gv[j] is tick j's view
 // (its hand-over slot, its staging outputs, its action index, its cost histogram).  The histograms are cleared by the host before the launch
 // (lpt_no_clear): inside one launch env 0's "clear the next pass's histogram" would race with the envs that are a tick ahead.
-struct StepTicksArgs {
-    int32_t n;
-    GymView gv[MAX_STEP_TICKS];
-};
-
 // One agent: ONE wave per env (the single-tick kernel's second wave only helps with the frame setup, and idles through the tick): the
 // workgroups stay resident for the whole call beside the observation passes of the previous one, and every wave of ~150 VGPRs they hold is
 // two or three waves the pass cannot have (measured: 21.1 M obs/s with two waves per env, 22.3 M with one).

@@ -47,6 +47,31 @@ __global__ __launch_bounds__(256) void step_obstacles_kernel(GymView gv, int W, 
     }
 }
 
+// k consecutive ticks of every env with one launch (one agent per env; see step_ticks_kernel, mv_step.hip, for why): one wave per env, resident for the
+// whole batched call; gv[j] is tick j's view.  An env that finishes swaps its next resident episode in at the tail of its tick as always -- a
+// batched call only ever spans ticks of gyms whose episodes are long (mv_step_n steps the others tick by tick), so the two resident episodes
+// outlast it.
+__global__ __launch_bounds__(64) void step_obstacles_ticks_kernel(StepTicksArgs a, int W, int H)
+{
+    __shared__ FrameScratch s_fs;
+    const int env = blockIdx.x;
+    for (int j = 0; j < a.n; ++j) {
+        const GymView &gv = a.gv[j];
+        obstacles_tick<1>(gv, env);
+        wave_sync();   // the tick's stores before the frame setup's loads (one wave: no barrier needed)
+        frame_setup_body<64, true>(gv, env, W, H, s_fs);
+    }
+}
+
+void launch_step_obstacles_ticks(const GymView *views, int k, hipStream_t stream, int W, int H)
+{
+    StepTicksArgs a;
+    a.n = k;
+    for (int j = 0; j < k; ++j) a.gv[j] = views[j];
+    for (int j = k; j < MAX_STEP_TICKS; ++j) a.gv[j] = views[k - 1];
+    hipLaunchKernelGGL(step_obstacles_ticks_kernel, dim3(views[0].num_envs), dim3(64), 0, stream, a, W, H);
+}
+
 __global__ __launch_bounds__(64) void reset_obstacles_kernel(GymView gv, const EpisodeBlob *blobs, int *status, int force_all)
 {
     const int env = blockIdx.x;

@@ -171,6 +171,12 @@ struct GymView {
     int32_t lpt_no_clear;      // 1: the frame setup does not clear the cost histogram of the next pass (a multi-tick step launch: cleared up front, mv_step.hip)
 };
 
+// the views of the n consecutive ticks of a multi-tick step launch (mv_step.hip: step_ticks_kernel, mv_step_obstacles.hip), the same envs in all of them
+struct StepTicksArgs {
+    int32_t n;
+    GymView gv[MAX_STEP_TICKS];
+};
+
 // One host-generated episode (Obstacles family): everything Env::reset produces, ready to be swapped in by
 // the reset kernel.  Fixed-size POD so that the host can fill a pinned staging copy and upload it as is.
 struct alignas(16) EpisodeBlob {

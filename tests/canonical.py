@@ -131,3 +131,30 @@ def corner_push(g, e, W, ticks=30):
         act(g, e, 0, FWD)
         tick(g)
         yield
+
+
+def free_jump(g, e, ticks=16):
+    """jump on the spot from the floor, nothing overhead, no key held afterwards (agent.cpp:157-161: vvel = 6.2 on the jump tick)"""
+    for t in range(ticks):
+        act(g, e, 0, JUMP if t == 0 else 0)
+        tick(g)
+        yield
+
+
+def jump_heights(n_max=12):
+    """height above the take-off point after tick n = 1 .. n_max of a free jump, derived from playerStep / stepUp / stepDown
+    (kinematic_character_controller.cpp:553-561, :223-238, :398-407): every tick vvel -= 13.72 dt FIRST, then the capsule moves by vvel dt
+    -- up through stepUp's jump offset while vvel > 0; once vvel < 0 stepUp raises it by the step height 0.2 and stepDown drops it by
+    0.2 + |vvel| dt, the same net vvel dt: y_n = dt (6.2 n - (13.72 dt) n (n + 1) / 2)"""
+    dt = 1.0 / 15.0
+    return [dt * (6.2 * n - 13.72 * dt * n * (n + 1) / 2.0) for n in range(1, n_max + 1)]
+
+
+def drop_onto_box(g, e, ox, oz, height=1.0, ticks=10):
+    """let go one unit above the resting height on top of a movable box (its collision shape's top: 1.5 - 0.05 + 0.4485), centred on it"""
+    top = 1.5 - 0.05 + 0.39 * 1.15
+    pose(g, e, 0, ox + 0.5, REST_ON(top) + height, oz + 0.5, 0.0)
+    for _ in range(ticks):
+        act(g, e, 0, 0)
+        tick(g)
+        yield

@@ -9,7 +9,8 @@ import numpy as np
 import pytest
 
 import oracle_lib
-from canonical import CCD, HH, R, REST_ON, box_block_then_jump, corner_push, find_isolated_box, find_wall_strip, head_on, slide_fixed_point, stairs, wall_slide
+from canonical import (CCD, HH, R, REST_ON, box_block_then_jump, corner_push, drop_onto_box, find_isolated_box, find_wall_strip, free_jump, head_on, jump_heights,
+                       pose, slide_fixed_point, stairs, wall_slide)
 
 
 def agent(g, e, a=0):
@@ -112,3 +113,63 @@ def test_two_agents_head_on_stop_each_other_in_agent_order():
     mid = 0.5 * float(a0["pos"][0] + a1["pos"][0])
     assert 6.0 < mid < 6.0 + 0.3                                               # agent 0 moves first: it gains up to one tick's travel (4.5 dt)
     g.close()
+
+
+# ---- cases that depend on the cast's FRACTION, tick by tick: a reformulated convex_cast / player_step has to keep reproducing numbers
+# derived from kinematic_character_controller.cpp, not a regenerated golden file
+
+@pytest.mark.parametrize("deg", [30, 60])
+def test_wall_slide_holds_the_contact_depth_on_every_tick(tower, deg):
+    """from the tick the capsule reaches the wall on, EVERY tick's forward sweep must stop it 0.04 inside the nominal contact again (hit fraction 0 of
+    the normal component, the tangential remainder kept: updateTargetPositionBasedOnCollision, :313-329) -- not only the last tick"""
+    e = next(e for e in range(64) if find_wall_strip(tower.snapshot(e)))
+    W = int(tower.snapshot(e)["W"])
+    xs, zs, us = [], [], []
+    for _ in wall_slide(tower, e, W, deg, ticks=30):
+        a = agent(tower, e)
+        xs.append(float(a["pos"][0])); zs.append(float(a["pos"][2])); us.append(-float(a["hv"][1]))
+    first = next(i for i, x in enumerate(xs) if x < 1.0 + R)          # the tick it touches
+    assert first < 12
+    for i in range(first + 1, len(xs)):
+        assert abs(xs[i] - (1.0 + R - CCD)) < 1.5e-3, (i, xs[i])
+        # the tangential travel of the tick is the speed the tick started with after acceleration and clamp, i.e. (speed after friction) + 15 dt
+        assert abs((zs[i - 1] - zs[i]) * 15.0 - (us[i] + 1.0)) < 5e-3 or us[i] == 0.0, (i, zs[i - 1] - zs[i], us[i])
+    assert abs(us[-1] - slide_fixed_point(deg)) < 2e-3 * slide_fixed_point(deg)
+
+
+def test_free_jump_follows_the_derived_heights_and_lands_on_tick_13(tower):
+    e = next(e for e in range(64) if find_wall_strip(tower.snapshot(e)))
+    W = int(tower.snapshot(e)["W"])
+    pose(tower, e, 0, 3.0, REST_ON(1.0), W - 2.5, 0.0)
+    for _ in range(3):   # settle
+        tower.set_action_mask(e, 0, 0); tower.step_norender()
+    y0 = float(agent(tower, e)["pos"][1])
+    assert abs(y0 - REST_ON(1.0)) < 1e-4
+    ys, vs = [], []
+    for _ in free_jump(tower, e, ticks=16):
+        a = agent(tower, e)
+        ys.append(float(a["pos"][1]) - y0); vs.append(float(a["vvel"]))
+    want = jump_heights(12)
+    for n in range(12):                                   # ticks 1 .. 12: in the air, on the derived parabola of the semi-implicit integrator
+        assert abs(ys[n] - want[n]) < 2e-4, (n + 1, ys[n], want[n])
+        assert abs(vs[n] - (6.2 - 13.72 * (n + 1) / 15.0)) < 1e-4
+    assert abs(max(ys) - want[5]) < 2e-4 and 1.19 < want[5] < 1.21 and want[6] < want[5]   # apex 1.1995 after tick 6 (the continuous 6.2^2 / (2 * 13.72) = 1.40 is never reached)
+    assert want[11] > 0.2 and ys[12] != want[11]          # tick 13 would go 0.38 below the floor: stepDown's sweep hits it
+    assert abs(ys[12]) < 1.5e-3 and vs[12] == 0.0         # landed: back at the resting height (0.04 inside the nominal contact), vertical velocity cleared
+    assert all(abs(y) < 1.5e-3 and v == 0.0 for y, v in zip(ys[13:], vs[13:]))
+
+
+def test_a_drop_lands_on_a_movable_box_on_tick_6(tower):
+    e, (ox, oz) = next((e, b) for e in range(64) for b in [find_isolated_box(tower.snapshot(e))] if b)
+    top = 1.5 - 0.05 + 0.39 * 1.15
+    ys, vs = [], []
+    for _ in drop_onto_box(tower, e, ox, oz, height=1.0, ticks=10):
+        a = agent(tower, e)
+        ys.append(float(a["pos"][1])); vs.append(float(a["vvel"]))
+    g_dt2 = 13.72 / 225.0
+    for n in range(1, 6):                                 # free fall: y = start - g dt^2 n (n + 1) / 2 (vvel -= g dt before every move)
+        assert abs(ys[n - 1] - (REST_ON(top) + 1.0 - g_dt2 * n * (n + 1) / 2.0)) < 2e-4, (n, ys[n - 1])
+        assert abs(vs[n - 1] + 13.72 * n / 15.0) < 1e-4
+    assert g_dt2 * 15 < 1.0 < g_dt2 * 21                  # 5 ticks fall 0.915, 6 ticks would fall 1.28: the sixth tick's sweep meets the box
+    assert abs(ys[5] - REST_ON(top)) < 1.5e-3 and vs[5] == 0.0, (ys[5], REST_ON(top))
+    assert all(abs(y - REST_ON(top)) < 1.5e-3 for y in ys[5:])

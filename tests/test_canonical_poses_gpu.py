@@ -3,7 +3,7 @@ state must equal the oracle's bit for bit.  (What the outcomes must be is assert
 import numpy as np
 import pytest
 
-from canonical import box_block_then_jump, corner_push, find_isolated_box, find_wall_strip, head_on, stairs, wall_slide
+from canonical import REST_ON, box_block_then_jump, corner_push, drop_onto_box, find_isolated_box, find_wall_strip, free_jump, head_on, pose, stairs, wall_slide
 from hip_util import diff_snapshots, hip_snapshot, make_pair
 
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
@@ -57,4 +57,21 @@ def test_head_on_bit_exact(hip):
         og.step_norender(); hg.step_no_render()
     y = float(og.snapshot(0)["agents"][0]["pos"][1])
     lockstep(og, hg, 0, 2, head_on(og, 0, y), head_on(hg, 0, y))
+    og.close(); hg.close()
+
+
+def test_free_jump_bit_exact(hip):
+    og, hg = make_pair(64, 1, 16, 16, seed=3)
+    e = next(e for e in range(64) if find_wall_strip(og.snapshot(e)))
+    W = int(og.snapshot(e)["W"])
+    for g in (og, hg):
+        pose(g, e, 0, 3.0, REST_ON(1.0), W - 2.5, 0.0)
+    lockstep(og, hg, e, 1, free_jump(og, e), free_jump(hg, e))
+    og.close(); hg.close()
+
+
+def test_drop_onto_a_box_bit_exact(hip):
+    og, hg = make_pair(64, 1, 16, 16, seed=3)
+    e, (ox, oz) = next((e, b) for e in range(64) for b in [find_isolated_box(og.snapshot(e))] if b)
+    lockstep(og, hg, e, 1, drop_onto_box(og, e, ox, oz), drop_onto_box(hg, e, ox, oz))
     og.close(); hg.close()
