@@ -123,7 +123,10 @@ void launch_step_ticks(const GymView *views, int k, hipStream_t stream, int W, i
     for (int j = 0; j < k; ++j) a.gv[j] = views[j];
     for (int j = k; j < MAX_STEP_TICKS; ++j) a.gv[j] = views[k - 1];
     const GymView &gv = views[0];
-    const dim3 grid(gv.num_envs), block(gv.num_agents == 1 ? 64 : 64 * std::min(gv.num_agents, 4));
+    // several agents: TWO waves per env (measured at 512 envs x 4 agents: one wave 20.3 M obs/s, two 21.7, four 16.1 -- four waves of ~180 VGPRs per env,
+    // resident for the whole call, are what the observation passes beside them cannot have; one-launch-per-tick: 19.4); MV_STEP_TICKS_WAVES overrides
+    static const int maWaves = getenv("MV_STEP_TICKS_WAVES") ? std::max(1, std::min(4, atoi(getenv("MV_STEP_TICKS_WAVES")))) : 2;
+    const dim3 grid(gv.num_envs), block(gv.num_agents == 1 ? 64 : 64 * std::min(gv.num_agents, maWaves));
     if (gv.num_agents == 1) hipExtLaunchKernelGGL(step_ticks_kernel<1>, grid, block, 0, stream, nullptr, done, 0, a, W, H);
     else hipExtLaunchKernelGGL(step_ticks_kernel<MAX_AGENTS>, grid, block, 0, stream, nullptr, done, 0, a, W, H);
 }

@@ -69,6 +69,31 @@ def test_full_size_rollout_equals_the_oracle(hip, scenario, N, A, params, TICKS,
                 d = diff_snapshots(og.snapshot(e), hip_snapshot(hg, e), A)
                 assert not d, (st, e, d[:4])
             pixels_agree(og, hg, sample, A, f"{scenario} {N}x{A} tick {st}")
+    # ---- the batched open-loop path the bench's headline runs: mv_step_n, 8 ticks per call (one multi-tick step launch and, with an output ring,
+    # one launch for the 8 observation passes), against the oracle's single ticks: state of every env afterwards, and the ring's last slab
+    import torch
+    ring = torch.zeros((8, N * A, H, W, 4), dtype=torch.uint8, device="cuda:0")
+    hg.set_output_ring(8, ring.data_ptr())
+    st = TICKS
+    for _ in range(4):
+        hg.step_n(8, "multidiscrete", 1234, st)
+        for j in range(8):
+            og.set_action_masks(action_masks(sample_actions(1234, st + j, N * A)))
+            og.step_norender()
+        st += 8
+    hg.synchronize(); torch.cuda.synchronize()
+    for e in range(N):
+        d = diff_snapshots(og.snapshot(e), hip_snapshot(hg, e), A)
+        assert not d, ("after batched calls", e, d[:4])
+    last = ring[7].cpu().numpy()                 # tick st - 1 went to ring entry (32 - 1) % 8
+    ndiff = ngt1 = npx = 0
+    for e in sample:
+        og.render_env(e)
+        for a in range(A):
+            dpx = np.abs(og.get_observation(e, a).astype(np.int16) - last[e * A + a].astype(np.int16)).max(axis=-1)
+            ndiff += int((dpx > 0).sum()); ngt1 += int((dpx > 1).sum()); npx += dpx.size
+    assert last[..., 3].min() == 255 and ngt1 <= max(2, 1e-4 * npx) and ndiff <= max(4, 5e-4 * npx), f"ring slab after batched calls: {ndiff} pixels differ, {ngt1} by more than 1"
+    hg.set_output_ring(0)
     if params:
         assert ndone > N // 2, f"only {ndone} episodes ended in {TICKS} ticks"
     elif scenario != "TowerBuilding":
