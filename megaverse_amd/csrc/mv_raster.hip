@@ -567,6 +567,7 @@ struct FastArgs {   // what raster_fast_kernel needs of the GymView (fewer live 
     unsigned long long *rdbg;   // instrumented builds: per wave, clock marks of the phases (dumped at exit)
 #endif
     int nosort;   // 1: frame = position (no look-up in the cost bins; MV_RASTER_NOSORT=1, measurements)
+    int tail_div, tail_split;   // d > 0: the cheapest 1/d of the frames -- the LAST workgroups of the launch -- are cut into tail_split pieces instead of the launch's split (launch_raster)
     int graded;   // d > 0: graded split -- the most expensive 1/d of the frames are cut into 4 workgroups instead of the launch's 2 (graded_heavy)
     int planar;   // 1: tiles that one face of one world box covers take the planar path (planar_tile); 0: every tile takes the general one (MV_PLANAR=0, comparisons)
 };
@@ -791,6 +792,10 @@ __device__ __forceinline__ FastFrame fast_prologue(const FastArgs &fa, int blk, 
             const int q = graded_heavy(frames, fa.graded);
             if (b < 4 * q) { split = 4; frames = q; }
             else { b -= 4 * q; first = q; split = 2; frames -= q; }
+        } else if (fa.tail_div) {   // the cheapest frames / tail_div frames, last in the cost order, in tail_split pieces each (tail_frames)
+            const int q = graded_heavy(frames, fa.tail_div), head = frames - q;
+            if (b < split * head) frames = head;
+            else { b -= split * head; first = head; split = fa.tail_split; frames = q; }
         }
         const int per = 8 * split, group = b / per, r = b - group * per;   // b: this workgroup's index within its segment of its gym's part of the grid
         position = group * 8 + (r & 7); part = r >> 3;
@@ -1582,6 +1587,24 @@ static void rdbg_dump()
         fprintf(stderr, "raster timing: mean wave life by decile of the launch order (us):");
         for (int d = 0; d < 10; ++d) fprintf(stderr, " %.1f", cnt[d] ? sum[d] / cnt[d] : 0.0);
         fprintf(stderr, "  (%zu waves)\n", nw);
+        {   // the phases by decile (k cycles), the start offsets, the list lengths
+            std::vector<double> pp(10, 0.0), pc(10, 0.0), pt(10, 0.0), ps(10, 0.0), pn(10, 0.0);
+            for (auto &p : byLife) {
+                const int d = (int)std::min<size_t>(9, p.second * 10 / (maxw + 1)); const unsigned long long *o = &h[p.second * 8];
+                pp[d] += double(o[1] - o[0]); pc[d] += double(o[2] - o[1]); pt[d] += double(o[3] - o[2]); ps[d] += double(o[4] - r0) * 0.01; pn[d] += double(o[6] & 0xffffffffull);
+            }
+            fprintf(stderr, "raster timing: by decile: prologue kcyc");
+            for (int d = 0; d < 10; ++d) fprintf(stderr, " %.1f", cnt[d] ? pp[d] / cnt[d] / 1e3 : 0.0);
+            fprintf(stderr, " | classification kcyc");
+            for (int d = 0; d < 10; ++d) fprintf(stderr, " %.1f", cnt[d] ? pc[d] / cnt[d] / 1e3 : 0.0);
+            fprintf(stderr, " | tiles kcyc");
+            for (int d = 0; d < 10; ++d) fprintf(stderr, " %.1f", cnt[d] ? pt[d] / cnt[d] / 1e3 : 0.0);
+            fprintf(stderr, " | start us");
+            for (int d = 0; d < 10; ++d) fprintf(stderr, " %.1f", cnt[d] ? ps[d] / cnt[d] : 0.0);
+            fprintf(stderr, " | nVis");
+            for (int d = 0; d < 10; ++d) fprintf(stderr, " %.0f", cnt[d] ? pn[d] / cnt[d] : 0.0);
+            fprintf(stderr, "\n");
+        }
     }
     std::sort(life.begin(), life.end()); std::sort(endAt.begin(), endAt.end());
     auto pct = [](const std::vector<double> &v, double p) { return v[std::min(v.size() - 1, (size_t)(p * v.size()))]; };
@@ -1603,7 +1626,7 @@ static FastArgs fast_args_of(const GymView &gv, const PublishTo *publish)
     fa.pub_n = publish ? frames : 0;
     const char *pe = getenv("MV_PLANAR");   // (read at every launch: the two paths are compared within one process by tests/test_fast_pixels_gpu.py)
     fa.planar = !(pe && *pe && atoi(pe) == 0);
-    fa.graded = 0;
+    fa.graded = 0; fa.tail_div = 0; fa.tail_split = 0;
     { const char *ns = getenv("MV_RASTER_NOSORT"); fa.nosort = ns && atoi(ns) != 0; }
 #ifdef MV_RASTER_TIMING
     if (!g_rdbg && hipMalloc((void **)&g_rdbg, (size_t)16384 * 4 * 8 * 8) == hipSuccess) { (void)hipMemset(g_rdbg, 0, (size_t)16384 * 4 * 8 * 8); atexit(rdbg_dump); }
@@ -1812,6 +1835,22 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
         if (!fg.graded && wide_workgroups(split, np) && gv.vis_stride <= VIS_SMALL && !hexScen) {   // a whole frame per eight-wave workgroup
             const KernelFn wfn = gv.scenario == SCN_REARRANGE ? raster_fast_kernel<VIS_SMALL, true, 6, false, 2, 512> : raster_fast_kernel<VIS_SMALL, false, 7, false, 2, 512>;
             launch_done(wfn, dim3(frames), dim3(512), dyn, stream, done, fg, obs, W, H, 1);
+            return 0;
+        }
+        // Fine-grained tail.  The SIMD's arbiter serves its OLDEST wave first: workgroups finish roughly in launch order whatever they cost (wave life
+        // by decile of the launch order, frames in random order: 18 us for the first tenth, 35 us for the eighth, all started within 0.3 us -- r05b),
+        // and a launch ends with its youngest workgroups finishing alone, a few waves per SIMD, far from filling it (the last 4 k of a SIMD's 20 k
+        // vector instructions take 22 of a launch's 49 us).  So the frames at the END of the cost order -- the cheapest -- are cut into more, smaller
+        // workgroups that keep arriving while the big early ones drain: the cheapest eighth in eight pieces each, 49.6 -> 48.3 us alone (r05d; a quarter
+        // in four: 48.5; a sixteenth in eight: 49.4).  MV_RASTER_TAIL_DIV (0: off) / MV_RASTER_TAIL_SPLIT.  (Also built and measured: the frame's cost as the
+        // last pass's tile classification found it fed back into the cost bins -- the right order, and 3 us slower, r05a: under oldest-first the order
+        // matters little, and the truly expensive frames all starting together crowd each other.)
+        static const int tailDiv = getenv("MV_RASTER_TAIL_DIV") ? std::max(0, atoi(getenv("MV_RASTER_TAIL_DIV"))) : 8;
+        static const int tailSplit = getenv("MV_RASTER_TAIL_SPLIT") ? std::max(2, atoi(getenv("MV_RASTER_TAIL_SPLIT"))) : 8;
+        if (!fg.graded && tailDiv >= 2 && gv.vis_stride <= VIS_SMALL && ftiles >= 16 * tailSplit && graded_heavy(frames, tailDiv) > 0 && tailSplit > split) {
+            const int q = graded_heavy(frames, tailDiv);
+            fg.tail_div = tailDiv; fg.tail_split = tailSplit;
+            launch_done(fn, dim3((frames - q) * split + q * tailSplit), dim3(256), dyn, stream, done, fg, obs, W, H, split);
             return 0;
         }
         launch_done(fn, dim3(fg.graded ? graded_workgroups(frames, fg.graded) : frames * split), dim3(256), dyn, stream, done, fg, obs, W, H, split);
