@@ -50,6 +50,9 @@ typedef struct mv_config {
 
 const char *mv_last_error(void);
 int mv_device_count(void);   /* HIP devices this process can see (0 when there is none or the runtime cannot start) */
+/* Version of this ABI.  2: mv_step* / mv_reset / mv_step_many / mv_group_step return 1 for "done, with a warning" (version 1 returned -1 for the same
+ * conditions BEFORE doing the work): callers written as `if (mv_step(g)) fail();` must test `< 0` instead -- ask here which contract the library has. */
+int mv_abi_version(void);
 
 /* MegaverseGym::MegaverseGym (megaverse.cpp:38-58) / close (:227-243).  mv_close is idempotent
  * and valid before the first reset (megaverse/tests/test_env.py:28-30). */

@@ -322,6 +322,7 @@ static int publish_outputs(mv_gym *g, int q, const OutPtrs &o)   // on the calle
 extern "C" {
 
 const char *mv_last_error(void) { return g_err.c_str(); }
+int mv_abi_version(void) { return 2; }
 
 int mv_device_count(void)
 {

@@ -339,6 +339,16 @@ __device__ __forceinline__ void recover_up_to_5(const Col (&col)[NC], V3 &pos)
     for (int it = 0; it < 5; ++it)   // (a counted loop, not five copies: the tick's code is ~100 KB as it is; `more` is wave-uniform)
         if (more) more = recover_from_penetration<NC, OBB>(col, pos);
 }
+// the same, telling `seen` every position on the way (player_step's reach: two opposite pushes can leave the capsule where it started -- the
+// positions in between were still occupied)
+template <int NC, bool OBB, class Seen>
+__device__ __forceinline__ void recover_up_to_5(const Col (&col)[NC], V3 &pos, Seen seen)
+{
+    bool more = true;
+#pragma unroll 1
+    for (int it = 0; it < 5; ++it)
+        if (more) { more = recover_from_penetration<NC, OBB>(col, pos); seen(pos); }
+}
 
 __device__ __forceinline__ bool on_ground(const AgentState &a) { return (fabsf(a.vvel) < SIMD_EPS) && (fabsf(a.voffset) < SIMD_EPS); }
 
@@ -407,7 +417,7 @@ __device__ __forceinline__ void player_step(AgentState &a, const Col (&col)[NC],
                 a.step_offset = stepHeight * f;
                 cur = lerp3(cur, target, f);
             }
-            recover_up_to_5<NC, OBB>(col, cur);
+            recover_up_to_5<NC, OBB>(col, cur, reached);
             target = cur;
             if (a.voffset > 0) { a.voffset = 0.0f; a.vvel = 0.0f; a.step_offset = STEP_HEIGHT; }
         } else {
@@ -478,7 +488,7 @@ __device__ __forceinline__ void player_step(AgentState &a, const Col (&col)[NC],
     a.hvx = (cur.x - original.x) / dt;
     a.hvz = (cur.z - original.z) / dt;
 
-    recover_up_to_5<NC, OBB>(col, cur);
+    recover_up_to_5<NC, OBB>(col, cur, reached);
     reached(cur);
     if (reach2) *reach2 = r2;
     a.pos[0] = cur.x; a.pos[1] = cur.y; a.pos[2] = cur.z;

@@ -28,7 +28,7 @@ class _Config(C.Structure):
 # every symbol include/megaverse_hip.h declares: (name, restype, argtypes)
 _P, _I, _U, _F = C.c_void_p, C.c_int32, C.c_uint32, C.c_float
 SYMBOLS = [
-    ("mv_last_error", C.c_char_p, []), ("mv_device_count", C.c_int, []),
+    ("mv_last_error", C.c_char_p, []), ("mv_device_count", C.c_int, []), ("mv_abi_version", C.c_int, []),
     ("mv_create", C.c_int, [C.POINTER(_Config), C.POINTER(_P)]),
     ("mv_close", C.c_int, [_P]), ("mv_destroy", C.c_int, [_P]),
     ("mv_num_agents", C.c_int, [_P]), ("mv_action_space_sizes", C.c_int, [_P]),
@@ -259,6 +259,9 @@ class MegaverseGym:
         self._ck(self._lib.mv_set_actions_batched(self._g, a.ctypes.data))
 
     def set_actions_device(self, device_ptr):
+        """int32 [num_agents, 6] multi-discrete actions in device memory.  Nothing is launched here: the NEXT step kernel reads the buffer (in the
+        order of the gym's stream), so the caller keeps it alive and unchanged until that step() call has returned; mv_reset and the host-side
+        action setters read a pending buffer at once instead (last writer wins)."""
         self._ck(self._lib.mv_set_actions_device(self._g, _P(int(device_ptr))))
 
     def sample_random_actions(self, seed, step_index):

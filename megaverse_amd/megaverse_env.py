@@ -140,14 +140,22 @@ class MegaverseEnv:
     def step_batched(self, actions=None):
         """actions: int32 [num_agents, 6] (numpy, or a CUDA torch tensor) or None (keep what was set).
         Returns (obs uint8 CUDA view (num_agents,3,H,W), rewards float32 np [num_agents], dones bool np [num_envs])."""
+        if self._obs_tensor is None:
+            self.observations_tensor()   # (allocates: before the action buffer is handed over, not between hand-over and step)
+        held = None
         if actions is not None:
             if hasattr(actions, 'data_ptr'):
-                self.env.set_actions_device(actions.contiguous().data_ptr())
+                # Lifetime rule of mv_set_actions_device: the buffer is READ BY THE NEXT STEP KERNEL, in the order of the gym's stream -- it must stay
+                # alive and unchanged until that step has been enqueued (a reset or a host-side action setter in between reads it at once instead).
+                # int32, contiguous, [num_agents, 6]; `held` keeps a converted copy alive until step() has returned (the caching allocator does not
+                # hand its memory to anyone on another stream before the stream's work is done).
+                import torch
+                held = actions.to(dtype=torch.int32).contiguous()
+                self.env.set_actions_device(held.data_ptr())
             else:
                 self.env.set_actions_batched(actions)
-        if self._obs_tensor is None:
-            self.observations_tensor()
         self.env.step()
+        del held
         return self.observations_tensor(), self.env.get_rewards_array(), self.env.get_dones().astype(bool)
 
     # ---- rendering (megaverse_env.py:164-184): returns the tiled BGR image, shows it if cv2 exists ----

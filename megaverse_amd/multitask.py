@@ -114,7 +114,15 @@ class MultiTaskGym:
         return self._group
 
     def step_n(self, k, policy="multidiscrete", seed=0, first_step_index=0):
-        """k open-loop ticks of every scenario with one call (union launches; mv_group_step)"""
+        """k open-loop ticks of every scenario with one call (union launches; mv_group_step); without the union (MV_MULTITASK_UNION=0, or more
+        scenarios than a group holds): k single steps of every sub-gym"""
+        if not self.union:
+            if policy != "multidiscrete":
+                raise ValueError("MultiTaskGym.step_n without union launches supports the 'multidiscrete' policy only")
+            for j in range(int(k)):
+                self.sample_random_actions(seed, int(first_step_index) + j)
+                self.step()
+            return
         self._ensure_group().step(k, True, policy, seed, first_step_index)
 
     def step(self):
