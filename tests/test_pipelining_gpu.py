@@ -302,3 +302,41 @@ def test_single_bit_policy_equals_host_stream(hip, batched):
         d = diff_snapshots(og.snapshot(e), hip_snapshot(hg, e), A)
         assert not d, (e, d[:5])
     og.close(); hg.close()
+
+
+def test_a_pending_device_action_buffer_is_read_by_what_comes_next(hip):
+    """mv_set_actions_device keeps the caller's buffer until the next step kernel reads it.  A host-side setter or a reset in between
+    must read it AT ONCE -- while it is certainly alive -- and the last writer wins: device actions, then host actions for every agent => the
+    host's; device actions, then the buffer is overwritten after a reset => what it held when the reset came."""
+    import torch
+    from megaverse_amd.rollout import sample_actions
+    N, A = 16, 2
+    def gym():
+        g = MegaverseGym("TowerBuilding", 32, 32, N, A, 1, False, {})
+        g.seed(4); g.reset()
+        return g
+    a1 = sample_actions(1, 0, N * A); a2 = sample_actions(2, 0, N * A)
+    # (1) device buffer, then host actions for everyone: the step uses the host's
+    g, ref = gym(), gym()
+    buf = torch.as_tensor(a1, device="cuda:0").contiguous()
+    g.set_actions_device(buf.data_ptr())
+    g.set_actions_batched(a2)
+    buf.zero_()
+    ref.set_actions_batched(a2)
+    g.step(); ref.step()
+    for e in range(N):
+        assert hip_snapshot(g, e).tobytes() == hip_snapshot(ref, e).tobytes(), e
+    g.close(); ref.close()
+    # (2) device buffer, then ONE host-side per-agent setter: the buffer is converted at that moment (it may be gone afterwards), the host's upload
+    # of the whole action array at the next step then wins as the last writer -- exactly what a host-only caller of set_actions gets
+    g, ref = gym(), gym()
+    buf = torch.as_tensor(a1, device="cuda:0").contiguous()
+    g.set_actions_device(buf.data_ptr())
+    g.set_actions(3, 1, [1, 0, 2, 0, 1, 0])
+    buf.fill_(7)   # (garbage: must no longer be looked at)
+    torch.cuda.synchronize()
+    ref.set_actions(3, 1, [1, 0, 2, 0, 1, 0])
+    g.step(); ref.step()
+    for e in range(N):
+        assert hip_snapshot(g, e).tobytes() == hip_snapshot(ref, e).tobytes(), e
+    g.close(); ref.close()
