@@ -1844,7 +1844,8 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
         // workgroups that keep arriving while the big early ones drain: the cheapest eighth in eight pieces each, 49.6 -> 48.3 us alone (r05d; a quarter
         // in four: 48.5; a sixteenth in eight: 49.4).  MV_RASTER_TAIL_DIV (0: off) / MV_RASTER_TAIL_SPLIT.  (Also built and measured: the frame's cost as the
         // last pass's tile classification found it fed back into the cost bins -- the right order, and 3 us slower, r05a: under oldest-first the order
-        // matters little, and the truly expensive frames all starting together crowd each other.)
+        // matters little, and the truly expensive frames all starting together crowd each other; and wave priorities -- s_setprio at every tile -- by
+        // the work the workgroup has left, "longest remaining work first": the life times flatten, the launch gets longer, 48.7 -> 50.9 us, r05g.)
         static const int tailDiv = getenv("MV_RASTER_TAIL_DIV") ? std::max(0, atoi(getenv("MV_RASTER_TAIL_DIV"))) : 8;
         static const int tailSplit = getenv("MV_RASTER_TAIL_SPLIT") ? std::max(2, atoi(getenv("MV_RASTER_TAIL_SPLIT"))) : 8;
         if (!fg.graded && tailDiv >= 2 && gv.vis_stride <= VIS_SMALL && ftiles >= 16 * tailSplit && graded_heavy(frames, tailDiv) > 0 && tailSplit > split) {
