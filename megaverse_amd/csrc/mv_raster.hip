@@ -1359,9 +1359,18 @@ __device__ __forceinline__ void raster_glist_body(const FastArgs &fa, uint32_t *
     const int numTiles = tilesX * tilesY;
     const int lx = lane & (TILE_W - 1), ly = lane / TILE_W;
 
-    int tx = part * 4 + wave, ty = 0;
-    for (int tile = part * 4 + wave; tile < numTiles; tile += 4 * split, tx += 4 * split) {
-        while (tx >= tilesX) { tx -= tilesX; ++ty; }
+    // the workgroup's tiles are handed out one at a time, as in raster_fast_body (a wave that always drew the same tile column lived as long as the
+    // most crowded one); u = 4 j + w is tile (j split + part) 4 + w of the frame
+    __shared__ int s_next;
+    if (tid == 0) s_next = 4;
+    __syncthreads();
+    const unsigned tilesXinv = (unsigned)((0x100000000ull + (unsigned)tilesX - 1u) / (unsigned)tilesX);
+    int unext = 0;
+    for (int u = wave; ; u = __builtin_amdgcn_readfirstlane(unext)) {
+        const int tile = ((u >> 2) * split + part) * 4 + (u & 3);
+        if (tile >= numTiles) break;
+        if (lane == 0) unext = atomicAdd(&s_next, 1);
+        const int ty = (int)__umulhi((unsigned)tile, tilesXinv), tx = tile - ty * tilesX;
         const int tx0 = tx * TILE_W, ty0 = ty * TH;
         const int tx1 = min(tx0 + TILE_W, W) - 1, ty1 = min(ty0 + TH, H) - 1;
         const int px = tx0 + lx, py0 = ty0 + ly;
