@@ -1857,7 +1857,7 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
         // the work the workgroup has left, "longest remaining work first": the life times flatten, the launch gets longer, 48.7 -> 50.9 us, r05g.)
         static const int tailDiv = getenv("MV_RASTER_TAIL_DIV") ? std::max(0, atoi(getenv("MV_RASTER_TAIL_DIV"))) : 8;
         static const int tailSplit = getenv("MV_RASTER_TAIL_SPLIT") ? std::max(2, atoi(getenv("MV_RASTER_TAIL_SPLIT"))) : 8;
-        if (!fg.graded && tailDiv >= 2 && gv.vis_stride <= VIS_SMALL && ftiles >= 16 * tailSplit && graded_heavy(frames, tailDiv) > 0 && tailSplit > split) {
+        if (!fg.graded && tailDiv >= 2 && split == 2 && gv.vis_stride <= VIS_SMALL && ftiles >= 16 * tailSplit && graded_heavy(frames, tailDiv) > 0 && tailSplit > split) {   // (split 2: a launch that fills the chip; 512 frames in four pieces each: 12.0 M obs/s with the tail cut finer, 12.4 without, r05i)
             const int q = graded_heavy(frames, tailDiv);
             fg.tail_div = tailDiv; fg.tail_split = tailSplit;
             launch_done(fn, dim3((frames - q) * split + q * tailSplit), dim3(256), dyn, stream, done, fg, obs, W, H, split);
