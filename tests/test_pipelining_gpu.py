@@ -340,3 +340,39 @@ def test_a_pending_device_action_buffer_is_read_by_what_comes_next(hip):
     for e in range(N):
         assert hip_snapshot(g, e).tobytes() == hip_snapshot(ref, e).tobytes(), e
     g.close(); ref.close()
+
+
+@pytest.mark.parametrize("scenario,N,A,W,H,params", [("TowerBuilding", 40, 1, 48, 20, {"episodeLengthSec": -200.0}), ("TowerBuilding", 33, 3, 128, 72, {}),
+                                                     ("TowerBuilding", 100, 1, 64, 64, {}), ("ObstaclesEasy", 800, 1, 33, 17, {}), ("Empty", 770, 1, 128, 128, {})])
+def test_one_launch_calls_fill_the_ring_like_single_ticks(hip, scenario, N, A, W, H, params):
+    """a batched call with an output ring -- ONE step launch for its k ticks (step_ticks_kernel / step_obstacles_ticks_kernel) and ONE raster launch for its k
+    observation passes (raster_fast_batch_kernel) -- against single ticks: every slab of the ring, rewards / dones rings, state; ragged sizes, one and
+    several agents, call sizes 2 .. 8 and chunks the ring wraps around in"""
+    import torch
+    R = 8
+    def make(with_ring):
+        g = MegaverseGym(scenario, W, H, N, A, 2, False, params)
+        g.set_pixel_mode("fast"); g.seed(33); g.reset()
+        obs = torch.zeros((R, N * A, H, W, 4), dtype=torch.uint8, device="cuda:0")
+        rew = torch.zeros((R, N * A), dtype=torch.float32, device="cuda:0")
+        don = torch.zeros((R, N), dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
+        g.set_output_ring(R, obs.data_ptr(), rew.data_ptr(), don.data_ptr())
+        return g, obs, rew, don
+    a, oa, ra, da = make(True)
+    b, ob, rb, db = make(True)
+    chunks = [8, 2, 5, 8, 3, 8, 7, 8]
+    st = 0
+    for k in chunks:
+        a.step_n(k, "multidiscrete", 5, st)
+        for j in range(k):
+            b.sample_random_actions(5, st + j); b.step()
+        st += k
+    a.synchronize(); b.synchronize(); torch.cuda.synchronize()
+    assert oa.cpu().numpy()[..., :3].max() > 0
+    assert torch.equal(oa, ob), "observation ring differs"
+    assert torch.equal(ra.view(torch.int32), rb.view(torch.int32)) and torch.equal(da, db)
+    for e in range(N):
+        assert a.debug_snapshot_bytes(e).tobytes() == b.debug_snapshot_bytes(e).tobytes(), e
+    assert a.get_true_objectives().tobytes() == b.get_true_objectives().tobytes()
+    a.close(); b.close()
