@@ -317,10 +317,9 @@ def main():
                          "Action(1 << randRange(0, 11)) (megaverse_test_app.cpp:140-147)")
     ap.add_argument("--batch", type=int, default=0,
                     help="ticks per stepping call (mv_step_n): every tick is stepped and rendered in full, the two stream hand-overs are paid once "
-                         "per call; 1 = one mv_step per tick; 0 (default) = 8 for runs of 200 steps and more, 2 below that -- the observation passes of a "
-                         "call start when its last step kernel is done, so a run pays about one call of step kernels (k x 20 us) before its passes "
-                         "stream: measured on 20-step runs 16.4 M obs/s with 2 ticks per call (r03a: 15.3 M with 4, 14.3 M with 8); 2000-step runs 17.1 M / "
-                         "17.8 M with 1 / 8.  N>1 with the gather on always steps tick by tick")
+                         "per call; 1 = one mv_step per tick; 0 (default) = 8, the first two calls after a synchronisation 1 and 3 ticks (the observation "
+                         "passes of a call start when its ticks are stepped: short first calls fill the pipeline sooner; 20-step runs: 20.0-20.25 M obs/s "
+                         "against 19.0 M with 2 ticks per call throughout).  N>1 with the gather on always steps tick by tick")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the single-step / unpipelined / closed-loop transparency legs")
     ap.add_argument("--profile-steps", type=int, default=256, help="steps of the untimed per-kernel profile loop (HIP events on the gym's stream)")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo run of the launcher + gather pipeline with a stand-in gym")
@@ -364,7 +363,7 @@ def main():
     n_env, A = args.envs_per_gpu, args.agents
     mixed = args.scenario.lower() == "mixed"
     frames = n_env * A
-    batch = args.batch if args.batch > 0 else (8 if args.steps >= 200 else 2)
+    batch = args.batch if args.batch > 0 else 8
     os.environ.setdefault("MV_PIPE_BATCH", str(max(8, min(16, batch))))
     batch = min(batch, int(os.environ["MV_PIPE_BATCH"]))
     if dry:
@@ -391,7 +390,8 @@ def main():
     # batched stepping: tick j of a call renders into slab j of a ring, so that all `batch` observations of a call exist side by side when it
     # is done (a k-step rollout buffer) -- the working set of the observation writes is batch x one slab, not one slab written over and over
     batched = batch > 1 and not dry
-    ring = torch.zeros((batch, frames, H, W, 4), dtype=torch.uint8, device=device) if batched and not mixed else None   # (Mixed: one slab, no ring)
+    ring_slots = max(batch, 8) if batched else 1   # (slabs of the output ring: a call never holds more ticks than that)
+    ring = torch.zeros((ring_slots, frames, H, W, 4), dtype=torch.uint8, device=device) if batched and not mixed else None   # (Mixed: one slab, no ring)
 
     def bind(b):
         if dry:
@@ -433,8 +433,12 @@ def main():
     def run_steps(first, n, with_gather, use_batch):
         if use_batch and not with_gather:
             i = 0
+            # A region starts right after a synchronisation, with an empty pipeline: its first observation pass can only start when the first call's
+            # ticks are stepped, so the first calls are short -- 1 tick, then 3, then --batch (measured on 20-step runs, r05k: 20.0-20.25 M obs/s
+            # against 19.0-19.1 M with 2 ticks per call throughout and 19.2-19.7 M with 8).  MV_BENCH_CALL_SCHEDULE=a,b,...: other first calls.
+            sched = [int(x) for x in os.environ.get("MV_BENCH_CALL_SCHEDULE", "1,3").split(",") if x]
             while i < n:
-                k = min(batch, n - i)
+                k = min(sched.pop(0) if sched else batch, n - i, ring_slots)
                 gym.step_n(k, args.policy, 1234, first + i)
                 i += k
         else:
@@ -455,7 +459,7 @@ def main():
     step0 = 0
     main_batched = batched and not do_gather
     if main_batched and ring is not None:
-        gym.set_output_ring(batch, ring.data_ptr())
+        gym.set_output_ring(ring_slots, ring.data_ptr())
     run_steps(step0, args.warmup, do_gather, main_batched)
     step0 += args.warmup
     elapsed = timed(step0, do_gather, main_batched)        # THE timed region: exactly --steps steps, no instrumentation
@@ -465,7 +469,7 @@ def main():
     if do_gather:                            # second leg, same step count, observations stay on the producing GPU
         bind(0)
         if batched and ring is not None:
-            gym.set_output_ring(batch, ring.data_ptr())
+            gym.set_output_ring(ring_slots, ring.data_ptr())
         elapsed_no_gather = timed(step0, False, batched)
         step0 += args.steps
     # N > 1: the one-GPU rate measured INSIDE this process group -- rank 0 steps alone while the other ranks wait at the barrier -- so that the
@@ -632,6 +636,7 @@ def main():
                        # stepped and rendered in full); ticks_per_call > 1: mv_step_n, the streams hand over once per call, tick j of a call
                        # leaves its observations in slab j of a ring of that many slabs
                        "pipelined": pipelined, "ticks_per_call": batch if main_batched else 1,
+                       **({"first_calls": os.environ.get("MV_BENCH_CALL_SCHEDULE", "1,3") + " ticks, then ticks_per_call (every tick stepped and rendered in full)"} if main_batched else {}),
                        **({"launches_per_tick": 2, "scenarios": "TowerBuilding, ObstaclesEasy, ObstaclesHard, Collect, Sokoban, HexMemory, HexExplore, Rearrange dealt round-robin "
                                                               "by env index (one gym per scenario, stepped as one mv_group: one step launch and one raster launch per tick)"} if mixed else {}),
                        "parallelism": f"env-shard x{world}"},
