@@ -81,6 +81,7 @@ if __name__ == "__main__":
             if not os.path.exists(os.path.join(HERE, name + ".npz")):
                 _make(name, **kw)
     make("tower_a1", N=6, A=1, steps=1200, trace_every=100, W=64, H=64)
+    make("tower_config0", N=2, A=1, steps=900, trace_every=100, W=128, H=128)   # BASELINE.json configs[0]'s shape: num_envs=2, one agent, 128 x 128
     make("tower_a4", N=3, A=4, steps=600, trace_every=100, W=64, H=64)
     make("tower_short_episodes", N=4, A=2, steps=400, trace_every=50, W=32, H=32, params={"episodeLengthSec": -220.0})
     make("obstacles_hard_a2", N=4, A=2, steps=500, trace_every=100, W=64, H=64, scenario="ObstaclesHard", seed=7)

@@ -291,7 +291,7 @@ def test_done_step_semantics():
     g.close()
 
 
-@pytest.mark.parametrize("name", ["tower_a1", "tower_a4", "tower_short_episodes", "obstacles_hard_a2", "obstacles_easy_a1", "collect_a2", "rearrange_a4"])
+@pytest.mark.parametrize("name", ["tower_a1", "tower_config0", "tower_a4", "tower_short_episodes", "obstacles_hard_a2", "obstacles_easy_a1", "collect_a2", "rearrange_a4"])
 def test_oracle_reproduces_golden(name):
     """restatement-relative: the committed vectors were generated by this oracle (tests/golden/make_golden.py)"""
     z = np.load(os.path.join(GOLDEN, name + ".npz"))

@@ -159,7 +159,7 @@ def test_auto_reset_parity_with_short_episodes(hip):
     og.close(); hg.close()
 
 
-@pytest.mark.parametrize("name", ["tower_a1", "tower_a4", "tower_short_episodes", "obstacles_hard_a2", "obstacles_easy_a1", "collect_a2", "rearrange_a4",
+@pytest.mark.parametrize("name", ["tower_a1", "tower_config0", "tower_a4", "tower_short_episodes", "obstacles_hard_a2", "obstacles_easy_a1", "collect_a2", "rearrange_a4",
                                   "sokoban_a2", "hex_memory_a2", "hex_explore_a3"])
 def test_hip_reproduces_committed_golden(hip, name, monkeypatch):
     monkeypatch.setenv("BOXOBAN_LEVELS", os.path.join(GOLDEN, "boxoban"))
