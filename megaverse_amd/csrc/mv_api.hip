@@ -1166,7 +1166,8 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
     static const bool ticksOff = getenv("MV_STEP_TICKS") && atoi(getenv("MV_STEP_TICKS")) == 0;
     const bool obstFamily = L->scenario == SCN_OBSTACLES || L->scenario == SCN_EMPTY;
     static const bool ticksMulti = !(getenv("MV_STEP_TICKS_MULTI") && atoi(getenv("MV_STEP_TICKS_MULTI")) == 0);   // (several agents per env, too -- TowerBuilding: two waves per env, launch_step_ticks; 0: off)
-    const bool canMultiTick = !ticksOff && n == 1 && (L->A == 1 || (ticksMulti && L->scenario == SCN_TOWER)) && k >= 2 && k <= MAX_STEP_TICKS && render && policy != POLICY_NONE && (L->scenario == SCN_TOWER || (obstFamily && L->N >= 768)) &&   // (Obstacles at 512 envs: 11.6 against 12.0 M obs/s, at 1024: 16.9 against 16.1; TowerBuilding 512 x 4: 21.7 against 19.4)
+    static const int obstMinEnvs = getenv("MV_STEP_TICKS_OBST_MIN_ENVS") ? atoi(getenv("MV_STEP_TICKS_OBST_MIN_ENVS")) : 0;   // (r06c, with the one-launch passes cut for k x frames workgroups: ObstaclesHard 512 envs 13.0 against 11.7 M obs/s, 256 envs 9.2 against 8.6)
+    const bool canMultiTick = !ticksOff && n == 1 && (L->A == 1 || (ticksMulti && L->scenario == SCN_TOWER)) && k >= 2 && k <= MAX_STEP_TICKS && render && policy != POLICY_NONE && (L->scenario == SCN_TOWER || (obstFamily && L->N >= obstMinEnvs)) &&   // (Obstacles at 512 envs: 11.6 against 12.0 M obs/s, at 1024: 16.9 against 16.1; TowerBuilding 512 x 4: 21.7 against 19.4)
                               !L->gv.dbg;
     // (the one-launch observation passes only beside the one-launch step: k separate step kernels starve beside a pass that long -- 70-190 us each, r04l)
     const bool canBatchRaster = canMultiTick && render && allFast && n == 1 && k >= 2 && L->ringObs && L->ringCount >= k;

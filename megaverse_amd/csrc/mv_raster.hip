@@ -1661,11 +1661,16 @@ static int fast_pixels_per_lane(int W, int H, bool longList = false)
 // group's two launches: 384 / 640 frames) a launch lasts as long as its slowest frame -- kernel traces: 128 HexMemory frames of 64 x 64 take
 // 43 us, 1024 of them 84 -- so the frame is cut into more pieces: enough workgroups to fill the chip about twice (4096 / 2048), at most 16 / 8,
 // at least one (long lists) / two tiles per wave.  MV_RASTER_SPLIT overrides.
-static int fast_split(int W, int H, int np, int frames, bool longList = false)
+// ONE workgroup per frame where the launch holds workgroups for several rounds of the chip anyway -- the k passes of a batched call in one
+// launch (`batch`, frames = k x the pass's), or 4096 frames and more in a single pass: the prologue and the tile classification are paid once
+// per frame instead of twice, and the frames that start later fill in behind the early ones (r06d/r06j, TowerBuilding 128 x 128, two -> one:
+// 1024 envs x 8 ticks 21.9 -> 23.3 M obs/s, 512 x 8: 17.9 -> 20.4, 512 x 4 agents x 8: 21.5 -> 23.3; single passes of 4096 frames 20.7 -> 22.3,
+// of 2048 frames 19.1 -> 18.4, of 1024: 50 -> 72 us -- 1024 workgroups are half a round).
+static int fast_split(int W, int H, int np, int frames, bool longList = false, bool batch = false)
 {
     static const int envSplit = getenv("MV_RASTER_SPLIT") ? atoi(getenv("MV_RASTER_SPLIT")) : 0;
     const int ftiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H * np - 1) / (TILE_H * np));
-    const int want = ((np >= 2 ? 2048 : 4096) + frames - 1) / std::max(frames, 1), lo = np >= 2 ? 2 : 4, hi = np >= 2 ? 8 : 16;
+    const int want = ((np >= 2 ? 2048 : 4096) + frames - 1) / std::max(frames, 1), lo = (batch || frames >= 4096) && np >= 2 && !longList ? 1 : np >= 2 ? 2 : 4, hi = np >= 2 ? 8 : 16;
     int split = lo;
     while (split < hi && split < want) split <<= 1;
     if (envSplit > 0) split = envSplit;
@@ -1779,7 +1784,10 @@ int launch_raster_batch(const GymView *views, uint32_t *const *obs, const Publis
     const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)W * sizeof(float) + (size_t)H * sizeof(float2) + lds_pad();
     const int frames = gv.num_envs * gv.num_agents;
     const int np = fast_pixels_per_lane(W, H);
-    int split = fast_split(W, H, np, frames);
+    // (the k passes fill the chip together -- later passes' workgroups start as earlier ones end -- so the frame is cut for k x frames of them:
+    // 512 TowerBuilding frames, 8 ticks per call: 16.2 M obs/s with two workgroups per frame, 14.0 M with the four a single pass of 512 frames takes)
+    static const bool splitPerPass = getenv("MV_RASTER_BATCH_SPLIT_PER_PASS") && atoi(getenv("MV_RASTER_BATCH_SPLIT_PER_PASS")) != 0;
+    int split = fast_split(W, H, np, splitPerPass ? frames : frames * k, false, !splitPerPass);
     const bool wide = wide_workgroups(split, np);   // a whole frame per eight-wave workgroup instead of two halves
     if (wide) split = 1;
     UnionRasterArgs ua;
@@ -1857,7 +1865,7 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
         // the work the workgroup has left, "longest remaining work first": the life times flatten, the launch gets longer, 48.7 -> 50.9 us, r05g.)
         static const int tailDiv = getenv("MV_RASTER_TAIL_DIV") ? std::max(0, atoi(getenv("MV_RASTER_TAIL_DIV"))) : 8;
         static const int tailSplit = getenv("MV_RASTER_TAIL_SPLIT") ? std::max(2, atoi(getenv("MV_RASTER_TAIL_SPLIT"))) : 8;
-        if (!fg.graded && tailDiv >= 2 && split == 2 && gv.vis_stride <= VIS_SMALL && ftiles >= 16 * tailSplit && graded_heavy(frames, tailDiv) > 0 && tailSplit > split) {   // (split 2: a launch that fills the chip; 512 frames in four pieces each: 12.0 M obs/s with the tail cut finer, 12.4 without, r05i)
+        if (!fg.graded && tailDiv >= 2 && split <= 2 && gv.vis_stride <= VIS_SMALL && ftiles >= 16 * tailSplit && graded_heavy(frames, tailDiv) > 0 && tailSplit > split) {   // (split 2: a launch that fills the chip; 512 frames in four pieces each: 12.0 M obs/s with the tail cut finer, 12.4 without, r05i)
             const int q = graded_heavy(frames, tailDiv);
             fg.tail_div = tailDiv; fg.tail_split = tailSplit;
             launch_done(fn, dim3((frames - q) * split + q * tailSplit), dim3(256), dyn, stream, done, fg, obs, W, H, split);
