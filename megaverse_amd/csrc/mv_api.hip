@@ -117,6 +117,11 @@ struct mv_gym {
     int batch = 8, slots = PIPE_GROUPS * 8, hists = PIPE_GROUPS * 8 + 1;   // slots per group (MV_PIPE_BATCH), slots, cost histograms
     int group = 0;                               // slot group of the last stepping call
     int parity = 0, hist3 = 0;                   // hand-over slot of the last tick; cost histogram of the last pass
+    // histClean[h]: cost histogram h is (or, in stream order, will be) all zero when the next frame setup counts into it.  A pass drawn by the
+    // one-launch observation kernel clears its histogram itself once its last workgroup has looked its frame up (mv_raster.hip: hist_done); a
+    // tick of the one-launch-per-tick path clears the NEXT pass's in its frame setup (mv_frame.h); what neither covers -- the hand-over between
+    // the two paths -- is cleared by take_hist with a memset.
+    std::vector<uint8_t> histClean;
     std::vector<GymView> gvp;                    // [slots] gv with the buffers of each slot swapped in
     GymView gv{};
     const int32_t *mdActions = nullptr;          // mv_set_actions_device: the caller's multi-discrete buffer, read by the next step kernel
@@ -289,6 +294,18 @@ static int refresh_mirrors(mv_gym *g)
     return 0;
 }
 
+// The next observation pass's cost histogram: advances hist3 and makes sure the histogram is zero before the pass's frame setup counts into it
+// (stream s: where that setup runs).  setupClearsNext: the frame setup of this pass clears the histogram after it (the one-launch-per-tick path).
+static int take_hist(mv_gym *g, hipStream_t s, bool setupClearsNext)
+{
+    g->hist3 = (g->hist3 + 1) % g->hists;
+    if (!g->histClean[(size_t)g->hist3])
+        HIP_TRY(hipMemsetAsync(g->gv.lpt_hist + (size_t)g->hist3 * LPT_BUCKETS * LPT_SUBS, 0, (size_t)LPT_BUCKETS * LPT_SUBS * sizeof(int32_t), s));
+    g->histClean[(size_t)g->hist3] = 0;
+    if (setupClearsNext) g->histClean[(size_t)((g->hist3 + 1) % g->hists)] = 1;
+    return 0;
+}
+
 // the view a kernel launch gets: the buffers of slot q, this pass's cost histogram, the action-sampling request
 static GymView view(const mv_gym *g, int q, const OutPtrs *direct = nullptr)   // direct: the step writes the public output arrays itself (not pipelined)
 {
@@ -423,6 +440,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     if (const char *e = getenv("MV_PIPE_BATCH")) g->batch = std::min((int)PIPE_BATCH_MAX, std::max(1, atoi(e)));   // ticks per call of mv_step_n
     g->slots = PIPE_GROUPS * g->batch;
     g->hists = g->slots + 1;
+    g->histClean.assign((size_t)g->hists, 1);   // (the arena is zeroed below)
     g->gvp.resize((size_t)g->slots);
     g->parity = g->slots - 1;
     g->group = PIPE_GROUPS - 1;
@@ -457,7 +475,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     const size_t szVisP = up(NA * (size_t)gv.vis_stride * 32), szVisR = up(NA * (size_t)gv.vis_stride * 8), szVisC = up(NA * sizeof(int32_t)),
                  szLpt = up(NA * sizeof(int32_t)) + up((NA + 1) * sizeof(int32_t)) + up(NA * (size_t)FRAME_HDR_BYTES) + up((size_t)LPT_BUCKETS * LPT_SUBS * lpt_sub_capacity(NA) * sizeof(int32_t));
     // per slot: frame lists, headers, cost lists, and the staging copies of rewards / dones / true objectives
-    const size_t szParity = szVisP + szVisR + szVisC + szLpt + szRew + szDone + szObjv, szHist = up((size_t)g->hists * LPT_BUCKETS * LPT_SUBS * sizeof(int32_t));
+    const size_t szParity = szVisP + szVisR + szVisC + szLpt + szRew + szDone + szObjv, szHist = up((size_t)g->hists * (LPT_BUCKETS * LPT_SUBS + 1) * sizeof(int32_t));   // (+ one "workgroups that have looked their frame up" counter per histogram, behind them)
     gv.lpt_hists = g->hists;
     const size_t total = szHdr + szBoxes + szObj + szAg + szAct + szRew + szDone + szObjv + szMd + (hostEpisodes ? 0 : szChunk) + szObs + szTerrain +
                          szRewObj + szHeight + szItems + szCells + szHexB + szHexO + szBlobs + szCnt + (size_t)g->slots * szParity + szHist;
@@ -820,7 +838,7 @@ int mv_render(mv_gym *g)
     if (check(g)) return -1;
     HIP_TRY(hipSetDevice(g->device));
     if (sim_join(g)) return -1;
-    g->hist3 = (g->hist3 + 1) % g->hists;
+    if (take_hist(g, g->stream, true)) return -1;
     if (launch_raster(view(g, g->parity), last_outputs(g).obs, g->w, g->h, g->stream, nullptr, g->fastPixels)) return fail("mv_render: observation size above 1024x1024");
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1193,7 +1211,7 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
             if (policy != POLICY_NONE) { g->gv.sample_on = policy; g->gv.sample_seed = seed; g->gv.sample_step = first_index + (uint32_t)j; }
             else { g->gv.sample_on = (j == 0 && g->samplePending) ? g->samplePolicy : (int)POLICY_NONE; }
             g->parity = g->group * g->batch + j;
-            if (render) g->hist3 = (g->hist3 + 1) % g->hists;   // (this pass's frame setup fills the next cost histogram and clears the one after)
+            if (render && take_hist(g, sim, !multiTick)) return -1;   // (this pass's frame setup fills the next cost histogram; one launch per tick: and clears the one after)
             OutPtrs &o = outs[(size_t)j * n + i];
             o = outputs_of(g, g->ringTick++);
             GymView &v = views[(size_t)j * n + i];
@@ -1206,13 +1224,10 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
         if (multiTick) {
             views[(size_t)j].lpt_no_clear = 1;
             if (j == k - 1) {
-                // the cost histograms of this call's later passes and of the pass after it (each pass's frame setup otherwise clears the next one's)
-                const int hists = L->hists, h0 = views[0].lpt_parity;
-                const size_t hb = (size_t)LPT_BUCKETS * LPT_SUBS * sizeof(int32_t);
-                const int a0 = (h0 + 1) % hists, cnt = k;
-                const int firstPart = std::min(cnt, hists - a0);
-                HIP_TRY(hipMemsetAsync(reinterpret_cast<uint8_t *>(L->gv.lpt_hist) + (size_t)a0 * hb, 0, (size_t)firstPart * hb, sim));
-                if (cnt > firstPart) HIP_TRY(hipMemsetAsync(L->gv.lpt_hist, 0, (size_t)(cnt - firstPart) * hb, sim));
+                // (the cost histograms of the call's passes are clean: take_hist.  In the steady state of batched calls nothing is cleared here at
+                // all -- every pass of the one-launch observation kernel leaves its histogram zero -- where r06l's kernel traces showed two fill
+                // kernels in front of every step launch, the second one waiting 30 us for a wave slot beside the observation passes: the chain
+                // of step launches is what bounds a batched call's rate at 1024 envs, 344 + 39 us per call against 288 us of passes.)
                 if (callEv) HIP_TRY(hipEventRecord(callEv[0], sim));
                 if (obstFamily) launch_step_obstacles_ticks(views.data(), k, sim, L->w, L->h);
                 else launch_step_ticks(views.data(), k, sim, L->w, L->h, own && !callEv ? L->simDone : nullptr);
@@ -1277,11 +1292,16 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
                 if (callEv) { HIP_TRY(hipEventRecord(callEv[2], L->stream)); HIP_TRY(hipEventRecord(callEv[3], L->stream)); }
                 int r = cn >= 2 ? launch_raster_batch(&views[(size_t)chunkFirst], chunkObs.data(), pubInRaster ? chunkPubs.data() : nullptr, cn, L->w, L->h, L->stream, mark) : 1;
                 if (r < 0) return fail("mv_step: observation size above 1024x1024");
+                if (r == 0)   // (every pass of the one-launch kernel leaves its cost histogram zero)
+                    for (int q = 0; q < cn; ++q) L->histClean[(size_t)views[(size_t)chunkFirst + q].lpt_parity] = 1;
                 if (r == 1)   // (not applicable to this gym -- long lists -- or a chunk of one tick: tick by tick)
                     for (int q = 0; q < cn; ++q)
+                    {
                         if (launch_raster(views[(size_t)chunkFirst + q], chunkObs[q], L->w, L->h, L->stream, nullptr, 1, /*setup_done=*/1, pubInRaster ? &chunkPubs[q] : nullptr,
                                           q == cn - 1 ? mark : nullptr))
                             return fail("mv_step: observation size above 1024x1024");
+                        if (views[(size_t)chunkFirst + q].lpt_no_clear) L->histClean[(size_t)views[(size_t)chunkFirst + q].lpt_parity] = 1;   // (self_clear, mv_raster.hip)
+                    }
                 if (callEv) HIP_TRY(hipEventRecord(callEv[4], L->stream));
                 chunkFirst = j + 1;
                 chunkPubs.clear(); chunkObs.clear();
@@ -1292,10 +1312,13 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
                 if (launch_raster_union(&views[(size_t)j * n], obsPtrs.data(), pubInRaster ? pubs.data() : nullptr, n, L->w, L->h, L->stream, evs[j] ? evs[j][3] : nullptr, mark))
                     return fail("mv_step: observation size above 1024x1024");
             } else {
-                for (int i = 0; i < n; ++i)
-                    if (launch_raster(views[(size_t)j * n + i], obsPtrs[i], L->w, L->h, L->stream, evs[j] && i == 0 ? evs[j][3] : nullptr, gs[i]->fastPixels, /*setup_done=*/1,
+                for (int i = 0; i < n; ++i) {
+                    const GymView &v = views[(size_t)j * n + i];
+                    if (launch_raster(v, obsPtrs[i], L->w, L->h, L->stream, evs[j] && i == 0 ? evs[j][3] : nullptr, gs[i]->fastPixels, /*setup_done=*/1,
                                       pubInRaster ? &pubs[i] : nullptr, i == n - 1 ? mark : nullptr))
                         return fail("mv_step: observation size above 1024x1024");
+                    if (v.lpt_no_clear && gs[i]->fastPixels) gs[i]->histClean[(size_t)v.lpt_parity] = 1;   // (self_clear, mv_raster.hip)
+                }
             }
         } else if (mark) HIP_TRY(hipEventRecord(mark, L->stream));
         if (evs[j]) HIP_TRY(hipEventRecord(evs[j][4], L->stream));
@@ -1569,7 +1592,7 @@ int mv_draw_hires(mv_gym *g)
         g->hiresW = g->renderW; g->hiresH = g->renderH;
     }
     if (sim_join(g)) return -1;
-    g->hist3 = (g->hist3 + 1) % g->hists;
+    if (take_hist(g, g->stream, true)) return -1;
     if (launch_raster(view(g, g->parity), g->hiresObs, g->hiresW, g->hiresH, g->stream, nullptr, g->fastPixels)) return fail("mv_draw_hires: render size above 1024x1024");
     HIP_TRY(hipGetLastError());
     return 0;

@@ -566,6 +566,11 @@ struct FastArgs {   // what raster_fast_kernel needs of the GymView (fewer live 
 #ifdef MV_RASTER_TIMING
     unsigned long long *rdbg;   // instrumented builds: per wave, clock marks of the phases (dumped at exit)
 #endif
+    // the one-launch passes of a batched call: a pass's cost histogram is cleared by the pass itself -- every workgroup counts itself in once it has
+    // looked its frame up, the one that completes the count (wg_total) zeroes the histogram and the counter -- so that the step launch of the call
+    // that reuses it finds it clean without a fill kernel in front of it (mv_api.hip: take_hist).  nullptr: not this launch's business.
+    int *hist_done;
+    int wg_total;
     int nosort;   // 1: frame = position (no look-up in the cost bins; MV_RASTER_NOSORT=1, measurements)
     int tail_div, tail_split;   // d > 0: the cheapest 1/d of the frames -- the LAST workgroups of the launch -- are cut into tail_split pieces instead of the launch's split (launch_raster)
     int graded;   // d > 0: graded split -- the most expensive 1/d of the frames are cut into 4 workgroups instead of the launch's 2 (graded_heavy)
@@ -804,7 +809,7 @@ __device__ __forceinline__ FastFrame fast_prologue(const FastArgs &fa, int blk, 
     }
     // position -> frame, most expensive frames first: the frame setup left every frame in the list of its cost bin; prefix-sum the 256 bin
     // counts (bin 255 first) and take entry (position - start) of the bin whose range holds `position`
-    __shared__ int s_wsum[4], s_frame;
+    __shared__ int s_wsum[4], s_frame, s_lastWG;
     if (fa.nosort) { if (tid == 0) s_frame = position; __syncthreads(); }
     else {
         static_assert(LPT_SUBS == 4, "the bin's counters are read as one int4");
@@ -832,6 +837,8 @@ __device__ __forceinline__ FastFrame fast_prologue(const FastArgs &fa, int blk, 
         }
         __syncthreads();
     }
+    // (every thread's loads from the histogram have returned -- their values went into the prefix sums above)
+    if (tid == 0) s_lastWG = fa.hist_done != nullptr && atomicAdd(fa.hist_done, 1) == fa.wg_total - 1;
     const int frame = __builtin_amdgcn_readfirstlane(s_frame);
     const int viewer = frame % A;
     const float *gh = reinterpret_cast<const float *>(fa.vis_hdr + (size_t)frame * FRAME_HDR_BYTES);
@@ -863,6 +870,11 @@ __device__ __forceinline__ FastFrame fast_prologue(const FastArgs &fa, int blk, 
         }
     }
     __syncthreads();
+    if (s_lastWG) {   // the pass's last workgroup: nobody reads the histogram any more
+        int *h = const_cast<int *>(fa.hist);
+        for (int i = tid; i < LPT_BUCKETS * LPT_SUBS; i += NT) h[i] = 0;
+        if (tid == 0) *fa.hist_done = 0;
+    }
 
     return FastFrame{frame, part, viewer, nVis, split};
 }
@@ -1624,6 +1636,10 @@ static void rdbg_dump()
 }
 #endif
 
+// a pass whose frame setup did not clear the next pass's cost histogram (a multi-tick step launch: GymView::lpt_no_clear) clears its own when its
+// last workgroup has looked its frame up (FastArgs::hist_done); `workgroups`: the launch's grid
+static void self_clear(struct FastArgs &fa, const GymView &gv, int workgroups);
+
 static FastArgs fast_args_of(const GymView &gv, const PublishTo *publish)
 {
     const int frames = gv.num_envs * gv.num_agents;
@@ -1636,12 +1652,20 @@ static FastArgs fast_args_of(const GymView &gv, const PublishTo *publish)
     const char *pe = getenv("MV_PLANAR");   // (read at every launch: the two paths are compared within one process by tests/test_fast_pixels_gpu.py)
     fa.planar = !(pe && *pe && atoi(pe) == 0);
     fa.graded = 0; fa.tail_div = 0; fa.tail_split = 0;
+    fa.hist_done = nullptr; fa.wg_total = 0;
     { const char *ns = getenv("MV_RASTER_NOSORT"); fa.nosort = ns && atoi(ns) != 0; }
 #ifdef MV_RASTER_TIMING
     if (!g_rdbg && hipMalloc((void **)&g_rdbg, (size_t)16384 * 4 * 8 * 8) == hipSuccess) { (void)hipMemset(g_rdbg, 0, (size_t)16384 * 4 * 8 * 8); atexit(rdbg_dump); }
     fa.rdbg = g_rdbg;
 #endif
     return fa;
+}
+
+static void self_clear(FastArgs &fa, const GymView &gv, int workgroups)
+{
+    if (!gv.lpt_no_clear) return;
+    fa.hist_done = gv.lpt_hist + (size_t)gv.lpt_hists * (LPT_BUCKETS * LPT_SUBS) + gv.lpt_parity;   // (the counters lie behind the histograms)
+    fa.wg_total = workgroups;
 }
 
 // Pixels per lane of the fast kernels (tile 16 x 4 NP): two from 8192 pixels per frame up; below that (64 x 64) the larger tiles cull worse than
@@ -1796,6 +1820,7 @@ int launch_raster_batch(const GymView *views, uint32_t *const *obs, const Publis
         ua.first[j] = j * frames * split;
         ua.obs[j] = obs[j];
         ua.fa[j] = fast_args_of(views[j], publish ? &publish[j] : nullptr);
+        self_clear(ua.fa[j], views[j], frames * split);
     }
     for (int j = k; j <= MAX_UNION; ++j) ua.first[j] = k * frames * split;
     const dim3 grid(k * frames * split), block(wide ? 512 : 256);
@@ -1851,6 +1876,7 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
         fg.graded = gradedEnv && gv.vis_stride <= VIS_SMALL && split == 2 && ftiles >= 32 && graded_heavy(frames, gradedDiv) > 0 ? gradedDiv : 0;
         if (!fg.graded && wide_workgroups(split, np) && gv.vis_stride <= VIS_SMALL && !hexScen) {   // a whole frame per eight-wave workgroup
             const KernelFn wfn = gv.scenario == SCN_REARRANGE ? raster_fast_kernel<VIS_SMALL, true, 6, false, 2, 512> : raster_fast_kernel<VIS_SMALL, false, 7, false, 2, 512>;
+            self_clear(fg, gv, frames);
             launch_done(wfn, dim3(frames), dim3(512), dyn, stream, done, fg, obs, W, H, 1);
             return 0;
         }
@@ -1868,9 +1894,11 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
         if (!fg.graded && tailDiv >= 2 && split <= 2 && gv.vis_stride <= VIS_SMALL && ftiles >= 16 * tailSplit && graded_heavy(frames, tailDiv) > 0 && tailSplit > split) {   // (split 2: a launch that fills the chip; 512 frames in four pieces each: 12.0 M obs/s with the tail cut finer, 12.4 without, r05i)
             const int q = graded_heavy(frames, tailDiv);
             fg.tail_div = tailDiv; fg.tail_split = tailSplit;
+            self_clear(fg, gv, (frames - q) * split + q * tailSplit);
             launch_done(fn, dim3((frames - q) * split + q * tailSplit), dim3(256), dyn, stream, done, fg, obs, W, H, split);
             return 0;
         }
+        self_clear(fg, gv, fg.graded ? graded_workgroups(frames, fg.graded) : frames * split);
         launch_done(fn, dim3(fg.graded ? graded_workgroups(frames, fg.graded) : frames * split), dim3(256), dyn, stream, done, fg, obs, W, H, split);
         return 0;
     }

@@ -127,8 +127,11 @@ void launch_step_ticks(const GymView *views, int k, hipStream_t stream, int W, i
     // resident for the whole call, are what the observation passes beside them cannot have; one-launch-per-tick: 19.4); MV_STEP_TICKS_WAVES overrides
     static const int maWaves = getenv("MV_STEP_TICKS_WAVES") ? std::max(1, std::min(4, atoi(getenv("MV_STEP_TICKS_WAVES")))) : 2;
     const dim3 grid(gv.num_envs), block(gv.num_agents == 1 ? 64 : 64 * std::min(gv.num_agents, maWaves));
-    if (gv.num_agents == 1) hipExtLaunchKernelGGL(step_ticks_kernel<1>, grid, block, 0, stream, nullptr, done, 0, a, W, H);
-    else hipExtLaunchKernelGGL(step_ticks_kernel<MAX_AGENTS>, grid, block, 0, stream, nullptr, done, 0, a, W, H);
+    static const bool attach = !(getenv("MV_ATTACH_DONE") && atoi(getenv("MV_ATTACH_DONE")) == 0);   // (0: launch, then record -- comparisons)
+    hipEvent_t ride = attach ? done : nullptr;
+    if (gv.num_agents == 1) hipExtLaunchKernelGGL(step_ticks_kernel<1>, grid, block, 0, stream, nullptr, ride, 0, a, W, H);
+    else hipExtLaunchKernelGGL(step_ticks_kernel<MAX_AGENTS>, grid, block, 0, stream, nullptr, ride, 0, a, W, H);
+    if (done && !attach) (void)hipEventRecord(done, stream);
 }
 
 // done: an event that completes with the launch, carried by its dispatch packet (cf. mv_raster.h)

@@ -55,6 +55,9 @@ __global__ __launch_bounds__(64) void step_obstacles_ticks_kernel(StepTicksArgs 
 {
     __shared__ FrameScratch s_fs;
     const int env = blockIdx.x;
+#ifdef MV_STEP_PRIO
+    __builtin_amdgcn_s_setprio(MV_STEP_PRIO);
+#endif
     for (int j = 0; j < a.n; ++j) {
         const GymView &gv = a.gv[j];
         obstacles_tick<1>(gv, env);
