@@ -1126,7 +1126,9 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
     unsigned long long rt_[6];
     rt_[0] = __builtin_amdgcn_s_memtime(); rt_[5] = __builtin_amdgcn_s_memrealtime();
 #define RT_MARK(i) rt_[i] = __builtin_amdgcn_s_memtime()
+#define RT_COUNT(i, n) do { const unsigned long long n_ = (unsigned long long)(n); if (fa.rdbg && lane == 0) atomicAdd(fa.rdbg + (size_t)16384 * 4 * 8 + (i), n_); } while (0)   /* census of the tile loop (wave-uniform events) */
 #else
+#define RT_COUNT(i, n) do { } while (0)
 #define RT_MARK(i) do { } while (0)
 #endif
     fast_publish(fa, blk);
@@ -1184,7 +1186,9 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
             const uint4 tc = s_tile[u];
             mv0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(tc.y) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(tc.x);
             const unsigned cover = (unsigned)__builtin_amdgcn_readfirstlane(tc.z);
+            RT_COUNT(0, 1);                                   // classified tiles
             if (mv0 == 0ull) {   // nothing: the clear colour
+                RT_COUNT(1, 1);
 #pragma unroll
                 for (int j = 0; j < NP; ++j) {
                     const int py = py0 + TILE_H * j;
@@ -1194,6 +1198,7 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
             }
             if ((mv0 & (mv0 - 1ull)) == 0ull && cover != 0u) {   // one box, and one of its faces covers the tile
                 const int k = (int)cover - 1;
+                RT_COUNT(2, 1);
                 planar_tile<NP>(__ffsll((long long)mv0) - 1, k, s_vis, s_hdr, s_col, s_row, s_rowq, s_colq, k == 0 ? nzm0 : k == 1 ? nzm1 : nzm2, px, py0, W, H, out);
                 continue;
             }
@@ -1204,7 +1209,11 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
             const uint2 rr = NP == 1 ? rr0 : *reinterpret_cast<const uint2 *>(&s_rect[cpos]);   // one 8-byte read; x0 | x1 << 16, y0 | y1 << 16 (all >= 0)
             const bool v = (lane < nVis) & ((int)(rr.x & 0xffffu) <= tx1) & ((int)(rr.x >> 16) >= tx0) & ((int)(rr.y & 0xffffu) <= ty1) & ((int)(rr.y >> 16) >= ty0);
             mv0 = __ballot(v);
+            RT_COUNT(3, 1);                                   // unclassified tiles
         }
+        RT_COUNT(4, 1);                                       // tiles on the general path
+        RT_COUNT(5, __popcll(mv0 & wb0));                     // their slab tests (first round)
+        RT_COUNT(6, __popcll(mv0 & ~wb0));                    // their other primitives
         V3 dw[NP], inv[NP];
         V3 ih0[NP], ih1[NP], ih2[NP];   // HEXF: the ray's inverse direction in wall frames 0, 1, 2
         float dcx = 0.0f, dcy[NP], a2[NP], ldc[NP];
@@ -1284,6 +1293,9 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
         }
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
+            RT_COUNT(7, __ballot(best[j] <= (KEY_FAR | POS_MASK)) != 0ull);                     // (wave, pixel row) pairs that shade at all
+            RT_COUNT(8, __popcll(__ballot(best[j] <= (KEY_FAR | POS_MASK))));                    // pixels with a hit on the general path
+            RT_COUNT(9, __ballot(best[j] <= (KEY_FAR | POS_MASK) && !((wb0 >> (best[j] & 63u)) & 1ull)) != 0ull);   // ... that shade something that is not a world box
             const unsigned rgba = fast_shade<SHAPES, POS_MASK>(best[j], bn[j], s_vis, s_hdr, camv, viewer, dw[j], inv[j], dcx, dcy[j], a2[j], ldc[j]);
             const int py = py0 + TILE_H * j;
             if (px < W && py < H) PIXEL_STORE(out[(unsigned)(py * W + px)], rgba);   // (32-bit offset from the frame's base: scalar-base addressing)
@@ -1574,6 +1586,13 @@ static void rdbg_dump()
 {   // the LAST launch's marks: phase cycles per wave, workgroup life times, when the workgroups ended relative to the launch's first start
     if (!g_rdbg) return;
     (void)hipDeviceSynchronize();
+    {   // the census of the tile loop over all launches (RT_COUNT)
+        unsigned long long c[16];
+        if (hipMemcpy(c, g_rdbg + (size_t)16384 * 4 * 8, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess && c[4])
+            fprintf(stderr, "raster census (all launches): classified tiles %llu (empty %llu, planar %llu), unclassified %llu, general-path tiles %llu: slab tests %.2f and other primitives %.2f per tile, "
+                            "shading wave-rows %.2f of 2, hit pixels %.1f of 128, wave-rows shading a non-box %.3f\n",
+                    c[0], c[1], c[2], c[3], c[4], double(c[5]) / c[4], double(c[6]) / c[4], double(c[7]) / c[4], double(c[8]) / c[4], double(c[9]) / c[4]);
+    }
     std::vector<unsigned long long> h((size_t)16384 * 4 * 8);
     if (hipMemcpy(h.data(), g_rdbg, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
     double sumP = 0, sumC = 0, sumT = 0; size_t n = 0;
@@ -1664,7 +1683,7 @@ static FastArgs fast_args_of(const GymView &gv, const PublishTo *publish)
     fa.hist_done = nullptr; fa.wg_total = 0;
     { const char *ns = getenv("MV_RASTER_NOSORT"); fa.nosort = ns && atoi(ns) != 0; }
 #ifdef MV_RASTER_TIMING
-    if (!g_rdbg && hipMalloc((void **)&g_rdbg, (size_t)16384 * 4 * 8 * 8) == hipSuccess) { (void)hipMemset(g_rdbg, 0, (size_t)16384 * 4 * 8 * 8); atexit(rdbg_dump); }
+    if (!g_rdbg && hipMalloc((void **)&g_rdbg, (size_t)(16384 * 4 * 8 + 64) * 8) == hipSuccess) { (void)hipMemset(g_rdbg, 0, (size_t)(16384 * 4 * 8 + 64) * 8); atexit(rdbg_dump); }
     fa.rdbg = g_rdbg;
 #endif
     return fa;
