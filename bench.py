@@ -686,10 +686,12 @@ def main():
             achieved = bytes_per_frame * frames / (raster_ms * 1e-3) / 1e9 if raster_ms > 0 else 0.0
             achieved_step = step_bytes_per_env * n_env / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
             long_list = args.scenario.lower() in ("collect", "hexmemory", "hexexplore")
-            batch_raster = batched and not mixed and not long_list and args.pixels == "fast"   # the k passes of a call as ONE launch (mv_raster.hip: raster_fast_batch_kernel)
-            batch_step = batched and not mixed and args.scenario == "TowerBuilding" and A == 1     # the k ticks of a call as ONE launch (mv_step.hip: step_ticks_kernel)
+            # the k ticks of a call as ONE step launch (step_ticks_kernel / step_<scenario>_ticks_kernel: one agent per env, TowerBuilding also with several) and its
+            # k observation passes as ONE launch (raster_fast_batch_kernel, raster_glist_batch_kernel for the long lists): mv_api.hip, canMultiTick / canBatchRaster
+            batch_step = batched and not mixed and (A == 1 or args.scenario == "TowerBuilding") and os.environ.get("MV_STEP_TICKS", "1") != "0"
+            batch_raster = batch_step and args.pixels == "fast" and os.environ.get("MV_RASTER_BATCH", "8") != "0"
             line["roofline"] = {"bound": "valu", "kernel": ("mv::raster_fast_union_kernel x 2 (short-list + long-list variant)" if mixed else
-                                                          "mv::raster_fast_batch_kernel (the %d observation passes of a call in one launch; every figure here is PER TICK)" % batch if batch_raster
+                                                          "mv::%s (the %d observation passes of a call in one launch; every figure here is PER TICK)" % ("raster_glist_batch_kernel" if long_list else "raster_fast_batch_kernel", batch) if batch_raster
                                                           else "mv::raster_glist_kernel" if long_list else "mv::raster_fast_kernel") if args.pixels == "fast" else "mv::raster_kernel",
                                 "ticks_per_launch": batch if batch_raster else 1,
                                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

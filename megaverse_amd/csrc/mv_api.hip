@@ -34,6 +34,10 @@ void launch_step(const GymView &gv, hipStream_t stream, int W, int H, int render
 void launch_step_ticks(const GymView *views, int k, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);   // k ticks + frame setups of every env, one launch (mv_step.hip)
 void launch_step_obstacles(const GymView &gv, hipStream_t stream, int W, int H, int render);
 void launch_step_obstacles_ticks(const GymView *views, int k, hipStream_t stream, int W, int H);   // k ticks + frame setups of every env (one agent), one launch
+void launch_step_rearrange_ticks(const GymView *views, int k, hipStream_t stream, int W, int H);
+void launch_step_sokoban_ticks(const GymView *views, int k, hipStream_t stream, int W, int H);
+void launch_step_collect_ticks(const GymView *views, int k, hipStream_t stream, int W, int H);
+void launch_step_hex_ticks(const GymView *views, int k, hipStream_t stream, int W, int H);
 void launch_reset_obstacles(const GymView &gv, const EpisodeBlob *blobs, int *status, int force_all, hipStream_t stream);
 void launch_step_rearrange(const GymView &gv, hipStream_t stream, int W, int H, int render);
 void launch_reset_rearrange(const GymView &gv, const RearrangeBlob *blobs, int *status, int force_all, hipStream_t stream);
@@ -1185,7 +1189,11 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
     const bool obstFamily = L->scenario == SCN_OBSTACLES || L->scenario == SCN_EMPTY;
     static const bool ticksMulti = !(getenv("MV_STEP_TICKS_MULTI") && atoi(getenv("MV_STEP_TICKS_MULTI")) == 0);   // (several agents per env, too -- TowerBuilding: two waves per env, launch_step_ticks; 0: off)
     static const int obstMinEnvs = getenv("MV_STEP_TICKS_OBST_MIN_ENVS") ? atoi(getenv("MV_STEP_TICKS_OBST_MIN_ENVS")) : 0;   // (r06c, with the one-launch passes cut for k x frames workgroups: ObstaclesHard 512 envs 13.0 against 11.7 M obs/s, 256 envs 9.2 against 8.6)
-    const bool canMultiTick = !ticksOff && n == 1 && (L->A == 1 || (ticksMulti && L->scenario == SCN_TOWER)) && k >= 2 && k <= MAX_STEP_TICKS && render && policy != POLICY_NONE && (L->scenario == SCN_TOWER || (obstFamily && L->N >= obstMinEnvs)) &&   // (Obstacles at 512 envs: 11.6 against 12.0 M obs/s, at 1024: 16.9 against 16.1; TowerBuilding 512 x 4: 21.7 against 19.4)
+    // (the other scenarios, one agent per env: MV_STEP_TICKS_OTHERS=0 keeps them on one launch per tick)
+    static const bool ticksOthers = !(getenv("MV_STEP_TICKS_OTHERS") && atoi(getenv("MV_STEP_TICKS_OTHERS")) == 0);
+    const bool otherFamily = ticksOthers && (L->scenario == SCN_REARRANGE || L->scenario == SCN_SOKOBAN || L->scenario == SCN_COLLECT || L->scenario == SCN_HEX_MEMORY || L->scenario == SCN_HEX_EXPLORE);
+    const bool canMultiTick = !ticksOff && n == 1 && (L->A == 1 || (ticksMulti && L->scenario == SCN_TOWER)) && k >= 2 && k <= MAX_STEP_TICKS && render && policy != POLICY_NONE &&
+                              (L->scenario == SCN_TOWER || (obstFamily && L->N >= obstMinEnvs) || otherFamily) &&   // (Obstacles at 512 envs: 11.6 against 12.0 M obs/s, at 1024: 16.9 against 16.1; TowerBuilding 512 x 4: 21.7 against 19.4)
                               !L->gv.dbg;
     // (the one-launch observation passes only beside the one-launch step: k separate step kernels starve beside a pass that long -- 70-190 us each, r04l)
     const bool canBatchRaster = canMultiTick && render && allFast && n == 1 && k >= 2 && L->ringObs && L->ringCount >= k;
@@ -1230,9 +1238,13 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
                 // of step launches is what bounds a batched call's rate at 1024 envs, 344 + 39 us per call against 288 us of passes.)
                 if (callEv) HIP_TRY(hipEventRecord(callEv[0], sim));
                 if (obstFamily) launch_step_obstacles_ticks(views.data(), k, sim, L->w, L->h);
+                else if (L->scenario == SCN_REARRANGE) launch_step_rearrange_ticks(views.data(), k, sim, L->w, L->h);
+                else if (L->scenario == SCN_SOKOBAN) launch_step_sokoban_ticks(views.data(), k, sim, L->w, L->h);
+                else if (L->scenario == SCN_COLLECT) launch_step_collect_ticks(views.data(), k, sim, L->w, L->h);
+                else if (L->scenario == SCN_HEX_MEMORY || L->scenario == SCN_HEX_EXPLORE) launch_step_hex_ticks(views.data(), k, sim, L->w, L->h);
                 else launch_step_ticks(views.data(), k, sim, L->w, L->h, own && !callEv ? L->simDone : nullptr);
                 if (callEv) HIP_TRY(hipEventRecord(callEv[1], sim));
-                simDoneRides = own && !callEv && !obstFamily;
+                simDoneRides = own && !callEv && L->scenario == SCN_TOWER;
             }
         } else if (n == 1) simDoneRides = launch_step_of(L, views[(size_t)j * n], sim, fused, own && j == k - 1 && !evs[j] ? L->simDone : nullptr);
         else {

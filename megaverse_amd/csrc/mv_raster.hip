@@ -1544,6 +1544,22 @@ __global__ __launch_bounds__(NT, WAVES) void raster_fast_batch_kernel(UnionRaste
     raster_fast_body<MAXVIS, SHAPES, false, NP, true, NT>(fa, ua.obs[s], W, H, split, (int)blockIdx.x - ua.first[s], s_buf);
 }
 
+// (the long-list variant of raster_fast_batch_kernel: the k passes of one batched call of a Collect / Hex gym)
+template <int MAXVIS, bool SHAPES, int WAVES, bool HEXF, int NP>
+__global__ __launch_bounds__(256, WAVES) void raster_glist_batch_kernel(UnionRasterArgs ua, int W, int H, int split)
+{
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_UNION; ++i)
+        if (i < ua.n && (int)blockIdx.x >= ua.first[i]) s = i;
+    if (s == 0)
+        for (int j = 0; j < ua.n; ++j) fast_publish(ua.fa[j], (int)blockIdx.x);
+    __shared__ __attribute__((aligned(16))) unsigned char s_buf[glist_lds_bytes(MAXVIS)];
+    FastArgs fa = ua.fa[s];
+    fa.pub_n = 0;
+    raster_glist_body<MAXVIS, SHAPES, HEXF, NP>(fa, ua.obs[s], W, H, split, (int)blockIdx.x - ua.first[s], s_buf);
+}
+
 template <int MAXVIS, bool SHAPES, int WAVES, bool HEXF, int NP>
 __global__ __launch_bounds__(256, WAVES) void raster_glist_union_kernel(UnionRasterArgs ua, int W, int H, int split)
 {
@@ -1830,11 +1846,33 @@ int launch_raster_batch(const GymView *views, uint32_t *const *obs, const Publis
 {
     if (W > MAX_W || H > MAX_H || k < 2 || k > MAX_UNION) return 1;
     const GymView &gv = views[0];
-    if (gv.vis_stride > VIS_SMALL || gv.scenario == SCN_HEX_MEMORY || gv.scenario == SCN_HEX_EXPLORE) return 1;
     static const int off = getenv("MV_RASTER_BATCH") && atoi(getenv("MV_RASTER_BATCH")) == 0;
     if (off) return 1;
     const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)W * sizeof(float) + (size_t)H * sizeof(float2) + lds_pad();
     const int frames = gv.num_envs * gv.num_agents;
+    const bool hexScen = gv.scenario == SCN_HEX_MEMORY || gv.scenario == SCN_HEX_EXPLORE;
+    if (gv.vis_stride > VIS_SMALL || hexScen) {   // the long-list variants (records through the scalar cache)
+        const int lnp = fast_pixels_per_lane(W, H, true);
+        const int lsplit = fast_split(W, H, lnp, frames * k, true, true);
+        UnionRasterArgs ua;
+        ua.n = k;
+        for (int j = 0; j < k; ++j) {
+            ua.first[j] = j * frames * lsplit;
+            ua.obs[j] = obs[j];
+            ua.fa[j] = fast_args_of(views[j], publish ? &publish[j] : nullptr);
+            self_clear(ua.fa[j], views[j], frames * lsplit);
+        }
+        for (int j = k; j <= MAX_UNION; ++j) ua.first[j] = k * frames * lsplit;
+        const dim3 grid(k * frames * lsplit), block(256);
+        if (lnp == 2) {
+            if (hexScen) launch_done(raster_glist_batch_kernel<VIS_XL, true, GLIST_WAVES_NP2, true, 2>, grid, block, dyn, stream, done, ua, W, H, lsplit);
+            else launch_done(raster_glist_batch_kernel<VIS_LARGE, false, GLIST_WAVES_NP2, false, 2>, grid, block, dyn, stream, done, ua, W, H, lsplit);
+        } else {
+            if (hexScen) launch_done(raster_glist_batch_kernel<VIS_XL, true, GLIST_WAVES_NP1, true, 1>, grid, block, dyn, stream, done, ua, W, H, lsplit);
+            else launch_done(raster_glist_batch_kernel<VIS_LARGE, false, GLIST_WAVES_NP1, false, 1>, grid, block, dyn, stream, done, ua, W, H, lsplit);
+        }
+        return 0;
+    }
     const int np = fast_pixels_per_lane(W, H);
     // (the k passes fill the chip together -- later passes' workgroups start as earlier ones end -- so the frame is cut for k x frames of them:
     // 512 TowerBuilding frames, 8 ticks per call: 16.2 M obs/s with two workgroups per frame, 14.0 M with the four a single pass of 512 frames takes)

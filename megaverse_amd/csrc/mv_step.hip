@@ -92,8 +92,14 @@ __global__ __launch_bounds__(256) void step_kernel(GymView gv, int W, int H, int
 // One agent: ONE wave per env (the single-tick kernel's second wave only helps with the frame setup, and idles through the tick): the
 // workgroups stay resident for the whole call beside the observation passes of the previous one, and every wave of ~150 VGPRs they hold is
 // two or three waves the pass cannot have (measured: 21.1 M obs/s with two waves per env, 22.3 M with one).
+// MV_STEP_TICKS_WAVES_PER_SIMD: the register budget of the one-wave-per-env multi-tick kernels (512 / n VGPRs).  Their waves stay resident for a whole
+// batched call beside the observation passes, and what they hold the passes cannot have: left to itself hipcc takes 236 VGPRs for the TowerBuilding
+// tick (launch bound 64: nothing asks it to be frugal), the one-launch-per-tick kernel does the same work in 97.
+#ifndef MV_STEP_TICKS_WAVES_PER_SIMD
+#define MV_STEP_TICKS_WAVES_PER_SIMD 4
+#endif
 template <int A_MAX>
-__global__ __launch_bounds__(A_MAX == 1 ? 64 : 256) void step_ticks_kernel(StepTicksArgs a, int W, int H)
+__device__ __forceinline__ void step_ticks_body(const StepTicksArgs &a, int W, int H)
 {
     __shared__ FrameScratch s_fs[A_MAX == 1 ? 1 : 4];
     const int env = blockIdx.x;
@@ -115,6 +121,11 @@ __global__ __launch_bounds__(A_MAX == 1 ? 64 : 256) void step_ticks_kernel(StepT
         }
     }
 }
+// (two kernels, not one template: a launch bound that depends on a template parameter is not applied)
+// (amdgpu_num_vgpr, not a waves-per-SIMD launch bound: with 24 KB of LDS per one-wave workgroup -- the in-kernel episode generator's -- hipcc finds four waves per SIMD
+// out of reach and drops the bound)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(512 / MV_STEP_TICKS_WAVES_PER_SIMD))) void step_ticks_kernel(StepTicksArgs a, int W, int H) { step_ticks_body<1>(a, W, H); }
+__global__ __launch_bounds__(256) void step_ticks_agents_kernel(StepTicksArgs a, int W, int H) { step_ticks_body<MAX_AGENTS>(a, W, H); }
 
 void launch_step_ticks(const GymView *views, int k, hipStream_t stream, int W, int H, hipEvent_t done)
 {
@@ -129,8 +140,8 @@ void launch_step_ticks(const GymView *views, int k, hipStream_t stream, int W, i
     const dim3 grid(gv.num_envs), block(gv.num_agents == 1 ? 64 : 64 * std::min(gv.num_agents, maWaves));
     static const bool attach = !(getenv("MV_ATTACH_DONE") && atoi(getenv("MV_ATTACH_DONE")) == 0);   // (0: launch, then record -- comparisons)
     hipEvent_t ride = attach ? done : nullptr;
-    if (gv.num_agents == 1) hipExtLaunchKernelGGL(step_ticks_kernel<1>, grid, block, 0, stream, nullptr, ride, 0, a, W, H);
-    else hipExtLaunchKernelGGL(step_ticks_kernel<MAX_AGENTS>, grid, block, 0, stream, nullptr, ride, 0, a, W, H);
+    if (gv.num_agents == 1) hipExtLaunchKernelGGL(step_ticks_kernel, grid, block, 0, stream, nullptr, ride, 0, a, W, H);
+    else hipExtLaunchKernelGGL(step_ticks_agents_kernel, grid, block, 0, stream, nullptr, ride, 0, a, W, H);
     if (done && !attach) (void)hipEventRecord(done, stream);
 }
 

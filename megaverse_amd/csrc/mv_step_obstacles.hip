@@ -51,7 +51,10 @@ __global__ __launch_bounds__(256) void step_obstacles_kernel(GymView gv, int W, 
 // whole batched call; gv[j] is tick j's view.  An env that finishes swaps its next resident episode in at the tail of its tick as always -- a
 // batched call only ever spans ticks of gyms whose episodes are long (mv_step_n steps the others tick by tick), so the two resident episodes
 // outlast it.
-__global__ __launch_bounds__(64) void step_obstacles_ticks_kernel(StepTicksArgs a, int W, int H)
+#ifndef MV_STEP_TICKS_WAVES_PER_SIMD
+#define MV_STEP_TICKS_WAVES_PER_SIMD 4   // (the register budget of the resident multi-tick waves: mv_step.hip)
+#endif
+__global__ __launch_bounds__(64, MV_STEP_TICKS_WAVES_PER_SIMD) void step_obstacles_ticks_kernel(StepTicksArgs a, int W, int H)
 {
     __shared__ FrameScratch s_fs;
     const int env = blockIdx.x;

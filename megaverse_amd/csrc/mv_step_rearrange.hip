@@ -52,6 +52,33 @@ __global__ __launch_bounds__(64) void reset_rearrange_kernel(GymView gv, const R
     swap_in_episode(gv, blobs, status, env, force_all);
 }
 
+// k consecutive ticks of every env with one launch (one agent per env; see step_ticks_kernel, mv_step.hip, for why): one wave per env, resident for the
+// whole batched call; gv[j] is tick j's view.  (Episodes come from the host: a batched call only ever spans ticks of gyms whose episodes are long,
+// mv_step_n steps the others tick by tick, so the two resident episodes outlast it.)
+#ifndef MV_STEP_TICKS_WAVES_PER_SIMD
+#define MV_STEP_TICKS_WAVES_PER_SIMD 4   // (the register budget of the resident multi-tick waves: mv_step.hip)
+#endif
+__global__ __launch_bounds__(64, MV_STEP_TICKS_WAVES_PER_SIMD) void step_rearrange_ticks_kernel(StepTicksArgs a, int W, int H)
+{
+    __shared__ FrameScratch s_fs;
+    const int env = blockIdx.x;
+    for (int j = 0; j < a.n; ++j) {
+        const GymView &gv = a.gv[j];
+        rearrange_tick<1>(gv, env);
+        wave_sync();   // the tick's stores before the frame setup's loads (one wave: no barrier needed)
+        frame_setup_body<64, true>(gv, env, W, H, s_fs);
+    }
+}
+
+void launch_step_rearrange_ticks(const GymView *views, int k, hipStream_t stream, int W, int H)
+{
+    StepTicksArgs a;
+    a.n = k;
+    for (int j = 0; j < k; ++j) a.gv[j] = views[j];
+    for (int j = k; j < MAX_STEP_TICKS; ++j) a.gv[j] = views[k - 1];
+    hipLaunchKernelGGL(step_rearrange_ticks_kernel, dim3(views[0].num_envs), dim3(64), 0, stream, a, W, H);
+}
+
 void launch_step_rearrange(const GymView &gv, hipStream_t stream, int W, int H, int render)
 {
     const dim3 grid(gv.num_envs), block(gv.num_agents == 1 ? STEP_THREADS : 64 * std::min(gv.num_agents, 4));

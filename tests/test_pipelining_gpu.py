@@ -343,12 +343,17 @@ def test_a_pending_device_action_buffer_is_read_by_what_comes_next(hip):
 
 
 @pytest.mark.parametrize("scenario,N,A,W,H,params", [("TowerBuilding", 40, 1, 48, 20, {"episodeLengthSec": -200.0}), ("TowerBuilding", 33, 3, 128, 72, {}),
-                                                     ("TowerBuilding", 100, 1, 64, 64, {}), ("ObstaclesEasy", 800, 1, 33, 17, {}), ("Empty", 770, 1, 128, 128, {})])
-def test_one_launch_calls_fill_the_ring_like_single_ticks(hip, scenario, N, A, W, H, params):
-    """a batched call with an output ring -- ONE step launch for its k ticks (step_ticks_kernel / step_obstacles_ticks_kernel) and ONE raster launch for its k
-    observation passes (raster_fast_batch_kernel) -- against single ticks: every slab of the ring, rewards / dones rings, state; ragged sizes, one and
-    several agents, call sizes 2 .. 8 and chunks the ring wraps around in"""
+                                                     ("TowerBuilding", 100, 1, 64, 64, {}), ("ObstaclesEasy", 800, 1, 33, 17, {}), ("Empty", 770, 1, 128, 128, {}),
+                                                     ("ObstaclesHard", 96, 1, 128, 128, {}), ("Rearrange", 70, 1, 128, 128, {}), ("Rearrange", 130, 1, 50, 30, {}),
+                                                     ("Sokoban", 90, 1, 128, 128, {}), ("Collect", 60, 1, 128, 128, {}), ("Collect", 140, 1, 64, 64, {}),
+                                                     ("HexMemory", 48, 1, 128, 128, {}), ("HexExplore", 72, 1, 64, 64, {})])
+def test_one_launch_calls_fill_the_ring_like_single_ticks(hip, monkeypatch, scenario, N, A, W, H, params):
+    """a batched call with an output ring -- ONE step launch for its k ticks (step_ticks_kernel / step_<scenario>_ticks_kernel) and ONE raster launch for its k
+    observation passes (raster_fast_batch_kernel, raster_glist_batch_kernel for the long lists) -- against single ticks: every slab of the ring, rewards /
+    dones rings, state; ragged sizes, one and several agents, every scenario, call sizes 2 .. 8 and chunks the ring wraps around in"""
+    import os
     import torch
+    monkeypatch.setenv("BOXOBAN_LEVELS", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "boxoban"))
     R = 8
     def make(with_ring):
         g = MegaverseGym(scenario, W, H, N, A, 2, False, params)
