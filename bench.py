@@ -689,6 +689,8 @@ def main():
             # the k ticks of a call as ONE step launch (step_ticks_kernel / step_<scenario>_ticks_kernel: one agent per env, TowerBuilding also with several) and its
             # k observation passes as ONE launch (raster_fast_batch_kernel, raster_glist_batch_kernel for the long lists): mv_api.hip, canMultiTick / canBatchRaster
             batch_step = batched and not mixed and (A == 1 or args.scenario == "TowerBuilding") and os.environ.get("MV_STEP_TICKS", "1") != "0"
+            fam = {"towerbuilding": "", "collect": "collect_", "rearrange": "rearrange_", "sokoban": "sokoban_", "hexmemory": "hex_", "hexexplore": "hex_"}.get(args.scenario.lower(), "obstacles_")
+            ticks_kernel_name = "step_ticks_agents_kernel" if A > 1 else "step_%sticks_kernel" % fam
             batch_raster = batch_step and args.pixels == "fast" and os.environ.get("MV_RASTER_BATCH", "8") != "0"
             line["roofline"] = {"bound": "valu", "kernel": ("mv::raster_fast_union_kernel x 2 (short-list + long-list variant)" if mixed else
                                                           "mv::%s (the %d observation passes of a call in one launch; every figure here is PER TICK)" % ("raster_glist_batch_kernel" if long_list else "raster_fast_batch_kernel", batch) if batch_raster
@@ -709,7 +711,7 @@ def main():
                                             # retires one per 1.11 ns (the clock under an all-VALU load is below 2.4 GHz); min / max / cndmask / max3 cost more
                                             "probed_ns_per_fma_per_simd": 1.11, "frac_of_probed_fma_rate": insts * 1.11e-9 / 1024.0 / (raster_ms * 1e-3),
                                             "source": valu.get("source")}
-            line["roofline_physics"] = {"bound": "latency", "kernel": ("mv::step_union_kernel" if mixed else "mv::step_ticks_kernel (the %d ticks of a call in one launch; per tick)" % batch if batch_step else "mv::step_kernel") +
+            line["roofline_physics"] = {"bound": "latency", "kernel": ("mv::step_union_kernel" if mixed else "mv::%s (the %d ticks of a call in one launch; per tick)" % (ticks_kernel_name, batch) if batch_step else "mv::step_kernel") +
                                                               " (voxel physics + scenario logic + auto-reset + frame setup)", "ticks_per_launch": batch if batch_step else 1, "achieved": achieved_step,
                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_step / HBM_PEAK_GBS, "traffic": traffic_step,
                                         "avg_launch_ms": step_ms, "launches_timed": prof["step"][1], "algorithmic_bytes_per_launch": step_bytes_per_env * n_env,
