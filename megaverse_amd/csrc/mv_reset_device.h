@@ -46,7 +46,6 @@ __device__ __forceinline__ void reset_env(const GymView &gv, int env, int force_
     __shared__ __attribute__((aligned(16))) uint32_t s_mt[624];
     __shared__ __attribute__((aligned(16))) uint16_t s_cand[32 * 32];
     __shared__ __attribute__((aligned(16))) uint16_t s_steps[32 * 32];   // the shuffle's swap partners
-    __shared__ __attribute__((aligned(16))) uint8_t s_chunk[CHUNK_BYTES];
     __shared__ MovableObject s_obj[MAX_OBJECTS];
 
     const int A = gv.num_agents;
@@ -113,8 +112,13 @@ __device__ __forceinline__ void reset_env(const GymView &gv, int env, int force_
     const bool drawWalls = random_bool(g);
     const unsigned wallColor = random_layout_color(g);
 
-    // ---- voxel chunk image in LDS: floor, then the four walls override (platforms.hpp:167-190,
-    // component_voxel_grid.hpp:73-90).  One 16-cell run per lane per round.
+    // ---- voxel chunk: floor, then the four walls override (platforms.hpp:167-190, component_voxel_grid.hpp:73-90).  One 16-cell run per lane
+    // per round, formed in registers and stored straight to the env's chunk (coalesced 16 B / lane); the object bits are then or-ed into
+    // their bytes in global memory.  (Until r06 the image was built in 16 KB of LDS first: the step kernel -- every step workgroup, resident
+    // for a whole batched call -- carried 24 KB of LDS for a generator that runs for one env in a thousand ticks, and four of them per CU left
+    // room for three workgroups of the observation pass instead of seven.)
+    uint8_t *gbytes = gv.chunk + (size_t)env * CHUNK_BYTES;
+    uint4 *gchunk = reinterpret_cast<uint4 *>(gbytes);
     const uint32_t vFloor = VX_SOLID | VX_OPAQUE;
     const uint32_t vWall = VX_SOLID | (drawWalls ? VX_OPAQUE : 0) | (1u << VX_COLOR_SHIFT);
     for (int grp = lane; grp < CHUNK_BYTES / 16; grp += 64) {
@@ -135,18 +139,20 @@ __device__ __forceinline__ void reset_env(const GymView &gv, int env, int force_
             }
             w[q] = word;
         }
-        *reinterpret_cast<uint4 *>(s_chunk + grp * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+        gchunk[grp] = make_uint4(w[0], w[1], w[2], w[3]);
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the fill before the bytes below are read back (other lanes' stores)
     wave_sync();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     for (int i = lane; i < numObjects; i += 64) {
         const MovableObject o = s_obj[i];
-        s_chunk[(o.y * CZ + o.z) * CX + o.x] |= VX_OBJECT;   // distinct cells, byte-wide LDS RMW
+        volatile uint8_t *cell = gbytes + (o.y * CZ + o.z) * CX + o.x;
+        *cell = (uint8_t)(*cell | VX_OBJECT);   // distinct cells, byte-wide read-modify-write
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     wave_sync();
 
-    // ---- write-out: chunk (coalesced 16 B / lane), objects, boxes, header, agents
-    uint4 *gchunk = reinterpret_cast<uint4 *>(gv.chunk + (size_t)env * CHUNK_BYTES);
-    for (int grp = lane; grp < CHUNK_BYTES / 16; grp += 64) gchunk[grp] = *reinterpret_cast<const uint4 *>(s_chunk + grp * 16);
+    // ---- write-out: objects, boxes, header, agents
 
     MovableObject *gobj = gv.objects + (size_t)env * MAX_OBJECTS;
     for (int i = lane; i < MAX_OBJECTS; i += 64) {

@@ -122,10 +122,8 @@ __device__ __forceinline__ void step_ticks_body(const StepTicksArgs &a, int W, i
     }
 }
 // (two kernels, not one template: a launch bound that depends on a template parameter is not applied)
-// (amdgpu_num_vgpr, not a waves-per-SIMD launch bound: with 24 KB of LDS per one-wave workgroup -- the in-kernel episode generator's -- hipcc finds four waves per SIMD
-// out of reach and drops the bound)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(512 / MV_STEP_TICKS_WAVES_PER_SIMD))) void step_ticks_kernel(StepTicksArgs a, int W, int H) { step_ticks_body<1>(a, W, H); }
-__global__ __launch_bounds__(256) void step_ticks_agents_kernel(StepTicksArgs a, int W, int H) { step_ticks_body<MAX_AGENTS>(a, W, H); }
+__global__ __launch_bounds__(64, MV_STEP_TICKS_WAVES_PER_SIMD) void step_ticks_kernel(StepTicksArgs a, int W, int H) { step_ticks_body<1>(a, W, H); }
+__global__ __launch_bounds__(256, 3) void step_ticks_agents_kernel(StepTicksArgs a, int W, int H) { step_ticks_body<MAX_AGENTS>(a, W, H); }
 
 void launch_step_ticks(const GymView *views, int k, hipStream_t stream, int W, int H, hipEvent_t done)
 {
