@@ -315,6 +315,10 @@ def main():
     ap.add_argument("--policy", default="multidiscrete", choices=["multidiscrete", "single-bit"],
                     help="random policy: uniform per head (action_space.sample(), megaverse_env.py:110-112) or the reference benchmark's "
                          "Action(1 << randRange(0, 11)) (megaverse_test_app.cpp:140-147)")
+    ap.add_argument("--pass-overlap", choices=("auto", "on", "off"), default="auto",
+                    help="output ring two calls deep, the observation passes of consecutive calls overlap (mv_set_pass_overlap).  auto: for the Obstacles scenarios "
+                         "(measured r07a/b, M obs/s with / without: ObstaclesHard 512 envs 16.9 / 13.9, 1024 envs 20.5 / 20.1; TowerBuilding 1024 envs 23.4 / 24.0, "
+                         "512 envs 20.1 / 20.9; Rearrange 19.4 / 19.5)")
     ap.add_argument("--batch", type=int, default=0,
                     help="ticks per stepping call (mv_step_n): every tick is stepped and rendered in full, the two stream hand-overs are paid once "
                          "per call; 1 = one mv_step per tick; 0 (default) = 8, the first two calls after a synchronisation 1 and 3 ticks (the observation "
@@ -390,7 +394,9 @@ def main():
     # batched stepping: tick j of a call renders into slab j of a ring, so that all `batch` observations of a call exist side by side when it
     # is done (a k-step rollout buffer) -- the working set of the observation writes is batch x one slab, not one slab written over and over
     batched = batch > 1 and not dry
-    ring_slots = max(batch, 8) if batched else 1   # (slabs of the output ring: a call never holds more ticks than that)
+    # (slabs of the output ring: a call never holds more ticks than `batch`; two calls deep, the passes of consecutive calls overlap: mv_set_pass_overlap)
+    pass_overlap = batched and not mixed and (args.pass_overlap == "on" or (args.pass_overlap == "auto" and args.scenario.lower().startswith("obstacles")))
+    ring_slots = (max(batch, 8) * (2 if pass_overlap else 1)) if batched else 1
     ring = torch.zeros((ring_slots, frames, H, W, 4), dtype=torch.uint8, device=device) if batched and not mixed else None   # (Mixed: one slab, no ring)
 
     def bind(b):
@@ -438,7 +444,7 @@ def main():
             # against 19.0-19.1 M with 2 ticks per call throughout and 19.2-19.7 M with 8).  MV_BENCH_CALL_SCHEDULE=a,b,...: other first calls.
             sched = [int(x) for x in os.environ.get("MV_BENCH_CALL_SCHEDULE", "1,3").split(",") if x]
             while i < n:
-                k = min(sched.pop(0) if sched else batch, n - i, ring_slots)
+                k = min(sched.pop(0) if sched else batch, n - i, max(batch, 8))
                 gym.step_n(k, args.policy, 1234, first + i)
                 i += k
         else:
@@ -460,6 +466,8 @@ def main():
     main_batched = batched and not do_gather
     if main_batched and ring is not None:
         gym.set_output_ring(ring_slots, ring.data_ptr())
+        if pass_overlap:
+            gym.set_pass_overlap(True)
     run_steps(step0, args.warmup, do_gather, main_batched)
     step0 += args.warmup
     elapsed = timed(step0, do_gather, main_batched)        # THE timed region: exactly --steps steps, no instrumentation
@@ -636,6 +644,7 @@ def main():
                        # stepped and rendered in full); ticks_per_call > 1: mv_step_n, the streams hand over once per call, tick j of a call
                        # leaves its observations in slab j of a ring of that many slabs
                        "pipelined": pipelined, "ticks_per_call": batch if main_batched else 1,
+                       **({"ring_slots": ring_slots, "overlapped_passes": bool(pass_overlap)} if main_batched else {}),
                        **({"first_calls": os.environ.get("MV_BENCH_CALL_SCHEDULE", "1,3") + " ticks, then ticks_per_call (every tick stepped and rendered in full)"} if main_batched else {}),
                        **({"launches_per_tick": 2, "scenarios": "TowerBuilding, ObstaclesEasy, ObstaclesHard, Collect, Sokoban, HexMemory, HexExplore, Rearrange dealt round-robin "
                                                               "by env index (one gym per scenario, stepped as one mv_group: one step launch and one raster launch per tick)"} if mixed else {}),

@@ -129,6 +129,14 @@ struct mv_gym {
     std::vector<GymView> gvp;                    // [slots] gv with the buffers of each slot swapped in
     GymView gv{};
     const int32_t *mdActions = nullptr;          // mv_set_actions_device: the caller's multi-discrete buffer, read by the next step kernel
+    // mv_set_pass_overlap(1), ring at least two calls deep: the one-launch observation passes of consecutive batched calls go to two internal streams
+    // in turn, so that the passes of call c + 1 start -- their step launch permitting -- while those of call c drain (a launch ends with its last
+    // workgroups finishing alone, and the next one could not begin before: ~7 % of a 1024-env call).  The caller's stream waits for every call's
+    // passes as before; what the passes of call c wait for on the caller's side is what was enqueued before call c - 1 began (callStart).
+    int passOverlap = 0;
+    hipStream_t passStream[2] = {nullptr, nullptr};
+    hipEvent_t callStart[2] = {nullptr, nullptr};
+    unsigned long long overlapCalls = 0;   // consecutive calls that took the overlapped path (0: the last call's passes ran on the caller's stream)
     // mv_set_output_ring: tick number t (since the ring was set) leaves its observations / rewards / dones in entry t % ringCount
     int ringCount = 0;
     unsigned long long ringTick = 0;
@@ -723,6 +731,11 @@ int mv_close(mv_gym *g)
     if (g->statusCopied) (void)hipEventDestroy(g->statusCopied);
     for (hipEvent_t e : g->uploadEvents) if (e) (void)hipEventDestroy(e);
     g->uploadEvents.clear();
+    for (int i = 0; i < 2; ++i) {
+        if (g->passStream[i]) (void)hipStreamDestroy(g->passStream[i]);
+        if (g->callStart[i]) (void)hipEventDestroy(g->callStart[i]);
+        g->passStream[i] = nullptr; g->callStart[i] = nullptr;
+    }
     if (g->copyStream) (void)hipStreamDestroy(g->copyStream);
     if (g->simStream) (void)hipStreamDestroy(g->simStream);
     for (hipEvent_t &e : g->userMark) { if (e) (void)hipEventDestroy(e); e = nullptr; }
@@ -1086,6 +1099,21 @@ int mv_set_output_ring(mv_gym *g, int32_t count, void *obs, float *rewards, uint
     return 0;
 }
 
+int mv_set_pass_overlap(mv_gym *g, int32_t on)
+{
+    if (check(g)) return -1;
+    HIP_TRY(hipSetDevice(g->device));
+    if (on && !g->passStream[0]) {
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(hipStreamCreateWithFlags(&g->passStream[i], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&g->callStart[i], hipEventDisableTiming));
+        }
+    }
+    g->passOverlap = on ? 1 : 0;
+    g->overlapCalls = 0;
+    return 0;
+}
+
 int mv_sample_random_actions(mv_gym *g, uint32_t seed, uint32_t step)
 {   // the draw itself happens inside the next step kernel (mv_actions.h): no separate launch, no action buffer traffic
     if (check(g)) return -1;
@@ -1273,6 +1301,7 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
         g->mirrorsFresh = false;
     }
     // ---- the caller's stream: per tick the step's outputs, then the observation pass
+    if (L->passOverlap && L->callStart[0]) HIP_TRY(hipEventRecord(L->callStart[(int)(L->overlapCalls & 1ull)], L->stream));   // (before this call enqueues anything there)
     if (own) HIP_TRY(hipStreamWaitEvent(L->stream, L->simDone, 0));
     std::vector<PublishTo> pubs((size_t)n);
     std::vector<uint32_t *> obsPtrs((size_t)n);
@@ -1281,6 +1310,18 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
     // the previous tick's pass).  The ticks are collected below and launched at the end of their chunk.
     bool batchRaster = canBatchRaster;
     for (int j = 0; j < k; ++j) batchRaster = batchRaster && !evs[j];
+    // overlapped passes (mv_set_pass_overlap): this call's one launch goes to an internal stream
+    // (an env must not finish in two consecutive calls: their passes may publish its true objective in either order -- episodes of at least
+    // baseEpisodeLen seconds, 15 ticks each)
+    const bool overlap = batchRaster && own && !callEv && L->passOverlap && L->passStream[0] && L->ringCount >= 2 * k && k <= MAX_UNION && L->baseEpisodeLen * 15.0f > float(2 * k + 2);
+    hipStream_t passOn = L->stream;
+    if (overlap) {
+        const int me = (int)(L->overlapCalls & 1ull);
+        passOn = L->passStream[me];
+        HIP_TRY(hipStreamWaitEvent(passOn, L->simDone, 0));                                      // this call's ticks
+        if (L->overlapCalls >= 1) HIP_TRY(hipStreamWaitEvent(passOn, L->callStart[1 - me], 0));   // what the caller had enqueued when the previous call began
+        else { HIP_TRY(hipEventRecord(L->userNow, L->stream)); HIP_TRY(hipStreamWaitEvent(passOn, L->userNow, 0)); }   // (first overlapped call: everything so far)
+    }
     std::vector<PublishTo> chunkPubs;
     std::vector<uint32_t *> chunkObs;
     int chunkFirst = 0;
@@ -1302,7 +1343,8 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
             if (j == k - 1 || (int)chunkObs.size() >= chunkMax) {
                 const int cn = (int)chunkObs.size();
                 if (callEv) { HIP_TRY(hipEventRecord(callEv[2], L->stream)); HIP_TRY(hipEventRecord(callEv[3], L->stream)); }
-                int r = cn >= 2 ? launch_raster_batch(&views[(size_t)chunkFirst], chunkObs.data(), pubInRaster ? chunkPubs.data() : nullptr, cn, L->w, L->h, L->stream, mark) : 1;
+                int r = cn >= 2 ? launch_raster_batch(&views[(size_t)chunkFirst], chunkObs.data(), pubInRaster ? chunkPubs.data() : nullptr, cn, L->w, L->h, overlap && cn == k ? passOn : L->stream, mark) : 1;
+                if (r == 0 && overlap && cn == k) HIP_TRY(hipStreamWaitEvent(L->stream, mark, 0));   // the caller's stream sees the call's outputs as always
                 if (r < 0) return fail("mv_step: observation size above 1024x1024");
                 if (r == 0)   // (every pass of the one-launch kernel leaves its cost histogram zero)
                     for (int q = 0; q < cn; ++q) L->histClean[(size_t)views[(size_t)chunkFirst + q].lpt_parity] = 1;
@@ -1339,6 +1381,7 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
         ++L->markCount;
         for (int i = 0; i < n; ++i) gs[i]->markCount = L->markCount;
     }
+    L->overlapCalls = overlap ? L->overlapCalls + 1 : 0;
     HIP_TRY(hipGetLastError());
     int rc = 0;
     std::string text;

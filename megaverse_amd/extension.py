@@ -41,6 +41,7 @@ SYMBOLS = [
     ("mv_step", C.c_int, [_P]), ("mv_step_no_render", C.c_int, [_P]), ("mv_render", C.c_int, [_P]),
     ("mv_step_n", C.c_int, [_P, _I, _I, _U, _U]), ("mv_set_sample_policy", C.c_int, [_P, _I]),
     ("mv_set_output_ring", C.c_int, [_P, _I, _P, _P, _P]),
+    ("mv_set_pass_overlap", C.c_int, [_P, _I]),
     ("mv_is_done", C.c_int, [_P, _I]), ("mv_get_dones", C.c_int, [_P, _P]),
     ("mv_get_last_rewards", C.c_int, [_P, _P]),
     ("mv_true_objective", C.c_int, [_P, _I, _I, C.POINTER(_F)]), ("mv_get_true_objectives", C.c_int, [_P, _P]),
@@ -283,6 +284,11 @@ class MegaverseGym:
     def set_output_ring(self, count, obs_ptr=0, rewards_ptr=0, dones_ptr=0):
         """tick t leaves its outputs in entry t % count of the given device rings (0 = keep that output in its single array)"""
         self._ck(self._lib.mv_set_output_ring(self._g, int(count), _P(int(obs_ptr) or None), _P(int(rewards_ptr) or None), _P(int(dones_ptr) or None)))
+
+    def set_pass_overlap(self, on=True):
+        """with a ring at least two calls deep, the observation passes of consecutive step_n calls overlap (include/megaverse_hip.h: mv_set_pass_overlap);
+        an entry must then be consumed before the next stepping call after the one that produced it"""
+        self._ck(self._lib.mv_set_pass_overlap(self._g, int(bool(on))))
 
     def render(self):
         self._ck(self._lib.mv_render(self._g))

@@ -381,3 +381,47 @@ def test_one_launch_calls_fill_the_ring_like_single_ticks(hip, monkeypatch, scen
         assert a.debug_snapshot_bytes(e).tobytes() == b.debug_snapshot_bytes(e).tobytes(), e
     assert a.get_true_objectives().tobytes() == b.get_true_objectives().tobytes()
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("scenario,N,A,W,H,params", [("TowerBuilding", 300, 1, 128, 128, {}), ("TowerBuilding", 64, 4, 64, 64, {}), ("ObstaclesHard", 200, 1, 128, 128, {}),
+                                                     ("Rearrange", 100, 1, 64, 64, {}), ("Collect", 80, 1, 64, 64, {}), ("TowerBuilding", 50, 1, 64, 64, {"episodeLengthSec": -200.0})])
+def test_overlapped_passes_fill_the_ring_like_single_ticks(hip, monkeypatch, scenario, N, A, W, H, params):
+    """mv_set_pass_overlap: with a ring two calls deep the one-launch observation passes of consecutive batched calls run on two internal streams
+    (the passes of call c + 1 begin while those of call c drain) -- against single ticks: every slab of the ring, the rewards / dones rings, the
+    state, the true objectives; full calls and ragged ones, and episodes short enough that the library must decline to overlap (last case)."""
+    import os
+    import torch
+    monkeypatch.setenv("BOXOBAN_LEVELS", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "boxoban"))
+    R = 16
+    def make(overlap):
+        g = MegaverseGym(scenario, W, H, N, A, 2, False, params)
+        g.set_pixel_mode("fast"); g.seed(35); g.reset()
+        obs = torch.zeros((R, N * A, H, W, 4), dtype=torch.uint8, device="cuda:0")
+        rew = torch.zeros((R, N * A), dtype=torch.float32, device="cuda:0")
+        don = torch.zeros((R, N), dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
+        g.set_output_ring(R, obs.data_ptr(), rew.data_ptr(), don.data_ptr())
+        if overlap:
+            g.set_pass_overlap(True)
+        return g, obs, rew, don
+    a, oa, ra, da = make(True)
+    b, ob, rb, db = make(False)
+    chunks = [8, 8, 8, 8, 8, 3, 8, 8, 5, 8, 8, 8, 2, 8, 8, 8]
+    st = 0
+    seen = []
+    for k in chunks:
+        a.step_n(k, "multidiscrete", 5, st)
+        for j in range(k):
+            b.sample_random_actions(5, st + j); b.step()
+        st += k
+        # a consumer on the caller's stream right after the call, as the contract asks: the entries this call filled
+        seen.append(int(oa[(st - 1) % R, ::7, ::5, ::3].to(torch.int64).sum().item()) - int(ob[(st - 1) % R, ::7, ::5, ::3].to(torch.int64).sum().item()))
+    a.synchronize(); b.synchronize(); torch.cuda.synchronize()
+    assert oa.cpu().numpy()[..., :3].max() > 0
+    assert not any(seen), "an entry read right after its call differs"
+    assert torch.equal(oa, ob), "observation ring differs"
+    assert torch.equal(ra.view(torch.int32), rb.view(torch.int32)) and torch.equal(da, db)
+    for e in range(N):
+        assert a.debug_snapshot_bytes(e).tobytes() == b.debug_snapshot_bytes(e).tobytes(), e
+    assert a.get_true_objectives().tobytes() == b.get_true_objectives().tobytes()
+    a.close(); b.close()
