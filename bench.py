@@ -440,9 +440,10 @@ def main():
         if use_batch and not with_gather:
             i = 0
             # A region starts right after a synchronisation, with an empty pipeline: its first observation pass can only start when the first call's
-            # ticks are stepped, so the first calls are short -- 1 tick, then 3, then --batch (measured on 20-step runs, r05k: 20.0-20.25 M obs/s
-            # against 19.0-19.1 M with 2 ticks per call throughout and 19.2-19.7 M with 8).  MV_BENCH_CALL_SCHEDULE=a,b,...: other first calls.
-            sched = [int(x) for x in os.environ.get("MV_BENCH_CALL_SCHEDULE", "1,3").split(",") if x]
+            # ticks are stepped, so the first calls are short -- 2 ticks, then 4, then 6, then --batch (measured on 20-step runs, three each, r07c:
+            # 2,4,6: 20.8-21.0 M obs/s; 1,3: 20.3-21.6; 1,3,4,4: 20.9; 3,8: 20.3-20.9; 2,2,4,4: 20.1-20.2; r05k: 19.0-19.1 M with 2 ticks per call throughout
+            # and 19.2-19.7 M with 8).  MV_BENCH_CALL_SCHEDULE=a,b,...: other first calls.
+            sched = [int(x) for x in os.environ.get("MV_BENCH_CALL_SCHEDULE", "2,4,6").split(",") if x]
             while i < n:
                 k = min(sched.pop(0) if sched else batch, n - i, max(batch, 8))
                 gym.step_n(k, args.policy, 1234, first + i)
@@ -645,7 +646,7 @@ def main():
                        # leaves its observations in slab j of a ring of that many slabs
                        "pipelined": pipelined, "ticks_per_call": batch if main_batched else 1,
                        **({"ring_slots": ring_slots, "overlapped_passes": bool(pass_overlap)} if main_batched else {}),
-                       **({"first_calls": os.environ.get("MV_BENCH_CALL_SCHEDULE", "1,3") + " ticks, then ticks_per_call (every tick stepped and rendered in full)"} if main_batched else {}),
+                       **({"first_calls": os.environ.get("MV_BENCH_CALL_SCHEDULE", "2,4,6") + " ticks, then ticks_per_call (every tick stepped and rendered in full)"} if main_batched else {}),
                        **({"launches_per_tick": 2, "scenarios": "TowerBuilding, ObstaclesEasy, ObstaclesHard, Collect, Sokoban, HexMemory, HexExplore, Rearrange dealt round-robin "
                                                               "by env index (one gym per scenario, stepped as one mv_group: one step launch and one raster launch per tick)"} if mixed else {}),
                        "parallelism": f"env-shard x{world}"},
