@@ -709,7 +709,8 @@ def main():
                                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                 "avg_launch_ms": raster_ms, "launches_timed": prof["raster"][1], "algorithmic_bytes_per_launch": bytes_per_frame * frames,
                                 "note": "dominant kernel; achieved / peak / frac are the HBM figures (algorithmic bytes per tick / launch time per tick against 8 TB/s); "
-                                        "the kernel moves ~1.0x its algorithmic bytes and is bound by VALU issue, see `valu`; launch time from HIP events "
+                                        "the kernel is bound by VALU issue, see `valu` (its HBM traffic is the pixels: with the non-temporal pixel stores of round 4 the write counter reads "
+                                        "~1.3x the algorithmic bytes -- half-line writes no longer merge in L2 -- against 1.0x with plain stores, which were 2.5 % slower); launch time from HIP events "
                                         "(same stream, around the launch the product runs: a batched call's one launch / its ticks) in a separate untimed loop; "
                                         "traffic = HBM bytes per tick from rocprofv3 PMC passes of the same kernel sources (null otherwise)"}
             if valu and raster_ms > 0:   # wave64 VALU instructions issue over 2 cycles on a SIMD-32; 256 CUs x 4 SIMDs x 2.4 GHz
@@ -720,6 +721,9 @@ def main():
                                             # scripts/probe_valu.hip on this part (profiles/README.md): a SIMD with 8 waves of back-to-back v_fma / v_mul
                                             # retires one per 1.11 ns (the clock under an all-VALU load is below 2.4 GHz); min / max / cndmask / max3 cost more
                                             "probed_ns_per_fma_per_simd": 1.11, "frac_of_probed_fma_rate": insts * 1.11e-9 / 1024.0 / (raster_ms * 1e-3),
+                                            # counters: quad-cycles the vector ALUs were busy, over the chip's 1024 SIMDs x the launch's clocks at 2.4 GHz
+                                            # (rocprofv3's derived VALUBusy of the same passes: 91 % for this kernel alone on the chip, profiles/r06s_*)
+                                            "valu_busy_frac_at_2.4GHz": (valu["active_inst_valu_quadcycles"] * 4.0 / 1024.0 / (raster_ms * 1e-3 * 2.4e9)) if valu.get("active_inst_valu_quadcycles") else None,
                                             "source": valu.get("source")}
             line["roofline_physics"] = {"bound": "latency", "kernel": ("mv::step_union_kernel" if mixed else "mv::%s (the %d ticks of a call in one launch; per tick)" % (ticks_kernel_name, batch) if batch_step else "mv::step_kernel") +
                                                               " (voxel physics + scenario logic + auto-reset + frame setup)", "ticks_per_launch": batch if batch_step else 1, "achieved": achieved_step,

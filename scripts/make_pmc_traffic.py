@@ -57,7 +57,10 @@ def main():
             e["valu"] = {"valu_insts_per_launch": per(s1, "SQ_INSTS_VALU"), "salu_insts_per_launch": per(s2, "SQ_INSTS_SALU"),
                          "lds_insts_per_launch": per(s1, "SQ_INSTS_LDS"), "wave_cycles": per(s1, "SQ_WAVE_CYCLES"),
                          "wait_inst_any": per(s1, "SQ_WAIT_INST_ANY"), "wait_any": per(s2, "SQ_WAIT_ANY"),
-                         "active_inst_any": per(s2, "SQ_ACTIVE_INST_ANY"), "source": f"profiles/{tag}_pmc_SQ.csv, {tag}_pmc_SQ2.csv"}
+                         "active_inst_any": per(s2, "SQ_ACTIVE_INST_ANY"),
+                         # quad-cycles (4 clocks) the SIMDs' vector ALUs were busy, summed over the chip's 1024 SIMDs: rocprofv3's derived VALUBusy is
+                         # 100 x this x 4 / 1024 / the launch's clocks
+                         "active_inst_valu_quadcycles": per(s1, "SQ_ACTIVE_INST_VALU"), "source": f"profiles/{tag}_pmc_SQ.csv, {tag}_pmc_SQ2.csv"}
         out["kernels"][key] = e   # ("per launch" in the field names: per TICK, the launch of the per-tick kernels)
     json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
