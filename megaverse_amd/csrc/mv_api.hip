@@ -326,6 +326,7 @@ static GymView view(const mv_gym *g, int q, const OutPtrs *direct = nullptr)   /
     v.sample_on = g->gv.sample_on; v.sample_seed = g->gv.sample_seed; v.sample_step = g->gv.sample_step;
     v.md_actions = nullptr;
     v.lpt_parity = g->hist3;
+    v.depth_sort = v.sort_scratch != nullptr && g->fastPixels != 0;   // (the exact kernel resolves depth ties by list position: its lists stay as found)
     return v;
 }
 
@@ -489,7 +490,10 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     // per slot: frame lists, headers, cost lists, and the staging copies of rewards / dones / true objectives
     const size_t szParity = szVisP + szVisR + szVisC + szLpt + szRew + szDone + szObjv, szHist = up((size_t)g->hists * (LPT_BUCKETS * LPT_SUBS + 1) * sizeof(int32_t));   // (+ one "workgroups that have looked their frame up" counter per histogram, behind them)
     gv.lpt_hists = g->hists;
-    const size_t total = szHdr + szBoxes + szObj + szAg + szAct + szRew + szDone + szObjv + szMd + (hostEpisodes ? 0 : szChunk) + szObs + szTerrain +
+    // long lists: the list as found, before the frame setup deals it into depth classes (mv_frame.h: DepthSortScratch); MV_DEPTH_SORT=0: lists stay as found
+    const bool depthSortOn = !(getenv("MV_DEPTH_SORT") && atoi(getenv("MV_DEPTH_SORT")) == 0);
+    const size_t szSort = gv.vis_stride > 256 && depthSortOn ? up(NA * (size_t)gv.vis_stride * 40) : 0;
+    const size_t total = szSort + szHdr + szBoxes + szObj + szAg + szAct + szRew + szDone + szObjv + szMd + (hostEpisodes ? 0 : szChunk) + szObs + szTerrain +
                          szRewObj + szHeight + szItems + szCells + szHexB + szHexO + szBlobs + szCnt + (size_t)g->slots * szParity + szHist;
     {
         hipError_t e_ = hipMalloc((void **)&g->arena, total);
@@ -522,6 +526,8 @@ int mv_create(const mv_config *cfg, mv_gym **out)
         if (sokoban) { gv.soko_cells = p; p += szCells; }
         if (hex) { gv.hex_boxes = (HexRec *)p; p += szHexB; gv.hex_objs = (HexRec *)p; p += szHexO; }
         gv.lpt_hist = (int32_t *)p; p += szHist;
+        gv.sort_scratch = szSort ? p : nullptr; p += szSort;
+        gv.depth_sort = 0;
         for (int q = 0; q < g->slots; ++q) {   // gv.rewards / done / true_objective stay the public arrays; the slot views write their own
             GymView &v = g->gvp[q];
             v = gv;

@@ -83,7 +83,7 @@ __device__ __forceinline__ V3 mat_tmul(const float *m, V3 v)
 // beyond that), and it carries a pixel of slack: its up to twenty reciprocals are the hardware's 1-ulp v_rcp_f32, not correctly rounded
 // divides (each a chain of ~12 dependent instructions on the step kernel's critical path).
 __device__ __forceinline__ int screen_rect(const float *blo, const float *bhi, int fr, const CamL *cams, int viewer, int W, int H,
-                                           int rect[4])
+                                           int rect[4], float *min_depth = nullptr)   // min_depth: the smallest camera depth of the box's corners
 {
     const CamL &cv = cams[viewer];
     float cx[8], cy[8], cw[8];
@@ -112,6 +112,7 @@ __device__ __forceinline__ int screen_rect(const float *blo, const float *bhi, i
         }
     }
     if (wmax < CLIP_W) return 0;
+    if (min_depth) *min_depth = wmin;
     float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
 #pragma unroll
     for (int c = 0; c < 8; ++c)
@@ -181,8 +182,30 @@ struct FrameScratch {
 #else
 #define MV_TF(k) do { } while (0)
 #endif
+// Long lists in depth classes.  A Hex frame holds ~700 visible primitives -- every wall of the maze inside the view frustum -- and all but the
+// few nearest are hidden behind those: the observation pass culled and intersected its way through the whole list for every tile (11 rounds of 64
+// positions, ~19 boxes surviving a tile's culling) to find out.  A ray's parameter t IS the camera depth of the hit (dc = (x, y, -1)), so the
+// smallest camera depth of a primitive's bounding-box corners bounds every t it can produce from below.  The frame setup files each visible
+// primitive under a depth class (64 classes, four per octave from 2^-7 up), first into a scratch copy of the list in the order found, then --
+// one counting pass -- into the list proper class by class, nearest first, and leaves in the header the lower bound of the class each round of 64
+// positions begins with (FH_WB + r: the long-list kernels do not use the world-box masks kept there for the short ones; FH_WB + 31: a marker that
+// the list is in this order).  The pass stops walking the list where every pixel of the tile already holds a hit nearer than the next round's
+// bound.  The pixels do not change: the winner is the minimum over (depth, slot), whatever the order (raster_glist_body).  Fast pixel mode only --
+// the exact kernel resolves depth ties by list position, which must stay the drawables' order.
+struct DepthSortScratch {
+    unsigned char bin[VIS_XL];   // depth class of every position of the list as found
+    int count[64];               // primitives per class, then the classes' write cursors
+    int first[64];               // first position of every class in the list proper
+};
+constexpr unsigned DEPTH_SORTED_MARK = 0x44505354u;
+__device__ __forceinline__ int depth_class(float d)   // d >= NEAR_Z: 0 .. 63, four classes per octave from 2^-7 (everything from 2^9 up: 63)
+{
+    return min(63, max(0, (int)(__float_as_uint(d) >> 21) - (120 << 2)));
+}
+__device__ __forceinline__ float depth_class_floor(int c) { return __uint_as_float((unsigned)(c + (120 << 2)) << 21); }
+
 template <int THREADS, bool WAVE_LOCAL>
-__device__ __forceinline__ void frame_setup_body(const GymView &gv, const int frame, const int W, const int H, FrameScratch &fs)
+__device__ __forceinline__ void frame_setup_body(const GymView &gv, const int frame, const int W, const int H, FrameScratch &fs, DepthSortScratch *ds = nullptr)
 {
     static_assert(!WAVE_LOCAL || THREADS == 64, "a wave-local frame setup is one wavefront");
     auto sync = [] { if (WAVE_LOCAL) wave_sync(); else __syncthreads(); };
@@ -205,6 +228,15 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
     int myCost = 0;
     Prim *vis = reinterpret_cast<Prim *>(gv.vis_prims) + (size_t)frame * maxVis;
     short4 *rects = reinterpret_cast<short4 *>(gv.vis_rects) + (size_t)frame * maxVis;
+    const bool sorted = ds != nullptr && gv.depth_sort != 0 && gv.sort_scratch != nullptr;   // (uniform over the launch)
+    Prim *visFound = vis;       // where the list goes as it is found: the list proper, or its scratch copy
+    short4 *rectsFound = rects;
+    if (sorted) {
+        uint8_t *sc = gv.sort_scratch + (size_t)frame * maxVis * (sizeof(Prim) + sizeof(short4));
+        visFound = reinterpret_cast<Prim *>(sc);
+        rectsFound = reinterpret_cast<short4 *>(sc + (size_t)maxVis * sizeof(Prim));
+        for (int i = tid; i < 64; i += THREADS) ds->count[i] = 0;
+    }
 
     // ---- cameras
     if (tid < A) {
@@ -414,6 +446,7 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
         // frame-level visibility
         int cls = 0;
         int rect[4] = {0, 0, 0, 0};
+        float minDepth = NEAR_Z;
         if (kind != PRIM_NONE) {
             float blo[3] = {lo[0], lo[1], lo[2]}, bhi[3] = {hi[0], hi[1], hi[2]};
             if (kind == PRIM_CAPSULE) {
@@ -430,7 +463,7 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
                 blo[1] = hi[2] > 0.0f ? lo[1] - h : lo[1];
                 bhi[1] = hi[2] > 0.0f ? lo[1] : lo[1] + h;
             }
-            cls = screen_rect(blo, bhi, fr, s_cam, viewer, W, H, rect);
+            cls = screen_rect(blo, bhi, fr, s_cam, viewer, W, H, rect, &minDepth);
         }
         MV_TF(2);   // screen rectangles
         const unsigned long long mV = __ballot(cls != 0);
@@ -462,8 +495,13 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
                 p.lo[0] = lo[0]; p.lo[1] = lo[1]; p.lo[2] = lo[2];
                 p.hi[0] = hi[0]; p.hi[1] = hi[1]; p.hi[2] = hi[2];
             }
-            vis[pos] = p;
-            rects[pos] = make_short4((short)rect[0], (short)rect[1], (short)rect[2], (short)rect[3]);
+            visFound[pos] = p;
+            rectsFound[pos] = make_short4((short)rect[0], (short)rect[1], (short)rect[2], (short)rect[3]);
+            if (sorted) {
+                const int dc = depth_class(fmaxf(minDepth, NEAR_Z));
+                ds->bin[pos] = (unsigned char)dc;
+                atomicAdd(&ds->count[dc], 1);
+            }
             if (kind == PRIM_BOX && fr == 0 && pos < 1024) atomicOr(&s_wbits[pos >> 5], 1u << (pos & 31));   // (the header's masks: the short-list raster)
             myCost += ((rect[1] / TILE_W) - (rect[0] / TILE_W) + 1) * ((rect[3] / TILE_H) - (rect[2] / TILE_H) + 1);
         }
@@ -471,6 +509,37 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
     MV_TF(4);   // records and rectangles written
     if (myCost) atomicAdd(&s_cost, myCost);
     sync();
+    float *const fhs = reinterpret_cast<float *>(gv.vis_hdr + (size_t)frame * FRAME_HDR_BYTES);
+    if (sorted) {   // the list as found -> the list proper, class by class
+        const int n = min(nVis, maxVis);
+        if (tid < 64) {   // (one wave: the classes' first positions = exclusive prefix sum of their counts)
+            const int h = ds->count[tid];
+            int x = h;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int y = __shfl_up(x, off, 64);
+                if (lane >= off) x += y;
+            }
+            ds->first[tid] = x - h;
+            ds->count[tid] = x - h;   // the class's write cursor
+        }
+        sync();
+        for (int i = tid; i < n; i += THREADS) {
+            const int place = atomicAdd(&ds->count[ds->bin[i]], 1);
+            vis[place] = visFound[i];
+            rects[place] = rectsFound[i];
+        }
+        // What the pass needs to know before it walks round r (positions 64 r ..): the class that round begins with -- nothing from there on is
+        // nearer than its floor.  (Also built and measured, r07e: the rectangle that holds everything from round r on, so that a tile it does not
+        // meet could stop as well -- no gain on top of the depth bound, and 10 us more frame setup per tick.)
+        if (tid < 32) {
+            const int p0 = 64 * tid;
+            int c = 0;
+            for (int q = 1; q < 64; ++q)
+                if (ds->first[q] <= p0) c = q;   // (first[] is non-decreasing; an empty class shares its first position with the next one)
+            fhs[FH_WB + tid] = __uint_as_float(tid == 31 ? DEPTH_SORTED_MARK : (p0 < n ? (unsigned)c : 0u));
+        }
+    }
     // The frame appends itself to its cost bin with a RETURNING atomic (its place in the bin's list), a round trip to L2 that nothing else in this
     // kernel waits for: issued first, the header's stores go out while it is in flight, the dependent store comes last.
     int binPlace = 0, bin = 0;
@@ -506,7 +575,7 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
             float *o = fh + FH_LREL + 4 * f;
             o[0] = l.x; o[1] = l.y; o[2] = l.z; o[3] = 0.0f;
         }
-        if (tid < 32) fh[FH_WB + tid] = __uint_as_float(s_wbits[tid]);
+        if (tid < 32 && !sorted) fh[FH_WB + tid] = __uint_as_float(tid == 31 ? 0u : s_wbits[tid]);   // (sorted: the rounds' depth bounds, above; word 31 -- positions 992 .. 1023, which no short list has -- is the marker's place)
     }
     if (tid == 0) gv.lpt_list[(size_t)(bin * LPT_SUBS + (frame & (LPT_SUBS - 1))) * lpt_sub_capacity(gv.num_envs * gv.num_agents) + binPlace] = frame;
     if (frame == 0 && !gv.lpt_no_clear)   // the histogram the NEXT pass fills: last read by a raster pass as many passes ago as there are slots, which this step waited for

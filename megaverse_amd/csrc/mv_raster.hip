@@ -248,7 +248,8 @@ __device__ __forceinline__ V3 safe_inv(V3 d)
 __global__ __launch_bounds__(256) void frame_setup_kernel(GymView gv, int W, int H)
 {
     __shared__ FrameScratch s_fs;
-    frame_setup_body<256, false>(gv, blockIdx.x, W, H, s_fs);
+    __shared__ DepthSortScratch s_ds;
+    frame_setup_body<256, false>(gv, blockIdx.x, W, H, s_fs, &s_ds);
 }
 
 // ---- pass 1b, one workgroup: counting sort of the frames by cost bin, most expensive first.  (A "last workgroup of
@@ -1331,6 +1332,11 @@ __device__ __forceinline__ void key2_min(Key2 &best, bool valid, unsigned d, uns
     best.p = less ? p : best.p;
 }
 
+// What breaks a depth tie is the drawable's SLOT (the reference's draw order), not its position in the list: the two orders are the same in a list kept
+// as found, but a long list may be in depth classes (mv_frame.h: DepthSortScratch).  The low 11 bits carry the position (< VIS_XL = 2048), for the shading.
+static_assert(VIS_XL <= 2048, "tie_key: 11 bits of list position");
+__device__ __forceinline__ unsigned tie_key(const float4 lo, int pos) { return ((__float_as_uint(lo.w) >> 8) << 11) | (unsigned)pos; }
+
 template <int NP>
 __device__ __forceinline__ void box_test_g(const V3 (&inv)[NP], const float4 lo, const float4 hi, int pos, Key2 (&best)[NP])
 {
@@ -1339,7 +1345,7 @@ __device__ __forceinline__ void box_test_g(const V3 (&inv)[NP], const float4 lo,
         const float t1x = lo.x * inv[j].x, t2x = hi.x * inv[j].x, t1y = lo.y * inv[j].y, t2y = hi.y * inv[j].y, t1z = lo.z * inv[j].z, t2z = hi.z * inv[j].z;
         const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)), __builtin_fminf(t1z, t2z));
         const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)), __builtin_fmaxf(t1z, t2z));
-        key2_min(best[j], tn <= tf, __float_as_uint(tn) - KEY_NEAR, (unsigned)pos);
+        key2_min(best[j], tn <= tf, __float_as_uint(tn) - KEY_NEAR, tie_key(lo, pos));
     }
 }
 
@@ -1397,6 +1403,7 @@ __device__ __forceinline__ void raster_glist_body(const FastArgs &fa, uint32_t *
     __shared__ int s_next;
     if (tid == 0) s_next = 4;
     __syncthreads();
+    const bool depthSorted = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_uint(s_hdr[FH_WB + 31])) == DEPTH_SORTED_MARK;   // (the frame setup says so in the header)
     const unsigned tilesXinv = (unsigned)((0x100000000ull + (unsigned)tilesX - 1u) / (unsigned)tilesX);
     int unext = 0;
     for (int u = wave; ; u = __builtin_amdgcn_readfirstlane(unext)) {
@@ -1420,6 +1427,19 @@ __device__ __forceinline__ void raster_glist_body(const FastArgs &fa, uint32_t *
         bool rayReady = false;
 #pragma unroll 1
         for (int k = 0; k * 64 < nVis; ++k) {
+            // A list in depth classes (DepthSortScratch): nothing from position 64 k on can be hit nearer than the round's bound -- when every pixel of
+            // the tile already holds a nearer hit, the rest of the list is hidden behind what has been found.
+            // The header's word for the round: the depth class it begins with.  A tile whose every pixel holds a hit nearer than the class's floor is
+            // done with the list: everything from here on is hidden behind what has been found.
+            if (depthSorted && k >= 1 && k < 31) {
+                const unsigned wd = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_uint(s_hdr[FH_WB + k]));
+                const float floorD = __uint_as_float(((wd & 63u) + (120u << 2)) << 21) * (1.0f - 1e-4f);   // (depth_class_floor, with a margin far above the rounding of the corners' depths)
+                const unsigned bound = floorD > NEAR_Z ? __float_as_uint(floorD) - KEY_NEAR : 0u;          // in the units of the depth keys; 0: never stop here
+                bool covered = true;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) covered = covered && (best[j].d < bound || px >= W || py0 + TILE_H * j >= H);
+                if (__all(covered)) break;
+            }
             const int cpos = min(lane + 64 * k, nVis - 1);
             const uint2 rr = *reinterpret_cast<const uint2 *>(&s_rect[cpos]);
             const bool v = (lane + 64 * k < nVis) & ((int)(rr.x & 0xffffu) <= tx1) & ((int)(rr.x >> 16) >= tx0) & ((int)(rr.y & 0xffffu) <= ty1) &
@@ -1470,8 +1490,9 @@ __device__ __forceinline__ void raster_glist_body(const FastArgs &fa, uint32_t *
                     float t;
                     const bool hit = other_rec<SHAPES>(lo, hi, s_hdr, camv, viewer, dw[j], dcx, dcy[j], t, n);
                     const unsigned d = __float_as_uint(t) - KEY_NEAR;
-                    const bool less = hit && (d < best[j].d || (d == best[j].d && (unsigned)pos < best[j].p));
-                    if (less) { best[j].d = d; best[j].p = (unsigned)pos; bn[j] = n; }
+                    const unsigned tk = tie_key(lo, pos);
+                    const bool less = hit && (d < best[j].d || (d == best[j].d && tk < best[j].p));
+                    if (less) { best[j].d = d; best[j].p = tk; bn[j] = n; }
                 }
             }
         }
@@ -1479,7 +1500,8 @@ __device__ __forceinline__ void raster_glist_body(const FastArgs &fa, uint32_t *
         for (int j = 0; j < NP; ++j) {
             unsigned rgba = 0xff000000u;
             if (best[j].d <= KEY_FAR) {   // a hit between the near and the far plane: the winner's record, one 32-byte read per lane
-                const float4 lo = gp[2 * best[j].p], hi = gp[2 * best[j].p + 1];
+                const unsigned wpos = best[j].p & 2047u;   // (tie_key: the position in its low bits)
+                const float4 lo = gp[2 * wpos], hi = gp[2 * wpos + 1];
                 rgba = shade_rec<SHAPES>(lo, hi, __uint_as_float(best[j].d + KEY_NEAR), bn[j], s_hdr, camv, viewer, dw[j], inv[j], dcx, dcy[j], a2[j], ldc[j]);
             }
             const int py = py0 + TILE_H * j;

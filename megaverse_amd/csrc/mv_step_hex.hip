@@ -29,14 +29,15 @@ template <int A_MAX>
 __global__ __launch_bounds__(256) void step_hex_kernel(GymView gv, int W, int H, int render)
 {
     __shared__ FrameScratch s_fs[A_MAX == 1 ? 1 : 4];
+    __shared__ DepthSortScratch s_ds[A_MAX == 1 ? 1 : 4];   // (long lists: mv_frame.h)
     const int env = blockIdx.x;
     if (threadIdx.x < 64) hex_tick<A_MAX>(gv, env);
     if (!render) return;
     __syncthreads();
-    if (A_MAX == 1) frame_setup_body<STEP_THREADS, false>(gv, env, W, H, s_fs[0]);
+    if (A_MAX == 1) frame_setup_body<STEP_THREADS, false>(gv, env, W, H, s_fs[0], &s_ds[0]);
     else {
         const int A = gv.num_agents, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
-        for (int a = wave; a < A; a += nw) frame_setup_body<64, true>(gv, env * A + a, W, H, s_fs[wave]);
+        for (int a = wave; a < A; a += nw) frame_setup_body<64, true>(gv, env * A + a, W, H, s_fs[wave], &s_ds[wave]);
     }
 }
 
@@ -57,12 +58,13 @@ __global__ __launch_bounds__(64) void reset_hex_kernel(GymView gv, const HexBlob
 __global__ __launch_bounds__(64, MV_STEP_TICKS_WAVES_PER_SIMD) void step_hex_ticks_kernel(StepTicksArgs a, int W, int H)
 {
     __shared__ FrameScratch s_fs;
+    __shared__ DepthSortScratch s_ds;
     const int env = blockIdx.x;
     for (int j = 0; j < a.n; ++j) {
         const GymView &gv = a.gv[j];
         hex_tick<1>(gv, env);
         wave_sync();   // the tick's stores before the frame setup's loads (one wave: no barrier needed)
-        frame_setup_body<64, true>(gv, env, W, H, s_fs);
+        frame_setup_body<64, true>(gv, env, W, H, s_fs, &s_ds);
     }
 }
 

@@ -26,6 +26,7 @@ template <int A_MAX>
 __global__ __launch_bounds__(256) void step_union_kernel(UnionStepArgs ua, int W, int H, int render)
 {
     __shared__ FrameScratch s_fs[A_MAX == 1 ? 1 : 4];
+    __shared__ DepthSortScratch s_ds[A_MAX == 1 ? 1 : 4];   // (long lists: mv_frame.h)
     int s = 0;
 #pragma unroll
     for (int i = 1; i < MAX_UNION; ++i)
@@ -45,10 +46,10 @@ __global__ __launch_bounds__(256) void step_union_kernel(UnionStepArgs ua, int W
     }
     if (!render) return;
     __syncthreads();   // the tick's stores (same CU: same L1) before the frame setup's loads
-    if (A_MAX == 1) frame_setup_body<STEP_THREADS, false>(gv, env, W, H, s_fs[0]);
+    if (A_MAX == 1) frame_setup_body<STEP_THREADS, false>(gv, env, W, H, s_fs[0], &s_ds[0]);
     else {
         const int A = gv.num_agents, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
-        for (int a = wave; a < A; a += nw) frame_setup_body<64, true>(gv, env * A + a, W, H, s_fs[wave]);
+        for (int a = wave; a < A; a += nw) frame_setup_body<64, true>(gv, env * A + a, W, H, s_fs[wave], &s_ds[wave]);
     }
 }
 

@@ -168,6 +168,10 @@ struct GymView {
     uint8_t *vis_hdr;          // [N*A][FRAME_HDR_BYTES] per-frame header for raster_fast_kernel (cameras, light vectors, masks, count)
     unsigned long long *dbg;   // null, or (builds with -DMV_TICK_TIMING, MV_TICK_TIMING=1) [N][64] counters of the TowerBuilding tick
     int32_t debug_redo;        // tests (MV_DEBUG_FORCE_REDO=1): the multi-agent tick takes its "check failed" path every time
+    // long lists (Collect, Hex), fast pixels: the frame setup leaves the list in depth classes, nearest first (mv_frame.h: DepthSortScratch), so that the
+    // observation pass can stop walking it where everything nearer has covered a tile (mv_raster.hip: raster_glist_body)
+    uint8_t *sort_scratch;     // [N*A][vis_stride] x (32 + 8) bytes: the list as found, before it is dealt into its depth classes (null: short lists)
+    int32_t depth_sort;        // 1: deal the list into depth classes (set per launch: fast pixel mode only -- the exact kernel resolves depth ties by list position)
     int32_t lpt_no_clear;      // 1: the frame setup does not clear the cost histogram of the next pass (a multi-tick step launch: cleared up front, mv_step.hip)
 };
 

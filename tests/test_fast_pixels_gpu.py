@@ -168,6 +168,47 @@ def test_planar_tiles_change_no_byte(hip, monkeypatch, scenario, N, A, W, H, ppl
     g.close()
 
 
+@pytest.mark.parametrize("scenario,N,A,W,H", [("HexMemory", 96, 1, 128, 128), ("HexExplore", 64, 2, 128, 128), ("HexMemory", 128, 1, 64, 64), ("Collect", 128, 1, 128, 128),
+                                              ("Collect", 64, 2, 50, 30), ("HexExplore", 40, 1, 33, 17)])
+def test_depth_classes_change_no_byte(hip, monkeypatch, scenario, N, A, W, H):
+    """long lists (Collect, Hex): the frame setup deals the visible primitives into depth classes, nearest first, and the observation pass stops walking
+    the list where everything nearer has covered a tile (mv_frame.h: DepthSortScratch; raster_glist_body) -- against a gym whose lists stay as found
+    (MV_DEPTH_SORT=0, read at creation): the winner of a pixel is the minimum over (depth, slot) in either order, so every byte of every slab must be
+    equal, along a rollout (pipelined steps and the one-launch batched calls), and after renders in both pixel modes (the exact kernel's lists stay as found)."""
+    import torch
+    def make(sort):
+        monkeypatch.setenv("MV_DEPTH_SORT", sort)
+        g = MegaverseGym(scenario, W, H, N, A, 2, False, {})
+        obs = torch.zeros((8, N * A, H, W, 4), dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
+        g.set_output_ring(8, obs.data_ptr())
+        g.set_pixel_mode("fast"); g.seed(29); g.reset()
+        return g, obs
+    a, oa = make("1")
+    b, ob = make("0")
+    st = 0
+    for rnd in range(3):
+        for g in (a, b):
+            for j in range(5):
+                g.sample_random_actions(41, st + j); g.step()
+            g.step_n(8, "multidiscrete", 41, st + 5)
+        st += 13
+        a.synchronize(); b.synchronize(); torch.cuda.synchronize()
+        assert oa.cpu().numpy()[..., :3].max() > 0
+        bad = (oa != ob).any(dim=-1)
+        assert not bool(bad.any()), f"{scenario} round {rnd}: {int(bad.sum())} pixels differ between the list in depth classes and the list as found, first at {torch.nonzero(bad)[:4].tolist()}"
+    # renders in both modes on the stepped state (exact: lists as found in both gyms; fast again afterwards)
+    slab_a = torch.zeros((N * A, H, W, 4), dtype=torch.uint8, device="cuda:0"); slab_b = torch.zeros_like(slab_a)
+    a.set_output_ring(0); b.set_output_ring(0)
+    a.set_obs_buffer(slab_a.data_ptr()); b.set_obs_buffer(slab_b.data_ptr())
+    for mode in ("exact", "fast"):
+        for g in (a, b):
+            g.set_pixel_mode(mode); g.render(); g.synchronize()
+        torch.cuda.synchronize()
+        assert torch.equal(slab_a, slab_b), f"{scenario}: {mode} renders differ"
+    a.close(); b.close()
+
+
 def test_fast_mode_is_deterministic(hip):
     N, A = 16, 2
     def run():
