@@ -1425,11 +1425,14 @@ __device__ __forceinline__ void raster_glist_body(const FastArgs &fa, uint32_t *
             best[j].d = ~0u; best[j].p = 0u;
         }
         bool rayReady = false;
+#ifdef MV_RASTER_TIMING
+        int metTotal = 0, metWorld = 0;
+#endif
+        RT_COUNT(10, 1);                  // tiles of the long-list pass
+        RT_COUNT(12, (nVis + 63) / 64);   // rounds their lists have
 #pragma unroll 1
         for (int k = 0; k * 64 < nVis; ++k) {
-            // A list in depth classes (DepthSortScratch): nothing from position 64 k on can be hit nearer than the round's bound -- when every pixel of
-            // the tile already holds a nearer hit, the rest of the list is hidden behind what has been found.
-            // The header's word for the round: the depth class it begins with.  A tile whose every pixel holds a hit nearer than the class's floor is
+            // A list in depth classes (DepthSortScratch).  The header's word for the round: the depth class it begins with.  A tile whose every pixel holds a hit nearer than the class's floor is
             // done with the list: everything from here on is hidden behind what has been found.
             if (depthSorted && k >= 1 && k < 31) {
                 const unsigned wd = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_uint(s_hdr[FH_WB + k]));
@@ -1438,13 +1441,18 @@ __device__ __forceinline__ void raster_glist_body(const FastArgs &fa, uint32_t *
                 bool covered = true;
 #pragma unroll
                 for (int j = 0; j < NP; ++j) covered = covered && (best[j].d < bound || px >= W || py0 + TILE_H * j >= H);
-                if (__all(covered)) break;
+                if (__all(covered)) { RT_COUNT(15, 1); break; }
             }
+            RT_COUNT(11, 1);   // rounds of the list walked
             const int cpos = min(lane + 64 * k, nVis - 1);
             const uint2 rr = *reinterpret_cast<const uint2 *>(&s_rect[cpos]);
             const bool v = (lane + 64 * k < nVis) & ((int)(rr.x & 0xffffu) <= tx1) & ((int)(rr.x >> 16) >= tx0) & ((int)(rr.y & 0xffffu) <= ty1) &
                            ((int)(rr.y >> 16) >= ty0);
             const unsigned long long mvis = __ballot(v);
+            RT_COUNT(13, __popcll(mvis));   // primitives whose rectangle meets the tile
+#ifdef MV_RASTER_TIMING
+            metTotal += __popcll(mvis); metWorld += __popcll(__ballot(v && s_cls[cpos] == 0u));
+#endif
             if (mvis == 0ull) continue;
             if (!rayReady) {
                 rayReady = true;
@@ -1496,6 +1504,13 @@ __device__ __forceinline__ void raster_glist_body(const FastArgs &fa, uint32_t *
                 }
             }
         }
+#ifdef MV_RASTER_TIMING
+        RT_COUNT(14, metTotal == 0);                       // tiles that met nothing
+        RT_COUNT(9, metTotal == 1 && metWorld == 1);       // ... one world-frame box and nothing else
+        RT_COUNT(8, metTotal == 2);
+        RT_COUNT(7, metTotal >= 3 && metTotal <= 5);
+        RT_COUNT(6, metTotal >= 6);
+#endif
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             unsigned rgba = 0xff000000u;
@@ -1626,7 +1641,13 @@ static void rdbg_dump()
     (void)hipDeviceSynchronize();
     {   // the census of the tile loop over all launches (RT_COUNT)
         unsigned long long c[16];
-        if (hipMemcpy(c, g_rdbg + (size_t)16384 * 4 * 8, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess && c[4])
+        const bool got = hipMemcpy(c, g_rdbg + (size_t)16384 * 4 * 8, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess;
+        if (got && c[10])
+            fprintf(stderr, "long-list census (all launches): tiles %llu, rounds of 64 list positions walked %.2f of %.2f per tile, early stops (every pixel nearer than the next class) in %.3f of the tiles, "
+                            "%.1f primitives met per tile; tiles that met nothing %.3f, one world-frame box only %.3f, two primitives %.3f, 3-5: %.3f, 6 and more: %.3f\n",
+                    c[10], double(c[11]) / c[10], double(c[12]) / c[10], double(c[15]) / c[10], double(c[13]) / c[10], double(c[14]) / c[10], double(c[9]) / c[10], double(c[8]) / c[10],
+                    double(c[7]) / c[10], double(c[6]) / c[10]);
+        if (got && c[4])
             fprintf(stderr, "raster census (all launches): classified tiles %llu (empty %llu, planar %llu), unclassified %llu, general-path tiles %llu: slab tests %.2f and other primitives %.2f per tile, "
                             "shading wave-rows %.2f of 2, hit pixels %.1f of 128, wave-rows shading a non-box %.3f\n",
                     c[0], c[1], c[2], c[3], c[4], double(c[5]) / c[4], double(c[6]) / c[4], double(c[7]) / c[4], double(c[8]) / c[4], double(c[9]) / c[4]);
