@@ -1760,11 +1760,14 @@ static void self_clear(FastArgs &fa, const GymView &gv, int workgroups)
 // overrides (read at every launch: the variants are compared within one process by tests/test_fast_pixels_gpu.py).
 // The long-list variants (Collect, Hex*) always take one: their two-pixel builds need 78-95 VGPRs, and with the records coming through the
 // scalar cache occupancy is worth more (Collect 128 x 128: 97.6 us with one, 146 with two; HexMemory 155 / 171).
-static int fast_pixels_per_lane(int W, int H, bool longList = false)
+// (In the one-launch passes of a batched call -- `batch` -- the long lists take two as well: eight passes' worth of workgroups keep the chip full at the lower
+// occupancy, and half as many tiles pay the per-tile work.  r07g/h, one / two pixels per lane: HexMemory 8.0 / 9.2 M obs/s, HexExplore 8.5 / 10.1, Collect 12.2 / 14.1,
+// Collect 128 x 72 15.3 / 16.8; one pass per launch: HexMemory 6.9 / 6.95, Collect 11.2 / 9.3.)
+static int fast_pixels_per_lane(int W, int H, bool longList = false, bool batch = false)
 {
     const char *e = getenv("MV_FAST_PPL");
     if (e && *e) return atoi(e) >= 2 ? 2 : 1;
-    return !longList && MV_FAST_PPL_DEFAULT >= 2 && W * H >= 8192 ? 2 : 1;
+    return (!longList || batch) && MV_FAST_PPL_DEFAULT >= 2 && W * H >= 8192 ? 2 : 1;
 }
 
 // Workgroups per frame of the fast kernels.  One pixel per lane: 4 (r02 sweeps: 4 and 8 best at 1024 frames).  Two pixels per lane (half as many
@@ -1895,7 +1898,7 @@ int launch_raster_batch(const GymView *views, uint32_t *const *obs, const Publis
     const int frames = gv.num_envs * gv.num_agents;
     const bool hexScen = gv.scenario == SCN_HEX_MEMORY || gv.scenario == SCN_HEX_EXPLORE;
     if (gv.vis_stride > VIS_SMALL || hexScen) {   // the long-list variants (records through the scalar cache)
-        const int lnp = fast_pixels_per_lane(W, H, true);
+        const int lnp = fast_pixels_per_lane(W, H, true, true);
         const int lsplit = fast_split(W, H, lnp, frames * k, true, true);
         UnionRasterArgs ua;
         ua.n = k;
