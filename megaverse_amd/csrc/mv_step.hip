@@ -87,8 +87,9 @@ __global__ __launch_bounds__(256) void step_kernel(GymView gv, int W, int H, int
 // long as its slowest env, and each having to find room for 1024 two-wave workgroups of ~150 VGPRs beside the observation pass of the previous
 // call (kernel traces, r04l: 70-190 us per step kernel while a pass runs, 20 us alone; the chain of step kernels, not the pass, set the pipelined
 // rate).  Here an env's workgroup becomes resident once and runs tick, frame setup (into slot j's lists), tick, ...: gv[j] is tick j's view
-// (its hand-over slot, its staging outputs, its action index, its cost histogram).  The histograms are cleared by the host before the launch
-// (lpt_no_clear): inside one launch env 0's "clear the next pass's histogram" would race with the envs that are a tick ahead.
+// (its hand-over slot, its staging outputs, its action index, its cost histogram).  The frame setups of such a launch do not clear the next pass's
+// histogram (lpt_no_clear: inside one launch env 0's clearing would race with the envs that are a tick ahead): every pass that draws from one clears it
+// when its last workgroup has looked its frame up (mv_raster.hip: hist_done; mv_api.hip: take_hist).
 // One agent: ONE wave per env (the single-tick kernel's second wave only helps with the frame setup, and idles through the tick): the
 // workgroups stay resident for the whole call beside the observation passes of the previous one, and every wave of ~150 VGPRs they hold is
 // two or three waves the pass cannot have (measured: 21.1 M obs/s with two waves per env, 22.3 M with one).

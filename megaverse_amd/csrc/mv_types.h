@@ -172,7 +172,7 @@ struct GymView {
     // observation pass can stop walking it where everything nearer has covered a tile (mv_raster.hip: raster_glist_body)
     uint8_t *sort_scratch;     // [N*A][vis_stride] x (32 + 8) bytes: the list as found, before it is dealt into its depth classes (null: short lists)
     int32_t depth_sort;        // 1: deal the list into depth classes (set per launch: fast pixel mode only -- the exact kernel resolves depth ties by list position)
-    int32_t lpt_no_clear;      // 1: the frame setup does not clear the cost histogram of the next pass (a multi-tick step launch: cleared up front, mv_step.hip)
+    int32_t lpt_no_clear;      // 1: the frame setup does not clear the cost histogram of the next pass (a multi-tick step launch: the pass that draws from a histogram clears it, mv_raster.hip: hist_done)
 };
 
 // the views of the n consecutive ticks of a multi-tick step launch (mv_step.hip: step_ticks_kernel, mv_step_obstacles.hip), the same envs in all of them
