@@ -49,4 +49,46 @@ for scenario, N, A, params in CASES:
     same = a[0] == b[0] and np.array_equal(a[1], b[1])
     print("%-14s %d steps x %d envs x %d agents: %s, sampled dones %d, %.2f M obs/s" % (scenario, STEPS, N, A, "identical" if same else "DIFFERENT", a[2], a[3] / 1e6), flush=True)
     assert same, scenario
+
+
+# ---- second part: long episodes, the one-launch batched calls (multi-tick step launch, one-launch observation passes into a ring two calls deep, the
+# passes of consecutive calls overlapped) over thousands of calls -- the cost histograms go round their ring hundreds of times, each cleared by the pass
+# that drew from it -- against the same rollout stepped tick by tick: state of the sampled envs and the last tick's slab
+CASES2 = [("TowerBuilding", 256, 1), ("TowerBuilding", 96, 3), ("ObstaclesHard", 192, 1), ("Collect", 128, 1), ("Rearrange", 128, 1), ("Sokoban", 128, 1), ("HexMemory", 96, 1),
+          ("HexExplore", 96, 1)]
+STEPS2 = max(8, (STEPS // 3) // 8 * 8)
+
+
+def run2(scenario, N, A, batched):
+    W, H, R = 64, 36, 16
+    g = MegaverseGym(scenario, W, H, N, A, 8, False, {})
+    g.set_pixel_mode("fast")
+    ring = torch.zeros((R, N * A, H, W, 4), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    g.set_output_ring(R, ring.data_ptr())
+    if batched:
+        g.set_pass_overlap(True)
+    g.seed(321); g.reset()
+    t0 = time.perf_counter()
+    st = 0
+    while st < STEPS2:
+        if batched:
+            g.step_n(8, "multidiscrete", 77, st); st += 8
+        else:
+            g.sample_random_actions(77, st); g.step(); st += 1
+    g.synchronize(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    snaps = b"".join(hip_snapshot(g, e).tobytes() for e in range(0, N, 5))
+    last = ring[(STEPS2 - 1) % R].cpu().numpy().copy()
+    g.close()
+    return snaps, last, STEPS2 * N * A / dt
+
+
+for scenario, N, A in CASES2:
+    a = run2(scenario, N, A, True)
+    b = run2(scenario, N, A, False)
+    same = a[0] == b[0] and np.array_equal(a[1], b[1])
+    print("%-14s %d steps x %d envs x %d agents, calls of 8 (one launch each, overlapped passes) against single ticks: %s, %.2f / %.2f M obs/s" %
+          (scenario, STEPS2, N, A, "identical" if same else "DIFFERENT", a[2] / 1e6, b[2] / 1e6), flush=True)
+    assert same, scenario
 print("soak ok")
