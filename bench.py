@@ -316,9 +316,9 @@ def main():
                     help="random policy: uniform per head (action_space.sample(), megaverse_env.py:110-112) or the reference benchmark's "
                          "Action(1 << randRange(0, 11)) (megaverse_test_app.cpp:140-147)")
     ap.add_argument("--pass-overlap", choices=("auto", "on", "off"), default="auto",
-                    help="output ring two calls deep, the observation passes of consecutive calls overlap (mv_set_pass_overlap).  auto: for the Obstacles scenarios "
+                    help="output ring two calls deep, the observation passes of consecutive calls overlap (mv_set_pass_overlap).  auto: for the Obstacles scenarios and Sokoban "
                          "(measured r07a/b, M obs/s with / without: ObstaclesHard 512 envs 16.9 / 13.9, 1024 envs 20.5 / 20.1; TowerBuilding 1024 envs 23.4 / 24.0, "
-                         "512 envs 20.1 / 20.9; Rearrange 19.4 / 19.5)")
+                         "512 envs 20.1 / 20.9; Rearrange 19.4 / 19.5; r07j: Sokoban 23.4 / 19.6, Collect 14.0 / 14.3, HexMemory 9.15 / 9.10)")
     ap.add_argument("--batch", type=int, default=0,
                     help="ticks per stepping call (mv_step_n): every tick is stepped and rendered in full, the two stream hand-overs are paid once "
                          "per call; 1 = one mv_step per tick; 0 (default) = 8, the first two calls after a synchronisation 1 and 3 ticks (the observation "
@@ -395,7 +395,7 @@ def main():
     # is done (a k-step rollout buffer) -- the working set of the observation writes is batch x one slab, not one slab written over and over
     batched = batch > 1 and not dry
     # (slabs of the output ring: a call never holds more ticks than `batch`; two calls deep, the passes of consecutive calls overlap: mv_set_pass_overlap)
-    pass_overlap = batched and not mixed and (args.pass_overlap == "on" or (args.pass_overlap == "auto" and args.scenario.lower().startswith("obstacles")))
+    pass_overlap = batched and not mixed and (args.pass_overlap == "on" or (args.pass_overlap == "auto" and (args.scenario.lower().startswith("obstacles") or args.scenario.lower() == "sokoban"))))
     ring_slots = (max(batch, 8) * (2 if pass_overlap else 1)) if batched else 1
     ring = torch.zeros((ring_slots, frames, H, W, 4), dtype=torch.uint8, device=device) if batched and not mixed else None   # (Mixed: one slab, no ring)
 
