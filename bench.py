@@ -395,7 +395,7 @@ def main():
     # is done (a k-step rollout buffer) -- the working set of the observation writes is batch x one slab, not one slab written over and over
     batched = batch > 1 and not dry
     # (slabs of the output ring: a call never holds more ticks than `batch`; two calls deep, the passes of consecutive calls overlap: mv_set_pass_overlap)
-    pass_overlap = batched and not mixed and (args.pass_overlap == "on" or (args.pass_overlap == "auto" and (args.scenario.lower().startswith("obstacles") or args.scenario.lower() == "sokoban"))))
+    pass_overlap = batched and not mixed and (args.pass_overlap == "on" or (args.pass_overlap == "auto" and (args.scenario.lower().startswith("obstacles") or args.scenario.lower() == "sokoban")))
     ring_slots = (max(batch, 8) * (2 if pass_overlap else 1)) if batched else 1
     ring = torch.zeros((ring_slots, frames, H, W, 4), dtype=torch.uint8, device=device) if batched and not mixed else None   # (Mixed: one slab, no ring)
 
