@@ -398,6 +398,12 @@ def main():
     pass_overlap = batched and not mixed and (args.pass_overlap == "on" or (args.pass_overlap == "auto" and (args.scenario.lower().startswith("obstacles") or args.scenario.lower() == "sokoban")))
     ring_slots = (max(batch, 8) * (2 if pass_overlap else 1)) if batched else 1
     ring = torch.zeros((ring_slots, frames, H, W, 4), dtype=torch.uint8, device=device) if batched and not mixed else None   # (Mixed: one slab, no ring)
+    # (rewards and dones get rings, too: a k-step rollout buffer holds all three -- and overlapped passes require it, include/megaverse_hip.h)
+    ring_rew = torch.zeros((ring_slots, frames), dtype=torch.float32, device=device) if ring is not None else None
+    ring_done = torch.zeros((ring_slots, n_env), dtype=torch.uint8, device=device) if ring is not None else None
+
+    def set_ring():
+        gym.set_output_ring(ring_slots, ring.data_ptr(), ring_rew.data_ptr(), ring_done.data_ptr())
 
     def bind(b):
         if dry:
@@ -466,7 +472,7 @@ def main():
     step0 = 0
     main_batched = batched and not do_gather
     if main_batched and ring is not None:
-        gym.set_output_ring(ring_slots, ring.data_ptr())
+        set_ring()
         if pass_overlap:
             gym.set_pass_overlap(True)
     run_steps(step0, args.warmup, do_gather, main_batched)
@@ -478,7 +484,7 @@ def main():
     if do_gather:                            # second leg, same step count, observations stay on the producing GPU
         bind(0)
         if batched and ring is not None:
-            gym.set_output_ring(ring_slots, ring.data_ptr())
+            set_ring()
         elapsed_no_gather = timed(step0, False, batched)
         step0 += args.steps
     # N > 1: the one-GPU rate measured INSIDE this process group -- rank 0 steps alone while the other ranks wait at the barrier -- so that the

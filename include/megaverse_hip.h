@@ -108,7 +108,8 @@ int mv_step_n(mv_gym *g, int32_t k, int32_t policy, uint32_t seed, uint32_t firs
  * and its dones in dones[t % count] ([count][N]); a NULL ring keeps that output where it was.  count = 0 switches back to the single
  * slab / arrays.  Host getters (mv_get_observation, mv_get_last_rewards, ...) read the entry of the last tick. */
 int mv_set_output_ring(mv_gym *g, int32_t count, void *obs, float *rewards, uint8_t *dones);
-/* Overlapped observation passes (opt-in).  With a ring at least TWO calls deep (count >= 2 k) the one-launch observation passes of consecutive
+/* Overlapped observation passes (opt-in).  With rings for all three outputs at least TWO calls deep (count >= 2 k, k = the ticks of one mv_step_n call,
+ * also where k exceeds the internal batch; otherwise the call runs as without the option) the one-launch observation passes of consecutive
  * mv_step_n calls run on two internal streams in turn: the passes of call c + 1 begin while the last workgroups of call c's drain.  The caller's
  * stream still waits for every call's passes before anything enqueued after the call runs.  The price is the ring's contract: an entry must be
  * consumed -- the consumer enqueued on the caller's stream -- before the NEXT stepping call after the one that produced it is issued (without

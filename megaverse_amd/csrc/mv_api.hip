@@ -1146,7 +1146,9 @@ static bool launch_step_of(const mv_gym *g, const GymView &v, hipStream_t sim, i
 // the last step ran on -- is kept on it and mirrored to the others.  policy != POLICY_NONE: tick j draws its actions inside the step kernel
 // from (seed, first_index + j); POLICY_NONE: the first tick acts on what mv_set_actions* left, the following ones on cleared actions
 // (env.cpp:141-142 clears them after every tick).
-static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, uint32_t seed, uint32_t first_index)
+// kCall: the ticks of the CALLER's call this chunk belongs to (mv_step_n splits a call of more than `batch` ticks): what the ring contract of
+// the overlapped passes is stated in (include/megaverse_hip.h).
+static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, uint32_t seed, uint32_t first_index, int kCall)
 {
     mv_gym *const L = gs[0];
     int batch = L->batch;
@@ -1319,7 +1321,11 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
     // overlapped passes (mv_set_pass_overlap): this call's one launch goes to an internal stream
     // (an env must not finish in two consecutive calls: their passes may publish its true objective in either order -- episodes of at least
     // baseEpisodeLen seconds, 15 ticks each)
-    const bool overlap = batchRaster && own && !callEv && L->passOverlap && L->passStream[0] && L->ringCount >= 2 * k && k <= MAX_UNION && L->baseEpisodeLen * 15.0f > float(2 * k + 2);
+    // The ring is two CALLS deep, in the caller's ticks per call (a call of 16 ticks runs as two chunks of 8: the second-next chunk's passes would overwrite
+    // what the consumer of the previous CALL -- enqueued after both of its chunks -- may still be reading), and rewards / dones have rings of
+    // their own (two passes in flight would both publish the single arrays, in either order).
+    const bool overlap = batchRaster && own && !callEv && L->passOverlap && L->passStream[0] && L->ringCount >= 2 * std::max(k, kCall) && L->ringRewards && L->ringDone &&
+                         k <= MAX_UNION && L->baseEpisodeLen * 15.0f > float(2 * k + 2);
     hipStream_t passOn = L->stream;
     if (overlap) {
         const int me = (int)(L->overlapCalls & 1ull);
@@ -1401,10 +1407,10 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
     return rc;
 }
 
-static int step_impl(mv_gym *g, bool render, int k, int policy, uint32_t seed, uint32_t first_index)
+static int step_impl(mv_gym *g, bool render, int k, int policy, uint32_t seed, uint32_t first_index, int kCall = 0)
 {
     if (g && g->inGroup) return fail("this gym belongs to an mv_group: step the group (mv_group_step)");
-    return step_gyms(&g, 1, render, k, policy, seed, first_index);
+    return step_gyms(&g, 1, render, k, policy, seed, first_index, kCall > 0 ? kCall : k);
 }
 
 int mv_step(mv_gym *g) { return step_impl(g, true, 1, POLICY_NONE, 0, 0); }
@@ -1421,7 +1427,7 @@ int mv_step_n(mv_gym *g, int32_t k, int32_t policy, uint32_t seed, uint32_t firs
     const int chunk = g->statusPeriod <= 1 ? 1 : g->batch;
     for (int done = 0; done < k; done += chunk) {
         const int n = std::min(chunk, k - done);
-        const int r = step_impl(g, true, n, policy, seed, first_step_index + (uint32_t)done);
+        const int r = step_impl(g, true, n, policy, seed, first_step_index + (uint32_t)done, k);
         if (r < 0) return -1;
         if (r > 0) { g->warning += (g->warning.empty() ? "" : " | ") + g_err; rc = 1; }   // (every chunk's warning text is kept)
     }
@@ -1504,7 +1510,7 @@ int mv_group_step(mv_group *grp, int32_t k, int32_t render, int32_t policy, uint
     int rc = 0;
     std::string text;
     for (int done = 0; done < k; done += chunk) {
-        const int r = step_gyms(grp->gyms.data(), (int)grp->gyms.size(), render != 0, std::min(chunk, k - done), policy, seed, first_step_index + (uint32_t)done);
+        const int r = step_gyms(grp->gyms.data(), (int)grp->gyms.size(), render != 0, std::min(chunk, k - done), policy, seed, first_step_index + (uint32_t)done, k);
         if (r < 0) return -1;
         if (r > 0) { text += (text.empty() ? "" : " | ") + g_err; rc = 1; }
     }

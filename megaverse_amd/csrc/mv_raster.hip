@@ -847,8 +847,12 @@ __device__ __forceinline__ FastFrame fast_prologue(const FastArgs &fa, int blk, 
         }
         __syncthreads();
     }
-    // (every thread's loads from the histogram have returned -- their values went into the prefix sums above)
-    if (tid == 0) s_lastWG = fa.hist_done != nullptr && atomicAdd(fa.hist_done, 1) == fa.wg_total - 1;
+    // Every thread's loads from the histogram have RETURNED here -- their values went into the prefix sums and the look-up above, on this side of the
+    // barriers (which are also compiler fences: no load can sink below them) -- so the count may be relaxed: the workgroup that completes it zeroes the
+    // histogram strictly after every reader's data arrived.  (A release / acquire pair at agent scope would be the textbook form; on gfx950 it is a
+    // buffer_wbl2 + buffer_inv per workgroup -- an L2 write-back in the middle of 8192 workgroups' pixel stores -- for an ordering the data dependence
+    // already gives.)  The zeroing itself is ordered against the next writer -- the frame setups of a later step launch -- by the kernel boundary.
+    if (tid == 0) s_lastWG = fa.hist_done != nullptr && __hip_atomic_fetch_add(fa.hist_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fa.wg_total - 1;
     const int frame = __builtin_amdgcn_readfirstlane(s_frame);
     const int viewer = frame % A;
     const float *gh = reinterpret_cast<const float *>(fa.vis_hdr + (size_t)frame * FRAME_HDR_BYTES);
@@ -883,7 +887,7 @@ __device__ __forceinline__ FastFrame fast_prologue(const FastArgs &fa, int blk, 
     if (s_lastWG) {   // the pass's last workgroup: nobody reads the histogram any more
         int *h = const_cast<int *>(fa.hist);
         for (int i = tid; i < LPT_BUCKETS * LPT_SUBS; i += NT) h[i] = 0;
-        if (tid == 0) *fa.hist_done = 0;
+        if (tid == 0) __hip_atomic_store(fa.hist_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
     return FastFrame{frame, part, viewer, nVis, split};

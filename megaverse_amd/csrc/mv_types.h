@@ -180,6 +180,8 @@ struct StepTicksArgs {
     int32_t n;
     GymView gv[MAX_STEP_TICKS];
 };
+// (the views travel BY VALUE as kernel arguments: a launch whose arguments exceed the 4 KB kernarg segment fails at run time, not at build time)
+static_assert(sizeof(StepTicksArgs) + 16 <= 4096, "StepTicksArgs + (W, H) must fit the 4 KB kernel-argument segment: slim GymView down or pass the views through device memory");
 
 // One host-generated episode (Obstacles family): everything Env::reset produces, ready to be swapped in by
 // the reset kernel.  Fixed-size POD so that the host can fill a pinned staging copy and upload it as is.

@@ -14,6 +14,8 @@ struct UnionStepArgs {
     GymView gv[MAX_UNION];
 };
 
+static_assert(sizeof(UnionStepArgs) + 16 <= 4096, "UnionStepArgs + (W, H, render) must fit the 4 KB kernel-argument segment");
+
 void launch_step_union(const UnionStepArgs &ua, hipStream_t stream, int W, int H, int render);
 
 }  // namespace mv

@@ -163,7 +163,10 @@ class OracleGym:
         out = {}
         for k in ("teamSpirit", "towerPickedUpObject", "towerVisitedBuildingZoneWithObject", "towerBuildingReward",
                   "obstaclesAgentAtExit", "obstaclesAllAgentsAtExit", "obstaclesExtraReward", "obstaclesAgentCarriedObjectToExit",
-                  "memoryCollectGood", "memoryCollectBad", "exploreSolved"):
+                  "memoryCollectGood", "memoryCollectBad", "exploreSolved",
+                  "collectSingleGood", "collectSingleBad", "collectAll", "collectAbyss",
+                  "rearrangeOneMoreObjectCorrectPosition", "rearrangeAllObjectsCorrectPosition",
+                  "sokobanBoxOnTarget", "sokobanBoxLeavesTarget", "sokobanAllBoxesOnTarget"):
             f = C.c_int(0)
             v = self.L.mvo_get_reward_shaping(self.g, env_idx, agent_idx, k.encode(), C.byref(f))
             if f.value:

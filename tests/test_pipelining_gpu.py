@@ -425,3 +425,64 @@ def test_overlapped_passes_fill_the_ring_like_single_ticks(hip, monkeypatch, sce
         assert a.debug_snapshot_bytes(e).tobytes() == b.debug_snapshot_bytes(e).tobytes(), e
     assert a.get_true_objectives().tobytes() == b.get_true_objectives().tobytes()
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("k,R,rings", [(16, 16, True), (16, 32, True), (8, 16, True), (8, 16, False), (12, 32, True)])
+def test_overlapped_passes_with_a_late_consumer(hip, k, R, rings):
+    """The ring contract of mv_set_pass_overlap under load: the consumer of a call's entries is ENQUEUED right after the call, as the
+    header asks, but still pending -- behind a slow kernel on the caller's stream -- when the next calls are issued; no host synchronisation between
+    calls.  k = 16 runs as two chunks of the internal batch (8): with a ring of 16 the library must decline to overlap (the ring is one CALL deep),
+    with 32 it may; without rewards / dones rings it must decline, too (two passes in flight would both publish the single arrays).  What every
+    consumer copied must be what single ticks produce."""
+    import torch
+    N, A, W, H = 96, 1, 64, 64
+    def make(overlap):
+        g = MegaverseGym("ObstaclesHard", W, H, N, A, 2, False, {})
+        g.set_pixel_mode("fast"); g.seed(77); g.reset()
+        obs = torch.zeros((R, N * A, H, W, 4), dtype=torch.uint8, device="cuda:0")
+        rew = torch.zeros((R, N * A), dtype=torch.float32, device="cuda:0")
+        don = torch.zeros((R, N), dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
+        g.set_output_ring(R, obs.data_ptr(), rew.data_ptr() if rings else 0, don.data_ptr() if rings else 0)
+        if overlap:
+            g.set_pass_overlap(True)
+        return g, obs, rew, don
+    a, oa, ra, da = make(True)
+    b, ob, rb, db = make(False)
+    calls = 6
+    big = torch.randn((3072, 3072), device="cuda:0")
+    log_o = torch.zeros((calls, k, N * A, H, W, 4), dtype=torch.uint8, device="cuda:0")
+    log_r = torch.zeros((calls, k, N * A), dtype=torch.float32, device="cuda:0")
+    log_d = torch.zeros((calls, k, N), dtype=torch.uint8, device="cuda:0")
+    want_o, want_r, want_d = torch.zeros_like(log_o), torch.zeros_like(log_r), torch.zeros_like(log_d)
+    torch.cuda.synchronize()
+    st = 0
+    for c in range(calls):
+        a.step_n(k, "multidiscrete", 9, st)
+        idx = torch.arange(st, st + k, device="cuda:0") % R
+        # the consumer, enqueued now (before the next call is issued) and slow to start: a few milliseconds of matrix products in front of it
+        for _ in range(3):
+            big = (big @ big).clamp_(-1.0, 1.0)
+        log_o[c].copy_(oa[idx])
+        if rings:
+            log_r[c].copy_(ra[idx]); log_d[c].copy_(da[idx])
+        st += k
+    torch.cuda.synchronize()
+    st = 0
+    for c in range(calls):
+        for j in range(k):
+            b.sample_random_actions(9, st + j); b.step()
+            b.synchronize()
+            want_o[c, j].copy_(ob[(st + j) % R])
+            if rings:
+                want_r[c, j].copy_(rb[(st + j) % R]); want_d[c, j].copy_(db[(st + j) % R])
+        st += k
+    torch.cuda.synchronize()
+    assert want_o[..., :3].max().item() > 0
+    assert torch.equal(log_o, want_o), "a consumer enqueued right after its call read something else than single ticks produce"
+    assert torch.equal(log_r.view(torch.int32), want_r.view(torch.int32)) and torch.equal(log_d, want_d)
+    if not rings:   # the single arrays hold the LAST tick's values, whatever ran in between
+        assert a.get_last_rewards().tobytes() == b.get_last_rewards().tobytes() and a.get_dones().tobytes() == b.get_dones().tobytes()
+    for e in range(N):
+        assert a.debug_snapshot_bytes(e).tobytes() == b.debug_snapshot_bytes(e).tobytes(), e
+    a.close(); b.close()
