@@ -584,7 +584,7 @@ struct FastArgs {   // what raster_fast_kernel needs of the GymView (fewer live 
     int nosort;   // 1: frame = position (no look-up in the cost bins; MV_RASTER_NOSORT=1, measurements)
     int tail_div, tail_split;   // d > 0: the cheapest 1/d of the frames -- the LAST workgroups of the launch -- are cut into tail_split pieces instead of the launch's split (launch_raster)
     int graded;   // d > 0: graded split -- the most expensive 1/d of the frames are cut into 4 workgroups instead of the launch's 2 (graded_heavy)
-    int planar;   // 1: tiles that one face of one world box covers take the planar path (planar_tile); 0: every tile takes the general one (MV_PLANAR=0, comparisons)
+    int planar;   // 1: tiles that one face of one world box covers take the planar path (planar_tile / overlay_tile); 0: every tile takes the general one (MV_PLANAR=0, comparisons); 2: no overlay_tile
 };
 
 // true_objective is only ever recorded by a finishing env (vector_env.cpp:96-101): the others keep the value of their last episode
@@ -637,13 +637,15 @@ constexpr unsigned KEY_NEAR = 0x3c23d70au;   // bits of NEAR_Z = 0.01f
 constexpr unsigned KEY_FAR = 0x42f00000u - KEY_NEAR;   // bits of FAR_Z = 120.0f, relative
 static_assert(NEAR_Z == 0.01f && FAR_Z == 120.0f, "update KEY_NEAR / KEY_FAR");
 
+// depthMask: ~POS_MASK, handed in IN A VECTOR REGISTER (box_run launders it): gfx950's VOP3 encoding takes one scalar operand and no literal, so "(x & literal) |
+// scalar" is two instructions, "(x & vector) | scalar" is one v_and_or_b32 -- 19 instead of 20 per box and pixel in the pass's innermost loop
 template <unsigned POS_MASK>
-__device__ __forceinline__ unsigned box_key(V3 inv, const float4 lo, const float4 hi, int pos)
+__device__ __forceinline__ unsigned box_key(V3 inv, const float4 lo, const float4 hi, int pos, unsigned depthMask = ~POS_MASK)
 {
     const float t1x = lo.x * inv.x, t2x = hi.x * inv.x, t1y = lo.y * inv.y, t2y = hi.y * inv.y, t1z = lo.z * inv.z, t2z = hi.z * inv.z;
     const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)), __builtin_fminf(t1z, t2z));
     const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)), __builtin_fmaxf(t1z, t2z));
-    const unsigned key = ((__float_as_uint(tn) - KEY_NEAR) & ~POS_MASK) | (unsigned)pos;
+    const unsigned key = ((__float_as_uint(tn) - KEY_NEAR) & depthMask) | (unsigned)pos;
     return tn <= tf ? key : ~0u;
 }
 template <unsigned POS_MASK>
@@ -668,6 +670,14 @@ namespace {
 
 // one primitive that is not an axis-aligned box of the world frame -- a camera-attached box, a capsule, a cone, a scaled shape -- against this
 // lane's ray: its depth key (or ~0u), and for the curved ones the normal in the primitive's frame
+// a box that lives in another frame of reference than the world's -- the viewer's own camera (its time bar, the object it carries) or another camera (another
+// agent's visor and bar) -- against this lane's ray: the entry depth, range-tested
+__device__ __forceinline__ bool other_box(const float4 lo, const float4 hi, int qfr, const float *s_hdr, int viewer, V3 dw, float dcx, float dcy, float &t)
+{
+    const V3 df = qfr == 1 + viewer ? v3(dcx, dcy, -1.0f) : lds_tmul(local_lds(s_hdr + FH_CAM + FH_CAM_STRIDE * (qfr - 1) + 3), dw);
+    return fast_box(v3(__builtin_amdgcn_rcpf(df.x), __builtin_amdgcn_rcpf(df.y), __builtin_amdgcn_rcpf(df.z)), lo, hi, t);
+}
+
 template <bool SHAPES>
 __device__ __forceinline__ bool other_rec(const float4 lo, const float4 hi, const float *s_hdr, const float *camv, int viewer, V3 dw, float dcx, float dcy, float &t, V3 &n)
 {
@@ -676,10 +686,8 @@ __device__ __forceinline__ bool other_rec(const float4 lo, const float4 hi, cons
     t = 0.0f;
     n = v3(0, 0, 0);
     bool hit;
-    if (qkind == PRIM_BOX) {
-        const V3 df = qfr == 1 + viewer ? v3(dcx, dcy, -1.0f) : lds_tmul(local_lds(s_hdr + FH_CAM + FH_CAM_STRIDE * (qfr - 1) + 3), dw);
-        hit = fast_box(v3(__builtin_amdgcn_rcpf(df.x), __builtin_amdgcn_rcpf(df.y), __builtin_amdgcn_rcpf(df.z)), lo, hi, t);
-    } else {
+    if (qkind == PRIM_BOX) hit = other_box(lo, hi, qfr, s_hdr, viewer, dw, dcx, dcy, t);
+    else {
         lds_float *ce = local_lds(camv);   // (read here, not kept in registers across the tile loop)
         const V3 eye = v3(ce[0], ce[1], ce[2]);
         if (qkind == PRIM_CAPSULE) hit = ray_capsule<true>(eye, dw, v3(lo.x, lo.y, lo.z), hi.x, hi.y, t, n);
@@ -703,6 +711,9 @@ __device__ __forceinline__ unsigned fast_other(int pos, const float4 *s_vis, con
 // The part of Phong every kind of hit shares: depth t along the pixel's ray, N . (L - P) and N . (-P) (both unnormalised in (L - P) / P), the
 // pixel's dc . dc and L . dc, the colour's bytes as floats -> RGBA8.  (One function for the general and the planar-tile path: the same
 // operations in the same order, so a tile drawn by either has the same bytes.)
+// SPEC = false: the caller has PROVED that no pixel it shades this way can lie inside the highlight cone (classify_tiles: highlight bound) -- the test
+// below would fail for every one of them and spec255 stay 0: the same bytes without the seven instructions of V . R.
+template <bool SPEC = true>
 __device__ __forceinline__ unsigned phong_tail(float t, float ndl, float nv, float a2, float ldc, float cr, float cg, float cb)
 {
     // |L - P|^2 = |L|^2 - 2 t (L . dc) + t^2 (dc . dc)
@@ -711,7 +722,7 @@ __device__ __forceinline__ unsigned phong_tail(float t, float ndl, float nv, flo
     const float rs = __builtin_amdgcn_rsqf(len2LP);
     const float intensity = __builtin_fmaxf(0.0f, ndl * rs);
     float spec255 = 0.0f;
-    if (intensity > 0.001f) {
+    if (SPEC && intensity > 0.001f) {
         // V . R with V = -P unnormalised: 2 (N . Ld)(N . -P) + Ld . P
         const float vr = __builtin_fmaf(2.0f * intensity, nv, (t * (ldc - ta)) * rs);
         const float p2 = t * ta;   // |P|^2
@@ -903,16 +914,18 @@ __device__ __forceinline__ void box_run(unsigned long long m, int k, const V3 (&
     int p0 = __ffsll((long long)m) - 1 + 64 * k, p1 = 0;
     m &= m - 1;
     float4 lo0 = s_vis[2 * p0], hi0 = s_vis[2 * p0 + 1], lo1 = lo0, hi1 = hi0;
+    unsigned depthMask = ~POS_MASK;
+    asm volatile("" : "+v"(depthMask));   // (a vector register: box_key)
     for (;;) {
         bool more = m != 0ull;
         if (more) { p1 = __ffsll((long long)m) - 1 + 64 * k; m &= m - 1; lo1 = s_vis[2 * p1]; hi1 = s_vis[2 * p1 + 1]; }
 #pragma unroll
-        for (int j = 0; j < NP; ++j) best[j] = min(best[j], box_key<POS_MASK>(inv[j], lo0, hi0, p0));
+        for (int j = 0; j < NP; ++j) best[j] = min(best[j], box_key<POS_MASK>(inv[j], lo0, hi0, p0, depthMask));
         if (!more) break;
         more = m != 0ull;
         if (more) { p0 = __ffsll((long long)m) - 1 + 64 * k; m &= m - 1; lo0 = s_vis[2 * p0]; hi0 = s_vis[2 * p0 + 1]; }
 #pragma unroll
-        for (int j = 0; j < NP; ++j) best[j] = min(best[j], box_key<POS_MASK>(inv[j], lo1, hi1, p1));
+        for (int j = 0; j < NP; ++j) best[j] = min(best[j], box_key<POS_MASK>(inv[j], lo1, hi1, p1, depthMask));
         if (!more) break;
     }
 }
@@ -951,7 +964,7 @@ constexpr int CLS_MAX_TILES = 128;   // tiles of one workgroup that can be class
 // inside at every pixel of the tile <=> a x0 + b y0 + c_in >= 0 at the tile's first pixel (x0, y0); outside at every pixel <=> that + span <= 0.
 // Called by all 256 threads after the prologue's barrier (s_vis, s_rect, the header are in LDS); ends with a barrier.
 template <int TH, int NT>
-__device__ __forceinline__ void classify_tiles(uint4 *s_tile, float4 *s_line, const float4 *s_vis, const short4 *s_rect, const float *camv, int nVis, unsigned long long wb0,
+__device__ __forceinline__ void classify_tiles(uint4 *s_tile, float4 *s_line, const float4 *s_vis, const short4 *s_rect, const float *s_hdr, const float *camv, int nVis, unsigned long long wb0,
                                                int W, int H, int part, int split, int tilesX, int numTiles, int perWG)
 {
     constexpr int NW = NT / 64;        // waves of the workgroup
@@ -1063,10 +1076,46 @@ __device__ __forceinline__ void classify_tiles(uint4 *s_tile, float4 *s_line, co
             if (cover[c]) atomicOr(&s_tile[u].z, cover[c]);
         }
     __syncthreads();
+    // ---- highlight bound: which covered tiles cannot hold a pixel of the specular highlight (s_tile[u].w = 1)?
+    // Shaders::Phong's highlight (magnum_env_renderer.cpp:200-203, shininess 300) is evaluated where cos(V, R) > 0.97 (phong_tail).  On a planar face,
+    // with L' the light mirrored in the face's plane, R at a point P of the face is the direction from L' to P, V the direction from P to the eye E: the
+    // angle between them is the exterior angle at P of the triangle E P L', the sum of its interior angles at E and at L' -- so it is at least the angle
+    // at E, the angle between the pixel's ray and the direction from the eye to L'.  If that angle at the tile's centre exceeds acos(0.965) (15.2 degrees:
+    // 1.1 degrees of margin over acos(0.97) for the rounding of either side) plus the tile's angular radius (two rays through points a, b of the plane
+    // z = -1: sin(angle) <= |a - b|), no pixel of the tile passes phong_tail's test: the planar path leaves the seven instructions of V . R out
+    // (phong_tail<false>), the bytes stay what they were.  One lane per tile, one wave per 64 tiles: ~30 instructions per frame.
+    {
+        const float hx = 0.5f * WX * sx, hy = 0.5f * WY * sy;
+        const float r2 = hx * hx + hy * hy;                                    // (tile radius)^2 on the plane z = -1 = sin^2 of the bound on its angular radius
+        const float cosT = 0.965f * __builtin_amdgcn_sqrtf(__builtin_fmaxf(1.0f - r2, 0.0f)) - 0.2623f * __builtin_amdgcn_sqrtf(r2);   // cos(acos(0.965) + asin(r)), rounded towards the larger angle
+        const bool usable = r2 < 0.5f && cosT > 0.0f;
+        const float cosT2 = cosT * cosT;
+        const float L0 = s_hdr[FH_LREL + 0], L1 = s_hdr[FH_LREL + 1], L2 = s_hdr[FH_LREL + 2];   // the light relative to the eye, world axes (frame 0)
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (wave != (c % NW) || !tvalid[c] || !usable) continue;
+            const int u = 64 * c + lane;
+            const uint4 tc = s_tile[u];
+            const unsigned long long m = ((unsigned long long)tc.y << 32) | tc.x;
+            if (m == 0ull || (m & (m - 1ull)) != 0ull || tc.z == 0u) continue;   // (not a covered tile with one candidate)
+            const int pos = __ffsll((long long)m) - 1, k = (int)tc.z - 1;
+            const float lok = reinterpret_cast<const float *>(s_vis)[8 * pos + k], hik = reinterpret_cast<const float *>(s_vis)[8 * pos + 4 + k];
+            const float plane = lok > 0.0f ? lok : hik;
+            const float m0 = k == 0 ? 2.0f * plane - L0 : L0, m1 = k == 1 ? 2.0f * plane - L1 : L1, m2 = k == 2 ? 2.0f * plane - L2 : L2;   // L'
+            const float xc = float(tX0[c]) + 0.5f * WX, yc = float(tY0[c]) + 0.5f * WY;
+            const float dcx = sx * xc + ox, dcy = sy * yc + oy;
+            const float d0 = (camv[3] * dcx + camv[4] * dcy) - camv[5], d1 = (camv[6] * dcx + camv[7] * dcy) - camv[8], d2 = (camv[9] * dcx + camv[10] * dcy) - camv[11];
+            const float dot = (d0 * m0 + d1 * m1) + d2 * m2;
+            const float dd = (d0 * d0 + d1 * d1) + d2 * d2, mm = (m0 * m0 + m1 * m1) + m2 * m2;
+            const bool maybe = dot > 0.0f && dot * dot >= cosT2 * (dd * mm);
+            if (!maybe) s_tile[u].w = 1u;
+        }
+        __syncthreads();
+    }
 }
 
 // the pixels of a tile that the face of axis k (the one towards the eye) of the world box at list position `pos` covers
-template <int NP>
+template <int NP, bool SPEC>
 __device__ __forceinline__ void planar_tile(int pos, int k, const float4 *s_vis, const float *s_hdr, const float4 *s_col, const float4 *s_row,
                                             const float2 *s_rowq, const float *s_colq, float nzk, int px, int py0, int W, int H, uint32_t *out)
 {
@@ -1087,7 +1136,128 @@ __device__ __forceinline__ void planar_tile(int pos, int k, const float4 *s_vis,
         const float dk = (colk + rowk) + nzk;                 // the ray's component along k: the same sum the general path forms
         const float t = plane * __builtin_amdgcn_rcpf(dk);    // == min(lo_k inv_k, hi_k inv_k) of the slab test
         const float nv = t * __builtin_fabsf(dk);
-        const unsigned rgba = phong_tail(t, nv - lks, nv, cq + rq.x, rq.y, cr, cg, cb);
+        const unsigned rgba = phong_tail<SPEC>(t, nv - lks, nv, cq + rq.x, rq.y, cr, cg, cb);
+        if (px < W && py < H) PIXEL_STORE(out[(unsigned)(py * W + px)], rgba);
+    }
+}
+
+// a tile nothing can be seen through: the clear colour (0, 0, 0), alpha 255 -- 16 pixels of a row are 64 bytes: four lanes per row write 16 bytes each
+// (a quarter of the store instructions of one dword per pixel) where the frame's rows allow it
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+template <int NP>
+__device__ __forceinline__ void clear_tile(uint32_t *out, int tx0, int ty0, int lane, int px, int py0, int W, int H)
+{
+    constexpr int TH = TILE_H * NP;
+    if ((W & 3) == 0 && tx0 + TILE_W <= W && (reinterpret_cast<uintptr_t>(out) & 15u) == 0u) {   // (uniform)
+        // (lane and colour are laundered: formed here, per tile -- hoisted out of the tile loop they cost the kernel five registers it does not have at seven waves per SIMD)
+        unsigned c = 0xff000000u;
+        asm volatile("" : "+v"(lane), "+v"(c));
+        const int row = ty0 + (lane >> 2), col = tx0 + 4 * (lane & 3);
+        const v4u_t v = {c, c, c, c};
+#ifndef MV_PIXEL_PLAIN
+        if (lane < 4 * TH && row < H) __builtin_nontemporal_store(v, reinterpret_cast<v4u_t *>(out + (unsigned)(row * W + col)));
+#else
+        if (lane < 4 * TH && row < H) *reinterpret_cast<v4u_t *>(out + (unsigned)(row * W + col)) = v;
+#endif
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int py = py0 + TILE_H * j;
+        if (px < W && py < H) PIXEL_STORE(out[(unsigned)(py * W + px)], 0xff000000u);
+    }
+}
+
+// A covered tile with company: ONE world box whose face covers the tile (as in planar_tile) and, in front of it or not, boxes of other frames of reference
+// whose rectangles meet the tile -- the viewer's time bar along the bottom row of tiles of every frame (scenario_default.hpp:137-145,164-169), the object it
+// carries (component_object_stacking.hpp:146-152).  The general path would set up the whole ray (three v_rcp_f32), run the slab test of the world box and
+// recover its entry axis per pixel; here the face's depth comes as in planar_tile -- the same product the slab test forms, so the same depth key -- the other
+// boxes are intersected by the very function the general path uses (other_box), the nearest wins by the same key comparison, and the pixel is shaded by
+// phong_tail with the face's constants or, where another box won, by the general path's fast_shade: the same bytes (test_planar_tiles_change_no_byte).
+template <bool SHAPES, unsigned POS_MASK, int NP>
+__device__ __forceinline__ void overlay_tile(int posA, int k, unsigned long long rest, const float4 *s_vis, const float *s_hdr, const float *camv, int viewer, const float4 *s_col,
+                                             const float4 *s_row, const float2 *s_rowq, const float *s_colq, float nzm0, float nzm1, float nzm2, int px, int py0, int W, int H, uint32_t *out)
+{
+    const float lok = uniform_f32(reinterpret_cast<const float *>(s_vis)[8 * posA + k]), hik = uniform_f32(reinterpret_cast<const float *>(s_vis)[8 * posA + 4 + k]);
+    const float plane = lok > 0.0f ? lok : hik;
+    const unsigned color = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_uint(reinterpret_cast<const float *>(s_vis)[8 * posA + 7]));
+    const float cr = float((color >> 16) & 255u), cg = float((color >> 8) & 255u), cb = float(color & 255u);
+    const float lk = uniform_f32(s_hdr[FH_LREL + k]);
+    const float lks = plane > 0.0f ? lk : 0.0f - lk;
+    const int pxc = min(px, W - 1);
+    const float4 cx = s_col[pxc];
+    const float cq = s_colq[pxc];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int py = py0 + TILE_H * j, pyc = min(py, H - 1);
+        const float4 ry = s_row[pyc];
+        const float2 rq = s_rowq[pyc];
+        const V3 dw = v3((cx.y + ry.y) + nzm0, (cx.z + ry.z) + nzm1, (cx.w + ry.w) + nzm2);
+        const float dk = k == 0 ? dw.x : k == 1 ? dw.y : dw.z;
+        const float t = plane * __builtin_amdgcn_rcpf(dk);
+        const unsigned keyA = ((__float_as_uint(t) - KEY_NEAR) & ~POS_MASK) | (unsigned)posA;   // box_key of the covering face: it is hit (classify_tiles), its entry depth is this product
+        unsigned best = keyA;
+        unsigned long long m = rest;
+        while (m) {
+            const int pos = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const float4 lo = s_vis[2 * pos], hi = s_vis[2 * pos + 1];
+            const int qfr = (int)((__builtin_amdgcn_readfirstlane(__float_as_uint(lo.w)) >> 4) & 15);
+            float tb;
+            const bool hit = other_box(lo, hi, qfr, s_hdr, viewer, dw, cx.x, ry.x, tb);
+            best = min(best, hit_key<POS_MASK>(hit, tb, pos));
+        }
+        const float a2 = cq + rq.x, ldc = rq.y;
+        unsigned rgba;
+        if (best == keyA) {
+            const float nv = t * __builtin_fabsf(dk);
+            rgba = phong_tail<true>(t, nv - lks, nv, a2, ldc, cr, cg, cb);
+        } else rgba = fast_shade<SHAPES, POS_MASK>(best, v3(0.0f, 0.0f, 0.0f), s_vis, s_hdr, camv, viewer, dw, v3(0.0f, 0.0f, 0.0f), cx.x, ry.x, a2, ldc);
+        if (px < W && py < H) PIXEL_STORE(out[(unsigned)(py * W + px)], rgba);
+    }
+}
+
+// The general path for a tile of a classified frame: its list is ONE culling round (at most 64 primitives) and the tile's candidates -- mv0, not empty -- came out of
+// the classification, so the rays are set up at once and there is no loop over rounds (the same arithmetic, in the same order, as the loop in raster_fast_body).
+template <bool SHAPES, unsigned POS_MASK, int NP>
+__device__ __forceinline__ void general_tile(unsigned long long mv0, unsigned long long wb0, const float4 *s_vis, const float *s_hdr, const float *camv, int viewer, const float4 *s_col,
+                                             const float4 *s_row, const float2 *s_rowq, const float *s_colq, float nzm0, float nzm1, float nzm2, int px, int py0, int W, int H, uint32_t *out)
+{
+    const int pxc = min(px, W - 1);
+    const float4 cx = s_col[pxc];
+    const float cq = s_colq[pxc];
+    const float dcx = cx.x;
+    V3 dw[NP], inv[NP], bn[NP];
+    float dcy[NP], a2[NP], ldc[NP];
+    unsigned best[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int pyc = min(py0 + TILE_H * j, H - 1);
+        const float4 ry = s_row[pyc];
+        const float2 rq = s_rowq[pyc];
+        dcy[j] = ry.x;
+        dw[j] = v3((cx.y + ry.y) + nzm0, (cx.z + ry.z) + nzm1, (cx.w + ry.w) + nzm2);
+        inv[j] = v3(__builtin_amdgcn_rcpf(dw[j].x), __builtin_amdgcn_rcpf(dw[j].y), __builtin_amdgcn_rcpf(dw[j].z));
+        a2[j] = cq + rq.x; ldc[j] = rq.y;
+        bn[j] = v3(0.0f, 0.0f, 0.0f);
+        best[j] = ~0u;
+    }
+    box_run<POS_MASK, NP>(mv0 & wb0, 0, inv, s_vis, best);
+    unsigned long long rest = mv0 & ~wb0;
+    while (rest) {
+        const int pos = __ffsll((long long)rest) - 1;
+        rest &= rest - 1;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            V3 n = v3(0, 0, 0);
+            const unsigned key = fast_other<SHAPES, POS_MASK>(pos, s_vis, s_hdr, camv, viewer, dw[j], dcx, dcy[j], n);
+            if (key < best[j]) { best[j] = key; bn[j] = n; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const unsigned rgba = fast_shade<SHAPES, POS_MASK>(best[j], bn[j], s_vis, s_hdr, camv, viewer, dw[j], inv[j], dcx, dcy[j], a2[j], ldc[j]);
+        const int py = py0 + TILE_H * j;
         if (px < W && py < H) PIXEL_STORE(out[(unsigned)(py * W + px)], rgba);
     }
 }
@@ -1167,9 +1337,12 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
     const bool cls = PLANAR && fa.planar && nVis <= 64 && perWG <= CLS_MAX_TILES && perWG >= 32;   // (uniform over the workgroup; few tiles do not repay the pass over the list)
     __shared__ int s_next;   // the tile loop's hand-out counter (below)
     if (tid == 0) s_next = NT / 64;
-    if (PLANAR && cls) classify_tiles<TH, NT>(s_tile, s_line, s_vis, s_rect, camv, nVis, wb0, W, H, part, split, tilesX, numTiles, perWG);   // (ends with a barrier)
+    if (PLANAR && cls) classify_tiles<TH, NT>(s_tile, s_line, s_vis, s_rect, s_hdr, camv, nVis, wb0, W, H, part, split, tilesX, numTiles, perWG);   // (ends with a barrier)
     else __syncthreads();
     RT_MARK(2);
+#if defined(MV_RASTER_DEBUG_SKIP) && MV_RASTER_DEBUG_SKIP == 1   // (measurement builds: the pass's fixed cost -- prologue + classification -- alone; pixels are NOT drawn)
+    return;
+#endif
 
     // The workgroup's tiles are handed out one at a time (an LDS counter; the next index is requested while the current tile is drawn): a wave
     // that always drew the same tile column of its frame -- tile index = wave mod 4 -- lived as long as the most crowded column, and the
@@ -1190,23 +1363,44 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
         if (PLANAR && cls) {   // classified: the answer is in the table, with the face that covers the tile if one does
             const uint4 tc = s_tile[u];
             mv0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(tc.y) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(tc.x);
-            const unsigned cover = (unsigned)__builtin_amdgcn_readfirstlane(tc.z);
+            const unsigned cover = (unsigned)__builtin_amdgcn_readfirstlane(tc.z), nospec = (unsigned)__builtin_amdgcn_readfirstlane(tc.w);
             RT_COUNT(0, 1);                                   // classified tiles
             if (mv0 == 0ull) {   // nothing: the clear colour
                 RT_COUNT(1, 1);
-#pragma unroll
-                for (int j = 0; j < NP; ++j) {
-                    const int py = py0 + TILE_H * j;
-                    if (px < W && py < H) PIXEL_STORE(out[(unsigned)(py * W + px)], 0xff000000u);
+                clear_tile<NP>(out, tx0, ty0, lane, px, py0, W, H);
+                continue;
+            }
+            const unsigned long long wbm = mv0 & wb0, others = mv0 & ~wb0;
+            if (wbm != 0ull && (wbm & (wbm - 1ull)) == 0ull && cover != 0u) {   // one world box, and one of its faces covers the tile
+                const int k = (int)cover - 1, posA = __ffsll((long long)wbm) - 1;
+                const float nzk = k == 0 ? nzm0 : k == 1 ? nzm1 : nzm2;
+#if defined(MV_RASTER_DEBUG_SKIP) && MV_RASTER_DEBUG_SKIP == 3   // (measurement builds: covered tiles cost nothing)
+                continue;
+#endif
+                if (others == 0ull) {   // ... and nothing else
+                    RT_COUNT(2, 1);
+                    RT_COUNT(12, nospec != 0u);
+                    if (nospec) planar_tile<NP, false>(posA, k, s_vis, s_hdr, s_col, s_row, s_rowq, s_colq, nzk, px, py0, W, H, out);   // (no pixel of the tile lies in the highlight cone: classify_tiles)
+                    else planar_tile<NP, true>(posA, k, s_vis, s_hdr, s_col, s_row, s_rowq, s_colq, nzk, px, py0, W, H, out);
+                    continue;
                 }
-                continue;
+                bool boxesOnly = true;   // ... and boxes of other frames of reference (the time bar, a carried object): overlay_tile
+                for (unsigned long long m = others; m; m &= m - 1ull)
+                    boxesOnly = boxesOnly && ((unsigned)__builtin_amdgcn_readfirstlane(__float_as_uint(s_vis[2 * (__ffsll((long long)m) - 1)].w)) & 15u) == (unsigned)PRIM_BOX;
+                if (boxesOnly && fa.planar != 2) {
+                    RT_COUNT(13, 1);
+                    overlay_tile<SHAPES, POS_MASK, NP>(posA, k, others, s_vis, s_hdr, camv, viewer, s_col, s_row, s_rowq, s_colq, nzm0, nzm1, nzm2, px, py0, W, H, out);
+                    continue;
+                }
             }
-            if ((mv0 & (mv0 - 1ull)) == 0ull && cover != 0u) {   // one box, and one of its faces covers the tile
-                const int k = (int)cover - 1;
-                RT_COUNT(2, 1);
-                planar_tile<NP>(__ffsll((long long)mv0) - 1, k, s_vis, s_hdr, s_col, s_row, s_rowq, s_colq, k == 0 ? nzm0 : k == 1 ? nzm1 : nzm2, px, py0, W, H, out);
-                continue;
-            }
+#if defined(MV_RASTER_DEBUG_SKIP) && MV_RASTER_DEBUG_SKIP == 2   // (measurement builds: general tiles cost nothing)
+            continue;
+#endif
+            RT_COUNT(4, 1);
+            RT_COUNT(5, __popcll(mv0 & wb0));
+            RT_COUNT(6, __popcll(mv0 & ~wb0));
+            general_tile<SHAPES, POS_MASK, NP>(mv0, wb0, s_vis, s_hdr, camv, viewer, s_col, s_row, s_rowq, s_colq, nzm0, nzm1, nzm2, px, py0, W, H, out);
+            continue;
         } else {   // tile culling: one primitive per lane, four integer compares against its screen rectangle
             int l2 = lane;
             asm volatile("" : "+v"(l2));   // (the rectangle's address is formed here, per tile: kept across the loop it was spilled at seven waves per SIMD)
@@ -1652,9 +1846,9 @@ static void rdbg_dump()
                     c[10], double(c[11]) / c[10], double(c[12]) / c[10], double(c[15]) / c[10], double(c[13]) / c[10], double(c[14]) / c[10], double(c[9]) / c[10], double(c[8]) / c[10],
                     double(c[7]) / c[10], double(c[6]) / c[10]);
         if (got && c[4])
-            fprintf(stderr, "raster census (all launches): classified tiles %llu (empty %llu, planar %llu), unclassified %llu, general-path tiles %llu: slab tests %.2f and other primitives %.2f per tile, "
-                            "shading wave-rows %.2f of 2, hit pixels %.1f of 128, wave-rows shading a non-box %.3f\n",
-                    c[0], c[1], c[2], c[3], c[4], double(c[5]) / c[4], double(c[6]) / c[4], double(c[7]) / c[4], double(c[8]) / c[4], double(c[9]) / c[4]);
+            fprintf(stderr, "raster census (all launches): classified tiles %llu (empty %llu, planar %llu of which %llu without the highlight test, covered + overlay %llu), unclassified %llu, general-path tiles %llu: "
+                            "slab tests %.2f and other primitives %.2f per tile\n",
+                    c[0], c[1], c[2], c[12], c[13], c[3], c[4], double(c[5]) / c[4], double(c[6]) / c[4]);
     }
     std::vector<unsigned long long> h((size_t)16384 * 4 * 8);
     if (hipMemcpy(h.data(), g_rdbg, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
@@ -1741,7 +1935,7 @@ static FastArgs fast_args_of(const GymView &gv, const PublishTo *publish)
     fa.pub_rewards = publish ? publish->rewards : nullptr; fa.pub_true = publish ? publish->true_objective : nullptr; fa.pub_done = publish ? publish->done : nullptr;
     fa.pub_n = publish ? frames : 0;
     const char *pe = getenv("MV_PLANAR");   // (read at every launch: the two paths are compared within one process by tests/test_fast_pixels_gpu.py)
-    fa.planar = !(pe && *pe && atoi(pe) == 0);
+    fa.planar = pe && *pe ? atoi(pe) : 1;   // (2: classified, but without overlay_tile -- comparisons)
     fa.graded = 0; fa.tail_div = 0; fa.tail_split = 0;
     fa.hist_done = nullptr; fa.wg_total = 0;
     { const char *ns = getenv("MV_RASTER_NOSORT"); fa.nosort = ns && atoi(ns) != 0; }

@@ -482,7 +482,7 @@ def test_overlapped_passes_with_a_late_consumer(hip, k, R, rings):
     assert torch.equal(log_o, want_o), "a consumer enqueued right after its call read something else than single ticks produce"
     assert torch.equal(log_r.view(torch.int32), want_r.view(torch.int32)) and torch.equal(log_d, want_d)
     if not rings:   # the single arrays hold the LAST tick's values, whatever ran in between
-        assert a.get_last_rewards().tobytes() == b.get_last_rewards().tobytes() and a.get_dones().tobytes() == b.get_dones().tobytes()
+        assert a.get_rewards_array().tobytes() == b.get_rewards_array().tobytes() and a.get_dones().tobytes() == b.get_dones().tobytes()
     for e in range(N):
         assert a.debug_snapshot_bytes(e).tobytes() == b.debug_snapshot_bytes(e).tobytes(), e
     a.close(); b.close()
