@@ -378,7 +378,7 @@ def main():
         gym.set_pixel_mode(args.pixels)
     else:
         from megaverse_amd.extension import MegaverseGym
-        gym = MegaverseGym(args.scenario, W, H, n_env, A, 8, False, {},   # 8 = episode-feeder threads (host-generated scenarios)
+        gym = MegaverseGym(args.scenario, W, H, n_env, A, 0, False, {},   # 0 = episode-feeder threads: this rank's share of the host's cores (host-generated scenarios)
                            device=local_rank, env_offset=rank * n_env, total_envs=world * n_env)
         gym.set_stream(torch.cuda.current_stream().cuda_stream)
         gym.set_pixel_mode(args.pixels)

@@ -32,7 +32,9 @@ typedef struct mv_config {
     int32_t obs_width, obs_height; /* megaverse.cpp:38 w, h */
     int32_t num_envs;              /* envs simulated by THIS process (one process per GPU) */
     int32_t num_agents_per_env;
-    int32_t num_simulation_threads;/* worker threads of the background episode generator (Obstacles, Collect); stepping itself has no threads */
+    int32_t num_simulation_threads;/* worker threads of the background episode generator (every scenario but TowerBuilding, whose generator runs on the device);
+                                      <= 0: this process's share of the host's cores (cores it may use / ranks of the job, at most 16); MV_FEEDER_THREADS overrides;
+                                      stepping itself has no threads */
     int32_t use_vulkan;            /* accepted for signature parity; ignored */
     int32_t device;                /* HIP device ordinal */
     const char *const *param_keys; /* FloatParams (megaverse.cpp:45, scenario.hpp:225-242) */

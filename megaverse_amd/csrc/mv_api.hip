@@ -7,6 +7,8 @@
 // There is NO CPU fallback: if no HIP device can be opened mv_create fails.
 #include <hip/hip_runtime.h>
 
+#include <sched.h>
+
 #include <algorithm>
 #include <cctype>
 #include <cstdio>
@@ -14,6 +16,7 @@
 #include <memory>
 #include <random>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/megaverse_hip.h"
@@ -28,6 +31,8 @@
 
 namespace mv {
 void launch_reset(const GymView &gv, int force_all, hipStream_t stream);
+void launch_tower_draw(const GymView &gv, hipStream_t stream);                          // TowerBuilding: tops every env's ring of drawn episodes up (mv_reset.hip)
+void launch_tower_seed(const GymView &gv, const uint32_t *seeds, hipStream_t stream);   // Env::seed for every env's generator
 // step kernels: one 256-thread workgroup per env = the tick (wave 0) + the frame setup of the env's frames for a W x H observation
 // (render = 0: tick only)
 void launch_step(const GymView &gv, hipStream_t stream, int W, int H, int render, hipEvent_t done = nullptr);
@@ -174,6 +179,14 @@ struct mv_gym {
     uint8_t *dBlobs = nullptr, *hBlobs = nullptr;   // device [N][blobBytes], pinned feeder slots [N][blobBytes]
     size_t blobBytes = 0;                           // sizeof(EpisodeBlob) or sizeof(CollectBlob)
     bool hostEpisodes() const { return scenario != SCN_TOWER; }
+    // TowerBuilding: the episode generator's serial half (tower_draw_kernel, ~47 us of one wavefront per finished env) runs on a stream of its own,
+    // behind the step launch whose finished envs it refills and beside everything else; a stepping call waits for the draw launch BEFORE the last one
+    // (two episodes are resident per env: what the last launch is still drawing is not needed yet).  drawPeriod: ticks between draw launches -- 8 where
+    // episodes last at least 64 ticks, every call where they can be a few ticks long (those calls are one tick each: mv_step_n).
+    hipStream_t genStream = nullptr;
+    hipEvent_t stepForDraw = nullptr, drawDone[2] = {nullptr, nullptr};
+    unsigned long long drawCount = 0;
+    int ticksSinceDraw = 0, drawPeriod = 1;
     int *dStatus = nullptr, *hStatus = nullptr;     // [N + 2]: consumed per env, total, error flags (device, pinned mirror)
     int lastTotalSeen = 0;
     bool statusPending = false, refillForce = true;
@@ -200,12 +213,6 @@ struct mv_gym {
 // ------------------------------------------------------------------------------------------------
 // small utility kernels
 // ------------------------------------------------------------------------------------------------
-__global__ void set_seeds_kernel(EnvHeader *hdr, const uint32_t *seeds, int n)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { hdr[i].next_seed = seeds[i]; hdr[i].seed_is_env_seed = 1; }
-}
-
 __global__ void masks_from_multidiscrete_kernel(const int32_t *md, int32_t *masks, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -339,6 +346,35 @@ static int sim_join(mv_gym *g)
     return 0;
 }
 
+// TowerBuilding: before anything on the caller's stream touches the generators or the ring of drawn episodes (mv_reset, mv_seed): the last draw launch
+static int tower_join(mv_gym *g)
+{
+    if (g->genStream && g->drawCount > 0) HIP_TRY(hipStreamWaitEvent(g->stream, g->drawDone[(size_t)((g->drawCount - 1) & 1ull)], 0));
+    return 0;
+}
+
+// TowerBuilding, a stepping call: before its step launches the simulation stream waits for the draw launch BEFORE the last one (two episodes are resident per
+// env; what the last launch may still be drawing replaces an episode consumed a call ago: not needed yet) ...
+static int tower_draw_before(mv_gym *g, hipStream_t sim)
+{
+    if (g->genStream && g->drawCount >= 2) HIP_TRY(hipStreamWaitEvent(sim, g->drawDone[(size_t)(g->drawCount & 1ull)], 0));
+    return 0;
+}
+// ... and behind them, every drawPeriod ticks, the draw kernel goes to its own stream: it tops up the rings of the envs that finished
+static int tower_draw_after(mv_gym *g, hipStream_t sim, int ticks)
+{
+    if (!g->genStream) return 0;
+    g->ticksSinceDraw += ticks;
+    if (g->ticksSinceDraw < g->drawPeriod) return 0;
+    g->ticksSinceDraw = 0;
+    HIP_TRY(hipEventRecord(g->stepForDraw, sim));
+    HIP_TRY(hipStreamWaitEvent(g->genStream, g->stepForDraw, 0));
+    launch_tower_draw(g->gv, g->genStream);
+    HIP_TRY(hipEventRecord(g->drawDone[(size_t)(g->drawCount & 1ull)], g->genStream));
+    ++g->drawCount;
+    return 0;
+}
+
 static int publish_outputs(mv_gym *g, int q, const OutPtrs &o)   // on the caller's stream
 {
     const GymView &v = g->gvp[q];
@@ -391,6 +427,30 @@ static bool scenario_from_name(const std::string &scen, int &scenario, ObstacleC
     else if (scen == "hexexplore") scenario = SCN_HEX_EXPLORE;                         // scenarios/init.hpp:48
     else return false;
     return true;
+}
+
+// cores this process may use: the affinity mask, capped by the cgroup's CPU quota (a container with 16 of the host's 192 cores sees all of them in the mask)
+static int usable_host_cores()
+{
+    int n = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+    for (const char *path : {"/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"}) {
+        FILE *f = std::fopen(path, "r");
+        if (!f) continue;
+        char a[64] = {0}, b[64] = {0};
+        const int got = std::fscanf(f, "%63s %63s", a, b);
+        std::fclose(f);
+        if (got >= 1 && std::strcmp(a, "max") != 0 && std::atol(a) > 0) {
+            long period = got >= 2 ? std::atol(b) : 0;
+            if (period <= 0) {   // cgroup v1: the period is in a file of its own
+                if (FILE *p = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(p, "%ld", &period) != 1) period = 0; std::fclose(p); }
+            }
+            if (period > 0) n = std::min(n, std::max(1, (int)((std::atol(a) + period - 1) / period)));
+        }
+        break;
+    }
+    return std::max(1, n);
 }
 
 // the simulation stream; MV_SIM_PRIORITY=low|high gives its queue another priority than the caller's (an experiment knob: measured, no gain)
@@ -467,7 +527,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     gv.scenario = scenario;
     gv.box_stride = collect ? COLLECT_MAX_BOXES : MAX_BOXES;
     gv.reward_stride = collect ? COLLECT_MAX_REWARDS : MAX_REWARDS;
-    g->blobBytes = collect ? sizeof(CollectBlob) : obstacles ? sizeof(EpisodeBlob) : rearrange ? sizeof(RearrangeBlob) : sokoban ? sizeof(SokobanBlob) : hex ? sizeof(HexBlob) : 0;
+    g->blobBytes = collect ? sizeof(CollectBlob) : obstacles ? sizeof(EpisodeBlob) : rearrange ? sizeof(RearrangeBlob) : sokoban ? sizeof(SokobanBlob) : hex ? sizeof(HexBlob) : sizeof(TowerBlob);
     // ONE arena for all simulator state: a step touches ~8 arrays per env, separate small allocations
     // cost a TLB miss each per wave (measured: 83 % of the physics kernel's time was spent waiting on
     // ~30 memory operations); one large allocation is backed by large pages.
@@ -480,7 +540,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     const size_t szTerrain = obstacles ? up(N * MAX_TERRAIN * sizeof(TerrainBox)) : 0,
                  szRewObj = hostEpisodes ? up(N * (size_t)gv.reward_stride * sizeof(MovableObject)) : 0,
                  szHeight = collect ? up(N * (size_t)HM_BYTES) : 0, szItems = rearrange ? up(N * MAX_ITEMS * sizeof(ArrangementItem)) : 0, szCells = sokoban ? up(N * (size_t)(SOKO_DIM * SOKO_DIM)) : 0,
-                 szHexB = hex ? up(N * (size_t)HEX_MAX_BOXES * sizeof(HexRec)) : 0, szHexO = hex ? up(N * (size_t)HEX_MAX_OBJS * sizeof(HexRec)) : 0, szBlobs = up(N * g->blobBytes * (size_t)g->spares), szCnt = up((N + 2) * sizeof(int32_t));
+                 szHexB = hex ? up(N * (size_t)HEX_MAX_BOXES * sizeof(HexRec)) : 0, szHexO = hex ? up(N * (size_t)HEX_MAX_OBJS * sizeof(HexRec)) : 0, szBlobs = up(N * g->blobBytes * (size_t)g->spares), szCnt = up((N + 2) * sizeof(int32_t)), szGen = hostEpisodes ? 0 : up(N * sizeof(TowerGen));
     gv.vis_stride = hex ? 2048 : collect ? 1024 : 256;
     if (const char *e = getenv("MV_DEBUG_VIS_STRIDE")) gv.vis_stride = std::min(gv.vis_stride, std::max(8, atoi(e)));   // (tests: provoke ST_VISIBLE)
     gv.debug_redo = getenv("MV_DEBUG_FORCE_REDO") && atoi(getenv("MV_DEBUG_FORCE_REDO")) ? 1 : 0;   // (tests: mv_tick_tower.h's sequential redo)
@@ -494,7 +554,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     const bool depthSortOn = !(getenv("MV_DEPTH_SORT") && atoi(getenv("MV_DEPTH_SORT")) == 0);
     const size_t szSort = gv.vis_stride > 256 && depthSortOn ? up(NA * (size_t)gv.vis_stride * 40) : 0;
     const size_t total = szSort + szHdr + szBoxes + szObj + szAg + szAct + szRew + szDone + szObjv + szMd + (hostEpisodes ? 0 : szChunk) + szObs + szTerrain +
-                         szRewObj + szHeight + szItems + szCells + szHexB + szHexO + szBlobs + szCnt + (size_t)g->slots * szParity + szHist;
+                         szRewObj + szHeight + szItems + szCells + szHexB + szHexO + szBlobs + szCnt + szGen + (size_t)g->slots * szParity + szHist;
     {
         hipError_t e_ = hipMalloc((void **)&g->arena, total);
         if (e_ != hipSuccess) { mv_destroy(g); return fail(std::string("hipMalloc arena: ") + hipGetErrorString(e_)); }
@@ -516,11 +576,10 @@ int mv_create(const mv_config *cfg, mv_gym **out)
         g->dStatus = (int *)p; p += szCnt;
         gv.episode_status = g->dStatus;
         if (obstacles) { gv.terrain = (TerrainBox *)p; p += szTerrain; }
-        if (hostEpisodes) {
-            gv.rewards_obj = (MovableObject *)p; p += szRewObj;
-            g->dBlobs = p; p += szBlobs;
-            gv.blobs = g->dBlobs;
-        }
+        if (hostEpisodes) { gv.rewards_obj = (MovableObject *)p; p += szRewObj; }
+        g->dBlobs = p; p += szBlobs;   // the ring of resident next episodes: uploaded by the host's feeder, or (TowerBuilding) drawn on the device
+        gv.blobs = g->dBlobs;
+        if (!hostEpisodes) { gv.tower_gen = (TowerGen *)p; p += szGen; }
         if (collect) { gv.heightmap = (int8_t *)p; p += szHeight; }
         if (rearrange) { gv.items = (ArrangementItem *)p; p += szItems; }
         if (sokoban) { gv.soko_cells = p; p += szCells; }
@@ -594,16 +653,40 @@ int mv_create(const mv_config *cfg, mv_gym **out)
         }
         std::memset(g->hStatus, 0, (N + 2) * sizeof(int));
     }
-    if (hostEpisodes) {
-        g->uploaded.assign(N, 0);
-        g->feederThreads = std::min(32, std::max(1, (int)cfg->num_simulation_threads));
-        if (const char *e = getenv("MV_FEEDER_THREADS")) g->feederThreads = std::min(64, std::max(1, atoi(e)));
+    {
         // An env needs a fresh resident episode at every reset.  Two are kept resident, and the consumed counts are read back
         // every 16th step -- unless episodes can time out within a few ticks (a small or negative episodeLengthSec: the Obstacles
-        // family never goes below 35 s per platform, Collect and Rearrange take the parameter as is), then after every step.
+        // family never goes below 35 s per platform, the others take the parameter as is -- TowerBuilding adds 4 s per object), then after every step.
         const float minLenSec = scenario == SCN_OBSTACLES ? std::max(episodeLen, 35.0f) : episodeLen;
         g->statusPeriod = minLenSec * 15.0f >= 64.0f ? 16 : 1;
         if (const char *e = getenv("MV_STATUS_PERIOD")) g->statusPeriod = std::max(1, atoi(e));   // (tests: provoke starvation)
+    }
+    if (!hostEpisodes) {   // TowerBuilding: the generators' state (unseeded envs take their seed from random_device, env.hpp:169), the draw stream
+        std::vector<TowerGen> tg(N);
+        std::random_device rdev;
+        for (auto &t : tg) { t.seed = (uint32_t)rdev(); t.seed_is_env_seed = 1; t.generated = 0; t.pad = 0; }
+        bool ok = hipMemcpy(gv.tower_gen, tg.data(), N * sizeof(TowerGen), hipMemcpyHostToDevice) == hipSuccess &&
+                  hipEventCreateWithFlags(&g->stepForDraw, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&g->drawDone[0], hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&g->drawDone[1], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            mv_destroy(g);
+            return fail("mv_create: generator state / draw stream allocation failed");
+        }
+        // (the draws share the side stream of the status read-backs: a stream more per gym and HIP's few hardware queues are oversubscribed -- measured with
+        // two gyms stepped in turn, each with its own draw stream: 13.7 -> 8.5 M obs/s, the two gyms' caller streams had come to share a queue)
+        g->genStream = g->copyStream;
+        g->drawPeriod = g->statusPeriod > 1 ? 8 : 1;
+    }
+    if (hostEpisodes) {
+        g->uploaded.assign(N, 0);
+        // Worker threads of the episode feeder: what the caller asks for (MegaverseGym's num_simulation_threads), or -- 0 / negative -- this process's
+        // share of the host: the cores it may run on (affinity mask, cgroup quota) divided by the ranks of the job (total_envs / num_envs shards, one
+        // process per GPU), at most 16.  What a thread sustains (episodes per second, measured: DESIGN.md 3.2): ObstaclesHard 15 k, ObstaclesEasy 44 k,
+        // Collect 4.5 k, HexMemory 22 k, Rearrange 330 k; what one GPU consumes at its benchmark rate: ObstaclesHard ~7 k, Collect ~12 k.
+        g->feederThreads = cfg->num_simulation_threads > 0 ? std::min(32, (int)cfg->num_simulation_threads)
+                                                           : std::max(1, std::min(16, usable_host_cores() / std::max(1, g->totalEnvs / std::max(1, g->N))));
+        if (const char *e = getenv("MV_FEEDER_THREADS")) g->feederThreads = std::min(64, std::max(1, atoi(e)));
         g->uploadEvents.assign(64, nullptr);
         bool ok = hipHostMalloc((void **)&g->hBlobs, N * g->blobBytes, hipHostMallocDefault) == hipSuccess;
         for (auto &e : g->uploadEvents) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
@@ -670,6 +753,7 @@ int mv_close(mv_gym *g)
     if (g->simStream) (void)hipStreamSynchronize(g->simStream);
     (void)hipStreamSynchronize(g->stream);
     (void)hipGetLastError();
+    if (g->genStream) (void)hipStreamSynchronize(g->genStream);
     if (g->copyStream) (void)hipStreamSynchronize(g->copyStream);
     (void)hipDeviceSynchronize();
     g->feeder.reset();   // joins the workers before their slots go away
@@ -742,6 +826,9 @@ int mv_close(mv_gym *g)
         if (g->callStart[i]) (void)hipEventDestroy(g->callStart[i]);
         g->passStream[i] = nullptr; g->callStart[i] = nullptr;
     }
+    if (g->stepForDraw) (void)hipEventDestroy(g->stepForDraw);
+    for (hipEvent_t &e : g->drawDone) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    g->genStream = nullptr; g->stepForDraw = nullptr;
     if (g->copyStream) (void)hipStreamDestroy(g->copyStream);
     if (g->simStream) (void)hipStreamDestroy(g->simStream);
     for (hipEvent_t &e : g->userMark) { if (e) (void)hipEventDestroy(e); e = nullptr; }
@@ -846,11 +933,14 @@ int mv_seed(mv_gym *g, int32_t seed)
         g->feeder->reseed(seeds, first);
         return 0;
     }
-    if (sim_join(g)) return -1;
+    // TowerBuilding: Env::seed on the device-side generators -- what they drew ahead from the old stream is dropped, the rings are drawn again from the new one
+    if (sim_join(g) || tower_join(g)) return -1;
     uint32_t *d = nullptr;
     HIP_TRY(hipMalloc((void **)&d, g->N * sizeof(uint32_t)));
     HIP_TRY(hipMemcpyAsync(d, seeds.data(), g->N * sizeof(uint32_t), hipMemcpyHostToDevice, g->stream));
-    hipLaunchKernelGGL(set_seeds_kernel, dim3((g->N + 255) / 256), dim3(256), 0, g->stream, g->gv.hdr, d, g->N);
+    launch_tower_seed(g->gv, d, g->stream);
+    launch_tower_draw(g->gv, g->stream);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(g->stream));
     HIP_TRY(hipFree(d));
     return 0;
@@ -1031,9 +1121,13 @@ int mv_reset(mv_gym *g)
         HIP_TRY(hipEventRecord(g->stepDone, g->stream));   // (the reset kernel reads the ring too)
         g->stepDoneValid = true;
         if (read_back_status(g, g->stream)) return -1;  // the second resident episodes go up with the next steps
-    } else {
+    } else {   // TowerBuilding: every ring topped up, every env takes its next episode, the rings topped up again
+        if (tower_join(g)) return -1;
         const OutPtrs outs = last_outputs(g);
-        launch_reset(view(g, g->parity, &outs), 1, g->stream);
+        const GymView v = view(g, g->parity, &outs);
+        launch_tower_draw(v, g->stream);
+        launch_reset(v, 1, g->stream);
+        launch_tower_draw(v, g->stream);
     }
     HIP_TRY(hipGetLastError());
     g->wasReset = true;
@@ -1192,6 +1286,7 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
     }
     for (int i = 0; i < n; ++i) {
         mv_gym *g = gs[i];
+        if (tower_draw_before(g, sim)) return -1;
         g->simMustWaitUser = false;
         g->simOnOwnStream = own;
         g->markCount = L->markCount;
@@ -1291,6 +1386,8 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
         simDoneRodeAlong = simDoneRodeAlong || simDoneRides;
     }
     if (own && !simDoneRodeAlong) HIP_TRY(hipEventRecord(L->simDone, sim));   // (not pipelined: stream order does it)
+    for (int i = 0; i < n; ++i)
+        if (tower_draw_after(gs[i], sim, k)) return -1;
     // (every step kernel regenerates / swaps the next episode into the envs it finishes)
     // An env needs a fresh resident episode only at its NEXT reset, normally hundreds of steps away, and two are resident: the status
     // words are read back -- and the refill considered -- every statusPeriod-th step (16; 1 when episodes can be a few ticks long).

@@ -41,7 +41,7 @@ public:
     {
         double sum = 0, weight = 1;
         for (int o = 0; o < octaves; ++o) {
-            sum += at(x, y, 0) * weight;
+            sum += at_z0(x, y) * weight;
             x *= 2; y *= 2; weight /= 2;
         }
         return std::clamp<double>(sum * 0.5 + 0.5, 0, 1);
@@ -57,6 +57,20 @@ private:
         h &= 15;
         const double u = h < 8 ? x : y, v = h < 4 ? y : (h == 12 || h == 14) ? x : z;
         return ((h & 1) ? -u : u) + ((h & 2) ? -v : v);
+    }
+    // at(x, y, 0): the plane the landscape samples (perlin_noise.hpp:315-318 calls the 3-D noise with z = 0).  There w = smooth(0) = 0 and the result
+    // is near + 0 * (far - near) = near: the four corners of the far layer are not evaluated (they were half of this generator's arithmetic).  The only
+    // thing lost is the sign of a zero result, which the sum over the octaves does not see.
+    double at_z0(double x, double y) const
+    {
+        const double fx = std::floor(x), fy = std::floor(y);
+        const int ix = int(fx) & 255, iy = int(fy) & 255;
+        x -= fx; y -= fy;
+        const double u = smooth(x), v = smooth(y);
+        const int a = perm_[ix] + iy, b = perm_[ix + 1] + iy;
+        const int aa = perm_[a], ab = perm_[a + 1], ba = perm_[b], bb = perm_[b + 1];
+        return blend(v, blend(u, corner(perm_[aa], x, y, 0.0), corner(perm_[ba], x - 1, y, 0.0)),
+                        blend(u, corner(perm_[ab], x, y - 1, 0.0), corner(perm_[bb], x - 1, y - 1, 0.0)));
     }
     double at(double x, double y, double z) const
     {

@@ -332,6 +332,9 @@ void generate_obstacles_episode(std::mt19937 &rng, const ObstacleConfig &cfg, in
                 for (int z = b.lo.z; z < b.hi.z; ++z) at(x, y, z) = v;
     };
     const uint8_t v_floor = VX_SOLID | VX_OPAQUE, v_wall = uint8_t(VX_SOLID | (draw_walls ? VX_OPAQUE : 0) | (1 << VX_COLOR_SHIFT));
+    // (the merge below visits the classes in key order; only these two values are ever painted: the ten other classes are not scanned for -- the merge,
+    // twelve passes over ~10^5 cells, was 5/6 of this generator's time)
+    const unsigned present = (1u << (((v_floor & 3) << 2) | (v_floor >> VX_COLOR_SHIFT))) | (1u << (((v_wall & 3) << 2) | (v_wall >> VX_COLOR_SHIFT)));
     for (const auto &p : chain) {
         for (const auto &b : p.floor_boxes) paint(placed(p.root, b), v_floor);
         for (const auto &b : p.wall_boxes) paint(placed(p.root, b), v_wall);
@@ -345,6 +348,7 @@ void generate_obstacles_episode(std::mt19937 &rng, const ObstacleConfig &cfg, in
         auto idx = [&](int x, int y, int z) { return (size_t(y) * nz + z) * nx + x; };
         int nb = 0;
         for (int key = 4; key < 16; ++key) {
+            if (!((present >> key) & 1u)) continue;
             const int type = key >> 2, slot = key & 3;
             auto is = [&](int x, int y, int z) {
                 if (x < 0 || y < 0 || z < 0 || x >= nx || y >= ny || z >= nz) return false;

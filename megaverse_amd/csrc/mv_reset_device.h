@@ -37,12 +37,23 @@ __device__ __forceinline__ float building_reward_coeff(int h)
     return res;
 }
 
-// Regenerates env `env` (the caller has decided that it must be: done, or a forced reset).  Called by all 64 lanes of the
-// env's wavefront, which must be the whole workgroup (the function orders its LDS traffic with wave_sync()).
-__device__ __forceinline__ void reset_env(const GymView &gv, int env, int force_all)
+// ---- Env::reset in two halves -----------------------------------------------------------------------------------------------------------
+// tower_draw:     everything that consumes the env's random stream -- the serial part: seeding mt19937 is 623 dependent steps, the whole draw ~47 us
+//                 of one wavefront, 7 KB of LDS -- into a TowerBlob of the env's ring of resident episodes.  Runs in tower_draw_kernel, launched
+//                 behind the step kernels on a stream of its own (mv_api.hip), never inside a tick.
+// tower_swap_in:  the blob -> voxel chunk, objects, boxes, header, agents: lane-parallel copies, a few microseconds, no LDS.  Runs at the tail of a
+//                 finishing env's tick (VectorEnv::step's auto-reset, vector_env.cpp:93-105) and in the reset kernel (mv_reset).
+// Until round 5 both halves ran inside the finishing env's tick: its wave was the launch's straggler by ~47 us, and every step workgroup -- resident
+// for a whole batched call beside the observation passes -- carried the generator's LDS.  The episodes are the same, byte for byte: the draws happen
+// in the reference's order (the parts of Env::reset that were moved behind them consume nothing).
+
+// Draws episode number `seq` of env `env` (the next one of its generator: tg->generated + 1) into its ring slot.  Called by all 64 lanes of the env's
+// wavefront, which must be the whole workgroup (the function orders its LDS traffic with wave_sync()).
+__device__ __forceinline__ void tower_draw(const GymView &gv, int env, int seq)
 {
     const int lane = lane_id();
-    EnvHeader *hdr = gv.hdr + env;
+    TowerGen *tg = gv.tower_gen + env;
+    TowerBlob *blob = const_cast<TowerBlob *>(reinterpret_cast<const TowerBlob *>(gv.blobs)) + (size_t)env * gv.spares + (seq - 1) % gv.spares;
     __shared__ __attribute__((aligned(16))) uint32_t s_mt[624];
     __shared__ __attribute__((aligned(16))) uint16_t s_cand[32 * 32];
     __shared__ __attribute__((aligned(16))) uint16_t s_steps[32 * 32];   // the shuffle's swap partners
@@ -52,8 +63,8 @@ __device__ __forceinline__ void reset_env(const GymView &gv, int env, int force_
     Mt19937 g{s_mt, 624};
 
     // ---- Env::reset: seed = randRange(0, 1<<30, rng); rng.seed(seed)  (env.cpp:61-62)
-    uint32_t seed = hdr->next_seed;
-    if (hdr->seed_is_env_seed) {
+    uint32_t seed = tg->seed;
+    if (tg->seed_is_env_seed) {
         mt_seed(g, seed);
         seed = (uint32_t)rand_range(g, 0, 1 << 30);
     }
@@ -92,95 +103,26 @@ __device__ __forceinline__ void reset_env(const GymView &gv, int env, int force_
     const int numObjects = min(spawnObjects + matL * matW, (int)MAX_OBJECTS);
 
     // objects: the random ones (:53-66) then the materials rectangle (:68-72)
-    for (int i = lane; i < numObjects; i += 64) {
-        MovableObject o;
+    for (int i = lane; i < MAX_OBJECTS; i += 64) {
+        MovableObject o{0, 0, 0, 0};
         if (i < spawnObjects) {
             const uint16_t c = s_cand[nSpawn + i];
             const int x = c >> 8, z = c & 255;
             const bool inMat = x >= matX && x < matX + matL && z >= matZ && z < matZ + matW;
             o.x = (int8_t)x; o.y = (int8_t)(inMat ? 2 : 1); o.z = (int8_t)z;
-        } else {
+        } else if (i < numObjects) {
             const int j = i - spawnObjects;
             o.x = (int8_t)(matX + j / matW); o.y = 1; o.z = (int8_t)(matZ + j % matW);
         }
-        o.state = 0;
         s_obj[i] = o;
+        blob->objects[i] = o;
     }
+    wave_sync();
 
     // vg.addPlatform(platform, layoutColor, randomLayoutColor(rng), randomBool(rng)) (:145); the
     // reference is built with GCC, which evaluates the arguments right to left.
     const bool drawWalls = random_bool(g);
     const unsigned wallColor = random_layout_color(g);
-
-    // ---- voxel chunk: floor, then the four walls override (platforms.hpp:167-190, component_voxel_grid.hpp:73-90).  One 16-cell run per lane
-    // per round, formed in registers and stored straight to the env's chunk (coalesced 16 B / lane); the object bits are then or-ed into
-    // their bytes in global memory.  (Until r06 the image was built in 16 KB of LDS first: the step kernel -- every step workgroup, resident
-    // for a whole batched call -- carried 24 KB of LDS for a generator that runs for one env in a thousand ticks, and four of them per CU left
-    // room for three workgroups of the observation pass instead of seven.)
-    uint8_t *gbytes = gv.chunk + (size_t)env * CHUNK_BYTES;
-    uint4 *gchunk = reinterpret_cast<uint4 *>(gbytes);
-    const uint32_t vFloor = VX_SOLID | VX_OPAQUE;
-    const uint32_t vWall = VX_SOLID | (drawWalls ? VX_OPAQUE : 0) | (1u << VX_COLOR_SHIFT);
-    for (int grp = lane; grp < CHUNK_BYTES / 16; grp += 64) {
-        const int x0 = (grp & 1) * 16, z = (grp >> 1) & (CZ - 1), y = grp >> 6;
-        uint32_t w[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            uint32_t word = 0;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int x = x0 + q * 4 + b;
-                uint32_t v = 0;
-                if (x < length && z < width) {
-                    if (y == 0) v = vFloor;
-                    if (y < height && (x == 0 || x == length - 1 || z == 0 || z == width - 1)) v = vWall;
-                }
-                word |= v << (8 * b);
-            }
-            w[q] = word;
-        }
-        gchunk[grp] = make_uint4(w[0], w[1], w[2], w[3]);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the fill before the bytes below are read back (other lanes' stores)
-    wave_sync();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    for (int i = lane; i < numObjects; i += 64) {
-        const MovableObject o = s_obj[i];
-        volatile uint8_t *cell = gbytes + (o.y * CZ + o.z) * CX + o.x;
-        *cell = (uint8_t)(*cell | VX_OBJECT);   // distinct cells, byte-wide read-modify-write
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    wave_sync();
-
-    // ---- write-out: objects, boxes, header, agents
-
-    MovableObject *gobj = gv.objects + (size_t)env * MAX_OBJECTS;
-    for (int i = lane; i < MAX_OBJECTS; i += 64) {
-        MovableObject o{0, 0, 0, 0};
-        if (i < numObjects) o = s_obj[i];
-        gobj[i] = o;
-    }
-
-    // canonical layout parallelepipeds (== the generic greedy merge the oracle runs on the voxels:
-    // keys sorted by (type, slot), scan y,z,x, grow x then z then y).  For this room that is the
-    // interior floor slab and four wall slabs.
-    if (lane < TOWER_BOXES) {
-        LayoutBox b{{0, 0, 0}, 0, {0, 0, 0}, 0};
-        const int wallType = VX_SOLID | (drawWalls ? VX_OPAQUE : 0);
-        const int floorIdx = drawWalls ? 0 : 4;       // key 12 vs wall key 13 (drawn) / 5 (invisible)
-        const int wallIdx = drawWalls ? lane - 1 : lane;
-        if (lane == floorIdx) {
-            b.min[0] = 1; b.min[1] = 0; b.min[2] = 1; b.max[0] = length - 1; b.max[1] = 1; b.max[2] = width - 1;
-            b.type = VX_SOLID | VX_OPAQUE; b.slot = 0;
-        } else if (lane < 5) {
-            b.type = wallType; b.slot = 1; b.min[1] = 0; b.max[1] = height;
-            if (wallIdx == 0) { b.min[0] = 0; b.min[2] = 0; b.max[0] = length; b.max[2] = 1; }
-            if (wallIdx == 1) { b.min[0] = 0; b.min[2] = 1; b.max[0] = 1; b.max[2] = width; }
-            if (wallIdx == 2) { b.min[0] = length - 1; b.min[2] = 1; b.max[0] = length; b.max[2] = width; }
-            if (wallIdx == 3) { b.min[0] = 1; b.min[2] = width - 1; b.max[0] = length - 1; b.max[2] = width; }
-        }
-        gv.boxes[(size_t)env * MAX_BOXES + lane] = b;
-    }
 
     const int bz[4] = {bzX, bzX + bzL, bzZ, bzZ + bzW};
 
@@ -194,10 +136,111 @@ __device__ __forceinline__ void reset_env(const GymView &gv, int env, int force_
     // ---- agents (scenario_default.hpp:80-97, agent.cpp:24-65); one frand per agent, in order
     for (int k = 0; k < A; ++k) {
         const uint16_t c = s_cand[k < nSpawn ? k : 0];
-        const int sx = c >> 8, sz = c & 255;
         const float rot = frand(g) * 3.14159274f * 2;
+        if (lane == 0) { blob->spawn[k] = (int32_t)c; blob->yaw_rot[k] = rot; }
+    }
+
+    // value the next Env::reset() will draw; nothing consumes the env rng during an episode
+    const uint32_t nextSeed = (uint32_t)rand_range(g, 0, 1 << 30);
+
+    if (lane == 0) {
+        blob->L = length; blob->H = height; blob->W = width;
+        blob->bz[0] = bz[0]; blob->bz[1] = bz[1]; blob->bz[2] = bz[2]; blob->bz[3] = bz[3];
+        blob->layout_color = (int)layoutColor; blob->wall_color = (int)wallColor; blob->draw_walls = drawWalls ? 1 : 0;
+        blob->num_objects = numObjects;
+        blob->bz_reward = bzReward;
+        blob->seq = seq;
+        tg->seed = nextSeed; tg->seed_is_env_seed = 0; tg->generated = seq;
+    }
+    wave_sync();   // (the LDS arrays are reused by the next draw of this wave)
+}
+
+// Env::reset of env `env` from the next episode of its ring.  Called by all 64 lanes of ONE wavefront (stores are ordered with wave_sync()).
+// -> false: the episode is not resident -- its draw kernel has not run yet, which the host's launch order rules out (mv_api.hip) -- the env keeps its
+// done state, repeats its done step, and ST_STARVED is raised (reported by mv_step like the host-generated scenarios' starvation).
+__device__ __forceinline__ bool tower_swap_in(const GymView &gv, int env, int force_all)
+{
+    const int lane = lane_id();
+    EnvHeader *hdr = gv.hdr + env;
+    const int consumed = hdr->episodes_consumed;
+    const TowerBlob *b = reinterpret_cast<const TowerBlob *>(gv.blobs) + (size_t)env * gv.spares + consumed % gv.spares;   // ring slot of episode number consumed + 1
+    if (b->seq != consumed + 1) {
+        if (lane == 0) { hdr->starved |= 1; atomicOr(&gv.episode_status[gv.num_envs + 1], (int)ST_STARVED); }
+        return false;
+    }
+    const int A = gv.num_agents;
+    const int length = b->L, height = b->H, width = b->W, numObjects = b->num_objects;
+    const bool drawWalls = b->draw_walls != 0;
+
+    // ---- voxel chunk: floor, then the four walls override (platforms.hpp:167-190, component_voxel_grid.hpp:73-90).  One 16-cell run per lane
+    // per round, formed in registers and stored straight to the env's chunk (coalesced 16 B / lane); the object bits are then or-ed into
+    // their bytes in global memory.
+    uint8_t *gbytes = gv.chunk + (size_t)env * CHUNK_BYTES;
+    uint4 *gchunk = reinterpret_cast<uint4 *>(gbytes);
+    const uint32_t vFloor = VX_SOLID | VX_OPAQUE;
+    const uint32_t vWall = VX_SOLID | (drawWalls ? VX_OPAQUE : 0) | (1u << VX_COLOR_SHIFT);
+    for (int grp = lane; grp < CHUNK_BYTES / 16; grp += 64) {
+        const int x0 = (grp & 1) * 16, z = (grp >> 1) & (CZ - 1), y = grp >> 6;
+        uint32_t w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t word = 0;
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                const int x = x0 + q * 4 + bb;
+                uint32_t v = 0;
+                if (x < length && z < width) {
+                    if (y == 0) v = vFloor;
+                    if (y < height && (x == 0 || x == length - 1 || z == 0 || z == width - 1)) v = vWall;
+                }
+                word |= v << (8 * bb);
+            }
+            w[q] = word;
+        }
+        gchunk[grp] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the fill before the bytes below are read back (other lanes' stores)
+    wave_sync();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    MovableObject *gobj = gv.objects + (size_t)env * MAX_OBJECTS;
+    for (int i = lane; i < MAX_OBJECTS; i += 64) {
+        const MovableObject o = b->objects[i];   // (zero beyond num_objects)
+        gobj[i] = o;
+        if (i < numObjects) {
+            volatile uint8_t *cell = gbytes + (o.y * CZ + o.z) * CX + o.x;
+            *cell = (uint8_t)(*cell | VX_OBJECT);   // distinct cells, byte-wide read-modify-write
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    wave_sync();
+
+    // canonical layout parallelepipeds (== the generic greedy merge the oracle runs on the voxels:
+    // keys sorted by (type, slot), scan y,z,x, grow x then z then y).  For this room that is the
+    // interior floor slab and four wall slabs.
+    if (lane < TOWER_BOXES) {
+        LayoutBox bx{{0, 0, 0}, 0, {0, 0, 0}, 0};
+        const int wallType = VX_SOLID | (drawWalls ? VX_OPAQUE : 0);
+        const int floorIdx = drawWalls ? 0 : 4;       // key 12 vs wall key 13 (drawn) / 5 (invisible)
+        const int wallIdx = drawWalls ? lane - 1 : lane;
+        if (lane == floorIdx) {
+            bx.min[0] = 1; bx.min[1] = 0; bx.min[2] = 1; bx.max[0] = length - 1; bx.max[1] = 1; bx.max[2] = width - 1;
+            bx.type = VX_SOLID | VX_OPAQUE; bx.slot = 0;
+        } else if (lane < 5) {
+            bx.type = wallType; bx.slot = 1; bx.min[1] = 0; bx.max[1] = height;
+            if (wallIdx == 0) { bx.min[0] = 0; bx.min[2] = 0; bx.max[0] = length; bx.max[2] = 1; }
+            if (wallIdx == 1) { bx.min[0] = 0; bx.min[2] = 1; bx.max[0] = 1; bx.max[2] = width; }
+            if (wallIdx == 2) { bx.min[0] = length - 1; bx.min[2] = 1; bx.max[0] = length; bx.max[2] = width; }
+            if (wallIdx == 3) { bx.min[0] = 1; bx.min[2] = width - 1; bx.max[0] = length - 1; bx.max[2] = width; }
+        }
+        gv.boxes[(size_t)env * MAX_BOXES + lane] = bx;
+    }
+
+    // ---- agents (scenario_default.hpp:80-97, agent.cpp:24-65)
+    for (int k = 0; k < A; ++k) {
+        const int c = b->spawn[k];
+        const int sx = c >> 8, sz = c & 255;
         float cs, sn;
-        yaw_matrix(rot, cs, sn);
+        yaw_matrix(b->yaw_rot[k], cs, sn);
         if (lane == 0) {
             AgentState *ga = gv.agents + (size_t)env * A + k;
             AgentState a = *ga;   // keeps the per-agent reward shaping
@@ -213,24 +256,22 @@ __device__ __forceinline__ void reset_env(const GymView &gv, int env, int force_
         }
     }
 
-    // value the next Env::reset() will draw; nothing consumes the env rng during an episode
-    const uint32_t nextSeed = (uint32_t)rand_range(g, 0, 1 << 30);
-
     if (lane == 0) {
         EnvHeader h = *hdr;
         h.L = length; h.H = height; h.W = width;
-        h.bz[0] = bz[0]; h.bz[1] = bz[1]; h.bz[2] = bz[2]; h.bz[3] = bz[3];
-        h.layout_color = (int)layoutColor; h.wall_color = (int)wallColor; h.draw_walls = drawWalls ? 1 : 0;
+        h.bz[0] = b->bz[0]; h.bz[1] = b->bz[1]; h.bz[2] = b->bz[2]; h.bz[3] = b->bz[3];
+        h.layout_color = b->layout_color; h.wall_color = b->wall_color; h.draw_walls = drawWalls ? 1 : 0;
         h.num_objects = numObjects; h.num_boxes = 5;
         h.num_frames = 0; h.done = 0; h.highest_tower = 0;
         h.episode_sec = 0.0f;
         h.episode_len = h.p_episode_len_sec + 4.0f * float(numObjects);   // :263-266
-        h.bz_reward = bzReward;
+        h.bz_reward = b->bz_reward;
         h.bar_half_width = 0.24f;
-        h.next_seed = nextSeed; h.seed_is_env_seed = 0;
+        h.episodes_consumed = consumed + 1;
         *hdr = h;
         if (force_all) gv.done[env] = 0;
     }
+    return true;
 }
 
 }  // namespace

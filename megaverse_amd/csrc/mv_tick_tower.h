@@ -423,8 +423,8 @@ __device__ __forceinline__ void tower_tick(const GymView &gv, const int env)
     // this costs nothing, where a separate "reset whoever is done" launch cost 4-7 us per step.
 #ifndef MV_EXP_NO_AUTO_RESET   // (timing experiments only: what the generator's 20 KB of LDS cost the kernels that run beside this one)
     if (h.done) {
-        wave_sync();   // one wave per env: orders the stores above before the generator's
-        reset_env(gv, env, 0);
+        wave_sync();   // one wave per env: orders the stores above before the swap-in's
+        (void)tower_swap_in(gv, env, 0);   // the next episode, drawn ahead of time (mv_reset_device.h)
     }
 #endif
 }

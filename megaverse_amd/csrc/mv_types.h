@@ -173,6 +173,7 @@ struct GymView {
     uint8_t *sort_scratch;     // [N*A][vis_stride] x (32 + 8) bytes: the list as found, before it is dealt into its depth classes (null: short lists)
     int32_t depth_sort;        // 1: deal the list into depth classes (set per launch: fast pixel mode only -- the exact kernel resolves depth ties by list position)
     int32_t lpt_no_clear;      // 1: the frame setup does not clear the cost histogram of the next pass (a multi-tick step launch: the pass that draws from a histogram clears it, mv_raster.hip: hist_done)
+    struct TowerGen *tower_gen;// [N] TowerBuilding: where each env's episode generator stands (mv_reset_device.h: tower_draw); its resident episodes are `blobs` (TowerBlob)
 };
 
 // the views of the n consecutive ticks of a multi-tick step launch (mv_step.hip: step_ticks_kernel, mv_step_obstacles.hip), the same envs in all of them
@@ -182,6 +183,30 @@ struct StepTicksArgs {
 };
 // (the views travel BY VALUE as kernel arguments: a launch whose arguments exceed the 4 KB kernarg segment fails at run time, not at build time)
 static_assert(sizeof(StepTicksArgs) + 16 <= 4096, "StepTicksArgs + (W, H) must fit the 4 KB kernel-argument segment: slim GymView down or pass the views through device memory");
+
+// TowerBuilding: one episode as its generator DREW it -- everything of Env::reset that consumes the env's random stream (scenario_tower_building.cpp:19-89,
+// 129-154, scenario_default.hpp:80-97) -- resident in HBM ahead of the reset that will build it (mv_reset_device.h: tower_draw fills it in a kernel of its own,
+// off the step path; tower_swap_in -- the tail of a finishing env's tick, or mv_reset -- turns it into chunk, boxes, header and agents).
+struct alignas(16) TowerBlob {
+    int32_t seq;                        // 1-based index of this episode for its env; 0 = empty
+    int32_t L, H, W;                    // room extents
+    int32_t bz[4];                      // building zone
+    int32_t layout_color, wall_color, draw_walls, num_objects;
+    float bz_reward;                    // initial tower reward, summed in object order
+    int32_t pad[3];
+    int32_t spawn[MAX_AGENTS];          // x << 8 | z of every agent's spawn cell (y = 2)
+    float yaw_rot[MAX_AGENTS];          // frand * 2 pi as drawn for the agent's spawn rotation
+    MovableObject objects[MAX_OBJECTS];
+};
+static_assert(sizeof(TowerBlob) == 448, "TowerBlob: 448 B");
+
+// where an env's TowerBuilding generator stands: the seed the NEXT episode's Env::reset re-seeds with (env.cpp:61-62) and how many episodes were drawn
+struct alignas(16) TowerGen {
+    uint32_t seed;
+    int32_t seed_is_env_seed;           // 1: `seed` is the Env::seed() value, the reset draws its seed from it first
+    int32_t generated;                  // episodes drawn so far (episode `generated` lives in ring slot (generated - 1) % spares)
+    int32_t pad;
+};
 
 // One host-generated episode (Obstacles family): everything Env::reset produces, ready to be swapped in by
 // the reset kernel.  Fixed-size POD so that the host can fill a pinned staging copy and upload it as is.
