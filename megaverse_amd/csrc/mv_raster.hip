@@ -904,10 +904,23 @@ __device__ __forceinline__ FastFrame fast_prologue(const FastArgs &fa, int blk, 
     return FastFrame{frame, part, viewer, nVis, split};
 }
 
+// box_key where the SIGN of every component of the ray's direction is known, the same for all pixels of the tile (SGN bit a set: component a is negative --
+// classify_tiles finds that out per tile, from the tile's corner rays): the near plane of axis a is lo_a (hi_a if negative), so the six min / max of the
+// general form are not needed -- the products are the same ones, picked by the compiler instead of by v_min / v_max: 13 instead of 19 instructions
+template <unsigned POS_MASK, int SGN>
+__device__ __forceinline__ unsigned box_key_signed(V3 inv, const float4 lo, const float4 hi, int pos, unsigned depthMask)
+{
+    const float nx = (SGN & 1) ? hi.x : lo.x, fx = (SGN & 1) ? lo.x : hi.x, ny = (SGN & 2) ? hi.y : lo.y, fy = (SGN & 2) ? lo.y : hi.y, nz = (SGN & 4) ? hi.z : lo.z, fz = (SGN & 4) ? lo.z : hi.z;
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(nx * inv.x, ny * inv.y), nz * inv.z);
+    const float tf = __builtin_fminf(__builtin_fminf(fx * inv.x, fy * inv.y), fz * inv.z);
+    const unsigned key = ((__float_as_uint(tn) - KEY_NEAR) & depthMask) | (unsigned)pos;
+    return tn <= tf ? key : ~0u;
+}
+
 // the boxes of one frame of reference among list positions 64 k .. 64 k + 63 (mask m) against this lane's NP rays, given each ray's inverse
 // direction in that frame: the next record is fetched from LDS while the current one is intersected (with NP = 2 a record fetched once serves
 // two pixels, and the two slab tests are independent instruction chains)
-template <unsigned POS_MASK, int NP>
+template <unsigned POS_MASK, int NP, int SGN = -1>   // SGN >= 0: the signs of the rays' components, uniform over the tile (box_key_signed)
 __device__ __forceinline__ void box_run(unsigned long long m, int k, const V3 (&inv)[NP], const float4 *s_vis, unsigned (&best)[NP])
 {
     if (!m) return;
@@ -920,12 +933,12 @@ __device__ __forceinline__ void box_run(unsigned long long m, int k, const V3 (&
         bool more = m != 0ull;
         if (more) { p1 = __ffsll((long long)m) - 1 + 64 * k; m &= m - 1; lo1 = s_vis[2 * p1]; hi1 = s_vis[2 * p1 + 1]; }
 #pragma unroll
-        for (int j = 0; j < NP; ++j) best[j] = min(best[j], box_key<POS_MASK>(inv[j], lo0, hi0, p0, depthMask));
+        for (int j = 0; j < NP; ++j) best[j] = min(best[j], SGN >= 0 ? box_key_signed<POS_MASK, (SGN >= 0 ? SGN : 0)>(inv[j], lo0, hi0, p0, depthMask) : box_key<POS_MASK>(inv[j], lo0, hi0, p0, depthMask));
         if (!more) break;
         more = m != 0ull;
         if (more) { p0 = __ffsll((long long)m) - 1 + 64 * k; m &= m - 1; lo0 = s_vis[2 * p0]; hi0 = s_vis[2 * p0 + 1]; }
 #pragma unroll
-        for (int j = 0; j < NP; ++j) best[j] = min(best[j], box_key<POS_MASK>(inv[j], lo1, hi1, p1, depthMask));
+        for (int j = 0; j < NP; ++j) best[j] = min(best[j], SGN >= 0 ? box_key_signed<POS_MASK, (SGN >= 0 ? SGN : 0)>(inv[j], lo1, hi1, p1, depthMask) : box_key<POS_MASK>(inv[j], lo1, hi1, p1, depthMask));
         if (!more) break;
     }
 }
@@ -956,6 +969,7 @@ __device__ __forceinline__ void box_run(unsigned long long m, int k, const V3 (&
 // the general path with the refined survivor mask.
 // Reference for what is drawn: magnum_env_renderer.cpp:288-330 (depth-tested, back-face-culled boxes), :200-203 (Phong uniforms).
 constexpr float PLANAR_MARGIN = 2e-4f;
+enum : unsigned { TC_EMPTY = 0, TC_PLANAR = 1, TC_PLANAR_SPEC = 2, TC_OVERLAY = 3, TC_GENERAL = 4 };   // a classified tile's class (s_tile[u].w, classify_tiles)
 constexpr int CLS_MAX_TILES = 128;   // tiles of one workgroup that can be classified (LDS: 16 B each); more (hires frames): the general path throughout
 
 // s_tile[u] of the workgroup's u-th tile (u = 4 j + w is tile (j split + part) 4 + w of the frame, the tile loop's order): x, y = the list positions
@@ -965,7 +979,7 @@ constexpr int CLS_MAX_TILES = 128;   // tiles of one workgroup that can be class
 // Called by all 256 threads after the prologue's barrier (s_vis, s_rect, the header are in LDS); ends with a barrier.
 template <int TH, int NT>
 __device__ __forceinline__ void classify_tiles(uint4 *s_tile, float4 *s_line, const float4 *s_vis, const short4 *s_rect, const float *s_hdr, const float *camv, int nVis, unsigned long long wb0,
-                                               int W, int H, int part, int split, int tilesX, int numTiles, int perWG)
+                                               int W, int H, int part, int split, int tilesX, int numTiles, int perWG, bool overlayOn)
 {
     constexpr int NW = NT / 64;        // waves of the workgroup
     constexpr int PPR = 16 / NW;       // list positions per wave and round (256 edge-function slots in all: 4 with four waves, 2 with eight)
@@ -1076,14 +1090,16 @@ __device__ __forceinline__ void classify_tiles(uint4 *s_tile, float4 *s_line, co
             if (cover[c]) atomicOr(&s_tile[u].z, cover[c]);
         }
     __syncthreads();
-    // ---- highlight bound: which covered tiles cannot hold a pixel of the specular highlight (s_tile[u].w = 1)?
-    // Shaders::Phong's highlight (magnum_env_renderer.cpp:200-203, shininess 300) is evaluated where cos(V, R) > 0.97 (phong_tail).  On a planar face,
-    // with L' the light mirrored in the face's plane, R at a point P of the face is the direction from L' to P, V the direction from P to the eye E: the
-    // angle between them is the exterior angle at P of the triangle E P L', the sum of its interior angles at E and at L' -- so it is at least the angle
-    // at E, the angle between the pixel's ray and the direction from the eye to L'.  If that angle at the tile's centre exceeds acos(0.965) (15.2 degrees:
-    // 1.1 degrees of margin over acos(0.97) for the rounding of either side) plus the tile's angular radius (two rays through points a, b of the plane
-    // z = -1: sin(angle) <= |a - b|), no pixel of the tile passes phong_tail's test: the planar path leaves the seven instructions of V . R out
-    // (phong_tail<false>), the bytes stay what they were.  One lane per tile, one wave per 64 tiles: ~30 instructions per frame.
+    // ---- every tile's class, ONE word the tile loop dispatches on (s_tile[u].w): TC_EMPTY nothing can be hit; TC_PLANAR / TC_PLANAR_SPEC one face of one
+    // world box covers the tile and nothing else can be hit (without / with the highlight test); TC_OVERLAY the same with boxes of other frames of reference
+    // in front of it or not (overlay_tile); TC_GENERAL everything else.  Covered classes carry the face: axis << 3 | list position << 5.
+    // The highlight bound: Shaders::Phong's highlight (magnum_env_renderer.cpp:200-203, shininess 300) is evaluated where cos(V, R) > 0.97 (phong_tail).
+    // On a planar face, with L' the light mirrored in the face's plane, R at a point P of the face is the direction from L' to P, V the direction from P to
+    // the eye E: the angle between them is the exterior angle at P of the triangle E P L', the sum of its interior angles at E and at L' -- so it is at
+    // least the angle at E, the angle between the pixel's ray and the direction from the eye to L'.  If that angle at the tile's centre exceeds acos(0.965)
+    // (15.2 degrees: 1.1 degrees of margin over acos(0.97) for the rounding of either side) plus the tile's angular radius (two rays through points a, b of
+    // the plane z = -1: sin(angle) <= |a - b|), no pixel of the tile passes phong_tail's test: the planar path leaves the seven instructions of V . R out
+    // (phong_tail<false>), the bytes stay what they were.  One lane per tile, one wave per 64 tiles: ~40 instructions per frame.
     {
         const float hx = 0.5f * WX * sx, hy = 0.5f * WY * sy;
         const float r2 = hx * hx + hy * hy;                                    // (tile radius)^2 on the plane z = -1 = sin^2 of the bound on its angular radius
@@ -1091,24 +1107,53 @@ __device__ __forceinline__ void classify_tiles(uint4 *s_tile, float4 *s_line, co
         const bool usable = r2 < 0.5f && cosT > 0.0f;
         const float cosT2 = cosT * cosT;
         const float L0 = s_hdr[FH_LREL + 0], L1 = s_hdr[FH_LREL + 1], L2 = s_hdr[FH_LREL + 2];   // the light relative to the eye, world axes (frame 0)
+        // list positions that hold anything but a box (capsules, cones, scaled shapes): a covered tile with one of those among its candidates stays general
+        const unsigned long long nonBox = __ballot(lane < nVis && (__float_as_uint(s_vis[2 * min(lane, max(nVis - 1, 0))].w) & 15u) != (unsigned)PRIM_BOX);
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            if (wave != (c % NW) || !tvalid[c] || !usable) continue;
+            if (wave != (c % NW) || !tvalid[c]) continue;
             const int u = 64 * c + lane;
             const uint4 tc = s_tile[u];
-            const unsigned long long m = ((unsigned long long)tc.y << 32) | tc.x;
-            if (m == 0ull || (m & (m - 1ull)) != 0ull || tc.z == 0u) continue;   // (not a covered tile with one candidate)
-            const int pos = __ffsll((long long)m) - 1, k = (int)tc.z - 1;
-            const float lok = reinterpret_cast<const float *>(s_vis)[8 * pos + k], hik = reinterpret_cast<const float *>(s_vis)[8 * pos + 4 + k];
-            const float plane = lok > 0.0f ? lok : hik;
-            const float m0 = k == 0 ? 2.0f * plane - L0 : L0, m1 = k == 1 ? 2.0f * plane - L1 : L1, m2 = k == 2 ? 2.0f * plane - L2 : L2;   // L'
-            const float xc = float(tX0[c]) + 0.5f * WX, yc = float(tY0[c]) + 0.5f * WY;
-            const float dcx = sx * xc + ox, dcy = sy * yc + oy;
-            const float d0 = (camv[3] * dcx + camv[4] * dcy) - camv[5], d1 = (camv[6] * dcx + camv[7] * dcy) - camv[8], d2 = (camv[9] * dcx + camv[10] * dcy) - camv[11];
-            const float dot = (d0 * m0 + d1 * m1) + d2 * m2;
-            const float dd = (d0 * d0 + d1 * d1) + d2 * d2, mm = (m0 * m0 + m1 * m1) + m2 * m2;
-            const bool maybe = dot > 0.0f && dot * dot >= cosT2 * (dd * mm);
-            if (!maybe) s_tile[u].w = 1u;
+            const unsigned long long m = ((unsigned long long)tc.y << 32) | tc.x, wbm = m & wb0, others = m & ~wb0;
+            unsigned info = TC_GENERAL;
+            if (m == 0ull) info = TC_EMPTY;
+            else if (wbm != 0ull && (wbm & (wbm - 1ull)) == 0ull && tc.z != 0u) {   // one world box, and one of its faces covers the tile
+                const int pos = __ffsll((long long)wbm) - 1, k = (int)tc.z - 1;
+                if (others == 0ull) {
+                    bool maybe = true;   // may a pixel of the tile lie in the highlight cone?
+                    if (usable) {
+                        const float lok = reinterpret_cast<const float *>(s_vis)[8 * pos + k], hik = reinterpret_cast<const float *>(s_vis)[8 * pos + 4 + k];
+                        const float plane = lok > 0.0f ? lok : hik;
+                        const float m0 = k == 0 ? 2.0f * plane - L0 : L0, m1 = k == 1 ? 2.0f * plane - L1 : L1, m2 = k == 2 ? 2.0f * plane - L2 : L2;   // L'
+                        const float xc = float(tX0[c]) + 0.5f * WX, yc = float(tY0[c]) + 0.5f * WY;
+                        const float dcx = sx * xc + ox, dcy = sy * yc + oy;
+                        const float d0 = (camv[3] * dcx + camv[4] * dcy) - camv[5], d1 = (camv[6] * dcx + camv[7] * dcy) - camv[8], d2 = (camv[9] * dcx + camv[10] * dcy) - camv[11];
+                        const float dot = (d0 * m0 + d1 * m1) + d2 * m2;
+                        const float dd = (d0 * d0 + d1 * d1) + d2 * d2, mm = (m0 * m0 + m1 * m1) + m2 * m2;
+                        maybe = dot > 0.0f && dot * dot >= cosT2 * (dd * mm);
+                    }
+                    info = (maybe ? (unsigned)TC_PLANAR_SPEC : (unsigned)TC_PLANAR) | ((unsigned)k << 3) | ((unsigned)pos << 5);
+                } else if ((others & nonBox) == 0ull && overlayOn) info = (unsigned)TC_OVERLAY | ((unsigned)k << 3) | ((unsigned)pos << 5);
+            }
+            if (info == TC_GENERAL) {
+                // The signs of the rays' world components over the tile (bits 11..14: 8 | sign bits where every component keeps its sign; general_tile,
+                // box_key_signed).  A component is affine in the pixel: it keeps the sign -- and the magnitude, far above either arithmetic's rounding -- of
+                // the tile's four corner rays if those agree.
+                const float xa = float(tX0[c]), xb = float(tX1[c]), ya = float(tY0[c]), yb = float(tY1[c]);
+                unsigned sg = 8u;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const float Aa = camv[3 + 3 * a] * sx, Ba = camv[4 + 3 * a] * sy, Ca = (camv[3 + 3 * a] * ox + camv[4 + 3 * a] * oy) - camv[5 + 3 * a];
+                    const float v00 = __builtin_fmaf(Aa, xa, __builtin_fmaf(Ba, ya, Ca)), v10 = __builtin_fmaf(Aa, xb, __builtin_fmaf(Ba, ya, Ca));
+                    const float v01 = __builtin_fmaf(Aa, xa, __builtin_fmaf(Ba, yb, Ca)), v11 = __builtin_fmaf(Aa, xb, __builtin_fmaf(Ba, yb, Ca));
+                    const float lo4 = __builtin_fminf(__builtin_fminf(v00, v10), __builtin_fminf(v01, v11)), hi4 = __builtin_fmaxf(__builtin_fmaxf(v00, v10), __builtin_fmaxf(v01, v11));
+                    if (hi4 < -1e-4f) sg |= 1u << a;
+                    else if (!(lo4 > 1e-4f)) sg = 0u;
+                    if (sg == 0u) break;
+                }
+                info |= sg << 11;
+            }
+            s_tile[u].w = info;
         }
         __syncthreads();
     }
@@ -1145,13 +1190,13 @@ __device__ __forceinline__ void planar_tile(int pos, int k, const float4 *s_vis,
 // (a quarter of the store instructions of one dword per pixel) where the frame's rows allow it
 typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 template <int NP>
-__device__ __forceinline__ void clear_tile(uint32_t *out, int tx0, int ty0, int lane, int px, int py0, int W, int H)
+__device__ __forceinline__ void clear_tile(uint32_t *out, int tx0, int ty0, int lane, int W, int H)
 {
     constexpr int TH = TILE_H * NP;
+    // (lane and colour are laundered: what is derived from them is formed here, per tile -- hoisted out of the tile loop it costs the kernel registers it does not have at seven waves per SIMD)
+    unsigned c = 0xff000000u;
+    asm volatile("" : "+v"(lane), "+v"(c));
     if ((W & 3) == 0 && tx0 + TILE_W <= W && (reinterpret_cast<uintptr_t>(out) & 15u) == 0u) {   // (uniform)
-        // (lane and colour are laundered: formed here, per tile -- hoisted out of the tile loop they cost the kernel five registers it does not have at seven waves per SIMD)
-        unsigned c = 0xff000000u;
-        asm volatile("" : "+v"(lane), "+v"(c));
         const int row = ty0 + (lane >> 2), col = tx0 + 4 * (lane & 3);
         const v4u_t v = {c, c, c, c};
 #ifndef MV_PIXEL_PLAIN
@@ -1161,10 +1206,11 @@ __device__ __forceinline__ void clear_tile(uint32_t *out, int tx0, int ty0, int 
 #endif
         return;
     }
+    const int px = tx0 + (lane & (TILE_W - 1)), py0 = ty0 + lane / TILE_W;
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
         const int py = py0 + TILE_H * j;
-        if (px < W && py < H) PIXEL_STORE(out[(unsigned)(py * W + px)], 0xff000000u);
+        if (px < W && py < H) PIXEL_STORE(out[(unsigned)(py * W + px)], c);
     }
 }
 
@@ -1220,7 +1266,7 @@ __device__ __forceinline__ void overlay_tile(int posA, int k, unsigned long long
 // The general path for a tile of a classified frame: its list is ONE culling round (at most 64 primitives) and the tile's candidates -- mv0, not empty -- came out of
 // the classification, so the rays are set up at once and there is no loop over rounds (the same arithmetic, in the same order, as the loop in raster_fast_body).
 template <bool SHAPES, unsigned POS_MASK, int NP>
-__device__ __forceinline__ void general_tile(unsigned long long mv0, unsigned long long wb0, const float4 *s_vis, const float *s_hdr, const float *camv, int viewer, const float4 *s_col,
+__device__ __forceinline__ void general_tile(unsigned long long mv0, unsigned long long wb0, unsigned signs, const float4 *s_vis, const float *s_hdr, const float *camv, int viewer, const float4 *s_col,
                                              const float4 *s_row, const float2 *s_rowq, const float *s_colq, float nzm0, float nzm1, float nzm2, int px, int py0, int W, int H, uint32_t *out)
 {
     const int pxc = min(px, W - 1);
@@ -1242,7 +1288,19 @@ __device__ __forceinline__ void general_tile(unsigned long long mv0, unsigned lo
         bn[j] = v3(0.0f, 0.0f, 0.0f);
         best[j] = ~0u;
     }
-    box_run<POS_MASK, NP>(mv0 & wb0, 0, inv, s_vis, best);
+    // signs: 8 | the sign bits of the rays' world components where each is the same over the whole tile (classify_tiles), else 0
+    const unsigned long long wbm = mv0 & wb0;
+    switch (signs) {   // (uniform)
+    case 8: box_run<POS_MASK, NP, 0>(wbm, 0, inv, s_vis, best); break;
+    case 9: box_run<POS_MASK, NP, 1>(wbm, 0, inv, s_vis, best); break;
+    case 10: box_run<POS_MASK, NP, 2>(wbm, 0, inv, s_vis, best); break;
+    case 11: box_run<POS_MASK, NP, 3>(wbm, 0, inv, s_vis, best); break;
+    case 12: box_run<POS_MASK, NP, 4>(wbm, 0, inv, s_vis, best); break;
+    case 13: box_run<POS_MASK, NP, 5>(wbm, 0, inv, s_vis, best); break;
+    case 14: box_run<POS_MASK, NP, 6>(wbm, 0, inv, s_vis, best); break;
+    case 15: box_run<POS_MASK, NP, 7>(wbm, 0, inv, s_vis, best); break;
+    default: box_run<POS_MASK, NP>(wbm, 0, inv, s_vis, best); break;
+    }
     unsigned long long rest = mv0 & ~wb0;
     while (rest) {
         const int pos = __ffsll((long long)rest) - 1;
@@ -1317,7 +1375,6 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
     uint32_t *out = obs + (size_t)frame * W * H;
     const int tilesX = (W + TILE_W - 1) / TILE_W, tilesY = (H + TH - 1) / TH;
     const int numTiles = tilesX * tilesY;
-    const int lx = lane & (TILE_W - 1), ly = lane / TILE_W;
 
     // What the first round of 64 list positions needs is the same for every tile of the frame: this lane's primitive's rectangle and the
     // world-box mask stay in registers (two VGPRs, two SGPRs) instead of costing two dependent LDS round trips per tile (most frames of the
@@ -1337,7 +1394,7 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
     const bool cls = PLANAR && fa.planar && nVis <= 64 && perWG <= CLS_MAX_TILES && perWG >= 32;   // (uniform over the workgroup; few tiles do not repay the pass over the list)
     __shared__ int s_next;   // the tile loop's hand-out counter (below)
     if (tid == 0) s_next = NT / 64;
-    if (PLANAR && cls) classify_tiles<TH, NT>(s_tile, s_line, s_vis, s_rect, s_hdr, camv, nVis, wb0, W, H, part, split, tilesX, numTiles, perWG);   // (ends with a barrier)
+    if (PLANAR && cls) classify_tiles<TH, NT>(s_tile, s_line, s_vis, s_rect, s_hdr, camv, nVis, wb0, W, H, part, split, tilesX, numTiles, perWG, fa.planar != 2);   // (ends with a barrier)
     else __syncthreads();
     RT_MARK(2);
 #if defined(MV_RASTER_DEBUG_SKIP) && MV_RASTER_DEBUG_SKIP == 1   // (measurement builds: the pass's fixed cost -- prologue + classification -- alone; pixels are NOT drawn)
@@ -1356,52 +1413,53 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
         const int ty = (int)__umulhi((unsigned)tile, tilesXinv), tx = tile - ty * tilesX;
         const int tx0 = tx * TILE_W, ty0 = ty * TH;
         const int tx1 = min(tx0 + TILE_W, W) - 1, ty1 = min(ty0 + TH, H) - 1;
-        const int px = tx0 + lx, py0 = ty0 + ly;
-        const int pxc = min(px, W - 1);
         // ---- which primitives can this tile's pixels hit?  (first round of 64 list positions)
         unsigned long long mv0;
-        if (PLANAR && cls) {   // classified: the answer is in the table, with the face that covers the tile if one does
-            const uint4 tc = s_tile[u];
-            mv0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(tc.y) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(tc.x);
-            const unsigned cover = (unsigned)__builtin_amdgcn_readfirstlane(tc.z), nospec = (unsigned)__builtin_amdgcn_readfirstlane(tc.w);
+        if (PLANAR && cls) {   // classified: the tile's class is in the table (classify_tiles), with the covering face if there is one
+            const unsigned info = (unsigned)__builtin_amdgcn_readfirstlane(s_tile[u].w), tclass = info & 7u;
             RT_COUNT(0, 1);                                   // classified tiles
-            if (mv0 == 0ull) {   // nothing: the clear colour
+            if (tclass == TC_EMPTY) {   // nothing: the clear colour
                 RT_COUNT(1, 1);
-                clear_tile<NP>(out, tx0, ty0, lane, px, py0, W, H);
+                clear_tile<NP>(out, tx0, ty0, lane, W, H);
                 continue;
             }
-            const unsigned long long wbm = mv0 & wb0, others = mv0 & ~wb0;
-            if (wbm != 0ull && (wbm & (wbm - 1ull)) == 0ull && cover != 0u) {   // one world box, and one of its faces covers the tile
-                const int k = (int)cover - 1, posA = __ffsll((long long)wbm) - 1;
-                const float nzk = k == 0 ? nzm0 : k == 1 ? nzm1 : nzm2;
+            int lpx = lane;
+            asm volatile("" : "+v"(lpx));   // (this lane's place in the tile is formed here, per tile: kept across the loop it is spilled at seven waves per SIMD, and the reload's s_waitcnt vmcnt(0) also waits for the previous tile's pixel stores)
+            const int px = tx0 + (lpx & (TILE_W - 1)), py0 = ty0 + lpx / TILE_W;
+            if (tclass <= TC_OVERLAY) {   // one world box, and one of its faces covers the tile
 #if defined(MV_RASTER_DEBUG_SKIP) && MV_RASTER_DEBUG_SKIP == 3   // (measurement builds: covered tiles cost nothing)
                 continue;
 #endif
-                if (others == 0ull) {   // ... and nothing else
-                    RT_COUNT(2, 1);
-                    RT_COUNT(12, nospec != 0u);
-                    if (nospec) planar_tile<NP, false>(posA, k, s_vis, s_hdr, s_col, s_row, s_rowq, s_colq, nzk, px, py0, W, H, out);   // (no pixel of the tile lies in the highlight cone: classify_tiles)
-                    else planar_tile<NP, true>(posA, k, s_vis, s_hdr, s_col, s_row, s_rowq, s_colq, nzk, px, py0, W, H, out);
-                    continue;
-                }
-                bool boxesOnly = true;   // ... and boxes of other frames of reference (the time bar, a carried object): overlay_tile
-                for (unsigned long long m = others; m; m &= m - 1ull)
-                    boxesOnly = boxesOnly && ((unsigned)__builtin_amdgcn_readfirstlane(__float_as_uint(s_vis[2 * (__ffsll((long long)m) - 1)].w)) & 15u) == (unsigned)PRIM_BOX;
-                if (boxesOnly && fa.planar != 2) {
-                    RT_COUNT(13, 1);
+                const int k = (int)((info >> 3) & 3u), posA = (int)(info >> 5);
+                const float nzk = k == 0 ? nzm0 : k == 1 ? nzm1 : nzm2;
+                RT_COUNT(2, tclass != TC_OVERLAY);
+                RT_COUNT(12, tclass == TC_PLANAR);
+                RT_COUNT(13, tclass == TC_OVERLAY);
+                if (tclass == TC_PLANAR) planar_tile<NP, false>(posA, k, s_vis, s_hdr, s_col, s_row, s_rowq, s_colq, nzk, px, py0, W, H, out);   // (no pixel of the tile lies in the highlight cone)
+                else if (tclass == TC_PLANAR_SPEC) planar_tile<NP, true>(posA, k, s_vis, s_hdr, s_col, s_row, s_rowq, s_colq, nzk, px, py0, W, H, out);
+                else {   // ... and boxes of other frames of reference (the time bar, a carried object)
+                    const uint2 tm = *reinterpret_cast<const uint2 *>(&s_tile[u]);
+                    const unsigned long long others = (((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(tm.y) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(tm.x)) & ~wb0;
                     overlay_tile<SHAPES, POS_MASK, NP>(posA, k, others, s_vis, s_hdr, camv, viewer, s_col, s_row, s_rowq, s_colq, nzm0, nzm1, nzm2, px, py0, W, H, out);
-                    continue;
                 }
+                continue;
             }
 #if defined(MV_RASTER_DEBUG_SKIP) && MV_RASTER_DEBUG_SKIP == 2   // (measurement builds: general tiles cost nothing)
             continue;
 #endif
+            const uint2 tm = *reinterpret_cast<const uint2 *>(&s_tile[u]);
+            mv0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(tm.y) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(tm.x);
             RT_COUNT(4, 1);
             RT_COUNT(5, __popcll(mv0 & wb0));
             RT_COUNT(6, __popcll(mv0 & ~wb0));
-            general_tile<SHAPES, POS_MASK, NP>(mv0, wb0, s_vis, s_hdr, camv, viewer, s_col, s_row, s_rowq, s_colq, nzm0, nzm1, nzm2, px, py0, W, H, out);
+            general_tile<SHAPES, POS_MASK, NP>(mv0, wb0, fa.planar == 3 ? 0u : (info >> 11) & 15u, s_vis, s_hdr, camv, viewer, s_col, s_row, s_rowq, s_colq, nzm0, nzm1, nzm2, px, py0, W, H, out);
             continue;
-        } else {   // tile culling: one primitive per lane, four integer compares against its screen rectangle
+        }
+        int lpx = lane;
+        asm volatile("" : "+v"(lpx));
+        const int px = tx0 + (lpx & (TILE_W - 1)), py0 = ty0 + lpx / TILE_W;
+        const int pxc = min(px, W - 1);
+        {   // tile culling: one primitive per lane, four integer compares against its screen rectangle
             int l2 = lane;
             asm volatile("" : "+v"(l2));   // (the rectangle's address is formed here, per tile: kept across the loop it was spilled at seven waves per SIMD)
             const int cpos = min(l2, max(nVis - 1, 0));
@@ -1935,7 +1993,7 @@ static FastArgs fast_args_of(const GymView &gv, const PublishTo *publish)
     fa.pub_rewards = publish ? publish->rewards : nullptr; fa.pub_true = publish ? publish->true_objective : nullptr; fa.pub_done = publish ? publish->done : nullptr;
     fa.pub_n = publish ? frames : 0;
     const char *pe = getenv("MV_PLANAR");   // (read at every launch: the two paths are compared within one process by tests/test_fast_pixels_gpu.py)
-    fa.planar = pe && *pe ? atoi(pe) : 1;   // (2: classified, but without overlay_tile -- comparisons)
+    fa.planar = pe && *pe ? atoi(pe) : 1;   // (2: classified, but without overlay_tile; 3: without the sign-specialised slab tests -- comparisons)
     fa.graded = 0; fa.tail_div = 0; fa.tail_split = 0;
     fa.hist_done = nullptr; fa.wg_total = 0;
     { const char *ns = getenv("MV_RASTER_NOSORT"); fa.nosort = ns && atoi(ns) != 0; }

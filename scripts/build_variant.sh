@@ -15,7 +15,7 @@ for o in $R/megaverse_amd/csrc/_obj/*.o; do
 done
 for s in $SRCS; do
   b=$(basename $s .hip)
-  EXTRA=""; [ "$b" = "mv_raster" ] && EXTRA="-fno-slp-vectorize"
+  EXTRA=""; [ "$b" = "mv_raster" ] && EXTRA="-fno-slp-vectorize -mllvm -amdgpu-atomic-optimizer-strategy=None"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-pass-failed $EXTRA $FLAGS -c -o $R/megaverse_amd/csrc/_obj_var_$NAME/$b.o $R/megaverse_amd/csrc/$s
   OBJS="$OBJS $R/megaverse_amd/csrc/_obj_var_$NAME/$b.o"
 done

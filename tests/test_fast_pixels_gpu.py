@@ -156,13 +156,13 @@ def test_planar_tiles_change_no_byte(hip, monkeypatch, scenario, N, A, W, H, ppl
         for st in range(25):
             g.sample_random_actions(31, 25 * rnd + st); g.step_no_render()
         got = {}
-        for planar in ("0", "2", "1"):   # general path everywhere / classified without overlay_tile / everything
+        for planar in ("0", "2", "3", "1"):   # general path everywhere / classified without overlay_tile / classified without the sign-specialised slab tests / everything
             monkeypatch.setenv("MV_PLANAR", planar)
             obs.zero_(); torch.cuda.synchronize()
             g.render(); g.synchronize()
             got[planar] = obs.cpu().numpy().copy()
         assert got["0"][..., :3].max() > 0 and got["0"][..., 3].min() == 255
-        for planar in ("2", "1"):
+        for planar in ("2", "3", "1"):
             bad = (got["0"] != got[planar]).any(axis=-1)
             assert not bad.any(), (f"{scenario} round {rnd}: {int(bad.sum())} pixels differ between the classified paths (MV_PLANAR={planar}) and the general path, first at "
                                    f"{np.argwhere(bad)[:4].tolist()}")
