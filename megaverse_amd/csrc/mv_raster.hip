@@ -561,6 +561,29 @@ constexpr float SPEC_COS2 = 0.97f * 0.97f;
 #define PIXEL_STORE(dst, v) ((dst) = (v))
 #endif
 
+// Where the short-list pass's pixels go: the frame as a BUFFER (four scalar registers: base, size), a pixel's place in it a 32-bit byte offset -- one
+// v_mad_i32_i24 per pixel where the 64-bit address arithmetic of a global store took three vector instructions; `edgeless`: the frame is whole tiles
+// (every BASELINE size is), so no pixel needs its "inside the frame?" compares.  (A store beyond the frame's bytes would be dropped by the buffer's range check.)
+struct PixOut {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int W, H, W4;
+    bool edgeless;
+};
+#ifndef MV_PIXEL_PLAIN
+constexpr int PIXEL_AUX = 2;   // nt
+#else
+constexpr int PIXEL_AUX = 0;
+#endif
+__device__ __forceinline__ void put_px(const PixOut &po, int px, int py, unsigned rgba)
+{
+    const unsigned off = (unsigned)(__mul24(py, po.W4) + px * 4);
+    if (__builtin_expect(po.edgeless, 1)) __builtin_amdgcn_raw_buffer_store_b32(rgba, po.rsrc, off, 0, PIXEL_AUX);
+    else {
+        asm volatile("" ::: "memory");   // (keeps the two stores apart: merged, the compares run for every pixel and their result is or-ed with `edgeless`)
+        if (px < po.W && py < po.H) __builtin_amdgcn_raw_buffer_store_b32(rgba, po.rsrc, off, 0, PIXEL_AUX);
+    }
+}
+
 struct FastArgs {   // what raster_fast_kernel needs of the GymView (fewer live SGPRs than the whole view)
     const unsigned char *vis_hdr;
     const Prim *vis_prims;
@@ -1162,8 +1185,9 @@ __device__ __forceinline__ void classify_tiles(uint4 *s_tile, float4 *s_line, co
 // the pixels of a tile that the face of axis k (the one towards the eye) of the world box at list position `pos` covers
 template <int NP, bool SPEC>
 __device__ __forceinline__ void planar_tile(int pos, int k, const float4 *s_vis, const float *s_hdr, const float4 *s_col, const float4 *s_row,
-                                            const float2 *s_rowq, const float *s_colq, float nzk, int px, int py0, int W, int H, uint32_t *out)
+                                            const float2 *s_rowq, const float *s_colq, float nzk, int px, int py0, const PixOut &po)
 {
+    const int W = po.W, H = po.H;
     const float lok = uniform_f32(reinterpret_cast<const float *>(s_vis)[8 * pos + k]), hik = uniform_f32(reinterpret_cast<const float *>(s_vis)[8 * pos + 4 + k]);
     const float plane = lok > 0.0f ? lok : hik;   // the face towards the eye
     const unsigned color = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_uint(reinterpret_cast<const float *>(s_vis)[8 * pos + 7]));
@@ -1182,7 +1206,7 @@ __device__ __forceinline__ void planar_tile(int pos, int k, const float4 *s_vis,
         const float t = plane * __builtin_amdgcn_rcpf(dk);    // == min(lo_k inv_k, hi_k inv_k) of the slab test
         const float nv = t * __builtin_fabsf(dk);
         const unsigned rgba = phong_tail<SPEC>(t, nv - lks, nv, cq + rq.x, rq.y, cr, cg, cb);
-        if (px < W && py < H) PIXEL_STORE(out[(unsigned)(py * W + px)], rgba);
+        put_px(po, px, py, rgba);
     }
 }
 
@@ -1190,27 +1214,23 @@ __device__ __forceinline__ void planar_tile(int pos, int k, const float4 *s_vis,
 // (a quarter of the store instructions of one dword per pixel) where the frame's rows allow it
 typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 template <int NP>
-__device__ __forceinline__ void clear_tile(uint32_t *out, int tx0, int ty0, int lane, int W, int H)
+__device__ __forceinline__ void clear_tile(const PixOut &po, int tx0, int ty0, int lane)
 {
     constexpr int TH = TILE_H * NP;
     // (lane and colour are laundered: what is derived from them is formed here, per tile -- hoisted out of the tile loop it costs the kernel registers it does not have at seven waves per SIMD)
     unsigned c = 0xff000000u;
     asm volatile("" : "+v"(lane), "+v"(c));
-    if ((W & 3) == 0 && tx0 + TILE_W <= W && (reinterpret_cast<uintptr_t>(out) & 15u) == 0u) {   // (uniform)
+    if ((po.W & 3) == 0 && tx0 + TILE_W <= po.W) {   // (uniform; the frame's base is 16-byte aligned: raster_fast_body checks)
         const int row = ty0 + (lane >> 2), col = tx0 + 4 * (lane & 3);
         const v4u_t v = {c, c, c, c};
-#ifndef MV_PIXEL_PLAIN
-        if (lane < 4 * TH && row < H) __builtin_nontemporal_store(v, reinterpret_cast<v4u_t *>(out + (unsigned)(row * W + col)));
-#else
-        if (lane < 4 * TH && row < H) *reinterpret_cast<v4u_t *>(out + (unsigned)(row * W + col)) = v;
-#endif
+        if (lane < 4 * TH && row < po.H) __builtin_amdgcn_raw_buffer_store_b128(v, po.rsrc, (unsigned)(__mul24(row, po.W4) + col * 4), 0, PIXEL_AUX);
         return;
     }
     const int px = tx0 + (lane & (TILE_W - 1)), py0 = ty0 + lane / TILE_W;
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
         const int py = py0 + TILE_H * j;
-        if (px < W && py < H) PIXEL_STORE(out[(unsigned)(py * W + px)], c);
+        if (px < po.W && py < po.H) __builtin_amdgcn_raw_buffer_store_b32(c, po.rsrc, (unsigned)(__mul24(py, po.W4) + px * 4), 0, PIXEL_AUX);
     }
 }
 
@@ -1222,8 +1242,9 @@ __device__ __forceinline__ void clear_tile(uint32_t *out, int tx0, int ty0, int 
 // phong_tail with the face's constants or, where another box won, by the general path's fast_shade: the same bytes (test_planar_tiles_change_no_byte).
 template <bool SHAPES, unsigned POS_MASK, int NP>
 __device__ __forceinline__ void overlay_tile(int posA, int k, unsigned long long rest, const float4 *s_vis, const float *s_hdr, const float *camv, int viewer, const float4 *s_col,
-                                             const float4 *s_row, const float2 *s_rowq, const float *s_colq, float nzm0, float nzm1, float nzm2, int px, int py0, int W, int H, uint32_t *out)
+                                             const float4 *s_row, const float2 *s_rowq, const float *s_colq, float nzm0, float nzm1, float nzm2, int px, int py0, const PixOut &po)
 {
+    const int W = po.W, H = po.H;
     const float lok = uniform_f32(reinterpret_cast<const float *>(s_vis)[8 * posA + k]), hik = uniform_f32(reinterpret_cast<const float *>(s_vis)[8 * posA + 4 + k]);
     const float plane = lok > 0.0f ? lok : hik;
     const unsigned color = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_uint(reinterpret_cast<const float *>(s_vis)[8 * posA + 7]));
@@ -1259,7 +1280,7 @@ __device__ __forceinline__ void overlay_tile(int posA, int k, unsigned long long
             const float nv = t * __builtin_fabsf(dk);
             rgba = phong_tail<true>(t, nv - lks, nv, a2, ldc, cr, cg, cb);
         } else rgba = fast_shade<SHAPES, POS_MASK>(best, v3(0.0f, 0.0f, 0.0f), s_vis, s_hdr, camv, viewer, dw, v3(0.0f, 0.0f, 0.0f), cx.x, ry.x, a2, ldc);
-        if (px < W && py < H) PIXEL_STORE(out[(unsigned)(py * W + px)], rgba);
+        put_px(po, px, py, rgba);
     }
 }
 
@@ -1267,8 +1288,9 @@ __device__ __forceinline__ void overlay_tile(int posA, int k, unsigned long long
 // the classification, so the rays are set up at once and there is no loop over rounds (the same arithmetic, in the same order, as the loop in raster_fast_body).
 template <bool SHAPES, unsigned POS_MASK, int NP>
 __device__ __forceinline__ void general_tile(unsigned long long mv0, unsigned long long wb0, unsigned signs, const float4 *s_vis, const float *s_hdr, const float *camv, int viewer, const float4 *s_col,
-                                             const float4 *s_row, const float2 *s_rowq, const float *s_colq, float nzm0, float nzm1, float nzm2, int px, int py0, int W, int H, uint32_t *out)
+                                             const float4 *s_row, const float2 *s_rowq, const float *s_colq, float nzm0, float nzm1, float nzm2, int px, int py0, const PixOut &po)
 {
+    const int W = po.W, H = po.H;
     const int pxc = min(px, W - 1);
     const float4 cx = s_col[pxc];
     const float cq = s_colq[pxc];
@@ -1315,8 +1337,7 @@ __device__ __forceinline__ void general_tile(unsigned long long mv0, unsigned lo
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
         const unsigned rgba = fast_shade<SHAPES, POS_MASK>(best[j], bn[j], s_vis, s_hdr, camv, viewer, dw[j], inv[j], dcx, dcy[j], a2[j], ldc[j]);
-        const int py = py0 + TILE_H * j;
-        if (px < W && py < H) PIXEL_STORE(out[(unsigned)(py * W + px)], rgba);
+        put_px(po, px, py0 + TILE_H * j, rgba);
     }
 }
 
@@ -1375,6 +1396,10 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
     uint32_t *out = obs + (size_t)frame * W * H;
     const int tilesX = (W + TILE_W - 1) / TILE_W, tilesY = (H + TH - 1) / TH;
     const int numTiles = tilesX * tilesY;
+    PixOut po;
+    po.rsrc = __builtin_amdgcn_make_buffer_rsrc(out, /*stride*/ 0, W * H * 4, 0x00020000);
+    po.W = W; po.H = H; po.W4 = 4 * W;
+    po.edgeless = (W % TILE_W) == 0 && (H % TH) == 0;
 
     // What the first round of 64 list positions needs is the same for every tile of the frame: this lane's primitive's rectangle and the
     // world-box mask stay in registers (two VGPRs, two SGPRs) instead of costing two dependent LDS round trips per tile (most frames of the
@@ -1420,7 +1445,7 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
             RT_COUNT(0, 1);                                   // classified tiles
             if (tclass == TC_EMPTY) {   // nothing: the clear colour
                 RT_COUNT(1, 1);
-                clear_tile<NP>(out, tx0, ty0, lane, W, H);
+                clear_tile<NP>(po, tx0, ty0, lane);
                 continue;
             }
             int lpx = lane;
@@ -1435,12 +1460,12 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
                 RT_COUNT(2, tclass != TC_OVERLAY);
                 RT_COUNT(12, tclass == TC_PLANAR);
                 RT_COUNT(13, tclass == TC_OVERLAY);
-                if (tclass == TC_PLANAR) planar_tile<NP, false>(posA, k, s_vis, s_hdr, s_col, s_row, s_rowq, s_colq, nzk, px, py0, W, H, out);   // (no pixel of the tile lies in the highlight cone)
-                else if (tclass == TC_PLANAR_SPEC) planar_tile<NP, true>(posA, k, s_vis, s_hdr, s_col, s_row, s_rowq, s_colq, nzk, px, py0, W, H, out);
+                if (tclass == TC_PLANAR) planar_tile<NP, false>(posA, k, s_vis, s_hdr, s_col, s_row, s_rowq, s_colq, nzk, px, py0, po);   // (no pixel of the tile lies in the highlight cone)
+                else if (tclass == TC_PLANAR_SPEC) planar_tile<NP, true>(posA, k, s_vis, s_hdr, s_col, s_row, s_rowq, s_colq, nzk, px, py0, po);
                 else {   // ... and boxes of other frames of reference (the time bar, a carried object)
                     const uint2 tm = *reinterpret_cast<const uint2 *>(&s_tile[u]);
                     const unsigned long long others = (((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(tm.y) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(tm.x)) & ~wb0;
-                    overlay_tile<SHAPES, POS_MASK, NP>(posA, k, others, s_vis, s_hdr, camv, viewer, s_col, s_row, s_rowq, s_colq, nzm0, nzm1, nzm2, px, py0, W, H, out);
+                    overlay_tile<SHAPES, POS_MASK, NP>(posA, k, others, s_vis, s_hdr, camv, viewer, s_col, s_row, s_rowq, s_colq, nzm0, nzm1, nzm2, px, py0, po);
                 }
                 continue;
             }
@@ -1452,7 +1477,7 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
             RT_COUNT(4, 1);
             RT_COUNT(5, __popcll(mv0 & wb0));
             RT_COUNT(6, __popcll(mv0 & ~wb0));
-            general_tile<SHAPES, POS_MASK, NP>(mv0, wb0, fa.planar == 3 ? 0u : (info >> 11) & 15u, s_vis, s_hdr, camv, viewer, s_col, s_row, s_rowq, s_colq, nzm0, nzm1, nzm2, px, py0, W, H, out);
+            general_tile<SHAPES, POS_MASK, NP>(mv0, wb0, fa.planar == 3 ? 0u : (info >> 11) & 15u, s_vis, s_hdr, camv, viewer, s_col, s_row, s_rowq, s_colq, nzm0, nzm1, nzm2, px, py0, po);
             continue;
         }
         int lpx = lane;
@@ -1554,8 +1579,7 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
             RT_COUNT(8, __popcll(__ballot(best[j] <= (KEY_FAR | POS_MASK))));                    // pixels with a hit on the general path
             RT_COUNT(9, __ballot(best[j] <= (KEY_FAR | POS_MASK) && !((wb0 >> (best[j] & 63u)) & 1ull)) != 0ull);   // ... that shade something that is not a world box
             const unsigned rgba = fast_shade<SHAPES, POS_MASK>(best[j], bn[j], s_vis, s_hdr, camv, viewer, dw[j], inv[j], dcx, dcy[j], a2[j], ldc[j]);
-            const int py = py0 + TILE_H * j;
-            if (px < W && py < H) PIXEL_STORE(out[(unsigned)(py * W + px)], rgba);   // (32-bit offset from the frame's base: scalar-base addressing)
+            put_px(po, px, py0 + TILE_H * j, rgba);
         }
     }
 #ifdef MV_RASTER_TIMING
