@@ -453,17 +453,8 @@ static int usable_host_cores()
     return std::max(1, n);
 }
 
-// the simulation stream; MV_SIM_PRIORITY=low|high gives its queue another priority than the caller's (an experiment knob: measured, no gain)
-static hipError_t create_sim_stream(hipStream_t *s)
-{
-    const char *e = getenv("MV_SIM_PRIORITY");
-    if (e && *e) {
-        int lo = 0, hi = 0;   // (numerically: lowest priority = `lo`, the larger value)
-        if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
-            return hipStreamCreateWithPriority(s, hipStreamNonBlocking, std::string(e) == "low" ? lo : hi);
-    }
-    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
-}
+// the simulation stream (another queue priority than the caller's was measured, low and high: no gain, r06k)
+static hipError_t create_sim_stream(hipStream_t *s) { return hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
 
 extern "C" {
 
@@ -1318,14 +1309,8 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
     // env (launch_step_ticks; MV_STEP_TICKS=0: k launches).  Its views are collected in the loop below.
     static const bool ticksOff = getenv("MV_STEP_TICKS") && atoi(getenv("MV_STEP_TICKS")) == 0;
     const bool obstFamily = L->scenario == SCN_OBSTACLES || L->scenario == SCN_EMPTY;
-    static const bool ticksMulti = !(getenv("MV_STEP_TICKS_MULTI") && atoi(getenv("MV_STEP_TICKS_MULTI")) == 0);   // (several agents per env, too -- TowerBuilding: two waves per env, launch_step_ticks; 0: off)
-    static const int obstMinEnvs = getenv("MV_STEP_TICKS_OBST_MIN_ENVS") ? atoi(getenv("MV_STEP_TICKS_OBST_MIN_ENVS")) : 0;   // (r06c, with the one-launch passes cut for k x frames workgroups: ObstaclesHard 512 envs 13.0 against 11.7 M obs/s, 256 envs 9.2 against 8.6)
-    // (the other scenarios, one agent per env: MV_STEP_TICKS_OTHERS=0 keeps them on one launch per tick)
-    static const bool ticksOthers = !(getenv("MV_STEP_TICKS_OTHERS") && atoi(getenv("MV_STEP_TICKS_OTHERS")) == 0);
-    const bool otherFamily = ticksOthers && (L->scenario == SCN_REARRANGE || L->scenario == SCN_SOKOBAN || L->scenario == SCN_COLLECT || L->scenario == SCN_HEX_MEMORY || L->scenario == SCN_HEX_EXPLORE);
-    const bool canMultiTick = !ticksOff && n == 1 && (L->A == 1 || (ticksMulti && L->scenario == SCN_TOWER)) && k >= 2 && k <= MAX_STEP_TICKS && render && policy != POLICY_NONE &&
-                              (L->scenario == SCN_TOWER || (obstFamily && L->N >= obstMinEnvs) || otherFamily) &&   // (Obstacles at 512 envs: 11.6 against 12.0 M obs/s, at 1024: 16.9 against 16.1; TowerBuilding 512 x 4: 21.7 against 19.4)
-                              !L->gv.dbg;
+    // (every scenario with one agent per env; several agents: TowerBuilding only -- two waves per env, launch_step_ticks)
+    const bool canMultiTick = !ticksOff && n == 1 && (L->A == 1 || L->scenario == SCN_TOWER) && k >= 2 && k <= MAX_STEP_TICKS && render && policy != POLICY_NONE && !L->gv.dbg;
     // (the one-launch observation passes only beside the one-launch step: k separate step kernels starve beside a pass that long -- 70-190 us each, r04l)
     const bool canBatchRaster = canMultiTick && render && allFast && n == 1 && k >= 2 && L->ringObs && L->ringCount >= k;
     // timing (mv_profile_begin): a batched call that takes both one-launch paths is timed as a whole -- one entry, events around the step

@@ -604,9 +604,7 @@ struct FastArgs {   // what raster_fast_kernel needs of the GymView (fewer live 
     // that reuses it finds it clean without a fill kernel in front of it (mv_api.hip: take_hist).  nullptr: not this launch's business.
     int *hist_done;
     int wg_total;
-    int nosort;   // 1: frame = position (no look-up in the cost bins; MV_RASTER_NOSORT=1, measurements)
     int tail_div, tail_split;   // d > 0: the cheapest 1/d of the frames -- the LAST workgroups of the launch -- are cut into tail_split pieces instead of the launch's split (launch_raster)
-    int graded;   // d > 0: graded split -- the most expensive 1/d of the frames are cut into 4 workgroups instead of the launch's 2 (graded_heavy)
     int planar;   // 1: tiles that one face of one world box covers take the planar path (planar_tile / overlay_tile); 0: every tile takes the general one (MV_PLANAR=0, comparisons); 2: no overlay_tile
 };
 
@@ -815,13 +813,8 @@ __device__ __forceinline__ unsigned fast_shade(unsigned best, V3 bn, const float
 
 struct FastFrame { int frame, part, viewer, nVis, split; };
 
-// Graded split.  A launch lasts as long as its slowest workgroup, and the frames differ several-fold in cost (the most expensive one about twice
-// the mean; wave life times p50 26.7, p90 33.5, max 44.2 us of a 45.6 us launch with every frame cut into two, r04e): in the cost order the
-// frames are looked up in anyway, the first graded_heavy(frames) positions -- an eighth of the frames -- are cut into four workgroups, the
-// others into two.  (Also measured: the expensive quarter into four and the cheap HALF into one, the same number of workgroups: 63 us -- a
-// whole frame per workgroup, started last, is the new tail.)  MV_RASTER_GRADED_DIV sets the divisor (8).
-__host__ __device__ inline int graded_heavy(int frames, int div) { return (frames / div) & ~7; }
-__host__ __device__ inline int graded_workgroups(int frames, int div) { return 2 * frames + 2 * graded_heavy(frames, div); }
+// the frames at the END of the cost order -- the cheapest 1/div of them, a multiple of 8 -- that a launch cuts finer than the others (launch_raster: fine-grained tail)
+__host__ __device__ inline int tail_frames(int frames, int div) { return (frames / div) & ~7; }
 
 // The fast kernels' prologue: which frame is this workgroup's, then copies (header, list, rectangles) + the separable ray tables; ends with the
 // one barrier.  Workgroup ids are dealt round-robin over the 8 XCDs; the `split` parts of one frame get ids that are congruent mod 8 so that they
@@ -837,12 +830,8 @@ __device__ __forceinline__ FastFrame fast_prologue(const FastArgs &fa, int blk, 
     int position, part;
     {
         int b = blk, first = 0, frames = fa.frames;   // the segment of the cost order this workgroup belongs to: its first position, its length, its split
-        if (fa.graded) {   // (fa.graded: the divisor)
-            const int q = graded_heavy(frames, fa.graded);
-            if (b < 4 * q) { split = 4; frames = q; }
-            else { b -= 4 * q; first = q; split = 2; frames -= q; }
-        } else if (fa.tail_div) {   // the cheapest frames / tail_div frames, last in the cost order, in tail_split pieces each (tail_frames)
-            const int q = graded_heavy(frames, fa.tail_div), head = frames - q;
+        if (fa.tail_div) {   // the cheapest frames / tail_div frames, last in the cost order, in tail_split pieces each (tail_frames)
+            const int q = tail_frames(frames, fa.tail_div), head = frames - q;
             if (b < split * head) frames = head;
             else { b -= split * head; first = head; split = fa.tail_split; frames = q; }
         }
@@ -854,8 +843,7 @@ __device__ __forceinline__ FastFrame fast_prologue(const FastArgs &fa, int blk, 
     // position -> frame, most expensive frames first: the frame setup left every frame in the list of its cost bin; prefix-sum the 256 bin
     // counts (bin 255 first) and take entry (position - start) of the bin whose range holds `position`
     __shared__ int s_wsum[4], s_frame, s_lastWG;
-    if (fa.nosort) { if (tid == 0) s_frame = position; __syncthreads(); }
-    else {
+    {
         static_assert(LPT_SUBS == 4, "the bin's counters are read as one int4");
         const bool binThread = NT == 256 || tid < LPT_BUCKETS;   // (one thread per cost bin; a 512-thread workgroup's other waves only keep the barriers company)
         const int4 c0 = binThread ? *reinterpret_cast<const int4 *>(fa.hist + (LPT_BUCKETS - 1 - tid) * LPT_SUBS) : make_int4(0, 0, 0, 0);   // the bin's LPT_SUBS counters
@@ -1357,8 +1345,6 @@ __device__ __forceinline__ void general_tile(unsigned long long mv0, unsigned lo
 constexpr int fast_lds_bytes(int maxvis) { return 40 * maxvis + 4 * FH_FLOATS; }    // records 32 B + rectangles 8 B per primitive, frame header
 constexpr int glist_lds_bytes(int maxvis) { return 9 * maxvis + 4 * FH_FLOATS; }    // rectangles 8 B + class 1 B per primitive, frame header
 
-// NT = 512 (MV_RASTER_WIDE=1, an experiment): ONE eight-wave workgroup per frame (the launch's split is 1): prologue and classification once per
-// frame instead of once per half frame, the eight waves share the frame's tiles out among them.  Measured slower (wide_workgroups below).
 template <int MAXVIS, bool SHAPES, bool HEXF, int NP, bool CLS = true, int NT = 256>   // CLS: with the tile classification
 __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *obs, int W, int H, int split, int blk, unsigned char *lds)
 {
@@ -1389,7 +1375,7 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
     const FastFrame ff = fast_prologue<MAXVIS, false, NT>(fa, blk, W, H, split, s_vis, s_rect, s_hdr, s_col, s_row, s_rowq, s_colq);
     RT_MARK(1);
     const int frame = ff.frame, part = ff.part, viewer = ff.viewer, nVis = ff.nVis;
-    split = ff.split;   // (graded split: this workgroup's frame may be cut into more or fewer pieces than the launch's nominal number)
+    split = ff.split;   // (fine-grained tail: this workgroup's frame may be cut into more pieces than the launch's nominal number)
 
     const float *camv = s_hdr + FH_CAM + FH_CAM_STRIDE * viewer;   // eye(3) c(9) origin(3)
     const float nzm0 = uniform_f32(-camv[3 + 2]), nzm1 = uniform_f32(-camv[3 + 5]), nzm2 = uniform_f32(-camv[3 + 8]);
@@ -1667,7 +1653,7 @@ __device__ __forceinline__ void raster_glist_body(const FastArgs &fa, uint32_t *
     fast_publish(fa, blk);
     const FastFrame ff = fast_prologue<MAXVIS, true>(fa, blk, W, H, split, nullptr, s_rect, s_hdr, s_col, s_row, s_rowq, s_colq, s_cls);
     const int frame = ff.frame, part = ff.part, viewer = ff.viewer, nVis = ff.nVis;
-    split = ff.split;   // (graded split: this workgroup's frame may be cut into more or fewer pieces than the launch's nominal number)
+    split = ff.split;   // (fine-grained tail: this workgroup's frame may be cut into more pieces than the launch's nominal number)
     const float4 *gp = reinterpret_cast<const float4 *>(fa.vis_prims + (size_t)frame * fa.vis_stride);   // this frame's records
     cfloat *cp = (cfloat *)gp;
 
@@ -2018,9 +2004,8 @@ static FastArgs fast_args_of(const GymView &gv, const PublishTo *publish)
     fa.pub_n = publish ? frames : 0;
     const char *pe = getenv("MV_PLANAR");   // (read at every launch: the two paths are compared within one process by tests/test_fast_pixels_gpu.py)
     fa.planar = pe && *pe ? atoi(pe) : 1;   // (2: classified, but without overlay_tile; 3: without the sign-specialised slab tests -- comparisons)
-    fa.graded = 0; fa.tail_div = 0; fa.tail_split = 0;
+    fa.tail_div = 0; fa.tail_split = 0;
     fa.hist_done = nullptr; fa.wg_total = 0;
-    { const char *ns = getenv("MV_RASTER_NOSORT"); fa.nosort = ns && atoi(ns) != 0; }
 #ifdef MV_RASTER_TIMING
     if (!g_rdbg && hipMalloc((void **)&g_rdbg, (size_t)(16384 * 4 * 8 + 64) * 8) == hipSuccess) { (void)hipMemset(g_rdbg, 0, (size_t)(16384 * 4 * 8 + 64) * 8); atexit(rdbg_dump); }
     fa.rdbg = g_rdbg;
@@ -2054,7 +2039,7 @@ static int fast_pixels_per_lane(int W, int H, bool longList = false, bool batch 
 // tiles, a prologue per workgroup): measured on 1024 frames of 128 x 128, 2: 58.0 us, 4: 61.3, 8: 69.7.  With FEW frames in a launch (a Mixed
 // group's two launches: 384 / 640 frames) a launch lasts as long as its slowest frame -- kernel traces: 128 HexMemory frames of 64 x 64 take
 // 43 us, 1024 of them 84 -- so the frame is cut into more pieces: enough workgroups to fill the chip about twice (4096 / 2048), at most 16 / 8,
-// at least one (long lists) / two tiles per wave.  MV_RASTER_SPLIT overrides.
+// at least one (long lists) / two tiles per wave.
 // ONE workgroup per frame where the launch holds workgroups for several rounds of the chip anyway -- the k passes of a batched call in one
 // launch (`batch`, frames = k x the pass's), or 4096 frames and more in a single pass: the prologue and the tile classification are paid once
 // per frame instead of twice, and the frames that start later fill in behind the early ones (r06d/r06j, TowerBuilding 128 x 128, two -> one:
@@ -2062,12 +2047,10 @@ static int fast_pixels_per_lane(int W, int H, bool longList = false, bool batch 
 // of 2048 frames 19.1 -> 18.4, of 1024: 50 -> 72 us -- 1024 workgroups are half a round).
 static int fast_split(int W, int H, int np, int frames, bool longList = false, bool batch = false)
 {
-    static const int envSplit = getenv("MV_RASTER_SPLIT") ? atoi(getenv("MV_RASTER_SPLIT")) : 0;
     const int ftiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H * np - 1) / (TILE_H * np));
     const int want = ((np >= 2 ? 2048 : 4096) + frames - 1) / std::max(frames, 1), lo = (batch || frames >= 4096) && np >= 2 && !longList ? 1 : np >= 2 ? 2 : 4, hi = np >= 2 ? 8 : 16;
     int split = lo;
     while (split < hi && split < want) split <<= 1;
-    if (envSplit > 0) split = envSplit;
     while (split > 1 && ftiles < 4 * split * (longList ? 1 : 2)) split >>= 1;
     return split;
 }
@@ -2077,16 +2060,12 @@ static int fast_split(int W, int H, int np, int frames, bool longList = false, b
 // up to 1024 (Collect, HexMemory, HexExplore: the large variant with the wall-frame box runs; a Collect frame has no wall-frame boxes and
 // takes the same path as in its own variant: its world boxes through the box runs, its cones through the general loop).  Pixels are the ones
 // each gym's own launch produces, byte for byte (same per-pixel arithmetic; tests/test_multitask_gpu.py).
-// a launch whose completion signal is `done` (null: a plain launch); MV_ATTACH_DONE=0: launch, then record (comparisons)
+// a launch whose completion signal is `done`, carried by its dispatch packet (null: a plain launch)
 template <class K, class... A>
 static void launch_done(K kernel, dim3 grid, dim3 block, size_t dyn, hipStream_t stream, hipEvent_t done, A... args)
 {
-    static const bool attach = !(getenv("MV_ATTACH_DONE") && atoi(getenv("MV_ATTACH_DONE")) == 0);
-    if (done && attach) hipExtLaunchKernelGGL(kernel, grid, block, dyn, stream, nullptr, done, 0, args...);
-    else {
-        hipLaunchKernelGGL(kernel, grid, block, dyn, stream, args...);
-        if (done) (void)hipEventRecord(done, stream);
-    }
+    if (done) hipExtLaunchKernelGGL(kernel, grid, block, dyn, stream, nullptr, done, 0, args...);
+    else hipLaunchKernelGGL(kernel, grid, block, dyn, stream, args...);
 }
 
 int launch_raster_union(const GymView *views, uint32_t *const *obs, const PublishTo *publish, int n, int W, int H, hipStream_t stream, hipEvent_t between, hipEvent_t done)
@@ -2097,8 +2076,7 @@ int launch_raster_union(const GymView *views, uint32_t *const *obs, const Publis
     int unionFrames[2] = {0, 0};
     for (int i = 0; i < n; ++i) unionFrames[views[i].vis_stride > VIS_SMALL ? 1 : 0] += views[i].num_envs * views[i].num_agents;
     if (between) (void)hipEventRecord(between, stream);
-    static const int oneLaunch = getenv("MV_UNION_ONE_LAUNCH") ? atoi(getenv("MV_UNION_ONE_LAUNCH")) : 1;
-    if (oneLaunch && unionFrames[0] > 0 && unionFrames[1] > 0) {   // both list lengths present: one launch for all gyms (raster_union_all_kernel)
+    if (unionFrames[0] > 0 && unionFrames[1] > 0) {   // both list lengths present: one launch for all gyms (raster_union_all_kernel)
         UnionRasterAllArgs a;
         a.u.n = 0;
         a.split_small = fast_split(W, H, np, unionFrames[0] + unionFrames[1], false);
@@ -2152,29 +2130,13 @@ int launch_raster_union(const GymView *views, uint32_t *const *obs, const Publis
 // the fast observation passes of k ticks of one gym (views[j]: the slot tick j's step kernel filled; obs[j] / publish[j]: where tick j's
 // outputs go, which must differ from tick to tick -- an output ring -- for the observations) with one launch; 1: not this gym (long lists, hires
 // sizes, k out of range): the caller launches tick by tick
-// Eight-wave workgroups (one per frame) where the launch would cut every frame into two four-wave ones (two pixels per lane, nominal split 2):
-// MV_RASTER_WIDE=1.  Off by default: measured r04v, the kernel alone 51.2 us against 49.6 (the classification per wave only went from 11.3 k to
-// 9.6 k cycles, and a second round made of whole frames is a longer tail), the pipelined headline 19.7 M obs/s against 22.2 M.
-static bool wide_workgroups(int split, int np)
-{
-    static const bool on = getenv("MV_RASTER_WIDE") && atoi(getenv("MV_RASTER_WIDE")) != 0;
-    return on && split == 2 && np == 2;
-}
-
-// MV_RASTER_LDS_PAD=bytes: dynamic LDS the fast kernels ask for beyond their tables (an experiment knob: caps their workgroups per CU, leaving registers to the step kernels that run beside them)
-static size_t lds_pad()
-{
-    static const size_t pad = getenv("MV_RASTER_LDS_PAD") ? (size_t)atol(getenv("MV_RASTER_LDS_PAD")) : 0;
-    return pad;
-}
-
 int launch_raster_batch(const GymView *views, uint32_t *const *obs, const PublishTo *publish, int k, int W, int H, hipStream_t stream, hipEvent_t done)
 {
     if (W > MAX_W || H > MAX_H || k < 2 || k > MAX_UNION) return 1;
     const GymView &gv = views[0];
     static const int off = getenv("MV_RASTER_BATCH") && atoi(getenv("MV_RASTER_BATCH")) == 0;
     if (off) return 1;
-    const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)W * sizeof(float) + (size_t)H * sizeof(float2) + lds_pad();
+    const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)W * sizeof(float) + (size_t)H * sizeof(float2);
     const int frames = gv.num_envs * gv.num_agents;
     const bool hexScen = gv.scenario == SCN_HEX_MEMORY || gv.scenario == SCN_HEX_EXPLORE;
     if (gv.vis_stride > VIS_SMALL || hexScen) {   // the long-list variants (records through the scalar cache)
@@ -2202,10 +2164,7 @@ int launch_raster_batch(const GymView *views, uint32_t *const *obs, const Publis
     const int np = fast_pixels_per_lane(W, H);
     // (the k passes fill the chip together -- later passes' workgroups start as earlier ones end -- so the frame is cut for k x frames of them:
     // 512 TowerBuilding frames, 8 ticks per call: 16.2 M obs/s with two workgroups per frame, 14.0 M with the four a single pass of 512 frames takes)
-    static const bool splitPerPass = getenv("MV_RASTER_BATCH_SPLIT_PER_PASS") && atoi(getenv("MV_RASTER_BATCH_SPLIT_PER_PASS")) != 0;
-    int split = fast_split(W, H, np, splitPerPass ? frames : frames * k, false, !splitPerPass);
-    const bool wide = wide_workgroups(split, np);   // a whole frame per eight-wave workgroup instead of two halves
-    if (wide) split = 1;
+    const int split = fast_split(W, H, np, frames * k, false, true);
     UnionRasterArgs ua;
     ua.n = k;
     for (int j = 0; j < k; ++j) {
@@ -2215,12 +2174,9 @@ int launch_raster_batch(const GymView *views, uint32_t *const *obs, const Publis
         self_clear(ua.fa[j], views[j], frames * split);
     }
     for (int j = k; j <= MAX_UNION; ++j) ua.first[j] = k * frames * split;
-    const dim3 grid(k * frames * split), block(wide ? 512 : 256);
+    const dim3 grid(k * frames * split), block(256);
     const bool shapes = gv.scenario == SCN_REARRANGE;
-    if (wide) {
-        if (shapes) launch_done(raster_fast_batch_kernel<VIS_SMALL, true, 6, 2, 512>, grid, block, dyn, stream, done, ua, W, H, split);
-        else launch_done(raster_fast_batch_kernel<VIS_SMALL, false, 7, 2, 512>, grid, block, dyn, stream, done, ua, W, H, split);
-    } else if (np == 2) {
+    if (np == 2) {
         if (shapes) launch_done(raster_fast_batch_kernel<VIS_SMALL, true, 6, 2>, grid, block, dyn, stream, done, ua, W, H, split);
         else launch_done(raster_fast_batch_kernel<VIS_SMALL, false, 7, 2>, grid, block, dyn, stream, done, ua, W, H, split);
     } else {
@@ -2233,69 +2189,52 @@ int launch_raster_batch(const GymView *views, uint32_t *const *obs, const Publis
 int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream, hipEvent_t between, int fast, int setup_done, const PublishTo *publish, hipEvent_t done)
 {
     if (W > MAX_W || H > MAX_H) return -1;
-    static const int envSplit = getenv("MV_RASTER_SPLIT") ? atoi(getenv("MV_RASTER_SPLIT")) : 0;
     const int tiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H * PPL - 1) / (TILE_H * PPL));
     const int frames = gv.num_envs * gv.num_agents;
     if (!setup_done) hipLaunchKernelGGL(frame_setup_kernel, dim3(frames), dim3(256), 0, stream, gv, W, H);
     if (!fast) hipLaunchKernelGGL(frame_order_kernel, dim3(1), dim3(1024), 0, stream, gv, frames, gv.lpt_order);   // (fast: no sort kernel)
     if (between) (void)hipEventRecord(between, stream);
     if (fast) {
-        const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)W * sizeof(float) + (size_t)H * sizeof(float2) + lds_pad();
+        const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)W * sizeof(float) + (size_t)H * sizeof(float2);
         const int np = fast_pixels_per_lane(W, H, gv.vis_stride > VIS_SMALL);
         const int split = fast_split(W, H, np, frames, gv.vis_stride > VIS_SMALL);
-        // variants: [0] <=256 visible primitives, [1] + scaled shapes (Rearrange), [2] <=1024 (Collect), [3] <=1024 + scaled shapes (Hex*); the
-        // small ones are built for 8 and for 6 waves per SIMD (64 / 80 VGPRs), MV_FAST_WAVES picks (two pixels per lane: 7 / 6 waves)
-        static const int wavesSel = getenv("MV_FAST_WAVES") ? atoi(getenv("MV_FAST_WAVES")) : 8;
+        // variants: <= 256 visible primitives, + scaled shapes (Rearrange), <= 1024 through the scalar cache (Collect), <= 2048 + scaled shapes + wall frames
+        // (Hex*); the short-list ones are built for 8 waves per SIMD with one pixel per lane (64 VGPRs), for 7 with two (72; with the scaled shapes: 6, 80)
         using KernelFn = void (*)(FastArgs, uint32_t *, int, int, int);
-        const FastArgs fa = fast_args_of(gv, publish);
+        FastArgs fa = fast_args_of(gv, publish);
         // (Collect, measured and rejected: a 1024-entry launch for the frames above 256 visible primitives + a 256-entry launch for the rest,
         // 75 + 69 us against 107 us for the single 1024-entry launch: each launch pays its own tail, and the cones, not occupancy, dominate)
         const bool hexScen = gv.scenario == SCN_HEX_MEMORY || gv.scenario == SCN_HEX_EXPLORE;
         KernelFn fn;
-        if (np == 2)   // (the small variants: 72 VGPRs / 7 waves, 80 / 6; at 64 they would spill)
+        if (np == 2)
             fn = hexScen ? raster_glist_kernel<VIS_XL, true, GLIST_WAVES_NP2, true, 2> : gv.vis_stride > VIS_SMALL ? raster_glist_kernel<VIS_LARGE, false, GLIST_WAVES_NP2, false, 2>
-               : gv.scenario == SCN_REARRANGE ? raster_fast_kernel<VIS_SMALL, true, 6, false, 2>   // (with the scaled shapes 72 VGPRs would spill)
-                                              : (wavesSel >= 7 ? raster_fast_kernel<VIS_SMALL, false, 7, false, 2> : raster_fast_kernel<VIS_SMALL, false, 6, false, 2>);
+               : gv.scenario == SCN_REARRANGE ? raster_fast_kernel<VIS_SMALL, true, 6, false, 2> : raster_fast_kernel<VIS_SMALL, false, 7, false, 2>;
         else
             fn = hexScen ? raster_glist_kernel<VIS_XL, true, GLIST_WAVES_NP1, true, 1> : gv.vis_stride > VIS_SMALL ? raster_glist_kernel<VIS_LARGE, false, GLIST_WAVES_NP1, false, 1>
-               : gv.scenario == SCN_REARRANGE ? (wavesSel >= 8 ? raster_fast_kernel<VIS_SMALL, true, 8> : raster_fast_kernel<VIS_SMALL, true, 6>)
-                                              : (wavesSel >= 8 ? raster_fast_kernel<VIS_SMALL, false, 8> : raster_fast_kernel<VIS_SMALL, false, 6>);
-        // graded split (graded_heavy): the short-list variants, when the nominal split is 2 and a frame has the tiles for four pieces; MV_RASTER_GRADED=0: uniform
-        static const int gradedEnv = getenv("MV_RASTER_GRADED") ? atoi(getenv("MV_RASTER_GRADED")) : 0;   // (off: measured without gain, see graded_heavy)
-        FastArgs fg = fa;
+               : gv.scenario == SCN_REARRANGE ? raster_fast_kernel<VIS_SMALL, true, 8> : raster_fast_kernel<VIS_SMALL, false, 8>;
         const int ftiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H * np - 1) / (TILE_H * np));
-        static const int gradedDiv = getenv("MV_RASTER_GRADED_DIV") ? std::max(2, atoi(getenv("MV_RASTER_GRADED_DIV"))) : 8;
-        fg.graded = gradedEnv && gv.vis_stride <= VIS_SMALL && split == 2 && ftiles >= 32 && graded_heavy(frames, gradedDiv) > 0 ? gradedDiv : 0;
-        if (!fg.graded && wide_workgroups(split, np) && gv.vis_stride <= VIS_SMALL && !hexScen) {   // a whole frame per eight-wave workgroup
-            const KernelFn wfn = gv.scenario == SCN_REARRANGE ? raster_fast_kernel<VIS_SMALL, true, 6, false, 2, 512> : raster_fast_kernel<VIS_SMALL, false, 7, false, 2, 512>;
-            self_clear(fg, gv, frames);
-            launch_done(wfn, dim3(frames), dim3(512), dyn, stream, done, fg, obs, W, H, 1);
-            return 0;
-        }
         // Fine-grained tail.  The SIMD's arbiter serves its OLDEST wave first: workgroups finish roughly in launch order whatever they cost (wave life
         // by decile of the launch order, frames in random order: 18 us for the first tenth, 35 us for the eighth, all started within 0.3 us -- r05b),
         // and a launch ends with its youngest workgroups finishing alone, a few waves per SIMD, far from filling it (the last 4 k of a SIMD's 20 k
         // vector instructions take 22 of a launch's 49 us).  So the frames at the END of the cost order -- the cheapest -- are cut into more, smaller
         // workgroups that keep arriving while the big early ones drain: the cheapest eighth in eight pieces each, 49.6 -> 48.3 us alone (r05d; a quarter
-        // in four: 48.5; a sixteenth in eight: 49.4).  MV_RASTER_TAIL_DIV (0: off) / MV_RASTER_TAIL_SPLIT.  (Also built and measured: the frame's cost as the
-        // last pass's tile classification found it fed back into the cost bins -- the right order, and 3 us slower, r05a: under oldest-first the order
-        // matters little, and the truly expensive frames all starting together crowd each other; and wave priorities -- s_setprio at every tile -- by
-        // the work the workgroup has left, "longest remaining work first": the life times flatten, the launch gets longer, 48.7 -> 50.9 us, r05g.)
-        static const int tailDiv = getenv("MV_RASTER_TAIL_DIV") ? std::max(0, atoi(getenv("MV_RASTER_TAIL_DIV"))) : 8;
-        static const int tailSplit = getenv("MV_RASTER_TAIL_SPLIT") ? std::max(2, atoi(getenv("MV_RASTER_TAIL_SPLIT"))) : 8;
-        if (!fg.graded && tailDiv >= 2 && split <= 2 && gv.vis_stride <= VIS_SMALL && ftiles >= 16 * tailSplit && graded_heavy(frames, tailDiv) > 0 && tailSplit > split) {   // (split 2: a launch that fills the chip; 512 frames in four pieces each: 12.0 M obs/s with the tail cut finer, 12.4 without, r05i)
-            const int q = graded_heavy(frames, tailDiv);
-            fg.tail_div = tailDiv; fg.tail_split = tailSplit;
-            self_clear(fg, gv, (frames - q) * split + q * tailSplit);
-            launch_done(fn, dim3((frames - q) * split + q * tailSplit), dim3(256), dyn, stream, done, fg, obs, W, H, split);
+        // in four: 48.5; a sixteenth in eight: 49.4).  (Built, measured and removed, DESIGN.md 0b.3: a graded split -- the expensive eighth in four
+        // pieces --, the frame's cost as the last pass's classification found it fed back into the cost bins, wave priorities by remaining work, a whole
+        // frame per eight-wave workgroup.)
+        constexpr int TAIL_DIV = 8, TAIL_SPLIT = 8;
+        if (split <= 2 && gv.vis_stride <= VIS_SMALL && ftiles >= 16 * TAIL_SPLIT && tail_frames(frames, TAIL_DIV) > 0) {   // (split 2: a launch that fills the chip; 512 frames in four pieces each: 12.0 M obs/s with the tail cut finer, 12.4 without, r05i)
+            const int q = tail_frames(frames, TAIL_DIV);
+            fa.tail_div = TAIL_DIV; fa.tail_split = TAIL_SPLIT;
+            self_clear(fa, gv, (frames - q) * split + q * TAIL_SPLIT);
+            launch_done(fn, dim3((frames - q) * split + q * TAIL_SPLIT), dim3(256), dyn, stream, done, fa, obs, W, H, split);
             return 0;
         }
-        self_clear(fg, gv, fg.graded ? graded_workgroups(frames, fg.graded) : frames * split);
-        launch_done(fn, dim3(fg.graded ? graded_workgroups(frames, fg.graded) : frames * split), dim3(256), dyn, stream, done, fg, obs, W, H, split);
+        self_clear(fa, gv, frames * split);
+        launch_done(fn, dim3(frames * split), dim3(256), dyn, stream, done, fa, obs, W, H, split);
         return 0;
     }
     const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)(W + H) * sizeof(float);
-    int split = envSplit > 0 ? envSplit : 4;
+    int split = 4;
     while (split > 1 && tiles < 4 * split * 2) split >>= 1;   // keep at least two tiles per wave
     const dim3 grid(frames * split), block(256);
     if (gv.scenario == SCN_HEX_MEMORY || gv.scenario == SCN_HEX_EXPLORE) hipLaunchKernelGGL((raster_kernel<VIS_XL, true>), grid, block, dyn, stream, gv, obs, W, H, split, gv.lpt_order);

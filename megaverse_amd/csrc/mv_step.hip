@@ -134,14 +134,10 @@ void launch_step_ticks(const GymView *views, int k, hipStream_t stream, int W, i
     for (int j = k; j < MAX_STEP_TICKS; ++j) a.gv[j] = views[k - 1];
     const GymView &gv = views[0];
     // several agents: TWO waves per env (measured at 512 envs x 4 agents: one wave 20.3 M obs/s, two 21.7, four 16.1 -- four waves of ~180 VGPRs per env,
-    // resident for the whole call, are what the observation passes beside them cannot have; one-launch-per-tick: 19.4); MV_STEP_TICKS_WAVES overrides
-    static const int maWaves = getenv("MV_STEP_TICKS_WAVES") ? std::max(1, std::min(4, atoi(getenv("MV_STEP_TICKS_WAVES")))) : 2;
-    const dim3 grid(gv.num_envs), block(gv.num_agents == 1 ? 64 : 64 * std::min(gv.num_agents, maWaves));
-    static const bool attach = !(getenv("MV_ATTACH_DONE") && atoi(getenv("MV_ATTACH_DONE")) == 0);   // (0: launch, then record -- comparisons)
-    hipEvent_t ride = attach ? done : nullptr;
-    if (gv.num_agents == 1) hipExtLaunchKernelGGL(step_ticks_kernel, grid, block, 0, stream, nullptr, ride, 0, a, W, H);
-    else hipExtLaunchKernelGGL(step_ticks_agents_kernel, grid, block, 0, stream, nullptr, ride, 0, a, W, H);
-    if (done && !attach) (void)hipEventRecord(done, stream);
+    // resident for the whole call, are what the observation passes beside them cannot have; one-launch-per-tick: 19.4)
+    const dim3 grid(gv.num_envs), block(gv.num_agents == 1 ? 64 : 64 * std::min(gv.num_agents, 2));
+    if (gv.num_agents == 1) hipExtLaunchKernelGGL(step_ticks_kernel, grid, block, 0, stream, nullptr, done, 0, a, W, H);
+    else hipExtLaunchKernelGGL(step_ticks_agents_kernel, grid, block, 0, stream, nullptr, done, 0, a, W, H);
 }
 
 // done: an event that completes with the launch, carried by its dispatch packet (cf. mv_raster.h)
