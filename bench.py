@@ -71,7 +71,7 @@ def host_threads():
     return max(1, n), note
 
 
-def cpu_baseline(scenario, obs_w, obs_h, n_env, agents, policy="multidiscrete"):
+def cpu_baseline(scenario, obs_w, obs_h, n_env, agents, policy="multidiscrete", full=False):
     """Oracle (CPU restatement, kind 'port') timed on this box's host cores on bounded samples of the same workload: same scenario /
     obs size / seed / action stream.  The oracle runs as BASELINE.md 3 plans it: the reference's persistent worker pool (vector_env.cpp:16-40,
     71-87: static block partition, the caller takes block 0 and spins on an atomic count), threads pinned one per allowed CPU (MVO_PIN=1),
@@ -82,7 +82,9 @@ def cpu_baseline(scenario, obs_w, obs_h, n_env, agents, policy="multidiscrete"):
       physics_only       mvo_step_norender on all threads; physics_one_thread the same on one thread, all n_env envs: their ratio is printed as
                          physics_scaling = rate(all) / (threads x rate(1)) (the serial auto-reset section and the memory system bound it);
       raster_only        mvo_render on all threads (a software raster -- NOT the reference's GL renderer; a baseline, not a target).
-    Actions go in through ONE batched call per tick."""
+    Actions go in through ONE batched call per tick.
+    full (--cpu-baseline-full): the all-threads leg exactly as BASELINE.md section 3 states it -- 100 warm-up steps, 2 000 measured steps, median of 5 runs,
+    no time bound (minutes of CPU work); the default is the bounded sample the bench contract asks for (seconds), and the `sample` string says which ran."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib
@@ -95,7 +97,7 @@ def cpu_baseline(scenario, obs_w, obs_h, n_env, agents, policy="multidiscrete"):
             return sample_single_bit_masks(1234, step, n * agents)
         return action_masks(sample_actions(1234, step, n * agents))
 
-    def leg(n, T, what, budget_s, reps=3, pin=None, warm=20):
+    def leg(n, T, what, budget_s, reps=3, pin=None, warm=20, max_steps=700):
         old = None
         if pin is not None and hasattr(os, "sched_setaffinity"):
             old = os.sched_getaffinity(0)
@@ -123,7 +125,7 @@ def cpu_baseline(scenario, obs_w, obs_h, n_env, agents, policy="multidiscrete"):
                     steps += 1
                     st += 1
                     el = time.perf_counter() - t0
-                    if el > budget_s / reps or steps >= 700:
+                    if (budget_s is not None and el > budget_s / reps) or steps >= max_steps:
                         break
                 rates.append(n * agents * steps / el)
                 steps_total += steps
@@ -136,7 +138,7 @@ def cpu_baseline(scenario, obs_w, obs_h, n_env, agents, policy="multidiscrete"):
                 "steps": steps_total, "seconds": round(t_total, 2), "median_of": reps, "warmup_ticks": warm}
 
     n1 = max(1, min(n_env, 4))
-    legs = {"all_threads": leg(n_env, threads, "full", 8.0),
+    legs = {"all_threads": leg(n_env, threads, "full", None, reps=5, warm=100, max_steps=2000) if full else leg(n_env, threads, "full", 8.0),
             "one_thread": leg(n1, 1, "full", 4.0, pin=0),
             "physics_only": leg(n_env, threads, "physics", 3.0),
             "physics_one_thread": leg(n_env, 1, "physics", 3.0, pin=0),
@@ -146,7 +148,9 @@ def cpu_baseline(scenario, obs_w, obs_h, n_env, agents, policy="multidiscrete"):
            "physics_scaling": legs["physics_only"]["value"] / (threads * legs["physics_one_thread"]["value"]),
            "sample": f"oracle (CPU restatement of VectorEnv::step with a tile-culled software raster; NOT the reference binary) {scenario} num_envs={n_env} agents={agents} "
                      f"obs {obs_w}x{obs_h}, policy {policy}: {a['steps']} steps in {a['seconds']} s on {threads} pinned threads ({quota_note}; persistent worker pool, static block "
-                     f"partition, caller participates: vector_env.cpp:16-40,65-87), 20 warm-up ticks, median of {a['median_of']}; one_thread = {n1} envs pinned to one core"}
+                     f"partition, caller participates: vector_env.cpp:16-40,65-87), {a['warmup_ticks']} warm-up ticks, median of {a['median_of']}"
+                     f"{' (BASELINE.md section 3 in full: --cpu-baseline-full)' if full else ' (a bounded sample: the plan of BASELINE.md section 3 in full -- 100 warm-up, 2 000 steps, median of 5 -- runs with --cpu-baseline-full)'}; "
+                     f"one_thread = {n1} envs pinned to one core"}
     out.update(legs)
     return out
 
@@ -311,6 +315,8 @@ def main():
     ap.add_argument("--gather-format", default="rgb", choices=["rgba", "rgb"],
                     help="N>1: what the gather moves: the slab as rendered, or R, G, B packed on the communication stream (alpha is 255 everywhere): 3/4 of the bytes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="the CPU baseline's all-threads leg as BASELINE.md section 3 states it: 100 warm-up steps, 2 000 measured steps, median of 5 runs (minutes); default: a bounded sample")
     ap.add_argument("--pixels", default="fast", choices=["fast", "exact"], help="observation arithmetic (DESIGN.md 'pixel tolerance')")
     ap.add_argument("--policy", default="multidiscrete", choices=["multidiscrete", "single-bit"],
                     help="random policy: uniform per head (action_space.sample(), megaverse_env.py:110-112) or the reference benchmark's "
@@ -365,7 +371,7 @@ def main():
         os.environ.setdefault("BOXOBAN_LEVELS", os.path.join(ROOT, "tests", "golden", "boxoban"))
     W, H = args.obs
     n_env, A = args.envs_per_gpu, args.agents
-    mixed = args.scenario.lower() == "mixed"
+    mixed = args.scenario.lower() in ("mixed", "mixed4")
     frames = n_env * A
     batch = args.batch if args.batch > 0 else 8
     os.environ.setdefault("MV_PIPE_BATCH", str(max(8, min(16, batch))))
@@ -374,7 +380,9 @@ def main():
         gym = DryGym(rank)
     elif mixed:   # BASELINE.json configs[4]: the eight MEGAVERSE8 scenarios dealt round-robin by env index
         from megaverse_amd.multitask import MEGAVERSE_IN_SCOPE, MultiTaskGym
-        gym = MultiTaskGym(MEGAVERSE_IN_SCOPE, W, H, n_env, A, 8, {}, device=local_rank, env_offset=rank * n_env, total_envs=world * n_env)
+        # --scenario Mixed: the reference's eight-scenario multi-task set (megaverse_env.py:11-20); Mixed4: the four BASELINE.md section 3 row 5 names
+        mixed_set = ["TowerBuilding", "ObstaclesEasy", "ObstaclesHard", "Collect"] if args.scenario.lower() == "mixed4" else MEGAVERSE_IN_SCOPE
+        gym = MultiTaskGym(mixed_set, W, H, n_env, A, 0, {}, device=local_rank, env_offset=rank * n_env, total_envs=world * n_env)
         gym.set_pixel_mode(args.pixels)
     else:
         from megaverse_amd.extension import MegaverseGym
@@ -403,7 +411,10 @@ def main():
     ring_done = torch.zeros((ring_slots, n_env), dtype=torch.uint8, device=device) if ring is not None else None
 
     def set_ring():
-        gym.set_output_ring(ring_slots, ring.data_ptr(), ring_rew.data_ptr(), ring_done.data_ptr())
+        if mixed:   # one set of rings per scenario (MultiTaskGym.set_output_ring): a batched group call is then two launches
+            gym.set_output_ring(ring_slots)
+        else:
+            gym.set_output_ring(ring_slots, ring.data_ptr(), ring_rew.data_ptr(), ring_done.data_ptr())
 
     def bind(b):
         if dry:
@@ -471,7 +482,7 @@ def main():
 
     step0 = 0
     main_batched = batched and not do_gather
-    if main_batched and ring is not None:
+    if main_batched and (ring is not None or mixed):
         set_ring()
         if pass_overlap:
             gym.set_pass_overlap(True)
@@ -483,7 +494,7 @@ def main():
     elapsed_no_gather = None
     if do_gather:                            # second leg, same step count, observations stay on the producing GPU
         bind(0)
-        if batched and ring is not None:
+        if batched and (ring is not None or mixed):
             set_ring()
         elapsed_no_gather = timed(step0, False, batched)
         step0 += args.steps
@@ -510,7 +521,10 @@ def main():
         if mixed:
             prof = prof[0]   # (the union launches are timed on the group leader's events)
         step0 += args.profile_steps
-    if batched and ring is not None:
+    mixed_ring_checksum = 0
+    if batched and mixed and getattr(gym, "ring_obs", None):
+        mixed_ring_checksum = sum(int(r[:, ::97].to(torch.int64).sum().item()) for r in gym.ring_obs)
+    if batched and (ring is not None or mixed):
         gym.set_output_ring(0)
         bind(0)
 
@@ -602,6 +616,7 @@ def main():
     checksum = int(slabs[0][::97].to(torch.int64).sum().item())   # touch the result so nothing is optimised away
     if ring is not None:
         checksum += int(ring[:, ::97].to(torch.int64).sum().item())
+    checksum += mixed_ring_checksum
     if dry and do_gather:   # every rank's shard of the last gathered step must have arrived, in rank order
         g0 = gather.out[last_gathered & 1]
         for r in range(world):
@@ -653,8 +668,10 @@ def main():
                        "pipelined": pipelined, "ticks_per_call": batch if main_batched else 1,
                        **({"ring_slots": ring_slots, "overlapped_passes": bool(pass_overlap)} if main_batched else {}),
                        **({"first_calls": os.environ.get("MV_BENCH_CALL_SCHEDULE", "2,4,6") + " ticks, then ticks_per_call (every tick stepped and rendered in full)"} if main_batched else {}),
-                       **({"launches_per_tick": 2, "scenarios": "TowerBuilding, ObstaclesEasy, ObstaclesHard, Collect, Sokoban, HexMemory, HexExplore, Rearrange dealt round-robin "
-                                                              "by env index (one gym per scenario, stepped as one mv_group: one step launch and one raster launch per tick)"} if mixed else {}),
+                       **({"launches_per_call": 2 if main_batched else None, "launches_per_tick": None if main_batched else 2,
+                           "scenarios": ", ".join(gym.scenarios) + " dealt round-robin by env index (one gym per scenario, stepped as one mv_group: "
+                                        + ("one step launch and one observation launch per batched CALL, every scenario's ticks in its own rollout rings)" if main_batched
+                                           else "one step launch and one raster launch per tick)")} if mixed else {}),
                        "parallelism": f"env-shard x{world}"},
         }
         for key, el in extra.items():
@@ -679,6 +696,11 @@ def main():
         if do_gather:
             slab_bytes = frames * H * W * gather.channels
             line["value_no_gather"] = total_obs / elapsed_no_gather
+            # north_star: "near-linear env-shard scaling" -- the envs shard without any exchange, so the claim about the SIMULATOR is read against
+            # value_no_gather (every rank's observations stay in its own HBM, where a per-GPU learner consumes them: the reference's own 8-GPU recipe,
+            # performance_benchmark_all_envs.py:3-21); `value` adds north_star's "RCCL all-gather to assemble the final observation batch", whose cost is the
+            # links' (gather.link_bound_*): at these rates it, not the simulator, bounds `value` from about two GPUs on
+            line["scaling_claim_read_against"] = "value_no_gather (simulator, shards only); value = the same steps with every rank receiving the whole batch over xGMI"
             line["ms_per_step_no_gather"] = elapsed_no_gather / args.steps * 1e3
             line["gather"] = {"collective": ("all_gather_into_tensor (RCCL)" if args.gather == "allgather" else "grouped isend / irecv, one shard per peer (RCCL point-to-point)") +
                                             ", double-buffered on a communication stream",
@@ -746,7 +768,7 @@ def main():
                 from megaverse_amd.multitask import MEGAVERSE_IN_SCOPE as _MT
                 line["cpu_baseline"] = cpu_baseline_mixed(_MT, W, H, n_env, A)
             else:
-                line["cpu_baseline"] = cpu_baseline(args.scenario, W, H, n_env, A, args.policy)
+                line["cpu_baseline"] = cpu_baseline(args.scenario, W, H, n_env, A, args.policy, full=args.cpu_baseline_full)
         print(json.dumps(line), flush=True)
 
     gym.close()

@@ -1323,6 +1323,11 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
         ++L->profCount;
     }
     const bool multiTick = canMultiTick && (!profiling || callEv);
+    // A group (n > 1), several rendered ticks with device-drawn actions, every member with an observation ring at least k deep and one agent per env: ONE
+    // union step launch runs the k ticks of every env of every gym (step_union_ticks_kernel) and ONE launch draws their k x n observation passes
+    // (raster_union_batch_kernel) -- two launches per call where the tick-by-tick path takes 2 k (BASELINE configs[4]: the scenarios of a multi-task batch).
+    bool groupBatch = n > 1 && !ticksOff && own && render && allFast && k >= 2 && k <= MAX_STEP_TICKS && policy != POLICY_NONE && !profiling && raster_union_batch_applicable(k, n, L->w, L->h);
+    for (int i = 0; i < n && groupBatch; ++i) groupBatch = gs[i]->A == 1 && gs[i]->ringObs && gs[i]->ringCount >= k && !gs[i]->gv.dbg;
     for (int j = 0; j < k; ++j) {
         const bool prof = !callEv && render && L->profCount < L->profMax;
         evs[j] = prof ? &L->profEvents[(size_t)L->profCount * 5] : nullptr;
@@ -1335,12 +1340,13 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
             if (policy != POLICY_NONE) { g->gv.sample_on = policy; g->gv.sample_seed = seed; g->gv.sample_step = first_index + (uint32_t)j; }
             else { g->gv.sample_on = (j == 0 && g->samplePending) ? g->samplePolicy : (int)POLICY_NONE; }
             g->parity = g->group * g->batch + j;
-            if (render && take_hist(g, sim, !multiTick)) return -1;   // (this pass's frame setup fills the next cost histogram; one launch per tick: and clears the one after)
+            if (render && take_hist(g, sim, !(multiTick || groupBatch))) return -1;   // (this pass's frame setup fills the next cost histogram; one launch per tick: and clears the one after)
             OutPtrs &o = outs[(size_t)j * n + i];
             o = outputs_of(g, g->ringTick++);
             GymView &v = views[(size_t)j * n + i];
             v = view(g, g->parity, own ? nullptr : &o);
             if (j == 0 && g->gv.sample_on == POLICY_NONE) v.md_actions = g->mdActions;
+            if (groupBatch) v.lpt_no_clear = 1;   // (the passes clear their histograms themselves: mv_raster.hip, hist_done)
             if (n > 1) { ua.first[i] = envs; ua.gv[i] = v; envs += g->N; }
         }
         if (evs[j]) HIP_TRY(hipEventRecord(evs[j][0], sim));
@@ -1363,7 +1369,20 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
                 simDoneRides = own && !callEv && L->scenario == SCN_TOWER;
             }
         } else if (n == 1) simDoneRides = launch_step_of(L, views[(size_t)j * n], sim, fused, own && j == k - 1 && !evs[j] ? L->simDone : nullptr);
-        else {
+        else if (groupBatch) {
+            if (j == k - 1) {   // every tick's views are collected: one launch for the k ticks of all n gyms
+                UnionTicksArgs ta;
+                ta.n = n; ta.k = k;
+                for (int i = 0; i < n; ++i) {
+                    ta.first[i] = ua.first[i];
+                    ta.gv[i] = views[(size_t)i];   // tick 0's
+                    ta.slot_stride[i] = (int64_t)((const uint8_t *)views[(size_t)n + i].vis_prims - (const uint8_t *)views[(size_t)i].vis_prims);
+                }
+                for (int i = n; i <= MAX_UNION; ++i) ta.first[i] = envs;
+                for (int i = n; i < MAX_UNION; ++i) { ta.gv[i] = views[0]; ta.slot_stride[i] = 0; }
+                launch_step_union_ticks(ta, sim, L->w, L->h);
+            }
+        } else {
             for (int i = n; i <= MAX_UNION; ++i) ua.first[i] = envs;
             launch_step_union(ua, sim, L->w, L->h, fused);
         }
@@ -1453,6 +1472,18 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
                 if (callEv) HIP_TRY(hipEventRecord(callEv[4], L->stream));
                 chunkFirst = j + 1;
                 chunkPubs.clear(); chunkObs.clear();
+            }
+        } else if (render && groupBatch) {
+            if (j == k - 1) {   // the k x n observation passes of the call with one launch
+                std::vector<PublishTo> allPubs((size_t)n * k);
+                std::vector<uint32_t *> allObs((size_t)n * k);
+                for (size_t q = 0; q < (size_t)n * k; ++q) {
+                    allPubs[q] = PublishTo{outs[q].rewards, outs[q].done, gs[q % (size_t)n]->gv.true_objective};
+                    allObs[q] = outs[q].obs;
+                }
+                const int r = launch_raster_union_batch(views.data(), allObs.data(), allPubs.data(), k, n, L->w, L->h, L->stream, mark);
+                if (r != 0) return fail(r == -2 ? "mv_group_step: the hand-over slots of a batched call are not one slot apart (internal)" : "mv_group_step: observation size above 1024x1024");
+                for (size_t q = 0; q < (size_t)n * k; ++q) gs[q % (size_t)n]->histClean[(size_t)views[q].lpt_parity] = 1;   // (every pass leaves its cost histogram zero)
             }
         } else if (render) {
             const bool pubInRaster = own && allFast;

@@ -33,6 +33,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <cstring>
 #include <numeric>
 #include <vector>
 #include <stdio.h>
@@ -1899,6 +1900,68 @@ __global__ __launch_bounds__(256, WAVES) void raster_union_all_kernel(UnionRaste
     else raster_fast_body<VIS_SMALL, true, false, NPS, false>(a.u.fa[s], a.u.obs[s], W, H, a.split_small, blk, s_buf);   // (no tile classification: this kernel's LDS is the long-list body's, and occupancy is what it lives on)
 }
 
+// The observation passes of the k ticks of ONE batched group call (mv_group_step: n gyms -- scenarios -- x k ticks) with one launch: what
+// raster_fast_batch_kernel does for one gym and raster_union_all_kernel for one tick, together.  Workgroups are dealt tick by tick (tick j's passes start
+// in the tail of tick j - 1's), inside a tick gym by gym, the long-list gyms first.  k x n FastArgs do not fit the 4 KB of kernel arguments: tick 0's are
+// passed, tick j's differ from them in the hand-over slot (slot_stride bytes further per tick: mv_union.h, tick_view), the cost histogram (consecutive,
+// modulo their number) and where the outputs go (passed per tick: rings wrap).
+struct UnionBatchArgs {
+    int32_t n, k, per_tick;             // gyms, ticks, workgroups of one tick's passes
+    int32_t first[MAX_UNION + 1];       // first workgroup of gym s within a tick; first[n] = per_tick
+    int32_t large[MAX_UNION];
+    int32_t split_small, split_large;
+    int32_t hists[MAX_UNION], parity0[MAX_UNION];   // gym s: its cost histograms, the one tick 0's pass draws from
+    int64_t slot_stride[MAX_UNION];
+    const int *hist_base[MAX_UNION];    // histogram 0 of gym s
+    int *done_base[MAX_UNION];          // "workgroups that have looked their frame up" counter of histogram 0 (null: the pass does not clear its histogram)
+    uint32_t *obs[MAX_STEP_TICKS][MAX_UNION];
+    float *pub_rewards[MAX_STEP_TICKS][MAX_UNION];
+    uint8_t *pub_done[MAX_STEP_TICKS][MAX_UNION];
+    FastArgs fa[MAX_UNION];             // tick 0's
+};
+static_assert(sizeof(UnionBatchArgs) + 16 <= 4096, "UnionBatchArgs + (W, H) must fit the 4 KB kernel-argument segment");
+
+__device__ __forceinline__ FastArgs union_batch_args(const UnionBatchArgs &a, int s, int t)
+{
+    FastArgs f = a.fa[s];
+    const int64_t d = a.slot_stride[s] * t;
+    f.vis_hdr += d;
+    f.vis_prims = reinterpret_cast<const Prim *>(reinterpret_cast<const unsigned char *>(f.vis_prims) + d);
+    f.vis_rects = reinterpret_cast<const short4 *>(reinterpret_cast<const unsigned char *>(f.vis_rects) + d);
+    f.list = reinterpret_cast<const int *>(reinterpret_cast<const unsigned char *>(f.list) + d);
+    f.stage_rewards = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(f.stage_rewards) + d);
+    f.stage_true = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(f.stage_true) + d);
+    f.stage_done += d;
+    const int par = (a.parity0[s] + t) % a.hists[s];
+    f.hist = a.hist_base[s] + par * (LPT_BUCKETS * LPT_SUBS);
+    f.hist_done = a.done_base[s] ? a.done_base[s] + par : nullptr;
+    f.pub_rewards = a.pub_rewards[t][s];
+    f.pub_done = a.pub_done[t][s];
+    return f;
+}
+
+template <int WAVES, int NPS>
+__global__ __launch_bounds__(256, WAVES) void raster_union_batch_kernel(UnionBatchArgs a, int W, int H)
+{
+    int j = 0, r = (int)blockIdx.x;
+    while (r >= a.per_tick) { r -= a.per_tick; ++j; }   // (at most k - 1 scalar iterations)
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_UNION; ++i)
+        if (i < a.n && r >= a.first[i]) s = i;
+    const int blk = r - a.first[s];
+    // the staged outputs of ALL k ticks of gym s are published by the first workgroups of its tick-0 pass, element by element in tick order (what a later
+    // tick does not touch -- true_objective of an env that did not finish -- keeps the earlier tick's value, as with one launch per tick)
+    if (j == 0)
+        for (int t = 0; t < a.k; ++t) fast_publish(union_batch_args(a, s, t), blk);
+    constexpr int LDS = fast_lds_bytes(VIS_SMALL) > glist_lds_bytes(VIS_XL) ? fast_lds_bytes(VIS_SMALL) : glist_lds_bytes(VIS_XL);
+    __shared__ __attribute__((aligned(16))) unsigned char s_buf[LDS];
+    FastArgs fa = union_batch_args(a, s, j);
+    fa.pub_n = 0;
+    if (a.large[s]) raster_glist_body<VIS_XL, true, true, 1>(fa, a.obs[j][s], W, H, a.split_large, blk, s_buf);
+    else raster_fast_body<VIS_SMALL, true, false, NPS, false>(fa, a.obs[j][s], W, H, a.split_small, blk, s_buf);
+}
+
 #ifdef MV_RASTER_TIMING
 static unsigned long long *g_rdbg = nullptr;
 static void rdbg_dump()
@@ -2095,7 +2158,7 @@ int launch_raster_union(const GymView *views, uint32_t *const *obs, const Publis
         for (int i = a.u.n; i <= MAX_UNION; ++i) a.u.first[i] = wgs;
         for (int i = a.u.n; i < MAX_UNION; ++i) a.large[i] = 0;
         if (np == 2) launch_done(raster_union_all_kernel<6, 2>, dim3(wgs), dim3(256), dyn, stream, done, a, W, H);
-        else launch_done(raster_union_all_kernel<8, 1>, dim3(wgs), dim3(256), dyn, stream, done, a, W, H);
+        else launch_done(raster_union_all_kernel<7, 1>, dim3(wgs), dim3(256), dyn, stream, done, a, W, H);
         return 0;
     }
     for (int large = 1; large >= 0; --large) {   // the expensive frames first
@@ -2130,6 +2193,60 @@ int launch_raster_union(const GymView *views, uint32_t *const *obs, const Publis
 // the fast observation passes of k ticks of one gym (views[j]: the slot tick j's step kernel filled; obs[j] / publish[j]: where tick j's
 // outputs go, which must differ from tick to tick -- an output ring -- for the observations) with one launch; 1: not this gym (long lists, hires
 // sizes, k out of range): the caller launches tick by tick
+// the fast observation passes of k ticks of n gyms (a batched group call: views / obs / publish tick-major, [j * n + i]) with ONE launch
+// (raster_union_batch_kernel); 1: not applicable -- decide with raster_union_batch_applicable BEFORE the step launch (its frame setups then leave the
+// clearing of the cost histograms to the passes)
+bool raster_union_batch_applicable(int k, int n, int W, int H)
+{
+    static const int off = getenv("MV_RASTER_BATCH") && atoi(getenv("MV_RASTER_BATCH")) == 0;
+    return !off && W <= MAX_W && H <= MAX_H && k >= 2 && k <= MAX_STEP_TICKS && n >= 1 && n <= MAX_UNION;
+}
+
+int launch_raster_union_batch(const GymView *views, uint32_t *const *obs, const PublishTo *publish, int k, int n, int W, int H, hipStream_t stream, hipEvent_t done)
+{
+    if (!raster_union_batch_applicable(k, n, W, H)) return 1;
+    const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)W * sizeof(float) + (size_t)H * sizeof(float2);
+    const int np = fast_pixels_per_lane(W, H);
+    int unionFrames[2] = {0, 0};
+    for (int i = 0; i < n; ++i) unionFrames[views[i].vis_stride > VIS_SMALL ? 1 : 0] += views[i].num_envs * views[i].num_agents;
+    UnionBatchArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.n = 0; a.k = k;
+    a.split_small = fast_split(W, H, np, (unionFrames[0] + unionFrames[1]) * k, false, true);
+    a.split_large = fast_split(W, H, 1, (unionFrames[0] + unionFrames[1]) * k, true, true);
+    int wgs = 0;
+    for (int large = 1; large >= 0; --large)   // the expensive frames first
+        for (int i = 0; i < n; ++i) {
+            const GymView &v0 = views[i];
+            if ((v0.vis_stride > VIS_SMALL) != (large != 0)) continue;
+            const int q = a.n++;
+            const int frames = v0.num_envs * v0.num_agents, split = large ? a.split_large : a.split_small;
+            a.first[q] = wgs;
+            a.large[q] = large;
+            a.fa[q] = fast_args_of(v0, publish ? &publish[i] : nullptr);
+            a.fa[q].wg_total = frames * split;
+            a.hists[q] = v0.lpt_hists; a.parity0[q] = v0.lpt_parity;
+            a.hist_base[q] = v0.lpt_hist;
+            a.done_base[q] = v0.lpt_no_clear ? v0.lpt_hist + (size_t)v0.lpt_hists * (LPT_BUCKETS * LPT_SUBS) : nullptr;
+            a.slot_stride[q] = k > 1 ? (int64_t)(reinterpret_cast<const unsigned char *>(views[n + i].vis_prims) - reinterpret_cast<const unsigned char *>(v0.vis_prims)) : 0;
+            for (int j = 0; j < k; ++j) {   // (tick j's view is tick 0's, one slot further per tick: mv_union.h)
+                const GymView &vj = views[(size_t)j * n + i], want = tick_view(v0, a.slot_stride[q], j);
+                if (vj.vis_prims != want.vis_prims || vj.vis_hdr != want.vis_hdr || vj.lpt_list != want.lpt_list || vj.rewards != want.rewards || vj.done != want.done ||
+                    vj.true_objective != want.true_objective || vj.lpt_parity != want.lpt_parity || vj.lpt_no_clear != v0.lpt_no_clear)
+                    return -2;
+                a.obs[j][q] = obs[(size_t)j * n + i];
+                a.pub_rewards[j][q] = publish ? publish[(size_t)j * n + i].rewards : nullptr;
+                a.pub_done[j][q] = publish ? publish[(size_t)j * n + i].done : nullptr;
+            }
+            wgs += frames * split;
+        }
+    for (int i = a.n; i <= MAX_UNION; ++i) a.first[i] = wgs;
+    a.per_tick = wgs;
+    if (np == 2) launch_done(raster_union_batch_kernel<6, 2>, dim3(wgs * k), dim3(256), dyn, stream, done, a, W, H);
+    else launch_done(raster_union_batch_kernel<7, 1>, dim3(wgs * k), dim3(256), dyn, stream, done, a, W, H);
+    return 0;
+}
+
 int launch_raster_batch(const GymView *views, uint32_t *const *obs, const PublishTo *publish, int k, int W, int H, hipStream_t stream, hipEvent_t done)
 {
     if (W > MAX_W || H > MAX_H || k < 2 || k > MAX_UNION) return 1;

@@ -53,6 +53,59 @@ __global__ __launch_bounds__(256) void step_union_kernel(UnionStepArgs ua, int W
     }
 }
 
+// k ticks of every env of every gym of the group, the env's workgroup resident for the whole call (cf. mv_step.hip: step_ticks_kernel): tick, frame setup
+// into tick j's slot, tick, ...  Built for the register budget of the other resident multi-tick kernels (they run beside the observation passes of the
+// previous call, and what they hold the passes cannot have).
+// One wave per env -- except for the gyms with long frame lists (Collect, Hex*: up to 2048 visible primitives): their frame setup is most of their tick, one wave
+// per env made their envs the launch's stragglers (57 us per tick where the short-list scenarios need 15-20: measured r08i), so the launch has WAVES waves per
+// workgroup, the long-list gyms use them all for the frame setup (wave 0 ticks, the others wait at the barrier) and the other gyms' extra waves leave at once.
+#ifndef MV_UNION_TICKS_WAVES_PER_SIMD
+#define MV_UNION_TICKS_WAVES_PER_SIMD 3   // the register budget (512 / n): all eight scenarios' ticks in one kernel need ~175 VGPRs; at 128 it spills 1.1 KB per lane into the ticks' inner loops
+#endif
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES, MV_UNION_TICKS_WAVES_PER_SIMD) void step_union_ticks_kernel(UnionTicksArgs ua, int W, int H)
+{
+    __shared__ FrameScratch s_fs;
+    __shared__ DepthSortScratch s_ds;
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_UNION; ++i)
+        if (i < ua.n && (int)blockIdx.x >= ua.first[i]) s = i;
+    const int env = (int)blockIdx.x - ua.first[s];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const bool wide = WAVES > 1 && ua.gv[s].vis_stride > VIS_SMALL;   // (uniform over the workgroup)
+    if (!wide && wave > 0) return;
+    for (int j = 0; j < ua.k; ++j) {
+        const GymView gv = tick_view(ua.gv[s], ua.slot_stride[s], j);
+        if (wave == 0) {
+            switch (gv.scenario) {   // (uniform per workgroup)
+            case SCN_TOWER: tick_tower::tower_tick<1>(gv, env); break;
+            case SCN_OBSTACLES:
+            case SCN_EMPTY: tick_obstacles::obstacles_tick<1>(gv, env); break;
+            case SCN_COLLECT: tick_collect::collect_tick<1>(gv, env); break;
+            case SCN_REARRANGE: tick_rearrange::rearrange_tick<1>(gv, env); break;
+            case SCN_SOKOBAN: tick_sokoban::sokoban_tick<1>(gv, env); break;
+            default: tick_hex::hex_tick<1>(gv, env); break;   // SCN_HEX_MEMORY, SCN_HEX_EXPLORE
+            }
+        }
+        if (wide) {
+            __syncthreads();   // the tick's stores (same CU: same L1) before the frame setup's loads
+            frame_setup_body<64 * WAVES, false>(gv, env, W, H, s_fs, &s_ds);   // (ends with a barrier: the next tick starts when every wave is done with the state)
+        } else {
+            wave_sync();   // one wave: no barrier needed
+            frame_setup_body<64, true>(gv, env, W, H, s_fs, &s_ds);
+        }
+    }
+}
+
+void launch_step_union_ticks(const UnionTicksArgs &ua, hipStream_t stream, int W, int H)
+{
+    bool anyLong = false;
+    for (int i = 0; i < ua.n; ++i) anyLong = anyLong || ua.gv[i].vis_stride > VIS_SMALL;
+    if (anyLong) hipLaunchKernelGGL(step_union_ticks_kernel<4>, dim3(ua.first[ua.n]), dim3(256), 0, stream, ua, W, H);
+    else hipLaunchKernelGGL(step_union_ticks_kernel<1>, dim3(ua.first[ua.n]), dim3(64), 0, stream, ua, W, H);
+}
+
 void launch_step_union(const UnionStepArgs &ua, hipStream_t stream, int W, int H, int render)
 {
     const int A = ua.gv[0].num_agents;

@@ -16,6 +16,39 @@ struct UnionStepArgs {
 
 static_assert(sizeof(UnionStepArgs) + 16 <= 4096, "UnionStepArgs + (W, H, render) must fit the 4 KB kernel-argument segment");
 
+// k consecutive ticks of every gym of a group with ONE launch (step_union_ticks_kernel): tick 0's view of every gym; tick j's differs from it in its
+// hand-over slot -- ten buffers, all `slot_stride` bytes further per tick (mv_api.hip carves a gym's slots out of its arena one after the other) --, its
+// action index and its cost histogram (consecutive, modulo their number): derived in the kernel (tick_view), not passed (k x n views do not fit the 4 KB of
+// kernel arguments).
+struct UnionTicksArgs {
+    int32_t n, k;
+    int32_t first[MAX_UNION + 1];
+    int64_t slot_stride[MAX_UNION];
+    GymView gv[MAX_UNION];
+};
+static_assert(sizeof(UnionTicksArgs) + 16 <= 4096, "UnionTicksArgs + (W, H) must fit the 4 KB kernel-argument segment");
+
+__host__ __device__ inline GymView tick_view(const GymView &base, int64_t slot_stride, int j)
+{
+    GymView v = base;
+    const int64_t d = slot_stride * j;
+    v.vis_prims = (uint8_t *)base.vis_prims + d;
+    v.vis_rects = (uint8_t *)base.vis_rects + d;
+    v.vis_count = (int32_t *)((uint8_t *)base.vis_count + d);
+    v.lpt_bucket = (int32_t *)((uint8_t *)base.lpt_bucket + d);
+    v.lpt_order = (int32_t *)((uint8_t *)base.lpt_order + d);
+    v.vis_hdr = base.vis_hdr + d;
+    v.lpt_list = (int32_t *)((uint8_t *)base.lpt_list + d);
+    v.rewards = (float *)((uint8_t *)base.rewards + d);
+    v.done = base.done + d;
+    v.true_objective = (float *)((uint8_t *)base.true_objective + d);
+    v.sample_step = base.sample_step + (uint32_t)j;
+    v.lpt_parity = (base.lpt_parity + j) % base.lpt_hists;
+    return v;
+}
+
+void launch_step_union_ticks(const UnionTicksArgs &ua, hipStream_t stream, int W, int H);   // (one agent per env)
+
 void launch_step_union(const UnionStepArgs &ua, hipStream_t stream, int W, int H, int render);
 
 }  // namespace mv

@@ -47,6 +47,7 @@ class MultiTaskGym:
         self._obs = None
         self._handles = None
         self._sample = None
+        self.ring_obs = self.ring_rewards = self.ring_dones = None
 
     # ---- plumbing: torch owns the slab and the streams
     def attach(self, torch_device):
@@ -74,6 +75,27 @@ class MultiTaskGym:
         for k, g in enumerate(self.gyms):
             g.set_obs_buffer(obs.data_ptr() + k * n * A * frame_bytes)
         return obs
+
+    def set_output_ring(self, count):
+        """Rollout rings, one set per scenario (mv_set_output_ring): tick t of sub-gym k leaves its observations in ``ring_obs[k][t % count]``
+        ([count, n_k * A, h, w, 4] uint8), its rewards in ``ring_rewards[k][t % count]`` and its dones in ``ring_dones[k][t % count]``.  With rings at
+        least as deep as a call, ``step_n`` is TWO launches for all scenarios and all of its ticks (one union step launch, one union observation
+        launch).  count = 0: back to the shared slab.  -> (ring_obs, ring_rewards, ring_dones), lists of CUDA tensors."""
+        import torch
+        if count <= 0:
+            for g in self.gyms:
+                g.set_output_ring(0)
+            self.ring_obs = self.ring_rewards = self.ring_dones = None
+            return None
+        dev = self._obs.device if self._obs is not None else torch.device("cuda", self.gyms[0].device if hasattr(self.gyms[0], "device") else 0)
+        A, n = self.num_agents_per_env, self.per_task
+        self.ring_obs = [torch.zeros((count, n * A, self.h, self.w, 4), dtype=torch.uint8, device=dev) for _ in self.gyms]
+        self.ring_rewards = [torch.zeros((count, n * A), dtype=torch.float32, device=dev) for _ in self.gyms]
+        self.ring_dones = [torch.zeros((count, n), dtype=torch.uint8, device=dev) for _ in self.gyms]
+        torch.cuda.synchronize(dev)
+        for k, g in enumerate(self.gyms):
+            g.set_output_ring(count, self.ring_obs[k].data_ptr(), self.ring_rewards[k].data_ptr(), self.ring_dones[k].data_ptr())
+        return self.ring_obs, self.ring_rewards, self.ring_dones
 
     def set_pixel_mode(self, mode):
         for g in self.gyms:

@@ -105,9 +105,12 @@ def test_full_size_rollout_equals_the_oracle(hip, scenario, N, A, params, TICKS,
 
 def test_full_size_mixed_scenarios_equal_their_oracles(hip, monkeypatch):
     """one GPU's share of configs[4]: the eight megaverse8 scenarios dealt round-robin over 1024 envs, one union step launch and one observation
-    launch per tick -- against eight oracles (the oracle has no env stride: each simulates all 1024 global envs as its scenario, the owned ones are compared)"""
+    launch per tick -- against eight oracles (the oracle has no env stride: each simulates all 1024 global envs as its scenario, the owned ones are compared):
+    rewards and dones of every env on every tick, every env's whole state every 40 ticks and -- at those ticks -- the exact-mode pixels of one sampled env
+    per scenario, 64 x 64, byte for byte against the oracle's software raster"""
     monkeypatch.setenv("BOXOBAN_LEVELS", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "boxoban"))
     N, A, S, ticks = 1024, 1, len(MEGAVERSE_IN_SCOPE), 120
+    W = H = 64   # (configs[4]'s observation size)
     mt = MultiTaskGym(MEGAVERSE_IN_SCOPE, W, H, N, A, 8)
     mt.set_pixel_mode("fast")
     mt.attach("cuda:0")
@@ -135,6 +138,15 @@ def test_full_size_mixed_scenarios_equal_their_oracles(hip, monkeypatch):
                 k, j = i % S, i // S
                 d = diff_snapshots(ogs[k].snapshot(i), hip_snapshot(mt.gyms[k], j), A)
                 assert not d, (st, i, MEGAVERSE_IN_SCOPE[k], d[:4])
+            # pixels: one sampled env per scenario, exact mode (bit for bit against the oracle's software raster), then back to the product's fast mode
+            for k in range(S):
+                j = ((st // 40) * 37 + 5 * k) % (N // S)
+                i = k + S * j
+                g = mt.gyms[k]
+                g.set_pixel_mode("exact"); g.render(); g.synchronize()
+                ogs[k].render_env(i)
+                assert np.array_equal(ogs[k].get_observation(i, 0), g.get_observation(j, 0)), (st, i, MEGAVERSE_IN_SCOPE[k], "pixels")
+                g.set_pixel_mode("fast")
     for og in ogs:
         og.close()
     mt.close()

@@ -91,6 +91,7 @@ def test_union_launches_equal_one_launch_per_gym(hip, monkeypatch, A, W, H):
 
     same("reset")
     st = 0
+    ring_tick = 0
     for _ in range(30):
         a.sample_random_actions(9, st); a.step()
         b.sample_random_actions(9, st); b.step()
@@ -102,6 +103,30 @@ def test_union_launches_equal_one_launch_per_gym(hip, monkeypatch, A, W, H):
             b.sample_random_actions(9, st + j); b.step()
         st += k
     same("batched ticks")
+    # rollout rings on every scenario: a batched group call is TWO launches (step_union_ticks_kernel, raster_union_batch_kernel; one agent per env) --
+    # every ring entry against the single ticks of the gyms stepped one by one
+    R = 8
+    ro, rr, rd = a.set_output_ring(R)
+    for k in (8, 5, 8, 2, 8):
+        a.step_n(k, "multidiscrete", 9, st)
+        want = []
+        for j in range(k):
+            b.sample_random_actions(9, st + j); b.step()
+            b.synchronize(); torch.cuda.synchronize()
+            want.append((ob.clone(), [g.get_rewards_array().copy() for g in b.gyms], [g.get_dones().copy() for g in b.gyms]))
+        a.synchronize(); torch.cuda.synchronize()
+        n = N // S
+        for j in range(k):   # (ring entries of this call: ticks t0 .. t0 + k - 1 since the ring was set)
+            e = (ring_tick + j) % R
+            for q in range(S):
+                assert torch.equal(ro[q][e], want[j][0][q * n * A:(q + 1) * n * A]), ("ring observations", MEGAVERSE_IN_SCOPE[q], k, j)
+                assert rr[q][e].cpu().numpy().tobytes() == want[j][1][q].tobytes(), ("ring rewards", MEGAVERSE_IN_SCOPE[q], k, j)
+                assert np.array_equal(rd[q][e].cpu().numpy(), want[j][2][q]), ("ring dones", MEGAVERSE_IN_SCOPE[q], k, j)
+        ring_tick += k
+        st += k
+    for q in range(S):
+        for j in range(N // S):
+            assert a.gyms[q].debug_snapshot_bytes(j).tobytes() == b.gyms[q].debug_snapshot_bytes(j).tobytes(), ("rings", MEGAVERSE_IN_SCOPE[q], j)
     a.close(); b.close()
 
 
