@@ -1,72 +1,15 @@
 // megaverse_amd/csrc/mv_api.hip -- host side of libmegaverse_hip.so: the C ABI declared in
-// include/megaverse_hip.h, HBM allocation, kernel sequencing on one HIP stream.
+// include/megaverse_hip.h -- this file: create / close (HBM allocation), seeding, reset, actions, output rings, getters, reward shaping,
+// the episode refill protocol; mv_api_step.hip: stepping (pipelining, batched calls, groups, profiling); mv_api_debug.hip: test hooks;
+// mv_api_internal.h: what they share (struct mv_gym).
 //
 // Mirrors class MegaverseGym of the reference (src/libs/bindings/megaverse.cpp:34-262) method by
 // method; the per-step control flow mirrors VectorEnv::step (src/libs/env/src/vector_env.cpp:89-108):
 //   step all envs  ->  for done envs: record trueObjective, reset  ->  draw.
 // There is NO CPU fallback: if no HIP device can be opened mv_create fails.
-#include <hip/hip_runtime.h>
+#include "mv_api_internal.h"
 
-#include <sched.h>
-
-#include <algorithm>
-#include <cctype>
-#include <cstdio>
-#include <cstring>
-#include <memory>
-#include <random>
-#include <string>
-#include <thread>
-#include <vector>
-
-#include "../../include/megaverse_hip.h"
-#include "mv_feeder.h"
-#include "mv_actions.h"
-#include "mv_gen.h"
-#include "mv_raster.h"
-#include "mv_math.h"
-#include "mv_rng.h"
-#include "mv_types.h"
-#include "mv_union.h"
-
-namespace mv {
-void launch_reset(const GymView &gv, int force_all, hipStream_t stream);
-void launch_tower_draw(const GymView &gv, hipStream_t stream);                          // TowerBuilding: tops every env's ring of drawn episodes up (mv_reset.hip)
-void launch_tower_seed(const GymView &gv, const uint32_t *seeds, hipStream_t stream);   // Env::seed for every env's generator
-// step kernels: one 256-thread workgroup per env = the tick (wave 0) + the frame setup of the env's frames for a W x H observation
-// (render = 0: tick only)
-void launch_step(const GymView &gv, hipStream_t stream, int W, int H, int render, hipEvent_t done = nullptr);
-void launch_step_ticks(const GymView *views, int k, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);   // k ticks + frame setups of every env, one launch (mv_step.hip)
-void launch_step_obstacles(const GymView &gv, hipStream_t stream, int W, int H, int render);
-void launch_step_obstacles_ticks(const GymView *views, int k, hipStream_t stream, int W, int H);   // k ticks + frame setups of every env (one agent), one launch
-void launch_step_rearrange_ticks(const GymView *views, int k, hipStream_t stream, int W, int H);
-void launch_step_sokoban_ticks(const GymView *views, int k, hipStream_t stream, int W, int H);
-void launch_step_collect_ticks(const GymView *views, int k, hipStream_t stream, int W, int H);
-void launch_step_hex_ticks(const GymView *views, int k, hipStream_t stream, int W, int H);
-void launch_reset_obstacles(const GymView &gv, const EpisodeBlob *blobs, int *status, int force_all, hipStream_t stream);
-void launch_step_rearrange(const GymView &gv, hipStream_t stream, int W, int H, int render);
-void launch_reset_rearrange(const GymView &gv, const RearrangeBlob *blobs, int *status, int force_all, hipStream_t stream);
-void launch_step_collect(const GymView &gv, hipStream_t stream, int W, int H, int render);
-void launch_step_sokoban(const GymView &gv, hipStream_t stream, int W, int H, int render);
-void launch_reset_sokoban(const GymView &gv, const SokobanBlob *blobs, int *status, int force_all, hipStream_t stream);
-void launch_reset_collect(const GymView &gv, const CollectBlob *blobs, int *status, int force_all, hipStream_t stream);
-void launch_step_hex(const GymView &gv, hipStream_t stream, int W, int H, int render);
-void launch_reset_hex(const GymView &gv, const HexBlob *blobs, int *status, int force_all, hipStream_t stream);
-}  // namespace mv
-
-using namespace mv;
-
-static thread_local std::string g_err;
-static int fail(const std::string &msg)
-{
-    g_err = msg;
-    return -1;
-}
-#define HIP_TRY(expr)                                                                                  \
-    do {                                                                                               \
-        hipError_t e_ = (expr);                                                                        \
-        if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_));          \
-    } while (0)
+thread_local std::string mvapi::g_err;
 
 static const char *SHAPING_KEYS_TOWER[4] = {"teamSpirit", "towerPickedUpObject", "towerVisitedBuildingZoneWithObject",
                                            "towerBuildingReward"};
@@ -92,124 +35,6 @@ static const char *SHAPING_KEYS_COLLECT[5] = {"teamSpirit", "collectSingleGood",
 static const float SHAPING_DEFAULT_COLLECT[5] = {0.0f, 1.0f, -1.0f, 5.0f, -0.5f};
 static const int ACTION_SPACE[6] = {3, 3, 3, 2, 2, 3};                          // env.cpp:33
 
-static_assert(PIPE_GROUPS == 3, "userMark events are created one by one in mv_create");
-struct mv_gym;
-struct mv_group {
-    std::vector<mv_gym *> gyms;   // gyms[0] is the leader; empty once a member was closed
-};
-struct mv_gym {
-    int device = 0;
-    int w = 0, h = 0, renderW = 768, renderH = 432;   // megaverse.cpp:261
-    int N = 0, A = 0, envOffset = 0, envStride = 1, totalEnvs = 0;
-    bool samplePending = false;                  // mv_sample_random_actions: the next step draws its own actions
-    int samplePolicy = POLICY_MULTIDISCRETE;     // mv_set_sample_policy: which generator mv_sample_random_actions requests
-    bool closed = false, wasReset = false;
-    hipStream_t stream = nullptr;                // the caller's stream: observation passes, published outputs, everything it may consume
-    // One-step-ahead pipelining: the step kernels run on an internal stream.  A step only waits for what the caller had
-    // enqueued on its stream when the PREVIOUS mv_step began (consumers of outputs two steps old), so step t + 1 overlaps the observation
-    // pass of step t whenever nothing on the caller's stream feeds it (device-sampled or host-provided actions).  Everything a step
-    // hands to the observation pass or to the caller exists PIPE_BUFS times: frame lists / headers / cost lists, and the rewards /
-    // dones / true objectives, which the observation pass (on the caller's stream) publishes into the stable public arrays.
-    // Slots: PIPE_GROUPS groups of `batch` hand-over buffers.  One call -- mv_step (one tick) or mv_step_n (up to `batch` ticks) -- takes the
-    // next group; its step kernels wait for the mark recorded PIPE_GROUPS - 1 calls ago.  With k ticks per call the two cross-queue
-    // hand-overs (mark -> simulation stream, simDone -> caller's stream, ~10 us of command-processor time each) are paid once per k ticks.
-    hipStream_t simStream = nullptr;
-    int pipelined = 1;                           // mv_set_pipelining / MV_PIPELINE: 0 = everything on the caller's stream, in order
-    bool simOnOwnStream = false;                 // where the last step ran
-    hipEvent_t userMark[PIPE_GROUPS] = {};       // completed when the last observation pass of a stepping call is, round-robin over the calls
-    hipEvent_t userNow = nullptr;                // recorded on `stream` when the simulation must wait for all of it
-    long dbgCalls = 0;                           // (instrumented builds)
-    unsigned long long markCount = 0;             // (64 bits: a training run takes 2^31 steps in a day and a half)
-    bool simMustWaitUser = true;                 // the caller's stream holds work the next step depends on (reset, render, device actions, ...)
-    hipEvent_t simDone = nullptr;                // after the last kernel on simStream
-    bool simDoneValid = false;
-    int batch = 8, slots = PIPE_GROUPS * 8, hists = PIPE_GROUPS * 8 + 1;   // slots per group (MV_PIPE_BATCH), slots, cost histograms
-    int group = 0;                               // slot group of the last stepping call
-    int parity = 0, hist3 = 0;                   // hand-over slot of the last tick; cost histogram of the last pass
-    // histClean[h]: cost histogram h is (or, in stream order, will be) all zero when the next frame setup counts into it.  A pass drawn by the
-    // one-launch observation kernel clears its histogram itself once its last workgroup has looked its frame up (mv_raster.hip: hist_done); a
-    // tick of the one-launch-per-tick path clears the NEXT pass's in its frame setup (mv_frame.h); what neither covers -- the hand-over between
-    // the two paths -- is cleared by take_hist with a memset.
-    std::vector<uint8_t> histClean;
-    std::vector<GymView> gvp;                    // [slots] gv with the buffers of each slot swapped in
-    GymView gv{};
-    const int32_t *mdActions = nullptr;          // mv_set_actions_device: the caller's multi-discrete buffer, read by the next step kernel
-    // mv_set_pass_overlap(1), ring at least two calls deep: the one-launch observation passes of consecutive batched calls go to two internal streams
-    // in turn, so that the passes of call c + 1 start -- their step launch permitting -- while those of call c drain (a launch ends with its last
-    // workgroups finishing alone, and the next one could not begin before: ~7 % of a 1024-env call).  The caller's stream waits for every call's
-    // passes as before; what the passes of call c wait for on the caller's side is what was enqueued before call c - 1 began (callStart).
-    int passOverlap = 0;
-    hipStream_t passStream[2] = {nullptr, nullptr};
-    hipEvent_t callStart[2] = {nullptr, nullptr};
-    unsigned long long overlapCalls = 0;   // consecutive calls that took the overlapped path (0: the last call's passes ran on the caller's stream)
-    // mv_set_output_ring: tick number t (since the ring was set) leaves its observations / rewards / dones in entry t % ringCount
-    int ringCount = 0;
-    unsigned long long ringTick = 0;
-    uint8_t *ringObs = nullptr, *ringDone = nullptr;
-    float *ringRewards = nullptr;
-    std::string warning;                         // soft conditions (capacity flags) of the last call: returned as 1, not as an error
-    // mv_group: the gyms of a group share the leader's simulation stream and events; a member keeps its own handles here until it leaves
-    mv_group *inGroup = nullptr;
-    hipStream_t ownSimStream = nullptr;
-    hipEvent_t ownUserMark[PIPE_GROUPS] = {}, ownSimDone = nullptr, ownStepDone = nullptr;
-    uint8_t *arena = nullptr;
-    uint32_t *obs = nullptr, *ownedObs = nullptr, *hiresObs = nullptr;
-    int hiresW = 0, hiresH = 0;
-    int fastPixels = 1;                          // mv_set_pixel_mode: 1 = raster_fast_kernel (default), 0 = bit-exact raster_kernel
-    // host mirrors
-    int32_t *hActions[2] = {nullptr, nullptr};   // pinned staging, double buffered
-    hipEvent_t actionsCopied[2] = {nullptr, nullptr};
-    int stage = 0;
-    bool actionsDirty = false;
-    int32_t *dMultiDiscrete = nullptr;           // [N*A*6] scratch for batched host actions
-    std::vector<float> hRewards, hTrueObj;
-    std::vector<uint8_t> hDone;
-    bool mirrorsFresh = false;
-    std::mt19937 rng{std::random_device{}()};    // megaverse.cpp:253
-    // scenario
-    int scenario = SCN_TOWER;
-    int numShaping = 4;
-    const char *const *shapingKeys = SHAPING_KEYS_TOWER;
-    ObstacleConfig obst;
-    float baseEpisodeLen = 60.0f;
-    // Obstacles / Collect: background episode feeder + one resident episode per env (refill protocol below)
-    std::unique_ptr<EpisodeFeeder> feeder;
-    int feederThreads = 1;
-    std::vector<int> uploaded, uploadBatch;         // episodes uploaded per env; envs of the current upload batch
-    uint8_t *dBlobs = nullptr, *hBlobs = nullptr;   // device [N][blobBytes], pinned feeder slots [N][blobBytes]
-    size_t blobBytes = 0;                           // sizeof(EpisodeBlob) or sizeof(CollectBlob)
-    bool hostEpisodes() const { return scenario != SCN_TOWER; }
-    // TowerBuilding: the episode generator's serial half (tower_draw_kernel, ~47 us of one wavefront per finished env) runs on a stream of its own,
-    // behind the step launch whose finished envs it refills and beside everything else; a stepping call waits for the draw launch BEFORE the last one
-    // (two episodes are resident per env: what the last launch is still drawing is not needed yet).  drawPeriod: ticks between draw launches -- 8 where
-    // episodes last at least 64 ticks, every call where they can be a few ticks long (those calls are one tick each: mv_step_n).
-    hipStream_t genStream = nullptr;
-    hipEvent_t stepForDraw = nullptr, drawDone[2] = {nullptr, nullptr};
-    unsigned long long drawCount = 0;
-    int ticksSinceDraw = 0, drawPeriod = 1;
-    int *dStatus = nullptr, *hStatus = nullptr;     // [N + 2]: consumed per env, total, error flags (device, pinned mirror)
-    int lastTotalSeen = 0;
-    bool statusPending = false, refillForce = true;
-    int pendingAge = 0;                             // steps since the pending read-back was first looked for
-    int stepsSinceStatus = 0;
-    int spares = 2;                                 // resident episodes per env (ring); the host keeps uploaded <= consumed + spares
-    int statusPeriod = 16;                          // steps between status read-backs (1 when episodes can be only a few ticks long)
-    int deficit = 0;                                // spares still to be uploaded (their episodes were not generated yet at the last look)
-    hipEvent_t stepDone = nullptr;                  // after the last step kernel: uploads never overlap a kernel that may read the ring
-    hipStream_t copyStream = nullptr;               // status read-back + episode uploads, off the step path
-    hipEvent_t resetDone = nullptr, statusCopied = nullptr;
-    bool stepDoneValid = false;
-    std::vector<hipEvent_t> uploadEvents;           // ring, one per upload batch
-    hipEvent_t lastUpload = nullptr;                // the most recent batch (mv_reset: the caller's stream waits for it too)
-    bool uploadNotOnUser = false;                   // ... and a step that runs on the caller's stream has not waited for it yet
-    size_t uploadRing = 0;
-    // in-stream profiling
-    std::vector<hipEvent_t> profEvents;          // 5 per profiled tick: [0] [1] around the step kernel (its stream), [2] [3] [4] before the
-                                                 // observation pass, between frame sort and raster, after the raster (the caller's stream)
-    int profMax = 0, profCount = 0;
-    std::vector<int> profTicks;                  // ticks an entry covers: 1, or the k ticks of a batched call whose launches are timed as a whole
-};
-
 // ------------------------------------------------------------------------------------------------
 // small utility kernels
 // ------------------------------------------------------------------------------------------------
@@ -233,51 +58,17 @@ __global__ void publish_kernel(const float *s_rew, const uint8_t *s_done, const 
 
 __global__ void clear_flags_kernel(int *word, int reported) { atomicAnd(word, ~reported); }   // only the bits that were reported: a bit raised since stays
 __global__ void set_shaping_kernel(AgentState *agents, int idx, int key, float v) { agents[idx].shaping[key] = v; }
-__global__ void set_agent_pos_kernel(AgentState *agents, int idx, float x, float y, float z) { agents[idx].pos[0] = x; agents[idx].pos[1] = y; agents[idx].pos[2] = z; }
-__global__ void set_agent_yaw_kernel(AgentState *agents, int idx, float c, float s) { agents[idx].m00 = c; agents[idx].m02 = s; agents[idx].m20 = -s; agents[idx].m22 = c; }
-__global__ void set_agent_velocity_kernel(AgentState *agents, int idx, float hvx, float hvz, float vvel) { agents[idx].hvx = hvx; agents[idx].hvz = hvz; agents[idx].vvel = vvel; }
 
-__global__ void debug_rng_kernel(uint32_t seed, int what, const int32_t *lo, const int32_t *hi, int n, void *out)
-{
-    __shared__ uint32_t s_mt[624];
-    __shared__ uint16_t s_items[4096];
-    Mt19937 g{s_mt, 624};
-    mt_seed(g, seed);
-    const int lane = threadIdx.x & 63;
-    if (what == 0) {
-        for (int i = 0; i < n; ++i) { const uint32_t v = mt_next(g); if (lane == 0) ((uint32_t *)out)[i] = v; }
-    } else if (what == 1) {
-        for (int i = 0; i < n; ++i) { const int v = rand_range(g, lo[i], hi[i]); if (lane == 0) ((int32_t *)out)[i] = v; }
-    } else if (what == 2) {
-        for (int i = 0; i < n; ++i) { const float v = frand(g); if (lane == 0) ((float *)out)[i] = v; }
-    } else if (what == 3) {
-        for (int i = lane; i < n; i += 64) s_items[i] = (uint16_t)i;
-        __syncthreads();
-        shuffle_u16(g, s_items, n);
-        for (int i = lane; i < n; i += 64) ((int32_t *)out)[i] = s_items[i];
-    }
-}
-
-__global__ void debug_math_kernel(int what, const float *a, const float *b, int n, float *out)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (what == 0) out[i] = a[i] / b[i];
-    else if (what == 1) out[i] = sqrtf(a[i]);
-    else if (what == 2) { float s, c; sincos_poly(a[i], s, c); out[2 * i] = s; out[2 * i + 1] = c; }
-    else if (what == 3) out[i] = a[i] * b[i] + a[i];   // must NOT be contracted into an fma
-    else if (what == 4) out[i] = floorf(a[i]);
-}
-
+namespace mvapi {
 // ------------------------------------------------------------------------------------------------
-static std::string lower(const char *s)
+std::string lower(const char *s)
 {
     std::string r(s ? s : "");
     for (auto &c : r) c = (char)std::tolower((unsigned char)c);
     return r;
 }
 
-static int check(mv_gym *g)
+int check(mv_gym *g)
 {
     if (!g) return fail("null gym handle");
     if (g->closed) return fail("gym is closed");
@@ -286,8 +77,7 @@ static int check(mv_gym *g)
 
 // Where a tick's public outputs go: the observation slab and the reward / done arrays -- or, with mv_set_output_ring, entry (tick % count)
 // of the caller's rings.  true_objective is state (only a finishing env records it, vector_env.cpp:96-101): never ringed.
-struct OutPtrs { uint32_t *obs; float *rewards; uint8_t *done; };
-static OutPtrs outputs_of(const mv_gym *g, unsigned long long tick)
+OutPtrs outputs_of(const mv_gym *g, unsigned long long tick)
 {
     OutPtrs o{g->obs, g->gv.rewards, g->gv.done};
     if (g->ringCount > 0) {
@@ -298,9 +88,9 @@ static OutPtrs outputs_of(const mv_gym *g, unsigned long long tick)
     }
     return o;
 }
-static OutPtrs last_outputs(const mv_gym *g) { return outputs_of(g, g->ringTick ? g->ringTick - 1 : 0); }   // of the last tick (reset / render / getters)
+OutPtrs last_outputs(const mv_gym *g) { return outputs_of(g, g->ringTick ? g->ringTick - 1 : 0); }   // of the last tick (reset / render / getters)
 
-static int refresh_mirrors(mv_gym *g)
+int refresh_mirrors(mv_gym *g)
 {
     if (g->mirrorsFresh) return 0;
     const size_t NA = (size_t)g->N * g->A;
@@ -315,7 +105,7 @@ static int refresh_mirrors(mv_gym *g)
 
 // The next observation pass's cost histogram: advances hist3 and makes sure the histogram is zero before the pass's frame setup counts into it
 // (stream s: where that setup runs).  setupClearsNext: the frame setup of this pass clears the histogram after it (the one-launch-per-tick path).
-static int take_hist(mv_gym *g, hipStream_t s, bool setupClearsNext)
+int take_hist(mv_gym *g, hipStream_t s, bool setupClearsNext)
 {
     g->hist3 = (g->hist3 + 1) % g->hists;
     if (!g->histClean[(size_t)g->hist3])
@@ -326,7 +116,7 @@ static int take_hist(mv_gym *g, hipStream_t s, bool setupClearsNext)
 }
 
 // the view a kernel launch gets: the buffers of slot q, this pass's cost histogram, the action-sampling request
-static GymView view(const mv_gym *g, int q, const OutPtrs *direct = nullptr)   // direct: the step writes the public output arrays itself (not pipelined)
+GymView view(const mv_gym *g, int q, const OutPtrs *direct)   // direct: the step writes the public output arrays itself (not pipelined)
 {
     GymView v = g->gvp[q];
     if (direct) { v.rewards = direct->rewards; v.done = direct->done; v.true_objective = g->gv.true_objective; }
@@ -339,7 +129,7 @@ static GymView view(const mv_gym *g, int q, const OutPtrs *direct = nullptr)   /
 
 // Before anything on the caller's stream reads or writes simulator state (reset, render, hires, seeds, test hooks): it waits for the
 // simulation stream, and the next step will wait for it.
-static int sim_join(mv_gym *g)
+int sim_join(mv_gym *g)
 {
     if (g->simDoneValid && g->simOnOwnStream) HIP_TRY(hipStreamWaitEvent(g->stream, g->simDone, 0));
     g->simMustWaitUser = true;
@@ -347,7 +137,7 @@ static int sim_join(mv_gym *g)
 }
 
 // TowerBuilding: before anything on the caller's stream touches the generators or the ring of drawn episodes (mv_reset, mv_seed): the last draw launch
-static int tower_join(mv_gym *g)
+int tower_join(mv_gym *g)
 {
     if (g->genStream && g->drawCount > 0) HIP_TRY(hipStreamWaitEvent(g->stream, g->drawDone[(size_t)((g->drawCount - 1) & 1ull)], 0));
     return 0;
@@ -355,13 +145,13 @@ static int tower_join(mv_gym *g)
 
 // TowerBuilding, a stepping call: before its step launches the simulation stream waits for the draw launch BEFORE the last one (two episodes are resident per
 // env; what the last launch may still be drawing replaces an episode consumed a call ago: not needed yet) ...
-static int tower_draw_before(mv_gym *g, hipStream_t sim)
+int tower_draw_before(mv_gym *g, hipStream_t sim)
 {
     if (g->genStream && g->drawCount >= 2) HIP_TRY(hipStreamWaitEvent(sim, g->drawDone[(size_t)(g->drawCount & 1ull)], 0));
     return 0;
 }
 // ... and behind them, every drawPeriod ticks, the draw kernel goes to its own stream: it tops up the rings of the envs that finished
-static int tower_draw_after(mv_gym *g, hipStream_t sim, int ticks)
+int tower_draw_after(mv_gym *g, hipStream_t sim, int ticks)
 {
     if (!g->genStream) return 0;
     g->ticksSinceDraw += ticks;
@@ -375,7 +165,7 @@ static int tower_draw_after(mv_gym *g, hipStream_t sim, int ticks)
     return 0;
 }
 
-static int publish_outputs(mv_gym *g, int q, const OutPtrs &o)   // on the caller's stream
+int publish_outputs(mv_gym *g, int q, const OutPtrs &o)   // on the caller's stream
 {
     const GymView &v = g->gvp[q];
     const int n = g->N * g->A;
@@ -384,6 +174,7 @@ static int publish_outputs(mv_gym *g, int q, const OutPtrs &o)   // on the calle
     HIP_TRY(hipGetLastError());
     return 0;
 }
+}  // namespace mvapi
 
 extern "C" {
 
@@ -406,7 +197,8 @@ int mv_action_space_sizes(int32_t *out6)
 }  // extern "C" (helper below has C++ linkage)
 
 // scenario name -> kernel family + generator parameters (scenarios/init.hpp:30-52)
-static bool scenario_from_name(const std::string &scen, int &scenario, ObstacleConfig &oc)
+namespace mvapi {
+bool scenario_from_name(const std::string &scen, int &scenario, ObstacleConfig &oc)
 {
     if (scen == "towerbuilding") scenario = SCN_TOWER;
     else if (scen == "obstacleseasy") scenario = SCN_OBSTACLES;                       // scenario_obstacles.hpp:112-138
@@ -428,6 +220,7 @@ static bool scenario_from_name(const std::string &scen, int &scenario, ObstacleC
     else return false;
     return true;
 }
+}  // namespace mvapi
 
 // cores this process may use: the affinity mask, capped by the cgroup's CPU quota (a container with 16 of the host's 192 cores sees all of them in the mask)
 static int usable_host_cores()
@@ -727,8 +520,6 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     return 0;
 }
 
-static void group_detach(mv_gym *g);
-
 int mv_close(mv_gym *g)
 {
     if (!g || g->closed) return 0;
@@ -948,11 +739,14 @@ int mv_render(mv_gym *g)
     return 0;
 }
 
+}  // extern "C"
+
+namespace mvapi {
 // ---- status flags ----------------------------------------------------------------------------------------------------
 // Kernels raise ST_* bits in status[N + 1], the host generators GEN_* bits (mv_gen.h); both are limits the reference does not
 // have.  They are reported ONCE, by the mv_step / mv_reset that sees them, and cleared: the gym stays usable.  They are WARNINGS: the call
 // that reports one does all of its work and returns 1 instead of 0 (mv_last_error() has the text); -1 stays what it was, a real failure.
-static int check_status_flags(mv_gym *g)
+int check_status_flags(mv_gym *g)
 {
     const int N = g->N;
     const int flags = g->hStatus[N + 1], gen = g->feeder ? g->feeder->take_overflow() : 0;
@@ -977,7 +771,7 @@ static int check_status_flags(mv_gym *g)
     return 1;
 }
 // what a call that did its work returns: 0, or 1 with the warning text where mv_last_error() finds it
-static int finish_with_warning(mv_gym *g)
+int finish_with_warning(mv_gym *g)
 {
     if (g->warning.empty()) return 0;
     g_err = g->warning;
@@ -993,7 +787,7 @@ static int finish_with_warning(mv_gym *g)
 // slots, where the episodes were generated ahead of time by the worker pool.  The step path itself only ever enqueues; it waits
 // for the host only if an env has NO resident episode left and its next one is still being generated.  An upload never overlaps a
 // step kernel (stepDone): a finished env must not read a half-written slot.
-static int refill_episodes(mv_gym *g)
+int refill_episodes(mv_gym *g)
 {
     if (g->statusPending) {
         // The read-back was enqueued behind a step kernel the host is normally several ticks ahead of: waiting for it here would drain
@@ -1058,7 +852,7 @@ static int refill_episodes(mv_gym *g)
 }
 
 // after a step / reset kernel: read the status words back without touching the step path
-static int read_back_status(mv_gym *g, hipStream_t after)
+int read_back_status(mv_gym *g, hipStream_t after)
 {
     HIP_TRY(hipEventRecord(g->resetDone, after));
     HIP_TRY(hipStreamWaitEvent(g->copyStream, g->resetDone, 0));
@@ -1072,7 +866,7 @@ static int read_back_status(mv_gym *g, hipStream_t after)
 // comes between the two -- a reset, a host-side setter -- first turns the pending buffer into bitmasks (on the caller's stream, where the
 // buffer's producer ran), so that the buffer is read NOW, while it is certainly alive, and the last writer wins as it did when
 // mv_set_actions_device converted at once.
-static int flush_device_actions(mv_gym *g)
+int flush_device_actions(mv_gym *g)
 {
     if (!g->mdActions) return 0;
     const int n = g->N * g->A;
@@ -1082,6 +876,10 @@ static int flush_device_actions(mv_gym *g)
     g->simMustWaitUser = true;
     return 0;
 }
+
+}  // namespace mvapi
+
+extern "C" {
 
 int mv_reset(mv_gym *g)
 {   // MegaverseGym::reset (megaverse.cpp:76-93) -> VectorEnv::reset (vector_env.cpp:110-120)
@@ -1214,490 +1012,11 @@ int mv_sample_random_actions(mv_gym *g, uint32_t seed, uint32_t step)
     return 0;
 }
 
-// -> whether `done` rides on the launch (TowerBuilding's launcher); otherwise the caller records it
-static bool launch_step_of(const mv_gym *g, const GymView &v, hipStream_t sim, int fused, hipEvent_t done = nullptr)
-{
-    if (g->scenario == SCN_OBSTACLES || g->scenario == SCN_EMPTY) launch_step_obstacles(v, sim, g->w, g->h, fused);
-    else if (g->scenario == SCN_COLLECT) launch_step_collect(v, sim, g->w, g->h, fused);
-    else if (g->scenario == SCN_REARRANGE) launch_step_rearrange(v, sim, g->w, g->h, fused);
-    else if (g->scenario == SCN_SOKOBAN) launch_step_sokoban(v, sim, g->w, g->h, fused);
-    else if (g->scenario == SCN_HEX_MEMORY || g->scenario == SCN_HEX_EXPLORE) launch_step_hex(v, sim, g->w, g->h, fused);
-    else { launch_step(v, sim, g->w, g->h, fused, done); return done != nullptr; }
-    return false;
-}
-
-// One stepping call = k ticks (mv_step: 1; mv_step_n: up to `batch`) of n gyms that share one pair of streams (n = 1: a gym on its own;
-// n > 1: an mv_group, stepped by union launches).  gs[0] is the leader: the stream state that changes with every call -- marks, which stream
-// the last step ran on -- is kept on it and mirrored to the others.  policy != POLICY_NONE: tick j draws its actions inside the step kernel
-// from (seed, first_index + j); POLICY_NONE: the first tick acts on what mv_set_actions* left, the following ones on cleared actions
-// (env.cpp:141-142 clears them after every tick).
-// kCall: the ticks of the CALLER's call this chunk belongs to (mv_step_n splits a call of more than `batch` ticks): what the ring contract of
-// the overlapped passes is stated in (include/megaverse_hip.h).
-static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, uint32_t seed, uint32_t first_index, int kCall)
-{
-    mv_gym *const L = gs[0];
-    int batch = L->batch;
-    bool mustWait = false, allFast = true, anyHostEpisodes = false;
-    for (int i = 0; i < n; ++i) {
-        mv_gym *g = gs[i];
-        if (check(g)) return -1;
-        if (!g->wasReset) return fail("mv_step: call mv_reset first");
-        batch = std::min(batch, g->batch);
-        mustWait = mustWait || g->simMustWaitUser;
-        allFast = allFast && g->fastPixels != 0;
-        anyHostEpisodes = anyHostEpisodes || g->hostEpisodes();
-    }
-    if (k < 1 || k > batch) return fail("mv_step_n: 1 <= k <= " + std::to_string(batch) + " (MV_PIPE_BATCH) required");
-    HIP_TRY(hipSetDevice(L->device));
-    for (int i = 0; i < n; ++i)
-        if (refill_episodes(gs[i]) < 0) return -1;
-    // ---- what this call must wait for on the caller's stream.  Always: whatever was there when the call PIPE_GROUPS - 1 calls ago began --
-    // the observation passes and the consumers of the call that used this slot group last.  Everything, when the caller's stream
-    // feeds the simulation (reset / render / device actions / test hooks since the last step).  (Both raster kernels read nothing but the
-    // frame lists and headers of their tick: the simulator state may move on underneath them.)
-    // Not pipelined (mv_set_pipelining(0)), or ONE tick whose inputs come from the caller's stream (a policy in the loop: nothing can overlap,
-    // the two queue hand-overs, ~10 us each, would be pure cost): the step runs on the caller's stream like everything else.
-    const bool own = L->pipelined != 0 && !(mustWait && k == 1);
-    hipStream_t sim = own ? L->simStream : L->stream;
-    if (own) {
-        // The simulation stream may reuse a slot group once the observation passes that read it are done: the END of the call PIPE_GROUPS calls
-        // ago (userMark, completed by that call's last pass, see below).  When the caller's stream feeds the simulation (reset / render / device
-        // actions / test hooks since the last step), or the last step ran there: everything enqueued on it so far.
-        if (mustWait || !L->simOnOwnStream) {
-            HIP_TRY(hipEventRecord(L->userNow, L->stream));
-            HIP_TRY(hipStreamWaitEvent(sim, L->userNow, 0));
-        } else if (L->markCount >= PIPE_GROUPS) HIP_TRY(hipStreamWaitEvent(sim, L->userMark[L->markCount % PIPE_GROUPS], 0));
-    } else {
-        if (L->simOnOwnStream && L->simDoneValid) HIP_TRY(hipStreamWaitEvent(sim, L->simDone, 0));   // the last step ran on the other stream
-        for (int i = 0; i < n; ++i) {   // (episode uploads make the simulation stream wait)
-            if (gs[i]->uploadNotOnUser && gs[i]->lastUpload) HIP_TRY(hipStreamWaitEvent(sim, gs[i]->lastUpload, 0));
-            gs[i]->uploadNotOnUser = false;
-        }
-        L->markCount = 0;
-    }
-    for (int i = 0; i < n; ++i) {
-        mv_gym *g = gs[i];
-        if (tower_draw_before(g, sim)) return -1;
-        g->simMustWaitUser = false;
-        g->simOnOwnStream = own;
-        g->markCount = L->markCount;
-        if (g->actionsDirty) {
-            const int s = g->stage;
-            HIP_TRY(hipMemcpyAsync(g->gv.actions, g->hActions[s], (size_t)g->N * g->A * sizeof(int32_t), hipMemcpyHostToDevice, sim));
-            HIP_TRY(hipEventRecord(g->actionsCopied[s], sim));
-            g->stage = 1 - s;
-            HIP_TRY(hipEventSynchronize(g->actionsCopied[g->stage]));   // long done: recorded one step ago
-            std::memset(g->hActions[g->stage], 0, (size_t)g->N * g->A * sizeof(int32_t));   // actions are cleared every tick (env.cpp:141-142)
-            g->actionsDirty = false;
-        }
-        g->group = (g->group + 1) % PIPE_GROUPS;
-    }
-    const int fused = render ? 1 : 0;   // the step kernel also builds the frame lists when an observation pass follows
-    if (L->gv.dbg) {   // (instrumented builds: MV_TICK_TIMING_SKIP=n starts the statistics after n stepping calls -- the steady state, not the first ticks of fresh episodes)
-        static const long skip = getenv("MV_TICK_TIMING_SKIP") ? atol(getenv("MV_TICK_TIMING_SKIP")) : 0;
-        if (skip > 0 && ++L->dbgCalls == skip) HIP_TRY(hipMemsetAsync(L->gv.dbg, 0, (size_t)L->N * 64 * sizeof(unsigned long long), sim));
-    }
-    // A batched call hands over ONCE: all k step kernels, then all k observation passes.  (Handing over tick by tick when the caller's stream is
-    // found idle -- the first call after a synchronisation -- was built and measured on 20-step runs: 15.0-15.6 M obs/s against 16.2 M without;
-    // short runs use short calls instead, bench.py's --batch.)
-    std::vector<GymView> views((size_t)n * k);
-    std::vector<OutPtrs> outs((size_t)n * k);
-    hipEvent_t *evs[PIPE_BATCH_MAX];
-    // ---- the k step kernels, back to back on the simulation stream
-    bool simDoneRodeAlong = false;   // (the last step kernel's dispatch packet completes simDone itself)
-    // One TowerBuilding gym, several rendered ticks with device-drawn actions, nothing timed per tick: ONE step launch runs the k ticks of every
-    // env (launch_step_ticks; MV_STEP_TICKS=0: k launches).  Its views are collected in the loop below.
-    static const bool ticksOff = getenv("MV_STEP_TICKS") && atoi(getenv("MV_STEP_TICKS")) == 0;
-    const bool obstFamily = L->scenario == SCN_OBSTACLES || L->scenario == SCN_EMPTY;
-    // (every scenario with one agent per env; several agents: TowerBuilding only -- two waves per env, launch_step_ticks)
-    const bool canMultiTick = !ticksOff && n == 1 && (L->A == 1 || L->scenario == SCN_TOWER) && k >= 2 && k <= MAX_STEP_TICKS && render && policy != POLICY_NONE && !L->gv.dbg;
-    // (the one-launch observation passes only beside the one-launch step: k separate step kernels starve beside a pass that long -- 70-190 us each, r04l)
-    const bool canBatchRaster = canMultiTick && render && allFast && n == 1 && k >= 2 && L->ringObs && L->ringCount >= k;
-    // timing (mv_profile_begin): a batched call that takes both one-launch paths is timed as a whole -- one entry, events around the step
-    // launch and around the raster launch, k ticks -- so that the figures are those of the launches the product runs; otherwise tick by tick
-    const bool profiling = render && L->profCount < L->profMax;
-    hipEvent_t *callEv = nullptr;
-    if (profiling && canMultiTick && canBatchRaster && k <= MAX_UNION) {
-        callEv = &L->profEvents[(size_t)L->profCount * 5];
-        L->profTicks[(size_t)L->profCount] = k;
-        ++L->profCount;
-    }
-    const bool multiTick = canMultiTick && (!profiling || callEv);
-    // A group (n > 1), several rendered ticks with device-drawn actions, every member with an observation ring at least k deep and one agent per env: ONE
-    // union step launch runs the k ticks of every env of every gym (step_union_ticks_kernel) and ONE launch draws their k x n observation passes
-    // (raster_union_batch_kernel) -- two launches per call where the tick-by-tick path takes 2 k (BASELINE configs[4]: the scenarios of a multi-task batch).
-    bool groupBatch = n > 1 && !ticksOff && own && render && allFast && k >= 2 && k <= MAX_STEP_TICKS && policy != POLICY_NONE && !profiling && raster_union_batch_applicable(k, n, L->w, L->h);
-    for (int i = 0; i < n && groupBatch; ++i) groupBatch = gs[i]->A == 1 && gs[i]->ringObs && gs[i]->ringCount >= k && !gs[i]->gv.dbg;
-    for (int j = 0; j < k; ++j) {
-        const bool prof = !callEv && render && L->profCount < L->profMax;
-        evs[j] = prof ? &L->profEvents[(size_t)L->profCount * 5] : nullptr;
-        if (prof) { L->profTicks[(size_t)L->profCount] = 1; ++L->profCount; }
-        UnionStepArgs ua;
-        ua.n = n;
-        int envs = 0;
-        for (int i = 0; i < n; ++i) {
-            mv_gym *g = gs[i];
-            if (policy != POLICY_NONE) { g->gv.sample_on = policy; g->gv.sample_seed = seed; g->gv.sample_step = first_index + (uint32_t)j; }
-            else { g->gv.sample_on = (j == 0 && g->samplePending) ? g->samplePolicy : (int)POLICY_NONE; }
-            g->parity = g->group * g->batch + j;
-            if (render && take_hist(g, sim, !(multiTick || groupBatch))) return -1;   // (this pass's frame setup fills the next cost histogram; one launch per tick: and clears the one after)
-            OutPtrs &o = outs[(size_t)j * n + i];
-            o = outputs_of(g, g->ringTick++);
-            GymView &v = views[(size_t)j * n + i];
-            v = view(g, g->parity, own ? nullptr : &o);
-            if (j == 0 && g->gv.sample_on == POLICY_NONE) v.md_actions = g->mdActions;
-            if (groupBatch) v.lpt_no_clear = 1;   // (the passes clear their histograms themselves: mv_raster.hip, hist_done)
-            if (n > 1) { ua.first[i] = envs; ua.gv[i] = v; envs += g->N; }
-        }
-        if (evs[j]) HIP_TRY(hipEventRecord(evs[j][0], sim));
-        bool simDoneRides = false;
-        if (multiTick) {
-            views[(size_t)j].lpt_no_clear = 1;
-            if (j == k - 1) {
-                // (the cost histograms of the call's passes are clean: take_hist.  In the steady state of batched calls nothing is cleared here at
-                // all -- every pass of the one-launch observation kernel leaves its histogram zero -- where r06l's kernel traces showed two fill
-                // kernels in front of every step launch, the second one waiting 30 us for a wave slot beside the observation passes: the chain
-                // of step launches is what bounds a batched call's rate at 1024 envs, 344 + 39 us per call against 288 us of passes.)
-                if (callEv) HIP_TRY(hipEventRecord(callEv[0], sim));
-                if (obstFamily) launch_step_obstacles_ticks(views.data(), k, sim, L->w, L->h);
-                else if (L->scenario == SCN_REARRANGE) launch_step_rearrange_ticks(views.data(), k, sim, L->w, L->h);
-                else if (L->scenario == SCN_SOKOBAN) launch_step_sokoban_ticks(views.data(), k, sim, L->w, L->h);
-                else if (L->scenario == SCN_COLLECT) launch_step_collect_ticks(views.data(), k, sim, L->w, L->h);
-                else if (L->scenario == SCN_HEX_MEMORY || L->scenario == SCN_HEX_EXPLORE) launch_step_hex_ticks(views.data(), k, sim, L->w, L->h);
-                else launch_step_ticks(views.data(), k, sim, L->w, L->h, own && !callEv ? L->simDone : nullptr);
-                if (callEv) HIP_TRY(hipEventRecord(callEv[1], sim));
-                simDoneRides = own && !callEv && L->scenario == SCN_TOWER;
-            }
-        } else if (n == 1) simDoneRides = launch_step_of(L, views[(size_t)j * n], sim, fused, own && j == k - 1 && !evs[j] ? L->simDone : nullptr);
-        else if (groupBatch) {
-            if (j == k - 1) {   // every tick's views are collected: one launch for the k ticks of all n gyms
-                UnionTicksArgs ta;
-                ta.n = n; ta.k = k;
-                for (int i = 0; i < n; ++i) {
-                    ta.first[i] = ua.first[i];
-                    ta.gv[i] = views[(size_t)i];   // tick 0's
-                    ta.slot_stride[i] = (int64_t)((const uint8_t *)views[(size_t)n + i].vis_prims - (const uint8_t *)views[(size_t)i].vis_prims);
-                }
-                for (int i = n; i <= MAX_UNION; ++i) ta.first[i] = envs;
-                for (int i = n; i < MAX_UNION; ++i) { ta.gv[i] = views[0]; ta.slot_stride[i] = 0; }
-                launch_step_union_ticks(ta, sim, L->w, L->h);
-            }
-        } else {
-            for (int i = n; i <= MAX_UNION; ++i) ua.first[i] = envs;
-            launch_step_union(ua, sim, L->w, L->h, fused);
-        }
-        if (evs[j]) HIP_TRY(hipEventRecord(evs[j][1], sim));
-        simDoneRodeAlong = simDoneRodeAlong || simDoneRides;
-    }
-    if (own && !simDoneRodeAlong) HIP_TRY(hipEventRecord(L->simDone, sim));   // (not pipelined: stream order does it)
-    for (int i = 0; i < n; ++i)
-        if (tower_draw_after(gs[i], sim, k)) return -1;
-    // (every step kernel regenerates / swaps the next episode into the envs it finishes)
-    // An env needs a fresh resident episode only at its NEXT reset, normally hundreds of steps away, and two are resident: the status
-    // words are read back -- and the refill considered -- every statusPeriod-th step (16; 1 when episodes can be a few ticks long).
-    if (anyHostEpisodes) HIP_TRY(hipEventRecord(L->stepDone, sim));   // (the gyms of a group share the leader's event)
-    for (int i = 0; i < n; ++i) {
-        mv_gym *g = gs[i];
-        g->samplePending = false;
-        g->mdActions = nullptr;
-        if (own) g->simDoneValid = true;
-        if (anyHostEpisodes) g->stepDoneValid = true;
-        g->stepsSinceStatus += k;
-        if (g->stepsSinceStatus >= g->statusPeriod) {   // (TowerBuilding regenerates finished envs in the kernel: only the error flags matter)
-            if (read_back_status(g, sim)) return -1;
-            g->stepsSinceStatus = 0;
-        }
-        g->mirrorsFresh = false;
-    }
-    // ---- the caller's stream: per tick the step's outputs, then the observation pass
-    if (L->passOverlap && L->callStart[0]) HIP_TRY(hipEventRecord(L->callStart[(int)(L->overlapCalls & 1ull)], L->stream));   // (before this call enqueues anything there)
-    if (own) HIP_TRY(hipStreamWaitEvent(L->stream, L->simDone, 0));
-    std::vector<PublishTo> pubs((size_t)n);
-    std::vector<uint32_t *> obsPtrs((size_t)n);
-    // One gym, several ticks, every tick's observations in a slab of its own (an output ring at least k deep), nothing timed per tick: the
-    // observation passes of up to MAX_UNION ticks go out as ONE launch (launch_raster_batch: the next tick's expensive frames fill the tail of
-    // the previous tick's pass).  The ticks are collected below and launched at the end of their chunk.
-    bool batchRaster = canBatchRaster;
-    for (int j = 0; j < k; ++j) batchRaster = batchRaster && !evs[j];
-    // overlapped passes (mv_set_pass_overlap): this call's one launch goes to an internal stream
-    // (an env must not finish in two consecutive calls: their passes may publish its true objective in either order -- episodes of at least
-    // baseEpisodeLen seconds, 15 ticks each)
-    // The ring is two CALLS deep, in the caller's ticks per call (a call of 16 ticks runs as two chunks of 8: the second-next chunk's passes would overwrite
-    // what the consumer of the previous CALL -- enqueued after both of its chunks -- may still be reading), and rewards / dones have rings of
-    // their own (two passes in flight would both publish the single arrays, in either order).
-    const bool overlap = batchRaster && own && !callEv && L->passOverlap && L->passStream[0] && L->ringCount >= 2 * std::max(k, kCall) && L->ringRewards && L->ringDone &&
-                         k <= MAX_UNION && L->baseEpisodeLen * 15.0f > float(2 * k + 2);
-    hipStream_t passOn = L->stream;
-    if (overlap) {
-        const int me = (int)(L->overlapCalls & 1ull);
-        passOn = L->passStream[me];
-        HIP_TRY(hipStreamWaitEvent(passOn, L->simDone, 0));                                      // this call's ticks
-        if (L->overlapCalls >= 1) HIP_TRY(hipStreamWaitEvent(passOn, L->callStart[1 - me], 0));   // what the caller had enqueued when the previous call began
-        else { HIP_TRY(hipEventRecord(L->userNow, L->stream)); HIP_TRY(hipStreamWaitEvent(passOn, L->userNow, 0)); }   // (first overlapped call: everything so far)
-    }
-    std::vector<PublishTo> chunkPubs;
-    std::vector<uint32_t *> chunkObs;
-    int chunkFirst = 0;
-    for (int j = 0; j < k; ++j) {
-        if (evs[j]) HIP_TRY(hipEventRecord(evs[j][2], L->stream));
-        for (int i = 0; i < n; ++i) {
-            const OutPtrs &o = outs[(size_t)j * n + i];
-            pubs[i] = PublishTo{o.rewards, o.done, gs[i]->gv.true_objective};
-            obsPtrs[i] = o.obs;
-            if (own && (!render || !allFast) && publish_outputs(gs[i], gs[i]->group * gs[i]->batch + j, o)) return -1;   // (the fast observation pass publishes with its first workgroups)
-        }
-        // the call's last pass completes this call's mark (what the simulation stream waits for before it reuses the slot group)
-        hipEvent_t mark = own && j == k - 1 ? L->userMark[L->markCount % PIPE_GROUPS] : nullptr;
-        if (render && batchRaster) {
-            const bool pubInRaster = own;
-            chunkPubs.push_back(pubs[0]);
-            chunkObs.push_back(obsPtrs[0]);
-            static const int chunkMax = getenv("MV_RASTER_BATCH") ? std::min((int)MAX_UNION, std::max(1, atoi(getenv("MV_RASTER_BATCH")))) : (int)MAX_UNION;   // (0: off, launch_raster_batch declines)
-            if (j == k - 1 || (int)chunkObs.size() >= chunkMax) {
-                const int cn = (int)chunkObs.size();
-                if (callEv) { HIP_TRY(hipEventRecord(callEv[2], L->stream)); HIP_TRY(hipEventRecord(callEv[3], L->stream)); }
-                int r = cn >= 2 ? launch_raster_batch(&views[(size_t)chunkFirst], chunkObs.data(), pubInRaster ? chunkPubs.data() : nullptr, cn, L->w, L->h, overlap && cn == k ? passOn : L->stream, mark) : 1;
-                if (r == 0 && overlap && cn == k) HIP_TRY(hipStreamWaitEvent(L->stream, mark, 0));   // the caller's stream sees the call's outputs as always
-                if (r < 0) return fail("mv_step: observation size above 1024x1024");
-                if (r == 0)   // (every pass of the one-launch kernel leaves its cost histogram zero)
-                    for (int q = 0; q < cn; ++q) L->histClean[(size_t)views[(size_t)chunkFirst + q].lpt_parity] = 1;
-                if (r == 1)   // (not applicable to this gym -- long lists -- or a chunk of one tick: tick by tick)
-                    for (int q = 0; q < cn; ++q)
-                    {
-                        if (launch_raster(views[(size_t)chunkFirst + q], chunkObs[q], L->w, L->h, L->stream, nullptr, 1, /*setup_done=*/1, pubInRaster ? &chunkPubs[q] : nullptr,
-                                          q == cn - 1 ? mark : nullptr))
-                            return fail("mv_step: observation size above 1024x1024");
-                        if (views[(size_t)chunkFirst + q].lpt_no_clear) L->histClean[(size_t)views[(size_t)chunkFirst + q].lpt_parity] = 1;   // (self_clear, mv_raster.hip)
-                    }
-                if (callEv) HIP_TRY(hipEventRecord(callEv[4], L->stream));
-                chunkFirst = j + 1;
-                chunkPubs.clear(); chunkObs.clear();
-            }
-        } else if (render && groupBatch) {
-            if (j == k - 1) {   // the k x n observation passes of the call with one launch
-                std::vector<PublishTo> allPubs((size_t)n * k);
-                std::vector<uint32_t *> allObs((size_t)n * k);
-                for (size_t q = 0; q < (size_t)n * k; ++q) {
-                    allPubs[q] = PublishTo{outs[q].rewards, outs[q].done, gs[q % (size_t)n]->gv.true_objective};
-                    allObs[q] = outs[q].obs;
-                }
-                const int r = launch_raster_union_batch(views.data(), allObs.data(), allPubs.data(), k, n, L->w, L->h, L->stream, mark);
-                if (r != 0) return fail(r == -2 ? "mv_group_step: the hand-over slots of a batched call are not one slot apart (internal)" : "mv_group_step: observation size above 1024x1024");
-                for (size_t q = 0; q < (size_t)n * k; ++q) gs[q % (size_t)n]->histClean[(size_t)views[q].lpt_parity] = 1;   // (every pass leaves its cost histogram zero)
-            }
-        } else if (render) {
-            const bool pubInRaster = own && allFast;
-            if (n > 1 && allFast) {
-                if (launch_raster_union(&views[(size_t)j * n], obsPtrs.data(), pubInRaster ? pubs.data() : nullptr, n, L->w, L->h, L->stream, evs[j] ? evs[j][3] : nullptr, mark))
-                    return fail("mv_step: observation size above 1024x1024");
-            } else {
-                for (int i = 0; i < n; ++i) {
-                    const GymView &v = views[(size_t)j * n + i];
-                    if (launch_raster(v, obsPtrs[i], L->w, L->h, L->stream, evs[j] && i == 0 ? evs[j][3] : nullptr, gs[i]->fastPixels, /*setup_done=*/1,
-                                      pubInRaster ? &pubs[i] : nullptr, i == n - 1 ? mark : nullptr))
-                        return fail("mv_step: observation size above 1024x1024");
-                    if (v.lpt_no_clear && gs[i]->fastPixels) gs[i]->histClean[(size_t)v.lpt_parity] = 1;   // (self_clear, mv_raster.hip)
-                }
-            }
-        } else if (mark) HIP_TRY(hipEventRecord(mark, L->stream));
-        if (evs[j]) HIP_TRY(hipEventRecord(evs[j][4], L->stream));
-    }
-    if (own) {
-        ++L->markCount;
-        for (int i = 0; i < n; ++i) gs[i]->markCount = L->markCount;
-    }
-    L->overlapCalls = overlap ? L->overlapCalls + 1 : 0;
-    HIP_TRY(hipGetLastError());
-    int rc = 0;
-    std::string text;
-    for (int i = 0; i < n; ++i)
-        if (!gs[i]->warning.empty()) {
-            text += (text.empty() ? "" : " | ") + (n > 1 ? "gym " + std::to_string(i) + ": " : std::string()) + gs[i]->warning;
-            gs[i]->warning.clear();
-            rc = 1;
-        }
-    if (rc) g_err = text;
-    return rc;
-}
-
-static int step_impl(mv_gym *g, bool render, int k, int policy, uint32_t seed, uint32_t first_index, int kCall = 0)
-{
-    if (g && g->inGroup) return fail("this gym belongs to an mv_group: step the group (mv_group_step)");
-    return step_gyms(&g, 1, render, k, policy, seed, first_index, kCall > 0 ? kCall : k);
-}
-
-int mv_step(mv_gym *g) { return step_impl(g, true, 1, POLICY_NONE, 0, 0); }
-int mv_step_no_render(mv_gym *g) { return step_impl(g, false, 1, POLICY_NONE, 0, 0); }
-
-int mv_step_n(mv_gym *g, int32_t k, int32_t policy, uint32_t seed, uint32_t first_step_index)
-{
-    if (check(g)) return -1;
-    if (policy != MV_POLICY_NONE && policy != MV_POLICY_MULTIDISCRETE && policy != MV_POLICY_SINGLE_BIT) return fail("mv_step_n: unknown policy");
-    if (k < 1) return fail("mv_step_n: k >= 1 required");
-    int rc = 0;
-    // Episodes that can end within a few ticks (statusPeriod 1: the refill protocol looks at the consumed counts after every tick) are
-    // stepped one tick per call; otherwise `batch` ticks at a time.
-    const int chunk = g->statusPeriod <= 1 ? 1 : g->batch;
-    for (int done = 0; done < k; done += chunk) {
-        const int n = std::min(chunk, k - done);
-        const int r = step_impl(g, true, n, policy, seed, first_step_index + (uint32_t)done, k);
-        if (r < 0) return -1;
-        if (r > 0) { g->warning += (g->warning.empty() ? "" : " | ") + g_err; rc = 1; }   // (every chunk's warning text is kept)
-    }
-    if (rc) { g_err = g->warning; g->warning.clear(); }
-    return rc;
-}
-
-// ---- groups: several gyms of one job stepped with union launches (mv_step_union.hip, mv_raster.hip: launch_raster_union)
-static void group_detach(mv_gym *g)
-{   // back to the gym's own simulation stream and events (they were kept aside while it was a member)
-    if (!g->inGroup) return;
-    mv_group *grp = g->inGroup;
-    for (mv_gym *m : grp->gyms) {
-        if (m != grp->gyms[0]) {
-            m->simStream = m->ownSimStream; m->simDone = m->ownSimDone; m->stepDone = m->ownStepDone;
-            for (int q = 0; q < PIPE_GROUPS; ++q) m->userMark[q] = m->ownUserMark[q];
-        }
-        m->inGroup = nullptr;
-        m->simMustWaitUser = true; m->simOnOwnStream = false; m->simDoneValid = false; m->stepDoneValid = false; m->markCount = 0;
-    }
-    grp->gyms.clear();   // (the handle stays valid until mv_group_destroy; stepping it is an error from now on)
-}
-
-int mv_group_create(mv_gym *const *gyms, int32_t n, mv_group **out)
-{
-    if (!gyms || !out || n < 1 || n > MAX_UNION) return fail("mv_group_create: 1 <= n <= 8 gyms required");
-    *out = nullptr;
-    mv_gym *L = gyms[0];
-    for (int i = 0; i < n; ++i) {
-        mv_gym *g = gyms[i];
-        if (check(g)) return -1;
-        if (g->inGroup) return fail("mv_group_create: a gym already belongs to a group");
-        for (int j = 0; j < i; ++j) if (gyms[j] == g) return fail("mv_group_create: the same gym twice");
-        if (g->device != L->device || g->w != L->w || g->h != L->h || g->A != L->A || g->stream != L->stream || g->batch != L->batch || g->pipelined != L->pipelined)
-            return fail("mv_group_create: the gyms of a group share device, observation size, agents per env, stream (mv_set_stream first), batch and pipelining");
-    }
-    HIP_TRY(hipSetDevice(L->device));
-    for (int i = 0; i < n; ++i) {   // nothing in flight on the streams a member is about to leave
-        HIP_TRY(hipStreamSynchronize(gyms[i]->simStream));
-        HIP_TRY(hipStreamSynchronize(gyms[i]->stream));
-    }
-    mv_group *grp = new mv_group();
-    grp->gyms.assign(gyms, gyms + n);
-    for (int i = 0; i < n; ++i) {
-        mv_gym *g = gyms[i];
-        g->inGroup = grp;
-        if (i > 0) {
-            g->ownSimStream = g->simStream; g->ownSimDone = g->simDone; g->ownStepDone = g->stepDone;
-            g->simStream = L->simStream; g->simDone = L->simDone; g->stepDone = L->stepDone;
-            for (int q = 0; q < PIPE_GROUPS; ++q) { g->ownUserMark[q] = g->userMark[q]; g->userMark[q] = L->userMark[q]; }
-        }
-        g->simMustWaitUser = true; g->simOnOwnStream = false; g->simDoneValid = false; g->stepDoneValid = false; g->markCount = 0;
-    }
-    *out = grp;
-    return 0;
-}
-
-int mv_group_destroy(mv_group *grp)
-{
-    if (!grp) return 0;
-    if (!grp->gyms.empty()) {
-        mv_gym *L = grp->gyms[0];
-        (void)hipSetDevice(L->device);
-        (void)hipStreamSynchronize(L->simStream);
-        (void)hipStreamSynchronize(L->stream);
-        group_detach(L);
-    }
-    delete grp;
-    return 0;
-}
-
-int mv_group_step(mv_group *grp, int32_t k, int32_t render, int32_t policy, uint32_t seed, uint32_t first_step_index)
-{
-    if (!grp || grp->gyms.empty()) return fail("mv_group_step: the group is gone (a member was closed)");
-    if (policy != MV_POLICY_NONE && policy != MV_POLICY_MULTIDISCRETE && policy != MV_POLICY_SINGLE_BIT) return fail("mv_group_step: unknown policy");
-    if (k < 1) return fail("mv_group_step: k >= 1 required");
-    int chunk = grp->gyms[0]->batch;
-    for (mv_gym *g : grp->gyms)
-        if (!g->closed && g->statusPeriod <= 1) chunk = 1;   // (episodes of a few ticks: the refill protocol looks at the consumed counts after every tick)
-    int rc = 0;
-    std::string text;
-    for (int done = 0; done < k; done += chunk) {
-        const int r = step_gyms(grp->gyms.data(), (int)grp->gyms.size(), render != 0, std::min(chunk, k - done), policy, seed, first_step_index + (uint32_t)done, k);
-        if (r < 0) return -1;
-        if (r > 0) { text += (text.empty() ? "" : " | ") + g_err; rc = 1; }
-    }
-    if (rc) g_err = text;
-    return rc;
-}
-
-int mv_step_many(mv_gym *const *gyms, int32_t n, int32_t render, int32_t sample, uint32_t seed, uint32_t step_index)
-{   // several gyms of one job (MultiTaskGym: one per scenario, one stream each) stepped by one call: at eight sub-gyms the per-call cost of
-    // the language binding is a third of the step.  EVERY gym is stepped, whatever another one reports: a failure (or a warning) is
-    // collected and returned after the loop, so the sub-gyms never get out of step with each other.
-    if (!gyms || n < 0) return fail("mv_step_many: bad arguments");
-    int rc = 0;
-    std::string msgs;
-    for (int i = 0; i < n; ++i) {
-        int r = sample ? mv_sample_random_actions(gyms[i], seed, step_index) : 0;
-        if (r == 0) r = step_impl(gyms[i], render != 0, 1, POLICY_NONE, 0, 0);
-        if (r != 0) {
-            msgs += (msgs.empty() ? "gym " : " | gym ") + std::to_string(i) + ": " + g_err;
-            if (r < 0 || rc == 0) rc = r < 0 ? -1 : 1;
-        }
-    }
-    if (rc) g_err = msgs;
-    return rc;
-}
-
 int mv_synchronize(mv_gym *g)
 {
     if (check(g)) return -1;
     HIP_TRY(hipStreamSynchronize(g->simStream));
     HIP_TRY(hipStreamSynchronize(g->stream));
-    return 0;
-}
-
-int mv_profile_begin(mv_gym *g, int32_t max_steps)
-{
-    if (check(g)) return -1;
-    if (max_steps < 0) return fail("mv_profile_begin: max_steps < 0");
-    HIP_TRY(hipSetDevice(g->device));
-    while ((int)g->profEvents.size() < max_steps * 5) {
-        hipEvent_t e;
-        HIP_TRY(hipEventCreate(&e));
-        g->profEvents.push_back(e);
-    }
-    g->profTicks.assign((size_t)max_steps, 1);
-    g->profMax = max_steps;
-    g->profCount = 0;
-    return 0;
-}
-
-int mv_profile_end(mv_gym *g, float *avg_ms4, int32_t *counts4)
-{
-    if (check(g)) return -1;
-    HIP_TRY(hipStreamSynchronize(g->simStream));
-    HIP_TRY(hipStreamSynchronize(g->stream));
-    // every interval lies on ONE stream: [0] step kernel = events 0 -> 1 (the stream the step ran on); [2] publish / frame sort = 2 -> 3 and
-    // [3] raster = 3 -> 4 (the caller's stream).  [1] (the old status read-back gap) is gone: it spanned two streams when pipelined.
-    double sum[4] = {0, 0, 0, 0};
-    static const int FROM[4] = {0, -1, 2, 3};
-    for (int i = 0; i < g->profCount; ++i)
-        for (int k = 0; k < 4; ++k) {
-            if (FROM[k] < 0) continue;
-            float ms = 0.0f;
-            HIP_TRY(hipEventElapsedTime(&ms, g->profEvents[(size_t)i * 5 + FROM[k]], g->profEvents[(size_t)i * 5 + FROM[k] + 1]));
-            sum[k] += ms;
-        }
-    int ticks = 0;   // (an entry of a batched call covers its k ticks: the averages are per tick)
-    for (int i = 0; i < g->profCount; ++i) ticks += g->profTicks[(size_t)i];
-    for (int k = 0; k < 4; ++k) {
-        avg_ms4[k] = ticks ? (float)(sum[k] / ticks) : 0.0f;
-        counts4[k] = ticks;
-    }
-    g->profMax = 0;
-    g->profCount = 0;
     return 0;
 }
 
@@ -1822,304 +1141,6 @@ int mv_set_reward_shaping(mv_gym *g, int32_t env, int32_t agent, const char *key
     if (sim_join(g)) return -1;
     hipLaunchKernelGGL(set_shaping_kernel, dim3(1), dim3(1), 0, g->stream, g->gv.agents, env * g->A + agent, k, v);
     HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-// ---- test hooks ---------------------------------------------------------------------------------
-#pragma pack(push, 4)
-struct SnapAgent {
-    float pos[3], basis[4], pitch, hv[2], vvel, voffset, step_offset, jump_speed;
-    int32_t was_jumping, carrying, picked_up, visited_zone, spawn[3];
-    float last_reward, total_reward, shaping[NUM_SHAPING];
-};
-struct Snap {
-    int32_t scenario, L, H, W, bz[4], layout_color, wall_color, draw_walls, num_objects, num_boxes, num_frames, done, highest_tower,
-        num_agents, num_terrain, num_rewards, num_platforms, solved;
-    float episode_sec, episode_len, bz_reward, bar_half_width;
-    int32_t boxes[COLLECT_MAX_BOXES][8];
-    int32_t terrain[MAX_TERRAIN][8];
-    int8_t objects[MAX_OBJECTS][4];
-    int8_t rewards[COLLECT_MAX_REWARDS][4];
-    SnapAgent agents[MAX_AGENTS];
-    uint8_t chunk[CHUNK_BYTES];
-    int8_t heightmap[HM_DIM * HM_DIM];
-    int32_t num_items, items[MAX_ITEMS][5];
-    uint8_t soko[32 * 32];   // Sokoban level cells
-    int32_t hex_num_boxes, hex_num_objs;
-    float hex_target[3];
-    HexRec hex_boxes[HEX_MAX_BOXES], hex_objs[HEX_MAX_OBJS];
-};
-#pragma pack(pop)
-
-int mv_debug_set_agent_pos(mv_gym *g, int32_t env, int32_t agent, float x, float y, float z)
-{
-    if (check(g)) return -1;
-    if (env < 0 || env >= g->N || agent < 0 || agent >= g->A) return fail("mv_debug_set_agent_pos: index out of range");
-    if (sim_join(g)) return -1;
-    hipLaunchKernelGGL(set_agent_pos_kernel, dim3(1), dim3(1), 0, g->stream, g->gv.agents, env * g->A + agent, x, y, z);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-int mv_debug_set_agent_yaw(mv_gym *g, int32_t env, int32_t agent, float c, float s)
-{
-    if (check(g)) return -1;
-    if (env < 0 || env >= g->N || agent < 0 || agent >= g->A) return fail("mv_debug_set_agent_yaw: index out of range");
-    if (sim_join(g)) return -1;
-    hipLaunchKernelGGL(set_agent_yaw_kernel, dim3(1), dim3(1), 0, g->stream, g->gv.agents, env * g->A + agent, c, s);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-int mv_debug_set_agent_velocity(mv_gym *g, int32_t env, int32_t agent, float hvx, float hvz, float vvel)
-{
-    if (check(g)) return -1;
-    if (env < 0 || env >= g->N || agent < 0 || agent >= g->A) return fail("mv_debug_set_agent_velocity: index out of range");
-    if (sim_join(g)) return -1;
-    hipLaunchKernelGGL(set_agent_velocity_kernel, dim3(1), dim3(1), 0, g->stream, g->gv.agents, env * g->A + agent, hvx, hvz, vvel);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-int mv_debug_snapshot_size(const mv_gym *) { return (int)sizeof(Snap); }
-
-int mv_debug_snapshot(mv_gym *g, int32_t env, void *out)
-{
-    if (check(g)) return -1;
-    if (env < 0 || env >= g->N) return fail("mv_debug_snapshot: index out of range");
-    HIP_TRY(hipStreamSynchronize(g->simStream));
-    HIP_TRY(hipStreamSynchronize(g->stream));
-    EnvHeader h;
-    std::vector<LayoutBox> boxes(g->gv.box_stride);
-    std::vector<MovableObject> objs(MAX_OBJECTS);
-    std::vector<AgentState> ag(g->A);
-    Snap *s = new Snap();
-    std::memset(s, 0, sizeof *s);
-    hipError_t e = hipMemcpy(&h, g->gv.hdr + env, sizeof h, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(boxes.data(), g->gv.boxes + (size_t)env * g->gv.box_stride, g->gv.box_stride * sizeof(LayoutBox), hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(objs.data(), g->gv.objects + (size_t)env * MAX_OBJECTS, MAX_OBJECTS * sizeof(MovableObject), hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(ag.data(), g->gv.agents + (size_t)env * g->A, g->A * sizeof(AgentState), hipMemcpyDeviceToHost);
-    if (e == hipSuccess && g->gv.chunk) e = hipMemcpy(s->chunk, g->gv.chunk + (size_t)env * CHUNK_BYTES, CHUNK_BYTES, hipMemcpyDeviceToHost);
-    std::vector<TerrainBox> terr(MAX_TERRAIN);
-    std::vector<MovableObject> rew(g->gv.reward_stride);
-    if (e == hipSuccess && g->gv.terrain) e = hipMemcpy(terr.data(), g->gv.terrain + (size_t)env * MAX_TERRAIN, MAX_TERRAIN * sizeof(TerrainBox), hipMemcpyDeviceToHost);
-    if (e == hipSuccess && g->gv.rewards_obj) e = hipMemcpy(rew.data(), g->gv.rewards_obj + (size_t)env * g->gv.reward_stride, g->gv.reward_stride * sizeof(MovableObject), hipMemcpyDeviceToHost);
-    if (e == hipSuccess && g->gv.items) {
-        std::vector<ArrangementItem> its(MAX_ITEMS);
-        e = hipMemcpy(its.data(), g->gv.items + (size_t)env * MAX_ITEMS, MAX_ITEMS * sizeof(ArrangementItem), hipMemcpyDeviceToHost);
-        s->num_items = h.num_terrain;
-        for (int i = 0; i < h.num_terrain && i < MAX_ITEMS; ++i) {
-            s->items[i][0] = its[i].shape; s->items[i][1] = its[i].color;
-            s->items[i][2] = its[i].off[0]; s->items[i][3] = its[i].off[1]; s->items[i][4] = its[i].off[2];
-        }
-    }
-    if (e == hipSuccess && g->gv.soko_cells) e = hipMemcpy(s->soko, g->gv.soko_cells + (size_t)env * (SOKO_DIM * SOKO_DIM), SOKO_DIM * SOKO_DIM, hipMemcpyDeviceToHost);
-    std::memset(s->heightmap, 0xff, sizeof s->heightmap);
-    if (e == hipSuccess && g->gv.heightmap) e = hipMemcpy(s->heightmap, g->gv.heightmap + (size_t)env * HM_BYTES, sizeof s->heightmap, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) { delete s; return fail(std::string("mv_debug_snapshot: ") + hipGetErrorString(e)); }
-    if (h.scenario == SCN_REARRANGE) h.num_terrain = 0;   // (the header reuses it for the item count, reported as num_items)
-    if (e == hipSuccess && g->gv.hex_boxes) {   // Hex*: the header's box / collider / reward counts describe the hex lists
-        s->hex_num_boxes = h.num_boxes; s->hex_num_objs = h.num_rewards;
-        s->hex_target[0] = h.hex_target[0]; s->hex_target[1] = 0.0f; s->hex_target[2] = h.hex_target[1];
-        e = hipMemcpy(s->hex_boxes, g->gv.hex_boxes + (size_t)env * HEX_MAX_BOXES, (size_t)std::min(h.num_boxes, (int)HEX_MAX_BOXES) * sizeof(HexRec), hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(s->hex_objs, g->gv.hex_objs + (size_t)env * HEX_MAX_OBJS, (size_t)std::min(h.num_rewards, (int)HEX_MAX_OBJS) * sizeof(HexRec), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) { delete s; return fail(std::string("mv_debug_snapshot: ") + hipGetErrorString(e)); }
-        h.num_boxes = 0; h.num_rewards = 0; h.num_terrain = 0;
-    }
-    s->scenario = h.scenario; s->num_terrain = h.num_terrain; s->num_rewards = h.num_rewards; s->num_platforms = h.num_platforms; s->solved = h.solved;
-    for (int i = 0; i < h.num_terrain && i < MAX_TERRAIN; ++i) {
-        const TerrainBox &t = terr[i];
-        int32_t *o = s->terrain[i];
-        o[0] = t.min[0]; o[1] = t.min[1]; o[2] = t.min[2]; o[3] = t.max[0]; o[4] = t.max[1]; o[5] = t.max[2]; o[6] = t.type; o[7] = 0;
-    }
-    for (int i = 0; i < h.num_rewards && i < g->gv.reward_stride; ++i) {
-        s->rewards[i][0] = rew[i].x; s->rewards[i][1] = rew[i].y; s->rewards[i][2] = rew[i].z; s->rewards[i][3] = rew[i].state;
-    }
-    s->L = h.L; s->H = h.H; s->W = h.W;
-    for (int i = 0; i < 4; ++i) s->bz[i] = h.bz[i];
-    s->layout_color = h.layout_color; s->wall_color = h.wall_color; s->draw_walls = h.draw_walls;
-    s->num_objects = h.num_objects; s->num_boxes = h.num_boxes; s->num_frames = h.num_frames; s->done = h.done;
-    s->highest_tower = h.highest_tower; s->num_agents = g->A;
-    s->episode_sec = h.episode_sec; s->episode_len = h.episode_len; s->bz_reward = h.bz_reward; s->bar_half_width = h.bar_half_width;
-    for (int i = 0; i < h.num_boxes && i < g->gv.box_stride; ++i) {
-        const LayoutBox &b = boxes[i];
-        int32_t *o = s->boxes[i];
-        o[0] = b.min[0]; o[1] = b.min[1]; o[2] = b.min[2]; o[3] = b.max[0]; o[4] = b.max[1]; o[5] = b.max[2]; o[6] = b.type; o[7] = b.slot;
-    }
-    for (int i = 0; i < h.num_objects && i < MAX_OBJECTS; ++i) {
-        s->objects[i][0] = objs[i].x; s->objects[i][1] = objs[i].y; s->objects[i][2] = objs[i].z; s->objects[i][3] = objs[i].state;
-    }
-    for (int i = 0; i < g->A; ++i) {
-        const AgentState &a = ag[i];
-        SnapAgent &o = s->agents[i];
-        o.pos[0] = a.pos[0]; o.pos[1] = a.pos[1]; o.pos[2] = a.pos[2];
-        o.basis[0] = a.m00; o.basis[1] = a.m02; o.basis[2] = a.m20; o.basis[3] = a.m22;
-        o.pitch = a.pitch; o.hv[0] = a.hvx; o.hv[1] = a.hvz; o.vvel = a.vvel; o.voffset = a.voffset;
-        o.step_offset = a.step_offset; o.jump_speed = a.jump_speed; o.was_jumping = a.was_jumping; o.carrying = a.carrying;
-        o.picked_up = a.picked_up; o.visited_zone = a.visited_zone;
-        for (int k = 0; k < 3; ++k) o.spawn[k] = a.spawn[k];
-        o.last_reward = a.last_reward; o.total_reward = a.total_reward;
-        for (int k = 0; k < NUM_SHAPING; ++k) o.shaping[k] = a.shaping[k];
-    }
-    std::memcpy(out, s, sizeof *s);
-    delete s;
-    return 0;
-}
-
-// Host-only test hook (no device needed): the n-th episode an env seeded with `env_seed` generates, as the raw
-// blob the reset kernel consumes (EpisodeBlob for the Obstacles family, CollectBlob for Collect).
-int mv_debug_generate_episode(const char *scenario_name, int32_t num_agents, int32_t env_seed, int32_t n, float base_episode_len,
-                              void *out, int32_t out_bytes)
-{
-    int scenario = SCN_TOWER;
-    ObstacleConfig oc;
-    if (!scenario_name || !scenario_from_name(lower(scenario_name), scenario, oc) || scenario == SCN_TOWER || scenario == SCN_SOKOBAN || scenario == SCN_EMPTY)
-        return fail("mv_debug_generate_episode: the Obstacles family, Collect, Rearrange, HexMemory and HexExplore (Sokoban: mv_debug_generate_sokoban)");
-    if (num_agents < 1 || num_agents > MAX_AGENTS || n < 1) return fail("mv_debug_generate_episode: bad arguments");
-    const bool hex = scenario == SCN_HEX_MEMORY || scenario == SCN_HEX_EXPLORE;
-    const size_t bytes = scenario == SCN_COLLECT ? sizeof(CollectBlob) : scenario == SCN_REARRANGE ? sizeof(RearrangeBlob) : hex ? sizeof(HexBlob) : sizeof(EpisodeBlob);
-    if (!out) return (int)bytes;
-    if ((size_t)out_bytes < bytes) return fail("mv_debug_generate_episode: buffer too small");
-    std::mt19937 rng;
-    rng.seed((unsigned long)env_seed);
-    std::vector<uint8_t> buf(bytes, 0);
-    for (int i = 0; i < n; ++i) {
-        std::memset(buf.data(), 0, bytes);
-        if (scenario == SCN_COLLECT) generate_collect_episode(rng, num_agents, base_episode_len, *reinterpret_cast<CollectBlob *>(buf.data()));
-        else if (scenario == SCN_HEX_MEMORY) generate_hex_memory_episode(rng, num_agents, base_episode_len, *reinterpret_cast<HexBlob *>(buf.data()));
-        else if (scenario == SCN_HEX_EXPLORE) generate_hex_explore_episode(rng, num_agents, base_episode_len, *reinterpret_cast<HexBlob *>(buf.data()));
-        else if (scenario == SCN_REARRANGE) generate_rearrange_episode(rng, num_agents, base_episode_len, *reinterpret_cast<RearrangeBlob *>(buf.data()));
-        else generate_obstacles_episode(rng, oc, num_agents, base_episode_len, *reinterpret_cast<EpisodeBlob *>(buf.data()));
-    }
-    std::memcpy(out, buf.data(), bytes);
-    return (int)bytes;
-}
-
-// Host-only test hook: drives an EpisodeFeeder (worker pool, per-env ordering, recycle) without a device and checks
-// every episode it delivers against a straight sequential generation from the same seeds.  Returns 0 when equal.
-int mv_debug_feeder_selftest(const char *scenario_name, int32_t num_envs, int32_t num_agents, int32_t threads, int32_t rounds)
-{
-    int scenario = SCN_TOWER;
-    ObstacleConfig oc;
-    if (!scenario_name || !scenario_from_name(lower(scenario_name), scenario, oc) || scenario == SCN_TOWER || scenario == SCN_SOKOBAN || scenario == SCN_EMPTY)
-        return fail("mv_debug_feeder_selftest: the Obstacles family, Collect, Rearrange, HexMemory and HexExplore");
-    const bool hex = scenario == SCN_HEX_MEMORY || scenario == SCN_HEX_EXPLORE;
-    const size_t bytes = scenario == SCN_COLLECT ? sizeof(CollectBlob) : scenario == SCN_REARRANGE ? sizeof(RearrangeBlob) : hex ? sizeof(HexBlob) : sizeof(EpisodeBlob);
-    std::vector<uint8_t> slots((size_t)num_envs * bytes, 0), want(bytes);
-    std::vector<uint32_t> seeds(num_envs);
-    for (int i = 0; i < num_envs; ++i) seeds[i] = 1000u + 7u * (uint32_t)i;
-    std::vector<std::mt19937> rng(num_envs);
-    for (int i = 0; i < num_envs; ++i) rng[i].seed((unsigned long)seeds[i]);
-    EpisodeFeeder feeder(scenario, oc, num_envs, num_agents, 60.0f, slots.data(), bytes, 0, threads);
-    feeder.reseed(seeds, std::vector<int>(num_envs, 1));
-    for (int r = 1; r <= rounds; ++r)
-        for (int k = 0; k < num_envs; ++k) {
-            const int i = (r & 1) ? k : num_envs - 1 - k;   // consume in varying order
-            size_t used = 0;
-            const uint8_t *got = feeder.wait_ready(i, r, &used);
-            if (!got) return fail("feeder selftest: episode not delivered");
-            std::memset(want.data(), 0, bytes);
-            if (hex) {   // the box list comes last and only its used prefix is meaningful
-                HexBlob &b = *reinterpret_cast<HexBlob *>(want.data());
-                if (scenario == SCN_HEX_MEMORY) generate_hex_memory_episode(rng[i], num_agents, 60.0f, b);
-                else generate_hex_explore_episode(rng[i], num_agents, 60.0f, b);
-                b.seq = r;
-                const HexBlob &a = *reinterpret_cast<const HexBlob *>(got);
-                if (used != offsetof(HexBlob, boxes) + sizeof(HexRec) * (size_t)b.num_boxes || std::memcmp(&a, &b, offsetof(HexBlob, objs)) ||
-                    std::memcmp(a.objs, b.objs, sizeof(HexRec) * (size_t)b.num_objs) || std::memcmp(a.boxes, b.boxes, sizeof(HexRec) * (size_t)b.num_boxes))
-                    return fail("feeder selftest: Hex episode differs from sequential generation");
-                feeder.recycle(i, nullptr);
-                continue;
-            }
-            if (scenario == SCN_REARRANGE) {
-                RearrangeBlob &b = *reinterpret_cast<RearrangeBlob *>(want.data());
-                generate_rearrange_episode(rng[i], num_agents, 60.0f, b);
-                b.seq = r;
-                if (std::memcmp(got, &b, sizeof b)) return fail("feeder selftest: Rearrange episode differs from sequential generation");
-                feeder.recycle(i, nullptr);
-                continue;
-            }
-            if (scenario == SCN_COLLECT) {
-                CollectBlob &b = *reinterpret_cast<CollectBlob *>(want.data());
-                generate_collect_episode(rng[i], num_agents, 60.0f, b);
-                b.seq = r;
-            } else {
-                EpisodeBlob &b = *reinterpret_cast<EpisodeBlob *>(want.data());
-                generate_obstacles_episode(rng[i], oc, num_agents, 60.0f, b);
-                b.seq = r;
-            }
-            if (used > bytes) return fail("feeder selftest: used bytes out of range");
-            // compare the meaningful fields: counts first, then the used prefix of each array via the generators' own layout
-            if (scenario == SCN_COLLECT) {
-                const CollectBlob &a = *reinterpret_cast<const CollectBlob *>(got), &b = *reinterpret_cast<const CollectBlob *>(want.data());
-                if (a.seq != b.seq || a.num_boxes != b.num_boxes || a.num_objects != b.num_objects || a.num_rewards != b.num_rewards ||
-                    std::memcmp(a.boxes, b.boxes, sizeof(LayoutBox) * (size_t)b.num_boxes) || std::memcmp(a.heightmap, b.heightmap, HM_DIM * HM_DIM) ||
-                    std::memcmp(a.spawn, b.spawn, sizeof a.spawn) || std::memcmp(a.yaw_frand, b.yaw_frand, sizeof(float) * (size_t)num_agents))
-                    return fail("feeder selftest: Collect episode differs from sequential generation");
-            } else {
-                const EpisodeBlob &a = *reinterpret_cast<const EpisodeBlob *>(got), &b = *reinterpret_cast<const EpisodeBlob *>(want.data());
-                if (a.seq != b.seq || a.num_boxes != b.num_boxes || a.num_objects != b.num_objects || a.num_rewards != b.num_rewards ||
-                    std::memcmp(a.boxes, b.boxes, sizeof(LayoutBox) * (size_t)b.num_boxes) || std::memcmp(a.spawn, b.spawn, sizeof a.spawn) ||
-                    std::memcmp(a.yaw_frand, b.yaw_frand, sizeof(float) * (size_t)num_agents))
-                    return fail("feeder selftest: Obstacles episode differs from sequential generation");
-            }
-            feeder.recycle(i, nullptr);
-        }
-    return 0;
-}
-
-// Host-only test hook for the Sokoban generator: the first `n` episodes an env
-// seeded with env_seed generates from the level files under $BOXOBAN_LEVELS, as n consecutive SokobanBlob records.
-int mv_debug_generate_sokoban(int32_t num_agents, int32_t env_seed, int32_t n, float base_episode_len, void *out, int32_t out_bytes)
-{
-    if (!out) return (int)sizeof(SokobanBlob);
-    if (num_agents < 1 || num_agents > MAX_AGENTS || n < 1 || (size_t)out_bytes < (size_t)n * sizeof(SokobanBlob))
-        return fail("mv_debug_generate_sokoban: bad arguments");
-    const std::vector<std::string> files = find_boxoban_level_files();
-    if (files.empty()) return fail("mv_debug_generate_sokoban: no Boxoban levels found (BOXOBAN_LEVELS)");
-    std::mt19937 rng;
-    rng.seed((unsigned long)env_seed);
-    SokobanLevels levels;
-    for (int i = 0; i < n; ++i)
-        if (!generate_sokoban_episode(rng, levels, files, num_agents, base_episode_len, reinterpret_cast<SokobanBlob *>(out)[i]))
-            return fail("mv_debug_generate_sokoban: unreadable level file");
-    return n;
-}
-
-int mv_debug_rng(int32_t device, uint32_t seed, int32_t what, const int32_t *lo, const int32_t *hi, int32_t n, void *out)
-{
-    HIP_TRY(hipSetDevice(device));
-    if (what == 3 && n > 4096) return fail("mv_debug_rng: shuffle n <= 4096");
-    int32_t *dlo = nullptr, *dhi = nullptr;
-    void *dout = nullptr;
-    HIP_TRY(hipMalloc(&dout, (size_t)n * 4));
-    if (what == 1) {
-        HIP_TRY(hipMalloc((void **)&dlo, (size_t)n * 4));
-        HIP_TRY(hipMalloc((void **)&dhi, (size_t)n * 4));
-        HIP_TRY(hipMemcpy(dlo, lo, (size_t)n * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(dhi, hi, (size_t)n * 4, hipMemcpyHostToDevice));
-    }
-    hipLaunchKernelGGL(debug_rng_kernel, dim3(1), dim3(64), 0, nullptr, seed, what, dlo, dhi, n, dout);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(dout); (void)hipFree(dlo); (void)hipFree(dhi);
-    return 0;
-}
-
-int mv_debug_math(int32_t device, int32_t what, const float *a, const float *b, int32_t n, float *out)
-{
-    HIP_TRY(hipSetDevice(device));
-    float *da = nullptr, *db = nullptr, *dout = nullptr;
-    const size_t outN = (what == 2) ? 2 * (size_t)n : (size_t)n;
-    HIP_TRY(hipMalloc((void **)&da, (size_t)n * 4));
-    HIP_TRY(hipMalloc((void **)&db, (size_t)n * 4));
-    HIP_TRY(hipMalloc((void **)&dout, outN * 4));
-    HIP_TRY(hipMemcpy(da, a, (size_t)n * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(db, b ? b : a, (size_t)n * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(debug_math_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, what, da, db, n, dout);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out, dout, outN * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
     return 0;
 }
 
