@@ -327,7 +327,7 @@ def main():
                          "512 envs 20.1 / 20.9; Rearrange 19.4 / 19.5; r07j: Sokoban 23.4 / 19.6, Collect 14.0 / 14.3, HexMemory 9.15 / 9.10)")
     ap.add_argument("--batch", type=int, default=0,
                     help="ticks per stepping call (mv_step_n): every tick is stepped and rendered in full, the two stream hand-overs are paid once "
-                         "per call; 1 = one mv_step per tick; 0 (default) = 8, the first two calls after a synchronisation 1 and 3 ticks (the observation "
+                         "per call; 1 = one mv_step per tick; 0 (default) = 16, the first calls after a synchronisation 2, 4 and 6 ticks (the observation "
                          "passes of a call start when its ticks are stepped: short first calls fill the pipeline sooner; 20-step runs: 20.0-20.25 M obs/s "
                          "against 19.0 M with 2 ticks per call throughout).  N>1 with the gather on always steps tick by tick")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the single-step / unpipelined / closed-loop transparency legs")
@@ -373,7 +373,7 @@ def main():
     n_env, A = args.envs_per_gpu, args.agents
     mixed = args.scenario.lower() in ("mixed", "mixed4")
     frames = n_env * A
-    batch = args.batch if args.batch > 0 else 8
+    batch = args.batch if args.batch > 0 else 16
     os.environ.setdefault("MV_PIPE_BATCH", str(max(8, min(16, batch))))
     batch = min(batch, int(os.environ["MV_PIPE_BATCH"]))
     if dry:
@@ -757,9 +757,15 @@ def main():
                                                               " (voxel physics + scenario logic + auto-reset + frame setup)", "ticks_per_launch": batch if batch_step else 1, "achieved": achieved_step,
                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_step / HBM_PEAK_GBS, "traffic": traffic_step,
                                         "avg_launch_ms": step_ms, "launches_timed": prof["step"][1], "algorithmic_bytes_per_launch": step_bytes_per_env * n_env,
-                                        "note": "north_star's >=40 % HBM target names this kernel; its working set is 1.7 KB per env (the 16 KB voxel chunk "
-                                                "is not streamed), so it is latency-bound: one wave per env, launch length = slowest wave (DESIGN.md 3.1); "
-                                                "when pipelined it runs concurrently with the previous ticks' rasters, which stretches its launches"}
+                                        # the same launch priced with SURVEY 8(d)'s per-env figure (17.9 KB for one agent, 18.7 KB for four: the 16 KB voxel chunk
+                                        # counted as read every tick -- which this kernel does NOT do: it works from the box lists, DESIGN.md header)
+                                        "survey_bytes_per_env": 17900 + (A - 1) * 267,
+                                        "frac_survey_bytes": ((17900 + (A - 1) * 267) * n_env / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if step_ms else None,
+                                        "note": "north_star's >=40 % HBM target names this kernel and is NOT met in either convention (`frac`: the bytes the kernel moves; "
+                                                "`frac_survey_bytes`: SURVEY 8(d)'s 17.9 KB per env, chunk included): its working set is 1.7 KB per env (the 16 KB voxel chunk "
+                                                "is not streamed), so it is latency-bound, not bandwidth-bound: one wave per env, launch length = slowest wave (DESIGN.md 3.1); "
+                                                "when pipelined it runs concurrently with the previous ticks' rasters, which stretches its launches.  40 % of 8 TB/s would mean "
+                                                "a 1024-env tick in 1.2 us of streaming for 3.8 MB -- the tick's dependent chain of casts is ~10 us whatever the bandwidth"}
             if args.pixels == "exact":
                 line["kernels"] = {"publish_and_frame_sort": {"avg_launch_ms": prof["setup"][0], "note": "exact pixel mode only; same-stream interval"}}
         line["checksum"] = checksum

@@ -103,7 +103,7 @@ int mv_step_no_render(mv_gym *g);                   /* physics/logic/auto-reset 
  * step kernel and renders every agent's observation.  Exactly the ticks k calls of mv_sample_random_actions + mv_step make -- but the
  * simulation stream and the caller's stream hand over to each other once per call instead of once per tick.  policy
  * MV_POLICY_NONE: the first tick acts on what mv_set_actions* left, the others on cleared actions.  The public arrays hold the LAST tick's
- * outputs -- or, with mv_set_output_ring, every tick's.  k may exceed the internal batch (MV_PIPE_BATCH, default 8): the call splits it. */
+ * outputs -- or, with mv_set_output_ring, every tick's.  k may exceed the internal batch (MV_PIPE_BATCH, default 16): the call splits it. */
 int mv_step_n(mv_gym *g, int32_t k, int32_t policy, uint32_t seed, uint32_t first_step_index);
 /* Rollout rings (no reference counterpart: its learner copies each step's observation out of the gym, megaverse_env.py:121-130): tick
  * number t since this call leaves its observations in obs[t % count] ([count][N*A][h][w][4]), its rewards in rewards[t % count] ([count][N*A])

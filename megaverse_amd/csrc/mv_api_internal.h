@@ -35,13 +35,13 @@ void launch_tower_seed(const GymView &gv, const uint32_t *seeds, hipStream_t str
 // step kernels: one 256-thread workgroup per env = the tick (wave 0) + the frame setup of the env's frames for a W x H observation
 // (render = 0: tick only)
 void launch_step(const GymView &gv, hipStream_t stream, int W, int H, int render, hipEvent_t done = nullptr);
-void launch_step_ticks(const GymView *views, int k, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);   // k ticks + frame setups of every env, one launch (mv_step.hip)
+void launch_step_ticks(const GymView *views, GymView *dviews, int k, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);   // k ticks + frame setups of every env, one launch (mv_step.hip)
 void launch_step_obstacles(const GymView &gv, hipStream_t stream, int W, int H, int render);
-void launch_step_obstacles_ticks(const GymView *views, int k, hipStream_t stream, int W, int H);   // k ticks + frame setups of every env (one agent), one launch
-void launch_step_rearrange_ticks(const GymView *views, int k, hipStream_t stream, int W, int H);
-void launch_step_sokoban_ticks(const GymView *views, int k, hipStream_t stream, int W, int H);
-void launch_step_collect_ticks(const GymView *views, int k, hipStream_t stream, int W, int H);
-void launch_step_hex_ticks(const GymView *views, int k, hipStream_t stream, int W, int H);
+void launch_step_obstacles_ticks(const GymView *views, GymView *dviews, int k, hipStream_t stream, int W, int H);   // k ticks + frame setups of every env (one agent), one launch
+void launch_step_rearrange_ticks(const GymView *views, GymView *dviews, int k, hipStream_t stream, int W, int H);
+void launch_step_sokoban_ticks(const GymView *views, GymView *dviews, int k, hipStream_t stream, int W, int H);
+void launch_step_collect_ticks(const GymView *views, GymView *dviews, int k, hipStream_t stream, int W, int H);
+void launch_step_hex_ticks(const GymView *views, GymView *dviews, int k, hipStream_t stream, int W, int H);
 void launch_reset_obstacles(const GymView &gv, const EpisodeBlob *blobs, int *status, int force_all, hipStream_t stream);
 void launch_step_rearrange(const GymView &gv, hipStream_t stream, int W, int H, int render);
 void launch_reset_rearrange(const GymView &gv, const RearrangeBlob *blobs, int *status, int force_all, hipStream_t stream);
@@ -102,7 +102,7 @@ struct mv_gym {
     bool simMustWaitUser = true;                 // the caller's stream holds work the next step depends on (reset, render, device actions, ...)
     hipEvent_t simDone = nullptr;                // after the last kernel on simStream
     bool simDoneValid = false;
-    int batch = 8, slots = PIPE_GROUPS * 8, hists = PIPE_GROUPS * 8 + 1;   // slots per group (MV_PIPE_BATCH), slots, cost histograms
+    int batch = 16, slots = PIPE_GROUPS * 16, hists = PIPE_GROUPS * 16 + 1;   // slots per group (MV_PIPE_BATCH; 16: one tail of the observation launch per 16 ticks -- measured against 8: TowerBuilding 26.6 -> 28.3 M obs/s, Collect 14.4 -> 15.1), slots, cost histograms
     int group = 0;                               // slot group of the last stepping call
     int parity = 0, hist3 = 0;                   // hand-over slot of the last tick; cost histogram of the last pass
     // histClean[h]: cost histogram h is (or, in stream order, will be) all zero when the next frame setup counts into it.  A pass drawn by the
@@ -111,6 +111,7 @@ struct mv_gym {
     // the two paths -- is cleared by take_hist with a memset.
     std::vector<uint8_t> histClean;
     std::vector<GymView> gvp;                    // [slots] gv with the buffers of each slot swapped in
+    GymView *dViews = nullptr;                   // [MAX_STEP_TICKS] device copies of the views of the multi-tick step launch in flight (mv_types.h: StepTicksArgs)
     GymView gv{};
     const int32_t *mdActions = nullptr;          // mv_set_actions_device: the caller's multi-discrete buffer, read by the next step kernel
     // mv_set_pass_overlap(1), ring at least two calls deep: the one-launch observation passes of consecutive batched calls go to two internal streams

@@ -108,7 +108,7 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
     // launch and around the raster launch, k ticks -- so that the figures are those of the launches the product runs; otherwise tick by tick
     const bool profiling = render && L->profCount < L->profMax;
     hipEvent_t *callEv = nullptr;
-    if (profiling && canMultiTick && canBatchRaster && k <= MAX_UNION) {
+    if (profiling && canMultiTick && canBatchRaster && k <= MAX_STEP_TICKS) {
         callEv = &L->profEvents[(size_t)L->profCount * 5];
         L->profTicks[(size_t)L->profCount] = k;
         ++L->profCount;
@@ -150,12 +150,12 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
                 // kernels in front of every step launch, the second one waiting 30 us for a wave slot beside the observation passes: the chain
                 // of step launches is what bounds a batched call's rate at 1024 envs, 344 + 39 us per call against 288 us of passes.)
                 if (callEv) HIP_TRY(hipEventRecord(callEv[0], sim));
-                if (obstFamily) launch_step_obstacles_ticks(views.data(), k, sim, L->w, L->h);
-                else if (L->scenario == SCN_REARRANGE) launch_step_rearrange_ticks(views.data(), k, sim, L->w, L->h);
-                else if (L->scenario == SCN_SOKOBAN) launch_step_sokoban_ticks(views.data(), k, sim, L->w, L->h);
-                else if (L->scenario == SCN_COLLECT) launch_step_collect_ticks(views.data(), k, sim, L->w, L->h);
-                else if (L->scenario == SCN_HEX_MEMORY || L->scenario == SCN_HEX_EXPLORE) launch_step_hex_ticks(views.data(), k, sim, L->w, L->h);
-                else launch_step_ticks(views.data(), k, sim, L->w, L->h, own && !callEv ? L->simDone : nullptr);
+                if (obstFamily) launch_step_obstacles_ticks(views.data(), L->dViews, k, sim, L->w, L->h);
+                else if (L->scenario == SCN_REARRANGE) launch_step_rearrange_ticks(views.data(), L->dViews, k, sim, L->w, L->h);
+                else if (L->scenario == SCN_SOKOBAN) launch_step_sokoban_ticks(views.data(), L->dViews, k, sim, L->w, L->h);
+                else if (L->scenario == SCN_COLLECT) launch_step_collect_ticks(views.data(), L->dViews, k, sim, L->w, L->h);
+                else if (L->scenario == SCN_HEX_MEMORY || L->scenario == SCN_HEX_EXPLORE) launch_step_hex_ticks(views.data(), L->dViews, k, sim, L->w, L->h);
+                else launch_step_ticks(views.data(), L->dViews, k, sim, L->w, L->h, own && !callEv ? L->simDone : nullptr);
                 if (callEv) HIP_TRY(hipEventRecord(callEv[1], sim));
                 simDoneRides = own && !callEv && L->scenario == SCN_TOWER;
             }
@@ -206,7 +206,7 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
     std::vector<PublishTo> pubs((size_t)n);
     std::vector<uint32_t *> obsPtrs((size_t)n);
     // One gym, several ticks, every tick's observations in a slab of its own (an output ring at least k deep), nothing timed per tick: the
-    // observation passes of up to MAX_UNION ticks go out as ONE launch (launch_raster_batch: the next tick's expensive frames fill the tail of
+    // observation passes of up to MAX_STEP_TICKS ticks go out as ONE launch (launch_raster_batch: the next tick's expensive frames fill the tail of
     // the previous tick's pass).  The ticks are collected below and launched at the end of their chunk.
     bool batchRaster = canBatchRaster;
     for (int j = 0; j < k; ++j) batchRaster = batchRaster && !evs[j];
@@ -217,7 +217,7 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
     // what the consumer of the previous CALL -- enqueued after both of its chunks -- may still be reading), and rewards / dones have rings of
     // their own (two passes in flight would both publish the single arrays, in either order).
     const bool overlap = batchRaster && own && !callEv && L->passOverlap && L->passStream[0] && L->ringCount >= 2 * std::max(k, kCall) && L->ringRewards && L->ringDone &&
-                         k <= MAX_UNION && L->baseEpisodeLen * 15.0f > float(2 * k + 2);
+                         k <= MAX_STEP_TICKS && L->baseEpisodeLen * 15.0f > float(2 * k + 2);
     hipStream_t passOn = L->stream;
     if (overlap) {
         const int me = (int)(L->overlapCalls & 1ull);
@@ -243,7 +243,7 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
             const bool pubInRaster = own;
             chunkPubs.push_back(pubs[0]);
             chunkObs.push_back(obsPtrs[0]);
-            static const int chunkMax = getenv("MV_RASTER_BATCH") ? std::min((int)MAX_UNION, std::max(1, atoi(getenv("MV_RASTER_BATCH")))) : (int)MAX_UNION;   // (0: off, launch_raster_batch declines)
+            static const int chunkMax = getenv("MV_RASTER_BATCH") ? std::min((int)MAX_STEP_TICKS, std::max(1, atoi(getenv("MV_RASTER_BATCH")))) : (int)MAX_STEP_TICKS;   // (0: off, launch_raster_batch declines)
             if (j == k - 1 || (int)chunkObs.size() >= chunkMax) {
                 const int cn = (int)chunkObs.size();
                 if (callEv) { HIP_TRY(hipEventRecord(callEv[2], L->stream)); HIP_TRY(hipEventRecord(callEv[3], L->stream)); }

@@ -1827,41 +1827,70 @@ __global__ __launch_bounds__(256, WAVES) void raster_fast_union_kernel(UnionRast
     raster_fast_body<MAXVIS, SHAPES, HEXF, NP>(ua.fa[s], ua.obs[s], W, H, split, (int)blockIdx.x - ua.first[s], s_buf);
 }
 
-// The observation passes of the k ticks of ONE batched call (mv_step_n) with one launch: workgroup b draws for tick j with first[j] <= b <
-// first[j + 1], every tick in its own cost order (its own bins, lists, header slab, observation slab).  A launch is throughput-bound while the
-// chip is full and has a tail while its expensive frames finish -- half of a launch's waves are done after 32 of its 47 us (r04g); here the
-// next tick's expensive frames start in that tail, and there is one tail per call instead of one per tick.  The step's staged outputs of ALL k
-// ticks are published by the first workgroups, element by element in tick order (true_objective is only ever written by a finishing env:
-// what a later tick does not touch keeps the earlier tick's value, as with one launch per tick).
-template <int MAXVIS, bool SHAPES, int WAVES, int NP, int NT = 256>
-__global__ __launch_bounds__(NT, WAVES) void raster_fast_batch_kernel(UnionRasterArgs ua, int W, int H, int split)
+// The observation passes of the k ticks of ONE batched call (mv_step_n) with one launch: workgroups are dealt tick by tick, every tick in its own cost order
+// (its own bins, lists, header slab, observation slab).  A launch is throughput-bound while the chip is full and has a tail while its expensive frames
+// finish -- half of a launch's waves are done after 32 of its 47 us (r04g); here the next tick's expensive frames start in that tail, and there is one
+// tail per call instead of one per tick.  The step's staged outputs of ALL k ticks are published by the first workgroups, element by element in tick
+// order (true_objective is only ever written by a finishing env: what a later tick does not touch keeps the earlier tick's value, as with one launch
+// per tick).  Arguments: tick 0's FastArgs; tick j's differ from them in the hand-over slot (slot_stride bytes further per tick, mv_types.h: tick_view),
+// the cost histogram (consecutive, modulo their number) and where the outputs go (passed per tick: rings wrap) -- k sets of FastArgs do not fit the
+// 4 KB of kernel arguments beyond k = 8, and k is up to MAX_STEP_TICKS = 16.
+struct TicksRasterArgs {
+    int32_t k, per_tick;                // ticks, workgroups of one tick's pass
+    int32_t hists, parity0;             // the gym's cost histograms, the one tick 0's pass draws from
+    int64_t slot_stride;
+    const int *hist_base;               // histogram 0
+    int *done_base;                     // "workgroups that have looked their frame up" counter of histogram 0 (null: the passes do not clear their histograms)
+    uint32_t *obs[MAX_STEP_TICKS];
+    float *pub_rewards[MAX_STEP_TICKS];
+    uint8_t *pub_done[MAX_STEP_TICKS];
+    FastArgs fa;                        // tick 0's
+};
+
+__device__ __forceinline__ FastArgs ticks_raster_args(const TicksRasterArgs &a, int t)
 {
-    int s = 0;
-#pragma unroll
-    for (int i = 1; i < MAX_UNION; ++i)
-        if (i < ua.n && (int)blockIdx.x >= ua.first[i]) s = i;
-    if (s == 0)
-        for (int j = 0; j < ua.n; ++j) fast_publish(ua.fa[j], (int)blockIdx.x);   // (first[1] = frames x split >= the frames / 256 workgroups this takes)
+    FastArgs f = a.fa;
+    const int64_t d = a.slot_stride * t;
+    f.vis_hdr += d;
+    f.vis_prims = reinterpret_cast<const Prim *>(reinterpret_cast<const unsigned char *>(f.vis_prims) + d);
+    f.vis_rects = reinterpret_cast<const short4 *>(reinterpret_cast<const unsigned char *>(f.vis_rects) + d);
+    f.list = reinterpret_cast<const int *>(reinterpret_cast<const unsigned char *>(f.list) + d);
+    f.stage_rewards = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(f.stage_rewards) + d);
+    f.stage_true = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(f.stage_true) + d);
+    f.stage_done += d;
+    const int par = (a.parity0 + t) % a.hists;
+    f.hist = a.hist_base + par * (LPT_BUCKETS * LPT_SUBS);
+    f.hist_done = a.done_base ? a.done_base + par : nullptr;
+    f.pub_rewards = a.pub_rewards[t];
+    f.pub_done = a.pub_done[t];
+    return f;
+}
+
+template <int MAXVIS, bool SHAPES, int WAVES, int NP, int NT = 256>
+__global__ __launch_bounds__(NT, WAVES) void raster_fast_batch_kernel(TicksRasterArgs a, int W, int H, int split)
+{
+    int j = 0, r = (int)blockIdx.x;
+    while (r >= a.per_tick) { r -= a.per_tick; ++j; }   // (at most k - 1 scalar iterations)
+    if (j == 0)
+        for (int t = 0; t < a.k; ++t) fast_publish(ticks_raster_args(a, t), r);   // (per_tick = frames x split >= the frames / 256 workgroups this takes)
     __shared__ __attribute__((aligned(16))) unsigned char s_buf[fast_lds_bytes(MAXVIS)];
-    FastArgs fa = ua.fa[s];
+    FastArgs fa = ticks_raster_args(a, j);
     fa.pub_n = 0;
-    raster_fast_body<MAXVIS, SHAPES, false, NP, true, NT>(fa, ua.obs[s], W, H, split, (int)blockIdx.x - ua.first[s], s_buf);
+    raster_fast_body<MAXVIS, SHAPES, false, NP, true, NT>(fa, a.obs[j], W, H, split, r, s_buf);
 }
 
 // (the long-list variant of raster_fast_batch_kernel: the k passes of one batched call of a Collect / Hex gym)
 template <int MAXVIS, bool SHAPES, int WAVES, bool HEXF, int NP>
-__global__ __launch_bounds__(256, WAVES) void raster_glist_batch_kernel(UnionRasterArgs ua, int W, int H, int split)
+__global__ __launch_bounds__(256, WAVES) void raster_glist_batch_kernel(TicksRasterArgs a, int W, int H, int split)
 {
-    int s = 0;
-#pragma unroll
-    for (int i = 1; i < MAX_UNION; ++i)
-        if (i < ua.n && (int)blockIdx.x >= ua.first[i]) s = i;
-    if (s == 0)
-        for (int j = 0; j < ua.n; ++j) fast_publish(ua.fa[j], (int)blockIdx.x);
+    int j = 0, r = (int)blockIdx.x;
+    while (r >= a.per_tick) { r -= a.per_tick; ++j; }
+    if (j == 0)
+        for (int t = 0; t < a.k; ++t) fast_publish(ticks_raster_args(a, t), r);
     __shared__ __attribute__((aligned(16))) unsigned char s_buf[glist_lds_bytes(MAXVIS)];
-    FastArgs fa = ua.fa[s];
+    FastArgs fa = ticks_raster_args(a, j);
     fa.pub_n = 0;
-    raster_glist_body<MAXVIS, SHAPES, HEXF, NP>(fa, ua.obs[s], W, H, split, (int)blockIdx.x - ua.first[s], s_buf);
+    raster_glist_body<MAXVIS, SHAPES, HEXF, NP>(fa, a.obs[j], W, H, split, r, s_buf);
 }
 
 template <int MAXVIS, bool SHAPES, int WAVES, bool HEXF, int NP>
@@ -1914,9 +1943,9 @@ struct UnionBatchArgs {
     int64_t slot_stride[MAX_UNION];
     const int *hist_base[MAX_UNION];    // histogram 0 of gym s
     int *done_base[MAX_UNION];          // "workgroups that have looked their frame up" counter of histogram 0 (null: the pass does not clear its histogram)
-    uint32_t *obs[MAX_STEP_TICKS][MAX_UNION];
-    float *pub_rewards[MAX_STEP_TICKS][MAX_UNION];
-    uint8_t *pub_done[MAX_STEP_TICKS][MAX_UNION];
+    uint32_t *obs[MAX_GROUP_TICKS][MAX_UNION];
+    float *pub_rewards[MAX_GROUP_TICKS][MAX_UNION];
+    uint8_t *pub_done[MAX_GROUP_TICKS][MAX_UNION];
     FastArgs fa[MAX_UNION];             // tick 0's
 };
 static_assert(sizeof(UnionBatchArgs) + 16 <= 4096, "UnionBatchArgs + (W, H) must fit the 4 KB kernel-argument segment");
@@ -2199,7 +2228,7 @@ int launch_raster_union(const GymView *views, uint32_t *const *obs, const Publis
 bool raster_union_batch_applicable(int k, int n, int W, int H)
 {
     static const int off = getenv("MV_RASTER_BATCH") && atoi(getenv("MV_RASTER_BATCH")) == 0;
-    return !off && W <= MAX_W && H <= MAX_H && k >= 2 && k <= MAX_STEP_TICKS && n >= 1 && n <= MAX_UNION;
+    return !off && W <= MAX_W && H <= MAX_H && k >= 2 && k <= MAX_GROUP_TICKS && n >= 1 && n <= MAX_UNION;
 }
 
 int launch_raster_union_batch(const GymView *views, uint32_t *const *obs, const PublishTo *publish, int k, int n, int W, int H, hipStream_t stream, hipEvent_t done)
@@ -2249,56 +2278,51 @@ int launch_raster_union_batch(const GymView *views, uint32_t *const *obs, const 
 
 int launch_raster_batch(const GymView *views, uint32_t *const *obs, const PublishTo *publish, int k, int W, int H, hipStream_t stream, hipEvent_t done)
 {
-    if (W > MAX_W || H > MAX_H || k < 2 || k > MAX_UNION) return 1;
+    if (W > MAX_W || H > MAX_H || k < 2 || k > MAX_STEP_TICKS) return 1;
     const GymView &gv = views[0];
     static const int off = getenv("MV_RASTER_BATCH") && atoi(getenv("MV_RASTER_BATCH")) == 0;
     if (off) return 1;
     const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)W * sizeof(float) + (size_t)H * sizeof(float2);
     const int frames = gv.num_envs * gv.num_agents;
-    const bool hexScen = gv.scenario == SCN_HEX_MEMORY || gv.scenario == SCN_HEX_EXPLORE;
-    if (gv.vis_stride > VIS_SMALL || hexScen) {   // the long-list variants (records through the scalar cache)
-        const int lnp = fast_pixels_per_lane(W, H, true, true);
-        const int lsplit = fast_split(W, H, lnp, frames * k, true, true);
-        UnionRasterArgs ua;
-        ua.n = k;
-        for (int j = 0; j < k; ++j) {
-            ua.first[j] = j * frames * lsplit;
-            ua.obs[j] = obs[j];
-            ua.fa[j] = fast_args_of(views[j], publish ? &publish[j] : nullptr);
-            self_clear(ua.fa[j], views[j], frames * lsplit);
-        }
-        for (int j = k; j <= MAX_UNION; ++j) ua.first[j] = k * frames * lsplit;
-        const dim3 grid(k * frames * lsplit), block(256);
-        if (lnp == 2) {
-            if (hexScen) launch_done(raster_glist_batch_kernel<VIS_XL, true, GLIST_WAVES_NP2, true, 2>, grid, block, dyn, stream, done, ua, W, H, lsplit);
-            else launch_done(raster_glist_batch_kernel<VIS_LARGE, false, GLIST_WAVES_NP2, false, 2>, grid, block, dyn, stream, done, ua, W, H, lsplit);
+    const bool hexScen = gv.scenario == SCN_HEX_MEMORY || gv.scenario == SCN_HEX_EXPLORE, longList = gv.vis_stride > VIS_SMALL || hexScen;
+    // (the k passes fill the chip together -- later passes' workgroups start as earlier ones end -- so the frame is cut for k x frames of them:
+    // 512 TowerBuilding frames, 8 ticks per call: 16.2 M obs/s with two workgroups per frame, 14.0 M with the four a single pass of 512 frames takes)
+    const int np = longList ? fast_pixels_per_lane(W, H, true, true) : fast_pixels_per_lane(W, H);
+    const int split = fast_split(W, H, np, frames * k, longList, true);
+    int64_t slotStride = 0;
+    if (!slot_stride_of(views, k, slotStride)) return 1;   // (views that are not one hand-over slot apart per tick: tick by tick)
+    TicksRasterArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.k = k; a.per_tick = frames * split;
+    a.hists = gv.lpt_hists; a.parity0 = gv.lpt_parity;
+    a.slot_stride = slotStride;
+    a.hist_base = gv.lpt_hist;
+    a.done_base = gv.lpt_no_clear ? gv.lpt_hist + (size_t)gv.lpt_hists * (LPT_BUCKETS * LPT_SUBS) : nullptr;
+    a.fa = fast_args_of(gv, publish ? &publish[0] : nullptr);
+    a.fa.wg_total = frames * split;
+    for (int j = 0; j < k; ++j) {
+        a.obs[j] = obs[j];
+        a.pub_rewards[j] = publish ? publish[j].rewards : nullptr;
+        a.pub_done[j] = publish ? publish[j].done : nullptr;
+    }
+    const dim3 grid(k * frames * split), block(256);
+    if (longList) {   // the long-list variants (records through the scalar cache)
+        if (np == 2) {
+            if (hexScen) launch_done(raster_glist_batch_kernel<VIS_XL, true, GLIST_WAVES_NP2, true, 2>, grid, block, dyn, stream, done, a, W, H, split);
+            else launch_done(raster_glist_batch_kernel<VIS_LARGE, false, GLIST_WAVES_NP2, false, 2>, grid, block, dyn, stream, done, a, W, H, split);
         } else {
-            if (hexScen) launch_done(raster_glist_batch_kernel<VIS_XL, true, GLIST_WAVES_NP1, true, 1>, grid, block, dyn, stream, done, ua, W, H, lsplit);
-            else launch_done(raster_glist_batch_kernel<VIS_LARGE, false, GLIST_WAVES_NP1, false, 1>, grid, block, dyn, stream, done, ua, W, H, lsplit);
+            if (hexScen) launch_done(raster_glist_batch_kernel<VIS_XL, true, GLIST_WAVES_NP1, true, 1>, grid, block, dyn, stream, done, a, W, H, split);
+            else launch_done(raster_glist_batch_kernel<VIS_LARGE, false, GLIST_WAVES_NP1, false, 1>, grid, block, dyn, stream, done, a, W, H, split);
         }
         return 0;
     }
-    const int np = fast_pixels_per_lane(W, H);
-    // (the k passes fill the chip together -- later passes' workgroups start as earlier ones end -- so the frame is cut for k x frames of them:
-    // 512 TowerBuilding frames, 8 ticks per call: 16.2 M obs/s with two workgroups per frame, 14.0 M with the four a single pass of 512 frames takes)
-    const int split = fast_split(W, H, np, frames * k, false, true);
-    UnionRasterArgs ua;
-    ua.n = k;
-    for (int j = 0; j < k; ++j) {
-        ua.first[j] = j * frames * split;
-        ua.obs[j] = obs[j];
-        ua.fa[j] = fast_args_of(views[j], publish ? &publish[j] : nullptr);
-        self_clear(ua.fa[j], views[j], frames * split);
-    }
-    for (int j = k; j <= MAX_UNION; ++j) ua.first[j] = k * frames * split;
-    const dim3 grid(k * frames * split), block(256);
     const bool shapes = gv.scenario == SCN_REARRANGE;
     if (np == 2) {
-        if (shapes) launch_done(raster_fast_batch_kernel<VIS_SMALL, true, 6, 2>, grid, block, dyn, stream, done, ua, W, H, split);
-        else launch_done(raster_fast_batch_kernel<VIS_SMALL, false, 7, 2>, grid, block, dyn, stream, done, ua, W, H, split);
+        if (shapes) launch_done(raster_fast_batch_kernel<VIS_SMALL, true, 6, 2>, grid, block, dyn, stream, done, a, W, H, split);
+        else launch_done(raster_fast_batch_kernel<VIS_SMALL, false, 7, 2>, grid, block, dyn, stream, done, a, W, H, split);
     } else {
-        if (shapes) launch_done(raster_fast_batch_kernel<VIS_SMALL, true, 8, 1>, grid, block, dyn, stream, done, ua, W, H, split);
-        else launch_done(raster_fast_batch_kernel<VIS_SMALL, false, 8, 1>, grid, block, dyn, stream, done, ua, W, H, split);
+        if (shapes) launch_done(raster_fast_batch_kernel<VIS_SMALL, true, 8, 1>, grid, block, dyn, stream, done, a, W, H, split);
+        else launch_done(raster_fast_batch_kernel<VIS_SMALL, false, 8, 1>, grid, block, dyn, stream, done, a, W, H, split);
     }
     return 0;
 }

@@ -25,6 +25,8 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 #include "mv_tick_tower.h"
 
@@ -108,7 +110,7 @@ __device__ __forceinline__ void step_ticks_body(const StepTicksArgs &a, int W, i
     __builtin_amdgcn_s_setprio(MV_STEP_PRIO);
 #endif
     for (int j = 0; j < a.n; ++j) {
-        const GymView &gv = a.gv[j];
+        const GymView &gv = a.views[j];
         if (A_MAX == 1) {
             tower_tick<A_MAX>(gv, env);
             wave_sync();   // the tick's stores before the frame setup's loads (one wave: no barrier needed)
@@ -126,12 +128,31 @@ __device__ __forceinline__ void step_ticks_body(const StepTicksArgs &a, int W, i
 __global__ __launch_bounds__(64, MV_STEP_TICKS_WAVES_PER_SIMD) void step_ticks_kernel(StepTicksArgs a, int W, int H) { step_ticks_body<1>(a, W, H); }
 __global__ __launch_bounds__(256, 3) void step_ticks_agents_kernel(StepTicksArgs a, int W, int H) { step_ticks_body<MAX_AGENTS>(a, W, H); }
 
-void launch_step_ticks(const GymView *views, int k, hipStream_t stream, int W, int H, hipEvent_t done)
+// the views of a multi-tick launch -> device memory, eight at a time as the arguments of a one-workgroup kernel (a copy from host memory would need a staging
+// buffer per call in flight: the host runs calls ahead of the device)
+struct ViewsChunk { GymView v[8]; };
+__global__ void write_views_kernel(ViewsChunk c, GymView *dst, int n)
 {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(&c);
+    uint32_t *d = reinterpret_cast<uint32_t *>(dst);
+    for (int i = (int)threadIdx.x; i < n * (int)(sizeof(GymView) / 4); i += (int)blockDim.x) d[i] = src[i];
+}
+static_assert(sizeof(GymView) % 4 == 0 && sizeof(ViewsChunk) + 16 <= 4096, "write_views_kernel");
+void upload_tick_views(const GymView *views, int k, GymView *dviews, hipStream_t stream)
+{
+    for (int first = 0; first < k; first += 8) {
+        ViewsChunk c;
+        const int n = std::min(8, k - first);
+        for (int j = 0; j < 8; ++j) c.v[j] = views[first + std::min(j, n - 1)];
+        hipLaunchKernelGGL(write_views_kernel, dim3(1), dim3(256), 0, stream, c, dviews + first, n);
+    }
+}
+
+void launch_step_ticks(const GymView *views, GymView *dviews, int k, hipStream_t stream, int W, int H, hipEvent_t done)
+{
+    upload_tick_views(views, k, dviews, stream);
     StepTicksArgs a;
-    a.n = k;
-    for (int j = 0; j < k; ++j) a.gv[j] = views[j];
-    for (int j = k; j < MAX_STEP_TICKS; ++j) a.gv[j] = views[k - 1];
+    a.n = k; a.pad = 0; a.views = dviews;
     const GymView &gv = views[0];
     // several agents: TWO waves per env (measured at 512 envs x 4 agents: one wave 20.3 M obs/s, two 21.7, four 16.1 -- four waves of ~180 VGPRs per env,
     // resident for the whole call, are what the observation passes beside them cannot have; one-launch-per-tick: 19.4)

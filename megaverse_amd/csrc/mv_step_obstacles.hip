@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 #include "mv_tick_obstacles.h"
 
@@ -62,19 +64,18 @@ __global__ __launch_bounds__(64, MV_STEP_TICKS_WAVES_PER_SIMD) void step_obstacl
     __builtin_amdgcn_s_setprio(MV_STEP_PRIO);
 #endif
     for (int j = 0; j < a.n; ++j) {
-        const GymView &gv = a.gv[j];
+        const GymView &gv = a.views[j];
         obstacles_tick<1>(gv, env);
         wave_sync();   // the tick's stores before the frame setup's loads (one wave: no barrier needed)
         frame_setup_body<64, true>(gv, env, W, H, s_fs);
     }
 }
 
-void launch_step_obstacles_ticks(const GymView *views, int k, hipStream_t stream, int W, int H)
+void launch_step_obstacles_ticks(const GymView *views, GymView *dviews, int k, hipStream_t stream, int W, int H)
 {
+    upload_tick_views(views, k, dviews, stream);
     StepTicksArgs a;
-    a.n = k;
-    for (int j = 0; j < k; ++j) a.gv[j] = views[j];
-    for (int j = k; j < MAX_STEP_TICKS; ++j) a.gv[j] = views[k - 1];
+    a.n = k; a.pad = 0; a.views = dviews;
     hipLaunchKernelGGL(step_obstacles_ticks_kernel, dim3(views[0].num_envs), dim3(64), 0, stream, a, W, H);
 }
 

@@ -4,6 +4,7 @@
 // for an env is contiguous per env (array-of-structs per kind); the raster kernel reads the same
 // arrays.  All sizes are multiples of 16 B so a wave's loads are aligned dwordx4.
 #pragma once
+#include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace mv {
@@ -117,7 +118,7 @@ struct alignas(16) AgentState {   // 128 B
 static_assert(sizeof(AgentState) == 128, "AgentState must be 128 B");
 
 // ---- cost bins of the observation pass (mv_frame.h fills them, mv_raster.hip reads them, mv_api.hip sizes them)
-constexpr int MAX_STEP_TICKS = 8;   // ticks of one multi-tick step launch (mv_step.hip: step_ticks_kernel; the views travel as kernel arguments)
+constexpr int MAX_STEP_TICKS = 16;   // ticks of one multi-tick step launch (mv_step.hip: step_ticks_kernel) = of one observation launch of a batched call
 constexpr int LPT_BUCKETS = 256;
 // Every cost bin has LPT_SUBS counters and lists, picked by frame index: the frames of a launch finish together and most of them fall into
 // the same three or four bins -- one counter per bin made their returning atomics queue up at one L2 address (measured: 1.3 us of a 7 us frame setup).
@@ -176,13 +177,51 @@ struct GymView {
     struct TowerGen *tower_gen;// [N] TowerBuilding: where each env's episode generator stands (mv_reset_device.h: tower_draw); its resident episodes are `blobs` (TowerBlob)
 };
 
-// the views of the n consecutive ticks of a multi-tick step launch (mv_step.hip: step_ticks_kernel, mv_step_obstacles.hip), the same envs in all of them
+// The n consecutive ticks of a multi-tick step launch (mv_step.hip: step_ticks_kernel, and every mv_step_*.hip), the same envs in all of them: their views, in
+// DEVICE memory (mv_gym::dViews; upload_tick_views puts them there on the launch's stream, in front of it).  The kernels read a tick's view like kernel
+// arguments -- scalar loads on demand -- without its fields living in registers across the tick.  (Until round 5 the n views travelled by value: 2.6 KB of the
+// 4 KB kernel-argument segment for 8 ticks, and no more than 8; deriving tick j's view from tick 0's in the kernel -- ten pointers one hand-over slot further
+// per tick -- cost the resident one-wave kernels 100-140 bytes of scratch per lane more and 1.5-3.5 % of the rate.)
 struct StepTicksArgs {
-    int32_t n;
-    GymView gv[MAX_STEP_TICKS];
+    int32_t n, pad;
+    const GymView *views;   // [n]
 };
-// (the views travel BY VALUE as kernel arguments: a launch whose arguments exceed the 4 KB kernarg segment fails at run time, not at build time)
-static_assert(sizeof(StepTicksArgs) + 16 <= 4096, "StepTicksArgs + (W, H) must fit the 4 KB kernel-argument segment: slim GymView down or pass the views through device memory");
+// views[0 .. k) -> dviews (device) on `stream`, ordered in front of whatever is launched there next (a kernel with up to 8 views as its arguments per launch)
+void upload_tick_views(const GymView *views, int k, GymView *dviews, hipStream_t stream);
+
+// tick j's view from tick 0's: ten buffers one hand-over slot (slot_stride bytes) further per tick (mv_api.hip carves a gym's slots out of its arena one after
+// the other), the action index, the cost histogram (consecutive, modulo their number).  Used where k x n views are too many to pass or to upload: the
+// group kernels (mv_union.h) and the observation launch of a batched call (mv_raster.hip).
+__host__ __device__ inline GymView tick_view(const GymView &base, int64_t slot_stride, int j)
+{
+    GymView v = base;
+    const int64_t d = slot_stride * j;
+    v.vis_prims = (uint8_t *)base.vis_prims + d;
+    v.vis_rects = (uint8_t *)base.vis_rects + d;
+    v.vis_count = (int32_t *)((uint8_t *)base.vis_count + d);
+    v.lpt_bucket = (int32_t *)((uint8_t *)base.lpt_bucket + d);
+    v.lpt_order = (int32_t *)((uint8_t *)base.lpt_order + d);
+    v.vis_hdr = base.vis_hdr + d;
+    v.lpt_list = (int32_t *)((uint8_t *)base.lpt_list + d);
+    v.rewards = (float *)((uint8_t *)base.rewards + d);
+    v.done = base.done + d;
+    v.true_objective = (float *)((uint8_t *)base.true_objective + d);
+    v.sample_step = base.sample_step + (uint32_t)j;
+    v.lpt_parity = (base.lpt_parity + j) % base.lpt_hists;
+    return v;
+}
+// the slot stride of k views that are one hand-over slot apart per tick (what mv_api.hip hands over); false: they are not
+inline bool slot_stride_of(const GymView *views, int k, int64_t &stride)
+{
+    stride = k > 1 ? (int64_t)((const uint8_t *)views[1].vis_prims - (const uint8_t *)views[0].vis_prims) : 0;
+    for (int j = 1; j < k; ++j) {
+        const GymView w = tick_view(views[0], stride, j);
+        if (views[j].vis_prims != w.vis_prims || views[j].vis_hdr != w.vis_hdr || views[j].lpt_list != w.lpt_list || views[j].rewards != w.rewards || views[j].done != w.done ||
+            views[j].true_objective != w.true_objective || views[j].lpt_parity != w.lpt_parity || views[j].lpt_no_clear != w.lpt_no_clear)
+            return false;
+    }
+    return true;
+}
 
 // TowerBuilding: one episode as its generator DREW it -- everything of Env::reset that consumes the env's random stream (scenario_tower_building.cpp:19-89,
 // 129-154, scenario_default.hpp:80-97) -- resident in HBM ahead of the reset that will build it (mv_reset_device.h: tower_draw fills it in a kernel of its own,

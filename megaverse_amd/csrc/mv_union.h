@@ -7,6 +7,7 @@
 namespace mv {
 
 enum : int { MAX_UNION = 8 };   // gyms per group (the reference's multi-task set has eight scenarios, megaverse_env.py:18-21)
+enum : int { MAX_GROUP_TICKS = 8 };   // ticks of one batched group call's two launches (k x n output pointers travel as kernel arguments)
 
 struct UnionStepArgs {
     int32_t n;                      // gyms
@@ -18,7 +19,7 @@ static_assert(sizeof(UnionStepArgs) + 16 <= 4096, "UnionStepArgs + (W, H, render
 
 // k consecutive ticks of every gym of a group with ONE launch (step_union_ticks_kernel): tick 0's view of every gym; tick j's differs from it in its
 // hand-over slot -- ten buffers, all `slot_stride` bytes further per tick (mv_api.hip carves a gym's slots out of its arena one after the other) --, its
-// action index and its cost histogram (consecutive, modulo their number): derived in the kernel (tick_view), not passed (k x n views do not fit the 4 KB of
+// action index and its cost histogram (consecutive, modulo their number): derived in the kernel (mv_types.h: tick_view), not passed (k x n views do not fit the 4 KB of
 // kernel arguments).
 struct UnionTicksArgs {
     int32_t n, k;
@@ -27,25 +28,6 @@ struct UnionTicksArgs {
     GymView gv[MAX_UNION];
 };
 static_assert(sizeof(UnionTicksArgs) + 16 <= 4096, "UnionTicksArgs + (W, H) must fit the 4 KB kernel-argument segment");
-
-__host__ __device__ inline GymView tick_view(const GymView &base, int64_t slot_stride, int j)
-{
-    GymView v = base;
-    const int64_t d = slot_stride * j;
-    v.vis_prims = (uint8_t *)base.vis_prims + d;
-    v.vis_rects = (uint8_t *)base.vis_rects + d;
-    v.vis_count = (int32_t *)((uint8_t *)base.vis_count + d);
-    v.lpt_bucket = (int32_t *)((uint8_t *)base.lpt_bucket + d);
-    v.lpt_order = (int32_t *)((uint8_t *)base.lpt_order + d);
-    v.vis_hdr = base.vis_hdr + d;
-    v.lpt_list = (int32_t *)((uint8_t *)base.lpt_list + d);
-    v.rewards = (float *)((uint8_t *)base.rewards + d);
-    v.done = base.done + d;
-    v.true_objective = (float *)((uint8_t *)base.true_objective + d);
-    v.sample_step = base.sample_step + (uint32_t)j;
-    v.lpt_parity = (base.lpt_parity + j) % base.lpt_hists;
-    return v;
-}
 
 void launch_step_union_ticks(const UnionTicksArgs &ua, hipStream_t stream, int W, int H);   // (one agent per env)
 

@@ -427,12 +427,12 @@ def test_overlapped_passes_fill_the_ring_like_single_ticks(hip, monkeypatch, sce
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("k,R,rings", [(16, 16, True), (16, 32, True), (8, 16, True), (8, 16, False), (12, 32, True)])
+@pytest.mark.parametrize("k,R,rings", [(16, 16, True), (16, 32, True), (8, 16, True), (8, 16, False), (12, 32, True), (24, 32, True), (24, 48, True)])
 def test_overlapped_passes_with_a_late_consumer(hip, k, R, rings):
     """The ring contract of mv_set_pass_overlap under load: the consumer of a call's entries is ENQUEUED right after the call, as the
     header asks, but still pending -- behind a slow kernel on the caller's stream -- when the next calls are issued; no host synchronisation between
-    calls.  k = 16 runs as two chunks of the internal batch (8): with a ring of 16 the library must decline to overlap (the ring is one CALL deep),
-    with 32 it may; without rewards / dones rings it must decline, too (two passes in flight would both publish the single arrays).  What every
+    calls.  k = 24 runs as two chunks (the internal batch is 16): with a ring of 32 the library must decline to overlap (the ring is not two CALLS deep),
+    with 48 it may; k = 16 with a ring of 16 must decline, with 32 it may; without rewards / dones rings it must decline, too (two passes in flight would both publish the single arrays).  What every
     consumer copied must be what single ticks produce."""
     import torch
     N, A, W, H = 96, 1, 64, 64
