@@ -327,7 +327,7 @@ def main():
                          "512 envs 20.1 / 20.9; Rearrange 19.4 / 19.5; r07j: Sokoban 23.4 / 19.6, Collect 14.0 / 14.3, HexMemory 9.15 / 9.10)")
     ap.add_argument("--batch", type=int, default=0,
                     help="ticks per stepping call (mv_step_n): every tick is stepped and rendered in full, the two stream hand-overs are paid once "
-                         "per call; 1 = one mv_step per tick; 0 (default) = 16, the first calls after a synchronisation 2, 4 and 6 ticks (the observation "
+                         "per call; 1 = one mv_step per tick; 0 (default) = 16 (8 where a call's 16 observation slabs would exceed ~1 GB), the first calls after a synchronisation 2, 4 and 6 ticks (the observation "
                          "passes of a call start when its ticks are stepped: short first calls fill the pipeline sooner; 20-step runs: 20.0-20.25 M obs/s "
                          "against 19.0 M with 2 ticks per call throughout).  N>1 with the gather on always steps tick by tick")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the single-step / unpipelined / closed-loop transparency legs")
@@ -373,7 +373,10 @@ def main():
     n_env, A = args.envs_per_gpu, args.agents
     mixed = args.scenario.lower() in ("mixed", "mixed4")
     frames = n_env * A
-    batch = args.batch if args.batch > 0 else 16
+    # ticks per stepping call: 16 -- one tail of the observation launch per 16 ticks (TowerBuilding 1024 envs: 28.4 M obs/s against 26.6 M with 8) -- where the
+    # call's ring of observation slabs stays within ~1 GB; beyond that 8 (measured, 16 against 8: 4096 envs 28.4 / 30.5 M, 512 envs x 4 agents 19.5 / 26.0 M:
+    # the working set of a call's pixel stores outgrows what the address translation reaches)
+    batch = args.batch if args.batch > 0 else (16 if frames * W * H * 4 * 16 <= 1.25e9 and not mixed else 8)
     os.environ.setdefault("MV_PIPE_BATCH", str(max(8, min(16, batch))))
     batch = min(batch, int(os.environ["MV_PIPE_BATCH"]))
     if dry:

@@ -101,8 +101,8 @@ __global__ __launch_bounds__(256) void step_kernel(GymView gv, int W, int H, int
 #ifndef MV_STEP_TICKS_WAVES_PER_SIMD
 #define MV_STEP_TICKS_WAVES_PER_SIMD 4
 #endif
-template <int A_MAX>
-__device__ __forceinline__ void step_ticks_body(const StepTicksArgs &a, int W, int H)
+template <int A_MAX, class Args>
+__device__ __forceinline__ void step_ticks_body(const Args &a, int W, int H)
 {
     __shared__ FrameScratch s_fs[A_MAX == 1 ? 1 : 4];
     const int env = blockIdx.x;
@@ -110,7 +110,7 @@ __device__ __forceinline__ void step_ticks_body(const StepTicksArgs &a, int W, i
     __builtin_amdgcn_s_setprio(MV_STEP_PRIO);
 #endif
     for (int j = 0; j < a.n; ++j) {
-        const GymView &gv = a.views[j];
+        const GymView &gv = a.view(j);
         if (A_MAX == 1) {
             tower_tick<A_MAX>(gv, env);
             wave_sync();   // the tick's stores before the frame setup's loads (one wave: no barrier needed)
@@ -125,8 +125,8 @@ __device__ __forceinline__ void step_ticks_body(const StepTicksArgs &a, int W, i
     }
 }
 // (two kernels, not one template: a launch bound that depends on a template parameter is not applied)
-__global__ __launch_bounds__(64, MV_STEP_TICKS_WAVES_PER_SIMD) void step_ticks_kernel(StepTicksArgs a, int W, int H) { step_ticks_body<1>(a, W, H); }
-__global__ __launch_bounds__(256, 3) void step_ticks_agents_kernel(StepTicksArgs a, int W, int H) { step_ticks_body<MAX_AGENTS>(a, W, H); }
+template <class Args> __global__ __launch_bounds__(64, MV_STEP_TICKS_WAVES_PER_SIMD) void step_ticks_kernel(Args a, int W, int H) { step_ticks_body<1>(a, W, H); }
+template <class Args> __global__ __launch_bounds__(256, 3) void step_ticks_agents_kernel(Args a, int W, int H) { step_ticks_body<MAX_AGENTS>(a, W, H); }
 
 // the views of a multi-tick launch -> device memory, eight at a time as the arguments of a one-workgroup kernel (a copy from host memory would need a staging
 // buffer per call in flight: the host runs calls ahead of the device)
@@ -150,15 +150,23 @@ void upload_tick_views(const GymView *views, int k, GymView *dviews, hipStream_t
 
 void launch_step_ticks(const GymView *views, GymView *dviews, int k, hipStream_t stream, int W, int H, hipEvent_t done)
 {
-    upload_tick_views(views, k, dviews, stream);
-    StepTicksArgs a;
-    a.n = k; a.pad = 0; a.views = dviews;
     const GymView &gv = views[0];
     // several agents: TWO waves per env (measured at 512 envs x 4 agents: one wave 20.3 M obs/s, two 21.7, four 16.1 -- four waves of ~180 VGPRs per env,
     // resident for the whole call, are what the observation passes beside them cannot have; one-launch-per-tick: 19.4)
     const dim3 grid(gv.num_envs), block(gv.num_agents == 1 ? 64 : 64 * std::min(gv.num_agents, 2));
-    if (gv.num_agents == 1) hipExtLaunchKernelGGL(step_ticks_kernel, grid, block, 0, stream, nullptr, done, 0, a, W, H);
-    else hipExtLaunchKernelGGL(step_ticks_agents_kernel, grid, block, 0, stream, nullptr, done, 0, a, W, H);
+    if (k <= 8) {   // the views as the launch's arguments
+        StepTicksArgs8 a;
+        a.n = k; a.pad = 0;
+        for (int j = 0; j < 8; ++j) a.gv[j] = views[std::min(j, k - 1)];
+        if (gv.num_agents == 1) hipExtLaunchKernelGGL(step_ticks_kernel<StepTicksArgs8>, grid, block, 0, stream, nullptr, done, 0, a, W, H);
+        else hipExtLaunchKernelGGL(step_ticks_agents_kernel<StepTicksArgs8>, grid, block, 0, stream, nullptr, done, 0, a, W, H);
+        return;
+    }
+    upload_tick_views(views, k, dviews, stream);
+    StepTicksArgs a;
+    a.n = k; a.pad = 0; a.views = dviews;
+    if (gv.num_agents == 1) hipExtLaunchKernelGGL(step_ticks_kernel<StepTicksArgs>, grid, block, 0, stream, nullptr, done, 0, a, W, H);
+    else hipExtLaunchKernelGGL(step_ticks_agents_kernel<StepTicksArgs>, grid, block, 0, stream, nullptr, done, 0, a, W, H);
 }
 
 // done: an event that completes with the launch, carried by its dispatch packet (cf. mv_raster.h)

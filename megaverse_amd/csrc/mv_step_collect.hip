@@ -66,13 +66,14 @@ __global__ __launch_bounds__(64) void reset_collect_kernel(GymView gv, const Col
 #ifndef MV_STEP_TICKS_WAVES_PER_SIMD
 #define MV_STEP_TICKS_WAVES_PER_SIMD 4   // (the register budget of the resident multi-tick waves: mv_step.hip)
 #endif
-__global__ __launch_bounds__(64, MV_STEP_TICKS_WAVES_PER_SIMD) void step_collect_ticks_kernel(StepTicksArgs a, int W, int H)
+template <class Args>
+__global__ __launch_bounds__(64, MV_STEP_TICKS_WAVES_PER_SIMD) void step_collect_ticks_kernel(Args a, int W, int H)
 {
     __shared__ FrameScratch s_fs;
     __shared__ DepthSortScratch s_ds;
     const int env = blockIdx.x;
     for (int j = 0; j < a.n; ++j) {
-        const GymView &gv = a.views[j];
+        const GymView &gv = a.view(j);
         collect_tick<1>(gv, env);
         wave_sync();   // the tick's stores before the frame setup's loads (one wave: no barrier needed)
         frame_setup_body<64, true>(gv, env, W, H, s_fs, &s_ds);
@@ -81,10 +82,17 @@ __global__ __launch_bounds__(64, MV_STEP_TICKS_WAVES_PER_SIMD) void step_collect
 
 void launch_step_collect_ticks(const GymView *views, GymView *dviews, int k, hipStream_t stream, int W, int H)
 {
+    if (k <= 8) {   // the views as the launch's arguments (mv_types.h: StepTicksArgs8)
+        StepTicksArgs8 a8;
+        a8.n = k; a8.pad = 0;
+        for (int j = 0; j < 8; ++j) a8.gv[j] = views[std::min(j, k - 1)];
+        hipLaunchKernelGGL(step_collect_ticks_kernel<StepTicksArgs8>, dim3(views[0].num_envs), dim3(64), 0, stream, a8, W, H);
+        return;
+    }
     upload_tick_views(views, k, dviews, stream);
     StepTicksArgs a;
     a.n = k; a.pad = 0; a.views = dviews;
-    hipLaunchKernelGGL(step_collect_ticks_kernel, dim3(views[0].num_envs), dim3(64), 0, stream, a, W, H);
+    hipLaunchKernelGGL(step_collect_ticks_kernel<StepTicksArgs>, dim3(views[0].num_envs), dim3(64), 0, stream, a, W, H);
 }
 
 void launch_step_collect(const GymView &gv, hipStream_t stream, int W, int H, int render)
