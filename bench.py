@@ -373,10 +373,11 @@ def main():
     n_env, A = args.envs_per_gpu, args.agents
     mixed = args.scenario.lower() in ("mixed", "mixed4")
     frames = n_env * A
-    # ticks per stepping call: 16 -- one tail of the observation launch per 16 ticks (TowerBuilding 1024 envs: 28.4 M obs/s against 26.6 M with 8) -- where the
-    # call's ring of observation slabs stays within ~1 GB; beyond that 8 (measured, 16 against 8: 4096 envs 28.4 / 30.5 M, 512 envs x 4 agents 19.5 / 26.0 M:
-    # the working set of a call's pixel stores outgrows what the address translation reaches)
-    batch = args.batch if args.batch > 0 else (16 if frames * W * H * 4 * 16 <= 1.25e9 and not mixed else 8)
+    # ticks per stepping call: 16 -- one tail of the observation launch per 16 ticks -- where the observation passes are what a call waits for, 8 where the
+    # step launch is (it grows per tick with the call's length).  Measured, 16 against 8 (M obs/s, `profiles/r08y_*`, `r08p`): TowerBuilding 1024 envs 28.5 / 26.8,
+    # ObstaclesHard 1024 24.5 / 22.7, Rearrange 23.7 / 21.5, Collect 15.0 / 14.5; 512 envs 16.2 / 19.3, ObstaclesHard 512 13.2 / 18.8, Sokoban 19.9 / 25.9,
+    # 512 envs x 4 agents 19.5 / 26.0, 4096 envs 28.4 / 30.5.  Hence: 1024 ... 2047 frames, not Sokoban.
+    batch = args.batch if args.batch > 0 else (16 if 1024 <= frames < 2048 and not mixed and args.scenario.lower() != "sokoban" else 8)
     os.environ.setdefault("MV_PIPE_BATCH", str(max(8, min(16, batch))))
     batch = min(batch, int(os.environ["MV_PIPE_BATCH"]))
     if dry:

@@ -151,14 +151,13 @@ int tower_draw_before(mv_gym *g, hipStream_t sim)
     return 0;
 }
 // ... and behind them, every drawPeriod ticks, the draw kernel goes to its own stream: it tops up the rings of the envs that finished
-int tower_draw_after(mv_gym *g, hipStream_t sim, int ticks)
+int tower_draw_after(mv_gym *g, hipEvent_t after, int ticks)
 {
     if (!g->genStream) return 0;
     g->ticksSinceDraw += ticks;
     if (g->ticksSinceDraw < g->drawPeriod) return 0;
     g->ticksSinceDraw = 0;
-    HIP_TRY(hipEventRecord(g->stepForDraw, sim));
-    HIP_TRY(hipStreamWaitEvent(g->genStream, g->stepForDraw, 0));
+    HIP_TRY(hipStreamWaitEvent(g->genStream, after, 0));
     launch_tower_draw(g->gv, g->genStream);
     HIP_TRY(hipEventRecord(g->drawDone[(size_t)(g->drawCount & 1ull)], g->genStream));
     ++g->drawCount;
@@ -247,7 +246,16 @@ static int usable_host_cores()
 }
 
 // the simulation stream (another queue priority than the caller's was measured, low and high: no gain, r06k)
-static hipError_t create_sim_stream(hipStream_t *s) { return hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
+static hipError_t create_sim_stream(hipStream_t *s)
+{
+    static const char *prio = getenv("MV_X_SIM_PRIORITY");   // (experiment r08r)
+    if (prio && !std::strcmp(prio, "high")) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        return hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi);
+    }
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
 
 extern "C" {
 
@@ -429,7 +437,6 @@ int mv_create(const mv_config *cfg, mv_gym **out)
                   hipEventCreateWithFlags(&g->userMark[2], hipEventDisableTiming) == hipSuccess &&
                   hipEventCreateWithFlags(&g->userNow, hipEventDisableTiming) == hipSuccess &&
                   hipEventCreateWithFlags(&g->simDone, hipEventDisableTiming) == hipSuccess &&
-                  hipEventCreateWithFlags(&g->resetDone, hipEventDisableTiming) == hipSuccess &&
                   hipEventCreateWithFlags(&g->stepDone, hipEventDisableTiming) == hipSuccess &&
                   hipEventCreateWithFlags(&g->statusCopied, hipEventDisableTiming) == hipSuccess;
         if (!ok) {
@@ -451,7 +458,6 @@ int mv_create(const mv_config *cfg, mv_gym **out)
         std::random_device rdev;
         for (auto &t : tg) { t.seed = (uint32_t)rdev(); t.seed_is_env_seed = 1; t.generated = 0; t.pad = 0; }
         bool ok = hipMemcpy(gv.tower_gen, tg.data(), N * sizeof(TowerGen), hipMemcpyHostToDevice) == hipSuccess &&
-                  hipEventCreateWithFlags(&g->stepForDraw, hipEventDisableTiming) == hipSuccess &&
                   hipEventCreateWithFlags(&g->drawDone[0], hipEventDisableTiming) == hipSuccess &&
                   hipEventCreateWithFlags(&g->drawDone[1], hipEventDisableTiming) == hipSuccess;
         if (!ok) {
@@ -599,7 +605,6 @@ int mv_close(mv_gym *g)
     if (g->hiresObs) (void)hipFree(g->hiresObs);
     if (g->hBlobs) (void)hipHostFree(g->hBlobs);
     if (g->hStatus) (void)hipHostFree(g->hStatus);
-    if (g->resetDone) (void)hipEventDestroy(g->resetDone);
     if (g->stepDone) (void)hipEventDestroy(g->stepDone);
     if (g->statusCopied) (void)hipEventDestroy(g->statusCopied);
     for (hipEvent_t e : g->uploadEvents) if (e) (void)hipEventDestroy(e);
@@ -609,9 +614,8 @@ int mv_close(mv_gym *g)
         if (g->callStart[i]) (void)hipEventDestroy(g->callStart[i]);
         g->passStream[i] = nullptr; g->callStart[i] = nullptr;
     }
-    if (g->stepForDraw) (void)hipEventDestroy(g->stepForDraw);
     for (hipEvent_t &e : g->drawDone) { if (e) (void)hipEventDestroy(e); e = nullptr; }
-    g->genStream = nullptr; g->stepForDraw = nullptr;
+    g->genStream = nullptr;
     if (g->copyStream) (void)hipStreamDestroy(g->copyStream);
     if (g->simStream) (void)hipStreamDestroy(g->simStream);
     for (hipEvent_t &e : g->userMark) { if (e) (void)hipEventDestroy(e); e = nullptr; }
@@ -619,7 +623,7 @@ int mv_close(mv_gym *g)
     g->userNow = nullptr;
     if (g->simDone) (void)hipEventDestroy(g->simDone);
     g->simStream = nullptr; g->simDone = nullptr;
-    g->hBlobs = nullptr; g->hStatus = nullptr; g->resetDone = g->stepDone = g->statusCopied = nullptr; g->copyStream = nullptr; g->dBlobs = nullptr; g->dStatus = nullptr;
+    g->hBlobs = nullptr; g->hStatus = nullptr; g->stepDone = g->statusCopied = nullptr; g->lastStep = nullptr; g->copyStream = nullptr; g->dBlobs = nullptr; g->dStatus = nullptr;
     g->arena = nullptr;
     for (int b = 0; b < 2; ++b) {
         if (g->hActions[b]) (void)hipHostFree(g->hActions[b]);
@@ -822,6 +826,20 @@ int refill_episodes(mv_gym *g)
         batch.clear();
         int deficit = 0;
         bool waited = false;
+        // Consecutive envs whose next episode goes to the same ring slot travel as ONE strided copy (rows: the pinned slots, blobBytes apart, to the ring slots,
+        // spares x blobBytes apart).  Scenarios whose episodes all last the same -- Empty, Rearrange, Sokoban, Hex*: every env of the batch finishes on the very
+        // same tick -- used to pay a thousand hipMemcpyAsync calls, ~5 ms of host time, at every such tick.
+        int runFirst = -1, runLen = 0, runSlot = 0;
+        size_t runBytes = 0;
+        auto flush_run = [&]() -> int {
+            if (runLen <= 0) return 0;
+            uint8_t *dst = g->dBlobs + ((size_t)runFirst * K + (size_t)runSlot) * g->blobBytes;
+            const uint8_t *src = g->hBlobs + (size_t)runFirst * g->blobBytes;
+            if (runLen == 1) HIP_TRY(hipMemcpyAsync(dst, src, runBytes, hipMemcpyHostToDevice, g->copyStream));
+            else HIP_TRY(hipMemcpy2DAsync(dst, (size_t)K * g->blobBytes, src, g->blobBytes, runBytes, (size_t)runLen, hipMemcpyHostToDevice, g->copyStream));
+            runLen = 0;
+            return 0;
+        };
         for (int i = 0; i < N; ++i) {
             const int consumed = g->hStatus[i];
             if (g->uploaded[i] >= consumed + K) continue;            // ring full
@@ -832,12 +850,18 @@ int refill_episodes(mv_gym *g)
             const uint8_t *src = g->feeder->wait_ready(i, need, &bytes);
             if (!src) return fail(g->feeder->failed() ? std::string("episode feeder: a level file could not be read (Sokoban)")
                                                       : "episode feeder: episode " + std::to_string(need) + " of env " + std::to_string(i) + " was never generated");
-            if (!waited && g->stepDoneValid) { HIP_TRY(hipStreamWaitEvent(g->copyStream, g->stepDone, 0)); waited = true; }
-            HIP_TRY(hipMemcpyAsync(g->dBlobs + ((size_t)i * K + (size_t)((need - 1) % K)) * g->blobBytes, src, bytes, hipMemcpyHostToDevice, g->copyStream));
+            if (!waited && g->lastStep) { HIP_TRY(hipStreamWaitEvent(g->copyStream, g->lastStep, 0)); waited = true; }
+            const int slot = (need - 1) % K;
+            if (runLen > 0 && (i != runFirst + runLen || slot != runSlot) && flush_run()) return -1;
+            if (runLen == 0) { runFirst = i; runSlot = slot; runBytes = 0; }
+            ++runLen;
+            runBytes = std::max(runBytes, bytes);   // (the used prefix of the longest record of the run: what lies behind a shorter one's is never read)
+            (void)src;
             ++g->uploaded[i];
             deficit += consumed + K - g->uploaded[i];
             batch.push_back(i);
         }
+        if (flush_run()) return -1;
         if (!batch.empty()) {
             HIP_TRY(hipEventRecord(ev, g->copyStream));
             for (int i : batch) g->feeder->recycle(i, ev);   // regenerate a slot only once its upload has left it
@@ -853,10 +877,9 @@ int refill_episodes(mv_gym *g)
 }
 
 // after a step / reset kernel: read the status words back without touching the step path
-int read_back_status(mv_gym *g, hipStream_t after)
+int read_back_status(mv_gym *g, hipEvent_t after)
 {
-    HIP_TRY(hipEventRecord(g->resetDone, after));
-    HIP_TRY(hipStreamWaitEvent(g->copyStream, g->resetDone, 0));
+    HIP_TRY(hipStreamWaitEvent(g->copyStream, after, 0));
     HIP_TRY(hipMemcpyAsync(g->hStatus, g->dStatus, (size_t)(g->N + 2) * sizeof(int), hipMemcpyDeviceToHost, g->copyStream));
     HIP_TRY(hipEventRecord(g->statusCopied, g->copyStream));
     g->statusPending = true;
@@ -909,8 +932,8 @@ int mv_reset(mv_gym *g)
         else if (g->scenario == SCN_HEX_MEMORY || g->scenario == SCN_HEX_EXPLORE) launch_reset_hex(v, (const HexBlob *)g->dBlobs, g->dStatus, 1, g->stream);
         else launch_reset_collect(v, (const CollectBlob *)g->dBlobs, g->dStatus, 1, g->stream);
         HIP_TRY(hipEventRecord(g->stepDone, g->stream));   // (the reset kernel reads the ring too)
-        g->stepDoneValid = true;
-        if (read_back_status(g, g->stream)) return -1;  // the second resident episodes go up with the next steps
+        g->lastStep = g->stepDone;
+        if (read_back_status(g, g->stepDone)) return -1;  // the second resident episodes go up with the next steps
     } else {   // TowerBuilding: every ring topped up, every env takes its next episode, the rings topped up again
         if (tower_join(g)) return -1;
         const OutPtrs outs = last_outputs(g);

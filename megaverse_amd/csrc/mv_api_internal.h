@@ -37,11 +37,11 @@ void launch_tower_seed(const GymView &gv, const uint32_t *seeds, hipStream_t str
 void launch_step(const GymView &gv, hipStream_t stream, int W, int H, int render, hipEvent_t done = nullptr);
 void launch_step_ticks(const GymView *views, GymView *dviews, int k, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);   // k ticks + frame setups of every env, one launch (mv_step.hip)
 void launch_step_obstacles(const GymView &gv, hipStream_t stream, int W, int H, int render);
-void launch_step_obstacles_ticks(const GymView *views, GymView *dviews, int k, hipStream_t stream, int W, int H);   // k ticks + frame setups of every env (one agent), one launch
-void launch_step_rearrange_ticks(const GymView *views, GymView *dviews, int k, hipStream_t stream, int W, int H);
-void launch_step_sokoban_ticks(const GymView *views, GymView *dviews, int k, hipStream_t stream, int W, int H);
-void launch_step_collect_ticks(const GymView *views, GymView *dviews, int k, hipStream_t stream, int W, int H);
-void launch_step_hex_ticks(const GymView *views, GymView *dviews, int k, hipStream_t stream, int W, int H);
+void launch_step_obstacles_ticks(const GymView *views, GymView *dviews, int k, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);   // k ticks + frame setups of every env (one agent), one launch
+void launch_step_rearrange_ticks(const GymView *views, GymView *dviews, int k, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);
+void launch_step_sokoban_ticks(const GymView *views, GymView *dviews, int k, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);
+void launch_step_collect_ticks(const GymView *views, GymView *dviews, int k, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);
+void launch_step_hex_ticks(const GymView *views, GymView *dviews, int k, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);
 void launch_reset_obstacles(const GymView &gv, const EpisodeBlob *blobs, int *status, int force_all, hipStream_t stream);
 void launch_step_rearrange(const GymView &gv, hipStream_t stream, int W, int H, int render);
 void launch_reset_rearrange(const GymView &gv, const RearrangeBlob *blobs, int *status, int force_all, hipStream_t stream);
@@ -130,7 +130,7 @@ struct mv_gym {
     std::string warning;                         // soft conditions (capacity flags) of the last call: returned as 1, not as an error
     // mv_group: the gyms of a group share the leader's simulation stream and events; a member keeps its own handles here until it leaves
     mv_group *inGroup = nullptr;
-    hipStream_t ownSimStream = nullptr;
+    hipStream_t ownSimStream = nullptr, ownCopyStream = nullptr;
     hipEvent_t ownUserMark[PIPE_GROUPS] = {}, ownSimDone = nullptr, ownStepDone = nullptr;
     uint8_t *arena = nullptr;
     uint32_t *obs = nullptr, *ownedObs = nullptr, *hiresObs = nullptr;
@@ -164,7 +164,7 @@ struct mv_gym {
     // (two episodes are resident per env: what the last launch is still drawing is not needed yet).  drawPeriod: ticks between draw launches -- 8 where
     // episodes last at least 64 ticks, every call where they can be a few ticks long (those calls are one tick each: mv_step_n).
     hipStream_t genStream = nullptr;
-    hipEvent_t stepForDraw = nullptr, drawDone[2] = {nullptr, nullptr};
+    hipEvent_t drawDone[2] = {nullptr, nullptr};
     unsigned long long drawCount = 0;
     int ticksSinceDraw = 0, drawPeriod = 1;
     int *dStatus = nullptr, *hStatus = nullptr;     // [N + 2]: consumed per env, total, error flags (device, pinned mirror)
@@ -177,8 +177,8 @@ struct mv_gym {
     int deficit = 0;                                // spares still to be uploaded (their episodes were not generated yet at the last look)
     hipEvent_t stepDone = nullptr;                  // after the last step kernel: uploads never overlap a kernel that may read the ring
     hipStream_t copyStream = nullptr;               // status read-back + episode uploads, off the step path
-    hipEvent_t resetDone = nullptr, statusCopied = nullptr;
-    bool stepDoneValid = false;
+    hipEvent_t statusCopied = nullptr;
+    hipEvent_t lastStep = nullptr;                  // the event behind the last kernel that may read the ring (a step launch's simDone / stepDone, mv_reset's stepDone)
     std::vector<hipEvent_t> uploadEvents;           // ring, one per upload batch
     hipEvent_t lastUpload = nullptr;                // the most recent batch (mv_reset: the caller's stream waits for it too)
     bool uploadNotOnUser = false;                   // ... and a step that runs on the caller's stream has not waited for it yet
@@ -204,13 +204,13 @@ GymView view(const mv_gym *g, int q, const OutPtrs *direct = nullptr);   // dire
 int sim_join(mv_gym *g);
 int tower_join(mv_gym *g);
 int tower_draw_before(mv_gym *g, hipStream_t sim);
-int tower_draw_after(mv_gym *g, hipStream_t sim, int ticks);
+int tower_draw_after(mv_gym *g, hipEvent_t after, int ticks);
 int publish_outputs(mv_gym *g, int q, const OutPtrs &o);   // on the caller's stream
 bool scenario_from_name(const std::string &scen, int &scenario, ObstacleConfig &oc);
 int check_status_flags(mv_gym *g);
 int finish_with_warning(mv_gym *g);
 int refill_episodes(mv_gym *g);
-int read_back_status(mv_gym *g, hipStream_t after);
+int read_back_status(mv_gym *g, hipEvent_t after);   // after: an event recorded behind the kernel whose status words are wanted
 int flush_device_actions(mv_gym *g);
 void group_detach(mv_gym *g);   // (mv_api_step.hip)
 }  // namespace mvapi

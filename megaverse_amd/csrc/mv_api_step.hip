@@ -150,14 +150,15 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
                 // kernels in front of every step launch, the second one waiting 30 us for a wave slot beside the observation passes: the chain
                 // of step launches is what bounds a batched call's rate at 1024 envs, 344 + 39 us per call against 288 us of passes.)
                 if (callEv) HIP_TRY(hipEventRecord(callEv[0], sim));
-                if (obstFamily) launch_step_obstacles_ticks(views.data(), L->dViews, k, sim, L->w, L->h);
-                else if (L->scenario == SCN_REARRANGE) launch_step_rearrange_ticks(views.data(), L->dViews, k, sim, L->w, L->h);
-                else if (L->scenario == SCN_SOKOBAN) launch_step_sokoban_ticks(views.data(), L->dViews, k, sim, L->w, L->h);
-                else if (L->scenario == SCN_COLLECT) launch_step_collect_ticks(views.data(), L->dViews, k, sim, L->w, L->h);
-                else if (L->scenario == SCN_HEX_MEMORY || L->scenario == SCN_HEX_EXPLORE) launch_step_hex_ticks(views.data(), L->dViews, k, sim, L->w, L->h);
-                else launch_step_ticks(views.data(), L->dViews, k, sim, L->w, L->h, own && !callEv ? L->simDone : nullptr);
+                hipEvent_t rides = own && !callEv ? L->simDone : nullptr;   // (completed by the launch's own dispatch packet: no marker behind it on the simulation stream)
+                if (obstFamily) launch_step_obstacles_ticks(views.data(), L->dViews, k, sim, L->w, L->h, rides);
+                else if (L->scenario == SCN_REARRANGE) launch_step_rearrange_ticks(views.data(), L->dViews, k, sim, L->w, L->h, rides);
+                else if (L->scenario == SCN_SOKOBAN) launch_step_sokoban_ticks(views.data(), L->dViews, k, sim, L->w, L->h, rides);
+                else if (L->scenario == SCN_COLLECT) launch_step_collect_ticks(views.data(), L->dViews, k, sim, L->w, L->h, rides);
+                else if (L->scenario == SCN_HEX_MEMORY || L->scenario == SCN_HEX_EXPLORE) launch_step_hex_ticks(views.data(), L->dViews, k, sim, L->w, L->h, rides);
+                else launch_step_ticks(views.data(), L->dViews, k, sim, L->w, L->h, rides);
                 if (callEv) HIP_TRY(hipEventRecord(callEv[1], sim));
-                simDoneRides = own && !callEv && L->scenario == SCN_TOWER;
+                simDoneRides = rides != nullptr;
             }
         } else if (n == 1) simDoneRides = launch_step_of(L, views[(size_t)j * n], sim, fused, own && j == k - 1 && !evs[j] ? L->simDone : nullptr);
         else if (groupBatch) {
@@ -171,7 +172,8 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
                 }
                 for (int i = n; i <= MAX_UNION; ++i) ta.first[i] = envs;
                 for (int i = n; i < MAX_UNION; ++i) { ta.gv[i] = views[0]; ta.slot_stride[i] = 0; }
-                launch_step_union_ticks(ta, sim, L->w, L->h);
+                launch_step_union_ticks(ta, sim, L->w, L->h, own ? L->simDone : nullptr);
+                simDoneRides = own;
             }
         } else {
             for (int i = n; i <= MAX_UNION; ++i) ua.first[i] = envs;
@@ -180,22 +182,28 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
         if (evs[j]) HIP_TRY(hipEventRecord(evs[j][1], sim));
         simDoneRodeAlong = simDoneRodeAlong || simDoneRides;
     }
-    if (own && !simDoneRodeAlong) HIP_TRY(hipEventRecord(L->simDone, sim));   // (not pipelined: stream order does it)
+    // ONE event behind the call's step launches -- simDone (pipelined: often completed by the last launch's own dispatch packet), else stepDone -- is what
+    // the caller's stream, the episode draws / uploads and the status read-backs wait for.  (There used to be up to 2 + n event records here -- simDone,
+    // stepDone, TowerBuilding's stepForDraw, a resetDone per member whose status was due; every one is a marker packet the simulation queue works off before
+    // it reaches the NEXT call's step launch, while that call's observation launch -- one wait on the caller's queue -- was already taking the chip: a step
+    // launch that starts behind the observation launch it runs beside waits for that launch's workgroups to drain, r08q timeline.)
+    hipEvent_t after = L->simDone;
+    if (own) { if (!simDoneRodeAlong) HIP_TRY(hipEventRecord(L->simDone, sim)); }
+    else { HIP_TRY(hipEventRecord(L->stepDone, sim)); after = L->stepDone; }   // (not pipelined: the caller's stream needs no event, the side streams do)
     for (int i = 0; i < n; ++i)
-        if (tower_draw_after(gs[i], sim, k)) return -1;
+        if (tower_draw_after(gs[i], after, k)) return -1;
     // (every step kernel regenerates / swaps the next episode into the envs it finishes)
     // An env needs a fresh resident episode only at its NEXT reset, normally hundreds of steps away, and two are resident: the status
-    // words are read back -- and the refill considered -- every statusPeriod-th step (16; 1 when episodes can be a few ticks long).
-    if (anyHostEpisodes) HIP_TRY(hipEventRecord(L->stepDone, sim));   // (the gyms of a group share the leader's event)
+    // words are read back -- and the refill considered -- every statusPeriod-th step (16 ... 64; 1 when episodes can be a few ticks long).
     for (int i = 0; i < n; ++i) {
         mv_gym *g = gs[i];
         g->samplePending = false;
         g->mdActions = nullptr;
         if (own) g->simDoneValid = true;
-        if (anyHostEpisodes) g->stepDoneValid = true;
+        g->lastStep = after;   // (uploads never overlap a kernel that may read the ring: refill_episodes)
         g->stepsSinceStatus += k;
-        if (g->stepsSinceStatus >= g->statusPeriod) {   // (TowerBuilding regenerates finished envs in the kernel: only the error flags matter)
-            if (read_back_status(g, sim)) return -1;
+        if (g->stepsSinceStatus >= g->statusPeriod) {   // (TowerBuilding: the error flags and the episodes consumed, for the draw launches)
+            if (read_back_status(g, after)) return -1;
             g->stepsSinceStatus = 0;
         }
         g->mirrorsFresh = false;
@@ -349,9 +357,14 @@ void mvapi::group_detach(mv_gym *g)
         if (m != grp->gyms[0]) {
             m->simStream = m->ownSimStream; m->simDone = m->ownSimDone; m->stepDone = m->ownStepDone;
             for (int q = 0; q < PIPE_GROUPS; ++q) m->userMark[q] = m->ownUserMark[q];
+            if (m->ownCopyStream) {
+                (void)hipStreamSynchronize(m->copyStream);   // (the leader's: this member's uploads and read-backs are on it)
+                if (m->genStream) m->genStream = m->ownCopyStream;
+                m->copyStream = m->ownCopyStream; m->ownCopyStream = nullptr;
+            }
         }
         m->inGroup = nullptr;
-        m->simMustWaitUser = true; m->simOnOwnStream = false; m->simDoneValid = false; m->stepDoneValid = false; m->markCount = 0;
+        m->simMustWaitUser = true; m->simOnOwnStream = false; m->simDoneValid = false; m->lastStep = nullptr; m->markCount = 0;
     }
     grp->gyms.clear();   // (the handle stays valid until mv_group_destroy; stepping it is an error from now on)
 }
@@ -374,6 +387,7 @@ int mv_group_create(mv_gym *const *gyms, int32_t n, mv_group **out)
     for (int i = 0; i < n; ++i) {   // nothing in flight on the streams a member is about to leave
         HIP_TRY(hipStreamSynchronize(gyms[i]->simStream));
         HIP_TRY(hipStreamSynchronize(gyms[i]->stream));
+        if (gyms[i]->copyStream) HIP_TRY(hipStreamSynchronize(gyms[i]->copyStream));
     }
     mv_group *grp = new mv_group();
     grp->gyms.assign(gyms, gyms + n);
@@ -384,8 +398,16 @@ int mv_group_create(mv_gym *const *gyms, int32_t n, mv_group **out)
             g->ownSimStream = g->simStream; g->ownSimDone = g->simDone; g->ownStepDone = g->stepDone;
             g->simStream = L->simStream; g->simDone = L->simDone; g->stepDone = L->stepDone;
             for (int q = 0; q < PIPE_GROUPS; ++q) { g->ownUserMark[q] = g->userMark[q]; g->userMark[q] = L->userMark[q]; }
+            // ONE copy stream for the group's status read-backs and episode uploads.  A device has four hardware queues and HIP deals its streams over
+            // them: with a copy stream per member some of them shared a queue with the caller's stream or the simulation stream, and a read-back that
+            // waits there for the step launch holds up the observation launch queued behind it (60-180 us gaps every other call in the traces of r08k).
+            static const bool ownCopy = getenv("MV_X_COPY") && !std::strcmp(getenv("MV_X_COPY"), "own");   // (experiment r08r)
+            if (L->copyStream && g->copyStream && !ownCopy) {
+                g->ownCopyStream = g->copyStream; g->copyStream = L->copyStream;
+                if (g->genStream) g->genStream = g->copyStream;
+            }
         }
-        g->simMustWaitUser = true; g->simOnOwnStream = false; g->simDoneValid = false; g->stepDoneValid = false; g->markCount = 0;
+        g->simMustWaitUser = true; g->simOnOwnStream = false; g->simDoneValid = false; g->lastStep = nullptr; g->markCount = 0;
     }
     *out = grp;
     return 0;

@@ -16,6 +16,7 @@
 // so voxel questions ("is this cell solid / lava / exit / holding a diamond?") are answered from the box
 // lists with ballots instead of a dense chunk; column occupancy for drops and teleports is a 128-bit wave OR.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -72,19 +73,19 @@ __global__ __launch_bounds__(64, MV_STEP_TICKS_WAVES_PER_SIMD) void step_obstacl
     }
 }
 
-void launch_step_obstacles_ticks(const GymView *views, GymView *dviews, int k, hipStream_t stream, int W, int H)
+void launch_step_obstacles_ticks(const GymView *views, GymView *dviews, int k, hipStream_t stream, int W, int H, hipEvent_t done)
 {
     if (k <= 8) {   // the views as the launch's arguments (mv_types.h: StepTicksArgs8)
         StepTicksArgs8 a8;
         a8.n = k; a8.pad = 0;
         for (int j = 0; j < 8; ++j) a8.gv[j] = views[std::min(j, k - 1)];
-        hipLaunchKernelGGL(step_obstacles_ticks_kernel<StepTicksArgs8>, dim3(views[0].num_envs), dim3(64), 0, stream, a8, W, H);
+        hipExtLaunchKernelGGL(step_obstacles_ticks_kernel<StepTicksArgs8>, dim3(views[0].num_envs), dim3(64), 0, stream, nullptr, done, 0, a8, W, H);
         return;
     }
     upload_tick_views(views, k, dviews, stream);
     StepTicksArgs a;
     a.n = k; a.pad = 0; a.views = dviews;
-    hipLaunchKernelGGL(step_obstacles_ticks_kernel<StepTicksArgs>, dim3(views[0].num_envs), dim3(64), 0, stream, a, W, H);
+    hipExtLaunchKernelGGL(step_obstacles_ticks_kernel<StepTicksArgs>, dim3(views[0].num_envs), dim3(64), 0, stream, nullptr, done, 0, a, W, H);
 }
 
 __global__ __launch_bounds__(64) void reset_obstacles_kernel(GymView gv, const EpisodeBlob *blobs, int *status, int force_all)

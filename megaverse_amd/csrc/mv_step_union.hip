@@ -9,6 +9,7 @@
 // Registers and LDS are the maxima over the scenarios' ticks (176 VGPRs, ~30 KB): two waves per SIMD, four workgroups per CU -- 1024 envs of
 // one agent are still resident at once.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 
@@ -98,12 +99,12 @@ __global__ __launch_bounds__(64 * WAVES, MV_UNION_TICKS_WAVES_PER_SIMD) void ste
     }
 }
 
-void launch_step_union_ticks(const UnionTicksArgs &ua, hipStream_t stream, int W, int H)
+void launch_step_union_ticks(const UnionTicksArgs &ua, hipStream_t stream, int W, int H, hipEvent_t done)
 {
     bool anyLong = false;
     for (int i = 0; i < ua.n; ++i) anyLong = anyLong || ua.gv[i].vis_stride > VIS_SMALL;
-    if (anyLong) hipLaunchKernelGGL(step_union_ticks_kernel<4>, dim3(ua.first[ua.n]), dim3(256), 0, stream, ua, W, H);
-    else hipLaunchKernelGGL(step_union_ticks_kernel<1>, dim3(ua.first[ua.n]), dim3(64), 0, stream, ua, W, H);
+    if (anyLong) hipExtLaunchKernelGGL(step_union_ticks_kernel<4>, dim3(ua.first[ua.n]), dim3(256), 0, stream, nullptr, done, 0, ua, W, H);
+    else hipExtLaunchKernelGGL(step_union_ticks_kernel<1>, dim3(ua.first[ua.n]), dim3(64), 0, stream, nullptr, done, 0, ua, W, H);
 }
 
 void launch_step_union(const UnionStepArgs &ua, hipStream_t stream, int W, int H, int render)

@@ -29,7 +29,7 @@ struct UnionTicksArgs {
 };
 static_assert(sizeof(UnionTicksArgs) + 16 <= 4096, "UnionTicksArgs + (W, H) must fit the 4 KB kernel-argument segment");
 
-void launch_step_union_ticks(const UnionTicksArgs &ua, hipStream_t stream, int W, int H);   // (one agent per env)
+void launch_step_union_ticks(const UnionTicksArgs &ua, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);   // done: completed by the launch's own dispatch packet   // (one agent per env)
 
 void launch_step_union(const UnionStepArgs &ua, hipStream_t stream, int W, int H, int render);
 
