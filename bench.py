@@ -568,6 +568,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(args.steps):
             policy_step(step0 + i)
+        host_enqueue_ms_loop = (time.perf_counter() - t0) / args.steps * 1e3
         fence()
         extra["closed_loop"] = time.perf_counter() - t0
         step0 += args.steps
@@ -604,6 +605,9 @@ def main():
             step0 += wu
             torch.cuda.set_stream(main_stream)
             fence()
+            # One host thread enqueues both halves in turn: per step it pays the Python + launch cost of a tick TWICE (~75 us at 2 x 512 envs: this leg is bound by the
+            # host -- `host_enqueue_ms_per_step_closed_loop_double_buffered` ~ the leg's time -- where `closed_loop` is bound by its three kernels back to back).
+            # A host thread per half was built and measured: 9.2 M obs/s against 13.5 M (r08v: two Python threads contend for the interpreter lock, 109 us per step).
             t0 = time.perf_counter()
             for i in range(args.steps):
                 half_step(0, step0 + i); half_step(1, step0 + i)
@@ -681,6 +685,8 @@ def main():
         for key, el in extra.items():
             line["value_" + key] = total_obs / el
             line["ms_per_step_" + key] = el / args.steps * 1e3
+        if "closed_loop" in extra:
+            line["host_enqueue_ms_per_step_closed_loop"] = host_enqueue_ms_loop
         if "closed_loop_double_buffered" in extra:
             line["host_enqueue_ms_per_step_closed_loop_double_buffered"] = host_enqueue_ms
         if dry:
@@ -757,8 +763,8 @@ def main():
                                             # (rocprofv3's derived VALUBusy of the same passes: 91 % for this kernel alone on the chip, profiles/r06s_*)
                                             "valu_busy_frac_at_2.4GHz": (valu["active_inst_valu_quadcycles"] * 4.0 / 1024.0 / (raster_ms * 1e-3 * 2.4e9)) if valu.get("active_inst_valu_quadcycles") else None,
                                             "source": valu.get("source")}
-            line["roofline_physics"] = {"bound": "latency", "kernel": ("mv::step_union_kernel" if mixed else "mv::%s (the %d ticks of a call in one launch; per tick)" % (ticks_kernel_name, batch) if batch_step else "mv::step_kernel") +
-                                                              " (voxel physics + scenario logic + auto-reset + frame setup)", "ticks_per_launch": batch if batch_step else 1, "achieved": achieved_step,
+            line["roofline_physics"] = {"bound": "latency", "kernel": ("mv::step_union_kernel" if mixed else "mv::%s (the %d ticks of a call in %d launch%s; per tick)" % (ticks_kernel_name, batch, (batch + 7) // 8, "es of 8" if batch > 8 else "") if batch_step else "mv::step_kernel") +
+                                                              " (voxel physics + scenario logic + auto-reset + frame setup)", "ticks_per_launch": min(batch, 8) if batch_step else 1, "achieved": achieved_step,
                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_step / HBM_PEAK_GBS, "traffic": traffic_step,
                                         "avg_launch_ms": step_ms, "launches_timed": prof["step"][1], "algorithmic_bytes_per_launch": step_bytes_per_env * n_env,
                                         # the same launch priced with SURVEY 8(d)'s per-env figure (17.9 KB for one agent, 18.7 KB for four: the 16 KB voxel chunk

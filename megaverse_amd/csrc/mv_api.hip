@@ -147,7 +147,10 @@ int tower_join(mv_gym *g)
 // env; what the last launch may still be drawing replaces an episode consumed a call ago: not needed yet) ...
 int tower_draw_before(mv_gym *g, hipStream_t sim)
 {
-    if (g->genStream && g->drawCount >= 2) HIP_TRY(hipStreamWaitEvent(sim, g->drawDone[(size_t)(g->drawCount & 1ull)], 0));
+    if (!g->genStream || g->drawCount < 2) return 0;
+    if (g->drawWaitedCount == g->drawCount && g->drawWaitedOn == sim) return 0;   // (draw launches come every drawPeriod ticks: a tick-by-tick caller waits once per launch, not per tick)
+    HIP_TRY(hipStreamWaitEvent(sim, g->drawDone[(size_t)(g->drawCount & 1ull)], 0));
+    g->drawWaitedCount = g->drawCount; g->drawWaitedOn = sim;
     return 0;
 }
 // ... and behind them, every drawPeriod ticks, the draw kernel goes to its own stream: it tops up the rings of the envs that finished
@@ -246,13 +249,18 @@ static int usable_host_cores()
 }
 
 // the simulation stream (another queue priority than the caller's was measured, low and high: no gain, r06k)
+// The simulation stream has the device's highest stream priority: when a call's observation launch and the next call's step launch become ready together --
+// the end of a step launch releases both -- the step launch's few fat workgroups (one or four waves of 128-168 VGPRs) should reach the chip first; behind an
+// observation launch that has filled it with 72-VGPR waves they wait for holes that never get large enough until that launch has drained.  Measured (r08s, two
+// runs each, normal / high): ObstaclesHard 512 envs 18.6 / 20.8 M obs/s, 1024 envs 24.1 / 26.3, Sokoban 26.2 / 28.2, Mixed 64 x 64 16.8 / 18.3, Mixed4 20.6 / 18.7,
+// TowerBuilding (1024, 4096, 512 x 4), Collect, Empty: unchanged.  MV_SIM_PRIORITY=normal: a stream of default priority.
 static hipError_t create_sim_stream(hipStream_t *s)
 {
-    static const char *prio = getenv("MV_X_SIM_PRIORITY");   // (experiment r08r)
-    if (prio && !std::strcmp(prio, "high")) {
+    static const char *prio = getenv("MV_SIM_PRIORITY");
+    if (!prio || std::strcmp(prio, "normal")) {
         int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        return hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi);
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi) == hipSuccess) return hipSuccess;
+        (void)hipGetLastError();   // (no priorities on this device / runtime: a stream of default priority does the same work)
     }
     return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
 }
@@ -332,7 +340,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     const size_t szTerrain = obstacles ? up(N * MAX_TERRAIN * sizeof(TerrainBox)) : 0,
                  szRewObj = hostEpisodes ? up(N * (size_t)gv.reward_stride * sizeof(MovableObject)) : 0,
                  szHeight = collect ? up(N * (size_t)HM_BYTES) : 0, szItems = rearrange ? up(N * MAX_ITEMS * sizeof(ArrangementItem)) : 0, szCells = sokoban ? up(N * (size_t)(SOKO_DIM * SOKO_DIM)) : 0,
-                 szHexB = hex ? up(N * (size_t)HEX_MAX_BOXES * sizeof(HexRec)) : 0, szHexO = hex ? up(N * (size_t)HEX_MAX_OBJS * sizeof(HexRec)) : 0, szBlobs = up(N * g->blobBytes * (size_t)g->spares), szCnt = up((N + 2) * sizeof(int32_t)), szGen = hostEpisodes ? 0 : up(N * sizeof(TowerGen)), szViews = up((size_t)MAX_STEP_TICKS * sizeof(GymView));
+                 szHexB = hex ? up(N * (size_t)HEX_MAX_BOXES * sizeof(HexRec)) : 0, szHexO = hex ? up(N * (size_t)HEX_MAX_OBJS * sizeof(HexRec)) : 0, szBlobs = up(N * g->blobBytes * (size_t)g->spares), szCnt = up((N + 2) * sizeof(int32_t)), szGen = hostEpisodes ? 0 : up(N * sizeof(TowerGen));
     gv.vis_stride = hex ? 2048 : collect ? 1024 : 256;
     if (const char *e = getenv("MV_DEBUG_VIS_STRIDE")) gv.vis_stride = std::min(gv.vis_stride, std::max(8, atoi(e)));   // (tests: provoke ST_VISIBLE)
     gv.debug_redo = getenv("MV_DEBUG_FORCE_REDO") && atoi(getenv("MV_DEBUG_FORCE_REDO")) ? 1 : 0;   // (tests: mv_tick_tower.h's sequential redo)
@@ -346,7 +354,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     const bool depthSortOn = !(getenv("MV_DEPTH_SORT") && atoi(getenv("MV_DEPTH_SORT")) == 0);
     const size_t szSort = gv.vis_stride > 256 && depthSortOn ? up(NA * (size_t)gv.vis_stride * 40) : 0;
     const size_t total = szSort + szHdr + szBoxes + szObj + szAg + szAct + szRew + szDone + szObjv + szMd + (hostEpisodes ? 0 : szChunk) + szObs + szTerrain +
-                         szRewObj + szHeight + szItems + szCells + szHexB + szHexO + szBlobs + szCnt + szGen + szViews + (size_t)g->slots * szParity + szHist;
+                         szRewObj + szHeight + szItems + szCells + szHexB + szHexO + szBlobs + szCnt + szGen + (size_t)g->slots * szParity + szHist;
     {
         hipError_t e_ = hipMalloc((void **)&g->arena, total);
         if (e_ != hipSuccess) { mv_destroy(g); return fail(std::string("hipMalloc arena: ") + hipGetErrorString(e_)); }
@@ -372,7 +380,6 @@ int mv_create(const mv_config *cfg, mv_gym **out)
         g->dBlobs = p; p += szBlobs;   // the ring of resident next episodes: uploaded by the host's feeder, or (TowerBuilding) drawn on the device
         gv.blobs = g->dBlobs;
         if (!hostEpisodes) { gv.tower_gen = (TowerGen *)p; p += szGen; }
-        g->dViews = (GymView *)p; p += szViews;
         if (collect) { gv.heightmap = (int8_t *)p; p += szHeight; }
         if (rearrange) { gv.items = (ArrangementItem *)p; p += szItems; }
         if (sokoban) { gv.soko_cells = p; p += szCells; }

@@ -35,13 +35,13 @@ void launch_tower_seed(const GymView &gv, const uint32_t *seeds, hipStream_t str
 // step kernels: one 256-thread workgroup per env = the tick (wave 0) + the frame setup of the env's frames for a W x H observation
 // (render = 0: tick only)
 void launch_step(const GymView &gv, hipStream_t stream, int W, int H, int render, hipEvent_t done = nullptr);
-void launch_step_ticks(const GymView *views, GymView *dviews, int k, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);   // k ticks + frame setups of every env, one launch (mv_step.hip)
+void launch_step_ticks(const GymView *views, int k, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);   // k ticks + frame setups of every env, one launch (mv_step.hip)
 void launch_step_obstacles(const GymView &gv, hipStream_t stream, int W, int H, int render);
-void launch_step_obstacles_ticks(const GymView *views, GymView *dviews, int k, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);   // k ticks + frame setups of every env (one agent), one launch
-void launch_step_rearrange_ticks(const GymView *views, GymView *dviews, int k, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);
-void launch_step_sokoban_ticks(const GymView *views, GymView *dviews, int k, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);
-void launch_step_collect_ticks(const GymView *views, GymView *dviews, int k, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);
-void launch_step_hex_ticks(const GymView *views, GymView *dviews, int k, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);
+void launch_step_obstacles_ticks(const GymView *views, int k, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);   // k ticks + frame setups of every env (one agent), one launch
+void launch_step_rearrange_ticks(const GymView *views, int k, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);
+void launch_step_sokoban_ticks(const GymView *views, int k, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);
+void launch_step_collect_ticks(const GymView *views, int k, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);
+void launch_step_hex_ticks(const GymView *views, int k, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);
 void launch_reset_obstacles(const GymView &gv, const EpisodeBlob *blobs, int *status, int force_all, hipStream_t stream);
 void launch_step_rearrange(const GymView &gv, hipStream_t stream, int W, int H, int render);
 void launch_reset_rearrange(const GymView &gv, const RearrangeBlob *blobs, int *status, int force_all, hipStream_t stream);
@@ -111,7 +111,6 @@ struct mv_gym {
     // the two paths -- is cleared by take_hist with a memset.
     std::vector<uint8_t> histClean;
     std::vector<GymView> gvp;                    // [slots] gv with the buffers of each slot swapped in
-    GymView *dViews = nullptr;                   // [MAX_STEP_TICKS] device copies of the views of the multi-tick step launch in flight (mv_types.h: StepTicksArgs)
     GymView gv{};
     const int32_t *mdActions = nullptr;          // mv_set_actions_device: the caller's multi-discrete buffer, read by the next step kernel
     // mv_set_pass_overlap(1), ring at least two calls deep: the one-launch observation passes of consecutive batched calls go to two internal streams
@@ -165,7 +164,8 @@ struct mv_gym {
     // episodes last at least 64 ticks, every call where they can be a few ticks long (those calls are one tick each: mv_step_n).
     hipStream_t genStream = nullptr;
     hipEvent_t drawDone[2] = {nullptr, nullptr};
-    unsigned long long drawCount = 0;
+    unsigned long long drawCount = 0, drawWaitedCount = 0;   // draw launches so far; the count at the last tower_draw_before wait ...
+    hipStream_t drawWaitedOn = nullptr;                       // ... and the stream that waited
     int ticksSinceDraw = 0, drawPeriod = 1;
     int *dStatus = nullptr, *hStatus = nullptr;     // [N + 2]: consumed per env, total, error flags (device, pinned mirror)
     int lastTotalSeen = 0;

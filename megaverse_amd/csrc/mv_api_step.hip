@@ -119,6 +119,11 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
     // (raster_union_batch_kernel) -- two launches per call where the tick-by-tick path takes 2 k (BASELINE configs[4]: the scenarios of a multi-task batch).
     bool groupBatch = n > 1 && !ticksOff && own && render && allFast && k >= 2 && k <= MAX_STEP_TICKS && policy != POLICY_NONE && !profiling && raster_union_batch_applicable(k, n, L->w, L->h);
     for (int i = 0; i < n && groupBatch; ++i) groupBatch = gs[i]->A == 1 && gs[i]->ringObs && gs[i]->ringCount >= k && !gs[i]->gv.dbg;
+    // not pipelined: the caller's stream needs no event behind the step launches; the side streams do when a draw launch, a status read-back or an upload will wait for this call
+    bool sideWaits = anyHostEpisodes;
+    for (int i = 0; i < n; ++i)
+        sideWaits = sideWaits || (gs[i]->genStream && gs[i]->ticksSinceDraw + k >= gs[i]->drawPeriod) || gs[i]->stepsSinceStatus + k >= gs[i]->statusPeriod;
+    bool stepDoneRodeAlong = false;
     for (int j = 0; j < k; ++j) {
         const bool prof = !callEv && render && L->profCount < L->profMax;
         evs[j] = prof ? &L->profEvents[(size_t)L->profCount * 5] : nullptr;
@@ -150,17 +155,28 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
                 // kernels in front of every step launch, the second one waiting 30 us for a wave slot beside the observation passes: the chain
                 // of step launches is what bounds a batched call's rate at 1024 envs, 344 + 39 us per call against 288 us of passes.)
                 if (callEv) HIP_TRY(hipEventRecord(callEv[0], sim));
-                hipEvent_t rides = own && !callEv ? L->simDone : nullptr;   // (completed by the launch's own dispatch packet: no marker behind it on the simulation stream)
-                if (obstFamily) launch_step_obstacles_ticks(views.data(), L->dViews, k, sim, L->w, L->h, rides);
-                else if (L->scenario == SCN_REARRANGE) launch_step_rearrange_ticks(views.data(), L->dViews, k, sim, L->w, L->h, rides);
-                else if (L->scenario == SCN_SOKOBAN) launch_step_sokoban_ticks(views.data(), L->dViews, k, sim, L->w, L->h, rides);
-                else if (L->scenario == SCN_COLLECT) launch_step_collect_ticks(views.data(), L->dViews, k, sim, L->w, L->h, rides);
-                else if (L->scenario == SCN_HEX_MEMORY || L->scenario == SCN_HEX_EXPLORE) launch_step_hex_ticks(views.data(), L->dViews, k, sim, L->w, L->h, rides);
-                else launch_step_ticks(views.data(), L->dViews, k, sim, L->w, L->h, rides);
+                hipEvent_t rides = own && !callEv ? L->simDone : nullptr;   // (completed by the last launch's own dispatch packet: no marker behind it on the simulation stream)
+                const int chunkTicks = 8;   // (a launch holds the views of up to 8 ticks as its arguments, mv_types.h: StepTicksArgs8)
+                for (int j0 = 0; j0 < k; j0 += chunkTicks) {
+                    const int kk = std::min(chunkTicks, k - j0);
+                    const GymView *vw = views.data() + j0;
+                    hipEvent_t r = j0 + kk == k ? rides : nullptr;
+                    if (obstFamily) launch_step_obstacles_ticks(vw, kk, sim, L->w, L->h, r);
+                    else if (L->scenario == SCN_REARRANGE) launch_step_rearrange_ticks(vw, kk, sim, L->w, L->h, r);
+                    else if (L->scenario == SCN_SOKOBAN) launch_step_sokoban_ticks(vw, kk, sim, L->w, L->h, r);
+                    else if (L->scenario == SCN_COLLECT) launch_step_collect_ticks(vw, kk, sim, L->w, L->h, r);
+                    else if (L->scenario == SCN_HEX_MEMORY || L->scenario == SCN_HEX_EXPLORE) launch_step_hex_ticks(vw, kk, sim, L->w, L->h, r);
+                    else launch_step_ticks(vw, kk, sim, L->w, L->h, r);
+                }
                 if (callEv) HIP_TRY(hipEventRecord(callEv[1], sim));
                 simDoneRides = rides != nullptr;
             }
-        } else if (n == 1) simDoneRides = launch_step_of(L, views[(size_t)j * n], sim, fused, own && j == k - 1 && !evs[j] ? L->simDone : nullptr);
+        } else if (n == 1) {
+            hipEvent_t rides = j == k - 1 && !evs[j] ? (own ? L->simDone : sideWaits ? L->stepDone : nullptr) : nullptr;
+            const bool rode = launch_step_of(L, views[(size_t)j * n], sim, fused, rides);
+            simDoneRides = rode && own;
+            stepDoneRodeAlong = rode && !own;
+        }
         else if (groupBatch) {
             if (j == k - 1) {   // every tick's views are collected: one launch for the k ticks of all n gyms
                 UnionTicksArgs ta;
@@ -189,7 +205,10 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
     // launch that starts behind the observation launch it runs beside waits for that launch's workgroups to drain, r08q timeline.)
     hipEvent_t after = L->simDone;
     if (own) { if (!simDoneRodeAlong) HIP_TRY(hipEventRecord(L->simDone, sim)); }
-    else { HIP_TRY(hipEventRecord(L->stepDone, sim)); after = L->stepDone; }   // (not pipelined: the caller's stream needs no event, the side streams do)
+    else {
+        after = sideWaits ? L->stepDone : nullptr;
+        if (sideWaits && !stepDoneRodeAlong) HIP_TRY(hipEventRecord(L->stepDone, sim));
+    }
     for (int i = 0; i < n; ++i)
         if (tower_draw_after(gs[i], after, k)) return -1;
     // (every step kernel regenerates / swaps the next episode into the envs it finishes)
@@ -200,7 +219,7 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
         g->samplePending = false;
         g->mdActions = nullptr;
         if (own) g->simDoneValid = true;
-        g->lastStep = after;   // (uploads never overlap a kernel that may read the ring: refill_episodes)
+        if (after) g->lastStep = after;   // (uploads never overlap a kernel that may read the ring: refill_episodes; host-generated scenarios always have one)
         g->stepsSinceStatus += k;
         if (g->stepsSinceStatus >= g->statusPeriod) {   // (TowerBuilding: the error flags and the episodes consumed, for the draw launches)
             if (read_back_status(g, after)) return -1;
@@ -400,9 +419,9 @@ int mv_group_create(mv_gym *const *gyms, int32_t n, mv_group **out)
             for (int q = 0; q < PIPE_GROUPS; ++q) { g->ownUserMark[q] = g->userMark[q]; g->userMark[q] = L->userMark[q]; }
             // ONE copy stream for the group's status read-backs and episode uploads.  A device has four hardware queues and HIP deals its streams over
             // them: with a copy stream per member some of them shared a queue with the caller's stream or the simulation stream, and a read-back that
-            // waits there for the step launch holds up the observation launch queued behind it (60-180 us gaps every other call in the traces of r08k).
-            static const bool ownCopy = getenv("MV_X_COPY") && !std::strcmp(getenv("MV_X_COPY"), "own");   // (experiment r08r)
-            if (L->copyStream && g->copyStream && !ownCopy) {
+            // waits there for the step launch holds up the observation launch queued behind it (60-180 us gaps every other call in the traces of r08k;
+            // Mixed 64 x 64, a copy stream per member / one for the group: 14.1 / 17.3 M obs/s, r08r).
+            if (L->copyStream && g->copyStream) {
                 g->ownCopyStream = g->copyStream; g->copyStream = L->copyStream;
                 if (g->genStream) g->genStream = g->copyStream;
             }

@@ -128,45 +128,17 @@ __device__ __forceinline__ void step_ticks_body(const Args &a, int W, int H)
 template <class Args> __global__ __launch_bounds__(64, MV_STEP_TICKS_WAVES_PER_SIMD) void step_ticks_kernel(Args a, int W, int H) { step_ticks_body<1>(a, W, H); }
 template <class Args> __global__ __launch_bounds__(256, 3) void step_ticks_agents_kernel(Args a, int W, int H) { step_ticks_body<MAX_AGENTS>(a, W, H); }
 
-// the views of a multi-tick launch -> device memory, eight at a time as the arguments of a one-workgroup kernel (a copy from host memory would need a staging
-// buffer per call in flight: the host runs calls ahead of the device)
-struct ViewsChunk { GymView v[8]; };
-__global__ void write_views_kernel(ViewsChunk c, GymView *dst, int n)
-{
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(&c);
-    uint32_t *d = reinterpret_cast<uint32_t *>(dst);
-    for (int i = (int)threadIdx.x; i < n * (int)(sizeof(GymView) / 4); i += (int)blockDim.x) d[i] = src[i];
-}
-static_assert(sizeof(GymView) % 4 == 0 && sizeof(ViewsChunk) + 16 <= 4096, "write_views_kernel");
-void upload_tick_views(const GymView *views, int k, GymView *dviews, hipStream_t stream)
-{
-    for (int first = 0; first < k; first += 8) {
-        ViewsChunk c;
-        const int n = std::min(8, k - first);
-        for (int j = 0; j < 8; ++j) c.v[j] = views[first + std::min(j, n - 1)];
-        hipLaunchKernelGGL(write_views_kernel, dim3(1), dim3(256), 0, stream, c, dviews + first, n);
-    }
-}
-
-void launch_step_ticks(const GymView *views, GymView *dviews, int k, hipStream_t stream, int W, int H, hipEvent_t done)
+void launch_step_ticks(const GymView *views, int k, hipStream_t stream, int W, int H, hipEvent_t done)
 {
     const GymView &gv = views[0];
     // several agents: TWO waves per env (measured at 512 envs x 4 agents: one wave 20.3 M obs/s, two 21.7, four 16.1 -- four waves of ~180 VGPRs per env,
     // resident for the whole call, are what the observation passes beside them cannot have; one-launch-per-tick: 19.4)
     const dim3 grid(gv.num_envs), block(gv.num_agents == 1 ? 64 : 64 * std::min(gv.num_agents, 2));
-    if (k <= 8) {   // the views as the launch's arguments
-        StepTicksArgs8 a;
-        a.n = k; a.pad = 0;
-        for (int j = 0; j < 8; ++j) a.gv[j] = views[std::min(j, k - 1)];
-        if (gv.num_agents == 1) hipExtLaunchKernelGGL(step_ticks_kernel<StepTicksArgs8>, grid, block, 0, stream, nullptr, done, 0, a, W, H);
-        else hipExtLaunchKernelGGL(step_ticks_agents_kernel<StepTicksArgs8>, grid, block, 0, stream, nullptr, done, 0, a, W, H);
-        return;
-    }
-    upload_tick_views(views, k, dviews, stream);
-    StepTicksArgs a;
-    a.n = k; a.pad = 0; a.views = dviews;
-    if (gv.num_agents == 1) hipExtLaunchKernelGGL(step_ticks_kernel<StepTicksArgs>, grid, block, 0, stream, nullptr, done, 0, a, W, H);
-    else hipExtLaunchKernelGGL(step_ticks_agents_kernel<StepTicksArgs>, grid, block, 0, stream, nullptr, done, 0, a, W, H);
+    StepTicksArgs8 a;   // (k <= 8: the views are the launch's arguments)
+    a.n = k; a.pad = 0;
+    for (int j = 0; j < 8; ++j) a.gv[j] = views[std::min(j, k - 1)];
+    if (gv.num_agents == 1) hipExtLaunchKernelGGL(step_ticks_kernel<StepTicksArgs8>, grid, block, 0, stream, nullptr, done, 0, a, W, H);
+    else hipExtLaunchKernelGGL(step_ticks_agents_kernel<StepTicksArgs8>, grid, block, 0, stream, nullptr, done, 0, a, W, H);
 }
 
 // done: an event that completes with the launch, carried by its dispatch packet (cf. mv_raster.h)

@@ -70,19 +70,12 @@ __global__ __launch_bounds__(64, MV_STEP_TICKS_WAVES_PER_SIMD) void step_sokoban
     }
 }
 
-void launch_step_sokoban_ticks(const GymView *views, GymView *dviews, int k, hipStream_t stream, int W, int H, hipEvent_t done)
+void launch_step_sokoban_ticks(const GymView *views, int k, hipStream_t stream, int W, int H, hipEvent_t done)
 {
-    if (k <= 8) {   // the views as the launch's arguments (mv_types.h: StepTicksArgs8)
-        StepTicksArgs8 a8;
-        a8.n = k; a8.pad = 0;
-        for (int j = 0; j < 8; ++j) a8.gv[j] = views[std::min(j, k - 1)];
-        hipExtLaunchKernelGGL(step_sokoban_ticks_kernel<StepTicksArgs8>, dim3(views[0].num_envs), dim3(64), 0, stream, nullptr, done, 0, a8, W, H);
-        return;
-    }
-    upload_tick_views(views, k, dviews, stream);
-    StepTicksArgs a;
-    a.n = k; a.pad = 0; a.views = dviews;
-    hipExtLaunchKernelGGL(step_sokoban_ticks_kernel<StepTicksArgs>, dim3(views[0].num_envs), dim3(64), 0, stream, nullptr, done, 0, a, W, H);
+    StepTicksArgs8 a8;   // (k <= 8: the views are the launch's arguments, mv_types.h)
+    a8.n = k; a8.pad = 0;
+    for (int j = 0; j < 8; ++j) a8.gv[j] = views[std::min(j, k - 1)];
+    hipExtLaunchKernelGGL(step_sokoban_ticks_kernel<StepTicksArgs8>, dim3(views[0].num_envs), dim3(64), 0, stream, nullptr, done, 0, a8, W, H);
 }
 
 void launch_step_sokoban(const GymView &gv, hipStream_t stream, int W, int H, int render)

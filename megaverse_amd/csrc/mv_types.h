@@ -118,7 +118,7 @@ struct alignas(16) AgentState {   // 128 B
 static_assert(sizeof(AgentState) == 128, "AgentState must be 128 B");
 
 // ---- cost bins of the observation pass (mv_frame.h fills them, mv_raster.hip reads them, mv_api.hip sizes them)
-constexpr int MAX_STEP_TICKS = 16;   // ticks of one multi-tick step launch (mv_step.hip: step_ticks_kernel) = of one observation launch of a batched call
+constexpr int MAX_STEP_TICKS = 16;   // ticks of one batched call = of its one observation launch (its step launches hold up to 8 each: StepTicksArgs8)
 constexpr int LPT_BUCKETS = 256;
 // Every cost bin has LPT_SUBS counters and lists, picked by frame index: the frames of a launch finish together and most of them fall into
 // the same three or four bins -- one counter per bin made their returning atomics queue up at one L2 address (measured: 1.3 us of a 7 us frame setup).
@@ -177,29 +177,21 @@ struct GymView {
     struct TowerGen *tower_gen;// [N] TowerBuilding: where each env's episode generator stands (mv_reset_device.h: tower_draw); its resident episodes are `blobs` (TowerBlob)
 };
 
-// The n consecutive ticks of a multi-tick step launch (mv_step.hip: step_ticks_kernel, and every mv_step_*.hip), the same envs in all of them: their views, in
-// DEVICE memory (mv_gym::dViews; upload_tick_views puts them there on the launch's stream, in front of it).  The kernels read a tick's view like kernel
-// arguments -- scalar loads on demand -- without its fields living in registers across the tick.  (Until round 5 the n views travelled by value: 2.6 KB of the
-// 4 KB kernel-argument segment for 8 ticks, and no more than 8; deriving tick j's view from tick 0's in the kernel -- ten pointers one hand-over slot further
-// per tick -- cost the resident one-wave kernels 100-140 bytes of scratch per lane more and 1.5-3.5 % of the rate.)
-struct StepTicksArgs {
-    int32_t n, pad;
-    const GymView *views;   // [n]
-    __host__ __device__ const GymView &view(int j) const { return views[j]; }
-};
-// ... or, up to eight ticks, BY VALUE as the launch's own arguments: no upload kernel in front of the launch (its ~25 us of queue latency per call are a sixth
-// of a 20-step run: 22.6 against 19.1 M obs/s)
+// The n <= 8 consecutive ticks of a multi-tick step launch (mv_step.hip: step_ticks_kernel, and every mv_step_*.hip), the same envs in all of them: their views BY
+// VALUE as the launch's arguments -- 2.6 KB of the 4 KB kernel-argument segment; the kernels read a tick's view with scalar loads on demand, its fields do not live
+// in registers across the tick.  A call of more than 8 ticks (MAX_STEP_TICKS: 16) is two such launches back to back.  (Built and measured in round 5, removed:
+// one launch of 16 ticks with its views in device memory, written there by a small kernel in front of it -- that kernel, queued behind the previous step launch
+// and beside an observation launch that had just taken the chip, took 10-44 us and made the step launch arrive late: Empty 27.6 M obs/s against 41.5 M with two
+// launches of 8, r08t; and deriving tick j's view from tick 0's in the kernel: 100-140 bytes of scratch per lane more and 1.5-3.5 % of the rate.)
 struct StepTicksArgs8 {
     int32_t n, pad;
     GymView gv[8];
     __host__ __device__ const GymView &view(int j) const { return gv[j]; }
 };
 static_assert(sizeof(StepTicksArgs8) + 16 <= 4096, "StepTicksArgs8 + (W, H) must fit the 4 KB kernel-argument segment");
-// views[0 .. k) -> dviews (device) on `stream`, ordered in front of whatever is launched there next (a kernel with up to 8 views as its arguments per launch)
-void upload_tick_views(const GymView *views, int k, GymView *dviews, hipStream_t stream);
 
 // tick j's view from tick 0's: ten buffers one hand-over slot (slot_stride bytes) further per tick (mv_api.hip carves a gym's slots out of its arena one after
-// the other), the action index, the cost histogram (consecutive, modulo their number).  Used where k x n views are too many to pass or to upload: the
+// the other), the action index, the cost histogram (consecutive, modulo their number).  Used where k x n views are too many to pass: the
 // group kernels (mv_union.h) and the observation launch of a batched call (mv_raster.hip).
 __host__ __device__ inline GymView tick_view(const GymView &base, int64_t slot_stride, int j)
 {

@@ -23,6 +23,11 @@ pmc SQ2 "$SQ2"
  python $R/scripts/kernel_timeline.py $OUT/db_s/run_results.db 40 20 > $OUT/timeline_batched.txt 2>/dev/null; rm -rf $OUT/db_s)
 (cd /tmp; MV_PIPELINE=0 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/db_u -o run -- python $R/bench.py --steps 400 --warmup 50 --no-cpu-baseline --profile-steps 0 --no-extra-legs --batch 1 > $OUT/tower_unpipelined_stats.log 2>&1
  python $R/scripts/rocpd_summary.py $OUT/db_u/run_results.db > $OUT/tower_unpipelined_kernel_stats.csv 2>> $OUT/tower_unpipelined_stats.log; rm -rf $OUT/db_u)
+(cd /tmp; timeout 300 rocprofv3 --kernel-trace -d $OUT/db_c -o run -- python $R/scripts/probe_closed_loop.py 1024 200 > $OUT/closed_loop.log 2>&1
+ python $R/scripts/kernel_timeline.py $OUT/db_c/run_results.db 60 40 > $OUT/timeline_closed_loop.txt 2>/dev/null; rm -rf $OUT/db_c)
+(cd /tmp; export BOXOBAN_LEVELS=$R/tests/golden/boxoban; timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/db_m -o run -- python $R/bench.py --scenario Mixed --obs 64 64 --steps 240 --warmup 48 --no-cpu-baseline --profile-steps 0 --no-extra-legs > $OUT/mixed_64_stats.log 2>&1
+ python $R/scripts/rocpd_summary.py $OUT/db_m/run_results.db > $OUT/mixed_64_kernel_stats.csv 2>> $OUT/mixed_64_stats.log
+ python $R/scripts/kernel_timeline.py $OUT/db_m/run_results.db 60 40 > $OUT/timeline_mixed_64.txt 2>/dev/null; rm -rf $OUT/db_m)
 cd $R
 timeout 900 python bench.py > $OUT/tower_bench.json 2> $OUT/tower_bench.err
 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/tower_bench_driver_style.json 2> $OUT/tower_bench_driver_style.err
@@ -36,6 +41,8 @@ $B --envs-per-gpu 512 > $OUT/tower_512_bench.json 2> /dev/null
 $B --envs-per-gpu 512 --agents 4 > $OUT/tower_512x4_bench.json 2> /dev/null
 $B --envs-per-gpu 4096 > $OUT/tower_4096_bench.json 2> /dev/null
 $B --batch 8 > $OUT/tower_8_ticks_per_call_bench.json 2> /dev/null
+MV_SIM_PRIORITY=normal $B > $OUT/tower_normal_priority_bench.json 2> /dev/null
+MV_SIM_PRIORITY=normal $B --scenario ObstaclesHard --envs-per-gpu 512 > $OUT/obstacles_hard_512_normal_priority_bench.json 2> /dev/null
 $B --scenario ObstaclesHard --envs-per-gpu 512 > $OUT/obstacles_hard_512_bench.json 2> /dev/null
 $B --scenario ObstaclesHard --envs-per-gpu 512 --pass-overlap off > $OUT/obstacles_hard_512_no_overlap_bench.json 2> /dev/null
 $B --scenario ObstaclesHard > $OUT/obstacles_hard_1024_bench.json 2> /dev/null

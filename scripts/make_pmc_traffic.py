@@ -39,8 +39,9 @@ def main():
                      "per dispatch; FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section; unit KB)",
            "source_sha16": kernel_sources_sha16(),   # bench.py prints these figures only while the kernel sources are the ones the passes ran on
            "config": {"envs_per_gpu": 1024, "agents_per_env": 1, "obs": [128, 128]}, "kernels": {}}
-    # the batched kernels (k ticks per launch) when the passes ran bench.py's default call size, else the per-tick kernels; everything PER TICK
-    for key, needles in (("raster", (("raster_fast_batch_kernel", ticks), ("raster_fast_kernel", 1))), ("step", (("step_ticks_kernel", ticks), ("step_kernel", 1)))):
+    # the batched kernels (k ticks per launch; a step launch holds at most 8: a call of 16 is two of them) when the passes ran bench.py's default call size,
+    # else the per-tick kernels; everything PER TICK
+    for key, needles in (("raster", (("raster_fast_batch_kernel", ticks), ("raster_fast_kernel", 1))), ("step", (("step_ticks_kernel", min(ticks, 8)), ("step_kernel", 1)))):
         for needle, div in needles:
             kn, w = pick(wr, needle)
             if w:
