@@ -86,8 +86,8 @@ int mv_set_sample_policy(mv_gym *g, int32_t policy);
 int mv_step_many(mv_gym *const *gyms, int32_t n, int32_t render, int32_t sample, uint32_t seed, uint32_t step_index);
 
 /* Groups: up to 8 gyms of one job -- one per scenario of a multi-task batch, the reference's layout (megaverse/megaverse_env.py:27-39: one
- * MegaverseGym per task) -- stepped TOGETHER: one step launch and at most two observation launches per tick for all of them, on one
- * shared pair of streams (BASELINE.json configs[4]: scenarios dealt round-robin over the envs of one batch; every gym keeps its env_offset /
+ * MegaverseGym per task) -- stepped TOGETHER: one step launch and one observation launch per tick for all of them -- per CALL of 2..8 ticks
+ * when every member has output rings (mv_set_output_ring) at least that deep -- on one shared pair of streams (BASELINE.json configs[4]: scenarios dealt round-robin over the envs of one batch; every gym keeps its env_offset /
  * env_stride, so seeds and sampled actions are the job-wide ones).  The members must share device, observation size, agents per env and
  * stream.  While grouped a gym is stepped through the group only; everything else (reset, seed, getters, shaping) stays per gym.
  * mv_group_step: k ticks like mv_step_n (render = 0: no observation pass).  Closing a member dissolves the group. */

@@ -799,15 +799,83 @@ int finish_with_warning(mv_gym *g)
 // slots, where the episodes were generated ahead of time by the worker pool.  The step path itself only ever enqueues; it waits
 // for the host only if an env has NO resident episode left and its next one is still being generated.  An upload never overlaps a
 // step kernel (stepDone): a finished env must not read a half-written slot.
-int refill_episodes(mv_gym *g)
+// One pass over the envs: whoever has a free ring entry (by the consumed counts last read back: g->consumedSeen) and a generated episode waiting in its pinned
+// slot gets it uploaded -- one episode per env and pass: the feeder keeps ONE episode per env ahead -- and what is still missing afterwards is g->deficit.
+static int upload_pass(mv_gym *g)
+{
+    const int N = g->N, K = g->spares;
+    hipEvent_t ev = g->uploadEvents[g->uploadRing++ % g->uploadEvents.size()];
+    HIP_TRY(hipEventSynchronize(ev));   // 64 batches ago
+    std::vector<int> &batch = g->uploadBatch;
+    batch.clear();
+    int deficit = 0;
+    bool waited = false;
+    // Consecutive envs whose next episode goes to the same ring slot travel as ONE strided copy (rows: the pinned slots, blobBytes apart, to the ring slots,
+    // spares x blobBytes apart).  Scenarios whose episodes all last the same -- Empty, Rearrange, Sokoban, Hex*: every env of the batch finishes on the very
+    // same tick -- used to pay a thousand hipMemcpyAsync calls, ~5 ms of host time, at every such tick.
+    int runFirst = -1, runLen = 0, runSlot = 0;
+    size_t runBytes = 0;
+    auto flush_run = [&]() -> int {
+        if (runLen <= 0) return 0;
+        uint8_t *dst = g->dBlobs + ((size_t)runFirst * K + (size_t)runSlot) * g->blobBytes;
+        const uint8_t *src = g->hBlobs + (size_t)runFirst * g->blobBytes;
+        if (runLen == 1) HIP_TRY(hipMemcpyAsync(dst, src, runBytes, hipMemcpyHostToDevice, g->copyStream));
+        else HIP_TRY(hipMemcpy2DAsync(dst, (size_t)K * g->blobBytes, src, g->blobBytes, runBytes, (size_t)runLen, hipMemcpyHostToDevice, g->copyStream));
+        runLen = 0;
+        return 0;
+    };
+    for (int i = 0; i < N; ++i) {
+        const int consumed = g->consumedSeen[(size_t)i];
+        if (g->uploaded[i] >= consumed + K) continue;            // ring full
+        const int need = g->uploaded[i] + 1;
+        const bool must = g->uploaded[i] == consumed;            // nothing resident: the next reset would starve
+        if (!must && !g->feeder->is_ready(i, need)) { deficit += consumed + K - g->uploaded[i]; continue; }   // later
+        size_t bytes = 0;
+        const uint8_t *src = g->feeder->wait_ready(i, need, &bytes);
+        if (!src) return fail(g->feeder->failed() ? std::string("episode feeder: a level file could not be read (Sokoban)")
+                                                  : "episode feeder: episode " + std::to_string(need) + " of env " + std::to_string(i) + " was never generated");
+        if (!waited && g->lastStep) { HIP_TRY(hipStreamWaitEvent(g->copyStream, g->lastStep, 0)); waited = true; }
+        const int slot = (need - 1) % K;
+        if (runLen > 0 && (i != runFirst + runLen || slot != runSlot) && flush_run()) return -1;
+        if (runLen == 0) { runFirst = i; runSlot = slot; runBytes = 0; }
+        ++runLen;
+        runBytes = std::max(runBytes, bytes);   // (the used prefix of the longest record of the run: what lies behind a shorter one's is never read)
+        (void)src;
+        ++g->uploaded[i];
+        deficit += consumed + K - g->uploaded[i];
+        batch.push_back(i);
+    }
+    if (flush_run()) return -1;
+    if (!batch.empty()) {
+        HIP_TRY(hipEventRecord(ev, g->copyStream));
+        for (int i : batch) g->feeder->recycle(i, ev);   // regenerate a slot only once its upload has left it
+        HIP_TRY(hipStreamWaitEvent(g->simStream, ev, 0));   // (a step that runs on the caller's stream, and mv_reset, wait for lastUpload themselves)
+        g->lastUpload = ev;
+        g->uploadNotOnUser = true;
+    }
+    g->deficit = deficit;
+    return 0;
+}
+
+int refill_episodes(mv_gym *g, int k)
 {
     if (g->statusPending) {
-        // The read-back was enqueued behind a step kernel the host is normally several ticks ahead of: waiting for it here would drain
-        // that run-ahead every statusPeriod steps.  With long episodes (period 16, two resident episodes per env) the words may arrive a few
-        // steps later: look again at the next step, but never let them age beyond 32 steps.
-        if (g->statusPeriod > 1 && g->pendingAge < 32 && hipEventQuery(g->statusCopied) == hipErrorNotReady) {
+        // The read-back was enqueued behind a step launch the host is normally ahead of: waiting for it at once would drain that run-ahead every statusPeriod
+        // ticks.  With long episodes (period 16, two resident episodes per env) the words may arrive later: look again at the next call -- every period a fresh
+        // read-back takes the pending one's place, so a host that runs ahead never finds it ready -- and wait for the latest one once max(32, 4 k) TICKS have been
+        // enqueued since the first.  That wait is what bounds the host's run-ahead, and with it how late a refill can land: an upload is ordered behind the LAST
+        // step launch enqueued.  It costs nothing: the host catches up with the STEP launches, which run up to three calls ahead of the observation passes the
+        // device is busy with.  (Until round 5 the bound was 32 CALLS -- 256 ticks at 8 per call, 512 at 16: a HexExplore env that found its goal twice within
+        // ~300 ticks starved, scripts/soak.py in r08z.  Measured, r08x2, bound 3 k / 6 k / 32 k ticks at k = 16: TowerBuilding 28.8 / 28.7 / 28.1 M obs/s, Empty
+        // 38.3 / 39.4 / 39.9; with ONE read-back in flight instead (polled until ready, no forced wait) the host's run-ahead was bounded by nothing: 26.3-28.9 / 36-38.
+        // r08x4, three runs each, this scheme / the 32-call bound: ObstaclesHard 512 envs 20.9 / 21.5, Empty 38.9 / 39.6: what the bound costs.)
+        const int bound = std::max(32, 4 * k);
+        if (g->statusPeriod > 1 && g->pendingAge < bound && hipEventQuery(g->statusCopied) == hipErrorNotReady) {
             (void)hipGetLastError();   // ("not ready" is an answer, not an error to report at the end of the step)
-            ++g->pendingAge;
+            g->pendingAge += k;
+            // (no fresh counts: but envs known to be short of an episode whose successor was not generated yet -- or had just sent one: one episode per env and pass --
+            // are served now, not at the next read-back: with every env finishing every 70 ticks and a pass every 80 the ring fell behind until it starved)
+            if (g->hostEpisodes() && g->deficit > 0 && !g->consumedSeen.empty() && upload_pass(g)) return -1;
             return 0;
         }
         (void)hipGetLastError();
@@ -815,7 +883,7 @@ int refill_episodes(mv_gym *g)
         g->statusPending = false;
         g->pendingAge = 0;
     }
-    const int N = g->N, K = g->spares;
+    const int N = g->N;
     const bool starved = (g->hStatus[N + 1] & ST_STARVED) != 0;
     if (starved && g->hostEpisodes()) {   // recover: take the current counts and upload synchronously below
         HIP_TRY(hipStreamSynchronize(g->simStream));
@@ -827,56 +895,8 @@ int refill_episodes(mv_gym *g)
         g->refillForce = true;
     }
     if (g->hostEpisodes() && (g->refillForce || g->deficit > 0 || g->hStatus[N] != g->lastTotalSeen)) {
-        hipEvent_t ev = g->uploadEvents[g->uploadRing++ % g->uploadEvents.size()];
-        HIP_TRY(hipEventSynchronize(ev));   // 64 batches ago
-        std::vector<int> &batch = g->uploadBatch;
-        batch.clear();
-        int deficit = 0;
-        bool waited = false;
-        // Consecutive envs whose next episode goes to the same ring slot travel as ONE strided copy (rows: the pinned slots, blobBytes apart, to the ring slots,
-        // spares x blobBytes apart).  Scenarios whose episodes all last the same -- Empty, Rearrange, Sokoban, Hex*: every env of the batch finishes on the very
-        // same tick -- used to pay a thousand hipMemcpyAsync calls, ~5 ms of host time, at every such tick.
-        int runFirst = -1, runLen = 0, runSlot = 0;
-        size_t runBytes = 0;
-        auto flush_run = [&]() -> int {
-            if (runLen <= 0) return 0;
-            uint8_t *dst = g->dBlobs + ((size_t)runFirst * K + (size_t)runSlot) * g->blobBytes;
-            const uint8_t *src = g->hBlobs + (size_t)runFirst * g->blobBytes;
-            if (runLen == 1) HIP_TRY(hipMemcpyAsync(dst, src, runBytes, hipMemcpyHostToDevice, g->copyStream));
-            else HIP_TRY(hipMemcpy2DAsync(dst, (size_t)K * g->blobBytes, src, g->blobBytes, runBytes, (size_t)runLen, hipMemcpyHostToDevice, g->copyStream));
-            runLen = 0;
-            return 0;
-        };
-        for (int i = 0; i < N; ++i) {
-            const int consumed = g->hStatus[i];
-            if (g->uploaded[i] >= consumed + K) continue;            // ring full
-            const int need = g->uploaded[i] + 1;
-            const bool must = g->uploaded[i] == consumed;            // nothing resident: the next reset would starve
-            if (!must && !g->feeder->is_ready(i, need)) { deficit += consumed + K - g->uploaded[i]; continue; }   // later
-            size_t bytes = 0;
-            const uint8_t *src = g->feeder->wait_ready(i, need, &bytes);
-            if (!src) return fail(g->feeder->failed() ? std::string("episode feeder: a level file could not be read (Sokoban)")
-                                                      : "episode feeder: episode " + std::to_string(need) + " of env " + std::to_string(i) + " was never generated");
-            if (!waited && g->lastStep) { HIP_TRY(hipStreamWaitEvent(g->copyStream, g->lastStep, 0)); waited = true; }
-            const int slot = (need - 1) % K;
-            if (runLen > 0 && (i != runFirst + runLen || slot != runSlot) && flush_run()) return -1;
-            if (runLen == 0) { runFirst = i; runSlot = slot; runBytes = 0; }
-            ++runLen;
-            runBytes = std::max(runBytes, bytes);   // (the used prefix of the longest record of the run: what lies behind a shorter one's is never read)
-            (void)src;
-            ++g->uploaded[i];
-            deficit += consumed + K - g->uploaded[i];
-            batch.push_back(i);
-        }
-        if (flush_run()) return -1;
-        if (!batch.empty()) {
-            HIP_TRY(hipEventRecord(ev, g->copyStream));
-            for (int i : batch) g->feeder->recycle(i, ev);   // regenerate a slot only once its upload has left it
-            HIP_TRY(hipStreamWaitEvent(g->simStream, ev, 0));   // (a step that runs on the caller's stream, and mv_reset, wait for lastUpload themselves)
-            g->lastUpload = ev;
-            g->uploadNotOnUser = true;
-        }
-        g->deficit = deficit;
+        g->consumedSeen.assign(g->hStatus, g->hStatus + N);   // (the pinned words are the target of the next read-back: the passes between two of them work from this copy)
+        if (upload_pass(g)) return -1;
         g->lastTotalSeen = g->hStatus[N];
         g->refillForce = false;
     }
@@ -889,6 +909,7 @@ int read_back_status(mv_gym *g, hipEvent_t after)
     HIP_TRY(hipStreamWaitEvent(g->copyStream, after, 0));
     HIP_TRY(hipMemcpyAsync(g->hStatus, g->dStatus, (size_t)(g->N + 2) * sizeof(int), hipMemcpyDeviceToHost, g->copyStream));
     HIP_TRY(hipEventRecord(g->statusCopied, g->copyStream));
+    if (!g->statusPending) g->pendingAge = 0;   // (a read-back issued while one is pending takes its place -- the event is re-recorded -- and keeps its age)
     g->statusPending = true;
     return 0;
 }
@@ -929,7 +950,7 @@ int mv_reset(mv_gym *g)
         g->pendingAge = 0;
         g->stepsSinceStatus = 0;
         g->refillForce = true;
-        if (refill_episodes(g) < 0) return -1;          // every env has an unconsumed episode resident
+        if (refill_episodes(g, 1) < 0) return -1;       // every env has an unconsumed episode resident
         if (g->lastUpload) HIP_TRY(hipStreamWaitEvent(g->stream, g->lastUpload, 0));
         const OutPtrs outs = last_outputs(g);
         const GymView v = view(g, g->parity, &outs);

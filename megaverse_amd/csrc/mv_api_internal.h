@@ -154,6 +154,7 @@ struct mv_gym {
     // Obstacles / Collect: background episode feeder + one resident episode per env (refill protocol below)
     std::unique_ptr<EpisodeFeeder> feeder;
     int feederThreads = 1;
+    std::vector<int> consumedSeen;                  // the consumed counts of the last status read-back that was looked at (host copy)
     std::vector<int> uploaded, uploadBatch;         // episodes uploaded per env; envs of the current upload batch
     uint8_t *dBlobs = nullptr, *hBlobs = nullptr;   // device [N][blobBytes], pinned feeder slots [N][blobBytes]
     size_t blobBytes = 0;                           // sizeof(EpisodeBlob) or sizeof(CollectBlob)
@@ -170,7 +171,7 @@ struct mv_gym {
     int *dStatus = nullptr, *hStatus = nullptr;     // [N + 2]: consumed per env, total, error flags (device, pinned mirror)
     int lastTotalSeen = 0;
     bool statusPending = false, refillForce = true;
-    int pendingAge = 0;                             // steps since the pending read-back was first looked for
+    int pendingAge = 0;                             // ticks enqueued since the pending read-back was issued
     int stepsSinceStatus = 0;
     int spares = 2;                                 // resident episodes per env (ring); the host keeps uploaded <= consumed + spares
     int statusPeriod = 16;                          // steps between status read-backs (1 when episodes can be only a few ticks long)
@@ -209,7 +210,7 @@ int publish_outputs(mv_gym *g, int q, const OutPtrs &o);   // on the caller's st
 bool scenario_from_name(const std::string &scen, int &scenario, ObstacleConfig &oc);
 int check_status_flags(mv_gym *g);
 int finish_with_warning(mv_gym *g);
-int refill_episodes(mv_gym *g);
+int refill_episodes(mv_gym *g, int k);   // k: the ticks of the stepping call that is about to be enqueued
 int read_back_status(mv_gym *g, hipEvent_t after);   // after: an event recorded behind the kernel whose status words are wanted
 int flush_device_actions(mv_gym *g);
 void group_detach(mv_gym *g);   // (mv_api_step.hip)

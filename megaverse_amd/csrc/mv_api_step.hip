@@ -41,7 +41,7 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
     if (k < 1 || k > batch) return fail("mv_step_n: 1 <= k <= " + std::to_string(batch) + " (MV_PIPE_BATCH) required");
     HIP_TRY(hipSetDevice(L->device));
     for (int i = 0; i < n; ++i)
-        if (refill_episodes(gs[i]) < 0) return -1;
+        if (refill_episodes(gs[i], k) < 0) return -1;
     // ---- what this call must wait for on the caller's stream.  Always: whatever was there when the call PIPE_GROUPS - 1 calls ago began --
     // the observation passes and the consumers of the call that used this slot group last.  Everything, when the caller's stream
     // feeds the simulation (reset / render / device actions / test hooks since the last step).  (Both raster kernels read nothing but the
@@ -221,7 +221,7 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
         if (own) g->simDoneValid = true;
         if (after) g->lastStep = after;   // (uploads never overlap a kernel that may read the ring: refill_episodes; host-generated scenarios always have one)
         g->stepsSinceStatus += k;
-        if (g->stepsSinceStatus >= g->statusPeriod) {   // (TowerBuilding: the error flags and the episodes consumed, for the draw launches)
+        if (g->stepsSinceStatus >= g->statusPeriod) {   // (TowerBuilding: the error flags)
             if (read_back_status(g, after)) return -1;
             g->stepsSinceStatus = 0;
         }

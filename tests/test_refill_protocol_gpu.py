@@ -131,3 +131,42 @@ def test_close_with_work_in_flight_and_two_gyms():
         b.sample_random_actions(6, st); b.step()
     assert b.get_dones().shape == (32,)
     b.close(); b.close()
+
+
+@pytest.mark.parametrize("scenario,k", [("Rearrange", 16), ("Rearrange", 8), ("Sokoban", 16)])
+def test_batched_calls_with_the_host_far_ahead_never_starve(scenario, k, monkeypatch, recwarn):
+    """Episodes of ~70 ticks (long enough for the 16-tick status period, two resident per env), stepped open loop with calls of k ticks and no
+    host synchronisation: the host enqueues far faster than the device steps.  An upload lands behind the last step launch ENQUEUED, so how late
+    a refill arrives is the host's run-ahead -- bounded in ticks (mv_api.hip: refill_episodes); bounded in calls, as it was until round 5 (32 calls
+    = 512 ticks at k = 16), an env that finished twice inside the window repeated its done step (scripts/soak.py found it on HexExplore).  No
+    capacity warning may be raised, and the rollout equals the same ticks stepped one by one."""
+    import torch
+    monkeypatch.setenv("BOXOBAN_LEVELS", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "boxoban"))
+    N, A, W, H, ticks = 48, 1, 32, 32, 1600
+    params = {"episodeLengthSec": 70.0 / 15.0}
+
+    def run(batched):
+        g = MegaverseGym(scenario, W, H, N, A, 8, False, params)
+        g.set_pixel_mode("fast")
+        ring = torch.zeros((2 * k, N * A, H, W, 4), dtype=torch.uint8, device="cuda:0")
+        g.set_output_ring(2 * k, ring.data_ptr())
+        g.seed(9); g.reset()
+        st = 0
+        while st < ticks:
+            if batched:
+                g.step_n(k, "multidiscrete", 31, st); st += k
+            else:
+                g.sample_random_actions(31, st); g.step(); st += 1
+        g.synchronize(); torch.cuda.synchronize()
+        snaps = [hip_snapshot(g, e).copy() for e in range(N)]
+        last = ring[(ticks - 1) % (2 * k)].cpu().numpy().copy()
+        g.close()
+        return snaps, last
+
+    a = run(True)
+    assert not [w for w in recwarn.list if "capacity" in str(w.message) or "resident" in str(w.message)], [str(w.message) for w in recwarn.list]
+    b = run(False)
+    for e in range(N):
+        d = diff_snapshots(a[0][e], b[0][e], A)
+        assert not d, (e, d[:4])
+    assert np.array_equal(a[1], b[1])
