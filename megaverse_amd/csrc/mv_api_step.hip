@@ -213,7 +213,7 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
         if (tower_draw_after(gs[i], after, k)) return -1;
     // (every step kernel regenerates / swaps the next episode into the envs it finishes)
     // An env needs a fresh resident episode only at its NEXT reset, normally hundreds of steps away, and two are resident: the status
-    // words are read back -- and the refill considered -- every statusPeriod-th step (16 ... 64; 1 when episodes can be a few ticks long).
+    // words are read back -- and the refill considered -- every statusPeriod-th step (16; 1 when episodes can be a few ticks long).
     for (int i = 0; i < n; ++i) {
         mv_gym *g = gs[i];
         g->samplePending = false;
