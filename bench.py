@@ -676,9 +676,10 @@ def main():
                        "pipelined": pipelined, "ticks_per_call": batch if main_batched else 1,
                        **({"ring_slots": ring_slots, "overlapped_passes": bool(pass_overlap)} if main_batched else {}),
                        **({"first_calls": os.environ.get("MV_BENCH_CALL_SCHEDULE", "2,4,6") + " ticks, then ticks_per_call (every tick stepped and rendered in full)"} if main_batched else {}),
-                       **({"launches_per_call": 2 if main_batched else None, "launches_per_tick": None if main_batched else 2,
+                       # (a batched group call is two launches where all of the group's envs are resident at once -- up to 1024 -- else two per tick: mv_api_step.hip, groupBatch)
+                       **({"launches_per_call": 2 if main_batched and n_env <= 1024 else None, "launches_per_tick": None if main_batched and n_env <= 1024 else 2,
                            "scenarios": ", ".join(gym.scenarios) + " dealt round-robin by env index (one gym per scenario, stepped as one mv_group: "
-                                        + ("one step launch and one observation launch per batched CALL, every scenario's ticks in its own rollout rings)" if main_batched
+                                        + ("one step launch and one observation launch per batched CALL, every scenario's ticks in its own rollout rings)" if main_batched and n_env <= 1024
                                            else "one step launch and one raster launch per tick)")} if mixed else {}),
                        "parallelism": f"env-shard x{world}"},
         }

@@ -119,6 +119,12 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
     // (raster_union_batch_kernel) -- two launches per call where the tick-by-tick path takes 2 k (BASELINE configs[4]: the scenarios of a multi-task batch).
     bool groupBatch = n > 1 && !ticksOff && own && render && allFast && k >= 2 && k <= MAX_STEP_TICKS && policy != POLICY_NONE && !profiling && raster_union_batch_applicable(k, n, L->w, L->h);
     for (int i = 0; i < n && groupBatch; ++i) groupBatch = gs[i]->A == 1 && gs[i]->ringObs && gs[i]->ringCount >= k && !gs[i]->gv.dbg;
+    {   // ... and all of the group's envs resident at once: the union step launch keeps a workgroup per env alive for the whole call (four waves of 168 VGPRs for the long-list
+        // gyms); beyond one round of the chip the tick-by-tick launches win (Mixed 64 x 64, batched / tick by tick: 512 envs 12.2 / 8.6 M obs/s, 1024: 17.6 / 16.2, 2048: 16.1 / 20.5; r08z_rules)
+        int envs = 0;
+        for (int i = 0; i < n; ++i) envs += gs[i]->N;
+        groupBatch = groupBatch && envs <= 1024;
+    }
     // not pipelined: the caller's stream needs no event behind the step launches; the side streams do when a draw launch, a status read-back or an upload will wait for this call
     bool sideWaits = anyHostEpisodes;
     for (int i = 0; i < n; ++i)
