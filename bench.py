@@ -741,7 +741,7 @@ def main():
             fam = {"towerbuilding": "", "collect": "collect_", "rearrange": "rearrange_", "sokoban": "sokoban_", "hexmemory": "hex_", "hexexplore": "hex_"}.get(args.scenario.lower(), "obstacles_")
             ticks_kernel_name = "step_ticks_agents_kernel" if A > 1 else "step_%sticks_kernel" % fam
             batch_raster = batch_step and args.pixels == "fast" and os.environ.get("MV_RASTER_BATCH", "8") != "0"
-            line["roofline"] = {"bound": "valu", "kernel": ("mv::raster_fast_union_kernel x 2 (short-list + long-list variant)" if mixed else
+            line["roofline"] = {"bound": "valu", "kernel": (("mv::raster_union_batch_kernel (the k x n observation passes of a group call in one launch: short-list and long-list bodies; per tick)" if batched and n_env <= 1024 else "mv::raster_union_all_kernel (one launch per tick for all scenarios: short-list and long-list bodies)") if mixed else
                                                           "mv::%s (the %d observation passes of a call in one launch; every figure here is PER TICK)" % ("raster_glist_batch_kernel" if long_list else "raster_fast_batch_kernel", batch) if batch_raster
                                                           else "mv::raster_glist_kernel" if long_list else "mv::raster_fast_kernel") if args.pixels == "fast" else "mv::raster_kernel",
                                 "ticks_per_launch": batch if batch_raster else 1,
@@ -764,7 +764,7 @@ def main():
                                             # (rocprofv3's derived VALUBusy of the same passes: 91 % for this kernel alone on the chip, profiles/r06s_*)
                                             "valu_busy_frac_at_2.4GHz": (valu["active_inst_valu_quadcycles"] * 4.0 / 1024.0 / (raster_ms * 1e-3 * 2.4e9)) if valu.get("active_inst_valu_quadcycles") else None,
                                             "source": valu.get("source")}
-            line["roofline_physics"] = {"bound": "latency", "kernel": ("mv::step_union_kernel" if mixed else "mv::%s (the %d ticks of a call in %d launch%s; per tick)" % (ticks_kernel_name, batch, (batch + 7) // 8, "es of 8" if batch > 8 else "") if batch_step else "mv::step_kernel") +
+            line["roofline_physics"] = {"bound": "latency", "kernel": (("mv::step_union_ticks_kernel (the k ticks of all scenarios in one launch; per tick)" if batched and n_env <= 1024 else "mv::step_union_kernel") if mixed else "mv::%s (the %d ticks of a call in %d launch%s; per tick)" % (ticks_kernel_name, batch, (batch + 7) // 8, "es of 8" if batch > 8 else "") if batch_step else "mv::step_kernel") +
                                                               " (voxel physics + scenario logic + auto-reset + frame setup)", "ticks_per_launch": min(batch, 8) if batch_step else 1, "achieved": achieved_step,
                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_step / HBM_PEAK_GBS, "traffic": traffic_step,
                                         "avg_launch_ms": step_ms, "launches_timed": prof["step"][1], "algorithmic_bytes_per_launch": step_bytes_per_env * n_env,
