@@ -79,8 +79,8 @@ class MultiTaskGym:
     def set_output_ring(self, count):
         """Rollout rings, one set per scenario (mv_set_output_ring): tick t of sub-gym k leaves its observations in ``ring_obs[k][t % count]``
         ([count, n_k * A, h, w, 4] uint8), its rewards in ``ring_rewards[k][t % count]`` and its dones in ``ring_dones[k][t % count]``.  With rings at
-        least as deep as a call, ``step_n`` is TWO launches for all scenarios and all of its ticks (one union step launch, one union observation
-        launch).  count = 0: back to the shared slab.  -> (ring_obs, ring_rewards, ring_dones), lists of CUDA tensors."""
+        least as deep as a call (of 2 ... 8 ticks; up to 1024 envs in the group), ``step_n`` is TWO launches for all scenarios and all of its ticks (one union
+        step launch, one union observation launch); otherwise two launches per tick.  count = 0: back to the shared slab.  -> (ring_obs, ring_rewards, ring_dones), lists of CUDA tensors."""
         import torch
         if count <= 0:
             for g in self.gyms:
