@@ -217,11 +217,12 @@ class ObsGather:
     slab; before slab b is rendered into again the compute stream waits for its gather.  CPU / gloo (dry run): same bookkeeping
     with async work handles."""
 
-    def __init__(self, dist, torch, local_shape, world, device, cuda, mode="allgather", channels=4):
+    def __init__(self, dist, torch, local_shape, world, device, cuda, mode="allgather", channels=4, local=None):
         self.dist, self.torch, self.cuda, self.mode, self.world = dist, torch, cuda, mode, world
         self.rank = dist.get_rank() if world > 1 else 0
         self.n_local = local_shape[0]
-        self.local = [torch.zeros(local_shape, dtype=torch.uint8, device=device) for _ in range(2)]
+        # local: the two buffers the gym renders into, handed in -- the two halves of a batched call's output ring, k slabs each: ONE collective per call of k ticks
+        self.local = local if local is not None else [torch.zeros(local_shape, dtype=torch.uint8, device=device) for _ in range(2)]
         # channels = 3: what travels is R, G, B (alpha is 255 everywhere): a packing kernel on the communication stream, 3/4 of the link traffic
         self.channels = channels
         sent_shape = tuple(local_shape[:-1]) + (channels,)
@@ -296,6 +297,15 @@ class DryGym:
     def sample_random_actions(self, seed, i): self.i = i
     def step(self): self.buf.fill_((self.rank * 31 + self.i) % 251)
     def close(self): pass
+    # batched calls into an output ring (the gather-on leg of N > 1 runs them like the N = 1 headline: one collective per call)
+    def recommended_ticks_per_call(self): return 4
+    def recommended_pass_overlap(self): return False
+    def set_ring_tensor(self, ring): self.ring, self.tick = ring, 0
+
+    def step_n(self, k, policy, seed, first):
+        for j in range(k):
+            self.ring[self.tick % self.ring.shape[0]].fill_((self.rank * 31 + first + j) % 251)
+            self.tick += 1
 
 
 def main():
@@ -329,7 +339,7 @@ def main():
                     help="ticks per stepping call (mv_step_n): every tick is stepped and rendered in full, the two stream hand-overs are paid once "
                          "per call; 1 = one mv_step per tick; 0 (default) = 16 (8 where a call's 16 observation slabs would exceed ~1 GB), the first calls after a synchronisation 2, 4 and 6 ticks (the observation "
                          "passes of a call start when its ticks are stepped: short first calls fill the pipeline sooner; 20-step runs: 20.0-20.25 M obs/s "
-                         "against 19.0 M with 2 ticks per call throughout).  N>1 with the gather on always steps tick by tick")
+                         "against 19.0 M with 2 ticks per call throughout).  N>1: calls of that many ticks throughout, with the gather on one collective per call (the call's half of a ring of 2 x batch slabs)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the single-step / unpipelined / closed-loop transparency legs")
     ap.add_argument("--profile-steps", type=int, default=256, help="steps of the untimed per-kernel profile loop (HIP events on the gym's stream)")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo run of the launcher + gather pipeline with a stand-in gym")
@@ -377,9 +387,10 @@ def main():
     # step launch is (it grows per tick with the call's length).  Measured, 16 against 8 (M obs/s, `profiles/r08y_*`, `r08p`): TowerBuilding 1024 envs 28.5 / 26.8,
     # ObstaclesHard 1024 24.5 / 22.7, Rearrange 23.7 / 21.5, Collect 15.0 / 14.5; 512 envs 16.2 / 19.3, ObstaclesHard 512 13.2 / 18.8, Sokoban 19.9 / 25.9,
     # 512 envs x 4 agents 19.5 / 26.0, 4096 envs 28.4 / 30.5.  Hence: 1024 ... 2047 frames, not Sokoban.
-    batch = args.batch if args.batch > 0 else (16 if 1024 <= frames < 2048 and not mixed and args.scenario.lower() != "sokoban" else 8)
-    os.environ.setdefault("MV_PIPE_BATCH", str(max(8, min(16, batch))))
-    batch = min(batch, int(os.environ["MV_PIPE_BATCH"]))
+    # The rule itself lives behind the ABI (mv_recommended_ticks_per_call, include/megaverse_hip.h): --batch 0 asks the library, after the gym exists; an explicit
+    # --batch sizes the gym's slot groups for it (MV_PIPE_BATCH, read by mv_create).
+    if args.batch > 0:
+        os.environ.setdefault("MV_PIPE_BATCH", str(max(8, min(16, args.batch))))
     if dry:
         gym = DryGym(rank)
     elif mixed:   # BASELINE.json configs[4]: the eight MEGAVERSE8 scenarios dealt round-robin by env index
@@ -396,26 +407,46 @@ def main():
         gym.set_pixel_mode(args.pixels)
         gym.set_sample_policy(args.policy)
 
-    do_gather = world > 1 and not args.no_gather_obs
-    gather = ObsGather(dist, torch, (frames, H, W, 4), world, "cpu" if single else device, cuda=not dry and not single, mode=args.gather,
-                       channels=3 if args.gather_format == "rgb" else 4) if world > 1 else None
-    if gather and single:   # the gym renders into device slabs; their host copies are what gloo gathers
-        slabs = [torch.zeros((frames, H, W, 4), dtype=torch.uint8, device=device) for _ in range(2)]
+    if dry:
+        batch = args.batch if args.batch > 0 else 8
     else:
-        slabs = gather.local if gather else [torch.zeros((frames, H, W, 4), dtype=torch.uint8, device=device)]
+        batch = min(args.batch, int(os.environ["MV_PIPE_BATCH"])) if args.batch > 0 else gym.recommended_ticks_per_call()
+
+    do_gather = world > 1 and not args.no_gather_obs
     # batched stepping: tick j of a call renders into slab j of a ring, so that all `batch` observations of a call exist side by side when it
     # is done (a k-step rollout buffer) -- the working set of the observation writes is batch x one slab, not one slab written over and over
-    batched = batch > 1 and not dry
+    batched = batch > 1 and (not dry or world > 1)
+    # N > 1 with the gather on: the SAME batched calls as the N = 1 headline -- a call renders its k ticks into one half of a ring of 2 k slabs
+    # while the collective for the other half (the previous call's k slabs) runs on the communication stream: one collective per call, not one per tick
+    gather_batched = do_gather and batched and not mixed
     # (slabs of the output ring: a call never holds more ticks than `batch`; two calls deep, the passes of consecutive calls overlap: mv_set_pass_overlap)
-    pass_overlap = batched and not mixed and (args.pass_overlap == "on" or (args.pass_overlap == "auto" and (args.scenario.lower().startswith("obstacles") or args.scenario.lower() == "sokoban")))
-    ring_slots = (max(batch, 8) * (2 if pass_overlap else 1)) if batched else 1
+    pass_overlap = batched and not mixed and (args.pass_overlap == "on" or (args.pass_overlap == "auto" and gym.recommended_pass_overlap()))   # (the rule: mv_recommended_pass_overlap)
+    if gather_batched:
+        pass_overlap = False   # (the ring's two halves belong to the gather pipeline)
+    ring_slots = 2 * batch if gather_batched else (max(batch, 8) * (2 if pass_overlap else 1)) if batched else 1
     ring = torch.zeros((ring_slots, frames, H, W, 4), dtype=torch.uint8, device=device) if batched and not mixed else None   # (Mixed: one slab, no ring)
+    gather = None
+    if world > 1:
+        gdev, gch = "cpu" if single else device, 3 if args.gather_format == "rgb" else 4
+        if gather_batched:   # a buffer = one half of the ring: `batch` slabs (single-device tests: host copies of the halves are what gloo gathers)
+            halves = None if single else [ring[h * batch:(h + 1) * batch].view(batch * frames, H, W, 4) for h in range(2)]
+            gather = ObsGather(dist, torch, (batch * frames, H, W, 4), world, gdev, cuda=not dry and not single, mode=args.gather, channels=gch, local=halves)
+        else:
+            gather = ObsGather(dist, torch, (frames, H, W, 4), world, gdev, cuda=not dry and not single, mode=args.gather, channels=gch)
+    if gather and not gather_batched and not single:
+        slabs = gather.local
+    elif gather and single and not gather_batched:   # the gym renders into device slabs; their host copies are what gloo gathers
+        slabs = [torch.zeros((frames, H, W, 4), dtype=torch.uint8, device=device) for _ in range(2)]
+    else:
+        slabs = [torch.zeros((frames, H, W, 4), dtype=torch.uint8, device=device)]
     # (rewards and dones get rings, too: a k-step rollout buffer holds all three -- and overlapped passes require it, include/megaverse_hip.h)
     ring_rew = torch.zeros((ring_slots, frames), dtype=torch.float32, device=device) if ring is not None else None
     ring_done = torch.zeros((ring_slots, n_env), dtype=torch.uint8, device=device) if ring is not None else None
 
-    def set_ring():
-        if mixed:   # one set of rings per scenario (MultiTaskGym.set_output_ring): a batched group call is then two launches
+    def set_ring():   # (also restarts the ring at entry 0: a region of batched gather calls begins with half 0)
+        if dry:
+            gym.set_ring_tensor(ring)
+        elif mixed:   # one set of rings per scenario (MultiTaskGym.set_output_ring): a batched group call is then two launches
             gym.set_output_ring(ring_slots)
         else:
             gym.set_output_ring(ring_slots, ring.data_ptr(), ring_rew.data_ptr(), ring_done.data_ptr())
@@ -457,14 +488,33 @@ def main():
         if not dry:
             torch.cuda.synchronize()
 
+    last_call = {}   # the last gathered call of a batched gather region: ring half, ticks, first step index
+
     def run_steps(first, n, with_gather, use_batch):
+        if use_batch and with_gather:
+            # one collective per CALL: call c renders its k ticks into half c & 1 of the ring (entries (c & 1) k ...: the ring restarts with every region) while the
+            # collective of the previous call's half runs on the communication stream; the step / observation launches are the N = 1 headline's
+            set_ring()
+            i = c = 0
+            while i < n:
+                kk = min(batch, n - i)
+                h = c & 1
+                gather.before_render(h)
+                gym.step_n(kk, args.policy, 1234, first + i)
+                if single:
+                    gather.local[h].copy_(ring[h * batch:(h + 1) * batch].view(batch * frames, H, W, 4))   # (device -> host on the gym's stream, synchronous)
+                gather.after_render(h)
+                last_call.update(half=h, ticks=kk, first=first + i)
+                i += kk
+                c += 1
+            return
         if use_batch and not with_gather:
             i = 0
             # A region starts right after a synchronisation, with an empty pipeline: its first observation pass can only start when the first call's
             # ticks are stepped, so the first calls are short -- 2 ticks, then 4, then 6, then --batch (measured on 20-step runs, three each, r07c:
             # 2,4,6: 20.8-21.0 M obs/s; 1,3: 20.3-21.6; 1,3,4,4: 20.9; 3,8: 20.3-20.9; 2,2,4,4: 20.1-20.2; r05k: 19.0-19.1 M with 2 ticks per call throughout
             # and 19.2-19.7 M with 8).  MV_BENCH_CALL_SCHEDULE=a,b,...: other first calls.
-            sched = [int(x) for x in os.environ.get("MV_BENCH_CALL_SCHEDULE", "2,4,6").split(",") if x]
+            sched = [int(x) for x in os.environ.get("MV_BENCH_CALL_SCHEDULE", "2,4,6" if world == 1 else "").split(",") if x]   # (N > 1: calls of `batch` ticks throughout, like the gather-on leg)
             while i < n:
                 k = min(sched.pop(0) if sched else batch, n - i, max(batch, 8))
                 gym.step_n(k, args.policy, 1234, first + i)
@@ -485,8 +535,8 @@ def main():
         return float(t.item())
 
     step0 = 0
-    main_batched = batched and not do_gather
-    if main_batched and (ring is not None or mixed):
+    main_batched = batched and (not do_gather or gather_batched)
+    if main_batched and not gather_batched and (ring is not None or mixed):
         set_ring()
         if pass_overlap:
             gym.set_pass_overlap(True)
@@ -528,7 +578,7 @@ def main():
     mixed_ring_checksum = 0
     if batched and mixed and getattr(gym, "ring_obs", None):
         mixed_ring_checksum = sum(int(r[:, ::97].to(torch.int64).sum().item()) for r in gym.ring_obs)
-    if batched and (ring is not None or mixed):
+    if batched and not dry and (ring is not None or mixed):
         gym.set_output_ring(0)
         bind(0)
 
@@ -621,11 +671,56 @@ def main():
             for h in halves:
                 h[0].close()
 
+    # env_step / env_step_batched: what a drop-in user of the reference's Python class calls (megaverse/megaverse_env.py:132-162 <->
+    # megaverse_amd/megaverse_env.py).  env_step: MegaverseEnv.step(list of per-agent actions) -> (list of per-agent (3, H, W) numpy frames, rewards, dones, infos) --
+    # the reference's exact shape, which here includes ONE device-to-host copy of the whole RGBA slab per step over PCIe (the reference's getObservation is a view of
+    # host memory, megaverse.cpp:139-143: its frames never leave the host) and the per-agent list building; env_step_batched: step_batched(device action tensor) ->
+    # (device view of the slab, rewards, dones): observations stay in HBM, two small read-backs per step.  Actions are drawn ahead (the sampler is not the surface).
+    if not dry and not mixed and world == 1 and not args.no_extra_legs:
+        import numpy as np
+        from megaverse_amd.megaverse_env import MegaverseEnv
+        env = MegaverseEnv(args.scenario, n_env, A, 0, False, None, img_w=W, img_h=H, device=local_rank)
+        env.env.set_pixel_mode(args.pixels)
+        env.seed(42)
+        env.reset()
+        rng = np.random.RandomState(7)
+        sizes_np = np.array([3, 3, 3, 2, 2, 3])
+        host_acts = [[tuple(int(v) for v in row) for row in (rng.randint(0, 1 << 30, size=(frames, 6)) % sizes_np)] for _ in range(4)]
+        dev_acts = [torch.from_numpy((rng.randint(0, 1 << 30, size=(frames, 6)) % sizes_np).astype(np.int32)).to(device) for _ in range(4)]
+        n_env_steps = max(10, min(args.steps, 100))
+        for i in range(5):
+            env.step(host_acts[i % 4])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_env_steps):
+            obs_list, rew, dn, inf = env.step(host_acts[i % 4])
+        torch.cuda.synchronize()
+        extra_env = {"env_step": (time.perf_counter() - t0, n_env_steps)}
+        assert len(obs_list) == frames and obs_list[0].shape == (3, H, W) and len(dn) == frames and len(inf) == frames
+        for i in range(5):
+            env.step_batched(dev_acts[i % 4])
+        torch.cuda.synchronize()
+        n_b = max(10, min(args.steps, 400))
+        t0 = time.perf_counter()
+        for i in range(n_b):
+            obs_t, rew, dn = env.step_batched(dev_acts[i % 4])
+        torch.cuda.synchronize()
+        extra_env["env_step_batched"] = (time.perf_counter() - t0, n_b)
+        assert tuple(obs_t.shape) == (frames, 3, H, W) and obs_t.is_cuda
+        env.close()
+    else:
+        extra_env = {}
+
     checksum = int(slabs[0][::97].to(torch.int64).sum().item())   # touch the result so nothing is optimised away
     if ring is not None:
         checksum += int(ring[:, ::97].to(torch.int64).sum().item())
     checksum += mixed_ring_checksum
-    if dry and do_gather:   # every rank's shard of the last gathered step must have arrived, in rank order
+    if dry and do_gather and gather_batched:   # every rank's half-ring of the last gathered call must have arrived, in rank order, tick by tick
+        g0 = gather.out[last_call["half"]].view(world, batch, frames, H, W, -1)
+        for r in range(world):
+            for j in range(last_call["ticks"]):
+                assert int(g0[r, j, 0, 0, 0, 0]) == (r * 31 + last_call["first"] + j) % 251, "gathered ring half does not hold rank %d's tick %d" % (r, j)
+    elif dry and do_gather:   # every rank's shard of the last gathered step must have arrived, in rank order
         g0 = gather.out[last_gathered & 1]
         for r in range(world):
             assert int(g0[r * frames, 0, 0, 0]) == (r * 31 + last_gathered) % 251, "gathered slab does not hold rank %d's shard" % r
@@ -643,7 +738,10 @@ def main():
         for i in range(last_gathered + 1):
             big.sample_random_actions(1234, i); big.step()
         big.synchronize(); torch.cuda.synchronize()
-        got = gather.out[last_gathered & 1].cpu()
+        if gather_batched:   # the last tick of the last gathered call: slab (ticks - 1) of every rank's half
+            got = gather.out[last_call["half"]].view(world, batch, frames, H, W, -1)[:, last_call["ticks"] - 1].reshape(world * frames, H, W, -1).cpu()
+        else:
+            got = gather.out[last_gathered & 1].cpu()
         gather_check = bool(torch.equal(got, whole.cpu()[..., :got.shape[-1]])) and int(got[..., :3].max()) > 0
         big.close()
 
@@ -677,7 +775,7 @@ def main():
                        **({"ring_slots": ring_slots, "overlapped_passes": bool(pass_overlap)} if main_batched else {}),
                        **({"first_calls": os.environ.get("MV_BENCH_CALL_SCHEDULE", "2,4,6") + " ticks, then ticks_per_call (every tick stepped and rendered in full)"} if main_batched else {}),
                        # (a batched group call is two launches where all of the group's envs are resident at once -- up to 1024 -- else two per tick: mv_api_step.hip, groupBatch)
-                       **({"launches_per_call": 2 if main_batched and n_env <= 1024 else None, "launches_per_tick": None if main_batched and n_env <= 1024 else 2,
+                       **({"launches_per_call": 2 * ((batch + 7) // 8) if main_batched and n_env <= 1024 else None, "launches_per_tick": None if main_batched and n_env <= 1024 else 2,
                            "scenarios": ", ".join(gym.scenarios) + " dealt round-robin by env index (one gym per scenario, stepped as one mv_group: "
                                         + ("one step launch and one observation launch per batched CALL, every scenario's ticks in its own rollout rings)" if main_batched and n_env <= 1024
                                            else "one step launch and one raster launch per tick)")} if mixed else {}),
@@ -686,6 +784,12 @@ def main():
         for key, el in extra.items():
             line["value_" + key] = total_obs / el
             line["ms_per_step_" + key] = el / args.steps * 1e3
+        for key, (el, n) in extra_env.items():   # (their own step counts: the reference-shaped leg moves 64 MB over PCIe per step)
+            line["value_" + key] = frames * n / el
+            line["ms_per_step_" + key] = el / n * 1e3
+        if extra_env:
+            line["env_step_note"] = ("value_env_step = megaverse_amd.MegaverseEnv.step(list of actions): the reference's Python surface, incl. one device-to-host copy of the RGBA slab "
+                                     "(%.0f MB over PCIe per step) and the per-agent lists; value_env_step_batched = step_batched(device action tensor): observations stay in HBM" % (frames * H * W * 4 / 1e6))
         if "closed_loop" in extra:
             line["host_enqueue_ms_per_step_closed_loop"] = host_enqueue_ms_loop
         if "closed_loop_double_buffered" in extra:
@@ -719,9 +823,15 @@ def main():
                               "achieved_GBps_per_gpu": (world - 1) * slab_bytes / (elapsed / args.steps) / 1e9,
                               "xgmi_peak_GBps_per_gpu": XGMI_PEAK_GBS,
                               # what the links allow: every GPU receives (world - 1) shards per step over its 7 point-to-point links
-                              "xgmi_bound_ms_per_step": (world - 1) * slab_bytes / (XGMI_PEAK_GBS * 1e9) * 1e3}
+                              "xgmi_bound_ms_per_step": (world - 1) * slab_bytes / (XGMI_PEAK_GBS * 1e9) * 1e3,
+                              # the gather-on leg runs the N = 1 headline's batched calls: ONE collective per call of ticks_per_call ticks (the call's half of a ring of
+                              # 2 x ticks_per_call slabs) beside the next call's launches; tick by tick (Mixed, --batch 1): one collective per tick
+                              "collectives_per_call": 1, "ticks_per_collective": batch if gather_batched else 1,
+                              "bytes_received_per_gpu_per_collective": (world - 1) * slab_bytes * (batch if gather_batched else 1),
+                              "xgmi_bound_ms_per_collective": (world - 1) * slab_bytes * (batch if gather_batched else 1) / (XGMI_PEAK_GBS * 1e9) * 1e3,
+                              "measured_on": "gloo / host copies (single-device test run)" if single else "CPU stand-in (dry run)" if dry else "RCCL over xGMI"}
         if prof is not None:
-            traffic = traffic_step = valu = None
+            traffic = traffic_step = valu = lds = None
             try:   # per-launch PMC figures from the committed rocprofv3 passes (profiles/), only for the profiled config
                 pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
                 pmc_stale = pt.get("source_sha16") != kernel_sources_sha16()   # counters of other sources are not this run's: traffic / valu stay null
@@ -729,6 +839,7 @@ def main():
                     traffic = pt["kernels"].get("raster", {}).get("traffic_bytes_per_launch")
                     traffic_step = pt["kernels"].get("step", {}).get("traffic_bytes_per_launch")
                     valu = pt["kernels"].get("raster", {}).get("valu")
+                    lds = pt["kernels"].get("raster", {}).get("lds")
             except Exception:  # noqa: BLE001
                 pass
             raster_ms, step_ms = prof["raster"][0], prof["step"][0]
@@ -764,6 +875,8 @@ def main():
                                             # (rocprofv3's derived VALUBusy of the same passes: 91 % for this kernel alone on the chip, profiles/r06s_*)
                                             "valu_busy_frac_at_2.4GHz": (valu["active_inst_valu_quadcycles"] * 4.0 / 1024.0 / (raster_ms * 1e-3 * 2.4e9)) if valu.get("active_inst_valu_quadcycles") else None,
                                             "source": valu.get("source")}
+            if lds:   # north_star: "LDS hit rate on the raster tile" -- an LDS access has no miss, only bank-conflict replays: the counters of the committed SQ passes, per tick
+                line["roofline"]["lds"] = dict(lds, note="LDS instructions per tick (wave-level), quad-cycles the LDS pipe was busy / replaying bank conflicts; hit rate = 1 - conflict_frac")
             line["roofline_physics"] = {"bound": "latency", "kernel": (("mv::step_union_ticks_kernel (the k ticks of all scenarios in one launch; per tick)" if batched and n_env <= 1024 else "mv::step_union_kernel") if mixed else "mv::%s (the %d ticks of a call in %d launch%s; per tick)" % (ticks_kernel_name, batch, (batch + 7) // 8, "es of 8" if batch > 8 else "") if batch_step else "mv::step_kernel") +
                                                               " (voxel physics + scenario logic + auto-reset + frame setup)", "ticks_per_launch": min(batch, 8) if batch_step else 1, "achieved": achieved_step,
                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_step / HBM_PEAK_GBS, "traffic": traffic_step,
@@ -782,8 +895,7 @@ def main():
         line["checksum"] = checksum
         if world == 1 and not args.no_cpu_baseline and not dry:
             if mixed:
-                from megaverse_amd.multitask import MEGAVERSE_IN_SCOPE as _MT
-                line["cpu_baseline"] = cpu_baseline_mixed(_MT, W, H, n_env, A)
+                line["cpu_baseline"] = cpu_baseline_mixed(list(gym.scenarios), W, H, n_env, A)   # (the same scenario set the GPU gym ran: Mixed4's four, not the eight)
             else:
                 line["cpu_baseline"] = cpu_baseline(args.scenario, W, H, n_env, A, args.policy, full=args.cpu_baseline_full)
         print(json.dumps(line), flush=True)

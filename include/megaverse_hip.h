@@ -87,7 +87,7 @@ int mv_step_many(mv_gym *const *gyms, int32_t n, int32_t render, int32_t sample,
 
 /* Groups: up to 8 gyms of one job -- one per scenario of a multi-task batch, the reference's layout (megaverse/megaverse_env.py:27-39: one
  * MegaverseGym per task) -- stepped TOGETHER: one step launch and one observation launch per tick for all of them -- per CALL of 2..8 ticks
- * when every member has output rings (mv_set_output_ring) at least that deep -- on one shared pair of streams (BASELINE.json configs[4]: scenarios dealt round-robin over the envs of one batch; every gym keeps its env_offset /
+ * when every member has output rings (mv_set_output_ring) at least that deep and the group holds at most 1024 envs (all resident at once; a longer call is split into chunks of 8) -- on one shared pair of streams (BASELINE.json configs[4]: scenarios dealt round-robin over the envs of one batch; every gym keeps its env_offset /
  * env_stride, so seeds and sampled actions are the job-wide ones).  The members must share device, observation size, agents per env and
  * stream.  While grouped a gym is stepped through the group only; everything else (reset, seed, getters, shaping) stays per gym.
  * mv_group_step: k ticks like mv_step_n (render = 0: no observation pass).  Closing a member dissolves the group. */
@@ -103,7 +103,7 @@ int mv_step_no_render(mv_gym *g);                   /* physics/logic/auto-reset 
  * step kernel and renders every agent's observation.  Exactly the ticks k calls of mv_sample_random_actions + mv_step make -- but the
  * simulation stream and the caller's stream hand over to each other once per call instead of once per tick.  policy
  * MV_POLICY_NONE: the first tick acts on what mv_set_actions* left, the others on cleared actions.  The public arrays hold the LAST tick's
- * outputs -- or, with mv_set_output_ring, every tick's.  k may exceed the internal batch (MV_PIPE_BATCH, default 16): the call splits it. */
+ * outputs -- or, with mv_set_output_ring, every tick's.  k may exceed the internal batch (mv_recommended_ticks_per_call; MV_PIPE_BATCH overrides its sizing): the call splits it. */
 int mv_step_n(mv_gym *g, int32_t k, int32_t policy, uint32_t seed, uint32_t first_step_index);
 /* Rollout rings (no reference counterpart: its learner copies each step's observation out of the gym, megaverse_env.py:121-130): tick
  * number t since this call leaves its observations in obs[t % count] ([count][N*A][h][w][4]), its rewards in rewards[t % count] ([count][N*A])
@@ -117,6 +117,15 @@ int mv_set_output_ring(mv_gym *g, int32_t count, void *obs, float *rewards, uint
  * consumed -- the consumer enqueued on the caller's stream -- before the NEXT stepping call after the one that produced it is issued (without
  * overlap: before the call that overwrites it).  No reference counterpart (the reference renders synchronously, vector_env.cpp:112-118). */
 int mv_set_pass_overlap(mv_gym *g, int32_t on);
+/* What a caller who just wants throughput should ask mv_step_n for -- the measured rules that used to live in bench.py (no reference counterpart):
+ * mv_recommended_ticks_per_call: 16 (one tail of the one-launch observation pass per 16 ticks) for 1024 .. 2047 agent frames per tick where the gym's slot groups hold
+ * 16 (mv_create sizes them by footprint, MV_PIPE_BATCH overrides) and the scenario is not Sokoban; 8 otherwise; 1 where episodes can end within a few ticks
+ * (such gyms are stepped tick by tick whatever k says).  A gym in a group: at most 8 (the two-launch group call's limit, and only while the group's envs are
+ * all resident at once: 1024).  mv_recommended_pass_overlap: 1 for the Obstacles family and Sokoban (short passes: the next call's may begin in the tail), else 0.
+ * mv_arena_bytes: the device memory this gym holds (state + the hand-over slots of PIPE_GROUPS x ticks-per-call ticks + its own observation slab). */
+int mv_recommended_ticks_per_call(const mv_gym *g);
+int mv_recommended_pass_overlap(const mv_gym *g);
+int64_t mv_arena_bytes(const mv_gym *g);
 int mv_render(mv_gym *g);                           /* observation pass only */
 
 int mv_is_done(mv_gym *g, int32_t env_idx);         /* isDone(), :123-126 -> 0/1, <0 on error */

@@ -305,18 +305,15 @@ int mv_create(const mv_config *cfg, mv_gym **out)
                    : scenario == SCN_COLLECT ? SHAPING_KEYS_COLLECT : scenario == SCN_SOKOBAN ? SHAPING_KEYS_SOKOBAN
                    : scenario == SCN_HEX_MEMORY ? SHAPING_KEYS_HEX_MEMORY : scenario == SCN_HEX_EXPLORE ? SHAPING_KEYS_HEX_EXPLORE
                    : scenario == SCN_EMPTY ? SHAPING_KEYS_EMPTY : SHAPING_KEYS_REARRANGE;
+    // Resident episodes per env: two where an episode ends at its time limit only (TowerBuilding, Empty); THREE where a goal can end it early (the exit pad, every
+    // diamond collected, the level solved, the arrangement matched, the maze's target found): the host's run-ahead is bounded in TICKS (refill_episodes), the status
+    // words are read back every 16th, and a lucky env can finish twice inside that window -- a third resident episode covers it where two starved.
+    g->spares = scenario == SCN_TOWER || scenario == SCN_EMPTY ? 2 : 3;
     g->envOffset = cfg->total_envs > 0 ? cfg->env_offset : 0;
     g->envStride = cfg->total_envs > 0 && cfg->env_stride > 1 ? cfg->env_stride : 1;
     g->gv.sample_on = 0; g->gv.sample_seed = g->gv.sample_step = 0;
     g->gv.env_offset = g->envOffset; g->gv.env_stride = g->envStride;
     g->totalEnvs = cfg->total_envs > 0 ? cfg->total_envs : cfg->num_envs;
-    if (const char *e = getenv("MV_PIPE_BATCH")) g->batch = std::min((int)PIPE_BATCH_MAX, std::max(1, atoi(e)));   // ticks per call of mv_step_n
-    g->slots = PIPE_GROUPS * g->batch;
-    g->hists = g->slots + 1;
-    g->histClean.assign((size_t)g->hists, 1);   // (the arena is zeroed below)
-    g->gvp.resize((size_t)g->slots);
-    g->parity = g->slots - 1;
-    g->group = PIPE_GROUPS - 1;
     const size_t N = g->N, NA = (size_t)g->N * g->A;
 
     GymView &gv = g->gv;
@@ -348,7 +345,19 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     const size_t szVisP = up(NA * (size_t)gv.vis_stride * 32), szVisR = up(NA * (size_t)gv.vis_stride * 8), szVisC = up(NA * sizeof(int32_t)),
                  szLpt = up(NA * sizeof(int32_t)) + up((NA + 1) * sizeof(int32_t)) + up(NA * (size_t)FRAME_HDR_BYTES) + up((size_t)LPT_BUCKETS * LPT_SUBS * lpt_sub_capacity(NA) * sizeof(int32_t));
     // per slot: frame lists, headers, cost lists, and the staging copies of rewards / dones / true objectives
-    const size_t szParity = szVisP + szVisR + szVisC + szLpt + szRew + szDone + szObjv, szHist = up((size_t)g->hists * (LPT_BUCKETS * LPT_SUBS + 1) * sizeof(int32_t));   // (+ one "workgroups that have looked their frame up" counter per histogram, behind them)
+    const size_t szParity = szVisP + szVisR + szVisC + szLpt + szRew + szDone + szObjv;
+    // Ticks per call of mv_step_n (`batch`; a gym holds PIPE_GROUPS x batch hand-over slots of szParity bytes each): 16 -- one tail of the one-launch observation
+    // pass per 16 ticks, measured against 8: TowerBuilding 1024 envs 26.6 -> 28.3 M obs/s -- where the 48 slots that takes stay under 1 GiB, else 8 (a Hex frame's
+    // slot is 80 KB: 3.8 GB per 1024 frames at 16; TowerBuilding's 12 KB: 0.6 GB).  MV_PIPE_BATCH=1..16 overrides; mv_recommended_ticks_per_call says what to ask for.
+    g->batch = (size_t)PIPE_GROUPS * 16 * szParity <= (size_t(1) << 30) ? 16 : 8;
+    if (const char *e = getenv("MV_PIPE_BATCH")) g->batch = std::min((int)PIPE_BATCH_MAX, std::max(1, atoi(e)));
+    g->slots = PIPE_GROUPS * g->batch;
+    g->hists = g->slots + 1;
+    g->histClean.assign((size_t)g->hists, 1);   // (the arena is zeroed below)
+    g->gvp.resize((size_t)g->slots);
+    g->parity = g->slots - 1;
+    g->group = PIPE_GROUPS - 1;
+    const size_t szHist = up((size_t)g->hists * (LPT_BUCKETS * LPT_SUBS + 1) * sizeof(int32_t));   // (+ one "workgroups that have looked their frame up" counter per histogram, behind them)
     gv.lpt_hists = g->hists;
     // long lists: the list as found, before the frame setup deals it into depth classes (mv_frame.h: DepthSortScratch); MV_DEPTH_SORT=0: lists stay as found
     const bool depthSortOn = !(getenv("MV_DEPTH_SORT") && atoi(getenv("MV_DEPTH_SORT")) == 0);
@@ -357,7 +366,13 @@ int mv_create(const mv_config *cfg, mv_gym **out)
                          szRewObj + szHeight + szItems + szCells + szHexB + szHexO + szBlobs + szCnt + szGen + (size_t)g->slots * szParity + szHist;
     {
         hipError_t e_ = hipMalloc((void **)&g->arena, total);
-        if (e_ != hipSuccess) { mv_destroy(g); return fail(std::string("hipMalloc arena: ") + hipGetErrorString(e_)); }
+        if (e_ != hipSuccess) {
+            const int b = g->batch;
+            mv_destroy(g);
+            return fail("hipMalloc arena (" + std::to_string(total >> 20) + " MiB, of which " + std::to_string(((size_t)PIPE_GROUPS * b * szParity) >> 20) + " MiB are the " +
+                        std::to_string(PIPE_GROUPS * b) + " hand-over slots of " + std::to_string(b) + " ticks per call: a smaller MV_PIPE_BATCH shrinks them): " + hipGetErrorString(e_));
+        }
+        g->arenaBytes = total;
         (void)hipMemset(g->arena, 0, total);
     }
     {

@@ -102,7 +102,7 @@ struct mv_gym {
     bool simMustWaitUser = true;                 // the caller's stream holds work the next step depends on (reset, render, device actions, ...)
     hipEvent_t simDone = nullptr;                // after the last kernel on simStream
     bool simDoneValid = false;
-    int batch = 16, slots = PIPE_GROUPS * 16, hists = PIPE_GROUPS * 16 + 1;   // slots per group (MV_PIPE_BATCH; 16: one tail of the observation launch per 16 ticks -- measured against 8: TowerBuilding 26.6 -> 28.3 M obs/s, Collect 14.4 -> 15.1), slots, cost histograms
+    int batch = 8, slots = PIPE_GROUPS * 8, hists = PIPE_GROUPS * 8 + 1;   // slots per group (ticks per call: set by mv_create from the slots' footprint, or MV_PIPE_BATCH), slots, cost histograms
     int group = 0;                               // slot group of the last stepping call
     int parity = 0, hist3 = 0;                   // hand-over slot of the last tick; cost histogram of the last pass
     // histClean[h]: cost histogram h is (or, in stream order, will be) all zero when the next frame setup counts into it.  A pass drawn by the
@@ -132,6 +132,7 @@ struct mv_gym {
     hipStream_t ownSimStream = nullptr, ownCopyStream = nullptr;
     hipEvent_t ownUserMark[PIPE_GROUPS] = {}, ownSimDone = nullptr, ownStepDone = nullptr;
     uint8_t *arena = nullptr;
+    size_t arenaBytes = 0;
     uint32_t *obs = nullptr, *ownedObs = nullptr, *hiresObs = nullptr;
     int hiresW = 0, hiresH = 0;
     int fastPixels = 1;                          // mv_set_pixel_mode: 1 = raster_fast_kernel (default), 0 = bit-exact raster_kernel

@@ -405,8 +405,8 @@ int mv_group_create(mv_gym *const *gyms, int32_t n, mv_group **out)
         if (check(g)) return -1;
         if (g->inGroup) return fail("mv_group_create: a gym already belongs to a group");
         for (int j = 0; j < i; ++j) if (gyms[j] == g) return fail("mv_group_create: the same gym twice");
-        if (g->device != L->device || g->w != L->w || g->h != L->h || g->A != L->A || g->stream != L->stream || g->batch != L->batch || g->pipelined != L->pipelined)
-            return fail("mv_group_create: the gyms of a group share device, observation size, agents per env, stream (mv_set_stream first), batch and pipelining");
+        if (g->device != L->device || g->w != L->w || g->h != L->h || g->A != L->A || g->stream != L->stream || g->pipelined != L->pipelined)
+            return fail("mv_group_create: the gyms of a group share device, observation size, agents per env, stream (mv_set_stream first) and pipelining");
     }
     HIP_TRY(hipSetDevice(L->device));
     for (int i = 0; i < n; ++i) {   // nothing in flight on the streams a member is about to leave
@@ -457,7 +457,10 @@ int mv_group_step(mv_group *grp, int32_t k, int32_t render, int32_t policy, uint
     if (!grp || grp->gyms.empty()) return fail("mv_group_step: the group is gone (a member was closed)");
     if (policy != MV_POLICY_NONE && policy != MV_POLICY_MULTIDISCRETE && policy != MV_POLICY_SINGLE_BIT) return fail("mv_group_step: unknown policy");
     if (k < 1) return fail("mv_group_step: k >= 1 required");
-    int chunk = grp->gyms[0]->batch;
+    // A call's chunks: what every member's slot groups hold, and at most MAX_GROUP_TICKS -- the two-launch batched path's limit (raster_union_batch_applicable): a chunk
+    // of 9..16 ticks would fall back to two launches per TICK.
+    int chunk = (int)MAX_GROUP_TICKS;
+    for (mv_gym *g : grp->gyms) chunk = std::min(chunk, g->batch);
     for (mv_gym *g : grp->gyms)
         if (!g->closed && g->statusPeriod <= 1) chunk = 1;   // (episodes of a few ticks: the refill protocol looks at the consumed counts after every tick)
     int rc = 0;
@@ -470,6 +473,26 @@ int mv_group_step(mv_group *grp, int32_t k, int32_t render, int32_t policy, uint
     if (rc) g_err = text;
     return rc;
 }
+
+// the measured rules bench.py used to carry (r08p / r08y: 16 against 8 ticks per call, M obs/s: TowerBuilding 1024 envs 28.5 / 26.8, ObstaclesHard 1024 24.5 / 22.7, Rearrange 23.7 / 21.5,
+// Collect 15.0 / 14.5; 512 envs 16.2 / 19.3, ObstaclesHard 512 13.2 / 18.8, Sokoban 19.9 / 25.9, 512 envs x 4 agents 19.5 / 26.0, 4096 envs 28.4 / 30.5; overlap r07a/b/j)
+int mv_recommended_ticks_per_call(const mv_gym *g)
+{
+    if (!g || g->closed) return 1;
+    if (g->statusPeriod <= 1) return 1;
+    const int frames = g->N * g->A;
+    int k = frames >= 1024 && frames < 2048 && g->scenario != SCN_SOKOBAN ? 16 : 8;
+    if (g->inGroup) k = std::min(k, (int)MAX_GROUP_TICKS);
+    return std::max(1, std::min(k, g->batch));
+}
+
+int mv_recommended_pass_overlap(const mv_gym *g)
+{
+    if (!g || g->closed || g->inGroup) return 0;
+    return g->scenario == SCN_OBSTACLES || g->scenario == SCN_SOKOBAN ? 1 : 0;
+}
+
+int64_t mv_arena_bytes(const mv_gym *g) { return g ? (int64_t)g->arenaBytes : 0; }
 
 int mv_step_many(mv_gym *const *gyms, int32_t n, int32_t render, int32_t sample, uint32_t seed, uint32_t step_index)
 {   // several gyms of one job (MultiTaskGym: one per scenario, one stream each) stepped by one call: at eight sub-gyms the per-call cost of

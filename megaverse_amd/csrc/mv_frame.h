@@ -204,7 +204,10 @@ __device__ __forceinline__ int depth_class(float d)   // d >= NEAR_Z: 0 .. 63, f
 }
 __device__ __forceinline__ float depth_class_floor(int c) { return __uint_as_float((unsigned)(c + (120 << 2)) << 21); }
 
-template <int THREADS, bool WAVE_LOCAL>
+// PIPE (the software-pipelined multi-tick step kernels, mv_step.hip: step_ticks_pipe_kernel): this wave sets tick j's frame up WHILE the env's tick wave
+// computes tick j + 1; everything read from the simulator state (header, agents, box / object / reward records) is loaded before one workgroup
+// barrier -- in the last round of slots, behind its record loads --, which the tick wave meets before it writes tick j + 1's state back.
+template <int THREADS, bool WAVE_LOCAL, bool PIPE = false>
 __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int frame, const int W, const int H, FrameScratch &fs, DepthSortScratch *ds = nullptr)
 {
     static_assert(!WAVE_LOCAL || THREADS == 64, "a wave-local frame setup is one wavefront");
@@ -443,6 +446,7 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
             }
         }
         MV_TF(1);   // the slots' records
+        if (PIPE && (rd + 1) * THREADS >= numSlots) __syncthreads();   // the state is read (the loads have returned: the barrier's fences): the tick wave may write the next tick's
         // frame-level visibility
         int cls = 0;
         int rect[4] = {0, 0, 0, 0};

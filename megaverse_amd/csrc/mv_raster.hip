@@ -875,7 +875,11 @@ __device__ __forceinline__ FastFrame fast_prologue(const FastArgs &fa, int blk, 
     // histogram strictly after every reader's data arrived.  (A release / acquire pair at agent scope would be the textbook form; on gfx950 it is a
     // buffer_wbl2 + buffer_inv per workgroup -- an L2 write-back in the middle of 8192 workgroups' pixel stores -- for an ordering the data dependence
     // already gives.)  The zeroing itself is ordered against the next writer -- the frame setups of a later step launch -- by the kernel boundary.
+#ifdef MV_HIST_FENCE   // (the textbook form, for the A/B measurement DESIGN.md 3.3 quotes: release / acquire at agent scope on the count)
+    if (tid == 0) s_lastWG = fa.hist_done != nullptr && __hip_atomic_fetch_add(fa.hist_done, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == fa.wg_total - 1;
+#else
     if (tid == 0) s_lastWG = fa.hist_done != nullptr && __hip_atomic_fetch_add(fa.hist_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fa.wg_total - 1;
+#endif
     const int frame = __builtin_amdgcn_readfirstlane(s_frame);
     const int viewer = frame % A;
     const float *gh = reinterpret_cast<const float *>(fa.vis_hdr + (size_t)frame * FRAME_HDR_BYTES);

@@ -143,13 +143,19 @@ __device__ __forceinline__ void tower_draw(const GymView &gv, int env, int seq)
     // value the next Env::reset() will draw; nothing consumes the env rng during an episode
     const uint32_t nextSeed = (uint32_t)rand_range(g, 0, 1 << 30);
 
+    // `seq` PUBLISHES the episode: every lane's stores to the blob (objects, spawns) are released at agent scope before lane 0 writes it, and tower_swap_in
+    // acquires after it has read it -- the host's launch order (the draw before the last one is waited for) already keeps a step kernel off a blob that is being
+    // drawn; should a starved env ever race a running draw, it sees seq unset (ST_STARVED) or the whole episode, never a torn one.  Once per episode.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    wave_sync();
     if (lane == 0) {
         blob->L = length; blob->H = height; blob->W = width;
         blob->bz[0] = bz[0]; blob->bz[1] = bz[1]; blob->bz[2] = bz[2]; blob->bz[3] = bz[3];
         blob->layout_color = (int)layoutColor; blob->wall_color = (int)wallColor; blob->draw_walls = drawWalls ? 1 : 0;
         blob->num_objects = numObjects;
         blob->bz_reward = bzReward;
-        blob->seq = seq;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_store(&blob->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         tg->seed = nextSeed; tg->seed_is_env_seed = 0; tg->generated = seq;
     }
     wave_sync();   // (the LDS arrays are reused by the next draw of this wave)
@@ -164,10 +170,11 @@ __device__ __forceinline__ bool tower_swap_in(const GymView &gv, int env, int fo
     EnvHeader *hdr = gv.hdr + env;
     const int consumed = hdr->episodes_consumed;
     const TowerBlob *b = reinterpret_cast<const TowerBlob *>(gv.blobs) + (size_t)env * gv.spares + consumed % gv.spares;   // ring slot of episode number consumed + 1
-    if (b->seq != consumed + 1) {
+    if (__hip_atomic_load(&b->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != consumed + 1) {
         if (lane == 0) { hdr->starved |= 1; atomicOr(&gv.episode_status[gv.num_envs + 1], (int)ST_STARVED); }
         return false;
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (pairs with tower_draw's release before it published seq)
     const int A = gv.num_agents;
     const int length = b->L, height = b->H, width = b->W, numObjects = b->num_objects;
     const bool drawWalls = b->draw_walls != 0;

@@ -128,6 +128,42 @@ __device__ __forceinline__ void step_ticks_body(const Args &a, int W, int H)
 template <class Args> __global__ __launch_bounds__(64, MV_STEP_TICKS_WAVES_PER_SIMD) void step_ticks_kernel(Args a, int W, int H) { step_ticks_body<1>(a, W, H); }
 template <class Args> __global__ __launch_bounds__(256, 3) void step_ticks_agents_kernel(Args a, int W, int H) { step_ticks_body<MAX_AGENTS>(a, W, H); }
 
+// Software-pipelined (one agent per env): TWO waves per env.  Wave 0 runs tick j + 1 while wave 1 sets tick j's frame up (mv_frame.h) -- the two halves of a tick's
+// work that step_ticks_body runs back to back in one wave, each a chain of dependent loads and a few thousand vector instructions of ONE wave on its SIMD
+// (48 % of the resident wave's cycles were spent in s_waitcnt, r08z_pmc_SQ2.csv).  The frame setup reads the simulator state in place, so the two waves meet at
+// two workgroup barriers per tick:
+//   A(j): tick j's state is written (wave 0: behind its write-back and the episode swap-in of a finished env; wave 1: before it reads anything)
+//   B(j): tick j's state is read    (wave 1: behind the record loads of its last round of slots; wave 0: before tick j + 1's write-back, tower_tick's pipe_wait)
+// An iteration lasts max(tick, frame setup) instead of their sum; the last frame setup runs alone.
+template <class Args>
+__global__ __launch_bounds__(128, MV_STEP_TICKS_WAVES_PER_SIMD) void step_ticks_pipe_kernel(Args a, int W, int H)
+{
+    __shared__ FrameScratch s_fs;
+    const int env = blockIdx.x;
+#ifdef MV_STEP_PRIO
+    __builtin_amdgcn_s_setprio(MV_STEP_PRIO);
+#endif
+    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) {
+        for (int j = 0; j < a.n; ++j) {
+            tower_tick<1>(a.view(j), env, j > 0);   // (j > 0: B(j - 1) inside, before the write-back)
+            __syncthreads();                        // A(j)
+        }
+        __syncthreads();                            // B(n - 1): the last frame setup's
+    } else {
+        for (int j = 0; j < a.n; ++j) {
+            __syncthreads();                        // A(j)
+            frame_setup_body<64, true, true>(a.view(j), env, W, H, s_fs);   // B(j) inside
+        }
+    }
+}
+
+// MV_STEP_PIPE=0: the one-wave-per-env multi-tick kernels (A/B measurements)
+bool step_pipe_enabled()
+{
+    static const bool on = !(getenv("MV_STEP_PIPE") && atoi(getenv("MV_STEP_PIPE")) == 0);
+    return on;
+}
+
 void launch_step_ticks(const GymView *views, int k, hipStream_t stream, int W, int H, hipEvent_t done)
 {
     const GymView &gv = views[0];
@@ -137,7 +173,8 @@ void launch_step_ticks(const GymView *views, int k, hipStream_t stream, int W, i
     StepTicksArgs8 a;   // (k <= 8: the views are the launch's arguments)
     a.n = k; a.pad = 0;
     for (int j = 0; j < 8; ++j) a.gv[j] = views[std::min(j, k - 1)];
-    if (gv.num_agents == 1) hipExtLaunchKernelGGL(step_ticks_kernel<StepTicksArgs8>, grid, block, 0, stream, nullptr, done, 0, a, W, H);
+    if (gv.num_agents == 1 && step_pipe_enabled()) hipExtLaunchKernelGGL(step_ticks_pipe_kernel<StepTicksArgs8>, grid, dim3(128), 0, stream, nullptr, done, 0, a, W, H);
+    else if (gv.num_agents == 1) hipExtLaunchKernelGGL(step_ticks_kernel<StepTicksArgs8>, grid, block, 0, stream, nullptr, done, 0, a, W, H);
     else hipExtLaunchKernelGGL(step_ticks_agents_kernel<StepTicksArgs8>, grid, block, 0, stream, nullptr, done, 0, a, W, H);
 }
 

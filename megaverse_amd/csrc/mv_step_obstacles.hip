@@ -73,12 +73,38 @@ __global__ __launch_bounds__(64, MV_STEP_TICKS_WAVES_PER_SIMD) void step_obstacl
     }
 }
 
+// software-pipelined: two waves per env, wave 0 ticks while wave 1 sets the previous tick's frame up (mv_step.hip: step_ticks_pipe_kernel)
+template <class Args>
+__global__ __launch_bounds__(128, MV_STEP_TICKS_WAVES_PER_SIMD) void step_obstacles_ticks_pipe_kernel(Args a, int W, int H)
+{
+    __shared__ FrameScratch s_fs;
+    const int env = blockIdx.x;
+#ifdef MV_STEP_PRIO
+    __builtin_amdgcn_s_setprio(MV_STEP_PRIO);
+#endif
+    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) {
+        for (int j = 0; j < a.n; ++j) {
+            obstacles_tick<1>(a.view(j), env, j > 0);
+            __syncthreads();
+        }
+        __syncthreads();
+    } else {
+        for (int j = 0; j < a.n; ++j) {
+            __syncthreads();
+            frame_setup_body<64, true, true>(a.view(j), env, W, H, s_fs);
+        }
+    }
+}
+
+bool step_pipe_enabled();   // mv_step.hip
+
 void launch_step_obstacles_ticks(const GymView *views, int k, hipStream_t stream, int W, int H, hipEvent_t done)
 {
     StepTicksArgs8 a8;   // (k <= 8: the views are the launch's arguments, mv_types.h)
     a8.n = k; a8.pad = 0;
     for (int j = 0; j < 8; ++j) a8.gv[j] = views[std::min(j, k - 1)];
-    hipExtLaunchKernelGGL(step_obstacles_ticks_kernel<StepTicksArgs8>, dim3(views[0].num_envs), dim3(64), 0, stream, nullptr, done, 0, a8, W, H);
+    if (step_pipe_enabled()) hipExtLaunchKernelGGL(step_obstacles_ticks_pipe_kernel<StepTicksArgs8>, dim3(views[0].num_envs), dim3(128), 0, stream, nullptr, done, 0, a8, W, H);
+    else hipExtLaunchKernelGGL(step_obstacles_ticks_kernel<StepTicksArgs8>, dim3(views[0].num_envs), dim3(64), 0, stream, nullptr, done, 0, a8, W, H);
 }
 
 __global__ __launch_bounds__(64) void reset_obstacles_kernel(GymView gv, const EpisodeBlob *blobs, int *status, int force_all)

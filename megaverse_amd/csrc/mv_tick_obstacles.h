@@ -109,8 +109,9 @@ __device__ __forceinline__ void swap_in_episode(const GymView &gv, const Episode
     }
 }
 
+// pipe_wait: see tower_tick (mv_tick_tower.h) -- a workgroup barrier before the tick writes anything the previous tick's frame setup may still be reading
 template <int A_MAX>
-__device__ __forceinline__ void obstacles_tick(const GymView &gv, const int env)
+__device__ __forceinline__ void obstacles_tick(const GymView &gv, const int env, const int pipe_wait = 0)
 {
     const int lane = lane_id();
     if (env >= gv.num_envs) return;
@@ -327,6 +328,7 @@ __device__ __forceinline__ void obstacles_tick(const GymView &gv, const int env)
     ++numFrames;
 
     // ---- write back
+    if (pipe_wait) __syncthreads();
     MovableObject *gobjw = gv.objects + (size_t)env * MAX_OBJECTS;
 #pragma unroll
     for (int k = 0; k < 2; ++k)

@@ -113,8 +113,11 @@ __device__ __forceinline__ bool in_chunk(int x, int y, int z) { return x >= 0 &&
 //     sweeps or depenetration, so the results ARE the sequential loop's.  Should a pair fail (a depenetration push longer than the margin), the
 //     env's agents are restored and stepped again in a row.
 // A launch lasts as long as its slowest env: that used to be A controllers in a row, now the env with the largest group of near agents.
+// pipe_wait (wave-uniform; the software-pipelined multi-tick kernel, mv_step.hip: step_ticks_pipe_kernel): the env's second wave is still reading the
+// state of the previous tick for that tick's frame setup -- this tick computes beside it and meets it at a workgroup barrier before it writes anything
+// the frame setup reads (objects, header, agents; the chunk is the tick's alone).
 template <int A_MAX, bool PAR = false>
-__device__ __forceinline__ void tower_tick(const GymView &gv, const int env)
+__device__ __forceinline__ void tower_tick(const GymView &gv, const int env, const int pipe_wait = 0)
 {
     static_assert(!PAR || A_MAX > 1, "one agent: nothing to share out");
     const int lane = lane_id();
@@ -400,6 +403,7 @@ __device__ __forceinline__ void tower_tick(const GymView &gv, const int env)
 
     MV_T(4);   // fall detection, zone shaping, timers
     // ---- write back
+    if (pipe_wait) __syncthreads();
     MovableObject *gobjw = gv.objects + (size_t)env * MAX_OBJECTS;
 #pragma unroll
     for (int k = 0; k < 2; ++k)

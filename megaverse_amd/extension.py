@@ -42,6 +42,7 @@ SYMBOLS = [
     ("mv_step_n", C.c_int, [_P, _I, _I, _U, _U]), ("mv_set_sample_policy", C.c_int, [_P, _I]),
     ("mv_set_output_ring", C.c_int, [_P, _I, _P, _P, _P]),
     ("mv_set_pass_overlap", C.c_int, [_P, _I]),
+    ("mv_recommended_ticks_per_call", C.c_int, [_P]), ("mv_recommended_pass_overlap", C.c_int, [_P]), ("mv_arena_bytes", C.c_int64, [_P]),
     ("mv_is_done", C.c_int, [_P, _I]), ("mv_get_dones", C.c_int, [_P, _P]),
     ("mv_get_last_rewards", C.c_int, [_P, _P]),
     ("mv_true_objective", C.c_int, [_P, _I, _I, C.POINTER(_F)]), ("mv_get_true_objectives", C.c_int, [_P, _P]),
@@ -289,6 +290,16 @@ class MegaverseGym:
         """with a ring at least two calls deep, the observation passes of consecutive step_n calls overlap (include/megaverse_hip.h: mv_set_pass_overlap);
         an entry must then be consumed before the next stepping call after the one that produced it"""
         self._ck(self._lib.mv_set_pass_overlap(self._g, int(bool(on))))
+
+    def recommended_ticks_per_call(self):
+        """the k to ask step_n for (the measured rules of include/megaverse_hip.h: 16 for 1024..2047 frames per tick, else 8; 1 for few-tick episodes)"""
+        return int(self._lib.mv_recommended_ticks_per_call(self._g))
+
+    def recommended_pass_overlap(self):
+        return bool(self._lib.mv_recommended_pass_overlap(self._g))
+
+    def arena_bytes(self):
+        return int(self._lib.mv_arena_bytes(self._g))
 
     def render(self):
         self._ck(self._lib.mv_render(self._g))

@@ -77,6 +77,7 @@ class MegaverseEnv:
         self.action_space = self.generate_action_space(self.env.action_space_sizes())
         self.observation_space = spaces.Box(0, 255, (self.channels, self.img_h, self.img_w), dtype=np.uint8)
         self._obs_tensor = None
+        self._host_obs = None
 
     @staticmethod
     def generate_action_space(action_space_sizes):
@@ -95,9 +96,16 @@ class MegaverseEnv:
         return [frames[i] for i in range(self.num_agents)]
 
     def observations_numpy(self):
-        """(num_agents, 3, H, W) uint8 on the host: one D2H copy for the whole batch"""
-        t = self.observations_tensor()
-        return t.cpu().numpy()
+        """(num_agents, 3, H, W) uint8 on the host: ONE D2H copy of the RGBA slab into a pinned buffer (PCIe: ~64 MB per step at 1024 x 128 x 128 -- the
+        reference's getObservation is a view of host memory, megaverse.cpp:139-143, here the frames live in HBM), returned as a transposed view of it like
+        the reference's np.transpose(obs[:, :, :3], (2, 0, 1)) (megaverse_env.py:121-130); valid until the next call"""
+        torch = self._torch()
+        slab = self.observations_tensor(rgba=True)
+        if self._host_obs is None:
+            self._host_obs = torch.empty(slab.shape, dtype=torch.uint8, pin_memory=True)
+        self._host_obs.copy_(slab, non_blocking=True)
+        torch.cuda.current_stream(slab.device).synchronize()
+        return self._host_obs.numpy()[..., :3].transpose(0, 3, 1, 2)
 
     def reset(self):
         self.env.reset()
@@ -106,16 +114,15 @@ class MegaverseEnv:
     def step(self, actions):
         self.env.set_actions_batched(np.asarray(actions, dtype=np.int32).reshape(self.num_agents, -1))
         self.env.step()
-        dones_env = self.env.get_dones()
-        dones, infos = [], []
-        true_obj = self.env.get_true_objectives() if dones_env.any() else None
-        for env_i in range(self.num_envs):
-            done = bool(dones_env[env_i])
-            dones.extend([done] * self.num_agents_per_env)
-            if done:
-                infos.extend([dict(true_reward=float(true_obj[env_i * self.num_agents_per_env + j])) for j in range(self.num_agents_per_env)])
-            else:
-                infos.extend([{} for _ in range(self.num_agents_per_env)])
+        dones_env = self.env.get_dones().astype(bool)
+        A = self.num_agents_per_env
+        dones = np.repeat(dones_env, A).tolist()          # (megaverse_env.py:149-150: the env's done, once per agent)
+        infos = [{} for _ in range(self.num_agents)]
+        if dones_env.any():                                # true_reward of the agents whose episode just ended (megaverse_env.py:152-156)
+            true_obj = self.env.get_true_objectives()
+            for env_i in np.nonzero(dones_env)[0]:
+                for j in range(A):
+                    infos[env_i * A + j] = dict(true_reward=float(true_obj[env_i * A + j]))
         rewards = self.env.get_last_rewards()
         return self.observations(), rewards, dones, infos
 

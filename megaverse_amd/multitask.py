@@ -97,6 +97,13 @@ class MultiTaskGym:
             g.set_output_ring(count, self.ring_obs[k].data_ptr(), self.ring_rewards[k].data_ptr(), self.ring_dones[k].data_ptr())
         return self.ring_obs, self.ring_rewards, self.ring_dones
 
+    def recommended_ticks_per_call(self):
+        """the k to ask step_n for: what every member recommends (mv_recommended_ticks_per_call), at most 8 -- the two-launch group call's limit"""
+        return max(1, min([8] + [g.recommended_ticks_per_call() for g in self.gyms]))
+
+    def recommended_pass_overlap(self):
+        return False
+
     def set_pixel_mode(self, mode):
         for g in self.gyms:
             g.set_pixel_mode(mode)

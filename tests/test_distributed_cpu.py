@@ -63,8 +63,8 @@ def test_two_rank_gloo_shards_compose():
 
 
 @pytest.mark.timeout(240)
-@pytest.mark.parametrize("mode,fmt", [("allgather", "rgba"), ("p2p", "rgba"), ("p2p", "rgb")])
-def test_bench_self_spawns_its_ranks_and_gathers_dry_run(mode, fmt):
+@pytest.mark.parametrize("mode,fmt,batch", [("allgather", "rgba", 4), ("p2p", "rgba", 4), ("p2p", "rgb", 1), ("allgather", "rgb", 3)])
+def test_bench_self_spawns_its_ranks_and_gathers_dry_run(mode, fmt, batch):
     """`python bench.py --gpus 2` (no torchrun around it, the way the driver runs N=1) must start its own ranks; --dry-run swaps
     the gym for a CPU stand-in and RCCL for gloo, everything else -- launcher, double-buffered gather pipeline, both timed legs,
     the JSON line -- is the code the GPU run executes.  The run itself asserts that every rank's shard arrived in rank order."""
@@ -73,14 +73,18 @@ def test_bench_self_spawns_its_ranks_and_gathers_dry_run(mode, fmt):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "5", "--warmup", "2",
+    # batch > 1: the gather-on leg steps in batched calls, ONE collective per call (the call's half of a ring of 2 x batch slabs; 9 steps = calls of 4, 4, 1 -- the last
+    # one short); batch 1: one collective per tick
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "9", "--warmup", "5", "--batch", str(batch),
                           "--envs-per-gpu", "4", "--obs", "8", "8", "--gather", mode, "--gather-format", fmt], capture_output=True, text=True, timeout=200, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout
     rec = json.loads(lines[0])
     assert ("point-to-point" in rec["gather"]["collective"]) == (mode == "p2p")
-    assert rec["n_gpus"] == 2 and rec["dry_run"] is True and rec["steps"] == 5 and rec["scaling"] == "weak"
+    assert rec["n_gpus"] == 2 and rec["dry_run"] is True and rec["steps"] == 9 and rec["scaling"] == "weak"
+    assert rec["gather"]["ticks_per_collective"] == batch and rec["config"]["ticks_per_call"] == batch
+    assert rec["gather"]["bytes_received_per_gpu_per_collective"] == batch * rec["gather"]["bytes_received_per_gpu_per_step"]
     assert rec["config"]["gather_obs"] is True and rec["value"] > 0 and rec["value_no_gather"] > 0
     assert rec["gather"]["bytes_received_per_gpu_per_step"] == 4 * 8 * 8 * (3 if fmt == "rgb" else 4)
 

@@ -15,12 +15,15 @@ pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("scenario,agents,mode,fmt", [("TowerBuilding", 2, "allgather", "rgba"), ("ObstaclesHard", 1, "p2p", "rgba"), ("TowerBuilding", 1, "p2p", "rgb")])
-def test_two_ranks_of_real_gyms_gather_the_single_gym_slab(hip, scenario, agents, mode, fmt):
+@pytest.mark.parametrize("scenario,agents,mode,fmt,batch", [("TowerBuilding", 2, "allgather", "rgba", 0), ("ObstaclesHard", 1, "p2p", "rgba", 0), ("TowerBuilding", 1, "p2p", "rgb", 1),
+                                                            ("TowerBuilding", 1, "allgather", "rgb", 4)])
+def test_two_ranks_of_real_gyms_gather_the_single_gym_slab(hip, scenario, agents, mode, fmt, batch):
+    """batch 0: what the library recommends (8 ticks per call at this size: the gather-on leg runs batched calls, one collective per call, 9 steps = a call of 8
+    and a call of 1); 4: calls of 4, 4, 1; 1: tick by tick, one collective per tick"""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MV_PIXEL_MODE")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-device", "--check-gather", "--scenario", scenario,
                           "--agents", str(agents), "--envs-per-gpu", "12", "--obs", "48", "32", "--steps", "9", "--warmup", "4", "--no-cpu-baseline",
-                          "--profile-steps", "0", "--no-extra-legs", "--gather", mode, "--gather-format", fmt], capture_output=True, text=True, timeout=500, env=env)
+                          "--profile-steps", "0", "--no-extra-legs", "--gather", mode, "--gather-format", fmt, "--batch", str(batch)], capture_output=True, text=True, timeout=500, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout
@@ -34,3 +37,4 @@ def test_two_ranks_of_real_gyms_gather_the_single_gym_slab(hip, scenario, agents
     assert rec["value_solo_rank0"] > 0 and 0 < rec["value_efficiency"] and 0 < rec["value_no_gather_efficiency"]
     assert abs(rec["value_efficiency"] - rec["value"] / 2 / rec["value_solo_rank0"]) < 1e-9
     assert rec["gather"]["xgmi_bound_ms_per_step"] > 0
+    assert rec["gather"]["ticks_per_collective"] == (batch if batch else 8) and rec["gather"]["collectives_per_call"] == 1

@@ -37,6 +37,50 @@ def pixels_agree(og, hg, envs, A, what):
     assert ngt1 <= max(2, 1e-4 * npx) and ndiff <= max(4, 5e-4 * npx), f"{what}: fast pixels: {ndiff} differ, {ngt1} by more than 1 of {npx}"
 
 
+def batched_calls_equal_the_oracle(og, hg, N, A, st, k, calls, depth, overlap, sample, what, check_entries=(0, 5, 11, 15)):
+    """`calls` calls of hg.step_n(k) into output rings `depth` entries deep (observations, rewards, dones) against the oracle's single ticks: every entry's
+    rewards (bit patterns) and dones, the sampled envs' fast pixels in the entries `check_entries` of every call, every env's whole state afterwards.
+    With overlap an entry is consumed (copied out) before the next stepping call after the one that produced it is issued: the ring's contract.  -> the next tick index"""
+    import torch
+    ring = torch.zeros((depth, N * A, H, W, 4), dtype=torch.uint8, device="cuda:0")
+    rrew = torch.zeros((depth, N * A), dtype=torch.float32, device="cuda:0")
+    rdone = torch.zeros((depth, N), dtype=torch.uint8, device="cuda:0")
+    hg.synchronize(); torch.cuda.synchronize()
+    hg.set_output_ring(depth, ring.data_ptr(), rrew.data_ptr(), rdone.data_ptr())
+    if overlap:
+        hg.set_pass_overlap(True)
+    t0 = st   # ring entry of tick t = (t - t0) % depth
+    ndiff = ngt1 = npx = 0
+    for c in range(calls):
+        hg.step_n(k, "multidiscrete", 1234, st)
+        hg.synchronize(); torch.cuda.synchronize()
+        rr, dd = rrew.cpu().numpy(), rdone.cpu().numpy()
+        for j in range(k):
+            og.set_action_masks(action_masks(sample_actions(1234, st + j, N * A)))
+            og.step_norender()
+            e = (st + j - t0) % depth
+            ro, do = og.get_last_rewards(), og.get_dones().astype(bool)
+            assert np.array_equal(ro.view(np.uint32), rr[e].view(np.uint32)), f"{what}: call {c} tick {j} (ring entry {e}): rewards differ for agents {np.nonzero(ro.view(np.uint32) != rr[e].view(np.uint32))[0][:8].tolist()}"
+            assert np.array_equal(do, dd[e].astype(bool)), f"{what}: call {c} tick {j} (ring entry {e}): dones differ"
+            if j in check_entries:
+                slab = ring[e].cpu().numpy()
+                assert slab[..., 3].min() == 255, f"{what}: call {c} tick {j}: ring entry {e} holds unwritten pixels"
+                for en in sample:
+                    og.render_env(en)
+                    for a in range(A):
+                        dpx = np.abs(og.get_observation(en, a).astype(np.int16) - slab[en * A + a].astype(np.int16)).max(axis=-1)
+                        ndiff += int((dpx > 0).sum()); ngt1 += int((dpx > 1).sum()); npx += dpx.size
+        st += k
+    assert ngt1 <= max(2, 1e-4 * npx) and ndiff <= max(4, 5e-4 * npx), f"{what}: ring pixels: {ndiff} differ, {ngt1} by more than 1 of {npx}"
+    for e in range(N):
+        d = diff_snapshots(og.snapshot(e), hip_snapshot(hg, e), A)
+        assert not d, (what, "state after the batched calls", e, d[:4])
+    if overlap:
+        hg.set_pass_overlap(False)
+    hg.set_output_ring(0)
+    return st
+
+
 @pytest.mark.parametrize("scenario,N,A,params,TICKS,EVERY", [
     ("TowerBuilding", 1024, 1, {"episodeLengthSec": -190.0}, 300, 50),   # configs[1] (short episodes: resets all through the run)
     ("TowerBuilding", 1024, 1, {}, 300, 50),                              # configs[1] exactly as benchmarked (episodes end naturally only after the run)
@@ -94,6 +138,12 @@ def test_full_size_rollout_equals_the_oracle(hip, scenario, N, A, params, TICKS,
             ndiff += int((dpx > 0).sum()); ngt1 += int((dpx > 1).sum()); npx += dpx.size
     assert last[..., 3].min() == 255 and ngt1 <= max(2, 1e-4 * npx) and ndiff <= max(4, 5e-4 * npx), f"ring slab after batched calls: {ndiff} pixels differ, {ngt1} by more than 1"
     hg.set_output_ring(0)
+    # ---- the launch shapes the bench times: 16 ticks per call into a ring of 16 (two step launches of 8 + ONE observation launch of 16
+    # passes); and -- ObstaclesHard, as bench.py runs one GPU's share of configs[2] -- overlapped passes into rings two calls deep (mv_set_pass_overlap).  EVERY
+    # ring entry's rewards and dones against the oracle's tick, the pixels of the sampled envs in several entries of every call, every env's state afterwards.
+    st = batched_calls_equal_the_oracle(og, hg, N, A, st, k=16, calls=3, depth=16, overlap=False, sample=sample, what=f"{scenario} {N}x{A} step_n(16)")
+    if scenario == "ObstaclesHard":
+        st = batched_calls_equal_the_oracle(og, hg, N, A, st, k=16, calls=4, depth=32, overlap=True, sample=sample, what=f"{scenario} {N}x{A} step_n(16), overlapped passes")
     if params:
         assert ndone > N // 2, f"only {ndone} episodes ended in {TICKS} ticks"
     elif scenario != "TowerBuilding":
@@ -147,6 +197,62 @@ def test_full_size_mixed_scenarios_equal_their_oracles(hip, monkeypatch):
                 ogs[k].render_env(i)
                 assert np.array_equal(ogs[k].get_observation(i, 0), g.get_observation(j, 0)), (st, i, MEGAVERSE_IN_SCOPE[k], "pixels")
                 g.set_pixel_mode("fast")
+    for og in ogs:
+        og.close()
+    mt.close()
+
+
+@pytest.mark.parametrize("scenarios", [MEGAVERSE_IN_SCOPE, ["TowerBuilding", "ObstaclesEasy", "ObstaclesHard", "Collect"]], ids=["megaverse8", "mixed4"])
+def test_full_size_mixed_batched_calls_equal_their_oracles(hip, monkeypatch, scenarios):
+    """configs[4] on the path bench.py times it on: MultiTaskGym.set_output_ring(8) + step_n(8) at 1024 envs -- ONE union step launch
+    (step_union_ticks_kernel) and ONE union observation launch (raster_union_batch_kernel) per call -- for the reference's eight-scenario set
+    (megaverse_env.py:18-21) and for BASELINE.md section 3 row 5's four, against one oracle per scenario stepped tick by tick: every ring entry's rewards
+    (bit patterns) and dones of every env, the fast pixels (64 x 64, DESIGN.md's tolerance) of one sampled env per scenario in three entries of every call,
+    every env's whole state after the calls."""
+    import torch
+    monkeypatch.setenv("BOXOBAN_LEVELS", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "boxoban"))
+    N, A, S, K, CALLS = 1024, 1, len(scenarios), 8, 6
+    W = H = 64
+    mt = MultiTaskGym(scenarios, W, H, N, A, 8)
+    mt.set_pixel_mode("fast")
+    mt.attach("cuda:0")
+    mt.seed(42); mt.reset()
+    assert mt.recommended_ticks_per_call() == K
+    ogs = []
+    for name in scenarios:
+        og = oracle_lib.OracleGym(name, W, H, N, A, 16)
+        og.seed(42); og.reset()
+        ogs.append(og)
+    owned = [np.arange(k, N, S) for k in range(S)]
+    ring_obs, ring_rew, ring_done = mt.set_output_ring(K)
+    ndiff = ngt1 = npx = 0
+    st = 0
+    for c in range(CALLS):
+        mt.step_n(K, "multidiscrete", 1234, st)
+        mt.synchronize(); torch.cuda.synchronize()
+        rr = [r.cpu().numpy() for r in ring_rew]
+        dd = [d.cpu().numpy() for d in ring_done]
+        for j in range(K):
+            masks = action_masks(sample_actions(1234, st + j, N * A))
+            for k, og in enumerate(ogs):
+                og.set_action_masks(masks)
+                og.step_norender()
+                ro = og.get_last_rewards().reshape(N, A)[owned[k]].reshape(-1)
+                assert np.array_equal(ro.view(np.uint32), rr[k][j].view(np.uint32)), (c, j, scenarios[k], "rewards")
+                assert np.array_equal(og.get_dones()[owned[k]].astype(bool), dd[k][j].astype(bool)), (c, j, scenarios[k], "dones")
+                if j in (0, 3, 7):
+                    jl = (c * 37 + 5 * k + j) % (N // S)   # local env of sub-gym k; global index k + S * jl
+                    og.render_env(k + S * jl)
+                    got = ring_obs[k][j, jl * A].cpu().numpy()
+                    assert got[..., 3].min() == 255, (c, j, scenarios[k], "unwritten pixels")
+                    dpx = np.abs(og.get_observation(k + S * jl, 0).astype(np.int16) - got.astype(np.int16)).max(axis=-1)
+                    ndiff += int((dpx > 0).sum()); ngt1 += int((dpx > 1).sum()); npx += dpx.size
+        st += K
+    assert ngt1 <= max(4, 2e-4 * npx) and ndiff <= max(8, 1e-3 * npx), f"ring pixels: {ndiff} differ, {ngt1} by more than 1 of {npx}"
+    for i in range(N):
+        k, j = i % S, i // S
+        d = diff_snapshots(ogs[k].snapshot(i), hip_snapshot(mt.gyms[k], j), A)
+        assert not d, ("state after the batched calls", i, scenarios[k], d[:4])
     for og in ogs:
         og.close()
     mt.close()

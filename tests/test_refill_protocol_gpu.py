@@ -133,7 +133,7 @@ def test_close_with_work_in_flight_and_two_gyms():
     b.close(); b.close()
 
 
-@pytest.mark.parametrize("scenario,k", [("Rearrange", 16), ("Rearrange", 8), ("Sokoban", 16)])
+@pytest.mark.parametrize("scenario,k", [("Rearrange", 16), ("Rearrange", 8), ("Sokoban", 16), ("HexExplore", 16), ("ObstaclesEasy", 16)])
 def test_batched_calls_with_the_host_far_ahead_never_starve(scenario, k, monkeypatch, recwarn):
     """Episodes of ~70 ticks (long enough for the 16-tick status period, two resident per env), stepped open loop with calls of k ticks and no
     host synchronisation: the host enqueues far faster than the device steps.  An upload lands behind the last step launch ENQUEUED, so how late
@@ -144,6 +144,8 @@ def test_batched_calls_with_the_host_far_ahead_never_starve(scenario, k, monkeyp
     monkeypatch.setenv("BOXOBAN_LEVELS", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "boxoban"))
     N, A, W, H, ticks = 48, 1, 32, 32, 1600
     params = {"episodeLengthSec": 70.0 / 15.0}
+    if scenario in ("HexExplore", "ObstaclesEasy"):   # goal-terminated: default time limits, an episode ends early where the random walk finds the target / the exit
+        N, ticks, params = 96, 2400, {}
 
     def run(batched):
         g = MegaverseGym(scenario, W, H, N, A, 8, False, params)
