@@ -11,16 +11,20 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # One scripted rollout per case.  `shaping_at`: {step: (actor_idx, {key: value})} applied through Wrapper.set_reward_shaping BEFORE that step;
 # `training_steps_per_step`: what the learner's side would write into training_info["approx_total_training_steps"] (step * this).
 CASES = {
+    # `policy`: the generator's purposeful controller (make_py_surface_golden.py: POLICIES), mixed with the random script with probability `eps`; the actions it chose are
+    # recorded in the fixture (npz "actions") and replayed blind.  `min_nonzero_rewards` / `reward_windows`: what the generator asserts about the recorded rewards.
     "tower_a2": dict(scenario="TowerBuilding", num_envs=3, agents=2, seed=42, steps=300, params={"episodeLengthSec": -215.0},
                      increase_team_spirit=True, max_team_spirit_steps=1000, training_steps_per_step=5,
-                     shaping_at={70: (1, {"towerPickedUpObject": 0.25}), 150: (4, {"teamSpirit": 0.5, "towerBuildingReward": 2.0})}),
+                     shaping_at={70: (1, {"towerPickedUpObject": 0.25}), 150: (4, {"teamSpirit": 0.5, "towerBuildingReward": 2.0})},
+                     policy="tower", eps=0.25, min_nonzero_rewards=30, reward_windows=[[0, 70], [70, 150], [150, 300]]),
     "rearrange_a2": dict(scenario="Rearrange", num_envs=2, agents=2, seed=7, steps=300, params={"episodeLengthSec": 5.0},
                               increase_team_spirit=True, max_team_spirit_steps=600, training_steps_per_step=3,
-                              shaping_at={90: (2, {"teamSpirit": 0.9})}),
+                              shaping_at={90: (2, {"teamSpirit": 0.9})}, policy="rearrange", eps=0.15, min_nonzero_rewards=5, reward_windows=[[0, 90], [90, 300]]),
     "collect_a1": dict(scenario="Collect", num_envs=4, agents=1, seed=11, steps=300, params={"episodeLengthSec": -60.0},
-                       increase_team_spirit=False, max_team_spirit_steps=1e9, training_steps_per_step=1, shaping_at={}),
-    "multitask_megaverse8_task15": dict(scenario="multitask_megaverse8", task_idx=15, num_envs=2, agents=2, seed=5, steps=120, params={"episodeLengthSec": 2.0},
-                                       increase_team_spirit=False, max_team_spirit_steps=1e9, training_steps_per_step=1, shaping_at={}),
+                       increase_team_spirit=False, max_team_spirit_steps=1e9, training_steps_per_step=1, shaping_at={}, policy="collect", eps=0.2, min_nonzero_rewards=10),
+    "multitask_megaverse8_task15": dict(scenario="multitask_megaverse8", task_idx=15, num_envs=2, agents=2, seed=5, steps=160, params={"episodeLengthSec": 4.0},
+                                       increase_team_spirit=False, max_team_spirit_steps=1e9, training_steps_per_step=1, shaping_at={},
+                                       policy="rearrange", eps=0.15, min_nonzero_rewards=2),
 }
 
 
@@ -69,7 +73,9 @@ def replay(w, rec, data, shaping_calls, check_obs):
             cur.update(upd)
             w.set_reward_shaping(cur, actor)
         w.set_training_info({"approx_total_training_steps": st * spec["training_steps_per_step"]})
-        obs, rewards, terminated, truncated, infos = w.step(scripted_actions(spec["seed"], st, n))
+        # the recorded actions where the fixture holds them (a purposeful script the generator read off the oracle's state), else the random script
+        acts = [[int(v) for v in row] for row in data["actions"][st]] if "actions" in data.files else scripted_actions(spec["seed"], st, n)
+        obs, rewards, terminated, truncated, infos = w.step(acts)
         want = rec["steps"][st]
         assert len(obs) == len(rewards) == len(terminated) == len(truncated) == len(infos) == n
         assert [float(r) for r in rewards] == data["rewards"][st].tolist(), f"rewards, step {st}"

@@ -34,7 +34,8 @@ class ReplayingEnv:
     def reset(self): return [None] * self.num_agents
 
     def step(self, actions):
-        assert actions == py_surface.scripted_actions(self.rec["spec"]["seed"], self.t, self.num_agents)
+        want = [[int(v) for v in row] for row in self.data["actions"][self.t]] if "actions" in self.data.files else py_surface.scripted_actions(self.rec["spec"]["seed"], self.t, self.num_agents)
+        assert actions == want   # (the recorded script reaches the env unchanged)
         dones = self.data["dones"][self.t].tolist()
         infos = [{"true_reward": i["true_reward"]} if d else {} for d, i in zip(dones, self.rec["steps"][self.t]["infos"])]
         rewards = self.data["rewards"][self.t].tolist()
@@ -59,6 +60,10 @@ def test_wrapper_equals_the_reference_wrapper(name):
     w = Wrapper(ReplayingEnv(rec, data, calls), spec["increase_team_spirit"], spec["max_team_spirit_steps"])
     py_surface.replay(w, rec, data, calls, check_obs=False)
     assert rec["episodes_finished"] >= 2 * spec["num_envs"]
+    # the rewards the Wrapper's statistics were checked on are not all zeros: the purposeful scripts earn them on both sides of the shaping changes
+    assert int((data["rewards"] != 0).sum()) >= spec.get("min_nonzero_rewards", 0)
+    for a, b in spec.get("reward_windows", []):
+        assert (data["rewards"][a:b] != 0).any(), (name, a, b)
 
 
 def test_fixture_specs_are_the_committed_scripts():
