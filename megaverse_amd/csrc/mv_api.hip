@@ -25,7 +25,8 @@ static const float SHAPING_DEFAULT_REARRANGE[3] = {0.0f, 1.0f, 10.0f};
 // scenario_sokoban.hpp:40-47, teamSpirit 0
 static const char *SHAPING_KEYS_SOKOBAN[4] = {"teamSpirit", "sokobanBoxOnTarget", "sokobanBoxLeavesTarget", "sokobanAllBoxesOnTarget"};
 static const float SHAPING_DEFAULT_SOKOBAN[4] = {0.0f, 1.0f, -1.0f, 10.0f};
-static const char *SHAPING_KEYS_EMPTY[1] = {"teamSpirit"};   // EmptyScenario::defaultRewardShaping() is {} (scenario_empty.hpp:28) + Scenario::init's teamSpirit
+// EmptyScenario::defaultRewardShaping() is {} (scenario_empty.hpp:28) + Scenario::init's teamSpirit
+static const char *SHAPING_KEYS_EMPTY[1] = {"teamSpirit"};
 // scenario_hex_memory.hpp:37-43, scenario_hex_explore.hpp:28-31 (+ teamSpirit 0)
 static const char *SHAPING_KEYS_HEX_MEMORY[3] = {"teamSpirit", "memoryCollectGood", "memoryCollectBad"};
 static const float SHAPING_DEFAULT_HEX_MEMORY[3] = {0.0f, 1.0f, -1.0f};
@@ -148,7 +149,8 @@ int tower_join(mv_gym *g)
 int tower_draw_before(mv_gym *g, hipStream_t sim)
 {
     if (!g->genStream || g->drawCount < 2) return 0;
-    if (g->drawWaitedCount == g->drawCount && g->drawWaitedOn == sim) return 0;   // (draw launches come every drawPeriod ticks: a tick-by-tick caller waits once per launch, not per tick)
+    // (draw launches come every drawPeriod ticks: a tick-by-tick caller waits once per launch, not per tick)
+    if (g->drawWaitedCount == g->drawCount && g->drawWaitedOn == sim) return 0;
     HIP_TRY(hipStreamWaitEvent(sim, g->drawDone[(size_t)(g->drawCount & 1ull)], 0));
     g->drawWaitedCount = g->drawCount; g->drawWaitedOn = sim;
     return 0;
@@ -252,7 +254,8 @@ static int usable_host_cores()
 // The simulation stream has the device's highest stream priority: when a call's observation launch and the next call's step launch become ready together --
 // the end of a step launch releases both -- the step launch's few fat workgroups (one or four waves of 128-168 VGPRs) should reach the chip first; behind an
 // observation launch that has filled it with 72-VGPR waves they wait for holes that never get large enough until that launch has drained.  Measured (r08s, two
-// runs each, normal / high): ObstaclesHard 512 envs 18.6 / 20.8 M obs/s, 1024 envs 24.1 / 26.3, Sokoban 26.2 / 28.2, Mixed 64 x 64 16.8 / 18.3, Mixed4 20.6 / 18.7,
+// runs each, normal / high): ObstaclesHard 512 envs 18.6 / 20.8 M obs/s, 1024 envs 24.1 / 26.3, Sokoban 26.2 / 28.2, Mixed 64 x 64 16.8 / 18.3, Mixed4 20.6 /
+// 18.7,
 // TowerBuilding (1024, 4096, 512 x 4), Collect, Empty: unchanged.  MV_SIM_PRIORITY=normal: a stream of default priority.
 static hipError_t create_sim_stream(hipStream_t *s)
 {
@@ -305,8 +308,10 @@ int mv_create(const mv_config *cfg, mv_gym **out)
                    : scenario == SCN_COLLECT ? SHAPING_KEYS_COLLECT : scenario == SCN_SOKOBAN ? SHAPING_KEYS_SOKOBAN
                    : scenario == SCN_HEX_MEMORY ? SHAPING_KEYS_HEX_MEMORY : scenario == SCN_HEX_EXPLORE ? SHAPING_KEYS_HEX_EXPLORE
                    : scenario == SCN_EMPTY ? SHAPING_KEYS_EMPTY : SHAPING_KEYS_REARRANGE;
-    // Resident episodes per env: two where an episode ends at its time limit only (TowerBuilding, Empty); THREE where a goal can end it early (the exit pad, every
-    // diamond collected, the level solved, the arrangement matched, the maze's target found): the host's run-ahead is bounded in TICKS (refill_episodes), the status
+    // Resident episodes per env: two where an episode ends at its time limit only (TowerBuilding, Empty); THREE where a goal can end it early (the exit pad,
+    // every
+    // diamond collected, the level solved, the arrangement matched, the maze's target found): the host's run-ahead is bounded in TICKS (refill_episodes), the
+    // status
     // words are read back every 16th, and a lucky env can finish twice inside that window -- a third resident episode covers it where two starved.
     g->spares = scenario == SCN_TOWER || scenario == SCN_EMPTY ? 2 : 3;
     g->envOffset = cfg->total_envs > 0 ? cfg->env_offset : 0;
@@ -346,9 +351,12 @@ int mv_create(const mv_config *cfg, mv_gym **out)
                  szLpt = up(NA * sizeof(int32_t)) + up((NA + 1) * sizeof(int32_t)) + up(NA * (size_t)FRAME_HDR_BYTES) + up((size_t)LPT_BUCKETS * LPT_SUBS * lpt_sub_capacity(NA) * sizeof(int32_t));
     // per slot: frame lists, headers, cost lists, and the staging copies of rewards / dones / true objectives
     const size_t szParity = szVisP + szVisR + szVisC + szLpt + szRew + szDone + szObjv;
-    // Ticks per call of mv_step_n (`batch`; a gym holds PIPE_GROUPS x batch hand-over slots of szParity bytes each): 16 -- one tail of the one-launch observation
-    // pass per 16 ticks, measured against 8: TowerBuilding 1024 envs 26.6 -> 28.3 M obs/s -- where the 48 slots that takes stay under 1 GiB, else 8 (a Hex frame's
-    // slot is 80 KB: 3.8 GB per 1024 frames at 16; TowerBuilding's 12 KB: 0.6 GB).  MV_PIPE_BATCH=1..16 overrides; mv_recommended_ticks_per_call says what to ask for.
+    // Ticks per call of mv_step_n (`batch`; a gym holds PIPE_GROUPS x batch hand-over slots of szParity bytes each): 16 -- one tail of the one-launch
+    // observation
+    // pass per 16 ticks, measured against 8: TowerBuilding 1024 envs 26.6 -> 28.3 M obs/s -- where the 48 slots that takes stay under 1 GiB, else 8 (a Hex
+    // frame's
+    // slot is 80 KB: 3.8 GB per 1024 frames at 16; TowerBuilding's 12 KB: 0.6 GB).  MV_PIPE_BATCH=1..16 overrides; mv_recommended_ticks_per_call says what to
+    // ask for.
     g->batch = (size_t)PIPE_GROUPS * 16 * szParity <= (size_t(1) << 30) ? 16 : 8;
     if (const char *e = getenv("MV_PIPE_BATCH")) g->batch = std::min((int)PIPE_BATCH_MAX, std::max(1, atoi(e)));
     g->slots = PIPE_GROUPS * g->batch;
@@ -357,7 +365,8 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     g->gvp.resize((size_t)g->slots);
     g->parity = g->slots - 1;
     g->group = PIPE_GROUPS - 1;
-    const size_t szHist = up((size_t)g->hists * (LPT_BUCKETS * LPT_SUBS + 1) * sizeof(int32_t));   // (+ one "workgroups that have looked their frame up" counter per histogram, behind them)
+    // (+ one "workgroups that have looked their frame up" counter per histogram, behind them)
+    const size_t szHist = up((size_t)g->hists * (LPT_BUCKETS * LPT_SUBS + 1) * sizeof(int32_t));
     gv.lpt_hists = g->hists;
     // long lists: the list as found, before the frame setup deals it into depth classes (mv_frame.h: DepthSortScratch); MV_DEPTH_SORT=0: lists stay as found
     const bool depthSortOn = !(getenv("MV_DEPTH_SORT") && atoi(getenv("MV_DEPTH_SORT")) == 0);
@@ -538,7 +547,8 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     {
         std::vector<int32_t> iota(NA);
         for (size_t i = 0; i < NA; ++i) iota[i] = (int32_t)i;
-        for (int q = 0; q < g->slots; ++q) (void)hipMemcpy(g->gvp[q].lpt_order, iota.data(), NA * sizeof(int32_t), hipMemcpyHostToDevice);   // identity until the first frame sort
+        // identity until the first frame sort
+        for (int q = 0; q < g->slots; ++q) (void)hipMemcpy(g->gvp[q].lpt_order, iota.data(), NA * sizeof(int32_t), hipMemcpyHostToDevice);
     }
     if (hipMemcpy(gv.hdr, hh.data(), N * sizeof(EnvHeader), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(gv.agents, ha.data(), NA * sizeof(AgentState), hipMemcpyHostToDevice) != hipSuccess) {
@@ -725,7 +735,8 @@ int mv_seed(mv_gym *g, int32_t seed)
         HIP_TRY(hipStreamSynchronize(g->simStream));
         HIP_TRY(hipStreamSynchronize(g->stream));
         HIP_TRY(hipStreamSynchronize(g->copyStream));
-        HIP_TRY(hipMemcpy(g->hStatus, g->dStatus, (size_t)(g->N + 2) * sizeof(int), hipMemcpyDeviceToHost));   // the current counts, not the last periodic read-back
+        // the current counts, not the last periodic read-back
+        HIP_TRY(hipMemcpy(g->hStatus, g->dStatus, (size_t)(g->N + 2) * sizeof(int), hipMemcpyDeviceToHost));
         g->statusPending = false;
         g->pendingAge = 0;
         g->stepsSinceStatus = 0;
@@ -877,18 +888,23 @@ int refill_episodes(mv_gym *g, int k)
     if (g->statusPending) {
         // The read-back was enqueued behind a step launch the host is normally ahead of: waiting for it at once would drain that run-ahead every statusPeriod
         // ticks.  With long episodes (period 16, two resident episodes per env) the words may arrive later: look again at the next call -- every period a fresh
-        // read-back takes the pending one's place, so a host that runs ahead never finds it ready -- and wait for the latest one once max(32, 4 k) TICKS have been
-        // enqueued since the first.  That wait is what bounds the host's run-ahead, and with it how late a refill can land: an upload is ordered behind the LAST
+        // read-back takes the pending one's place, so a host that runs ahead never finds it ready -- and wait for the latest one once max(32, 4 k) TICKS have
+        // been
+        // enqueued since the first.  That wait is what bounds the host's run-ahead, and with it how late a refill can land: an upload is ordered behind the
+        // LAST
         // step launch enqueued.  It costs nothing: the host catches up with the STEP launches, which run up to three calls ahead of the observation passes the
         // device is busy with.  (Until round 5 the bound was 32 CALLS -- 256 ticks at 8 per call, 512 at 16: a HexExplore env that found its goal twice within
-        // ~300 ticks starved, scripts/soak.py in r08z.  Measured, r08x2, bound 3 k / 6 k / 32 k ticks at k = 16: TowerBuilding 28.8 / 28.7 / 28.1 M obs/s, Empty
-        // 38.3 / 39.4 / 39.9; with ONE read-back in flight instead (polled until ready, no forced wait) the host's run-ahead was bounded by nothing: 26.3-28.9 / 36-38.
+        // ~300 ticks starved, scripts/soak.py in r08z.  Measured, r08x2, bound 3 k / 6 k / 32 k ticks at k = 16: TowerBuilding 28.8 / 28.7 / 28.1 M obs/s,
+        // Empty
+        // 38.3 / 39.4 / 39.9; with ONE read-back in flight instead (polled until ready, no forced wait) the host's run-ahead was bounded by nothing: 26.3-28.9
+        // / 36-38.
         // r08x4, three runs each, this scheme / the 32-call bound: ObstaclesHard 512 envs 20.9 / 21.5, Empty 38.9 / 39.6: what the bound costs.)
         const int bound = std::max(32, 4 * k);
         if (g->statusPeriod > 1 && g->pendingAge < bound && hipEventQuery(g->statusCopied) == hipErrorNotReady) {
             (void)hipGetLastError();   // ("not ready" is an answer, not an error to report at the end of the step)
             g->pendingAge += k;
-            // (no fresh counts: but envs known to be short of an episode whose successor was not generated yet -- or had just sent one: one episode per env and pass --
+            // (no fresh counts: but envs known to be short of an episode whose successor was not generated yet -- or had just sent one: one episode per env and
+            // pass --
             // are served now, not at the next read-back: with every env finishing every 70 ticks and a pass every 80 the ring fell behind until it starved)
             if (g->hostEpisodes() && g->deficit > 0 && !g->consumedSeen.empty() && upload_pass(g)) return -1;
             return 0;
@@ -902,7 +918,8 @@ int refill_episodes(mv_gym *g, int k)
     const bool starved = (g->hStatus[N + 1] & ST_STARVED) != 0;
     if (starved && g->hostEpisodes()) {   // recover: take the current counts and upload synchronously below
         HIP_TRY(hipStreamSynchronize(g->simStream));
-        if (!g->simOnOwnStream) HIP_TRY(hipStreamSynchronize(g->stream));   // (closed-loop / unpipelined steps run on the caller's stream, which may be a non-blocking one)
+        // (closed-loop / unpipelined steps run on the caller's stream, which may be a non-blocking one)
+        if (!g->simOnOwnStream) HIP_TRY(hipStreamSynchronize(g->stream));
         HIP_TRY(hipStreamSynchronize(g->copyStream));
         const int keep = g->hStatus[N + 1];
         HIP_TRY(hipMemcpy(g->hStatus, g->dStatus, (size_t)(N + 2) * sizeof(int), hipMemcpyDeviceToHost));
@@ -910,7 +927,8 @@ int refill_episodes(mv_gym *g, int k)
         g->refillForce = true;
     }
     if (g->hostEpisodes() && (g->refillForce || g->deficit > 0 || g->hStatus[N] != g->lastTotalSeen)) {
-        g->consumedSeen.assign(g->hStatus, g->hStatus + N);   // (the pinned words are the target of the next read-back: the passes between two of them work from this copy)
+        // (the pinned words are the target of the next read-back: the passes between two of them work from this copy)
+        g->consumedSeen.assign(g->hStatus, g->hStatus + N);
         if (upload_pass(g)) return -1;
         g->lastTotalSeen = g->hStatus[N];
         g->refillForce = false;

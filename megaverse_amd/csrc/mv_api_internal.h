@@ -30,14 +30,17 @@
 
 namespace mv {
 void launch_reset(const GymView &gv, int force_all, hipStream_t stream);
-void launch_tower_draw(const GymView &gv, hipStream_t stream);                          // TowerBuilding: tops every env's ring of drawn episodes up (mv_reset.hip)
+// TowerBuilding: tops every env's ring of drawn episodes up (mv_reset.hip)
+void launch_tower_draw(const GymView &gv, hipStream_t stream);
 void launch_tower_seed(const GymView &gv, const uint32_t *seeds, hipStream_t stream);   // Env::seed for every env's generator
 // step kernels: one 256-thread workgroup per env = the tick (wave 0) + the frame setup of the env's frames for a W x H observation
 // (render = 0: tick only)
 void launch_step(const GymView &gv, hipStream_t stream, int W, int H, int render, hipEvent_t done = nullptr);
-void launch_step_ticks(const GymView *views, int k, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);   // k ticks + frame setups of every env, one launch (mv_step.hip)
+// k ticks + frame setups of every env, one launch (mv_step.hip)
+void launch_step_ticks(const GymView *views, int k, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);
 void launch_step_obstacles(const GymView &gv, hipStream_t stream, int W, int H, int render);
-void launch_step_obstacles_ticks(const GymView *views, int k, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);   // k ticks + frame setups of every env (one agent), one launch
+// k ticks + frame setups of every env (one agent), one launch
+void launch_step_obstacles_ticks(const GymView *views, int k, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);
 void launch_step_rearrange_ticks(const GymView *views, int k, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);
 void launch_step_sokoban_ticks(const GymView *views, int k, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);
 void launch_step_collect_ticks(const GymView *views, int k, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);
@@ -102,7 +105,8 @@ struct mv_gym {
     bool simMustWaitUser = true;                 // the caller's stream holds work the next step depends on (reset, render, device actions, ...)
     hipEvent_t simDone = nullptr;                // after the last kernel on simStream
     bool simDoneValid = false;
-    int batch = 8, slots = PIPE_GROUPS * 8, hists = PIPE_GROUPS * 8 + 1;   // slots per group (ticks per call: set by mv_create from the slots' footprint, or MV_PIPE_BATCH), slots, cost histograms
+    // slots per group (ticks per call: set by mv_create from the slots' footprint, or MV_PIPE_BATCH), slots, cost histograms
+    int batch = 8, slots = PIPE_GROUPS * 8, hists = PIPE_GROUPS * 8 + 1;
     int group = 0;                               // slot group of the last stepping call
     int parity = 0, hist3 = 0;                   // hand-over slot of the last tick; cost histogram of the last pass
     // histClean[h]: cost histogram h is (or, in stream order, will be) all zero when the next frame setup counts into it.  A pass drawn by the
@@ -180,7 +184,8 @@ struct mv_gym {
     hipEvent_t stepDone = nullptr;                  // after the last step kernel: uploads never overlap a kernel that may read the ring
     hipStream_t copyStream = nullptr;               // status read-back + episode uploads, off the step path
     hipEvent_t statusCopied = nullptr;
-    hipEvent_t lastStep = nullptr;                  // the event behind the last kernel that may read the ring (a step launch's simDone / stepDone, mv_reset's stepDone)
+    // the event behind the last kernel that may read the ring (a step launch's simDone / stepDone, mv_reset's stepDone)
+    hipEvent_t lastStep = nullptr;
     std::vector<hipEvent_t> uploadEvents;           // ring, one per upload batch
     hipEvent_t lastUpload = nullptr;                // the most recent batch (mv_reset: the caller's stream waits for it too)
     bool uploadNotOnUser = false;                   // ... and a step that runs on the caller's stream has not waited for it yet

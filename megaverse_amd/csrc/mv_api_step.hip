@@ -84,7 +84,8 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
         g->group = (g->group + 1) % PIPE_GROUPS;
     }
     const int fused = render ? 1 : 0;   // the step kernel also builds the frame lists when an observation pass follows
-    if (L->gv.dbg) {   // (instrumented builds: MV_TICK_TIMING_SKIP=n starts the statistics after n stepping calls -- the steady state, not the first ticks of fresh episodes)
+    // (instrumented builds: MV_TICK_TIMING_SKIP=n starts the statistics after n stepping calls -- the steady state, not the first ticks of fresh episodes)
+    if (L->gv.dbg) {
         static const long skip = getenv("MV_TICK_TIMING_SKIP") ? atol(getenv("MV_TICK_TIMING_SKIP")) : 0;
         if (skip > 0 && ++L->dbgCalls == skip) HIP_TRY(hipMemsetAsync(L->gv.dbg, 0, (size_t)L->N * 64 * sizeof(unsigned long long), sim));
     }
@@ -120,12 +121,14 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
     bool groupBatch = n > 1 && !ticksOff && own && render && allFast && k >= 2 && k <= MAX_STEP_TICKS && policy != POLICY_NONE && !profiling && raster_union_batch_applicable(k, n, L->w, L->h);
     for (int i = 0; i < n && groupBatch; ++i) groupBatch = gs[i]->A == 1 && gs[i]->ringObs && gs[i]->ringCount >= k && !gs[i]->gv.dbg;
     {   // ... and all of the group's envs resident at once: the union step launch keeps a workgroup per env alive for the whole call (four waves of 168 VGPRs for the long-list
-        // gyms); beyond one round of the chip the tick-by-tick launches win (Mixed 64 x 64, batched / tick by tick: 512 envs 12.2 / 8.6 M obs/s, 1024: 17.6 / 16.2, 2048: 16.1 / 20.5; r08z_rules)
+        // gyms); beyond one round of the chip the tick-by-tick launches win (Mixed 64 x 64, batched / tick by tick: 512 envs 12.2 / 8.6 M obs/s, 1024: 17.6 /
+        // 16.2, 2048: 16.1 / 20.5; r08z_rules)
         int envs = 0;
         for (int i = 0; i < n; ++i) envs += gs[i]->N;
         groupBatch = groupBatch && envs <= 1024;
     }
-    // not pipelined: the caller's stream needs no event behind the step launches; the side streams do when a draw launch, a status read-back or an upload will wait for this call
+    // not pipelined: the caller's stream needs no event behind the step launches; the side streams do when a draw launch, a status read-back or an upload will
+    // wait for this call
     bool sideWaits = anyHostEpisodes;
     for (int i = 0; i < n; ++i)
         sideWaits = sideWaits || (gs[i]->genStream && gs[i]->ticksSinceDraw + k >= gs[i]->drawPeriod) || gs[i]->stepsSinceStatus + k >= gs[i]->statusPeriod;
@@ -142,7 +145,8 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
             if (policy != POLICY_NONE) { g->gv.sample_on = policy; g->gv.sample_seed = seed; g->gv.sample_step = first_index + (uint32_t)j; }
             else { g->gv.sample_on = (j == 0 && g->samplePending) ? g->samplePolicy : (int)POLICY_NONE; }
             g->parity = g->group * g->batch + j;
-            if (render && take_hist(g, sim, !(multiTick || groupBatch))) return -1;   // (this pass's frame setup fills the next cost histogram; one launch per tick: and clears the one after)
+            // (this pass's frame setup fills the next cost histogram; one launch per tick: and clears the one after)
+            if (render && take_hist(g, sim, !(multiTick || groupBatch))) return -1;
             OutPtrs &o = outs[(size_t)j * n + i];
             o = outputs_of(g, g->ringTick++);
             GymView &v = views[(size_t)j * n + i];
@@ -161,7 +165,8 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
                 // kernels in front of every step launch, the second one waiting 30 us for a wave slot beside the observation passes: the chain
                 // of step launches is what bounds a batched call's rate at 1024 envs, 344 + 39 us per call against 288 us of passes.)
                 if (callEv) HIP_TRY(hipEventRecord(callEv[0], sim));
-                hipEvent_t rides = own && !callEv ? L->simDone : nullptr;   // (completed by the last launch's own dispatch packet: no marker behind it on the simulation stream)
+                // (completed by the last launch's own dispatch packet: no marker behind it on the simulation stream)
+                hipEvent_t rides = own && !callEv ? L->simDone : nullptr;
                 const int chunkTicks = 8;   // (a launch holds the views of up to 8 ticks as its arguments, mv_types.h: StepTicksArgs8)
                 for (int j0 = 0; j0 < k; j0 += chunkTicks) {
                     const int kk = std::min(chunkTicks, k - j0);
@@ -234,7 +239,8 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
         g->mirrorsFresh = false;
     }
     // ---- the caller's stream: per tick the step's outputs, then the observation pass
-    if (L->passOverlap && L->callStart[0]) HIP_TRY(hipEventRecord(L->callStart[(int)(L->overlapCalls & 1ull)], L->stream));   // (before this call enqueues anything there)
+    // (before this call enqueues anything there)
+    if (L->passOverlap && L->callStart[0]) HIP_TRY(hipEventRecord(L->callStart[(int)(L->overlapCalls & 1ull)], L->stream));
     if (own) HIP_TRY(hipStreamWaitEvent(L->stream, L->simDone, 0));
     std::vector<PublishTo> pubs((size_t)n);
     std::vector<uint32_t *> obsPtrs((size_t)n);
@@ -257,7 +263,8 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
         passOn = L->passStream[me];
         HIP_TRY(hipStreamWaitEvent(passOn, L->simDone, 0));                                      // this call's ticks
         if (L->overlapCalls >= 1) HIP_TRY(hipStreamWaitEvent(passOn, L->callStart[1 - me], 0));   // what the caller had enqueued when the previous call began
-        else { HIP_TRY(hipEventRecord(L->userNow, L->stream)); HIP_TRY(hipStreamWaitEvent(passOn, L->userNow, 0)); }   // (first overlapped call: everything so far)
+        // (first overlapped call: everything so far)
+        else { HIP_TRY(hipEventRecord(L->userNow, L->stream)); HIP_TRY(hipStreamWaitEvent(passOn, L->userNow, 0)); }
     }
     std::vector<PublishTo> chunkPubs;
     std::vector<uint32_t *> chunkObs;
@@ -268,7 +275,8 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
             const OutPtrs &o = outs[(size_t)j * n + i];
             pubs[i] = PublishTo{o.rewards, o.done, gs[i]->gv.true_objective};
             obsPtrs[i] = o.obs;
-            if (own && (!render || !allFast) && publish_outputs(gs[i], gs[i]->group * gs[i]->batch + j, o)) return -1;   // (the fast observation pass publishes with its first workgroups)
+            // (the fast observation pass publishes with its first workgroups)
+            if (own && (!render || !allFast) && publish_outputs(gs[i], gs[i]->group * gs[i]->batch + j, o)) return -1;
         }
         // the call's last pass completes this call's mark (what the simulation stream waits for before it reuses the slot group)
         hipEvent_t mark = own && j == k - 1 ? L->userMark[L->markCount % PIPE_GROUPS] : nullptr;
@@ -276,7 +284,8 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
             const bool pubInRaster = own;
             chunkPubs.push_back(pubs[0]);
             chunkObs.push_back(obsPtrs[0]);
-            static const int chunkMax = getenv("MV_RASTER_BATCH") ? std::min((int)MAX_STEP_TICKS, std::max(1, atoi(getenv("MV_RASTER_BATCH")))) : (int)MAX_STEP_TICKS;   // (0: off, launch_raster_batch declines)
+            // (0: off, launch_raster_batch declines)
+            static const int chunkMax = getenv("MV_RASTER_BATCH") ? std::min((int)MAX_STEP_TICKS, std::max(1, atoi(getenv("MV_RASTER_BATCH")))) : (int)MAX_STEP_TICKS;
             if (j == k - 1 || (int)chunkObs.size() >= chunkMax) {
                 const int cn = (int)chunkObs.size();
                 if (callEv) { HIP_TRY(hipEventRecord(callEv[2], L->stream)); HIP_TRY(hipEventRecord(callEv[3], L->stream)); }
@@ -291,7 +300,8 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
                         if (launch_raster(views[(size_t)chunkFirst + q], chunkObs[q], L->w, L->h, L->stream, nullptr, 1, /*setup_done=*/1, pubInRaster ? &chunkPubs[q] : nullptr,
                                           q == cn - 1 ? mark : nullptr))
                             return fail("mv_step: observation size above 1024x1024");
-                        if (views[(size_t)chunkFirst + q].lpt_no_clear) L->histClean[(size_t)views[(size_t)chunkFirst + q].lpt_parity] = 1;   // (self_clear, mv_raster.hip)
+                        // (self_clear, mv_raster.hip)
+                        if (views[(size_t)chunkFirst + q].lpt_no_clear) L->histClean[(size_t)views[(size_t)chunkFirst + q].lpt_parity] = 1;
                     }
                 if (callEv) HIP_TRY(hipEventRecord(callEv[4], L->stream));
                 chunkFirst = j + 1;
@@ -307,7 +317,8 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
                 }
                 const int r = launch_raster_union_batch(views.data(), allObs.data(), allPubs.data(), k, n, L->w, L->h, L->stream, mark);
                 if (r != 0) return fail(r == -2 ? "mv_group_step: the hand-over slots of a batched call are not one slot apart (internal)" : "mv_group_step: observation size above 1024x1024");
-                for (size_t q = 0; q < (size_t)n * k; ++q) gs[q % (size_t)n]->histClean[(size_t)views[q].lpt_parity] = 1;   // (every pass leaves its cost histogram zero)
+                // (every pass leaves its cost histogram zero)
+                for (size_t q = 0; q < (size_t)n * k; ++q) gs[q % (size_t)n]->histClean[(size_t)views[q].lpt_parity] = 1;
             }
         } else if (render) {
             const bool pubInRaster = own && allFast;
@@ -457,7 +468,8 @@ int mv_group_step(mv_group *grp, int32_t k, int32_t render, int32_t policy, uint
     if (!grp || grp->gyms.empty()) return fail("mv_group_step: the group is gone (a member was closed)");
     if (policy != MV_POLICY_NONE && policy != MV_POLICY_MULTIDISCRETE && policy != MV_POLICY_SINGLE_BIT) return fail("mv_group_step: unknown policy");
     if (k < 1) return fail("mv_group_step: k >= 1 required");
-    // A call's chunks: what every member's slot groups hold, and at most MAX_GROUP_TICKS -- the two-launch batched path's limit (raster_union_batch_applicable): a chunk
+    // A call's chunks: what every member's slot groups hold, and at most MAX_GROUP_TICKS -- the two-launch batched path's limit
+    // (raster_union_batch_applicable): a chunk
     // of 9..16 ticks would fall back to two launches per TICK.
     int chunk = (int)MAX_GROUP_TICKS;
     for (mv_gym *g : grp->gyms) chunk = std::min(chunk, g->batch);
@@ -474,8 +486,10 @@ int mv_group_step(mv_group *grp, int32_t k, int32_t render, int32_t policy, uint
     return rc;
 }
 
-// the measured rules bench.py used to carry (r08p / r08y: 16 against 8 ticks per call, M obs/s: TowerBuilding 1024 envs 28.5 / 26.8, ObstaclesHard 1024 24.5 / 22.7, Rearrange 23.7 / 21.5,
-// Collect 15.0 / 14.5; 512 envs 16.2 / 19.3, ObstaclesHard 512 13.2 / 18.8, Sokoban 19.9 / 25.9, 512 envs x 4 agents 19.5 / 26.0, 4096 envs 28.4 / 30.5; overlap r07a/b/j)
+// the measured rules bench.py used to carry (r08p / r08y: 16 against 8 ticks per call, M obs/s: TowerBuilding 1024 envs 28.5 / 26.8, ObstaclesHard 1024 24.5 /
+// 22.7, Rearrange 23.7 / 21.5,
+// Collect 15.0 / 14.5; 512 envs 16.2 / 19.3, ObstaclesHard 512 13.2 / 18.8, Sokoban 19.9 / 25.9, 512 envs x 4 agents 19.5 / 26.0, 4096 envs 28.4 / 30.5;
+// overlap r07a/b/j)
 int mv_recommended_ticks_per_call(const mv_gym *g)
 {
     if (!g || g->closed) return 1;

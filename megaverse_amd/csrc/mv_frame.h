@@ -446,7 +446,8 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
             }
         }
         MV_TF(1);   // the slots' records
-        if (PIPE && (rd + 1) * THREADS >= numSlots) __syncthreads();   // the state is read (the loads have returned: the barrier's fences): the tick wave may write the next tick's
+        // the state is read (the loads have returned: the barrier's fences): the tick wave may write the next tick's
+        if (PIPE && (rd + 1) * THREADS >= numSlots) __syncthreads();
         // frame-level visibility
         int cls = 0;
         int rect[4] = {0, 0, 0, 0};
@@ -572,17 +573,20 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
             for (int q = 0; q < 9; ++q) o[3 + q] = cm.c[q];
             o[12] = cm.origin[0]; o[13] = cm.origin[1]; o[14] = cm.origin[2];   // (o[15] of record 0 is the count)
         }
-        if (tid >= 32 && (tid <= 32 + A || (hex && tid > 32 + MAX_AGENTS && tid <= 32 + MAX_CAMS))) {   // light (0,4,2) camera-relative (magnum_env_renderer.cpp:201) in the axes of every frame a box can live in
+        // light (0,4,2) camera-relative (magnum_env_renderer.cpp:201) in the axes of every frame a box can live in
+        if (tid >= 32 && (tid <= 32 + A || (hex && tid > 32 + MAX_AGENTS && tid <= 32 + MAX_CAMS))) {
             const int f = tid - 32;
             const V3 lw = mat_mul(s_cam[viewer].c, v3(0.0f, 4.0f, 2.0f));
             const V3 l = f == 0 ? lw : f == 1 + viewer ? v3(0.0f, 4.0f, 2.0f) : mat_tmul(s_cam[f - 1].c, lw);
             float *o = fh + FH_LREL + 4 * f;
             o[0] = l.x; o[1] = l.y; o[2] = l.z; o[3] = 0.0f;
         }
-        if (tid < 32 && !sorted) fh[FH_WB + tid] = __uint_as_float(tid == 31 ? 0u : s_wbits[tid]);   // (sorted: the rounds' depth bounds, above; word 31 -- positions 992 .. 1023, which no short list has -- is the marker's place)
+        // (sorted: the rounds' depth bounds, above; word 31 -- positions 992 .. 1023, which no short list has -- is the marker's place)
+        if (tid < 32 && !sorted) fh[FH_WB + tid] = __uint_as_float(tid == 31 ? 0u : s_wbits[tid]);
     }
     if (tid == 0) gv.lpt_list[(size_t)(bin * LPT_SUBS + (frame & (LPT_SUBS - 1))) * lpt_sub_capacity(gv.num_envs * gv.num_agents) + binPlace] = frame;
-    if (frame == 0 && !gv.lpt_no_clear)   // the histogram the NEXT pass fills: last read by a raster pass as many passes ago as there are slots, which this step waited for
+    // the histogram the NEXT pass fills: last read by a raster pass as many passes ago as there are slots, which this step waited for
+    if (frame == 0 && !gv.lpt_no_clear)
         for (int i = tid; i < LPT_BUCKETS * LPT_SUBS; i += THREADS) gv.lpt_hist[((gv.lpt_parity + 1) % gv.lpt_hists) * (LPT_BUCKETS * LPT_SUBS) + i] = 0;
     MV_TF(5);   // header, cost bin
     sync();   // the LDS scratch above is reused by the next frame of this workgroup (fused step + setup kernels)

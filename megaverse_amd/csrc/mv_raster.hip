@@ -564,7 +564,8 @@ constexpr float SPEC_COS2 = 0.97f * 0.97f;
 
 // Where the short-list pass's pixels go: the frame as a BUFFER (four scalar registers: base, size), a pixel's place in it a 32-bit byte offset -- one
 // v_mad_i32_i24 per pixel where the 64-bit address arithmetic of a global store took three vector instructions; `edgeless`: the frame is whole tiles
-// (every BASELINE size is), so no pixel needs its "inside the frame?" compares.  (A store beyond the frame's bytes would be dropped by the buffer's range check.)
+// (every BASELINE size is), so no pixel needs its "inside the frame?" compares.  (A store beyond the frame's bytes would be dropped by the buffer's range
+// check.)
 struct PixOut {
     __amdgpu_buffer_rsrc_t rsrc;
     int W, H, W4;
@@ -605,8 +606,12 @@ struct FastArgs {   // what raster_fast_kernel needs of the GymView (fewer live 
     // that reuses it finds it clean without a fill kernel in front of it (mv_api.hip: take_hist).  nullptr: not this launch's business.
     int *hist_done;
     int wg_total;
-    int tail_div, tail_split;   // d > 0: the cheapest 1/d of the frames -- the LAST workgroups of the launch -- are cut into tail_split pieces instead of the launch's split (launch_raster)
-    int planar;   // 1: tiles that one face of one world box covers take the planar path (planar_tile / overlay_tile); 0: every tile takes the general one (MV_PLANAR=0, comparisons); 2: no overlay_tile
+    // d > 0: the cheapest 1/d of the frames -- the LAST workgroups of the launch -- are cut into tail_split pieces instead of the launch's split
+    // (launch_raster)
+    int tail_div, tail_split;
+    // 1: tiles that one face of one world box covers take the planar path (planar_tile / overlay_tile); 0: every tile takes the general one (MV_PLANAR=0,
+    // comparisons); 2: no overlay_tile
+    int planar;
 };
 
 // true_objective is only ever recorded by a finishing env (vector_env.cpp:96-101): the others keep the value of their last episode
@@ -659,7 +664,8 @@ constexpr unsigned KEY_NEAR = 0x3c23d70au;   // bits of NEAR_Z = 0.01f
 constexpr unsigned KEY_FAR = 0x42f00000u - KEY_NEAR;   // bits of FAR_Z = 120.0f, relative
 static_assert(NEAR_Z == 0.01f && FAR_Z == 120.0f, "update KEY_NEAR / KEY_FAR");
 
-// depthMask: ~POS_MASK, handed in IN A VECTOR REGISTER (box_run launders it): gfx950's VOP3 encoding takes one scalar operand and no literal, so "(x & literal) |
+// depthMask: ~POS_MASK, handed in IN A VECTOR REGISTER (box_run launders it): gfx950's VOP3 encoding takes one scalar operand and no literal, so "(x & literal)
+// |
 // scalar" is two instructions, "(x & vector) | scalar" is one v_and_or_b32 -- 19 instead of 20 per box and pixel in the pass's innermost loop
 template <unsigned POS_MASK>
 __device__ __forceinline__ unsigned box_key(V3 inv, const float4 lo, const float4 hi, int pos, unsigned depthMask = ~POS_MASK)
@@ -814,7 +820,8 @@ __device__ __forceinline__ unsigned fast_shade(unsigned best, V3 bn, const float
 
 struct FastFrame { int frame, part, viewer, nVis, split; };
 
-// the frames at the END of the cost order -- the cheapest 1/div of them, a multiple of 8 -- that a launch cuts finer than the others (launch_raster: fine-grained tail)
+// the frames at the END of the cost order -- the cheapest 1/div of them, a multiple of 8 -- that a launch cuts finer than the others (launch_raster:
+// fine-grained tail)
 __host__ __device__ inline int tail_frames(int frames, int div) { return (frames / div) & ~7; }
 
 // The fast kernels' prologue: which frame is this workgroup's, then copies (header, list, rectangles) + the separable ray tables; ends with the
@@ -846,8 +853,10 @@ __device__ __forceinline__ FastFrame fast_prologue(const FastArgs &fa, int blk, 
     __shared__ int s_wsum[4], s_frame, s_lastWG;
     {
         static_assert(LPT_SUBS == 4, "the bin's counters are read as one int4");
-        const bool binThread = NT == 256 || tid < LPT_BUCKETS;   // (one thread per cost bin; a 512-thread workgroup's other waves only keep the barriers company)
-        const int4 c0 = binThread ? *reinterpret_cast<const int4 *>(fa.hist + (LPT_BUCKETS - 1 - tid) * LPT_SUBS) : make_int4(0, 0, 0, 0);   // the bin's LPT_SUBS counters
+        // (one thread per cost bin; a 512-thread workgroup's other waves only keep the barriers company)
+        const bool binThread = NT == 256 || tid < LPT_BUCKETS;
+        // the bin's LPT_SUBS counters
+        const int4 c0 = binThread ? *reinterpret_cast<const int4 *>(fa.hist + (LPT_BUCKETS - 1 - tid) * LPT_SUBS) : make_int4(0, 0, 0, 0);
         const int h = (c0.x + c0.y) + (c0.z + c0.w);
         int x = h;
 #pragma unroll
@@ -985,7 +994,8 @@ __device__ __forceinline__ void box_run(unsigned long long m, int k, const V3 (&
 // the general path with the refined survivor mask.
 // Reference for what is drawn: magnum_env_renderer.cpp:288-330 (depth-tested, back-face-culled boxes), :200-203 (Phong uniforms).
 constexpr float PLANAR_MARGIN = 2e-4f;
-enum : unsigned { TC_EMPTY = 0, TC_PLANAR = 1, TC_PLANAR_SPEC = 2, TC_OVERLAY = 3, TC_GENERAL = 4 };   // a classified tile's class (s_tile[u].w, classify_tiles)
+// a classified tile's class (s_tile[u].w, classify_tiles)
+enum : unsigned { TC_EMPTY = 0, TC_PLANAR = 1, TC_PLANAR_SPEC = 2, TC_OVERLAY = 3, TC_GENERAL = 4 };
 constexpr int CLS_MAX_TILES = 128;   // tiles of one workgroup that can be classified (LDS: 16 B each); more (hires frames): the general path throughout
 
 // s_tile[u] of the workgroup's u-th tile (u = 4 j + w is tile (j split + part) 4 + w of the frame, the tile loop's order): x, y = the list positions
@@ -993,13 +1003,16 @@ constexpr int CLS_MAX_TILES = 128;   // tiles of one workgroup that can be class
 // of the mask is set).  s_line[64 wave + 16 s + 4 f + e]: edge e of face f of the s-th box of the wave's current round as (a, b, c_in, span):
 // inside at every pixel of the tile <=> a x0 + b y0 + c_in >= 0 at the tile's first pixel (x0, y0); outside at every pixel <=> that + span <= 0.
 // Called by all 256 threads after the prologue's barrier (s_vis, s_rect, the header are in LDS); ends with a barrier.
-// The tile loop's ORDER (raster_fast_body): the classification also files every tile under its class -- s_cnt[c] tiles of category c (0 general, 1 overlay, 2 planar with the
-// highlight test, 3 planar, 4 empty), the tile's place within its category in s_tile[u].z (cat | place << 3: the covering face it held moved into the class word) and
-// its first pixel in s_txy[u] (x | y << 16) -- so that the workgroup draws its tiles most expensive class first from a compact list, and clears the empty ones -- 43 % of a
+// The tile loop's ORDER (raster_fast_body): the classification also files every tile under its class -- s_cnt[c] tiles of category c (0 general, 1 overlay, 2
+// planar with the
+// highlight test, 3 planar, 4 empty), the entry's category, run length and place within its category in s_tile[u].z (the covering face it held moved into the
+// class word) and
+// its first pixel in s_txy[u] (x | y << 16) -- so that the workgroup draws its tiles most expensive class first from a compact list, and clears the empty ones
+// -- 43 % of a
 // TowerBuilding frame's tiles (r07d census) -- with all its threads at once instead of handing them out one by one.
 template <int TH, int NT>
 __device__ __forceinline__ void classify_tiles(uint4 *s_tile, float4 *s_line, const float4 *s_vis, const short4 *s_rect, const float *s_hdr, const float *camv, int nVis, unsigned long long wb0,
-                                               int W, int H, int part, int split, int tilesX, int numTiles, int perWG, bool overlayOn, int *s_cnt, unsigned *s_txy)
+                                               int W, int H, int part, int split, int tilesX, int numTiles, int perWG, bool overlayOn, int *s_cnt, unsigned *s_txy, bool bulkClear)
 {
     constexpr int NW = NT / 64;        // waves of the workgroup
     constexpr int PPR = 16 / NW;       // list positions per wave and round (256 edge-function slots in all: 4 with four waves, 2 with eight)
@@ -1054,7 +1067,8 @@ __device__ __forceinline__ void classify_tiles(uint4 *s_tile, float4 *s_line, co
         const float mg = PLANAR_MARGIN * (__builtin_fabsf(pk) + __builtin_fabsf(bnd));
         const float cin = ((ec + __builtin_fminf(0.0f, ea * WX)) + __builtin_fminf(0.0f, eb * WY)) - mg;
         const float span = (__builtin_fabsf(ea) * WX + __builtin_fabsf(eb) * WY) + 2.0f * mg;
-        if (es < PPR) myLines[lane] = cand ? make_float4(ea, eb, cin, span) : make_float4(0.0f, 0.0f, -1.0f, 0.0f);   // (no such face: never inside, always outside)
+        // (no such face: never inside, always outside)
+        if (es < PPR) myLines[lane] = cand ? make_float4(ea, eb, cin, span) : make_float4(0.0f, 0.0f, -1.0f, 0.0f);
         const unsigned long long candMask = __ballot(cand), coverMask = __ballot(coverOK);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (a wave's LDS operations execute in order: only the compiler has to keep them so)
         __builtin_amdgcn_wave_barrier();
@@ -1124,7 +1138,8 @@ __device__ __forceinline__ void classify_tiles(uint4 *s_tile, float4 *s_line, co
     {
         const float hx = 0.5f * WX * sx, hy = 0.5f * WY * sy;
         const float r2 = hx * hx + hy * hy;                                    // (tile radius)^2 on the plane z = -1 = sin^2 of the bound on its angular radius
-        const float cosT = 0.965f * __builtin_amdgcn_sqrtf(__builtin_fmaxf(1.0f - r2, 0.0f)) - 0.2623f * __builtin_amdgcn_sqrtf(r2);   // cos(acos(0.965) + asin(r)), rounded towards the larger angle
+        // cos(acos(0.965) + asin(r)), rounded towards the larger angle
+        const float cosT = 0.965f * __builtin_amdgcn_sqrtf(__builtin_fmaxf(1.0f - r2, 0.0f)) - 0.2623f * __builtin_amdgcn_sqrtf(r2);
         const bool usable = r2 < 0.5f && cosT > 0.0f;
         const float cosT2 = cosT * cosT;
         const float L0 = s_hdr[FH_LREL + 0], L1 = s_hdr[FH_LREL + 1], L2 = s_hdr[FH_LREL + 2];   // the light relative to the eye, world axes (frame 0)
@@ -1176,10 +1191,71 @@ __device__ __forceinline__ void classify_tiles(uint4 *s_tile, float4 *s_line, co
             }
             s_tile[u].w = info;
             const unsigned tclass = info & 7u, cat = tclass == TC_GENERAL ? 0u : tclass == TC_OVERLAY ? 1u : tclass == TC_PLANAR_SPEC ? 2u : tclass == TC_PLANAR ? 3u : 4u;
-            s_tile[u].z = cat | ((unsigned)atomicAdd(&s_cnt[cat], 1) << 3);   // (the covering face this word held is in the class word now)
-            s_txy[u] = (unsigned)tX0[c] | ((unsigned)tY0[c] << 16);
+            // RUNS: neighbours in a tile row that one face of one box covers alike (the same class word), or that are empty, are ONE entry of the drawing order
+            // -- at
+            // most four tiles: the run's uniform set-up (the face's plane, colour, light term), its rows' ray terms and its hand-out are paid once.  The valid
+            // tiles
+            // of a chunk are its first lanes (every lane here is one); a run's tiles are neighbours in one tile row.
+            const bool runs = tclass == TC_PLANAR || tclass == TC_PLANAR_SPEC || (tclass == TC_EMPTY && !bulkClear);
+            // (the previous lane's tile is the left neighbour only where the workgroup owns whole tile rows: a frame cut into `split` pieces deals its tiles
+            // out in fours)
+            const unsigned txy = (unsigned)tX0[c] | ((unsigned)tY0[c] << 16);
+            const unsigned prevInfo = (unsigned)__shfl_up((int)info, 1, 64), prevTxy = (unsigned)__shfl_up((int)txy, 1, 64);
+            const bool natHead = !runs || lane == 0 || prevInfo != info || prevTxy + (unsigned)TILE_W != txy;
+            const unsigned long long nat = __ballot(natHead), below = nat & ((2ull << lane) - 1ull);   // (bit `lane` and lower; lane 0 is a head: never empty)
+            const int posInRun = lane - (63 - __clzll((long long)below));
+            const bool head = natHead || (posInRun & 3) == 0;
+            const unsigned long long heads = __ballot(head), valid = __ballot(true), above = lane < 63 ? heads >> (lane + 1) : 0ull;
+            const int nextHead = above ? lane + __ffsll((long long)above) : 64;
+            const int len = min(nextHead, (int)__popcll(valid)) - lane;                                  // (1 .. 4)
+            // cat | run length << 3 | place within the category << 6; 7: not a run's first tile, not listed.  (The covering face this word held is in the class
+            // word now.)
+            s_tile[u].z = head ? cat | ((unsigned)len << 3) | ((unsigned)atomicAdd(&s_cnt[cat], 1) << 6) : 7u;
+            s_txy[u] = txy;
         }
         __syncthreads();
+    }
+}
+
+// the pixels of `n` neighbouring tiles of one tile row (first pixel (tx0, ty0)) that the face of axis k (the one towards the eye) of the world box at list
+// position
+// `pos` covers: the face's constants and the rows' ray terms once, per tile the columns' terms and the pixels -- planar_tile's arithmetic, operation for
+// operation
+template <int NP, bool SPEC>
+__device__ __forceinline__ void planar_run(int pos, int k, int n, const float4 *s_vis, const float *s_hdr, const float4 *s_col, const float4 *s_row,
+                                           const float2 *s_rowq, const float *s_colq, float nzk, int tx0, int ty0, int lane, const PixOut &po)
+{
+    const int W = po.W, H = po.H;
+    const float lok = uniform_f32(reinterpret_cast<const float *>(s_vis)[8 * pos + k]), hik = uniform_f32(reinterpret_cast<const float *>(s_vis)[8 * pos + 4 + k]);
+    const float plane = lok > 0.0f ? lok : hik;   // the face towards the eye
+    const unsigned color = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_uint(reinterpret_cast<const float *>(s_vis)[8 * pos + 7]));
+    const float cr = float((color >> 16) & 255u), cg = float((color >> 8) & 255u), cb = float(color & 255u);
+    const float lk = uniform_f32(s_hdr[FH_LREL + k]);
+    const float lks = plane > 0.0f ? lk : 0.0f - lk;
+    int lpx = lane;
+    asm volatile("" : "+v"(lpx));   // (this lane's place in the tile is formed here, per run: kept across the tile loop it is spilled at seven waves per SIMD)
+    const int lx = lpx & (TILE_W - 1), py0 = ty0 + lpx / TILE_W;
+    float rowk[NP];
+    float2 rq[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int pyc = min(py0 + TILE_H * j, H - 1);
+        rowk[j] = reinterpret_cast<const float *>(s_row)[4 * pyc + 1 + k];
+        rq[j] = s_rowq[pyc];
+    }
+#pragma unroll 1
+    for (int q = 0; q < n; ++q) {
+        const int px = tx0 + TILE_W * q + lx, pxc = min(px, W - 1);
+        const float colk = reinterpret_cast<const float *>(s_col)[4 * pxc + 1 + k];
+        const float cq = s_colq[pxc];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const float dk = (colk + rowk[j]) + nzk;              // the ray's component along k: the same sum the general path forms
+            const float t = plane * __builtin_amdgcn_rcpf(dk);    // == min(lo_k inv_k, hi_k inv_k) of the slab test
+            const float nv = t * __builtin_fabsf(dk);
+            const unsigned rgba = phong_tail<SPEC>(t, nv - lks, nv, cq + rq[j].x, rq[j].y, cr, cg, cb);
+            put_px(po, px, py0 + TILE_H * j, rgba);
+        }
     }
 }
 
@@ -1218,7 +1294,8 @@ template <int NP>
 __device__ __forceinline__ void clear_tile(const PixOut &po, int tx0, int ty0, int lane)
 {
     constexpr int TH = TILE_H * NP;
-    // (lane and colour are laundered: what is derived from them is formed here, per tile -- hoisted out of the tile loop it costs the kernel registers it does not have at seven waves per SIMD)
+    // (lane and colour are laundered: what is derived from them is formed here, per tile -- hoisted out of the tile loop it costs the kernel registers it does
+    // not have at seven waves per SIMD)
     unsigned c = 0xff000000u;
     asm volatile("" : "+v"(lane), "+v"(c));
     if ((po.W & 3) == 0 && tx0 + TILE_W <= po.W) {   // (uniform; the frame's base is 16-byte aligned: raster_fast_body checks)
@@ -1263,7 +1340,8 @@ __device__ __forceinline__ void overlay_tile(int posA, int k, unsigned long long
         const V3 dw = v3((cx.y + ry.y) + nzm0, (cx.z + ry.z) + nzm1, (cx.w + ry.w) + nzm2);
         const float dk = k == 0 ? dw.x : k == 1 ? dw.y : dw.z;
         const float t = plane * __builtin_amdgcn_rcpf(dk);
-        const unsigned keyA = ((__float_as_uint(t) - KEY_NEAR) & ~POS_MASK) | (unsigned)posA;   // box_key of the covering face: it is hit (classify_tiles), its entry depth is this product
+        // box_key of the covering face: it is hit (classify_tiles), its entry depth is this product
+        const unsigned keyA = ((__float_as_uint(t) - KEY_NEAR) & ~POS_MASK) | (unsigned)posA;
         unsigned best = keyA;
         unsigned long long m = rest;
         while (m) {
@@ -1285,8 +1363,10 @@ __device__ __forceinline__ void overlay_tile(int posA, int k, unsigned long long
     }
 }
 
-// The general path for a tile of a classified frame: its list is ONE culling round (at most 64 primitives) and the tile's candidates -- mv0, not empty -- came out of
-// the classification, so the rays are set up at once and there is no loop over rounds (the same arithmetic, in the same order, as the loop in raster_fast_body).
+// The general path for a tile of a classified frame: its list is ONE culling round (at most 64 primitives) and the tile's candidates -- mv0, not empty -- came
+// out of
+// the classification, so the rays are set up at once and there is no loop over rounds (the same arithmetic, in the same order, as the loop in
+// raster_fast_body).
 template <bool SHAPES, unsigned POS_MASK, int NP>
 __device__ __forceinline__ void general_tile(unsigned long long mv0, unsigned long long wb0, unsigned signs, const float4 *s_vis, const float *s_hdr, const float *camv, int viewer, const float4 *s_col,
                                              const float4 *s_row, const float2 *s_rowq, const float *s_colq, float nzm0, float nzm1, float nzm2, int px, int py0, const PixOut &po)
@@ -1358,6 +1438,70 @@ __device__ __forceinline__ void general_tile(unsigned long long mv0, unsigned lo
 constexpr int fast_lds_bytes(int maxvis) { return 40 * maxvis + 4 * FH_FLOATS; }    // records 32 B + rectangles 8 B per primitive, frame header
 constexpr int glist_lds_bytes(int maxvis) { return 9 * maxvis + 4 * FH_FLOATS; }    // rectangles 8 B + class 1 B per primitive, frame header
 
+#ifdef MV_RASTER_TIMING
+#define RT_COUNT(i, n) do { const unsigned long long n_ = (unsigned long long)(n); if (fa.rdbg && lane == 0) atomicAdd(fa.rdbg + (size_t)16384 * 4 * 8 + (i), n_); } while (0)   /* census of the tile loop (wave-uniform events) */
+#else
+#define RT_COUNT(i, n) do { } while (0)
+#endif
+// a classified tile -- or, LISTED, an entry of the drawing order: a run of up to four planar / empty neighbours of a tile row -- by its class (classify_tiles)
+template <bool SHAPES, unsigned POS_MASK, int NP, bool LISTED>
+__device__ __forceinline__ void classified_tile(const FastArgs &fa, const int u, const int tx0, const int ty0, const uint4 *s_tile, const float4 *s_vis, const float *s_hdr, const float *camv, int viewer,
+                                            const float4 *s_col, const float4 *s_row, const float2 *s_rowq, const float *s_colq, float nzm0, float nzm1, float nzm2, unsigned long long wb0,
+                                            int lane, const PixOut &po)
+{
+    const unsigned info = (unsigned)__builtin_amdgcn_readfirstlane(s_tile[u].w), tclass = info & 7u;
+    const int run = LISTED ? (int)(((unsigned)__builtin_amdgcn_readfirstlane(s_tile[u].z) >> 3) & 7u) : 1;
+    RT_COUNT(0, run);                                 // classified tiles
+    if (tclass == TC_EMPTY) {   // nothing: the clear colour
+        RT_COUNT(1, run);
+        for (int q = 0; q < run; ++q) clear_tile<NP>(po, tx0 + TILE_W * q, ty0, lane);
+        return;
+    }
+    if (LISTED && tclass <= TC_PLANAR_SPEC) {   // a run of tiles one face covers
+        const int k = (int)((info >> 3) & 3u), posA = (int)(info >> 5);
+        const float nzk = k == 0 ? nzm0 : k == 1 ? nzm1 : nzm2;
+        RT_COUNT(2, run);
+        RT_COUNT(12, tclass == TC_PLANAR ? run : 0);
+        // (no pixel of these tiles lies in the highlight cone)
+        if (tclass == TC_PLANAR) planar_run<NP, false>(posA, k, run, s_vis, s_hdr, s_col, s_row, s_rowq, s_colq, nzk, tx0, ty0, lane, po);
+        else planar_run<NP, true>(posA, k, run, s_vis, s_hdr, s_col, s_row, s_rowq, s_colq, nzk, tx0, ty0, lane, po);
+        return;
+    }
+    int lpx = lane;
+    // (this lane's place in the tile is formed here, per tile: kept across the loop it is spilled at seven waves per SIMD, and the reload's s_waitcnt vmcnt(0)
+    // also waits for the previous tile's pixel stores)
+    asm volatile("" : "+v"(lpx));
+    const int px = tx0 + (lpx & (TILE_W - 1)), py0 = ty0 + lpx / TILE_W;
+    if (tclass <= TC_OVERLAY) {   // one world box, and one of its faces covers the tile
+#if defined(MV_RASTER_DEBUG_SKIP) && MV_RASTER_DEBUG_SKIP == 3   // (measurement builds: covered tiles cost nothing)
+        return;
+#endif
+        const int k = (int)((info >> 3) & 3u), posA = (int)(info >> 5);
+        const float nzk = k == 0 ? nzm0 : k == 1 ? nzm1 : nzm2;
+        RT_COUNT(2, tclass != TC_OVERLAY);
+        RT_COUNT(12, tclass == TC_PLANAR);
+        RT_COUNT(13, tclass == TC_OVERLAY);
+        // (no pixel of the tile lies in the highlight cone)
+        if (tclass == TC_PLANAR) planar_tile<NP, false>(posA, k, s_vis, s_hdr, s_col, s_row, s_rowq, s_colq, nzk, px, py0, po);
+        else if (tclass == TC_PLANAR_SPEC) planar_tile<NP, true>(posA, k, s_vis, s_hdr, s_col, s_row, s_rowq, s_colq, nzk, px, py0, po);
+        else {   // ... and boxes of other frames of reference (the time bar, a carried object)
+            const uint2 tm = *reinterpret_cast<const uint2 *>(&s_tile[u]);
+            const unsigned long long others = (((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(tm.y) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(tm.x)) & ~wb0;
+            overlay_tile<SHAPES, POS_MASK, NP>(posA, k, others, s_vis, s_hdr, camv, viewer, s_col, s_row, s_rowq, s_colq, nzm0, nzm1, nzm2, px, py0, po);
+        }
+        return;
+    }
+#if defined(MV_RASTER_DEBUG_SKIP) && MV_RASTER_DEBUG_SKIP == 2   // (measurement builds: general tiles cost nothing)
+    return;
+#endif
+    const uint2 tm = *reinterpret_cast<const uint2 *>(&s_tile[u]);
+    const unsigned long long mv0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(tm.y) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(tm.x);
+    RT_COUNT(4, 1);
+    RT_COUNT(5, __popcll(mv0 & wb0));
+    RT_COUNT(6, __popcll(mv0 & ~wb0));
+    general_tile<SHAPES, POS_MASK, NP>(mv0, wb0, fa.planar == 3 ? 0u : (info >> 11) & 15u, s_vis, s_hdr, camv, viewer, s_col, s_row, s_rowq, s_colq, nzm0, nzm1, nzm2, px, py0, po);
+}
+
 template <int MAXVIS, bool SHAPES, bool HEXF, int NP, bool CLS = true, int NT = 256>   // CLS: with the tile classification
 __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *obs, int W, int H, int split, int blk, unsigned char *lds)
 {
@@ -1379,9 +1523,7 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
     unsigned long long rt_[6];
     rt_[0] = __builtin_amdgcn_s_memtime(); rt_[5] = __builtin_amdgcn_s_memrealtime();
 #define RT_MARK(i) rt_[i] = __builtin_amdgcn_s_memtime()
-#define RT_COUNT(i, n) do { const unsigned long long n_ = (unsigned long long)(n); if (fa.rdbg && lane == 0) atomicAdd(fa.rdbg + (size_t)16384 * 4 * 8 + (i), n_); } while (0)   /* census of the tile loop (wave-uniform events) */
 #else
-#define RT_COUNT(i, n) do { } while (0)
 #define RT_MARK(i) do { } while (0)
 #endif
     fast_publish(fa, blk);
@@ -1415,7 +1557,8 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
     float4 *s_line = s_vis + 2 * 64;
     uint4 *s_tile = reinterpret_cast<uint4 *>(s_vis + 2 * 64 + 256);
     const int perWG = (numTiles - part * 4 + 4 * split - 1) / (4 * split) * 4;   // this workgroup's tiles, rounded up to four per turn of its waves
-    const bool cls = PLANAR && fa.planar && nVis <= 64 && perWG <= CLS_MAX_TILES && perWG >= 32;   // (uniform over the workgroup; few tiles do not repay the pass over the list)
+    // (uniform over the workgroup; few tiles do not repay the pass over the list)
+    const bool cls = PLANAR && fa.planar && nVis <= 64 && perWG <= CLS_MAX_TILES && perWG >= 32;
     __shared__ int s_next;   // the tile loop's hand-out counter (below)
     __shared__ int s_cnt[8];                                  // classified frames: tiles per category (classify_tiles)
     __shared__ unsigned s_txy[CLS_MAX_TILES];                 // ... every tile's first pixel, x | y << 16
@@ -1426,20 +1569,21 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
 #define MV_TILE_LIST 1   // (0: the tiles in frame order, the empty ones handed out like the others -- the A/B of r09c)
 #endif
     constexpr bool LISTED = PLANAR && MV_TILE_LIST != 0;
-    if (PLANAR && cls && !LISTED) classify_tiles<TH, NT>(s_tile, s_line, s_vis, s_rect, s_hdr, camv, nVis, wb0, W, H, part, split, tilesX, numTiles, perWG, fa.planar != 2, s_cnt, s_txy);
+    // whole tiles, rows of whole 16-byte groups: the empty tiles are cleared by all threads together (below) and stay out of the list
+    const bool bulk = LISTED && po.edgeless && (W & 3) == 0;
+    if (PLANAR && cls && !LISTED) classify_tiles<TH, NT>(s_tile, s_line, s_vis, s_rect, s_hdr, camv, nVis, wb0, W, H, part, split, tilesX, numTiles, perWG, fa.planar != 2, s_cnt, s_txy, true);
     else if (PLANAR && cls) {
-        classify_tiles<TH, NT>(s_tile, s_line, s_vis, s_rect, s_hdr, camv, nVis, wb0, W, H, part, split, tilesX, numTiles, perWG, fa.planar != 2, s_cnt, s_txy);   // (ends with a barrier)
-        // whole tiles, rows of whole 16-byte groups: the empty tiles are cleared by all threads together (below) and stay out of the list
-        const bool bulk = po.edgeless && (W & 3) == 0;
+        // (ends with a barrier)
+        classify_tiles<TH, NT>(s_tile, s_line, s_vis, s_rect, s_hdr, camv, nVis, wb0, W, H, part, split, tilesX, numTiles, perWG, fa.planar != 2, s_cnt, s_txy, bulk);
         const int c0 = s_cnt[0], c1 = s_cnt[1], c2 = s_cnt[2], c3 = s_cnt[3], nE = s_cnt[4];
         nList = __builtin_amdgcn_readfirstlane(c0 + c1 + c2 + c3 + (bulk ? 0 : nE));
         if (tid < CLS_MAX_TILES) {
             const int tile = ((tid >> 2) * split + part) * 4 + (tid & 3);
             if (tid < perWG && tile < numTiles) {
-                const unsigned z = s_tile[tid].z, cat = z & 7u, place = z >> 3;
+                const unsigned z = s_tile[tid].z, cat = z & 7u, place = z >> 6;
                 const int base = cat == 0u ? 0 : cat == 1u ? c0 : cat == 2u ? c0 + c1 : cat == 3u ? c0 + c1 + c2 : c0 + c1 + c2 + c3;
                 if (cat == 4u && bulk) s_empty[place] = (unsigned short)tid;
-                else s_order[base + (int)place] = (unsigned short)tid;
+                else if (cat != 7u) s_order[base + (int)place] = (unsigned short)tid;   // (7: inside a run, drawn with the run's first tile)
             }
         }
         __syncthreads();
@@ -1459,69 +1603,40 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
         }
     } else __syncthreads();
     RT_MARK(2);
-#if defined(MV_RASTER_DEBUG_SKIP) && MV_RASTER_DEBUG_SKIP == 1   // (measurement builds: the pass's fixed cost -- prologue + classification -- alone; pixels are NOT drawn)
+// (measurement builds: the pass's fixed cost -- prologue + classification -- alone; pixels are NOT drawn)
+#if defined(MV_RASTER_DEBUG_SKIP) && MV_RASTER_DEBUG_SKIP == 1
     return;
 #endif
 
     // The workgroup's tiles are handed out one at a time (an LDS counter; the next index is requested while the current tile is drawn): a wave
     // that always drew the same tile column of its frame -- tile index = wave mod 4 -- lived as long as the most crowded column, and the
     // workgroup's other three waited for it 4-5 us on average, up to 17 (r04e).  u = 4 j + w is tile (j split + part) 4 + w of the frame.
-    const unsigned tilesXinv = (unsigned)((0x100000000ull + (unsigned)tilesX - 1u) / (unsigned)tilesX);   // tile / tilesX == umulhi(tile, ceil(2^32 / tilesX)) while tile * tilesX < 2^32
     int unext = 0;
-    for (int it = wave; ; it = __builtin_amdgcn_readfirstlane(unext)) {
-        int u = it;
-        if (LISTED && cls) {   // classified: the it-th tile of the drawing order
-            if (it >= nList) break;
-            u = __builtin_amdgcn_readfirstlane((int)s_order[it]);
+    // classified frames, LISTED: the entries of the drawing order (most expensive class first), one at a time; a tile's first pixel comes from the table (no
+    // tile
+    // arithmetic, and none of its scalars alive in this loop: at seven waves per SIMD the loop below keeps the register file full)
+    if (LISTED && cls)
+        for (int it = wave; it < nList; it = __builtin_amdgcn_readfirstlane(unext)) {
+            const int u = __builtin_amdgcn_readfirstlane((int)s_order[it]);
+            if (lane == 0) unext = atomicAdd(&s_next, 1);
+            const unsigned txy = (unsigned)__builtin_amdgcn_readfirstlane(s_txy[u]);
+            classified_tile<SHAPES, POS_MASK, NP, LISTED>(fa, u, (int)(txy & 0xffffu), (int)(txy >> 16), s_tile, s_vis, s_hdr, camv, viewer, s_col, s_row, s_rowq, s_colq, nzm0, nzm1, nzm2, wb0, lane, po);
         }
+    // tile / tilesX == umulhi(tile, ceil(2^32 / tilesX)) while tile * tilesX < 2^32
+    const unsigned tilesXinv = (unsigned)((0x100000000ull + (unsigned)tilesX - 1u) / (unsigned)tilesX);
+    for (int u = wave; !(LISTED && cls); u = __builtin_amdgcn_readfirstlane(unext)) {
         const int tile = ((u >> 2) * split + part) * 4 + (u & 3);
-        if (tile >= numTiles) break;   // (unclassified: u grows with every request, every later tile of this wave is out of range, too)
+        if (tile >= numTiles) break;   // (u grows with every request: every later tile of this wave is out of range, too)
         if (lane == 0) unext = atomicAdd(&s_next, 1);
         const int ty = (int)__umulhi((unsigned)tile, tilesXinv), tx = tile - ty * tilesX;
         const int tx0 = tx * TILE_W, ty0 = ty * TH;
         const int tx1 = min(tx0 + TILE_W, W) - 1, ty1 = min(ty0 + TH, H) - 1;
-        // ---- which primitives can this tile's pixels hit?  (first round of 64 list positions)
-        unsigned long long mv0;
-        if (PLANAR && cls) {   // classified: the tile's class is in the table (classify_tiles), with the covering face if there is one
-            const unsigned info = (unsigned)__builtin_amdgcn_readfirstlane(s_tile[u].w), tclass = info & 7u;
-            RT_COUNT(0, 1);                                   // classified tiles
-            if (tclass == TC_EMPTY) {   // nothing: the clear colour
-                RT_COUNT(1, 1);
-                clear_tile<NP>(po, tx0, ty0, lane);
-                continue;
-            }
-            int lpx = lane;
-            asm volatile("" : "+v"(lpx));   // (this lane's place in the tile is formed here, per tile: kept across the loop it is spilled at seven waves per SIMD, and the reload's s_waitcnt vmcnt(0) also waits for the previous tile's pixel stores)
-            const int px = tx0 + (lpx & (TILE_W - 1)), py0 = ty0 + lpx / TILE_W;
-            if (tclass <= TC_OVERLAY) {   // one world box, and one of its faces covers the tile
-#if defined(MV_RASTER_DEBUG_SKIP) && MV_RASTER_DEBUG_SKIP == 3   // (measurement builds: covered tiles cost nothing)
-                continue;
-#endif
-                const int k = (int)((info >> 3) & 3u), posA = (int)(info >> 5);
-                const float nzk = k == 0 ? nzm0 : k == 1 ? nzm1 : nzm2;
-                RT_COUNT(2, tclass != TC_OVERLAY);
-                RT_COUNT(12, tclass == TC_PLANAR);
-                RT_COUNT(13, tclass == TC_OVERLAY);
-                if (tclass == TC_PLANAR) planar_tile<NP, false>(posA, k, s_vis, s_hdr, s_col, s_row, s_rowq, s_colq, nzk, px, py0, po);   // (no pixel of the tile lies in the highlight cone)
-                else if (tclass == TC_PLANAR_SPEC) planar_tile<NP, true>(posA, k, s_vis, s_hdr, s_col, s_row, s_rowq, s_colq, nzk, px, py0, po);
-                else {   // ... and boxes of other frames of reference (the time bar, a carried object)
-                    const uint2 tm = *reinterpret_cast<const uint2 *>(&s_tile[u]);
-                    const unsigned long long others = (((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(tm.y) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(tm.x)) & ~wb0;
-                    overlay_tile<SHAPES, POS_MASK, NP>(posA, k, others, s_vis, s_hdr, camv, viewer, s_col, s_row, s_rowq, s_colq, nzm0, nzm1, nzm2, px, py0, po);
-                }
-                continue;
-            }
-#if defined(MV_RASTER_DEBUG_SKIP) && MV_RASTER_DEBUG_SKIP == 2   // (measurement builds: general tiles cost nothing)
-            continue;
-#endif
-            const uint2 tm = *reinterpret_cast<const uint2 *>(&s_tile[u]);
-            mv0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(tm.y) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(tm.x);
-            RT_COUNT(4, 1);
-            RT_COUNT(5, __popcll(mv0 & wb0));
-            RT_COUNT(6, __popcll(mv0 & ~wb0));
-            general_tile<SHAPES, POS_MASK, NP>(mv0, wb0, fa.planar == 3 ? 0u : (info >> 11) & 15u, s_vis, s_hdr, camv, viewer, s_col, s_row, s_rowq, s_colq, nzm0, nzm1, nzm2, px, py0, po);
+        if (PLANAR && !LISTED && cls) {   // (MV_TILE_LIST=0: the classified tiles in frame order)
+            classified_tile<SHAPES, POS_MASK, NP, LISTED>(fa, u, tx0, ty0, s_tile, s_vis, s_hdr, camv, viewer, s_col, s_row, s_rowq, s_colq, nzm0, nzm1, nzm2, wb0, lane, po);
             continue;
         }
+        // ---- which primitives can this tile's pixels hit?  (first round of 64 list positions)
+        unsigned long long mv0;
         int lpx = lane;
         asm volatile("" : "+v"(lpx));
         const int px = tx0 + (lpx & (TILE_W - 1)), py0 = ty0 + lpx / TILE_W;
@@ -1619,7 +1734,8 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
         for (int j = 0; j < NP; ++j) {
             RT_COUNT(7, __ballot(best[j] <= (KEY_FAR | POS_MASK)) != 0ull);                     // (wave, pixel row) pairs that shade at all
             RT_COUNT(8, __popcll(__ballot(best[j] <= (KEY_FAR | POS_MASK))));                    // pixels with a hit on the general path
-            RT_COUNT(9, __ballot(best[j] <= (KEY_FAR | POS_MASK) && !((wb0 >> (best[j] & 63u)) & 1ull)) != 0ull);   // ... that shade something that is not a world box
+            // ... that shade something that is not a world box
+            RT_COUNT(9, __ballot(best[j] <= (KEY_FAR | POS_MASK) && !((wb0 >> (best[j] & 63u)) & 1ull)) != 0ull);
             const unsigned rgba = fast_shade<SHAPES, POS_MASK>(best[j], bn[j], s_vis, s_hdr, camv, viewer, dw[j], inv[j], dcx, dcy[j], a2[j], ldc[j]);
             put_px(po, px, py0 + TILE_H * j, rgba);
         }
@@ -1725,7 +1841,8 @@ __device__ __forceinline__ void raster_glist_body(const FastArgs &fa, uint32_t *
     __shared__ int s_next;
     if (tid == 0) s_next = 4;
     __syncthreads();
-    const bool depthSorted = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_uint(s_hdr[FH_WB + 31])) == DEPTH_SORTED_MARK;   // (the frame setup says so in the header)
+    // (the frame setup says so in the header)
+    const bool depthSorted = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_uint(s_hdr[FH_WB + 31])) == DEPTH_SORTED_MARK;
     const unsigned tilesXinv = (unsigned)((0x100000000ull + (unsigned)tilesX - 1u) / (unsigned)tilesX);
     int unext = 0;
     for (int u = wave; ; u = __builtin_amdgcn_readfirstlane(unext)) {
@@ -1754,11 +1871,13 @@ __device__ __forceinline__ void raster_glist_body(const FastArgs &fa, uint32_t *
         RT_COUNT(12, (nVis + 63) / 64);   // rounds their lists have
 #pragma unroll 1
         for (int k = 0; k * 64 < nVis; ++k) {
-            // A list in depth classes (DepthSortScratch).  The header's word for the round: the depth class it begins with.  A tile whose every pixel holds a hit nearer than the class's floor is
+            // A list in depth classes (DepthSortScratch).  The header's word for the round: the depth class it begins with.  A tile whose every pixel holds a
+            // hit nearer than the class's floor is
             // done with the list: everything from here on is hidden behind what has been found.
             if (depthSorted && k >= 1 && k < 31) {
                 const unsigned wd = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_uint(s_hdr[FH_WB + k]));
-                const float floorD = __uint_as_float(((wd & 63u) + (120u << 2)) << 21) * (1.0f - 1e-4f);   // (depth_class_floor, with a margin far above the rounding of the corners' depths)
+                // (depth_class_floor, with a margin far above the rounding of the corners' depths)
+                const float floorD = __uint_as_float(((wd & 63u) + (120u << 2)) << 21) * (1.0f - 1e-4f);
                 const unsigned bound = floorD > NEAR_Z ? __float_as_uint(floorD) - KEY_NEAR : 0u;          // in the units of the depth keys; 0: never stop here
                 bool covered = true;
 #pragma unroll
@@ -1854,7 +1973,8 @@ __global__ __launch_bounds__(256, WAVES) void raster_glist_kernel(FastArgs fa, u
     raster_glist_body<MAXVIS, SHAPES, HEXF, NP>(fa, obs, W, H, split, (int)blockIdx.x, s_buf);
 }
 
-template <int MAXVIS, bool SHAPES, int WAVES, bool HEXF = false, int NP = 1, int NT = 256>   // WAVES: waves per SIMD the variant is compiled for (register budget 512 / WAVES)
+// WAVES: waves per SIMD the variant is compiled for (register budget 512 / WAVES)
+template <int MAXVIS, bool SHAPES, int WAVES, bool HEXF = false, int NP = 1, int NT = 256>
 __global__ __launch_bounds__(NT, WAVES) void raster_fast_kernel(FastArgs fa, uint32_t *obs, int W, int H, int split)
 {
     __shared__ __attribute__((aligned(16))) unsigned char s_buf[fast_lds_bytes(MAXVIS)];
@@ -1981,7 +2101,8 @@ __global__ __launch_bounds__(256, WAVES) void raster_union_all_kernel(UnionRaste
     __shared__ __attribute__((aligned(16))) unsigned char s_buf[LDS];
     const int blk = (int)blockIdx.x - a.u.first[s];
     if (a.large[s]) raster_glist_body<VIS_XL, true, true, 1>(a.u.fa[s], a.u.obs[s], W, H, a.split_large, blk, s_buf);
-    else raster_fast_body<VIS_SMALL, true, false, NPS, false>(a.u.fa[s], a.u.obs[s], W, H, a.split_small, blk, s_buf);   // (no tile classification: this kernel's LDS is the long-list body's, and occupancy is what it lives on)
+    // (no tile classification: this kernel's LDS is the long-list body's, and occupancy is what it lives on)
+    else raster_fast_body<VIS_SMALL, true, false, NPS, false>(a.u.fa[s], a.u.obs[s], W, H, a.split_small, blk, s_buf);
 }
 
 // The observation passes of the k ticks of ONE batched group call (mv_group_step: n gyms -- scenarios -- x k ticks) with one launch: what
@@ -2173,7 +2294,8 @@ static void self_clear(FastArgs &fa, const GymView &gv, int workgroups)
 // The long-list variants (Collect, Hex*) always take one: their two-pixel builds need 78-95 VGPRs, and with the records coming through the
 // scalar cache occupancy is worth more (Collect 128 x 128: 97.6 us with one, 146 with two; HexMemory 155 / 171).
 // (In the one-launch passes of a batched call -- `batch` -- the long lists take two as well: eight passes' worth of workgroups keep the chip full at the lower
-// occupancy, and half as many tiles pay the per-tile work.  r07g/h, one / two pixels per lane: HexMemory 8.0 / 9.2 M obs/s, HexExplore 8.5 / 10.1, Collect 12.2 / 14.1,
+// occupancy, and half as many tiles pay the per-tile work.  r07g/h, one / two pixels per lane: HexMemory 8.0 / 9.2 M obs/s, HexExplore 8.5 / 10.1, Collect 12.2
+// / 14.1,
 // Collect 128 x 72 15.3 / 16.8; one pass per launch: HexMemory 6.9 / 6.95, Collect 11.2 / 9.3.)
 static int fast_pixels_per_lane(int W, int H, bool longList = false, bool batch = false)
 {
@@ -2418,7 +2540,8 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
         // pieces --, the frame's cost as the last pass's classification found it fed back into the cost bins, wave priorities by remaining work, a whole
         // frame per eight-wave workgroup.)
         constexpr int TAIL_DIV = 8, TAIL_SPLIT = 8;
-        if (split <= 2 && gv.vis_stride <= VIS_SMALL && ftiles >= 16 * TAIL_SPLIT && tail_frames(frames, TAIL_DIV) > 0) {   // (split 2: a launch that fills the chip; 512 frames in four pieces each: 12.0 M obs/s with the tail cut finer, 12.4 without, r05i)
+        // (split 2: a launch that fills the chip; 512 frames in four pieces each: 12.0 M obs/s with the tail cut finer, 12.4 without, r05i)
+        if (split <= 2 && gv.vis_stride <= VIS_SMALL && ftiles >= 16 * TAIL_SPLIT && tail_frames(frames, TAIL_DIV) > 0) {
             const int q = tail_frames(frames, TAIL_DIV);
             fa.tail_div = TAIL_DIV; fa.tail_split = TAIL_SPLIT;
             self_clear(fa, gv, (frames - q) * split + q * TAIL_SPLIT);

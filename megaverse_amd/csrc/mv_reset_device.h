@@ -144,8 +144,10 @@ __device__ __forceinline__ void tower_draw(const GymView &gv, int env, int seq)
     const uint32_t nextSeed = (uint32_t)rand_range(g, 0, 1 << 30);
 
     // `seq` PUBLISHES the episode: every lane's stores to the blob (objects, spawns) are released at agent scope before lane 0 writes it, and tower_swap_in
-    // acquires after it has read it -- the host's launch order (the draw before the last one is waited for) already keeps a step kernel off a blob that is being
-    // drawn; should a starved env ever race a running draw, it sees seq unset (ST_STARVED) or the whole episode, never a torn one.  Once per episode.
+    // acquires after it has read it -- the host's launch order (the draw before the last one is waited for) already keeps a step kernel off a blob that is
+    // being
+    // drawn; should a starved env ever race a running draw, it sees seq unset (ST_STARVED) or the whole episode, never a torn one.  Once per
+    // episode.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     wave_sync();
     if (lane == 0) {
@@ -169,7 +171,8 @@ __device__ __forceinline__ bool tower_swap_in(const GymView &gv, int env, int fo
     const int lane = lane_id();
     EnvHeader *hdr = gv.hdr + env;
     const int consumed = hdr->episodes_consumed;
-    const TowerBlob *b = reinterpret_cast<const TowerBlob *>(gv.blobs) + (size_t)env * gv.spares + consumed % gv.spares;   // ring slot of episode number consumed + 1
+    // ring slot of episode number consumed + 1
+    const TowerBlob *b = reinterpret_cast<const TowerBlob *>(gv.blobs) + (size_t)env * gv.spares + consumed % gv.spares;
     if (__hip_atomic_load(&b->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != consumed + 1) {
         if (lane == 0) { hdr->starved |= 1; atomicOr(&gv.episode_status[gv.num_envs + 1], (int)ST_STARVED); }
         return false;

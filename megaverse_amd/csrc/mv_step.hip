@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256) void step_kernel(GymView gv, int W, int H, int
         const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
         unsigned long long *d = gv.dbg + (size_t)env * 64;
         d[48] += rt1 - rt0; d[49] += 1; d[50] = rt0; d[51] = rt1;
-        if (gv.hdr[env].num_frames == 0) { d[52] += rt1 - rt0; d[53] += 1; }      // (tick-only launches: 52..55 = ticks that regenerated the env, longest other tick)
+        // (tick-only launches: 52..55 = ticks that regenerated the env, longest other tick)
+        if (gv.hdr[env].num_frames == 0) { d[52] += rt1 - rt0; d[53] += 1; }
         else if (rt1 - rt0 > d[54]) { d[54] = rt1 - rt0; for (int k = 0; k < 16; ++k) d[32 + k] = d[16 + k]; }
     }
 #endif
@@ -128,12 +129,14 @@ __device__ __forceinline__ void step_ticks_body(const Args &a, int W, int H)
 template <class Args> __global__ __launch_bounds__(64, MV_STEP_TICKS_WAVES_PER_SIMD) void step_ticks_kernel(Args a, int W, int H) { step_ticks_body<1>(a, W, H); }
 template <class Args> __global__ __launch_bounds__(256, 3) void step_ticks_agents_kernel(Args a, int W, int H) { step_ticks_body<MAX_AGENTS>(a, W, H); }
 
-// Software-pipelined (one agent per env): TWO waves per env.  Wave 0 runs tick j + 1 while wave 1 sets tick j's frame up (mv_frame.h) -- the two halves of a tick's
+// Software-pipelined (one agent per env): TWO waves per env.  Wave 0 runs tick j + 1 while wave 1 sets tick j's frame up (mv_frame.h) -- the two halves of a
+// tick's
 // work that step_ticks_body runs back to back in one wave, each a chain of dependent loads and a few thousand vector instructions of ONE wave on its SIMD
 // (48 % of the resident wave's cycles were spent in s_waitcnt, r08z_pmc_SQ2.csv).  The frame setup reads the simulator state in place, so the two waves meet at
 // two workgroup barriers per tick:
 //   A(j): tick j's state is written (wave 0: behind its write-back and the episode swap-in of a finished env; wave 1: before it reads anything)
-//   B(j): tick j's state is read    (wave 1: behind the record loads of its last round of slots; wave 0: before tick j + 1's write-back, tower_tick's pipe_wait)
+//   B(j): tick j's state is read    (wave 1: behind the record loads of its last round of slots; wave 0: before tick j + 1's write-back, tower_tick's
+//   pipe_wait)
 // An iteration lasts max(tick, frame setup) instead of their sum; the last frame setup runs alone.
 template <class Args>
 __global__ __launch_bounds__(128, MV_STEP_TICKS_WAVES_PER_SIMD) void step_ticks_pipe_kernel(Args a, int W, int H)
@@ -157,10 +160,17 @@ __global__ __launch_bounds__(128, MV_STEP_TICKS_WAVES_PER_SIMD) void step_ticks_
     }
 }
 
-// MV_STEP_PIPE=0: the one-wave-per-env multi-tick kernels (A/B measurements)
+// MV_STEP_PIPE=1 selects the two-wave kernels.  Measured (r09a / r09b / r09d, M obs/s, one wave / two): ALONE on the chip the step launch is a quarter shorter
+// (TowerBuilding
+// 16.6 -> 12.3 us per tick: 98 us per 8 ticks, Empty 16.9 -> 14.5) -- but beside the observation passes, where the batched calls run it, its length follows the
+// passes' VALU
+// load, not its own dependent chains: TowerBuilding 28.7 / 28.2, Empty 45.8 / 47.0, ObstaclesHard 512 envs 20.8 / 21.2, 1024 envs 26.3 / 23.6 (the Obstacles
+// tick spills at
+// 128 VGPRs with the frame setup's registers beside it; at 168: 24.4), the driver's 20-step form 22.9 / 23.2.  Off by default: twice the resident waves for +-2
+// %.
 bool step_pipe_enabled()
 {
-    static const bool on = !(getenv("MV_STEP_PIPE") && atoi(getenv("MV_STEP_PIPE")) == 0);
+    static const bool on = getenv("MV_STEP_PIPE") && atoi(getenv("MV_STEP_PIPE")) != 0;
     return on;
 }
 
@@ -183,7 +193,8 @@ void launch_step(const GymView &gv, hipStream_t stream, int W, int H, int render
 {
     const dim3 grid(gv.num_envs), block(gv.num_agents == 1 ? STEP_THREADS : 64 * std::min(gv.num_agents, 4));
     if (gv.num_agents == 1) hipExtLaunchKernelGGL(step_kernel<1>, grid, block, 0, stream, nullptr, done, 0, gv, W, H, render);
-    else hipExtLaunchKernelGGL(step_kernel<MAX_AGENTS>, grid, block, 0, stream, nullptr, done, 0, gv, W, H, render);   // (agent loops are real loops: one multi-agent build)
+    // (agent loops are real loops: one multi-agent build)
+    else hipExtLaunchKernelGGL(step_kernel<MAX_AGENTS>, grid, block, 0, stream, nullptr, done, 0, gv, W, H, render);
 }
 
 }  // namespace mv

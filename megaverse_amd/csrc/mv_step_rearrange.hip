@@ -86,7 +86,8 @@ void launch_step_rearrange(const GymView &gv, hipStream_t stream, int W, int H, 
 {
     const dim3 grid(gv.num_envs), block(gv.num_agents == 1 ? STEP_THREADS : 64 * std::min(gv.num_agents, 4));
     if (gv.num_agents == 1) hipLaunchKernelGGL(step_rearrange_kernel<1>, grid, block, 0, stream, gv, W, H, render);
-    else hipLaunchKernelGGL(step_rearrange_kernel<MAX_AGENTS>, grid, block, 0, stream, gv, W, H, render);   // (agent loops are real loops: one multi-agent build)
+    // (agent loops are real loops: one multi-agent build)
+    else hipLaunchKernelGGL(step_rearrange_kernel<MAX_AGENTS>, grid, block, 0, stream, gv, W, H, render);
 }
 
 void launch_reset_rearrange(const GymView &gv, const RearrangeBlob *blobs, int *status, int force_all, hipStream_t stream)

@@ -57,11 +57,13 @@ __global__ __launch_bounds__(256) void step_union_kernel(UnionStepArgs ua, int W
 // k ticks of every env of every gym of the group, the env's workgroup resident for the whole call (cf. mv_step.hip: step_ticks_kernel): tick, frame setup
 // into tick j's slot, tick, ...  Built for the register budget of the other resident multi-tick kernels (they run beside the observation passes of the
 // previous call, and what they hold the passes cannot have).
-// One wave per env -- except for the gyms with long frame lists (Collect, Hex*: up to 2048 visible primitives): their frame setup is most of their tick, one wave
+// One wave per env -- except for the gyms with long frame lists (Collect, Hex*: up to 2048 visible primitives): their frame setup is most of their tick, one
+// wave
 // per env made their envs the launch's stragglers (57 us per tick where the short-list scenarios need 15-20: measured r08i), so the launch has WAVES waves per
 // workgroup, the long-list gyms use them all for the frame setup (wave 0 ticks, the others wait at the barrier) and the other gyms' extra waves leave at once.
 #ifndef MV_UNION_TICKS_WAVES_PER_SIMD
-#define MV_UNION_TICKS_WAVES_PER_SIMD 3   // the register budget (512 / n): all eight scenarios' ticks in one kernel need ~175 VGPRs; at 128 it spills 1.1 KB per lane into the ticks' inner loops
+// the register budget (512 / n): all eight scenarios' ticks in one kernel need ~175 VGPRs; at 128 it spills 1.1 KB per lane into the ticks' inner loops
+#define MV_UNION_TICKS_WAVES_PER_SIMD 3
 #endif
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES, MV_UNION_TICKS_WAVES_PER_SIMD) void step_union_ticks_kernel(UnionTicksArgs ua, int W, int H)
@@ -91,7 +93,8 @@ __global__ __launch_bounds__(64 * WAVES, MV_UNION_TICKS_WAVES_PER_SIMD) void ste
         }
         if (wide) {
             __syncthreads();   // the tick's stores (same CU: same L1) before the frame setup's loads
-            frame_setup_body<64 * WAVES, false>(gv, env, W, H, s_fs, &s_ds);   // (ends with a barrier: the next tick starts when every wave is done with the state)
+            // (ends with a barrier: the next tick starts when every wave is done with the state)
+            frame_setup_body<64 * WAVES, false>(gv, env, W, H, s_fs, &s_ds);
         } else {
             wave_sync();   // one wave: no barrier needed
             frame_setup_body<64, true>(gv, env, W, H, s_fs, &s_ds);

@@ -129,7 +129,8 @@ __device__ __forceinline__ void sokoban_tick(const GymView &gv, const int env)
         if (ovalid[k]) {
             const MovableObject o = gobj[oi[k]];
             ox[k] = o.x; oy[k] = o.y; oz[k] = o.z;
-            // scenario_sokoban.cpp:275-293: drawn half extents (0.8, 0.36, 0.8) at (x + 0.5, y + 0.2, z + 0.5) voxels; collision scale (1.15, 3, 1.15), offset (0, 0.6, 0)
+            // scenario_sokoban.cpp:275-293: drawn half extents (0.8, 0.36, 0.8) at (x + 0.5, y + 0.2, z + 0.5) voxels; collision scale (1.15, 3, 1.15), offset
+            // (0, 0.6, 0)
             const float sx = (VOXEL / 2) * 0.8f, sy = 0.45f * 0.8f;
             const float cx = (float(o.x) + 0.5f) * VOXEL, cy = (float(o.y) + 0.2f) * VOXEL + 0.6f, cz = (float(o.z) + 0.5f) * VOXEL;
             col[2 + k].kind = 1;

@@ -172,13 +172,18 @@ struct GymView {
     // long lists (Collect, Hex), fast pixels: the frame setup leaves the list in depth classes, nearest first (mv_frame.h: DepthSortScratch), so that the
     // observation pass can stop walking it where everything nearer has covered a tile (mv_raster.hip: raster_glist_body)
     uint8_t *sort_scratch;     // [N*A][vis_stride] x (32 + 8) bytes: the list as found, before it is dealt into its depth classes (null: short lists)
-    int32_t depth_sort;        // 1: deal the list into depth classes (set per launch: fast pixel mode only -- the exact kernel resolves depth ties by list position)
-    int32_t lpt_no_clear;      // 1: the frame setup does not clear the cost histogram of the next pass (a multi-tick step launch: the pass that draws from a histogram clears it, mv_raster.hip: hist_done)
+    // 1: deal the list into depth classes (set per launch: fast pixel mode only -- the exact kernel resolves depth ties by list position)
+    int32_t depth_sort;
+    // 1: the frame setup does not clear the cost histogram of the next pass (a multi-tick step launch: the pass that draws from a histogram clears it,
+    // mv_raster.hip: hist_done)
+    int32_t lpt_no_clear;
     struct TowerGen *tower_gen;// [N] TowerBuilding: where each env's episode generator stands (mv_reset_device.h: tower_draw); its resident episodes are `blobs` (TowerBlob)
 };
 
-// The n <= 8 consecutive ticks of a multi-tick step launch (mv_step.hip: step_ticks_kernel, and every mv_step_*.hip), the same envs in all of them: their views BY
-// VALUE as the launch's arguments -- 2.6 KB of the 4 KB kernel-argument segment; the kernels read a tick's view with scalar loads on demand, its fields do not live
+// The n <= 8 consecutive ticks of a multi-tick step launch (mv_step.hip: step_ticks_kernel, and every mv_step_*.hip), the same envs in all of them: their views
+// BY
+// VALUE as the launch's arguments -- 2.6 KB of the 4 KB kernel-argument segment; the kernels read a tick's view with scalar loads on demand, its fields do not
+// live
 // in registers across the tick.  A call of more than 8 ticks (MAX_STEP_TICKS: 16) is two such launches back to back.  (Built and measured in round 5, removed:
 // one launch of 16 ticks with its views in device memory, written there by a small kernel in front of it -- that kernel, queued behind the previous step launch
 // and beside an observation launch that had just taken the chip, took 10-44 us and made the step launch arrive late: Empty 27.6 M obs/s against 41.5 M with two

@@ -19,7 +19,8 @@ static_assert(sizeof(UnionStepArgs) + 16 <= 4096, "UnionStepArgs + (W, H, render
 
 // k consecutive ticks of every gym of a group with ONE launch (step_union_ticks_kernel): tick 0's view of every gym; tick j's differs from it in its
 // hand-over slot -- ten buffers, all `slot_stride` bytes further per tick (mv_api.hip carves a gym's slots out of its arena one after the other) --, its
-// action index and its cost histogram (consecutive, modulo their number): derived in the kernel (mv_types.h: tick_view), not passed (k x n views do not fit the 4 KB of
+// action index and its cost histogram (consecutive, modulo their number): derived in the kernel (mv_types.h: tick_view), not passed (k x n views do not fit the
+// 4 KB of
 // kernel arguments).
 struct UnionTicksArgs {
     int32_t n, k;
@@ -29,7 +30,8 @@ struct UnionTicksArgs {
 };
 static_assert(sizeof(UnionTicksArgs) + 16 <= 4096, "UnionTicksArgs + (W, H) must fit the 4 KB kernel-argument segment");
 
-void launch_step_union_ticks(const UnionTicksArgs &ua, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);   // done: completed by the launch's own dispatch packet   // (one agent per env)
+// done: completed by the launch's own dispatch packet   // (one agent per env)
+void launch_step_union_ticks(const UnionTicksArgs &ua, hipStream_t stream, int W, int H, hipEvent_t done = nullptr);
 
 void launch_step_union(const UnionStepArgs &ua, hipStream_t stream, int W, int H, int render);
 
