@@ -342,7 +342,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     const size_t szTerrain = obstacles ? up(N * MAX_TERRAIN * sizeof(TerrainBox)) : 0,
                  szRewObj = hostEpisodes ? up(N * (size_t)gv.reward_stride * sizeof(MovableObject)) : 0,
                  szHeight = collect ? up(N * (size_t)HM_BYTES) : 0, szItems = rearrange ? up(N * MAX_ITEMS * sizeof(ArrangementItem)) : 0, szCells = sokoban ? up(N * (size_t)(SOKO_DIM * SOKO_DIM)) : 0,
-                 szHexB = hex ? up(N * (size_t)HEX_MAX_BOXES * sizeof(HexRec)) : 0, szHexO = hex ? up(N * (size_t)HEX_MAX_OBJS * sizeof(HexRec)) : 0, szBlobs = up(N * g->blobBytes * (size_t)g->spares), szCnt = up((N + 2) * sizeof(int32_t)), szGen = hostEpisodes ? 0 : up(N * sizeof(TowerGen));
+                 szHexB = hex ? up(N * (size_t)HEX_MAX_BOXES * sizeof(HexRec)) : 0, szHexO = hex ? up(N * (size_t)HEX_MAX_OBJS * sizeof(HexRec)) : 0, szClusters = (hex || collect) && !(getenv("MV_BOX_CLUSTERS") && atoi(getenv("MV_BOX_CLUSTERS")) == 0) ? up(N * (size_t)MAX_BOX_CLUSTERS * BOX_CLUSTER_FLOATS * sizeof(float)) : 0, szBlobs = up(N * g->blobBytes * (size_t)g->spares), szCnt = up((N + 2) * sizeof(int32_t)), szGen = hostEpisodes ? 0 : up(N * sizeof(TowerGen));
     gv.vis_stride = hex ? 2048 : collect ? 1024 : 256;
     if (const char *e = getenv("MV_DEBUG_VIS_STRIDE")) gv.vis_stride = std::min(gv.vis_stride, std::max(8, atoi(e)));   // (tests: provoke ST_VISIBLE)
     gv.debug_redo = getenv("MV_DEBUG_FORCE_REDO") && atoi(getenv("MV_DEBUG_FORCE_REDO")) ? 1 : 0;   // (tests: mv_tick_tower.h's sequential redo)
@@ -371,7 +371,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     // long lists: the list as found, before the frame setup deals it into depth classes (mv_frame.h: DepthSortScratch); MV_DEPTH_SORT=0: lists stay as found
     const bool depthSortOn = !(getenv("MV_DEPTH_SORT") && atoi(getenv("MV_DEPTH_SORT")) == 0);
     const size_t szSort = gv.vis_stride > 256 && depthSortOn ? up(NA * (size_t)gv.vis_stride * 40) : 0;
-    const size_t total = szSort + szHdr + szBoxes + szObj + szAg + szAct + szRew + szDone + szObjv + szMd + (hostEpisodes ? 0 : szChunk) + szObs + szTerrain +
+    const size_t total = szClusters + szSort + szHdr + szBoxes + szObj + szAg + szAct + szRew + szDone + szObjv + szMd + (hostEpisodes ? 0 : szChunk) + szObs + szTerrain +
                          szRewObj + szHeight + szItems + szCells + szHexB + szHexO + szBlobs + szCnt + szGen + (size_t)g->slots * szParity + szHist;
     {
         hipError_t e_ = hipMalloc((void **)&g->arena, total);
@@ -408,6 +408,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
         if (rearrange) { gv.items = (ArrangementItem *)p; p += szItems; }
         if (sokoban) { gv.soko_cells = p; p += szCells; }
         if (hex) { gv.hex_boxes = (HexRec *)p; p += szHexB; gv.hex_objs = (HexRec *)p; p += szHexO; }
+        gv.box_clusters = szClusters ? (float *)p : nullptr; p += szClusters;   // (MV_BOX_CLUSTERS=0: every box is projected every tick, as before round 6)
         gv.lpt_hist = (int32_t *)p; p += szHist;
         gv.sort_scratch = szSort ? p : nullptr; p += szSort;
         gv.depth_sort = 0;

@@ -2090,6 +2090,12 @@ struct UnionRasterAllArgs {
     int32_t split_small, split_large;
 };
 
+// The short-list gyms' frames of a union launch take the tile classification where a frame is large enough to repay it -- two pixels per lane, 8192 pixels and more --
+// and not below: r09f, Mixed (eight scenarios) without / with, M obs/s: 128 x 128 11.0 / 12.8; 64 x 64 17.3 / 16.7 (the classified body's code and registers cost the
+// small frames' passes 6 % even where no frame is classified).
+#ifndef MV_UNION_CLS
+#define MV_UNION_CLS (NPS >= 2)
+#endif
 template <int WAVES, int NPS>
 __global__ __launch_bounds__(256, WAVES) void raster_union_all_kernel(UnionRasterAllArgs a, int W, int H)
 {
@@ -2102,7 +2108,7 @@ __global__ __launch_bounds__(256, WAVES) void raster_union_all_kernel(UnionRaste
     const int blk = (int)blockIdx.x - a.u.first[s];
     if (a.large[s]) raster_glist_body<VIS_XL, true, true, 1>(a.u.fa[s], a.u.obs[s], W, H, a.split_large, blk, s_buf);
     // (no tile classification: this kernel's LDS is the long-list body's, and occupancy is what it lives on)
-    else raster_fast_body<VIS_SMALL, true, false, NPS, false>(a.u.fa[s], a.u.obs[s], W, H, a.split_small, blk, s_buf);
+    else raster_fast_body<VIS_SMALL, true, false, NPS, MV_UNION_CLS>(a.u.fa[s], a.u.obs[s], W, H, a.split_small, blk, s_buf);
 }
 
 // The observation passes of the k ticks of ONE batched group call (mv_group_step: n gyms -- scenarios -- x k ticks) with one launch: what
@@ -2164,7 +2170,7 @@ __global__ __launch_bounds__(256, WAVES) void raster_union_batch_kernel(UnionBat
     FastArgs fa = union_batch_args(a, s, j);
     fa.pub_n = 0;
     if (a.large[s]) raster_glist_body<VIS_XL, true, true, 1>(fa, a.obs[j][s], W, H, a.split_large, blk, s_buf);
-    else raster_fast_body<VIS_SMALL, true, false, NPS, false>(fa, a.obs[j][s], W, H, a.split_small, blk, s_buf);
+    else raster_fast_body<VIS_SMALL, true, false, NPS, MV_UNION_CLS>(fa, a.obs[j][s], W, H, a.split_small, blk, s_buf);
 }
 
 #ifdef MV_RASTER_TIMING
@@ -2317,7 +2323,8 @@ static int fast_pixels_per_lane(int W, int H, bool longList = false, bool batch 
 static int fast_split(int W, int H, int np, int frames, bool longList = false, bool batch = false)
 {
     const int ftiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H * np - 1) / (TILE_H * np));
-    const int want = ((np >= 2 ? 2048 : 4096) + frames - 1) / std::max(frames, 1), lo = (batch || frames >= 4096) && np >= 2 && !longList ? 1 : np >= 2 ? 2 : 4, hi = np >= 2 ? 8 : 16;
+    // (one pixel per lane -- frames below 8192 pixels -- in the one-launch passes of a batched call: whole frames per workgroup as well; r09f, Mixed 64 x 64, four / one: 17.3 / 19.4 M obs/s)
+    const int want = ((np >= 2 ? 2048 : 4096) + frames - 1) / std::max(frames, 1), lo = (batch || frames >= 4096) && np >= 2 && !longList ? 1 : batch && !longList ? 1 : np >= 2 ? 2 : 4, hi = np >= 2 ? 8 : 16;
     int split = lo;
     while (split < hi && split < want) split <<= 1;
     while (split > 1 && ftiles < 4 * split * (longList ? 1 : 2)) split >>= 1;
@@ -2420,6 +2427,8 @@ int launch_raster_union_batch(const GymView *views, uint32_t *const *obs, const 
     a.n = 0; a.k = k;
     a.split_small = fast_split(W, H, np, (unionFrames[0] + unionFrames[1]) * k, false, true);
     a.split_large = fast_split(W, H, 1, (unionFrames[0] + unionFrames[1]) * k, true, true);
+    if (const char *e = getenv("MV_UNION_SPLIT_SMALL")) a.split_small = std::max(1, atoi(e));   // (experiments)
+    if (const char *e = getenv("MV_UNION_SPLIT_LARGE")) a.split_large = std::max(1, atoi(e));
     int wgs = 0;
     for (int large = 1; large >= 0; --large)   // the expensive frames first
         for (int i = 0; i < n; ++i) {

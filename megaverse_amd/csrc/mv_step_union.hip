@@ -12,6 +12,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "mv_tick_collect.h"
 #include "mv_tick_hex.h"
@@ -106,7 +107,9 @@ void launch_step_union_ticks(const UnionTicksArgs &ua, hipStream_t stream, int W
 {
     bool anyLong = false;
     for (int i = 0; i < ua.n; ++i) anyLong = anyLong || ua.gv[i].vis_stride > VIS_SMALL;
-    if (anyLong) hipExtLaunchKernelGGL(step_union_ticks_kernel<4>, dim3(ua.first[ua.n]), dim3(256), 0, stream, nullptr, done, 0, ua, W, H);
+    static const int wideWaves = getenv("MV_UNION_TICKS_WAVES") ? atoi(getenv("MV_UNION_TICKS_WAVES")) : 4;   // (2: measured in r09f)
+    if (anyLong && wideWaves == 2) hipExtLaunchKernelGGL(step_union_ticks_kernel<2>, dim3(ua.first[ua.n]), dim3(128), 0, stream, nullptr, done, 0, ua, W, H);
+    else if (anyLong) hipExtLaunchKernelGGL(step_union_ticks_kernel<4>, dim3(ua.first[ua.n]), dim3(256), 0, stream, nullptr, done, 0, ua, W, H);
     else hipExtLaunchKernelGGL(step_union_ticks_kernel<1>, dim3(ua.first[ua.n]), dim3(64), 0, stream, nullptr, done, 0, ua, W, H);
 }
 
