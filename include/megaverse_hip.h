@@ -119,7 +119,7 @@ int mv_set_output_ring(mv_gym *g, int32_t count, void *obs, float *rewards, uint
 int mv_set_pass_overlap(mv_gym *g, int32_t on);
 /* What a caller who just wants throughput should ask mv_step_n for -- the measured rules that used to live in bench.py (no reference counterpart):
  * mv_recommended_ticks_per_call: 16 (one tail of the one-launch observation pass per 16 ticks) for 1024 .. 2047 agent frames per tick where the gym's slot groups hold
- * 16 (mv_create sizes them by footprint, MV_PIPE_BATCH overrides) and the scenario is not Sokoban; 8 otherwise; 1 where episodes can end within a few ticks
+ * 16 (mv_create sizes them by footprint: 16 where the 48 hand-over slots that takes stay under 2.25 GiB, else 8; MV_PIPE_BATCH overrides) and the scenario is not Sokoban; 8 otherwise; 1 where episodes can end within a few ticks
  * (such gyms are stepped tick by tick whatever k says).  A gym in a group: at most 8 (the two-launch group call's limit, and only while the group's envs are
  * all resident at once: 1024).  mv_recommended_pass_overlap: 1 for the Obstacles family and Sokoban (short passes: the next call's may begin in the tail), else 0.
  * mv_arena_bytes: the device memory this gym holds (state + the hand-over slots of PIPE_GROUPS x ticks-per-call ticks + its own observation slab). */

@@ -255,8 +255,7 @@ static int usable_host_cores()
 // the end of a step launch releases both -- the step launch's few fat workgroups (one or four waves of 128-168 VGPRs) should reach the chip first; behind an
 // observation launch that has filled it with 72-VGPR waves they wait for holes that never get large enough until that launch has drained.  Measured (r08s, two
 // runs each, normal / high): ObstaclesHard 512 envs 18.6 / 20.8 M obs/s, 1024 envs 24.1 / 26.3, Sokoban 26.2 / 28.2, Mixed 64 x 64 16.8 / 18.3, Mixed4 20.6 /
-// 18.7,
-// TowerBuilding (1024, 4096, 512 x 4), Collect, Empty: unchanged.  MV_SIM_PRIORITY=normal: a stream of default priority.
+// 18.7, TowerBuilding (1024, 4096, 512 x 4), Collect, Empty: unchanged.  MV_SIM_PRIORITY=normal: a stream of default priority.
 static hipError_t create_sim_stream(hipStream_t *s)
 {
     static const char *prio = getenv("MV_SIM_PRIORITY");
@@ -309,10 +308,9 @@ int mv_create(const mv_config *cfg, mv_gym **out)
                    : scenario == SCN_HEX_MEMORY ? SHAPING_KEYS_HEX_MEMORY : scenario == SCN_HEX_EXPLORE ? SHAPING_KEYS_HEX_EXPLORE
                    : scenario == SCN_EMPTY ? SHAPING_KEYS_EMPTY : SHAPING_KEYS_REARRANGE;
     // Resident episodes per env: two where an episode ends at its time limit only (TowerBuilding, Empty); THREE where a goal can end it early (the exit pad,
-    // every
-    // diamond collected, the level solved, the arrangement matched, the maze's target found): the host's run-ahead is bounded in TICKS (refill_episodes), the
-    // status
-    // words are read back every 16th, and a lucky env can finish twice inside that window -- a third resident episode covers it where two starved.
+    // every diamond collected, the level solved, the arrangement matched, the maze's target found): the host's run-ahead is bounded in TICKS (refill_episodes),
+    // the status words are read back every 16th, and a lucky env can finish twice inside that window -- a third resident episode covers it where two starved
+    // (ADVICE r05).
     g->spares = scenario == SCN_TOWER || scenario == SCN_EMPTY ? 2 : 3;
     g->envOffset = cfg->total_envs > 0 ? cfg->env_offset : 0;
     g->envStride = cfg->total_envs > 0 && cfg->env_stride > 1 ? cfg->env_stride : 1;
@@ -342,7 +340,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     const size_t szTerrain = obstacles ? up(N * MAX_TERRAIN * sizeof(TerrainBox)) : 0,
                  szRewObj = hostEpisodes ? up(N * (size_t)gv.reward_stride * sizeof(MovableObject)) : 0,
                  szHeight = collect ? up(N * (size_t)HM_BYTES) : 0, szItems = rearrange ? up(N * MAX_ITEMS * sizeof(ArrangementItem)) : 0, szCells = sokoban ? up(N * (size_t)(SOKO_DIM * SOKO_DIM)) : 0,
-                 szHexB = hex ? up(N * (size_t)HEX_MAX_BOXES * sizeof(HexRec)) : 0, szHexO = hex ? up(N * (size_t)HEX_MAX_OBJS * sizeof(HexRec)) : 0, szClusters = (hex || collect) && !(getenv("MV_BOX_CLUSTERS") && atoi(getenv("MV_BOX_CLUSTERS")) == 0) ? up(N * (size_t)MAX_BOX_CLUSTERS * BOX_CLUSTER_FLOATS * sizeof(float)) : 0, szBlobs = up(N * g->blobBytes * (size_t)g->spares), szCnt = up((N + 2) * sizeof(int32_t)), szGen = hostEpisodes ? 0 : up(N * sizeof(TowerGen));
+                 szHexB = hex ? up(N * (size_t)HEX_MAX_BOXES * sizeof(HexRec)) : 0, szHexO = hex ? up(N * (size_t)HEX_MAX_OBJS * sizeof(HexRec)) : 0, szBlobs = up(N * g->blobBytes * (size_t)g->spares), szCnt = up((N + 2) * sizeof(int32_t)), szGen = hostEpisodes ? 0 : up(N * sizeof(TowerGen));
     gv.vis_stride = hex ? 2048 : collect ? 1024 : 256;
     if (const char *e = getenv("MV_DEBUG_VIS_STRIDE")) gv.vis_stride = std::min(gv.vis_stride, std::max(8, atoi(e)));   // (tests: provoke ST_VISIBLE)
     gv.debug_redo = getenv("MV_DEBUG_FORCE_REDO") && atoi(getenv("MV_DEBUG_FORCE_REDO")) ? 1 : 0;   // (tests: mv_tick_tower.h's sequential redo)
@@ -352,12 +350,10 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     // per slot: frame lists, headers, cost lists, and the staging copies of rewards / dones / true objectives
     const size_t szParity = szVisP + szVisR + szVisC + szLpt + szRew + szDone + szObjv;
     // Ticks per call of mv_step_n (`batch`; a gym holds PIPE_GROUPS x batch hand-over slots of szParity bytes each): 16 -- one tail of the one-launch
-    // observation
-    // pass per 16 ticks, measured against 8: TowerBuilding 1024 envs 26.6 -> 28.3 M obs/s -- where the 48 slots that takes stay under 1 GiB, else 8 (a Hex
-    // frame's
-    // slot is 80 KB: 3.8 GB per 1024 frames at 16; TowerBuilding's 12 KB: 0.6 GB).  MV_PIPE_BATCH=1..16 overrides; mv_recommended_ticks_per_call says what to
-    // ask for.
-    g->batch = (size_t)PIPE_GROUPS * 16 * szParity <= (size_t(1) << 30) ? 16 : 8;
+    // observation pass per 16 ticks, measured against 8: TowerBuilding 1024 envs 26.6 -> 28.3 M obs/s -- where the 48 slots that takes stay under 2.25 GiB, else 8
+    // (a Hex frame's slot is 80 KB: 3.8 GB per 1024 frames at 16, 1.9 GB at 8 -- and 16 buys it nothing: 9.32 / 9.40 M obs/s, r09k; Collect's 42 KB: 2.1 GB at 16,
+    // 13.9 -> 14.8 M; TowerBuilding's 12 KB: 0.6 GB).  MV_PIPE_BATCH=1..16 overrides; mv_recommended_ticks_per_call says what to ask for.
+    g->batch = (size_t)PIPE_GROUPS * 16 * szParity <= (size_t(9) << 28) ? 16 : 8;   // (2.25 GiB)
     if (const char *e = getenv("MV_PIPE_BATCH")) g->batch = std::min((int)PIPE_BATCH_MAX, std::max(1, atoi(e)));
     g->slots = PIPE_GROUPS * g->batch;
     g->hists = g->slots + 1;
@@ -371,7 +367,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     // long lists: the list as found, before the frame setup deals it into depth classes (mv_frame.h: DepthSortScratch); MV_DEPTH_SORT=0: lists stay as found
     const bool depthSortOn = !(getenv("MV_DEPTH_SORT") && atoi(getenv("MV_DEPTH_SORT")) == 0);
     const size_t szSort = gv.vis_stride > 256 && depthSortOn ? up(NA * (size_t)gv.vis_stride * 40) : 0;
-    const size_t total = szClusters + szSort + szHdr + szBoxes + szObj + szAg + szAct + szRew + szDone + szObjv + szMd + (hostEpisodes ? 0 : szChunk) + szObs + szTerrain +
+    const size_t total = szSort + szHdr + szBoxes + szObj + szAg + szAct + szRew + szDone + szObjv + szMd + (hostEpisodes ? 0 : szChunk) + szObs + szTerrain +
                          szRewObj + szHeight + szItems + szCells + szHexB + szHexO + szBlobs + szCnt + szGen + (size_t)g->slots * szParity + szHist;
     {
         hipError_t e_ = hipMalloc((void **)&g->arena, total);
@@ -408,7 +404,6 @@ int mv_create(const mv_config *cfg, mv_gym **out)
         if (rearrange) { gv.items = (ArrangementItem *)p; p += szItems; }
         if (sokoban) { gv.soko_cells = p; p += szCells; }
         if (hex) { gv.hex_boxes = (HexRec *)p; p += szHexB; gv.hex_objs = (HexRec *)p; p += szHexO; }
-        gv.box_clusters = szClusters ? (float *)p : nullptr; p += szClusters;   // (MV_BOX_CLUSTERS=0: every box is projected every tick, as before round 6)
         gv.lpt_hist = (int32_t *)p; p += szHist;
         gv.sort_scratch = szSort ? p : nullptr; p += szSort;
         gv.depth_sort = 0;
@@ -890,14 +885,12 @@ int refill_episodes(mv_gym *g, int k)
         // The read-back was enqueued behind a step launch the host is normally ahead of: waiting for it at once would drain that run-ahead every statusPeriod
         // ticks.  With long episodes (period 16, two resident episodes per env) the words may arrive later: look again at the next call -- every period a fresh
         // read-back takes the pending one's place, so a host that runs ahead never finds it ready -- and wait for the latest one once max(32, 4 k) TICKS have
-        // been
-        // enqueued since the first.  That wait is what bounds the host's run-ahead, and with it how late a refill can land: an upload is ordered behind the
-        // LAST
-        // step launch enqueued.  It costs nothing: the host catches up with the STEP launches, which run up to three calls ahead of the observation passes the
-        // device is busy with.  (Until round 5 the bound was 32 CALLS -- 256 ticks at 8 per call, 512 at 16: a HexExplore env that found its goal twice within
-        // ~300 ticks starved, scripts/soak.py in r08z.  Measured, r08x2, bound 3 k / 6 k / 32 k ticks at k = 16: TowerBuilding 28.8 / 28.7 / 28.1 M obs/s,
-        // Empty
-        // 38.3 / 39.4 / 39.9; with ONE read-back in flight instead (polled until ready, no forced wait) the host's run-ahead was bounded by nothing: 26.3-28.9
+        // been enqueued since the first.  That wait is what bounds the host's run-ahead, and with it how late a refill can land: an upload is ordered behind
+        // the LAST step launch enqueued.  It costs nothing: the host catches up with the STEP launches, which run up to three calls ahead of the observation
+        // passes the device is busy with.  (Until round 5 the bound was 32 CALLS -- 256 ticks at 8 per call, 512 at 16: a HexExplore env that found its goal
+        // twice within ~300 ticks starved, scripts/soak.py in r08z.  Measured, r08x2, bound 3 k / 6 k / 32 k ticks at k = 16: TowerBuilding 28.8 / 28.7 / 28.1
+        // M obs/s, Empty 38.3 / 39.4 / 39.9; with ONE read-back in flight instead (polled until ready, no forced wait) the host's run-ahead was bounded by
+        // nothing: 26.3-28.9
         // / 36-38.
         // r08x4, three runs each, this scheme / the 32-call bound: ObstaclesHard 512 envs 20.9 / 21.5, Empty 38.9 / 39.6: what the bound costs.)
         const int bound = std::max(32, 4 * k);
@@ -905,8 +898,8 @@ int refill_episodes(mv_gym *g, int k)
             (void)hipGetLastError();   // ("not ready" is an answer, not an error to report at the end of the step)
             g->pendingAge += k;
             // (no fresh counts: but envs known to be short of an episode whose successor was not generated yet -- or had just sent one: one episode per env and
-            // pass --
-            // are served now, not at the next read-back: with every env finishing every 70 ticks and a pass every 80 the ring fell behind until it starved)
+            // pass -- are served now, not at the next read-back: with every env finishing every 70 ticks and a pass every 80 the ring fell behind until it
+            // starved)
             if (g->hostEpisodes() && g->deficit > 0 && !g->consumedSeen.empty() && upload_pass(g)) return -1;
             return 0;
         }

@@ -161,35 +161,6 @@ __device__ __forceinline__ CamL hex_frame(int k)
     return f;
 }
 
-// ---- box clusters (long lists).  A Hex maze is ~1500 static boxes, a Collect landscape up to 1024 slabs, and a camera sees a third of them: the frame setup used to load, transform
-// and project every one, every tick (34 rounds of 64 slots for one wavefront per env: most of the Hex step launch).  The episode swap-in leaves, per 64 consecutive list
-// positions, the bounds of those boxes in the world (a hair generous: + 1e-3 on every side, so that a member's conservative screen rectangle cannot reach where the
-// cluster's does not); the frame setup projects the clusters first -- one lane per cluster, the very screen_rect the boxes go through -- and a round whose cluster is
-// nowhere on the screen skips its 64 record loads and projections: every one of them would have been dropped.  The visible list is what it was.
-__device__ __forceinline__ float wave_min_f32(float v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
-    return v;
-}
-__device__ __forceinline__ float wave_max_f32(float v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
-}
-// called by all 64 lanes of the env's wavefront for cluster c: this lane's box (world bounds lo .. hi; valid = it exists) -> the cluster's record
-__device__ __forceinline__ void box_cluster_store(float *clusters, int c, bool valid, V3 lo, V3 hi)
-{
-    const float BIG = 1e30f, EPS = 1e-3f;
-    const float x0 = wave_min_f32(valid ? lo.x : BIG), y0 = wave_min_f32(valid ? lo.y : BIG), z0 = wave_min_f32(valid ? lo.z : BIG);
-    const float x1 = wave_max_f32(valid ? hi.x : -BIG), y1 = wave_max_f32(valid ? hi.y : -BIG), z1 = wave_max_f32(valid ? hi.z : -BIG);
-    if ((threadIdx.x & 63) == 0) {
-        float *o = clusters + c * BOX_CLUSTER_FLOATS;
-        o[0] = x0 - EPS; o[1] = y0 - EPS; o[2] = z0 - EPS; o[3] = 0.0f; o[4] = x1 + EPS; o[5] = y1 + EPS; o[6] = z1 + EPS; o[7] = 0.0f;
-    }
-}
-
 // LDS scratch of one frame setup in flight (one per workgroup, or one per wave when every wave of a workgroup sets up its own frame)
 struct FrameScratch {
     CamL cam[MAX_CAMS];      // agent cameras, then (Hex scenarios) the three wall orientations as eye-less frames
@@ -241,16 +212,6 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
 {
     static_assert(!WAVE_LOCAL || THREADS == 64, "a wave-local frame setup is one wavefront");
     auto sync = [] { if (WAVE_LOCAL) wave_sync(); else __syncthreads(); };
-    // Inside the rounds only LDS words travel between the lanes (the waves' counts).  One wavefront's LDS operations execute in order: a wave-local setup needs the COMPILER
-    // to keep them so, nothing else -- wave_sync()'s workgroup-scope fences are an s_waitcnt vmcnt(0) per round, i.e. every round waited for the previous round's record
-    // STORES to drain before it issued its record loads (a long list is 12-34 rounds of one wavefront: r09h).  The list itself is read back only behind the sync() after the rounds.
-    auto sync_rounds = [] {
-        if (WAVE_LOCAL) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        } else __syncthreads();
-    };
 #ifdef MV_TICK_TIMING
     unsigned long long tf_last_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -320,20 +281,6 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
     const int numSlots = slotAgents + 3 * A;
     const LayoutBox *gboxes = gv.boxes + (size_t)env * gv.box_stride;
 
-    // long lists: which clusters of 64 static boxes can this camera see at all?  One lane per cluster, every wave for itself (the same answer: no exchange needed)
-    unsigned clusterVis = ~0u;
-    const bool clustered = gv.box_clusters != nullptr && (hex || scen == SCN_COLLECT);
-    if (clustered) {
-        const int nCl = min((nLayout + BOX_CLUSTER - 1) / BOX_CLUSTER, (int)MAX_BOX_CLUSTERS);
-        bool seen = lane >= nCl;   // (positions beyond the clusters there are: never skipped)
-        if (lane < nCl) {
-            const float *cb = gv.box_clusters + ((size_t)env * MAX_BOX_CLUSTERS + lane) * BOX_CLUSTER_FLOATS;
-            const float clo[3] = {cb[0], cb[1], cb[2]}, chi[3] = {cb[4], cb[5], cb[6]};
-            int crect[4];
-            seen = screen_rect(clo, chi, 0, s_cam, viewer, W, H, crect) != 0;
-        }
-        clusterVis = (unsigned)__ballot(seen);   // (32 clusters at most: the low word)
-    }
     // Each round classifies THREADS slots and appends the visible ones to the LDS list (order-free: depth ties are
     // resolved on the slot id).
     int nVis = 0;   // wave-uniform running total
@@ -344,10 +291,7 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
         int kind = PRIM_NONE, fr = 0;
         unsigned color = 0;
         float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-        // (this wave's 64 slots are one cluster of static boxes -- slot >> 6 is wave-uniform -- and the camera cannot see it: none of them would survive)
-        const int cl = __builtin_amdgcn_readfirstlane(slot >> 6);
-        const bool skipCluster = clustered && cl < (int)MAX_BOX_CLUSTERS && (cl + 1) * BOX_CLUSTER <= nLayout && !((clusterVis >> cl) & 1u);
-        if (slot < numSlots && !skipCluster) {
+        if (slot < numSlots) {
             if (slot < nLayout && hex) {   // floor / wall / edging / landmark: a box in the world or in a wall frame (records 8..10)
                 const HexRec b = gv.hex_boxes[(size_t)env * HEX_MAX_BOXES + slot];
                 kind = PRIM_BOX;
@@ -530,7 +474,7 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
         const unsigned long long mV = __ballot(cls != 0);
         int *cnt = s_cnt + (rd & 1) * 4;   // double-buffered: one barrier per round
         if (lane == 0) cnt[wave] = __popcll(mV);
-        sync_rounds();
+        sync();
         int pos = nVis, tot = 0;
 #pragma unroll
         for (int q = 0; q < NW; ++q) {

@@ -665,8 +665,7 @@ constexpr unsigned KEY_FAR = 0x42f00000u - KEY_NEAR;   // bits of FAR_Z = 120.0f
 static_assert(NEAR_Z == 0.01f && FAR_Z == 120.0f, "update KEY_NEAR / KEY_FAR");
 
 // depthMask: ~POS_MASK, handed in IN A VECTOR REGISTER (box_run launders it): gfx950's VOP3 encoding takes one scalar operand and no literal, so "(x & literal)
-// |
-// scalar" is two instructions, "(x & vector) | scalar" is one v_and_or_b32 -- 19 instead of 20 per box and pixel in the pass's innermost loop
+// | scalar" is two instructions, "(x & vector) | scalar" is one v_and_or_b32 -- 19 instead of 20 per box and pixel in the pass's innermost loop
 template <unsigned POS_MASK>
 __device__ __forceinline__ unsigned box_key(V3 inv, const float4 lo, const float4 hi, int pos, unsigned depthMask = ~POS_MASK)
 {
@@ -1004,12 +1003,10 @@ constexpr int CLS_MAX_TILES = 128;   // tiles of one workgroup that can be class
 // inside at every pixel of the tile <=> a x0 + b y0 + c_in >= 0 at the tile's first pixel (x0, y0); outside at every pixel <=> that + span <= 0.
 // Called by all 256 threads after the prologue's barrier (s_vis, s_rect, the header are in LDS); ends with a barrier.
 // The tile loop's ORDER (raster_fast_body): the classification also files every tile under its class -- s_cnt[c] tiles of category c (0 general, 1 overlay, 2
-// planar with the
-// highlight test, 3 planar, 4 empty), the entry's category, run length and place within its category in s_tile[u].z (the covering face it held moved into the
-// class word) and
-// its first pixel in s_txy[u] (x | y << 16) -- so that the workgroup draws its tiles most expensive class first from a compact list, and clears the empty ones
-// -- 43 % of a
-// TowerBuilding frame's tiles (r07d census) -- with all its threads at once instead of handing them out one by one.
+// planar with the highlight test, 3 planar, 4 empty), the entry's category, run length and place within its category in s_tile[u].z (the covering face it held
+// moved into the class word) and its first pixel in s_txy[u] (x | y << 16) -- so that the workgroup draws its tiles most expensive class first from a compact
+// list, and clears the empty ones -- 43 % of a TowerBuilding frame's tiles (r07d census) -- with all its threads at once instead of handing them out one by
+// one.
 template <int TH, int NT>
 __device__ __forceinline__ void classify_tiles(uint4 *s_tile, float4 *s_line, const float4 *s_vis, const short4 *s_rect, const float *s_hdr, const float *camv, int nVis, unsigned long long wb0,
                                                int W, int H, int part, int split, int tilesX, int numTiles, int perWG, bool overlayOn, int *s_cnt, unsigned *s_txy, bool bulkClear)
@@ -1192,10 +1189,8 @@ __device__ __forceinline__ void classify_tiles(uint4 *s_tile, float4 *s_line, co
             s_tile[u].w = info;
             const unsigned tclass = info & 7u, cat = tclass == TC_GENERAL ? 0u : tclass == TC_OVERLAY ? 1u : tclass == TC_PLANAR_SPEC ? 2u : tclass == TC_PLANAR ? 3u : 4u;
             // RUNS: neighbours in a tile row that one face of one box covers alike (the same class word), or that are empty, are ONE entry of the drawing order
-            // -- at
-            // most four tiles: the run's uniform set-up (the face's plane, colour, light term), its rows' ray terms and its hand-out are paid once.  The valid
-            // tiles
-            // of a chunk are its first lanes (every lane here is one); a run's tiles are neighbours in one tile row.
+            // -- at most eight tiles (a tile row of a 128-pixel frame): the run's uniform set-up (the face's plane, colour, light term), its rows' ray terms and its hand-out are paid once.  The
+            // valid tiles of a chunk are its first lanes (every lane here is one); a run's tiles are neighbours in one tile row.
             const bool runs = tclass == TC_PLANAR || tclass == TC_PLANAR_SPEC || (tclass == TC_EMPTY && !bulkClear);
             // (the previous lane's tile is the left neighbour only where the workgroup owns whole tile rows: a frame cut into `split` pieces deals its tiles
             // out in fours)
@@ -1204,13 +1199,13 @@ __device__ __forceinline__ void classify_tiles(uint4 *s_tile, float4 *s_line, co
             const bool natHead = !runs || lane == 0 || prevInfo != info || prevTxy + (unsigned)TILE_W != txy;
             const unsigned long long nat = __ballot(natHead), below = nat & ((2ull << lane) - 1ull);   // (bit `lane` and lower; lane 0 is a head: never empty)
             const int posInRun = lane - (63 - __clzll((long long)below));
-            const bool head = natHead || (posInRun & 3) == 0;
+            const bool head = natHead || (posInRun & 7) == 0;
             const unsigned long long heads = __ballot(head), valid = __ballot(true), above = lane < 63 ? heads >> (lane + 1) : 0ull;
             const int nextHead = above ? lane + __ffsll((long long)above) : 64;
-            const int len = min(nextHead, (int)__popcll(valid)) - lane;                                  // (1 .. 4)
-            // cat | run length << 3 | place within the category << 6; 7: not a run's first tile, not listed.  (The covering face this word held is in the class
+            const int len = min(nextHead, (int)__popcll(valid)) - lane;                                  // (1 .. 8)
+            // cat | run length << 3 | place within the category << 7; 7: not a run's first tile, not listed.  (The covering face this word held is in the class
             // word now.)
-            s_tile[u].z = head ? cat | ((unsigned)len << 3) | ((unsigned)atomicAdd(&s_cnt[cat], 1) << 6) : 7u;
+            s_tile[u].z = head ? cat | ((unsigned)len << 3) | ((unsigned)atomicAdd(&s_cnt[cat], 1) << 7) : 7u;
             s_txy[u] = txy;
         }
         __syncthreads();
@@ -1218,9 +1213,8 @@ __device__ __forceinline__ void classify_tiles(uint4 *s_tile, float4 *s_line, co
 }
 
 // the pixels of `n` neighbouring tiles of one tile row (first pixel (tx0, ty0)) that the face of axis k (the one towards the eye) of the world box at list
-// position
-// `pos` covers: the face's constants and the rows' ray terms once, per tile the columns' terms and the pixels -- planar_tile's arithmetic, operation for
-// operation
+// position `pos` covers: the face's constants and the rows' ray terms once, per tile the columns' terms and the pixels -- planar_tile's arithmetic, operation
+// for operation
 template <int NP, bool SPEC>
 __device__ __forceinline__ void planar_run(int pos, int k, int n, const float4 *s_vis, const float *s_hdr, const float4 *s_col, const float4 *s_row,
                                            const float2 *s_rowq, const float *s_colq, float nzk, int tx0, int ty0, int lane, const PixOut &po)
@@ -1364,8 +1358,7 @@ __device__ __forceinline__ void overlay_tile(int posA, int k, unsigned long long
 }
 
 // The general path for a tile of a classified frame: its list is ONE culling round (at most 64 primitives) and the tile's candidates -- mv0, not empty -- came
-// out of
-// the classification, so the rays are set up at once and there is no loop over rounds (the same arithmetic, in the same order, as the loop in
+// out of the classification, so the rays are set up at once and there is no loop over rounds (the same arithmetic, in the same order, as the loop in
 // raster_fast_body).
 template <bool SHAPES, unsigned POS_MASK, int NP>
 __device__ __forceinline__ void general_tile(unsigned long long mv0, unsigned long long wb0, unsigned signs, const float4 *s_vis, const float *s_hdr, const float *camv, int viewer, const float4 *s_col,
@@ -1443,14 +1436,14 @@ constexpr int glist_lds_bytes(int maxvis) { return 9 * maxvis + 4 * FH_FLOATS; }
 #else
 #define RT_COUNT(i, n) do { } while (0)
 #endif
-// a classified tile -- or, LISTED, an entry of the drawing order: a run of up to four planar / empty neighbours of a tile row -- by its class (classify_tiles)
+// a classified tile -- or, LISTED, an entry of the drawing order: a run of up to eight planar / empty neighbours of a tile row -- by its class (classify_tiles)
 template <bool SHAPES, unsigned POS_MASK, int NP, bool LISTED>
 __device__ __forceinline__ void classified_tile(const FastArgs &fa, const int u, const int tx0, const int ty0, const uint4 *s_tile, const float4 *s_vis, const float *s_hdr, const float *camv, int viewer,
                                             const float4 *s_col, const float4 *s_row, const float2 *s_rowq, const float *s_colq, float nzm0, float nzm1, float nzm2, unsigned long long wb0,
                                             int lane, const PixOut &po)
 {
     const unsigned info = (unsigned)__builtin_amdgcn_readfirstlane(s_tile[u].w), tclass = info & 7u;
-    const int run = LISTED ? (int)(((unsigned)__builtin_amdgcn_readfirstlane(s_tile[u].z) >> 3) & 7u) : 1;
+    const int run = LISTED ? (int)(((unsigned)__builtin_amdgcn_readfirstlane(s_tile[u].z) >> 3) & 15u) : 1;
     RT_COUNT(0, run);                                 // classified tiles
     if (tclass == TC_EMPTY) {   // nothing: the clear colour
         RT_COUNT(1, run);
@@ -1580,7 +1573,7 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
         if (tid < CLS_MAX_TILES) {
             const int tile = ((tid >> 2) * split + part) * 4 + (tid & 3);
             if (tid < perWG && tile < numTiles) {
-                const unsigned z = s_tile[tid].z, cat = z & 7u, place = z >> 6;
+                const unsigned z = s_tile[tid].z, cat = z & 7u, place = z >> 7;
                 const int base = cat == 0u ? 0 : cat == 1u ? c0 : cat == 2u ? c0 + c1 : cat == 3u ? c0 + c1 + c2 : c0 + c1 + c2 + c3;
                 if (cat == 4u && bulk) s_empty[place] = (unsigned short)tid;
                 else if (cat != 7u) s_order[base + (int)place] = (unsigned short)tid;   // (7: inside a run, drawn with the run's first tile)
@@ -1613,8 +1606,7 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
     // workgroup's other three waited for it 4-5 us on average, up to 17 (r04e).  u = 4 j + w is tile (j split + part) 4 + w of the frame.
     int unext = 0;
     // classified frames, LISTED: the entries of the drawing order (most expensive class first), one at a time; a tile's first pixel comes from the table (no
-    // tile
-    // arithmetic, and none of its scalars alive in this loop: at seven waves per SIMD the loop below keeps the register file full)
+    // tile arithmetic, and none of its scalars alive in this loop: at seven waves per SIMD the loop below keeps the register file full)
     if (LISTED && cls)
         for (int it = wave; it < nList; it = __builtin_amdgcn_readfirstlane(unext)) {
             const int u = __builtin_amdgcn_readfirstlane((int)s_order[it]);
@@ -2301,8 +2293,7 @@ static void self_clear(FastArgs &fa, const GymView &gv, int workgroups)
 // scalar cache occupancy is worth more (Collect 128 x 128: 97.6 us with one, 146 with two; HexMemory 155 / 171).
 // (In the one-launch passes of a batched call -- `batch` -- the long lists take two as well: eight passes' worth of workgroups keep the chip full at the lower
 // occupancy, and half as many tiles pay the per-tile work.  r07g/h, one / two pixels per lane: HexMemory 8.0 / 9.2 M obs/s, HexExplore 8.5 / 10.1, Collect 12.2
-// / 14.1,
-// Collect 128 x 72 15.3 / 16.8; one pass per launch: HexMemory 6.9 / 6.95, Collect 11.2 / 9.3.)
+// / 14.1, Collect 128 x 72 15.3 / 16.8; one pass per launch: HexMemory 6.9 / 6.95, Collect 11.2 / 9.3.)
 static int fast_pixels_per_lane(int W, int H, bool longList = false, bool batch = false)
 {
     const char *e = getenv("MV_FAST_PPL");

@@ -145,8 +145,7 @@ __device__ __forceinline__ void tower_draw(const GymView &gv, int env, int seq)
 
     // `seq` PUBLISHES the episode: every lane's stores to the blob (objects, spawns) are released at agent scope before lane 0 writes it, and tower_swap_in
     // acquires after it has read it -- the host's launch order (the draw before the last one is waited for) already keeps a step kernel off a blob that is
-    // being
-    // drawn; should a starved env ever race a running draw, it sees seq unset (ST_STARVED) or the whole episode, never a torn one.  Once per
+    // being drawn; should a starved env ever race a running draw, it sees seq unset (ST_STARVED) or the whole episode, never a torn one.  Once per
     // episode.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     wave_sync();

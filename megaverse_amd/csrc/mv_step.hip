@@ -130,14 +130,12 @@ template <class Args> __global__ __launch_bounds__(64, MV_STEP_TICKS_WAVES_PER_S
 template <class Args> __global__ __launch_bounds__(256, 3) void step_ticks_agents_kernel(Args a, int W, int H) { step_ticks_body<MAX_AGENTS>(a, W, H); }
 
 // Software-pipelined (one agent per env): TWO waves per env.  Wave 0 runs tick j + 1 while wave 1 sets tick j's frame up (mv_frame.h) -- the two halves of a
-// tick's
-// work that step_ticks_body runs back to back in one wave, each a chain of dependent loads and a few thousand vector instructions of ONE wave on its SIMD
-// (48 % of the resident wave's cycles were spent in s_waitcnt, r08z_pmc_SQ2.csv).  The frame setup reads the simulator state in place, so the two waves meet at
-// two workgroup barriers per tick:
+// tick's work that step_ticks_body runs back to back in one wave, each a chain of dependent loads and a few thousand vector instructions of ONE wave on its
+// SIMD (48 % of the resident wave's cycles were spent in s_waitcnt, r08z_pmc_SQ2.csv).  The frame setup reads the simulator state in place, so the two waves
+// meet at two workgroup barriers per tick:
 //   A(j): tick j's state is written (wave 0: behind its write-back and the episode swap-in of a finished env; wave 1: before it reads anything)
 //   B(j): tick j's state is read    (wave 1: behind the record loads of its last round of slots; wave 0: before tick j + 1's write-back, tower_tick's
-//   pipe_wait)
-// An iteration lasts max(tick, frame setup) instead of their sum; the last frame setup runs alone.
+// pipe_wait) An iteration lasts max(tick, frame setup) instead of their sum; the last frame setup runs alone.
 template <class Args>
 __global__ __launch_bounds__(128, MV_STEP_TICKS_WAVES_PER_SIMD) void step_ticks_pipe_kernel(Args a, int W, int H)
 {
@@ -161,13 +159,10 @@ __global__ __launch_bounds__(128, MV_STEP_TICKS_WAVES_PER_SIMD) void step_ticks_
 }
 
 // MV_STEP_PIPE=1 selects the two-wave kernels.  Measured (r09a / r09b / r09d, M obs/s, one wave / two): ALONE on the chip the step launch is a quarter shorter
-// (TowerBuilding
-// 16.6 -> 12.3 us per tick: 98 us per 8 ticks, Empty 16.9 -> 14.5) -- but beside the observation passes, where the batched calls run it, its length follows the
-// passes' VALU
-// load, not its own dependent chains: TowerBuilding 28.7 / 28.2, Empty 45.8 / 47.0, ObstaclesHard 512 envs 20.8 / 21.2, 1024 envs 26.3 / 23.6 (the Obstacles
-// tick spills at
-// 128 VGPRs with the frame setup's registers beside it; at 168: 24.4), the driver's 20-step form 22.9 / 23.2.  Off by default: twice the resident waves for +-2
-// %.
+// (TowerBuilding 16.6 -> 12.3 us per tick: 98 us per 8 ticks, Empty 16.9 -> 14.5) -- but beside the observation passes, where the batched calls run it, its
+// length follows the passes' VALU load, not its own dependent chains: TowerBuilding 28.7 / 28.2, Empty 45.8 / 47.0, ObstaclesHard 512 envs 20.8 / 21.2, 1024
+// envs 26.3 / 23.6 (the Obstacles tick spills at 128 VGPRs with the frame setup's registers beside it; at 168: 24.4), the driver's 20-step form 22.9 / 23.2.
+// Off by default: twice the resident waves for +-2 %.
 bool step_pipe_enabled()
 {
     static const bool on = getenv("MV_STEP_PIPE") && atoi(getenv("MV_STEP_PIPE")) != 0;

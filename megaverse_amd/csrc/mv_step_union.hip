@@ -59,9 +59,9 @@ __global__ __launch_bounds__(256) void step_union_kernel(UnionStepArgs ua, int W
 // into tick j's slot, tick, ...  Built for the register budget of the other resident multi-tick kernels (they run beside the observation passes of the
 // previous call, and what they hold the passes cannot have).
 // One wave per env -- except for the gyms with long frame lists (Collect, Hex*: up to 2048 visible primitives): their frame setup is most of their tick, one
-// wave
-// per env made their envs the launch's stragglers (57 us per tick where the short-list scenarios need 15-20: measured r08i), so the launch has WAVES waves per
-// workgroup, the long-list gyms use them all for the frame setup (wave 0 ticks, the others wait at the barrier) and the other gyms' extra waves leave at once.
+// wave per env made their envs the launch's stragglers (57 us per tick where the short-list scenarios need 15-20: measured r08i), so the launch has WAVES waves
+// per workgroup, the long-list gyms use them all for the frame setup (wave 0 ticks, the others wait at the barrier) and the other gyms' extra waves leave at
+// once.
 #ifndef MV_UNION_TICKS_WAVES_PER_SIMD
 // the register budget (512 / n): all eight scenarios' ticks in one kernel need ~175 VGPRs; at 128 it spills 1.1 KB per lane into the ticks' inner loops
 #define MV_UNION_TICKS_WAVES_PER_SIMD 3

@@ -91,15 +91,6 @@ __device__ __forceinline__ void swap_in_episode(const GymView &gv, const Collect
     const uint4 *src = reinterpret_cast<const uint4 *>(b->boxes);
     uint4 *dst = reinterpret_cast<uint4 *>(gv.boxes + (size_t)env * gv.box_stride);
     for (int i = lane; i < nb * 2; i += 64) dst[i] = src[i];
-    if (gv.box_clusters) {   // the slabs' bounds per 64 list positions (mv_frame.h: box clusters)
-        float *clusters = gv.box_clusters + (size_t)env * MAX_BOX_CLUSTERS * BOX_CLUSTER_FLOATS;
-        for (int c = 0; c * BOX_CLUSTER < nb && c < (int)MAX_BOX_CLUSTERS; ++c) {
-            const int i = c * BOX_CLUSTER + lane;
-            const bool valid = i < nb;
-            const LayoutBox lb = b->boxes[valid ? i : 0];
-            box_cluster_store(clusters, c, valid, v3(float(lb.min[0]), float(lb.min[1]), float(lb.min[2])), v3(float(lb.max[0]), float(lb.max[1]), float(lb.max[2])));
-        }
-    }
     const uint4 *hsrc = reinterpret_cast<const uint4 *>(b->heightmap);
     uint4 *hdst = reinterpret_cast<uint4 *>(gv.heightmap + (size_t)env * HM_BYTES);
     for (int i = lane; i < HM_BYTES / 16; i += 64) hdst[i] = hsrc[i];

@@ -87,24 +87,6 @@ __device__ __forceinline__ void swap_in_episode(const GymView &gv, const HexBlob
         uint4 *odst = reinterpret_cast<uint4 *>(gv.hex_objs + (size_t)env * HEX_MAX_OBJS);
         for (int i = lane; i < no * 2; i += 64) odst[i] = osrc[i];
     }
-    if (gv.box_clusters) {   // the boxes' bounds in the world, per 64 list positions (mv_frame.h: box clusters); a wall frame is a rotation about Y: x' = c x + s z, z' = -s x + c z
-        float *clusters = gv.box_clusters + (size_t)env * MAX_BOX_CLUSTERS * BOX_CLUSTER_FLOATS;
-        for (int c = 0; c * BOX_CLUSTER < nb && c < (int)MAX_BOX_CLUSTERS; ++c) {
-            const int i = c * BOX_CLUSTER + lane;
-            const bool valid = i < nb;
-            const HexRec r = b->boxes[valid ? i : 0];
-            const int fr = r.meta & 15;
-            V3 lo = v3(r.a[0], r.a[1], r.a[2]), hi = v3(r.b[0], r.b[1], r.b[2]);
-            if (fr != 0) {
-                const float cs = fr == 3 ? 0.0f : 0.8660254f, sn = fr == 1 ? 0.5f : fr == 2 ? -0.5f : 1.0f;
-                const float xa = cs * r.a[0], xb = cs * r.b[0], xc = sn * r.a[2], xd = sn * r.b[2];
-                const float za = -sn * r.a[0], zb = -sn * r.b[0], zc = cs * r.a[2], zd = cs * r.b[2];
-                lo.x = fminf(xa, xb) + fminf(xc, xd); hi.x = fmaxf(xa, xb) + fmaxf(xc, xd);
-                lo.z = fminf(za, zb) + fminf(zc, zd); hi.z = fmaxf(za, zb) + fmaxf(zc, zd);
-            }
-            box_cluster_store(clusters, c, valid, lo, hi);
-        }
-    }
     for (int k = 0; k < A; ++k) {
         float cs, sn;
         yaw_matrix(b->yaw[k], cs, sn);
@@ -190,23 +172,7 @@ __device__ __forceinline__ void hex_tick(const GymView &gv, const int env)
         phys_load(a, s_ag[i]);
         const Envelope env_i = step_envelope(a, dt);
         int count = 0;
-        // which clusters of 64 boxes can the envelope touch at all (mv_frame.h: box clusters)?  meets() compares a box with the envelope's bounding box in the box's own
-        // frame -- inside a circle of radius sqrt 2 (hx + hz) around the envelope's centre --; a cluster whose bounds in the world miss the square around that circle holds
-        // no box that meets() would keep: its round of loads is skipped, the candidate list is what it was
-        unsigned clusterMeet = ~0u;
-        if (gv.box_clusters) {
-            const int nCl = min((numCol + BOX_CLUSTER - 1) / BOX_CLUSTER, (int)MAX_BOX_CLUSTERS);
-            bool m = lane >= nCl;
-            if (lane < nCl) {
-                const float *cb = gv.box_clusters + ((size_t)env * MAX_BOX_CLUSTERS + lane) * BOX_CLUSTER_FLOATS;
-                const float r = 1.4143f * (env_i.h[0] + env_i.h[2]) + 4e-3f;
-                m = cb[0] <= env_i.c[0] + r && cb[4] >= env_i.c[0] - r && cb[2] <= env_i.c[2] + r && cb[6] >= env_i.c[2] - r &&
-                    cb[1] - CAP_HH <= env_i.c[1] + env_i.h[1] && cb[5] + CAP_HH >= env_i.c[1] - env_i.h[1];
-            }
-            clusterMeet = (unsigned)__ballot(m);
-        }
         for (int base = 0; base < numCol; base += 64) {   // floor and walls, in list order
-            if ((base >> 6) < (int)MAX_BOX_CLUSTERS && !((clusterMeet >> (base >> 6)) & 1u)) continue;
             const int bi = base + lane;
             bool keep = false;
             V3 lo = v3(0, 0, 0), hi = v3(0, 0, 0);

@@ -21,8 +21,6 @@ enum : int {
     // edging and up to 4 landmarks: 1765 boxes at most), collectables (one per cell but the centre one, + the landmark object)
     HEX_MAX_BOXES = 2048, HEX_MAX_OBJS = 128, HEX_FRAMES = 3,
     MAX_CAMS = MAX_AGENTS + HEX_FRAMES,   // frames of reference a box can live in besides the world: agent cameras, hex wall orientations
-    // long lists (Hex*, Collect): the static boxes of an episode in clusters of 64 list positions, each with its bounds in the world (GymView::box_clusters)
-    BOX_CLUSTER = 64, MAX_BOX_CLUSTERS = HEX_MAX_BOXES / BOX_CLUSTER, BOX_CLUSTER_FLOATS = 8,
 };
 
 enum : int { FRAME_HDR_BYTES = 1024 };
@@ -148,9 +146,6 @@ struct GymView {
     uint8_t *soko_cells;       // [N][SOKO_DIM * SOKO_DIM] (Sokoban: SOKO_WALL / SOKO_GOAL per level cell, [x * SOKO_DIM + z])
     HexRec *hex_boxes;         // [N][HEX_MAX_BOXES] (Hex*: hdr.num_boxes boxes, the first hdr.num_terrain of them collide)
     HexRec *hex_objs;          // [N][HEX_MAX_OBJS]  (Hex*: hdr.num_rewards collectables)
-    // [N][MAX_BOX_CLUSTERS][8] (Hex*, Collect; else null): lo(3), 0, hi(3), 0 -- the bounds in the WORLD of the episode's static boxes 64 c .. 64 c + 63, a hair
-    // generous, written by the episode swap-in: the frame setup skips the clusters the camera cannot see (mv_frame.h)
-    float *box_clusters;
     int32_t *episode_status;   // [N + 2] episodes consumed per env (host-generated scenarios), their total, error flags (ST_*)
     const void *blobs;         // [N][spares] resident next episodes (EpisodeBlob / CollectBlob / RearrangeBlob / SokobanBlob): episode
                                // number q (1-based) of an env lives in ring slot (q - 1) % spares
@@ -186,13 +181,12 @@ struct GymView {
 };
 
 // The n <= 8 consecutive ticks of a multi-tick step launch (mv_step.hip: step_ticks_kernel, and every mv_step_*.hip), the same envs in all of them: their views
-// BY
-// VALUE as the launch's arguments -- 2.6 KB of the 4 KB kernel-argument segment; the kernels read a tick's view with scalar loads on demand, its fields do not
-// live
-// in registers across the tick.  A call of more than 8 ticks (MAX_STEP_TICKS: 16) is two such launches back to back.  (Built and measured in round 5, removed:
-// one launch of 16 ticks with its views in device memory, written there by a small kernel in front of it -- that kernel, queued behind the previous step launch
-// and beside an observation launch that had just taken the chip, took 10-44 us and made the step launch arrive late: Empty 27.6 M obs/s against 41.5 M with two
-// launches of 8, r08t; and deriving tick j's view from tick 0's in the kernel: 100-140 bytes of scratch per lane more and 1.5-3.5 % of the rate.)
+// BY VALUE as the launch's arguments -- 2.6 KB of the 4 KB kernel-argument segment; the kernels read a tick's view with scalar loads on demand, its fields do
+// not live in registers across the tick.  A call of more than 8 ticks (MAX_STEP_TICKS: 16) is two such launches back to back.  (Built and measured in round 5,
+// removed: one launch of 16 ticks with its views in device memory, written there by a small kernel in front of it -- that kernel, queued behind the previous
+// step launch and beside an observation launch that had just taken the chip, took 10-44 us and made the step launch arrive late: Empty 27.6 M obs/s against
+// 41.5 M with two launches of 8, r08t; and deriving tick j's view from tick 0's in the kernel: 100-140 bytes of scratch per lane more and 1.5-3.5 % of the
+// rate.)
 struct StepTicksArgs8 {
     int32_t n, pad;
     GymView gv[8];

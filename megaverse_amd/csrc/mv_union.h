@@ -20,8 +20,7 @@ static_assert(sizeof(UnionStepArgs) + 16 <= 4096, "UnionStepArgs + (W, H, render
 // k consecutive ticks of every gym of a group with ONE launch (step_union_ticks_kernel): tick 0's view of every gym; tick j's differs from it in its
 // hand-over slot -- ten buffers, all `slot_stride` bytes further per tick (mv_api.hip carves a gym's slots out of its arena one after the other) --, its
 // action index and its cost histogram (consecutive, modulo their number): derived in the kernel (mv_types.h: tick_view), not passed (k x n views do not fit the
-// 4 KB of
-// kernel arguments).
+// 4 KB of kernel arguments).
 struct UnionTicksArgs {
     int32_t n, k;
     int32_t first[MAX_UNION + 1];
