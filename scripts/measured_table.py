@@ -20,7 +20,16 @@ ROWS = [("tower_bench.json", "**TowerBuilding 1024 envs x 1, 128x128 (BASELINE c
         ("Empty_bench.json", "Empty 1024 x 1"), ("Empty_800_steps_bench.json", "Empty 1024 x 1, 800 steps"),
         ("mixed_64_bench.json", "**Mixed: all eight `megaverse8` scenarios round-robin, 1024 x 1, 64x64 (one GPU's share of configs[4])**"),
         ("mixed4_64_bench.json", "Mixed4: TowerBuilding, ObstaclesEasy, ObstaclesHard, Collect round-robin, 1024 x 1, 64x64 (BASELINE.md 3 row 5)"),
-        ("mixed_128_bench.json", "Mixed, 1024 envs, 128x128")]
+        ("mixed_128_bench.json", "Mixed, 1024 envs, 128x128"),
+        ("tower_128x72_bench.json", "TowerBuilding 1024 x 1, 128x72 (the reference's own obs size)"),
+        ("tower_64x64_bench.json", "TowerBuilding 1024 x 1, 64x64"),
+        ("Collect_128x72_bench.json", "Collect 1024 x 1, 128x72"),
+        ("tower_exact_pixels_bench.json", "same as the headline, exact pixels (`--pixels exact`)"),
+        ("tower_single_bit_bench.json", "same, the reference benchmark's single-bit policy (`--policy single-bit`)"),
+        ("tower_planar_off_bench.json", "same, tiles not classified (`MV_PLANAR=0`)"),
+        ("tower_step_pipe_bench.json", "same, the two-wave step kernels (`MV_STEP_PIPE=1`)"),
+        ("tower_normal_priority_bench.json", "same, simulation stream at default priority (`MV_SIM_PRIORITY=normal`)"),
+        ("obstacles_hard_512_normal_priority_bench.json", "ObstaclesHard 512, overlapped passes, `MV_SIM_PRIORITY=normal`")]
 
 
 def main():

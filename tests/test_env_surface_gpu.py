@@ -212,3 +212,37 @@ def test_pybind_flavour_places_its_envs_from_the_environment(hip, monkeypatch):
     for j in range(N):
         assert np.array_equal(a.get_observation(j, 0), b.get_observation(j, 0))
     a.close(); b.close(); whole.close()
+
+
+def test_call_size_advice_and_arena(hip, monkeypatch):
+    """mv_recommended_ticks_per_call / mv_recommended_pass_overlap / mv_arena_bytes (include/megaverse_hip.h): the measured rules bench.py used to hold, behind the
+    ABI -- 16 ticks per call for 1024 .. 2047 frames where the slot groups hold them (sized by footprint; MV_PIPE_BATCH overrides), 8 otherwise, 1 for few-tick
+    episodes; overlapped passes for the Obstacles family and Sokoban; a step_n of more ticks than the slot groups hold is split by the library"""
+    import os
+    import torch
+    from megaverse_amd.extension import MegaverseGym
+    monkeypatch.setenv("BOXOBAN_LEVELS", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "boxoban"))
+    cases = [("TowerBuilding", 1024, 1, {}, 16, False), ("TowerBuilding", 64, 1, {}, 8, False), ("TowerBuilding", 512, 4, {}, 8, False),
+             ("ObstaclesHard", 1024, 1, {}, 16, True), ("Sokoban", 1024, 1, {}, 8, True), ("HexMemory", 1024, 1, {}, 8, False),
+             ("Rearrange", 64, 1, {"episodeLengthSec": 0.5}, 1, False)]
+    for scenario, n, a, params, want, overlap in cases:
+        g = MegaverseGym(scenario, 32, 32, n, a, 2, False, params)
+        assert g.recommended_ticks_per_call() == want, (scenario, n, a, g.recommended_ticks_per_call())
+        assert g.recommended_pass_overlap() == overlap, scenario
+        assert g.arena_bytes() > n * a * 32 * 32 * 4
+        g.close()
+    monkeypatch.setenv("MV_PIPE_BATCH", "8")
+    g = MegaverseGym("TowerBuilding", 32, 32, 1024, 1, 2, False, {})
+    assert g.recommended_ticks_per_call() == 8
+    small = g.arena_bytes()
+    ring = torch.zeros((24, 1024, 32, 32, 4), dtype=torch.uint8, device="cuda:0")
+    g.set_output_ring(24, ring.data_ptr())
+    g.seed(3); g.reset()
+    g.step_n(20, "multidiscrete", 5, 0)   # 8 + 8 + 4: split by the library
+    g.synchronize(); torch.cuda.synchronize()
+    assert int(ring[:20, :, :, :, 3].min()) == 255 and int(ring[20:].max()) == 0
+    g.close()
+    monkeypatch.setenv("MV_PIPE_BATCH", "16")
+    g = MegaverseGym("TowerBuilding", 32, 32, 1024, 1, 2, False, {})
+    assert g.arena_bytes() > small and g.recommended_ticks_per_call() == 16
+    g.close()
