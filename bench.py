@@ -12,9 +12,11 @@ kernel (physics + scenario logic + auto-reset of finished episodes) -> frame set
 Workload at N=1: BASELINE.json configs[1] = TowerBuilding, num_envs=1024, num_agents_per_env=1, obs 128x128.
 N>1: weak scaling, 1024 envs per GPU, envs sharded by contiguous blocks with job-wide seeds (a sharded run
 simulates exactly the envs the single-process run of N*1024 would) and -- north_star's layout -- ONE data-path
-collective: the RCCL all-gather of the observation slab, issued on a communication stream from one of two
-slabs so that step t+1's kernels overlap gather t.  `value` is the rate WITH the gather; `value_no_gather` (same
-line) is the rate when every GPU's consumer reads its own shard (the reference's multi-GPU mode).
+collective: the RCCL all-gather of the observation slabs, issued on a communication stream -- ONE collective
+per batched call: a call of k ticks (mv_step_n, the same launches as the N=1 headline) renders into one half of a
+ring of 2k slabs while the other half, the previous call's k slabs, travels (--batch 1: one tick and one collective
+at a time).  `value` is the rate WITH the gather; `value_no_gather` (same line, the identical calls) is the rate
+when every GPU's consumer reads its own shard (the reference's multi-GPU mode).
 
 Timing: the K timed steps carry no instrumentation.  The per-kernel figures of `roofline` / `roofline_physics`
 come from a second, untimed loop with HIP events on the gym's stream (mv_profile_begin).
