@@ -261,7 +261,8 @@ static hipError_t create_sim_stream(hipStream_t *s)
     static const char *prio = getenv("MV_SIM_PRIORITY");
     if (!prio || std::strcmp(prio, "normal")) {
         int lo = 0, hi = 0;
-        if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi) == hipSuccess) return hipSuccess;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess
+            && hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi) == hipSuccess) return hipSuccess;
         (void)hipGetLastError();   // (no priorities on this device / runtime: a stream of default priority does the same work)
     }
     return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
@@ -278,7 +279,9 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     int scenario = SCN_TOWER;
     ObstacleConfig oc;
     if (!scenario_from_name(scen, scenario, oc))
-        return fail("Unknown scenario " + scen + " (this build accelerates: TowerBuilding, ObstaclesEasy/Medium/Hard/Walls/Steps/Lava, Collect, Rearrange, Sokoban, HexMemory, HexExplore, Empty)");
+        return fail("Unknown scenario " + scen
+                    + " (this build accelerates: TowerBuilding, ObstaclesEasy/Medium/Hard/Walls/Steps/Lava, Collect, Rearrange, Sokoban, HexMemory, "
+                         "HexExplore, Empty)");
     std::vector<std::string> levelFiles;
     if (scenario == SCN_SOKOBAN) {   // SokobanScenario's constructor looks the level files up (scenario_sokoban.cpp:40-78); none is fatal there too
         levelFiles = find_boxoban_level_files();
@@ -286,7 +289,8 @@ int mv_create(const mv_config *cfg, mv_gym **out)
     }
     if (cfg->num_envs < 1 || cfg->num_agents_per_env < 1 || cfg->num_agents_per_env > MAX_AGENTS)
         return fail("mv_create: num_envs >= 1 and 1 <= num_agents_per_env <= 8 required");
-    if (cfg->obs_width < 1 || cfg->obs_height < 1 || cfg->obs_width > 1024 || cfg->obs_height > 1024) return fail("mv_create: observation size must be within 1..1024");
+    if (cfg->obs_width < 1 || cfg->obs_height < 1 || cfg->obs_width > 1024
+        || cfg->obs_height > 1024) return fail("mv_create: observation size must be within 1..1024");
 
     int ndev = 0;
     hipError_t derr = hipInit(0);
@@ -321,13 +325,15 @@ int mv_create(const mv_config *cfg, mv_gym **out)
 
     GymView &gv = g->gv;
     gv.num_envs = g->N; gv.num_agents = g->A;
-    const bool obstacles = scenario == SCN_OBSTACLES || scenario == SCN_EMPTY, collect = scenario == SCN_COLLECT, rearrange = scenario == SCN_REARRANGE, sokoban = scenario == SCN_SOKOBAN;
+    const bool obstacles = scenario == SCN_OBSTACLES || scenario == SCN_EMPTY, collect = scenario == SCN_COLLECT,
+            rearrange = scenario == SCN_REARRANGE, sokoban = scenario == SCN_SOKOBAN;
     const bool hex = scenario == SCN_HEX_MEMORY || scenario == SCN_HEX_EXPLORE;
     const bool hostEpisodes = obstacles || collect || rearrange || sokoban || hex;
     gv.scenario = scenario;
     gv.box_stride = collect ? COLLECT_MAX_BOXES : MAX_BOXES;
     gv.reward_stride = collect ? COLLECT_MAX_REWARDS : MAX_REWARDS;
-    g->blobBytes = collect ? sizeof(CollectBlob) : obstacles ? sizeof(EpisodeBlob) : rearrange ? sizeof(RearrangeBlob) : sokoban ? sizeof(SokobanBlob) : hex ? sizeof(HexBlob) : sizeof(TowerBlob);
+    g->blobBytes = collect ? sizeof(CollectBlob) : obstacles ? sizeof(EpisodeBlob) : rearrange ? sizeof(RearrangeBlob)
+                                    : sokoban ? sizeof(SokobanBlob) : hex ? sizeof(HexBlob) : sizeof(TowerBlob);
     // ONE arena for all simulator state: a step touches ~8 arrays per env, separate small allocations
     // cost a TLB miss each per wave (measured: 83 % of the physics kernel's time was spent waiting on
     // ~30 memory operations); one large allocation is backed by large pages.
@@ -339,20 +345,24 @@ int mv_create(const mv_config *cfg, mv_gym **out)
                  szObs = up(NA * (size_t)g->w * g->h * 4);
     const size_t szTerrain = obstacles ? up(N * MAX_TERRAIN * sizeof(TerrainBox)) : 0,
                  szRewObj = hostEpisodes ? up(N * (size_t)gv.reward_stride * sizeof(MovableObject)) : 0,
-                 szHeight = collect ? up(N * (size_t)HM_BYTES) : 0, szItems = rearrange ? up(N * MAX_ITEMS * sizeof(ArrangementItem)) : 0, szCells = sokoban ? up(N * (size_t)(SOKO_DIM * SOKO_DIM)) : 0,
-                 szHexB = hex ? up(N * (size_t)HEX_MAX_BOXES * sizeof(HexRec)) : 0, szHexO = hex ? up(N * (size_t)HEX_MAX_OBJS * sizeof(HexRec)) : 0, szBlobs = up(N * g->blobBytes * (size_t)g->spares), szCnt = up((N + 2) * sizeof(int32_t)), szGen = hostEpisodes ? 0 : up(N * sizeof(TowerGen));
+                 szHeight = collect ? up(N * (size_t)HM_BYTES) : 0, szItems = rearrange ? up(N * MAX_ITEMS * sizeof(ArrangementItem))
+                                         : 0, szCells = sokoban ? up(N * (size_t)(SOKO_DIM * SOKO_DIM)) : 0,
+                 szHexB = hex ? up(N * (size_t)HEX_MAX_BOXES * sizeof(HexRec)) : 0, szHexO = hex ? up(N * (size_t)HEX_MAX_OBJS * sizeof(HexRec)) : 0,
+                                   szBlobs = up(N * g->blobBytes * (size_t)g->spares), szCnt = up((N + 2) * sizeof(int32_t)),
+                                                szGen = hostEpisodes ? 0 : up(N * sizeof(TowerGen));
     gv.vis_stride = hex ? 2048 : collect ? 1024 : 256;
     if (const char *e = getenv("MV_DEBUG_VIS_STRIDE")) gv.vis_stride = std::min(gv.vis_stride, std::max(8, atoi(e)));   // (tests: provoke ST_VISIBLE)
     gv.debug_redo = getenv("MV_DEBUG_FORCE_REDO") && atoi(getenv("MV_DEBUG_FORCE_REDO")) ? 1 : 0;   // (tests: mv_tick_tower.h's sequential redo)
     gv.spares = g->spares;
     const size_t szVisP = up(NA * (size_t)gv.vis_stride * 32), szVisR = up(NA * (size_t)gv.vis_stride * 8), szVisC = up(NA * sizeof(int32_t)),
-                 szLpt = up(NA * sizeof(int32_t)) + up((NA + 1) * sizeof(int32_t)) + up(NA * (size_t)FRAME_HDR_BYTES) + up((size_t)LPT_BUCKETS * LPT_SUBS * lpt_sub_capacity(NA) * sizeof(int32_t));
+                 szLpt = up(NA * sizeof(int32_t)) + up((NA + 1) * sizeof(int32_t)) + up(NA * (size_t)FRAME_HDR_BYTES)
+                            + up((size_t)LPT_BUCKETS * LPT_SUBS * lpt_sub_capacity(NA) * sizeof(int32_t));
     // per slot: frame lists, headers, cost lists, and the staging copies of rewards / dones / true objectives
     const size_t szParity = szVisP + szVisR + szVisC + szLpt + szRew + szDone + szObjv;
     // Ticks per call of mv_step_n (`batch`; a gym holds PIPE_GROUPS x batch hand-over slots of szParity bytes each): 16 -- one tail of the one-launch
-    // observation pass per 16 ticks, measured against 8: TowerBuilding 1024 envs 26.6 -> 28.3 M obs/s -- where the 48 slots that takes stay under 2.25 GiB, else 8
-    // (a Hex frame's slot is 80 KB: 3.8 GB per 1024 frames at 16, 1.9 GB at 8 -- and 16 buys it nothing: 9.32 / 9.40 M obs/s, r09k; Collect's 42 KB: 2.1 GB at 16,
-    // 13.9 -> 14.8 M; TowerBuilding's 12 KB: 0.6 GB).  MV_PIPE_BATCH=1..16 overrides; mv_recommended_ticks_per_call says what to ask for.
+    // observation pass per 16 ticks, measured against 8: TowerBuilding 1024 envs 26.6 -> 28.3 M obs/s -- where the 48 slots that takes stay under 2.25 GiB,
+    // else 8 (a Hex frame's slot is 80 KB: 3.8 GB per 1024 frames at 16, 1.9 GB at 8 -- and 16 buys it nothing: 9.32 / 9.40 M obs/s, r09k; Collect's 42 KB: 2.1
+    // GB at 16, 13.9 -> 14.8 M; TowerBuilding's 12 KB: 0.6 GB).  MV_PIPE_BATCH=1..16 overrides; mv_recommended_ticks_per_call says what to ask for.
     g->batch = (size_t)PIPE_GROUPS * 16 * szParity <= (size_t(9) << 28) ? 16 : 8;   // (2.25 GiB)
     if (const char *e = getenv("MV_PIPE_BATCH")) g->batch = std::min((int)PIPE_BATCH_MAX, std::max(1, atoi(e)));
     g->slots = PIPE_GROUPS * g->batch;
@@ -374,8 +384,10 @@ int mv_create(const mv_config *cfg, mv_gym **out)
         if (e_ != hipSuccess) {
             const int b = g->batch;
             mv_destroy(g);
-            return fail("hipMalloc arena (" + std::to_string(total >> 20) + " MiB, of which " + std::to_string(((size_t)PIPE_GROUPS * b * szParity) >> 20) + " MiB are the " +
-                        std::to_string(PIPE_GROUPS * b) + " hand-over slots of " + std::to_string(b) + " ticks per call: a smaller MV_PIPE_BATCH shrinks them): " + hipGetErrorString(e_));
+            return fail("hipMalloc arena (" + std::to_string(total >> 20) + " MiB, of which "
+                        + std::to_string(((size_t)PIPE_GROUPS * b * szParity) >> 20) + " MiB are the " +
+                        std::to_string(PIPE_GROUPS * b) + " hand-over slots of " + std::to_string(b)
+                                       + " ticks per call: a smaller MV_PIPE_BATCH shrinks them): " + hipGetErrorString(e_));
         }
         g->arenaBytes = total;
         (void)hipMemset(g->arena, 0, total);
@@ -423,7 +435,8 @@ int mv_create(const mv_config *cfg, mv_gym **out)
         }
     }
     if (getenv("MV_TICK_TIMING") && atoi(getenv("MV_TICK_TIMING"))) {   // (an instrumented build, -DMV_TICK_TIMING: phase cycle sums, printed by mv_close)
-        if (hipMalloc((void **)&g->gv.dbg, N * 64 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemset(g->gv.dbg, 0, N * 64 * sizeof(unsigned long long));
+        if (hipMalloc((void **)&g->gv.dbg, N * 64 * sizeof(unsigned long long)) == hipSuccess)
+            (void)hipMemset(g->gv.dbg, 0, N * 64 * sizeof(unsigned long long));
         else g->gv.dbg = nullptr;
         for (int q = 0; q < g->slots; ++q) g->gvp[q].dbg = g->gv.dbg;
     }
@@ -581,7 +594,8 @@ int mv_close(mv_gym *g)
         std::vector<unsigned long long> h((size_t)N * 64);
         if (hipMemcpy(h.data(), gv.dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
             auto at = [&](int e, int k) { return h[(size_t)e * 64 + k]; };
-            static const char *names[8] = {"loads", "actions", "physics", "interact", "fall/zone/timers", "write-back", "tick (both waves, to the barrier)", "frame setup (both waves)"};
+            static const char *names[8] = {"loads", "actions", "physics", "interact", "fall/zone/timers", "write-back",
+                    "tick (both waves, to the barrier)", "frame setup (both waves)"};
             for (int k = 0; k < 8; ++k) {
                 double sum = 0.0; unsigned long long mx = 0;
                 for (int e = 0; e < N; ++e) { sum += (double)at(e, k); mx = std::max(mx, at(e, k)); }
@@ -597,7 +611,8 @@ int mv_close(mv_gym *g)
             }
             double cs[5] = {0, 0, 0, 0, 0};
             for (int e = 0; e < N; ++e) for (int k = 0; k < 5; ++k) cs[k] += (double)at(e, 8 + k);
-            std::fprintf(stderr, "[mv tick timing] casts, all ticks of all envs: %.0f sweeps, %.0f casts started, %.0f wave iterations slot by slot, %.0f if a lane's casts were queued\n", cs[0], cs[4], cs[1], cs[2]);
+            std::fprintf(stderr, "[mv tick timing] casts, all ticks of all envs: %.0f sweeps, %.0f casts started, %.0f wave iterations slot by slot, %.0f if "
+                         "a lane's casts were queued\n", cs[0], cs[4], cs[1], cs[2]);
             const bool tickOnly = at(0, 49) != 0;
             if (tickOnly) {
                 int worst = 0; double mxsum = 0.0, wi[5] = {0, 0, 0, 0, 0};
@@ -606,14 +621,17 @@ int mv_close(mv_gym *g)
                     if (at(e, 54) > at(worst, 54)) worst = e;
                     for (int k = 0; k < 5; ++k) wi[k] += (double)at(e, 32 + 8 + k);
                 }
-                std::fprintf(stderr, "[mv tick timing] longest tick of an env: %.2f us on average over envs, with on average %.1f sweeps, %.1f casts, %.1f wave iterations (%.1f queued), longest cast %.1f\n",
+                std::fprintf(stderr, "[mv tick timing] longest tick of an env: %.2f us on average over envs, with on average %.1f sweeps, %.1f casts, %.1f "
+                             "wave iterations (%.1f queued), longest cast %.1f\n",
                              mxsum / N * 0.01, wi[0] / N, wi[4] / N, wi[1] / N, wi[2] / N, wi[3] / N);
-                std::fprintf(stderr, "[mv tick timing] the longest of all (env %d, %.2f us), cycles per phase: loads %llu actions %llu physics %llu interact %llu fall %llu write-back %llu; %llu sweeps, %llu casts, %llu wave iterations (%llu queued), longest cast %llu\n",
+                std::fprintf(stderr, "[mv tick timing] the longest of all (env %d, %.2f us), cycles per phase: loads %llu actions %llu physics %llu interact "
+                             "%llu fall %llu write-back %llu; %llu sweeps, %llu casts, %llu wave iterations (%llu queued), longest cast %llu\n",
                              worst, (double)at(worst, 54) * 0.01, at(worst, 32), at(worst, 33), at(worst, 34), at(worst, 35), at(worst, 36), at(worst, 37),
                              at(worst, 40), at(worst, 44), at(worst, 41), at(worst, 42), at(worst, 43));
                 double rl = 0.0, rc = 0.0;
                 for (int e = 0; e < N; ++e) { rl += (double)at(e, 52); rc += (double)at(e, 53); }
-                std::fprintf(stderr, "[mv tick timing] tick-only launches: %.0f ticks regenerated their env and lived %.2f us on average\n", rc, rc > 0 ? rl / rc * 0.01 : 0.0);
+                std::fprintf(stderr, "[mv tick timing] tick-only launches: %.0f ticks regenerated their env and lived %.2f us on average\n",
+                             rc, rc > 0 ? rl / rc * 0.01 : 0.0);
             }
             {   // {sum of wave-0 lifetimes, launches, start and end of the last one}
                 const int b = tickOnly ? 48 : 52;
@@ -623,7 +641,8 @@ int mv_close(mv_gym *g)
                     if (at(e, b + 1)) { s0 = std::min(s0, at(e, b + 2)); s1 = std::max(s1, at(e, b + 2)); e1 = std::max(e1, at(e, b + 3)); }
                 }
                 if (cnt > 0)
-                    std::fprintf(stderr, "[mv tick timing] %s launches: wave 0 lives %.2f us on average; last launch: starts spread over %.2f us, first start to last end %.2f us\n",
+                    std::fprintf(stderr, "[mv tick timing] %s launches: wave 0 lives %.2f us on average; last launch: starts spread over %.2f us, first "
+                                 "start to last end %.2f us\n",
                                  tickOnly ? "tick-only" : "fused", life / cnt * 0.01, (double)(s1 - s0) * 0.01, (double)(e1 - s0) * 0.01);
             }
         }
@@ -651,7 +670,8 @@ int mv_close(mv_gym *g)
     g->userNow = nullptr;
     if (g->simDone) (void)hipEventDestroy(g->simDone);
     g->simStream = nullptr; g->simDone = nullptr;
-    g->hBlobs = nullptr; g->hStatus = nullptr; g->stepDone = g->statusCopied = nullptr; g->lastStep = nullptr; g->copyStream = nullptr; g->dBlobs = nullptr; g->dStatus = nullptr;
+    g->hBlobs = nullptr; g->hStatus = nullptr; g->stepDone = g->statusCopied = nullptr; g->lastStep = nullptr;
+            g->copyStream = nullptr; g->dBlobs = nullptr; g->dStatus = nullptr;
     g->arena = nullptr;
     for (int b = 0; b < 2; ++b) {
         if (g->hActions[b]) (void)hipHostFree(g->hActions[b]);
@@ -768,7 +788,8 @@ int mv_render(mv_gym *g)
     HIP_TRY(hipSetDevice(g->device));
     if (sim_join(g)) return -1;
     if (take_hist(g, g->stream, true)) return -1;
-    if (launch_raster(view(g, g->parity), last_outputs(g).obs, g->w, g->h, g->stream, nullptr, g->fastPixels)) return fail("mv_render: observation size above 1024x1024");
+    if (launch_raster(view(g, g->parity), last_outputs(g).obs, g->w, g->h, g->stream, nullptr, g->fastPixels))
+        return fail("mv_render: observation size above 1024x1024");
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -786,7 +807,8 @@ int check_status_flags(mv_gym *g)
     const int flags = g->hStatus[N + 1], gen = g->feeder ? g->feeder->take_overflow() : 0;
     if (!flags && !gen) return 0;
     std::string msg;
-    if (flags & ST_STARVED) msg += "an env finished again before its next episode was resident (it repeated its done step; the next episodes are being uploaded now); ";
+    if (flags & ST_STARVED) msg += "an env finished again before its next episode was resident (it repeated its done step; the next episodes are being "
+        "uploaded now); ";
     if (flags & ST_CANDIDATES) msg += "collision candidate list overflow (more than 128 bodies around one agent); ";
     if (flags & ST_VISIBLE) msg += "a frame had more visible primitives than the raster keeps (256; Collect 1024; Hex* 2048): the excess was not drawn; ";
     if (flags & ST_CHUNK) msg += "an object placement outside the 32 x 16 x 32 voxel chunk was refused (the reference's grid is unbounded); ";
@@ -855,7 +877,8 @@ static int upload_pass(mv_gym *g)
         size_t bytes = 0;
         const uint8_t *src = g->feeder->wait_ready(i, need, &bytes);
         if (!src) return fail(g->feeder->failed() ? std::string("episode feeder: a level file could not be read (Sokoban)")
-                                                  : "episode feeder: episode " + std::to_string(need) + " of env " + std::to_string(i) + " was never generated");
+                                                  : "episode feeder: episode " + std::to_string(need)
+                                                          + " of env " + std::to_string(i) + " was never generated");
         if (!waited && g->lastStep) { HIP_TRY(hipStreamWaitEvent(g->copyStream, g->lastStep, 0)); waited = true; }
         const int slot = (need - 1) % K;
         if (runLen > 0 && (i != runFirst + runLen || slot != runSlot) && flush_run()) return -1;
@@ -1051,7 +1074,8 @@ int mv_set_actions_device(mv_gym *g, const int32_t *device_actions)
 int mv_set_sample_policy(mv_gym *g, int32_t policy)
 {
     if (check(g)) return -1;
-    if (policy != MV_POLICY_MULTIDISCRETE && policy != MV_POLICY_SINGLE_BIT) return fail("mv_set_sample_policy: MV_POLICY_MULTIDISCRETE (1) or MV_POLICY_SINGLE_BIT (2)");
+    if (policy != MV_POLICY_MULTIDISCRETE
+        && policy != MV_POLICY_SINGLE_BIT) return fail("mv_set_sample_policy: MV_POLICY_MULTIDISCRETE (1) or MV_POLICY_SINGLE_BIT (2)");
     g->samplePolicy = policy;
     return 0;
 }
@@ -1142,7 +1166,8 @@ int mv_get_observation(mv_gym *g, int32_t env, int32_t agent, uint8_t *out)
     if (check(g)) return -1;
     if (env < 0 || env >= g->N || agent < 0 || agent >= g->A) return fail("mv_get_observation: index out of range");
     const size_t frameBytes = (size_t)g->w * g->h * 4;
-    HIP_TRY(hipMemcpyAsync(out, (const uint8_t *)last_outputs(g).obs + ((size_t)env * g->A + agent) * frameBytes, frameBytes, hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipMemcpyAsync(out, (const uint8_t *)last_outputs(g).obs + ((size_t)env * g->A + agent) * frameBytes,
+            frameBytes, hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
     return 0;
 }
@@ -1171,7 +1196,8 @@ int mv_draw_hires(mv_gym *g)
     }
     if (sim_join(g)) return -1;
     if (take_hist(g, g->stream, true)) return -1;
-    if (launch_raster(view(g, g->parity), g->hiresObs, g->hiresW, g->hiresH, g->stream, nullptr, g->fastPixels)) return fail("mv_draw_hires: render size above 1024x1024");
+    if (launch_raster(view(g, g->parity), g->hiresObs, g->hiresW, g->hiresH, g->stream, nullptr,
+        g->fastPixels)) return fail("mv_draw_hires: render size above 1024x1024");
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -2,9 +2,12 @@
 // the host-side episode generators and the feeder without a device, the device's RNG helpers and single fp32 operations.  Used by tests/ only.
 #include "mv_api_internal.h"
 
-__global__ void set_agent_pos_kernel(AgentState *agents, int idx, float x, float y, float z) { agents[idx].pos[0] = x; agents[idx].pos[1] = y; agents[idx].pos[2] = z; }
-__global__ void set_agent_yaw_kernel(AgentState *agents, int idx, float c, float s) { agents[idx].m00 = c; agents[idx].m02 = s; agents[idx].m20 = -s; agents[idx].m22 = c; }
-__global__ void set_agent_velocity_kernel(AgentState *agents, int idx, float hvx, float hvz, float vvel) { agents[idx].hvx = hvx; agents[idx].hvz = hvz; agents[idx].vvel = vvel; }
+__global__ void set_agent_pos_kernel(AgentState *agents, int idx, float x, float y,
+                                     float z) { agents[idx].pos[0] = x; agents[idx].pos[1] = y; agents[idx].pos[2] = z; }
+__global__ void set_agent_yaw_kernel(AgentState *agents, int idx, float c,
+                                     float s) { agents[idx].m00 = c; agents[idx].m02 = s; agents[idx].m20 = -s; agents[idx].m22 = c; }
+__global__ void set_agent_velocity_kernel(AgentState *agents, int idx, float hvx, float hvz,
+                                          float vvel) { agents[idx].hvx = hvx; agents[idx].hvz = hvz; agents[idx].vvel = vvel; }
 
 __global__ void debug_rng_kernel(uint32_t seed, int what, const int32_t *lo, const int32_t *hi, int n, void *out)
 {
@@ -117,8 +120,10 @@ int mv_debug_snapshot(mv_gym *g, int32_t env, void *out)
     if (e == hipSuccess && g->gv.chunk) e = hipMemcpy(s->chunk, g->gv.chunk + (size_t)env * CHUNK_BYTES, CHUNK_BYTES, hipMemcpyDeviceToHost);
     std::vector<TerrainBox> terr(MAX_TERRAIN);
     std::vector<MovableObject> rew(g->gv.reward_stride);
-    if (e == hipSuccess && g->gv.terrain) e = hipMemcpy(terr.data(), g->gv.terrain + (size_t)env * MAX_TERRAIN, MAX_TERRAIN * sizeof(TerrainBox), hipMemcpyDeviceToHost);
-    if (e == hipSuccess && g->gv.rewards_obj) e = hipMemcpy(rew.data(), g->gv.rewards_obj + (size_t)env * g->gv.reward_stride, g->gv.reward_stride * sizeof(MovableObject), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && g->gv.terrain) e = hipMemcpy(terr.data(), g->gv.terrain + (size_t)env * MAX_TERRAIN,
+        MAX_TERRAIN * sizeof(TerrainBox), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && g->gv.rewards_obj) e = hipMemcpy(rew.data(), g->gv.rewards_obj + (size_t)env * g->gv.reward_stride,
+        g->gv.reward_stride * sizeof(MovableObject), hipMemcpyDeviceToHost);
     if (e == hipSuccess && g->gv.items) {
         std::vector<ArrangementItem> its(MAX_ITEMS);
         e = hipMemcpy(its.data(), g->gv.items + (size_t)env * MAX_ITEMS, MAX_ITEMS * sizeof(ArrangementItem), hipMemcpyDeviceToHost);
@@ -128,7 +133,8 @@ int mv_debug_snapshot(mv_gym *g, int32_t env, void *out)
             s->items[i][2] = its[i].off[0]; s->items[i][3] = its[i].off[1]; s->items[i][4] = its[i].off[2];
         }
     }
-    if (e == hipSuccess && g->gv.soko_cells) e = hipMemcpy(s->soko, g->gv.soko_cells + (size_t)env * (SOKO_DIM * SOKO_DIM), SOKO_DIM * SOKO_DIM, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && g->gv.soko_cells) e = hipMemcpy(s->soko, g->gv.soko_cells + (size_t)env * (SOKO_DIM * SOKO_DIM),
+        SOKO_DIM * SOKO_DIM, hipMemcpyDeviceToHost);
     std::memset(s->heightmap, 0xff, sizeof s->heightmap);
     if (e == hipSuccess && g->gv.heightmap) e = hipMemcpy(s->heightmap, g->gv.heightmap + (size_t)env * HM_BYTES, sizeof s->heightmap, hipMemcpyDeviceToHost);
     if (e != hipSuccess) { delete s; return fail(std::string("mv_debug_snapshot: ") + hipGetErrorString(e)); }
@@ -136,8 +142,10 @@ int mv_debug_snapshot(mv_gym *g, int32_t env, void *out)
     if (e == hipSuccess && g->gv.hex_boxes) {   // Hex*: the header's box / collider / reward counts describe the hex lists
         s->hex_num_boxes = h.num_boxes; s->hex_num_objs = h.num_rewards;
         s->hex_target[0] = h.hex_target[0]; s->hex_target[1] = 0.0f; s->hex_target[2] = h.hex_target[1];
-        e = hipMemcpy(s->hex_boxes, g->gv.hex_boxes + (size_t)env * HEX_MAX_BOXES, (size_t)std::min(h.num_boxes, (int)HEX_MAX_BOXES) * sizeof(HexRec), hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(s->hex_objs, g->gv.hex_objs + (size_t)env * HEX_MAX_OBJS, (size_t)std::min(h.num_rewards, (int)HEX_MAX_OBJS) * sizeof(HexRec), hipMemcpyDeviceToHost);
+        e = hipMemcpy(s->hex_boxes, g->gv.hex_boxes + (size_t)env * HEX_MAX_BOXES,
+                      (size_t)std::min(h.num_boxes, (int)HEX_MAX_BOXES) * sizeof(HexRec), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(s->hex_objs, g->gv.hex_objs + (size_t)env * HEX_MAX_OBJS,
+            (size_t)std::min(h.num_rewards, (int)HEX_MAX_OBJS) * sizeof(HexRec), hipMemcpyDeviceToHost);
         if (e != hipSuccess) { delete s; return fail(std::string("mv_debug_snapshot: ") + hipGetErrorString(e)); }
         h.num_boxes = 0; h.num_rewards = 0; h.num_terrain = 0;
     }
@@ -192,7 +200,8 @@ int mv_debug_generate_episode(const char *scenario_name, int32_t num_agents, int
         return fail("mv_debug_generate_episode: the Obstacles family, Collect, Rearrange, HexMemory and HexExplore (Sokoban: mv_debug_generate_sokoban)");
     if (num_agents < 1 || num_agents > MAX_AGENTS || n < 1) return fail("mv_debug_generate_episode: bad arguments");
     const bool hex = scenario == SCN_HEX_MEMORY || scenario == SCN_HEX_EXPLORE;
-    const size_t bytes = scenario == SCN_COLLECT ? sizeof(CollectBlob) : scenario == SCN_REARRANGE ? sizeof(RearrangeBlob) : hex ? sizeof(HexBlob) : sizeof(EpisodeBlob);
+    const size_t bytes = scenario == SCN_COLLECT ? sizeof(CollectBlob) : scenario == SCN_REARRANGE
+                                                          ? sizeof(RearrangeBlob) : hex ? sizeof(HexBlob) : sizeof(EpisodeBlob);
     if (!out) return (int)bytes;
     if ((size_t)out_bytes < bytes) return fail("mv_debug_generate_episode: buffer too small");
     std::mt19937 rng;
@@ -219,7 +228,8 @@ int mv_debug_feeder_selftest(const char *scenario_name, int32_t num_envs, int32_
     if (!scenario_name || !scenario_from_name(lower(scenario_name), scenario, oc) || scenario == SCN_TOWER || scenario == SCN_SOKOBAN || scenario == SCN_EMPTY)
         return fail("mv_debug_feeder_selftest: the Obstacles family, Collect, Rearrange, HexMemory and HexExplore");
     const bool hex = scenario == SCN_HEX_MEMORY || scenario == SCN_HEX_EXPLORE;
-    const size_t bytes = scenario == SCN_COLLECT ? sizeof(CollectBlob) : scenario == SCN_REARRANGE ? sizeof(RearrangeBlob) : hex ? sizeof(HexBlob) : sizeof(EpisodeBlob);
+    const size_t bytes = scenario == SCN_COLLECT ? sizeof(CollectBlob) : scenario == SCN_REARRANGE
+                                                          ? sizeof(RearrangeBlob) : hex ? sizeof(HexBlob) : sizeof(EpisodeBlob);
     std::vector<uint8_t> slots((size_t)num_envs * bytes, 0), want(bytes);
     std::vector<uint32_t> seeds(num_envs);
     for (int i = 0; i < num_envs; ++i) seeds[i] = 1000u + 7u * (uint32_t)i;

@@ -102,7 +102,8 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
     static const bool ticksOff = getenv("MV_STEP_TICKS") && atoi(getenv("MV_STEP_TICKS")) == 0;
     const bool obstFamily = L->scenario == SCN_OBSTACLES || L->scenario == SCN_EMPTY;
     // (every scenario with one agent per env; several agents: TowerBuilding only -- two waves per env, launch_step_ticks)
-    const bool canMultiTick = !ticksOff && n == 1 && (L->A == 1 || L->scenario == SCN_TOWER) && k >= 2 && k <= MAX_STEP_TICKS && render && policy != POLICY_NONE && !L->gv.dbg;
+    const bool canMultiTick = !ticksOff && n == 1 && (L->A == 1 || L->scenario == SCN_TOWER) && k >= 2
+                                                      && k <= MAX_STEP_TICKS && render && policy != POLICY_NONE && !L->gv.dbg;
     // (the one-launch observation passes only beside the one-launch step: k separate step kernels starve beside a pass that long -- 70-190 us each, r04l)
     const bool canBatchRaster = canMultiTick && render && allFast && n == 1 && k >= 2 && L->ringObs && L->ringCount >= k;
     // timing (mv_profile_begin): a batched call that takes both one-launch paths is timed as a whole -- one entry, events around the step
@@ -118,7 +119,8 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
     // A group (n > 1), several rendered ticks with device-drawn actions, every member with an observation ring at least k deep and one agent per env: ONE
     // union step launch runs the k ticks of every env of every gym (step_union_ticks_kernel) and ONE launch draws their k x n observation passes
     // (raster_union_batch_kernel) -- two launches per call where the tick-by-tick path takes 2 k (BASELINE configs[4]: the scenarios of a multi-task batch).
-    bool groupBatch = n > 1 && !ticksOff && own && render && allFast && k >= 2 && k <= MAX_STEP_TICKS && policy != POLICY_NONE && !profiling && raster_union_batch_applicable(k, n, L->w, L->h);
+    bool groupBatch = n > 1 && !ticksOff && own && render && allFast && k >= 2 && k <= MAX_STEP_TICKS && policy != POLICY_NONE
+            && !profiling && raster_union_batch_applicable(k, n, L->w, L->h);
     for (int i = 0; i < n && groupBatch; ++i) groupBatch = gs[i]->A == 1 && gs[i]->ringObs && gs[i]->ringCount >= k && !gs[i]->gv.dbg;
     {   // ... and all of the group's envs resident at once: the union step launch keeps a workgroup per env alive for the whole call (four waves of 168 VGPRs for the long-list
         // gyms); beyond one round of the chip the tick-by-tick launches win (Mixed 64 x 64, batched / tick by tick: 512 envs 12.2 / 8.6 M obs/s, 1024: 17.6 /
@@ -255,7 +257,8 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
     // The ring is two CALLS deep, in the caller's ticks per call (a call of 16 ticks runs as two chunks of 8: the second-next chunk's passes would overwrite
     // what the consumer of the previous CALL -- enqueued after both of its chunks -- may still be reading), and rewards / dones have rings of
     // their own (two passes in flight would both publish the single arrays, in either order).
-    const bool overlap = batchRaster && own && !callEv && L->passOverlap && L->passStream[0] && L->ringCount >= 2 * std::max(k, kCall) && L->ringRewards && L->ringDone &&
+    const bool overlap = batchRaster && own && !callEv && L->passOverlap && L->passStream[0]
+            && L->ringCount >= 2 * std::max(k, kCall) && L->ringRewards && L->ringDone &&
                          k <= MAX_STEP_TICKS && L->baseEpisodeLen * 15.0f > float(2 * k + 2);
     hipStream_t passOn = L->stream;
     if (overlap) {
@@ -285,11 +288,13 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
             chunkPubs.push_back(pubs[0]);
             chunkObs.push_back(obsPtrs[0]);
             // (0: off, launch_raster_batch declines)
-            static const int chunkMax = getenv("MV_RASTER_BATCH") ? std::min((int)MAX_STEP_TICKS, std::max(1, atoi(getenv("MV_RASTER_BATCH")))) : (int)MAX_STEP_TICKS;
+            static const int chunkMax = getenv("MV_RASTER_BATCH") ? std::min((int)MAX_STEP_TICKS, std::max(1, atoi(getenv("MV_RASTER_BATCH"))))
+                                               : (int)MAX_STEP_TICKS;
             if (j == k - 1 || (int)chunkObs.size() >= chunkMax) {
                 const int cn = (int)chunkObs.size();
                 if (callEv) { HIP_TRY(hipEventRecord(callEv[2], L->stream)); HIP_TRY(hipEventRecord(callEv[3], L->stream)); }
-                int r = cn >= 2 ? launch_raster_batch(&views[(size_t)chunkFirst], chunkObs.data(), pubInRaster ? chunkPubs.data() : nullptr, cn, L->w, L->h, overlap && cn == k ? passOn : L->stream, mark) : 1;
+                int r = cn >= 2 ? launch_raster_batch(&views[(size_t)chunkFirst], chunkObs.data(), pubInRaster ? chunkPubs.data()
+                                                      : nullptr, cn, L->w, L->h, overlap && cn == k ? passOn : L->stream, mark) : 1;
                 if (r == 0 && overlap && cn == k) HIP_TRY(hipStreamWaitEvent(L->stream, mark, 0));   // the caller's stream sees the call's outputs as always
                 if (r < 0) return fail("mv_step: observation size above 1024x1024");
                 if (r == 0)   // (every pass of the one-launch kernel leaves its cost histogram zero)
@@ -297,7 +302,8 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
                 if (r == 1)   // (not applicable to this gym -- long lists -- or a chunk of one tick: tick by tick)
                     for (int q = 0; q < cn; ++q)
                     {
-                        if (launch_raster(views[(size_t)chunkFirst + q], chunkObs[q], L->w, L->h, L->stream, nullptr, 1, /*setup_done=*/1, pubInRaster ? &chunkPubs[q] : nullptr,
+                        if (launch_raster(views[(size_t)chunkFirst + q], chunkObs[q], L->w, L->h, L->stream,
+                            nullptr, 1, /*setup_done=*/1, pubInRaster ? &chunkPubs[q] : nullptr,
                                           q == cn - 1 ? mark : nullptr))
                             return fail("mv_step: observation size above 1024x1024");
                         // (self_clear, mv_raster.hip)
@@ -316,14 +322,16 @@ static int step_gyms(mv_gym *const *gs, int n, bool render, int k, int policy, u
                     allObs[q] = outs[q].obs;
                 }
                 const int r = launch_raster_union_batch(views.data(), allObs.data(), allPubs.data(), k, n, L->w, L->h, L->stream, mark);
-                if (r != 0) return fail(r == -2 ? "mv_group_step: the hand-over slots of a batched call are not one slot apart (internal)" : "mv_group_step: observation size above 1024x1024");
+                if (r != 0) return fail(r == -2 ? "mv_group_step: the hand-over slots of a batched call are not one slot apart (internal)"
+                    : "mv_group_step: observation size above 1024x1024");
                 // (every pass leaves its cost histogram zero)
                 for (size_t q = 0; q < (size_t)n * k; ++q) gs[q % (size_t)n]->histClean[(size_t)views[q].lpt_parity] = 1;
             }
         } else if (render) {
             const bool pubInRaster = own && allFast;
             if (n > 1 && allFast) {
-                if (launch_raster_union(&views[(size_t)j * n], obsPtrs.data(), pubInRaster ? pubs.data() : nullptr, n, L->w, L->h, L->stream, evs[j] ? evs[j][3] : nullptr, mark))
+                if (launch_raster_union(&views[(size_t)j * n], obsPtrs.data(), pubInRaster ? pubs.data() : nullptr,
+                    n, L->w, L->h, L->stream, evs[j] ? evs[j][3] : nullptr, mark))
                     return fail("mv_step: observation size above 1024x1024");
             } else {
                 for (int i = 0; i < n; ++i) {
@@ -478,7 +486,8 @@ int mv_group_step(mv_group *grp, int32_t k, int32_t render, int32_t policy, uint
     int rc = 0;
     std::string text;
     for (int done = 0; done < k; done += chunk) {
-        const int r = step_gyms(grp->gyms.data(), (int)grp->gyms.size(), render != 0, std::min(chunk, k - done), policy, seed, first_step_index + (uint32_t)done, k);
+        const int r = step_gyms(grp->gyms.data(), (int)grp->gyms.size(), render != 0, std::min(chunk, k - done),
+                                policy, seed, first_step_index + (uint32_t)done, k);
         if (r < 0) return -1;
         if (r > 0) { text += (text.empty() ? "" : " | ") + g_err; rc = 1; }
     }

@@ -320,7 +320,8 @@ __device__ __forceinline__ void frame_setup_body(const GymView &gv, const int fr
                     } else {                // the target arrangement on the left pedestal
                         const ArrangementItem it = gv.items[(size_t)env * MAX_ITEMS + (j - NUM_STATIC)];
                         const V3 sc = item_draw_scale(it.shape);
-                        const float cx = float(it.off[0] + RE_LEFT_X) + 0.5f, cy = float(it.off[1] + RE_LEFT_Y) + 0.5f, cz = float(it.off[2] + RE_LEFT_Z) + 0.5f;
+                        const float cx = float(it.off[0] + RE_LEFT_X) + 0.5f, cy = float(it.off[1] + RE_LEFT_Y)
+                                               + 0.5f, cz = float(it.off[2] + RE_LEFT_Z) + 0.5f;
                         color = (unsigned)it.color;
                         if (it.shape == SHAPE_BOX) {
                             kind = PRIM_BOX;

@@ -208,7 +208,8 @@ void generate_collect_episode(std::mt19937 &rng, int num_agents, float base_epis
         if (good) ++out.num_positive;
         if (int(i) >= COLLECT_MAX_REWARDS) generator_overflow_raise(GEN_REWARDS);
         if (int(i) < COLLECT_MAX_REWARDS)
-            out.rewards[out.num_rewards++] = MovableObject{int8_t(reward_cells[i].x), int8_t(reward_cells[i].y), int8_t(reward_cells[i].z), int8_t(good ? 1 : 2)};
+            out.rewards[out.num_rewards++] = MovableObject{int8_t(reward_cells[i].x), int8_t(reward_cells[i].y),
+                                                                  int8_t(reward_cells[i].z), int8_t(good ? 1 : 2)};
     }
 }
 

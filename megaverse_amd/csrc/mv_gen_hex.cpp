@@ -75,10 +75,14 @@ private:
         static const int STEP[6][2] = {{-1, 0}, {-1, 1}, {0, 1}, {1, 0}, {1, -1}, {0, -1}};
         // corner offsets: cos / sin of (n - 2.5) pi / 3 and of (n - 1.5) pi / 3 as the reference's build evaluates them, as literals (a
         // compiler may use sincos() where another calls cos(): one ulp of a double in a cancelling sum)
-        static const double FROM_X[6] = {-0x1.bb67ae8584cabp-1, 0x1.1a62633145c07p-54, 0x1.bb67ae8584cabp-1, 0x1.bb67ae8584cabp-1, 0x1.1a62633145c07p-54, -0x1.bb67ae8584cabp-1};
-        static const double FROM_Y[6] = {-0x1.fffffffffffffp-2, -0x1.0000000000000p+0, -0x1.fffffffffffffp-2, 0x1.fffffffffffffp-2, 0x1.0000000000000p+0, 0x1.fffffffffffffp-2};
-        static const double TO_X[6] = {-0x1.72cece675d1fcp-53, 0x1.bb67ae8584caap-1, 0x1.bb67ae8584cabp-1, 0x1.1a62633145c07p-54, -0x1.bb67ae8584ca9p-1, -0x1.bb67ae8584caap-1};
-        static const double TO_Y[6] = {-0x1.0000000000000p+0, -0x1.0000000000000p-1, 0x1.fffffffffffffp-2, 0x1.0000000000000p+0, 0x1.0000000000003p-1, -0x1.0000000000001p-1};
+        static const double FROM_X[6] = {-0x1.bb67ae8584cabp-1, 0x1.1a62633145c07p-54, 0x1.bb67ae8584cabp-1,
+                0x1.bb67ae8584cabp-1, 0x1.1a62633145c07p-54, -0x1.bb67ae8584cabp-1};
+        static const double FROM_Y[6] = {-0x1.fffffffffffffp-2, -0x1.0000000000000p+0, -0x1.fffffffffffffp-2,
+                0x1.fffffffffffffp-2, 0x1.0000000000000p+0, 0x1.fffffffffffffp-2};
+        static const double TO_X[6] = {-0x1.72cece675d1fcp-53, 0x1.bb67ae8584caap-1, 0x1.bb67ae8584cabp-1,
+                0x1.1a62633145c07p-54, -0x1.bb67ae8584ca9p-1, -0x1.bb67ae8584caap-1};
+        static const double TO_Y[6] = {-0x1.0000000000000p+0, -0x1.0000000000000p-1, 0x1.fffffffffffffp-2,
+                0x1.0000000000000p+0, 0x1.0000000000003p-1, -0x1.0000000000001p-1};
         for (int u = -size_ + 1; u < size_; ++u)
             for (int v = first_v(u); v <= last_v(u); ++v) {
                 const int cell = index(u, v);
@@ -275,7 +279,8 @@ void generate_hex_explore_episode(std::mt19937 &rng, int num_agents, float base_
     std::vector<HexRec> boxes, objs;
     build_maze_boxes(rng, maze, look, boxes);
     const float sc = 1.9f;   // the reward object: a VIOLET diamond above the goal cell
-    objs.push_back(object_record(HEX_DIAMOND, 0xd468ee, P3{target.x + 0.0f, target.y + 1.2f, target.z + 0.0f}, P3{0.17f * sc, 0.35f * sc, 0.17f * sc}, true, true, target));
+    objs.push_back(object_record(HEX_DIAMOND, 0xd468ee, P3{target.x + 0.0f, target.y + 1.2f, target.z + 0.0f},
+                   P3{0.17f * sc, 0.35f * sc, 0.17f * sc}, true, true, target));
 
     store(out, boxes, objs, spawn, yaw);
     out.num_good = 0;
@@ -337,7 +342,8 @@ void generate_hex_memory_episode(std::mt19937 &rng, int num_agents, float base_e
     auto shift_of = [](int shape) { return shape == HEX_SPHERE ? P3{0.5f, 0.1f, 0.5f} : shape == HEX_PILLAR ? P3{0.5f, 0.05f, 0.5f} : P3{0.5f, 0.6f, 0.5f}; };
     {   // the object in the middle cell shows what to collect; it cannot be collected itself
         const P3 sh = shift_of(good_shape);
-        objs.push_back(object_record(good_shape, good_color, P3{landmark.x + sh.x, landmark.y + sh.y, landmark.z + sh.z}, scale_of(good_shape), true, false, landmark));
+        objs.push_back(object_record(good_shape, good_color, P3{landmark.x + sh.x, landmark.y + sh.y, landmark.z + sh.z},
+                       scale_of(good_shape), true, false, landmark));
     }
     const float shrink = 0.6f;
     for (long i = 0; i < good_count + bad_count; ++i) {

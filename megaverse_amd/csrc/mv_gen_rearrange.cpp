@@ -140,7 +140,8 @@ void generate_rearrange_episode(std::mt19937 &rng, int num_agents, float base_ep
     for (int i = 0; i < out.num_items; ++i) {
         const Offset at{out.objects[i].x - kRight[0], out.objects[i].y - kRight[1], out.objects[i].z - kRight[2]};
         for (int k = 0; k < out.num_items; ++k)
-            if (items[k].shape == items[i].shape && items[k].color == items[i].color && items[k].off[0] == at.x && items[k].off[1] == at.y && items[k].off[2] == at.z) {
+            if (items[k].shape == items[i].shape && items[k].color == items[i].color && items[k].off[0] == at.x
+                && items[k].off[1] == at.y && items[k].off[2] == at.z) {
                 ++out.max_matching;
                 break;
             }

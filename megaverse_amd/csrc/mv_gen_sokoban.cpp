@@ -131,7 +131,8 @@ bool generate_sokoban_episode(std::mt19937 &rng, SokobanLevels &levels, const st
                 if (out.cells[x * SOKO_DIM + z] == SOKO_WALL && rows[size_t(x)][size_t(z)] == '#') type[id(x, 1, z)] = type[id(x, 2, z)] = VX_SOLID;
             }
         for (const int want : {int(VX_SOLID), int(VX_SOLID | VX_OPAQUE)}) {
-            auto open_cell = [&](int x, int y, int z) { return x >= 0 && x < nx && y >= 0 && y < ny && z >= 0 && z < wz && type[id(x, y, z)] == want && !used[id(x, y, z)]; };
+            auto open_cell = [&](int x, int y, int z) { return x >= 0 && x < nx && y >= 0 && y < ny && z >= 0
+                                 && z < wz && type[id(x, y, z)] == want && !used[id(x, y, z)]; };
             for (int y = 0; y < ny; ++y)
                 for (int z = 0; z < wz; ++z)
                     for (int x = 0; x < nx; ++x) {

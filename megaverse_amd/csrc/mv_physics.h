@@ -264,7 +264,8 @@ __device__ __forceinline__ bool sweep(const Col (&col)[NC], V3 from, V3 to, V3 u
         unsigned longest = 0;
 #pragma unroll
         for (int k = 0; k < NC; ++k) longest = max(longest, ~wave_min_u32(~(unsigned)its[k]));
-        if (lane_id() == 0) { s_cast_dbg[0] += 1; s_cast_dbg[1] += serial; s_cast_dbg[2] += queued; s_cast_dbg[3] = max(s_cast_dbg[3], longest); s_cast_dbg[4] += started; }
+        if (lane_id() == 0) { s_cast_dbg[0] += 1; s_cast_dbg[1] += serial; s_cast_dbg[2] += queued; s_cast_dbg[3] = max(s_cast_dbg[3],
+            longest); s_cast_dbg[4] += started; }
     }
 #endif
     // the closest hit of the wave; ties resolve towards the lowest slot (slot = lane + 64 k: the serial order of the reference's callback):

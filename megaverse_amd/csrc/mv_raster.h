@@ -20,17 +20,20 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
 
 // the fast observation pass of n gyms of one job (frame lists already built by their step kernels) with at most two launches; publish: n
 // entries or null; -1 if W / H / n are too large
-int launch_raster_union(const GymView *views, uint32_t *const *obs, const PublishTo *publish, int n, int W, int H, hipStream_t stream, hipEvent_t between = nullptr,
+int launch_raster_union(const GymView *views, uint32_t *const *obs, const PublishTo *publish, int n,
+                        int W, int H, hipStream_t stream, hipEvent_t between = nullptr,
                         hipEvent_t done = nullptr);
 
 // the fast observation passes of k ticks of ONE gym (a batched call; views[j] / obs[j] / publish[j] of tick j, the observation slabs distinct) with one
 // launch: the next tick's expensive frames run in the tail of the previous tick's pass; 0: launched, 1: not applicable (the caller launches tick by tick)
-int launch_raster_batch(const GymView *views, uint32_t *const *obs, const PublishTo *publish, int k, int W, int H, hipStream_t stream, hipEvent_t done = nullptr);
+int launch_raster_batch(const GymView *views, uint32_t *const *obs, const PublishTo *publish, int k,
+                        int W, int H, hipStream_t stream, hipEvent_t done = nullptr);
 
 // the fast observation passes of k ticks of n gyms of one job (a batched group call; views / obs / publish tick-major: [j * n + i]) with ONE launch.
 // raster_union_batch_applicable: decided before the step launch (its frame setups leave the clearing of the cost histograms to the passes);
 // launch_raster_union_batch: 0 launched, 1 not applicable, -1 / -2 bad sizes / views that are not one hand-over slot apart per tick
 bool raster_union_batch_applicable(int k, int n, int W, int H);
-int launch_raster_union_batch(const GymView *views, uint32_t *const *obs, const PublishTo *publish, int k, int n, int W, int H, hipStream_t stream, hipEvent_t done = nullptr);
+int launch_raster_union_batch(const GymView *views, uint32_t *const *obs, const PublishTo *publish, int k,
+                              int n, int W, int H, hipStream_t stream, hipEvent_t done = nullptr);
 
 }  // namespace mv

@@ -287,7 +287,8 @@ __global__ __launch_bounds__(1024) void frame_order_kernel(GymView gv, int frame
 }
 
 template <int MAXVIS, bool SHAPES>   // SHAPES: the frame may hold scaled spheres / capsules / cylinders (Rearrange)
-__global__ __launch_bounds__(256, MAXVIS <= 256 && !SHAPES ? MV_RASTER_WAVES : MAXVIS <= 256 ? 5 : MAXVIS <= 1024 ? 2 : 1) void raster_kernel(GymView gv, uint32_t *obs, int W, int H, int split, const int *order)
+__global__ __launch_bounds__(256, MAXVIS <= 256 && !SHAPES ? MV_RASTER_WAVES : MAXVIS <= 256 ? 5 : MAXVIS <= 1024 ? 2
+                             : 1) void raster_kernel(GymView gv, uint32_t *obs, int W, int H, int split, const int *order)
 {
     constexpr int ROUNDS = MAXVIS / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // column/row ray tables
@@ -706,7 +707,8 @@ __device__ __forceinline__ bool other_box(const float4 lo, const float4 hi, int 
 }
 
 template <bool SHAPES>
-__device__ __forceinline__ bool other_rec(const float4 lo, const float4 hi, const float *s_hdr, const float *camv, int viewer, V3 dw, float dcx, float dcy, float &t, V3 &n)
+__device__ __forceinline__ bool other_rec(const float4 lo, const float4 hi, const float *s_hdr, const float *camv,
+                                          int viewer, V3 dw, float dcx, float dcy, float &t, V3 &n)
 {
     const unsigned meta = __builtin_amdgcn_readfirstlane(__float_as_uint(lo.w));
     const int qkind = meta & 15, qfr = (meta >> 4) & 15;
@@ -728,7 +730,8 @@ __device__ __forceinline__ bool other_rec(const float4 lo, const float4 hi, cons
 }
 
 template <bool SHAPES, unsigned POS_MASK>
-__device__ __forceinline__ unsigned fast_other(int pos, const float4 *s_vis, const float *s_hdr, const float *camv, int viewer, V3 dw, float dcx, float dcy, V3 &n)
+__device__ __forceinline__ unsigned fast_other(int pos, const float4 *s_vis, const float *s_hdr,
+                                               const float *camv, int viewer, V3 dw, float dcx, float dcy, V3 &n)
 {
     float t;
     const bool hit = other_rec<SHAPES>(s_vis[2 * pos], s_vis[2 * pos + 1], s_hdr, camv, viewer, dw, dcx, dcy, t, n);
@@ -768,7 +771,8 @@ __device__ __forceinline__ unsigned phong_tail(float t, float ndl, float nv, flo
 // Phong (Magnum Shaders::Phong, uniforms of magnum_env_renderer.cpp:200-203) for the winning hit of a pixel; 0xff000000 when there is none
 // the winning primitive's record (lo, hi) and -- for the curved kinds -- the depth and normal kept with the hit -> the pixel's colour
 template <bool SHAPES>
-__device__ __forceinline__ unsigned shade_rec(const float4 lo, const float4 hi, float tkey, V3 bn, const float *s_hdr, const float *camv, int viewer, V3 dw, V3 inv, float dcx, float dcy, float a2, float ldc)
+__device__ __forceinline__ unsigned shade_rec(const float4 lo, const float4 hi, float tkey, V3 bn, const float *s_hdr, const float *camv,
+                                              int viewer, V3 dw, V3 inv, float dcx, float dcy, float a2, float ldc)
 {
     unsigned rgba;
     {
@@ -807,12 +811,14 @@ __device__ __forceinline__ unsigned shade_rec(const float4 lo, const float4 hi, 
 }
 
 template <bool SHAPES, unsigned POS_MASK>
-__device__ __forceinline__ unsigned fast_shade(unsigned best, V3 bn, const float4 *s_vis, const float *s_hdr, const float *camv, int viewer, V3 dw, V3 inv, float dcx, float dcy, float a2, float ldc)
+__device__ __forceinline__ unsigned fast_shade(unsigned best, V3 bn, const float4 *s_vis, const float *s_hdr, const float *camv,
+                                               int viewer, V3 dw, V3 inv, float dcx, float dcy, float a2, float ldc)
 {
     unsigned rgba = 0xff000000u;
     if (best <= (KEY_FAR | POS_MASK)) {   // a hit between the near and the far plane
         const int pos = (int)(best & POS_MASK);
-        rgba = shade_rec<SHAPES>(s_vis[2 * pos], s_vis[2 * pos + 1], __uint_as_float((best & ~POS_MASK) + KEY_NEAR), bn, s_hdr, camv, viewer, dw, inv, dcx, dcy, a2, ldc);
+        rgba = shade_rec<SHAPES>(s_vis[2 * pos], s_vis[2 * pos + 1], __uint_as_float((best & ~POS_MASK) + KEY_NEAR),
+                                 bn, s_hdr, camv, viewer, dw, inv, dcx, dcy, a2, ldc);
     }
     return rgba;
 }
@@ -829,7 +835,8 @@ __host__ __device__ inline int tail_frames(int frames, int div) { return (frames
 // GLIST: the records stay in global memory (the tile loop fetches the surviving ones with scalar loads); LDS gets the rectangles and one class
 // byte per primitive instead: 0 a box in the world frame, 1..3 a box in hex wall frame 0..2, 4 anything else
 template <int MAXVIS, bool GLIST = false, int NT = 256>   // NT: threads of the workgroup (256, or 512: a whole frame per workgroup, raster_fast_body)
-__device__ __forceinline__ FastFrame fast_prologue(const FastArgs &fa, int blk, int W, int H, int split, float4 *s_vis, short4 *s_rect, float *s_hdr, float4 *s_col,
+__device__ __forceinline__ FastFrame fast_prologue(const FastArgs &fa, int blk, int W, int H, int split,
+                                                   float4 *s_vis, short4 *s_rect, float *s_hdr, float4 *s_col,
                                                    float4 *s_row, float2 *s_rowq, float *s_colq, unsigned char *s_cls = nullptr)
 {
     const int A = fa.num_agents;
@@ -934,7 +941,8 @@ __device__ __forceinline__ FastFrame fast_prologue(const FastArgs &fa, int blk, 
 template <unsigned POS_MASK, int SGN>
 __device__ __forceinline__ unsigned box_key_signed(V3 inv, const float4 lo, const float4 hi, int pos, unsigned depthMask)
 {
-    const float nx = (SGN & 1) ? hi.x : lo.x, fx = (SGN & 1) ? lo.x : hi.x, ny = (SGN & 2) ? hi.y : lo.y, fy = (SGN & 2) ? lo.y : hi.y, nz = (SGN & 4) ? hi.z : lo.z, fz = (SGN & 4) ? lo.z : hi.z;
+    const float nx = (SGN & 1) ? hi.x : lo.x, fx = (SGN & 1) ? lo.x : hi.x, ny = (SGN & 2) ? hi.y : lo.y, fy = (SGN & 2)
+                      ? lo.y : hi.y, nz = (SGN & 4) ? hi.z : lo.z, fz = (SGN & 4) ? lo.z : hi.z;
     const float tn = __builtin_fmaxf(__builtin_fmaxf(nx * inv.x, ny * inv.y), nz * inv.z);
     const float tf = __builtin_fminf(__builtin_fminf(fx * inv.x, fy * inv.y), fz * inv.z);
     const unsigned key = ((__float_as_uint(tn) - KEY_NEAR) & depthMask) | (unsigned)pos;
@@ -957,12 +965,14 @@ __device__ __forceinline__ void box_run(unsigned long long m, int k, const V3 (&
         bool more = m != 0ull;
         if (more) { p1 = __ffsll((long long)m) - 1 + 64 * k; m &= m - 1; lo1 = s_vis[2 * p1]; hi1 = s_vis[2 * p1 + 1]; }
 #pragma unroll
-        for (int j = 0; j < NP; ++j) best[j] = min(best[j], SGN >= 0 ? box_key_signed<POS_MASK, (SGN >= 0 ? SGN : 0)>(inv[j], lo0, hi0, p0, depthMask) : box_key<POS_MASK>(inv[j], lo0, hi0, p0, depthMask));
+        for (int j = 0; j < NP; ++j) best[j] = min(best[j], SGN >= 0 ? box_key_signed<POS_MASK, (SGN >= 0 ? SGN : 0)>(inv[j], lo0, hi0, p0, depthMask)
+             : box_key<POS_MASK>(inv[j], lo0, hi0, p0, depthMask));
         if (!more) break;
         more = m != 0ull;
         if (more) { p0 = __ffsll((long long)m) - 1 + 64 * k; m &= m - 1; lo0 = s_vis[2 * p0]; hi0 = s_vis[2 * p0 + 1]; }
 #pragma unroll
-        for (int j = 0; j < NP; ++j) best[j] = min(best[j], SGN >= 0 ? box_key_signed<POS_MASK, (SGN >= 0 ? SGN : 0)>(inv[j], lo1, hi1, p1, depthMask) : box_key<POS_MASK>(inv[j], lo1, hi1, p1, depthMask));
+        for (int j = 0; j < NP; ++j) best[j] = min(best[j], SGN >= 0 ? box_key_signed<POS_MASK, (SGN >= 0 ? SGN : 0)>(inv[j], lo1, hi1, p1, depthMask)
+             : box_key<POS_MASK>(inv[j], lo1, hi1, p1, depthMask));
         if (!more) break;
     }
 }
@@ -1008,8 +1018,10 @@ constexpr int CLS_MAX_TILES = 128;   // tiles of one workgroup that can be class
 // list, and clears the empty ones -- 43 % of a TowerBuilding frame's tiles (r07d census) -- with all its threads at once instead of handing them out one by
 // one.
 template <int TH, int NT>
-__device__ __forceinline__ void classify_tiles(uint4 *s_tile, float4 *s_line, const float4 *s_vis, const short4 *s_rect, const float *s_hdr, const float *camv, int nVis, unsigned long long wb0,
-                                               int W, int H, int part, int split, int tilesX, int numTiles, int perWG, bool overlayOn, int *s_cnt, unsigned *s_txy, bool bulkClear)
+__device__ __forceinline__ void classify_tiles(uint4 *s_tile, float4 *s_line, const float4 *s_vis, const short4 *s_rect,
+                                               const float *s_hdr, const float *camv, int nVis, unsigned long long wb0,
+                                               int W, int H, int part, int split, int tilesX, int numTiles,
+                                                       int perWG, bool overlayOn, int *s_cnt, unsigned *s_txy, bool bulkClear)
 {
     constexpr int NW = NT / 64;        // waves of the workgroup
     constexpr int PPR = 16 / NW;       // list positions per wave and round (256 edge-function slots in all: 4 with four waves, 2 with eight)
@@ -1080,7 +1092,8 @@ __device__ __forceinline__ void classify_tiles(uint4 *s_tile, float4 *s_line, co
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
                 if (64 * c >= perWG) break;
-                const bool ov = tvalid[c] & ((int)(rr.x & 0xffffu) <= tX1[c]) & ((int)(rr.x >> 16) >= tX0[c]) & ((int)(rr.y & 0xffffu) <= tY1[c]) & ((int)(rr.y >> 16) >= tY0[c]);
+                const bool ov = tvalid[c] & ((int)(rr.x & 0xffffu) <= tX1[c]) & ((int)(rr.x >> 16) >= tX0[c])
+                                             & ((int)(rr.y & 0xffffu) <= tY1[c]) & ((int)(rr.y >> 16) >= tY0[c]);
                 if (!__any(ov)) continue;
                 bool hit = ov;
                 unsigned cov = 0u;
@@ -1160,7 +1173,8 @@ __device__ __forceinline__ void classify_tiles(uint4 *s_tile, float4 *s_line, co
                         const float m0 = k == 0 ? 2.0f * plane - L0 : L0, m1 = k == 1 ? 2.0f * plane - L1 : L1, m2 = k == 2 ? 2.0f * plane - L2 : L2;   // L'
                         const float xc = float(tX0[c]) + 0.5f * WX, yc = float(tY0[c]) + 0.5f * WY;
                         const float dcx = sx * xc + ox, dcy = sy * yc + oy;
-                        const float d0 = (camv[3] * dcx + camv[4] * dcy) - camv[5], d1 = (camv[6] * dcx + camv[7] * dcy) - camv[8], d2 = (camv[9] * dcx + camv[10] * dcy) - camv[11];
+                        const float d0 = (camv[3] * dcx + camv[4] * dcy) - camv[5], d1 = (camv[6] * dcx + camv[7] * dcy) - camv[8],
+                                          d2 = (camv[9] * dcx + camv[10] * dcy) - camv[11];
                         const float dot = (d0 * m0 + d1 * m1) + d2 * m2;
                         const float dd = (d0 * d0 + d1 * d1) + d2 * d2, mm = (m0 * m0 + m1 * m1) + m2 * m2;
                         maybe = dot > 0.0f && dot * dot >= cosT2 * (dd * mm);
@@ -1179,7 +1193,8 @@ __device__ __forceinline__ void classify_tiles(uint4 *s_tile, float4 *s_line, co
                     const float Aa = camv[3 + 3 * a] * sx, Ba = camv[4 + 3 * a] * sy, Ca = (camv[3 + 3 * a] * ox + camv[4 + 3 * a] * oy) - camv[5 + 3 * a];
                     const float v00 = __builtin_fmaf(Aa, xa, __builtin_fmaf(Ba, ya, Ca)), v10 = __builtin_fmaf(Aa, xb, __builtin_fmaf(Ba, ya, Ca));
                     const float v01 = __builtin_fmaf(Aa, xa, __builtin_fmaf(Ba, yb, Ca)), v11 = __builtin_fmaf(Aa, xb, __builtin_fmaf(Ba, yb, Ca));
-                    const float lo4 = __builtin_fminf(__builtin_fminf(v00, v10), __builtin_fminf(v01, v11)), hi4 = __builtin_fmaxf(__builtin_fmaxf(v00, v10), __builtin_fmaxf(v01, v11));
+                    const float lo4 = __builtin_fminf(__builtin_fminf(v00, v10), __builtin_fminf(v01, v11)),
+                                                      hi4 = __builtin_fmaxf(__builtin_fmaxf(v00, v10), __builtin_fmaxf(v01, v11));
                     if (hi4 < -1e-4f) sg |= 1u << a;
                     else if (!(lo4 > 1e-4f)) sg = 0u;
                     if (sg == 0u) break;
@@ -1187,9 +1202,11 @@ __device__ __forceinline__ void classify_tiles(uint4 *s_tile, float4 *s_line, co
                 info |= sg << 11;
             }
             s_tile[u].w = info;
-            const unsigned tclass = info & 7u, cat = tclass == TC_GENERAL ? 0u : tclass == TC_OVERLAY ? 1u : tclass == TC_PLANAR_SPEC ? 2u : tclass == TC_PLANAR ? 3u : 4u;
+            const unsigned tclass = info & 7u, cat = tclass == TC_GENERAL ? 0u : tclass == TC_OVERLAY ? 1u
+                    : tclass == TC_PLANAR_SPEC ? 2u : tclass == TC_PLANAR ? 3u : 4u;
             // RUNS: neighbours in a tile row that one face of one box covers alike (the same class word), or that are empty, are ONE entry of the drawing order
-            // -- at most eight tiles (a tile row of a 128-pixel frame): the run's uniform set-up (the face's plane, colour, light term), its rows' ray terms and its hand-out are paid once.  The
+            // -- at most eight tiles (a tile row of a 128-pixel frame): the run's uniform set-up (the face's plane, colour, light term), its rows' ray terms
+            // and its hand-out are paid once.  The
             // valid tiles of a chunk are its first lanes (every lane here is one); a run's tiles are neighbours in one tile row.
             const bool runs = tclass == TC_PLANAR || tclass == TC_PLANAR_SPEC || (tclass == TC_EMPTY && !bulkClear);
             // (the previous lane's tile is the left neighbour only where the workgroup owns whole tile rows: a frame cut into `split` pieces deals its tiles
@@ -1220,7 +1237,8 @@ __device__ __forceinline__ void planar_run(int pos, int k, int n, const float4 *
                                            const float2 *s_rowq, const float *s_colq, float nzk, int tx0, int ty0, int lane, const PixOut &po)
 {
     const int W = po.W, H = po.H;
-    const float lok = uniform_f32(reinterpret_cast<const float *>(s_vis)[8 * pos + k]), hik = uniform_f32(reinterpret_cast<const float *>(s_vis)[8 * pos + 4 + k]);
+    const float lok = uniform_f32(reinterpret_cast<const float *>(s_vis)[8 * pos + k]),
+                                  hik = uniform_f32(reinterpret_cast<const float *>(s_vis)[8 * pos + 4 + k]);
     const float plane = lok > 0.0f ? lok : hik;   // the face towards the eye
     const unsigned color = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_uint(reinterpret_cast<const float *>(s_vis)[8 * pos + 7]));
     const float cr = float((color >> 16) & 255u), cg = float((color >> 8) & 255u), cb = float(color & 255u);
@@ -1259,7 +1277,8 @@ __device__ __forceinline__ void planar_tile(int pos, int k, const float4 *s_vis,
                                             const float2 *s_rowq, const float *s_colq, float nzk, int px, int py0, const PixOut &po)
 {
     const int W = po.W, H = po.H;
-    const float lok = uniform_f32(reinterpret_cast<const float *>(s_vis)[8 * pos + k]), hik = uniform_f32(reinterpret_cast<const float *>(s_vis)[8 * pos + 4 + k]);
+    const float lok = uniform_f32(reinterpret_cast<const float *>(s_vis)[8 * pos + k]),
+                                  hik = uniform_f32(reinterpret_cast<const float *>(s_vis)[8 * pos + 4 + k]);
     const float plane = lok > 0.0f ? lok : hik;   // the face towards the eye
     const unsigned color = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_uint(reinterpret_cast<const float *>(s_vis)[8 * pos + 7]));
     const float cr = float((color >> 16) & 255u), cg = float((color >> 8) & 255u), cb = float(color & 255u);
@@ -1313,11 +1332,14 @@ __device__ __forceinline__ void clear_tile(const PixOut &po, int tx0, int ty0, i
 // boxes are intersected by the very function the general path uses (other_box), the nearest wins by the same key comparison, and the pixel is shaded by
 // phong_tail with the face's constants or, where another box won, by the general path's fast_shade: the same bytes (test_planar_tiles_change_no_byte).
 template <bool SHAPES, unsigned POS_MASK, int NP>
-__device__ __forceinline__ void overlay_tile(int posA, int k, unsigned long long rest, const float4 *s_vis, const float *s_hdr, const float *camv, int viewer, const float4 *s_col,
-                                             const float4 *s_row, const float2 *s_rowq, const float *s_colq, float nzm0, float nzm1, float nzm2, int px, int py0, const PixOut &po)
+__device__ __forceinline__ void overlay_tile(int posA, int k, unsigned long long rest, const float4 *s_vis,
+                                             const float *s_hdr, const float *camv, int viewer, const float4 *s_col,
+                                             const float4 *s_row, const float2 *s_rowq, const float *s_colq,
+                                                     float nzm0, float nzm1, float nzm2, int px, int py0, const PixOut &po)
 {
     const int W = po.W, H = po.H;
-    const float lok = uniform_f32(reinterpret_cast<const float *>(s_vis)[8 * posA + k]), hik = uniform_f32(reinterpret_cast<const float *>(s_vis)[8 * posA + 4 + k]);
+    const float lok = uniform_f32(reinterpret_cast<const float *>(s_vis)[8 * posA + k]),
+                                  hik = uniform_f32(reinterpret_cast<const float *>(s_vis)[8 * posA + 4 + k]);
     const float plane = lok > 0.0f ? lok : hik;
     const unsigned color = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_uint(reinterpret_cast<const float *>(s_vis)[8 * posA + 7]));
     const float cr = float((color >> 16) & 255u), cg = float((color >> 8) & 255u), cb = float(color & 255u);
@@ -1361,8 +1383,10 @@ __device__ __forceinline__ void overlay_tile(int posA, int k, unsigned long long
 // out of the classification, so the rays are set up at once and there is no loop over rounds (the same arithmetic, in the same order, as the loop in
 // raster_fast_body).
 template <bool SHAPES, unsigned POS_MASK, int NP>
-__device__ __forceinline__ void general_tile(unsigned long long mv0, unsigned long long wb0, unsigned signs, const float4 *s_vis, const float *s_hdr, const float *camv, int viewer, const float4 *s_col,
-                                             const float4 *s_row, const float2 *s_rowq, const float *s_colq, float nzm0, float nzm1, float nzm2, int px, int py0, const PixOut &po)
+__device__ __forceinline__ void general_tile(unsigned long long mv0, unsigned long long wb0, unsigned signs, const float4 *s_vis,
+                                             const float *s_hdr, const float *camv, int viewer, const float4 *s_col,
+                                             const float4 *s_row, const float2 *s_rowq, const float *s_colq,
+                                                     float nzm0, float nzm1, float nzm2, int px, int py0, const PixOut &po)
 {
     const int W = po.W, H = po.H;
     const int pxc = min(px, W - 1);
@@ -1438,8 +1462,10 @@ constexpr int glist_lds_bytes(int maxvis) { return 9 * maxvis + 4 * FH_FLOATS; }
 #endif
 // a classified tile -- or, LISTED, an entry of the drawing order: a run of up to eight planar / empty neighbours of a tile row -- by its class (classify_tiles)
 template <bool SHAPES, unsigned POS_MASK, int NP, bool LISTED>
-__device__ __forceinline__ void classified_tile(const FastArgs &fa, const int u, const int tx0, const int ty0, const uint4 *s_tile, const float4 *s_vis, const float *s_hdr, const float *camv, int viewer,
-                                            const float4 *s_col, const float4 *s_row, const float2 *s_rowq, const float *s_colq, float nzm0, float nzm1, float nzm2, unsigned long long wb0,
+__device__ __forceinline__ void classified_tile(const FastArgs &fa, const int u, const int tx0, const int ty0, const uint4 *s_tile,
+                                                const float4 *s_vis, const float *s_hdr, const float *camv, int viewer,
+                                            const float4 *s_col, const float4 *s_row, const float2 *s_rowq,
+                                                    const float *s_colq, float nzm0, float nzm1, float nzm2, unsigned long long wb0,
                                             int lane, const PixOut &po)
 {
     const unsigned info = (unsigned)__builtin_amdgcn_readfirstlane(s_tile[u].w), tclass = info & 7u;
@@ -1479,7 +1505,8 @@ __device__ __forceinline__ void classified_tile(const FastArgs &fa, const int u,
         else if (tclass == TC_PLANAR_SPEC) planar_tile<NP, true>(posA, k, s_vis, s_hdr, s_col, s_row, s_rowq, s_colq, nzk, px, py0, po);
         else {   // ... and boxes of other frames of reference (the time bar, a carried object)
             const uint2 tm = *reinterpret_cast<const uint2 *>(&s_tile[u]);
-            const unsigned long long others = (((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(tm.y) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(tm.x)) & ~wb0;
+            const unsigned long long others = (((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(tm.y) << 32)
+                                               | (unsigned)__builtin_amdgcn_readfirstlane(tm.x)) & ~wb0;
             overlay_tile<SHAPES, POS_MASK, NP>(posA, k, others, s_vis, s_hdr, camv, viewer, s_col, s_row, s_rowq, s_colq, nzm0, nzm1, nzm2, px, py0, po);
         }
         return;
@@ -1492,7 +1519,8 @@ __device__ __forceinline__ void classified_tile(const FastArgs &fa, const int u,
     RT_COUNT(4, 1);
     RT_COUNT(5, __popcll(mv0 & wb0));
     RT_COUNT(6, __popcll(mv0 & ~wb0));
-    general_tile<SHAPES, POS_MASK, NP>(mv0, wb0, fa.planar == 3 ? 0u : (info >> 11) & 15u, s_vis, s_hdr, camv, viewer, s_col, s_row, s_rowq, s_colq, nzm0, nzm1, nzm2, px, py0, po);
+    general_tile<SHAPES, POS_MASK, NP>(mv0, wb0, fa.planar == 3 ? 0u : (info >> 11) & 15u, s_vis, s_hdr, camv,
+                                       viewer, s_col, s_row, s_rowq, s_colq, nzm0, nzm1, nzm2, px, py0, po);
 }
 
 template <int MAXVIS, bool SHAPES, bool HEXF, int NP, bool CLS = true, int NT = 256>   // CLS: with the tile classification
@@ -1564,10 +1592,12 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
     constexpr bool LISTED = PLANAR && MV_TILE_LIST != 0;
     // whole tiles, rows of whole 16-byte groups: the empty tiles are cleared by all threads together (below) and stay out of the list
     const bool bulk = LISTED && po.edgeless && (W & 3) == 0;
-    if (PLANAR && cls && !LISTED) classify_tiles<TH, NT>(s_tile, s_line, s_vis, s_rect, s_hdr, camv, nVis, wb0, W, H, part, split, tilesX, numTiles, perWG, fa.planar != 2, s_cnt, s_txy, true);
+    if (PLANAR && cls && !LISTED) classify_tiles<TH, NT>(s_tile, s_line, s_vis, s_rect, s_hdr, camv, nVis, wb0, W, H,
+        part, split, tilesX, numTiles, perWG, fa.planar != 2, s_cnt, s_txy, true);
     else if (PLANAR && cls) {
         // (ends with a barrier)
-        classify_tiles<TH, NT>(s_tile, s_line, s_vis, s_rect, s_hdr, camv, nVis, wb0, W, H, part, split, tilesX, numTiles, perWG, fa.planar != 2, s_cnt, s_txy, bulk);
+        classify_tiles<TH, NT>(s_tile, s_line, s_vis, s_rect, s_hdr, camv, nVis, wb0, W, H, part, split,
+                               tilesX, numTiles, perWG, fa.planar != 2, s_cnt, s_txy, bulk);
         const int c0 = s_cnt[0], c1 = s_cnt[1], c2 = s_cnt[2], c3 = s_cnt[3], nE = s_cnt[4];
         nList = __builtin_amdgcn_readfirstlane(c0 + c1 + c2 + c3 + (bulk ? 0 : nE));
         if (tid < CLS_MAX_TILES) {
@@ -1612,7 +1642,8 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
             const int u = __builtin_amdgcn_readfirstlane((int)s_order[it]);
             if (lane == 0) unext = atomicAdd(&s_next, 1);
             const unsigned txy = (unsigned)__builtin_amdgcn_readfirstlane(s_txy[u]);
-            classified_tile<SHAPES, POS_MASK, NP, LISTED>(fa, u, (int)(txy & 0xffffu), (int)(txy >> 16), s_tile, s_vis, s_hdr, camv, viewer, s_col, s_row, s_rowq, s_colq, nzm0, nzm1, nzm2, wb0, lane, po);
+            classified_tile<SHAPES, POS_MASK, NP, LISTED>(fa, u, (int)(txy & 0xffffu), (int)(txy >> 16), s_tile, s_vis, s_hdr,
+                                                          camv, viewer, s_col, s_row, s_rowq, s_colq, nzm0, nzm1, nzm2, wb0, lane, po);
         }
     // tile / tilesX == umulhi(tile, ceil(2^32 / tilesX)) while tile * tilesX < 2^32
     const unsigned tilesXinv = (unsigned)((0x100000000ull + (unsigned)tilesX - 1u) / (unsigned)tilesX);
@@ -1624,7 +1655,8 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
         const int tx0 = tx * TILE_W, ty0 = ty * TH;
         const int tx1 = min(tx0 + TILE_W, W) - 1, ty1 = min(ty0 + TH, H) - 1;
         if (PLANAR && !LISTED && cls) {   // (MV_TILE_LIST=0: the classified tiles in frame order)
-            classified_tile<SHAPES, POS_MASK, NP, LISTED>(fa, u, tx0, ty0, s_tile, s_vis, s_hdr, camv, viewer, s_col, s_row, s_rowq, s_colq, nzm0, nzm1, nzm2, wb0, lane, po);
+            classified_tile<SHAPES, POS_MASK, NP, LISTED>(fa, u, tx0, ty0, s_tile, s_vis, s_hdr, camv, viewer,
+                                                          s_col, s_row, s_rowq, s_colq, nzm0, nzm1, nzm2, wb0, lane, po);
             continue;
         }
         // ---- which primitives can this tile's pixels hit?  (first round of 64 list positions)
@@ -1638,7 +1670,8 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
             asm volatile("" : "+v"(l2));   // (the rectangle's address is formed here, per tile: kept across the loop it was spilled at seven waves per SIMD)
             const int cpos = min(l2, max(nVis - 1, 0));
             const uint2 rr = NP == 1 ? rr0 : *reinterpret_cast<const uint2 *>(&s_rect[cpos]);   // one 8-byte read; x0 | x1 << 16, y0 | y1 << 16 (all >= 0)
-            const bool v = (lane < nVis) & ((int)(rr.x & 0xffffu) <= tx1) & ((int)(rr.x >> 16) >= tx0) & ((int)(rr.y & 0xffffu) <= ty1) & ((int)(rr.y >> 16) >= ty0);
+            const bool v = (lane < nVis) & ((int)(rr.x & 0xffffu) <= tx1) & ((int)(rr.x >> 16) >= tx0)
+                            & ((int)(rr.y & 0xffffu) <= ty1) & ((int)(rr.y >> 16) >= ty0);
             mv0 = __ballot(v);
             RT_COUNT(3, 1);                                   // unclassified tiles
         }
@@ -1666,7 +1699,8 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
             bool v = (mv0 >> lane) & 1ull;
             if (k > 0) {
                 const uint2 rr = *reinterpret_cast<const uint2 *>(&s_rect[cpos]);
-                v = (lane + 64 * k < nVis) & ((int)(rr.x & 0xffffu) <= tx1) & ((int)(rr.x >> 16) >= tx0) & ((int)(rr.y & 0xffffu) <= ty1) & ((int)(rr.y >> 16) >= ty0);
+                v = (lane + 64 * k < nVis) & ((int)(rr.x & 0xffffu) <= tx1) & ((int)(rr.x >> 16) >= tx0)
+                     & ((int)(rr.y & 0xffffu) <= ty1) & ((int)(rr.y >> 16) >= ty0);
                 mvis = __ballot(v);
             }
             if (mvis == 0ull) continue;
@@ -2082,9 +2116,9 @@ struct UnionRasterAllArgs {
     int32_t split_small, split_large;
 };
 
-// The short-list gyms' frames of a union launch take the tile classification where a frame is large enough to repay it -- two pixels per lane, 8192 pixels and more --
-// and not below: r09f, Mixed (eight scenarios) without / with, M obs/s: 128 x 128 11.0 / 12.8; 64 x 64 17.3 / 16.7 (the classified body's code and registers cost the
-// small frames' passes 6 % even where no frame is classified).
+// The short-list gyms' frames of a union launch take the tile classification where a frame is large enough to repay it -- two pixels per lane, 8192 pixels and
+// more -- and not below: r09f, Mixed (eight scenarios) without / with, M obs/s: 128 x 128 11.0 / 12.8; 64 x 64 17.3 / 16.7 (the classified body's code and
+// registers cost the small frames' passes 6 % even where no frame is classified).
 #ifndef MV_UNION_CLS
 #define MV_UNION_CLS (NPS >= 2)
 #endif
@@ -2175,12 +2209,16 @@ static void rdbg_dump()
         unsigned long long c[16];
         const bool got = hipMemcpy(c, g_rdbg + (size_t)16384 * 4 * 8, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess;
         if (got && c[10])
-            fprintf(stderr, "long-list census (all launches): tiles %llu, rounds of 64 list positions walked %.2f of %.2f per tile, early stops (every pixel nearer than the next class) in %.3f of the tiles, "
-                            "%.1f primitives met per tile; tiles that met nothing %.3f, one world-frame box only %.3f, two primitives %.3f, 3-5: %.3f, 6 and more: %.3f\n",
-                    c[10], double(c[11]) / c[10], double(c[12]) / c[10], double(c[15]) / c[10], double(c[13]) / c[10], double(c[14]) / c[10], double(c[9]) / c[10], double(c[8]) / c[10],
+            fprintf(stderr, "long-list census (all launches): tiles %llu, rounds of 64 list positions walked %.2f of %.2f per tile, early stops (every pixel "
+                    "nearer than the next class) in %.3f of the tiles, "
+                            "%.1f primitives met per tile; tiles that met nothing %.3f, one world-frame box only %.3f, two primitives %.3f, 3-5: %.3f, 6 and "
+                                    "more: %.3f\n",
+                    c[10], double(c[11]) / c[10], double(c[12]) / c[10], double(c[15]) / c[10], double(c[13]) / c[10],
+                                  double(c[14]) / c[10], double(c[9]) / c[10], double(c[8]) / c[10],
                     double(c[7]) / c[10], double(c[6]) / c[10]);
         if (got && c[4])
-            fprintf(stderr, "raster census (all launches): classified tiles %llu (empty %llu, planar %llu of which %llu without the highlight test, covered + overlay %llu), unclassified %llu, general-path tiles %llu: "
+            fprintf(stderr, "raster census (all launches): classified tiles %llu (empty %llu, planar %llu of which %llu without the highlight test, covered "
+                    "+ overlay %llu), unclassified %llu, general-path tiles %llu: "
                             "slab tests %.2f and other primitives %.2f per tile\n",
                     c[0], c[1], c[2], c[12], c[13], c[3], c[4], double(c[5]) / c[4], double(c[6]) / c[4]);
     }
@@ -2209,14 +2247,16 @@ static void rdbg_dump()
     }
     std::sort(spread.begin(), spread.end());
     if (!spread.empty()) fprintf(stderr, "raster timing: within a workgroup, last wave's end - first wave's end (us): mean %.1f p50 %.1f p90 %.1f max %.1f\n",
-                                 std::accumulate(spread.begin(), spread.end(), 0.0) / spread.size(), spread[spread.size() / 2], spread[spread.size() * 9 / 10], spread.back());
+                                 std::accumulate(spread.begin(), spread.end(), 0.0) / spread.size(),
+                                                 spread[spread.size() / 2], spread[spread.size() * 9 / 10], spread.back());
     {   // the longest-lived waves: where in the cost order was their workgroup (blk = its index in the launch), how long is their frame's list?
         std::vector<std::pair<double, size_t>> byLife;
         for (size_t w = 0; w < (size_t)16384 * 4; ++w) { const unsigned long long *o = &h[w * 8]; if (o[0]) byLife.push_back({double(o[5] - o[4]) * 0.01, w}); }
         std::sort(byLife.begin(), byLife.end(), [](auto &a, auto &b) { return a.first > b.first; });
         for (size_t q = 0; q < std::min<size_t>(byLife.size(), 12); q += 1) {
             const size_t w = byLife[q].second; const unsigned long long *o = &h[w * 8];
-            fprintf(stderr, "raster timing: long wave #%zu: life %.1f us (start +%.1f us), workgroup %zu of the launch, frame %llu, nVis %llu, classified %llu, cycles prologue %llu cls %llu tiles %llu\n", q,
+            fprintf(stderr, "raster timing: long wave #%zu: life %.1f us (start +%.1f us), workgroup %zu of the launch, frame %llu, nVis %llu, classified "
+                    "%llu, cycles prologue %llu cls %llu tiles %llu\n", q,
                     byLife[q].first, double(o[4] - r0) * 0.01, w / 4, o[7], o[6] & 0xffffffffull, o[6] >> 32, o[1] - o[0], o[2] - o[1], o[3] - o[2]);
         }
         // mean life by decile of the launch order
@@ -2231,7 +2271,8 @@ static void rdbg_dump()
             std::vector<double> pp(10, 0.0), pc(10, 0.0), pt(10, 0.0), ps(10, 0.0), pn(10, 0.0);
             for (auto &p : byLife) {
                 const int d = (int)std::min<size_t>(9, p.second * 10 / (maxw + 1)); const unsigned long long *o = &h[p.second * 8];
-                pp[d] += double(o[1] - o[0]); pc[d] += double(o[2] - o[1]); pt[d] += double(o[3] - o[2]); ps[d] += double(o[4] - r0) * 0.01; pn[d] += double(o[6] & 0xffffffffull);
+                pp[d] += double(o[1] - o[0]); pc[d] += double(o[2] - o[1]); pt[d] += double(o[3] - o[2]);
+                                ps[d] += double(o[4] - r0) * 0.01; pn[d] += double(o[6] & 0xffffffffull);
             }
             fprintf(stderr, "raster timing: by decile: prologue kcyc");
             for (int d = 0; d < 10; ++d) fprintf(stderr, " %.1f", cnt[d] ? pp[d] / cnt[d] / 1e3 : 0.0);
@@ -2248,9 +2289,11 @@ static void rdbg_dump()
     }
     std::sort(life.begin(), life.end()); std::sort(endAt.begin(), endAt.end());
     auto pct = [](const std::vector<double> &v, double p) { return v[std::min(v.size() - 1, (size_t)(p * v.size()))]; };
-    fprintf(stderr, "raster timing (last launch, %zu waves): cycles per wave: prologue %.0f, classification %.0f, tile loop %.0f | wave life us: mean %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f | "
+    fprintf(stderr, "raster timing (last launch, %zu waves): cycles per wave: prologue %.0f, classification %.0f, tile loop %.0f | wave life us: mean %.1f "
+            "p10 %.1f p50 %.1f p90 %.1f max %.1f | "
                     "launch %.1f us; waves ended by (us): 10%% %.1f, 25%% %.1f, 50%% %.1f, 75%% %.1f, 90%% %.1f, 99%% %.1f\n",
-            n, sumP / n, sumC / n, sumT / n, std::accumulate(life.begin(), life.end(), 0.0) / life.size(), pct(life, 0.1), pct(life, 0.5), pct(life, 0.9), life.back(),
+            n, sumP / n, sumC / n, sumT / n, std::accumulate(life.begin(), life.end(), 0.0) / life.size(),
+                                                             pct(life, 0.1), pct(life, 0.5), pct(life, 0.9), life.back(),
             double(r1 - r0) * 0.01, pct(endAt, 0.1), pct(endAt, 0.25), pct(endAt, 0.5), pct(endAt, 0.75), pct(endAt, 0.9), pct(endAt, 0.99));
 }
 #endif
@@ -2264,16 +2307,19 @@ static FastArgs fast_args_of(const GymView &gv, const PublishTo *publish)
     const int frames = gv.num_envs * gv.num_agents;
     FastArgs fa;
     fa.vis_hdr = gv.vis_hdr; fa.vis_prims = reinterpret_cast<const Prim *>(gv.vis_prims); fa.vis_rects = reinterpret_cast<const short4 *>(gv.vis_rects);
-    fa.hist = gv.lpt_hist + gv.lpt_parity * (LPT_BUCKETS * LPT_SUBS); fa.list = gv.lpt_list; fa.num_agents = gv.num_agents; fa.vis_stride = gv.vis_stride; fa.frames = frames;
+    fa.hist = gv.lpt_hist + gv.lpt_parity * (LPT_BUCKETS * LPT_SUBS); fa.list = gv.lpt_list; fa.num_agents = gv.num_agents;
+                                             fa.vis_stride = gv.vis_stride; fa.frames = frames;
     fa.stage_rewards = gv.rewards; fa.stage_true = gv.true_objective; fa.stage_done = gv.done;
-    fa.pub_rewards = publish ? publish->rewards : nullptr; fa.pub_true = publish ? publish->true_objective : nullptr; fa.pub_done = publish ? publish->done : nullptr;
+    fa.pub_rewards = publish ? publish->rewards : nullptr; fa.pub_true = publish ? publish->true_objective
+            : nullptr; fa.pub_done = publish ? publish->done : nullptr;
     fa.pub_n = publish ? frames : 0;
     const char *pe = getenv("MV_PLANAR");   // (read at every launch: the two paths are compared within one process by tests/test_fast_pixels_gpu.py)
     fa.planar = pe && *pe ? atoi(pe) : 1;   // (2: classified, but without overlay_tile; 3: without the sign-specialised slab tests -- comparisons)
     fa.tail_div = 0; fa.tail_split = 0;
     fa.hist_done = nullptr; fa.wg_total = 0;
 #ifdef MV_RASTER_TIMING
-    if (!g_rdbg && hipMalloc((void **)&g_rdbg, (size_t)(16384 * 4 * 8 + 64) * 8) == hipSuccess) { (void)hipMemset(g_rdbg, 0, (size_t)(16384 * 4 * 8 + 64) * 8); atexit(rdbg_dump); }
+    if (!g_rdbg && hipMalloc((void **)&g_rdbg, (size_t)(16384 * 4 * 8 + 64) * 8) == hipSuccess) { (void)hipMemset(g_rdbg,
+        0, (size_t)(16384 * 4 * 8 + 64) * 8); atexit(rdbg_dump); }
     fa.rdbg = g_rdbg;
 #endif
     return fa;
@@ -2314,8 +2360,10 @@ static int fast_pixels_per_lane(int W, int H, bool longList = false, bool batch 
 static int fast_split(int W, int H, int np, int frames, bool longList = false, bool batch = false)
 {
     const int ftiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H * np - 1) / (TILE_H * np));
-    // (one pixel per lane -- frames below 8192 pixels -- in the one-launch passes of a batched call: whole frames per workgroup as well; r09f, Mixed 64 x 64, four / one: 17.3 / 19.4 M obs/s)
-    const int want = ((np >= 2 ? 2048 : 4096) + frames - 1) / std::max(frames, 1), lo = (batch || frames >= 4096) && np >= 2 && !longList ? 1 : batch && !longList ? 1 : np >= 2 ? 2 : 4, hi = np >= 2 ? 8 : 16;
+    // (one pixel per lane -- frames below 8192 pixels -- in the one-launch passes of a batched call: whole frames per workgroup as well; r09f, Mixed 64 x 64,
+    // four / one: 17.3 / 19.4 M obs/s)
+    const int want = ((np >= 2 ? 2048 : 4096) + frames - 1) / std::max(frames, 1), lo = (batch || frames >= 4096) && np >= 2
+                      && !longList ? 1 : batch && !longList ? 1 : np >= 2 ? 2 : 4, hi = np >= 2 ? 8 : 16;
     int split = lo;
     while (split < hi && split < want) split <<= 1;
     while (split > 1 && ftiles < 4 * split * (longList ? 1 : 2)) split >>= 1;
@@ -2335,7 +2383,8 @@ static void launch_done(K kernel, dim3 grid, dim3 block, size_t dyn, hipStream_t
     else hipLaunchKernelGGL(kernel, grid, block, dyn, stream, args...);
 }
 
-int launch_raster_union(const GymView *views, uint32_t *const *obs, const PublishTo *publish, int n, int W, int H, hipStream_t stream, hipEvent_t between, hipEvent_t done)
+int launch_raster_union(const GymView *views, uint32_t *const *obs, const PublishTo *publish, int n, int W,
+                        int H, hipStream_t stream, hipEvent_t between, hipEvent_t done)
 {
     if (W > MAX_W || H > MAX_H || n > MAX_UNION) return -1;
     const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)W * sizeof(float) + (size_t)H * sizeof(float2);
@@ -2383,7 +2432,8 @@ int launch_raster_union(const GymView *views, uint32_t *const *obs, const Publis
         if (!ua.n) continue;
         for (int i = ua.n; i <= MAX_UNION; ++i) ua.first[i] = wgs;
         if (large) {
-            if (lnp == 2) hipLaunchKernelGGL((raster_glist_union_kernel<VIS_XL, true, GLIST_WAVES_NP2, true, 2>), dim3(wgs), dim3(256), dyn, stream, ua, W, H, split);
+            if (lnp == 2) hipLaunchKernelGGL((raster_glist_union_kernel<VIS_XL, true, GLIST_WAVES_NP2, true, 2>),
+                dim3(wgs), dim3(256), dyn, stream, ua, W, H, split);
             else hipLaunchKernelGGL((raster_glist_union_kernel<VIS_XL, true, GLIST_WAVES_NP1, true, 1>), dim3(wgs), dim3(256), dyn, stream, ua, W, H, split);
         } else {
             if (lnp == 2) hipLaunchKernelGGL((raster_fast_union_kernel<VIS_SMALL, true, 6, false, 2>), dim3(wgs), dim3(256), dyn, stream, ua, W, H, split);
@@ -2406,7 +2456,8 @@ bool raster_union_batch_applicable(int k, int n, int W, int H)
     return !off && W <= MAX_W && H <= MAX_H && k >= 2 && k <= MAX_GROUP_TICKS && n >= 1 && n <= MAX_UNION;
 }
 
-int launch_raster_union_batch(const GymView *views, uint32_t *const *obs, const PublishTo *publish, int k, int n, int W, int H, hipStream_t stream, hipEvent_t done)
+int launch_raster_union_batch(const GymView *views, uint32_t *const *obs, const PublishTo *publish,
+                              int k, int n, int W, int H, hipStream_t stream, hipEvent_t done)
 {
     if (!raster_union_batch_applicable(k, n, W, H)) return 1;
     const size_t dyn = (size_t)(W + H) * sizeof(float4) + (size_t)W * sizeof(float) + (size_t)H * sizeof(float2);
@@ -2437,7 +2488,8 @@ int launch_raster_union_batch(const GymView *views, uint32_t *const *obs, const 
             a.slot_stride[q] = k > 1 ? (int64_t)(reinterpret_cast<const unsigned char *>(views[n + i].vis_prims) - reinterpret_cast<const unsigned char *>(v0.vis_prims)) : 0;
             for (int j = 0; j < k; ++j) {   // (tick j's view is tick 0's, one slot further per tick: mv_union.h)
                 const GymView &vj = views[(size_t)j * n + i], want = tick_view(v0, a.slot_stride[q], j);
-                if (vj.vis_prims != want.vis_prims || vj.vis_hdr != want.vis_hdr || vj.lpt_list != want.lpt_list || vj.rewards != want.rewards || vj.done != want.done ||
+                if (vj.vis_prims != want.vis_prims || vj.vis_hdr != want.vis_hdr || vj.lpt_list != want.lpt_list
+                    || vj.rewards != want.rewards || vj.done != want.done ||
                     vj.true_objective != want.true_objective || vj.lpt_parity != want.lpt_parity || vj.lpt_no_clear != v0.lpt_no_clear)
                     return -2;
                 a.obs[j][q] = obs[(size_t)j * n + i];
@@ -2504,7 +2556,8 @@ int launch_raster_batch(const GymView *views, uint32_t *const *obs, const Publis
     return 0;
 }
 
-int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream, hipEvent_t between, int fast, int setup_done, const PublishTo *publish, hipEvent_t done)
+int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t stream, hipEvent_t between,
+                  int fast, int setup_done, const PublishTo *publish, hipEvent_t done)
 {
     if (W > MAX_W || H > MAX_H) return -1;
     const int tiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H * PPL - 1) / (TILE_H * PPL));
@@ -2525,10 +2578,12 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
         const bool hexScen = gv.scenario == SCN_HEX_MEMORY || gv.scenario == SCN_HEX_EXPLORE;
         KernelFn fn;
         if (np == 2)
-            fn = hexScen ? raster_glist_kernel<VIS_XL, true, GLIST_WAVES_NP2, true, 2> : gv.vis_stride > VIS_SMALL ? raster_glist_kernel<VIS_LARGE, false, GLIST_WAVES_NP2, false, 2>
+            fn = hexScen ? raster_glist_kernel<VIS_XL, true, GLIST_WAVES_NP2, true, 2> : gv.vis_stride > VIS_SMALL
+                    ? raster_glist_kernel<VIS_LARGE, false, GLIST_WAVES_NP2, false, 2>
                : gv.scenario == SCN_REARRANGE ? raster_fast_kernel<VIS_SMALL, true, 6, false, 2> : raster_fast_kernel<VIS_SMALL, false, 7, false, 2>;
         else
-            fn = hexScen ? raster_glist_kernel<VIS_XL, true, GLIST_WAVES_NP1, true, 1> : gv.vis_stride > VIS_SMALL ? raster_glist_kernel<VIS_LARGE, false, GLIST_WAVES_NP1, false, 1>
+            fn = hexScen ? raster_glist_kernel<VIS_XL, true, GLIST_WAVES_NP1, true, 1> : gv.vis_stride > VIS_SMALL
+                    ? raster_glist_kernel<VIS_LARGE, false, GLIST_WAVES_NP1, false, 1>
                : gv.scenario == SCN_REARRANGE ? raster_fast_kernel<VIS_SMALL, true, 8> : raster_fast_kernel<VIS_SMALL, false, 8>;
         const int ftiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H * np - 1) / (TILE_H * np));
         // Fine-grained tail.  The SIMD's arbiter serves its OLDEST wave first: workgroups finish roughly in launch order whatever they cost (wave life
@@ -2556,7 +2611,8 @@ int launch_raster(const GymView &gv, uint32_t *obs, int W, int H, hipStream_t st
     int split = 4;
     while (split > 1 && tiles < 4 * split * 2) split >>= 1;   // keep at least two tiles per wave
     const dim3 grid(frames * split), block(256);
-    if (gv.scenario == SCN_HEX_MEMORY || gv.scenario == SCN_HEX_EXPLORE) hipLaunchKernelGGL((raster_kernel<VIS_XL, true>), grid, block, dyn, stream, gv, obs, W, H, split, gv.lpt_order);
+    if (gv.scenario == SCN_HEX_MEMORY || gv.scenario == SCN_HEX_EXPLORE) hipLaunchKernelGGL((raster_kernel<VIS_XL, true>),
+        grid, block, dyn, stream, gv, obs, W, H, split, gv.lpt_order);
     else if (gv.vis_stride > VIS_SMALL) hipLaunchKernelGGL((raster_kernel<VIS_LARGE, false>), grid, block, dyn, stream, gv, obs, W, H, split, gv.lpt_order);
     else if (gv.scenario == SCN_REARRANGE) hipLaunchKernelGGL((raster_kernel<VIS_SMALL, true>), grid, block, dyn, stream, gv, obs, W, H, split, gv.lpt_order);
     else hipLaunchKernelGGL((raster_kernel<VIS_SMALL, false>), grid, block, dyn, stream, gv, obs, W, H, split, gv.lpt_order);

@@ -126,7 +126,8 @@ __device__ __forceinline__ void step_ticks_body(const Args &a, int W, int H)
     }
 }
 // (two kernels, not one template: a launch bound that depends on a template parameter is not applied)
-template <class Args> __global__ __launch_bounds__(64, MV_STEP_TICKS_WAVES_PER_SIMD) void step_ticks_kernel(Args a, int W, int H) { step_ticks_body<1>(a, W, H); }
+template <class Args> __global__ __launch_bounds__(64, MV_STEP_TICKS_WAVES_PER_SIMD) void step_ticks_kernel(Args a,
+                                                   int W, int H) { step_ticks_body<1>(a, W, H); }
 template <class Args> __global__ __launch_bounds__(256, 3) void step_ticks_agents_kernel(Args a, int W, int H) { step_ticks_body<MAX_AGENTS>(a, W, H); }
 
 // Software-pipelined (one agent per env): TWO waves per env.  Wave 0 runs tick j + 1 while wave 1 sets tick j's frame up (mv_frame.h) -- the two halves of a
@@ -178,7 +179,8 @@ void launch_step_ticks(const GymView *views, int k, hipStream_t stream, int W, i
     StepTicksArgs8 a;   // (k <= 8: the views are the launch's arguments)
     a.n = k; a.pad = 0;
     for (int j = 0; j < 8; ++j) a.gv[j] = views[std::min(j, k - 1)];
-    if (gv.num_agents == 1 && step_pipe_enabled()) hipExtLaunchKernelGGL(step_ticks_pipe_kernel<StepTicksArgs8>, grid, dim3(128), 0, stream, nullptr, done, 0, a, W, H);
+    if (gv.num_agents == 1 && step_pipe_enabled()) hipExtLaunchKernelGGL(step_ticks_pipe_kernel<StepTicksArgs8>,
+        grid, dim3(128), 0, stream, nullptr, done, 0, a, W, H);
     else if (gv.num_agents == 1) hipExtLaunchKernelGGL(step_ticks_kernel<StepTicksArgs8>, grid, block, 0, stream, nullptr, done, 0, a, W, H);
     else hipExtLaunchKernelGGL(step_ticks_agents_kernel<StepTicksArgs8>, grid, block, 0, stream, nullptr, done, 0, a, W, H);
 }

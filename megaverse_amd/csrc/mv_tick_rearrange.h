@@ -205,7 +205,8 @@ __device__ __forceinline__ void rearrange_tick(const GymView &gv, const int env)
 #pragma unroll
         for (int k = 0; k < MAX_ITEMS; ++k) {
             const int src = LANE_TARGET + k;
-            const int ks = __shfl(shape, src, 64), kc = __shfl(color, src, 64), kx = __shfl(offx, src, 64), ky = __shfl(offy, src, 64), kz = __shfl(offz, src, 64);
+            const int ks = __shfl(shape, src, 64), kc = __shfl(color, src, 64), kx = __shfl(offx, src, 64),
+                                  ky = __shfl(offy, src, 64), kz = __shfl(offz, src, 64);
             if (k < numItems && ks == shape && kc == color && kx == rx && ky == ry && kz == rz) match = true;
         }
         return __popcll(__ballot(isItem && hasItem && ostate <= 0 && match));

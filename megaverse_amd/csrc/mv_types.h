@@ -221,7 +221,8 @@ inline bool slot_stride_of(const GymView *views, int k, int64_t &stride)
     stride = k > 1 ? (int64_t)((const uint8_t *)views[1].vis_prims - (const uint8_t *)views[0].vis_prims) : 0;
     for (int j = 1; j < k; ++j) {
         const GymView w = tick_view(views[0], stride, j);
-        if (views[j].vis_prims != w.vis_prims || views[j].vis_hdr != w.vis_hdr || views[j].lpt_list != w.lpt_list || views[j].rewards != w.rewards || views[j].done != w.done ||
+        if (views[j].vis_prims != w.vis_prims || views[j].vis_hdr != w.vis_hdr || views[j].lpt_list != w.lpt_list
+            || views[j].rewards != w.rewards || views[j].done != w.done ||
             views[j].true_objective != w.true_objective || views[j].lpt_parity != w.lpt_parity || views[j].lpt_no_clear != w.lpt_no_clear)
             return false;
     }
