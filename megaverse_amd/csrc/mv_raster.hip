@@ -1833,6 +1833,15 @@ __device__ __forceinline__ void box_run_g(unsigned long long m, int k, const V3 
     }
 }
 
+// one round of a tile's culling: lane i holds list position 64 k + i -- its rectangle against the tile's; -> the mask of the positions that meet it
+__device__ __forceinline__ unsigned long long cull_round_g(const short4 *s_rect, int lane, int k, int nVis, int tx0, int tx1, int ty0, int ty1, int &cpos, bool &v)
+{
+    cpos = min(lane + 64 * k, nVis - 1);
+    const uint2 rr = *reinterpret_cast<const uint2 *>(&s_rect[cpos]);   // x0 | x1 << 16, y0 | y1 << 16
+    v = (lane + 64 * k < nVis) & ((int)(rr.x & 0xffffu) <= tx1) & ((int)(rr.x >> 16) >= tx0) & ((int)(rr.y & 0xffffu) <= ty1) & ((int)(rr.y >> 16) >= ty0);
+    return __ballot(v);
+}
+
 template <int MAXVIS, bool SHAPES, bool HEXF, int NP>
 __device__ __forceinline__ void raster_glist_body(const FastArgs &fa, uint32_t *obs, int W, int H, int split, int blk, unsigned char *lds)
 {
@@ -1880,69 +1889,74 @@ __device__ __forceinline__ void raster_glist_body(const FastArgs &fa, uint32_t *
         const int tx1 = min(tx0 + TILE_W, W) - 1, ty1 = min(ty0 + TH, H) - 1;
         const int px = tx0 + lx, py0 = ty0 + ly;
         const int pxc = min(px, W - 1);
-        V3 dw[NP], inv[NP], ih0[NP], ih1[NP], ih2[NP], bn[NP];
-        float dcx = 0.0f, dcy[NP], a2[NP], ldc[NP];
-        Key2 best[NP];
-#pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            dw[j] = inv[j] = bn[j] = ih0[j] = ih1[j] = ih2[j] = v3(0, 0, 0);
-            dcy[j] = a2[j] = ldc[j] = 0.0f;
-            best[j].d = ~0u; best[j].p = 0u;
-        }
-        bool rayReady = false;
 #ifdef MV_RASTER_TIMING
         int metTotal = 0, metWorld = 0;
 #endif
         RT_COUNT(10, 1);                  // tiles of the long-list pass
         RT_COUNT(12, (nVis + 63) / 64);   // rounds their lists have
+        // ---- the rounds of the list up to the first one with a primitive on this tile: there is nothing to set up before (a third of a Hex frame's tiles,
+        // half of a Collect frame's, meet nothing at all: they are cleared here)
+        int k = 0, cpos = 0;
+        bool v = false;
+        unsigned long long mvis = 0ull;
 #pragma unroll 1
-        for (int k = 0; k * 64 < nVis; ++k) {
-            // A list in depth classes (DepthSortScratch).  The header's word for the round: the depth class it begins with.  A tile whose every pixel holds a
-            // hit nearer than the class's floor is
-            // done with the list: everything from here on is hidden behind what has been found.
-            if (depthSorted && k >= 1 && k < 31) {
-                const unsigned wd = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_uint(s_hdr[FH_WB + k]));
-                // (depth_class_floor, with a margin far above the rounding of the corners' depths)
-                const float floorD = __uint_as_float(((wd & 63u) + (120u << 2)) << 21) * (1.0f - 1e-4f);
-                const unsigned bound = floorD > NEAR_Z ? __float_as_uint(floorD) - KEY_NEAR : 0u;          // in the units of the depth keys; 0: never stop here
-                bool covered = true;
-#pragma unroll
-                for (int j = 0; j < NP; ++j) covered = covered && (best[j].d < bound || px >= W || py0 + TILE_H * j >= H);
-                if (__all(covered)) { RT_COUNT(15, 1); break; }
-            }
+        for (; k * 64 < nVis; ++k) {
             RT_COUNT(11, 1);   // rounds of the list walked
-            const int cpos = min(lane + 64 * k, nVis - 1);
-            const uint2 rr = *reinterpret_cast<const uint2 *>(&s_rect[cpos]);
-            const bool v = (lane + 64 * k < nVis) & ((int)(rr.x & 0xffffu) <= tx1) & ((int)(rr.x >> 16) >= tx0) & ((int)(rr.y & 0xffffu) <= ty1) &
-                           ((int)(rr.y >> 16) >= ty0);
-            const unsigned long long mvis = __ballot(v);
+            mvis = cull_round_g(s_rect, lane, k, nVis, tx0, tx1, ty0, ty1, cpos, v);
+#if defined(MV_GLIST_DEBUG_SKIP) && MV_GLIST_DEBUG_SKIP == 3   // (measurement builds: the list is culled, nothing else)
+            mvis = 0ull;
+#endif
+            if (mvis) break;
+        }
+        if (mvis == 0ull) {
+            RT_COUNT(14, 1);   // tiles that met nothing
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const int py = py0 + TILE_H * j;
+                if (px < W && py < H) PIXEL_STORE(out[(unsigned)(py * W + px)], 0xff000000u);
+            }
+            continue;
+        }
+        // ---- the pixels' rays
+        V3 dw[NP], inv[NP], ih0[NP], ih1[NP], ih2[NP], bn[NP];
+        float dcx, dcy[NP], a2[NP], ldc[NP];
+        Key2 best[NP];
+        {
+            const float4 cx = s_col[pxc];
+            const float cq = s_colq[pxc];
+            dcx = cx.x;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const int pyc = min(py0 + TILE_H * j, H - 1);
+                const float4 ry = s_row[pyc];
+                const float2 rq = s_rowq[pyc];
+                dcy[j] = ry.x;
+                dw[j] = v3((cx.y + ry.y) + nzm0, (cx.z + ry.z) + nzm1, (cx.w + ry.w) + nzm2);
+                inv[j] = v3(__builtin_amdgcn_rcpf(dw[j].x), __builtin_amdgcn_rcpf(dw[j].y), __builtin_amdgcn_rcpf(dw[j].z));
+                a2[j] = cq + rq.x; ldc[j] = rq.y;
+                if (HEXF) {   // (same products and sums as mat_tmul with the frame's matrix: c x + (-s) z, s x + c z)
+                    const float cx8 = 0.8660254f * dw[j].x, cz8 = 0.8660254f * dw[j].z, hx5 = 0.5f * dw[j].x, hz5 = 0.5f * dw[j].z;
+                    ih0[j] = v3(__builtin_amdgcn_rcpf(cx8 - hz5), inv[j].y, __builtin_amdgcn_rcpf(hx5 + cz8));
+                    ih1[j] = v3(__builtin_amdgcn_rcpf(cx8 + hz5), inv[j].y, __builtin_amdgcn_rcpf(cz8 - hx5));
+                    ih2[j] = v3(0.0f - inv[j].z, inv[j].y, inv[j].x);   // 90 degrees: (x, z) -> (-z, x)
+                } else ih0[j] = ih1[j] = ih2[j] = inv[j];
+                bn[j] = v3(0, 0, 0);
+                best[j].d = ~0u; best[j].p = 0u;
+            }
+        }
+        // ---- the rounds with primitives on this tile
+        bool more = true;
+#pragma unroll 1
+        while (more) {
             RT_COUNT(13, __popcll(mvis));   // primitives whose rectangle meets the tile
 #ifdef MV_RASTER_TIMING
             metTotal += __popcll(mvis); metWorld += __popcll(__ballot(v && s_cls[cpos] == 0u));
 #endif
-            if (mvis == 0ull) continue;
-            if (!rayReady) {
-                rayReady = true;
-                const float4 cx = s_col[pxc];
-                const float cq = s_colq[pxc];
-                dcx = cx.x;
+#if defined(MV_GLIST_DEBUG_SKIP) && MV_GLIST_DEBUG_SKIP == 2   // (measurement builds: culled, the rays set up, nothing tested)
 #pragma unroll
-                for (int j = 0; j < NP; ++j) {
-                    const int pyc = min(py0 + TILE_H * j, H - 1);
-                    const float4 ry = s_row[pyc];
-                    const float2 rq = s_rowq[pyc];
-                    dcy[j] = ry.x;
-                    dw[j] = v3((cx.y + ry.y) + nzm0, (cx.z + ry.z) + nzm1, (cx.w + ry.w) + nzm2);
-                    inv[j] = v3(__builtin_amdgcn_rcpf(dw[j].x), __builtin_amdgcn_rcpf(dw[j].y), __builtin_amdgcn_rcpf(dw[j].z));
-                    a2[j] = cq + rq.x; ldc[j] = rq.y;
-                    if (HEXF) {   // (same products and sums as mat_tmul with the frame's matrix: c x + (-s) z, s x + c z)
-                        const float cx8 = 0.8660254f * dw[j].x, cz8 = 0.8660254f * dw[j].z, hx5 = 0.5f * dw[j].x, hz5 = 0.5f * dw[j].z;
-                        ih0[j] = v3(__builtin_amdgcn_rcpf(cx8 - hz5), inv[j].y, __builtin_amdgcn_rcpf(hx5 + cz8));
-                        ih1[j] = v3(__builtin_amdgcn_rcpf(cx8 + hz5), inv[j].y, __builtin_amdgcn_rcpf(cz8 - hx5));
-                        ih2[j] = v3(0.0f - inv[j].z, inv[j].y, inv[j].x);   // 90 degrees: (x, z) -> (-z, x)
-                    }
-                }
-            }
+            for (int j = 0; j < NP; ++j)
+                best[j].p += __float_as_uint(inv[j].x + inv[j].y + inv[j].z + ih0[j].x + ih0[j].z + ih1[j].x + ih1[j].z + a2[j] + ldc[j]);
+#else
             const unsigned cl = s_cls[cpos];
             const unsigned long long m0 = __ballot(v && cl == 0u);
             unsigned long long boxes = m0;
@@ -1970,9 +1984,29 @@ __device__ __forceinline__ void raster_glist_body(const FastArgs &fa, uint32_t *
                     if (less) { best[j].d = d; best[j].p = tk; bn[j] = n; }
                 }
             }
+#endif
+            // the next round with a primitive on this tile
+            more = false;
+#pragma unroll 1
+            for (++k; k * 64 < nVis; ++k) {
+                // A list in depth classes (DepthSortScratch).  The header's word for the round: the depth class it begins with.  A tile whose every pixel
+                // holds a hit nearer than the class's floor is done with the list: everything from here on is hidden behind what has been found.
+                if (depthSorted && k < 31) {
+                    const unsigned wd = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_uint(s_hdr[FH_WB + k]));
+                    // (depth_class_floor, with a margin far above the rounding of the corners' depths)
+                    const float floorD = __uint_as_float(((wd & 63u) + (120u << 2)) << 21) * (1.0f - 1e-4f);
+                    const unsigned bound = floorD > NEAR_Z ? __float_as_uint(floorD) - KEY_NEAR : 0u;          // in the units of the depth keys; 0: never stop here
+                    bool covered = true;
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) covered = covered && (best[j].d < bound || px >= W || py0 + TILE_H * j >= H);
+                    if (__all(covered)) { RT_COUNT(15, 1); break; }
+                }
+                RT_COUNT(11, 1);   // rounds of the list walked
+                mvis = cull_round_g(s_rect, lane, k, nVis, tx0, tx1, ty0, ty1, cpos, v);
+                if (mvis) { more = true; break; }
+            }
         }
 #ifdef MV_RASTER_TIMING
-        RT_COUNT(14, metTotal == 0);                       // tiles that met nothing
         RT_COUNT(9, metTotal == 1 && metWorld == 1);       // ... one world-frame box and nothing else
         RT_COUNT(8, metTotal == 2);
         RT_COUNT(7, metTotal >= 3 && metTotal <= 5);
@@ -1981,7 +2015,13 @@ __device__ __forceinline__ void raster_glist_body(const FastArgs &fa, uint32_t *
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             unsigned rgba = 0xff000000u;
-            if (best[j].d <= KEY_FAR) {   // a hit between the near and the far plane: the winner's record, one 32-byte read per lane
+#if defined(MV_GLIST_DEBUG_SKIP) && MV_GLIST_DEBUG_SKIP >= 1   // (measurement builds: nothing shaded)
+            rgba = best[j].d ^ best[j].p;
+            if (false)
+#else
+            if (best[j].d <= KEY_FAR)
+#endif
+            {   // a hit between the near and the far plane: the winner's record, one 32-byte read per lane
                 const unsigned wpos = best[j].p & 2047u;   // (tie_key: the position in its low bits)
                 const float4 lo = gp[2 * wpos], hi = gp[2 * wpos + 1];
                 rgba = shade_rec<SHAPES>(lo, hi, __uint_as_float(best[j].d + KEY_NEAR), bn[j], s_hdr, camv, viewer, dw[j], inv[j], dcx, dcy[j], a2[j], ldc[j]);
