@@ -657,9 +657,11 @@ def main():
             step0 += wu
             torch.cuda.set_stream(main_stream)
             fence()
-            # One host thread enqueues both halves in turn: per step it pays the Python + launch cost of a tick TWICE (~75 us at 2 x 512 envs: this leg is bound by the
-            # host -- `host_enqueue_ms_per_step_closed_loop_double_buffered` ~ the leg's time -- where `closed_loop` is bound by its three kernels back to back).
-            # A host thread per half was built and measured: 9.2 M obs/s against 13.5 M (r08v: two Python threads contend for the interpreter lock, 109 us per step).
+            # One host thread enqueues both halves in turn.  The host is NOT the bound: a half-step costs it 16 us (r10a: scripts/probe_host_cost.py, the device
+            # kept idle); `host_enqueue_ms_per_step_*` equals the leg's time because the library bounds the host's run-ahead (the status read-back).  The two
+            # chains fall into step with each other -- both policies, both step kernels, then both observation passes side by side -- so the pair behaves like
+            # one gym (r03c timeline).  Forcing the stagger costs more than it gives: every cross-queue dependency on a chain is 10-40 us on this part (the
+            # halves' passes on one stream: 7.3 M, r10e / r10f; passes taking turns through events: r03).  A host thread per half: 9.2 M against 13.5 M (r08v).
             t0 = time.perf_counter()
             for i in range(args.steps):
                 half_step(0, step0 + i); half_step(1, step0 + i)
