@@ -47,11 +47,59 @@ public:
         return std::clamp<double>(sum * 0.5 + 0.5, 0, 1);
     }
 
+    // One axis of a grid of samples: for sample i and octave o the coordinate i / step * 2^o (the doublings are exact, so the table holds the very values
+    // layered01 walks through) split into lattice cell, offset and smoothed offset -- a landscape's nx x nz samples share nx + nz of these per octave instead
+    // of computing them nx x nz times.
+    struct Axis { int cell; double t, s; };
+    static void axis_table(int n, double step, int octaves, std::vector<Axis> &out)
+    {
+        out.resize(size_t(n) * octaves);
+        for (int i = 0; i < n; ++i) {
+            double c = i / step;
+            for (int o = 0; o < octaves; ++o, c *= 2) {
+                const double f = std::floor(c);
+                Axis &a = out[size_t(i) * octaves + o];
+                a.cell = int(f) & 255; a.t = c - f; a.s = smooth(a.t);
+            }
+        }
+    }
+    // layered01(x / step_x, z / step_z, octaves) from the two axes' tables: the same operations on the same values, in the same order
+    double layered01(const Axis *ax, const Axis *az, int octaves) const
+    {
+        double sum = 0, weight = 1;
+        for (int o = 0; o < octaves; ++o) {
+            const int ix = ax[o].cell, iy = az[o].cell;
+            const double x = ax[o].t, y = az[o].t, u = ax[o].s, v = az[o].s;
+            const int a = perm_[ix] + iy, b = perm_[ix + 1] + iy;
+            const int aa = perm_[a], ab = perm_[a + 1], ba = perm_[b], bb = perm_[b + 1];
+            const double n = blend(v, blend(u, corner0(perm_[aa], x, y), corner0(perm_[ba], x - 1, y)),
+                                      blend(u, corner0(perm_[ab], x, y - 1), corner0(perm_[bb], x - 1, y - 1)));
+            sum += n * weight;
+            weight /= 2;
+        }
+        return std::clamp<double>(sum * 0.5 + 0.5, 0, 1);
+    }
+
 private:
     uint8_t perm_[512];
 
     static double smooth(double t) { return t * t * t * (t * (t * 6 - 15) + 10); }
     static double blend(double t, double a, double b) { return a + t * (b - a); }
+    // corner(h, x, y, 0) without the branches (h is as good as random: every one of them mispredicts half of the time): which of x, y, 0 the two terms are, and
+    // their signs, from a table -- the same two values, negated or not, and their sum
+    static double corner0(uint8_t h, double x, double y)
+    {
+        static const uint8_t kU[16] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1};
+        static const uint8_t kV[16] = {1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 0, 2, 0, 2};
+        h &= 15;
+        const double val[3] = {x, y, 0.0};
+        uint64_t ub, vb;
+        std::memcpy(&ub, &val[kU[h]], 8); std::memcpy(&vb, &val[kV[h]], 8);
+        ub ^= uint64_t(h & 1) << 63; vb ^= uint64_t(h & 2) << 62;
+        double u, v;
+        std::memcpy(&u, &ub, 8); std::memcpy(&v, &vb, 8);
+        return u + v;
+    }
     static double corner(uint8_t h, double x, double y, double z)
     {
         h &= 15;
@@ -118,11 +166,14 @@ void generate_collect_episode(std::mt19937 &rng, int num_agents, float base_epis
     std::memset(out.heightmap, 0xff, sizeof out.heightmap);
     auto height = [&](int x, int z) -> int8_t & { return out.heightmap[x * HM_DIM + z]; };
     int top = 0;
+    std::vector<Noise::Axis> axis_x, axis_z;
+    Noise::axis_table(nx, step_x, octaves, axis_x);
+    Noise::axis_table(nz, step_z, octaves, axis_z);
     for (int x = 0; x < nx; ++x)
         for (int z = 0; z < nz; ++z) {
             int h = 0;
             if (x >= 1 && x < nx - 1 && z >= 1 && z < nz - 1) {
-                const double elevation = intensity * (noise.layered01(x / step_x, z / step_z, octaves) - ground);
+                const double elevation = intensity * (noise.layered01(&axis_x[size_t(x) * octaves], &axis_z[size_t(z) * octaves], octaves) - ground);
                 if (elevation >= 1) h = int(std::lround(elevation));
             }
             height(x, z) = int8_t(h);
