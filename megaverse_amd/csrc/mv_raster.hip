@@ -1786,6 +1786,9 @@ __device__ __forceinline__ void raster_fast_body(const FastArgs &fa, uint32_t *o
 typedef __attribute__((address_space(4))) const float cfloat;   // constant address space: loads from uniform addresses become s_load
 __device__ __forceinline__ float4 rec4(cfloat *p, int i) { return make_float4(p[4 * i], p[4 * i + 1], p[4 * i + 2], p[4 * i + 3]); }   // (one s_load_dwordx4)
 
+#ifndef MV_GLIST_TILE_W
+#define MV_GLIST_TILE_W 16
+#endif
 struct Key2 { unsigned d, p; };   // depth bits minus KEY_NEAR (> KEY_FAR: not a hit), list position
 
 __device__ __forceinline__ void key2_min(Key2 &best, bool valid, unsigned d, unsigned p)
@@ -1845,7 +1848,8 @@ __device__ __forceinline__ unsigned long long cull_round_g(const short4 *s_rect,
 template <int MAXVIS, bool SHAPES, bool HEXF, int NP>
 __device__ __forceinline__ void raster_glist_body(const FastArgs &fa, uint32_t *obs, int W, int H, int split, int blk, unsigned char *lds)
 {
-    constexpr int TH = TILE_H * NP;
+    // the long-list pass's tile: GT_W x GT_H pixels of one wave (x NP rows of them); 32 x 2: every row a wave stores is one whole 128-byte line
+    constexpr int GT_W = MV_GLIST_TILE_W, GT_H = 64 / GT_W, TH = GT_H * NP;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     short4 *s_rect = reinterpret_cast<short4 *>(lds);                 // [MAXVIS]
     float *s_hdr = reinterpret_cast<float *>(lds + 8 * MAXVIS);       // [FH_FLOATS]
@@ -1867,9 +1871,9 @@ __device__ __forceinline__ void raster_glist_body(const FastArgs &fa, uint32_t *
     const float *camv = s_hdr + FH_CAM + FH_CAM_STRIDE * viewer;
     const float nzm0 = uniform_f32(-camv[3 + 2]), nzm1 = uniform_f32(-camv[3 + 5]), nzm2 = uniform_f32(-camv[3 + 8]);
     uint32_t *out = obs + (size_t)frame * W * H;
-    const int tilesX = (W + TILE_W - 1) / TILE_W, tilesY = (H + TH - 1) / TH;
+    const int tilesX = (W + GT_W - 1) / GT_W, tilesY = (H + TH - 1) / TH;
     const int numTiles = tilesX * tilesY;
-    const int lx = lane & (TILE_W - 1), ly = lane / TILE_W;
+    const int lx = lane & (GT_W - 1), ly = lane / GT_W;
 
     // the workgroup's tiles are handed out one at a time, as in raster_fast_body (a wave that always drew the same tile column lived as long as the
     // most crowded one); u = 4 j + w is tile (j split + part) 4 + w of the frame
@@ -1885,8 +1889,8 @@ __device__ __forceinline__ void raster_glist_body(const FastArgs &fa, uint32_t *
         if (tile >= numTiles) break;
         if (lane == 0) unext = atomicAdd(&s_next, 1);
         const int ty = (int)__umulhi((unsigned)tile, tilesXinv), tx = tile - ty * tilesX;
-        const int tx0 = tx * TILE_W, ty0 = ty * TH;
-        const int tx1 = min(tx0 + TILE_W, W) - 1, ty1 = min(ty0 + TH, H) - 1;
+        const int tx0 = tx * GT_W, ty0 = ty * TH;
+        const int tx1 = min(tx0 + GT_W, W) - 1, ty1 = min(ty0 + TH, H) - 1;
         const int px = tx0 + lx, py0 = ty0 + ly;
         const int pxc = min(px, W - 1);
 #ifdef MV_RASTER_TIMING
@@ -1912,7 +1916,7 @@ __device__ __forceinline__ void raster_glist_body(const FastArgs &fa, uint32_t *
             RT_COUNT(14, 1);   // tiles that met nothing
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
-                const int py = py0 + TILE_H * j;
+                const int py = py0 + GT_H * j;
                 if (px < W && py < H) PIXEL_STORE(out[(unsigned)(py * W + px)], 0xff000000u);
             }
             continue;
@@ -1927,7 +1931,7 @@ __device__ __forceinline__ void raster_glist_body(const FastArgs &fa, uint32_t *
             dcx = cx.x;
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
-                const int pyc = min(py0 + TILE_H * j, H - 1);
+                const int pyc = min(py0 + GT_H * j, H - 1);
                 const float4 ry = s_row[pyc];
                 const float2 rq = s_rowq[pyc];
                 dcy[j] = ry.x;
@@ -1969,6 +1973,8 @@ __device__ __forceinline__ void raster_glist_body(const FastArgs &fa, uint32_t *
                 boxes |= m1 | m2 | m3;
             }
             unsigned long long rest = mvis & ~boxes;   // camera-attached boxes, capsules, cones, scaled shapes (and, not HEXF, wall-frame boxes)
+            RT_COUNT(4, __popcll(boxes));   // slab tests
+            RT_COUNT(5, __popcll(rest));    // other primitives tested
             while (rest) {
                 const int pos = __ffsll((long long)rest) - 1 + 64 * k;
                 rest &= rest - 1;
@@ -1998,7 +2004,7 @@ __device__ __forceinline__ void raster_glist_body(const FastArgs &fa, uint32_t *
                     const unsigned bound = floorD > NEAR_Z ? __float_as_uint(floorD) - KEY_NEAR : 0u;          // in the units of the depth keys; 0: never stop here
                     bool covered = true;
 #pragma unroll
-                    for (int j = 0; j < NP; ++j) covered = covered && (best[j].d < bound || px >= W || py0 + TILE_H * j >= H);
+                    for (int j = 0; j < NP; ++j) covered = covered && (best[j].d < bound || px >= W || py0 + GT_H * j >= H);
                     if (__all(covered)) { RT_COUNT(15, 1); break; }
                 }
                 RT_COUNT(11, 1);   // rounds of the list walked
@@ -2026,7 +2032,8 @@ __device__ __forceinline__ void raster_glist_body(const FastArgs &fa, uint32_t *
                 const float4 lo = gp[2 * wpos], hi = gp[2 * wpos + 1];
                 rgba = shade_rec<SHAPES>(lo, hi, __uint_as_float(best[j].d + KEY_NEAR), bn[j], s_hdr, camv, viewer, dw[j], inv[j], dcx, dcy[j], a2[j], ldc[j]);
             }
-            const int py = py0 + TILE_H * j;
+            RT_COUNT(3, __popcll(__ballot(best[j].d <= KEY_FAR)));   // pixels with a hit
+            const int py = py0 + GT_H * j;
             if (px < W && py < H) PIXEL_STORE(out[(unsigned)(py * W + px)], rgba);
         }
     }
@@ -2256,7 +2263,11 @@ static void rdbg_dump()
                     c[10], double(c[11]) / c[10], double(c[12]) / c[10], double(c[15]) / c[10], double(c[13]) / c[10],
                                   double(c[14]) / c[10], double(c[9]) / c[10], double(c[8]) / c[10],
                     double(c[7]) / c[10], double(c[6]) / c[10]);
-        if (got && c[4])
+        if (got && c[10])
+            fprintf(stderr, "long-list census, tests: %.2f slab tests and %.2f other primitives per tile (%.2f / %.2f per tile that meets anything), %.1f of a tile's "
+                    "pixels hit something\n", double(c[4]) / c[10], double(c[5]) / c[10], double(c[4]) / double(c[10] - c[14]), double(c[5]) / double(c[10] - c[14]),
+                    double(c[3]) / c[10]);
+        if (got && c[4] && !c[10])
             fprintf(stderr, "raster census (all launches): classified tiles %llu (empty %llu, planar %llu of which %llu without the highlight test, covered "
                     "+ overlay %llu), unclassified %llu, general-path tiles %llu: "
                             "slab tests %.2f and other primitives %.2f per tile\n",
