@@ -103,10 +103,27 @@ __global__ __launch_bounds__(64 * WAVES, MV_UNION_TICKS_WAVES_PER_SIMD) void ste
     }
 }
 
-void launch_step_union_ticks(const UnionTicksArgs &ua, hipStream_t stream, int W, int H, hipEvent_t done)
+void launch_step_union_ticks(const UnionTicksArgs &ua0, hipStream_t stream, int W, int H, hipEvent_t done)
 {
     bool anyLong = false;
-    for (int i = 0; i < ua.n; ++i) anyLong = anyLong || ua.gv[i].vis_stride > VIS_SMALL;
+    for (int i = 0; i < ua0.n; ++i) anyLong = anyLong || ua0.gv[i].vis_stride > VIS_SMALL;
+    // The gyms with long frame lists LAST, whatever the group's order.  Workgroups start in the order of their ids, and a long-list env's workgroup is the
+    // launch's heaviest (four waves of 168 VGPRs for the whole call): started first they take the chip from the previous call's observation launch, which the
+    // short ones beside them leave room for -- Mixed 64 x 64 (eight scenarios x 128 envs), long lists first / in MEGAVERSE8's order / last: 15.3-17.2 /
+    // 19.1-19.5 / 19.5-19.6 M obs/s (r10m).  (Which block steps which env is this launch's own business: every env's results go to its own gym's arrays.)
+    static const int longFirst = getenv("MV_UNION_LONG_FIRST") ? atoi(getenv("MV_UNION_LONG_FIRST")) : 2;   // 1: long lists first, 2: last, 0: the group's order
+    UnionTicksArgs ua = ua0;
+    if (anyLong && longFirst) {
+        int m = 0, envs = 0;
+        for (int pass = 0; pass < 2; ++pass)
+            for (int i = 0; i < ua0.n; ++i)
+                if ((ua0.gv[i].vis_stride > VIS_SMALL) == (pass == (longFirst == 2 ? 1 : 0))) {
+                    ua.gv[m] = ua0.gv[i]; ua.slot_stride[m] = ua0.slot_stride[i]; ua.first[m] = envs;
+                    envs += ua0.first[i + 1] - ua0.first[i];
+                    ++m;
+                }
+        for (int i = m; i <= MAX_UNION; ++i) ua.first[i] = envs;
+    }
     static const int wideWaves = getenv("MV_UNION_TICKS_WAVES") ? atoi(getenv("MV_UNION_TICKS_WAVES")) : 4;   // (2: measured in r09f)
     if (anyLong && wideWaves == 2) hipExtLaunchKernelGGL(step_union_ticks_kernel<2>, dim3(ua.first[ua.n]), dim3(128), 0, stream, nullptr, done, 0, ua, W, H);
     else if (anyLong) hipExtLaunchKernelGGL(step_union_ticks_kernel<4>, dim3(ua.first[ua.n]), dim3(256), 0, stream, nullptr, done, 0, ua, W, H);
