@@ -711,6 +711,16 @@ def main():
         torch.cuda.synchronize()
         extra_env["env_step_batched"] = (time.perf_counter() - t0, n_b)
         assert tuple(obs_t.shape) == (frames, 3, H, W) and obs_t.is_cuda
+        # env_step_device: step_device(device action tensor) -> three device tensors, no host synchronisation: the Python class with a policy on the device
+        for i in range(5):
+            env.step_device(dev_acts[i % 4])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_b):
+            obs_t, rew_t, dn_t = env.step_device(dev_acts[i % 4])
+        torch.cuda.synchronize()
+        extra_env["env_step_device"] = (time.perf_counter() - t0, n_b)
+        assert obs_t.is_cuda and rew_t.is_cuda and dn_t.is_cuda and tuple(rew_t.shape) == (frames,) and tuple(dn_t.shape) == (n_env,)
         env.close()
     else:
         extra_env = {}
@@ -793,7 +803,8 @@ def main():
             line["ms_per_step_" + key] = el / n * 1e3
         if extra_env:
             line["env_step_note"] = ("value_env_step = megaverse_amd.MegaverseEnv.step(list of actions): the reference's Python surface, incl. one device-to-host copy of the RGBA slab "
-                                     "(%.0f MB over PCIe per step) and the per-agent lists; value_env_step_batched = step_batched(device action tensor): observations stay in HBM" % (frames * H * W * 4 / 1e6))
+                                     "(%.0f MB over PCIe per step) and the per-agent lists; value_env_step_batched = step_batched(device action tensor): observations stay in HBM, rewards and dones are read back; "
+                                     "value_env_step_device = step_device(device action tensor): all three outputs stay on the device, no host synchronisation" % (frames * H * W * 4 / 1e6))
         if "closed_loop" in extra:
             line["host_enqueue_ms_per_step_closed_loop"] = host_enqueue_ms_loop
         if "closed_loop_double_buffered" in extra:

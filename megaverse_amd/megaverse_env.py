@@ -8,7 +8,7 @@ conventions: ``reset() -> [obs]*num_agents`` with obs uint8 (3, H, W) *un-flippe
 
 Differences, all additive:
   * img_w/img_h are constructor keywords (reference hard-codes 128x72, megaverse_env.py:51-52);
-  * ``step_batched`` / ``observations_tensor`` return one device tensor instead of O(num_agents)
+  * ``step_batched`` / ``step_device`` / ``observations_tensor`` return one device tensor instead of O(num_agents)
     numpy views (the Python loops at megaverse_env.py:121-130,138-141 cap the reference well below
     the GPU's rate);
   * gym and cv2 are optional.
@@ -78,6 +78,7 @@ class MegaverseEnv:
         self.observation_space = spaces.Box(0, 255, (self.channels, self.img_h, self.img_w), dtype=np.uint8)
         self._obs_tensor = None
         self._host_obs = None
+        self._dev_out = None
 
     @staticmethod
     def generate_action_space(action_space_sizes):
@@ -164,6 +165,29 @@ class MegaverseEnv:
         self.env.step()
         del held
         return self.observations_tensor(), self.env.get_rewards_array(), self.env.get_dones().astype(bool)
+
+    def step_device(self, actions=None):
+        """step_batched without a host synchronisation: (obs uint8 (num_agents, 3, H, W), rewards float32 [num_agents], dones uint8 [num_envs]), all three
+        CUDA tensors the step writes into (mv_set_output_ring with one entry), valid in the order of the gym's stream -- torch's current stream when the
+        env's first observation was asked for -- until the next step.  What a learner whose policy runs on the device wants (the reference has no
+        counterpart: its outputs are host arrays, megaverse_env.py:121-162); `infos` / true rewards stay available through env.get_true_objectives()."""
+        torch = self._torch()
+        if self._obs_tensor is None:
+            self.observations_tensor()
+        if self._dev_out is None:
+            dev = self._obs_tensor.device
+            self._dev_out = (torch.zeros(self.num_agents, dtype=torch.float32, device=dev), torch.zeros(self.num_envs, dtype=torch.uint8, device=dev))
+            self.env.set_output_ring(1, self._obs_tensor.data_ptr(), self._dev_out[0].data_ptr(), self._dev_out[1].data_ptr())
+        held = None
+        if actions is not None:
+            if hasattr(actions, 'data_ptr'):   # (the lifetime rule of step_batched)
+                held = actions.to(dtype=torch.int32).contiguous()
+                self.env.set_actions_device(held.data_ptr())
+            else:
+                self.env.set_actions_batched(actions)
+        self.env.step()
+        del held
+        return self._obs_tensor[..., :3].permute(0, 3, 1, 2), self._dev_out[0], self._dev_out[1]
 
     # ---- rendering (megaverse_env.py:164-184): returns the tiled BGR image, shows it if cv2 exists ----
     def convert_obs(self, obs):

@@ -115,6 +115,39 @@ def test_batched_device_observations(hip):
     e.close()
 
 
+def test_step_device_equals_step_batched(hip):
+    """step_device: the same ticks as step_batched, its three outputs device tensors, no host synchronisation between steps; a policy on the device in the loop"""
+    import torch
+    spaces_t = torch.tensor([3, 3, 3, 2, 2, 3], dtype=torch.int32, device='cuda')
+
+    def rollout(device_outputs):
+        e = MegaverseEnv('TowerBuilding', 12, 2, 1, img_w=64, img_h=64, params={'episodeLengthSec': -300.0})
+        e.seed(5)
+        e.reset()
+        obs = e.observations_tensor()
+        rewards, dones, frames = [], [], []
+        for st in range(70):   # (negative episode length, as in the reference's test_env.py:57-88: the envs reset inside the rollout)
+            acts = ((obs.reshape(24, -1)[:, 37:37 + 6 * 97:97].to(torch.int32) + st) % spaces_t).contiguous()
+            if device_outputs:
+                obs, r, d = e.step_device(acts)
+                rewards.append(r.clone()); dones.append(d.clone())
+            else:
+                obs, r, d = e.step_batched(acts)
+                rewards.append(torch.from_numpy(r)); dones.append(torch.from_numpy(d.astype(np.uint8)))
+            if st % 23 == 0:
+                frames.append(obs.clone())
+        torch.cuda.synchronize()
+        out = (torch.stack([r.cpu() for r in rewards]).numpy(), torch.stack([d.cpu() for d in dones]).numpy(), torch.stack(frames).cpu().numpy(),
+               e.env.get_rewards_array().copy(), e.env.get_dones().copy())
+        e.close()
+        return out
+
+    a, b = rollout(True), rollout(False)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])   # (the host getters read the ring's entry)
+    assert b[1].sum() > 0                                                # an episode ended on the way
+
+
 def test_rl_wrapper_bookkeeping(hip):
     """megaverse_rl/megaverse_utils.py:30-93: 5-tuple step, per-episode extra stats, team-spirit annealing"""
     from types import SimpleNamespace
