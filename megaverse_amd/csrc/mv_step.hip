@@ -159,15 +159,22 @@ __global__ __launch_bounds__(128, MV_STEP_TICKS_WAVES_PER_SIMD) void step_ticks_
     }
 }
 
-// MV_STEP_PIPE=1 selects the two-wave kernels.  Measured (r09a / r09b / r09d, M obs/s, one wave / two): ALONE on the chip the step launch is a quarter shorter
-// (TowerBuilding 16.6 -> 12.3 us per tick: 98 us per 8 ticks, Empty 16.9 -> 14.5) -- but beside the observation passes, where the batched calls run it, its
-// length follows the passes' VALU load, not its own dependent chains: TowerBuilding 28.7 / 28.2, Empty 45.8 / 47.0, ObstaclesHard 512 envs 20.8 / 21.2, 1024
-// envs 26.3 / 23.6 (the Obstacles tick spills at 128 VGPRs with the frame setup's registers beside it; at 168: 24.4), the driver's 20-step form 22.9 / 23.2.
-// Off by default: twice the resident waves for +-2 %.
-bool step_pipe_enabled()
+// When the two-wave kernels run.  ALONE on the chip their launch is a quarter shorter (TowerBuilding 16.6 -> 12.3 us per tick: 98 us per 8 ticks, Empty 16.9 ->
+// 14.5, r09a); beside the observation passes of a FULL chip -- 1024 envs: a resident wave on every SIMD -- its length follows the passes' vector load, not its
+// own dependent chains, and the second wave per env is registers the passes lose: TowerBuilding 32.8 / 32.1 M obs/s (one wave / two), ObstaclesHard 28.6 / 26.1
+// (r09z, r10r).  With fewer envs than SIMDs the second wave is free and the step launch is what a call waits for (r10s, one wave / two, M obs/s):
+//   envs           256            512            768
+//   TowerBuilding  11.6 / 16.9    24.0 / 25.2    28.5 / 28.2
+//   ObstaclesHard  11.6 / 14.0    20.7 / 23.1    26.0 / 26.3      (512: one GPU's share of BASELINE configs[2])
+//   ObstaclesEasy  12.3 / 14.0    21.3 / 23.8    26.5 / 27.3
+//   Empty          15.4 / 17.9    26.1 / 33.1    35.4 / 44.6      (1024: 45.8 / 47.0)
+// So: up to 512 envs always, the Obstacles family up to 768, Empty at any size.  MV_STEP_PIPE=0 / 1 forces one or the other (read at every launch: tests switch).
+bool step_pipe_enabled(const GymView &gv)
 {
-    static const bool on = getenv("MV_STEP_PIPE") && atoi(getenv("MV_STEP_PIPE")) != 0;
-    return on;
+    const char *e = getenv("MV_STEP_PIPE");
+    if (e && *e) return atoi(e) != 0;
+    const bool obstFamily = gv.scenario == SCN_OBSTACLES || gv.scenario == SCN_EMPTY;
+    return gv.num_envs <= 512 || (obstFamily && gv.num_envs <= 768) || gv.scenario == SCN_EMPTY;
 }
 
 void launch_step_ticks(const GymView *views, int k, hipStream_t stream, int W, int H, hipEvent_t done)
@@ -179,7 +186,7 @@ void launch_step_ticks(const GymView *views, int k, hipStream_t stream, int W, i
     StepTicksArgs8 a;   // (k <= 8: the views are the launch's arguments)
     a.n = k; a.pad = 0;
     for (int j = 0; j < 8; ++j) a.gv[j] = views[std::min(j, k - 1)];
-    if (gv.num_agents == 1 && step_pipe_enabled()) hipExtLaunchKernelGGL(step_ticks_pipe_kernel<StepTicksArgs8>,
+    if (gv.num_agents == 1 && step_pipe_enabled(gv)) hipExtLaunchKernelGGL(step_ticks_pipe_kernel<StepTicksArgs8>,
         grid, dim3(128), 0, stream, nullptr, done, 0, a, W, H);
     else if (gv.num_agents == 1) hipExtLaunchKernelGGL(step_ticks_kernel<StepTicksArgs8>, grid, block, 0, stream, nullptr, done, 0, a, W, H);
     else hipExtLaunchKernelGGL(step_ticks_agents_kernel<StepTicksArgs8>, grid, block, 0, stream, nullptr, done, 0, a, W, H);

@@ -96,14 +96,14 @@ __global__ __launch_bounds__(128, MV_STEP_TICKS_WAVES_PER_SIMD) void step_obstac
     }
 }
 
-bool step_pipe_enabled();   // mv_step.hip
+bool step_pipe_enabled(const GymView &gv);   // mv_step.hip
 
 void launch_step_obstacles_ticks(const GymView *views, int k, hipStream_t stream, int W, int H, hipEvent_t done)
 {
     StepTicksArgs8 a8;   // (k <= 8: the views are the launch's arguments, mv_types.h)
     a8.n = k; a8.pad = 0;
     for (int j = 0; j < 8; ++j) a8.gv[j] = views[std::min(j, k - 1)];
-    if (step_pipe_enabled()) hipExtLaunchKernelGGL(step_obstacles_ticks_pipe_kernel<StepTicksArgs8>,
+    if (step_pipe_enabled(views[0])) hipExtLaunchKernelGGL(step_obstacles_ticks_pipe_kernel<StepTicksArgs8>,
         dim3(views[0].num_envs), dim3(128), 0, stream, nullptr, done, 0, a8, W, H);
     else hipExtLaunchKernelGGL(step_obstacles_ticks_kernel<StepTicksArgs8>, dim3(views[0].num_envs), dim3(64), 0, stream, nullptr, done, 0, a8, W, H);
 }

@@ -210,6 +210,45 @@ def test_step_n_equals_k_single_steps(hip, monkeypatch, scenario, A, params):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("pipe", ["0", "1"])
+@pytest.mark.parametrize("scenario,params", [("TowerBuilding", {"episodeLengthSec": -200.0}), ("ObstaclesHard", {}), ("ObstaclesEasy", {"episodeLengthSec": -250.0}),
+                                             ("Empty", {})])
+def test_both_resident_step_kernels_equal_single_steps(hip, monkeypatch, scenario, params, pipe):
+    """The resident multi-tick step launch has two flavours -- one wave per env, or two (wave 0 ticks while wave 1 sets the previous tick's frame up:
+    step_ticks_pipe_kernel / step_obstacles_ticks_pipe_kernel) -- chosen by env count (mv_step.hip: step_pipe_enabled); MV_STEP_PIPE forces one.  Either must
+    leave what single ticks leave: state, outputs, every frame of every ring entry of the last call."""
+    import torch
+    monkeypatch.setenv("MV_STEP_PIPE", pipe)
+    N, W, H, K = 40, 64, 64, 8
+    obs = torch.zeros((K, N, H, W, 4), dtype=torch.uint8, device="cuda:0")
+
+    def make():
+        g = MegaverseGym(scenario, W, H, N, 1, 2, False, params)
+        g.set_pixel_mode("fast"); g.seed(31); g.reset()
+        return g
+
+    a, b = make(), make()
+    b.set_output_ring(K, obs.data_ptr())
+    calls = 9
+    frames = []
+    for st in range(calls * K):
+        a.sample_random_actions(77, st); a.step()
+        if st >= (calls - 1) * K:
+            frames.append(np.stack([a.get_observation(e, 0) for e in range(N)]))
+    for c in range(calls):
+        b.step_n(K, "multidiscrete", 77, c * K)
+    a.synchronize(); b.synchronize(); torch.cuda.synchronize()
+    for e in range(N):
+        assert a.debug_snapshot_bytes(e).tobytes() == b.debug_snapshot_bytes(e).tobytes(), e
+    assert a.get_rewards_array().tobytes() == b.get_rewards_array().tobytes()
+    assert np.array_equal(a.get_dones(), b.get_dones())
+    ring = obs.cpu().numpy()
+    for j in range(K):
+        assert np.array_equal(ring[j], frames[j]), j
+    assert ring[..., :3].max() > 0
+    a.close(); b.close()
+
+
 def test_step_n_against_the_oracle(hip):
     """the batched call against the CPU oracle directly (not only against the single-step path): state, rewards, dones after 200 ticks with resets"""
     scenario, N, A, W, H = "TowerBuilding", 16, 2, 48, 32
