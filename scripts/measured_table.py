@@ -27,7 +27,11 @@ ROWS = [("tower_bench.json", "**TowerBuilding 1024 envs x 1, 128x128 (BASELINE c
         ("tower_exact_pixels_bench.json", "same as the headline, exact pixels (`--pixels exact`)"),
         ("tower_single_bit_bench.json", "same, the reference benchmark's single-bit policy (`--policy single-bit`)"),
         ("tower_planar_off_bench.json", "same, tiles not classified (`MV_PLANAR=0`)"),
-        ("tower_step_pipe_bench.json", "same, the two-wave step kernels (`MV_STEP_PIPE=1`)"),
+        ("tower_step_pipe_bench.json", "same, the two-wave step kernels (`MV_STEP_PIPE=1`; the rule takes one wave at 1024 envs)"),
+        ("tower_256_bench.json", "TowerBuilding 256 envs x 1 (two-wave step kernels by the rule)"),
+        ("tower_512_one_wave_step_bench.json", "TowerBuilding 512 envs x 1, one-wave step kernels (`MV_STEP_PIPE=0`)"),
+        ("obstacles_hard_512_one_wave_step_bench.json", "ObstaclesHard 512 envs x 1, one-wave step kernels (`MV_STEP_PIPE=0`)"),
+        ("Empty_one_wave_step_bench.json", "Empty 1024 x 1, one-wave step kernels (`MV_STEP_PIPE=0`)"),
         ("tower_normal_priority_bench.json", "same, simulation stream at default priority (`MV_SIM_PRIORITY=normal`)"),
         ("obstacles_hard_512_normal_priority_bench.json", "ObstaclesHard 512, overlapped passes, `MV_SIM_PRIORITY=normal`")]
 
