@@ -223,7 +223,8 @@ class ObsGather:
         self.dist, self.torch, self.cuda, self.mode, self.world = dist, torch, cuda, mode, world
         self.rank = dist.get_rank() if world > 1 else 0
         self.n_local = local_shape[0]
-        # local: the two buffers the gym renders into, handed in -- the two halves of a batched call's output ring, k slabs each: ONE collective per call of k ticks
+        # local: the two buffers the gym renders into, handed in -- the two halves of a batched call's output ring, k slabs each: ONE collective per call of k
+        # ticks
         self.local = local if local is not None else [torch.zeros(local_shape, dtype=torch.uint8, device=device) for _ in range(2)]
         # channels = 3: what travels is R, G, B (alpha is 255 everywhere): a packing kernel on the communication stream, 3/4 of the link traffic
         self.channels = channels
@@ -385,12 +386,12 @@ def main():
     n_env, A = args.envs_per_gpu, args.agents
     mixed = args.scenario.lower() in ("mixed", "mixed4")
     frames = n_env * A
-    # ticks per stepping call: 16 -- one tail of the observation launch per 16 ticks -- where the observation passes are what a call waits for, 8 where the
-    # step launch is (it grows per tick with the call's length).  Measured, 16 against 8 (M obs/s, `profiles/r08y_*`, `r08p`): TowerBuilding 1024 envs 28.5 / 26.8,
-    # ObstaclesHard 1024 24.5 / 22.7, Rearrange 23.7 / 21.5, Collect 15.0 / 14.5; 512 envs 16.2 / 19.3, ObstaclesHard 512 13.2 / 18.8, Sokoban 19.9 / 25.9,
-    # 512 envs x 4 agents 19.5 / 26.0, 4096 envs 28.4 / 30.5.  Hence: 1024 ... 2047 frames, not Sokoban.
-    # The rule itself lives behind the ABI (mv_recommended_ticks_per_call, include/megaverse_hip.h): --batch 0 asks the library, after the gym exists; an explicit
-    # --batch sizes the gym's slot groups for it (MV_PIPE_BATCH, read by mv_create).
+    # ticks per stepping call: 16 -- one tail of the observation launch per 16 ticks -- where the observation passes are what a call waits for, 8 where the step
+    # launch is (it grows per tick with the call's length).  Measured, 16 against 8 (M obs/s, `profiles/r08y_*`, `r08p`): TowerBuilding 1024 envs 28.5 / 26.8,
+    # ObstaclesHard 1024 24.5 / 22.7, Rearrange 23.7 / 21.5, Collect 15.0 / 14.5; 512 envs 16.2 / 19.3, ObstaclesHard 512 13.2 / 18.8, Sokoban 19.9 / 25.9, 512
+    # envs x 4 agents 19.5 / 26.0, 4096 envs 28.4 / 30.5.  Hence: 1024 ... 2047 frames, not Sokoban. The rule itself lives behind the ABI
+    # (mv_recommended_ticks_per_call, include/megaverse_hip.h): --batch 0 asks the library, after the gym exists; an explicit --batch sizes the gym's slot
+    # groups for it (MV_PIPE_BATCH, read by mv_create).
     if args.batch > 0:
         os.environ.setdefault("MV_PIPE_BATCH", str(max(8, min(16, args.batch))))
     if dry:
@@ -403,7 +404,8 @@ def main():
         gym.set_pixel_mode(args.pixels)
     else:
         from megaverse_amd.extension import MegaverseGym
-        gym = MegaverseGym(args.scenario, W, H, n_env, A, 0, False, {},   # 0 = episode-feeder threads: this rank's share of the host's cores (host-generated scenarios)
+        # 0 = episode-feeder threads: this rank's share of the host's cores (host-generated scenarios)
+        gym = MegaverseGym(args.scenario, W, H, n_env, A, 0, False, {},
                            device=local_rank, env_offset=rank * n_env, total_envs=world * n_env)
         gym.set_stream(torch.cuda.current_stream().cuda_stream)
         gym.set_pixel_mode(args.pixels)
@@ -418,11 +420,12 @@ def main():
     # batched stepping: tick j of a call renders into slab j of a ring, so that all `batch` observations of a call exist side by side when it
     # is done (a k-step rollout buffer) -- the working set of the observation writes is batch x one slab, not one slab written over and over
     batched = batch > 1 and (not dry or world > 1)
-    # N > 1 with the gather on: the SAME batched calls as the N = 1 headline -- a call renders its k ticks into one half of a ring of 2 k slabs
-    # while the collective for the other half (the previous call's k slabs) runs on the communication stream: one collective per call, not one per tick
+    # N > 1 with the gather on: the SAME batched calls as the N = 1 headline -- a call renders its k ticks into one half of a ring of 2 k
+    # slabs while the collective for the other half (the previous call's k slabs) runs on the communication stream: one collective per call, not one per tick
     gather_batched = do_gather and batched and not mixed
     # (slabs of the output ring: a call never holds more ticks than `batch`; two calls deep, the passes of consecutive calls overlap: mv_set_pass_overlap)
-    pass_overlap = batched and not mixed and (args.pass_overlap == "on" or (args.pass_overlap == "auto" and gym.recommended_pass_overlap()))   # (the rule: mv_recommended_pass_overlap)
+    # (the rule: mv_recommended_pass_overlap)
+    pass_overlap = batched and not mixed and (args.pass_overlap == "on" or (args.pass_overlap == "auto" and gym.recommended_pass_overlap()))
     if gather_batched:
         pass_overlap = False   # (the ring's two halves belong to the gather pipeline)
     ring_slots = 2 * batch if gather_batched else (max(batch, 8) * (2 if pass_overlap else 1)) if batched else 1
@@ -494,8 +497,8 @@ def main():
 
     def run_steps(first, n, with_gather, use_batch):
         if use_batch and with_gather:
-            # one collective per CALL: call c renders its k ticks into half c & 1 of the ring (entries (c & 1) k ...: the ring restarts with every region) while the
-            # collective of the previous call's half runs on the communication stream; the step / observation launches are the N = 1 headline's
+            # one collective per CALL: call c renders its k ticks into half c & 1 of the ring (entries (c & 1) k ...: the ring restarts with every region) while
+            # the collective of the previous call's half runs on the communication stream; the step / observation launches are the N = 1 headline's
             set_ring()
             i = c = 0
             while i < n:
@@ -516,7 +519,8 @@ def main():
             # ticks are stepped, so the first calls are short -- 2 ticks, then 4, then 6, then --batch (measured on 20-step runs, three each, r07c:
             # 2,4,6: 20.8-21.0 M obs/s; 1,3: 20.3-21.6; 1,3,4,4: 20.9; 3,8: 20.3-20.9; 2,2,4,4: 20.1-20.2; r05k: 19.0-19.1 M with 2 ticks per call throughout
             # and 19.2-19.7 M with 8).  MV_BENCH_CALL_SCHEDULE=a,b,...: other first calls.
-            sched = [int(x) for x in os.environ.get("MV_BENCH_CALL_SCHEDULE", "2,4,6" if world == 1 else "").split(",") if x]   # (N > 1: calls of `batch` ticks throughout, like the gather-on leg)
+            # (N > 1: calls of `batch` ticks throughout, like the gather-on leg)
+            sched = [int(x) for x in os.environ.get("MV_BENCH_CALL_SCHEDULE", "2,4,6" if world == 1 else "").split(",") if x]
             while i < n:
                 k = min(sched.pop(0) if sched else batch, n - i, max(batch, 8))
                 gym.step_n(k, args.policy, 1234, first + i)
@@ -676,10 +680,11 @@ def main():
                 h[0].close()
 
     # env_step / env_step_batched: what a drop-in user of the reference's Python class calls (megaverse/megaverse_env.py:132-162 <->
-    # megaverse_amd/megaverse_env.py).  env_step: MegaverseEnv.step(list of per-agent actions) -> (list of per-agent (3, H, W) numpy frames, rewards, dones, infos) --
-    # the reference's exact shape, which here includes ONE device-to-host copy of the whole RGBA slab per step over PCIe (the reference's getObservation is a view of
-    # host memory, megaverse.cpp:139-143: its frames never leave the host) and the per-agent list building; env_step_batched: step_batched(device action tensor) ->
-    # (device view of the slab, rewards, dones): observations stay in HBM, two small read-backs per step.  Actions are drawn ahead (the sampler is not the surface).
+    # megaverse_amd/megaverse_env.py).  env_step: MegaverseEnv.step(list of per-agent actions) -> (list of per-agent (3, H, W) numpy frames, rewards, dones,
+    # infos) -- the reference's exact shape, which here includes ONE device-to-host copy of the whole RGBA slab per step over PCIe (the reference's
+    # getObservation is a view of host memory, megaverse.cpp:139-143: its frames never leave the host) and the per-agent list building; env_step_batched:
+    # step_batched(device action tensor) -> (device view of the slab, rewards, dones): observations stay in HBM, two small read-backs per step.  Actions are
+    # drawn ahead (the sampler is not the surface).
     if not dry and not mixed and world == 1 and not args.no_extra_legs:
         import numpy as np
         from megaverse_amd.megaverse_env import MegaverseEnv
@@ -788,7 +793,8 @@ def main():
                        "pipelined": pipelined, "ticks_per_call": batch if main_batched else 1,
                        **({"ring_slots": ring_slots, "overlapped_passes": bool(pass_overlap)} if main_batched else {}),
                        **({"first_calls": os.environ.get("MV_BENCH_CALL_SCHEDULE", "2,4,6") + " ticks, then ticks_per_call (every tick stepped and rendered in full)"} if main_batched else {}),
-                       # (a batched group call is two launches where all of the group's envs are resident at once -- up to 1024 -- else two per tick: mv_api_step.hip, groupBatch)
+                       # (a batched group call is two launches where all of the group's envs are resident at once -- up to 1024 -- else two per tick:
+                       # mv_api_step.hip, groupBatch)
                        **({"launches_per_call": 2 * ((batch + 7) // 8) if main_batched and n_env <= 1024 else None, "launches_per_tick": None if main_batched and n_env <= 1024 else 2,
                            "scenarios": ", ".join(gym.scenarios) + " dealt round-robin by env index (one gym per scenario, stepped as one mv_group: "
                                         + ("one step launch and one observation launch per batched CALL, every scenario's ticks in its own rollout rings)" if main_batched and n_env <= 1024
@@ -839,8 +845,8 @@ def main():
                               "xgmi_peak_GBps_per_gpu": XGMI_PEAK_GBS,
                               # what the links allow: every GPU receives (world - 1) shards per step over its 7 point-to-point links
                               "xgmi_bound_ms_per_step": (world - 1) * slab_bytes / (XGMI_PEAK_GBS * 1e9) * 1e3,
-                              # the gather-on leg runs the N = 1 headline's batched calls: ONE collective per call of ticks_per_call ticks (the call's half of a ring of
-                              # 2 x ticks_per_call slabs) beside the next call's launches; tick by tick (Mixed, --batch 1): one collective per tick
+                              # the gather-on leg runs the N = 1 headline's batched calls: ONE collective per call of ticks_per_call ticks (the call's half of a
+                              # ring of 2 x ticks_per_call slabs) beside the next call's launches; tick by tick (Mixed, --batch 1): one collective per tick
                               "collectives_per_call": 1, "ticks_per_collective": batch if gather_batched else 1,
                               "bytes_received_per_gpu_per_collective": (world - 1) * slab_bytes * (batch if gather_batched else 1),
                               "xgmi_bound_ms_per_collective": (world - 1) * slab_bytes * (batch if gather_batched else 1) / (XGMI_PEAK_GBS * 1e9) * 1e3,
@@ -861,8 +867,9 @@ def main():
             achieved = bytes_per_frame * frames / (raster_ms * 1e-3) / 1e9 if raster_ms > 0 else 0.0
             achieved_step = step_bytes_per_env * n_env / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
             long_list = args.scenario.lower() in ("collect", "hexmemory", "hexexplore")
-            # the k ticks of a call as ONE step launch (step_ticks_kernel / step_<scenario>_ticks_kernel: one agent per env, TowerBuilding also with several) and its
-            # k observation passes as ONE launch (raster_fast_batch_kernel, raster_glist_batch_kernel for the long lists): mv_api.hip, canMultiTick / canBatchRaster
+            # the k ticks of a call as ONE step launch (step_ticks_kernel / step_<scenario>_ticks_kernel: one agent per env, TowerBuilding also with several)
+            # and its k observation passes as ONE launch (raster_fast_batch_kernel, raster_glist_batch_kernel for the long lists): mv_api.hip, canMultiTick /
+            # canBatchRaster
             batch_step = batched and not mixed and (A == 1 or args.scenario == "TowerBuilding") and os.environ.get("MV_STEP_TICKS", "1") != "0"
             fam = {"towerbuilding": "", "collect": "collect_", "rearrange": "rearrange_", "sokoban": "sokoban_", "hexmemory": "hex_", "hexexplore": "hex_"}.get(args.scenario.lower(), "obstacles_")
             ticks_kernel_name = "step_ticks_agents_kernel" if A > 1 else "step_%sticks_kernel" % fam
@@ -890,14 +897,16 @@ def main():
                                             # (rocprofv3's derived VALUBusy of the same passes: 91 % for this kernel alone on the chip, profiles/r06s_*)
                                             "valu_busy_frac_at_2.4GHz": (valu["active_inst_valu_quadcycles"] * 4.0 / 1024.0 / (raster_ms * 1e-3 * 2.4e9)) if valu.get("active_inst_valu_quadcycles") else None,
                                             "source": valu.get("source")}
-            if lds:   # north_star: "LDS hit rate on the raster tile" -- an LDS access has no miss, only bank-conflict replays: the counters of the committed SQ passes, per tick
+            # north_star: "LDS hit rate on the raster tile" -- an LDS access has no miss, only bank-conflict replays: the counters of the committed SQ passes,
+            # per tick
+            if lds:
                 line["roofline"]["lds"] = dict(lds, note="LDS instructions per tick (wave-level), quad-cycles the LDS pipe was busy / replaying bank conflicts; hit rate = 1 - conflict_frac")
             line["roofline_physics"] = {"bound": "latency", "kernel": (("mv::step_union_ticks_kernel (the k ticks of all scenarios in one launch; per tick)" if batched and n_env <= 1024 else "mv::step_union_kernel") if mixed else "mv::%s (the %d ticks of a call in %d launch%s; per tick)" % (ticks_kernel_name, batch, (batch + 7) // 8, "es of 8" if batch > 8 else "") if batch_step else "mv::step_kernel") +
                                                               " (voxel physics + scenario logic + auto-reset + frame setup)", "ticks_per_launch": min(batch, 8) if batch_step else 1, "achieved": achieved_step,
                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_step / HBM_PEAK_GBS, "traffic": traffic_step,
                                         "avg_launch_ms": step_ms, "launches_timed": prof["step"][1], "algorithmic_bytes_per_launch": step_bytes_per_env * n_env,
-                                        # the same launch priced with SURVEY 8(d)'s per-env figure (17.9 KB for one agent, 18.7 KB for four: the 16 KB voxel chunk
-                                        # counted as read every tick -- which this kernel does NOT do: it works from the box lists, DESIGN.md header)
+                                        # the same launch priced with SURVEY 8(d)'s per-env figure (17.9 KB for one agent, 18.7 KB for four: the 16 KB voxel
+                                        # chunk counted as read every tick -- which this kernel does NOT do: it works from the box lists, DESIGN.md header)
                                         "survey_bytes_per_env": 17900 + (A - 1) * 267,
                                         "frac_survey_bytes": ((17900 + (A - 1) * 267) * n_env / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if step_ms else None,
                                         "note": "north_star's >=40 % HBM target names this kernel and is NOT met in either convention (`frac`: the bytes the kernel moves; "
@@ -910,7 +919,8 @@ def main():
         line["checksum"] = checksum
         if world == 1 and not args.no_cpu_baseline and not dry:
             if mixed:
-                line["cpu_baseline"] = cpu_baseline_mixed(list(gym.scenarios), W, H, n_env, A)   # (the same scenario set the GPU gym ran: Mixed4's four, not the eight)
+                # (the same scenario set the GPU gym ran: Mixed4's four, not the eight)
+                line["cpu_baseline"] = cpu_baseline_mixed(list(gym.scenarios), W, H, n_env, A)
             else:
                 line["cpu_baseline"] = cpu_baseline(args.scenario, W, H, n_env, A, args.policy, full=args.cpu_baseline_full)
         print(json.dumps(line), flush=True)

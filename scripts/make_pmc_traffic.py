@@ -64,8 +64,9 @@ def main():
                          # 100 x this x 4 / 1024 / the launch's clocks
                          "active_inst_valu_quadcycles": per(s1, "SQ_ACTIVE_INST_VALU"), "source": f"profiles/{tag}_pmc_SQ.csv, {tag}_pmc_SQ2.csv"}
         if s1 and "SQ_LDS_BANK_CONFLICT" in s1:
-            # north_star's "LDS ... on the raster tile": LDS instructions per tick, the quad-cycles the LDS pipe was busy with them (SQ3 pass, when it ran) and the
-            # quad-cycles it spent replaying bank conflicts; conflict_frac = conflict / busy ("hit rate" = 1 - conflict_frac: an LDS access has no miss, only a replay)
+            # north_star's "LDS ... on the raster tile": LDS instructions per tick, the quad-cycles the LDS pipe was busy with them (SQ3 pass, when it ran) and
+            # the quad-cycles it spent replaying bank conflicts; conflict_frac = conflict / busy ("hit rate" = 1 - conflict_frac: an LDS access has no miss,
+            # only a replay)
             per = lambda d, k: (d[k][1] / div) if d and k in d else None
             busy = per(s3, "SQ_ACTIVE_INST_LDS")
             conf = per(s1, "SQ_LDS_BANK_CONFLICT")

@@ -11,8 +11,9 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # One scripted rollout per case.  `shaping_at`: {step: (actor_idx, {key: value})} applied through Wrapper.set_reward_shaping BEFORE that step;
 # `training_steps_per_step`: what the learner's side would write into training_info["approx_total_training_steps"] (step * this).
 CASES = {
-    # `policy`: the generator's purposeful controller (make_py_surface_golden.py: POLICIES), mixed with the random script with probability `eps`; the actions it chose are
-    # recorded in the fixture (npz "actions") and replayed blind.  `min_nonzero_rewards` / `reward_windows`: what the generator asserts about the recorded rewards.
+    # `policy`: the generator's purposeful controller (make_py_surface_golden.py: POLICIES), mixed with the random script with probability `eps`; the actions it
+    # chose are recorded in the fixture (npz "actions") and replayed blind.  `min_nonzero_rewards` / `reward_windows`: what the generator asserts about the
+    # recorded rewards.
     "tower_a2": dict(scenario="TowerBuilding", num_envs=3, agents=2, seed=42, steps=300, params={"episodeLengthSec": -215.0},
                      increase_team_spirit=True, max_team_spirit_steps=1000, training_steps_per_step=5,
                      shaping_at={70: (1, {"towerPickedUpObject": 0.25}), 150: (4, {"teamSpirit": 0.5, "towerBuildingReward": 2.0})},

@@ -73,8 +73,8 @@ def test_bench_self_spawns_its_ranks_and_gathers_dry_run(mode, fmt, batch):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    # batch > 1: the gather-on leg steps in batched calls, ONE collective per call (the call's half of a ring of 2 x batch slabs; 9 steps = calls of 4, 4, 1 -- the last
-    # one short); batch 1: one collective per tick
+    # batch > 1: the gather-on leg steps in batched calls, ONE collective per call (the call's half of a ring of 2 x batch slabs; 9 steps = calls of 4, 4, 1 --
+    # the last one short); batch 1: one collective per tick
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "9", "--warmup", "5", "--batch", str(batch),
                           "--envs-per-gpu", "4", "--obs", "8", "8", "--gather", mode, "--gather-format", fmt], capture_output=True, text=True, timeout=200, env=env)
     assert out.returncode == 0, out.stderr[-2000:]

@@ -156,7 +156,8 @@ def test_planar_tiles_change_no_byte(hip, monkeypatch, scenario, N, A, W, H, ppl
         for st in range(25):
             g.sample_random_actions(31, 25 * rnd + st); g.step_no_render()
         got = {}
-        for planar in ("0", "2", "3", "1"):   # general path everywhere / classified without overlay_tile / classified without the sign-specialised slab tests / everything
+        # general path everywhere / classified without overlay_tile / classified without the sign-specialised slab tests / everything
+        for planar in ("0", "2", "3", "1"):
             monkeypatch.setenv("MV_PLANAR", planar)
             obs.zero_(); torch.cuda.synchronize()
             g.render(); g.synchronize()

@@ -39,7 +39,8 @@ def run_gym(scenario, N, A, W, H, steps, params):
 
 @pytest.mark.parametrize("scenario,N,A,params,steps", [
     ("TowerBuilding", 512, 4, {"episodeLengthSec": -150.0}, 300),       # configs[3]: multi-agent shared-scene physics (short episodes: resets happen)
-    ("ObstaclesHard", 512, 1, {}, 1400),                                # one GPU's share of configs[2]: episodes of >= 70 s = 1050 ticks, the natural resets fall into the step-by-step tail
+    # one GPU's share of configs[2]: episodes of >= 70 s = 1050 ticks, the natural resets fall into the step-by-step tail
+    ("ObstaclesHard", 512, 1, {}, 1400),
 ])
 def test_full_size_properties(hip, scenario, N, A, params, steps):
     W = H = 128
@@ -83,4 +84,5 @@ def test_full_size_mixed_scenarios_64x64(hip, monkeypatch):
     s2, r2, n2 = run()
     assert np.array_equal(s1, s2) and np.array_equal(r1, r2) and all(a.tobytes() == b.tobytes() for a, b in zip(n1, n2))
     assert s1.shape == (N, H, W, 4) and s1[..., 3].min() == 255 and (s1[..., :3].reshape(N, -1).max(axis=1) > 0).mean() > 0.98
-    assert sorted({int(s["scenario"]) for s in n1}) == [0, 1, 2, 3, 4, 6, 7]      # TowerBuilding, Obstacles family, Collect, Rearrange, Sokoban, HexMemory, HexExplore
+    # TowerBuilding, Obstacles family, Collect, Rearrange, Sokoban, HexMemory, HexExplore
+    assert sorted({int(s["scenario"]) for s in n1}) == [0, 1, 2, 3, 4, 6, 7]

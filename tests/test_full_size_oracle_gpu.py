@@ -85,7 +85,8 @@ def batched_calls_equal_the_oracle(og, hg, N, A, st, k, calls, depth, overlap, s
     ("TowerBuilding", 1024, 1, {"episodeLengthSec": -190.0}, 300, 50),   # configs[1] (short episodes: resets all through the run)
     ("TowerBuilding", 1024, 1, {}, 300, 50),                              # configs[1] exactly as benchmarked (episodes end naturally only after the run)
     ("TowerBuilding", 512, 4, {"episodeLengthSec": -150.0}, 300, 50),     # configs[3]
-    ("ObstaclesHard", 512, 1, {}, 1200, 150),                             # one GPU's share of configs[2]: episodes of >= 70 s = 1050 ticks, the natural resets fall into the run
+    # one GPU's share of configs[2]: episodes of >= 70 s = 1050 ticks, the natural resets fall into the run
+    ("ObstaclesHard", 512, 1, {}, 1200, 150),
 ])
 def test_full_size_rollout_equals_the_oracle(hip, scenario, N, A, params, TICKS, EVERY):
     og = oracle_lib.OracleGym(scenario, W, H, N, A, 16, False, params)

@@ -60,7 +60,8 @@ def test_wrapper_equals_the_reference_wrapper(name):
     w = Wrapper(ReplayingEnv(rec, data, calls), spec["increase_team_spirit"], spec["max_team_spirit_steps"])
     py_surface.replay(w, rec, data, calls, check_obs=False)
     assert rec["episodes_finished"] >= 2 * spec["num_envs"]
-    # the rewards the Wrapper's statistics were checked on are not all zeros: the purposeful scripts earn them on both sides of the shaping changes
+    # the rewards the Wrapper's statistics were checked on are not all zeros: the purposeful scripts earn them on both sides of the
+    # shaping changes
     assert int((data["rewards"] != 0).sum()) >= spec.get("min_nonzero_rewards", 0)
     for a, b in spec.get("reward_windows", []):
         assert (data["rewards"][a:b] != 0).any(), (name, a, b)

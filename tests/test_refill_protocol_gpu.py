@@ -144,7 +144,8 @@ def test_batched_calls_with_the_host_far_ahead_never_starve(scenario, k, monkeyp
     monkeypatch.setenv("BOXOBAN_LEVELS", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "boxoban"))
     N, A, W, H, ticks = 48, 1, 32, 32, 1600
     params = {"episodeLengthSec": 70.0 / 15.0}
-    if scenario in ("HexExplore", "ObstaclesEasy"):   # goal-terminated: default time limits, an episode ends early where the random walk finds the target / the exit
+    # goal-terminated: default time limits, an episode ends early where the random walk finds the target / the exit
+    if scenario in ("HexExplore", "ObstaclesEasy"):
         N, ticks, params = 96, 2400, {}
 
     def run(batched):
