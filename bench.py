@@ -335,9 +335,10 @@ def main():
                     help="random policy: uniform per head (action_space.sample(), megaverse_env.py:110-112) or the reference benchmark's "
                          "Action(1 << randRange(0, 11)) (megaverse_test_app.cpp:140-147)")
     ap.add_argument("--pass-overlap", choices=("auto", "on", "off"), default="auto",
-                    help="output ring two calls deep, the observation passes of consecutive calls overlap (mv_set_pass_overlap).  auto: for the Obstacles scenarios and Sokoban "
-                         "(measured r07a/b, M obs/s with / without: ObstaclesHard 512 envs 16.9 / 13.9, 1024 envs 20.5 / 20.1; TowerBuilding 1024 envs 23.4 / 24.0, "
-                         "512 envs 20.1 / 20.9; Rearrange 19.4 / 19.5; r07j: Sokoban 23.4 / 19.6, Collect 14.0 / 14.3, HexMemory 9.15 / 9.10)")
+                    help="output ring two calls deep, the observation passes of consecutive calls overlap (mv_set_pass_overlap).  auto: what mv_recommended_pass_overlap says -- "
+                         "every scenario but Empty; TowerBuilding with one or two agents per env from 512 frames per tick on (measured r10za/b/c, M obs/s with / without: "
+                         "TowerBuilding 1024 envs 34.4 / 32.5, 512 envs 26.9 / 25.4, 512 x 4 agents 24.5 / 28.8; Rearrange 28.6 / 25.6; Collect 16.9 / 16.6; HexMemory 9.8 / 9.5; "
+                         "in round 4, r07: TowerBuilding 23.4 / 24.0 -- the passes were not yet what a call waits for)")
     ap.add_argument("--batch", type=int, default=0,
                     help="ticks per stepping call (mv_step_n): every tick is stepped and rendered in full, the two stream hand-overs are paid once "
                          "per call; 1 = one mv_step per tick; 0 (default) = 16 (8 where a call's 16 observation slabs would exceed ~1 GB), the first calls after a synchronisation 2, 4 and 6 ticks (the observation "

@@ -121,7 +121,10 @@ int mv_set_pass_overlap(mv_gym *g, int32_t on);
  * mv_recommended_ticks_per_call: 16 (one tail of the one-launch observation pass per 16 ticks) for 1024 .. 2047 agent frames per tick where the gym's slot groups hold
  * 16 (mv_create sizes them by footprint: 16 where the 48 hand-over slots that takes stay under 2.25 GiB, else 8; MV_PIPE_BATCH overrides) and the scenario is not Sokoban; 8 otherwise; 1 where episodes can end within a few ticks
  * (such gyms are stepped tick by tick whatever k says).  A gym in a group: at most 8 (the two-launch group call's limit, and only while the group's envs are
- * all resident at once: 1024).  mv_recommended_pass_overlap: 1 for the Obstacles family and Sokoban (short passes: the next call's may begin in the tail), else 0.
+ * all resident at once: 1024).  mv_recommended_pass_overlap: 1 wherever the
+ * observation passes are what a call waits for (the next call's begin in the tail of this one's) -- every scenario but Empty; TowerBuilding with one or two agents per
+ * env from 512 frames per tick on (with fewer frames, or four agents per env, the step launch bounds the call and the second pass stream only costs) --, 0 for
+ * gyms whose episodes last a few ticks (the library declines to overlap there) and in groups.
  * mv_arena_bytes: the device memory this gym holds (state + the hand-over slots of PIPE_GROUPS x ticks-per-call ticks + its own observation slab). */
 int mv_recommended_ticks_per_call(const mv_gym *g);
 int mv_recommended_pass_overlap(const mv_gym *g);

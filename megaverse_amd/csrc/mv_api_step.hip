@@ -512,7 +512,14 @@ int mv_recommended_ticks_per_call(const mv_gym *g)
 int mv_recommended_pass_overlap(const mv_gym *g)
 {
     if (!g || g->closed || g->inGroup) return 0;
-    return g->scenario == SCN_OBSTACLES || g->scenario == SCN_SOKOBAN ? 1 : 0;
+    if (g->statusPeriod <= 1) return 0;   // (episodes of a few ticks: stepped tick by tick, and two passes in flight may not both publish an env's true objective)
+    // Measured on / off, M obs/s (r10za, r10zb, r10zc; the Obstacles family and Sokoban: r07j): wherever the passes are what a call waits for, the next call's
+    // begin in the tail of this one's -- Rearrange 25.6 -> 28.6, HexMemory 9.5 -> 9.8, HexExplore 10.8 -> 11.0, Collect 16.6 -> 16.9; TowerBuilding 512 envs 25.4 ->
+    // 26.9, 1024: 32.5 -> 34.4, 2048: 33.7 -> 35.0, 4096: 34.9 -> 35.6, 512 x 2 agents 22.1 -> 23.7 -- but 256 envs 17.1 -> 16.6 and 512 x 4 agents 28.8 -> 24.5
+    // (their step launches, not their passes, bound them), Empty 46.9 -> 46.3.
+    if (g->scenario == SCN_EMPTY) return 0;
+    if (g->scenario == SCN_TOWER) return g->A <= 2 && g->N * g->A >= 512 ? 1 : 0;
+    return 1;
 }
 
 int64_t mv_arena_bytes(const mv_gym *g) { return g ? (int64_t)g->arenaBytes : 0; }

@@ -140,10 +140,10 @@ def test_full_size_rollout_equals_the_oracle(hip, scenario, N, A, params, TICKS,
     assert last[..., 3].min() == 255 and ngt1 <= max(2, 1e-4 * npx) and ndiff <= max(4, 5e-4 * npx), f"ring slab after batched calls: {ndiff} pixels differ, {ngt1} by more than 1"
     hg.set_output_ring(0)
     # ---- the launch shapes the bench times: 16 ticks per call into a ring of 16 (two step launches of 8 + ONE observation launch of 16
-    # passes); and -- ObstaclesHard, as bench.py runs one GPU's share of configs[2] -- overlapped passes into rings two calls deep (mv_set_pass_overlap).  EVERY
+    # passes); and -- one agent per env, as bench.py runs configs[1] and one GPU's share of configs[2] -- overlapped passes into rings two calls deep (mv_set_pass_overlap).  EVERY
     # ring entry's rewards and dones against the oracle's tick, the pixels of the sampled envs in several entries of every call, every env's state afterwards.
     st = batched_calls_equal_the_oracle(og, hg, N, A, st, k=16, calls=3, depth=16, overlap=False, sample=sample, what=f"{scenario} {N}x{A} step_n(16)")
-    if scenario == "ObstaclesHard":
+    if A == 1:   # (what mv_recommended_pass_overlap says for these gyms, and bench.py follows; with the short episodes of the first case the library declines)
         st = batched_calls_equal_the_oracle(og, hg, N, A, st, k=16, calls=4, depth=32, overlap=True, sample=sample, what=f"{scenario} {N}x{A} step_n(16), overlapped passes")
     if params:
         assert ndone > N // 2, f"only {ndone} episodes ended in {TICKS} ticks"

@@ -423,7 +423,8 @@ def test_one_launch_calls_fill_the_ring_like_single_ticks(hip, monkeypatch, scen
 
 
 @pytest.mark.parametrize("scenario,N,A,W,H,params", [("TowerBuilding", 300, 1, 128, 128, {}), ("TowerBuilding", 64, 4, 64, 64, {}), ("ObstaclesHard", 200, 1, 128, 128, {}),
-                                                     ("Rearrange", 100, 1, 64, 64, {}), ("Collect", 80, 1, 64, 64, {}), ("TowerBuilding", 50, 1, 64, 64, {"episodeLengthSec": -200.0})])
+                                                     ("Rearrange", 100, 1, 64, 64, {}), ("Collect", 80, 1, 64, 64, {}), ("HexMemory", 60, 1, 64, 64, {}), ("HexExplore", 40, 1, 128, 72, {}),
+                                                     ("Sokoban", 90, 1, 64, 64, {}), ("TowerBuilding", 50, 1, 64, 64, {"episodeLengthSec": -200.0})])
 def test_overlapped_passes_fill_the_ring_like_single_ticks(hip, monkeypatch, scenario, N, A, W, H, params):
     """mv_set_pass_overlap: with a ring two calls deep the one-launch observation passes of consecutive batched calls run on two internal streams
     (the passes of call c + 1 begin while those of call c drain) -- against single ticks: every slab of the ring, the rewards / dones rings, the
