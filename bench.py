@@ -28,6 +28,11 @@ import socket
 import sys
 import time
 
+# HIP deals a process's streams over 4 hardware queues unless told otherwise; a gym holds up to six (the caller's, simulation, copy, episode draws, two pass
+# streams) and the transparency legs make more gyms: streams that land on one queue serialise (r11a / r11b: the legs that make NEW gyms after the main one ran at half
+# their rate -- MegaverseEnv.step_device 7.5 M obs/s against 16.7 M -- until the process had 8 queues; the main loop's rate does not move).  Before HIP starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -426,7 +431,10 @@ def main():
     gather_batched = do_gather and batched and not mixed
     # (slabs of the output ring: a call never holds more ticks than `batch`; two calls deep, the passes of consecutive calls overlap: mv_set_pass_overlap)
     # (the rule: mv_recommended_pass_overlap)
-    pass_overlap = batched and not mixed and (args.pass_overlap == "on" or (args.pass_overlap == "auto" and gym.recommended_pass_overlap()))
+    # -- for a region of at least four full calls: a region that starts from an empty pipeline and ends after a handful of short calls (the driver's 20-step form)
+    # gains nothing from a second pass stream and, box by box, loses up to 8 % to it (r10zc / r11b, on / off: 25.5 25.3 25.6 23.8 / 25.3 25.1 25.1 25.4, and 23.5
+    # 23.5 23.6 23.1 23.8 24.5 / 25.3 25.4 25.3 25.3 25.1 25.1 M obs/s)
+    pass_overlap = batched and not mixed and (args.pass_overlap == "on" or (args.pass_overlap == "auto" and gym.recommended_pass_overlap() and args.steps >= 4 * batch))
     if gather_batched:
         pass_overlap = False   # (the ring's two halves belong to the gather pipeline)
     ring_slots = 2 * batch if gather_batched else (max(batch, 8) * (2 if pass_overlap else 1)) if batched else 1
@@ -586,6 +594,8 @@ def main():
     if batched and mixed and getattr(gym, "ring_obs", None):
         mixed_ring_checksum = sum(int(r[:, ::97].to(torch.int64).sum().item()) for r in gym.ring_obs)
     if batched and not dry and (ring is not None or mixed):
+        if pass_overlap:
+            gym.set_pass_overlap(False)   # (the transparency legs below run without it, and without its two streams)
         gym.set_output_ring(0)
         bind(0)
 
@@ -793,6 +803,7 @@ def main():
                        # leaves its observations in slab j of a ring of that many slabs
                        "pipelined": pipelined, "ticks_per_call": batch if main_batched else 1,
                        **({"ring_slots": ring_slots, "overlapped_passes": bool(pass_overlap)} if main_batched else {}),
+                       "hip_hardware_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        **({"first_calls": os.environ.get("MV_BENCH_CALL_SCHEDULE", "2,4,6") + " ticks, then ticks_per_call (every tick stepped and rendered in full)"} if main_batched else {}),
                        # (a batched group call is two launches where all of the group's envs are resident at once -- up to 1024 -- else two per tick:
                        # mv_api_step.hip, groupBatch)

@@ -115,7 +115,8 @@ int mv_set_output_ring(mv_gym *g, int32_t count, void *obs, float *rewards, uint
  * mv_step_n calls run on two internal streams in turn: the passes of call c + 1 begin while the last workgroups of call c's drain.  The caller's
  * stream still waits for every call's passes before anything enqueued after the call runs.  The price is the ring's contract: an entry must be
  * consumed -- the consumer enqueued on the caller's stream -- before the NEXT stepping call after the one that produced it is issued (without
- * overlap: before the call that overwrites it).  No reference counterpart (the reference renders synchronously, vector_env.cpp:112-118). */
+ * overlap: before the call that overwrites it).  on = 0 also releases the two internal streams (a HIP process shares few hardware queues among its streams:
+ * GPU_MAX_HW_QUEUES, 4 by default).  No reference counterpart (the reference renders synchronously, vector_env.cpp:112-118). */
 int mv_set_pass_overlap(mv_gym *g, int32_t on);
 /* What a caller who just wants throughput should ask mv_step_n for -- the measured rules that used to live in bench.py (no reference counterpart):
  * mv_recommended_ticks_per_call: 16 (one tail of the one-launch observation pass per 16 ticks) for 1024 .. 2047 agent frames per tick where the gym's slot groups hold

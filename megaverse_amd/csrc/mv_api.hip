@@ -1101,6 +1101,15 @@ int mv_set_pass_overlap(mv_gym *g, int32_t on)
             HIP_TRY(hipEventCreateWithFlags(&g->callStart[i], hipEventDisableTiming));
         }
     }
+    if (!on && g->passStream[0]) {   // switched off: the two pass streams go (a process holds few hardware queues: idle streams are not free for the gyms made later)
+        if (sim_join(g)) return -1;
+        HIP_TRY(hipStreamSynchronize(g->stream));
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(hipStreamSynchronize(g->passStream[i]));
+            (void)hipStreamDestroy(g->passStream[i]); (void)hipEventDestroy(g->callStart[i]);
+            g->passStream[i] = nullptr; g->callStart[i] = nullptr;
+        }
+    }
     g->passOverlap = on ? 1 : 0;
     g->overlapCalls = 0;
     return 0;
