@@ -6,17 +6,20 @@ import sys
 
 ROWS = [("tower_bench.json", "**TowerBuilding 1024 envs x 1, 128x128 (BASELINE configs[1])**"),
         ("tower_bench_driver_style.json", "same, the driver's form (`--gpus 1 --steps 20 --warmup 5`)"),
+        ("tower_no_overlap_bench.json", "same, passes not overlapped (`--pass-overlap off`: round 6's headline until `r10zb`)"),
         ("tower_8_ticks_per_call_bench.json", "same, 8 ticks per call (`--batch 8`)"),
         ("tower_no_multitick_bench.json", "same, k step launches + k raster launches per call (`MV_STEP_TICKS=0 --batch 8`)"),
         ("tower_512x4_bench.json", "TowerBuilding 512 envs x 4 agents (configs[3])"),
-        ("tower_512_bench.json", "TowerBuilding 512 envs x 1"),
+        ("tower_512_bench.json", "TowerBuilding 512 envs x 1 (overlapped passes)"), ("tower_512_no_overlap_bench.json", "same, passes not overlapped"),
         ("tower_4096_bench.json", "TowerBuilding 4096 envs x 1"),
         ("obstacles_hard_512_bench.json", "ObstaclesHard 512 envs x 1 (one GPU's share of configs[2]), overlapped passes"),
         ("obstacles_hard_512_no_overlap_bench.json", "same, passes not overlapped (`--pass-overlap off`)"),
         ("obstacles_hard_1024_bench.json", "ObstaclesHard 1024 x 1 (overlapped passes)"),
-        ("Collect_bench.json", "Collect 1024 x 1"), ("Rearrange_bench.json", "Rearrange 1024 x 1"),
+        ("Collect_bench.json", "Collect 1024 x 1 (overlapped passes)"), ("Collect_no_overlap_bench.json", "same, passes not overlapped"),
+        ("Rearrange_bench.json", "Rearrange 1024 x 1 (overlapped passes)"), ("Rearrange_no_overlap_bench.json", "same, passes not overlapped"),
         ("Sokoban_bench.json", "Sokoban 1024 x 1 (synthetic Boxoban-format levels; overlapped passes)"),
-        ("HexMemory_bench.json", "HexMemory 1024 x 1"), ("HexExplore_bench.json", "HexExplore 1024 x 1"),
+        ("HexMemory_bench.json", "HexMemory 1024 x 1 (overlapped passes)"), ("HexMemory_no_overlap_bench.json", "same, passes not overlapped"),
+        ("HexExplore_bench.json", "HexExplore 1024 x 1 (overlapped passes)"), ("HexExplore_no_overlap_bench.json", "same, passes not overlapped"),
         ("Empty_bench.json", "Empty 1024 x 1"), ("Empty_800_steps_bench.json", "Empty 1024 x 1, 800 steps"),
         ("mixed_64_bench.json", "**Mixed: all eight `megaverse8` scenarios round-robin, 1024 x 1, 64x64 (one GPU's share of configs[4])**"),
         ("mixed4_64_bench.json", "Mixed4: TowerBuilding, ObstaclesEasy, ObstaclesHard, Collect round-robin, 1024 x 1, 64x64 (BASELINE.md 3 row 5)"),
