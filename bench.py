@@ -804,6 +804,9 @@ def main():
                        "pipelined": pipelined, "ticks_per_call": batch if main_batched else 1,
                        **({"ring_slots": ring_slots, "overlapped_passes": bool(pass_overlap)} if main_batched else {}),
                        "hip_hardware_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+                       # who draws the episodes (mv_host_generator_threads): the host feeder's threads, or 0 = on the device (TowerBuilding; Collect where the
+                       # rank's share of the host is under three cores, or MV_COLLECT_DEVICE_GEN=1)
+                       **({"host_generator_threads": gym.host_generator_threads()} if hasattr(gym, "host_generator_threads") else {}),
                        **({"first_calls": os.environ.get("MV_BENCH_CALL_SCHEDULE", "2,4,6") + " ticks, then ticks_per_call (every tick stepped and rendered in full)"} if main_batched else {}),
                        # (a batched group call is two launches where all of the group's envs are resident at once -- up to 1024 -- else two per tick:
                        # mv_api_step.hip, groupBatch)

@@ -130,6 +130,10 @@ int mv_set_pass_overlap(mv_gym *g, int32_t on);
 int mv_recommended_ticks_per_call(const mv_gym *g);
 int mv_recommended_pass_overlap(const mv_gym *g);
 int64_t mv_arena_bytes(const mv_gym *g);
+/* Who draws this gym's episodes (Env::reset, env.cpp:57-76, off the step path in every case): the number of host threads of its episode feeder, or 0 when the
+ * episodes are drawn on the device -- TowerBuilding always (tower_draw_kernel); Collect where the process's share of the host is under three cores, or
+ * MV_COLLECT_DEVICE_GEN=1 (collect_draw_kernel: the host generator's episodes, byte for byte).  -1: no such gym. */
+int mv_host_generator_threads(const mv_gym *g);
 int mv_render(mv_gym *g);                           /* observation pass only */
 
 int mv_is_done(mv_gym *g, int32_t env_idx);         /* isDone(), :123-126 -> 0/1, <0 on error */
@@ -217,6 +221,15 @@ int mv_debug_feeder_selftest(const char *scenario, int32_t num_envs, int32_t num
 /* Host-only: the first n episodes of the Sokoban level generator (scenario_sokoban.cpp:80-170; its kernels come next) as n
  * packed records; out == NULL: record size.  Returns n, -1 on error. */
 int mv_debug_generate_sokoban(int32_t num_agents, int32_t env_seed, int32_t n, float base_episode_len, void *out, int32_t out_bytes);
+
+/* Collect's episode generator as it runs on the DEVICE (megaverse_amd/csrc/mv_collect_draw.h; the product's feeder uses it where mv_host_generator_threads
+ * says 0 for a Collect gym).  _host: the same code compiled for the CPU, no device needed -- the n-th episode of an env seeded
+ * with env_seed, the record mv_debug_generate_episode("Collect", ...) returns (seq = n).  _device: `count` envs draw their first n episodes on the GPU, out
+ * receives the n-th of each (count x the record size), *ms_per_launch the mean duration of a launch of `count` wavefronts.  Replaces CollectScenario::reset +
+ * createLandscape + addEpisodeDrawables (scenario_collect.cpp:20-161,190-214), siv::PerlinNoise (perlin_noise.hpp:118-126,315-318). */
+int mv_debug_collect_draw_host(int32_t num_agents, int32_t env_seed, int32_t n, float base_episode_len, void *out, int32_t out_bytes);
+int mv_debug_collect_draw_device(int32_t device, int32_t num_agents, const int32_t *env_seeds, int32_t count, int32_t n, float base_episode_len, void *out,
+                                 int64_t out_bytes, float *ms_per_launch);
 
 #ifdef __cplusplus
 }

@@ -519,13 +519,24 @@ int mv_create(const mv_config *cfg, mv_gym **out)
                                                            : std::max(1, std::min(16, usable_host_cores() / std::max(1, g->totalEnvs / std::max(1, g->N))));
         if (const char *e = getenv("MV_FEEDER_THREADS")) g->feederThreads = std::min(64, std::max(1, atoi(e)));
         g->uploadEvents.assign(64, nullptr);
-        bool ok = hipHostMalloc((void **)&g->hBlobs, N * g->blobBytes, hipHostMallocDefault) == hipSuccess;
+        // Collect: the episodes may be drawn on the DEVICE (mv_collect_draw.h: the same episodes, byte for byte) instead of by the host's worker threads --
+        // MV_COLLECT_DEVICE_GEN=1 / 0, otherwise where this process's share of the host is under three cores (eight ranks under a 16-CPU quota: two host
+        // threads hold Collect at 13.7 M obs/s, the device generator does not care).  The staging slots are device memory then.
+        g->blobsOnDevice = collect && (getenv("MV_COLLECT_DEVICE_GEN") ? atoi(getenv("MV_COLLECT_DEVICE_GEN")) != 0
+                                                                        : cfg->num_simulation_threads <= 0 && !getenv("MV_FEEDER_THREADS") && g->feederThreads < 3);
+        bool ok = g->blobsOnDevice ? hipMalloc((void **)&g->hBlobs, N * g->blobBytes) == hipSuccess && hipMemset(g->hBlobs, 0, N * g->blobBytes) == hipSuccess
+                                   : hipHostMalloc((void **)&g->hBlobs, N * g->blobBytes, hipHostMallocDefault) == hipSuccess;
         for (auto &e : g->uploadEvents) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
         if (!ok) {
             mv_destroy(g);
             return fail("mv_create: pinned episode staging allocation failed");
         }
-        g->feeder = std::make_unique<EpisodeFeeder>(scenario, oc, g->N, g->A, episodeLen, g->hBlobs, g->blobBytes, g->device, g->feederThreads, levelFiles);
+        g->feeder = std::make_unique<EpisodeFeeder>(scenario, oc, g->N, g->A, episodeLen, g->hBlobs, g->blobBytes, g->device, g->feederThreads, levelFiles,
+                                                    g->blobsOnDevice);
+        if (g->feeder->failed()) {
+            mv_destroy(g);
+            return fail("mv_create: the device-side episode generator's allocations failed");
+        }
         std::vector<uint32_t> seeds(N);
         std::random_device rdev;   // unseeded envs take their seed from random_device (env.hpp:169)
         for (auto &v : seeds) v = (uint32_t)rdev();
@@ -650,7 +661,7 @@ int mv_close(mv_gym *g)
     }
     if (g->arena) (void)hipFree(g->arena);
     if (g->hiresObs) (void)hipFree(g->hiresObs);
-    if (g->hBlobs) (void)hipHostFree(g->hBlobs);
+    if (g->hBlobs) (void)(g->blobsOnDevice ? hipFree(g->hBlobs) : hipHostFree(g->hBlobs));
     if (g->hStatus) (void)hipHostFree(g->hStatus);
     if (g->stepDone) (void)hipEventDestroy(g->stepDone);
     if (g->statusCopied) (void)hipEventDestroy(g->statusCopied);
@@ -859,12 +870,19 @@ static int upload_pass(mv_gym *g)
     // same tick -- used to pay a thousand hipMemcpyAsync calls, ~5 ms of host time, at every such tick.
     int runFirst = -1, runLen = 0, runSlot = 0;
     size_t runBytes = 0;
+    // Host-generated episodes travel on the copy stream (a DMA engine's work, ordered against the step launches by events).  Device-drawn ones are copied
+    // device to device by ONE small kernel per pass (collect_blob_copy_kernel), and that goes to the SIMULATION stream itself, in order between the step
+    // launches: on the copy stream it would queue behind whatever shares its hardware queue (an observation launch lasts a millisecond) with the step
+    // launches waiting for it (r12a: 13.7 M obs/s; on the simulation stream as one hipMemcpyAsync per episode 15.7 M, r12b; the host feeder: 16.8 M).
+    hipStream_t up = g->blobsOnDevice ? g->simStream : g->copyStream;
+    std::vector<int32_t> devEnvs, devSlots;
     auto flush_run = [&]() -> int {
         if (runLen <= 0) return 0;
         uint8_t *dst = g->dBlobs + ((size_t)runFirst * K + (size_t)runSlot) * g->blobBytes;
         const uint8_t *src = g->hBlobs + (size_t)runFirst * g->blobBytes;
-        if (runLen == 1) HIP_TRY(hipMemcpyAsync(dst, src, runBytes, hipMemcpyHostToDevice, g->copyStream));
-        else HIP_TRY(hipMemcpy2DAsync(dst, (size_t)K * g->blobBytes, src, g->blobBytes, runBytes, (size_t)runLen, hipMemcpyHostToDevice, g->copyStream));
+        const hipMemcpyKind kind = g->blobsOnDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;   // (device-drawn Collect episodes: staging is device memory)
+        if (runLen == 1) HIP_TRY(hipMemcpyAsync(dst, src, runBytes, kind, up));
+        else HIP_TRY(hipMemcpy2DAsync(dst, (size_t)K * g->blobBytes, src, g->blobBytes, runBytes, (size_t)runLen, kind, up));
         runLen = 0;
         return 0;
     };
@@ -879,8 +897,15 @@ static int upload_pass(mv_gym *g)
         if (!src) return fail(g->feeder->failed() ? std::string("episode feeder: a level file could not be read (Sokoban)")
                                                   : "episode feeder: episode " + std::to_string(need)
                                                           + " of env " + std::to_string(i) + " was never generated");
-        if (!waited && g->lastStep) { HIP_TRY(hipStreamWaitEvent(g->copyStream, g->lastStep, 0)); waited = true; }
+        if (!waited && g->lastStep) { HIP_TRY(hipStreamWaitEvent(up, g->lastStep, 0)); waited = true; }
         const int slot = (need - 1) % K;
+        if (g->blobsOnDevice) {   // (device-drawn: gathered, one copy launch for the pass below)
+            devEnvs.push_back(i); devSlots.push_back(slot);
+            ++g->uploaded[i];
+            deficit += consumed + K - g->uploaded[i];
+            batch.push_back(i);
+            continue;
+        }
         if (runLen > 0 && (i != runFirst + runLen || slot != runSlot) && flush_run()) return -1;
         if (runLen == 0) { runFirst = i; runSlot = slot; runBytes = 0; }
         ++runLen;
@@ -891,8 +916,12 @@ static int upload_pass(mv_gym *g)
         batch.push_back(i);
     }
     if (flush_run()) return -1;
+    if (!devEnvs.empty()) {
+        launch_collect_blob_copy(devEnvs.data(), devSlots.data(), (int)devEnvs.size(), g->hBlobs, g->dBlobs, g->blobBytes, K, up);
+        HIP_TRY(hipGetLastError());
+    }
     if (!batch.empty()) {
-        HIP_TRY(hipEventRecord(ev, g->copyStream));
+        HIP_TRY(hipEventRecord(ev, up));
         for (int i : batch) g->feeder->recycle(i, ev);   // regenerate a slot only once its upload has left it
         HIP_TRY(hipStreamWaitEvent(g->simStream, ev, 0));   // (a step that runs on the caller's stream, and mv_reset, wait for lastUpload themselves)
         g->lastUpload = ev;

@@ -33,6 +33,9 @@ void launch_reset(const GymView &gv, int force_all, hipStream_t stream);
 // TowerBuilding: tops every env's ring of drawn episodes up (mv_reset.hip)
 void launch_tower_draw(const GymView &gv, hipStream_t stream);
 void launch_tower_seed(const GymView &gv, const uint32_t *seeds, hipStream_t stream);   // Env::seed for every env's generator
+// Collect, device-drawn episodes (mv_collect_draw.hip): staging slots of envs[i] -> their ring slots slots[i], one launch per 64 episodes
+void launch_collect_blob_copy(const int32_t *envs, const int32_t *slots, int count, const uint8_t *staging, uint8_t *ring, size_t blob_bytes, int spares,
+                              hipStream_t stream);
 // step kernels: one 256-thread workgroup per env = the tick (wave 0) + the frame setup of the env's frames for a W x H observation
 // (render = 0: tick only)
 void launch_step(const GymView &gv, hipStream_t stream, int W, int H, int render, hipEvent_t done = nullptr);
@@ -162,6 +165,7 @@ struct mv_gym {
     std::vector<int> consumedSeen;                  // the consumed counts of the last status read-back that was looked at (host copy)
     std::vector<int> uploaded, uploadBatch;         // episodes uploaded per env; envs of the current upload batch
     uint8_t *dBlobs = nullptr, *hBlobs = nullptr;   // device [N][blobBytes], pinned feeder slots [N][blobBytes]
+    bool blobsOnDevice = false;                     // Collect with the device-side generator: hBlobs is device memory, filled by collect_draw_kernel (mv_feeder.cpp)
     size_t blobBytes = 0;                           // sizeof(EpisodeBlob) or sizeof(CollectBlob)
     bool hostEpisodes() const { return scenario != SCN_TOWER; }
     // TowerBuilding: the episode generator's serial half (tower_draw_kernel, ~47 us of one wavefront per finished env) runs on a stream of its own,

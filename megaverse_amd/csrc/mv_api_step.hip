@@ -509,6 +509,12 @@ int mv_recommended_ticks_per_call(const mv_gym *g)
     return std::max(1, std::min(k, g->batch));
 }
 
+int mv_host_generator_threads(const mv_gym *g)
+{
+    if (!g || g->closed) return -1;
+    return g->feeder && !g->feeder->device_gen() ? g->feeder->num_threads() : 0;
+}
+
 int mv_recommended_pass_overlap(const mv_gym *g)
 {
     if (!g || g->closed || g->inGroup) return 0;

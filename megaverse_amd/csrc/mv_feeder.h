@@ -27,8 +27,11 @@ class EpisodeFeeder {
 public:
     // slots: pinned host memory, num_envs * slot_bytes, owned by the caller
     // level_files: Sokoban only (the Boxoban level files found at construction, scenario_sokoban.cpp:40-78)
+    // device_gen (Collect only): `slots` is DEVICE memory and the episodes are drawn there by collect_draw_kernel (mv_collect_draw.h) -- one worker thread
+    // gathers the envs whose slots are free into a batch, launches the kernel for them on a stream of its own and waits for it; everything else --
+    // is_ready / wait_ready / recycle / reseed, the refill protocol around them -- is what it is for the host generators.
     EpisodeFeeder(int scenario, const ObstacleConfig &cfg, int num_envs, int num_agents, float base_episode_len, uint8_t *slots,
-                  size_t slot_bytes, int device, int num_threads, std::vector<std::string> level_files = {});
+                  size_t slot_bytes, int device, int num_threads, std::vector<std::string> level_files = {}, bool device_gen = false);
     ~EpisodeFeeder();
     EpisodeFeeder(const EpisodeFeeder &) = delete;
     EpisodeFeeder &operator=(const EpisodeFeeder &) = delete;
@@ -47,12 +50,14 @@ public:
     void recycle(int env, hipEvent_t copied);
 
     int num_threads() const { return int(workers_.size()); }
+    bool device_gen() const { return device_gen_; }
     bool failed() const { return failed_.load(std::memory_order_acquire); }   // a generator gave up (Sokoban: unreadable level file)
     int take_overflow() { return overflow_.exchange(0, std::memory_order_relaxed); }   // GEN_* flags this feeder's generators raised since the last call
 
 private:
     struct Task { int env; hipEvent_t after; };
     void worker_main();
+    void device_worker_main();
     void generate(int env);
 
     const int scenario_, num_envs_, num_agents_, device_;
@@ -78,6 +83,15 @@ private:
     std::vector<std::string> soko_files_;
     std::vector<SokobanLevels> soko_levels_;
     std::vector<std::deque<SokoUndo>> soko_undo_;
+    // device mode: the generators' states on the device (cdraw::GenState per env), a batch's env list (pinned + device), the flag word its kernels raise
+    const bool device_gen_;
+    bool urgent_ = false;       // under mu_: somebody waits for an episode, launch what is there
+    int linger_ms_ = 15;        // how long a batch gathers otherwise (MV_DRAW_LINGER_MS; r12k: 0 / 10 / 25 / 50 / 100 ms: 16.4 / 16.6 / 16.5 / 16.0 / 14.7 M obs/s)
+    void *d_states_ = nullptr;
+    int32_t *h_list_ = nullptr, *d_list_ = nullptr, *h_flags_ = nullptr, *d_flags_ = nullptr;
+    hipStream_t gen_stream_ = nullptr;
+    bool upload_states();   // next_seq_ / seeds -> d_states_ (reseed, under mu_ with no batch in flight)
+    std::vector<uint32_t> seeds_;
 };
 
 }  // namespace mv

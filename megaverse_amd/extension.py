@@ -43,6 +43,7 @@ SYMBOLS = [
     ("mv_set_output_ring", C.c_int, [_P, _I, _P, _P, _P]),
     ("mv_set_pass_overlap", C.c_int, [_P, _I]),
     ("mv_recommended_ticks_per_call", C.c_int, [_P]), ("mv_recommended_pass_overlap", C.c_int, [_P]), ("mv_arena_bytes", C.c_int64, [_P]),
+    ("mv_host_generator_threads", C.c_int, [_P]),
     ("mv_is_done", C.c_int, [_P, _I]), ("mv_get_dones", C.c_int, [_P, _P]),
     ("mv_get_last_rewards", C.c_int, [_P, _P]),
     ("mv_true_objective", C.c_int, [_P, _I, _I, C.POINTER(_F)]), ("mv_get_true_objectives", C.c_int, [_P, _P]),
@@ -67,6 +68,8 @@ SYMBOLS = [
     ("mv_debug_generate_episode", C.c_int, [C.c_char_p, _I, _I, _I, _F, _P, _I]),
     ("mv_debug_feeder_selftest", C.c_int, [C.c_char_p, _I, _I, _I, _I]),
     ("mv_debug_generate_sokoban", C.c_int, [_I, _I, _I, _F, _P, _I]),
+    ("mv_debug_collect_draw_host", C.c_int, [_I, _I, _I, _F, _P, _I]),
+    ("mv_debug_collect_draw_device", C.c_int, [_I, _I, _P, _I, _I, _F, _P, C.c_int64, _P]),
 ]
 
 
@@ -297,6 +300,10 @@ class MegaverseGym:
 
     def recommended_pass_overlap(self):
         return bool(self._lib.mv_recommended_pass_overlap(self._g))
+
+    def host_generator_threads(self):
+        """threads of the host-side episode feeder; 0 = the episodes are drawn on the device (TowerBuilding; Collect with the device generator)"""
+        return int(self._lib.mv_host_generator_threads(self._g))
 
     def arena_bytes(self):
         return int(self._lib.mv_arena_bytes(self._g))
