@@ -131,7 +131,7 @@ int mv_recommended_ticks_per_call(const mv_gym *g);
 int mv_recommended_pass_overlap(const mv_gym *g);
 int64_t mv_arena_bytes(const mv_gym *g);
 /* Who draws this gym's episodes (Env::reset, env.cpp:57-76, off the step path in every case): the number of host threads of its episode feeder, or 0 when the
- * episodes are drawn on the device -- TowerBuilding always (tower_draw_kernel); Collect where the process's share of the host is under three cores, or
+ * episodes are drawn on the device -- TowerBuilding always (tower_draw_kernel); Collect where the process's share of the host is under three cores and the gym has 256 envs and more, or
  * MV_COLLECT_DEVICE_GEN=1 (collect_draw_kernel: the host generator's episodes, byte for byte).  -1: no such gym. */
 int mv_host_generator_threads(const mv_gym *g);
 int mv_render(mv_gym *g);                           /* observation pass only */

@@ -508,6 +508,7 @@ int mv_create(const mv_config *cfg, mv_gym **out)
         // two gyms stepped in turn, each with its own draw stream: 13.7 -> 8.5 M obs/s, the two gyms' caller streams had come to share a queue)
         g->genStream = g->copyStream;
         g->drawPeriod = g->statusPeriod > 1 ? 8 : 1;
+        if (const char *e = getenv("MV_DRAW_PERIOD")) g->drawPeriod = g->statusPeriod > 1 ? std::max(1, atoi(e)) : 1;   // (measurements: r12m)
     }
     if (hostEpisodes) {
         g->uploaded.assign(N, 0);
@@ -521,9 +522,10 @@ int mv_create(const mv_config *cfg, mv_gym **out)
         g->uploadEvents.assign(64, nullptr);
         // Collect: the episodes may be drawn on the DEVICE (mv_collect_draw.h: the same episodes, byte for byte) instead of by the host's worker threads --
         // MV_COLLECT_DEVICE_GEN=1 / 0, otherwise where this process's share of the host is under three cores (eight ranks under a 16-CPU quota: two host
-        // threads hold Collect at 13.7 M obs/s, the device generator does not care).  The staging slots are device memory then.
+        // threads hold Collect at 13.0 M obs/s against 16.5 M) and the gym has 256 envs and more (r12n, two cores, host / device: a quarter of a
+        // Mixed4 batch 18.0 / 19.8 M obs/s, an eighth of a Mixed batch 16.9 / 16.2: too few episodes to pay for the draw launches).  The staging slots are device memory then.
         g->blobsOnDevice = collect && (getenv("MV_COLLECT_DEVICE_GEN") ? atoi(getenv("MV_COLLECT_DEVICE_GEN")) != 0
-                                                                        : cfg->num_simulation_threads <= 0 && !getenv("MV_FEEDER_THREADS") && g->feederThreads < 3);
+                                                                        : cfg->num_simulation_threads <= 0 && !getenv("MV_FEEDER_THREADS") && g->feederThreads < 3 && N >= 256);
         bool ok = g->blobsOnDevice ? hipMalloc((void **)&g->hBlobs, N * g->blobBytes) == hipSuccess && hipMemset(g->hBlobs, 0, N * g->blobBytes) == hipSuccess
                                    : hipHostMalloc((void **)&g->hBlobs, N * g->blobBytes, hipHostMallocDefault) == hipSuccess;
         for (auto &e : g->uploadEvents) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
