@@ -516,16 +516,19 @@ int mv_create(const mv_config *cfg, mv_gym **out)
         // share of the host: the cores it may run on (affinity mask, cgroup quota) divided by the ranks of the job (total_envs / num_envs shards, one
         // process per GPU), at most 16.  What a thread sustains (episodes per second, measured: DESIGN.md 3.2): ObstaclesHard 15 k, ObstaclesEasy 44 k,
         // Collect 4.5 k, HexMemory 22 k, Rearrange 330 k; what one GPU consumes at its benchmark rate: ObstaclesHard ~7 k, Collect ~12 k.
-        g->feederThreads = cfg->num_simulation_threads > 0 ? std::min(32, (int)cfg->num_simulation_threads)
-                                                           : std::max(1, std::min(16, usable_host_cores() / std::max(1, g->totalEnvs / std::max(1, g->N))));
+        // ONE core of the share stays with the caller's thread (the one that enqueues the launches): with two cores and the two feeder threads this rule
+        // used to start, ObstaclesHard 1024 envs ran at 21.5 - 25.6 M obs/s, with one thread at 29.4 M -- its rate with sixteen cores --, Collect 13.6 / 15.9
+        // (r12p, r12q; what a thread sustains on that box: ObstaclesHard 40 k, Collect 28 k, HexMemory 46 k episodes per second).
+        const int share = usable_host_cores() / std::max(1, g->totalEnvs / std::max(1, g->N));
+        g->feederThreads = cfg->num_simulation_threads > 0 ? std::min(32, (int)cfg->num_simulation_threads) : std::max(1, std::min(16, share - 1));
         if (const char *e = getenv("MV_FEEDER_THREADS")) g->feederThreads = std::min(64, std::max(1, atoi(e)));
         g->uploadEvents.assign(64, nullptr);
         // Collect: the episodes may be drawn on the DEVICE (mv_collect_draw.h: the same episodes, byte for byte) instead of by the host's worker threads --
         // MV_COLLECT_DEVICE_GEN=1 / 0, otherwise where this process's share of the host is under three cores (eight ranks under a 16-CPU quota: two host
-        // threads hold Collect at 13.0 M obs/s against 16.5 M) and the gym has 256 envs and more (r12n, two cores, host / device: a quarter of a
+        // thread holds Collect at 15.9 M obs/s against 16.6 M) and the gym has 256 envs and more (r12n, two cores, host / device: a quarter of a
         // Mixed4 batch 18.0 / 19.8 M obs/s, an eighth of a Mixed batch 16.9 / 16.2: too few episodes to pay for the draw launches).  The staging slots are device memory then.
         g->blobsOnDevice = collect && (getenv("MV_COLLECT_DEVICE_GEN") ? atoi(getenv("MV_COLLECT_DEVICE_GEN")) != 0
-                                                                        : cfg->num_simulation_threads <= 0 && !getenv("MV_FEEDER_THREADS") && g->feederThreads < 3 && N >= 256);
+                                                                        : cfg->num_simulation_threads <= 0 && !getenv("MV_FEEDER_THREADS") && share < 3 && N >= 256);
         bool ok = g->blobsOnDevice ? hipMalloc((void **)&g->hBlobs, N * g->blobBytes) == hipSuccess && hipMemset(g->hBlobs, 0, N * g->blobBytes) == hipSuccess
                                    : hipHostMalloc((void **)&g->hBlobs, N * g->blobBytes, hipHostMallocDefault) == hipSuccess;
         for (auto &e : g->uploadEvents) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
