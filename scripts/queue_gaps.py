@@ -29,3 +29,6 @@ others = [(r[3][:40], (r[1] - r[0]) / 1e3) for r in rows if r[2] != main]
 oc = collections.defaultdict(list)
 for n, d in others: oc[n].append(d)
 for n, d in oc.items(): print("  other queues: %-40s %5d launches, mean %7.2f us" % (n, len(d), sum(d) / len(d)))
+for n, d in dur.items():
+    d = sorted(d)
+    print("  %-50s percentiles 5 / 25 / 50 / 75 / 95 / 99: %s" % (n, " / ".join("%.1f" % d[min(len(d) - 1, int(len(d) * p / 100))] for p in (5, 25, 50, 75, 95, 99))))
