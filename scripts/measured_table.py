@@ -15,7 +15,11 @@ ROWS = [("tower_bench.json", "**TowerBuilding 1024 envs x 1, 128x128 (BASELINE c
         ("obstacles_hard_512_bench.json", "ObstaclesHard 512 envs x 1 (one GPU's share of configs[2]), overlapped passes"),
         ("obstacles_hard_512_no_overlap_bench.json", "same, passes not overlapped (`--pass-overlap off`)"),
         ("obstacles_hard_1024_bench.json", "ObstaclesHard 1024 x 1 (overlapped passes)"),
+        ("obstacles_hard_1024_2_cores_bench.json", "same on two host cores"), ("obstacles_hard_512_2_cores_bench.json", "ObstaclesHard 512 x 1 on two host cores"),
         ("Collect_bench.json", "Collect 1024 x 1 (overlapped passes)"), ("Collect_no_overlap_bench.json", "same, passes not overlapped"),
+        ("Collect_device_generator_bench.json", "same, episodes drawn on the device (`MV_COLLECT_DEVICE_GEN=1`)"),
+        ("Collect_2_cores_bench.json", "same on two host cores (`taskset -c 0,1`: the rule draws on the device there)"),
+        ("Collect_2_cores_host_2_threads_bench.json", "same on two host cores as before round 6's last changes (host feeder, two threads)"),
         ("Rearrange_bench.json", "Rearrange 1024 x 1 (overlapped passes)"), ("Rearrange_no_overlap_bench.json", "same, passes not overlapped"),
         ("Sokoban_bench.json", "Sokoban 1024 x 1 (synthetic Boxoban-format levels; overlapped passes)"),
         ("HexMemory_bench.json", "HexMemory 1024 x 1 (overlapped passes)"), ("HexMemory_no_overlap_bench.json", "same, passes not overlapped"),
@@ -23,6 +27,7 @@ ROWS = [("tower_bench.json", "**TowerBuilding 1024 envs x 1, 128x128 (BASELINE c
         ("Empty_bench.json", "Empty 1024 x 1"), ("Empty_800_steps_bench.json", "Empty 1024 x 1, 800 steps"),
         ("mixed_64_bench.json", "**Mixed: all eight `megaverse8` scenarios round-robin, 1024 x 1, 64x64 (one GPU's share of configs[4])**"),
         ("mixed4_64_bench.json", "Mixed4: TowerBuilding, ObstaclesEasy, ObstaclesHard, Collect round-robin, 1024 x 1, 64x64 (BASELINE.md 3 row 5)"),
+        ("mixed_64_2_cores_bench.json", "Mixed 64x64 on two host cores"), ("mixed4_64_2_cores_bench.json", "Mixed4 64x64 on two host cores"),
         ("mixed_128_bench.json", "Mixed, 1024 envs, 128x128"),
         ("tower_128x72_bench.json", "TowerBuilding 1024 x 1, 128x72 (the reference's own obs size)"),
         ("tower_64x64_bench.json", "TowerBuilding 1024 x 1, 64x64"),
