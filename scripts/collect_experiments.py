@@ -63,9 +63,9 @@ def main():
         if not os.path.isdir(d):
             continue
         script = os.path.join(ROOT, "scripts", "gpu_%s.sh" % tag)
-        if not os.path.exists(script):
-            script = os.path.join(ROOT, "scripts", "gpu_r08_final.sh")
-        print("== %s (scripts/%s)" % (tag, os.path.basename(script)))
+        if not os.path.exists(script):   # (one-off scripts move to scripts/archive/ with their round's closing pass)
+            script = os.path.join(ROOT, "scripts", "archive", "gpu_%s.sh" % tag)
+        print("== %s (%s)" % (tag, os.path.relpath(script, ROOT) if os.path.exists(script) else "no script kept"))
         h = header_of(script)
         if h:
             print("   " + h)
