@@ -63,6 +63,9 @@ def main():
         if not os.path.isdir(d):
             continue
         script = os.path.join(ROOT, "scripts", "gpu_%s.sh" % tag)
+        for alt in ("gpu_%s_final.sh" % tag[:-1], "gpu_%s_counters.sh" % tag[:-2]):   # (r12z: gpu_r12_final.sh, r12zc: gpu_r12_counters.sh)
+            if not os.path.exists(script) and tag[-1:] in "zc" and os.path.exists(os.path.join(ROOT, "scripts", alt)):
+                script = os.path.join(ROOT, "scripts", alt)
         if not os.path.exists(script):   # (one-off scripts move to scripts/archive/ with their round's closing pass)
             script = os.path.join(ROOT, "scripts", "archive", "gpu_%s.sh" % tag)
         print("== %s (%s)" % (tag, os.path.relpath(script, ROOT) if os.path.exists(script) else "no script kept"))
