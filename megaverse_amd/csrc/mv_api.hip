@@ -899,7 +899,8 @@ static int upload_pass(mv_gym *g)
         if (!must && !g->feeder->is_ready(i, need)) { deficit += consumed + K - g->uploaded[i]; continue; }   // later
         size_t bytes = 0;
         const uint8_t *src = g->feeder->wait_ready(i, need, &bytes);
-        if (!src) return fail(g->feeder->failed() ? std::string("episode feeder: a level file could not be read (Sokoban)")
+        if (!src) return fail(g->feeder->failed() ? std::string(g->feeder->device_gen() ? "episode feeder: a HIP call of the device-side generator failed (Collect)"
+                                                                                       : "episode feeder: a level file could not be read (Sokoban)")
                                                   : "episode feeder: episode " + std::to_string(need)
                                                           + " of env " + std::to_string(i) + " was never generated");
         if (!waited && g->lastStep) { HIP_TRY(hipStreamWaitEvent(up, g->lastStep, 0)); waited = true; }

@@ -1,7 +1,6 @@
 // megaverse_amd/csrc/mv_collect_draw.hip -- Collect episodes generated on the device (mv_collect_draw.h): the kernel, its launcher, and the test hooks that
 // hold it against mv_gen_collect.cpp (the host generator, which tests/test_host_generators.py holds against the oracle and tests/test_oracle_collect.py
 // against the reference's perlin_noise.hpp).
-#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -16,8 +15,9 @@ using namespace cdraw;
 
 // One wavefront per entry of `envs` (or per env when it is null): the env's next episode into its staging slot, its generator state advanced.
 // The slot's `seq` is written last, behind a release: whoever finds it set finds the whole episode (the host orders its copies behind this launch anyway).
-// DRAW_WAVES episodes per workgroup, one per wave: the generator's waves live for milliseconds beside the observation passes, and what they cost them they
-// cost per CU they sit on (r12h: 65 one-wave workgroups on 65 CUs, the passes 8 % slower; packed four to a workgroup: r12i)
+// DRAW_WAVES episodes per workgroup, one per wave (nothing in the kernel crosses a wave).  Measured both ways (r12h / r12i: 65 one-wave workgroups against 17
+// four-wave ones per launch): no difference to the observation launches beside them -- what a draw launch costs them it costs by being IN FLIGHT (mv_feeder.cpp:
+// the batches gather), not by where its waves sit.  Four keeps the grid small.
 #ifndef MV_DRAW_WAVES
 #define MV_DRAW_WAVES 4
 #endif
@@ -29,8 +29,8 @@ __global__ __launch_bounds__(64 * DRAW_WAVES) void collect_draw_kernel(GenState 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int k = (int)blockIdx.x * DRAW_WAVES + wave;   // (the waves of a workgroup draw episodes of their own: nothing below crosses a wave)
     if (k >= count) return;
-    // One lane's chain of dependent instructions: beside the observation passes' seven or eight waves per SIMD it would get every eighth issue slot and hold
-    // its workgroup's LDS -- one observation workgroup's worth on its CU -- eight times as long.  A few dozen such waves at top priority cost the passes nothing.
+    // One lane's chain of dependent instructions beside the observation passes' seven or eight waves per SIMD: top priority, so that the few dozen waves of a
+    // launch are done -- and the launch out of flight -- as soon as their own latencies allow (r12f: no measurable difference to the passes either way).
     __builtin_amdgcn_s_setprio(3);
     const int env = envs ? envs[k] : k;
     const int lane = lane_id();
