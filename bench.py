@@ -581,7 +581,7 @@ def main():
         fence()
 
     # ---- per-kernel profile: a separate, untimed loop with HIP events around every kernel, each interval on one stream
-    prof = None
+    prof = prof_alone = None
     if not dry and args.profile_steps > 0:
         fence()
         gym.profile_begin(args.profile_steps)
@@ -590,6 +590,18 @@ def main():
         if mixed:
             prof = prof[0]   # (the union launches are timed on the group leader's events)
         step0 += args.profile_steps
+        # the same launches ALONE on the chip (the physics kernel's figures "alone"): pipelining off -- a call's step launches, then its observation
+        # launch, one after the other on the caller's stream --, the same calls, the same events
+        if batched and not mixed and world == 1 and gym.pipelining():
+            gym.set_pipelining(False)
+            fence()
+            na = min(args.profile_steps, 4 * batch)
+            gym.profile_begin(na)
+            run_steps(step0, na, False, batched)
+            prof_alone = gym.profile_end()
+            step0 += na
+            gym.set_pipelining(True)
+            fence()
     mixed_ring_checksum = 0
     if batched and mixed and getattr(gym, "ring_obs", None):
         mixed_ring_checksum = sum(int(r[:, ::97].to(torch.int64).sum().item()) for r in gym.ring_obs)
@@ -929,6 +941,14 @@ def main():
                                                 "is not streamed), so it is latency-bound, not bandwidth-bound: one wave per env, launch length = slowest wave (DESIGN.md 3.1); "
                                                 "when pipelined it runs concurrently with the previous ticks' rasters, which stretches its launches.  40 % of 8 TB/s would mean "
                                                 "a 1024-env tick in 1.2 us of streaming for 3.8 MB -- the tick's dependent chain of casts is ~10 us whatever the bandwidth"}
+            if prof_alone and prof_alone["step"][0] > 0 and batch_step:
+                sa = prof_alone["step"][0]
+                line["roofline_physics"]["alone"] = {"avg_launch_ms": sa, "frac": step_bytes_per_env * n_env / (sa * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                     "frac_survey_bytes": (17900 + (A - 1) * 267) * n_env / (sa * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                     "note": "the same multi-tick launch with nothing beside it (pipelining off for a few calls after the timed region), per tick, "
+                                                             "between HIP events (a kernel trace reads ~4 us per tick less: r12zb, 114 us per 8 ticks); the kernel flavour the "
+                                                             "library's rule picks for this gym -- one wave per env at 1024 envs; the two-wave software-pipelined kernel, "
+                                                             "MV_STEP_PIPE=1, is a quarter shorter alone"}
             if args.pixels == "exact":
                 line["kernels"] = {"publish_and_frame_sort": {"avg_launch_ms": prof["setup"][0], "note": "exact pixel mode only; same-stream interval"}}
         line["checksum"] = checksum
