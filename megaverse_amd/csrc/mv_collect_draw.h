@@ -328,18 +328,20 @@ MV_HD void draw_head(Mt &g, const GenState &st, Scratch &w, Params &p)
 // tail (serial): the merged slabs from the heightfield in w.hm, then every draw behind the landscape.  `out`'s heightmap is written by the caller.
 // -> the value the env's NEXT Env::reset will draw for its seed (nothing consumes the env's stream in between)
 struct NoMark { MV_HD void operator()(int) const {} };
-template <class Mark = NoMark>   // mark(k): phase k of the tail ends here (the timing build of the test hook reads a clock there)
+// SLABS = false: the caller has merged the slabs already (collect_draw_kernel: all 64 lanes, draw_slabs_wave) and set out->num_boxes
+template <class Mark = NoMark, bool SLABS = true>   // mark(k): phase k of the tail ends here (the timing build of the test hook reads a clock there)
 MV_HD uint32_t draw_tail(Mt &g, const Params &p, Scratch &w, int top, int num_agents, float base_episode_len, CollectBlob *out, int &flags, Mark mark = Mark())
 {
     const int nx = p.nx, nz = p.nz, ny = top + 1;
     const int8_t *hm = w.hm;
-    out->num_boxes = 0; out->num_objects = 0; out->num_rewards = 0; out->num_positive = 0; out->pad = 0;
+    if (SLABS) out->num_boxes = 0;
+    out->num_objects = 0; out->num_rewards = 0; out->num_positive = 0; out->pad = 0;
     for (int i = 0; i < MAX_AGENTS; ++i) { out->spawn[i][0] = out->spawn[i][1] = out->spawn[i][2] = 0; }
     // ---- merged slabs: the floor layer (y == 0) and the hills, the lower colour value first, equal colours one class; seeds in (y, z, x) order, grown
     // along x, then z, then y
     const unsigned colorLo = p.land_color < p.floor_color ? p.land_color : p.floor_color, colorHi = p.land_color < p.floor_color ? p.floor_color : p.land_color;
     out->layout_color = (int)colorLo; out->wall_color = (int)colorHi;
-    {
+    if (SLABS) {
         uint32_t *taken = w.taken;
         const int words = (nx * ny * nz + 31) / 32;
         for (int i = 0; i < words; ++i) taken[i] = 0;

@@ -15,6 +15,67 @@ using namespace cdraw;
 
 // One wavefront per entry of `envs` (or per env when it is null): the env's next episode into its staging slot, its generator state advanced.
 // The slot's `seq` is written last, behind a release: whoever finds it set finds the whole episode (the host orders its copies behind this launch anyway).
+// The slab merge of draw_tail (mv_collect_draw.h) by all 64 lanes of the episode's wave -- the same greedy walk, box for box: the scan for the next free cell
+// takes 64 cells per round (a ballot), a box's growth along x, then z, then y one ballot each (lane k tests the k-th cell / row / layer beyond the seed, the run
+// of ones from lane 0 is the growth), the box's cells are marked by the lanes together.  The serial form scanned up to 25 k cells one LDS round trip at a time:
+// 880 us of an episode's 1.4 ms (r12c).
+__device__ __forceinline__ int trailing_ones(unsigned long long m) { return m == ~0ull ? 64 : __ffsll((long long)~m) - 1; }
+__device__ __forceinline__ void draw_slabs_wave(const Params &p, Scratch &w, int top, CollectBlob *out, int &flags)
+{
+    const int lane = lane_id();
+    const int nx = p.nx, nz = p.nz, ny = top + 1, total = nx * ny * nz;
+    const int8_t *hm = w.hm;
+    uint32_t *taken = w.taken;
+    for (int i = lane; i < (total + 31) / 32; i += 64) taken[i] = 0;
+    wave_sync();
+    const unsigned colorLo = p.land_color < p.floor_color ? p.land_color : p.floor_color, colorHi = p.land_color < p.floor_color ? p.floor_color : p.land_color;
+    int numBoxes = 0;
+    for (int slot = 0; slot < 2; ++slot) {
+        const unsigned want = slot == 0 ? colorLo : colorHi;
+        if (slot == 1 && colorHi == colorLo) break;
+        auto free_cell = [&](int x, int y, int z) {
+            if (x < 0 || x >= nx || z < 0 || z >= nz || y < 0 || y > hm[x * HM_DIM + z]) return false;
+            const int id = (y * nz + z) * nx + x;
+            return (y == 0 ? p.floor_color : p.land_color) == want && !((taken[id >> 5] >> (id & 31)) & 1u);
+        };
+        for (int base = 0; base < total; base += 64) {   // cells in scan order: id = (y nz + z) nx + x
+            const int id = base + lane, mx = id % nx, mt = id / nx, mz = mt % nz, my = mt / nz;
+            unsigned long long m = __ballot(id < total && free_cell(mx, my, mz));
+            while (m) {
+                const int seed = base + __ffsll((long long)m) - 1;
+                const int x = seed % nx, t = seed / nx, z = t % nz, y = t / nz;
+                const int xEnd = x + 1 + trailing_ones(__ballot(free_cell(x + 1 + lane, y, z)));
+                bool ok = z + 1 + lane < nz;
+                for (int xx = x; ok && xx < xEnd; ++xx) ok = free_cell(xx, y, z + 1 + lane);
+                const int zEnd = z + 1 + trailing_ones(__ballot(ok));
+                ok = y + 1 + lane < ny;
+                for (int zz = z; ok && zz < zEnd; ++zz)
+                    for (int xx = x; ok && xx < xEnd; ++xx) ok = free_cell(xx, y + 1 + lane, zz);
+                const int yEnd = y + 1 + trailing_ones(__ballot(ok));
+                const int wx = xEnd - x, wz = zEnd - z, vol = wx * wz * (yEnd - y);
+                wave_sync();   // (every lane's reads of the bits before they change)
+                for (int i = lane; i < vol; i += 64) {
+                    const int cx = x + i % wx, ct = i / wx, cz = z + ct % wz, cy = y + ct / wz, cid = (cy * nz + cz) * nx + cx;
+                    atomicOr(&taken[cid >> 5], 1u << (cid & 31));
+                }
+                wave_sync();
+                if (numBoxes >= COLLECT_MAX_BOXES) flags |= FLAG_SLABS;
+                else {
+                    if (lane == 0) {
+                        LayoutBox b;
+                        b.min[0] = x; b.min[1] = y; b.min[2] = z; b.max[0] = xEnd; b.max[1] = yEnd; b.max[2] = zEnd;
+                        b.type = VX_SOLID | VX_OPAQUE; b.slot = slot;
+                        out->boxes[numBoxes] = b;
+                    }
+                    ++numBoxes;
+                }
+                m = __ballot(id < total && free_cell(mx, my, mz));
+            }
+        }
+    }
+    if (lane == 0) out->num_boxes = numBoxes;
+}
+
 // DRAW_WAVES episodes per workgroup, one per wave (nothing in the kernel crosses a wave).  Measured both ways (r12h / r12i: 65 one-wave workgroups against 17
 // four-wave ones per launch): no difference to the observation launches beside them -- what a draw launch costs them it costs by being IN FLIGHT (mv_feeder.cpp:
 // the batches gather), not by where its waves sit.  Four keeps the grid small.
@@ -70,9 +131,13 @@ __global__ __launch_bounds__(64 * DRAW_WAVES) void collect_draw_kernel(GenState 
     int flags = 0;
     uint32_t nextSeed = 0;
     if (tm && lane == 0) tm[2] = wall_clock64();
+    draw_slabs_wave(sp, w, s_top, out, flags);
+    if (tm && lane == 0) tm[3] = wall_clock64();
     if (lane == 0) {
-        if (tm) nextSeed = draw_tail(g, sp, w, s_top, num_agents, base_episode_len, out, flags, [tm](int q) { tm[3 + q] = wall_clock64(); });
-        else nextSeed = draw_tail(g, sp, w, s_top, num_agents, base_episode_len, out, flags);
+        if (tm) {
+            auto mark = [tm](int q) { if (q > 0) tm[3 + q] = wall_clock64(); };
+            nextSeed = draw_tail<decltype(mark), false>(g, sp, w, s_top, num_agents, base_episode_len, out, flags, mark);
+        } else nextSeed = draw_tail<NoMark, false>(g, sp, w, s_top, num_agents, base_episode_len, out, flags);
     }
     if (tm && lane == 0) tm[6] = wall_clock64();
     for (int i = lane; i < HM_BYTES / 16; i += 64) reinterpret_cast<uint4 *>(out->heightmap)[i] = reinterpret_cast<const uint4 *>(w.hm)[i];
