@@ -20,7 +20,8 @@
 //
 // Execution model on the device: one wavefront per episode.  Everything that consumes a random stream is serial by nature and runs on LANE 0 ALONE
 // (plain loads and stores to LDS; the other lanes wait at a wave barrier); the heightfield -- nx x nz samples of up to nine octaves of noise -- is
-// spread over the 64 lanes.  An episode costs a few milliseconds of one wavefront, off the step path (mv_feeder.cpp: device mode).
+// spread over the 64 lanes, and so is the slab merge (mv_collect_draw.hip: draw_slabs_wave; the serial form below is the host's and the reference the tests
+// hold it against).  An episode costs 0.7 ms of one wavefront on average, off the step path (mv_feeder.cpp: device mode).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -157,8 +157,8 @@ void EpisodeFeeder::generate(int env)
     ready_seq_[env].store(seq, std::memory_order_release);
 }
 
-// Device mode's only worker: every env whose slot is free, in ONE launch of collect_draw_kernel on this feeder's stream -- while it runs (an episode is a few
-// milliseconds of one wavefront) the next batch gathers.  The launch is ordered behind the uploads that still read the batch's slots.
+// Device mode's only worker: every env whose slot is free, in ONE launch of collect_draw_kernel on this feeder's stream -- while it runs (an episode is 0.7 ms
+// of one wavefront on average, 2.5 ms the slowest) the next batch gathers.  The launch is ordered behind the uploads that still read the batch's slots.
 void EpisodeFeeder::device_worker_main()
 {
     (void)hipSetDevice(device_);
@@ -168,7 +168,7 @@ void EpisodeFeeder::device_worker_main()
         {
             std::unique_lock<std::mutex> lk(mu_);
             cv_task_.wait(lk, [this] { return stop_ || !tasks_.empty(); });
-            // A launch lasts as long as its slowest episode -- 5 to 7 ms, however few episodes it draws -- and while ANY kernel of another queue is in flight the
+            // A launch lasts as long as its slowest episode -- 2 to 3 ms (5 to 7 before the slab merge went to all lanes), however few it draws -- and while ANY kernel of another queue is in flight the
             // observation launches run 9 % slower (r12h / r12j: with the draws back to back, in flight 84 % of the time, 1014 -> 1105 us; the same with a launch
             // that only sleeps).  So the batch gathers for a while -- an env's ring holds two more episodes -- unless somebody is waiting for one (wait_ready:
             // a forced reset, a re-seed, episodes of a few ticks).
